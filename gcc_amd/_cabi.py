@@ -1,0 +1,115 @@
+"""ctypes binding of libgcc_amd.so (include/gcc_amd.h).
+
+This is the stub a maintainer of the reference would add: the
+reference is pure Python, so the FFI is ctypes.  The product path has NO CPU
+fallback: :func:`load` raises if the HIP library is missing, and every wrapper
+in this package refuses non-CUDA tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgcc_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gcc_amd.h")
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+
+STATUS_SCRATCH_OVERFLOW = 1
+STATUS_NODE_OVERFLOW = 2
+STATUS_EDGE_OVERFLOW = 4
+
+
+class GccGraph(ctypes.Structure):
+    _fields_ = [
+        ("row_ptr", ctypes.c_void_p),
+        ("col_idx", ctypes.c_void_p),
+        ("seed_cdf", ctypes.c_void_p),
+        ("ltab", ctypes.c_void_p),
+        ("num_nodes", ctypes.c_int64),
+        ("num_edges", ctypes.c_int64),
+        ("ltab_len", ctypes.c_int32),
+        ("lmax", ctypes.c_int32),
+    ]
+
+
+class GccSampleParams(ctypes.Structure):
+    _fields_ = [
+        ("run_seed", ctypes.c_uint64),
+        ("first_sample_id", ctypes.c_int64),
+        ("batch_size", ctypes.c_int32),
+        ("restart_u32", ctypes.c_uint32),
+        ("seeds", ctypes.c_void_p),
+    ]
+
+
+class GccBatchOut(ctypes.Structure):
+    _fields_ = [
+        ("node_off", ctypes.c_void_p),
+        ("edge_off", ctypes.c_void_p),
+        ("parent_nid", ctypes.c_void_p),
+        ("graph_id", ctypes.c_void_p),
+        ("row_ptr", ctypes.c_void_p),
+        ("col_idx", ctypes.c_void_p),
+        ("node_cap", ctypes.c_int64),
+        ("edge_cap", ctypes.c_int64),
+    ]
+
+
+# name -> (restype, argtypes); the single source of truth for the symbol test
+SIGNATURES = {
+    "gcc_abi_version": (ctypes.c_int32, []),
+    "gcc_last_error": (ctypes.c_char_p, []),
+    "gcc_sampler_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(GccGraph), ctypes.c_int32, ctypes.c_int64]),
+    "gcc_sample_batch": (ctypes.c_int32, [
+        ctypes.POINTER(GccGraph), ctypes.POINTER(GccSampleParams), ctypes.POINTER(GccBatchOut),
+        ctypes.POINTER(GccBatchOut), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_void_p]),
+}
+
+
+def declare(lib: ctypes.CDLL) -> ctypes.CDLL:
+    """Attach restype/argtypes for every symbol of include/gcc_amd.h."""
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Open the gfx950 library built in-tree by ``__graft_entry__.build()``."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  gcc_amd has no CPU fallback.")
+        _lib = declare(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {load().gcc_last_error().decode()}")
+
+
+def dev_ptr(t, dtype=None) -> int:
+    """data_ptr() of a contiguous CUDA (HIP) tensor; anything else is refused."""
+    import torch
+
+    if t is None:
+        return 0
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("gcc_amd kernels take device (HIP) tensors only; there is no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return t.data_ptr()

@@ -1,0 +1,148 @@
+// gcc_amd/csrc/device_compat.h -- the ONLY place that knows about the two ways
+// the kernels are compiled:
+//   * hipcc --offload-arch=gfx950  -> gcc_amd/csrc/libgcc_amd.so   (the product)
+//   * g++ -DGCC_AMD_HIPEMU         -> tests/hipemu/_build/libgcc_amd_emu.so
+//     (lock-step wave64 emulator; kernel-logic tests on machines without a GPU)
+// Kernels use the wave_* / mfma_* wrappers below instead of raw builtins.
+#pragma once
+#include <stdint.h>
+
+#ifdef GCC_AMD_HIPEMU
+#include "hipemu.h"
+
+#define DYN_SMEM(name) unsigned char *name = hipemu::g_dyn_smem
+typedef float f32x4 __attribute__((vector_size(16)));
+
+static inline int lane_id() { return hipemu::cur->lane; }
+static inline void wave_sync() { hipemu::wave_barrier_only(); }
+static inline unsigned long long wave_ballot(bool p)
+{
+    unsigned char v = p ? 1 : 0;
+    const unsigned char *t = hipemu::wave_gather(&v, 1, 0xBA1107u);
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) m |= (unsigned long long)(t[l] & 1) << l;
+    return m;
+}
+template <class T> static inline T wave_shfl(T v, int src)
+{
+    const unsigned char *t = hipemu::wave_gather(&v, sizeof(T), 0x5F1u + (unsigned)sizeof(T));
+    return hipemu::gather_at<T>(t, src & 63);
+}
+template <class T> static inline T wave_shfl_xor(T v, int mask) { return wave_shfl(v, lane_id() ^ mask); }
+template <class T> static inline T wave_shfl_up(T v, int delta)
+{
+    int src = lane_id() - delta;
+    T r = wave_shfl(v, src < 0 ? lane_id() : src);
+    return src < 0 ? v : r;
+}
+template <class T> static inline T wave_shfl_down(T v, int delta)
+{
+    int src = lane_id() + delta;
+    T r = wave_shfl(v, src > 63 ? lane_id() : src);
+    return src > 63 ? v : r;
+}
+template <class T> static inline T wave_bcast_first(T v) { return wave_shfl(v, 0); }
+// D = A(16x4) * B(4x16) + C; lane l: a = A[l&15][l>>4], b = B[l>>4][l&15],
+// c/d[r] = C[(l>>4)*4 + r][l&15]  (cdna_hip_programming.md §3)
+static inline f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c)
+{
+    struct AB { float a, b; } ab = {a, b};
+    const unsigned char *t = hipemu::wave_gather(&ab, sizeof(ab), 0x3F3Au);
+    int l = lane_id();
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r, col = l & 15;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            AB x = hipemu::gather_at<AB>(t, k * 16 + row);
+            AB y = hipemu::gather_at<AB>(t, k * 16 + col);
+            acc = fmaf(x.a, y.b, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+
+#else  // ------------------------------------------------------------ gfx950
+#include <hip/hip_runtime.h>
+
+#define DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
+// LDS hand-off between lanes of ONE wave: LDS operations of a wave execute in
+// order, so only the compiler has to be stopped from reordering them.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p); }
+template <class T> __device__ __forceinline__ T wave_shfl(T v, int src) { return __shfl(v, src, 64); }
+template <class T> __device__ __forceinline__ T wave_shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
+template <class T> __device__ __forceinline__ T wave_shfl_up(T v, int delta) { return __shfl_up(v, delta, 64); }
+template <class T> __device__ __forceinline__ T wave_shfl_down(T v, int delta) { return __shfl_down(v, delta, 64); }
+template <class T> __device__ __forceinline__ T wave_bcast_first(T v) { return __shfl(v, 0, 64); }
+__device__ __forceinline__ f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+#endif
+
+// ------------------------------------------------------------------ common
+__device__ __forceinline__ unsigned long long lanemask_lt()
+{
+    return (1ull << lane_id()) - 1ull;
+}
+
+// inclusive wave prefix sum (all 64 lanes must call)
+__device__ __forceinline__ int wave_scan_incl(int v)
+{
+    int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = wave_shfl_up(v, d);
+        if (l >= d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += wave_shfl_xor(v, d);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += wave_shfl_xor(v, d);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { float t = wave_shfl_xor(v, d); v = t > v ? t : v; }
+    return v;
+}
+
+// Philox4x32-10 (Salmon et al., Random123); identical to oracle/sampler_oracle.c
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}

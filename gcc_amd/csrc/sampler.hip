@@ -1,0 +1,518 @@
+// gcc_amd/csrc/sampler.hip -- RWR ego-net sampler + on-device batcher (gfx950).
+//
+// Replaces, for one DataLoader batch, the reference's CPU worker pipeline
+//   LoadBalanceGraphDataset.__iter__/__getitem__  gcc/datasets/graph_dataset.py:85-179
+//   _rwr_trace_to_dgl_graph (node set, subgraph)  gcc/datasets/data_util.py:218-239
+//   batcher / dgl.batch                           gcc/datasets/data_util.py:26-32
+// and the DGL C++ routines behind them (random_walk_with_restart, subgraph,
+// batch).  RNG / ordering spec: oracle/sampler_oracle.c header; results are
+// bit-exact against that oracle.
+//
+// Kernels (G = 2B subgraphs, g = view * B + b):
+//   rwr_walk_kernel   1 wave per subgraph.  Walk lengths depend on the RNG only
+//                     (no dead ends by contract), so 64 lanes run 64 walks at a
+//                     time and a wave prefix sum over the lengths reproduces the
+//                     sequential "stop after exactly L visited nodes" rule
+//                     exactly.  Trace in LDS -> bitonic sort -> unique -> seed
+//                     first; row extents of every member are fetched here.
+//   induce_kernel     WPS workgroups per subgraph; LDS hash map parent id ->
+//                     local id; every wave streams whole parent rows (coalesced
+//                     dword loads, 4 in flight per lane) and ballot-compacts the
+//                     hits, preserving parent-row order (DGL VertexSubgraph).
+//   pack_kernel       1 workgroup per subgraph: prefix sums over subgraphs
+//                     (dgl.batch offsets), row_ptr/col_idx with batched ids,
+//                     parent_nid, graph_id.
+// HBM-bound integer work; no MFMA anywhere in this file.
+#include "device_compat.h"
+#include "../../include/gcc_amd.h"
+
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr int kWps = 8;            // induce workgroups per subgraph
+constexpr int kInduceThreads = 256;
+
+__device__ __forceinline__ int pow2_ceil(int v)
+{
+    int p = 64;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// Per-call workspace carved from the caller's buffer.
+struct Work {
+    int32_t *seeds;       // [B]
+    int32_t *sub_n;       // [G]
+    int32_t *sub_cap;     // [G]   sum_i min(deg_i, n)
+    int32_t *sub_nnz;     // [G]
+    int32_t *nodes;       // [G][ncap]   parent ids, seed first
+    int32_t *rowbeg;      // [G][ncap]   row_ptr[node]
+    int32_t *rowdeg;      // [G][ncap]   parent degree
+    int32_t *rowoff;      // [G][ncap]   exclusive prefix of min(deg, n) within the subgraph
+    int32_t *rowcnt;      // [G][ncap]   induced degree
+    int32_t *scratch;     // [scratch_entries] local col ids, row-sparse
+    int32_t ncap;
+};
+
+struct WorkLayout {
+    int64_t off_seeds, off_n, off_cap, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowoff, off_rowcnt,
+        off_scratch, total;
+    int32_t ncap;
+};
+
+inline WorkLayout work_layout(int32_t lmax, int32_t B, int64_t scratch_entries)
+{
+    WorkLayout w;
+    auto al = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
+    const int64_t G = 2 * (int64_t)B;
+    w.ncap = ((lmax + 1 + 63) / 64) * 64;
+    int64_t o = 0;
+    w.off_seeds = o;  o = al(o + 4 * (int64_t)B);
+    w.off_n = o;      o = al(o + 4 * G);
+    w.off_cap = o;    o = al(o + 4 * G);
+    w.off_nnz = o;    o = al(o + 4 * G);
+    w.off_nodes = o;  o = al(o + 4 * G * w.ncap);
+    w.off_rowbeg = o; o = al(o + 4 * G * w.ncap);
+    w.off_rowdeg = o; o = al(o + 4 * G * w.ncap);
+    w.off_rowoff = o; o = al(o + 4 * G * w.ncap);
+    w.off_rowcnt = o; o = al(o + 4 * G * w.ncap);
+    w.off_scratch = o; o = al(o + 4 * scratch_entries);
+    w.total = o;
+    return w;
+}
+
+struct BatchOutDev {
+    int32_t *node_off, *edge_off, *parent_nid, *graph_id, *row_ptr, *col_idx;
+    int64_t node_cap, edge_cap;
+};
+
+// ------------------------------------------------------------------ K1 ----
+__global__ __launch_bounds__(64) void rwr_walk_kernel(
+    const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
+    const double *__restrict__ seed_cdf, const int32_t *__restrict__ ltab, int64_t num_nodes,
+    int32_t ltab_len, int32_t p2max, uint64_t run_seed, int64_t first_sample_id, int32_t B,
+    uint32_t restart_u32, const int32_t *__restrict__ seeds_in, Work w)
+{
+    DYN_SMEM(smem);
+    uint32_t *buf = (uint32_t *)smem;        // [p2max] trace -> sorted trace
+    int32_t *ldeg = (int32_t *)smem + p2max; // [p2max + 64] parent degree of kept nodes (n <= L + 1)
+    const int lane = lane_id();
+    const int g = (int)blockIdx.x;
+    const int view = g / B, b = g - view * B;
+    const uint64_t sid = (uint64_t)(first_sample_id + b);
+
+    // ---- seed: graph_dataset.py:85-92 (p ~ deg^0.75; numpy choice == cdf upper bound)
+    int32_t seed;
+    if (seeds_in) {
+        seed = seeds_in[b];
+    } else {
+        uint32_t x[4];
+        philox4x32_10((uint32_t)sid, (uint32_t)(sid >> 32), 0u, 0u, (uint32_t)run_seed ^ 0x5EED5EEDu,
+                      (uint32_t)(run_seed >> 32) ^ 0x00A11CE5u, x);
+        const uint64_t u53 = ((uint64_t)x[0] << 21) | (uint64_t)(x[1] >> 11);
+        const double u = (double)u53 * (1.0 / 9007199254740992.0);
+        // wave-cooperative 64-ary upper bound: first index with cdf[i] > u
+        int64_t lo = 0, hi = num_nodes;
+        while (lo < hi) {
+            const int64_t len = hi - lo;
+            const int64_t step = (len + 63) >> 6;
+            const int64_t idx = lo + (int64_t)lane * step;
+            const bool le = (idx < hi) && (seed_cdf[idx] <= u);
+            const int k = __popcll(wave_ballot(le));   // monotone: first k lanes true
+            if (k == 0) { hi = lo; break; }
+            const int64_t nhi = lo + (int64_t)k * step;
+            lo = lo + (int64_t)(k - 1) * step + 1;
+            if (nhi < hi) hi = nhi;
+        }
+        seed = (int32_t)(lo < num_nodes ? lo : num_nodes - 1);
+    }
+    if (view == 0 && lane == 0) w.seeds[b] = seed;
+
+    const int32_t rp0 = row_ptr[seed];
+    const int32_t deg0 = row_ptr[seed + 1] - rp0;
+    const int32_t L = ltab[deg0 < ltab_len ? deg0 : ltab_len - 1];   // graph_dataset.py:113-124
+    const int p2 = pow2_ceil(L);
+
+    for (int i = lane; i < p2; i += 64) buf[i] = kEmpty;
+    wave_sync();
+
+    // ---- walks: graph_dataset.py:125-130 (DGL random_walk_with_restart)
+    const uint64_t gid = sid * 2u + (uint64_t)view;
+    const uint32_t k0 = (uint32_t)run_seed, k1 = (uint32_t)(run_seed >> 32);
+    const uint32_t g0 = (uint32_t)gid, g1 = (uint32_t)(gid >> 32);
+    int total = 0;   // wave-uniform: trace entries assigned so far
+    for (int base = 0; total < L; base += 256) {
+        uint32_t x0[4][4];
+        int len[4], off[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t walk = (uint32_t)(base + j * 64 + lane);
+            philox4x32_10(walk, 0u, g0, g1, k0, k1, x0[j]);
+            // len = min{t >= 1 : word[2t-1] < restart_u32}, capped at L
+            int l = 1;
+            if (x0[j][1] >= restart_u32) {
+                l = 2;
+                if (x0[j][3] >= restart_u32) {
+                    l = 3;
+                    uint32_t y[4];
+                    for (uint32_t blk = 1; l < L; ++blk) {
+                        philox4x32_10(walk, blk, g0, g1, k0, k1, y);
+                        if (y[1] < restart_u32) break;
+                        ++l;
+                        if (l >= L || y[3] < restart_u32) break;
+                        ++l;
+                    }
+                }
+            }
+            len[j] = l;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int incl = wave_scan_incl(len[j]);
+            off[j] = total + incl - len[j];
+            total += wave_shfl(incl, 63);
+        }
+        // first step of every walk that is (at least partly) inside the budget
+        int32_t cur[4];
+        int allowed[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int a = L - off[j];
+            a = a < 0 ? 0 : (a > len[j] ? len[j] : a);
+            allowed[j] = a;
+            cur[j] = seed;
+            if (a > 0) cur[j] = col_idx[rp0 + (int32_t)__umulhi(x0[j][0], (uint32_t)deg0)];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (allowed[j] > 0) buf[off[j]] = (uint32_t)cur[j];
+            if (allowed[j] > 1) {
+                const uint32_t walk = (uint32_t)(base + j * 64 + lane);
+                uint32_t y[4] = {x0[j][0], x0[j][1], x0[j][2], x0[j][3]};
+                uint32_t yblk = 0;
+                int32_t c = cur[j];
+                for (int t = 1; t < allowed[j]; ++t) {
+                    const uint32_t blk = (uint32_t)t >> 1;      // word 2t lives in block t/2
+                    if (blk != yblk) { philox4x32_10(walk, blk, g0, g1, k0, k1, y); yblk = blk; }
+                    const uint32_t r = (t & 1) ? y[2] : y[0];
+                    const int32_t beg = row_ptr[c];
+                    const int32_t d = row_ptr[c + 1] - beg;
+                    c = col_idx[beg + (int32_t)__umulhi(r, (uint32_t)d)];
+                    buf[off[j] + t] = (uint32_t)c;
+                }
+            }
+        }
+    }
+    wave_sync();
+
+    // ---- torch.unique (data_util.py:221): bitonic sort of the padded trace
+    for (int k = 2; k <= p2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < (p2 >> 1); i += 64) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int hi = lo + j;
+                const bool up = (lo & k) == 0;
+                const uint32_t a = buf[lo], c = buf[hi];
+                if ((a > c) == up) { buf[lo] = c; buf[hi] = a; }
+            }
+            wave_sync();
+        }
+    }
+
+    // ---- subv = [seed] + (unique \ {seed})  (data_util.py:222-226); fetch row extents
+    int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
+    int32_t *rowbeg = w.rowbeg + (int64_t)g * w.ncap;
+    int32_t *rowdeg = w.rowdeg + (int64_t)g * w.ncap;
+    int32_t *rowoff = w.rowoff + (int64_t)g * w.ncap;
+    if (lane == 0) { nodes[0] = seed; rowbeg[0] = rp0; rowdeg[0] = deg0; ldeg[0] = deg0; }
+    int n = 1;   // wave-uniform
+    for (int i0 = 0; i0 < L; i0 += 64) {
+        const int i = i0 + lane;
+        uint32_t v = kEmpty, prev = kEmpty;
+        if (i < L) { v = buf[i]; if (i > 0) prev = buf[i - 1]; }
+        const bool keep = (i < L) && (v != (uint32_t)seed) && (i == 0 || v != prev);
+        const unsigned long long m = wave_ballot(keep);
+        if (keep) {
+            const int pos = n + __popcll(m & lanemask_lt());
+            const int32_t rb = row_ptr[v];
+            const int32_t d = row_ptr[v + 1] - rb;
+            nodes[pos] = (int32_t)v;
+            rowbeg[pos] = rb;
+            rowdeg[pos] = d;
+            ldeg[pos] = d;
+        }
+        n += __popcll(m);
+    }
+    wave_sync();
+    // scratch slot of row i starts at sum_{i' < i} min(deg_i', n)
+    int run = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        int c = 0;
+        if (i < n) { c = ldeg[i]; c = c < n ? c : n; }
+        const int incl = wave_scan_incl(c);
+        if (i < n) rowoff[i] = run + incl - c;
+        run += wave_shfl(incl, 63);
+    }
+    if (lane == 0) { w.sub_n[g] = n; w.sub_cap[g] = run; w.sub_nnz[g] = 0; }
+}
+
+// sum of arr[begin, end) by the whole workgroup (all threads get the result)
+__device__ __forceinline__ long long block_range_sum(const int32_t *arr, int begin, int end, long long *red)
+{
+    long long s = 0;
+    for (int i = begin + (int)threadIdx.x; i < end; i += (int)blockDim.x) s += arr[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = (int)blockDim.x >> 1; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    const long long r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------ K2 ----
+__global__ __launch_bounds__(kInduceThreads) void induce_kernel(
+    const int32_t *__restrict__ col_idx, int32_t hcap_log2, int64_t scratch_entries, Work w,
+    int32_t *__restrict__ status)
+{
+    DYN_SMEM(smem);
+    __shared__ long long red[kInduceThreads];
+    const int hcap = 1 << hcap_log2;
+    uint32_t *hkey = (uint32_t *)smem;                  // [hcap]
+    uint16_t *hval = (uint16_t *)(hkey + hcap);         // [hcap]
+    const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int g = (int)blockIdx.x / kWps, part = (int)blockIdx.x % kWps;
+    const int n = w.sub_n[g];
+    const long long sbase = block_range_sum(w.sub_cap, 0, g, red);
+    if (sbase + (long long)w.sub_cap[g] > scratch_entries) {
+        if (tid == 0) atomicOr(status, (int32_t)GCC_STATUS_SCRATCH_OVERFLOW);
+        return;
+    }
+    const int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
+    const int32_t *rowbeg = w.rowbeg + (int64_t)g * w.ncap;
+    const int32_t *rowdeg = w.rowdeg + (int64_t)g * w.ncap;
+    const int32_t *rowoff = w.rowoff + (int64_t)g * w.ncap;
+    int32_t *rowcnt = w.rowcnt + (int64_t)g * w.ncap;
+    int32_t *scratch = w.scratch + sbase;
+
+    for (int i = tid; i < hcap; i += kInduceThreads) hkey[i] = kEmpty;
+    __syncthreads();
+    const int shift = 32 - hcap_log2;
+    for (int i = tid; i < n; i += kInduceThreads) {
+        const uint32_t key = (uint32_t)nodes[i];
+        uint32_t h = (key * 0x9E3779B1u) >> shift;
+        for (;;) {
+            const uint32_t old = atomicCAS(&hkey[h], kEmpty, key);
+            if (old == kEmpty) { hval[h] = (uint16_t)i; break; }
+            h = (h + 1) & (uint32_t)(hcap - 1);
+        }
+    }
+    __syncthreads();
+
+    int my_nnz = 0;
+    for (int i = part * 4 + wave; i < n; i += 4 * kWps) {
+        const int32_t beg = rowbeg[i], deg = rowdeg[i];
+        int32_t *out = scratch + rowoff[i];
+        int cnt = 0;   // wave-uniform
+        for (int e0 = 0; e0 < deg; e0 += 256) {
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k * 64 + lane;
+                v[k] = e < deg ? (uint32_t)col_idx[beg + e] : kEmpty;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int loc = -1;
+                if (v[k] != kEmpty) {
+                    uint32_t h = (v[k] * 0x9E3779B1u) >> shift;
+                    for (;;) {
+                        const uint32_t key = hkey[h];
+                        if (key == v[k]) { loc = (int)hval[h]; break; }
+                        if (key == kEmpty) break;
+                        h = (h + 1) & (uint32_t)(hcap - 1);
+                    }
+                }
+                const unsigned long long m = wave_ballot(loc >= 0);
+                if (loc >= 0) out[cnt + __popcll(m & lanemask_lt())] = loc;
+                cnt += __popcll(m);
+            }
+        }
+        if (lane == 0) rowcnt[i] = cnt;
+        my_nnz += cnt;
+    }
+    if (lane == 0 && my_nnz) atomicAdd(&w.sub_nnz[g], my_nnz);
+}
+
+// ------------------------------------------------------------------ K3 ----
+__global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDev oq, BatchOutDev ok,
+                                                    int64_t scratch_entries, int32_t *__restrict__ status)
+{
+    DYN_SMEM(smem);
+    __shared__ long long red[256];
+    __shared__ int carry_s;
+    int32_t *excl = (int32_t *)smem;    // [ncap + 1] exclusive prefix of rowcnt
+    const int tid = (int)threadIdx.x;
+    const int g = (int)blockIdx.x;
+    const int view = g / B, b = g - view * B;
+    const BatchOutDev o = view ? ok : oq;
+    const int n = w.sub_n[g];
+    const int nnz = w.sub_nnz[g];
+    const long long node_base = block_range_sum(w.sub_n, view * B, g, red);
+    const long long edge_base = block_range_sum(w.sub_nnz, view * B, g, red);
+    const long long sbase = block_range_sum(w.sub_cap, 0, g, red);
+    if (tid == 0) {
+        o.node_off[b] = (int32_t)node_base;
+        o.edge_off[b] = (int32_t)edge_base;
+        if (b == B - 1) {
+            o.node_off[B] = (int32_t)(node_base + n);
+            o.edge_off[B] = (int32_t)(edge_base + nnz);
+        }
+    }
+    const bool bad_scratch = sbase + (long long)w.sub_cap[g] > scratch_entries;
+    const bool bad_nodes = node_base + n > o.node_cap;
+    const bool bad_edges = edge_base + nnz > o.edge_cap;
+    if (bad_scratch || bad_nodes || bad_edges) {
+        if (tid == 0)
+            atomicOr(status, (int32_t)((bad_scratch ? GCC_STATUS_SCRATCH_OVERFLOW : 0) |
+                                       (bad_nodes ? GCC_STATUS_NODE_OVERFLOW : 0) |
+                                       (bad_edges ? GCC_STATUS_EDGE_OVERFLOW : 0)));
+        return;
+    }
+    const int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
+    const int32_t *rowoff = w.rowoff + (int64_t)g * w.ncap;
+    const int32_t *rowcnt = w.rowcnt + (int64_t)g * w.ncap;
+    const int32_t *scratch = w.scratch + sbase;
+
+    // exclusive scan of rowcnt over the subgraph's rows (chunks of 256 with carry)
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        const int c = i < n ? rowcnt[i] : 0;
+        // wave scan, then combine the 4 waves through LDS
+        const int incl = wave_scan_incl(c);
+        if ((tid & 63) == 63) red[tid >> 6] = incl;
+        __syncthreads();
+        int wave_base = 0;
+        for (int k = 0; k < (tid >> 6); ++k) wave_base += (int)red[k];
+        const int chunk_total = (int)(red[0] + red[1] + red[2] + red[3]);
+        const int base = carry_s;
+        if (i < n) excl[i] = base + wave_base + incl - c;
+        __syncthreads();
+        if (tid == 0) carry_s = base + chunk_total;
+        __syncthreads();
+    }
+    if (tid == 0) excl[n] = carry_s;
+    __syncthreads();
+
+    for (int i = tid; i < n; i += 256) {
+        o.parent_nid[node_base + i] = nodes[i];
+        o.graph_id[node_base + i] = b;
+        o.row_ptr[node_base + i] = (int32_t)(edge_base + excl[i]);
+    }
+    if (b == B - 1 && tid == 0) o.row_ptr[node_base + n] = (int32_t)(edge_base + nnz);
+    // one thread per output edge; its row by binary search in excl[]
+    for (int e = tid; e < nnz; e += 256) {
+        int lo = 0, hi = n;   // last row with excl[row] <= e
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (excl[mid] <= e) lo = mid; else hi = mid;
+        }
+        const int32_t loc = scratch[rowoff[lo] + (e - excl[lo])];
+        o.col_idx[edge_base + e] = (int32_t)node_base + loc;
+    }
+}
+
+thread_local char g_err[256] = "";
+
+}  // namespace
+
+extern "C" {
+
+int32_t gcc_abi_version(void) { return GCC_AMD_ABI_VERSION; }
+const char *gcc_last_error(void) { return g_err; }
+
+int64_t gcc_sampler_workspace_bytes(const gcc_graph *g, int32_t batch_size, int64_t scratch_entries)
+{
+    if (!g || batch_size <= 0 || scratch_entries <= 0 || g->lmax <= 0) {
+        snprintf(g_err, sizeof(g_err), "gcc_sampler_workspace_bytes: bad argument");
+        return -1;
+    }
+    return work_layout(g->lmax, batch_size, scratch_entries).total;
+}
+
+int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const gcc_batch_out *out_q,
+                         const gcc_batch_out *out_k, void *workspace, int64_t workspace_bytes,
+                         int64_t scratch_entries, int32_t *status, void *stream)
+{
+    if (!g || !p || !out_q || !out_k || !workspace || !status) {
+        snprintf(g_err, sizeof(g_err), "gcc_sample_batch: null argument");
+        return -1;
+    }
+    if (p->batch_size <= 0 || g->lmax <= 0 || g->lmax > 65534 || g->num_nodes <= 0 ||
+        g->num_nodes > 0x7FFFFFFF || g->num_edges > 0x7FFFFFFF) {
+        snprintf(g_err, sizeof(g_err), "gcc_sample_batch: size out of range (B=%d lmax=%d V=%lld E=%lld)",
+                 p->batch_size, g->lmax, (long long)g->num_nodes, (long long)g->num_edges);
+        return -2;
+    }
+    const WorkLayout wl = work_layout(g->lmax, p->batch_size, scratch_entries);
+    if (workspace_bytes < wl.total) {
+        snprintf(g_err, sizeof(g_err), "gcc_sample_batch: workspace %lld < %lld bytes",
+                 (long long)workspace_bytes, (long long)wl.total);
+        return -3;
+    }
+    char *base = (char *)workspace;
+    Work w;
+    w.seeds = (int32_t *)(base + wl.off_seeds);
+    w.sub_n = (int32_t *)(base + wl.off_n);
+    w.sub_cap = (int32_t *)(base + wl.off_cap);
+    w.sub_nnz = (int32_t *)(base + wl.off_nnz);
+    w.nodes = (int32_t *)(base + wl.off_nodes);
+    w.rowbeg = (int32_t *)(base + wl.off_rowbeg);
+    w.rowdeg = (int32_t *)(base + wl.off_rowdeg);
+    w.rowoff = (int32_t *)(base + wl.off_rowoff);
+    w.rowcnt = (int32_t *)(base + wl.off_rowcnt);
+    w.scratch = (int32_t *)(base + wl.off_scratch);
+    w.ncap = wl.ncap;
+
+    const int B = p->batch_size, G = 2 * B;
+    hipStream_t s = (hipStream_t)stream;
+    (void)s;
+    int p2max = 64;
+    while (p2max < g->lmax) p2max <<= 1;
+    int hlog = 7;
+    while ((1 << hlog) < 2 * (g->lmax + 1)) ++hlog;
+    const size_t lds1 = ((size_t)p2max * 2 + 64) * 4;
+    const size_t lds2 = (size_t)(1 << hlog) * 6;
+    const size_t lds3 = (size_t)(wl.ncap + 1) * 4;
+    if (lds1 > 160 * 1024 || lds2 > 160 * 1024) {
+        snprintf(g_err, sizeof(g_err), "gcc_sample_batch: lmax=%d needs more than 160 KiB of LDS", g->lmax);
+        return -4;
+    }
+    BatchOutDev oq = {out_q->node_off, out_q->edge_off, out_q->parent_nid, out_q->graph_id,
+                      out_q->row_ptr, out_q->col_idx, out_q->node_cap, out_q->edge_cap};
+    BatchOutDev ok = {out_k->node_off, out_k->edge_off, out_k->parent_nid, out_k->graph_id,
+                      out_k->row_ptr, out_k->col_idx, out_k->node_cap, out_k->edge_cap};
+
+    hipLaunchKernelGGL(rwr_walk_kernel, dim3(G), dim3(64), lds1, s, g->row_ptr, g->col_idx, g->seed_cdf,
+                       g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, B,
+                       p->restart_u32, p->seeds, w);
+    hipLaunchKernelGGL(induce_kernel, dim3(G * kWps), dim3(kInduceThreads), lds2, s, g->col_idx, hlog,
+                       scratch_entries, w, status);
+    hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), lds3, s, B, w, oq, ok, scratch_entries, status);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "gcc_sample_batch: launch failed: %s", hipGetErrorString(e));
+        return -10;
+    }
+    return 0;
+}
+
+}  // extern "C"

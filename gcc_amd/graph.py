@@ -1,0 +1,77 @@
+"""Parent graph resident in HBM.
+
+The reference keeps one DGLGraph copy per DataLoader worker process
+(/root/reference/gcc/datasets/graph_dataset.py:23-30); here the CSR is uploaded
+once per GPU and every kernel reads it in place.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import numpy as np
+
+from . import _cabi
+from .graphgen import check_contract
+
+
+def seed_cdf_table(row_ptr: np.ndarray) -> np.ndarray:
+    """P(seed = v) ~ in_degree(v)^0.75 (graph_dataset.py:86-90) as the float64
+    cdf numpy's ``choice(p=...)`` searches (``cdf = p.cumsum(); cdf /= cdf[-1]``)."""
+    w = np.diff(row_ptr).astype(np.float64) ** 0.75
+    p = w / w.sum()
+    cdf = np.cumsum(p)
+    cdf /= cdf[-1]
+    return cdf
+
+
+def max_nodes_per_seed_table(max_degree: int, rw_hops: int, restart_prob: float) -> np.ndarray:
+    """max_nodes_per_seed of graph_dataset.py:113-124 for every in-degree 0..max_degree."""
+    c = math.e / (math.e - 1) / restart_prob
+    return np.array([max(rw_hops, int((d ** 0.75) * c + 0.5)) for d in range(max_degree + 1)],
+                    dtype=np.int32)
+
+
+def restart_threshold(restart_prob: float) -> int:
+    """restart <=> 32-bit draw < floor(restart_prob * 2^32)."""
+    return min(int(restart_prob * 4294967296.0), 0xFFFFFFFF)
+
+
+class DeviceGraph:
+    """int32 CSR + seed cdf + max_nodes table on one GPU."""
+
+    def __init__(self, row_ptr: np.ndarray, col_idx: np.ndarray, rw_hops: int = 256,
+                 restart_prob: float = 0.8, device="cuda", validate: bool = True):
+        import torch
+
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+        if validate:
+            check_contract(row_ptr, col_idx)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceGraph lives in HBM; device must be a HIP/CUDA device")
+        self.num_nodes = int(row_ptr.shape[0] - 1)
+        self.num_edges = int(col_idx.shape[0])
+        self.rw_hops = int(rw_hops)
+        self.restart_prob = float(restart_prob)
+        self.restart_u32 = restart_threshold(restart_prob)
+        deg = np.diff(row_ptr)
+        self.max_degree = int(deg.max())
+        ltab = max_nodes_per_seed_table(self.max_degree, rw_hops, restart_prob)
+        self.lmax = int(ltab.max())
+        self.row_ptr = torch.from_numpy(row_ptr).to(self.device)
+        self.col_idx = torch.from_numpy(col_idx).to(self.device)
+        self.seed_cdf = torch.from_numpy(seed_cdf_table(row_ptr)).to(self.device)
+        self.ltab = torch.from_numpy(ltab).to(self.device)
+        self.c = _cabi.GccGraph(
+            row_ptr=self.row_ptr.data_ptr(), col_idx=self.col_idx.data_ptr(),
+            seed_cdf=self.seed_cdf.data_ptr(), ltab=self.ltab.data_ptr(),
+            num_nodes=self.num_nodes, num_edges=self.num_edges,
+            ltab_len=int(ltab.shape[0]), lmax=self.lmax)
+
+    def byref(self):
+        return ctypes.byref(self.c)
+
+    def hbm_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.row_ptr, self.col_idx, self.seed_cdf, self.ltab))

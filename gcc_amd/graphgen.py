@@ -1,0 +1,118 @@
+"""Synthetic power-law pre-training graphs (SURVEY.md §8d "Synthetic inputs").
+
+The reference trains on ``data/small.bin`` which cannot be downloaded here, so
+bench.py and the parity tests use a deterministic Chung-Lu graph that obeys the
+same *input contract* the reference's converter establishes
+(/root/reference/gcc/utils/x2dgl.py:39-62): symmetric, no self loops, no
+duplicate edges, no zero-degree nodes, immutable CSR.  Rows are sorted
+ascending and ids are int32.
+
+Nothing here is on the timed path; it only produces inputs.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+__all__ = ["powerlaw_graph", "tiny_graphs", "check_contract"]
+
+
+def _expected_degrees(num_nodes: int, target_sum: float, gamma: float, wmax: float) -> np.ndarray:
+    # inverse CDF of a Pareto(gamma) truncated to [1, wmax], evaluated on a
+    # fixed lattice so that the sequence does not depend on an RNG
+    u = (np.arange(num_nodes, dtype=np.float64) + 0.5) / num_nodes
+    a = 1.0 - gamma
+    base = (1.0 - u * (1.0 - wmax ** a)) ** (1.0 / a)
+    lo, hi = 1e-3, 1e3
+    for _ in range(80):  # bisection on the scale so that sum(w) == target_sum
+        mid = 0.5 * (lo + hi)
+        s = np.clip(base * mid, 1.0, wmax).sum()
+        if s < target_sum:
+            lo = mid
+        else:
+            hi = mid
+    return np.clip(base * (0.5 * (lo + hi)), 1.0, wmax)
+
+
+def powerlaw_graph(num_nodes: int, num_directed_edges: int, seed: int = 0,
+                   gamma: float = 2.2):
+    """Chung-Lu graph -> (row_ptr int32[V+1], col_idx int32[E]).
+
+    ``num_directed_edges`` is the target for the symmetrised edge count
+    (G1: 1_000_000 / 10_000_000, G2: 10_000_000 / 200_000_000); the realised
+    count is slightly lower after duplicate / self-loop removal and V shrinks
+    by the zero-degree nodes that are dropped (x2dgl.py:61).
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n_und = num_directed_edges // 2
+    wmax = 4.0 * np.sqrt(num_nodes)
+    w = _expected_degrees(num_nodes, 2.0 * n_und, gamma, wmax)
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    # scatter the heavy nodes over the id range so that id order carries no
+    # degree information (real graphs are not degree-sorted)
+    perm = rng.permutation(num_nodes)
+    src = perm[np.minimum(np.searchsorted(cdf, rng.random(n_und), side="right"), num_nodes - 1)]
+    dst = perm[np.minimum(np.searchsorted(cdf, rng.random(n_und), side="right"), num_nodes - 1)]
+    keep = src != dst                                   # x2dgl.py:41-42
+    src, dst = src[keep], dst[keep]
+    lo = np.minimum(src, dst).astype(np.int64)
+    hi = np.maximum(src, dst).astype(np.int64)
+    key = np.unique(lo * num_nodes + hi)                # x2dgl.py:52-54 (dedup)
+    lo, hi = key // num_nodes, key % num_nodes
+    rows = np.concatenate([lo, hi])                     # x2dgl.py:43-47 (both directions)
+    cols = np.concatenate([hi, lo])
+    deg = np.bincount(rows, minlength=num_nodes)
+    alive = deg > 0                                     # x2dgl.py:61
+    relabel = np.cumsum(alive) - 1
+    v = int(alive.sum())
+    a = sp.csr_matrix((np.ones(rows.shape[0], dtype=np.int8), (relabel[rows], relabel[cols])),
+                      shape=(v, v))
+    a.sort_indices()
+    return a.indptr.astype(np.int32), a.indices.astype(np.int32)
+
+
+def from_edges(num_nodes: int, edges) -> tuple[np.ndarray, np.ndarray]:
+    """Undirected edge list -> symmetric sorted CSR (no relabelling)."""
+    e = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+    rows = np.concatenate([e[:, 0], e[:, 1]])
+    cols = np.concatenate([e[:, 1], e[:, 0]])
+    a = sp.csr_matrix((np.ones(rows.shape[0], dtype=np.int8), (rows, cols)),
+                      shape=(num_nodes, num_nodes))
+    a.sum_duplicates()
+    a.sort_indices()
+    return a.indptr.astype(np.int32), a.indices.astype(np.int32)
+
+
+def tiny_graphs() -> dict:
+    """Hand-checkable graphs used by the known-answer tests."""
+    out = {}
+    out["path5"] = from_edges(5, [(0, 1), (1, 2), (2, 3), (3, 4)])
+    out["star6"] = from_edges(6, [(0, i) for i in range(1, 6)])
+    out["tri_tail"] = from_edges(5, [(0, 1), (1, 2), (0, 2), (2, 3), (3, 4)])
+    out["k4"] = from_edges(4, [(i, j) for i in range(4) for j in range(i + 1, 4)])
+    return out
+
+
+def check_contract(row_ptr: np.ndarray, col_idx: np.ndarray) -> None:
+    """Raise ValueError unless the CSR obeys the sampler's input contract."""
+    v = row_ptr.shape[0] - 1
+    if row_ptr[0] != 0 or row_ptr[-1] != col_idx.shape[0]:
+        raise ValueError("row_ptr does not span col_idx")
+    deg = np.diff(row_ptr)
+    if (deg <= 0).any():
+        raise ValueError("zero-degree node: the reference removes them (x2dgl.py:61) "
+                         "and DGL's walker aborts on them")
+    if col_idx.min() < 0 or col_idx.max() >= v:
+        raise ValueError("col_idx out of range")
+    a = sp.csr_matrix((np.ones(col_idx.shape[0], dtype=np.int8), col_idx, row_ptr), shape=(v, v))
+    if not a.has_sorted_indices:
+        raise ValueError("rows must be sorted ascending")
+    if a.diagonal().any():
+        raise ValueError("self loop present (x2dgl.py:41-42)")
+    b = a.copy()
+    b.sum_duplicates()
+    if b.nnz != a.nnz:
+        raise ValueError("duplicate edge present (x2dgl.py:52-54)")
+    if (a != a.T).nnz != 0:
+        raise ValueError("graph is not symmetric (x2dgl.py:43-47)")

@@ -1,0 +1,294 @@
+"""Device-resident RWR ego-net sampler behind the reference's dataset API.
+
+Mirrors /root/reference/gcc/datasets/graph_dataset.py:23-179
+(``LoadBalanceGraphDataset``, ``worker_init_fn``) and
+gcc/datasets/data_util.py:26-32 (``batcher``): iterating the dataset yields
+``(graph_q, graph_k)`` pairs that ``train.py`` feeds to ``GraphEncoder``.  The
+pairs are produced already batched, in HBM, by the HIP kernels of
+gcc_amd/csrc/sampler.hip; no worker processes, no pickling, no H2D copy.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _cabi
+from .graph import DeviceGraph
+
+
+class BatchedCSR:
+    """One view's batched subgraphs = the ``dgl.batch(...)`` result the reference
+    passes around (data_util.py:26-32).  Duck-types the DGLGraph members the hot
+    path touches: ``ndata``, ``in_degrees``, ``to``,
+    ``batch_size``, ``number_of_nodes``, ``number_of_edges``, ``batch_num_nodes``.
+
+    All tensors are capacity-sized device buffers; the live extents are
+    ``node_off[batch_size]`` nodes and ``edge_off[batch_size]`` edges and stay on
+    the device (kernels read them there), so building a batch never syncs.
+    """
+
+    def __init__(self, batch_size, node_off, edge_off, parent_nid, graph_id, row_ptr, col_idx):
+        self.batch_size = int(batch_size)
+        self.node_off = node_off
+        self.edge_off = edge_off
+        self.parent_nid = parent_nid
+        self.graph_id = graph_id
+        self.row_ptr = row_ptr
+        self.col_idx = col_idx
+        self.pos_undirected = None      # [node_cap, P] f32, filled by gcc_amd.posemb
+        self._n = None
+        self._e = None
+        self.ndata = _NData(self)
+
+    # ---- DGLGraph surface -------------------------------------------------
+    def number_of_nodes(self) -> int:
+        if self._n is None:
+            self._n = int(self.node_off[self.batch_size].item())
+        return self._n
+
+    def number_of_edges(self) -> int:
+        if self._e is None:
+            self._e = int(self.edge_off[self.batch_size].item())
+        return self._e
+
+    @property
+    def batch_num_nodes(self):
+        off = self.node_off[: self.batch_size + 1].cpu().numpy()
+        return np.diff(off).tolist()
+
+    def in_degrees(self):
+        n = self.number_of_nodes()
+        rp = self.row_ptr[: n + 1].long()
+        return rp[1:] - rp[:-1]          # symmetric parent => in-degree == row length
+
+    def to(self, device):
+        return self
+
+    # ---- views used by tests / host code -----------------------------------
+    def csr_numpy(self):
+        n, e = self.number_of_nodes(), self.number_of_edges()
+        return dict(node_off=self.node_off.cpu().numpy(), edge_off=self.edge_off.cpu().numpy(),
+                    parent_nid=self.parent_nid[:n].cpu().numpy(), graph_id=self.graph_id[:n].cpu().numpy(),
+                    row_ptr=self.row_ptr[: n + 1].cpu().numpy(), col_idx=self.col_idx[:e].cpu().numpy())
+
+    def c_struct(self) -> _cabi.GccBatchOut:
+        return _cabi.GccBatchOut(
+            node_off=self.node_off.data_ptr(), edge_off=self.edge_off.data_ptr(),
+            parent_nid=self.parent_nid.data_ptr(), graph_id=self.graph_id.data_ptr(),
+            row_ptr=self.row_ptr.data_ptr(), col_idx=self.col_idx.data_ptr(),
+            node_cap=self.parent_nid.numel(), edge_cap=self.col_idx.numel())
+
+
+class _NData:
+    """``g.ndata[...]`` of the reference graphs (graph_encoder.py:153-162)."""
+
+    def __init__(self, g: BatchedCSR):
+        self._g = g
+
+    def __getitem__(self, key):
+        import torch
+
+        g = self._g
+        if key == "seed":                       # data_util.py:234-238: one-hot at local node 0
+            n = g.number_of_nodes()
+            s = torch.zeros(n, dtype=torch.long, device=g.node_off.device)
+            s[g.node_off[: g.batch_size].long()] = 1
+            return s
+        if key == "pos_undirected":
+            if g.pos_undirected is None:
+                raise KeyError("pos_undirected has not been computed for this batch")
+            return g.pos_undirected[: g.number_of_nodes()]
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key == "seed" or (key == "pos_undirected" and self._g.pos_undirected is not None)
+
+
+class DeviceRWRSampler:
+    """Owns the output/workspace buffers and issues ``gcc_sample_batch``."""
+
+    def __init__(self, graph: DeviceGraph, batch_size: int, run_seed: int = 0,
+                 edge_cap: int | None = None, scratch_entries: int | None = None, num_buffers: int = 2):
+        import torch
+
+        self.graph = graph
+        self.lib = _cabi.load()
+        self.batch_size = int(batch_size)
+        self.run_seed = int(run_seed) & 0xFFFFFFFFFFFFFFFF
+        dev = graph.device
+        B = self.batch_size
+        self.node_cap = B * (graph.lmax + 1)
+        self.edge_cap = int(edge_cap) if edge_cap else max(64 * B * (graph.rw_hops + 1), 2 * (graph.lmax + 1) ** 2)
+        # induction scratch: sum over subgraphs of sum_i min(deg_i, n) <= sum n^2; sized generously
+        # (HBM is 288 GB) and guarded by the device status word
+        self.scratch_entries = int(scratch_entries) if scratch_entries else max(
+            16 << 20, 256 * B * (graph.rw_hops + 1), 8 * (graph.lmax + 1) ** 2)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._alloc_workspace()
+        i32 = dict(dtype=torch.int32, device=dev)
+        self._ring = []
+        for _ in range(num_buffers):
+            views = []
+            for _v in range(2):
+                views.append(dict(
+                    node_off=torch.zeros(B + 1, **i32), edge_off=torch.zeros(B + 1, **i32),
+                    parent_nid=torch.zeros(self.node_cap, **i32), graph_id=torch.zeros(self.node_cap, **i32),
+                    row_ptr=torch.zeros(self.node_cap + 1, **i32), col_idx=torch.zeros(self.edge_cap, **i32)))
+            self._ring.append(views)
+        self._next = 0
+
+    def _alloc_workspace(self):
+        import torch
+
+        nbytes = self.lib.gcc_sampler_workspace_bytes(self.graph.byref(), self.batch_size, self.scratch_entries)
+        if nbytes < 0:
+            raise RuntimeError(self.lib.gcc_last_error().decode())
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.graph.device)
+
+    def sample(self, first_sample_id: int, seeds=None):
+        """-> (BatchedCSR q, BatchedCSR k) for samples first_sample_id .. +B-1.
+
+        ``seeds`` (int32 device tensor [B]) overrides the deg^0.75 seed draw.
+        """
+        import torch
+
+        views = self._ring[self._next]
+        self._next = (self._next + 1) % len(self._ring)
+        q = BatchedCSR(self.batch_size, **views[0])
+        k = BatchedCSR(self.batch_size, **views[1])
+        params = _cabi.GccSampleParams(
+            run_seed=self.run_seed, first_sample_id=int(first_sample_id), batch_size=self.batch_size,
+            restart_u32=self.graph.restart_u32,
+            seeds=_cabi.dev_ptr(seeds, torch.int32) if seeds is not None else None)
+        cq, ck = q.c_struct(), k.c_struct()
+        rc = self.lib.gcc_sample_batch(
+            self.graph.byref(), ctypes.byref(params), ctypes.byref(cq), ctypes.byref(ck),
+            self.workspace.data_ptr(), self.workspace.numel(), self.scratch_entries,
+            self.status.data_ptr(), torch.cuda.current_stream(self.graph.device).cuda_stream)
+        _cabi.check(rc, "gcc_sample_batch")
+        return q, k
+
+    def check_status(self) -> None:
+        """Synchronising check of the device overflow flags (raises, never truncates)."""
+        s = int(self.status.item())
+        if s:
+            what = [n for b, n in ((1, "induction scratch"), (2, "node capacity"), (4, "edge capacity")) if s & b]
+            raise RuntimeError("gcc_sample_batch overflow: " + ", ".join(what) +
+                               " -- construct DeviceRWRSampler with larger edge_cap/scratch_entries")
+
+    def last_seeds(self):
+        """int32 [B] device view of the seeds drawn by the most recent call."""
+        import torch
+
+        return self.workspace[: 4 * self.batch_size].view(torch.int32)
+
+
+# ------------------------------------------------------------------ reference API
+def worker_init_fn(worker_id):
+    """graph_dataset.py:23-30 loads a graph shard per DataLoader worker.  The
+    device sampler runs in-process (HIP contexts do not survive fork), so there
+    is nothing to initialise; kept so train.py's DataLoader call still type-checks."""
+    return None
+
+
+def batcher():
+    """data_util.py:26-32.  Samples arrive pre-batched from the device, so the
+    collate function only unwraps DataLoader's one-element list."""
+
+    def batcher_dev(batch):
+        if isinstance(batch, (list, tuple)) and len(batch) == 1:
+            return batch[0]
+        return batch
+
+    return batcher_dev
+
+
+class LoadBalanceGraphDataset:
+    """Same constructor arguments and attributes (``total``, ``jobs``,
+    ``num_samples``) as graph_dataset.py:33-80; iteration yields already-batched
+    ``(graph_q, graph_k)`` of ``batch_size`` samples each.
+
+    ``graph`` replaces the DGL ``.bin`` file (ingestion of DGL files is
+    SURVEY.md §8f#3): a :class:`DeviceGraph`, or ``(row_ptr, col_idx)`` arrays,
+    or a list of such pairs (disjoint graphs are unioned, which is what sampling
+    a node uniformly over all workers' graphs amounts to).
+    """
+
+    def __init__(self, rw_hops=64, restart_prob=0.8, positional_embedding_size=32,
+                 step_dist=[1.0, 0.0, 0.0], num_workers=1, dgl_graphs_file="./data/small.bin",
+                 num_samples=10000, num_copies=1, graph_transform=None, aug="rwr", num_neighbors=5,
+                 graph=None, batch_size=32, run_seed=0, device="cuda"):
+        self.rw_hops = rw_hops
+        self.num_neighbors = num_neighbors
+        self.restart_prob = restart_prob
+        self.positional_embedding_size = positional_embedding_size
+        self.step_dist = step_dist
+        self.num_samples = num_samples
+        assert sum(step_dist) == 1.0
+        assert positional_embedding_size > 1
+        if list(step_dist) != [1.0, 0.0, 0.0]:
+            raise NotImplementedError("only step_dist=[1,0,0] (train.py's only setting) is supported")
+        assert aug in ("rwr", "ns")
+        if aug != "rwr":
+            raise NotImplementedError("aug='ns' is never selected by train.py (graph_dataset.py:131-162)")
+        if graph_transform is not None:
+            raise NotImplementedError("graph_transform is never set by train.py")
+        self.aug = aug
+        self.dgl_graphs_file = dgl_graphs_file
+        self.graph_transform = graph_transform
+        if graph is None:
+            graph = _load_npz_graphs(dgl_graphs_file)
+        graphs = graph if isinstance(graph, list) else [graph]
+        if isinstance(graphs[0], DeviceGraph):
+            assert len(graphs) == 1
+            self.graph = graphs[0]
+            sizes = [self.graph.num_nodes]
+        else:
+            sizes = [len(rp) - 1 for rp, _ in graphs]
+            rp, ci = _disjoint_union(graphs)
+            self.graph = DeviceGraph(rp, ci, rw_hops=rw_hops, restart_prob=restart_prob, device=device)
+        # greedy LPT load balance of graph_dataset.py:63-77, kept for its attributes
+        assert num_workers % num_copies == 0
+        bins = max(num_workers // num_copies, 1)
+        jobs = [list() for _ in range(bins)]
+        workloads = [0] * bins
+        for idx, size in sorted(enumerate(sizes), key=lambda t: t[1], reverse=True):
+            argmin = workloads.index(min(workloads))
+            workloads[argmin] += size
+            jobs[argmin].append(idx)
+        self.jobs = jobs * num_copies
+        self.total = self.num_samples * num_workers
+        self.batch_size = batch_size
+        self.sampler = DeviceRWRSampler(self.graph, batch_size, run_seed=run_seed)
+        self._epoch = 0
+
+    def __len__(self):
+        return self.total
+
+    def __iter__(self):
+        n_batch = self.total // self.batch_size
+        base = self._epoch * self.total
+        self._epoch += 1
+        for i in range(n_batch):
+            yield self.sampler.sample(base + i * self.batch_size)
+
+
+def _disjoint_union(graphs):
+    rps, cis, off, eoff = [np.zeros(1, dtype=np.int64)], [], 0, 0
+    for rp, ci in graphs:
+        rp = np.asarray(rp, dtype=np.int64)
+        rps.append(rp[1:] + eoff)
+        cis.append(np.asarray(ci, dtype=np.int64) + off)
+        off += len(rp) - 1
+        eoff += int(rp[-1])
+    return np.concatenate(rps).astype(np.int32), np.concatenate(cis).astype(np.int32)
+
+
+def _load_npz_graphs(path):
+    if not str(path).endswith(".npz"):
+        raise NotImplementedError(
+            f"{path}: reading DGL .bin files needs DGL (SURVEY.md §8f#3); pass graph=(row_ptr, col_idx) "
+            "or an .npz with row_ptr/col_idx")
+    z = np.load(path)
+    return [(z["row_ptr"], z["col_idx"])]

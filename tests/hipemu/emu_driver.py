@@ -1,0 +1,85 @@
+"""Drives tests/hipemu/_build/libgcc_amd_emu.so (the kernels of gcc_amd/csrc
+compiled for the lock-step CPU emulator) through the C ABI with numpy buffers.
+
+TEST INFRASTRUCTURE ONLY -- lets the "not gpu" suite execute the kernel logic
+on machines without a GPU.  gcc_amd itself never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from gcc_amd import _cabi
+from gcc_amd.graph import max_nodes_per_seed_table, restart_threshold, seed_cdf_table
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_LIB = os.path.join(_HERE, "_build", "libgcc_amd_emu.so")
+_lib = None
+
+
+def emu_lib():
+    global _lib
+    if _lib is None:
+        subprocess.run(["make", "-C", os.path.join(_ROOT, "gcc_amd", "csrc"), "emu"], check=True,
+                       capture_output=True)
+        _lib = _cabi.declare(ctypes.CDLL(_LIB))
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data if a is not None else None
+
+
+class EmuGraph:
+    def __init__(self, row_ptr, col_idx, rw_hops=256, restart_prob=0.8):
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        self.col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+        self.cdf = seed_cdf_table(self.row_ptr)
+        deg = np.diff(self.row_ptr)
+        self.ltab = max_nodes_per_seed_table(int(deg.max()), rw_hops, restart_prob)
+        self.lmax = int(self.ltab.max())
+        self.rw_hops = rw_hops
+        self.restart_u32 = restart_threshold(restart_prob)
+        self.c = _cabi.GccGraph(row_ptr=_p(self.row_ptr), col_idx=_p(self.col_idx), seed_cdf=_p(self.cdf),
+                                ltab=_p(self.ltab), num_nodes=len(self.row_ptr) - 1,
+                                num_edges=len(self.col_idx), ltab_len=len(self.ltab), lmax=self.lmax)
+
+
+def emu_sample_batch(g: EmuGraph, B, run_seed, first_sample_id, seeds=None, edge_cap=None,
+                     scratch_entries=None, node_cap=None):
+    lib = emu_lib()
+    node_cap = node_cap or B * (g.lmax + 1)
+    edge_cap = edge_cap or B * (g.lmax + 1) ** 2
+    scratch_entries = scratch_entries or 2 * B * (g.lmax + 1) ** 2
+    nbytes = lib.gcc_sampler_workspace_bytes(ctypes.byref(g.c), B, scratch_entries)
+    assert nbytes > 0
+    ws = np.zeros(nbytes, dtype=np.uint8)
+    status = np.zeros(1, dtype=np.int32)
+    outs, structs = [], []
+    for _ in range(2):
+        o = dict(node_off=np.zeros(B + 1, np.int32), edge_off=np.zeros(B + 1, np.int32),
+                 parent_nid=np.zeros(node_cap, np.int32), graph_id=np.zeros(node_cap, np.int32),
+                 row_ptr=np.zeros(node_cap + 1, np.int32), col_idx=np.zeros(edge_cap, np.int32))
+        outs.append(o)
+        structs.append(_cabi.GccBatchOut(node_off=_p(o["node_off"]), edge_off=_p(o["edge_off"]),
+                                         parent_nid=_p(o["parent_nid"]), graph_id=_p(o["graph_id"]),
+                                         row_ptr=_p(o["row_ptr"]), col_idx=_p(o["col_idx"]),
+                                         node_cap=node_cap, edge_cap=edge_cap))
+    if seeds is not None:
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+    params = _cabi.GccSampleParams(run_seed=run_seed, first_sample_id=first_sample_id, batch_size=B,
+                                   restart_u32=g.restart_u32, seeds=_p(seeds))
+    rc = lib.gcc_sample_batch(ctypes.byref(g.c), ctypes.byref(params), ctypes.byref(structs[0]),
+                              ctypes.byref(structs[1]), _p(ws), nbytes, scratch_entries, _p(status), None)
+    if rc != 0:
+        raise RuntimeError(lib.gcc_last_error().decode())
+    res = []
+    for o in outs:
+        n, e = int(o["node_off"][B]), int(o["edge_off"][B])
+        res.append(dict(node_off=o["node_off"], edge_off=o["edge_off"], parent_nid=o["parent_nid"][:n],
+                        graph_id=o["graph_id"][:n], row_ptr=o["row_ptr"][: n + 1], col_idx=o["col_idx"][:e]))
+    return res, int(status[0]), ws[: 4 * B].view(np.int32).copy()

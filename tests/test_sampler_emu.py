@@ -1,0 +1,68 @@
+"""Kernel-logic parity on CPU: gcc_amd/csrc/sampler.hip compiled for the
+lock-step wave64 emulator (tests/hipemu) vs the C oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from gcc_amd.graphgen import powerlaw_graph, tiny_graphs
+from oracle import sampler as O
+from tests.hipemu.emu_driver import EmuGraph, emu_sample_batch
+
+KEYS = ("node_off", "parent_nid", "row_ptr", "col_idx")
+
+
+def _compare(coracle, rp, ci, g, B, run_seed, first, seeds=None, **kw):
+    res, status, used = emu_sample_batch(g, B, run_seed, first, seeds=seeds, **kw)
+    assert status == 0
+    oseeds = coracle.draw_seeds(O.seed_cdf(rp), run_seed, first, B) if seeds is None else np.asarray(seeds, np.int32)
+    assert used.tolist() == oseeds.tolist()
+    L = g.ltab[np.minimum(np.diff(rp)[oseeds], len(g.ltab) - 1)]
+    for view in range(2):
+        ref = coracle.sample_batch(rp, ci, oseeds, L, view, run_seed, first, g.restart_u32)
+        for k in KEYS:
+            assert np.array_equal(res[view][k], ref[k]), (view, k)
+        assert np.array_equal(res[view]["edge_off"], ref["edge_off"])
+        gid = np.repeat(np.arange(B), np.diff(ref["node_off"]))
+        assert np.array_equal(res[view]["graph_id"], gid)
+    return res
+
+
+@pytest.mark.parametrize("B,rw_hops,run_seed,first", [(1, 16, 0, 0), (5, 64, 11, 100), (9, 256, 2**40 + 5, 2**33)])
+def test_powerlaw_matches_oracle(coracle, B, rw_hops, run_seed, first):
+    rp, ci = powerlaw_graph(3000, 30000, 3)
+    _compare(coracle, rp, ci, EmuGraph(rp, ci, rw_hops=rw_hops), B, run_seed, first)
+
+
+def test_hub_seeds_exceed_rw_hops(coracle):
+    # degrees > 655 make max_nodes_per_seed > rw_hops (graph_dataset.py:113-124): bigger LDS / sort sizes
+    rp, ci = powerlaw_graph(20000, 400000, 1)
+    deg = np.diff(rp)
+    hubs = np.argsort(deg)[-3:].astype(np.int32)
+    g = EmuGraph(rp, ci, rw_hops=64)
+    assert g.ltab[deg[hubs]].min() > 128        # several sort sizes above the rw_hops floor
+    _compare(coracle, rp, ci, g, 3, 7, 0, seeds=hubs)
+
+
+@pytest.mark.parametrize("name", ["path5", "star6", "tri_tail", "k4"])
+def test_tiny_graphs(coracle, name):
+    rp, ci = tiny_graphs()[name]
+    g = EmuGraph(rp, ci, rw_hops=12)
+    _compare(coracle, rp, ci, g, 4, 5, 0)
+    _compare(coracle, rp, ci, g, 2, 5, 0, seeds=[0, len(rp) - 2])
+
+
+def test_restart_prob_extremes(coracle):
+    rp, ci = powerlaw_graph(1000, 8000, 6)
+    for prob in (0.05, 0.5, 0.999):
+        g = EmuGraph(rp, ci, rw_hops=64, restart_prob=prob)
+        _compare(coracle, rp, ci, g, 3, 1, 0)
+
+
+def test_overflow_is_flagged_not_truncated():
+    rp, ci = powerlaw_graph(3000, 30000, 3)
+    g = EmuGraph(rp, ci, rw_hops=64)
+    _, status, _ = emu_sample_batch(g, 4, 1, 0, scratch_entries=8)
+    assert status & 1
+    _, status, _ = emu_sample_batch(g, 4, 1, 0, edge_cap=4)
+    assert status & 4
+    _, status, _ = emu_sample_batch(g, 4, 1, 0, node_cap=4)
+    assert status & 2
