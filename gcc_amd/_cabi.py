@@ -43,6 +43,7 @@ class GccSampleParams(ctypes.Structure):
         ("batch_size", ctypes.c_int32),
         ("restart_u32", ctypes.c_uint32),
         ("seeds", ctypes.c_void_p),
+        ("prof", ctypes.c_void_p),
     ]
 
 
@@ -63,6 +64,9 @@ class GccBatchOut(ctypes.Structure):
 SIGNATURES = {
     "gcc_abi_version": (ctypes.c_int32, []),
     "gcc_last_error": (ctypes.c_char_p, []),
+    "gcc_prof_create": (ctypes.c_void_p, [ctypes.c_int32]),
+    "gcc_prof_destroy": (None, [ctypes.c_void_p]),
+    "gcc_prof_elapsed_ms": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_f32p]),
     "gcc_sampler_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(GccGraph), ctypes.c_int32, ctypes.c_int64]),
     "gcc_sample_batch": (ctypes.c_int32, [
         ctypes.POINTER(GccGraph), ctypes.POINTER(GccSampleParams), ctypes.POINTER(GccBatchOut),

@@ -26,8 +26,7 @@
 #include "device_compat.h"
 #include "../../include/gcc_amd.h"
 
-#include <stdio.h>
-#include <string.h>
+#include "host_common.h"
 
 namespace {
 
@@ -430,19 +429,14 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
     }
 }
 
-thread_local char g_err[256] = "";
-
 }  // namespace
 
 extern "C" {
 
-int32_t gcc_abi_version(void) { return GCC_AMD_ABI_VERSION; }
-const char *gcc_last_error(void) { return g_err; }
-
 int64_t gcc_sampler_workspace_bytes(const gcc_graph *g, int32_t batch_size, int64_t scratch_entries)
 {
     if (!g || batch_size <= 0 || scratch_entries <= 0 || g->lmax <= 0) {
-        snprintf(g_err, sizeof(g_err), "gcc_sampler_workspace_bytes: bad argument");
+        snprintf(g_err, kErrLen, "gcc_sampler_workspace_bytes: bad argument");
         return -1;
     }
     return work_layout(g->lmax, batch_size, scratch_entries).total;
@@ -453,18 +447,18 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
                          int64_t scratch_entries, int32_t *status, void *stream)
 {
     if (!g || !p || !out_q || !out_k || !workspace || !status) {
-        snprintf(g_err, sizeof(g_err), "gcc_sample_batch: null argument");
+        snprintf(g_err, kErrLen, "gcc_sample_batch: null argument");
         return -1;
     }
     if (p->batch_size <= 0 || g->lmax <= 0 || g->lmax > 65534 || g->num_nodes <= 0 ||
         g->num_nodes > 0x7FFFFFFF || g->num_edges > 0x7FFFFFFF) {
-        snprintf(g_err, sizeof(g_err), "gcc_sample_batch: size out of range (B=%d lmax=%d V=%lld E=%lld)",
+        snprintf(g_err, kErrLen, "gcc_sample_batch: size out of range (B=%d lmax=%d V=%lld E=%lld)",
                  p->batch_size, g->lmax, (long long)g->num_nodes, (long long)g->num_edges);
         return -2;
     }
     const WorkLayout wl = work_layout(g->lmax, p->batch_size, scratch_entries);
     if (workspace_bytes < wl.total) {
-        snprintf(g_err, sizeof(g_err), "gcc_sample_batch: workspace %lld < %lld bytes",
+        snprintf(g_err, kErrLen, "gcc_sample_batch: workspace %lld < %lld bytes",
                  (long long)workspace_bytes, (long long)wl.total);
         return -3;
     }
@@ -484,7 +478,6 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
 
     const int B = p->batch_size, G = 2 * B;
     hipStream_t s = (hipStream_t)stream;
-    (void)s;
     int p2max = 64;
     while (p2max < g->lmax) p2max <<= 1;
     int hlog = 7;
@@ -493,7 +486,7 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     const size_t lds2 = (size_t)(1 << hlog) * 6;
     const size_t lds3 = (size_t)(wl.ncap + 1) * 4;
     if (lds1 > 160 * 1024 || lds2 > 160 * 1024) {
-        snprintf(g_err, sizeof(g_err), "gcc_sample_batch: lmax=%d needs more than 160 KiB of LDS", g->lmax);
+        snprintf(g_err, kErrLen, "gcc_sample_batch: lmax=%d needs more than 160 KiB of LDS", g->lmax);
         return -4;
     }
     BatchOutDev oq = {out_q->node_off, out_q->edge_off, out_q->parent_nid, out_q->graph_id,
@@ -501,15 +494,19 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     BatchOutDev ok = {out_k->node_off, out_k->edge_off, out_k->parent_nid, out_k->graph_id,
                       out_k->row_ptr, out_k->col_idx, out_k->node_cap, out_k->edge_cap};
 
+    prof_mark(p->prof, 0, s);
     hipLaunchKernelGGL(rwr_walk_kernel, dim3(G), dim3(64), lds1, s, g->row_ptr, g->col_idx, g->seed_cdf,
                        g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, B,
                        p->restart_u32, p->seeds, w);
+    prof_mark(p->prof, 1, s);
     hipLaunchKernelGGL(induce_kernel, dim3(G * kWps), dim3(kInduceThreads), lds2, s, g->col_idx, hlog,
                        scratch_entries, w, status);
+    prof_mark(p->prof, 2, s);
     hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), lds3, s, B, w, oq, ok, scratch_entries, status);
+    prof_mark(p->prof, 3, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        snprintf(g_err, sizeof(g_err), "gcc_sample_batch: launch failed: %s", hipGetErrorString(e));
+        snprintf(g_err, kErrLen, "gcc_sample_batch: launch failed: %s", hipGetErrorString(e));
         return -10;
     }
     return 0;

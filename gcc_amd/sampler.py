@@ -146,7 +146,7 @@ class DeviceRWRSampler:
             raise RuntimeError(self.lib.gcc_last_error().decode())
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.graph.device)
 
-    def sample(self, first_sample_id: int, seeds=None):
+    def sample(self, first_sample_id: int, seeds=None, prof=None):
         """-> (BatchedCSR q, BatchedCSR k) for samples first_sample_id .. +B-1.
 
         ``seeds`` (int32 device tensor [B]) overrides the deg^0.75 seed draw.
@@ -160,7 +160,8 @@ class DeviceRWRSampler:
         params = _cabi.GccSampleParams(
             run_seed=self.run_seed, first_sample_id=int(first_sample_id), batch_size=self.batch_size,
             restart_u32=self.graph.restart_u32,
-            seeds=_cabi.dev_ptr(seeds, torch.int32) if seeds is not None else None)
+            seeds=_cabi.dev_ptr(seeds, torch.int32) if seeds is not None else None,
+            prof=prof.handle if prof is not None else None)
         cq, ck = q.c_struct(), k.c_struct()
         rc = self.lib.gcc_sample_batch(
             self.graph.byref(), ctypes.byref(params), ctypes.byref(cq), ctypes.byref(ck),

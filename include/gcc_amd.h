@@ -38,6 +38,17 @@ extern "C" {
 int32_t gcc_abi_version(void);
 const char *gcc_last_error(void);
 
+/* -------------------------------------------------------------- profiling ---
+ * A ring of hipEvents the kernels' launch functions record between kernels
+ * when a call's `prof` argument is non-NULL (bench.py's live per-kernel
+ * durations; no counterpart in the reference, whose only timers are the
+ * BT/DT wall-clock meters of train.py:367-368). */
+typedef struct gcc_prof gcc_prof;
+gcc_prof *gcc_prof_create(int32_t num_marks);
+void gcc_prof_destroy(gcc_prof *p);
+/* milliseconds between two recorded marks; synchronises on `to_mark`. */
+int32_t gcc_prof_elapsed_ms(gcc_prof *p, int32_t from_mark, int32_t to_mark, float *ms);
+
 /* ---------------------------------------------------------------- graph ---
  * The parent graph in the layout x2dgl.py:39-62 guarantees (symmetric, no self
  * loops, no duplicates, no zero-degree nodes, rows sorted), resident in HBM.
@@ -69,6 +80,7 @@ typedef struct gcc_sample_params {
     int32_t  batch_size;       /* B samples -> 2B subgraphs                           */
     uint32_t restart_u32;      /* floor(restart_prob * 2^32)                          */
     const int32_t *seeds;      /* device [B] or NULL; non-NULL overrides the seed draw */
+    gcc_prof *prof;            /* NULL, or marks 0..3 recorded around walk/induce/pack */
 } gcc_sample_params;
 
 /* One view's batched graph = dgl.batch(list of subgraphs), data_util.py:26-32.

@@ -75,6 +75,12 @@ static inline hipError_t hipGetLastError() { return 0; }
 static inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+typedef void *hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return 0; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 
 #define hipLaunchKernelGGL(kern, grid, block, smem, stream, ...) \
     hipemu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
