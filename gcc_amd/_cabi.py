@@ -60,6 +60,54 @@ class GccBatchOut(ctypes.Structure):
     ]
 
 
+GIN_MAX_LAYERS = 8
+GIN_HIDDEN = 64
+_VP = ctypes.c_void_p
+
+
+class GccBn(ctypes.Structure):
+    _fields_ = [("weight", _VP), ("bias", _VP), ("running_mean", _VP), ("running_var", _VP),
+                ("num_batches_tracked", _VP)]
+
+
+class GccGinWeights(ctypes.Structure):
+    _fields_ = [
+        ("num_gin_layers", ctypes.c_int32), ("pos_dim", ctypes.c_int32), ("deg_emb_dim", ctypes.c_int32),
+        ("max_degree", ctypes.c_int32),
+        ("degree_embedding", _VP),
+        ("lin0_w", _VP * GIN_MAX_LAYERS), ("lin0_b", _VP * GIN_MAX_LAYERS),
+        ("lin1_w", _VP * GIN_MAX_LAYERS), ("lin1_b", _VP * GIN_MAX_LAYERS),
+        ("bn_a", GccBn * GIN_MAX_LAYERS), ("bn_b", GccBn * GIN_MAX_LAYERS), ("bn_c", GccBn * GIN_MAX_LAYERS),
+        ("pred_w", _VP * (GIN_MAX_LAYERS + 1)), ("pred_b", _VP * (GIN_MAX_LAYERS + 1)),
+        ("bn_eps", ctypes.c_float), ("bn_momentum", ctypes.c_float), ("dropout_p", ctypes.c_float),
+        ("norm_eps", ctypes.c_float),
+    ]
+
+
+class GccGinPass(ctypes.Structure):
+    _fields_ = [
+        ("node_off", _VP), ("row_ptr", _VP), ("col_idx", _VP), ("graph_id", _VP), ("pos", _VP),
+        ("batch_size", ctypes.c_int32), ("training", ctypes.c_int32), ("update_running_stats", ctypes.c_int32),
+        ("normalize", ctypes.c_int32),
+        ("dropout_keep", _VP),
+        ("w", GccGinWeights),
+        ("x0", _VP), ("agg", _VP * GIN_MAX_LAYERS), ("z1", _VP * GIN_MAX_LAYERS), ("z2", _VP * GIN_MAX_LAYERS),
+        ("stats", _VP), ("pooled", _VP), ("score", _VP), ("feat", _VP),
+    ]
+
+
+class GccGinGrads(ctypes.Structure):
+    _fields_ = [
+        ("degree_embedding", _VP),
+        ("lin0_w", _VP * GIN_MAX_LAYERS), ("lin0_b", _VP * GIN_MAX_LAYERS),
+        ("lin1_w", _VP * GIN_MAX_LAYERS), ("lin1_b", _VP * GIN_MAX_LAYERS),
+        ("bn_a_w", _VP * GIN_MAX_LAYERS), ("bn_a_b", _VP * GIN_MAX_LAYERS),
+        ("bn_b_w", _VP * GIN_MAX_LAYERS), ("bn_b_b", _VP * GIN_MAX_LAYERS),
+        ("bn_c_w", _VP * GIN_MAX_LAYERS), ("bn_c_b", _VP * GIN_MAX_LAYERS),
+        ("pred_w", _VP * (GIN_MAX_LAYERS + 1)), ("pred_b", _VP * (GIN_MAX_LAYERS + 1)),
+    ]
+
+
 # name -> (restype, argtypes); the single source of truth for the symbol test
 SIGNATURES = {
     "gcc_abi_version": (ctypes.c_int32, []),
@@ -72,7 +120,11 @@ SIGNATURES = {
         ctypes.POINTER(GccGraph), ctypes.POINTER(GccSampleParams), ctypes.POINTER(GccBatchOut),
         ctypes.POINTER(GccBatchOut), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
         ctypes.c_void_p]),
+    "gcc_gin_forward": (ctypes.c_int32, [ctypes.POINTER(GccGinPass), ctypes.c_int32, ctypes.c_void_p,
+                                         ctypes.c_void_p]),
 }
+# symbols declared in the header but not built yet are listed here while the build is in progress
+PENDING = {"gcc_gin_backward_workspace_bytes", "gcc_gin_backward"}
 
 
 def declare(lib: ctypes.CDLL) -> ctypes.CDLL:

@@ -1,0 +1,475 @@
+// gcc_amd/csrc/encoder.hip -- GIN encoder forward (gfx950).
+//
+// Replaces GraphEncoder.forward (gcc/models/graph_encoder.py:132-200) ->
+// UnsupervisedGIN.forward (gcc/models/gin.py:213-232) and the DGL/torch kernels
+// behind it (GINConv copy_u/sum SpMM, nn.Linear GEMMs, BatchNorm1d, SumPooling,
+// linears_prediction, Dropout, F.normalize).
+//
+// The batches are small (N ~ 25k nodes, nnz ~ 1e5 at bsz 256), so a pass is
+// launch/latency bound, not FLOP bound.  Design:
+//   * BatchNorm in training mode needs statistics over all N nodes: every BN is
+//     a kernel boundary.  Statistics are column sums accumulated with fp64
+//     atomics (one per channel per workgroup); consumers turn them into
+//     scale/shift on the fly, so normalised activations are never materialised:
+//     only the Linear outputs z1, z2 (and agg for backward) are stored.
+//   * per GIN layer:  in  : gather (h + sum_{u->v} h_u, h = relu(bn_c(relu(bn_b(z2')))))
+//                           -> MFMA X W0^T + b0 -> z1, stats_a, SumPooling(h)
+//                     mid : relu(bn_a(z1)) -> MFMA X W1^T + b1 -> z2, stats_b
+//                     stat: relu(bn_b(z2)) -> stats_c
+//   * GEMMs use the exact-f32 MFMA (v_mfma_f32_16x16x4_f32) with swapped
+//     operands so that each lane ends up with 4 consecutive output channels of
+//     one node (16-byte stores), and with a K permutation so that A/B fragments
+//     are plain 16-byte row loads.
+//   * node tiles (64 rows per workgroup, grid-strided because N lives on the
+//     device); rows longer than kLongRow neighbours are gathered cooperatively
+//     by the whole workgroup so that hub rows do not serialise one wave.
+//   * several passes (query with model, key with model_ema) share each launch
+//     (blockIdx.y = pass).
+#include "encoder_common.h"
+
+namespace {
+
+// =========================================================================
+// F0: assemble input features (graph_encoder.py:158-165) + SumPooling of hidden_rep[0]
+struct FeatArgs {
+    const int32_t *node_off, *row_ptr, *graph_id;
+    const float *pos, *emb;
+    float *x0;
+    double *pooled0;
+    int32_t B, pos_dim, emb_dim, max_degree;
+};
+struct FeatLaunch { FeatArgs p[kMaxPass]; };
+
+__global__ __launch_bounds__(kThreads) void gin_feat_kernel(FeatLaunch L)
+{
+    __shared__ float T[kTile * kLdt];
+    const FeatArgs &a = L.p[blockIdx.y];
+    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
+    const int N = a.node_off[a.B];
+    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+        const int nrows = min(kTile, N - tile0);
+        for (int r = gi; r < kTile; r += 16) {
+            F4 x = {0.f, 0.f, 0.f, 0.f};
+            if (r < nrows) {
+                const int v = tile0 + r;
+                const int deg = a.row_ptr[v + 1] - a.row_ptr[v];          // g.in_degrees(), :154
+                const int dcl = deg < a.max_degree ? deg : a.max_degree;  // clamp(0, max_degree), :161
+                const bool is_seed = v == a.node_off[a.graph_id[v]];      // ndata["seed"], data_util.py:234-238
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * t + e;
+                    float val = 0.f;
+                    if (c < a.pos_dim) val = a.pos[(int64_t)v * a.pos_dim + c];
+                    else if (c < a.pos_dim + a.emb_dim) val = a.emb[(int64_t)dcl * a.emb_dim + (c - a.pos_dim)];
+                    else if (c == a.pos_dim + a.emb_dim) val = is_seed ? 1.f : 0.f;
+                    at(x, e) = val;
+                }
+                st4(a.x0 + (int64_t)v * H + 4 * t, x);
+            }
+            st4(&T[r * kLdt + 4 * t], x);
+        }
+        __syncthreads();
+        pool_tile(T, tile0, nrows, a.graph_id, a.pooled0);
+        __syncthreads();
+    }
+}
+
+// =========================================================================
+// F1: gather + Linear0
+struct InArgs {
+    const int32_t *node_off, *row_ptr, *col_idx, *graph_id;
+    const float *src;         // layer 0: x0; layer > 0: z2 of the previous layer
+    BnDev bnb, bnc;           // previous layer's apply_func.bn and gnn.batch_norms (layer > 0)
+    const float *w0, *b0;
+    float *agg;               // or NULL
+    float *z1;
+    double *stats_a;
+    double *pooled;           // SumPooling of this layer's input h (hidden_rep[layer]); NULL for layer 0 (done by F0)
+    int32_t B, first, kdim, training;
+    float eps;
+};
+struct InLaunch { InArgs p[kMaxPass]; };
+
+__global__ __launch_bounds__(kThreads) void gin_in_kernel(InLaunch L)
+{
+    __shared__ float T[kTile * kLdt];
+    __shared__ float part[16 * H];
+    __shared__ float red[4 * 2 * H];
+    __shared__ int longrows[kTile];
+    __shared__ int nlong;
+    const InArgs &a = L.p[blockIdx.y];
+    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
+    const int N = a.node_off[a.B];
+    const double dn = (double)N;
+    Aff4 ab, ac;
+    if (!a.first) {
+        ab = bn_aff4(a.bnb, 4 * t, dn, a.eps, a.training);
+        ac = bn_aff4(a.bnc, 4 * t, dn, a.eps, a.training);
+    }
+    auto feat = [&](int u) -> F4 {
+        F4 x = ld4(a.src + (int64_t)u * H + 4 * t);
+        if (!a.first) x = affine_relu(affine_relu(x, ab), ac);   // h = relu(bn_c(relu(bn_b(z2))))  gin.py:56-57,219-220
+        return x;
+    };
+    F4 wf[4][4];
+    load_w_frags(a.w0, a.kdim, wf);
+
+    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+        const int nrows = min(kTile, N - tile0);
+        if (tid == 0) nlong = 0;
+        // 1. own rows
+        for (int r = gi; r < kTile; r += 16) {
+            F4 x = {0.f, 0.f, 0.f, 0.f};
+            if (r < nrows) x = feat(tile0 + r);
+            st4(&T[r * kLdt + 4 * t], x);
+        }
+        __syncthreads();
+        // 2. SumPooling of hidden_rep[layer] (gin.py:228)
+        if (a.pooled) pool_tile(T, tile0, nrows, a.graph_id, a.pooled);
+        __syncthreads();
+        // 3. GINConv aggregate: (1 + eps) * h_v + sum_{u -> v} h_u, eps = 0 (gin.py:179-185,218)
+        for (int r = gi; r < nrows; r += 16) {
+            const int v = tile0 + r;
+            const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
+            if (end - beg > kLongRow) {
+                if (t == 0) longrows[atomicAdd(&nlong, 1)] = r;
+                continue;
+            }
+            F4 acc = ld4(&T[r * kLdt + 4 * t]);
+            int e = beg;
+            for (; e + 4 <= end; e += 4) {
+                const int u0 = a.col_idx[e], u1 = a.col_idx[e + 1], u2 = a.col_idx[e + 2], u3 = a.col_idx[e + 3];
+                const F4 f0 = feat(u0), f1 = feat(u1), f2 = feat(u2), f3 = feat(u3);
+                acc = add4(add4(acc, f0), add4(f1, add4(f2, f3)));
+            }
+            for (; e < end; ++e) acc = add4(acc, feat(a.col_idx[e]));
+            st4(&T[r * kLdt + 4 * t], acc);
+        }
+        __syncthreads();
+        const int nl = nlong;
+        for (int i = 0; i < nl; ++i) {          // hub rows: all 16 lane groups share one row
+            const int r = longrows[i], v = tile0 + r;
+            const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
+            F4 acc = {0.f, 0.f, 0.f, 0.f};
+            int e = beg + gi;
+            for (; e + 48 < end; e += 64) {
+                const int u0 = a.col_idx[e], u1 = a.col_idx[e + 16], u2 = a.col_idx[e + 32], u3 = a.col_idx[e + 48];
+                const F4 f0 = feat(u0), f1 = feat(u1), f2 = feat(u2), f3 = feat(u3);
+                acc = add4(add4(acc, f0), add4(f1, add4(f2, f3)));
+            }
+            for (; e < end; e += 16) acc = add4(acc, feat(a.col_idx[e]));
+            st4(&part[gi * H + 4 * t], acc);
+            __syncthreads();
+            if (tid < H) {
+                float s = T[r * kLdt + tid];
+                for (int k = 0; k < 16; ++k) s += part[k * H + tid];
+                T[r * kLdt + tid] = s;
+            }
+            __syncthreads();
+        }
+        // 4. keep agg for the weight gradient of linears.0
+        if (a.agg)
+            for (int r = gi; r < nrows; r += 16) st4(a.agg + (int64_t)(tile0 + r) * H + 4 * t, ld4(&T[r * kLdt + 4 * t]));
+        // 5. z1 = agg W0^T + b0 (gin.py:115: linears[0])
+        {
+            const int j = lane & 15, q = lane >> 4, rl = 16 * wv + j;
+            F4 xb[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xb[c] = ld4(&T[rl * kLdt + 16 * c + 4 * q]);
+            f32x4 acc[4];
+            mfma_rows16(xb, wf, acc);
+            epilogue_store_stats(acc, a.b0, a.z1, tile0 + rl, rl < nrows, &red[wv * 2 * H]);
+        }
+        __syncthreads();
+        flush_stats(red, a.stats_a);
+        __syncthreads();
+    }
+}
+
+// =========================================================================
+// F2: relu(bn_a(z1)) -> Linear1
+struct MidArgs {
+    const int32_t *node_off;
+    const float *z1;
+    BnDev bna;
+    const float *w1, *b1;
+    float *z2;
+    double *stats_b;
+    int32_t B, training;
+    float eps;
+};
+struct MidLaunch { MidArgs p[kMaxPass]; };
+
+__global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
+{
+    __shared__ float red[4 * 2 * H];
+    const MidArgs &a = L.p[blockIdx.y];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
+    const int N = a.node_off[a.B];
+    const double dn = (double)N;
+    Aff4 aa[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) aa[c] = bn_aff4(a.bna, 16 * c + 4 * q, dn, a.eps, a.training);
+    F4 wf[4][4];
+    load_w_frags(a.w1, H, wf);
+    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+        const int row = tile0 + 16 * wv + j;
+        const bool valid = row < N;
+        F4 xb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            F4 x = {0.f, 0.f, 0.f, 0.f};
+            if (valid) x = affine_relu(ld4(a.z1 + (int64_t)row * H + 16 * c + 4 * q), aa[c]);   // gin.py:115
+            xb[c] = x;
+        }
+        f32x4 acc[4];
+        mfma_rows16(xb, wf, acc);                                                              // gin.py:116
+        epilogue_store_stats(acc, a.b1, a.z2, row, valid, &red[wv * 2 * H]);
+        __syncthreads();
+        flush_stats(red, a.stats_b);
+        __syncthreads();
+    }
+}
+
+// =========================================================================
+// F3: statistics of y2 = relu(bn_b(z2)) for gnn.batch_norms[i] (gin.py:56-57,219)
+struct StatArgs {
+    const int32_t *node_off;
+    const float *z2;
+    BnDev bnb;
+    double *stats_c;
+    int32_t B, training;
+    float eps;
+};
+struct StatLaunch { StatArgs p[kMaxPass]; };
+
+__global__ __launch_bounds__(kThreads) void gin_stat_kernel(StatLaunch L)
+{
+    __shared__ float part[16 * 2 * H];
+    const StatArgs &a = L.p[blockIdx.y];
+    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
+    const int N = a.node_off[a.B];
+    const Aff4 ab = bn_aff4(a.bnb, 4 * t, (double)N, a.eps, a.training);
+    F4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+    bool any = false;
+    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+        any = true;
+        for (int r = tile0 + gi; r < min(tile0 + kTile, N); r += 16) {
+            const F4 y = affine_relu(ld4(a.z2 + (int64_t)r * H + 4 * t), ab);
+            s = add4(s, y);
+            ss.x = fmaf(y.x, y.x, ss.x); ss.y = fmaf(y.y, y.y, ss.y);
+            ss.z = fmaf(y.z, y.z, ss.z); ss.w = fmaf(y.w, y.w, ss.w);
+        }
+    }
+    if (!any) return;     // block-uniform
+    st4(&part[gi * 2 * H + 4 * t], s);
+    st4(&part[gi * 2 * H + H + 4 * t], ss);
+    __syncthreads();
+    if (tid < 2 * H) {
+        double v = 0.0;
+        for (int k = 0; k < 16; ++k) v += (double)part[k * 2 * H + tid];
+        atomicAdd(&a.stats_c[tid], v);
+    }
+}
+
+// =========================================================================
+// F4: SumPooling of the last hidden representation (gin.py:228, i = num_layers - 1)
+struct PoolArgs {
+    const int32_t *node_off, *graph_id;
+    const float *z2;
+    BnDev bnb, bnc;
+    double *pooled;
+    int32_t B, training;
+    float eps;
+};
+struct PoolLaunch { PoolArgs p[kMaxPass]; };
+
+__global__ __launch_bounds__(kThreads) void gin_pool_kernel(PoolLaunch L)
+{
+    __shared__ float T[kTile * kLdt];
+    const PoolArgs &a = L.p[blockIdx.y];
+    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
+    const int N = a.node_off[a.B];
+    const Aff4 ab = bn_aff4(a.bnb, 4 * t, (double)N, a.eps, a.training);
+    const Aff4 ac = bn_aff4(a.bnc, 4 * t, (double)N, a.eps, a.training);
+    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+        const int nrows = min(kTile, N - tile0);
+        for (int r = gi; r < nrows; r += 16)
+            st4(&T[r * kLdt + 4 * t], affine_relu(affine_relu(ld4(a.z2 + (int64_t)(tile0 + r) * H + 4 * t), ab), ac));
+        __syncthreads();
+        pool_tile(T, tile0, nrows, a.graph_id, a.pooled);
+        __syncthreads();
+    }
+}
+
+// =========================================================================
+// F5: readout (gin.py:223-232) + F.normalize (graph_encoder.py:195-196) + running statistics
+struct ReadArgs {
+    const int32_t *node_off;
+    const double *pooled;       // [L+1][B][64]
+    const float *pred_w[GCC_GIN_MAX_LAYERS + 1], *pred_b[GCC_GIN_MAX_LAYERS + 1];
+    const float *keep;          // [L+1][B][64] or NULL
+    float *score, *feat;
+    BnDev bn[3 * GCC_GIN_MAX_LAYERS];
+    int32_t B, nlayers, kdim0, normalize, update_running;
+    float inv_keep, norm_eps, momentum;
+};
+struct ReadLaunch { ReadArgs p[kMaxPass]; };
+
+__global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
+{
+    const ReadArgs &a = L.p[blockIdx.y];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const int b = (int)blockIdx.x * 4 + wv;
+    if (b < a.B) {
+        float s = 0.f;
+        for (int i = 0; i <= a.nlayers; ++i) {
+            const int kd = i == 0 ? a.kdim0 : H;
+            const double *pl = a.pooled + ((int64_t)i * a.B + b) * H;
+            const float *w = a.pred_w[i] + (int64_t)lane * kd;
+            float y = a.pred_b[i][lane];
+            for (int k = 0; k < kd; ++k) y = fmaf(w[k], (float)pl[k], y);          // linears_prediction[i](pooled_h)
+            if (a.keep) y = y * a.keep[((int64_t)i * a.B + b) * H + lane] * a.inv_keep;   // self.drop, gin.py:230
+            s += y;
+        }
+        a.score[(int64_t)b * H + lane] = s;
+        float o = s;
+        if (a.normalize) {
+            const float nrm = sqrtf(wave_sum(s * s));
+            o = s / fmaxf(nrm, a.norm_eps);                                         // F.normalize(p=2, eps=1e-5)
+        }
+        a.feat[(int64_t)b * H + lane] = o;
+    }
+    // BatchNorm running statistics (torch: momentum 0.1, unbiased variance) -- block 0 only
+    if (a.update_running && blockIdx.x == 0 && tid < H) {
+        const double n = (double)a.node_off[a.B];
+        for (int k = 0; k < 3 * a.nlayers; ++k) {
+            const BnDev &bn = a.bn[k];
+            const double mean = bn.stats[tid] / n;
+            double var = bn.stats[H + tid] / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+            bn.running_mean[tid] = (float)((1.0 - a.momentum) * (double)bn.running_mean[tid] + a.momentum * mean);
+            bn.running_var[tid] = (float)((1.0 - a.momentum) * (double)bn.running_var[tid] + a.momentum * unb);
+            if (tid == 0 && bn.nbt) bn.nbt[0] += 1;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gcc_prof *prof, void *stream)
+{
+    if (!passes || npass < 1 || npass > kMaxPass) {
+        snprintf(g_err, kErrLen, "gcc_gin_forward: npass must be 1..%d", kMaxPass);
+        return -1;
+    }
+    const int Lg = passes[0].w.num_gin_layers;
+    int maxB = 0;
+    for (int i = 0; i < npass; ++i) {
+        const gcc_gin_pass &p = passes[i];
+        const int din = p.w.pos_dim + p.w.deg_emb_dim + 1;
+        if (p.w.num_gin_layers != Lg || Lg < 1 || Lg > GCC_GIN_MAX_LAYERS || din > H || p.batch_size < 1) {
+            snprintf(g_err, kErrLen, "gcc_gin_forward: unsupported shape (layers=%d d_in=%d B=%d)",
+                     p.w.num_gin_layers, din, p.batch_size);
+            return -2;
+        }
+        maxB = p.batch_size > maxB ? p.batch_size : maxB;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    prof_mark(prof, 0, s);
+    for (int i = 0; i < npass; ++i) {
+        const gcc_gin_pass &p = passes[i];
+        (void)hipMemsetAsync(p.stats, 0, sizeof(double) * (size_t)Lg * 3 * 2 * H, s);
+        (void)hipMemsetAsync(p.pooled, 0, sizeof(double) * (size_t)(Lg + 1) * p.batch_size * H, s);
+    }
+    const dim3 grid(kGridX, npass), block(kThreads);
+    {
+        FeatLaunch L;
+        for (int i = 0; i < npass; ++i) {
+            const gcc_gin_pass &p = passes[i];
+            L.p[i] = {p.node_off, p.row_ptr, p.graph_id, p.pos, p.w.degree_embedding, p.x0, p.pooled,
+                      p.batch_size, p.w.pos_dim, p.w.deg_emb_dim, p.w.max_degree};
+        }
+        hipLaunchKernelGGL(gin_feat_kernel, grid, block, 0, s, L);
+    }
+    for (int l = 0; l < Lg; ++l) {
+        {
+            InLaunch L;
+            for (int i = 0; i < npass; ++i) {
+                const gcc_gin_pass &p = passes[i];
+                InArgs a;
+                a.node_off = p.node_off; a.row_ptr = p.row_ptr; a.col_idx = p.col_idx; a.graph_id = p.graph_id;
+                a.src = l == 0 ? p.x0 : p.z2[l - 1];
+                a.bnb = l == 0 ? BnDev() : bn_dev(p.w.bn_b[l - 1], stats_of(p, l - 1, 1));
+                a.bnc = l == 0 ? BnDev() : bn_dev(p.w.bn_c[l - 1], stats_of(p, l - 1, 2));
+                a.w0 = p.w.lin0_w[l]; a.b0 = p.w.lin0_b[l];
+                a.agg = p.agg[l]; a.z1 = p.z1[l];
+                a.stats_a = stats_of(p, l, 0);
+                a.pooled = l == 0 ? nullptr : p.pooled + (int64_t)l * p.batch_size * H;
+                a.B = p.batch_size; a.first = l == 0;
+                a.kdim = l == 0 ? p.w.pos_dim + p.w.deg_emb_dim + 1 : H;
+                a.training = p.training; a.eps = p.w.bn_eps;
+                L.p[i] = a;
+            }
+            hipLaunchKernelGGL(gin_in_kernel, grid, block, 0, s, L);
+        }
+        {
+            MidLaunch L;
+            for (int i = 0; i < npass; ++i) {
+                const gcc_gin_pass &p = passes[i];
+                L.p[i] = {p.node_off, p.z1[l], bn_dev(p.w.bn_a[l], stats_of(p, l, 0)), p.w.lin1_w[l], p.w.lin1_b[l],
+                          p.z2[l], stats_of(p, l, 1), p.batch_size, p.training, p.w.bn_eps};
+            }
+            hipLaunchKernelGGL(gin_mid_kernel, grid, block, 0, s, L);
+        }
+        {
+            StatLaunch L;
+            bool need = false;
+            for (int i = 0; i < npass; ++i) {
+                const gcc_gin_pass &p = passes[i];
+                L.p[i] = {p.node_off, p.z2[l], bn_dev(p.w.bn_b[l], stats_of(p, l, 1)), stats_of(p, l, 2),
+                          p.batch_size, p.training, p.w.bn_eps};
+                need = need || p.training;
+            }
+            if (need) hipLaunchKernelGGL(gin_stat_kernel, grid, block, 0, s, L);
+        }
+    }
+    {
+        PoolLaunch L;
+        for (int i = 0; i < npass; ++i) {
+            const gcc_gin_pass &p = passes[i];
+            L.p[i] = {p.node_off, p.graph_id, p.z2[Lg - 1], bn_dev(p.w.bn_b[Lg - 1], stats_of(p, Lg - 1, 1)),
+                      bn_dev(p.w.bn_c[Lg - 1], stats_of(p, Lg - 1, 2)), p.pooled + (int64_t)Lg * p.batch_size * H,
+                      p.batch_size, p.training, p.w.bn_eps};
+        }
+        hipLaunchKernelGGL(gin_pool_kernel, grid, block, 0, s, L);
+    }
+    {
+        ReadLaunch L;
+        for (int i = 0; i < npass; ++i) {
+            const gcc_gin_pass &p = passes[i];
+            ReadArgs a;
+            a.node_off = p.node_off; a.pooled = p.pooled;
+            for (int k = 0; k <= Lg; ++k) { a.pred_w[k] = p.w.pred_w[k]; a.pred_b[k] = p.w.pred_b[k]; }
+            a.keep = p.dropout_keep; a.score = p.score; a.feat = p.feat;
+            for (int l = 0; l < Lg; ++l) {
+                a.bn[3 * l + 0] = bn_dev(p.w.bn_a[l], stats_of(p, l, 0));
+                a.bn[3 * l + 1] = bn_dev(p.w.bn_b[l], stats_of(p, l, 1));
+                a.bn[3 * l + 2] = bn_dev(p.w.bn_c[l], stats_of(p, l, 2));
+            }
+            a.B = p.batch_size; a.nlayers = Lg; a.kdim0 = p.w.pos_dim + p.w.deg_emb_dim + 1;
+            a.normalize = p.normalize; a.update_running = p.training && p.update_running_stats;
+            a.inv_keep = 1.0f / (1.0f - p.w.dropout_p); a.norm_eps = p.w.norm_eps; a.momentum = p.w.bn_momentum;
+            L.p[i] = a;
+        }
+        hipLaunchKernelGGL(gin_readout_kernel, dim3((maxB + 3) / 4, npass), block, 0, s, L);
+    }
+    prof_mark(prof, 1, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, kErrLen, "gcc_gin_forward: launch failed: %s", hipGetErrorString(e));
+        return -10;
+    }
+    return 0;
+}

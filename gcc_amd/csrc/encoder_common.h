@@ -1,0 +1,213 @@
+// gcc_amd/csrc/encoder_common.h -- device helpers shared by the GIN encoder's
+// forward (encoder.hip) and backward (encoder_bwd.hip) kernels.
+#pragma once
+#include "host_common.h"
+
+namespace {
+
+constexpr int H = GCC_GIN_HIDDEN;   // 64
+constexpr int kTile = 64;           // rows per workgroup tile
+constexpr int kLdt = 72;            // LDS row stride in floats (conflict-free ds_read_b128 fragments)
+constexpr int kThreads = 256;
+constexpr int kGridX = 768;         // tiles are grid-strided
+constexpr int kLongRow = 48;
+constexpr int kMaxPass = 2;
+
+struct F4 { float x, y, z, w; };
+
+__device__ __forceinline__ F4 ld4(const float *p)
+{
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    F4 r = {v.x, v.y, v.z, v.w};
+    return r;
+}
+__device__ __forceinline__ void st4(float *p, F4 v)
+{
+    *reinterpret_cast<float4 *>(p) = make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ F4 add4(F4 a, F4 b) { F4 r = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; return r; }
+__device__ __forceinline__ float &at(F4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+// y = max(x * scale + shift, 0)
+struct Aff4 { F4 scale, shift; };
+__device__ __forceinline__ F4 affine_relu(F4 x, const Aff4 &a)
+{
+    F4 r;
+    r.x = fmaxf(fmaf(x.x, a.scale.x, a.shift.x), 0.f);
+    r.y = fmaxf(fmaf(x.y, a.scale.y, a.shift.y), 0.f);
+    r.z = fmaxf(fmaf(x.z, a.scale.z, a.shift.z), 0.f);
+    r.w = fmaxf(fmaf(x.w, a.scale.w, a.shift.w), 0.f);
+    return r;
+}
+
+struct BnDev {
+    const float *weight, *bias;
+    float *running_mean, *running_var;
+    int64_t *nbt;
+    const double *stats;    // [2][64] column sum / sum of squares of this BN's input (training mode)
+};
+
+// BatchNorm1d as y = x * scale + shift for channel c.  training: biased batch variance
+// (gin.py:56,115,219 -> torch.nn.functional.batch_norm); eval: running statistics.
+__device__ __forceinline__ void bn_scale_shift(const BnDev &bn, int c, double n, float eps, int training,
+                                               float &scale, float &shift)
+{
+    double mean, var;
+    if (training) {
+        mean = bn.stats[c] / n;
+        var = bn.stats[H + c] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+    } else {
+        mean = (double)bn.running_mean[c];
+        var = (double)bn.running_var[c];
+    }
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    scale = (float)((double)bn.weight[c] * rstd);
+    shift = (float)((double)bn.bias[c] - mean * (double)bn.weight[c] * rstd);
+}
+
+__device__ __forceinline__ Aff4 bn_aff4(const BnDev &bn, int c0, double n, float eps, int training)
+{
+    Aff4 a;
+    bn_scale_shift(bn, c0 + 0, n, eps, training, a.scale.x, a.shift.x);
+    bn_scale_shift(bn, c0 + 1, n, eps, training, a.scale.y, a.shift.y);
+    bn_scale_shift(bn, c0 + 2, n, eps, training, a.scale.z, a.shift.z);
+    bn_scale_shift(bn, c0 + 3, n, eps, training, a.scale.w, a.shift.w);
+    return a;
+}
+
+// ---- SumPooling of an LDS tile (rows tile0 .. tile0+nrows of the batched graph) into
+// pooled[graph][64] (fp64 atomics; one flush per run of equal graph ids per thread)
+__device__ __forceinline__ void pool_tile(const float *T, int tile0, int nrows, const int32_t *graph_id,
+                                          double *pooled)
+{
+    const int c = (int)threadIdx.x & 63, part = (int)threadIdx.x >> 6;
+    double acc = 0.0;
+    int cur = -1;
+    for (int r = part * 16; r < part * 16 + 16 && r < nrows; ++r) {
+        const int g = graph_id[tile0 + r];
+        if (g != cur) {
+            if (cur >= 0) atomicAdd(&pooled[(int64_t)cur * H + c], acc);
+            cur = g;
+            acc = 0.0;
+        }
+        acc += (double)T[r * kLdt + c];
+    }
+    if (cur >= 0) atomicAdd(&pooled[(int64_t)cur * H + c], acc);
+}
+
+// ---- one wave: Z[16 rows][64] = X[16 rows][64] * W^T, X fragments xb[c] = X[row j][16c+4q .. +3]
+// (j = lane & 15, q = lane >> 4), wf[cb][c] = W[16cb + j][16c+4q .. +3].
+// Result acc[cb][r] = Z[row j][16cb + 4q + r].
+__device__ __forceinline__ void mfma_rows16(const F4 xb[4], const F4 wf[4][4], f32x4 acc[4])
+{
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            a = mfma_16x16x4_f32(wf[cb][c].x, xb[c].x, a);
+            a = mfma_16x16x4_f32(wf[cb][c].y, xb[c].y, a);
+            a = mfma_16x16x4_f32(wf[cb][c].z, xb[c].z, a);
+            a = mfma_16x16x4_f32(wf[cb][c].w, xb[c].w, a);
+        }
+        acc[cb] = a;
+    }
+}
+
+// W [64][kdim] row-major (nn.Linear.weight) -> this lane's fragments; columns >= kdim read as 0
+__device__ __forceinline__ void load_w_frags(const float *W, int kdim, F4 wf[4][4])
+{
+    const int lane = lane_id(), j = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = 16 * cb + j, k0 = 16 * c + 4 * q;
+            const float *p = W + (int64_t)row * kdim + k0;
+            if ((kdim & 3) == 0 && k0 + 3 < kdim) {
+                wf[cb][c] = ld4(p);
+            } else {
+                wf[cb][c].x = k0 + 0 < kdim ? p[0] : 0.f;
+                wf[cb][c].y = k0 + 1 < kdim ? p[1] : 0.f;
+                wf[cb][c].z = k0 + 2 < kdim ? p[2] : 0.f;
+                wf[cb][c].w = k0 + 3 < kdim ? p[3] : 0.f;
+            }
+        }
+}
+
+// transposed fragments for dX = dZ * W (backward): wt[cb][c] = W[16c+4q .. +3][16cb + j] i.e. the
+// "weight" seen by the MFMA is W^T [kdim out][64 in]; rows >= kdim read as 0.
+__device__ __forceinline__ void load_wt_frags(const float *W, int kdim, F4 wf[4][4])
+{
+    const int lane = lane_id(), j = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int orow = 16 * cb + j;          // output index = input column of W
+            const int k0 = 16 * c + 4 * q;         // reduction index = output row of W
+            wf[cb][c].x = orow < kdim ? W[(int64_t)(k0 + 0) * kdim + orow] : 0.f;
+            wf[cb][c].y = orow < kdim ? W[(int64_t)(k0 + 1) * kdim + orow] : 0.f;
+            wf[cb][c].z = orow < kdim ? W[(int64_t)(k0 + 2) * kdim + orow] : 0.f;
+            wf[cb][c].w = orow < kdim ? W[(int64_t)(k0 + 3) * kdim + orow] : 0.f;
+        }
+}
+
+// bias add, masked store of the 16x64 block and per-channel sum / sum of squares of the
+// valid rows into red[wave][2][64]
+__device__ __forceinline__ void epilogue_store_stats(f32x4 acc[4], const float *bias, float *Z, int row,
+                                                     bool valid, float *red /* [128] of this wave */)
+{
+    const int lane = lane_id(), q = lane >> 4;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int ch = 16 * cb + 4 * q;
+        F4 z;
+        z.x = acc[cb][0] + (bias ? bias[ch + 0] : 0.f);
+        z.y = acc[cb][1] + (bias ? bias[ch + 1] : 0.f);
+        z.z = acc[cb][2] + (bias ? bias[ch + 2] : 0.f);
+        z.w = acc[cb][3] + (bias ? bias[ch + 3] : 0.f);
+        if (valid) st4(Z + (int64_t)row * H + ch, z);
+        if (red) {
+            float s[4] = {valid ? z.x : 0.f, valid ? z.y : 0.f, valid ? z.z : 0.f, valid ? z.w : 0.f};
+            float ss[4] = {s[0] * s[0], s[1] * s[1], s[2] * s[2], s[3] * s[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    s[e] += wave_shfl_xor(s[e], d);
+                    ss[e] += wave_shfl_xor(ss[e], d);
+                }
+            }
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { red[ch + e] = s[e]; red[H + ch + e] = ss[e]; }
+            }
+        }
+    }
+}
+
+// red[4 waves][128] -> fp64 atomics into stats[2][64]
+__device__ __forceinline__ void flush_stats(const float *red, double *stats)
+{
+    const int tid = (int)threadIdx.x;
+    if (tid < 2 * H) {
+        const double v = (double)red[tid] + (double)red[128 + tid] + (double)red[256 + tid] + (double)red[384 + tid];
+        atomicAdd(&stats[tid], v);
+    }
+}
+
+
+inline BnDev bn_dev(const gcc_bn &b, const double *stats)
+{
+    BnDev d = {b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked, stats};
+    return d;
+}
+
+inline double *stats_of(const gcc_gin_pass &p, int layer, int which)   // [layer][bn a|b|c][2][64]
+{
+    return p.stats + ((int64_t)layer * 3 + which) * 2 * H;
+}
+
+}  // namespace

@@ -1,0 +1,218 @@
+"""GraphEncoder -- drop-in for /root/reference/gcc/models/graph_encoder.py:19-200
+on the ``gnn_model="gin"`` path (the only one train.py's defaults and the
+README commands select), computed by the HIP kernels of gcc_amd/csrc/encoder*.hip.
+
+Same constructor signature, same ``forward(g, return_all_outputs=False)``, same
+``state_dict()`` keys and shapes so reference checkpoints load.
+``g`` is a :class:`gcc_amd.sampler.BatchedCSR` with ``pos_undirected`` attached.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _cabi
+
+H = _cabi.GIN_HIDDEN
+
+
+# ---------------------------------------------------------------------------
+# parameter containers with the reference's module tree (names = state_dict keys)
+class _MLP(nn.Module):                       # gin.py:61-105 (num_mlp_layers == 2)
+    def __init__(self, d_in, d_hid, d_out):
+        super().__init__()
+        self.linears = nn.ModuleList([nn.Linear(d_in, d_hid), nn.Linear(d_hid, d_out)])
+        self.batch_norms = nn.ModuleList([nn.BatchNorm1d(d_hid)])
+
+
+class _ApplyNodeFunc(nn.Module):             # gin.py:42-52
+    def __init__(self, mlp, d):
+        super().__init__()
+        self.mlp = mlp
+        self.bn = nn.BatchNorm1d(d)
+
+
+class _GINConv(nn.Module):                   # DGL GINConv(apply_func, "sum", 0, learn_eps=False)
+    def __init__(self, apply_func):
+        super().__init__()
+        self.apply_func = apply_func
+        self.register_buffer("eps", torch.FloatTensor([0]))
+
+
+class _UnsupervisedGIN(nn.Module):           # gin.py:119-211
+    def __init__(self, num_layers, input_dim, hidden_dim, output_dim, final_dropout):
+        super().__init__()
+        self.num_layers = num_layers
+        self.ginlayers = nn.ModuleList()
+        self.batch_norms = nn.ModuleList()
+        for layer in range(num_layers - 1):
+            mlp = _MLP(input_dim if layer == 0 else hidden_dim, hidden_dim, hidden_dim)
+            self.ginlayers.append(_GINConv(_ApplyNodeFunc(mlp, hidden_dim)))
+            self.batch_norms.append(nn.BatchNorm1d(hidden_dim))
+        self.linears_prediction = nn.ModuleList(
+            [nn.Linear(input_dim if layer == 0 else hidden_dim, output_dim) for layer in range(num_layers)])
+        self.drop = nn.Dropout(final_dropout)
+
+
+class _Set2Set(nn.Module):                   # allocated by the reference, never used on the GIN path
+    def __init__(self, d, n_layers):
+        super().__init__()
+        self.lstm = nn.LSTM(2 * d, d, n_layers)
+
+
+# ---------------------------------------------------------------------------
+def fill_weights(enc: "GraphEncoder", ptr) -> _cabi.GccGinWeights:
+    """state tensors -> gcc_gin_weights.  ``ptr`` maps a tensor to its address
+    (the product passes :func:`_cabi.dev_ptr`, which refuses CPU tensors)."""
+    w = _cabi.GccGinWeights()
+    g = enc.gnn
+    L = len(g.ginlayers)
+    w.num_gin_layers = L
+    w.pos_dim = enc.positional_embedding_size
+    w.deg_emb_dim = enc.degree_embedding_size
+    w.max_degree = enc.max_degree
+    w.degree_embedding = ptr(enc.degree_embedding.weight)
+
+    def bn(dst, m):
+        dst.weight, dst.bias = ptr(m.weight), ptr(m.bias)
+        dst.running_mean, dst.running_var = ptr(m.running_mean), ptr(m.running_var)
+        dst.num_batches_tracked = ptr(m.num_batches_tracked)
+
+    for i, layer in enumerate(g.ginlayers):
+        mlp = layer.apply_func.mlp
+        w.lin0_w[i], w.lin0_b[i] = ptr(mlp.linears[0].weight), ptr(mlp.linears[0].bias)
+        w.lin1_w[i], w.lin1_b[i] = ptr(mlp.linears[1].weight), ptr(mlp.linears[1].bias)
+        bn(w.bn_a[i], mlp.batch_norms[0])
+        bn(w.bn_b[i], layer.apply_func.bn)
+        bn(w.bn_c[i], g.batch_norms[i])
+    for i, lin in enumerate(g.linears_prediction):
+        w.pred_w[i], w.pred_b[i] = ptr(lin.weight), ptr(lin.bias)
+    bn0 = g.batch_norms[0]
+    w.bn_eps, w.bn_momentum = bn0.eps, bn0.momentum
+    w.dropout_p = g.drop.p
+    w.norm_eps = 1e-5                                   # graph_encoder.py:196
+    return w
+
+
+def grad_params(enc: "GraphEncoder"):
+    """Parameters that receive gradients, in gcc_gin_grads field order."""
+    g = enc.gnn
+    out = [("degree_embedding", None, enc.degree_embedding.weight)]
+    for i, layer in enumerate(g.ginlayers):
+        mlp = layer.apply_func.mlp
+        out += [("lin0_w", i, mlp.linears[0].weight), ("lin0_b", i, mlp.linears[0].bias),
+                ("lin1_w", i, mlp.linears[1].weight), ("lin1_b", i, mlp.linears[1].bias),
+                ("bn_a_w", i, mlp.batch_norms[0].weight), ("bn_a_b", i, mlp.batch_norms[0].bias),
+                ("bn_b_w", i, layer.apply_func.bn.weight), ("bn_b_b", i, layer.apply_func.bn.bias),
+                ("bn_c_w", i, g.batch_norms[i].weight), ("bn_c_b", i, g.batch_norms[i].bias)]
+    for i, lin in enumerate(g.linears_prediction):
+        out += [("pred_w", i, lin.weight), ("pred_b", i, lin.bias)]
+    return out
+
+
+class GinEngine:
+    """Buffers + C-ABI calls for encoder passes.  ``lib``/``ptr`` are injectable
+    only so that tests can run the same host code against the emulator build;
+    :class:`GraphEncoder` always uses the HIP library and device pointers."""
+
+    def __init__(self, lib=None, ptr=None):
+        self.lib = lib if lib is not None else _cabi.load()
+        self.ptr = ptr if ptr is not None else _cabi.dev_ptr
+        self._bufs = {}
+
+    def _buffers(self, key, node_cap, B, L, device):
+        k = (key, node_cap, B, L, str(device))
+        if k not in self._bufs:
+            f32 = dict(dtype=torch.float32, device=device)
+            self._bufs[k] = dict(
+                x0=torch.zeros(node_cap, H, **f32),
+                agg=[torch.zeros(node_cap, H, **f32) for _ in range(L)],
+                z1=[torch.zeros(node_cap, H, **f32) for _ in range(L)],
+                z2=[torch.zeros(node_cap, H, **f32) for _ in range(L)],
+                stats=torch.zeros(L, 3, 2, H, dtype=torch.float64, device=device),
+                pooled=torch.zeros(L + 1, B, H, dtype=torch.float64, device=device),
+                score=torch.zeros(B, H, **f32), feat=torch.zeros(B, H, **f32))
+        return self._bufs[k]
+
+    def make_pass(self, enc, g, training, keep=None, slot=0):
+        """-> (GccGinPass, buffers).  ``g`` needs node_off,row_ptr,col_idx,graph_id,pos_undirected,batch_size."""
+        ptr = self.ptr
+        L = len(enc.gnn.ginlayers)
+        node_cap = g.parent_nid.numel() if hasattr(g, "parent_nid") else g.graph_id.numel()
+        buf = self._buffers(slot, node_cap, g.batch_size, L, g.node_off.device)
+        p = _cabi.GccGinPass()
+        p.node_off, p.row_ptr, p.col_idx, p.graph_id = ptr(g.node_off), ptr(g.row_ptr), ptr(g.col_idx), ptr(g.graph_id)
+        if g.pos_undirected is None:
+            raise RuntimeError("the batch has no pos_undirected (run the positional embedding first)")
+        p.pos = ptr(g.pos_undirected)
+        p.batch_size = g.batch_size
+        p.training = int(training)
+        p.update_running_stats = int(training)
+        p.normalize = int(enc.norm)
+        p.dropout_keep = ptr(keep) if keep is not None else None
+        p.w = fill_weights(enc, ptr)
+        p.x0 = ptr(buf["x0"])
+        for i in range(L):
+            p.agg[i], p.z1[i], p.z2[i] = ptr(buf["agg"][i]), ptr(buf["z1"][i]), ptr(buf["z2"][i])
+        p.stats, p.pooled, p.score, p.feat = ptr(buf["stats"]), ptr(buf["pooled"]), ptr(buf["score"]), ptr(buf["feat"])
+        buf = dict(buf)
+        buf["_keepalive"] = (g, keep, enc)      # the struct holds raw pointers into these
+        return p, buf
+
+    def forward(self, passes, stream=None, prof=None):
+        arr = (_cabi.GccGinPass * len(passes))(*passes)
+        rc = self.lib.gcc_gin_forward(arr, len(passes), prof.handle if prof is not None else None, stream)
+        if rc != 0:
+            raise RuntimeError(f"gcc_gin_forward failed ({rc}): {self.lib.gcc_last_error().decode()}")
+
+
+class GraphEncoder(nn.Module):
+    """graph_encoder.py:44-63 signature; only gnn_model="gin" with degree_input=True
+    (train.py:601-618) is implemented -- the other backbones are out of scope."""
+
+    def __init__(self, positional_embedding_size=32, max_node_freq=8, max_edge_freq=8, max_degree=128,
+                 freq_embedding_size=32, degree_embedding_size=32, output_dim=32, node_hidden_dim=32,
+                 edge_hidden_dim=32, num_layers=6, num_heads=4, num_step_set2set=6, num_layer_set2set=3,
+                 norm=False, gnn_model="mpnn", degree_input=False, lstm_as_gate=False):
+        super().__init__()
+        if gnn_model != "gin":
+            raise NotImplementedError("gcc_amd accelerates the GIN path only (train.py:77 default)")
+        if not degree_input:
+            raise NotImplementedError("train.py:617 always passes degree_input=True")
+        if node_hidden_dim != H or output_dim != H:
+            raise NotImplementedError(f"hidden/output size is fixed at {H} (train.py:93 default)")
+        node_input_dim = positional_embedding_size + degree_embedding_size + 1      # graph_encoder.py:66-67
+        if node_input_dim > H:
+            raise NotImplementedError("positional + degree embedding + 1 must be <= 64")
+        if num_layers - 1 > _cabi.GIN_MAX_LAYERS:
+            raise NotImplementedError("too many GIN layers")
+        self.gnn = _UnsupervisedGIN(num_layers, node_input_dim, node_hidden_dim, output_dim, final_dropout=0.5)
+        self.gnn_model = gnn_model
+        self.max_node_freq, self.max_edge_freq = max_node_freq, max_edge_freq
+        self.max_degree = max_degree
+        self.degree_input = degree_input
+        self.positional_embedding_size = positional_embedding_size
+        self.degree_embedding_size = degree_embedding_size
+        self.degree_embedding = nn.Embedding(max_degree + 1, degree_embedding_size)   # :116-118
+        self.set2set = _Set2Set(node_hidden_dim, num_layer_set2set)                   # :124 (unused by GIN)
+        self.lin_readout = nn.Sequential(nn.Linear(2 * node_hidden_dim, node_hidden_dim), nn.ReLU(),
+                                         nn.Linear(node_hidden_dim, output_dim))     # :125-129 (unused by GIN)
+        self.norm = norm
+        self._engine = None
+        self._slot = id(self)
+
+    def engine(self) -> GinEngine:
+        if self._engine is None:
+            self._engine = GinEngine()
+        return self._engine
+
+    def bn_training(self) -> bool:
+        """train.py:357-365: model_ema is in eval() but its BatchNorm layers are switched back to train()."""
+        return self.gnn.batch_norms[0].training
+
+    def forward(self, g, return_all_outputs=False):
+        from .autograd import gin_apply
+
+        return gin_apply(self, g, return_all_outputs)

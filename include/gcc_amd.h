@@ -108,6 +108,84 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p,
                          void *workspace, int64_t workspace_bytes, int64_t scratch_entries,
                          int32_t *status, void *stream);
 
+/* ------------------------------------------------------------ GIN encoder ---
+ * GraphEncoder(gnn_model="gin", degree_input=True).forward of
+ * gcc/models/graph_encoder.py:132-200 -> UnsupervisedGIN.forward gcc/models/gin.py:213-232
+ * (DGL GINConv(sum, eps=0) + ApplyNodeFunc/MLP + BatchNorm1d + SumPooling +
+ * linears_prediction + Dropout + F.normalize), and its backward.  hidden is
+ * fixed at 64 (train.py:93 default); d_in = pos_dim + deg_emb_dim + 1 <= 64.
+ * All arithmetic is fp32 (f32 MFMA), BatchNorm / pooling sums accumulate in fp64. */
+#define GCC_GIN_MAX_LAYERS 8     /* GIN message-passing layers = num_layers - 1 (train.py:79 -> 4) */
+#define GCC_GIN_HIDDEN 64
+
+typedef struct gcc_bn {          /* torch.nn.BatchNorm1d(64) */
+    const float *weight, *bias;  /* device [64]                                           */
+    float *running_mean, *running_var;   /* device [64], updated when update_running_stats */
+    int64_t *num_batches_tracked;        /* device [1] or NULL                            */
+} gcc_bn;
+
+typedef struct gcc_gin_weights { /* state_dict of the reference GraphEncoder */
+    int32_t num_gin_layers;      /* len(gnn.ginlayers)                                    */
+    int32_t pos_dim, deg_emb_dim, max_degree;
+    const float *degree_embedding;               /* [max_degree + 1, deg_emb_dim]          */
+    const float *lin0_w[GCC_GIN_MAX_LAYERS];     /* ginlayers.i.apply_func.mlp.linears.0.weight [64, d_in|64] */
+    const float *lin0_b[GCC_GIN_MAX_LAYERS];
+    const float *lin1_w[GCC_GIN_MAX_LAYERS];     /* ...mlp.linears.1.weight [64, 64]       */
+    const float *lin1_b[GCC_GIN_MAX_LAYERS];
+    gcc_bn bn_a[GCC_GIN_MAX_LAYERS];             /* ...mlp.batch_norms.0                   */
+    gcc_bn bn_b[GCC_GIN_MAX_LAYERS];             /* ginlayers.i.apply_func.bn              */
+    gcc_bn bn_c[GCC_GIN_MAX_LAYERS];             /* gnn.batch_norms.i                      */
+    const float *pred_w[GCC_GIN_MAX_LAYERS + 1]; /* gnn.linears_prediction.i.weight [64, d_in|64] */
+    const float *pred_b[GCC_GIN_MAX_LAYERS + 1];
+    float bn_eps, bn_momentum;   /* 1e-5, 0.1 (torch defaults, gin.py:51,104,189)          */
+    float dropout_p;             /* 0.5 (graph_encoder.py:99)                              */
+    float norm_eps;              /* 1e-5 (graph_encoder.py:196)                            */
+} gcc_gin_weights;
+
+typedef struct gcc_gin_pass {    /* one encoder invocation on one batched graph            */
+    const int32_t *node_off, *row_ptr, *col_idx, *graph_id;   /* gcc_batch_out of the view */
+    const float *pos;            /* device [node_cap, pos_dim]: ndata["pos_undirected"]    */
+    int32_t batch_size;
+    int32_t training;            /* 1: BatchNorm uses batch statistics (train.py:357-365)  */
+    int32_t update_running_stats;/* 1: momentum update of running_mean/var                 */
+    int32_t normalize;           /* graph_encoder.py:195 (train.py:83 default True)        */
+    const float *dropout_keep;   /* device [num_gin_layers+1, B, 64] 0/1 keep masks, or NULL (no dropout) */
+    gcc_gin_weights w;
+    /* activations, caller-allocated, kept for backward: */
+    float *x0;                   /* [node_cap, 64] assembled input features (cols >= d_in are 0) */
+    float *agg[GCC_GIN_MAX_LAYERS];   /* [node_cap, 64] h + sum_{u->v} h_u                */
+    float *z1[GCC_GIN_MAX_LAYERS];    /* [node_cap, 64] linears.0 output                   */
+    float *z2[GCC_GIN_MAX_LAYERS];    /* [node_cap, 64] linears.1 output                   */
+    double *stats;               /* [num_gin_layers, 3, 2, 64] column sum / sum of squares */
+    double *pooled;              /* [num_gin_layers+1, B, 64] SumPooling of hidden_rep     */
+    float *score;                /* [B, 64] score_over_layer before normalisation          */
+    float *feat;                 /* [B, 64] output                                         */
+} gcc_gin_pass;
+
+/* Runs `npass` independent passes (e.g. query with model, key with model_ema)
+ * in the same launches.  prof marks: 0 before, 1 after. */
+int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gcc_prof *prof, void *stream);
+
+typedef struct gcc_gin_grads {   /* same shapes as the weights; written (not accumulated)  */
+    float *degree_embedding;
+    float *lin0_w[GCC_GIN_MAX_LAYERS], *lin0_b[GCC_GIN_MAX_LAYERS];
+    float *lin1_w[GCC_GIN_MAX_LAYERS], *lin1_b[GCC_GIN_MAX_LAYERS];
+    float *bn_a_w[GCC_GIN_MAX_LAYERS], *bn_a_b[GCC_GIN_MAX_LAYERS];
+    float *bn_b_w[GCC_GIN_MAX_LAYERS], *bn_b_b[GCC_GIN_MAX_LAYERS];
+    float *bn_c_w[GCC_GIN_MAX_LAYERS], *bn_c_b[GCC_GIN_MAX_LAYERS];
+    float *pred_w[GCC_GIN_MAX_LAYERS + 1], *pred_b[GCC_GIN_MAX_LAYERS + 1];
+} gcc_gin_grads;
+
+/* bytes of workspace gcc_gin_backward needs for a pass with this node capacity */
+int64_t gcc_gin_backward_workspace_bytes(int64_t node_cap, int32_t batch_size, int32_t num_gin_layers);
+
+/* Backward of one training-mode pass: dfeat [B, 64] -> grads (overwritten).
+ * If `accumulate` != 0 the results are added to `grads` instead (E2E mode runs
+ * two passes through the same weights, train.py:397-398). */
+int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat, const gcc_gin_grads *grads,
+                         int32_t accumulate, void *workspace, int64_t workspace_bytes, int64_t node_cap,
+                         gcc_prof *prof, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,9 @@
 // tests/hipemu/hipemu.cpp -- fiber scheduler behind hipemu.h (test infrastructure only).
 #include "hipemu.h"
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <vector>
 
 namespace hipemu {
@@ -115,8 +118,19 @@ const unsigned char *wave_gather(const void *in, size_t size, unsigned tag)
     return w.buf[par];
 }
 
+static void segv_handler(int sig)
+{
+    void *frames[48];
+    int n = backtrace(frames, 48);
+    fprintf(stderr, "hipemu: signal %d in block %u thread %u\n", sig, g_blockIdx.x, cur ? cur->tid.x : 0u);
+    backtrace_symbols_fd(frames, n, 2);
+    _exit(139);
+}
+
 void launch(Dim3 grid, Dim3 block, size_t smem, const std::function<void()> &body)
 {
+    static bool installed = false;
+    if (!installed && getenv("HIPEMU_BACKTRACE")) { signal(SIGSEGV, segv_handler); installed = true; }
     if (cur) die("nested launch");
     unsigned nthreads = block.x * block.y * block.z;
     if (nthreads == 0 || nthreads > 1024) die("bad block size");

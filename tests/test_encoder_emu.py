@@ -1,0 +1,89 @@
+"""Kernel-logic parity on CPU for the GIN encoder: gcc_amd/csrc/encoder*.hip on
+the wave64 emulator vs the reference-generated golden vectors and the oracle."""
+import os
+
+import pytest
+import torch
+
+from oracle import encoder as E
+from tests.hipemu.emu_encoder import CpuBatch, emu_engine, reference_encoder
+
+GOLD = torch.load(os.path.join(os.path.dirname(__file__), "golden", "encoder_golden.pt"), weights_only=False)
+TOL = dict(rtol=1e-4, atol=2e-5)     # north_star: 1e-3 rel; the f32 path is far inside it
+
+
+def _set_bn_train(model):
+    model.eval()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.train()
+
+
+def test_state_dict_is_a_drop_in():
+    enc = reference_encoder()
+    assert {k: tuple(v.shape) for k, v in enc.state_dict().items()} == GOLD["state_dict_shapes"]
+    assert [n for n, _ in enc.named_parameters()] == GOLD["param_names"]
+    enc.load_state_dict(GOLD["moco"]["init"]["model"], strict=True)
+
+
+def test_forward_q_and_k_match_reference_golden():
+    g = GOLD["moco"]
+    model, ema = reference_encoder(), reference_encoder()
+    model.load_state_dict(g["init"]["model"])
+    ema.load_state_dict(g["init"]["model_ema"])
+    model.train()
+    _set_bn_train(ema)
+    eng = emu_engine()
+    bq, bk = CpuBatch(GOLD["views"][0]), CpuBatch(GOLD["views"][1])
+    pq, bufq = eng.make_pass(model, bq, training=True, keep=g["masks"].contiguous(), slot=0)
+    pk, bufk = eng.make_pass(ema, bk, training=True, keep=None, slot=1)
+    eng.forward([pq, pk])
+    torch.testing.assert_close(bufq["feat"], g["feat_q"], **TOL)
+    torch.testing.assert_close(bufk["feat"], g["feat_k"], **TOL)
+    # SumPooling outputs (all_outputs of gin.py:232)
+    for i, ref in enumerate(g["all_outputs_q"]):
+        torch.testing.assert_close(bufq["pooled"][i + 1].float(), ref, rtol=1e-4, atol=1e-3)
+    # BatchNorm running statistics after one training forward
+    after = g["after"]["model"]
+    for k, v in model.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            torch.testing.assert_close(v, after[k], rtol=1e-4, atol=1e-5, msg=k)
+
+
+def test_eval_mode_matches_oracle():
+    g = GOLD["moco"]
+    model = reference_encoder()
+    model.load_state_dict(g["after"]["model"])
+    model.eval()
+    eng = emu_engine()
+    bq = CpuBatch(GOLD["views"][0])
+    pq, bufq = eng.make_pass(model, bq, training=False)
+    eng.forward([pq])
+    torch.testing.assert_close(bufq["feat"], g["feat_eval"], **TOL)
+
+
+def test_long_rows_and_ragged_tiles_match_oracle():
+    """a star-like batch: one hub row far above kLongRow, N not a multiple of the tile."""
+    import numpy as np
+
+    torch.manual_seed(3)
+    n0, n1 = 150, 7
+    edges = [(0, i) for i in range(1, n0)] + [(i, i + 1) for i in range(1, n0 - 1)]
+    edges += [(n0 + i, n0 + j) for i in range(n1) for j in range(i + 1, n1)]
+    import scipy.sparse as sp
+    e = np.array(edges)
+    a = sp.csr_matrix((np.ones(2 * len(e)), (np.r_[e[:, 0], e[:, 1]], np.r_[e[:, 1], e[:, 0]])), shape=(n0 + n1,) * 2)
+    a.sort_indices()
+    view = dict(node_off=torch.tensor([0, n0, n0 + n1]), row_ptr=torch.from_numpy(a.indptr.astype(np.int64)),
+                col_idx=torch.from_numpy(a.indices.astype(np.int64)), pos_undirected=torch.randn(n0 + n1, 32))
+    oracle = E.OracleGraphEncoder()
+    model = reference_encoder()
+    model.load_state_dict(oracle.state_dict())
+    oracle.train()
+    model.train()
+    keep = (torch.rand(5, 2, 64) > 0.5).float()
+    ref = oracle(view["node_off"], view["row_ptr"], view["col_idx"], view["pos_undirected"], dropout_masks=keep)
+    eng = emu_engine()
+    p, buf = eng.make_pass(model, CpuBatch(view), training=True, keep=keep)
+    eng.forward([p])
+    torch.testing.assert_close(buf["feat"], ref.detach(), **TOL)
