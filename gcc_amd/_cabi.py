@@ -122,9 +122,13 @@ SIGNATURES = {
         ctypes.c_void_p]),
     "gcc_gin_forward": (ctypes.c_int32, [ctypes.POINTER(GccGinPass), ctypes.c_int32, ctypes.c_void_p,
                                          ctypes.c_void_p]),
+    "gcc_gin_backward_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]),
+    "gcc_gin_backward": (ctypes.c_int32, [ctypes.POINTER(GccGinPass), ctypes.c_void_p, ctypes.POINTER(GccGinGrads),
+                                          ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.c_void_p, ctypes.c_void_p]),
 }
 # symbols declared in the header but not built yet are listed here while the build is in progress
-PENDING = {"gcc_gin_backward_workspace_bytes", "gcc_gin_backward"}
+PENDING = set()
 
 
 def declare(lib: ctypes.CDLL) -> ctypes.CDLL:

@@ -128,45 +128,7 @@ __global__ __launch_bounds__(kThreads) void gin_in_kernel(InLaunch L)
         if (a.pooled) pool_tile(T, tile0, nrows, a.graph_id, a.pooled);
         __syncthreads();
         // 3. GINConv aggregate: (1 + eps) * h_v + sum_{u -> v} h_u, eps = 0 (gin.py:179-185,218)
-        for (int r = gi; r < nrows; r += 16) {
-            const int v = tile0 + r;
-            const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
-            if (end - beg > kLongRow) {
-                if (t == 0) longrows[atomicAdd(&nlong, 1)] = r;
-                continue;
-            }
-            F4 acc = ld4(&T[r * kLdt + 4 * t]);
-            int e = beg;
-            for (; e + 4 <= end; e += 4) {
-                const int u0 = a.col_idx[e], u1 = a.col_idx[e + 1], u2 = a.col_idx[e + 2], u3 = a.col_idx[e + 3];
-                const F4 f0 = feat(u0), f1 = feat(u1), f2 = feat(u2), f3 = feat(u3);
-                acc = add4(add4(acc, f0), add4(f1, add4(f2, f3)));
-            }
-            for (; e < end; ++e) acc = add4(acc, feat(a.col_idx[e]));
-            st4(&T[r * kLdt + 4 * t], acc);
-        }
-        __syncthreads();
-        const int nl = nlong;
-        for (int i = 0; i < nl; ++i) {          // hub rows: all 16 lane groups share one row
-            const int r = longrows[i], v = tile0 + r;
-            const int beg = a.row_ptr[v], end = a.row_ptr[v + 1];
-            F4 acc = {0.f, 0.f, 0.f, 0.f};
-            int e = beg + gi;
-            for (; e + 48 < end; e += 64) {
-                const int u0 = a.col_idx[e], u1 = a.col_idx[e + 16], u2 = a.col_idx[e + 32], u3 = a.col_idx[e + 48];
-                const F4 f0 = feat(u0), f1 = feat(u1), f2 = feat(u2), f3 = feat(u3);
-                acc = add4(add4(acc, f0), add4(f1, add4(f2, f3)));
-            }
-            for (; e < end; e += 16) acc = add4(acc, feat(a.col_idx[e]));
-            st4(&part[gi * H + 4 * t], acc);
-            __syncthreads();
-            if (tid < H) {
-                float s = T[r * kLdt + tid];
-                for (int k = 0; k < 16; ++k) s += part[k * H + tid];
-                T[r * kLdt + tid] = s;
-            }
-            __syncthreads();
-        }
+        gather_tile(T, part, longrows, &nlong, tile0, nrows, a.row_ptr, a.col_idx, feat);
         // 4. keep agg for the weight gradient of linears.0
         if (a.agg)
             for (int r = gi; r < nrows; r += 16) st4(a.agg + (int64_t)(tile0 + r) * H + 4 * t, ld4(&T[r * kLdt + 4 * t]));

@@ -1,0 +1,662 @@
+// gcc_amd/csrc/encoder_bwd.hip -- GIN encoder backward (gfx950).
+//
+// Backward of encoder.hip's forward, i.e. of loss.backward() through
+// GraphEncoder (train.py:407-408; gin.py:213-232; graph_encoder.py:152-200).
+// Per GIN layer l (reverse order), with g = dL/dh' (h' = layer output):
+//   bwd_c   : g = dpooled_{l+1}[graph] + (I + A) dagg_{l+1}      (SumPooling + GINConv backward)
+//             u = g * [h' > 0];             sums S(u), S(u*yhat2)  -> d gamma_c, d beta_c
+//   bwd_b   : dy2 = BN_c'(u); v = dy2 * [y2 > 0]; S(v), S(v*zhat2) -> d gamma_b, d beta_b
+//   bwd_lin1: dz2 = BN_b'(v); da1 = dz2 W1 (MFMA); w = da1 * [a1 > 0]; S(w), S(w*zhat1); S(dz2) = db1
+//   bwd_lin0: dz1 = BN_a'(w); dagg = dz1 W0 (MFMA); S(dz1) = db0
+// BN'(g) = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) needs two column sums over all N nodes, so
+// (like the forward) every BatchNorm is a kernel boundary; the sums are fp64 atomics.
+// Normalised activations are recomputed from the stored Linear outputs z1/z2.
+// Weight gradients: one MFMA kernel over all 2L (dZ, X) pairs writes per-chunk 64x64 slabs that
+// a final kernel reduces in a fixed order (deterministic), together with the prediction-layer,
+// BatchNorm, bias and degree-embedding gradients.
+#include "encoder_common.h"
+
+namespace {
+
+constexpr int kWgChunks = 32;     // row chunks (slabs) per weight gradient
+
+// per-column training-mode BatchNorm constants
+struct BnCol { float mean, rstd, gamma, beta; };
+__device__ __forceinline__ BnCol bn_col(const BnDev &bn, int c, double n, float eps)
+{
+    const double mean = bn.stats[c] / n;
+    double var = bn.stats[H + c] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    BnCol r;
+    r.mean = (float)mean;
+    r.rstd = (float)(1.0 / sqrt(var + (double)eps));
+    r.gamma = bn.weight[c];
+    r.beta = bn.bias[c];
+    return r;
+}
+
+// LDS coefficient table rows (each [64] floats)
+//   xhat = x * RS + RM            (RS = rstd, RM = -mean * rstd)
+//   pre  = x * PS + PH            (gamma * xhat + beta)
+//   dx   = g * K1 + x * K2 + K3   (BatchNorm backward as an affine map of (g, x))
+enum { RS = 0, RM = 1, PS = 2, PH = 3, K1 = 4, K2 = 5, K3 = 6, kCoefRows = 7 };
+
+__device__ __forceinline__ void fill_coefs(float *C /* [7][64] */, const BnDev &bn, const double *bst, double n,
+                                           float eps)
+{
+    const int c = (int)threadIdx.x;
+    if (c < H) {
+        const BnCol b = bn_col(bn, c, n, eps);
+        C[RS * H + c] = b.rstd;
+        C[RM * H + c] = -b.mean * b.rstd;
+        C[PS * H + c] = b.gamma * b.rstd;
+        C[PH * H + c] = b.beta - b.gamma * b.rstd * b.mean;
+        if (bst) {
+            const float m1 = (float)(bst[c] / n), m2 = (float)(bst[H + c] / n);
+            const float k1 = b.gamma * b.rstd;
+            C[K1 * H + c] = k1;
+            C[K2 * H + c] = -k1 * m2 * b.rstd;
+            C[K3 * H + c] = k1 * (m2 * b.mean * b.rstd - m1);
+        }
+    }
+}
+
+__device__ __forceinline__ F4 fma4(F4 a, F4 b, F4 c)
+{
+    F4 r = {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
+    return r;
+}
+__device__ __forceinline__ F4 relu4(F4 a) { F4 r = {fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)}; return r; }
+__device__ __forceinline__ F4 mask4(F4 g, F4 pre)
+{
+    F4 r = {pre.x > 0.f ? g.x : 0.f, pre.y > 0.f ? g.y : 0.f, pre.z > 0.f ? g.z : 0.f, pre.w > 0.f ? g.w : 0.f};
+    return r;
+}
+__device__ __forceinline__ F4 zero4() { F4 r = {0.f, 0.f, 0.f, 0.f}; return r; }
+
+// block reduction of per-thread column sums held in the 16-lane-group layout
+// (thread -> columns 4t .. 4t+3, 16 groups) into fp64 atomics on dst0 / dst1
+__device__ __forceinline__ void reduce_groups(float *part /* [16][128] */, F4 s1, F4 s2, double *dst0, double *dst1)
+{
+    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
+    st4(&part[gi * 2 * H + 4 * t], s1);
+    st4(&part[gi * 2 * H + H + 4 * t], s2);
+    __syncthreads();
+    if (tid < 2 * H) {
+        double v = 0.0;
+        for (int k = 0; k < 16; ++k) v += (double)part[k * 2 * H + tid];
+        if (tid < H) atomicAdd(&dst0[tid], v);
+        else atomicAdd(&dst1[tid - H], v);
+    }
+    __syncthreads();
+}
+
+// sum over the 16 lanes that share q (= the 16 rows of a wave's block)
+__device__ __forceinline__ float sum_rows16(float v)
+{
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) v += wave_shfl_xor(v, d);
+    return v;
+}
+
+// =========================================================================
+// R1: d score, G_i = dscore * keep_i / (1 - p), dpooled_i = G_i W_i      (gin.py:227-230, graph_encoder.py:196)
+struct ReadBwdArgs {
+    const float *dfeat, *score, *feat, *keep;
+    const float *pred_w[GCC_GIN_MAX_LAYERS + 1];
+    float *G, *dpooled;       // [L+1][B][64]
+    int32_t B, nlayers, kdim0, normalize;
+    float inv_keep, norm_eps;
+};
+
+__global__ __launch_bounds__(kThreads) void gin_bwd_readout_kernel(ReadBwdArgs a)
+{
+    const int lane = lane_id(), wv = (int)threadIdx.x >> 6;
+    const int b = (int)blockIdx.x * 4 + wv;
+    if (b >= a.B) return;    // wave-uniform
+    const float df = a.dfeat[(int64_t)b * H + lane];
+    float ds = df;
+    if (a.normalize) {
+        const float s = a.score[(int64_t)b * H + lane], f = a.feat[(int64_t)b * H + lane];
+        const float nrm = sqrtf(wave_sum(s * s));
+        const float dot = wave_sum(f * df);
+        ds = nrm > a.norm_eps ? (df - f * dot) / nrm : df / a.norm_eps;
+    }
+    for (int i = 0; i <= a.nlayers; ++i) {
+        const int kd = i == 0 ? a.kdim0 : H;
+        const int64_t o = ((int64_t)i * a.B + b) * H + lane;
+        const float g = a.keep ? ds * a.keep[o] * a.inv_keep : ds;
+        a.G[o] = g;
+        float acc = 0.f;
+        for (int oo = 0; oo < H; ++oo) {
+            const float go = wave_shfl(g, oo);
+            if (lane < kd) acc = fmaf(go, a.pred_w[i][(int64_t)oo * kd + lane], acc);
+        }
+        a.dpooled[o] = acc;
+    }
+}
+
+// =========================================================================
+// Bk1
+struct BwdCArgs {
+    const int32_t *node_off, *row_ptr, *col_idx, *graph_id;
+    const float *D;           // dagg of layer l+1, or NULL for the last layer
+    const float *dpooled;     // [B][64] of hidden_rep[l+1]
+    const float *z2;
+    BnDev bnb, bnc;
+    float *U;
+    double *bst_c;            // [3][64]
+    int32_t B;
+    float eps;
+};
+
+__global__ __launch_bounds__(kThreads) void gin_bwd_c_kernel(BwdCArgs a)
+{
+    __shared__ float T[kTile * kLdt];
+    __shared__ float part[16 * 2 * H];
+    __shared__ float Cb[kCoefRows * H], Cc[kCoefRows * H];
+    __shared__ int longrows[kTile];
+    __shared__ int nlong;
+    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
+    const int N = a.node_off[a.B];
+    fill_coefs(Cb, a.bnb, nullptr, (double)N, a.eps);
+    fill_coefs(Cc, a.bnc, nullptr, (double)N, a.eps);
+    __syncthreads();
+    const F4 pbs = ld4(&Cb[PS * H + 4 * t]), pbh = ld4(&Cb[PH * H + 4 * t]);
+    const F4 rcs = ld4(&Cc[RS * H + 4 * t]), rcm = ld4(&Cc[RM * H + 4 * t]);
+    const F4 pcs = ld4(&Cc[PS * H + 4 * t]), pch = ld4(&Cc[PH * H + 4 * t]);
+    auto ident = [&](int u) -> F4 { return ld4(a.D + (int64_t)u * H + 4 * t); };
+    F4 s1 = zero4(), s2 = zero4();
+    bool any = false;
+    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+        any = true;
+        const int nrows = min(kTile, N - tile0);
+        if (a.D) {
+            if (tid == 0) nlong = 0;
+            for (int r = gi; r < kTile; r += 16) st4(&T[r * kLdt + 4 * t], r < nrows ? ident(tile0 + r) : zero4());
+            __syncthreads();
+            gather_tile(T, part, longrows, &nlong, tile0, nrows, a.row_ptr, a.col_idx, ident);
+        }
+        for (int r = gi; r < nrows; r += 16) {
+            const int v = tile0 + r;
+            F4 g = ld4(a.dpooled + (int64_t)a.graph_id[v] * H + 4 * t);
+            if (a.D) g = add4(g, ld4(&T[r * kLdt + 4 * t]));
+            const F4 y2 = relu4(fma4(ld4(a.z2 + (int64_t)v * H + 4 * t), pbs, pbh));
+            const F4 yh = fma4(y2, rcs, rcm);
+            const F4 u = mask4(g, fma4(y2, pcs, pch));
+            st4(a.U + (int64_t)v * H + 4 * t, u);
+            s1 = add4(s1, u);
+            s2 = fma4(u, yh, s2);
+        }
+        __syncthreads();
+    }
+    if (!any) return;
+    reduce_groups(part, s1, s2, a.bst_c, a.bst_c + H);
+}
+
+// =========================================================================
+// Bk2
+struct BwdBArgs {
+    const int32_t *node_off;
+    const float *U, *z2;
+    BnDev bnb, bnc;
+    const double *bst_c;
+    float *V;
+    double *bst_b;
+    int32_t B;
+    float eps;
+};
+
+__global__ __launch_bounds__(kThreads) void gin_bwd_b_kernel(BwdBArgs a)
+{
+    __shared__ float part[16 * 2 * H];
+    __shared__ float Cb[kCoefRows * H], Cc[kCoefRows * H];
+    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
+    const int N = a.node_off[a.B];
+    fill_coefs(Cb, a.bnb, nullptr, (double)N, a.eps);
+    fill_coefs(Cc, a.bnc, a.bst_c, (double)N, a.eps);
+    __syncthreads();
+    const F4 pbs = ld4(&Cb[PS * H + 4 * t]), pbh = ld4(&Cb[PH * H + 4 * t]);
+    const F4 rbs = ld4(&Cb[RS * H + 4 * t]), rbm = ld4(&Cb[RM * H + 4 * t]);
+    const F4 k1 = ld4(&Cc[K1 * H + 4 * t]), k2 = ld4(&Cc[K2 * H + 4 * t]), k3 = ld4(&Cc[K3 * H + 4 * t]);
+    F4 s1 = zero4(), s2 = zero4();
+    bool any = false;
+    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+        any = true;
+        for (int v = tile0 + gi; v < min(tile0 + kTile, N); v += 16) {
+            const F4 z = ld4(a.z2 + (int64_t)v * H + 4 * t);
+            const F4 pre = fma4(z, pbs, pbh);
+            const F4 y2 = relu4(pre);
+            const F4 dy2 = fma4(ld4(a.U + (int64_t)v * H + 4 * t), k1, fma4(y2, k2, k3));   // BN_c backward
+            const F4 vv = mask4(dy2, pre);
+            st4(a.V + (int64_t)v * H + 4 * t, vv);
+            s1 = add4(s1, vv);
+            s2 = fma4(vv, fma4(z, rbs, rbm), s2);
+        }
+    }
+    if (!any) return;
+    reduce_groups(part, s1, s2, a.bst_b, a.bst_b + H);
+}
+
+// =========================================================================
+// Bk3 / Bk4 share one kernel: dz = BN'(gin) ; store dz ; S(dz) ; dx = dz W (MFMA);
+//   kMask: out = dx * [pre(zout) > 0], S(out), S(out * xhat(zout))      (Bk3: through relu(bn_a))
+//   else : out = dx                                                      (Bk4: dagg)
+struct BwdLinArgs {
+    const int32_t *node_off;
+    const float *gin, *zin;   // upstream gradient and the Linear output feeding this BN (V,z2 | Wt,z1)
+    BnDev bn_in;              // BN applied to zin (bn_b | bn_a)
+    const double *bst_in;     // its backward sums [3][64] (slot 2 receives S(dz))
+    double *bst_bias;         // == bst_in + 2*H
+    const float *W;           // [64][kdim] the Linear being back-propagated through (W1 | W0)
+    int32_t kdim;
+    float *dz;                // [N][64] stored for the weight gradient
+    float *out;               // Wt | D
+    const float *zout;        // z1 (kMask) or NULL
+    BnDev bn_out;             // bn_a (kMask)
+    double *bst_out;          // [3][64] slots 0,1 (kMask)
+    int32_t B;
+    float eps;
+};
+
+template <bool kMask>
+__global__ __launch_bounds__(kThreads) void gin_bwd_lin_kernel(BwdLinArgs a)
+{
+    __shared__ float Ci[kCoefRows * H], Co[kCoefRows * H];
+    __shared__ float red[4 * 3 * H];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
+    const int N = a.node_off[a.B];
+    fill_coefs(Ci, a.bn_in, a.bst_in, (double)N, a.eps);
+    if (kMask) fill_coefs(Co, a.bn_out, nullptr, (double)N, a.eps);
+    __syncthreads();
+    F4 wf[4][4];
+    load_wt_frags(a.W, a.kdim, wf);
+    float *myred = &red[wv * 3 * H];
+    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+        const int row = tile0 + 16 * wv + j;
+        const bool valid = row < N;
+        F4 xb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = 16 * c + 4 * q;
+            F4 d = zero4();
+            if (valid) {
+                const F4 g = ld4(a.gin + (int64_t)row * H + col), z = ld4(a.zin + (int64_t)row * H + col);
+                d = fma4(g, ld4(&Ci[K1 * H + col]), fma4(z, ld4(&Ci[K2 * H + col]), ld4(&Ci[K3 * H + col])));
+                st4(a.dz + (int64_t)row * H + col, d);
+            }
+            xb[c] = d;
+            const float bx = sum_rows16(d.x), by = sum_rows16(d.y), bz = sum_rows16(d.z), bw = sum_rows16(d.w);
+            if (j == 0) { myred[2 * H + col] = bx; myred[2 * H + col + 1] = by; myred[2 * H + col + 2] = bz; myred[2 * H + col + 3] = bw; }
+        }
+        f32x4 acc[4];
+        mfma_rows16(xb, wf, acc);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int col = 16 * cb + 4 * q;
+            F4 o = {acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]};
+            if (kMask) {
+                F4 z = zero4();
+                if (valid) z = ld4(a.zout + (int64_t)row * H + col);
+                o = valid ? mask4(o, fma4(z, ld4(&Co[PS * H + col]), ld4(&Co[PH * H + col]))) : zero4();
+                const F4 xh = fma4(z, ld4(&Co[RS * H + col]), ld4(&Co[RM * H + col]));
+                const float s0 = sum_rows16(o.x), s1 = sum_rows16(o.y), s2 = sum_rows16(o.z), s3 = sum_rows16(o.w);
+                const float t0 = sum_rows16(o.x * xh.x), t1 = sum_rows16(o.y * xh.y), t2 = sum_rows16(o.z * xh.z),
+                            t3 = sum_rows16(o.w * xh.w);
+                if (j == 0) {
+                    myred[col] = s0; myred[col + 1] = s1; myred[col + 2] = s2; myred[col + 3] = s3;
+                    myred[H + col] = t0; myred[H + col + 1] = t1; myred[H + col + 2] = t2; myred[H + col + 3] = t3;
+                }
+            }
+            if (valid) st4(a.out + (int64_t)row * H + col, o);
+        }
+        __syncthreads();
+        if (tid < 3 * H) {
+            const double v = (double)red[tid] + (double)red[3 * H + tid] + (double)red[6 * H + tid] + (double)red[9 * H + tid];
+            if (tid >= 2 * H) atomicAdd(&a.bst_bias[tid - 2 * H], v);
+            else if (kMask) atomicAdd(&a.bst_out[tid], v);
+        }
+        __syncthreads();
+    }
+}
+
+// =========================================================================
+// degree-embedding gradient: dx0 = (I + A) dagg_0 + dpooled_0[graph]; d emb[clamp(deg)] += dx0[:, pos:pos+emb].
+// Many nodes share a (small) degree, so global atomics would serialise on a few cache lines:
+// each block accumulates into an LDS table (column c is owned by thread c: no atomics, fixed order)
+// and writes its table as one partial; the final kernel sums the kEmbBlocks partials.
+constexpr int kEmbBlocks = 64;
+constexpr int kEmbMaxElems = 10240;      // (max_degree + 1) * deg_emb_dim floats of LDS (40 KiB)
+
+struct EmbArgs {
+    const int32_t *node_off, *row_ptr, *col_idx, *graph_id;
+    const float *D, *dpooled0;
+    float *demb_parts;        // [kEmbBlocks][(max_degree + 1) * emb_dim]
+    int32_t B, pos_dim, emb_dim, max_degree;
+};
+
+__global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
+{
+    __shared__ float T[kTile * kLdt];
+    __shared__ float part[16 * H];
+    __shared__ float E[kEmbMaxElems];
+    __shared__ int longrows[kTile];
+    __shared__ int nlong;
+    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
+    const int N = a.node_off[a.B];
+    const int elems = (a.max_degree + 1) * a.emb_dim;
+    for (int i = tid; i < elems; i += kThreads) E[i] = 0.f;
+    auto ident = [&](int u) -> F4 { return ld4(a.D + (int64_t)u * H + 4 * t); };
+    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+        const int nrows = min(kTile, N - tile0);
+        if (tid == 0) nlong = 0;
+        for (int r = gi; r < kTile; r += 16) st4(&T[r * kLdt + 4 * t], r < nrows ? ident(tile0 + r) : zero4());
+        __syncthreads();
+        gather_tile(T, part, longrows, &nlong, tile0, nrows, a.row_ptr, a.col_idx, ident);
+        if (tid < a.emb_dim) {
+            for (int r = 0; r < nrows; ++r) {
+                const int v = tile0 + r;
+                const int deg = a.row_ptr[v + 1] - a.row_ptr[v];
+                const int dcl = deg < a.max_degree ? deg : a.max_degree;
+                E[dcl * a.emb_dim + tid] += T[r * kLdt + a.pos_dim + tid] +
+                                            a.dpooled0[(int64_t)a.graph_id[v] * H + a.pos_dim + tid];
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < elems; i += kThreads) a.demb_parts[(int64_t)blockIdx.x * elems + i] = E[i];
+}
+
+// =========================================================================
+// weight gradients: slab[y][chunk] = sum over the chunk's rows of dZ^T X     (y = 2*l + which)
+struct WgradJob {
+    const float *dZ, *X;
+    BnDev bn;                 // which == 1: X = relu(bn_a(z1)); which == 0: X = agg (bn.weight == NULL)
+};
+struct WgradArgs {
+    const int32_t *node_off;
+    WgradJob job[2 * GCC_GIN_MAX_LAYERS];
+    float *slabs;             // [njobs][kWgChunks][64 * 64]
+    int32_t B;
+    float eps;
+};
+
+__global__ __launch_bounds__(kThreads) void gin_wgrad_kernel(WgradArgs a)
+{
+    __shared__ float S[H * H];
+    __shared__ float Cx[2 * H];
+    const WgradJob &jb = a.job[blockIdx.y];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
+    const int N = a.node_off[a.B];
+    const bool act = jb.bn.weight != nullptr;
+    if (tid < H) {
+        float sc = 1.f, sh = 0.f;
+        if (act) bn_scale_shift(jb.bn, tid, (double)N, a.eps, 1, sc, sh);
+        Cx[tid] = sc;
+        Cx[H + tid] = sh;
+    }
+    __syncthreads();
+    float xs[4], xh[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) { xs[kb] = Cx[16 * kb + j]; xh[kb] = Cx[H + 16 * kb + j]; }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[ob][kb] = z; }
+    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = tile0 + 16 * wv + 4 * s + q;     // MFMA reduction index = row
+            float av[4], bv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                av[k] = row < N ? jb.dZ[(int64_t)row * H + 16 * k + j] : 0.f;
+                float x = row < N ? jb.X[(int64_t)row * H + 16 * k + j] : 0.f;
+                if (act) x = row < N ? fmaxf(fmaf(x, xs[k], xh[k]), 0.f) : 0.f;
+                bv[k] = x;
+            }
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) acc[ob][kb] = mfma_16x16x4_f32(av[ob], bv[kb], acc[ob][kb]);
+        }
+    }
+    // combine the 4 waves in a fixed order, then write this chunk's slab
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = 16 * ob + 4 * q + r, k = 16 * kb + j;
+                        S[o * H + k] = (w == 0 ? 0.f : S[o * H + k]) + acc[ob][kb][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float *slab = a.slabs + ((int64_t)blockIdx.y * kWgChunks + blockIdx.x) * H * H;
+    for (int i = tid; i < H * H; i += kThreads) slab[i] = S[i];
+}
+
+// =========================================================================
+// final: reduce slabs, prediction-layer / BatchNorm / bias / embedding gradients -> grads
+struct FinalArgs {
+    const float *slabs;
+    const float *G;           // [L+1][B][64]
+    const double *pooled;     // [L+1][B][64]
+    const double *bst;        // [L][3 (a,b,c)][3][64]
+    const float *demb_parts;  // [kEmbBlocks][emb_rows * emb_dim]
+    gcc_gin_grads g;
+    int32_t B, L, kdim0, emb_rows, emb_dim, accumulate;
+};
+
+__device__ __forceinline__ void put(float *dst, float v, int acc)
+{
+    if (dst) *dst = acc ? *dst + v : v;
+}
+
+__global__ __launch_bounds__(kThreads) void gin_grad_final_kernel(FinalArgs a)
+{
+    const int64_t gid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int L = a.L;
+    int64_t base = 0;
+    // (1) linears.{0,1}.weight of every layer
+    const int64_t n1 = (int64_t)2 * L * H * H;
+    if (gid < n1) {
+        const int y = (int)(gid / (H * H)), idx = (int)(gid % (H * H));
+        const int o = idx / H, k = idx % H, l = y >> 1, which = y & 1;
+        float s = 0.f;
+        for (int c = 0; c < kWgChunks; ++c) s += a.slabs[((int64_t)y * kWgChunks + c) * H * H + idx];
+        const int kd = (which == 0 && l == 0) ? a.kdim0 : H;
+        float *dst = which ? a.g.lin1_w[l] : a.g.lin0_w[l];
+        if (k < kd && dst) put(dst + (int64_t)o * kd + k, s, a.accumulate);
+        return;
+    }
+    base += n1;
+    // (2) linears_prediction.i.weight: G_i^T pooled_i
+    const int64_t n2 = (int64_t)(L + 1) * H * H;
+    if (gid < base + n2) {
+        const int64_t r = gid - base;
+        const int i = (int)(r / (H * H)), idx = (int)(r % (H * H)), o = idx / H, k = idx % H;
+        const int kd = i == 0 ? a.kdim0 : H;
+        if (k >= kd) return;
+        float s = 0.f;
+        for (int b = 0; b < a.B; ++b)
+            s = fmaf(a.G[((int64_t)i * a.B + b) * H + o], (float)a.pooled[((int64_t)i * a.B + b) * H + k], s);
+        if (a.g.pred_w[i]) put(a.g.pred_w[i] + (int64_t)o * kd + k, s, a.accumulate);
+        return;
+    }
+    base += n2;
+    // (3) linears_prediction.i.bias
+    const int64_t n3 = (int64_t)(L + 1) * H;
+    if (gid < base + n3) {
+        const int64_t r = gid - base;
+        const int i = (int)(r / H), o = (int)(r % H);
+        float s = 0.f;
+        for (int b = 0; b < a.B; ++b) s += a.G[((int64_t)i * a.B + b) * H + o];
+        if (a.g.pred_b[i]) put(a.g.pred_b[i] + o, s, a.accumulate);
+        return;
+    }
+    base += n3;
+    // (4) BatchNorm weight/bias and Linear bias gradients from the backward sums
+    const int64_t n4 = (int64_t)L * 3 * 3 * H;
+    if (gid < base + n4) {
+        const int64_t r = gid - base;
+        const int c = (int)(r % H), slot = (int)((r / H) % 3), which = (int)((r / (3 * H)) % 3), l = (int)(r / (9 * H));
+        const float v = (float)a.bst[r];
+        float *dst = nullptr;
+        if (which == 0) dst = slot == 0 ? a.g.bn_a_b[l] : slot == 1 ? a.g.bn_a_w[l] : a.g.lin0_b[l];
+        else if (which == 1) dst = slot == 0 ? a.g.bn_b_b[l] : slot == 1 ? a.g.bn_b_w[l] : a.g.lin1_b[l];
+        else dst = slot == 0 ? a.g.bn_c_b[l] : slot == 1 ? a.g.bn_c_w[l] : nullptr;
+        if (dst) put(dst + c, v, a.accumulate);
+        return;
+    }
+    base += n4;
+    // (5) degree embedding
+    const int64_t n5 = (int64_t)a.emb_rows * a.emb_dim;
+    if (gid < base + n5) {
+        const int64_t r = gid - base;
+        float sum = 0.f;
+        for (int k = 0; k < kEmbBlocks; ++k) sum += a.demb_parts[(int64_t)k * n5 + r];
+        if (a.g.degree_embedding) put(a.g.degree_embedding + r, sum, a.accumulate);
+    }
+}
+
+struct BwdWork {
+    float *U, *V, *Wt, *D;
+    float *dz1[GCC_GIN_MAX_LAYERS], *dz2[GCC_GIN_MAX_LAYERS];
+    float *G, *dpooled, *slabs;
+    double *bst;
+    float *demb_parts;
+    int64_t off_zero, zero_bytes, total;
+};
+
+inline BwdWork bwd_layout(char *base, int64_t node_cap, int32_t B, int32_t L, int32_t emb_elems)
+{
+    BwdWork w;
+    auto al = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) { int64_t at = o; o = al(o + bytes); return base ? base + at : (char *)nullptr; };
+    const int64_t act = node_cap * H * (int64_t)sizeof(float);
+    w.U = (float *)take(act); w.V = (float *)take(act); w.Wt = (float *)take(act); w.D = (float *)take(act);
+    for (int l = 0; l < GCC_GIN_MAX_LAYERS; ++l) {
+        w.dz1[l] = l < L ? (float *)take(act) : nullptr;
+        w.dz2[l] = l < L ? (float *)take(act) : nullptr;
+    }
+    w.G = (float *)take((int64_t)(L + 1) * B * H * sizeof(float));
+    w.dpooled = (float *)take((int64_t)(L + 1) * B * H * sizeof(float));
+    w.slabs = (float *)take((int64_t)2 * L * kWgChunks * H * H * sizeof(float));
+    w.demb_parts = (float *)take((int64_t)kEmbBlocks * emb_elems * sizeof(float));
+    w.off_zero = o;                                   // everything from here on is zeroed per call
+    w.bst = (double *)take((int64_t)L * 9 * H * sizeof(double));
+    w.zero_bytes = o - w.off_zero;
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+extern "C" int64_t gcc_gin_backward_workspace_bytes(int64_t node_cap, int32_t batch_size, int32_t num_gin_layers)
+{
+    if (node_cap <= 0 || batch_size <= 0 || num_gin_layers < 1 || num_gin_layers > GCC_GIN_MAX_LAYERS) {
+        snprintf(g_err, kErrLen, "gcc_gin_backward_workspace_bytes: bad argument");
+        return -1;
+    }
+    return bwd_layout(nullptr, node_cap, batch_size, num_gin_layers, kEmbMaxElems).total;
+}
+
+extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat, const gcc_gin_grads *grads,
+                                    int32_t accumulate, void *workspace, int64_t workspace_bytes,
+                                    int64_t node_cap, gcc_prof *prof, void *stream)
+{
+    if (!pass || !dfeat || !grads || !workspace) {
+        snprintf(g_err, kErrLen, "gcc_gin_backward: null argument");
+        return -1;
+    }
+    const gcc_gin_pass &p = *pass;
+    const int L = p.w.num_gin_layers, B = p.batch_size;
+    const int kdim0 = p.w.pos_dim + p.w.deg_emb_dim + 1;
+    const int emb_elems = (p.w.max_degree + 1) * p.w.deg_emb_dim;
+    if (!p.training || L < 1 || L > GCC_GIN_MAX_LAYERS || emb_elems > kEmbMaxElems) {
+        snprintf(g_err, kErrLen, "gcc_gin_backward: needs a training-mode pass (layers=%d)", L);
+        return -2;
+    }
+    for (int l = 0; l < L; ++l)
+        if (!p.agg[l]) { snprintf(g_err, kErrLen, "gcc_gin_backward: agg[%d] was not saved", l); return -2; }
+    const BwdWork w = bwd_layout((char *)workspace, node_cap, B, L, kEmbMaxElems);
+    if (workspace_bytes < w.total) {
+        snprintf(g_err, kErrLen, "gcc_gin_backward: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                 (long long)w.total);
+        return -3;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    prof_mark(prof, 0, s);
+    (void)hipMemsetAsync((char *)workspace + w.off_zero, 0, (size_t)w.zero_bytes, s);
+    const dim3 grid(kGridX), block(kThreads);
+    auto bst = [&](int l, int which) { return w.bst + ((int64_t)l * 3 + which) * 3 * H; };   // which: 0=a 1=b 2=c
+    {
+        ReadBwdArgs a;
+        a.dfeat = dfeat; a.score = p.score; a.feat = p.feat; a.keep = p.dropout_keep;
+        for (int i = 0; i <= L; ++i) a.pred_w[i] = p.w.pred_w[i];
+        a.G = w.G; a.dpooled = w.dpooled; a.B = B; a.nlayers = L; a.kdim0 = kdim0; a.normalize = p.normalize;
+        a.inv_keep = 1.0f / (1.0f - p.w.dropout_p); a.norm_eps = p.w.norm_eps;
+        hipLaunchKernelGGL(gin_bwd_readout_kernel, dim3((B + 3) / 4), block, 0, s, a);
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        const BnDev bna = bn_dev(p.w.bn_a[l], stats_of(p, l, 0));
+        const BnDev bnb = bn_dev(p.w.bn_b[l], stats_of(p, l, 1));
+        const BnDev bnc = bn_dev(p.w.bn_c[l], stats_of(p, l, 2));
+        {
+            BwdCArgs a = {p.node_off, p.row_ptr, p.col_idx, p.graph_id, l == L - 1 ? nullptr : w.D,
+                          w.dpooled + (int64_t)(l + 1) * B * H, p.z2[l], bnb, bnc, w.U, bst(l, 2), B, p.w.bn_eps};
+            hipLaunchKernelGGL(gin_bwd_c_kernel, grid, block, 0, s, a);
+        }
+        {
+            BwdBArgs a = {p.node_off, w.U, p.z2[l], bnb, bnc, bst(l, 2), w.V, bst(l, 1), B, p.w.bn_eps};
+            hipLaunchKernelGGL(gin_bwd_b_kernel, grid, block, 0, s, a);
+        }
+        {
+            BwdLinArgs a = {p.node_off, w.V, p.z2[l], bnb, bst(l, 1), bst(l, 1) + 2 * H, p.w.lin1_w[l], H,
+                            w.dz2[l], w.Wt, p.z1[l], bna, bst(l, 0), B, p.w.bn_eps};
+            hipLaunchKernelGGL((gin_bwd_lin_kernel<true>), grid, block, 0, s, a);
+        }
+        {
+            BwdLinArgs a = {p.node_off, w.Wt, p.z1[l], bna, bst(l, 0), bst(l, 0) + 2 * H, p.w.lin0_w[l],
+                            l == 0 ? kdim0 : H, w.dz1[l], w.D, nullptr, BnDev(), nullptr, B, p.w.bn_eps};
+            hipLaunchKernelGGL((gin_bwd_lin_kernel<false>), grid, block, 0, s, a);
+        }
+    }
+    {
+        EmbArgs a = {p.node_off, p.row_ptr, p.col_idx, p.graph_id, w.D, w.dpooled, w.demb_parts, B, p.w.pos_dim,
+                     p.w.deg_emb_dim, p.w.max_degree};
+        hipLaunchKernelGGL(gin_bwd_emb_kernel, dim3(kEmbBlocks), block, 0, s, a);
+    }
+    {
+        WgradArgs a;
+        a.node_off = p.node_off; a.slabs = w.slabs; a.B = B; a.eps = p.w.bn_eps;
+        for (int l = 0; l < L; ++l) {
+            a.job[2 * l + 0] = {w.dz1[l], p.agg[l], BnDev()};
+            a.job[2 * l + 1] = {w.dz2[l], p.z1[l], bn_dev(p.w.bn_a[l], stats_of(p, l, 0))};
+        }
+        hipLaunchKernelGGL(gin_wgrad_kernel, dim3(kWgChunks, 2 * L), block, 0, s, a);
+    }
+    {
+        FinalArgs a;
+        a.slabs = w.slabs; a.G = w.G; a.pooled = p.pooled; a.bst = w.bst; a.demb_parts = w.demb_parts; a.g = *grads;
+        a.B = B; a.L = L; a.kdim0 = kdim0; a.emb_rows = p.w.max_degree + 1; a.emb_dim = p.w.deg_emb_dim;
+        a.accumulate = accumulate;
+        const int64_t total = (int64_t)2 * L * H * H + (int64_t)(L + 1) * H * H + (int64_t)(L + 1) * H +
+                              (int64_t)L * 9 * H + (int64_t)a.emb_rows * a.emb_dim;
+        hipLaunchKernelGGL(gin_grad_final_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), block, 0, s, a);
+    }
+    prof_mark(prof, 1, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, kErrLen, "gcc_gin_backward: launch failed: %s", hipGetErrorString(e));
+        return -10;
+    }
+    return 0;
+}

@@ -199,6 +199,58 @@ __device__ __forceinline__ void flush_stats(const float *red, double *stats)
 }
 
 
+// ---- neighbourhood sum over an LDS tile.  Precondition: T rows [0, nrows) hold the self term,
+// *nlong == 0, and a __syncthreads() separates those writes from this call.  Postcondition:
+// T[r] = self + sum_{u in row(tile0 + r)} feat(u); ends with a __syncthreads().
+// Lane groups of 16 own rows (16 B per lane = one 256 B feature row per load); rows longer than
+// kLongRow are summed by all 16 groups together so that a hub row does not serialise one group.
+template <class Feat>
+__device__ __forceinline__ void gather_tile(float *T, float *part /* [16 * H] */, int *longrows, int *nlong,
+                                            int tile0, int nrows, const int32_t *row_ptr,
+                                            const int32_t *col_idx, Feat feat)
+{
+    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
+    for (int r = gi; r < nrows; r += 16) {
+        const int v = tile0 + r;
+        const int beg = row_ptr[v], end = row_ptr[v + 1];
+        if (end - beg > kLongRow) {
+            if (t == 0) longrows[atomicAdd(nlong, 1)] = r;
+            continue;
+        }
+        F4 acc = ld4(&T[r * kLdt + 4 * t]);
+        int e = beg;
+        for (; e + 4 <= end; e += 4) {
+            const int u0 = col_idx[e], u1 = col_idx[e + 1], u2 = col_idx[e + 2], u3 = col_idx[e + 3];
+            const F4 f0 = feat(u0), f1 = feat(u1), f2 = feat(u2), f3 = feat(u3);
+            acc = add4(add4(acc, f0), add4(f1, add4(f2, f3)));
+        }
+        for (; e < end; ++e) acc = add4(acc, feat(col_idx[e]));
+        st4(&T[r * kLdt + 4 * t], acc);
+    }
+    __syncthreads();
+    const int nl = *nlong;
+    for (int i = 0; i < nl; ++i) {
+        const int r = longrows[i], v = tile0 + r;
+        const int beg = row_ptr[v], end = row_ptr[v + 1];
+        F4 acc = {0.f, 0.f, 0.f, 0.f};
+        int e = beg + gi;
+        for (; e + 48 < end; e += 64) {
+            const int u0 = col_idx[e], u1 = col_idx[e + 16], u2 = col_idx[e + 32], u3 = col_idx[e + 48];
+            const F4 f0 = feat(u0), f1 = feat(u1), f2 = feat(u2), f3 = feat(u3);
+            acc = add4(add4(acc, f0), add4(f1, add4(f2, f3)));
+        }
+        for (; e < end; e += 16) acc = add4(acc, feat(col_idx[e]));
+        st4(&part[gi * H + 4 * t], acc);
+        __syncthreads();
+        if (tid < H) {
+            float s = T[r * kLdt + tid];
+            for (int k = 0; k < 16; ++k) s += part[k * H + tid];
+            T[r * kLdt + tid] = s;
+        }
+        __syncthreads();
+    }
+}
+
 inline BnDev bn_dev(const gcc_bn &b, const double *stats)
 {
     BnDev d = {b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked, stats};

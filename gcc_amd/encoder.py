@@ -168,6 +168,39 @@ class GinEngine:
             raise RuntimeError(f"gcc_gin_forward failed ({rc}): {self.lib.gcc_last_error().decode()}")
 
 
+    def backward(self, enc, p, buf, dfeat, accumulate=False, stream=None, prof=None):
+        """Backward of a training-mode pass: fills ``param.grad`` of every live parameter of ``enc``."""
+        ptr = self.ptr
+        L = len(enc.gnn.ginlayers)
+        g = buf["_keepalive"][0]
+        node_cap = g.parent_nid.numel() if hasattr(g, "parent_nid") else g.graph_id.numel()
+        nbytes = self.lib.gcc_gin_backward_workspace_bytes(node_cap, p.batch_size, L)
+        key = ("bwd", nbytes, str(dfeat.device))
+        if key not in self._bufs:
+            self._bufs[key] = torch.empty(nbytes, dtype=torch.uint8, device=dfeat.device)
+        ws = self._bufs[key]
+        grads = _cabi.GccGinGrads()
+        keep = []
+        for name, idx, param in grad_params(enc):
+            if param.grad is None:
+                param.grad = torch.zeros_like(param)
+                fresh = True
+            else:
+                fresh = False
+            keep.append(param.grad)
+            if idx is None:
+                setattr(grads, name, ptr(param.grad))
+            else:
+                getattr(grads, name)[idx] = ptr(param.grad)
+            del fresh
+        dfeat = dfeat.contiguous()
+        rc = self.lib.gcc_gin_backward(ctypes.byref(p), ptr(dfeat), ctypes.byref(grads), int(accumulate),
+                                       ptr(ws), nbytes, node_cap, prof.handle if prof is not None else None, stream)
+        if rc != 0:
+            raise RuntimeError(f"gcc_gin_backward failed ({rc}): {self.lib.gcc_last_error().decode()}")
+        return keep
+
+
 class GraphEncoder(nn.Module):
     """graph_encoder.py:44-63 signature; only gnn_model="gin" with degree_input=True
     (train.py:601-618) is implemented -- the other backbones are out of scope (SURVEY.md §2.1 #8)."""
