@@ -108,6 +108,15 @@ class GccGinGrads(ctypes.Structure):
     ]
 
 
+class GccNceArgs(ctypes.Structure):
+    _fields_ = [
+        ("q", _VP), ("k", _VP), ("mem", _VP), ("patch", _VP),
+        ("patch_index", ctypes.c_int32), ("patch_rows", ctypes.c_int32),
+        ("B", ctypes.c_int32), ("K", ctypes.c_int32), ("pos_mode", ctypes.c_int32), ("inv_T", ctypes.c_float),
+        ("lse", _VP), ("pos", _VP), ("loss", _VP), ("prob", _VP), ("out_dense", _VP),
+    ]
+
+
 # name -> (restype, argtypes); the single source of truth for the symbol test
 SIGNATURES = {
     "gcc_abi_version": (ctypes.c_int32, []),
@@ -126,6 +135,16 @@ SIGNATURES = {
     "gcc_gin_backward": (ctypes.c_int32, [ctypes.POINTER(GccGinPass), ctypes.c_void_p, ctypes.POINTER(GccGinGrads),
                                           ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_nce_workspace_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32]),
+    "gcc_nce_forward": (ctypes.c_int32, [ctypes.POINTER(GccNceArgs), ctypes.c_void_p, ctypes.c_int64,
+                                         ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_nce_backward": (ctypes.c_int32, [ctypes.POINTER(GccNceArgs), ctypes.c_void_p, ctypes.c_int32,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                          ctypes.c_void_p]),
+    "gcc_queue_enqueue": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                           ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_ema_update": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,
+                                        ctypes.c_void_p]),
 }
 # symbols declared in the header but not built yet are listed here while the build is in progress
 PENDING = set()

@@ -1,0 +1,237 @@
+"""MoCo / InfoNCE head behind the reference's API.
+
+Mirrors /root/reference/gcc/contrastive/memory_moco.py:7-63 (``MemoryMoCo``) and
+gcc/contrastive/criterions.py:5-33 (``NCESoftmaxLoss``, ``NCESoftmaxLossNS``).
+The logits [B, K+1] are not materialised: ``MemoryMoCo.forward`` returns a
+:class:`NCELogits` that carries the fused loss (HIP online-softmax kernels of
+gcc_amd/csrc/nce.hip) and supports exactly what train.py does with ``out``:
+``out[:, 0]`` (train.py:394), ``criterion(out)`` (train.py:407), ``out.shape``;
+``out.dense()`` builds the full tensor on demand.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+from torch import nn
+
+from . import _cabi
+
+D = 64
+
+
+class NceEngine:
+    """C-ABI calls of the head.  ``lib``/``ptr`` are injectable for the emulator tests only."""
+
+    def __init__(self, lib=None, ptr=None):
+        self.lib = lib if lib is not None else _cabi.load()
+        self.ptr = ptr if ptr is not None else _cabi.dev_ptr
+        self._ws = {}
+
+    def _workspace(self, B, K, device):
+        nbytes = self.lib.gcc_nce_workspace_bytes(B, K)
+        key = (nbytes, str(device))
+        if key not in self._ws:
+            self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._ws[key], nbytes
+
+    def _args(self, q, k, mem, inv_T, pos_mode, patch, patch_index, outs, dense):
+        ptr = self.ptr
+        a = _cabi.GccNceArgs()
+        a.q, a.k, a.mem = ptr(q), ptr(k) if k is not None else None, ptr(mem)
+        a.patch = ptr(patch) if patch is not None else None
+        a.patch_index = int(patch_index)
+        a.patch_rows = int(patch.shape[0]) if patch is not None else 0
+        a.B, a.K, a.pos_mode, a.inv_T = q.shape[0], mem.shape[0], pos_mode, inv_T
+        a.lse, a.pos, a.loss, a.prob = ptr(outs["lse"]), ptr(outs["pos"]), ptr(outs["loss"]), ptr(outs["prob"])
+        a.out_dense = ptr(dense) if dense is not None else None
+        return a
+
+    def forward(self, q, k, mem, T, pos_mode, dense=False, lse_rows=None, patch=None, patch_index=0, stream=None,
+                prof=None):
+        B, K = q.shape[0], mem.shape[0]
+        f32 = dict(dtype=torch.float32, device=q.device)
+        outs = dict(lse=torch.empty(lse_rows or B, **f32), pos=torch.empty(B, **f32), loss=torch.empty(1, **f32),
+                    prob=torch.empty(1, **f32))
+        out = torch.empty(B, K + (1 if pos_mode == 0 else 0), **f32) if dense else None
+        ws, nbytes = self._workspace(B, K, q.device)
+        a = self._args(q, k, mem, 1.0 / T, pos_mode, patch, patch_index, outs, out)
+        rc = self.lib.gcc_nce_forward(ctypes.byref(a), self.ptr(ws), nbytes, prof.handle if prof else None, stream)
+        if rc != 0:
+            raise RuntimeError(f"gcc_nce_forward failed ({rc}): {self.lib.gcc_last_error().decode()}")
+        outs["out"] = out
+        return outs
+
+    def backward(self, q, k, mem, T, pos_mode, outs, dloss, patch=None, patch_index=0, by_mem_row=False,
+                 stream=None, prof=None):
+        B, K = q.shape[0], mem.shape[0]
+        dq = torch.empty_like(q)
+        ws, nbytes = self._workspace(B, K, q.device)
+        a = self._args(q, k, mem, 1.0 / T, pos_mode, patch, patch_index, outs, None)
+        dloss = dloss.reshape(1).to(torch.float32).contiguous()
+        rc = self.lib.gcc_nce_backward(ctypes.byref(a), self.ptr(dloss), int(by_mem_row), self.ptr(dq), self.ptr(ws),
+                                       nbytes, prof.handle if prof else None, stream)
+        if rc != 0:
+            raise RuntimeError(f"gcc_nce_backward failed ({rc}): {self.lib.gcc_last_error().decode()}")
+        return dq
+
+    def enqueue(self, mem, keys, index, save=True, stream=None):
+        saved = torch.empty_like(keys) if save else None
+        rc = self.lib.gcc_queue_enqueue(self.ptr(mem), mem.shape[0], self.ptr(keys), keys.shape[0], int(index),
+                                        self.ptr(saved) if saved is not None else None, stream)
+        if rc != 0:
+            raise RuntimeError(f"gcc_queue_enqueue failed ({rc}): {self.lib.gcc_last_error().decode()}")
+        return saved
+
+    def ema(self, ema, p, m, stream=None):
+        rc = self.lib.gcc_ema_update(self.ptr(ema), self.ptr(p), ema.numel(), float(m), stream)
+        if rc != 0:
+            raise RuntimeError(f"gcc_ema_update failed ({rc}): {self.lib.gcc_last_error().decode()}")
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
+
+
+class _MoCoLoss(torch.autograd.Function):
+    """Attaches the HIP backward (recompute with the pre-enqueue queue rows) to the fused loss."""
+
+    @staticmethod
+    def forward(ctx, q, k, module, outs, patch, patch_index):
+        ctx.module, ctx.outs, ctx.patch, ctx.patch_index = module, outs, patch, patch_index
+        ctx.save_for_backward(q, k)
+        return outs["loss"].reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        q, k = ctx.saved_tensors
+        m = ctx.module
+        dq = m.engine().backward(q, k, m.memory, m.T, 0, ctx.outs, dloss, patch=ctx.patch,
+                                 patch_index=ctx.patch_index, stream=_stream(q))
+        return dq, None, None, None, None, None
+
+
+class _NSLoss(torch.autograd.Function):
+    """CE(feat_k feat_q^T / T, arange) of train.py:400 + criterions.py:27-33; gradients to both views."""
+
+    @staticmethod
+    def forward(ctx, feat_q, feat_k, T, eng):
+        fq, fk = feat_q.contiguous(), feat_k.contiguous()
+        outs = eng.forward(fk, None, fq, T, 1, stream=_stream(fq))     # rows = feat_k, columns = feat_q
+        ctx.eng, ctx.T, ctx.outs = eng, T, outs
+        ctx.save_for_backward(fq, fk)
+        ctx.mark_non_differentiable(outs["prob"])
+        return outs["loss"].reshape(()), outs["prob"].reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss, _dprob):
+        fq, fk = ctx.saved_tensors
+        eng, T, outs = ctx.eng, ctx.T, ctx.outs
+        dk = eng.backward(fk, None, fq, T, 1, outs, dloss, stream=_stream(fq))
+        dq = eng.backward(fq, None, fk, T, 1, outs, dloss, by_mem_row=True, stream=_stream(fq))
+        return dq, dk, None, None
+
+
+class NCELogits:
+    """What ``MemoryMoCo.forward`` returns in place of the dense [B, K+1] tensor."""
+
+    def __init__(self, loss, prob, pos, shape, dense_fn):
+        self.loss, self.prob, self.pos = loss, prob, pos
+        self.shape = torch.Size(shape)
+        self._dense_fn = dense_fn
+
+    def __getitem__(self, idx):
+        if isinstance(idx, tuple) and len(idx) == 2 and idx[0] == slice(None) and idx[1] == 0:
+            return self.pos                                             # out[:, 0]  (train.py:394)
+        return self.dense()[idx]
+
+    def squeeze(self):
+        return self
+
+    def dense(self):
+        return self._dense_fn()
+
+
+class MemoryMoCo(nn.Module):
+    """memory_moco.py:7-24: fixed-size queue; buffers ``params`` and ``memory`` (checkpoint["contrast"])."""
+
+    def __init__(self, inputSize, outputSize, K, T=0.07, use_softmax=False):
+        super().__init__()
+        if inputSize != D:
+            raise NotImplementedError("feature size is fixed at 64 (train.py:93 default)")
+        if not use_softmax:
+            raise NotImplementedError("train.py:628 always passes use_softmax=True (the exp/Z branch is dead)")
+        self.outputSize = outputSize
+        self.inputSize = inputSize
+        self.queueSize = K
+        self.T = T
+        self.index = 0                     # Python int, not saved -- as in the reference (memory_moco.py:16,61)
+        self.use_softmax = use_softmax
+        self.register_buffer("params", torch.tensor([-1]))
+        stdv = 1.0 / math.sqrt(inputSize / 3)
+        self.register_buffer("memory", torch.rand(self.queueSize, inputSize).mul_(2 * stdv).add_(-stdv))
+        self.gather_keys = None            # multi-GPU: all-gather of keys before the enqueue
+        self._engine = None
+        print("using queue shape: ({},{})".format(self.queueSize, inputSize))
+
+    def engine(self) -> NceEngine:
+        if self._engine is None:
+            self._engine = NceEngine()
+        return self._engine
+
+    def forward(self, q, k):
+        eng = self.engine()
+        qc = q.contiguous()
+        kc = k.detach().contiguous()                                   # memory_moco.py:28
+        st = _stream(qc)
+        outs = eng.forward(qc.detach(), kc, self.memory, self.T, 0, stream=st)   # logits vs the queue BEFORE the update
+        keys = self.gather_keys(kc) if self.gather_keys is not None else kc
+        index = self.index
+        with torch.no_grad():                                          # memory_moco.py:55-61
+            saved = eng.enqueue(self.memory, keys, index, save=True, stream=st)
+        self.index = (index + keys.shape[0]) % self.queueSize
+        loss = _MoCoLoss.apply(qc, kc, self, outs, saved, index)
+
+        def dense():
+            return eng.forward(qc.detach(), kc, self.memory, self.T, 0, dense=True, patch=saved, patch_index=index,
+                               stream=st)["out"]
+
+        return NCELogits(loss, outs["prob"].reshape(()), outs["pos"], (q.shape[0], self.queueSize + 1), dense)
+
+    def logits(self, q, k):
+        """Dense ``out`` of memory_moco.py:40-44 without the enqueue side effect (tests, debugging)."""
+        outs = self.engine().forward(q.detach().contiguous(), k.detach().contiguous(), self.memory, self.T, 0,
+                                     dense=True, stream=_stream(q))
+        return outs["out"]
+
+
+class NCESoftmaxLoss(nn.Module):
+    """criterions.py:5-17 (label 0)."""
+
+    def forward(self, x):
+        if isinstance(x, NCELogits):
+            return x.loss
+        raise TypeError("NCESoftmaxLoss expects the NCELogits returned by gcc_amd.contrast.MemoryMoCo")
+
+
+class NCESoftmaxLossNS(nn.Module):
+    """criterions.py:20-33 (labels on the diagonal).  ``x`` comes from :func:`e2e_logits`."""
+
+    def forward(self, x):
+        if isinstance(x, NCELogits):
+            return x.loss
+        raise TypeError("NCESoftmaxLossNS expects the NCELogits returned by gcc_amd.contrast.e2e_logits")
+
+
+def e2e_logits(feat_q, feat_k, T, engine=None):
+    """``torch.matmul(feat_k, feat_q.t()) / T`` of train.py:400, fused with its loss."""
+    eng = engine if engine is not None else NceEngine()
+    loss, prob = _NSLoss.apply(feat_q, feat_k, T, eng)
+
+    def dense():
+        return eng.forward(feat_k.detach().contiguous(), None, feat_q.detach().contiguous(), T, 1, dense=True,
+                           stream=_stream(feat_q))["out"]
+
+    B = feat_q.shape[0]
+    return NCELogits(loss, prob, None, (B, B), dense)

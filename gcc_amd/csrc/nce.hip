@@ -1,0 +1,361 @@
+// gcc_amd/csrc/nce.hip -- MoCo / InfoNCE head, queue enqueue, EMA (gfx950).
+//
+// Replaces MemoryMoCo.forward (gcc/contrastive/memory_moco.py:26-63: bmm/mm/cat/div/
+// clone/index_copy_), NCESoftmaxLoss / NCESoftmaxLossNS (gcc/contrastive/criterions.py:5-33:
+// CrossEntropyLoss over [B, K+1]) and moment_update (train.py:169-172).
+//
+//   nce_slice_kernel<false>  grid (S slices of the queue, B/64 query blocks).  The slice's rows
+//       are staged through LDS in 64-row chunks shared by the 4 waves; each wave owns 16 queries:
+//       logits tile = exact-f32 MFMA (queue rows x queries), online row-softmax (running max /
+//       sum) in registers; per-(slice, query) partials go to HBM.  K = 16384, B = 256: 537 MFLOP,
+//       4 MiB of queue read once per query block.
+//   nce_combine_kernel       merges the partials: lse, positive logit, mean loss, mean prob.
+//   nce_slice_kernel<true>   backward: recomputes the logits tile, p = exp(l - lse), and feeds it
+//       straight into a second MFMA (p^T x queue rows) -- the 4 logits a lane holds after the
+//       first MFMA are exactly the B-operand values it must supply to the second, so P never
+//       leaves registers.  Per-slice dq slabs are reduced in a fixed order by nce_dq_kernel.
+// [B, K+1] is only materialised when the caller asks for it (train.py indexes out[:, 0]).
+#include "host_common.h"
+
+namespace {
+
+constexpr int D = GCC_NCE_DIM;    // 64
+constexpr int kLd = 72;           // LDS row stride (floats)
+constexpr int kChunk = 64;        // queue rows per staged chunk
+constexpr int kThreads = 256;
+constexpr int kQPerBlock = 64;    // 4 waves x 16 queries
+
+struct F4 { float x, y, z, w; };
+__device__ __forceinline__ F4 ld4(const float *p)
+{
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    F4 r = {v.x, v.y, v.z, v.w};
+    return r;
+}
+__device__ __forceinline__ void st4(float *p, F4 v) { *reinterpret_cast<float4 *>(p) = make_float4(v.x, v.y, v.z, v.w); }
+
+struct NceDev {
+    const float *q, *k, *mem, *patch;
+    int32_t patch_index, patch_rows, B, K, pos_mode;
+    float inv_T;
+    float *lse, *pos, *loss, *prob, *out_dense;
+    int32_t S, R;             // slices and rows per slice (multiple of kChunk)
+    float *pm, *ps;           // [S][B] partial max / sum
+    float *slabs;             // [S][B][64] partial dq (backward)
+    const float *dloss;
+    int32_t by_mem_row;
+    float *dq;
+};
+
+struct Plan { int32_t S, R, QB; int64_t off_pm, off_ps, off_slabs, total; };
+
+inline Plan make_plan(int32_t B, int32_t K)
+{
+    Plan p;
+    p.QB = (B + kQPerBlock - 1) / kQPerBlock;
+    int s = (256 + p.QB - 1) / p.QB;
+    const int maxs = (K + kChunk - 1) / kChunk;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    p.R = (((K + s - 1) / s) + kChunk - 1) / kChunk * kChunk;
+    p.S = (K + p.R - 1) / p.R;
+    auto al = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
+    int64_t o = 0;
+    p.off_pm = o; o = al(o + (int64_t)p.S * B * 4);
+    p.off_ps = o; o = al(o + (int64_t)p.S * B * 4);
+    p.off_slabs = o; o = al(o + (int64_t)p.S * B * D * 4);
+    p.total = o;
+    return p;
+}
+
+__device__ __forceinline__ F4 load_mem4(const NceDev &a, int r, int c4)
+{
+    if (r >= a.K) { F4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+    if (a.patch) {
+        int rel = r - a.patch_index;
+        if (rel < 0) rel += a.K;
+        if (rel < a.patch_rows) return ld4(a.patch + (int64_t)rel * D + c4);
+    }
+    return ld4(a.mem + (int64_t)r * D + c4);
+}
+
+template <bool kBwd>
+__global__ __launch_bounds__(kThreads) void nce_slice_kernel(NceDev a)
+{
+    __shared__ float Ms[kChunk * kLd];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
+    const int s = (int)blockIdx.x;
+    const int qj = (int)blockIdx.y * kQPerBlock + 16 * wv + j;
+    const bool qvalid = qj < a.B;
+    F4 qf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        F4 z = {0.f, 0.f, 0.f, 0.f};
+        qf[c] = qvalid ? ld4(a.q + (int64_t)qj * D + 16 * c + 4 * q) : z;
+    }
+    const int row_beg = s * a.R, row_end = min(a.K, row_beg + a.R);
+    const int ld_out = a.K + (a.pos_mode == 0 ? 1 : 0), off_out = a.pos_mode == 0 ? 1 : 0;
+    float m = -INFINITY, ssum = 0.f;
+    float my_lse = 0.f;
+    if (kBwd && !a.by_mem_row && qvalid) my_lse = a.lse[qj];
+    f32x4 acc2[4];
+    if (kBwd) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc2[db] = z; }
+    }
+    for (int c0 = row_beg; c0 < row_end; c0 += kChunk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + kThreads * i, row = idx >> 4, c4 = (idx & 15) * 4;
+            st4(&Ms[row * kLd + c4], load_mem4(a, c0 + row, c4));
+        }
+        __syncthreads();
+        for (int t = 0; t < 4; ++t) {
+            if (c0 + 16 * t >= row_end) break;      // block-uniform
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const F4 mf = ld4(&Ms[(16 * t + j) * kLd + 16 * c + 4 * q]);
+                acc = mfma_16x16x4_f32(mf.x, qf[c].x, acc);
+                acc = mfma_16x16x4_f32(mf.y, qf[c].y, acc);
+                acc = mfma_16x16x4_f32(mf.z, qf[c].z, acc);
+                acc = mfma_16x16x4_f32(mf.w, qf[c].w, acc);
+            }
+            // acc[r] = mem[row0 + r] . q[qj], row0 = c0 + 16 t + 4 q
+            const int row0 = c0 + 16 * t + 4 * q;
+            float lv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float l = acc[r] * a.inv_T;                      // torch.div(out, self.T), memory_moco.py:43
+                const bool valid = row0 + r < row_end;
+                if (!kBwd && a.out_dense && qvalid && valid) a.out_dense[(int64_t)qj * ld_out + off_out + row0 + r] = l;
+                lv[r] = valid ? l : -INFINITY;
+            }
+            if (!kBwd) {
+                const float tmax = fmaxf(fmaxf(lv[0], lv[1]), fmaxf(lv[2], lv[3]));
+                if (tmax > -INFINITY) {
+                    const float mn = fmaxf(m, tmax);
+                    ssum = ssum * expf(m - mn) + expf(lv[0] - mn) + expf(lv[1] - mn) + expf(lv[2] - mn) + expf(lv[3] - mn);
+                    m = mn;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = 0.f;
+                    if (qvalid && lv[r] > -INFINITY) p = expf(lv[r] - (a.by_mem_row ? a.lse[row0 + r] : my_lse));
+                    // second GEMM: dq[query][d] += p[row][query] * mem[row][d]; this lane's p is the
+                    // B operand (k = q <-> row 4q + r, column j = query)
+#pragma unroll
+                    for (int db = 0; db < 4; ++db)
+                        acc2[db] = mfma_16x16x4_f32(Ms[(16 * t + 4 * q + r) * kLd + 16 * db + j], p, acc2[db]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!kBwd) {
+#pragma unroll
+        for (int d = 16; d <= 32; d <<= 1) {
+            const float m2 = wave_shfl_xor(m, d), s2 = wave_shfl_xor(ssum, d);
+            const float mn = fmaxf(m, m2);
+            ssum = mn > -INFINITY ? ssum * expf(m - mn) + s2 * expf(m2 - mn) : 0.f;
+            m = mn;
+        }
+        if (q == 0 && qvalid) {
+            a.pm[(int64_t)s * a.B + qj] = m;
+            a.ps[(int64_t)s * a.B + qj] = ssum;
+        }
+    } else if (qvalid) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            F4 o = {acc2[db][0], acc2[db][1], acc2[db][2], acc2[db][3]};
+            st4(a.slabs + ((int64_t)s * a.B + qj) * D + 16 * db + 4 * q, o);
+        }
+    }
+}
+
+__device__ __forceinline__ float dot64(const float *x, const float *y)
+{
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s = fmaf(x[d], y[d], s);
+    return s;
+}
+
+__global__ __launch_bounds__(kThreads) void nce_combine_kernel(NceDev a)
+{
+    __shared__ double red[2 * kThreads];
+    const int tid = (int)threadIdx.x;
+    double lsum = 0.0, psum = 0.0;
+    const int ld_out = a.K + (a.pos_mode == 0 ? 1 : 0);
+    for (int b = tid; b < a.B; b += kThreads) {
+        float pos, M, sum;
+        if (a.pos_mode == 0) {                       // l_pos = bmm(q, k), memory_moco.py:33-34
+            pos = dot64(a.q + (int64_t)b * D, a.k + (int64_t)b * D) * a.inv_T;
+            if (a.out_dense) a.out_dense[(int64_t)b * ld_out] = pos;
+            M = pos;
+        } else {                                     // positives on the diagonal, criterions.py:30-31
+            pos = dot64(a.q + (int64_t)b * D, a.mem + (int64_t)b * D) * a.inv_T;
+            M = -INFINITY;
+        }
+        for (int s = 0; s < a.S; ++s) M = fmaxf(M, a.pm[(int64_t)s * a.B + b]);
+        sum = a.pos_mode == 0 ? expf(pos - M) : 0.f;
+        for (int s = 0; s < a.S; ++s) {
+            const float pmv = a.pm[(int64_t)s * a.B + b];
+            if (pmv > -INFINITY) sum += a.ps[(int64_t)s * a.B + b] * expf(pmv - M);
+        }
+        const float lse = M + logf(sum);
+        a.lse[b] = lse;
+        a.pos[b] = pos;
+        lsum += (double)(lse - pos);                 // CrossEntropyLoss row term
+        psum += (double)pos;
+    }
+    red[tid] = lsum;
+    red[kThreads + tid] = psum;
+    __syncthreads();
+    for (int d = kThreads >> 1; d > 0; d >>= 1) {
+        if (tid < d) { red[tid] += red[tid + d]; red[kThreads + tid] += red[kThreads + tid + d]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.loss[0] = (float)(red[0] / (double)a.B);           // reduction="mean"
+        a.prob[0] = (float)(red[kThreads] / (double)a.B);    // out[:, 0].mean(), train.py:394
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void nce_dq_kernel(NceDev a)
+{
+    const int gid = (int)blockIdx.x * kThreads + (int)threadIdx.x;
+    const int b = gid >> 4, c4 = (gid & 15) * 4;
+    if (b >= a.B) return;
+    F4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < a.S; ++sl) {
+        const F4 v = ld4(a.slabs + ((int64_t)sl * a.B + b) * D + c4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int nrows = a.by_mem_row ? a.K : a.B;              // rows of the softmax that is averaged
+    const float coef = a.dloss[0] * a.inv_T / (float)nrows;
+    F4 o;
+    if (a.pos_mode == 0) {
+        const float pp = expf(a.pos[b] - a.lse[b]) - 1.f;
+        const F4 kv = ld4(a.k + (int64_t)b * D + c4);
+        o.x = coef * (s.x + pp * kv.x); o.y = coef * (s.y + pp * kv.y);
+        o.z = coef * (s.z + pp * kv.z); o.w = coef * (s.w + pp * kv.w);
+    } else {
+        const F4 mv = ld4(a.mem + (int64_t)b * D + c4);
+        o.x = coef * (s.x - mv.x); o.y = coef * (s.y - mv.y); o.z = coef * (s.z - mv.z); o.w = coef * (s.w - mv.w);
+    }
+    st4(a.dq + (int64_t)b * D + c4, o);
+}
+
+__global__ __launch_bounds__(kThreads) void queue_enqueue_kernel(float *mem, int K, const float *keys, int nkeys,
+                                                                 int index, float *saved)
+{
+    const int gid = (int)blockIdx.x * kThreads + (int)threadIdx.x;
+    const int i = gid >> 4, c4 = (gid & 15) * 4;
+    if (i >= nkeys) return;
+    const int row = (index + i) % K;                          // torch.fmod(out_ids + index, queueSize)
+    if (saved) st4(saved + (int64_t)i * D + c4, ld4(mem + (int64_t)row * D + c4));
+    st4(mem + (int64_t)row * D + c4, ld4(keys + (int64_t)i * D + c4));
+}
+
+__global__ __launch_bounds__(kThreads) void ema_kernel(float *ema, const float *p, int64_t n, float m)
+{
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride)
+        ema[i] = ema[i] * m + (1.f - m) * p[i];               // p2.mul_(m).add_(1 - m, p1)
+}
+
+inline int fill_dev(const gcc_nce_args *a, void *workspace, int64_t workspace_bytes, NceDev &d, Plan &pl)
+{
+    if (!a || !a->q || !a->mem || a->B < 1 || a->K < 1 || (a->pos_mode == 0 && !a->k) ||
+        (a->pos_mode == 1 && a->K < a->B) || !a->lse || !a->pos) {
+        snprintf(g_err, kErrLen, "gcc_nce: bad argument");
+        return -1;
+    }
+    pl = make_plan(a->B, a->K);
+    if (!workspace || workspace_bytes < pl.total) {
+        snprintf(g_err, kErrLen, "gcc_nce: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)pl.total);
+        return -3;
+    }
+    d.q = a->q; d.k = a->k; d.mem = a->mem; d.patch = a->patch;
+    d.patch_index = a->patch_index; d.patch_rows = a->patch ? a->patch_rows : 0;
+    d.B = a->B; d.K = a->K; d.pos_mode = a->pos_mode; d.inv_T = a->inv_T;
+    d.lse = a->lse; d.pos = a->pos; d.loss = a->loss; d.prob = a->prob; d.out_dense = a->out_dense;
+    d.S = pl.S; d.R = pl.R;
+    char *base = (char *)workspace;
+    d.pm = (float *)(base + pl.off_pm); d.ps = (float *)(base + pl.off_ps); d.slabs = (float *)(base + pl.off_slabs);
+    d.dloss = nullptr; d.by_mem_row = 0; d.dq = nullptr;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t gcc_nce_workspace_bytes(int32_t B, int32_t K)
+{
+    if (B < 1 || K < 1) { snprintf(g_err, kErrLen, "gcc_nce_workspace_bytes: bad argument"); return -1; }
+    return make_plan(B, K).total;
+}
+
+int32_t gcc_nce_forward(const gcc_nce_args *a, void *workspace, int64_t workspace_bytes, gcc_prof *prof, void *stream)
+{
+    NceDev d;
+    Plan pl;
+    int rc = fill_dev(a, workspace, workspace_bytes, d, pl);
+    if (rc) return rc;
+    if (!a->loss || !a->prob) { snprintf(g_err, kErrLen, "gcc_nce_forward: loss/prob are required"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    prof_mark(prof, 0, s);
+    hipLaunchKernelGGL((nce_slice_kernel<false>), dim3(pl.S, pl.QB), dim3(kThreads), 0, s, d);
+    hipLaunchKernelGGL(nce_combine_kernel, dim3(1), dim3(kThreads), 0, s, d);
+    prof_mark(prof, 1, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_nce_forward: %s", hipGetErrorString(e)); return -10; }
+    return 0;
+}
+
+int32_t gcc_nce_backward(const gcc_nce_args *a, const float *dloss, int32_t by_mem_row, float *dq, void *workspace,
+                         int64_t workspace_bytes, gcc_prof *prof, void *stream)
+{
+    NceDev d;
+    Plan pl;
+    int rc = fill_dev(a, workspace, workspace_bytes, d, pl);
+    if (rc) return rc;
+    if (!dloss || !dq || (by_mem_row && a->pos_mode != 1)) {
+        snprintf(g_err, kErrLen, "gcc_nce_backward: bad argument");
+        return -1;
+    }
+    d.dloss = dloss; d.by_mem_row = by_mem_row; d.dq = dq;
+    hipStream_t s = (hipStream_t)stream;
+    prof_mark(prof, 0, s);
+    hipLaunchKernelGGL((nce_slice_kernel<true>), dim3(pl.S, pl.QB), dim3(kThreads), 0, s, d);
+    hipLaunchKernelGGL(nce_dq_kernel, dim3((a->B * 16 + kThreads - 1) / kThreads), dim3(kThreads), 0, s, d);
+    prof_mark(prof, 1, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_nce_backward: %s", hipGetErrorString(e)); return -10; }
+    return 0;
+}
+
+int32_t gcc_queue_enqueue(float *mem, int32_t K, const float *keys, int32_t nkeys, int32_t index, float *saved,
+                          void *stream)
+{
+    if (!mem || !keys || K < 1 || nkeys < 1 || nkeys > K || index < 0 || index >= K) {
+        snprintf(g_err, kErrLen, "gcc_queue_enqueue: bad argument (K=%d n=%d index=%d)", K, nkeys, index);
+        return -1;
+    }
+    hipLaunchKernelGGL(queue_enqueue_kernel, dim3((nkeys * 16 + kThreads - 1) / kThreads), dim3(kThreads), 0,
+                       (hipStream_t)stream, mem, K, keys, nkeys, index, saved);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
+int32_t gcc_ema_update(float *ema, const float *p, int64_t n, float m, void *stream)
+{
+    if (!ema || !p || n < 1) { snprintf(g_err, kErrLen, "gcc_ema_update: bad argument"); return -1; }
+    int blocks = (int)((n + kThreads - 1) / kThreads);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(ema_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, ema, p, n, m);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
+}  // extern "C"

@@ -168,8 +168,9 @@ class GinEngine:
             raise RuntimeError(f"gcc_gin_forward failed ({rc}): {self.lib.gcc_last_error().decode()}")
 
 
-    def backward(self, enc, p, buf, dfeat, accumulate=False, stream=None, prof=None):
-        """Backward of a training-mode pass: fills ``param.grad`` of every live parameter of ``enc``."""
+    def backward(self, enc, p, buf, dfeat, targets=None, accumulate=False, stream=None, prof=None):
+        """Backward of a training-mode pass.  Gradients are written (or added, ``accumulate``) into
+        ``targets`` (tensors in :func:`grad_params` order); by default into each ``param.grad``."""
         ptr = self.ptr
         L = len(enc.gnn.ginlayers)
         g = buf["_keepalive"][0]
@@ -180,25 +181,24 @@ class GinEngine:
             self._bufs[key] = torch.empty(nbytes, dtype=torch.uint8, device=dfeat.device)
         ws = self._bufs[key]
         grads = _cabi.GccGinGrads()
-        keep = []
-        for name, idx, param in grad_params(enc):
-            if param.grad is None:
-                param.grad = torch.zeros_like(param)
-                fresh = True
-            else:
-                fresh = False
-            keep.append(param.grad)
+        plist = grad_params(enc)
+        if targets is None:
+            targets = []
+            for _, _, param in plist:
+                if param.grad is None:
+                    param.grad = torch.zeros_like(param)
+                targets.append(param.grad)
+        for (name, idx, _), tgt in zip(plist, targets):
             if idx is None:
-                setattr(grads, name, ptr(param.grad))
+                setattr(grads, name, ptr(tgt))
             else:
-                getattr(grads, name)[idx] = ptr(param.grad)
-            del fresh
+                getattr(grads, name)[idx] = ptr(tgt)
         dfeat = dfeat.contiguous()
         rc = self.lib.gcc_gin_backward(ctypes.byref(p), ptr(dfeat), ctypes.byref(grads), int(accumulate),
                                        ptr(ws), nbytes, node_cap, prof.handle if prof is not None else None, stream)
         if rc != 0:
             raise RuntimeError(f"gcc_gin_backward failed ({rc}): {self.lib.gcc_last_error().decode()}")
-        return keep
+        return targets
 
 
 class GraphEncoder(nn.Module):
@@ -235,6 +235,7 @@ class GraphEncoder(nn.Module):
         self.norm = norm
         self._engine = None
         self._slot = id(self)
+        self._calls = 0
 
     def engine(self) -> GinEngine:
         if self._engine is None:

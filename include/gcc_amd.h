@@ -186,6 +186,46 @@ int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat, const gcc
                          int32_t accumulate, void *workspace, int64_t workspace_bytes, int64_t node_cap,
                          gcc_prof *prof, void *stream);
 
+/* ------------------------------------------------------- MoCo / InfoNCE head ---
+ * MemoryMoCo.forward (gcc/contrastive/memory_moco.py:26-63, use_softmax=True) fused
+ * with NCESoftmaxLoss (gcc/contrastive/criterions.py:12-17), and the E2E variant
+ * out = feat_k feat_q^T / T with NCESoftmaxLossNS (train.py:400, criterions.py:27-33).
+ * logits[b][j] = q_b . mem_j * inv_T; the positive is an extra column q_b . k_b
+ * (pos_mode 0) or the diagonal column j == b (pos_mode 1).  The [B, K+1] logits are
+ * only written when out_dense != NULL; loss/backward use an online row-softmax. */
+#define GCC_NCE_DIM 64
+typedef struct gcc_nce_args {
+    const float *q;          /* device [B, 64] rows whose softmax is taken                      */
+    const float *k;          /* device [B, 64] positives (pos_mode 0) or NULL                   */
+    const float *mem;        /* device [K, 64] negatives: the queue, or the other view (E2E)    */
+    const float *patch;      /* device [patch_rows, 64] or NULL: rows patch_index.. (mod K) of   */
+    int32_t patch_index;     /*   mem are read from here (queue rows already overwritten by the */
+    int32_t patch_rows;      /*   enqueue that follows the forward, memory_moco.py:55-61)       */
+    int32_t B, K;
+    int32_t pos_mode;        /* 0: MoCo, 1: E2E diagonal                                        */
+    float inv_T;             /* 1 / nce_t (train.py:87)                                         */
+    float *lse, *pos;        /* device [B] out: row log-sum-exp and positive logit               */
+    float *loss, *prob;      /* device [1] out: mean(lse - pos) and mean(pos) (train.py:394,407) */
+    float *out_dense;        /* device [B, K + (pos_mode == 0)] or NULL                         */
+} gcc_nce_args;
+
+int64_t gcc_nce_workspace_bytes(int32_t B, int32_t K);
+int32_t gcc_nce_forward(const gcc_nce_args *a, void *workspace, int64_t workspace_bytes, gcc_prof *prof,
+                        void *stream);
+/* dq[b] = dloss / (B T) * (sum_j p_bj mem_j + [pos_mode 0] (p_b,pos - 1) k_b - [pos_mode 1] mem_b).
+ * by_mem_row != 0 computes the gradient w.r.t. the OTHER operand of the E2E product instead:
+ * call it with q/mem swapped; p is then normalised with lse[mem row] (args->lse has K entries). */
+int32_t gcc_nce_backward(const gcc_nce_args *a, const float *dloss, int32_t by_mem_row, float *dq,
+                         void *workspace, int64_t workspace_bytes, gcc_prof *prof, void *stream);
+
+/* memory.index_copy_(0, (arange(n) + index) % K, keys) of memory_moco.py:55-61; when saved != NULL
+ * the overwritten rows are first copied there (the `patch` of gcc_nce_args). */
+int32_t gcc_queue_enqueue(float *mem, int32_t K, const float *keys, int32_t nkeys, int32_t index, float *saved,
+                          void *stream);
+
+/* moment_update of train.py:169-172 over one flat parameter buffer: ema = m * ema + (1 - m) * p */
+int32_t gcc_ema_update(float *ema, const float *p, int64_t n, float m, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

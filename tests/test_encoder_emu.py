@@ -137,3 +137,36 @@ def test_backward_accumulates_for_e2e_two_passes():
     for n, ref in g["grads"].items():
         scale = max(float(ref.abs().max()), 1e-3)
         torch.testing.assert_close(got[n], ref, rtol=2e-3, atol=max(2e-4 * scale, 1e-6), msg=n)
+
+
+def test_api_path_autograd_matches_golden(monkeypatch):
+    """model(graph) -> contrast -> criterion -> loss.backward() exactly as train.py:389-408 spells it."""
+    from gcc_amd.contrast import MemoryMoCo, NCESoftmaxLoss
+    from tests.test_nce_emu import emu_nce
+
+    g = GOLD["moco"]
+    model, ema = reference_encoder(), reference_encoder()
+    model.load_state_dict(g["init"]["model"])
+    ema.load_state_dict(g["init"]["model_ema"])
+    model._engine = ema._engine = emu_engine()
+    model.train()
+    _set_bn_train(ema)
+    contrast = MemoryMoCo(64, None, g["K"], g["T"], use_softmax=True)
+    contrast._engine = emu_nce()
+    contrast.memory.copy_(g["init"]["memory"])
+    masks = g["masks"].contiguous()
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: masks.clone())    # keep = (rand >= 0.5) reproduces the golden masks
+    bq, bk = CpuBatch(GOLD["views"][0]), CpuBatch(GOLD["views"][1])
+    feat_q = model(bq)
+    with torch.no_grad():
+        feat_k = ema(bk)
+    out = contrast(feat_q, feat_k)
+    loss = NCESoftmaxLoss()(out)
+    loss.backward()
+    torch.testing.assert_close(loss.detach(), g["loss"], rtol=1e-4, atol=1e-5)
+    got = _grads_after_backward(model)
+    for n, ref in g["grads"].items():
+        scale = max(float(ref.abs().max()), 1e-3)
+        torch.testing.assert_close(got[n], ref, rtol=2e-3, atol=max(2e-4 * scale, 1e-6), msg=n)
+    # parameters the reference leaves without gradient (set2set, lin_readout) stay that way
+    assert all(p.grad is None for n, p in model.named_parameters() if n.startswith(("set2set", "lin_readout")))
