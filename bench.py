@@ -66,31 +66,94 @@ def sampler_algorithmic_bytes(rp, views):
     return dict(walk=walk, induce=induce, pack=pack, total=walk + induce + pack)
 
 
+def _posemb_init():
+    os.environ["OMP_NUM_THREADS"] = "1"          # one ARPACK process per core, no BLAS oversubscription
+    os.environ["MKL_NUM_THREADS"] = "1"
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
+
+
+def _posemb_chunk(job):
+    from oracle import posemb as P
+
+    node_off, row_ptr, col_idx, seed = job
+    return P.batched_positional_embedding(node_off, row_ptr, col_idx, 32, seed=seed)
+
+
 def cpu_baseline(rp, ci, args):
-    """Reference-shaped CPU path on this box's host cores: the C oracle of the
-    sampler (oracle/sampler_oracle.c, OpenMP over subgraphs) -- "port" kind."""
+    """The reference-shaped CPU path on this box's host cores ("port" kind): C oracle of the
+    sampler (OpenMP over subgraphs) + SciPy ARPACK positional embedding (data_util.py:242-281, one
+    process per core like the reference's DataLoader workers) + the torch-CPU oracle of
+    encoder/head/Adam/EMA (train.py:378-431)."""
+    import multiprocessing as mp
+
+    import torch
+
+    from oracle import encoder as E
     from oracle import sampler as O
 
     c = O.COracle()
-    threads = min(c.max_threads(), os.cpu_count() or 1)
+    cores = os.cpu_count() or 1
+    threads = min(c.max_threads(), cores)
+    workers = cores
+    torch.set_num_threads(min(cores, 32))
     cdf = O.seed_cdf(rp)
     lt = O.max_nodes_table(int(np.diff(rp).max()), args.rw_hops, args.restart_prob)
     thr = O.restart_threshold(args.restart_prob)
-    B = 4096
-    done, t0, first = 0, time.perf_counter(), 10_000_000
-    while True:
-        seeds = c.draw_seeds(cdf, args.run_seed, first, B)
-        L = lt[np.diff(rp)[seeds]]
-        for view in range(2):
-            c.sample_batch(rp, ci, seeds, L, view, args.run_seed, first, thr, threads=threads)
-        done += 2 * B
-        first += B
-        dt = time.perf_counter() - t0
-        if dt >= args.cpu_seconds:
-            break
-    return dict(value=done / dt, unit="subgraphs/s", cores=threads, kind="port",
-                sample=f"{done} subgraphs (sampler stages only: walk+unique+induce+batch) in {dt:.1f}s, "
-                       f"oracle/sampler_oracle.c, OpenMP x{threads}")
+    B = args.batch_size
+    model, ema = E.OracleGraphEncoder(), E.OracleGraphEncoder()
+    ema.load_state_dict(model.state_dict())
+    memory = E.memory_init(args.nce_k, 64)
+    opt = torch.optim.Adam(model.parameters(), lr=0.005, betas=(0.9, 0.999), weight_decay=1e-5)
+    model.train()
+    ema.train()
+    index, done, first = 0, 0, 10_000_000
+    pool = mp.get_context("spawn").Pool(workers, initializer=_posemb_init)
+    try:
+        pool.map(_posemb_chunk, [(np.array([0, 3]), np.array([0, 2, 4, 6]), np.array([1, 2, 0, 2, 0, 1]), 0)] * workers)   # import scipy in every worker before the clock
+        t0 = time.perf_counter()
+        while True:
+            seeds = c.draw_seeds(cdf, args.run_seed, first, B)
+            L = lt[np.diff(rp)[seeds]]
+            views = []
+            for view in range(2):
+                r = c.sample_batch(rp, ci, seeds, L, view, args.run_seed, first, thr, threads=threads)
+                nb = len(r["node_off"]) - 1
+                cuts = np.linspace(0, nb, workers + 1).astype(int)
+                jobs = []
+                for w in range(workers):
+                    lo, hi = cuts[w], cuts[w + 1]
+                    if hi > lo:
+                        n0, n1 = r["node_off"][lo], r["node_off"][hi]
+                        e0, e1 = r["row_ptr"][n0], r["row_ptr"][n1]
+                        jobs.append((r["node_off"][lo:hi + 1] - n0, r["row_ptr"][n0:n1 + 1] - e0,
+                                     r["col_idx"][e0:e1] - n0, first + w))
+                pos = np.concatenate(pool.map(_posemb_chunk, jobs))
+                views.append((r, torch.from_numpy(pos)))
+            keep = (torch.rand(5, B, 64) >= 0.5).float()
+            (rq, pq), (rk, pk) = views
+            fq = model(rq["node_off"].astype(np.int64), rq["row_ptr"].astype(np.int64),
+                       rq["col_idx"].astype(np.int64), pq, dropout_masks=keep)
+            with torch.no_grad():
+                fk = ema(rk["node_off"].astype(np.int64), rk["row_ptr"].astype(np.int64),
+                         rk["col_idx"].astype(np.int64), pk)
+            out, index = E.moco_forward(memory, index, fq, fk, 0.07)
+            loss = E.nce_softmax_loss(out)
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            E.moment_update(model, ema, 0.999)
+            done += 2 * B
+            first += B
+            dt = time.perf_counter() - t0
+            if dt >= args.cpu_seconds:
+                break
+    finally:
+        pool.terminate()
+    return dict(value=done / dt, unit="subgraphs/s", cores=cores, kind="port",
+                sample=f"{done // (2 * B)} full steps of bsz {B} ({done} subgraphs) in {dt:.1f}s: C sampler oracle "
+                       f"(OpenMP x{threads}) + SciPy eigsh pos-emb ({workers} processes) + torch-CPU "
+                       f"encoder/MoCo/Adam/EMA oracle ({torch.get_num_threads()} threads)")
 
 
 def main():
@@ -116,34 +179,60 @@ def main():
     from gcc_amd.prof import Prof
     from gcc_amd.sampler import DeviceRWRSampler
 
+    from gcc_amd.contrast import MemoryMoCo
+    from gcc_amd.encoder import GraphEncoder
+    from gcc_amd.misc import warmup_linear
+    from gcc_amd.posemb import PlaceholderPosEmb
+    from gcc_amd.train_step import MoCoTrainStep
+
     rp, ci = powerlaw_graph(args.nodes, args.edges, seed=0)
     graph = DeviceGraph(rp, ci, rw_hops=args.rw_hops, restart_prob=args.restart_prob, device=dev, validate=False)
     B = args.batch_size
+    torch.manual_seed(0)
     sampler = DeviceRWRSampler(graph, B, run_seed=args.run_seed)
-    stages = ["seed-draw", "rwr-walk", "induce", "batch-pack"]
+    enc_kw = dict(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
+                  freq_embedding_size=16, degree_embedding_size=16, output_dim=64, node_hidden_dim=64,
+                  edge_hidden_dim=64, num_layers=5, num_step_set2set=6, num_layer_set2set=3, norm=True,
+                  gnn_model="gin", degree_input=True)                 # train.py:601-618 with default flags
+    model, model_ema = GraphEncoder(**enc_kw).to(dev), GraphEncoder(**enc_kw).to(dev)
+    model_ema.load_state_dict(model.state_dict())                     # moment_update(model, model_ema, 0), train.py:624
+    contrast = MemoryMoCo(64, None, args.nce_k, 0.07, use_softmax=True).to(dev)
+    posemb = PlaceholderPosEmb(sampler.node_cap, 32, device=dev)
+    trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank)
+    stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder q+k fwd",
+              "moco-infonce fwd", "key all-gather" if world > 1 else "enqueue", "infonce bwd", "gin-encoder bwd",
+              "grad all-reduce" if world > 1 else "clip", "adam", "ema"]
+    n_batch = 2000 * 12 // 32                                          # train.py:356 with default flags
+    total_steps = 100 * n_batch
+
+    def lr_at(step):
+        return 0.005 * warmup_linear(step / total_steps, 0.1)          # train.py:411-414
+
+    names = ("gin_fwd", "nce_fwd", "nce_bwd", "gin_bwd")
 
     def first_id(step):
         return (step * world + rank) * B
 
     def step_fn(step, prof=None):
-        return sampler.sample(first_id(step), prof=prof)
+        return trainer.step(step, lr_at(step), prof=prof)
 
     for i in range(args.warmup):
         step_fn(i)
-    profs = [Prof(4) for _ in range(args.steps)]
+    profs = [dict(sampler=Prof(4), **{n: Prof(2) for n in names}) for _ in range(args.steps)]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step_fn(args.warmup + i, prof=profs[i])
+        last = step_fn(args.warmup + i, prof=profs[i])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     sampler.check_status()
+    final_loss = float(last["loss"].item())
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -151,16 +240,19 @@ def main():
 
     if rank == 0:
         # live per-kernel durations (HIP events recorded on the launch stream inside the timed region)
-        k_ms = np.array([[p.elapsed_ms(j, j + 1) for j in range(3)] for p in profs])
+        # (the sampler marks of timed step i belong to the batch prefetched for step i + 1)
+        k_ms = np.array([[p["sampler"].elapsed_ms(j, j + 1) for j in range(3)] for p in profs])
         kern = dict(rwr_walk_kernel=float(k_ms[:, 0].mean()), induce_kernel=float(k_ms[:, 1].mean()),
                     pack_kernel=float(k_ms[:, 2].mean()))
+        stage_ms = {n: float(np.mean([p[n].elapsed_ms(0, 1) for p in profs])) for n in names}
+        stage_ms["sampler"] = float(k_ms.sum(axis=1).mean())
         # algorithmic bytes of the timed steps (recomputed post hoc: sampling is deterministic)
         from oracle import sampler as O   # checker side only: L table for the byte count
         lt = O.max_nodes_table(int(np.diff(rp).max()), args.rw_hops, args.restart_prob)
         nsample = min(args.steps, 8)
         acc = dict(walk=0, induce=0, pack=0, total=0)
         for i in range(nsample):
-            q, k = step_fn(args.warmup + i)
+            q, k = sampler.sample(first_id(args.warmup + i))
             seeds = sampler.last_seeds().cpu().numpy()
             L = lt[np.diff(rp)[seeds]]
             b = sampler_algorithmic_bytes(rp, [(q.csr_numpy(), L), (k.csr_numpy(), L)])
@@ -172,7 +264,7 @@ def main():
         out = {
             "metric": "sampled-subgraphs/sec", "value": 2 * B * world * args.steps / dt, "unit": "subgraphs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 sampler / f32 encoder+head (exact-f32 MFMA)",
             "data": "synthetic",
             "steps_per_sec": args.steps / dt,
             "config": {"workload": "BASELINE configs[1]: MoCo K=16384 bsz=256 rw_hops=256 restart=0.8, "
@@ -181,7 +273,7 @@ def main():
                        "batch_size_per_gpu": B, "global_batch": B * world, "nce_k": args.nce_k,
                        "rw_hops": args.rw_hops, "restart_prob": args.restart_prob,
                        "stages": stages, "parallelism": f"dp{world} (seed batch sharded, graph replicated)"},
-            "kernel_ms": kern,
+            "kernel_ms": kern, "stage_ms": stage_ms, "final_loss": final_loss,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": acc["induce"], "traffic": args.pmc_traffic},

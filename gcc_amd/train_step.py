@@ -1,0 +1,174 @@
+"""One MoCo pre-training step of train.py:378-434 as a fixed sequence of HIP
+launches with no host synchronisation (the reference calls
+``torch.cuda.synchronize()`` every step, train.py:433).
+
+    sample(q, k) [side stream, one step ahead] -> positional embedding ->
+    encoder(q; model) + encoder(k; model_ema) in shared launches -> MoCo/InfoNCE
+    head (+ key all-gather, enqueue) -> head backward -> encoder backward ->
+    (gradient all-reduce) -> clip + Adam -> EMA
+
+Parameters of ``model`` and ``model_ema`` are re-homed into flat buffers so that
+the optimiser, the gradient all-reduce and the EMA are one launch/collective
+each; ``state_dict()`` is unaffected.
+"""
+from __future__ import annotations
+
+import torch
+
+from .contrast import MemoryMoCo, NceEngine
+from .encoder import GraphEncoder, H, grad_params
+
+
+def flatten_parameters(enc: GraphEncoder):
+    """Re-home every parameter of ``enc`` into one flat fp32 buffer, live parameters
+    (those that receive gradients on the GIN path, :func:`grad_params` order) first.
+    Returns (flat, n_live).  Idempotent."""
+    if getattr(enc, "_flat", None) is not None:
+        return enc._flat, enc._n_live
+    live = [p for _, _, p in grad_params(enc)]
+    live_ids = {id(p) for p in live}
+    dead = [p for p in enc.parameters() if id(p) not in live_ids]     # set2set.*, lin_readout.* (unused by GIN)
+    n_live = sum(p.numel() for p in live)
+    total = n_live + sum(p.numel() for p in dead)
+    dev = live[0].device
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    off = 0
+    with torch.no_grad():
+        for p in live + dead:
+            n = p.numel()
+            flat[off:off + n].copy_(p.reshape(-1))
+            p.data = flat[off:off + n].view_as(p)
+            off += n
+    enc._flat, enc._n_live = flat, n_live
+    return flat, n_live
+
+
+def moment_update(model, model_ema, m, engine: NceEngine | None = None):
+    """train.py:169-172: model_ema = m * model_ema + (1 - m) * model over ALL parameters
+    (the reference also averages the unused set2set / lin_readout weights)."""
+    eng = engine or NceEngine()
+    f1, f2 = getattr(model, "_flat", None), getattr(model_ema, "_flat", None)
+    if f1 is not None and f2 is not None and f1.numel() == f2.numel():
+        st = torch.cuda.current_stream(f1.device).cuda_stream if f1.is_cuda else None
+        eng.ema(f2, f1, m, stream=st)
+        return
+    for p1, p2 in zip(model.parameters(), model_ema.parameters()):
+        st = torch.cuda.current_stream(p2.device).cuda_stream if p2.is_cuda else None
+        eng.ema(p2.data, p1.detach().data.contiguous(), m, stream=st)
+
+
+def clip_grad_norm(params, max_norm):
+    """train.py:340-347."""
+    if max_norm > 0:
+        return torch.nn.utils.clip_grad_norm_(params, max_norm)
+    return torch.sqrt(sum(p.grad.data.norm() ** 2 for p in params if p.grad is not None))
+
+
+class MoCoTrainStep:
+    def __init__(self, model: GraphEncoder, model_ema: GraphEncoder, contrast: MemoryMoCo, sampler, posemb,
+                 learning_rate=0.005, betas=(0.9, 0.999), weight_decay=1e-5, clip_norm=1.0, alpha=0.999,
+                 world_size=1, rank=0, prefetch=True):
+        self.model, self.ema, self.contrast = model, model_ema, contrast
+        self.sampler, self.posemb = sampler, posemb
+        self.clip_norm, self.alpha = clip_norm, alpha
+        self.world, self.rank = world_size, rank
+        self.dev = next(model.parameters()).device
+        self.flat, self.n_live = flatten_parameters(model)
+        self.flat_ema, n2 = flatten_parameters(model_ema)
+        assert n2 == self.n_live and self.flat.numel() == self.flat_ema.numel()
+        # gradient buffer: views in grad_params order
+        self.flat_grad = torch.zeros(self.n_live, dtype=torch.float32, device=self.dev)
+        self.grad_views, off = [], 0
+        for _, _, p in grad_params(model):
+            self.grad_views.append(self.flat_grad[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.live = self.flat[: self.n_live]
+        self.live.grad = self.flat_grad
+        # Adam(lr, betas, weight_decay as L2) over exactly the parameters that get gradients, train.py:667-672
+        self.optimizer = torch.optim.Adam([self.live], lr=learning_rate, betas=betas, weight_decay=weight_decay,
+                                          fused=self.dev.type == "cuda")
+        self.gin = model.engine()
+        self.nce = contrast.engine()
+        self.B = sampler.batch_size
+        self.L = len(model.gnn.ginlayers)
+        self.keys_all = torch.empty(self.B * world_size, H, device=self.dev) if world_size > 1 else None
+        self.one = torch.ones(1, device=self.dev)
+        self.prefetch = prefetch and self.dev.type == "cuda"
+        self.side = torch.cuda.Stream(self.dev) if self.prefetch else None
+        self._ready = None           # (graphs, event) of the prefetched batch
+        self._done = [None, None]    # main-stream completion events of the two ring slots
+        self._slot = 0
+        self._prof = None
+        model.train()                                                    # train.py:357-365
+        model_ema.eval()
+        for mod in model_ema.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.train()
+
+    # ---- data: sampler + positional embedding, one step ahead on a side stream
+    def _produce(self, first_id):
+        q, k = self.sampler.sample(first_id, prof=self._prof.get("sampler") if self._prof else None)
+        self.posemb(q)
+        self.posemb(k)
+        return q, k
+
+    def _first_id(self, step):
+        return (step * self.world + self.rank) * self.B
+
+    def _next_batch(self, step):
+        if not self.prefetch:
+            return self._produce(self._first_id(step))
+        if self._ready is None or self._ready[0] != step:
+            self._launch_prefetch(step)
+        _, graphs, ev = self._ready
+        torch.cuda.current_stream(self.dev).wait_event(ev)
+        self._launch_prefetch(step + 1)
+        return graphs
+
+    def _launch_prefetch(self, step):
+        slot = step % 2
+        with torch.cuda.stream(self.side):
+            if self._done[slot] is not None:
+                self.side.wait_event(self._done[slot])       # the ring slot's previous user has finished
+            graphs = self._produce(self._first_id(step))
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self._ready = (step, graphs, ev)
+
+    # ---- one step
+    def step(self, step, lr, prof=None):
+        """``prof``: optional dict of gcc_amd.prof.Prof (sampler: 4 marks; gin_fwd/nce_fwd/nce_bwd/gin_bwd: 2)."""
+        self._prof = prof
+        pr = prof or {}
+        q, k = self._next_batch(step)
+        st = torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else None
+        p_drop = self.model.gnn.drop.p
+        keep = (torch.rand(self.L + 1, self.B, H, device=self.dev) >= p_drop).float() if p_drop > 0 else None
+        pq, bufq = self.gin.make_pass(self.model, q, training=True, keep=keep, slot=("step", 0))
+        pk, bufk = self.gin.make_pass(self.ema, k, training=True, keep=None, slot=("step", 1))
+        self.gin.forward([pq, pk], stream=st, prof=pr.get("gin_fwd"))      # train.py:389-391
+        feat_q, feat_k = bufq["feat"], bufk["feat"]
+        c = self.contrast
+        outs = self.nce.forward(feat_q, feat_k, c.memory, c.T, 0, stream=st, prof=pr.get("nce_fwd"))   # train.py:393,407
+        keys = feat_k
+        if self.world > 1:                                               # RCCL all-gather of keys over xGMI
+            torch.distributed.all_gather_into_tensor(self.keys_all, feat_k)
+            keys = self.keys_all
+        index = c.index
+        saved = self.nce.enqueue(c.memory, keys, index, save=True, stream=st)
+        c.index = (index + keys.shape[0]) % c.queueSize
+        dq = self.nce.backward(feat_q, feat_k, c.memory, c.T, 0, outs, self.one, patch=saved, patch_index=index,
+                               stream=st, prof=pr.get("nce_bwd"))         # loss.backward(), train.py:408
+        self.gin.backward(self.model, pq, bufq, dq, targets=self.grad_views, stream=st, prof=pr.get("gin_bwd"))
+        if self.world > 1:
+            torch.distributed.all_reduce(self.flat_grad, op=torch.distributed.ReduceOp.AVG)
+        gnorm = clip_grad_norm([self.live], self.clip_norm)             # train.py:409
+        for grp in self.optimizer.param_groups:                          # train.py:411-416
+            grp["lr"] = lr
+        self.optimizer.step()                                            # train.py:417
+        moment_update(self.model, self.ema, self.alpha, engine=self.nce)  # train.py:430-431
+        if self.prefetch:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            self._done[step % 2] = ev
+        return dict(loss=outs["loss"], prob=outs["prob"], grad_norm=gnorm, graph_q=q, graph_k=k)
