@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--run-seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--posemb", choices=["device", "placeholder"], default="device")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass")
     return ap.parse_args()
@@ -182,7 +183,7 @@ def main():
     from gcc_amd.contrast import MemoryMoCo
     from gcc_amd.encoder import GraphEncoder
     from gcc_amd.misc import warmup_linear
-    from gcc_amd.posemb import PlaceholderPosEmb
+    from gcc_amd.posemb import DevicePosEmb, PlaceholderPosEmb
     from gcc_amd.train_step import MoCoTrainStep
 
     rp, ci = powerlaw_graph(args.nodes, args.edges, seed=0)
@@ -197,7 +198,10 @@ def main():
     model, model_ema = GraphEncoder(**enc_kw).to(dev), GraphEncoder(**enc_kw).to(dev)
     model_ema.load_state_dict(model.state_dict())                     # moment_update(model, model_ema, 0), train.py:624
     contrast = MemoryMoCo(64, None, args.nce_k, 0.07, use_softmax=True).to(dev)
-    posemb = PlaceholderPosEmb(sampler.node_cap, 32, device=dev)
+    if args.posemb == "device":
+        posemb = DevicePosEmb(B, sampler.node_cap, 32, device=dev, seed=args.run_seed)
+    else:
+        posemb = PlaceholderPosEmb(sampler.node_cap, 32, device=dev)
     trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank)
     stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder q+k fwd",
               "moco-infonce fwd", "key all-gather" if world > 1 else "enqueue", "infonce bwd", "gin-encoder bwd",
@@ -219,6 +223,9 @@ def main():
     for i in range(args.warmup):
         step_fn(i)
     profs = [dict(sampler=Prof(4), **{n: Prof(2) for n in names}) for _ in range(args.steps)]
+    if args.posemb == "device":
+        for p in profs:
+            p["posemb"] = Prof(2)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -232,6 +239,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     sampler.check_status()
+    posemb_status = int(posemb.status.item()) if hasattr(posemb, "status") else 0
     final_loss = float(last["loss"].item())
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -246,6 +254,8 @@ def main():
                     pack_kernel=float(k_ms[:, 2].mean()))
         stage_ms = {n: float(np.mean([p[n].elapsed_ms(0, 1) for p in profs])) for n in names}
         stage_ms["sampler"] = float(k_ms.sum(axis=1).mean())
+        if args.posemb == "device":
+            stage_ms["posemb_one_view"] = float(np.mean([p["posemb"].elapsed_ms(0, 1) for p in profs]))
         # algorithmic bytes of the timed steps (recomputed post hoc: sampling is deterministic)
         from oracle import sampler as O   # checker side only: L table for the byte count
         lt = O.max_nodes_table(int(np.diff(rp).max()), args.rw_hops, args.restart_prob)
@@ -273,7 +283,7 @@ def main():
                        "batch_size_per_gpu": B, "global_batch": B * world, "nce_k": args.nce_k,
                        "rw_hops": args.rw_hops, "restart_prob": args.restart_prob,
                        "stages": stages, "parallelism": f"dp{world} (seed batch sharded, graph replicated)"},
-            "kernel_ms": kern, "stage_ms": stage_ms, "final_loss": final_loss,
+            "kernel_ms": kern, "stage_ms": stage_ms, "final_loss": final_loss, "posemb_status": posemb_status,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": acc["induce"], "traffic": args.pmc_traffic},

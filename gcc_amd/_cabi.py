@@ -129,6 +129,10 @@ SIGNATURES = {
         ctypes.POINTER(GccGraph), ctypes.POINTER(GccSampleParams), ctypes.POINTER(GccBatchOut),
         ctypes.POINTER(GccBatchOut), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
         ctypes.c_void_p]),
+    "gcc_posemb_workspace_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32]),
+    "gcc_posemb": (ctypes.c_int32, [ctypes.POINTER(GccBatchOut), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_gin_forward": (ctypes.c_int32, [ctypes.POINTER(GccGinPass), ctypes.c_int32, ctypes.c_void_p,
                                          ctypes.c_void_p]),
     "gcc_gin_backward_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]),

@@ -1,0 +1,481 @@
+// gcc_amd/csrc/posemb.hip -- positional embedding of sampled subgraphs (gfx950).
+//
+// Replaces _add_undirected_graph_positional_embedding / eigen_decomposision
+// (gcc/datasets/data_util.py:242-281: scipy.sparse.linalg.eigsh = ARPACK, ~35 ms per
+// subgraph per CPU core -- the dominant cost of the reference's data pipeline).
+//
+// Sampled ego-nets are star-like: ~75 % of them have FEWER than 32 positive eigenvalues, the
+// rest of the "top 32" is a large degenerate null space, and exact multiplicities occur among
+// the positive eigenvalues too.  Single-vector Krylov methods cannot resolve multiplicities, so
+// subgraphs that fit in LDS (n <= 128, ~85 % at rw_hops 256) get a FULL symmetric eigensolver:
+//   posemb_jacobi_kernel   one workgroup per subgraph; dense A = D^-1/2 Adj D^-1/2 and the
+//       accumulated rotations V live in LDS (2 x 66 KiB at n = 128, odd row stride -> column
+//       sweeps are bank-conflict free); two-sided Jacobi with round-robin (tournament) ordering:
+//       n/2 disjoint rotations per step, 3 barriers per step, threshold sweeps until no rotation
+//       above 1e-7 ||A||_F remains.  Robust for degenerate spectra, eigenvectors orthonormal to
+//       rounding.
+// Larger subgraphs (hub seeds) use posemb_krylov_kernel (see below).
+#include "host_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kJMax = GCC_POSEMB_JACOBI_MAX;
+constexpr int kMaxSweeps = 30;
+
+struct PosArgs {
+    const int32_t *node_off, *row_ptr, *col_idx;
+    float *pos, *evals, *raw;
+    int32_t B, hidden;
+    uint64_t seed;
+    int32_t *status;
+    const int32_t *list;     // subgraph indices handled by this launch, or NULL = all
+    const int32_t *count;    // device count for `list`
+};
+
+// ---- symmetric eigen-decomposition of the LDS matrix A (np x np, np even, row stride lda) by
+// two-sided Jacobi; V (same shape) accumulates the rotations (V = I on entry if want_vectors).
+// On exit diag(A) = eigenvalues, columns of V = eigenvectors.  All threads of the block call it.
+__device__ void jacobi_lds(float *A, float *V, int np, int lda, float *rot /* [np] (c,s) pairs */,
+                           int *flag /* LDS */, float tol)
+{
+    const int tid = (int)threadIdx.x;
+    const int half = np >> 1, ring = np - 1;
+    for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        for (int s = 0; s < ring; ++s) {
+            // (i) rotation parameters of the np/2 disjoint pairs of this step
+            if (tid < half) {
+                const int p0 = tid == 0 ? ring : (s + tid) % ring;
+                const int q0 = tid == 0 ? s : (s - tid + ring) % ring;
+                const int p = p0 < q0 ? p0 : q0, q = p0 < q0 ? q0 : p0;
+                const float apq = A[p * lda + q];
+                float c = 1.f, sn = 0.f;
+                if (fabsf(apq) > tol) {
+                    const float tau = (A[q * lda + q] - A[p * lda + p]) / (2.f * apq);
+                    const float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
+                    c = 1.f / sqrtf(1.f + t * t);
+                    sn = t * c;
+                    *flag = 1;
+                }
+                rot[2 * tid] = c;
+                rot[2 * tid + 1] = sn;
+            }
+            __syncthreads();
+            // (ii) columns p, q of A and of V:  X <- X J
+            for (int idx = tid; idx < half * np; idx += kThreads) {
+                const int pr = idx / np, r = idx - pr * np;
+                const float c = rot[2 * pr], sn = rot[2 * pr + 1];
+                if (sn != 0.f) {
+                    const int p0 = pr == 0 ? ring : (s + pr) % ring;
+                    const int q0 = pr == 0 ? s : (s - pr + ring) % ring;
+                    const int p = p0 < q0 ? p0 : q0, q = p0 < q0 ? q0 : p0;
+                    const float x = A[r * lda + p], y = A[r * lda + q];
+                    A[r * lda + p] = c * x - sn * y;
+                    A[r * lda + q] = sn * x + c * y;
+                    const float vx = V[r * lda + p], vy = V[r * lda + q];
+                    V[r * lda + p] = c * vx - sn * vy;
+                    V[r * lda + q] = sn * vx + c * vy;
+                }
+            }
+            __syncthreads();
+            // (iii) rows p, q of A:  A <- J^T A
+            for (int idx = tid; idx < half * np; idx += kThreads) {
+                const int pr = idx / np, cc = idx - pr * np;
+                const float c = rot[2 * pr], sn = rot[2 * pr + 1];
+                if (sn != 0.f) {
+                    const int p0 = pr == 0 ? ring : (s + pr) % ring;
+                    const int q0 = pr == 0 ? s : (s - pr + ring) % ring;
+                    const int p = p0 < q0 ? p0 : q0, q = p0 < q0 ? q0 : p0;
+                    const float x = A[p * lda + cc], y = A[q * lda + cc];
+                    A[p * lda + cc] = c * x - sn * y;
+                    A[q * lda + cc] = sn * x + c * y;
+                }
+            }
+            __syncthreads();
+        }
+        if (*flag == 0) break;      // block-uniform (read after the barrier that ends the last step)
+        __syncthreads();
+    }
+}
+
+// rank of eigenvalue i among `n` (0 = largest; ties by index)
+__device__ __forceinline__ int rank_desc(const float *lam, int n, int i)
+{
+    const float li = lam[i];
+    int r = 0;
+    for (int j = 0; j < n; ++j) {
+        const float lj = lam[j];
+        r += (lj > li || (lj == li && j < i)) ? 1 : 0;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(kThreads) void posemb_jacobi_kernel(PosArgs a)
+{
+    DYN_SMEM(smem);
+    __shared__ float rot[kJMax];
+    __shared__ float lam[kJMax];
+    __shared__ float dinv[kJMax];
+    __shared__ int colof[kJMax];
+    __shared__ int flag;
+    __shared__ float red[kThreads];
+    const int tid = (int)threadIdx.x;
+    const int b = (int)blockIdx.x;
+    if (b >= a.B) return;
+    const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+    if (n > kJMax) return;                         // handled by the Krylov kernel
+    const int k = min(n - 2, a.hidden);            // data_util.py:278
+    if (k <= 0) {                                  // data_util.py:243-244: zeros
+        for (int i = tid; i < n * a.hidden; i += kThreads) a.pos[(int64_t)n0 * a.hidden + i] = 0.f;
+        if (a.evals) for (int i = tid; i < a.hidden; i += kThreads) a.evals[(int64_t)b * a.hidden + i] = 0.f;
+        return;
+    }
+    const int np = (n + 1) & ~1, lda = np + 1;
+    float *A = (float *)smem, *V = A + np * lda;
+    for (int i = tid; i < np * lda; i += kThreads) { A[i] = 0.f; V[i] = 0.f; }
+    if (tid < np) {
+        int d = tid < n ? a.row_ptr[n0 + tid + 1] - a.row_ptr[n0 + tid] : 1;
+        dinv[tid] = 1.0f / sqrtf((float)(d < 1 ? 1 : d));     // in_degrees().clip(1) ** -0.5, data_util.py:274-276
+    }
+    __syncthreads();
+    if (tid < np) V[tid * lda + tid] = 1.f;
+    // laplacian = norm * adj * norm (data_util.py:277); one wave per row keeps the loads coalesced
+    for (int r = tid >> 6; r < n; r += kThreads >> 6) {
+        const int beg = a.row_ptr[n0 + r], end = a.row_ptr[n0 + r + 1];
+        for (int e = beg + (tid & 63); e < end; e += 64) {
+            const int c = a.col_idx[e] - n0;
+            A[r * lda + c] = dinv[r] * dinv[c];
+        }
+    }
+    __syncthreads();
+    // ||A||_F for the rotation threshold
+    float ss = 0.f;
+    for (int i = tid; i < np * lda; i += kThreads) ss += A[i] * A[i];
+    red[tid] = ss;
+    __syncthreads();
+    for (int d = kThreads >> 1; d > 0; d >>= 1) {
+        if (tid < d) red[tid] += red[tid + d];
+        __syncthreads();
+    }
+    const float tol = 1e-7f * sqrtf(red[0]) + 1e-30f;
+    __syncthreads();
+    jacobi_lds(A, V, np, lda, rot, &flag, tol);
+    __syncthreads();
+    // eigsh(which="LA") order: the k largest eigenvalues, ascending (data_util.py:251)
+    if (tid < n) lam[tid] = A[tid * lda + tid];
+    __syncthreads();
+    if (tid < n) {
+        const int r = rank_desc(lam, n, tid);
+        colof[tid] = r < k ? k - 1 - r : -1;
+        if (a.evals && r < k) a.evals[(int64_t)b * a.hidden + (k - 1 - r)] = lam[tid];
+    }
+    if (a.evals) for (int i = k + tid; i < a.hidden; i += kThreads) a.evals[(int64_t)b * a.hidden + i] = 0.f;
+    __syncthreads();
+    // x = normalize(u, "l2") row-wise, float32, zero padded to `hidden` columns (data_util.py:260-262)
+    for (int r = tid >> 6; r < n; r += kThreads >> 6) {
+        const int lane = tid & 63;
+        float s2 = 0.f;
+        for (int i = lane; i < n; i += 64) {
+            const float v = colof[i] >= 0 ? V[r * lda + i] : 0.f;
+            s2 += v * v;
+        }
+        s2 = wave_sum(s2);
+        const float inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
+        float *out = a.pos + (int64_t)(n0 + r) * a.hidden;
+        for (int i = lane; i < a.hidden; i += 64) out[i] = 0.f;
+        wave_sync();
+        for (int i = lane; i < n; i += 64)
+            if (colof[i] >= 0) out[colof[i]] = V[r * lda + i] * inv;
+        if (a.raw) {
+            float *ro = a.raw + (int64_t)(n0 + r) * a.hidden;
+            for (int i = lane; i < a.hidden; i += 64) ro[i] = 0.f;
+            wave_sync();
+            for (int i = lane; i < n; i += 64)
+                if (colof[i] >= 0) ro[colof[i]] = V[r * lda + i];
+        }
+    }
+}
+
+
+// =========================================================================
+// Large subgraphs (n > 128; hub seeds, graph_dataset.py:113-124 lets L grow with the seed degree):
+// thick-restart Krylov-Schur.  A symmetric Arnoldi process with classical Gram-Schmidt applied
+// twice builds V (n x (m+1), column-major in HBM/L2) and the dense projected matrix H = V^T M V
+// (LDS); every m = 64 columns the Ritz pairs of H come from jacobi_lds, convergence is judged by
+// |beta_m * y_{m,i}| for the k wanted pairs, and the basis is compressed to the k + 8 best Ritz
+// vectors plus the residual direction (the coupling entries of H are regenerated by the next
+// projection, so no arrowhead bookkeeping is needed).  One start vector ~ U[0,1)^n like the
+// reference (np.random.rand, data_util.py:248); as with ARPACK, exact multiplicities beyond the
+// first copy are only found through rounding.
+constexpr int kM = 64;
+constexpr int kKeepExtra = 8;
+constexpr int kMaxCycles = 80;
+constexpr int kLongDeg = 32;
+constexpr int kMaxLong = 256;
+
+struct KryArgs {
+    PosArgs p;
+    float *vws;              // [B][ (kM + 1) * ldv ]
+    int32_t ldv;             // column stride (>= max n, multiple of 64)
+};
+
+__device__ __forceinline__ float block_sum(float v, float *red)
+{
+    const int tid = (int)threadIdx.x;
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    const float r = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(kThreads) void posemb_krylov_kernel(KryArgs ka)
+{
+    DYN_SMEM(smem);
+    __shared__ float H[(kM + 1) * kM];              // H[i * kM + j], i <= j + 1
+    __shared__ float Aj[kM * (kM + 1)], Yj[kM * (kM + 1)];
+    __shared__ float rot[kM], theta[kM], hbuf[kM + 1], red[8];
+    __shared__ int sel[kM], longrows[kMaxLong];
+    __shared__ int flag, nlong, done;
+    const PosArgs &a = ka.p;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv_id = tid >> 6;
+    const int b = (int)blockIdx.x;
+    if (b >= a.B) return;
+    const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+    if (n <= kJMax) return;                          // handled by the Jacobi kernel
+    const int ldv = ka.ldv;
+    float *V = ka.vws + (int64_t)b * (kM + 1) * ldv;
+    float *x = (float *)smem, *w = x + ldv, *dinv = w + ldv;
+    const int k = min(n - 2, a.hidden);
+    const int keep = min(k + kKeepExtra, kM - 8);
+    const int lda = kM + 1;
+
+    if (tid == 0) nlong = 0;
+    for (int i = tid; i < (kM + 1) * kM; i += kThreads) H[i] = 0.f;
+    __syncthreads();
+    for (int r = tid; r < n; r += kThreads) {
+        const int d = a.row_ptr[n0 + r + 1] - a.row_ptr[n0 + r];
+        dinv[r] = 1.0f / sqrtf((float)(d < 1 ? 1 : d));
+        if (d > kLongDeg) {
+            const int slot = atomicAdd(&nlong, 1);
+            if (slot < kMaxLong) longrows[slot] = r;
+        }
+    }
+    // v0 = U[0,1)^n (np.random.rand(n)), normalised
+    float ss = 0.f;
+    for (int r = tid; r < n; r += kThreads) {
+        uint32_t rnd[4];
+        philox4x32_10((uint32_t)r, 0u, (uint32_t)b, 0x9E0B5EEDu, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
+        const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
+        w[r] = u;
+        ss += u * u;
+    }
+    __syncthreads();
+    float nrm = sqrtf(block_sum(ss, red));
+    for (int r = tid; r < n; r += kThreads) V[r] = w[r] / nrm;
+    __syncthreads();
+    const int nl = nlong < kMaxLong ? nlong : kMaxLong;
+    const bool long_overflow = nlong > kMaxLong;
+
+    // orthogonalise w against V[:, 0..ncols) twice; optionally accumulate the coefficients into H[:, hcol]
+    auto orth = [&](int ncols, int hcol) {
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int i = wv_id; i < ncols; i += 4) {
+                float s = 0.f;
+                for (int r = lane; r < n; r += 64) s = fmaf(V[(int64_t)i * ldv + r], w[r], s);
+                s = wave_sum(s);
+                if (lane == 0) hbuf[i] = s;
+            }
+            __syncthreads();
+            if (hcol >= 0 && tid < ncols) H[tid * kM + hcol] += hbuf[tid];
+            for (int r = tid; r < n; r += kThreads) {
+                float acc = w[r];
+                for (int i = 0; i < ncols; ++i) acc = fmaf(-V[(int64_t)i * ldv + r], hbuf[i], acc);
+                w[r] = acc;
+            }
+            __syncthreads();
+        }
+    };
+
+    int j = 0;
+    for (int cycle = 0; cycle < kMaxCycles; ++cycle) {
+        for (; j < kM; ++j) {
+            for (int r = tid; r < n; r += kThreads) x[r] = V[(int64_t)j * ldv + r] * dinv[r];
+            __syncthreads();
+            // w = D^-1/2 A D^-1/2 v_j   (short rows: one thread per row; long rows: one wave per row)
+            for (int r = tid; r < n; r += kThreads) {
+                const int beg = a.row_ptr[n0 + r], end = a.row_ptr[n0 + r + 1];
+                if (end - beg > kLongDeg && !long_overflow) continue;
+                float s = 0.f;
+                for (int e = beg; e < end; ++e) s += x[a.col_idx[e] - n0];
+                w[r] = s * dinv[r];
+            }
+            if (!long_overflow) {
+                for (int i = wv_id; i < nl; i += 4) {
+                    const int r = longrows[i];
+                    const int beg = a.row_ptr[n0 + r], end = a.row_ptr[n0 + r + 1];
+                    float s = 0.f;
+                    for (int e = beg + lane; e < end; e += 64) s += x[a.col_idx[e] - n0];
+                    s = wave_sum(s);
+                    if (lane == 0) w[r] = s * dinv[r];
+                }
+            }
+            __syncthreads();
+            orth(j + 1, j);
+            float s2 = 0.f;
+            for (int r = tid; r < n; r += kThreads) s2 = fmaf(w[r], w[r], s2);
+            float beta = sqrtf(block_sum(s2, red));
+            if (beta < 1e-6f) {                      // invariant subspace: continue with a fresh direction
+                for (int r = tid; r < n; r += kThreads) {
+                    uint32_t rnd[4];
+                    philox4x32_10((uint32_t)r, (uint32_t)(cycle * kM + j + 1), (uint32_t)b, 0x9E0B5EEDu,
+                                  (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
+                    w[r] = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f) - 0.5f;
+                }
+                __syncthreads();
+                orth(j + 1, -1);
+                float s3 = 0.f;
+                for (int r = tid; r < n; r += kThreads) s3 = fmaf(w[r], w[r], s3);
+                nrm = sqrtf(block_sum(s3, red));
+                beta = 0.f;
+            } else {
+                nrm = beta;
+            }
+            if (tid == 0) H[(j + 1) * kM + j] = beta;
+            for (int r = tid; r < n; r += kThreads) V[(int64_t)(j + 1) * ldv + r] = w[r] / nrm;
+            __syncthreads();
+        }
+        // Rayleigh-Ritz on the symmetric part of H
+        for (int i = tid; i < kM * lda; i += kThreads) {
+            const int r = i / lda, c = i - r * lda;
+            float v = 0.f;
+            if (c < kM) v = r <= c ? H[r * kM + c] : H[c * kM + r];
+            Aj[i] = v;
+            Yj[i] = (r == c) ? 1.f : 0.f;
+        }
+        __syncthreads();
+        jacobi_lds(Aj, Yj, kM, lda, rot, &flag, 1e-7f);
+        __syncthreads();
+        if (tid < kM) theta[tid] = Aj[tid * lda + tid];
+        __syncthreads();
+        const float beta_m = H[kM * kM + (kM - 1)];
+        if (tid == 0) done = 1;
+        __syncthreads();
+        if (tid < kM) {
+            const int r = rank_desc(theta, kM, tid);
+            sel[tid] = r;                           // 0 = largest Ritz value
+            if (r < k && fabsf(beta_m * Yj[(kM - 1) * lda + tid]) > 2e-5f) done = 0;
+        }
+        __syncthreads();
+        const bool finished = done != 0 || cycle == kMaxCycles - 1;
+        if (finished && done == 0 && tid == 0) atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
+        const int nout = finished ? k : keep;
+        // hbuf is free now: column of Y for output slot t = the Ritz vector of rank (finished ? k-1-t : t)
+        // V[:, 0..nout) <- V[:, 0..m) Y[:, chosen]  (row by row, in place)
+        for (int r = tid; r < n; r += kThreads) {
+            float vin[kM];
+#pragma unroll
+            for (int i = 0; i < kM; ++i) vin[i] = V[(int64_t)i * ldv + r];
+            if (!finished) {
+                for (int i = 0; i < kM; ++i) {
+                    const int t = sel[i];
+                    if (t < nout) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int c = 0; c < kM; ++c) acc = fmaf(vin[c], Yj[c * lda + i], acc);
+                        V[(int64_t)t * ldv + r] = acc;
+                    }
+                }
+            } else {
+                // final: eigsh(which="LA") order = ascending; row-normalise over the k wanted columns
+                float outv[64];
+                float s2 = 0.f;
+                for (int i = 0; i < kM; ++i) {
+                    const int t = sel[i];
+                    if (t < k) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int c = 0; c < kM; ++c) acc = fmaf(vin[c], Yj[c * lda + i], acc);
+                        outv[k - 1 - t] = acc;
+                        s2 = fmaf(acc, acc, s2);
+                    }
+                }
+                const float inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
+                float *po = a.pos + (int64_t)(n0 + r) * a.hidden;
+                for (int c = 0; c < a.hidden; ++c) po[c] = c < k ? outv[c] * inv : 0.f;
+                if (a.raw) {
+                    float *ro = a.raw + (int64_t)(n0 + r) * a.hidden;
+                    for (int c = 0; c < a.hidden; ++c) ro[c] = c < k ? outv[c] : 0.f;
+                }
+            }
+        }
+        if (finished) {
+            if (a.evals && tid < kM && sel[tid] < k) a.evals[(int64_t)b * a.hidden + (k - 1 - sel[tid])] = theta[tid];
+            if (a.evals) for (int c = k + tid; c < a.hidden; c += kThreads) a.evals[(int64_t)b * a.hidden + c] = 0.f;
+            break;
+        }
+        // restart: residual direction becomes column `keep`; H = diag(theta_kept)
+        for (int r = tid; r < n; r += kThreads) V[(int64_t)keep * ldv + r] = V[(int64_t)kM * ldv + r];
+        for (int i = tid; i < (kM + 1) * kM; i += kThreads) H[i] = 0.f;
+        __syncthreads();
+        if (tid < kM && sel[tid] < keep) H[sel[tid] * kM + sel[tid]] = theta[tid];
+        __syncthreads();
+        j = keep;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t gcc_posemb_workspace_bytes(int32_t batch_size, int64_t node_cap, int32_t hidden)
+{
+    if (batch_size < 1 || node_cap < 1 || hidden < 2 || hidden > 64) {
+        snprintf(g_err, kErrLen, "gcc_posemb_workspace_bytes: bad argument");
+        return -1;
+    }
+    const int64_t ldv = ((node_cap / batch_size + 63) / 64) * 64 + 64;
+    return (int64_t)batch_size * (kM + 1) * ldv * (int64_t)sizeof(float) + 256;
+}
+
+int32_t gcc_posemb(const gcc_batch_out *g, int32_t batch_size, int32_t hidden, float *pos, float *evals,
+                   float *raw, uint64_t seed, void *workspace, int64_t workspace_bytes, int32_t *status, gcc_prof *prof,
+                   void *stream)
+{
+    if (!g || !pos || !status || batch_size < 1 || hidden < 2 || hidden > 64) {
+        snprintf(g_err, kErrLen, "gcc_posemb: bad argument");
+        return -1;
+    }
+    const int64_t need = gcc_posemb_workspace_bytes(batch_size, g->node_cap, hidden);
+    if (!workspace || workspace_bytes < need) {
+        snprintf(g_err, kErrLen, "gcc_posemb: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+        return -3;
+    }
+    PosArgs a = {g->node_off, g->row_ptr, g->col_idx, pos, evals, raw, batch_size, hidden, seed, status, nullptr, nullptr};
+    hipStream_t s = (hipStream_t)stream;
+    const int np = kJMax, lda = np + 1;
+    const size_t lds = (size_t)2 * np * lda * sizeof(float);
+#ifndef GCC_AMD_HIPEMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)posemb_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+#endif
+    prof_mark(prof, 0, s);
+    hipLaunchKernelGGL(posemb_jacobi_kernel, dim3(batch_size), dim3(kThreads), lds, s, a);
+    KryArgs ka;
+    ka.p = a;
+    ka.vws = (float *)workspace;
+    ka.ldv = (int32_t)(((g->node_cap / batch_size + 63) / 64) * 64 + 64);
+    hipLaunchKernelGGL(posemb_krylov_kernel, dim3(batch_size), dim3(kThreads), (size_t)3 * ka.ldv * sizeof(float), s, ka);
+    prof_mark(prof, 1, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_posemb: %s", hipGetErrorString(e)); return -10; }
+    return 0;
+}
+
+}  // extern "C"

@@ -18,6 +18,56 @@ class PlaceholderPosEmb:
         self.table = torch.nn.functional.normalize(x, dim=1).to(device)
         self.kind = "placeholder-random-unit-rows"
 
-    def __call__(self, graph):
+    def __call__(self, graph, prof=None):
         graph.pos_undirected = self.table
         return graph
+
+
+class DevicePosEmb:
+    """``_add_undirected_graph_positional_embedding`` (data_util.py:266-281) for a whole
+    batched graph in one launch set (gcc_amd/csrc/posemb.hip).  ``lib``/``ptr`` are
+    injectable for the emulator tests only."""
+
+    kind = "device-jacobi+krylov-schur"
+
+    def __init__(self, batch_size, node_cap, hidden_size=32, device="cuda", seed=0, num_buffers=2, lib=None, ptr=None):
+        import ctypes
+
+        from . import _cabi
+
+        self._ct, self._cabi = ctypes, _cabi
+        self.lib = lib if lib is not None else _cabi.load()
+        self.ptr = ptr if ptr is not None else _cabi.dev_ptr
+        self.B, self.hidden, self.seed = int(batch_size), int(hidden_size), int(seed)
+        nbytes = self.lib.gcc_posemb_workspace_bytes(self.B, node_cap, self.hidden)
+        if nbytes < 0:
+            raise RuntimeError(self.lib.gcc_last_error().decode())
+        self.nbytes = nbytes
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        # one output buffer per in-flight batch view (q and k of each ring slot)
+        self._ring = [torch.zeros(node_cap, self.hidden, dtype=torch.float32, device=device)
+                      for _ in range(2 * num_buffers)]
+        self._next = 0
+
+    def __call__(self, graph, evals=None, raw=None, prof=None):
+        out = self._ring[self._next]
+        self._next = (self._next + 1) % len(self._ring)
+        c = self._cabi.GccBatchOut(node_off=self.ptr(graph.node_off), edge_off=0, parent_nid=0, graph_id=0,
+                                   row_ptr=self.ptr(graph.row_ptr), col_idx=self.ptr(graph.col_idx),
+                                   node_cap=out.shape[0], edge_cap=graph.col_idx.numel())
+        st = torch.cuda.current_stream(out.device).cuda_stream if out.is_cuda else None
+        rc = self.lib.gcc_posemb(self._ct.byref(c), self.B, self.hidden, self.ptr(out),
+                                 self.ptr(evals) if evals is not None else None,
+                                 self.ptr(raw) if raw is not None else None, self.seed,
+                                 self.ptr(self.workspace), self.nbytes, self.ptr(self.status),
+                                 prof.handle if prof is not None else None, st)
+        if rc != 0:
+            raise RuntimeError(f"gcc_posemb failed ({rc}): {self.lib.gcc_last_error().decode()}")
+        graph.pos_undirected = out
+        return graph
+
+    def check_status(self):
+        s = int(self.status.item())
+        if s:
+            raise RuntimeError(f"gcc_posemb: status {s} (8 = an eigen-iteration did not converge)")

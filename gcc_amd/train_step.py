@@ -108,7 +108,8 @@ class MoCoTrainStep:
     # ---- data: sampler + positional embedding, one step ahead on a side stream
     def _produce(self, first_id):
         q, k = self.sampler.sample(first_id, prof=self._prof.get("sampler") if self._prof else None)
-        self.posemb(q)
+        pp = self._prof.get("posemb") if self._prof else None
+        self.posemb(q, prof=pp) if pp is not None else self.posemb(q)
         self.posemb(k)
         return q, k
 

@@ -108,6 +108,28 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p,
                          void *workspace, int64_t workspace_bytes, int64_t scratch_entries,
                          int32_t *status, void *stream);
 
+/* --------------------------------------------------- positional embedding ---
+ * _add_undirected_graph_positional_embedding + eigen_decomposision of
+ * gcc/datasets/data_util.py:242-281 for every subgraph of a batched graph:
+ * the k = min(n - 2, hidden) largest-algebraic eigenpairs of D^-1/2 A D^-1/2
+ * (D = in-degree clipped at 1), eigenvalues ascending like scipy eigsh(which="LA"),
+ * rows L2-normalised, zero-padded to `hidden` columns; k <= 0 gives zeros.
+ * Subgraphs with n <= GCC_POSEMB_JACOBI_MAX use a full two-sided Jacobi
+ * eigensolver resident in LDS (exact multiplicities); larger ones a thick-restart
+ * Krylov-Schur iteration (single start vector, like ARPACK).  Eigenvectors are
+ * defined up to sign / rotation inside degenerate eigenspaces; the reference's
+ * own output depends on np.random.rand (data_util.py:248). */
+#define GCC_POSEMB_JACOBI_MAX 128
+#define GCC_STATUS_POSEMB_NOT_CONVERGED 8
+int64_t gcc_posemb_workspace_bytes(int32_t batch_size, int64_t node_cap, int32_t hidden);
+/* pos: device [node_cap, hidden] out (rows >= node_off[B] untouched);
+ * evals: device [B, hidden] out or NULL (eigenvalues, ascending, zero-padded);
+ * raw:   device [node_cap, hidden] out or NULL (the eigenvectors before row normalisation);
+ * seed: start vectors of the Krylov path are Philox(seed, subgraph) uniforms. */
+int32_t gcc_posemb(const gcc_batch_out *g, int32_t batch_size, int32_t hidden, float *pos, float *evals,
+                   float *raw, uint64_t seed, void *workspace, int64_t workspace_bytes, int32_t *status, gcc_prof *prof,
+                   void *stream);
+
 /* ------------------------------------------------------------ GIN encoder ---
  * GraphEncoder(gnn_model="gin", degree_input=True).forward of
  * gcc/models/graph_encoder.py:132-200 -> UnsupervisedGIN.forward gcc/models/gin.py:213-232

@@ -1,0 +1,139 @@
+"""Positional embedding kernels (gcc_amd/csrc/posemb.hip) on the wave64 emulator vs dense
+float64 eigendecompositions.  Eigenvectors are only defined up to sign / rotation inside
+degenerate eigenspaces (and the reference seeds ARPACK randomly, data_util.py:248), so parity is
+asserted on invariants: eigenvalues, residuals, orthonormality, unit rows, and -- whenever the
+wanted invariant subspace is unique -- the Gram matrix x x^T of the normalised rows."""
+import numpy as np
+import pytest
+import torch
+
+from gcc_amd.graphgen import powerlaw_graph, tiny_graphs
+from gcc_amd.posemb import DevicePosEmb
+from oracle import posemb as P
+from oracle import sampler as O
+from tests.hipemu.emu_driver import emu_lib
+from tests.hipemu.emu_encoder import CpuBatch
+
+HID = 32
+
+
+def _run(view):
+    b = CpuBatch(dict(view, pos_undirected=torch.zeros(int(view["node_off"][-1]), HID)))
+    pe = DevicePosEmb(b.batch_size, b.parent_nid.numel(), HID, device="cpu", lib=emu_lib(),
+                      ptr=lambda t: 0 if t is None else t.data_ptr())
+    evals = torch.zeros(b.batch_size, HID)
+    raw = torch.zeros(b.parent_nid.numel(), HID)
+    pe(b, evals=evals, raw=raw)
+    assert int(pe.status) == 0
+    return b.pos_undirected.numpy(), evals.numpy(), raw.numpy()
+
+
+def _check(view, x, evals, raw, tol=2e-4):
+    no = view["node_off"].numpy()
+    rp, ci = view["row_ptr"].numpy(), view["col_idx"].numpy()
+    for b in range(len(no) - 1):
+        lo, hi = no[b], no[b + 1]
+        n = hi - lo
+        k = min(n - 2, HID)
+        xb, ub = x[lo:hi], raw[lo:hi]
+        if k <= 0:
+            assert not xb.any()
+            continue
+        M = P.normalized_adjacency(rp[lo:hi + 1] - rp[lo], ci[rp[lo]:rp[hi]] - lo).toarray()
+        s, u = np.linalg.eigh(M)
+        assert np.allclose(evals[b, :k], s[-k:], atol=tol), (b, n)            # eigsh(which="LA"): ascending top-k
+        assert not evals[b, k:].any() and not xb[:, k:].any()                   # F.pad(..., hidden - k)
+        U = ub[:, :k].astype(np.float64)
+        assert np.abs(U.T @ U - np.eye(k)).max() < tol                          # orthonormal eigenvectors
+        assert np.abs(M @ U - U * evals[b, :k]).max() < tol                     # residual
+        norms = np.linalg.norm(xb[:, :k], axis=1)
+        assert np.all((np.abs(norms - 1) < 1e-4) | (norms == 0))               # sklearn normalize(norm="l2")
+        gap_ok = n - k - 1 < 0 or s[-k] - s[-k - 1] > 1e-3                      # wanted subspace unique?
+        if gap_ok:
+            xr, _ = P.eigen_decomposition(n, k, __import__("scipy.sparse").sparse.csr_matrix(M), HID,
+                                          rng=np.random.RandomState(b))
+            assert np.abs(xb @ xb.T - xr @ xr.T).max() < 5e-3, (b, n)          # same rows up to a rotation
+
+
+def _sampled_views(rw_hops, B, run_seed):
+    rp, ci = powerlaw_graph(3000, 30000, 3)
+    c = O.COracle()
+    seeds = c.draw_seeds(O.seed_cdf(rp), run_seed, 0, B)
+    L = O.max_nodes_table(int(np.diff(rp).max()), rw_hops, 0.8)[np.diff(rp)[seeds]]
+    r = c.sample_batch(rp, ci, seeds, L, 0, run_seed, 0, O.restart_threshold(0.8))
+    return dict(node_off=torch.from_numpy(r["node_off"].astype(np.int64)),
+                row_ptr=torch.from_numpy(r["row_ptr"].astype(np.int64)),
+                col_idx=torch.from_numpy(r["col_idx"].astype(np.int64)))
+
+
+def test_sampled_subgraphs_jacobi_path():
+    view = _sampled_views(rw_hops=48, B=6, run_seed=4)
+    assert np.diff(view["node_off"].numpy()).max() <= 128
+    _check(view, *_run(view))
+
+
+def test_tiny_and_degenerate_graphs():
+    # n = 1, 2 (k <= 0 -> zeros), path, star (null space of dimension n - 2), complete graph (n-1 fold eigenvalue)
+    blocks = [(1, []), (2, [(0, 1)]), (3, [(0, 1), (1, 2)])]
+    for name in ("path5", "star6", "k4", "tri_tail"):
+        rp, ci = tiny_graphs()[name]
+        n = len(rp) - 1
+        blocks.append((n, [(i, int(j)) for i in range(n) for j in ci[rp[i]:rp[i + 1]] if i < j]))
+    blocks.append((40, [(0, i) for i in range(1, 40)]))
+    import scipy.sparse as sp
+    node_off, rows, cols = [0], [], []
+    for n, edges in blocks:
+        o = node_off[-1]
+        for i, j in edges:
+            rows += [o + i, o + j]
+            cols += [o + j, o + i]
+        node_off.append(o + n)
+    N = node_off[-1]
+    a = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(N, N))
+    a.sort_indices()
+    view = dict(node_off=torch.tensor(node_off), row_ptr=torch.from_numpy(a.indptr.astype(np.int64)),
+                col_idx=torch.from_numpy(a.indices.astype(np.int64)))
+    _check(view, *_run(view))
+
+
+def _check_krylov(view, x, evals, raw, tol=1e-3):
+    """Large subgraphs go through the single-vector Krylov-Schur path: like ARPACK it may miss extra
+    copies of an exactly repeated eigenvalue, so eigenvalues are checked as 'true eigenvalues, top of
+    the spectrum, every distinct wanted eigenvalue present'."""
+    no = view["node_off"].numpy()
+    rp, ci = view["row_ptr"].numpy(), view["col_idx"].numpy()
+    for b in range(len(no) - 1):
+        lo, hi = no[b], no[b + 1]
+        n = hi - lo
+        if n <= 128:
+            continue
+        k = HID
+        M = P.normalized_adjacency(rp[lo:hi + 1] - rp[lo], ci[rp[lo]:rp[hi]] - lo).toarray()
+        s = np.linalg.eigvalsh(M)
+        got = evals[b]
+        assert np.all(np.diff(got) >= -1e-6)                                     # ascending
+        assert np.abs(got[:, None] - s[None, :]).min(axis=1).max() < tol         # each one is an eigenvalue
+        wanted = s[s >= got[0] + 10 * tol]                                       # every eigenvalue above the cut
+        assert np.abs(wanted[:, None] - got[None, :]).min(axis=1).max() < tol    # ... is represented
+        assert abs(got[-1] - 1.0) < tol                                          # connected ego-net: lambda_max = 1
+        U = raw[lo:hi, :k].astype(np.float64)
+        assert np.abs(U.T @ U - np.eye(k)).max() < tol
+        assert np.abs(M @ U - U * got).max() < tol
+        norms = np.linalg.norm(x[lo:hi, :k], axis=1)
+        assert np.all(np.abs(norms - 1) < 1e-4)
+
+
+def test_large_subgraphs_krylov_path():
+    rp, ci = powerlaw_graph(20000, 400000, 1)
+    c = O.COracle()
+    deg = np.diff(rp)
+    hubs = np.argsort(deg)[-2:].astype(np.int32)
+    L = np.array([300, 420], dtype=np.int32)
+    r = c.sample_batch(rp, ci, hubs, L, 0, 3, 0, O.restart_threshold(0.6))
+    sizes = np.diff(r["node_off"])
+    assert sizes.min() > 128
+    view = dict(node_off=torch.from_numpy(r["node_off"].astype(np.int64)),
+                row_ptr=torch.from_numpy(r["row_ptr"].astype(np.int64)),
+                col_idx=torch.from_numpy(r["col_idx"].astype(np.int64)))
+    x, evals, raw = _run(view)
+    _check_krylov(view, x, evals, raw)
