@@ -21,7 +21,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kJMax = GCC_POSEMB_JACOBI_MAX;
-constexpr int kMaxSweeps = 30;
+constexpr int kMaxSweeps = 14;
 
 struct PosArgs {
     const int32_t *node_off, *row_ptr, *col_idx;
@@ -37,15 +37,19 @@ struct PosArgs {
 // two-sided Jacobi; V (same shape) accumulates the rotations (V = I on entry if want_vectors).
 // On exit diag(A) = eigenvalues, columns of V = eigenvectors.  All threads of the block call it.
 __device__ void jacobi_lds(float *A, float *V, int np, int lda, float *rot /* [np] (c,s) pairs */,
-                           int *flag /* LDS */, float tol)
+                           int *pq /* [np] (p,q) pairs */, int *flag /* LDS */, float tol)
 {
     const int tid = (int)threadIdx.x;
     const int half = np >> 1, ring = np - 1;
+    // division-free task mapping: lanes run along a row/column (rw of them), thread groups over pairs
+    const int rw_log = np <= 64 ? 6 : 7;                 // np <= 128
+    const int r = tid & ((1 << rw_log) - 1), pg = tid >> rw_log, npg = kThreads >> rw_log;
+    const bool active = r < np;
     for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
         if (tid == 0) *flag = 0;
         __syncthreads();
         for (int s = 0; s < ring; ++s) {
-            // (i) rotation parameters of the np/2 disjoint pairs of this step
+            // (i) the np/2 disjoint pairs of this step (round-robin tournament) and their rotations
             if (tid < half) {
                 const int p0 = tid == 0 ? ring : (s + tid) % ring;
                 const int q0 = tid == 0 ? s : (s - tid + ring) % ring;
@@ -61,36 +65,38 @@ __device__ void jacobi_lds(float *A, float *V, int np, int lda, float *rot /* [n
                 }
                 rot[2 * tid] = c;
                 rot[2 * tid + 1] = sn;
+                pq[2 * tid] = p;
+                pq[2 * tid + 1] = q;
             }
             __syncthreads();
-            // (ii) columns p, q of A and of V:  X <- X J
-            for (int idx = tid; idx < half * np; idx += kThreads) {
-                const int pr = idx / np, r = idx - pr * np;
-                const float c = rot[2 * pr], sn = rot[2 * pr + 1];
-                if (sn != 0.f) {
-                    const int p0 = pr == 0 ? ring : (s + pr) % ring;
-                    const int q0 = pr == 0 ? s : (s - pr + ring) % ring;
-                    const int p = p0 < q0 ? p0 : q0, q = p0 < q0 ? q0 : p0;
-                    const float x = A[r * lda + p], y = A[r * lda + q];
-                    A[r * lda + p] = c * x - sn * y;
-                    A[r * lda + q] = sn * x + c * y;
-                    const float vx = V[r * lda + p], vy = V[r * lda + q];
-                    V[r * lda + p] = c * vx - sn * vy;
-                    V[r * lda + q] = sn * vx + c * vy;
+            // (ii) columns p, q of A and of V:  X <- X J      (lane = row: stride lda is odd, conflict free)
+            if (active) {
+                for (int pr = pg; pr < half; pr += npg) {
+                    const float sn = rot[2 * pr + 1];
+                    if (sn != 0.f) {
+                        const float c = rot[2 * pr];
+                        const int p = pq[2 * pr], q = pq[2 * pr + 1];
+                        const float x = A[r * lda + p], y = A[r * lda + q];
+                        A[r * lda + p] = c * x - sn * y;
+                        A[r * lda + q] = sn * x + c * y;
+                        const float vx = V[r * lda + p], vy = V[r * lda + q];
+                        V[r * lda + p] = c * vx - sn * vy;
+                        V[r * lda + q] = sn * vx + c * vy;
+                    }
                 }
             }
             __syncthreads();
-            // (iii) rows p, q of A:  A <- J^T A
-            for (int idx = tid; idx < half * np; idx += kThreads) {
-                const int pr = idx / np, cc = idx - pr * np;
-                const float c = rot[2 * pr], sn = rot[2 * pr + 1];
-                if (sn != 0.f) {
-                    const int p0 = pr == 0 ? ring : (s + pr) % ring;
-                    const int q0 = pr == 0 ? s : (s - pr + ring) % ring;
-                    const int p = p0 < q0 ? p0 : q0, q = p0 < q0 ? q0 : p0;
-                    const float x = A[p * lda + cc], y = A[q * lda + cc];
-                    A[p * lda + cc] = c * x - sn * y;
-                    A[q * lda + cc] = sn * x + c * y;
+            // (iii) rows p, q of A:  A <- J^T A             (lane = column: contiguous)
+            if (active) {
+                for (int pr = pg; pr < half; pr += npg) {
+                    const float sn = rot[2 * pr + 1];
+                    if (sn != 0.f) {
+                        const float c = rot[2 * pr];
+                        const int p = pq[2 * pr], q = pq[2 * pr + 1];
+                        const float x = A[p * lda + r], y = A[q * lda + r];
+                        A[p * lda + r] = c * x - sn * y;
+                        A[q * lda + r] = sn * x + c * y;
+                    }
                 }
             }
             __syncthreads();
@@ -116,6 +122,7 @@ __global__ __launch_bounds__(kThreads) void posemb_jacobi_kernel(PosArgs a)
 {
     DYN_SMEM(smem);
     __shared__ float rot[kJMax];
+    __shared__ int pq[kJMax];
     __shared__ float lam[kJMax];
     __shared__ float dinv[kJMax];
     __shared__ int colof[kJMax];
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void posemb_jacobi_kernel(PosArgs a)
     }
     const float tol = 1e-7f * sqrtf(red[0]) + 1e-30f;
     __syncthreads();
-    jacobi_lds(A, V, np, lda, rot, &flag, tol);
+    jacobi_lds(A, V, np, lda, rot, pq, &flag, tol);
     __syncthreads();
     // eigsh(which="LA") order: the k largest eigenvalues, ascending (data_util.py:251)
     if (tid < n) lam[tid] = A[tid * lda + tid];
@@ -238,6 +245,7 @@ __global__ __launch_bounds__(kThreads) void posemb_krylov_kernel(KryArgs ka)
     __shared__ float H[(kM + 1) * kM];              // H[i * kM + j], i <= j + 1
     __shared__ float Aj[kM * (kM + 1)], Yj[kM * (kM + 1)];
     __shared__ float rot[kM], theta[kM], hbuf[kM + 1], red[8];
+    __shared__ int pq[kM];
     __shared__ int sel[kM], longrows[kMaxLong];
     __shared__ int flag, nlong, done;
     const PosArgs &a = ka.p;
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void posemb_krylov_kernel(KryArgs ka)
             Yj[i] = (r == c) ? 1.f : 0.f;
         }
         __syncthreads();
-        jacobi_lds(Aj, Yj, kM, lda, rot, &flag, 1e-7f);
+        jacobi_lds(Aj, Yj, kM, lda, rot, pq, &flag, 1e-7f);
         __syncthreads();
         if (tid < kM) theta[tid] = Aj[tid * lda + tid];
         __syncthreads();

@@ -162,7 +162,8 @@ class MoCoTrainStep:
                                stream=st, prof=pr.get("nce_bwd"))         # loss.backward(), train.py:408
         self.gin.backward(self.model, pq, bufq, dq, targets=self.grad_views, stream=st, prof=pr.get("gin_bwd"))
         if self.world > 1:
-            torch.distributed.all_reduce(self.flat_grad, op=torch.distributed.ReduceOp.AVG)
+            torch.distributed.all_reduce(self.flat_grad)                # one flat bucket (248 KiB) over xGMI
+            self.flat_grad.mul_(1.0 / self.world)
         gnorm = clip_grad_norm([self.live], self.clip_norm)             # train.py:409
         for grp in self.optimizer.param_groups:                          # train.py:411-416
             grp["lr"] = lr
