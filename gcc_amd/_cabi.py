@@ -90,6 +90,7 @@ class GccGinPass(ctypes.Structure):
         ("batch_size", ctypes.c_int32), ("training", ctypes.c_int32), ("update_running_stats", ctypes.c_int32),
         ("normalize", ctypes.c_int32),
         ("dropout_keep", _VP),
+        ("dropout_seed", ctypes.c_uint64), ("dropout_philox", ctypes.c_int32),
         ("w", GccGinWeights),
         ("x0", _VP), ("agg", _VP * GIN_MAX_LAYERS), ("z1", _VP * GIN_MAX_LAYERS), ("z2", _VP * GIN_MAX_LAYERS),
         ("stats", _VP), ("pooled", _VP), ("score", _VP), ("feat", _VP),
@@ -147,6 +148,10 @@ SIGNATURES = {
                                           ctypes.c_void_p]),
     "gcc_queue_enqueue": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                            ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_adam_step": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                       ctypes.c_float, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p]),
     "gcc_ema_update": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,
                                         ctypes.c_void_p]),
 }

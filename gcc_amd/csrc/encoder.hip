@@ -101,10 +101,14 @@ __global__ __launch_bounds__(kThreads) void gin_in_kernel(InLaunch L)
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
     const int N = a.node_off[a.B];
     const double dn = (double)N;
+    __shared__ float tabb[2 * H], tabc[2 * H];
     Aff4 ab, ac;
     if (!a.first) {
-        ab = bn_aff4(a.bnb, 4 * t, dn, a.eps, a.training);
-        ac = bn_aff4(a.bnc, 4 * t, dn, a.eps, a.training);
+        bn_table(tabb, a.bnb, 0, dn, a.eps, a.training);
+        bn_table(tabc, a.bnc, H, dn, a.eps, a.training);
+        __syncthreads();
+        ab = aff4_from_table(tabb, 4 * t);
+        ac = aff4_from_table(tabc, 4 * t);
     }
     auto feat = [&](int u) -> F4 {
         F4 x = ld4(a.src + (int64_t)u * H + 4 * t);
@@ -169,9 +173,12 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
     const int N = a.node_off[a.B];
     const double dn = (double)N;
+    __shared__ float taba[2 * H];
+    bn_table(taba, a.bna, 0, dn, a.eps, a.training);
+    __syncthreads();
     Aff4 aa[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) aa[c] = bn_aff4(a.bna, 16 * c + 4 * q, dn, a.eps, a.training);
+    for (int c = 0; c < 4; ++c) aa[c] = aff4_from_table(taba, 16 * c + 4 * q);
     F4 wf[4][4];
     load_w_frags(a.w1, H, wf);
     for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
@@ -211,7 +218,10 @@ __global__ __launch_bounds__(kThreads) void gin_stat_kernel(StatLaunch L)
     const StatArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
     const int N = a.node_off[a.B];
-    const Aff4 ab = bn_aff4(a.bnb, 4 * t, (double)N, a.eps, a.training);
+    __shared__ float tabb[2 * H];
+    bn_table(tabb, a.bnb, 0, (double)N, a.eps, a.training);
+    __syncthreads();
+    const Aff4 ab = aff4_from_table(tabb, 4 * t);
     F4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
     bool any = false;
     for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void gin_stat_kernel(StatLaunch L)
     if (tid < 2 * H) {
         double v = 0.0;
         for (int k = 0; k < 16; ++k) v += (double)part[k * 2 * H + tid];
-        atomicAdd(&a.stats_c[tid], v);
+        atomicAdd(&a.stats_c[((int)blockIdx.x % kRep) * 2 * H + tid], v);
     }
 }
 
@@ -252,8 +262,12 @@ __global__ __launch_bounds__(kThreads) void gin_pool_kernel(PoolLaunch L)
     const PoolArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
     const int N = a.node_off[a.B];
-    const Aff4 ab = bn_aff4(a.bnb, 4 * t, (double)N, a.eps, a.training);
-    const Aff4 ac = bn_aff4(a.bnc, 4 * t, (double)N, a.eps, a.training);
+    __shared__ float tabb[2 * H], tabc[2 * H];
+    bn_table(tabb, a.bnb, 0, (double)N, a.eps, a.training);
+    bn_table(tabc, a.bnc, H, (double)N, a.eps, a.training);
+    __syncthreads();
+    const Aff4 ab = aff4_from_table(tabb, 4 * t);
+    const Aff4 ac = aff4_from_table(tabc, 4 * t);
     for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
         const int nrows = min(kTile, N - tile0);
         for (int r = gi; r < nrows; r += 16)
@@ -265,50 +279,82 @@ __global__ __launch_bounds__(kThreads) void gin_pool_kernel(PoolLaunch L)
 }
 
 // =========================================================================
-// F5: readout (gin.py:223-232) + F.normalize (graph_encoder.py:195-196) + running statistics
+// F5: readout (gin.py:223-232) + F.normalize (graph_encoder.py:195-196) + running statistics.
+// score[B, 64] = sum_i drop(pooled_i W_i^T + b_i) is a [B x d] x [d x 64] GEMM per hidden_rep: one wave
+// = 16 graphs on the exact-f32 MFMA (the per-lane GEMV it replaces read the weights uncoalesced: 69 us).
 struct ReadArgs {
     const int32_t *node_off;
     const double *pooled;       // [L+1][B][64]
     const float *pred_w[GCC_GIN_MAX_LAYERS + 1], *pred_b[GCC_GIN_MAX_LAYERS + 1];
-    const float *keep;          // [L+1][B][64] or NULL
+    DropCfg drop;
     float *score, *feat;
     BnDev bn[3 * GCC_GIN_MAX_LAYERS];
     int32_t B, nlayers, kdim0, normalize, update_running;
-    float inv_keep, norm_eps, momentum;
+    float norm_eps, momentum;
 };
 struct ReadLaunch { ReadArgs p[kMaxPass]; };
 
 __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
 {
     const ReadArgs &a = L.p[blockIdx.y];
-    const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6;
-    const int b = (int)blockIdx.x * 4 + wv;
-    if (b < a.B) {
-        float s = 0.f;
-        for (int i = 0; i <= a.nlayers; ++i) {
-            const int kd = i == 0 ? a.kdim0 : H;
-            const double *pl = a.pooled + ((int64_t)i * a.B + b) * H;
-            const float *w = a.pred_w[i] + (int64_t)lane * kd;
-            float y = a.pred_b[i][lane];
-            for (int k = 0; k < kd; ++k) y = fmaf(w[k], (float)pl[k], y);          // linears_prediction[i](pooled_h)
-            if (a.keep) y = y * a.keep[((int64_t)i * a.B + b) * H + lane] * a.inv_keep;   // self.drop, gin.py:230
-            s += y;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
+    const int b = ((int)blockIdx.x * 4 + wv) * 16 + j;
+    const bool valid = b < a.B;
+    F4 score[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) { F4 z = {0.f, 0.f, 0.f, 0.f}; score[cb] = z; }
+    for (int i = 0; i <= a.nlayers; ++i) {
+        const int kd = i == 0 ? a.kdim0 : H;
+        F4 xb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            F4 x = {0.f, 0.f, 0.f, 0.f};
+            if (valid) {
+                const double *pl = a.pooled + ((int64_t)i * a.B + b) * H + 16 * c + 4 * q;
+                x.x = (float)pl[0]; x.y = (float)pl[1]; x.z = (float)pl[2]; x.w = (float)pl[3];
+            }
+            xb[c] = x;
         }
-        a.score[(int64_t)b * H + lane] = s;
-        float o = s;
-        if (a.normalize) {
-            const float nrm = sqrtf(wave_sum(s * s));
-            o = s / fmaxf(nrm, a.norm_eps);                                         // F.normalize(p=2, eps=1e-5)
+        F4 wf[4][4];
+        load_w_frags(a.pred_w[i], kd, wf);
+        f32x4 acc[4];
+        mfma_rows16(xb, wf, acc);                                  // linears_prediction[i](pooled_h)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int ch = 16 * cb + 4 * q;
+            const F4 bias = ld4(a.pred_b[i] + ch);
+            const F4 m = valid ? drop_mul4(a.drop, i, b, ch) : bias;   // self.drop, gin.py:230
+            score[cb].x += (acc[cb][0] + bias.x) * m.x;
+            score[cb].y += (acc[cb][1] + bias.y) * m.y;
+            score[cb].z += (acc[cb][2] + bias.z) * m.z;
+            score[cb].w += (acc[cb][3] + bias.w) * m.w;
         }
-        a.feat[(int64_t)b * H + lane] = o;
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+        ss += score[cb].x * score[cb].x + score[cb].y * score[cb].y + score[cb].z * score[cb].z + score[cb].w * score[cb].w;
+    ss += wave_shfl_xor(ss, 16);
+    ss += wave_shfl_xor(ss, 32);
+    const float inv = a.normalize ? 1.0f / fmaxf(sqrtf(ss), a.norm_eps) : 1.0f;   // F.normalize(p=2, eps=1e-5)
+    if (valid) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int ch = 16 * cb + 4 * q;
+            st4(a.score + (int64_t)b * H + ch, score[cb]);
+            F4 o = {score[cb].x * inv, score[cb].y * inv, score[cb].z * inv, score[cb].w * inv};
+            st4(a.feat + (int64_t)b * H + ch, o);
+        }
     }
     // BatchNorm running statistics (torch: momentum 0.1, unbiased variance) -- block 0 only
     if (a.update_running && blockIdx.x == 0 && tid < H) {
         const double n = (double)a.node_off[a.B];
         for (int k = 0; k < 3 * a.nlayers; ++k) {
             const BnDev &bn = a.bn[k];
-            const double mean = bn.stats[tid] / n;
-            double var = bn.stats[H + tid] / n - mean * mean;
+            double s1 = 0.0, s2 = 0.0;
+            for (int r = 0; r < kRep; ++r) { s1 += bn.stats[r * 2 * H + tid]; s2 += bn.stats[r * 2 * H + H + tid]; }
+            const double mean = s1 / n;
+            double var = s2 / n - mean * mean;
             if (var < 0.0) var = 0.0;
             const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
             bn.running_mean[tid] = (float)((1.0 - a.momentum) * (double)bn.running_mean[tid] + a.momentum * mean);
@@ -342,7 +388,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
     prof_mark(prof, 0, s);
     for (int i = 0; i < npass; ++i) {
         const gcc_gin_pass &p = passes[i];
-        (void)hipMemsetAsync(p.stats, 0, sizeof(double) * (size_t)Lg * 3 * 2 * H, s);
+        (void)hipMemsetAsync(p.stats, 0, sizeof(double) * (size_t)Lg * 3 * kRep * 2 * H, s);
         (void)hipMemsetAsync(p.pooled, 0, sizeof(double) * (size_t)(Lg + 1) * p.batch_size * H, s);
     }
     const dim3 grid(kGridX, npass), block(kThreads);
@@ -414,7 +460,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
             ReadArgs a;
             a.node_off = p.node_off; a.pooled = p.pooled;
             for (int k = 0; k <= Lg; ++k) { a.pred_w[k] = p.w.pred_w[k]; a.pred_b[k] = p.w.pred_b[k]; }
-            a.keep = p.dropout_keep; a.score = p.score; a.feat = p.feat;
+            a.drop = drop_cfg(p); a.score = p.score; a.feat = p.feat;
             for (int l = 0; l < Lg; ++l) {
                 a.bn[3 * l + 0] = bn_dev(p.w.bn_a[l], stats_of(p, l, 0));
                 a.bn[3 * l + 1] = bn_dev(p.w.bn_b[l], stats_of(p, l, 1));
@@ -422,10 +468,10 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
             }
             a.B = p.batch_size; a.nlayers = Lg; a.kdim0 = p.w.pos_dim + p.w.deg_emb_dim + 1;
             a.normalize = p.normalize; a.update_running = p.training && p.update_running_stats;
-            a.inv_keep = 1.0f / (1.0f - p.w.dropout_p); a.norm_eps = p.w.norm_eps; a.momentum = p.w.bn_momentum;
+            a.norm_eps = p.w.norm_eps; a.momentum = p.w.bn_momentum;
             L.p[i] = a;
         }
-        hipLaunchKernelGGL(gin_readout_kernel, dim3((maxB + 3) / 4, npass), block, 0, s, L);
+        hipLaunchKernelGGL(gin_readout_kernel, dim3((maxB + 63) / 64, npass), block, 0, s, L);
     }
     prof_mark(prof, 1, s);
     hipError_t e = hipGetLastError();

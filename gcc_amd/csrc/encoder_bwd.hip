@@ -18,14 +18,16 @@
 
 namespace {
 
-constexpr int kWgChunks = 32;     // row chunks (slabs) per weight gradient
+constexpr int kWgChunks = 64;     // row chunks (slabs) per weight gradient
 
 // per-column training-mode BatchNorm constants
 struct BnCol { float mean, rstd, gamma, beta; };
 __device__ __forceinline__ BnCol bn_col(const BnDev &bn, int c, double n, float eps)
 {
-    const double mean = bn.stats[c] / n;
-    double var = bn.stats[H + c] / n - mean * mean;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < kRep; ++r) { s1 += bn.stats[r * 2 * H + c]; s2 += bn.stats[r * 2 * H + H + c]; }
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
     BnCol r;
     r.mean = (float)mean;
@@ -52,7 +54,9 @@ __device__ __forceinline__ void fill_coefs(float *C /* [7][64] */, const BnDev &
         C[PS * H + c] = b.gamma * b.rstd;
         C[PH * H + c] = b.beta - b.gamma * b.rstd * b.mean;
         if (bst) {
-            const float m1 = (float)(bst[c] / n), m2 = (float)(bst[H + c] / n);
+            double b1 = 0.0, b2 = 0.0;
+            for (int r = 0; r < kRep; ++r) { b1 += bst[r * 3 * H + c]; b2 += bst[r * 3 * H + H + c]; }
+            const float m1 = (float)(b1 / n), m2 = (float)(b2 / n);
             const float k1 = b.gamma * b.rstd;
             C[K1 * H + c] = k1;
             C[K2 * H + c] = -k1 * m2 * b.rstd;
@@ -85,8 +89,9 @@ __device__ __forceinline__ void reduce_groups(float *part /* [16][128] */, F4 s1
     if (tid < 2 * H) {
         double v = 0.0;
         for (int k = 0; k < 16; ++k) v += (double)part[k * 2 * H + tid];
-        if (tid < H) atomicAdd(&dst0[tid], v);
-        else atomicAdd(&dst1[tid - H], v);
+        const int rep = ((int)blockIdx.x % kRep) * 3 * H;
+        if (tid < H) atomicAdd(&dst0[rep + tid], v);
+        else atomicAdd(&dst1[rep + tid - H], v);
     }
     __syncthreads();
 }
@@ -101,38 +106,74 @@ __device__ __forceinline__ float sum_rows16(float v)
 
 // =========================================================================
 // R1: d score, G_i = dscore * keep_i / (1 - p), dpooled_i = G_i W_i      (gin.py:227-230, graph_encoder.py:196)
+// one wave = 16 graphs; G_i in the MFMA output layout is already the input layout of the next MFMA
 struct ReadBwdArgs {
-    const float *dfeat, *score, *feat, *keep;
+    const float *dfeat, *score, *feat;
+    DropCfg drop;
     const float *pred_w[GCC_GIN_MAX_LAYERS + 1];
     float *G, *dpooled;       // [L+1][B][64]
     int32_t B, nlayers, kdim0, normalize;
-    float inv_keep, norm_eps;
+    float norm_eps;
 };
 
 __global__ __launch_bounds__(kThreads) void gin_bwd_readout_kernel(ReadBwdArgs a)
 {
-    const int lane = lane_id(), wv = (int)threadIdx.x >> 6;
-    const int b = (int)blockIdx.x * 4 + wv;
-    if (b >= a.B) return;    // wave-uniform
-    const float df = a.dfeat[(int64_t)b * H + lane];
-    float ds = df;
+    const int lane = lane_id(), wv = (int)threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const int b = ((int)blockIdx.x * 4 + wv) * 16 + j;
+    const bool valid = b < a.B;
+    F4 ds[4];
+    float ss = 0.f, dot = 0.f;
+    F4 fv[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int ch = 16 * cb + 4 * q;
+        F4 z = {0.f, 0.f, 0.f, 0.f};
+        ds[cb] = valid ? ld4(a.dfeat + (int64_t)b * H + ch) : z;
+        fv[cb] = z;
+        if (a.normalize && valid) {
+            const F4 s = ld4(a.score + (int64_t)b * H + ch);
+            fv[cb] = ld4(a.feat + (int64_t)b * H + ch);
+            ss += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+            dot += fv[cb].x * ds[cb].x + fv[cb].y * ds[cb].y + fv[cb].z * ds[cb].z + fv[cb].w * ds[cb].w;
+        }
+    }
     if (a.normalize) {
-        const float s = a.score[(int64_t)b * H + lane], f = a.feat[(int64_t)b * H + lane];
-        const float nrm = sqrtf(wave_sum(s * s));
-        const float dot = wave_sum(f * df);
-        ds = nrm > a.norm_eps ? (df - f * dot) / nrm : df / a.norm_eps;
+        ss += wave_shfl_xor(ss, 16); ss += wave_shfl_xor(ss, 32);
+        dot += wave_shfl_xor(dot, 16); dot += wave_shfl_xor(dot, 32);
+        const float nrm = sqrtf(ss);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            if (nrm > a.norm_eps) {
+                ds[cb].x = (ds[cb].x - fv[cb].x * dot) / nrm; ds[cb].y = (ds[cb].y - fv[cb].y * dot) / nrm;
+                ds[cb].z = (ds[cb].z - fv[cb].z * dot) / nrm; ds[cb].w = (ds[cb].w - fv[cb].w * dot) / nrm;
+            } else {
+                ds[cb].x /= a.norm_eps; ds[cb].y /= a.norm_eps; ds[cb].z /= a.norm_eps; ds[cb].w /= a.norm_eps;
+            }
+        }
     }
     for (int i = 0; i <= a.nlayers; ++i) {
         const int kd = i == 0 ? a.kdim0 : H;
-        const int64_t o = ((int64_t)i * a.B + b) * H + lane;
-        const float g = a.keep ? ds * a.keep[o] * a.inv_keep : ds;
-        a.G[o] = g;
-        float acc = 0.f;
-        for (int oo = 0; oo < H; ++oo) {
-            const float go = wave_shfl(g, oo);
-            if (lane < kd) acc = fmaf(go, a.pred_w[i][(int64_t)oo * kd + lane], acc);
+        F4 g[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int ch = 16 * cb + 4 * q;
+            F4 m = {0.f, 0.f, 0.f, 0.f};
+            if (valid) m = drop_mul4(a.drop, i, b, ch);
+            F4 gg = {ds[cb].x * m.x, ds[cb].y * m.y, ds[cb].z * m.z, ds[cb].w * m.w};
+            g[cb] = gg;
+            if (valid) st4(a.G + ((int64_t)i * a.B + b) * H + ch, gg);
         }
-        a.dpooled[o] = acc;
+        F4 wf[4][4];
+        load_wt_frags(a.pred_w[i], kd, wf);
+        f32x4 acc[4];
+        mfma_rows16(g, wf, acc);                                   // dpooled_i = G_i W_i
+        if (valid) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                F4 o = {acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]};
+                st4(a.dpooled + ((int64_t)i * a.B + b) * H + 16 * cb + 4 * q, o);
+            }
+        }
     }
 }
 
@@ -313,8 +354,9 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_lin_kernel(BwdLinArgs a)
         __syncthreads();
         if (tid < 3 * H) {
             const double v = (double)red[tid] + (double)red[3 * H + tid] + (double)red[6 * H + tid] + (double)red[9 * H + tid];
-            if (tid >= 2 * H) atomicAdd(&a.bst_bias[tid - 2 * H], v);
-            else if (kMask) atomicAdd(&a.bst_out[tid], v);
+            const int rep = ((int)blockIdx.x % kRep) * 3 * H;
+            if (tid >= 2 * H) atomicAdd(&a.bst_bias[rep + tid - 2 * H], v);
+            else if (kMask) atomicAdd(&a.bst_out[rep + tid], v);
         }
         __syncthreads();
     }
@@ -340,6 +382,7 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
     __shared__ float T[kTile * kLdt];
     __shared__ float part[16 * H];
     __shared__ float E[kEmbMaxElems];
+    __shared__ int dclrow[kTile];
     __shared__ int longrows[kTile];
     __shared__ int nlong;
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
@@ -353,15 +396,20 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
         for (int r = gi; r < kTile; r += 16) st4(&T[r * kLdt + 4 * t], r < nrows ? ident(tile0 + r) : zero4());
         __syncthreads();
         gather_tile(T, part, longrows, &nlong, tile0, nrows, a.row_ptr, a.col_idx, ident);
-        if (tid < a.emb_dim) {
-            for (int r = 0; r < nrows; ++r) {
-                const int v = tile0 + r;
-                const int deg = a.row_ptr[v + 1] - a.row_ptr[v];
-                const int dcl = deg < a.max_degree ? deg : a.max_degree;
-                E[dcl * a.emb_dim + tid] += T[r * kLdt + a.pos_dim + tid] +
-                                            a.dpooled0[(int64_t)a.graph_id[v] * H + a.pos_dim + tid];
-            }
+        // all threads: add the pooled-path gradient and look the clamped degree up (global loads in parallel) ...
+        if (tid < nrows) {
+            const int v = tile0 + tid;
+            const int deg = a.row_ptr[v + 1] - a.row_ptr[v];
+            dclrow[tid] = deg < a.max_degree ? deg : a.max_degree;
         }
+        for (int idx = tid; idx < nrows * a.emb_dim; idx += kThreads) {
+            const int r = idx / a.emb_dim, c = idx - r * a.emb_dim;
+            T[r * kLdt + a.pos_dim + c] += a.dpooled0[(int64_t)a.graph_id[tile0 + r] * H + a.pos_dim + c];
+        }
+        __syncthreads();
+        // ... then column c is owned by thread c: LDS only, fixed order, no atomics
+        if (tid < a.emb_dim)
+            for (int r = 0; r < nrows; ++r) E[dclrow[r] * a.emb_dim + tid] += T[r * kLdt + a.pos_dim + tid];
         __syncthreads();
     }
     for (int i = tid; i < elems; i += kThreads) a.demb_parts[(int64_t)blockIdx.x * elems + i] = E[i];
@@ -371,12 +419,16 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
 // weight gradients: slab[y][chunk] = sum over the chunk's rows of dZ^T X     (y = 2*l + which)
 struct WgradJob {
     const float *dZ, *X;
+    const double *Xd;         // prediction layers: X = pooled_i (fp64), rows = graphs
     BnDev bn;                 // which == 1: X = relu(bn_a(z1)); which == 0: X = agg (bn.weight == NULL)
+    int32_t rows_fixed;       // > 0: number of rows (B); 0: node_off[B]
 };
+constexpr int kMaxWgJobs = 3 * GCC_GIN_MAX_LAYERS + 1;
 struct WgradArgs {
     const int32_t *node_off;
-    WgradJob job[2 * GCC_GIN_MAX_LAYERS];
+    WgradJob job[kMaxWgJobs];
     float *slabs;             // [njobs][kWgChunks][64 * 64]
+    float *bias_slabs;        // [njobs][kWgChunks][64]   column sums of dZ
     int32_t B;
     float eps;
 };
@@ -387,11 +439,13 @@ __global__ __launch_bounds__(kThreads) void gin_wgrad_kernel(WgradArgs a)
     __shared__ float Cx[2 * H];
     const WgradJob &jb = a.job[blockIdx.y];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
-    const int N = a.node_off[a.B];
+    __shared__ float Sb[4 * H];
+    const int Nn = a.node_off[a.B];
+    const int N = jb.rows_fixed > 0 ? jb.rows_fixed : Nn;
     const bool act = jb.bn.weight != nullptr;
     if (tid < H) {
         float sc = 1.f, sh = 0.f;
-        if (act) bn_scale_shift(jb.bn, tid, (double)N, a.eps, 1, sc, sh);
+        if (act) bn_scale_shift(jb.bn, tid, (double)Nn, a.eps, 1, sc, sh);
         Cx[tid] = sc;
         Cx[H + tid] = sh;
     }
@@ -400,6 +454,7 @@ __global__ __launch_bounds__(kThreads) void gin_wgrad_kernel(WgradArgs a)
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) { xs[kb] = Cx[16 * kb + j]; xh[kb] = Cx[H + 16 * kb + j]; }
     f32x4 acc[4][4];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
@@ -412,7 +467,9 @@ __global__ __launch_bounds__(kThreads) void gin_wgrad_kernel(WgradArgs a)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 av[k] = row < N ? jb.dZ[(int64_t)row * H + 16 * k + j] : 0.f;
-                float x = row < N ? jb.X[(int64_t)row * H + 16 * k + j] : 0.f;
+                bsum[k] += av[k];
+                float x = 0.f;
+                if (row < N) x = jb.Xd ? (float)jb.Xd[(int64_t)row * H + 16 * k + j] : jb.X[(int64_t)row * H + 16 * k + j];
                 if (act) x = row < N ? fmaxf(fmaf(x, xs[k], xh[k]), 0.f) : 0.f;
                 bv[k] = x;
             }
@@ -439,15 +496,24 @@ __global__ __launch_bounds__(kThreads) void gin_wgrad_kernel(WgradArgs a)
     }
     float *slab = a.slabs + ((int64_t)blockIdx.y * kWgChunks + blockIdx.x) * H * H;
     for (int i = tid; i < H * H; i += kThreads) slab[i] = S[i];
+    // bias gradient = column sums of dZ: over the 4 rows of a step (lanes q), then over the waves
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        bsum[k] += wave_shfl_xor(bsum[k], 16);
+        bsum[k] += wave_shfl_xor(bsum[k], 32);
+        if (q == 0) Sb[wv * H + 16 * k + j] = bsum[k];
+    }
+    __syncthreads();
+    if (tid < H)
+        a.bias_slabs[((int64_t)blockIdx.y * kWgChunks + blockIdx.x) * H + tid] =
+            (Sb[tid] + Sb[H + tid]) + (Sb[2 * H + tid] + Sb[3 * H + tid]);
 }
 
 // =========================================================================
 // final: reduce slabs, prediction-layer / BatchNorm / bias / embedding gradients -> grads
 struct FinalArgs {
-    const float *slabs;
-    const float *G;           // [L+1][B][64]
-    const double *pooled;     // [L+1][B][64]
-    const double *bst;        // [L][3 (a,b,c)][3][64]
+    const float *slabs, *bias_slabs;
+    const double *bst;        // [L][3 (a,b,c)][kRep][3][64]
     const float *demb_parts;  // [kEmbBlocks][emb_rows * emb_dim]
     gcc_gin_grads g;
     int32_t B, L, kdim0, emb_rows, emb_dim, accumulate;
@@ -463,40 +529,36 @@ __global__ __launch_bounds__(kThreads) void gin_grad_final_kernel(FinalArgs a)
     const int64_t gid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const int L = a.L;
     int64_t base = 0;
-    // (1) linears.{0,1}.weight of every layer
-    const int64_t n1 = (int64_t)2 * L * H * H;
+    // (1) weight gradients from the slabs: jobs [0, 2L) = linears.{0,1} of every layer, [2L, 3L+1) = linears_prediction
+    const int njobs = 3 * L + 1;
+    const int64_t n1 = (int64_t)njobs * H * H;
     if (gid < n1) {
         const int y = (int)(gid / (H * H)), idx = (int)(gid % (H * H));
-        const int o = idx / H, k = idx % H, l = y >> 1, which = y & 1;
+        const int o = idx / H, k = idx % H;
         float s = 0.f;
         for (int c = 0; c < kWgChunks; ++c) s += a.slabs[((int64_t)y * kWgChunks + c) * H * H + idx];
-        const int kd = (which == 0 && l == 0) ? a.kdim0 : H;
-        float *dst = which ? a.g.lin1_w[l] : a.g.lin0_w[l];
+        int kd = H;
+        float *dst;
+        if (y < 2 * L) {
+            const int l = y >> 1, which = y & 1;
+            kd = (which == 0 && l == 0) ? a.kdim0 : H;
+            dst = which ? a.g.lin1_w[l] : a.g.lin0_w[l];
+        } else {
+            const int i = y - 2 * L;
+            kd = i == 0 ? a.kdim0 : H;
+            dst = a.g.pred_w[i];
+        }
         if (k < kd && dst) put(dst + (int64_t)o * kd + k, s, a.accumulate);
         return;
     }
     base += n1;
-    // (2) linears_prediction.i.weight: G_i^T pooled_i
-    const int64_t n2 = (int64_t)(L + 1) * H * H;
-    if (gid < base + n2) {
-        const int64_t r = gid - base;
-        const int i = (int)(r / (H * H)), idx = (int)(r % (H * H)), o = idx / H, k = idx % H;
-        const int kd = i == 0 ? a.kdim0 : H;
-        if (k >= kd) return;
-        float s = 0.f;
-        for (int b = 0; b < a.B; ++b)
-            s = fmaf(a.G[((int64_t)i * a.B + b) * H + o], (float)a.pooled[((int64_t)i * a.B + b) * H + k], s);
-        if (a.g.pred_w[i]) put(a.g.pred_w[i] + (int64_t)o * kd + k, s, a.accumulate);
-        return;
-    }
-    base += n2;
-    // (3) linears_prediction.i.bias
+    // (3) linears_prediction.i.bias = column sums of G_i
     const int64_t n3 = (int64_t)(L + 1) * H;
     if (gid < base + n3) {
         const int64_t r = gid - base;
         const int i = (int)(r / H), o = (int)(r % H);
         float s = 0.f;
-        for (int b = 0; b < a.B; ++b) s += a.G[((int64_t)i * a.B + b) * H + o];
+        for (int c = 0; c < kWgChunks; ++c) s += a.bias_slabs[((int64_t)(2 * L + i) * kWgChunks + c) * H + o];
         if (a.g.pred_b[i]) put(a.g.pred_b[i] + o, s, a.accumulate);
         return;
     }
@@ -506,7 +568,9 @@ __global__ __launch_bounds__(kThreads) void gin_grad_final_kernel(FinalArgs a)
     if (gid < base + n4) {
         const int64_t r = gid - base;
         const int c = (int)(r % H), slot = (int)((r / H) % 3), which = (int)((r / (3 * H)) % 3), l = (int)(r / (9 * H));
-        const float v = (float)a.bst[r];
+        double acc = 0.0;
+        for (int rep = 0; rep < kRep; ++rep) acc += a.bst[(((int64_t)l * 3 + which) * kRep + rep) * 3 * H + slot * H + c];
+        const float v = (float)acc;
         float *dst = nullptr;
         if (which == 0) dst = slot == 0 ? a.g.bn_a_b[l] : slot == 1 ? a.g.bn_a_w[l] : a.g.lin0_b[l];
         else if (which == 1) dst = slot == 0 ? a.g.bn_b_b[l] : slot == 1 ? a.g.bn_b_w[l] : a.g.lin1_b[l];
@@ -528,7 +592,7 @@ __global__ __launch_bounds__(kThreads) void gin_grad_final_kernel(FinalArgs a)
 struct BwdWork {
     float *U, *V, *Wt, *D;
     float *dz1[GCC_GIN_MAX_LAYERS], *dz2[GCC_GIN_MAX_LAYERS];
-    float *G, *dpooled, *slabs;
+    float *G, *dpooled, *slabs, *bias_slabs;
     double *bst;
     float *demb_parts;
     int64_t off_zero, zero_bytes, total;
@@ -548,10 +612,11 @@ inline BwdWork bwd_layout(char *base, int64_t node_cap, int32_t B, int32_t L, in
     }
     w.G = (float *)take((int64_t)(L + 1) * B * H * sizeof(float));
     w.dpooled = (float *)take((int64_t)(L + 1) * B * H * sizeof(float));
-    w.slabs = (float *)take((int64_t)2 * L * kWgChunks * H * H * sizeof(float));
+    w.slabs = (float *)take((int64_t)(3 * L + 1) * kWgChunks * H * H * sizeof(float));
+    w.bias_slabs = (float *)take((int64_t)(3 * L + 1) * kWgChunks * H * sizeof(float));
     w.demb_parts = (float *)take((int64_t)kEmbBlocks * emb_elems * sizeof(float));
     w.off_zero = o;                                   // everything from here on is zeroed per call
-    w.bst = (double *)take((int64_t)L * 9 * H * sizeof(double));
+    w.bst = (double *)take((int64_t)L * 9 * kRep * H * sizeof(double));
     w.zero_bytes = o - w.off_zero;
     w.total = o;
     return w;
@@ -596,14 +661,14 @@ extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat
     prof_mark(prof, 0, s);
     (void)hipMemsetAsync((char *)workspace + w.off_zero, 0, (size_t)w.zero_bytes, s);
     const dim3 grid(kGridX), block(kThreads);
-    auto bst = [&](int l, int which) { return w.bst + ((int64_t)l * 3 + which) * 3 * H; };   // which: 0=a 1=b 2=c
+    auto bst = [&](int l, int which) { return w.bst + ((int64_t)l * 3 + which) * kRep * 3 * H; };   // which: 0=a 1=b 2=c
     {
         ReadBwdArgs a;
-        a.dfeat = dfeat; a.score = p.score; a.feat = p.feat; a.keep = p.dropout_keep;
+        a.dfeat = dfeat; a.score = p.score; a.feat = p.feat; a.drop = drop_cfg(p);
         for (int i = 0; i <= L; ++i) a.pred_w[i] = p.w.pred_w[i];
         a.G = w.G; a.dpooled = w.dpooled; a.B = B; a.nlayers = L; a.kdim0 = kdim0; a.normalize = p.normalize;
-        a.inv_keep = 1.0f / (1.0f - p.w.dropout_p); a.norm_eps = p.w.norm_eps;
-        hipLaunchKernelGGL(gin_bwd_readout_kernel, dim3((B + 3) / 4), block, 0, s, a);
+        a.norm_eps = p.w.norm_eps;
+        hipLaunchKernelGGL(gin_bwd_readout_kernel, dim3((B + 63) / 64), block, 0, s, a);
     }
     for (int l = L - 1; l >= 0; --l) {
         const BnDev bna = bn_dev(p.w.bn_a[l], stats_of(p, l, 0));
@@ -636,19 +701,21 @@ extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat
     }
     {
         WgradArgs a;
-        a.node_off = p.node_off; a.slabs = w.slabs; a.B = B; a.eps = p.w.bn_eps;
+        a.node_off = p.node_off; a.slabs = w.slabs; a.bias_slabs = w.bias_slabs; a.B = B; a.eps = p.w.bn_eps;
         for (int l = 0; l < L; ++l) {
-            a.job[2 * l + 0] = {w.dz1[l], p.agg[l], BnDev()};
-            a.job[2 * l + 1] = {w.dz2[l], p.z1[l], bn_dev(p.w.bn_a[l], stats_of(p, l, 0))};
+            a.job[2 * l + 0] = {w.dz1[l], p.agg[l], nullptr, BnDev(), 0};
+            a.job[2 * l + 1] = {w.dz2[l], p.z1[l], nullptr, bn_dev(p.w.bn_a[l], stats_of(p, l, 0)), 0};
         }
-        hipLaunchKernelGGL(gin_wgrad_kernel, dim3(kWgChunks, 2 * L), block, 0, s, a);
+        for (int i = 0; i <= L; ++i)      // linears_prediction[i]: dW = G_i^T pooled_i over the B graphs
+            a.job[2 * L + i] = {w.G + (int64_t)i * B * H, nullptr, p.pooled + (int64_t)i * B * H, BnDev(), B};
+        hipLaunchKernelGGL(gin_wgrad_kernel, dim3(kWgChunks, 3 * L + 1), block, 0, s, a);
     }
     {
         FinalArgs a;
-        a.slabs = w.slabs; a.G = w.G; a.pooled = p.pooled; a.bst = w.bst; a.demb_parts = w.demb_parts; a.g = *grads;
+        a.slabs = w.slabs; a.bias_slabs = w.bias_slabs; a.bst = w.bst; a.demb_parts = w.demb_parts; a.g = *grads;
         a.B = B; a.L = L; a.kdim0 = kdim0; a.emb_rows = p.w.max_degree + 1; a.emb_dim = p.w.deg_emb_dim;
         a.accumulate = accumulate;
-        const int64_t total = (int64_t)2 * L * H * H + (int64_t)(L + 1) * H * H + (int64_t)(L + 1) * H +
+        const int64_t total = (int64_t)(3 * L + 1) * H * H + (int64_t)(L + 1) * H +
                               (int64_t)L * 9 * H + (int64_t)a.emb_rows * a.emb_dim;
         hipLaunchKernelGGL(gin_grad_final_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), block, 0, s, a);
     }

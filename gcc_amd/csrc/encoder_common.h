@@ -12,6 +12,9 @@ constexpr int kThreads = 256;
 constexpr int kGridX = 768;         // tiles are grid-strided
 constexpr int kLongRow = 48;
 constexpr int kMaxPass = 2;
+constexpr int kRep = 32;            // replicas of every atomically accumulated statistics row: a block adds to
+                                    // copy (blockIdx.x % kRep), consumers sum the copies -- ~730 workgroups hitting the
+                                    // same 8 cache lines with fp64 atomics cost 20-40 us per kernel (rocprof, round 1)
 
 struct F4 { float x, y, z, w; };
 
@@ -44,7 +47,7 @@ struct BnDev {
     const float *weight, *bias;
     float *running_mean, *running_var;
     int64_t *nbt;
-    const double *stats;    // [2][64] column sum / sum of squares of this BN's input (training mode)
+    const double *stats;    // [kRep][2][64] column sum / sum of squares of this BN's input (training mode)
 };
 
 // BatchNorm1d as y = x * scale + shift for channel c.  training: biased batch variance
@@ -54,8 +57,10 @@ __device__ __forceinline__ void bn_scale_shift(const BnDev &bn, int c, double n,
 {
     double mean, var;
     if (training) {
-        mean = bn.stats[c] / n;
-        var = bn.stats[H + c] / n - mean * mean;
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < kRep; ++r) { s1 += bn.stats[r * 2 * H + c]; s2 += bn.stats[r * 2 * H + H + c]; }
+        mean = s1 / n;
+        var = s2 / n - mean * mean;
         if (var < 0.0) var = 0.0;
     } else {
         mean = (double)bn.running_mean[c];
@@ -64,6 +69,20 @@ __device__ __forceinline__ void bn_scale_shift(const BnDev &bn, int c, double n,
     const double rstd = 1.0 / sqrt(var + (double)eps);
     scale = (float)((double)bn.weight[c] * rstd);
     shift = (float)((double)bn.bias[c] - mean * (double)bn.weight[c] * rstd);
+}
+
+// scale/shift of all 64 channels into an LDS table tab[2][64]; called by threads [t0, t0 + 64)
+__device__ __forceinline__ void bn_table(float *tab, const BnDev &bn, int t0, double n, float eps, int training)
+{
+    const int c = (int)threadIdx.x - t0;
+    if (c >= 0 && c < H) bn_scale_shift(bn, c, n, eps, training, tab[c], tab[H + c]);
+}
+__device__ __forceinline__ Aff4 aff4_from_table(const float *tab, int c0)
+{
+    Aff4 a;
+    a.scale = ld4(&tab[c0]);
+    a.shift = ld4(&tab[H + c0]);
+    return a;
 }
 
 __device__ __forceinline__ Aff4 bn_aff4(const BnDev &bn, int c0, double n, float eps, int training)
@@ -194,7 +213,7 @@ __device__ __forceinline__ void flush_stats(const float *red, double *stats)
     const int tid = (int)threadIdx.x;
     if (tid < 2 * H) {
         const double v = (double)red[tid] + (double)red[128 + tid] + (double)red[256 + tid] + (double)red[384 + tid];
-        atomicAdd(&stats[tid], v);
+        atomicAdd(&stats[((int)blockIdx.x % kRep) * 2 * H + tid], v);
     }
 }
 
@@ -251,15 +270,48 @@ __device__ __forceinline__ void gather_tile(float *T, float *part /* [16 * H] */
     }
 }
 
+// ---- dropout multiplier of linears_prediction[layer](pooled)[b][ch .. ch+3] (gin.py:230):
+// explicit keep masks if given, else Philox (one call per 4 consecutive channels), else 1
+struct DropCfg {
+    const float *keep;
+    uint64_t seed;
+    int32_t philox, B;
+    float p, inv_keep;
+};
+__device__ __forceinline__ F4 drop_mul4(const DropCfg &d, int layer, int b, int ch)
+{
+    F4 m = {1.f, 1.f, 1.f, 1.f};
+    if (d.keep) {
+        m = ld4(d.keep + ((int64_t)layer * d.B + b) * H + ch);
+        m.x *= d.inv_keep; m.y *= d.inv_keep; m.z *= d.inv_keep; m.w *= d.inv_keep;
+    } else if (d.philox) {
+        uint32_t x[4];
+        philox4x32_10((uint32_t)(b * (H / 4) + (ch >> 2)), (uint32_t)layer, 0xD50Fu, 0u, (uint32_t)d.seed,
+                      (uint32_t)(d.seed >> 32), x);
+        const float thr = d.p * 16777216.0f;
+        m.x = (float)(x[0] >> 8) >= thr ? d.inv_keep : 0.f;
+        m.y = (float)(x[1] >> 8) >= thr ? d.inv_keep : 0.f;
+        m.z = (float)(x[2] >> 8) >= thr ? d.inv_keep : 0.f;
+        m.w = (float)(x[3] >> 8) >= thr ? d.inv_keep : 0.f;
+    }
+    return m;
+}
+inline DropCfg drop_cfg(const gcc_gin_pass &p)
+{
+    DropCfg d = {p.dropout_keep, p.dropout_seed, p.dropout_keep ? 0 : p.dropout_philox, p.batch_size,
+                 p.w.dropout_p, 1.0f / (1.0f - p.w.dropout_p)};
+    return d;
+}
+
 inline BnDev bn_dev(const gcc_bn &b, const double *stats)
 {
     BnDev d = {b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked, stats};
     return d;
 }
 
-inline double *stats_of(const gcc_gin_pass &p, int layer, int which)   // [layer][bn a|b|c][2][64]
+inline double *stats_of(const gcc_gin_pass &p, int layer, int which)   // [layer][bn a|b|c][kRep][2][64]
 {
-    return p.stats + ((int64_t)layer * 3 + which) * 2 * H;
+    return p.stats + ((int64_t)layer * 3 + which) * kRep * 2 * H;
 }
 
 }  // namespace

@@ -17,6 +17,8 @@
 // [B, K+1] is only materialised when the caller asks for it (train.py indexes out[:, 0]).
 #include "host_common.h"
 
+#include <math.h>
+
 namespace {
 
 constexpr int D = GCC_NCE_DIM;    // 64
@@ -53,7 +55,7 @@ inline Plan make_plan(int32_t B, int32_t K)
 {
     Plan p;
     p.QB = (B + kQPerBlock - 1) / kQPerBlock;
-    int s = (256 + p.QB - 1) / p.QB;
+    int s = (128 + p.QB - 1) / p.QB;       // ~128 workgroups: enough to spread the queue, few enough slabs to reduce
     const int maxs = (K + kChunk - 1) / kChunk;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
@@ -174,51 +176,41 @@ __global__ __launch_bounds__(kThreads) void nce_slice_kernel(NceDev a)
     }
 }
 
-__device__ __forceinline__ float dot64(const float *x, const float *y)
-{
-    float s = 0.f;
-    for (int d = 0; d < D; ++d) s = fmaf(x[d], y[d], s);
-    return s;
-}
-
 __global__ __launch_bounds__(kThreads) void nce_combine_kernel(NceDev a)
 {
-    __shared__ double red[2 * kThreads];
-    const int tid = (int)threadIdx.x;
+    // one block; each wave walks over queries, lanes over the 64 feature dims / the slices
+    __shared__ double red[8];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6;
     double lsum = 0.0, psum = 0.0;
     const int ld_out = a.K + (a.pos_mode == 0 ? 1 : 0);
-    for (int b = tid; b < a.B; b += kThreads) {
-        float pos, M, sum;
-        if (a.pos_mode == 0) {                       // l_pos = bmm(q, k), memory_moco.py:33-34
-            pos = dot64(a.q + (int64_t)b * D, a.k + (int64_t)b * D) * a.inv_T;
-            if (a.out_dense) a.out_dense[(int64_t)b * ld_out] = pos;
-            M = pos;
-        } else {                                     // positives on the diagonal, criterions.py:30-31
-            pos = dot64(a.q + (int64_t)b * D, a.mem + (int64_t)b * D) * a.inv_T;
-            M = -INFINITY;
-        }
-        for (int s = 0; s < a.S; ++s) M = fmaxf(M, a.pm[(int64_t)s * a.B + b]);
-        sum = a.pos_mode == 0 ? expf(pos - M) : 0.f;
-        for (int s = 0; s < a.S; ++s) {
+    for (int b = wv; b < a.B; b += kThreads >> 6) {
+        const float *other = a.pos_mode == 0 ? a.k : a.mem;        // l_pos = bmm(q, k) | diagonal of k q^T
+        const float pos = wave_sum(a.q[(int64_t)b * D + lane] * other[(int64_t)b * D + lane]) * a.inv_T;
+        float m = -INFINITY;
+        for (int s = lane; s < a.S; s += 64) m = fmaxf(m, a.pm[(int64_t)s * a.B + b]);
+        m = wave_max(m);
+        if (a.pos_mode == 0) m = fmaxf(m, pos);
+        float sum = 0.f;
+        for (int s = lane; s < a.S; s += 64) {
             const float pmv = a.pm[(int64_t)s * a.B + b];
-            if (pmv > -INFINITY) sum += a.ps[(int64_t)s * a.B + b] * expf(pmv - M);
+            if (pmv > -INFINITY) sum += a.ps[(int64_t)s * a.B + b] * expf(pmv - m);
         }
-        const float lse = M + logf(sum);
-        a.lse[b] = lse;
-        a.pos[b] = pos;
-        lsum += (double)(lse - pos);                 // CrossEntropyLoss row term
-        psum += (double)pos;
+        sum = wave_sum(sum);
+        if (a.pos_mode == 0) sum += expf(pos - m);
+        const float lse = m + logf(sum);
+        if (lane == 0) {
+            a.lse[b] = lse;
+            a.pos[b] = pos;
+            if (a.pos_mode == 0 && a.out_dense) a.out_dense[(int64_t)b * ld_out] = pos;
+            lsum += (double)(lse - pos);                 // CrossEntropyLoss row term
+            psum += (double)pos;
+        }
     }
-    red[tid] = lsum;
-    red[kThreads + tid] = psum;
+    if (lane == 0) { red[wv] = lsum; red[4 + wv] = psum; }
     __syncthreads();
-    for (int d = kThreads >> 1; d > 0; d >>= 1) {
-        if (tid < d) { red[tid] += red[tid + d]; red[kThreads + tid] += red[kThreads + tid + d]; }
-        __syncthreads();
-    }
     if (tid == 0) {
-        a.loss[0] = (float)(red[0] / (double)a.B);           // reduction="mean"
-        a.prob[0] = (float)(red[kThreads] / (double)a.B);    // out[:, 0].mean(), train.py:394
+        a.loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)a.B);    // reduction="mean"
+        a.prob[0] = (float)((red[4] + red[5] + red[6] + red[7]) / (double)a.B);    // out[:, 0].mean(), train.py:394
     }
 }
 
@@ -228,8 +220,16 @@ __global__ __launch_bounds__(kThreads) void nce_dq_kernel(NceDev a)
     const int b = gid >> 4, c4 = (gid & 15) * 4;
     if (b >= a.B) return;
     F4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int sl = 0; sl < a.S; ++sl) {
-        const F4 v = ld4(a.slabs + ((int64_t)sl * a.B + b) * D + c4);
+    const float *sp = a.slabs + (int64_t)b * D + c4;
+    const int64_t st = (int64_t)a.B * D;
+    int sl = 0;
+    for (; sl + 4 <= a.S; sl += 4) {                 // 4 independent 16-B loads in flight; fixed summation order
+        const F4 v0 = ld4(sp + sl * st), v1 = ld4(sp + (sl + 1) * st), v2 = ld4(sp + (sl + 2) * st), v3 = ld4(sp + (sl + 3) * st);
+        s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+        s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; sl < a.S; ++sl) {
+        const F4 v = ld4(sp + sl * st);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     const int nrows = a.by_mem_row ? a.K : a.B;              // rows of the softmax that is averaged
@@ -263,6 +263,48 @@ __global__ __launch_bounds__(kThreads) void ema_kernel(float *ema, const float *
     const int64_t stride = (int64_t)gridDim.x * kThreads;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride)
         ema[i] = ema[i] * m + (1.f - m) * p[i];               // p2.mul_(m).add_(1 - m, p1)
+}
+
+// ---- clip_grad_norm_ + Adam over one flat buffer (train.py:409,417)
+__global__ __launch_bounds__(1024) void gradnorm_kernel(const float *g, int64_t n, double *out)
+{
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)g[i] * (double)g[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        out[0] = t;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void adam_kernel(float *p, float *g, float *m, float *v, int64_t n, float lr,
+                                                        float b1, float b2, float eps, float wd, float bc1,
+                                                        float bc2_sqrt, float max_norm, const double *sumsq,
+                                                        float *grad_norm)
+{
+    const float norm = (float)sqrt(sumsq[0]);
+    float coef = 1.f;
+    if (max_norm > 0.f) {                                      // torch.nn.utils.clip_grad_norm_
+        coef = max_norm / (norm + 1e-6f);
+        coef = coef > 1.f ? 1.f : coef;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) grad_norm[0] = norm;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const float gc = g[i] * coef;
+        g[i] = gc;                                             // the clipped gradient stays visible, as in torch
+        const float gi = fmaf(wd, p[i], gc);                   // weight_decay: grad = grad + wd * param
+        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
 }
 
 inline int fill_dev(const gcc_nce_args *a, void *workspace, int64_t workspace_bytes, NceDev &d, Plan &pl)
@@ -346,6 +388,25 @@ int32_t gcc_queue_enqueue(float *mem, int32_t K, const float *keys, int32_t nkey
     }
     hipLaunchKernelGGL(queue_enqueue_kernel, dim3((nkeys * 16 + kThreads - 1) / kThreads), dim3(kThreads), 0,
                        (hipStream_t)stream, mem, K, keys, nkeys, index, saved);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
+int32_t gcc_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                      float *grad_norm, double *scratch, void *stream)
+{
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !grad_norm || !scratch || n < 1 || step < 1) {
+        snprintf(g_err, kErrLen, "gcc_adam_step: bad argument");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(gradnorm_kernel, dim3(1), dim3(1024), 0, s, (const float *)grad, n, scratch);
+    int blocks = (int)((n + kThreads - 1) / kThreads);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(kThreads), 0, s, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                       beta2, eps, weight_decay, bc1, bc2_sqrt, max_norm, (const double *)scratch, grad_norm);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 

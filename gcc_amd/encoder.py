@@ -16,6 +16,7 @@ import torch.nn as nn
 from . import _cabi
 
 H = _cabi.GIN_HIDDEN
+STATS_REPLICAS = 32        # kRep of gcc_amd/csrc/encoder_common.h
 
 
 # ---------------------------------------------------------------------------
@@ -131,12 +132,12 @@ class GinEngine:
                 agg=[torch.zeros(node_cap, H, **f32) for _ in range(L)],
                 z1=[torch.zeros(node_cap, H, **f32) for _ in range(L)],
                 z2=[torch.zeros(node_cap, H, **f32) for _ in range(L)],
-                stats=torch.zeros(L, 3, 2, H, dtype=torch.float64, device=device),
+                stats=torch.zeros(L, 3, STATS_REPLICAS, 2, H, dtype=torch.float64, device=device),
                 pooled=torch.zeros(L + 1, B, H, dtype=torch.float64, device=device),
                 score=torch.zeros(B, H, **f32), feat=torch.zeros(B, H, **f32))
         return self._bufs[k]
 
-    def make_pass(self, enc, g, training, keep=None, slot=0):
+    def make_pass(self, enc, g, training, keep=None, slot=0, dropout_seed=None):
         """-> (GccGinPass, buffers).  ``g`` needs node_off,row_ptr,col_idx,graph_id,pos_undirected,batch_size."""
         ptr = self.ptr
         L = len(enc.gnn.ginlayers)
@@ -152,6 +153,8 @@ class GinEngine:
         p.update_running_stats = int(training)
         p.normalize = int(enc.norm)
         p.dropout_keep = ptr(keep) if keep is not None else None
+        p.dropout_philox = int(keep is None and dropout_seed is not None)      # in-kernel Philox masks
+        p.dropout_seed = int(dropout_seed or 0) & 0xFFFFFFFFFFFFFFFF
         p.w = fill_weights(enc, ptr)
         p.x0 = ptr(buf["x0"])
         for i in range(L):

@@ -64,6 +64,37 @@ def clip_grad_norm(params, max_norm):
     return torch.sqrt(sum(p.grad.data.norm() ** 2 for p in params if p.grad is not None))
 
 
+class FlatAdam:
+    """clip_grad_norm_ + torch.optim.Adam(lr, betas, eps=1e-8, weight_decay) (train.py:409,667-672) over one flat
+    parameter buffer, as two HIP launches (gcc_adam_step).  ``param_groups`` / ``state_dict`` keep the shape
+    train.py expects (it sets ``param_group["lr"]`` every step and checkpoints ``optimizer.state_dict()``)."""
+
+    def __init__(self, param, grad, lr, betas, weight_decay, clip_norm, engine, eps=1e-8):
+        self.param, self.grad, self.engine = param, grad, engine
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
+        self.clip_norm = clip_norm
+        self.exp_avg = torch.zeros_like(param)
+        self.exp_avg_sq = torch.zeros_like(param)
+        self.steps = 0
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=param.device)
+        self._scratch = torch.zeros(1, dtype=torch.float64, device=param.device)
+
+    def step(self):
+        g = self.param_groups[0]
+        self.steps += 1
+        st = torch.cuda.current_stream(self.param.device).cuda_stream if self.param.is_cuda else None
+        self.engine.adam(self.param, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"], g["eps"],
+                         g["weight_decay"], self.steps, self.clip_norm, self.grad_norm, self._scratch, stream=st)
+        return self.grad_norm
+
+    def zero_grad(self):
+        pass                 # the backward kernels overwrite the flat gradient
+
+    def state_dict(self):
+        return dict(state=dict(step=self.steps, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq),
+                    param_groups=self.param_groups)
+
+
 class MoCoTrainStep:
     def __init__(self, model: GraphEncoder, model_ema: GraphEncoder, contrast: MemoryMoCo, sampler, posemb,
                  learning_rate=0.005, betas=(0.9, 0.999), weight_decay=1e-5, clip_norm=1.0, alpha=0.999,
@@ -83,12 +114,12 @@ class MoCoTrainStep:
             self.grad_views.append(self.flat_grad[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.live = self.flat[: self.n_live]
-        self.live.grad = self.flat_grad
-        # Adam(lr, betas, weight_decay as L2) over exactly the parameters that get gradients, train.py:667-672
-        self.optimizer = torch.optim.Adam([self.live], lr=learning_rate, betas=betas, weight_decay=weight_decay,
-                                          fused=self.dev.type == "cuda")
         self.gin = model.engine()
         self.nce = contrast.engine()
+        # Adam(lr, betas, weight_decay as L2) over exactly the parameters that get gradients, train.py:667-672
+        self.optimizer = FlatAdam(self.live, self.flat_grad, learning_rate, betas, weight_decay, clip_norm, self.nce)
+        self.mask_fn = None          # tests inject explicit dropout keep-masks here; default = in-kernel Philox
+        self.dropout_seed = 0x5EED0000
         self.B = sampler.batch_size
         self.L = len(model.gnn.ginlayers)
         self.keys_all = torch.empty(self.B * world_size, H, device=self.dev) if world_size > 1 else None
@@ -144,8 +175,9 @@ class MoCoTrainStep:
         q, k = self._next_batch(step)
         st = torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else None
         p_drop = self.model.gnn.drop.p
-        keep = (torch.rand(self.L + 1, self.B, H, device=self.dev) >= p_drop).float() if p_drop > 0 else None
-        pq, bufq = self.gin.make_pass(self.model, q, training=True, keep=keep, slot=("step", 0))
+        keep = self.mask_fn() if self.mask_fn is not None else None
+        seed = (self.dropout_seed + step * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF if p_drop > 0 else None
+        pq, bufq = self.gin.make_pass(self.model, q, training=True, keep=keep, slot=("step", 0), dropout_seed=seed)
         pk, bufk = self.gin.make_pass(self.ema, k, training=True, keep=None, slot=("step", 1))
         self.gin.forward([pq, pk], stream=st, prof=pr.get("gin_fwd"))      # train.py:389-391
         feat_q, feat_k = bufq["feat"], bufk["feat"]
@@ -164,10 +196,9 @@ class MoCoTrainStep:
         if self.world > 1:
             torch.distributed.all_reduce(self.flat_grad)                # one flat bucket (248 KiB) over xGMI
             self.flat_grad.mul_(1.0 / self.world)
-        gnorm = clip_grad_norm([self.live], self.clip_norm)             # train.py:409
         for grp in self.optimizer.param_groups:                          # train.py:411-416
             grp["lr"] = lr
-        self.optimizer.step()                                            # train.py:417
+        gnorm = self.optimizer.step()                                    # clip (train.py:409) + Adam (train.py:417)
         moment_update(self.model, self.ema, self.alpha, engine=self.nce)  # train.py:430-431
         if self.prefetch:
             ev = torch.cuda.Event()

@@ -139,6 +139,7 @@ int32_t gcc_posemb(const gcc_batch_out *g, int32_t batch_size, int32_t hidden, f
  * All arithmetic is fp32 (f32 MFMA), BatchNorm / pooling sums accumulate in fp64. */
 #define GCC_GIN_MAX_LAYERS 8     /* GIN message-passing layers = num_layers - 1 (train.py:79 -> 4) */
 #define GCC_GIN_HIDDEN 64
+#define GCC_GIN_STAT_REPLICAS 32  /* atomically accumulated rows are spread over this many copies */
 
 typedef struct gcc_bn {          /* torch.nn.BatchNorm1d(64) */
     const float *weight, *bias;  /* device [64]                                           */
@@ -171,14 +172,16 @@ typedef struct gcc_gin_pass {    /* one encoder invocation on one batched graph 
     int32_t training;            /* 1: BatchNorm uses batch statistics (train.py:357-365)  */
     int32_t update_running_stats;/* 1: momentum update of running_mean/var                 */
     int32_t normalize;           /* graph_encoder.py:195 (train.py:83 default True)        */
-    const float *dropout_keep;   /* device [num_gin_layers+1, B, 64] 0/1 keep masks, or NULL (no dropout) */
+    const float *dropout_keep;   /* device [num_gin_layers+1, B, 64] 0/1 keep masks, or NULL                    */
+    uint64_t dropout_seed;       /* used when dropout_keep == NULL and dropout_philox != 0: keep(i, b, o) =     */
+    int32_t dropout_philox;      /*   Philox4x32-10(key = seed, ctr = (b*64+o, i, 0xD50F, 0)).x >> 8 >= p * 2^24 */
     gcc_gin_weights w;
     /* activations, caller-allocated, kept for backward: */
     float *x0;                   /* [node_cap, 64] assembled input features (cols >= d_in are 0) */
     float *agg[GCC_GIN_MAX_LAYERS];   /* [node_cap, 64] h + sum_{u->v} h_u                */
     float *z1[GCC_GIN_MAX_LAYERS];    /* [node_cap, 64] linears.0 output                   */
     float *z2[GCC_GIN_MAX_LAYERS];    /* [node_cap, 64] linears.1 output                   */
-    double *stats;               /* [num_gin_layers, 3, 2, 64] column sum / sum of squares */
+    double *stats;               /* [num_gin_layers, 3, GCC_GIN_STAT_REPLICAS, 2, 64] column sum / sum of squares */
     double *pooled;              /* [num_gin_layers+1, B, 64] SumPooling of hidden_rep     */
     float *score;                /* [B, 64] score_over_layer before normalisation          */
     float *feat;                 /* [B, 64] output                                         */
@@ -244,6 +247,14 @@ int32_t gcc_nce_backward(const gcc_nce_args *a, const float *dloss, int32_t by_m
  * the overwritten rows are first copied there (the `patch` of gcc_nce_args). */
 int32_t gcc_queue_enqueue(float *mem, int32_t K, const float *keys, int32_t nkeys, int32_t index, float *saved,
                           void *stream);
+
+/* clip_grad_norm_(max_norm) + Adam.step() of train.py:409,417 over one flat buffer (torch.optim.Adam
+ * semantics: L2 weight decay added to the gradient, bias correction with `step` >= 1, eps outside the
+ * sqrt).  grad_norm: device [1] out (the pre-clip norm); max_norm <= 0 disables clipping.
+ * scratch: device double[1]. */
+int32_t gcc_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                      float *grad_norm, double *scratch, void *stream);
 
 /* moment_update of train.py:169-172 over one flat parameter buffer: ema = m * ema + (1 - m) * p */
 int32_t gcc_ema_update(float *ema, const float *p, int64_t n, float m, void *stream);

@@ -49,7 +49,7 @@ def _worker(rank, world, port, out_dir):
         views = (0, 1) if rank == 0 else (1, 0)          # the two ranks see different shards
         gold, step, model, ema, contrast = _build(views, world, rank)
         masks = gold["moco"]["masks"].contiguous()
-        torch.rand = lambda *a, **k: masks.clone()
+        step.mask_fn = lambda: masks
         out = step.step(0, gold["moco"]["lr"])
         torch.save(dict(model=model.state_dict(), ema=ema.state_dict(), memory=contrast.memory.clone(),
                         index=contrast.index, grad=step.flat_grad.clone(), loss=out["loss"].clone(),
@@ -73,16 +73,12 @@ def test_two_rank_step_over_gloo(tmp_path):
     torch.testing.assert_close(r0["grad"], r1["grad"], rtol=0, atol=0)
     assert r0["index"] == r1["index"] == 12              # 2 ranks x 6 keys enqueued
     # single-process references for each shard: averaged gradient and rank-ordered keys
-    torch_rand = torch.rand
     grads, keys = [], []
     for views in ((0, 1), (1, 0)):
         gold, step, model, ema, contrast = _build(views, 1, 0)
         masks = gold["moco"]["masks"].contiguous()
-        torch.rand = lambda *a, **k: masks.clone()
-        try:
-            step.step(0, gold["moco"]["lr"])
-        finally:
-            torch.rand = torch_rand
+        step.mask_fn = lambda: masks
+        step.step(0, gold["moco"]["lr"])
         grads.append(step.flat_grad.clone())
         keys.append(contrast.memory[:6].clone())         # this shard's keys were enqueued at rows 0..5
     torch.testing.assert_close(r0["grad"], (grads[0] + grads[1]) / 2, rtol=1e-5, atol=1e-7)
