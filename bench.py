@@ -26,6 +26,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # producer lanes run on their own HIP streams
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -48,6 +50,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--posemb", choices=["device", "placeholder"], default="device")
+    ap.add_argument("--lanes", type=int, default=12, help="producer streams (sampler + positional embedding)")
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight per producer lane")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass")
     return ap.parse_args()
@@ -190,7 +194,9 @@ def main():
     graph = DeviceGraph(rp, ci, rw_hops=args.rw_hops, restart_prob=args.restart_prob, device=dev, validate=False)
     B = args.batch_size
     torch.manual_seed(0)
-    sampler = DeviceRWRSampler(graph, B, run_seed=args.run_seed)
+    nbuf = args.depth + 1
+    samplers = [DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=nbuf) for _ in range(args.lanes)]
+    sampler = samplers[0]
     enc_kw = dict(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
                   freq_embedding_size=16, degree_embedding_size=16, output_dim=64, node_hidden_dim=64,
                   edge_hidden_dim=64, num_layers=5, num_step_set2set=6, num_layer_set2set=3, norm=True,
@@ -199,10 +205,13 @@ def main():
     model_ema.load_state_dict(model.state_dict())                     # moment_update(model, model_ema, 0), train.py:624
     contrast = MemoryMoCo(64, None, args.nce_k, 0.07, use_softmax=True).to(dev)
     if args.posemb == "device":
-        posemb = DevicePosEmb(B, sampler.node_cap, 32, device=dev, seed=args.run_seed)
+        posembs = [DevicePosEmb(B, sampler.node_cap, 32, device=dev, seed=args.run_seed, num_buffers=nbuf)
+                   for _ in range(args.lanes)]
     else:
-        posemb = PlaceholderPosEmb(sampler.node_cap, 32, device=dev)
-    trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank)
+        posembs = [PlaceholderPosEmb(sampler.node_cap, 32, device=dev)] * args.lanes
+    posemb = posembs[0]
+    trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank,
+                            extra_lanes=list(zip(samplers[1:], posembs[1:])), depth=args.depth)
     stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder q+k fwd",
               "moco-infonce fwd", "key all-gather" if world > 1 else "enqueue", "infonce bwd", "gin-encoder bwd",
               "grad all-reduce" if world > 1 else "clip", "adam", "ema"]
@@ -238,8 +247,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    sampler.check_status()
-    posemb_status = int(posemb.status.item()) if hasattr(posemb, "status") else 0
+    for smp in samplers:
+        smp.check_status()
+    posemb_status = [int(x) for x in sum(p.status.cpu() for p in posembs).tolist()] if hasattr(posemb, "status") else [0]
     final_loss = float(last["loss"].item())
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -282,7 +292,7 @@ def main():
                        "graph_nodes": int(len(rp) - 1), "graph_edges": int(len(ci)),
                        "batch_size_per_gpu": B, "global_batch": B * world, "nce_k": args.nce_k,
                        "rw_hops": args.rw_hops, "restart_prob": args.restart_prob,
-                       "stages": stages, "parallelism": f"dp{world} (seed batch sharded, graph replicated)"},
+                       "stages": stages, "producer_lanes": args.lanes, "producer_depth": args.depth, "parallelism": f"dp{world} (seed batch sharded, graph replicated)"},
             "kernel_ms": kern, "stage_ms": stage_ms, "final_loss": final_loss, "posemb_status": posemb_status,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

@@ -22,7 +22,8 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kJMax = GCC_POSEMB_JACOBI_MAX;
 constexpr int kMaxSweeps = 14;
-constexpr int kJThreads = 1024;   // the standalone Jacobi kernel: 4 waves per SIMD hide the LDS round trips
+constexpr int kJSmall = 64;        // size classes of the Jacobi kernel: n <= 64 needs 33 KiB of LDS (4 workgroups per CU,
+                                   // 256 threads), 65..128 needs 132 KiB (1 per CU, 1024 threads hide the LDS round trips)
 
 struct PosArgs {
     const int32_t *node_off, *row_ptr, *col_idx;
@@ -146,7 +147,8 @@ __device__ __forceinline__ int rank_desc(const float *lam, int n, int i)
     return r;
 }
 
-__global__ __launch_bounds__(kJThreads) void posemb_jacobi_kernel(PosArgs a)
+template <int kNMin, int kNMax, int kT>
+__global__ __launch_bounds__(kT) void posemb_jacobi_kernel(PosArgs a)
 {
     DYN_SMEM(smem);
     __shared__ float rot[kJMax];
@@ -155,21 +157,21 @@ __global__ __launch_bounds__(kJThreads) void posemb_jacobi_kernel(PosArgs a)
     __shared__ float dinv[kJMax];
     __shared__ int colof[kJMax];
     __shared__ int flag;
-    __shared__ float red[kJThreads];
+    __shared__ float red[kT];
     const int tid = (int)threadIdx.x;
     const int b = (int)blockIdx.x;
     if (b >= a.B) return;
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
-    if (n > kJMax) return;                         // handled by the Krylov kernel
+    if (n > kNMax || n < kNMin) return;            // other size class / Krylov kernel
     const int k = min(n - 2, a.hidden);            // data_util.py:278
     if (k <= 0) {                                  // data_util.py:243-244: zeros
-        for (int i = tid; i < n * a.hidden; i += kJThreads) a.pos[(int64_t)n0 * a.hidden + i] = 0.f;
-        if (a.evals) for (int i = tid; i < a.hidden; i += kJThreads) a.evals[(int64_t)b * a.hidden + i] = 0.f;
+        for (int i = tid; i < n * a.hidden; i += kT) a.pos[(int64_t)n0 * a.hidden + i] = 0.f;
+        if (a.evals) for (int i = tid; i < a.hidden; i += kT) a.evals[(int64_t)b * a.hidden + i] = 0.f;
         return;
     }
     const int np = (n + 1) & ~1, lda = np + 1;
     float *A = (float *)smem, *V = A + np * lda;
-    for (int i = tid; i < np * lda; i += kJThreads) { A[i] = 0.f; V[i] = 0.f; }
+    for (int i = tid; i < np * lda; i += kT) { A[i] = 0.f; V[i] = 0.f; }
     if (tid < np) {
         int d = tid < n ? a.row_ptr[n0 + tid + 1] - a.row_ptr[n0 + tid] : 1;
         dinv[tid] = 1.0f / sqrtf((float)(d < 1 ? 1 : d));     // in_degrees().clip(1) ** -0.5, data_util.py:274-276
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(kJThreads) void posemb_jacobi_kernel(PosArgs a)
     __syncthreads();
     if (tid < np) V[tid * lda + tid] = 1.f;
     // laplacian = norm * adj * norm (data_util.py:277); one wave per row keeps the loads coalesced
-    for (int r = tid >> 6; r < n; r += kJThreads >> 6) {
+    for (int r = tid >> 6; r < n; r += kT >> 6) {
         const int beg = a.row_ptr[n0 + r], end = a.row_ptr[n0 + r + 1];
         for (int e = beg + (tid & 63); e < end; e += 64) {
             const int c = a.col_idx[e] - n0;
@@ -187,10 +189,10 @@ __global__ __launch_bounds__(kJThreads) void posemb_jacobi_kernel(PosArgs a)
     __syncthreads();
     // ||A||_F for the rotation threshold
     float ss = 0.f;
-    for (int i = tid; i < np * lda; i += kJThreads) ss += A[i] * A[i];
+    for (int i = tid; i < np * lda; i += kT) ss += A[i] * A[i];
     red[tid] = ss;
     __syncthreads();
-    for (int d = kJThreads >> 1; d > 0; d >>= 1) {
+    for (int d = kT >> 1; d > 0; d >>= 1) {
         if (tid < d) red[tid] += red[tid + d];
         __syncthreads();
     }
@@ -206,10 +208,10 @@ __global__ __launch_bounds__(kJThreads) void posemb_jacobi_kernel(PosArgs a)
         colof[tid] = r < k ? k - 1 - r : -1;
         if (a.evals && r < k) a.evals[(int64_t)b * a.hidden + (k - 1 - r)] = lam[tid];
     }
-    if (a.evals) for (int i = k + tid; i < a.hidden; i += kJThreads) a.evals[(int64_t)b * a.hidden + i] = 0.f;
+    if (a.evals) for (int i = k + tid; i < a.hidden; i += kT) a.evals[(int64_t)b * a.hidden + i] = 0.f;
     __syncthreads();
     // x = normalize(u, "l2") row-wise, float32, zero padded to `hidden` columns (data_util.py:260-262)
-    for (int r = tid >> 6; r < n; r += kJThreads >> 6) {
+    for (int r = tid >> 6; r < n; r += kT >> 6) {
         const int lane = tid & 63;
         float s2 = 0.f;
         for (int i = lane; i < n; i += 64) {
@@ -246,35 +248,38 @@ __global__ __launch_bounds__(kJThreads) void posemb_jacobi_kernel(PosArgs a)
 // first copy are only found through rounding.
 constexpr int kM = 64;
 constexpr int kKeepExtra = 8;
-constexpr int kMaxCycles = 80;
+constexpr int kMaxCycles = 16;        // restarts; pairs next to a tiny spectral gap converge (and are defined) poorly
+constexpr float kRitzTol = 1e-4f;     // |beta_m y_mi| of the wanted pairs (ARPACK: machine eps; tests: 1e-3)
 constexpr int kLongDeg = 32;
-constexpr int kMaxLong = 256;
+constexpr int kMaxLong = 512;
+constexpr int kKThreads = 1024;      // 16 waves: the long-vector work is bound by L2 latency, not by FLOPs
+constexpr int kKWaves = kKThreads / 64;
 
 struct KryArgs {
     PosArgs p;
-    float *vws;              // [B][ (kM + 1) * ldv ]
+    float *vws;              // [B][2][(kM + 1) * ldv]   ping-pong basis (the restart rotation is out of place)
     int32_t ldv;             // column stride (>= max n, multiple of 64)
 };
 
-__device__ __forceinline__ float block_sum(float v, float *red)
+__device__ __forceinline__ float block_sum(float v, float *red /* [kKWaves] */)
 {
     const int tid = (int)threadIdx.x;
     v = wave_sum(v);
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    const float r = red[0] + red[1] + red[2] + red[3];
+    float r = 0.f;
+    for (int i = 0; i < ((int)blockDim.x >> 6); ++i) r += red[i];
     __syncthreads();
     return r;
 }
 
-__global__ __launch_bounds__(kThreads) void posemb_krylov_kernel(KryArgs ka)
+__global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
 {
     DYN_SMEM(smem);
     __shared__ float H[(kM + 1) * kM];              // H[i * kM + j], i <= j + 1
     __shared__ float Aj[kM * (kM + 1)], Yj[kM * (kM + 1)];
-    __shared__ float rot[kM], theta[kM], hbuf[kM + 1], red[8];
-    __shared__ int pq[kM];
-    __shared__ int sel[kM], longrows[kMaxLong];
+    __shared__ float rot[kM], theta[kM], hbuf[kM + 1], red[kKWaves];
+    __shared__ int pq[kM], sel[kM], colsrc[kM], longrows[kMaxLong];
     __shared__ int flag, nlong, done;
     const PosArgs &a = ka.p;
     const int tid = (int)threadIdx.x, lane = tid & 63, wv_id = tid >> 6;
@@ -283,16 +288,17 @@ __global__ __launch_bounds__(kThreads) void posemb_krylov_kernel(KryArgs ka)
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
     if (n <= kJMax) return;                          // handled by the Jacobi kernel
     const int ldv = ka.ldv;
-    float *V = ka.vws + (int64_t)b * (kM + 1) * ldv;
+    float *V = ka.vws + (int64_t)b * 2 * (kM + 1) * ldv;
+    float *Valt = V + (int64_t)(kM + 1) * ldv;
     float *x = (float *)smem, *w = x + ldv, *dinv = w + ldv;
     const int k = min(n - 2, a.hidden);
     const int keep = min(k + kKeepExtra, kM - 8);
     const int lda = kM + 1;
 
     if (tid == 0) nlong = 0;
-    for (int i = tid; i < (kM + 1) * kM; i += kThreads) H[i] = 0.f;
+    for (int i = tid; i < (kM + 1) * kM; i += kKThreads) H[i] = 0.f;
     __syncthreads();
-    for (int r = tid; r < n; r += kThreads) {
+    for (int r = tid; r < n; r += kKThreads) {
         const int d = a.row_ptr[n0 + r + 1] - a.row_ptr[n0 + r];
         dinv[r] = 1.0f / sqrtf((float)(d < 1 ? 1 : d));
         if (d > kLongDeg) {
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(kThreads) void posemb_krylov_kernel(KryArgs ka)
     }
     // v0 = U[0,1)^n (np.random.rand(n)), normalised
     float ss = 0.f;
-    for (int r = tid; r < n; r += kThreads) {
+    for (int r = tid; r < n; r += kKThreads) {
         uint32_t rnd[4];
         philox4x32_10((uint32_t)r, 0u, (uint32_t)b, 0x9E0B5EEDu, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
         const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
@@ -311,38 +317,48 @@ __global__ __launch_bounds__(kThreads) void posemb_krylov_kernel(KryArgs ka)
     }
     __syncthreads();
     float nrm = sqrtf(block_sum(ss, red));
-    for (int r = tid; r < n; r += kThreads) V[r] = w[r] / nrm;
+    for (int r = tid; r < n; r += kKThreads) V[r] = w[r] / nrm;
     __syncthreads();
     const int nl = nlong < kMaxLong ? nlong : kMaxLong;
     const bool long_overflow = nlong > kMaxLong;
 
-    // orthogonalise w against V[:, 0..ncols) twice; optionally accumulate the coefficients into H[:, hcol]
+    // orthogonalise w against V[:, 0..ncols) twice (CGS2); optionally accumulate the coefficients into H[:, hcol]
     auto orth = [&](int ncols, int hcol) {
         for (int pass = 0; pass < 2; ++pass) {
-            for (int i = wv_id; i < ncols; i += 4) {
-                float s = 0.f;
-                for (int r = lane; r < n; r += 64) s = fmaf(V[(int64_t)i * ldv + r], w[r], s);
-                s = wave_sum(s);
+            for (int i = wv_id; i < ncols; i += kKWaves) {
+                const float *vc = V + (int64_t)i * ldv;
+                float s0 = 0.f, s1 = 0.f;
+                int r = lane;
+                for (; r + 64 < n; r += 128) { s0 = fmaf(vc[r], w[r], s0); s1 = fmaf(vc[r + 64], w[r + 64], s1); }
+                if (r < n) s0 = fmaf(vc[r], w[r], s0);
+                const float s = wave_sum(s0 + s1);
                 if (lane == 0) hbuf[i] = s;
             }
             __syncthreads();
             if (hcol >= 0 && tid < ncols) H[tid * kM + hcol] += hbuf[tid];
-            for (int r = tid; r < n; r += kThreads) {
-                float acc = w[r];
-                for (int i = 0; i < ncols; ++i) acc = fmaf(-V[(int64_t)i * ldv + r], hbuf[i], acc);
-                w[r] = acc;
+            for (int r = tid; r < n; r += kKThreads) {
+                float a0 = w[r], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                int i = 0;
+                for (; i + 4 <= ncols; i += 4) {
+                    a0 = fmaf(-V[(int64_t)i * ldv + r], hbuf[i], a0);
+                    a1 = fmaf(-V[(int64_t)(i + 1) * ldv + r], hbuf[i + 1], a1);
+                    a2 = fmaf(-V[(int64_t)(i + 2) * ldv + r], hbuf[i + 2], a2);
+                    a3 = fmaf(-V[(int64_t)(i + 3) * ldv + r], hbuf[i + 3], a3);
+                }
+                for (; i < ncols; ++i) a0 = fmaf(-V[(int64_t)i * ldv + r], hbuf[i], a0);
+                w[r] = (a0 + a1) + (a2 + a3);
             }
             __syncthreads();
         }
     };
 
-    int j = 0;
-    for (int cycle = 0; cycle < kMaxCycles; ++cycle) {
-        for (; j < kM; ++j) {
-            for (int r = tid; r < n; r += kThreads) x[r] = V[(int64_t)j * ldv + r] * dinv[r];
+    int j = 0, steps = 0, cycle = 0;
+    for (; cycle < kMaxCycles; ++cycle) {
+        for (; j < kM; ++j, ++steps) {
+            for (int r = tid; r < n; r += kKThreads) x[r] = V[(int64_t)j * ldv + r] * dinv[r];
             __syncthreads();
             // w = D^-1/2 A D^-1/2 v_j   (short rows: one thread per row; long rows: one wave per row)
-            for (int r = tid; r < n; r += kThreads) {
+            for (int r = tid; r < n; r += kKThreads) {
                 const int beg = a.row_ptr[n0 + r], end = a.row_ptr[n0 + r + 1];
                 if (end - beg > kLongDeg && !long_overflow) continue;
                 float s = 0.f;
@@ -350,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void posemb_krylov_kernel(KryArgs ka)
                 w[r] = s * dinv[r];
             }
             if (!long_overflow) {
-                for (int i = wv_id; i < nl; i += 4) {
+                for (int i = wv_id; i < nl; i += kKWaves) {
                     const int r = longrows[i];
                     const int beg = a.row_ptr[n0 + r], end = a.row_ptr[n0 + r + 1];
                     float s = 0.f;
@@ -362,30 +378,30 @@ __global__ __launch_bounds__(kThreads) void posemb_krylov_kernel(KryArgs ka)
             __syncthreads();
             orth(j + 1, j);
             float s2 = 0.f;
-            for (int r = tid; r < n; r += kThreads) s2 = fmaf(w[r], w[r], s2);
+            for (int r = tid; r < n; r += kKThreads) s2 = fmaf(w[r], w[r], s2);
             float beta = sqrtf(block_sum(s2, red));
             if (beta < 1e-6f) {                      // invariant subspace: continue with a fresh direction
-                for (int r = tid; r < n; r += kThreads) {
+                for (int r = tid; r < n; r += kKThreads) {
                     uint32_t rnd[4];
-                    philox4x32_10((uint32_t)r, (uint32_t)(cycle * kM + j + 1), (uint32_t)b, 0x9E0B5EEDu,
+                    philox4x32_10((uint32_t)r, (uint32_t)(steps + 1), (uint32_t)b, 0x9E0B5EEDu,
                                   (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
                     w[r] = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f) - 0.5f;
                 }
                 __syncthreads();
                 orth(j + 1, -1);
                 float s3 = 0.f;
-                for (int r = tid; r < n; r += kThreads) s3 = fmaf(w[r], w[r], s3);
+                for (int r = tid; r < n; r += kKThreads) s3 = fmaf(w[r], w[r], s3);
                 nrm = sqrtf(block_sum(s3, red));
                 beta = 0.f;
             } else {
                 nrm = beta;
             }
             if (tid == 0) H[(j + 1) * kM + j] = beta;
-            for (int r = tid; r < n; r += kThreads) V[(int64_t)(j + 1) * ldv + r] = w[r] / nrm;
+            for (int r = tid; r < n; r += kKThreads) V[(int64_t)(j + 1) * ldv + r] = w[r] / nrm;
             __syncthreads();
         }
         // Rayleigh-Ritz on the symmetric part of H
-        for (int i = tid; i < kM * lda; i += kThreads) {
+        for (int i = tid; i < kM * lda; i += kKThreads) {
             const int r = i / lda, c = i - r * lda;
             float v = 0.f;
             if (c < kM) v = r <= c ? H[r * kM + c] : H[c * kM + r];
@@ -396,73 +412,93 @@ __global__ __launch_bounds__(kThreads) void posemb_krylov_kernel(KryArgs ka)
         jacobi_lds(Aj, Yj, kM, lda, rot, pq, &flag, 2e-6f);     // Ritz values are only needed to ~1e-5
         __syncthreads();
         if (tid < kM) theta[tid] = Aj[tid * lda + tid];
-        __syncthreads();
-        const float beta_m = H[kM * kM + (kM - 1)];
         if (tid == 0) done = 1;
         __syncthreads();
+        const float beta_m = H[kM * kM + (kM - 1)];
         if (tid < kM) {
             const int r = rank_desc(theta, kM, tid);
             sel[tid] = r;                           // 0 = largest Ritz value
-            if (r < k && fabsf(beta_m * Yj[(kM - 1) * lda + tid]) > 2e-5f) done = 0;
+            const float res = fabsf(beta_m * Yj[(kM - 1) * lda + tid]);
+            if (r < k && res > kRitzTol) done = 0;
+            if (r < k && res > 10.f * kRitzTol) flag = 2;     // far from converged (reported if the cycle cap is hit)
         }
         __syncthreads();
         const bool finished = done != 0 || cycle == kMaxCycles - 1;
-        if (finished && done == 0 && tid == 0) atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
+        if (finished && done == 0 && flag == 2 && tid == 0) atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
         const int nout = finished ? k : keep;
-        // hbuf is free now: column of Y for output slot t = the Ritz vector of rank (finished ? k-1-t : t)
-        // V[:, 0..nout) <- V[:, 0..m) Y[:, chosen]  (row by row, in place)
-        for (int r = tid; r < n; r += kThreads) {
-            float vin[kM];
+        // output column t <- Ritz vector: restart keeps rank t, the final result is ascending (rank k-1-t)
+        if (tid < kM) {
+            const int t = finished ? k - 1 - sel[tid] : sel[tid];
+            if (t >= 0 && t < nout) colsrc[t] = tid;
+        }
+        __syncthreads();
+        if (!finished) {
+            // Valt[:, t] = V[:, 0..m) Y[:, colsrc[t]]: one thread per (row, 8 output columns)
+            const int nchunk = (nout + 7) >> 3;
+            for (int task = tid; task < n * nchunk; task += kKThreads) {
+                const int ch = task / n, r = task - ch * n;       // consecutive threads -> consecutive rows
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                int src[8];
 #pragma unroll
-            for (int i = 0; i < kM; ++i) vin[i] = V[(int64_t)i * ldv + r];
-            if (!finished) {
-                for (int i = 0; i < kM; ++i) {
-                    const int t = sel[i];
-                    if (t < nout) {
-                        float acc = 0.f;
+                for (int u = 0; u < 8; ++u) src[u] = colsrc[min(8 * ch + u, nout - 1)];
+                for (int c = 0; c < kM; ++c) {
+                    const float v = V[(int64_t)c * ldv + r];
 #pragma unroll
-                        for (int c = 0; c < kM; ++c) acc = fmaf(vin[c], Yj[c * lda + i], acc);
-                        V[(int64_t)t * ldv + r] = acc;
-                    }
+                    for (int u = 0; u < 8; ++u) acc[u] = fmaf(v, Yj[c * lda + src[u]], acc[u]);
                 }
-            } else {
-                // final: eigsh(which="LA") order = ascending; row-normalise over the k wanted columns
-                float outv[64];
-                float s2 = 0.f;
-                for (int i = 0; i < kM; ++i) {
-                    const int t = sel[i];
-                    if (t < k) {
-                        float acc = 0.f;
 #pragma unroll
-                        for (int c = 0; c < kM; ++c) acc = fmaf(vin[c], Yj[c * lda + i], acc);
-                        outv[k - 1 - t] = acc;
-                        s2 = fmaf(acc, acc, s2);
-                    }
-                }
-                const float inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
-                float *po = a.pos + (int64_t)(n0 + r) * a.hidden;
-                for (int c = 0; c < a.hidden; ++c) po[c] = c < k ? outv[c] * inv : 0.f;
-                if (a.raw) {
-                    float *ro = a.raw + (int64_t)(n0 + r) * a.hidden;
-                    for (int c = 0; c < a.hidden; ++c) ro[c] = c < k ? outv[c] : 0.f;
-                }
+                for (int u = 0; u < 8; ++u)
+                    if (8 * ch + u < nout) Valt[(int64_t)(8 * ch + u) * ldv + r] = acc[u];
+            }
+            // the residual direction becomes column `keep`; H = diag(theta_kept)
+            for (int r = tid; r < n; r += kKThreads) Valt[(int64_t)keep * ldv + r] = V[(int64_t)kM * ldv + r];
+            for (int i = tid; i < (kM + 1) * kM; i += kKThreads) H[i] = 0.f;
+            __syncthreads();
+            if (tid < kM && sel[tid] < keep) H[sel[tid] * kM + sel[tid]] = theta[tid];
+            __syncthreads();
+            float *tmp = V; V = Valt; Valt = tmp;
+            j = keep;
+            continue;
+        }
+        // final: u_t = V Y[:, colsrc[t]] -> raw eigenvectors, then normalize(u, "l2") rows, zero padding
+        float *rawout = a.raw ? a.raw : a.pos;
+        const int nchunk = (k + 7) >> 3;
+        for (int task = tid; task < n * nchunk; task += kKThreads) {
+            const int ch = task / n, r = task - ch * n;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int src[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) src[u] = colsrc[min(8 * ch + u, k - 1)];
+            for (int c = 0; c < kM; ++c) {
+                const float v = V[(int64_t)c * ldv + r];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] = fmaf(v, Yj[c * lda + src[u]], acc[u]);
+            }
+            float *ro = rawout + (int64_t)(n0 + r) * a.hidden + 8 * ch;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (8 * ch + u < k) ro[u] = acc[u];
+        }
+        __syncthreads();
+        for (int r = tid; r < n; r += kKThreads) {
+            const float *ro = rawout + (int64_t)(n0 + r) * a.hidden;
+            float *po = a.pos + (int64_t)(n0 + r) * a.hidden;
+            float s2 = 0.f;
+            for (int c = 0; c < k; ++c) s2 = fmaf(ro[c], ro[c], s2);
+            const float inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
+            for (int c = 0; c < a.hidden; ++c) {
+                const float v = c < k ? ro[c] : 0.f;
+                po[c] = v * inv;
+                if (a.raw) a.raw[(int64_t)(n0 + r) * a.hidden + c] = v;
             }
         }
-        if (finished) {
-#ifdef GCC_AMD_HIPEMU
-            if (tid == 0 && getenv("GCC_POSEMB_DEBUG")) fprintf(stderr, "krylov b=%d n=%d cycles=%d done=%d\n", b, n, cycle + 1, done);
-#endif
-            if (a.evals && tid < kM && sel[tid] < k) a.evals[(int64_t)b * a.hidden + (k - 1 - sel[tid])] = theta[tid];
-            if (a.evals) for (int c = k + tid; c < a.hidden; c += kThreads) a.evals[(int64_t)b * a.hidden + c] = 0.f;
-            break;
-        }
-        // restart: residual direction becomes column `keep`; H = diag(theta_kept)
-        for (int r = tid; r < n; r += kThreads) V[(int64_t)keep * ldv + r] = V[(int64_t)kM * ldv + r];
-        for (int i = tid; i < (kM + 1) * kM; i += kThreads) H[i] = 0.f;
-        __syncthreads();
-        if (tid < kM && sel[tid] < keep) H[sel[tid] * kM + sel[tid]] = theta[tid];
-        __syncthreads();
-        j = keep;
+        if (a.evals && tid < kM && sel[tid] < k) a.evals[(int64_t)b * a.hidden + (k - 1 - sel[tid])] = theta[tid];
+        if (a.evals) for (int c = k + tid; c < a.hidden; c += kKThreads) a.evals[(int64_t)b * a.hidden + c] = 0.f;
+        break;
+    }
+    if (tid == 0) {                                  // diagnostics: status[1] = max restart cycles, status[2] = Arnoldi steps
+        atomicMax(a.status + 1, cycle + 1);
+        atomicAdd(a.status + 2, steps);
     }
 }
 
@@ -477,7 +513,7 @@ int64_t gcc_posemb_workspace_bytes(int32_t batch_size, int64_t node_cap, int32_t
         return -1;
     }
     const int64_t ldv = ((node_cap / batch_size + 63) / 64) * 64 + 64;
-    return (int64_t)batch_size * (kM + 1) * ldv * (int64_t)sizeof(float) + 256;
+    return (int64_t)batch_size * 2 * (kM + 1) * ldv * (int64_t)sizeof(float) + 256;
 }
 
 int32_t gcc_posemb(const gcc_batch_out *g, int32_t batch_size, int32_t hidden, float *pos, float *evals,
@@ -495,22 +531,24 @@ int32_t gcc_posemb(const gcc_batch_out *g, int32_t batch_size, int32_t hidden, f
     }
     PosArgs a = {g->node_off, g->row_ptr, g->col_idx, pos, evals, raw, batch_size, hidden, seed, status, nullptr, nullptr};
     hipStream_t s = (hipStream_t)stream;
-    const int np = kJMax, lda = np + 1;
-    const size_t lds = (size_t)2 * np * lda * sizeof(float);
+    const size_t lds_small = (size_t)2 * kJSmall * (kJSmall + 1) * sizeof(float);
+    const size_t lds_big = (size_t)2 * kJMax * (kJMax + 1) * sizeof(float);
 #ifndef GCC_AMD_HIPEMU
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)posemb_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)posemb_jacobi_kernel<kJSmall + 1, kJMax, 1024>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
         attr_set = true;
     }
 #endif
     prof_mark(prof, 0, s);
-    hipLaunchKernelGGL(posemb_jacobi_kernel, dim3(batch_size), dim3(kJThreads), lds, s, a);
+    hipLaunchKernelGGL((posemb_jacobi_kernel<0, kJSmall, 256>), dim3(batch_size), dim3(256), lds_small, s, a);
+    hipLaunchKernelGGL((posemb_jacobi_kernel<kJSmall + 1, kJMax, 1024>), dim3(batch_size), dim3(1024), lds_big, s, a);
     KryArgs ka;
     ka.p = a;
     ka.vws = (float *)workspace;
     ka.ldv = (int32_t)(((g->node_cap / batch_size + 63) / 64) * 64 + 64);
-    hipLaunchKernelGGL(posemb_krylov_kernel, dim3(batch_size), dim3(kThreads), (size_t)3 * ka.ldv * sizeof(float), s, ka);
+    hipLaunchKernelGGL(posemb_krylov_kernel, dim3(batch_size), dim3(kKThreads), (size_t)3 * ka.ldv * sizeof(float), s, ka);
     prof_mark(prof, 1, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_posemb: %s", hipGetErrorString(e)); return -10; }

@@ -64,6 +64,75 @@ def clip_grad_norm(params, max_norm):
     return torch.sqrt(sum(p.grad.data.norm() ** 2 for p in params if p.grad is not None))
 
 
+class BatchProducer:
+    """Runs sampler + positional embedding ahead of the training stream on several HIP streams
+    ("lanes").  Batches are independent, and a producer launch is bound by its slowest subgraph (hub seeds
+    need many eigen-iterations) while most CUs idle, so work from many future steps is kept in flight:
+    lane l owns steps l, l + lanes, ...; each lane has its own stream, sampler/eigensolver workspaces and a
+    ring of ``depth + 1`` output buffers.  This replaces the reference's DataLoader worker pool
+    (train.py:577-586) -- same role, same "prefetch" semantics, no processes."""
+
+    def __init__(self, lanes, first_id_fn, device, depth=2):
+        self.lanes = lanes                      # list of (sampler, posemb)
+        self.first_id = first_id_fn
+        self.dev = device
+        self.depth = depth
+        self.cuda = torch.device(device).type == "cuda"
+        self.streams = [torch.cuda.Stream(device) for _ in lanes] if self.cuda else [None] * len(lanes)
+        self.ready = {}                         # step -> (graphs, event)
+        self.released = {}                      # step -> event recorded on the consumer stream
+        self.next_step = 0
+        self.prof = None
+
+    def _produce(self, step):
+        lane = step % len(self.lanes)
+        sampler, posemb = self.lanes[lane]
+        pr = self.prof or {}
+        q, k = sampler.sample(self.first_id(step), prof=pr.get("sampler"))
+        pp = pr.get("posemb")
+        posemb(q, prof=pp) if pp is not None else posemb(q)
+        posemb(k)
+        return q, k
+
+    def _launch(self, step):
+        if not self.cuda:
+            self.ready[step] = (self._produce(step), None)
+            return
+        lane = step % len(self.lanes)
+        ring = self.depth + 1
+        st = self.streams[lane]
+        with torch.cuda.stream(st):
+            prev_user = step - len(self.lanes) * ring          # the step whose buffers this one overwrites
+            ev = self.released.pop(prev_user, None)
+            if ev is not None:
+                st.wait_event(ev)
+            graphs = self._produce(step)
+            done = torch.cuda.Event()
+            done.record(st)
+        self.ready[step] = (graphs, done)
+
+    def get(self, step, prof=None):
+        """Batch of ``step`` (made ready on the current stream); keeps lanes*depth steps in flight."""
+        self.prof = prof
+        horizon = step + len(self.lanes) * self.depth
+        if self.next_step < step:
+            self.next_step = step
+        while self.next_step <= horizon:
+            if self.next_step not in self.ready:
+                self._launch(self.next_step)
+            self.next_step += 1
+        graphs, ev = self.ready.pop(step)
+        if ev is not None:
+            torch.cuda.current_stream(self.dev).wait_event(ev)
+        return graphs
+
+    def release(self, step):
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            self.released[step] = ev
+
+
 class FlatAdam:
     """clip_grad_norm_ + torch.optim.Adam(lr, betas, eps=1e-8, weight_decay) (train.py:409,667-672) over one flat
     parameter buffer, as two HIP launches (gcc_adam_step).  ``param_groups`` / ``state_dict`` keep the shape
@@ -98,7 +167,9 @@ class FlatAdam:
 class MoCoTrainStep:
     def __init__(self, model: GraphEncoder, model_ema: GraphEncoder, contrast: MemoryMoCo, sampler, posemb,
                  learning_rate=0.005, betas=(0.9, 0.999), weight_decay=1e-5, clip_norm=1.0, alpha=0.999,
-                 world_size=1, rank=0, prefetch=True):
+                 world_size=1, rank=0, prefetch=True, extra_lanes=(), depth=2):
+        """``sampler``/``posemb``: producer lane 0; ``extra_lanes``: more (sampler, posemb) pairs with their own
+        workspaces for multi-stream prefetch (see :class:`BatchProducer`)."""
         self.model, self.ema, self.contrast = model, model_ema, contrast
         self.sampler, self.posemb = sampler, posemb
         self.clip_norm, self.alpha = clip_norm, alpha
@@ -125,54 +196,25 @@ class MoCoTrainStep:
         self.keys_all = torch.empty(self.B * world_size, H, device=self.dev) if world_size > 1 else None
         self.one = torch.ones(1, device=self.dev)
         self.prefetch = prefetch and self.dev.type == "cuda"
-        self.side = torch.cuda.Stream(self.dev) if self.prefetch else None
-        self._ready = None           # (graphs, event) of the prefetched batch
-        self._done = [None, None]    # main-stream completion events of the two ring slots
-        self._slot = 0
-        self._prof = None
+        lanes = [(sampler, posemb)] + list(extra_lanes)
+        self.producer = BatchProducer(lanes if self.prefetch else lanes[:1], self._first_id,
+                                      self.dev if self.prefetch else "cpu", depth=depth if self.prefetch else 0)
+        if not self.prefetch:
+            self.producer.cuda = False
         model.train()                                                    # train.py:357-365
         model_ema.eval()
         for mod in model_ema.modules():
             if isinstance(mod, torch.nn.BatchNorm1d):
                 mod.train()
 
-    # ---- data: sampler + positional embedding, one step ahead on a side stream
-    def _produce(self, first_id):
-        q, k = self.sampler.sample(first_id, prof=self._prof.get("sampler") if self._prof else None)
-        pp = self._prof.get("posemb") if self._prof else None
-        self.posemb(q, prof=pp) if pp is not None else self.posemb(q)
-        self.posemb(k)
-        return q, k
-
     def _first_id(self, step):
         return (step * self.world + self.rank) * self.B
-
-    def _next_batch(self, step):
-        if not self.prefetch:
-            return self._produce(self._first_id(step))
-        if self._ready is None or self._ready[0] != step:
-            self._launch_prefetch(step)
-        _, graphs, ev = self._ready
-        torch.cuda.current_stream(self.dev).wait_event(ev)
-        self._launch_prefetch(step + 1)
-        return graphs
-
-    def _launch_prefetch(self, step):
-        slot = step % 2
-        with torch.cuda.stream(self.side):
-            if self._done[slot] is not None:
-                self.side.wait_event(self._done[slot])       # the ring slot's previous user has finished
-            graphs = self._produce(self._first_id(step))
-            ev = torch.cuda.Event()
-            ev.record(self.side)
-        self._ready = (step, graphs, ev)
 
     # ---- one step
     def step(self, step, lr, prof=None):
         """``prof``: optional dict of gcc_amd.prof.Prof (sampler: 4 marks; gin_fwd/nce_fwd/nce_bwd/gin_bwd: 2)."""
-        self._prof = prof
         pr = prof or {}
-        q, k = self._next_batch(step)
+        q, k = self.producer.get(step, prof=prof)
         st = torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else None
         p_drop = self.model.gnn.drop.p
         keep = self.mask_fn() if self.mask_fn is not None else None
@@ -200,8 +242,5 @@ class MoCoTrainStep:
             grp["lr"] = lr
         gnorm = self.optimizer.step()                                    # clip (train.py:409) + Adam (train.py:417)
         moment_update(self.model, self.ema, self.alpha, engine=self.nce)  # train.py:430-431
-        if self.prefetch:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.dev))
-            self._done[step % 2] = ev
+        self.producer.release(step)
         return dict(loss=outs["loss"], prob=outs["prob"], grad_norm=gnorm, graph_q=q, graph_k=k)

@@ -24,7 +24,7 @@ def _run(view):
     evals = torch.zeros(b.batch_size, HID)
     raw = torch.zeros(b.parent_nid.numel(), HID)
     pe(b, evals=evals, raw=raw)
-    assert int(pe.status) == 0
+    assert int(pe.status[0]) == 0
     return b.pos_undirected.numpy(), evals.numpy(), raw.numpy()
 
 

@@ -17,7 +17,7 @@ def _device_posemb(q, B):
     evals = torch.zeros(B, HID, device="cuda")
     raw = torch.zeros(q.parent_nid.numel(), HID, device="cuda")
     pe(q, evals=evals, raw=raw)
-    pe.check_status()
+    pe.check_status(strict=True)
     c = q.csr_numpy()
     n = c["node_off"][-1]
     view = dict(node_off=torch.from_numpy(c["node_off"].astype(np.int64)),

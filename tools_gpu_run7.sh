@@ -1,0 +1,15 @@
+#!/bin/bash
+set -u
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+show='import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k:d[k] for k in ("value","ms_per_step","steps_per_sec","stage_ms","final_loss","posemb_status")})'
+for cfg in "4 3" "8 3" "8 6"; do
+  set -- $cfg
+  echo "=== bench lanes=$1 depth=$2"
+  timeout 900 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --lanes $1 --depth $2 2>gpurun_out/bench.err | tee gpurun_out/bench_run7_l$1_d$2.json | python -c "$show"
+  tail -2 gpurun_out/bench.err | grep -v amdgpu.ids
+done
+echo "=== gpu tests (quick subset)"
+timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -3

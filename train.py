@@ -17,6 +17,8 @@ import argparse
 import os
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # producer lanes (sampler + eigensolver) use their own HIP streams
+
 import numpy as np
 import psutil
 import torch
