@@ -19,7 +19,6 @@
 
 namespace {
 
-constexpr int kThreads = 256;
 constexpr int kJMax = GCC_POSEMB_JACOBI_MAX;
 constexpr int kMaxSweeps = 14;
 constexpr int kJSmall = 64;        // size classes of the Jacobi kernel: n <= 64 needs 33 KiB of LDS (4 workgroups per CU,

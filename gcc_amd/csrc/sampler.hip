@@ -15,10 +15,16 @@
 //                     sequential "stop after exactly L visited nodes" rule
 //                     exactly.  Trace in LDS -> bitonic sort -> unique -> seed
 //                     first; row extents of every member are fetched here.
-//   induce_kernel     WPS workgroups per subgraph; LDS hash map parent id ->
-//                     local id; every wave streams whole parent rows (coalesced
-//                     dword loads, 4 in flight per lane) and ballot-compacts the
-//                     hits, preserving parent-row order (DGL VertexSubgraph).
+//   induce_kernel     work unit = a 256-edge SEGMENT of a member's parent row (4
+//                     coalesced dword loads per lane in flight); a subgraph gets
+//                     ceil(segments / 16) virtual workgroups (device-side prefix +
+//                     binary search), so hub-seed subgraphs with 10x the edges get
+//                     10x the workgroups and every wave does <= 4 segments.  LDS hash
+//                     map parent id -> local id; hits are ballot-compacted per
+//                     segment in parent-row order (DGL VertexSubgraph) into that
+//                     segment's scratch slot.  (Round-1 profile: the previous
+//                     row-per-wave version was bound by one wave doing 78 iterations
+//                     vs 5.5 on average: 2 % of the HBM roof.)
 //   pack_kernel       1 workgroup per subgraph: prefix sums over subgraphs
 //                     (dgl.batch offsets), row_ptr/col_idx with batched ids,
 //                     parent_nid, graph_id.
@@ -31,7 +37,8 @@
 namespace {
 
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-constexpr int kWps = 8;            // induce workgroups per subgraph
+constexpr int kSeg = 256;           // parent edges per segment (64 lanes x 4 loads)
+constexpr int kSegPerWg = 16;      // segments per virtual workgroup (4 per wave)
 constexpr int kInduceThreads = 256;
 
 __device__ __forceinline__ int pow2_ceil(int v)
@@ -45,7 +52,8 @@ __device__ __forceinline__ int pow2_ceil(int v)
 struct Work {
     int32_t *seeds;       // [B]
     int32_t *sub_n;       // [G]
-    int32_t *sub_cap;     // [G]   sum_i min(deg_i, n)
+    int32_t *sub_cap;     // [G]   scratch slots: segments * (1 + min(kSeg, n))
+    int32_t *sub_seg;     // [G]   number of row segments
     int32_t *sub_nnz;     // [G]
     int32_t *nodes;       // [G][ncap]   parent ids, seed first
     int32_t *rowbeg;      // [G][ncap]   row_ptr[node]
@@ -57,7 +65,7 @@ struct Work {
 };
 
 struct WorkLayout {
-    int64_t off_seeds, off_n, off_cap, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowoff, off_rowcnt,
+    int64_t off_seeds, off_n, off_cap, off_seg, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowoff, off_rowcnt,
         off_scratch, total;
     int32_t ncap;
 };
@@ -72,6 +80,7 @@ inline WorkLayout work_layout(int32_t lmax, int32_t B, int64_t scratch_entries)
     w.off_seeds = o;  o = al(o + 4 * (int64_t)B);
     w.off_n = o;      o = al(o + 4 * G);
     w.off_cap = o;    o = al(o + 4 * G);
+    w.off_seg = o;    o = al(o + 4 * G);
     w.off_nnz = o;    o = al(o + 4 * G);
     w.off_nodes = o;  o = al(o + 4 * G * w.ncap);
     w.off_rowbeg = o; o = al(o + 4 * G * w.ncap);
@@ -225,7 +234,6 @@ __global__ __launch_bounds__(64) void rwr_walk_kernel(
     int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
     int32_t *rowbeg = w.rowbeg + (int64_t)g * w.ncap;
     int32_t *rowdeg = w.rowdeg + (int64_t)g * w.ncap;
-    int32_t *rowoff = w.rowoff + (int64_t)g * w.ncap;
     if (lane == 0) { nodes[0] = seed; rowbeg[0] = rp0; rowdeg[0] = deg0; ldeg[0] = deg0; }
     int n = 1;   // wave-uniform
     for (int i0 = 0; i0 < L; i0 += 64) {
@@ -246,17 +254,19 @@ __global__ __launch_bounds__(64) void rwr_walk_kernel(
         n += __popcll(m);
     }
     wave_sync();
-    // scratch slot of row i starts at sum_{i' < i} min(deg_i', n)
+    // induction work units: row i contributes ceil(deg_i / kSeg) segments
     int run = 0;
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
-        int c = 0;
-        if (i < n) { c = ldeg[i]; c = c < n ? c : n; }
-        const int incl = wave_scan_incl(c);
-        if (i < n) rowoff[i] = run + incl - c;
-        run += wave_shfl(incl, 63);
+        const int c = i < n ? (ldeg[i] + kSeg - 1) / kSeg : 0;
+        run += wave_shfl(wave_scan_incl(c), 63);
     }
-    if (lane == 0) { w.sub_n[g] = n; w.sub_cap[g] = run; w.sub_nnz[g] = 0; }
+    if (lane == 0) {
+        w.sub_n[g] = n;
+        w.sub_seg[g] = run;
+        w.sub_cap[g] = run * (1 + (n < kSeg ? n : kSeg));     // per segment: count header + at most min(kSeg, n) hits
+        w.sub_nnz[g] = 0;
+    }
 }
 
 // sum of arr[begin, end) by the whole workgroup (all threads get the result)
@@ -275,78 +285,134 @@ __device__ __forceinline__ long long block_range_sum(const int32_t *arr, int beg
     return r;
 }
 
+// block-wide exclusive scan of vals over [0, count) into LDS out[0..count] (out[count] = total);
+// f(i) supplies the i-th value.  All threads call.
+template <class T, class F>
+__device__ __forceinline__ void block_exclusive_scan(T *out, int count, F f, T *wsum /* [5] */)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) wsum[4] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < count; i0 += (int)blockDim.x) {
+        const int i = i0 + tid;
+        const T v = i < count ? f(i) : (T)0;
+        T incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const T t = wave_shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        T base = wsum[4];
+        for (int k = 0; k < wv; ++k) base += wsum[k];
+        if (i < count) out[i] = base + incl - v;
+        __syncthreads();
+        if (tid == 0) wsum[4] += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) out[count] = wsum[4];
+    __syncthreads();
+}
+
+// last index i in [0, count) with arr[i] <= key (arr ascending, arr[0] <= key)
+__device__ __forceinline__ int upper_slot(const int32_t *arr, int count, int key)
+{
+    int lo = 0, hi = count;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (arr[mid] <= key) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 // ------------------------------------------------------------------ K2 ----
 __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
-    const int32_t *__restrict__ col_idx, int32_t hcap_log2, int64_t scratch_entries, Work w,
+    const int32_t *__restrict__ col_idx, int32_t hcap_log2, int32_t G, int64_t scratch_entries, Work w,
     int32_t *__restrict__ status)
 {
     DYN_SMEM(smem);
-    __shared__ long long red[kInduceThreads];
+    __shared__ long long wsum64[5];
+    __shared__ int32_t wsum32[5];
     const int hcap = 1 << hcap_log2;
-    uint32_t *hkey = (uint32_t *)smem;                  // [hcap]
-    uint16_t *hval = (uint16_t *)(hkey + hcap);         // [hcap]
+    uint32_t *hkey = (uint32_t *)smem;                       // [hcap]
+    uint16_t *hval = (uint16_t *)(hkey + hcap);              // [hcap]
+    int32_t *segoff = (int32_t *)(hval + hcap);              // [ncap + 1] exclusive prefix of segments per row
+    int32_t *vbp = segoff + (w.ncap + 1);                    // [G + 1]   exclusive prefix of virtual blocks
+    long long *sbp = (long long *)(vbp + ((G + 2) & ~1));    // [G + 1]   exclusive prefix of scratch slots
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const int g = (int)blockIdx.x / kWps, part = (int)blockIdx.x % kWps;
-    const int n = w.sub_n[g];
-    const long long sbase = block_range_sum(w.sub_cap, 0, g, red);
-    if (sbase + (long long)w.sub_cap[g] > scratch_entries) {
-        if (tid == 0) atomicOr(status, (int32_t)GCC_STATUS_SCRATCH_OVERFLOW);
-        return;
-    }
-    const int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
-    const int32_t *rowbeg = w.rowbeg + (int64_t)g * w.ncap;
-    const int32_t *rowdeg = w.rowdeg + (int64_t)g * w.ncap;
-    const int32_t *rowoff = w.rowoff + (int64_t)g * w.ncap;
-    int32_t *rowcnt = w.rowcnt + (int64_t)g * w.ncap;
-    int32_t *scratch = w.scratch + sbase;
-
-    for (int i = tid; i < hcap; i += kInduceThreads) hkey[i] = kEmpty;
-    __syncthreads();
+    block_exclusive_scan<int32_t>(vbp, G, [&](int g) { return (w.sub_seg[g] + kSegPerWg - 1) / kSegPerWg; }, wsum32);
+    block_exclusive_scan<long long>(sbp, G, [&](int g) { return (long long)w.sub_cap[g]; }, wsum64);
+    const int total_vb = vbp[G];
     const int shift = 32 - hcap_log2;
-    for (int i = tid; i < n; i += kInduceThreads) {
-        const uint32_t key = (uint32_t)nodes[i];
-        uint32_t h = (key * 0x9E3779B1u) >> shift;
-        for (;;) {
-            const uint32_t old = atomicCAS(&hkey[h], kEmpty, key);
-            if (old == kEmpty) { hval[h] = (uint16_t)i; break; }
-            h = (h + 1) & (uint32_t)(hcap - 1);
+    int cur_g = -1;
+    for (int vb = (int)blockIdx.x; vb < total_vb; vb += (int)gridDim.x) {
+        const int g = upper_slot(vbp, G, vb);
+        const int part = vb - vbp[g];
+        const int n = w.sub_n[g], totseg = w.sub_seg[g];
+        const long long sbase = sbp[g];
+        if (sbase + (long long)w.sub_cap[g] > scratch_entries) {
+            if (tid == 0) atomicOr(status, (int32_t)GCC_STATUS_SCRATCH_OVERFLOW);
+            continue;
         }
-    }
-    __syncthreads();
-
-    int my_nnz = 0;
-    for (int i = part * 4 + wave; i < n; i += 4 * kWps) {
-        const int32_t beg = rowbeg[i], deg = rowdeg[i];
-        int32_t *out = scratch + rowoff[i];
-        int cnt = 0;   // wave-uniform
-        for (int e0 = 0; e0 < deg; e0 += 256) {
+        const int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
+        const int32_t *rowbeg = w.rowbeg + (int64_t)g * w.ncap;
+        const int32_t *rowdeg = w.rowdeg + (int64_t)g * w.ncap;
+        if (g != cur_g) {                                    // block-uniform
+            __syncthreads();
+            for (int i = tid; i < hcap; i += kInduceThreads) hkey[i] = kEmpty;
+            __syncthreads();
+            for (int i = tid; i < n; i += kInduceThreads) {
+                const uint32_t key = (uint32_t)nodes[i];
+                uint32_t h = (key * 0x9E3779B1u) >> shift;
+                for (;;) {
+                    const uint32_t old = atomicCAS(&hkey[h], kEmpty, key);
+                    if (old == kEmpty) { hval[h] = (uint16_t)i; break; }
+                    h = (h + 1) & (uint32_t)(hcap - 1);
+                }
+            }
+            block_exclusive_scan<int32_t>(segoff, n, [&](int i) { return (rowdeg[i] + kSeg - 1) / kSeg; }, wsum32);
+            cur_g = g;
+        }
+        const int stride = 1 + (n < kSeg ? n : kSeg);
+        int my_nnz = 0;
+#pragma unroll 1
+        for (int k = 0; k < kSegPerWg / 4; ++k) {
+            const int s = part * kSegPerWg + wave * (kSegPerWg / 4) + k;
+            if (s >= totseg) break;                          // wave-uniform
+            const int i = upper_slot(segoff, n, s);
+            const int e0 = (s - segoff[i]) * kSeg;
+            const int32_t beg = rowbeg[i] + e0;
+            const int len = min(kSeg, rowdeg[i] - e0);
+            int32_t *out = w.scratch + sbase + (long long)s * stride;
             uint32_t v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = e0 + k * 64 + lane;
-                v[k] = e < deg ? (uint32_t)col_idx[beg + e] : kEmpty;
+            for (int u = 0; u < 4; ++u) {
+                const int e = u * 64 + lane;
+                v[u] = e < len ? (uint32_t)col_idx[beg + e] : kEmpty;
             }
+            int cnt = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int u = 0; u < 4; ++u) {
                 int loc = -1;
-                if (v[k] != kEmpty) {
-                    uint32_t h = (v[k] * 0x9E3779B1u) >> shift;
+                if (v[u] != kEmpty) {
+                    uint32_t h = (v[u] * 0x9E3779B1u) >> shift;
                     for (;;) {
                         const uint32_t key = hkey[h];
-                        if (key == v[k]) { loc = (int)hval[h]; break; }
+                        if (key == v[u]) { loc = (int)hval[h]; break; }
                         if (key == kEmpty) break;
                         h = (h + 1) & (uint32_t)(hcap - 1);
                     }
                 }
                 const unsigned long long m = wave_ballot(loc >= 0);
-                if (loc >= 0) out[cnt + __popcll(m & lanemask_lt())] = loc;
+                if (loc >= 0) out[1 + cnt + __popcll(m & lanemask_lt())] = loc;
                 cnt += __popcll(m);
             }
+            if (lane == 0) out[0] = cnt;
+            my_nnz += cnt;
         }
-        if (lane == 0) rowcnt[i] = cnt;
-        my_nnz += cnt;
+        if (lane == 0 && my_nnz) atomicAdd(&w.sub_nnz[g], my_nnz);
     }
-    if (lane == 0 && my_nnz) atomicAdd(&w.sub_nnz[g], my_nnz);
 }
 
 // ------------------------------------------------------------------ K3 ----
@@ -355,8 +421,9 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
 {
     DYN_SMEM(smem);
     __shared__ long long red[256];
-    __shared__ int carry_s;
-    int32_t *excl = (int32_t *)smem;    // [ncap + 1] exclusive prefix of rowcnt
+    __shared__ int32_t wsum32[5];
+    int32_t *segoff = (int32_t *)smem;            // [ncap + 1] exclusive prefix of segments per row
+    int32_t *excl = segoff + (w.ncap + 1);        // [ncap + 1] exclusive prefix of induced degrees
     const int tid = (int)threadIdx.x;
     const int g = (int)blockIdx.x;
     const int view = g / B, b = g - view * B;
@@ -385,31 +452,17 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
         return;
     }
     const int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
-    const int32_t *rowoff = w.rowoff + (int64_t)g * w.ncap;
-    const int32_t *rowcnt = w.rowcnt + (int64_t)g * w.ncap;
+    const int32_t *rowdeg = w.rowdeg + (int64_t)g * w.ncap;
     const int32_t *scratch = w.scratch + sbase;
+    const int stride = 1 + (n < kSeg ? n : kSeg);
 
-    // exclusive scan of rowcnt over the subgraph's rows (chunks of 256 with carry)
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 256) {
-        const int i = i0 + tid;
-        const int c = i < n ? rowcnt[i] : 0;
-        // wave scan, then combine the 4 waves through LDS
-        const int incl = wave_scan_incl(c);
-        if ((tid & 63) == 63) red[tid >> 6] = incl;
-        __syncthreads();
-        int wave_base = 0;
-        for (int k = 0; k < (tid >> 6); ++k) wave_base += (int)red[k];
-        const int chunk_total = (int)(red[0] + red[1] + red[2] + red[3]);
-        const int base = carry_s;
-        if (i < n) excl[i] = base + wave_base + incl - c;
-        __syncthreads();
-        if (tid == 0) carry_s = base + chunk_total;
-        __syncthreads();
-    }
-    if (tid == 0) excl[n] = carry_s;
-    __syncthreads();
+    block_exclusive_scan<int32_t>(segoff, n, [&](int i) { return (rowdeg[i] + kSeg - 1) / kSeg; }, wsum32);
+    // induced degree of row i = sum of its segments' hit counts
+    block_exclusive_scan<int32_t>(excl, n, [&](int i) {
+        int c = 0;
+        for (int s = segoff[i]; s < segoff[i + 1]; ++s) c += scratch[(long long)s * stride];
+        return c;
+    }, wsum32);
 
     for (int i = tid; i < n; i += 256) {
         o.parent_nid[node_base + i] = nodes[i];
@@ -417,15 +470,18 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
         o.row_ptr[node_base + i] = (int32_t)(edge_base + excl[i]);
     }
     if (b == B - 1 && tid == 0) o.row_ptr[node_base + n] = (int32_t)(edge_base + nnz);
-    // one thread per output edge; its row by binary search in excl[]
+    // one thread per output edge: its row by binary search, then its segment inside the row
     for (int e = tid; e < nnz; e += 256) {
-        int lo = 0, hi = n;   // last row with excl[row] <= e
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (excl[mid] <= e) lo = mid; else hi = mid;
+        const int i = upper_slot(excl, n, e);
+        int off = e - excl[i];
+        int s = segoff[i];
+        for (;;) {
+            const int c = scratch[(long long)s * stride];
+            if (off < c) break;
+            off -= c;
+            ++s;
         }
-        const int32_t loc = scratch[rowoff[lo] + (e - excl[lo])];
-        o.col_idx[edge_base + e] = (int32_t)node_base + loc;
+        o.col_idx[edge_base + e] = (int32_t)node_base + scratch[(long long)s * stride + 1 + off];
     }
 }
 
@@ -467,6 +523,7 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     w.seeds = (int32_t *)(base + wl.off_seeds);
     w.sub_n = (int32_t *)(base + wl.off_n);
     w.sub_cap = (int32_t *)(base + wl.off_cap);
+    w.sub_seg = (int32_t *)(base + wl.off_seg);
     w.sub_nnz = (int32_t *)(base + wl.off_nnz);
     w.nodes = (int32_t *)(base + wl.off_nodes);
     w.rowbeg = (int32_t *)(base + wl.off_rowbeg);
@@ -483,10 +540,10 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     int hlog = 7;
     while ((1 << hlog) < 2 * (g->lmax + 1)) ++hlog;
     const size_t lds1 = ((size_t)p2max * 2 + 64) * 4;
-    const size_t lds2 = (size_t)(1 << hlog) * 6;
-    const size_t lds3 = (size_t)(wl.ncap + 1) * 4;
-    if (lds1 > 160 * 1024 || lds2 > 160 * 1024) {
-        snprintf(g_err, kErrLen, "gcc_sample_batch: lmax=%d needs more than 160 KiB of LDS", g->lmax);
+    const size_t lds2 = (size_t)(1 << hlog) * 6 + (size_t)(wl.ncap + 1) * 4 + (size_t)(G + 2) * 4 + (size_t)(G + 1) * 8 + 16;
+    const size_t lds3 = (size_t)(wl.ncap + 1) * 8;
+    if (lds1 > 64 * 1024 || lds2 > 64 * 1024 || lds3 > 64 * 1024) {
+        snprintf(g_err, kErrLen, "gcc_sample_batch: lmax=%d / batch too large for 64 KiB of LDS", g->lmax);
         return -4;
     }
     BatchOutDev oq = {out_q->node_off, out_q->edge_off, out_q->parent_nid, out_q->graph_id,
@@ -499,7 +556,7 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
                        g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, B,
                        p->restart_u32, p->seeds, w);
     prof_mark(p->prof, 1, s);
-    hipLaunchKernelGGL(induce_kernel, dim3(G * kWps), dim3(kInduceThreads), lds2, s, g->col_idx, hlog,
+    hipLaunchKernelGGL(induce_kernel, dim3(G * 8), dim3(kInduceThreads), lds2, s, g->col_idx, hlog, G,
                        scratch_entries, w, status);
     prof_mark(p->prof, 2, s);
     hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), lds3, s, B, w, oq, ok, scratch_entries, status);
