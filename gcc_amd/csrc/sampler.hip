@@ -52,7 +52,7 @@ __device__ __forceinline__ int pow2_ceil(int v)
 struct Work {
     int32_t *seeds;       // [B]
     int32_t *sub_n;       // [G]
-    int32_t *sub_cap;     // [G]   scratch slots: segments * (1 + min(kSeg, n))
+    int32_t *sub_cap;     // [G]   scratch slots: sum_i row_slots(deg_i, n)
     int32_t *sub_seg;     // [G]   number of row segments
     int32_t *sub_nnz;     // [G]
     int32_t *nodes;       // [G][ncap]   parent ids, seed first
@@ -96,6 +96,8 @@ struct BatchOutDev {
     int32_t *node_off, *edge_off, *parent_nid, *graph_id, *row_ptr, *col_idx;
     int64_t node_cap, edge_cap;
 };
+
+__device__ __forceinline__ int row_slots(int deg, int n);
 
 // ------------------------------------------------------------------ K1 ----
 __global__ __launch_bounds__(64) void rwr_walk_kernel(
@@ -254,17 +256,19 @@ __global__ __launch_bounds__(64) void rwr_walk_kernel(
         n += __popcll(m);
     }
     wave_sync();
-    // induction work units: row i contributes ceil(deg_i / kSeg) segments
-    int run = 0;
+    // induction work units: row i contributes ceil(deg_i / kSeg) segments and row_slots() scratch slots
+    int run = 0, slots = 0;
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
         const int c = i < n ? (ldeg[i] + kSeg - 1) / kSeg : 0;
+        const int sl = i < n ? row_slots(ldeg[i], n) : 0;
         run += wave_shfl(wave_scan_incl(c), 63);
+        slots += wave_shfl(wave_scan_incl(sl), 63);
     }
     if (lane == 0) {
         w.sub_n[g] = n;
         w.sub_seg[g] = run;
-        w.sub_cap[g] = run * (1 + (n < kSeg ? n : kSeg));     // per segment: count header + at most min(kSeg, n) hits
+        w.sub_cap[g] = slots;
         w.sub_nnz[g] = 0;
     }
 }
@@ -283,6 +287,15 @@ __device__ __forceinline__ long long block_range_sum(const int32_t *arr, int beg
     const long long r = red[0];
     __syncthreads();
     return r;
+}
+
+// scratch slots of one member row: every segment = 1 count header + at most min(segment length, n) hits
+__device__ __forceinline__ int row_slots(int deg, int n)
+{
+    const int nseg = (deg + kSeg - 1) / kSeg;
+    const int full = n < kSeg ? n : kSeg;
+    const int rem = deg - (nseg - 1) * kSeg;
+    return nseg + (nseg - 1) * full + (rem < n ? rem : n);
 }
 
 // block-wide exclusive scan of vals over [0, count) into LDS out[0..count] (out[count] = total);
@@ -338,7 +351,8 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
     uint32_t *hkey = (uint32_t *)smem;                       // [hcap]
     uint16_t *hval = (uint16_t *)(hkey + hcap);              // [hcap]
     int32_t *segoff = (int32_t *)(hval + hcap);              // [ncap + 1] exclusive prefix of segments per row
-    int32_t *vbp = segoff + (w.ncap + 1);                    // [G + 1]   exclusive prefix of virtual blocks
+    int32_t *capoff = segoff + (w.ncap + 1);                 // [ncap + 1] exclusive prefix of scratch slots per row
+    int32_t *vbp = capoff + (w.ncap + 1);                    // [G + 1]   exclusive prefix of virtual blocks
     long long *sbp = (long long *)(vbp + ((G + 2) & ~1));    // [G + 1]   exclusive prefix of scratch slots
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
     block_exclusive_scan<int32_t>(vbp, G, [&](int g) { return (w.sub_seg[g] + kSegPerWg - 1) / kSegPerWg; }, wsum32);
@@ -372,6 +386,7 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
                 }
             }
             block_exclusive_scan<int32_t>(segoff, n, [&](int i) { return (rowdeg[i] + kSeg - 1) / kSeg; }, wsum32);
+            block_exclusive_scan<int32_t>(capoff, n, [&](int i) { return row_slots(rowdeg[i], n); }, wsum32);
             cur_g = g;
         }
         const int stride = 1 + (n < kSeg ? n : kSeg);
@@ -384,7 +399,7 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
             const int e0 = (s - segoff[i]) * kSeg;
             const int32_t beg = rowbeg[i] + e0;
             const int len = min(kSeg, rowdeg[i] - e0);
-            int32_t *out = w.scratch + sbase + (long long)s * stride;
+            int32_t *out = w.scratch + sbase + capoff[i] + (s - segoff[i]) * stride;
             uint32_t v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -423,7 +438,8 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
     __shared__ long long red[256];
     __shared__ int32_t wsum32[5];
     int32_t *segoff = (int32_t *)smem;            // [ncap + 1] exclusive prefix of segments per row
-    int32_t *excl = segoff + (w.ncap + 1);        // [ncap + 1] exclusive prefix of induced degrees
+    int32_t *capoff = segoff + (w.ncap + 1);      // [ncap + 1] exclusive prefix of scratch slots per row
+    int32_t *excl = capoff + (w.ncap + 1);        // [ncap + 1] exclusive prefix of induced degrees
     const int tid = (int)threadIdx.x;
     const int g = (int)blockIdx.x;
     const int view = g / B, b = g - view * B;
@@ -444,23 +460,35 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
     const bool bad_scratch = sbase + (long long)w.sub_cap[g] > scratch_entries;
     const bool bad_nodes = node_base + n > o.node_cap;
     const bool bad_edges = edge_base + nnz > o.edge_cap;
+    const int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
     if (bad_scratch || bad_nodes || bad_edges) {
         if (tid == 0)
             atomicOr(status, (int32_t)((bad_scratch ? GCC_STATUS_SCRATCH_OVERFLOW : 0) |
                                        (bad_nodes ? GCC_STATUS_NODE_OVERFLOW : 0) |
                                        (bad_edges ? GCC_STATUS_EDGE_OVERFLOW : 0)));
+        // leave a VALID structure behind (rows without edges, offsets clamped to the capacity) so that a
+        // consumer that has not looked at `status` yet can never index out of bounds
+        const long long ecl = edge_base < o.edge_cap ? edge_base : o.edge_cap;
+        for (int i = tid; i < n; i += 256) {
+            if (node_base + i < o.node_cap) {
+                o.parent_nid[node_base + i] = nodes[i];
+                o.graph_id[node_base + i] = b;
+                o.row_ptr[node_base + i] = (int32_t)ecl;
+            }
+        }
+        if (b == B - 1 && tid == 0 && node_base + n <= o.node_cap) o.row_ptr[node_base + n] = (int32_t)ecl;
         return;
     }
-    const int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
     const int32_t *rowdeg = w.rowdeg + (int64_t)g * w.ncap;
     const int32_t *scratch = w.scratch + sbase;
     const int stride = 1 + (n < kSeg ? n : kSeg);
 
     block_exclusive_scan<int32_t>(segoff, n, [&](int i) { return (rowdeg[i] + kSeg - 1) / kSeg; }, wsum32);
+    block_exclusive_scan<int32_t>(capoff, n, [&](int i) { return row_slots(rowdeg[i], n); }, wsum32);
     // induced degree of row i = sum of its segments' hit counts
     block_exclusive_scan<int32_t>(excl, n, [&](int i) {
         int c = 0;
-        for (int s = segoff[i]; s < segoff[i + 1]; ++s) c += scratch[(long long)s * stride];
+        for (int k = 0; k < segoff[i + 1] - segoff[i]; ++k) c += scratch[capoff[i] + k * stride];
         return c;
     }, wsum32);
 
@@ -474,14 +502,14 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
     for (int e = tid; e < nnz; e += 256) {
         const int i = upper_slot(excl, n, e);
         int off = e - excl[i];
-        int s = segoff[i];
+        int at = capoff[i];
         for (;;) {
-            const int c = scratch[(long long)s * stride];
+            const int c = scratch[at];
             if (off < c) break;
             off -= c;
-            ++s;
+            at += stride;
         }
-        o.col_idx[edge_base + e] = (int32_t)node_base + scratch[(long long)s * stride + 1 + off];
+        o.col_idx[edge_base + e] = (int32_t)node_base + scratch[at + 1 + off];
     }
 }
 
@@ -540,8 +568,8 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     int hlog = 7;
     while ((1 << hlog) < 2 * (g->lmax + 1)) ++hlog;
     const size_t lds1 = ((size_t)p2max * 2 + 64) * 4;
-    const size_t lds2 = (size_t)(1 << hlog) * 6 + (size_t)(wl.ncap + 1) * 4 + (size_t)(G + 2) * 4 + (size_t)(G + 1) * 8 + 16;
-    const size_t lds3 = (size_t)(wl.ncap + 1) * 8;
+    const size_t lds2 = (size_t)(1 << hlog) * 6 + (size_t)(wl.ncap + 1) * 8 + (size_t)(G + 2) * 4 + (size_t)(G + 1) * 8 + 16;
+    const size_t lds3 = (size_t)(wl.ncap + 1) * 12;
     if (lds1 > 64 * 1024 || lds2 > 64 * 1024 || lds3 > 64 * 1024) {
         snprintf(g_err, kErrLen, "gcc_sample_batch: lmax=%d / batch too large for 64 KiB of LDS", g->lmax);
         return -4;

@@ -123,7 +123,7 @@ class DeviceRWRSampler:
         # induction scratch: sum over subgraphs of sum_i min(deg_i, n) <= sum n^2; sized generously
         # (HBM is 288 GB) and guarded by the device status word
         self.scratch_entries = int(scratch_entries) if scratch_entries else max(
-            16 << 20, 256 * B * (graph.rw_hops + 1), 8 * (graph.lmax + 1) ** 2)
+            32 << 20, 512 * B * (graph.rw_hops + 1), 8 * (graph.lmax + 1) ** 2)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self._alloc_workspace()
         i32 = dict(dtype=torch.int32, device=dev)

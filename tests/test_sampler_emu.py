@@ -66,3 +66,20 @@ def test_overflow_is_flagged_not_truncated():
     assert status & 4
     _, status, _ = emu_sample_batch(g, 4, 1, 0, node_cap=4)
     assert status & 2
+
+
+def test_overflow_leaves_a_valid_structure():
+    """A consumer that has not looked at `status` yet must never be able to index out of bounds."""
+    rp, ci = powerlaw_graph(3000, 30000, 3)
+    g = EmuGraph(rp, ci, rw_hops=64)
+    for kw in (dict(scratch_entries=300), dict(edge_cap=40)):
+        res, status, _ = emu_sample_batch(g, 6, 1, 0, **kw)
+        assert status != 0
+        for view in res:
+            N = int(view["node_off"][-1])
+            rptr = view["row_ptr"]
+            cap = kw.get("edge_cap", 10**9)
+            assert np.all(np.diff(rptr) >= 0) and rptr[0] == 0 and rptr[-1] <= max(cap, int(view["edge_off"][-1]))
+            e = min(int(rptr[-1]), cap)
+            cols = view["col_idx"][:e]
+            assert cols.size == 0 or (cols.min() >= 0 and cols.max() < N)
