@@ -40,6 +40,7 @@ constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 constexpr int kSeg = 256;           // parent edges per segment (64 lanes x 4 loads)
 constexpr int kSegPerWg = 16;      // segments per virtual workgroup (4 per wave)
 constexpr int kInduceThreads = 256;
+constexpr int kPackParts = 4;      // pack workgroups per subgraph (hub-seed subgraphs have 10x the rows/edges)
 
 __device__ __forceinline__ int pow2_ceil(int v)
 {
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
     int32_t *capoff = segoff + (w.ncap + 1);      // [ncap + 1] exclusive prefix of scratch slots per row
     int32_t *excl = capoff + (w.ncap + 1);        // [ncap + 1] exclusive prefix of induced degrees
     const int tid = (int)threadIdx.x;
-    const int g = (int)blockIdx.x;
+    const int g = (int)blockIdx.x / kPackParts, part = (int)blockIdx.x % kPackParts;
     const int view = g / B, b = g - view * B;
     const BatchOutDev o = view ? ok : oq;
     const int n = w.sub_n[g];
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
     const long long node_base = block_range_sum(w.sub_n, view * B, g, red);
     const long long edge_base = block_range_sum(w.sub_nnz, view * B, g, red);
     const long long sbase = block_range_sum(w.sub_cap, 0, g, red);
-    if (tid == 0) {
+    if (tid == 0 && part == 0) {
         o.node_off[b] = (int32_t)node_base;
         o.edge_off[b] = (int32_t)edge_base;
         if (b == B - 1) {
@@ -462,21 +463,21 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
     const bool bad_edges = edge_base + nnz > o.edge_cap;
     const int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
     if (bad_scratch || bad_nodes || bad_edges) {
-        if (tid == 0)
+        if (tid == 0 && part == 0)
             atomicOr(status, (int32_t)((bad_scratch ? GCC_STATUS_SCRATCH_OVERFLOW : 0) |
                                        (bad_nodes ? GCC_STATUS_NODE_OVERFLOW : 0) |
                                        (bad_edges ? GCC_STATUS_EDGE_OVERFLOW : 0)));
         // leave a VALID structure behind (rows without edges, offsets clamped to the capacity) so that a
         // consumer that has not looked at `status` yet can never index out of bounds
         const long long ecl = edge_base < o.edge_cap ? edge_base : o.edge_cap;
-        for (int i = tid; i < n; i += 256) {
+        for (int i = part * 256 + tid; i < n; i += 256 * kPackParts) {
             if (node_base + i < o.node_cap) {
                 o.parent_nid[node_base + i] = nodes[i];
                 o.graph_id[node_base + i] = b;
                 o.row_ptr[node_base + i] = (int32_t)ecl;
             }
         }
-        if (b == B - 1 && tid == 0 && node_base + n <= o.node_cap) o.row_ptr[node_base + n] = (int32_t)ecl;
+        if (b == B - 1 && tid == 0 && part == 0 && node_base + n <= o.node_cap) o.row_ptr[node_base + n] = (int32_t)ecl;
         return;
     }
     const int32_t *rowdeg = w.rowdeg + (int64_t)g * w.ncap;
@@ -492,14 +493,14 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
         return c;
     }, wsum32);
 
-    for (int i = tid; i < n; i += 256) {
+    for (int i = part * 256 + tid; i < n; i += 256 * kPackParts) {
         o.parent_nid[node_base + i] = nodes[i];
         o.graph_id[node_base + i] = b;
         o.row_ptr[node_base + i] = (int32_t)(edge_base + excl[i]);
     }
-    if (b == B - 1 && tid == 0) o.row_ptr[node_base + n] = (int32_t)(edge_base + nnz);
+    if (b == B - 1 && tid == 0 && part == 0) o.row_ptr[node_base + n] = (int32_t)(edge_base + nnz);
     // one thread per output edge: its row by binary search, then its segment inside the row
-    for (int e = tid; e < nnz; e += 256) {
+    for (int e = part * 256 + tid; e < nnz; e += 256 * kPackParts) {
         const int i = upper_slot(excl, n, e);
         int off = e - excl[i];
         int at = capoff[i];
@@ -570,8 +571,8 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     const size_t lds1 = ((size_t)p2max * 2 + 64) * 4;
     const size_t lds2 = (size_t)(1 << hlog) * 6 + (size_t)(wl.ncap + 1) * 8 + (size_t)(G + 2) * 4 + (size_t)(G + 1) * 8 + 16;
     const size_t lds3 = (size_t)(wl.ncap + 1) * 12;
-    if (lds1 > 64 * 1024 || lds2 > 64 * 1024 || lds3 > 64 * 1024) {
-        snprintf(g_err, kErrLen, "gcc_sample_batch: lmax=%d / batch too large for 64 KiB of LDS", g->lmax);
+    if (lds1 > 160 * 1024 || lds2 > 160 * 1024 || lds3 > 160 * 1024) {
+        snprintf(g_err, kErrLen, "gcc_sample_batch: lmax=%d / batch too large for 160 KiB of LDS", g->lmax);
         return -4;
     }
     BatchOutDev oq = {out_q->node_off, out_q->edge_off, out_q->parent_nid, out_q->graph_id,
@@ -580,6 +581,12 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
                       out_k->row_ptr, out_k->col_idx, out_k->node_cap, out_k->edge_cap};
 
     prof_mark(p->prof, 0, s);
+#ifndef GCC_AMD_HIPEMU
+    // more than 64 KiB of dynamic LDS has to be opted into per kernel
+    if (lds1 > 64 * 1024) (void)hipFuncSetAttribute((const void *)rwr_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (lds2 > 64 * 1024) (void)hipFuncSetAttribute((const void *)induce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    if (lds3 > 64 * 1024) (void)hipFuncSetAttribute((const void *)pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+#endif
     hipLaunchKernelGGL(rwr_walk_kernel, dim3(G), dim3(64), lds1, s, g->row_ptr, g->col_idx, g->seed_cdf,
                        g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, B,
                        p->restart_u32, p->seeds, w);
@@ -587,7 +594,7 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     hipLaunchKernelGGL(induce_kernel, dim3(G * 8), dim3(kInduceThreads), lds2, s, g->col_idx, hlog, G,
                        scratch_entries, w, status);
     prof_mark(p->prof, 2, s);
-    hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), lds3, s, B, w, oq, ok, scratch_entries, status);
+    hipLaunchKernelGGL(pack_kernel, dim3(G * kPackParts), dim3(256), lds3, s, B, w, oq, ok, scratch_entries, status);
     prof_mark(p->prof, 3, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
