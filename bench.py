@@ -53,7 +53,8 @@ def parse_args():
     ap.add_argument("--lanes", type=int, default=12, help="producer streams (sampler + positional embedding)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight per producer lane")
     ap.add_argument("--pmc-traffic", type=float, default=None,
-                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass")
+                    help="HBM bytes per launch of the roofline kernel from a separate rocprofv3 --pmc pass "
+                         "(default: the committed profiles/r1_pmc_sampler.json, if the workload is the default one)")
     return ap.parse_args()
 
 
@@ -159,6 +160,18 @@ def cpu_baseline(rp, ci, args):
                 sample=f"{done // (2 * B)} full steps of bsz {B} ({done} subgraphs) in {dt:.1f}s: C sampler oracle "
                        f"(OpenMP x{threads}) + SciPy eigsh pos-emb ({workers} processes) + torch-CPU "
                        f"encoder/MoCo/Adam/EMA oracle ({torch.get_num_threads()} threads)")
+
+
+def committed_pmc_traffic(args):
+    """PMC counters cannot be collected from inside the benchmarked process; the figure comes from the
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes committed under profiles/."""
+    if args.pmc_traffic is not None:
+        return args.pmc_traffic, "--pmc-traffic"
+    path = os.path.join(ROOT, "profiles", "r1_pmc_sampler.json")
+    default_workload = (args.batch_size, args.rw_hops, args.nodes, args.edges) == (256, 256, 1_000_000, 10_000_000)
+    if default_workload and os.path.exists(path):
+        return json.load(open(path))["induce_kernel_hbm_bytes_per_launch_raw"], "profiles/r1_pmc_sampler.json"
+    return None, None
 
 
 def main():
@@ -308,7 +321,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "measured": "isolated probe loop after the timed region",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "algorithmic_bytes_per_launch": acc["induce"], "traffic": args.pmc_traffic},
+                         "algorithmic_bytes_per_launch": acc["induce"], "traffic": committed_pmc_traffic(args)[0],
+                         "traffic_source": committed_pmc_traffic(args)[1]},
             "algorithmic_bytes_per_step": acc,
         }
         if not args.no_cpu_baseline:
