@@ -219,12 +219,14 @@ def main():
     contrast = MemoryMoCo(64, None, args.nce_k, 0.07, use_softmax=True).to(dev)
     if args.posemb == "device":
         posembs = [DevicePosEmb(B, sampler.node_cap, 32, device=dev, seed=args.run_seed, num_buffers=nbuf)
-                   for _ in range(args.lanes)]
+                   for _ in range(2 * args.lanes)]
     else:
-        posembs = [PlaceholderPosEmb(sampler.node_cap, 32, device=dev)] * args.lanes
+        posembs = [PlaceholderPosEmb(sampler.node_cap, 32, device=dev)] * (2 * args.lanes)
     posemb = posembs[0]
+    # every producer lane: one sampler + one eigensolver workspace per view (the two views run on two streams)
+    lanes = [(samplers[i], posembs[2 * i], posembs[2 * i + 1]) for i in range(args.lanes)]
     trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank,
-                            extra_lanes=list(zip(samplers[1:], posembs[1:])), depth=args.depth)
+                            lanes=lanes, depth=args.depth)
     stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder q+k fwd",
               "moco-infonce fwd", "key all-gather" if world > 1 else "enqueue", "infonce bwd", "gin-encoder bwd",
               "grad all-reduce" if world > 1 else "clip", "adam", "ema"]

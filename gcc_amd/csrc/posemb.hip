@@ -146,6 +146,22 @@ __device__ __forceinline__ int rank_desc(const float *lam, int n, int i)
     return r;
 }
 
+// ---- exact leaf deflation.  Degree-1 nodes that share a parent p are twins: with t of them, the
+// t - 1 contrast vectors on the leaves are exact null vectors of M = D^-1/2 A D^-1/2, and the rest of
+// the spectrum is that of the quotient matrix M' in which the t leaves are one "super-leaf" coupled
+// to p with sqrt(t / d_p).  Sampled ego-nets are star-like (a typical n = 92 has ~35 such null
+// vectors), so M' is ~40 % smaller and the O(n^3) Jacobi ~5x cheaper; an eigenvector y of M' expands
+// to the leaves as y[super-leaf] / sqrt(t).  Any orthonormal basis of a degenerate eigenspace is
+// as good as ARPACK's, so when the top-k reaches into the null space the contrasts are used.
+constexpr int kNodeMax = 1024;       // largest subgraph the deflating Jacobi kernels look at (per-node LDS tables)
+constexpr uint16_t kNone = 0xFFFFu;
+constexpr float kZeroEig = 1e-5f;    // |lambda| below this is "the null space" when ranking
+
+struct Defl {
+    uint16_t *par, *rep, *ridx, *ord;   // [kNodeMax] parent of a leaf | first leaf of a parent | reduced index | leaf order
+    int32_t *tcnt, *cbase;              // [kNodeMax] leaves per parent | contrast numbering (exclusive prefix of t - 1)
+};
+
 template <int kNMin, int kNMax, int kT>
 __global__ __launch_bounds__(kT) void posemb_jacobi_kernel(PosArgs a)
 {
@@ -153,83 +169,172 @@ __global__ __launch_bounds__(kT) void posemb_jacobi_kernel(PosArgs a)
     __shared__ float rot[kJMax];
     __shared__ int pq[kJMax];
     __shared__ float lam[kJMax];
-    __shared__ float dinv[kJMax];
-    __shared__ int colof[kJMax];
-    __shared__ int flag;
+    __shared__ int colE[kJMax];                 // output column of eigenpair i' of M' (or -1)
+    __shared__ int colsrc[64];                  // per output column: i' >= 0, or -(c + 1) for contrast c
+    __shared__ int flag, sh_np, sh_z, sh_npos, sh_nzer;
     __shared__ float red[kT];
-    const int tid = (int)threadIdx.x;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
     const int b = (int)blockIdx.x;
     if (b >= a.B) return;
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
-    if (n > kNMax || n < kNMin) return;            // other size class / Krylov kernel
+    if (n > kNodeMax) return;                      // Krylov kernel
     const int k = min(n - 2, a.hidden);            // data_util.py:278
     if (k <= 0) {                                  // data_util.py:243-244: zeros
-        for (int i = tid; i < n * a.hidden; i += kT) a.pos[(int64_t)n0 * a.hidden + i] = 0.f;
-        if (a.evals) for (int i = tid; i < a.hidden; i += kT) a.evals[(int64_t)b * a.hidden + i] = 0.f;
+        if (kNMin == 0) {
+            for (int i = tid; i < n * a.hidden; i += kT) a.pos[(int64_t)n0 * a.hidden + i] = 0.f;
+            if (a.evals) for (int i = tid; i < a.hidden; i += kT) a.evals[(int64_t)b * a.hidden + i] = 0.f;
+        }
         return;
     }
-    const int np = (n + 1) & ~1, lda = np + 1;
-    float *A = (float *)smem, *V = A + np * lda;
-    for (int i = tid; i < np * lda; i += kT) { A[i] = 0.f; V[i] = 0.f; }
-    if (tid < np) {
-        int d = tid < n ? a.row_ptr[n0 + tid + 1] - a.row_ptr[n0 + tid] : 1;
-        dinv[tid] = 1.0f / sqrtf((float)(d < 1 ? 1 : d));     // in_degrees().clip(1) ** -0.5, data_util.py:274-276
+    constexpr int kNpMax = (kNMax + 1) & ~1;
+    float *A = (float *)smem, *V = A + kNpMax * (kNpMax + 1);
+    Defl d;
+    d.tcnt = (int32_t *)(V + kNpMax * (kNpMax + 1));
+    d.cbase = d.tcnt + kNodeMax;
+    d.par = (uint16_t *)(d.cbase + kNodeMax);
+    d.rep = d.par + kNodeMax;
+    d.ridx = d.rep + kNodeMax;
+    d.ord = d.ridx + kNodeMax;
+    const int32_t *rp = a.row_ptr + n0;
+
+    // ---- leaf groups
+    for (int i = tid; i < n; i += kT) {
+        const int dg = rp[i + 1] - rp[i];
+        d.par[i] = dg == 1 ? (uint16_t)(a.col_idx[rp[i]] - n0) : kNone;
+        d.tcnt[i] = 0;
+        d.rep[i] = kNone;
+        d.ord[i] = 0;
     }
     __syncthreads();
-    if (tid < np) V[tid * lda + tid] = 1.f;
-    // laplacian = norm * adj * norm (data_util.py:277); one wave per row keeps the loads coalesced
-    for (int r = tid >> 6; r < n; r += kT >> 6) {
-        const int beg = a.row_ptr[n0 + r], end = a.row_ptr[n0 + r + 1];
-        for (int e = beg + (tid & 63); e < end; e += 64) {
-            const int c = a.col_idx[e] - n0;
-            A[r * lda + c] = dinv[r] * dinv[c];
+    for (int i = tid; i < n; i += kT)
+        if (d.par[i] != kNone) atomicAdd(&d.tcnt[d.par[i]], 1);
+    __syncthreads();
+    for (int p = tid; p < n; p += kT) {            // rows are sorted: a parent's leaves in index order
+        if (d.tcnt[p] >= 2) {
+            int o = 0;
+            for (int e = rp[p]; e < rp[p + 1]; ++e) {
+                const int j = a.col_idx[e] - n0;
+                if (d.par[j] == (uint16_t)p) {
+                    if (o == 0) d.rep[p] = (uint16_t)j;
+                    d.ord[j] = (uint16_t)o++;
+                }
+            }
         }
     }
     __syncthreads();
-    // ||A||_F for the rotation threshold
-    float ss = 0.f;
+    if (tid == 0) {                                // n <= 1024: a serial prefix is a few microseconds
+        int r = 0, c = 0;
+        for (int i = 0; i < n; ++i) {
+            d.cbase[i] = c;
+            if (d.tcnt[i] >= 2) c += d.tcnt[i] - 1;
+            const bool collapsed = d.par[i] != kNone && d.tcnt[d.par[i]] >= 2 && d.rep[d.par[i]] != (uint16_t)i;
+            d.ridx[i] = collapsed ? kNone : (uint16_t)r++;
+        }
+        sh_np = r;
+        sh_z = c;
+    }
+    __syncthreads();
+    const int nr = sh_np, z = sh_z;                // reduced size n', number of contrast null vectors
+    if (nr > kNMax || nr < kNMin) return;          // other size class / Krylov kernel
+    const int np = (nr + 1) & ~1, lda = np + 1;
+    for (int i = tid; i < np * lda; i += kT) { A[i] = 0.f; V[i] = 0.f; }
+    __syncthreads();
+    if (tid < np) V[tid * lda + tid] = 1.f;
+    // M' = norm * adj * norm on the kept nodes (data_util.py:273-277), super-leaf couplings scaled by sqrt(t)
+    for (int i = tid >> 6; i < n; i += kT >> 6) {
+        if (d.ridx[i] == kNone) continue;          // wave-uniform
+        const int ri = d.ridx[i];
+        const int di = rp[i + 1] - rp[i];
+        for (int e = rp[i] + lane; e < rp[i + 1]; e += 64) {
+            const int j = a.col_idx[e] - n0;
+            if (d.ridx[j] == kNone) continue;
+            const int dj = rp[j + 1] - rp[j];
+            float val = 1.0f / sqrtf((float)di * (float)dj);      // in_degrees().clip(1) ** -0.5 on both sides
+            if (d.par[j] == (uint16_t)i && d.tcnt[i] >= 2) val *= sqrtf((float)d.tcnt[i]);
+            if (d.par[i] == (uint16_t)j && d.tcnt[j] >= 2) val *= sqrtf((float)d.tcnt[j]);
+            A[ri * lda + d.ridx[j]] = val;
+        }
+    }
+    __syncthreads();
+    float ss = 0.f;                                // ||M'||_F for the rotation threshold
     for (int i = tid; i < np * lda; i += kT) ss += A[i] * A[i];
     red[tid] = ss;
     __syncthreads();
-    for (int d = kT >> 1; d > 0; d >>= 1) {
-        if (tid < d) red[tid] += red[tid + d];
+    for (int dd = kT >> 1; dd > 0; dd >>= 1) {
+        if (tid < dd) red[tid] += red[tid + dd];
         __syncthreads();
     }
     const float tol = 1e-7f * sqrtf(red[0]) + 1e-30f;
     __syncthreads();
     jacobi_lds(A, V, np, lda, rot, pq, &flag, tol);
     __syncthreads();
-    // eigsh(which="LA") order: the k largest eigenvalues, ascending (data_util.py:251)
-    if (tid < n) lam[tid] = A[tid * lda + tid];
+    // ---- rank the n' eigenvalues of M' together with the z contrast zeros:
+    //      positive, then null space (M' zeros, then contrasts), then negative; eigsh(which="LA") returns the
+    //      k largest in ascending order (data_util.py:251)
+    if (tid < nr) lam[tid] = A[tid * lda + tid];
+    if (tid < 64) colsrc[tid] = 0;
     __syncthreads();
-    if (tid < n) {
-        const int r = rank_desc(lam, n, tid);
-        colof[tid] = r < k ? k - 1 - r : -1;
-        if (a.evals && r < k) a.evals[(int64_t)b * a.hidden + (k - 1 - r)] = lam[tid];
+    if (tid == 0) {
+        int npos = 0, nzer = 0;
+        for (int i = 0; i < nr; ++i) { npos += lam[i] > kZeroEig; nzer += fabsf(lam[i]) <= kZeroEig; }
+        sh_npos = npos;
+        sh_nzer = nzer;
+    }
+    __syncthreads();
+    const int npos = sh_npos, nzer = sh_nzer;
+    if (tid < nr) {
+        const float li = lam[tid];
+        int r = 0;
+        if (li > kZeroEig) {
+            for (int j = 0; j < nr; ++j) r += (lam[j] > li || (lam[j] == li && j < tid)) ? 1 : 0;
+        } else if (fabsf(li) <= kZeroEig) {
+            r = npos;
+            for (int j = 0; j < tid; ++j) r += fabsf(lam[j]) <= kZeroEig ? 1 : 0;
+        } else {
+            r = npos + nzer + z;
+            for (int j = 0; j < nr; ++j)
+                r += (lam[j] < -kZeroEig && (lam[j] > li || (lam[j] == li && j < tid))) ? 1 : 0;
+        }
+        colE[tid] = r < k ? k - 1 - r : -1;
+        if (r < k) {
+            colsrc[k - 1 - r] = tid;
+            if (a.evals) a.evals[(int64_t)b * a.hidden + (k - 1 - r)] = fabsf(li) <= kZeroEig ? 0.f : li;
+        }
+    }
+    for (int c = tid; c < z; c += kT) {            // contrast c has rank npos + nzer + c
+        const int r = npos + nzer + c;
+        if (r < k) {
+            colsrc[k - 1 - r] = -(c + 1);
+            if (a.evals) a.evals[(int64_t)b * a.hidden + (k - 1 - r)] = 0.f;
+        }
     }
     if (a.evals) for (int i = k + tid; i < a.hidden; i += kT) a.evals[(int64_t)b * a.hidden + i] = 0.f;
     __syncthreads();
-    // x = normalize(u, "l2") row-wise, float32, zero padded to `hidden` columns (data_util.py:260-262)
-    for (int r = tid >> 6; r < n; r += kT >> 6) {
-        const int lane = tid & 63;
-        float s2 = 0.f;
-        for (int i = lane; i < n; i += 64) {
-            const float v = colof[i] >= 0 ? V[r * lda + i] : 0.f;
-            s2 += v * v;
+    // ---- expand to the n original nodes; x = normalize(u, "l2") row-wise, zero padded (data_util.py:260-262)
+    for (int v = tid >> 6; v < n; v += kT >> 6) {
+        const int pv = d.par[v];
+        const bool grouped = pv != kNone && d.tcnt[pv] >= 2;
+        const int rsrc = grouped ? d.ridx[d.rep[pv]] : d.ridx[v];
+        const float scale = grouped ? 1.0f / sqrtf((float)d.tcnt[pv]) : 1.0f;
+        float val = 0.f;
+        if (lane < k) {
+            const int src = colsrc[lane];
+            if (src >= 0) {
+                val = V[rsrc * lda + src] * scale;
+            } else if (grouped) {
+                const int jm1 = -src - 1 - d.cbase[pv];          // contrast j = jm1 + 1 of parent pv
+                if (jm1 >= 0 && jm1 < d.tcnt[pv] - 1) {
+                    const int j = jm1 + 1, o = d.ord[v];
+                    const float nrm = 1.0f / sqrtf((float)(j * (j + 1)));
+                    val = o < j ? nrm : (o == j ? -(float)j * nrm : 0.f);
+                }
+            }
         }
-        s2 = wave_sum(s2);
+        const float s2 = wave_sum(val * val);
         const float inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
-        float *out = a.pos + (int64_t)(n0 + r) * a.hidden;
-        for (int i = lane; i < a.hidden; i += 64) out[i] = 0.f;
-        wave_sync();
-        for (int i = lane; i < n; i += 64)
-            if (colof[i] >= 0) out[colof[i]] = V[r * lda + i] * inv;
-        if (a.raw) {
-            float *ro = a.raw + (int64_t)(n0 + r) * a.hidden;
-            for (int i = lane; i < a.hidden; i += 64) ro[i] = 0.f;
-            wave_sync();
-            for (int i = lane; i < n; i += 64)
-                if (colof[i] >= 0) ro[colof[i]] = V[r * lda + i];
+        if (lane < a.hidden) {
+            a.pos[(int64_t)(n0 + v) * a.hidden + lane] = val * inv;
+            if (a.raw) a.raw[(int64_t)(n0 + v) * a.hidden + lane] = val;
         }
     }
 }
@@ -285,8 +390,20 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
     const int b = (int)blockIdx.x;
     if (b >= a.B) return;
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
-    if (n <= kJMax) return;                          // handled by the Jacobi kernel
+    if (n <= kJMax) return;                          // handled by the Jacobi kernels
     const int ldv = ka.ldv;
+    if (n <= kNodeMax) {                             // ... which also take it if its leaf-deflated size fits
+        int32_t *tc = (int32_t *)smem;
+        for (int i = tid; i < n; i += kKThreads) tc[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += kKThreads)
+            if (a.row_ptr[n0 + i + 1] - a.row_ptr[n0 + i] == 1) atomicAdd(&tc[a.col_idx[a.row_ptr[n0 + i]] - n0], 1);
+        __syncthreads();
+        float zz = 0.f;
+        for (int i = tid; i < n; i += kKThreads) zz += tc[i] >= 2 ? (float)(tc[i] - 1) : 0.f;
+        const int nred = n - (int)(block_sum(zz, red) + 0.5f);
+        if (nred <= kJMax) return;
+    }
     float *V = ka.vws + (int64_t)b * 2 * (kM + 1) * ldv;
     float *Valt = V + (int64_t)(kM + 1) * ldv;
     float *x = (float *)smem, *w = x + ldv, *dinv = w + ldv;
@@ -423,6 +540,13 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
         }
         __syncthreads();
         const bool finished = done != 0 || cycle == kMaxCycles - 1;
+#ifdef GCC_AMD_HIPEMU
+        if (getenv("GCC_POSEMB_DEBUG") && tid == 0) {
+            float worst = 0.f; int nbad = 0;
+            for (int i = 0; i < kM; ++i) if (sel[i] < k) { const float rs = fabsf(beta_m * Yj[(kM - 1) * lda + i]); worst = rs > worst ? rs : worst; nbad += rs > kRitzTol; }
+            fprintf(stderr, "kry b=%d n=%d cycle=%d worst=%.2e nbad=%d theta_k=%.4f\n", b, n, cycle + 1, worst, nbad, 0.f);
+        }
+#endif
         if (finished && done == 0 && flag == 2 && tid == 0) atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
         const int nout = finished ? k : keep;
         // output column t <- Ritz vector: restart keeps rank t, the final result is ascending (rank k-1-t)
@@ -530,8 +654,9 @@ int32_t gcc_posemb(const gcc_batch_out *g, int32_t batch_size, int32_t hidden, f
     }
     PosArgs a = {g->node_off, g->row_ptr, g->col_idx, pos, evals, raw, batch_size, hidden, seed, status, nullptr, nullptr};
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds_small = (size_t)2 * kJSmall * (kJSmall + 1) * sizeof(float);
-    const size_t lds_big = (size_t)2 * kJMax * (kJMax + 1) * sizeof(float);
+    const size_t lds_tab = (size_t)kNodeMax * (2 * sizeof(int32_t) + 4 * sizeof(uint16_t));
+    const size_t lds_small = (size_t)2 * kJSmall * (kJSmall + 1) * sizeof(float) + lds_tab;
+    const size_t lds_big = (size_t)2 * kJMax * (kJMax + 1) * sizeof(float) + lds_tab;
 #ifndef GCC_AMD_HIPEMU
     static bool attr_set = false;
     if (!attr_set) {

@@ -73,12 +73,14 @@ class BatchProducer:
     (train.py:577-586) -- same role, same "prefetch" semantics, no processes."""
 
     def __init__(self, lanes, first_id_fn, device, depth=2):
-        self.lanes = lanes                      # list of (sampler, posemb)
+        self.lanes = lanes                      # list of (sampler, posemb) or (sampler, posemb_q, posemb_k)
         self.first_id = first_id_fn
         self.dev = device
         self.depth = depth
         self.cuda = torch.device(device).type == "cuda"
         self.streams = [torch.cuda.Stream(device) for _ in lanes] if self.cuda else [None] * len(lanes)
+        # a lane with separate eigensolver workspaces for the two views embeds them on two streams at once
+        self.streams_k = [torch.cuda.Stream(device) if self.cuda and len(l) == 3 else None for l in lanes]
         self.ready = {}                         # step -> (graphs, event)
         self.released = {}                      # step -> event recorded on the consumer stream
         self.next_step = 0
@@ -86,12 +88,26 @@ class BatchProducer:
 
     def _produce(self, step):
         lane = step % len(self.lanes)
-        sampler, posemb = self.lanes[lane]
+        sampler, posemb_q = self.lanes[lane][0], self.lanes[lane][1]
+        posemb_k = self.lanes[lane][2] if len(self.lanes[lane]) == 3 else posemb_q
         pr = self.prof or {}
         q, k = sampler.sample(self.first_id(step), prof=pr.get("sampler"))
         pp = pr.get("posemb")
-        posemb(q, prof=pp) if pp is not None else posemb(q)
-        posemb(k)
+        sk = self.streams_k[lane] if self.cuda else None
+        if sk is not None:                      # view k on its own stream, concurrently with view q
+            cur = torch.cuda.current_stream(self.dev)
+            sampled = torch.cuda.Event()
+            sampled.record(cur)
+            with torch.cuda.stream(sk):
+                sk.wait_event(sampled)
+                posemb_k(k)
+                kdone = torch.cuda.Event()
+                kdone.record(sk)
+            posemb_q(q, prof=pp) if pp is not None else posemb_q(q)
+            cur.wait_event(kdone)
+        else:
+            posemb_q(q, prof=pp) if pp is not None else posemb_q(q)
+            posemb_k(k)
         return q, k
 
     def _launch(self, step):
@@ -167,7 +183,7 @@ class FlatAdam:
 class MoCoTrainStep:
     def __init__(self, model: GraphEncoder, model_ema: GraphEncoder, contrast: MemoryMoCo, sampler, posemb,
                  learning_rate=0.005, betas=(0.9, 0.999), weight_decay=1e-5, clip_norm=1.0, alpha=0.999,
-                 world_size=1, rank=0, prefetch=True, extra_lanes=(), depth=2):
+                 world_size=1, rank=0, prefetch=True, extra_lanes=(), depth=2, lanes=None):
         """``sampler``/``posemb``: producer lane 0; ``extra_lanes``: more (sampler, posemb) pairs with their own
         workspaces for multi-stream prefetch (see :class:`BatchProducer`)."""
         self.model, self.ema, self.contrast = model, model_ema, contrast
@@ -196,7 +212,7 @@ class MoCoTrainStep:
         self.keys_all = torch.empty(self.B * world_size, H, device=self.dev) if world_size > 1 else None
         self.one = torch.ones(1, device=self.dev)
         self.prefetch = prefetch and self.dev.type == "cuda"
-        lanes = [(sampler, posemb)] + list(extra_lanes)
+        lanes = list(lanes) if lanes is not None else [(sampler, posemb)] + list(extra_lanes)
         self.producer = BatchProducer(lanes if self.prefetch else lanes[:1], self._first_id,
                                       self.dev if self.prefetch else "cpu", depth=depth if self.prefetch else 0)
         if not self.prefetch:

@@ -137,3 +137,28 @@ def test_large_subgraphs_krylov_path():
                 col_idx=torch.from_numpy(r["col_idx"].astype(np.int64)))
     x, evals, raw = _run(view)
     _check_krylov(view, x, evals, raw)
+
+
+def test_leafy_large_subgraph_is_solved_exactly_by_deflation():
+    """n = 331 original nodes, but 290 of them are leaves of 3 hubs: the deflated problem has ~45 nodes and
+    goes through the full Jacobi solver, so the STRICT invariants (all multiplicities) must hold."""
+    import scipy.sparse as sp
+
+    rng = np.random.RandomState(0)
+    core = 40
+    edges = [(i, j) for i in range(core) for j in range(i + 1, core) if rng.rand() < 0.15]
+    edges += [(i, i + 1) for i in range(core - 1)]                 # connected
+    nxt = core
+    for hub, t in ((0, 200), (5, 80), (9, 10), (12, 1)):
+        edges += [(hub, nxt + i) for i in range(t)]
+        nxt += t
+    n = nxt
+    e = np.array(edges)
+    a = sp.csr_matrix((np.ones(2 * len(e)), (np.r_[e[:, 0], e[:, 1]], np.r_[e[:, 1], e[:, 0]])), shape=(n, n))
+    a.sum_duplicates()
+    a.data[:] = 1
+    a.sort_indices()
+    view = dict(node_off=torch.tensor([0, n]), row_ptr=torch.from_numpy(a.indptr.astype(np.int64)),
+                col_idx=torch.from_numpy(a.indices.astype(np.int64)))
+    assert n > 128
+    _check(view, *_run(view))
