@@ -162,23 +162,274 @@ struct Defl {
     int32_t *tcnt, *cbase;              // [kNodeMax] leaves per parent | contrast numbering (exclusive prefix of t - 1)
 };
 
-template <int kNMin, int kNMax, int kT>
-__global__ __launch_bounds__(kT) void posemb_jacobi_kernel(PosArgs a)
+// =========================================================================
+// Direct solver for deflated size n' <= 128: Householder tridiagonalisation of the dense LDS matrix
+// (one wave per row, the reflector replicated in registers: 2 barriers per column), multi-section
+// bisection on Sturm counts for the k wanted eigenvalues (kT / 32 probe points per eigenvalue and
+// round), inverse iteration on the tridiagonal matrix with partial pivoting (one thread per
+// eigenvalue; three solve + re-orthogonalise rounds, classical Gram-Schmidt twice inside clusters of
+// eigenvalues closer than 1e-3, the LAPACK stein recipe) and the back-transformation by the stored
+// reflectors (one wave per vector, the vector in registers, no barriers).  ~25x less LDS traffic than
+// the two-sided Jacobi sweeps this replaces, and exact multiplicities are resolved the same way.
+constexpr int kYld = 33;             // row stride of the per-eigenvector arrays Y/Ud/Us ([i][j], j < 32): conflict free
+                                     // both for "lane = vector" (solves) and for "lane = row" (dots, back-transformation)
+constexpr int kMaxVec = 32;          // hidden <= 32 on this path (GCC: positional_embedding_size = 32)
+constexpr float kOrtol = 1e-3f;      // eigenvalues closer than this are re-orthogonalised against each other
+constexpr float kSep = 2e-6f;        // minimum distance between two inverse-iteration shifts
+constexpr float kPivTiny = 1.2e-7f;  // pivots of T - shift are clamped to eps * ||T||  (||T|| <= 1)
+
+struct TriLds {
+    float *A;                        // [kNMax][kNMax + 1]; after the reduction row k holds reflector k right of the diagonal
+    float *dg, *of, *of2, *tau;      // [kNMax] diagonal, off-diagonal, its square, reflector scales
+    float *pbuf, *vbuf;              // [kNMax]
+    float *Y, *Ud, *Us;              // [kNMax][kYld]
+    uint8_t *Uf;                     // [kNMax][32]
+    int *cnt;                        // [32][kT / 32] Sturm counts of one bisection round
+    float *coef;                     // [32][kYld] Gram-Schmidt coefficients; column 32 = squared norm
+};
+
+template <int kNMax, int kT>
+__host__ __device__ constexpr size_t tri_lds_bytes()
 {
+    return sizeof(float) * ((size_t)kNMax * (kNMax + 1) + 6 * kNMax + 3 * (size_t)kNMax * kYld + 32 * kYld)
+           + (size_t)kNMax * 32 + sizeof(int) * kT;
+}
+
+template <int kNMax, int kT>
+__device__ __forceinline__ TriLds tri_carve(unsigned char *smem)
+{
+    TriLds w;
+    w.A = (float *)smem;
+    w.dg = w.A + kNMax * (kNMax + 1);
+    w.of = w.dg + kNMax;
+    w.of2 = w.of + kNMax;
+    w.tau = w.of2 + kNMax;
+    w.pbuf = w.tau + kNMax;
+    w.vbuf = w.pbuf + kNMax;
+    w.Y = w.vbuf + kNMax;
+    w.Ud = w.Y + kNMax * kYld;
+    w.Us = w.Ud + kNMax * kYld;
+    w.coef = w.Us + kNMax * kYld;
+    w.cnt = (int *)(w.coef + 32 * kYld);
+    w.Uf = (uint8_t *)(w.cnt + kT);
+    return w;
+}
+
+// A (n x n, symmetric, both triangles kept) -> T = Q^T A Q; Q = H_0 H_1 ... H_{n-3}, H_k = I - tau_k v_k v_k^T with
+// v_k = (0, ..., 0, 1, A[k][k+2], ..., A[k][n-1]).  All threads call it; ends with a barrier.
+template <int kNMax, int kT>
+__device__ void tridiagonalize(const TriLds &w, int n)
+{
+    constexpr int kCPL = kNMax / 64, lda = kNMax + 1, kNW = kT / 64;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float *A = w.A;
+    for (int k = 0; k + 2 < n; ++k) {
+        // every wave forms reflector k from row k (columns k+1 .. n-1): identical arithmetic, no barrier
+        float v[kCPL];
+        float sig = 0.f;
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) {
+            const int c = lane + 64 * u;
+            v[u] = (c > k && c < n) ? A[k * lda + c] : 0.f;
+            sig += c > k + 1 ? v[u] * v[u] : 0.f;
+        }
+        sig = wave_sum(sig);
+        const float x0 = A[k * lda + k + 1];
+        if (sig <= 1e-30f) {                         // block-uniform: the column is already tridiagonal, H_k = I
+            if (tid == 0) { w.dg[k] = A[k * lda + k]; w.of[k] = x0; w.tau[k] = 0.f; }
+            continue;
+        }
+        const float mu = sqrtf(x0 * x0 + sig);
+        const float beta = x0 > 0.f ? -mu : mu;
+        const float t = (beta - x0) / beta;
+        const float scale = 1.0f / (x0 - beta);
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) {
+            const int c = lane + 64 * u;
+            v[u] = c == k + 1 ? 1.0f : v[u] * scale;
+        }
+        if (wv == 0) {
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) w.vbuf[lane + 64 * u] = v[u];
+        }
+        // p = tau A v on the trailing block
+        for (int i = k + 1 + wv; i < n; i += kNW) {
+            float s = 0.f;
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) {
+                const int c = lane + 64 * u;
+                s += (c > k && c < n) ? A[i * lda + c] * v[u] : 0.f;
+            }
+            s = wave_sum(s);
+            if (lane == 0) w.pbuf[i] = t * s;
+        }
+        __syncthreads();
+        if (wv == 0) {                               // row k is dead now: it stores the reflector
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) {
+                const int c = lane + 64 * u;
+                if (c > k + 1 && c < n) A[k * lda + c] = v[u];
+            }
+            if (lane == 0) { w.dg[k] = A[k * lda + k]; w.of[k] = beta; w.tau[k] = t; }
+        }
+        float pc[kCPL], pv = 0.f;
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) {
+            const int c = lane + 64 * u;
+            pc[u] = (c > k && c < n) ? w.pbuf[c] : 0.f;
+            pv += pc[u] * v[u];
+        }
+        const float K = 0.5f * t * wave_sum(pv);
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) pc[u] -= K * v[u];          // w = p - K v
+        for (int i = k + 1 + wv; i < n; i += kNW) {                 // A -= v w^T + w v^T
+            const float vi = w.vbuf[i], wi = w.pbuf[i] - K * vi;
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) {
+                const int c = lane + 64 * u;
+                if (c > k && c < n) A[i * lda + c] -= vi * pc[u] + wi * v[u];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (n >= 2) { w.dg[n - 2] = A[(n - 2) * lda + n - 2]; w.of[n - 2] = A[(n - 2) * lda + n - 1]; }
+        w.dg[n - 1] = A[(n - 1) * lda + n - 1];
+        w.of[n - 1] = 0.f;
+    }
+    __syncthreads();
+}
+
+// number of eigenvalues of T below x (Sturm sequence of the LDL^T pivots, as LAPACK's dlaebz)
+__device__ __forceinline__ int sturm_count(const float *dg, const float *of2, int n, float x)
+{
+    float q = dg[0] - x;
+    if (fabsf(q) < 1e-30f) q = -1e-30f;
+    int c = q < 0.f ? 1 : 0;
+    for (int i = 1; i < n; ++i) {
+        q = dg[i] - x - of2[i - 1] / q;
+        if (fabsf(q) < 1e-30f) q = -1e-30f;
+        c += q < 0.f ? 1 : 0;
+    }
+    return c;
+}
+
+__device__ __forceinline__ float hash_unit(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x165667B1u) * 0xC2B2AE3Du;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return (float)(h >> 8) * (2.0f / 16777216.0f) - 1.0f;
+}
+
+// one inverse-iteration step for eigenvector j (called by ONE thread): solve (T - shift) x = y in place in
+// column j of Y, by Gaussian elimination with partial pivoting fused with the right-hand side; x is normalised.
+// Returns false if the solution is not finite.
+__device__ bool inverse_iteration_step(const TriLds &w, int n, int j, float shift, bool random_rhs, uint32_t hseed)
+{
+    float *Y = w.Y + j, *Ud = w.Ud + j, *Us = w.Us + j;
+    uint8_t *Uf = w.Uf + j;
+    float cd = w.dg[0] - shift, cs = n > 1 ? w.of[0] : 0.f;
+    float cy = random_rhs ? hash_unit(hseed, (uint32_t)j, 0u) : Y[0];
+    for (int i = 0; i + 1 < n; ++i) {
+        const float sub = w.of[i], nd = w.dg[i + 1] - shift, ns = i + 2 < n ? w.of[i + 1] : 0.f;
+        const float by = random_rhs ? hash_unit(hseed, (uint32_t)j, (uint32_t)(i + 1)) : Y[(i + 1) * kYld];
+        if (fabsf(cd) >= fabsf(sub)) {
+            const float mult = cd != 0.f ? sub / cd : 0.f;
+            Ud[i * kYld] = cd; Us[i * kYld] = cs; Uf[i * 32] = 0; Y[i * kYld] = cy;
+            cd = nd - mult * cs; cs = ns; cy = by - mult * cy;
+        } else {
+            const float mult = cd / sub;
+            Ud[i * kYld] = sub; Us[i * kYld] = nd; Uf[i * 32] = 1; Y[i * kYld] = by;
+            cd = cs - mult * nd; cs = -mult * ns; cy = cy - mult * by;
+        }
+    }
+    Ud[(n - 1) * kYld] = cd; Us[(n - 1) * kYld] = 0.f; Uf[(n - 1) * 32] = 0; Y[(n - 1) * kYld] = cy;
+    float x1 = 0.f, x2 = 0.f, ss = 0.f;
+    for (int i = n - 1; i >= 0; --i) {
+        float d = Ud[i * kYld];
+        if (fabsf(d) < kPivTiny) d = d < 0.f ? -kPivTiny : kPivTiny;
+        const float s2 = (Uf[i * 32] && i + 2 < n) ? w.of[i + 1] : 0.f;
+        const float x = (Y[i * kYld] - Us[i * kYld] * x1 - s2 * x2) / d;
+        Y[i * kYld] = x;
+        x2 = x1; x1 = x;
+        ss = fmaf(x, x, ss);
+    }
+    const bool ok = ss > 0.f && ss < 3.0e38f;
+    const float inv = ok ? 1.0f / sqrtf(ss) : 0.f;
+    for (int i = 0; i < n; ++i) Y[i * kYld] *= inv;
+    return ok;
+}
+
+// classical Gram-Schmidt (twice) + normalisation inside every cluster; the t-th members of all clusters are
+// processed together.  Returns (block-uniform) the number of vectors that vanished (were in the span of
+// their predecessors).  All threads call it; ends with a barrier.
+template <int kNMax, int kT>
+__device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int *cs, const int *posi, int maxpos)
+{
+    constexpr int kNW = kT / 64, kJG = kT / kNMax;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = tid & (kNMax - 1), jg = tid / kNMax;
+    float *Y = w.Y, *coef = w.coef;
+    int lost = 0;
+    for (int t = 1; t <= maxpos; ++t) {
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int j = 0; j < na; ++j) {
+                if (posi[j] != t) continue;
+                for (int l = cs[j] + wv; l < j; l += kNW) {
+                    float s = 0.f;
+                    for (int r = lane; r < n; r += 64) s = fmaf(Y[r * kYld + j], Y[r * kYld + l], s);
+                    s = wave_sum(s);
+                    if (lane == 0) coef[j * kYld + l] = s;
+                }
+            }
+            __syncthreads();
+            if (i < n) {
+                for (int j = jg; j < na; j += kJG) {
+                    if (posi[j] != t) continue;
+                    float acc = 0.f;
+                    for (int l = cs[j]; l < j; ++l) acc = fmaf(coef[j * kYld + l], Y[i * kYld + l], acc);
+                    Y[i * kYld + j] -= acc;
+                }
+            }
+            __syncthreads();
+        }
+        for (int j = wv; j < na; j += kNW) {
+            if (posi[j] != t) continue;
+            float s = 0.f;
+            for (int r = lane; r < n; r += 64) s = fmaf(Y[r * kYld + j], Y[r * kYld + j], s);
+            s = wave_sum(s);
+            if (lane == 0) coef[j * kYld + 32] = s;
+        }
+        __syncthreads();
+        for (int j = 0; j < na; ++j)
+            if (posi[j] == t && coef[j * kYld + 32] < 1e-6f) ++lost;
+        if (i < n) {
+            for (int j = jg; j < na; j += kJG) {
+                if (posi[j] != t) continue;
+                Y[i * kYld + j] *= 1.0f / sqrtf(fmaxf(coef[j * kYld + 32], 1e-30f));
+            }
+        }
+        __syncthreads();
+    }
+    return lost;
+}
+
+template <int kNMin, int kNMax, int kT>
+__global__ __launch_bounds__(kT) void posemb_direct_kernel(PosArgs a)
+{
+    static_assert(kNMax % 64 == 0 && (kNMax & (kNMax - 1)) == 0 && kT % kNMax == 0, "size class");
     DYN_SMEM(smem);
-    __shared__ float rot[kJMax];
-    __shared__ int pq[kJMax];
-    __shared__ float lam[kJMax];
-    __shared__ int colE[kJMax];                 // output column of eigenpair i' of M' (or -1)
-    __shared__ int colsrc[64];                  // per output column: i' >= 0, or -(c + 1) for contrast c
-    __shared__ int flag, sh_np, sh_z, sh_npos, sh_nzer;
-    __shared__ float red[kT];
-    const int tid = (int)threadIdx.x, lane = tid & 63;
+    __shared__ float lamv[kMaxVec], shiftv[kMaxVec], lo[kMaxVec], hi[kMaxVec];
+    __shared__ int cs[kMaxVec], posi[kMaxVec];
+    __shared__ int colsrc[64];                  // per output column: eigenvector j >= 0, or -(c + 1) for contrast c
+    __shared__ int sh_np, sh_z, sh_na, sh_maxpos, sh_bad;
+    constexpr int kNW = kT / 64, kCPL = kNMax / 64, lda = kNMax + 1, kP = kT / 32;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = (int)blockIdx.x;
     if (b >= a.B) return;
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
     if (n > kNodeMax) return;                      // Krylov kernel
-    const int k = min(n - 2, a.hidden);            // data_util.py:278
+    const int k = min(min(n - 2, a.hidden), kMaxVec);   // data_util.py:278
     if (k <= 0) {                                  // data_util.py:243-244: zeros
         if (kNMin == 0) {
             for (int i = tid; i < n * a.hidden; i += kT) a.pos[(int64_t)n0 * a.hidden + i] = 0.f;
@@ -186,10 +437,10 @@ __global__ __launch_bounds__(kT) void posemb_jacobi_kernel(PosArgs a)
         }
         return;
     }
-    constexpr int kNpMax = (kNMax + 1) & ~1;
-    float *A = (float *)smem, *V = A + kNpMax * (kNpMax + 1);
+    const TriLds w = tri_carve<kNMax, kT>(smem);
+    float *A = w.A;
     Defl d;
-    d.tcnt = (int32_t *)(V + kNpMax * (kNpMax + 1));
+    d.tcnt = (int32_t *)(smem + tri_lds_bytes<kNMax, kT>());
     d.cbase = d.tcnt + kNodeMax;
     d.par = (uint16_t *)(d.cbase + kNodeMax);
     d.rep = d.par + kNodeMax;
@@ -232,16 +483,15 @@ __global__ __launch_bounds__(kT) void posemb_jacobi_kernel(PosArgs a)
         }
         sh_np = r;
         sh_z = c;
+        sh_bad = 0;
     }
     __syncthreads();
     const int nr = sh_np, z = sh_z;                // reduced size n', number of contrast null vectors
     if (nr > kNMax || nr < kNMin) return;          // other size class / Krylov kernel
-    const int np = (nr + 1) & ~1, lda = np + 1;
-    for (int i = tid; i < np * lda; i += kT) { A[i] = 0.f; V[i] = 0.f; }
+    for (int i = tid; i < nr * lda; i += kT) A[i] = 0.f;
     __syncthreads();
-    if (tid < np) V[tid * lda + tid] = 1.f;
     // M' = norm * adj * norm on the kept nodes (data_util.py:273-277), super-leaf couplings scaled by sqrt(t)
-    for (int i = tid >> 6; i < n; i += kT >> 6) {
+    for (int i = wv; i < n; i += kNW) {
         if (d.ridx[i] == kNone) continue;          // wave-uniform
         const int ri = d.ridx[i];
         const int di = rp[i + 1] - rp[i];
@@ -256,62 +506,111 @@ __global__ __launch_bounds__(kT) void posemb_jacobi_kernel(PosArgs a)
         }
     }
     __syncthreads();
-    float ss = 0.f;                                // ||M'||_F for the rotation threshold
-    for (int i = tid; i < np * lda; i += kT) ss += A[i] * A[i];
-    red[tid] = ss;
+
+    tridiagonalize<kNMax, kT>(w, nr);
+    if (tid < nr) w.of2[tid] = w.of[tid] * w.of[tid];
+    // ---- the kq largest eigenvalues of T: eigenvalue j (descending) has ascending index nr - 1 - j and lies in
+    //      [lo, hi] with count(lo) <= nr - 1 - j < count(hi); every round probes kP interior points
+    const int kq = min(k, nr);
+    if (tid < kMaxVec) { lo[tid] = -1.001f; hi[tid] = 1.001f; }   // spectrum of a normalised adjacency matrix
     __syncthreads();
-    for (int dd = kT >> 1; dd > 0; dd >>= 1) {
-        if (tid < dd) red[tid] += red[tid + dd];
-        __syncthreads();
+    {
+        const int j = tid / kP, ip = tid - j * kP;
+        constexpr int kRounds = kP >= 32 ? 6 : 9;                  // 2.002 / (kP + 1)^rounds < 1e-8
+        for (int round = 0; round < kRounds; ++round) {
+            const float xlo = lo[j], xhi = hi[j];
+            const float step = (xhi - xlo) * (1.0f / (float)(kP + 1));
+            const float x = xlo + step * (float)(ip + 1);
+            const int c = j < kq ? sturm_count(w.dg, w.of2, nr, x) : 0;
+            w.cnt[tid] = c;
+            __syncthreads();
+            if (j < kq) {
+                const int tgt = nr - 1 - j;
+                const bool above = c > tgt;
+                const bool prev_above = ip > 0 && w.cnt[tid - 1] > tgt;
+                if (above && !prev_above) {
+                    hi[j] = x;
+                    if (ip > 0) lo[j] = xlo + step * (float)ip;
+                }
+                if (ip == kP - 1 && !above) lo[j] = x;
+            }
+            __syncthreads();
+        }
     }
-    const float tol = 1e-7f * sqrtf(red[0]) + 1e-30f;
-    __syncthreads();
-    jacobi_lds(A, V, np, lda, rot, pq, &flag, tol);
-    __syncthreads();
-    // ---- rank the n' eigenvalues of M' together with the z contrast zeros:
-    //      positive, then null space (M' zeros, then contrasts), then negative; eigsh(which="LA") returns the
-    //      k largest in ascending order (data_util.py:251)
-    if (tid < nr) lam[tid] = A[tid * lda + tid];
+    // ---- ranks (positive, null space = zeros of M' then the z contrasts, negative; eigsh(which="LA") returns the k
+    //      largest in ascending order, data_util.py:251), inverse-iteration shifts and clusters
     if (tid < 64) colsrc[tid] = 0;
     __syncthreads();
     if (tid == 0) {
-        int npos = 0, nzer = 0;
-        for (int i = 0; i < nr; ++i) { npos += lam[i] > kZeroEig; nzer += fabsf(lam[i]) <= kZeroEig; }
-        sh_npos = npos;
-        sh_nzer = nzer;
-    }
-    __syncthreads();
-    const int npos = sh_npos, nzer = sh_nzer;
-    if (tid < nr) {
-        const float li = lam[tid];
-        int r = 0;
-        if (li > kZeroEig) {
-            for (int j = 0; j < nr; ++j) r += (lam[j] > li || (lam[j] == li && j < tid)) ? 1 : 0;
-        } else if (fabsf(li) <= kZeroEig) {
-            r = npos;
-            for (int j = 0; j < tid; ++j) r += fabsf(lam[j]) <= kZeroEig ? 1 : 0;
-        } else {
-            r = npos + nzer + z;
-            for (int j = 0; j < nr; ++j)
-                r += (lam[j] < -kZeroEig && (lam[j] > li || (lam[j] == li && j < tid))) ? 1 : 0;
+        int na = 0, npz = 0, maxpos = 0;
+        for (int j = 0; j < kq; ++j) {
+            float l = 0.5f * (lo[j] + hi[j]);
+            if (j > 0 && l > lamv[j - 1]) l = lamv[j - 1];
+            lamv[j] = l;
+            shiftv[j] = (j > 0 && shiftv[j - 1] - l < kSep) ? shiftv[j - 1] - kSep : l;
+            cs[j] = (j > 0 && lamv[j - 1] - l <= kOrtol) ? cs[j - 1] : j;
+            posi[j] = j - cs[j];
+            const int r = l < -kZeroEig ? j + z : j;
+            if (l >= -kZeroEig) npz = j + 1;
+            if (r < k) {
+                na = j + 1;
+                maxpos = posi[j] > maxpos ? posi[j] : maxpos;
+                colsrc[k - 1 - r] = j;
+                if (a.evals) a.evals[(int64_t)b * a.hidden + (k - 1 - r)] = fabsf(l) <= kZeroEig ? 0.f : l;
+            }
         }
-        colE[tid] = r < k ? k - 1 - r : -1;
-        if (r < k) {
-            colsrc[k - 1 - r] = tid;
-            if (a.evals) a.evals[(int64_t)b * a.hidden + (k - 1 - r)] = fabsf(li) <= kZeroEig ? 0.f : li;
+        for (int c = 0; c < z && npz + c < k; ++c) {              // contrast c has rank npz + c
+            colsrc[k - 1 - (npz + c)] = -(c + 1);
+            if (a.evals) a.evals[(int64_t)b * a.hidden + (k - 1 - (npz + c))] = 0.f;
         }
-    }
-    for (int c = tid; c < z; c += kT) {            // contrast c has rank npos + nzer + c
-        const int r = npos + nzer + c;
-        if (r < k) {
-            colsrc[k - 1 - r] = -(c + 1);
-            if (a.evals) a.evals[(int64_t)b * a.hidden + (k - 1 - r)] = 0.f;
-        }
+        sh_na = na;
+        sh_maxpos = maxpos;
     }
     if (a.evals) for (int i = k + tid; i < a.hidden; i += kT) a.evals[(int64_t)b * a.hidden + i] = 0.f;
     __syncthreads();
+    const int na = sh_na, maxpos = sh_maxpos;
+    // ---- eigenvectors of T
+    int lost = 0;
+    for (int it = 0; it < 3; ++it) {
+        if (tid < na) {
+            const bool ok = inverse_iteration_step(w, nr, tid, shiftv[tid], it == 0, (uint32_t)a.seed ^ (uint32_t)(b * 0x9E3779B1u));
+            if (!ok) sh_bad = 1;
+        }
+        __syncthreads();
+        lost = cluster_orthonormalize<kNMax, kT>(w, nr, na, cs, posi, maxpos);
+    }
+    if (tid == 0 && (lost > 0 || sh_bad)) atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
+    // ---- eigenvectors of M': x = H_0 ... H_{nr-3} y, one wave per vector, the vector in registers
+    for (int j = wv; j < na; j += kNW) {
+        float y[kCPL];
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) {
+            const int c = lane + 64 * u;
+            y[u] = c < nr ? w.Y[c * kYld + j] : 0.f;
+        }
+        for (int kk = nr - 3; kk >= 0; --kk) {
+            const float t = w.tau[kk];
+            if (t == 0.f) continue;
+            float v[kCPL], s = 0.f;
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) {
+                const int c = lane + 64 * u;
+                v[u] = c == kk + 1 ? 1.0f : ((c > kk + 1 && c < nr) ? A[kk * lda + c] : 0.f);
+                s += v[u] * y[u];
+            }
+            s = t * wave_sum(s);
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) y[u] -= s * v[u];
+        }
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) {
+            const int c = lane + 64 * u;
+            if (c < nr) w.Y[c * kYld + j] = y[u];
+        }
+    }
+    __syncthreads();
     // ---- expand to the n original nodes; x = normalize(u, "l2") row-wise, zero padded (data_util.py:260-262)
-    for (int v = tid >> 6; v < n; v += kT >> 6) {
+    for (int v = wv; v < n; v += kNW) {
         const int pv = d.par[v];
         const bool grouped = pv != kNone && d.tcnt[pv] >= 2;
         const int rsrc = grouped ? d.ridx[d.rep[pv]] : d.ridx[v];
@@ -320,7 +619,7 @@ __global__ __launch_bounds__(kT) void posemb_jacobi_kernel(PosArgs a)
         if (lane < k) {
             const int src = colsrc[lane];
             if (src >= 0) {
-                val = V[rsrc * lda + src] * scale;
+                val = w.Y[rsrc * kYld + src] * scale;
             } else if (grouped) {
                 const int jm1 = -src - 1 - d.cbase[pv];          // contrast j = jm1 + 1 of parent pv
                 if (jm1 >= 0 && jm1 < d.tcnt[pv] - 1) {
@@ -654,20 +953,26 @@ int32_t gcc_posemb(const gcc_batch_out *g, int32_t batch_size, int32_t hidden, f
     }
     PosArgs a = {g->node_off, g->row_ptr, g->col_idx, pos, evals, raw, batch_size, hidden, seed, status, nullptr, nullptr};
     hipStream_t s = (hipStream_t)stream;
+    if (hidden > kMaxVec) {
+        snprintf(g_err, kErrLen, "gcc_posemb: hidden %d > %d", hidden, kMaxVec);
+        return -1;
+    }
     const size_t lds_tab = (size_t)kNodeMax * (2 * sizeof(int32_t) + 4 * sizeof(uint16_t));
-    const size_t lds_small = (size_t)2 * kJSmall * (kJSmall + 1) * sizeof(float) + lds_tab;
-    const size_t lds_big = (size_t)2 * kJMax * (kJMax + 1) * sizeof(float) + lds_tab;
+    const size_t lds_small = tri_lds_bytes<kJSmall, 256>() + lds_tab;
+    const size_t lds_big = tri_lds_bytes<kJMax, 1024>() + lds_tab;
 #ifndef GCC_AMD_HIPEMU
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)posemb_jacobi_kernel<kJSmall + 1, kJMax, 1024>,
+        (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<0, kJSmall, 256>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
+        (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kJSmall + 1, kJMax, 1024>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
         attr_set = true;
     }
 #endif
     prof_mark(prof, 0, s);
-    hipLaunchKernelGGL((posemb_jacobi_kernel<0, kJSmall, 256>), dim3(batch_size), dim3(256), lds_small, s, a);
-    hipLaunchKernelGGL((posemb_jacobi_kernel<kJSmall + 1, kJMax, 1024>), dim3(batch_size), dim3(1024), lds_big, s, a);
+    hipLaunchKernelGGL((posemb_direct_kernel<0, kJSmall, 256>), dim3(batch_size), dim3(256), lds_small, s, a);
+    hipLaunchKernelGGL((posemb_direct_kernel<kJSmall + 1, kJMax, 1024>), dim3(batch_size), dim3(1024), lds_big, s, a);
     KryArgs ka;
     ka.p = a;
     ka.vws = (float *)workspace;

@@ -212,6 +212,11 @@ class MoCoTrainStep:
         self.keys_all = torch.empty(self.B * world_size, H, device=self.dev) if world_size > 1 else None
         self.one = torch.ones(1, device=self.dev)
         self.prefetch = prefetch and self.dev.type == "cuda"
+        # the ~75 short training kernels of a step must not queue behind the producers' millisecond-long
+        # eigensolver workgroups: the step runs on a high-priority stream
+        # (CU-masked streams were tried to partition the chip instead: with ~25 masked streams the queues get
+        # time-sliced and a step takes 5x longer)
+        self.main = torch.cuda.Stream(self.dev, priority=-1) if self.prefetch else None
         lanes = list(lanes) if lanes is not None else [(sampler, posemb)] + list(extra_lanes)
         self.producer = BatchProducer(lanes if self.prefetch else lanes[:1], self._first_id,
                                       self.dev if self.prefetch else "cpu", depth=depth if self.prefetch else 0)
@@ -229,6 +234,16 @@ class MoCoTrainStep:
     # ---- one step
     def step(self, step, lr, prof=None):
         """``prof``: optional dict of gcc_amd.prof.Prof (sampler: 4 marks; gin_fwd/nce_fwd/nce_bwd/gin_bwd: 2)."""
+        if self.main is None:
+            return self._step(step, lr, prof)
+        caller = torch.cuda.current_stream(self.dev)
+        self.main.wait_stream(caller)
+        with torch.cuda.stream(self.main):
+            out = self._step(step, lr, prof)
+        caller.wait_stream(self.main)
+        return out
+
+    def _step(self, step, lr, prof=None):
         pr = prof or {}
         q, k = self.producer.get(step, prof=prof)
         st = torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else None

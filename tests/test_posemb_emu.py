@@ -162,3 +162,27 @@ def test_leafy_large_subgraph_is_solved_exactly_by_deflation():
                 col_idx=torch.from_numpy(a.indices.astype(np.int64)))
     assert n > 128
     _check(view, *_run(view))
+
+
+def test_both_size_classes_of_the_direct_solver():
+    """Deflated sizes on both sides of 64 (256-thread and 1024-thread instantiations of posemb_direct_kernel)."""
+    view = _sampled_views(rw_hops=160, B=10, run_seed=11)
+    no = view["node_off"].numpy()
+    rp, ci = view["row_ptr"].numpy(), view["col_idx"].numpy()
+    reduced = []
+    for b in range(len(no) - 1):
+        lo, hi = no[b], no[b + 1]
+        deg = np.diff(rp[lo:hi + 1])
+        leaves = np.where(deg == 1)[0]
+        par = ci[rp[lo + leaves]]
+        cnt = np.bincount(par - lo, minlength=hi - lo)
+        reduced.append((hi - lo) - int(np.maximum(cnt - 1, 0).sum()))
+    reduced = np.array(reduced)
+    assert (reduced <= 64).any() and ((reduced > 64) & (reduced <= 128)).any(), reduced
+    keep = np.where(reduced <= 128)[0]
+    x, evals, raw = _run(view)
+    for b in keep:
+        lo, hi = no[b], no[b + 1]
+        sub = dict(node_off=torch.tensor([0, hi - lo]), row_ptr=view["row_ptr"][lo:hi + 1] - view["row_ptr"][lo],
+                   col_idx=view["col_idx"][view["row_ptr"][lo]:view["row_ptr"][hi]] - lo)
+        _check(sub, x[lo:hi], evals[b:b + 1], raw[lo:hi])
