@@ -26,7 +26,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # producer lanes run on their own HIP streams
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")      # the command processor serves few queues well (tools/contention_probe.py)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -50,7 +50,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--posemb", choices=["device", "placeholder"], default="device")
-    ap.add_argument("--lanes", type=int, default=12, help="producer streams (sampler + positional embedding)")
+    ap.add_argument("--lanes", type=int, default=3, help="producer streams (sampler + positional embedding)")
+    ap.add_argument("--chunk", type=int, default=8, help="steps a producer lane prepares per turn (one multi-view eigensolver call)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight per producer lane")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the roofline kernel from a separate rocprofv3 --pmc pass "
@@ -207,7 +208,7 @@ def main():
     graph = DeviceGraph(rp, ci, rw_hops=args.rw_hops, restart_prob=args.restart_prob, device=dev, validate=False)
     B = args.batch_size
     torch.manual_seed(0)
-    nbuf = args.depth + 1
+    nbuf = args.depth * args.chunk
     samplers = [DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=nbuf) for _ in range(args.lanes)]
     sampler = samplers[0]
     enc_kw = dict(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
@@ -218,15 +219,15 @@ def main():
     model_ema.load_state_dict(model.state_dict())                     # moment_update(model, model_ema, 0), train.py:624
     contrast = MemoryMoCo(64, None, args.nce_k, 0.07, use_softmax=True).to(dev)
     if args.posemb == "device":
-        posembs = [DevicePosEmb(B, sampler.node_cap, 32, device=dev, seed=args.run_seed, num_buffers=nbuf)
-                   for _ in range(2 * args.lanes)]
+        posembs = [DevicePosEmb(B, sampler.node_cap, 32, device=dev, seed=args.run_seed, num_buffers=nbuf,
+                                max_views=min(2 * args.chunk, 32)) for _ in range(args.lanes)]
     else:
-        posembs = [PlaceholderPosEmb(sampler.node_cap, 32, device=dev)] * (2 * args.lanes)
+        posembs = [PlaceholderPosEmb(sampler.node_cap, 32, device=dev)] * args.lanes
     posemb = posembs[0]
-    # every producer lane: one sampler + one eigensolver workspace per view (the two views run on two streams)
-    lanes = [(samplers[i], posembs[2 * i], posembs[2 * i + 1]) for i in range(args.lanes)]
+    # every producer lane: one sampler + one eigensolver workspace, `chunk` steps (2 * chunk views) per turn
+    lanes = [(samplers[i], posembs[i]) for i in range(args.lanes)]
     trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank,
-                            lanes=lanes, depth=args.depth)
+                            lanes=lanes, depth=args.depth, chunk=args.chunk)
     stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder q+k fwd",
               "moco-infonce fwd", "key all-gather" if world > 1 else "enqueue", "infonce bwd", "gin-encoder bwd",
               "grad all-reduce" if world > 1 else "clip", "adam", "ema"]
@@ -274,13 +275,16 @@ def main():
     if rank == 0:
         # live per-kernel durations (HIP events recorded on the launch stream inside the timed region)
         # (the sampler marks of timed step i belong to the batch prefetched for step i + 1)
-        k_ms = np.array([[p["sampler"].elapsed_ms(j, j + 1) for j in range(3)] for p in profs])
-        kern = dict(rwr_walk_kernel=float(k_ms[:, 0].mean()), induce_kernel=float(k_ms[:, 1].mean()),
-                    pack_kernel=float(k_ms[:, 2].mean()))
+        # (producer marks exist only for the steps whose get() launched a chunk: the first sampler call and the
+        # multi-view eigensolver call of that chunk)
+        used = [p for p in profs if p.get("used")]
         stage_ms = {n: float(np.mean([p[n].elapsed_ms(0, 1) for p in profs])) for n in names}
-        stage_ms["sampler"] = float(k_ms.sum(axis=1).mean())
-        if args.posemb == "device":
-            stage_ms["posemb_one_view"] = float(np.mean([p["posemb"].elapsed_ms(0, 1) for p in profs]))
+        if used:
+            k_ms = np.array([[p["sampler"].elapsed_ms(j, j + 1) for j in range(3)] for p in used])
+            stage_ms["sampler"] = float(k_ms.sum(axis=1).mean())
+            if args.posemb == "device":
+                stage_ms["posemb_chunk_of_%d_views" % min(2 * args.chunk, 32)] = float(
+                    np.mean([p["posemb"].elapsed_ms(0, 1) for p in used]))
         # algorithmic bytes of the timed steps (recomputed post hoc: sampling is deterministic)
         from oracle import sampler as O   # checker side only: L table for the byte count
         lt = O.max_nodes_table(int(np.diff(rp).max()), args.rw_hops, args.restart_prob)
@@ -318,8 +322,8 @@ def main():
                        "graph_nodes": int(len(rp) - 1), "graph_edges": int(len(ci)),
                        "batch_size_per_gpu": B, "global_batch": B * world, "nce_k": args.nce_k,
                        "rw_hops": args.rw_hops, "restart_prob": args.restart_prob,
-                       "stages": stages, "producer_lanes": args.lanes, "producer_depth": args.depth, "parallelism": f"dp{world} (seed batch sharded, graph replicated)"},
-            "kernel_ms": kern, "kernel_ms_isolated": kern_iso, "stage_ms": stage_ms, "final_loss": final_loss, "posemb_status": posemb_status,
+                       "stages": stages, "producer_lanes": args.lanes, "producer_depth": args.depth, "producer_chunk": args.chunk, "parallelism": f"dp{world} (seed batch sharded, graph replicated)"},
+            "kernel_ms_isolated": kern_iso, "stage_ms": stage_ms, "final_loss": final_loss, "posemb_status": posemb_status,
             "roofline": {"bound": "hbm", "kernel": dom, "measured": "isolated probe loop after the timed region",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

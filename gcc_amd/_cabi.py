@@ -47,6 +47,10 @@ class GccSampleParams(ctypes.Structure):
     ]
 
 
+class GccPosembView(ctypes.Structure):
+    _fields_ = [("g", ctypes.c_void_p), ("pos", ctypes.c_void_p), ("evals", ctypes.c_void_p), ("raw", ctypes.c_void_p)]
+
+
 class GccBatchOut(ctypes.Structure):
     _fields_ = [
         ("node_off", ctypes.c_void_p),
@@ -131,6 +135,10 @@ SIGNATURES = {
         ctypes.POINTER(GccBatchOut), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
         ctypes.c_void_p]),
     "gcc_posemb_workspace_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32]),
+    "gcc_posemb_multi_workspace_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32]),
+    "gcc_posemb_multi": (ctypes.c_int32, [ctypes.POINTER(GccPosembView), ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                          ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_posemb": (ctypes.c_int32, [ctypes.POINTER(GccBatchOut), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p]),

@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #ifdef GCC_AMD_HIPEMU
+#define TRAIN_STEP_WAVE_PRIORITY() ((void)0)
 #include "hipemu.h"
 
 #define DYN_SMEM(name) unsigned char *name = hipemu::g_dyn_smem
@@ -65,6 +66,10 @@ static inline f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c)
 
 #else  // ------------------------------------------------------------ gfx950
 #include <hip/hip_runtime.h>
+
+// Waves of the training step share SIMDs with the data pipeline's long-running eigensolver waves; the
+// step's kernels are short and on the critical path, so their waves take the issue slots first.
+#define TRAIN_STEP_WAVE_PRIORITY() __builtin_amdgcn_s_setprio(3)
 
 #define DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -42,6 +42,7 @@ struct FeatLaunch { FeatArgs p[kMaxPass]; };
 
 __global__ __launch_bounds__(kThreads) void gin_feat_kernel(FeatLaunch L)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
     const FeatArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
@@ -92,6 +93,7 @@ struct InLaunch { InArgs p[kMaxPass]; };
 
 __global__ __launch_bounds__(kThreads) void gin_in_kernel(InLaunch L)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
     __shared__ float part[16 * H];
     __shared__ float red[4 * 2 * H];
@@ -168,6 +170,7 @@ struct MidLaunch { MidArgs p[kMaxPass]; };
 
 __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float red[4 * 2 * H];
     const MidArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
@@ -214,6 +217,7 @@ struct StatLaunch { StatArgs p[kMaxPass]; };
 
 __global__ __launch_bounds__(kThreads) void gin_stat_kernel(StatLaunch L)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float part[16 * 2 * H];
     const StatArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
@@ -258,6 +262,7 @@ struct PoolLaunch { PoolArgs p[kMaxPass]; };
 
 __global__ __launch_bounds__(kThreads) void gin_pool_kernel(PoolLaunch L)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
     const PoolArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
@@ -296,6 +301,7 @@ struct ReadLaunch { ReadArgs p[kMaxPass]; };
 
 __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     const ReadArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
     const int b = ((int)blockIdx.x * 4 + wv) * 16 + j;

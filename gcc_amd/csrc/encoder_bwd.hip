@@ -118,6 +118,7 @@ struct ReadBwdArgs {
 
 __global__ __launch_bounds__(kThreads) void gin_bwd_readout_kernel(ReadBwdArgs a)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     const int lane = lane_id(), wv = (int)threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
     const int b = ((int)blockIdx.x * 4 + wv) * 16 + j;
     const bool valid = b < a.B;
@@ -193,6 +194,7 @@ struct BwdCArgs {
 
 __global__ __launch_bounds__(kThreads) void gin_bwd_c_kernel(BwdCArgs a)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
     __shared__ float part[16 * 2 * H];
     __shared__ float Cb[kCoefRows * H], Cc[kCoefRows * H];
@@ -250,6 +252,7 @@ struct BwdBArgs {
 
 __global__ __launch_bounds__(kThreads) void gin_bwd_b_kernel(BwdBArgs a)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float part[16 * 2 * H];
     __shared__ float Cb[kCoefRows * H], Cc[kCoefRows * H];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
@@ -303,6 +306,7 @@ struct BwdLinArgs {
 template <bool kMask>
 __global__ __launch_bounds__(kThreads) void gin_bwd_lin_kernel(BwdLinArgs a)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float Ci[kCoefRows * H], Co[kCoefRows * H];
     __shared__ float red[4 * 3 * H];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
@@ -379,6 +383,7 @@ struct EmbArgs {
 
 __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
     __shared__ float part[16 * H];
     __shared__ float E[kEmbMaxElems];
@@ -435,6 +440,7 @@ struct WgradArgs {
 
 __global__ __launch_bounds__(kThreads) void gin_wgrad_kernel(WgradArgs a)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float S[H * H];
     __shared__ float Cx[2 * H];
     const WgradJob &jb = a.job[blockIdx.y];
@@ -526,6 +532,7 @@ __device__ __forceinline__ void put(float *dst, float v, int acc)
 
 __global__ __launch_bounds__(kThreads) void gin_grad_final_kernel(FinalArgs a)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     const int64_t gid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const int L = a.L;
     int64_t base = 0;

@@ -84,6 +84,7 @@ __device__ __forceinline__ F4 load_mem4(const NceDev &a, int r, int c4)
 template <bool kBwd>
 __global__ __launch_bounds__(kThreads) void nce_slice_kernel(NceDev a)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float Ms[kChunk * kLd];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
     const int s = (int)blockIdx.x;
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(kThreads) void nce_slice_kernel(NceDev a)
 
 __global__ __launch_bounds__(kThreads) void nce_combine_kernel(NceDev a)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     // one block; each wave walks over queries, lanes over the 64 feature dims / the slices
     __shared__ double red[8];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6;
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(kThreads) void nce_combine_kernel(NceDev a)
 
 __global__ __launch_bounds__(kThreads) void nce_dq_kernel(NceDev a)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     const int gid = (int)blockIdx.x * kThreads + (int)threadIdx.x;
     const int b = gid >> 4, c4 = (gid & 15) * 4;
     if (b >= a.B) return;
@@ -250,6 +253,7 @@ __global__ __launch_bounds__(kThreads) void nce_dq_kernel(NceDev a)
 __global__ __launch_bounds__(kThreads) void queue_enqueue_kernel(float *mem, int K, const float *keys, int nkeys,
                                                                  int index, float *saved)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     const int gid = (int)blockIdx.x * kThreads + (int)threadIdx.x;
     const int i = gid >> 4, c4 = (gid & 15) * 4;
     if (i >= nkeys) return;
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(kThreads) void queue_enqueue_kernel(float *mem, int
 
 __global__ __launch_bounds__(kThreads) void ema_kernel(float *ema, const float *p, int64_t n, float m)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     const int64_t stride = (int64_t)gridDim.x * kThreads;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride)
         ema[i] = ema[i] * m + (1.f - m) * p[i];               // p2.mul_(m).add_(1 - m, p1)
@@ -268,6 +273,7 @@ __global__ __launch_bounds__(kThreads) void ema_kernel(float *ema, const float *
 // ---- clip_grad_norm_ + Adam over one flat buffer (train.py:409,417)
 __global__ __launch_bounds__(1024) void gradnorm_kernel(const float *g, int64_t n, double *out)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     __shared__ double red[16];
     double s = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)g[i] * (double)g[i];
@@ -286,6 +292,7 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(float *p, float *g, floa
                                                         float bc2_sqrt, float max_norm, const double *sumsq,
                                                         float *grad_norm)
 {
+    TRAIN_STEP_WAVE_PRIORITY();
     const float norm = (float)sqrt(sumsq[0]);
     float coef = 1.f;
     if (max_norm > 0.f) {                                      // torch.nn.utils.clip_grad_norm_

@@ -24,6 +24,18 @@ constexpr int kMaxSweeps = 14;
 constexpr int kJSmall = 64;        // size classes of the Jacobi kernel: n <= 64 needs 33 KiB of LDS (4 workgroups per CU,
                                    // 256 threads), 65..128 needs 132 KiB (1 per CU, 1024 threads hide the LDS round trips)
 
+constexpr int kMaxViews = GCC_POSEMB_MAX_VIEWS;
+struct PosView {
+    const int32_t *node_off, *row_ptr, *col_idx;
+    float *pos, *evals, *raw;
+};
+struct PosMulti {                    // one launch covers the subgraphs of all views: item id = view * B + subgraph
+    PosView v[kMaxViews];
+    int32_t nviews, B, hidden;
+    uint64_t seed;
+    int32_t *status;
+};
+
 struct PosArgs {
     const int32_t *node_off, *row_ptr, *col_idx;
     float *pos, *evals, *raw;
@@ -33,6 +45,8 @@ struct PosArgs {
     const int32_t *list;     // subgraph indices handled by this launch, or NULL = all
     const int32_t *count;    // device count for `list`
 };
+
+__device__ __forceinline__ void item_args(const PosMulti &m, int item, struct PosArgs &a, int &b);
 
 // ---- symmetric eigen-decomposition of the LDS matrix A (np x np, np even, row stride lda) by
 // two-sided Jacobi; V (same shape) accumulates the rotations (V = I on entry if want_vectors).
@@ -163,66 +177,78 @@ struct Defl {
 };
 
 // =========================================================================
-// Direct solver for deflated size n' <= 128: Householder tridiagonalisation of the dense LDS matrix
-// (one wave per row, the reflector replicated in registers: 2 barriers per column), multi-section
-// bisection on Sturm counts for the k wanted eigenvalues (kT / 32 probe points per eigenvalue and
-// round), inverse iteration on the tridiagonal matrix with partial pivoting (one thread per
-// eigenvalue; three solve + re-orthogonalise rounds, classical Gram-Schmidt twice inside clusters of
-// eigenvalues closer than 1e-3, the LAPACK stein recipe) and the back-transformation by the stored
-// reflectors (one wave per vector, the vector in registers, no barriers).  ~25x less LDS traffic than
-// the two-sided Jacobi sweeps this replaces, and exact multiplicities are resolved the same way.
-constexpr int kYld = 33;             // row stride of the per-eigenvector arrays Y/Ud/Us ([i][j], j < 32): conflict free
-                                     // both for "lane = vector" (solves) and for "lane = row" (dots, back-transformation)
+// Direct solver: Householder tridiagonalisation of the dense deflated matrix (one wave per row, the
+// reflector replicated in registers: 2 barriers per column), multi-section bisection on Sturm counts
+// for the k wanted eigenvalues (kT / 32 probe points per eigenvalue and round), inverse iteration on
+// the tridiagonal matrix with partial pivoting (one thread per eigenvalue; three solve +
+// re-orthogonalise rounds, classical Gram-Schmidt twice inside clusters of eigenvalues closer than
+// 1e-3: the LAPACK stein recipe) and the back-transformation by the stored reflectors (one wave per
+// vector pair, vectors in registers, no barriers).  ~25x less LDS traffic than two-sided Jacobi sweeps,
+// deterministic run time, and exact multiplicities are resolved.
+// Three instantiations by deflated size n':  <= 64 and 65..128 keep the matrix in LDS;  129..384 keep
+// it in a workspace slot (rows are streamed coalesced, 4 n'^3 bytes in total; one CU sustains ~40 GB/s
+// from beyond its L2, which is what bounds this class and why it stops at 384) with the tridiagonal
+// data and the eigenvectors in LDS.
+constexpr int kYld = 33;             // row stride of Y ([i][j], j < 32): conflict free both for "lane = vector" (solves)
+                                     // and for "lane = row" (dots, back-transformation)
 constexpr int kMaxVec = 32;          // hidden <= 32 on this path (GCC: positional_embedding_size = 32)
 constexpr float kOrtol = 1e-3f;      // eigenvalues closer than this are re-orthogonalised against each other
 constexpr float kSep = 2e-6f;        // minimum distance between two inverse-iteration shifts
 constexpr float kPivTiny = 1.2e-7f;  // pivots of T - shift are clamped to eps * ||T||  (||T|| <= 1)
+constexpr int kGMax = GCC_POSEMB_DIRECT_MAX;   // largest deflated size of the workspace-resident class
+constexpr int kGLds = 128 * 1024;    // dynamic LDS of that class (of 160 KiB per CU)
 
-struct TriLds {
-    float *A;                        // [kNMax][kNMax + 1]; after the reduction row k holds reflector k right of the diagonal
-    float *dg, *of, *of2, *tau;      // [kNMax] diagonal, off-diagonal, its square, reflector scales
-    float *pbuf, *vbuf;              // [kNMax]
-    float *Y, *Ud, *Us;              // [kNMax][kYld]
-    uint8_t *Uf;                     // [kNMax][32]
-    int *cnt;                        // [32][kT / 32] Sturm counts of one bisection round
-    float *coef;                     // [32][kYld] Gram-Schmidt coefficients; column 32 = squared norm
+__device__ __forceinline__ void item_args(const PosMulti &m, int item, PosArgs &a, int &b)
+{
+    const int view = item / m.B;
+    b = item - view * m.B;
+    const PosView &pv = m.v[view];
+    a.node_off = pv.node_off; a.row_ptr = pv.row_ptr; a.col_idx = pv.col_idx;
+    a.pos = pv.pos; a.evals = pv.evals; a.raw = pv.raw;
+    a.B = m.B; a.hidden = m.hidden; a.seed = m.seed; a.status = m.status;
+    a.list = nullptr; a.count = nullptr;
+}
+
+// Work lists.  posemb_classify_kernel sorts the subgraphs of a batch into four classes by deflated size; every
+// solver kernel is launched with a SMALL fixed grid whose workgroups pull items from their class list.  (A grid of
+// one fat workgroup per subgraph that exits early when the class does not match keeps the workgroup dispatcher
+// busy placing 160-KiB-LDS / 1024-thread workgroups that do nothing, which delays every other queue.)
+enum { kClsSmall = 0, kClsMid = 1, kClsSlot = 2, kClsKrylov = 3, kNumCls = 4 };
+struct PosHead {                     // head of the caller's workspace (zeroed per call)
+    int32_t *count;                  // [4] items per class
+    int32_t *next;                   // [4] work counters
+    int32_t *list;                   // [4][T] item ids, T = views * B
+    float *slots;                    // [workgroups of the slot class][slot_floats]: matrix (kGMax x kGMax) + deflation tables
+    int32_t T;
+    int64_t slot_floats;
 };
 
-template <int kNMax, int kT>
-__host__ __device__ constexpr size_t tri_lds_bytes()
+template <int kNMax, int kT, bool kGlobalA>
+__host__ __device__ constexpr int direct_lds_bytes()
 {
-    return sizeof(float) * ((size_t)kNMax * (kNMax + 1) + 6 * kNMax + 3 * (size_t)kNMax * kYld + 32 * kYld)
-           + (size_t)kNMax * 32 + sizeof(int) * kT;
+    return kGlobalA ? kGLds
+                    : (int)(sizeof(float) * (6 * kNMax + 32 * kYld + kT + kNMax * (kNMax + 1) + kNMax * kYld)
+                            + kNodeMax * 16 + kNMax * (33 * 8 + 32));
 }
 
-template <int kNMax, int kT>
-__device__ __forceinline__ TriLds tri_carve(unsigned char *smem)
-{
-    TriLds w;
-    w.A = (float *)smem;
-    w.dg = w.A + kNMax * (kNMax + 1);
-    w.of = w.dg + kNMax;
-    w.of2 = w.of + kNMax;
-    w.tau = w.of2 + kNMax;
-    w.pbuf = w.tau + kNMax;
-    w.vbuf = w.pbuf + kNMax;
-    w.Y = w.vbuf + kNMax;
-    w.Ud = w.Y + kNMax * kYld;
-    w.Us = w.Ud + kNMax * kYld;
-    w.coef = w.Us + kNMax * kYld;
-    w.cnt = (int *)(w.coef + 32 * kYld);
-    w.Uf = (uint8_t *)(w.cnt + kT);
-    return w;
-}
+struct TriLds {
+    float *dg, *of, *of2, *tau;      // [kNMax] diagonal, off-diagonal, its square, reflector scales
+    float *pbuf, *vbuf;              // [kNMax]
+    float *coef;                     // [32][kYld] Gram-Schmidt coefficients; column 32 = squared norm
+    int *cnt;                        // [kT] Sturm counts of one bisection round
+    float *Y;                        // [n'][kYld] eigenvectors
+    float *Ud, *Us;                  // [n'][bw + 1] LU factors of the current batch of bw inverse iterations
+    uint8_t *Uf;                     // [n'][bw]
+    int bw, ldu;
+};
 
-// A (n x n, symmetric, both triangles kept) -> T = Q^T A Q; Q = H_0 H_1 ... H_{n-3}, H_k = I - tau_k v_k v_k^T with
-// v_k = (0, ..., 0, 1, A[k][k+2], ..., A[k][n-1]).  All threads call it; ends with a barrier.
-template <int kNMax, int kT>
-__device__ void tridiagonalize(const TriLds &w, int n)
+// A (n x n, symmetric, both triangles kept, row stride lda) -> T = Q^T A Q; Q = H_0 H_1 ... H_{n-3},
+// H_k = I - tau_k v_k v_k^T with v_k = (0, ..., 0, 1, A[k][k+2], ..., A[k][n-1]).  All threads call it; ends with a barrier.
+template <int kCPL, int kT, int kR>
+__device__ void tridiagonalize(float *A, int lda, int n, const TriLds &w)
 {
-    constexpr int kCPL = kNMax / 64, lda = kNMax + 1, kNW = kT / 64;
+    constexpr int kNW = kT / 64;                     // kR rows per wave are in flight (memory-level parallelism)
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    float *A = w.A;
     for (int k = 0; k + 2 < n; ++k) {
         // every wave forms reflector k from row k (columns k+1 .. n-1): identical arithmetic, no barrier
         float v[kCPL];
@@ -230,13 +256,13 @@ __device__ void tridiagonalize(const TriLds &w, int n)
 #pragma unroll
         for (int u = 0; u < kCPL; ++u) {
             const int c = lane + 64 * u;
-            v[u] = (c > k && c < n) ? A[k * lda + c] : 0.f;
+            v[u] = (c > k && c < n) ? A[(int64_t)k * lda + c] : 0.f;
             sig += c > k + 1 ? v[u] * v[u] : 0.f;
         }
         sig = wave_sum(sig);
-        const float x0 = A[k * lda + k + 1];
+        const float x0 = A[(int64_t)k * lda + k + 1];
         if (sig <= 1e-30f) {                         // block-uniform: the column is already tridiagonal, H_k = I
-            if (tid == 0) { w.dg[k] = A[k * lda + k]; w.of[k] = x0; w.tau[k] = 0.f; }
+            if (tid == 0) { w.dg[k] = A[(int64_t)k * lda + k]; w.of[k] = x0; w.tau[k] = 0.f; }
             continue;
         }
         const float mu = sqrtf(x0 * x0 + sig);
@@ -250,27 +276,36 @@ __device__ void tridiagonalize(const TriLds &w, int n)
         }
         if (wv == 0) {
 #pragma unroll
-            for (int u = 0; u < kCPL; ++u) w.vbuf[lane + 64 * u] = v[u];
+            for (int u = 0; u < kCPL; ++u)
+                if (lane + 64 * u < n) w.vbuf[lane + 64 * u] = v[u];
         }
         // p = tau A v on the trailing block
-        for (int i = k + 1 + wv; i < n; i += kNW) {
-            float s = 0.f;
+        for (int i0 = k + 1 + wv * kR; i0 < n; i0 += kNW * kR) {
+            float s[kR];
 #pragma unroll
-            for (int u = 0; u < kCPL; ++u) {
-                const int c = lane + 64 * u;
-                s += (c > k && c < n) ? A[i * lda + c] * v[u] : 0.f;
+            for (int r = 0; r < kR; ++r) {
+                s[r] = 0.f;
+                const int i = i0 + r < n ? i0 + r : n - 1;
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) {
+                    const int c = lane + 64 * u;
+                    s[r] += (c > k && c < n) ? A[(int64_t)i * lda + c] * v[u] : 0.f;
+                }
             }
-            s = wave_sum(s);
-            if (lane == 0) w.pbuf[i] = t * s;
+#pragma unroll
+            for (int r = 0; r < kR; ++r) {
+                const float sr = wave_sum(s[r]);
+                if (lane == 0 && i0 + r < n) w.pbuf[i0 + r] = t * sr;
+            }
         }
         __syncthreads();
         if (wv == 0) {                               // row k is dead now: it stores the reflector
 #pragma unroll
             for (int u = 0; u < kCPL; ++u) {
                 const int c = lane + 64 * u;
-                if (c > k + 1 && c < n) A[k * lda + c] = v[u];
+                if (c > k + 1 && c < n) A[(int64_t)k * lda + c] = v[u];
             }
-            if (lane == 0) { w.dg[k] = A[k * lda + k]; w.of[k] = beta; w.tau[k] = t; }
+            if (lane == 0) { w.dg[k] = A[(int64_t)k * lda + k]; w.of[k] = beta; w.tau[k] = t; }
         }
         float pc[kCPL], pv = 0.f;
 #pragma unroll
@@ -282,19 +317,34 @@ __device__ void tridiagonalize(const TriLds &w, int n)
         const float K = 0.5f * t * wave_sum(pv);
 #pragma unroll
         for (int u = 0; u < kCPL; ++u) pc[u] -= K * v[u];          // w = p - K v
-        for (int i = k + 1 + wv; i < n; i += kNW) {                 // A -= v w^T + w v^T
-            const float vi = w.vbuf[i], wi = w.pbuf[i] - K * vi;
+        for (int i0 = k + 1 + wv * kR; i0 < n; i0 += kNW * kR) {    // A -= v w^T + w v^T
+            float arow[kR][kCPL];
 #pragma unroll
-            for (int u = 0; u < kCPL; ++u) {
-                const int c = lane + 64 * u;
-                if (c > k && c < n) A[i * lda + c] -= vi * pc[u] + wi * v[u];
+            for (int r = 0; r < kR; ++r) {
+                const int i = i0 + r < n ? i0 + r : n - 1;
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) {
+                    const int c = lane + 64 * u;
+                    arow[r][u] = (c > k && c < n) ? A[(int64_t)i * lda + c] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kR; ++r) {
+                const int i = i0 + r;
+                if (i >= n) continue;
+                const float vi = w.vbuf[i], wi = w.pbuf[i] - K * vi;
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) {
+                    const int c = lane + 64 * u;
+                    if (c > k && c < n) A[(int64_t)i * lda + c] = arow[r][u] - (vi * pc[u] + wi * v[u]);
+                }
             }
         }
         __syncthreads();
     }
     if (tid == 0) {
-        if (n >= 2) { w.dg[n - 2] = A[(n - 2) * lda + n - 2]; w.of[n - 2] = A[(n - 2) * lda + n - 1]; }
-        w.dg[n - 1] = A[(n - 1) * lda + n - 1];
+        if (n >= 2) { w.dg[n - 2] = A[(int64_t)(n - 2) * lda + n - 2]; w.of[n - 2] = A[(int64_t)(n - 2) * lda + n - 1]; }
+        w.dg[n - 1] = A[(int64_t)(n - 1) * lda + n - 1];
         w.of[n - 1] = 0.f;
     }
     __syncthreads();
@@ -321,13 +371,14 @@ __device__ __forceinline__ float hash_unit(uint32_t a, uint32_t b, uint32_t c)
     return (float)(h >> 8) * (2.0f / 16777216.0f) - 1.0f;
 }
 
-// one inverse-iteration step for eigenvector j (called by ONE thread): solve (T - shift) x = y in place in
-// column j of Y, by Gaussian elimination with partial pivoting fused with the right-hand side; x is normalised.
-// Returns false if the solution is not finite.
-__device__ bool inverse_iteration_step(const TriLds &w, int n, int j, float shift, bool random_rhs, uint32_t hseed)
+// one inverse-iteration step for eigenvector j (called by ONE thread, slot jl of the LU batch): solve
+// (T - shift) x = y in place in column j of Y, by Gaussian elimination with partial pivoting fused with the
+// right-hand side; x is normalised.  Returns false if the solution is not finite.
+__device__ bool inverse_iteration_step(const TriLds &w, int n, int j, int jl, float shift, bool random_rhs, uint32_t hseed)
 {
-    float *Y = w.Y + j, *Ud = w.Ud + j, *Us = w.Us + j;
-    uint8_t *Uf = w.Uf + j;
+    float *Y = w.Y + j, *Ud = w.Ud + jl, *Us = w.Us + jl;
+    uint8_t *Uf = w.Uf + jl;
+    const int ldu = w.ldu, ldf = w.bw;
     float cd = w.dg[0] - shift, cs = n > 1 ? w.of[0] : 0.f;
     float cy = random_rhs ? hash_unit(hseed, (uint32_t)j, 0u) : Y[0];
     for (int i = 0; i + 1 < n; ++i) {
@@ -335,21 +386,21 @@ __device__ bool inverse_iteration_step(const TriLds &w, int n, int j, float shif
         const float by = random_rhs ? hash_unit(hseed, (uint32_t)j, (uint32_t)(i + 1)) : Y[(i + 1) * kYld];
         if (fabsf(cd) >= fabsf(sub)) {
             const float mult = cd != 0.f ? sub / cd : 0.f;
-            Ud[i * kYld] = cd; Us[i * kYld] = cs; Uf[i * 32] = 0; Y[i * kYld] = cy;
+            Ud[i * ldu] = cd; Us[i * ldu] = cs; Uf[i * ldf] = 0; Y[i * kYld] = cy;
             cd = nd - mult * cs; cs = ns; cy = by - mult * cy;
         } else {
             const float mult = cd / sub;
-            Ud[i * kYld] = sub; Us[i * kYld] = nd; Uf[i * 32] = 1; Y[i * kYld] = by;
+            Ud[i * ldu] = sub; Us[i * ldu] = nd; Uf[i * ldf] = 1; Y[i * kYld] = by;
             cd = cs - mult * nd; cs = -mult * ns; cy = cy - mult * by;
         }
     }
-    Ud[(n - 1) * kYld] = cd; Us[(n - 1) * kYld] = 0.f; Uf[(n - 1) * 32] = 0; Y[(n - 1) * kYld] = cy;
+    Ud[(n - 1) * ldu] = cd; Us[(n - 1) * ldu] = 0.f; Uf[(n - 1) * ldf] = 0; Y[(n - 1) * kYld] = cy;
     float x1 = 0.f, x2 = 0.f, ss = 0.f;
     for (int i = n - 1; i >= 0; --i) {
-        float d = Ud[i * kYld];
+        float d = Ud[i * ldu];
         if (fabsf(d) < kPivTiny) d = d < 0.f ? -kPivTiny : kPivTiny;
-        const float s2 = (Uf[i * 32] && i + 2 < n) ? w.of[i + 1] : 0.f;
-        const float x = (Y[i * kYld] - Us[i * kYld] * x1 - s2 * x2) / d;
+        const float s2 = (Uf[i * ldf] && i + 2 < n) ? w.of[i + 1] : 0.f;
+        const float x = (Y[i * kYld] - Us[i * ldu] * x1 - s2 * x2) / d;
         Y[i * kYld] = x;
         x2 = x1; x1 = x;
         ss = fmaf(x, x, ss);
@@ -363,12 +414,11 @@ __device__ bool inverse_iteration_step(const TriLds &w, int n, int j, float shif
 // classical Gram-Schmidt (twice) + normalisation inside every cluster; the t-th members of all clusters are
 // processed together.  Returns (block-uniform) the number of vectors that vanished (were in the span of
 // their predecessors).  All threads call it; ends with a barrier.
-template <int kNMax, int kT>
+template <int kT>
 __device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int *cs, const int *posi, int maxpos)
 {
-    constexpr int kNW = kT / 64, kJG = kT / kNMax;
+    constexpr int kNW = kT / 64;
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int i = tid & (kNMax - 1), jg = tid / kNMax;
     float *Y = w.Y, *coef = w.coef;
     int lost = 0;
     for (int t = 1; t <= maxpos; ++t) {
@@ -383,9 +433,9 @@ __device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int 
                 }
             }
             __syncthreads();
-            if (i < n) {
-                for (int j = jg; j < na; j += kJG) {
-                    if (posi[j] != t) continue;
+            for (int j = 0; j < na; ++j) {
+                if (posi[j] != t) continue;
+                for (int i = tid; i < n; i += kT) {
                     float acc = 0.f;
                     for (int l = cs[j]; l < j; ++l) acc = fmaf(coef[j * kYld + l], Y[i * kYld + l], acc);
                     Y[i * kYld + j] -= acc;
@@ -401,52 +451,105 @@ __device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int 
             if (lane == 0) coef[j * kYld + 32] = s;
         }
         __syncthreads();
-        for (int j = 0; j < na; ++j)
-            if (posi[j] == t && coef[j * kYld + 32] < 1e-6f) ++lost;
-        if (i < n) {
-            for (int j = jg; j < na; j += kJG) {
-                if (posi[j] != t) continue;
-                Y[i * kYld + j] *= 1.0f / sqrtf(fmaxf(coef[j * kYld + 32], 1e-30f));
-            }
+        for (int j = 0; j < na; ++j) {
+            if (posi[j] != t) continue;
+            const float s = coef[j * kYld + 32];
+            if (s < 1e-6f) ++lost;
+            const float inv = 1.0f / sqrtf(fmaxf(s, 1e-30f));
+            for (int i = tid; i < n; i += kT) Y[i * kYld + j] *= inv;
         }
         __syncthreads();
     }
     return lost;
 }
 
-template <int kNMin, int kNMax, int kT>
-__global__ __launch_bounds__(kT) void posemb_direct_kernel(PosArgs a)
+// one wave per subgraph: deflated size -> class list; k <= 0 subgraphs are finished here (zeros, data_util.py:243-244)
+constexpr int kClsThreads = 256;
+__global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m, PosHead hd)
 {
-    static_assert(kNMax % 64 == 0 && (kNMax & (kNMax - 1)) == 0 && kT % kNMax == 0, "size class");
+    __shared__ int32_t tc[kClsThreads / 64][kNodeMax];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int item = (int)blockIdx.x * (kClsThreads / 64) + wv;
+    if (item >= hd.T) return;
+    PosArgs a;
+    int b;
+    item_args(m, item, a, b);
+    const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+    const int k = min(min(n - 2, a.hidden), kMaxVec);   // data_util.py:278
+    if (k <= 0) {
+        for (int i = lane; i < n * a.hidden; i += 64) a.pos[(int64_t)n0 * a.hidden + i] = 0.f;
+        if (a.raw) for (int i = lane; i < n * a.hidden; i += 64) a.raw[(int64_t)n0 * a.hidden + i] = 0.f;
+        if (a.evals) for (int i = lane; i < a.hidden; i += 64) a.evals[(int64_t)b * a.hidden + i] = 0.f;
+        return;
+    }
+    int cls = kClsKrylov;
+    if (n <= kNodeMax) {
+        const int32_t *rp = a.row_ptr + n0;
+        int32_t *t = tc[wv];
+        for (int i = lane; i < n; i += 64) t[i] = 0;
+        wave_sync();
+        for (int i = lane; i < n; i += 64)
+            if (rp[i + 1] - rp[i] == 1) atomicAdd(&t[a.col_idx[rp[i]] - n0], 1);
+        wave_sync();
+        int zz = 0;
+        for (int i = lane; i < n; i += 64) zz += t[i] >= 2 ? t[i] - 1 : 0;
+        for (int dd = 32; dd >= 1; dd >>= 1) zz += wave_shfl_xor(zz, dd);
+        const int nr = n - zz;                         // t >= 2 leaves of one parent count once
+        cls = nr <= kJSmall ? kClsSmall : nr <= kJMax ? kClsMid : nr <= kGMax ? kClsSlot : kClsKrylov;
+    }
+    if (lane == 0) hd.list[(int64_t)cls * hd.T + atomicAdd(hd.count + cls, 1)] = item;
+}
+
+template <int kCls, int kNMin, int kNMax, int kT, bool kGlobalA>
+__global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead hd)
+{
+    static_assert(kNMax % 64 == 0 && kT % 64 == 0 && kT >= 256, "size class");
     DYN_SMEM(smem);
     __shared__ float lamv[kMaxVec], shiftv[kMaxVec], lo[kMaxVec], hi[kMaxVec];
     __shared__ int cs[kMaxVec], posi[kMaxVec];
     __shared__ int colsrc[64];                  // per output column: eigenvector j >= 0, or -(c + 1) for contrast c
-    __shared__ int sh_np, sh_z, sh_na, sh_maxpos, sh_bad;
-    constexpr int kNW = kT / 64, kCPL = kNMax / 64, lda = kNMax + 1, kP = kT / 32;
+    __shared__ int sh_np, sh_z, sh_na, sh_maxpos, sh_bad, sh_item;
+    constexpr int kNW = kT / 64, kCPL = kNMax / 64, kP = kT / 32;
+    constexpr int lda = kGlobalA ? kNMax : kNMax + 1;   // LDS: odd stride; workspace: rows start on 256-byte boundaries
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int b = (int)blockIdx.x;
-    if (b >= a.B) return;
+    for (;;) {                                     // items of this class
+    __syncthreads();
+    if (tid == 0) sh_item = atomicAdd(hd.next + kCls, 1);
+    __syncthreads();
+    if (sh_item >= hd.count[kCls]) return;
+    const int gb = hd.list[(int64_t)kCls * hd.T + sh_item];
+    PosArgs a;
+    int b;
+    item_args(m, gb, a, b);
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
-    if (n > kNodeMax) return;                      // Krylov kernel
-    const int k = min(min(n - 2, a.hidden), kMaxVec);   // data_util.py:278
-    if (k <= 0) {                                  // data_util.py:243-244: zeros
-        if (kNMin == 0) {
-            for (int i = tid; i < n * a.hidden; i += kT) a.pos[(int64_t)n0 * a.hidden + i] = 0.f;
-            if (a.evals) for (int i = tid; i < a.hidden; i += kT) a.evals[(int64_t)b * a.hidden + i] = 0.f;
-        }
-        return;
-    }
-    const TriLds w = tri_carve<kNMax, kT>(smem);
-    float *A = w.A;
+    const int k = min(min(n - 2, a.hidden), kMaxVec);   // data_util.py:278; k >= 1 (classify kernel)
+    // ---- LDS carve-up
+    TriLds w;
+    w.dg = (float *)smem;
+    w.of = w.dg + kNMax;
+    w.of2 = w.of + kNMax;
+    w.tau = w.of2 + kNMax;
+    w.pbuf = w.tau + kNMax;
+    w.vbuf = w.pbuf + kNMax;
+    w.coef = w.vbuf + kNMax;
+    w.cnt = (int *)(w.coef + 32 * kYld);
+    float *lds_rest = (float *)(w.cnt + kT);
     Defl d;
-    d.tcnt = (int32_t *)(smem + tri_lds_bytes<kNMax, kT>());
+    float *A = nullptr;
+    if (!kGlobalA) {
+        A = lds_rest;
+        lds_rest += kNMax * lda;
+    }
+    // the deflation tables are built in LDS; the workspace class moves them to its slot once the matrix is filled
+    // (the eigenvector arrays overlay them)
+    d.tcnt = (int32_t *)lds_rest;
+    if (!kGlobalA) lds_rest += kNodeMax * 4;       // 2 int32 + 4 uint16 tables = 16 KiB
+    const int32_t *rp = a.row_ptr + n0;
     d.cbase = d.tcnt + kNodeMax;
     d.par = (uint16_t *)(d.cbase + kNodeMax);
     d.rep = d.par + kNodeMax;
     d.ridx = d.rep + kNodeMax;
     d.ord = d.ridx + kNodeMax;
-    const int32_t *rp = a.row_ptr + n0;
 
     // ---- leaf groups
     for (int i = tid; i < n; i += kT) {
@@ -487,7 +590,22 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosArgs a)
     }
     __syncthreads();
     const int nr = sh_np, z = sh_z;                // reduced size n', number of contrast null vectors
-    if (nr > kNMax || nr < kNMin) return;          // other size class / Krylov kernel
+    if (nr > kNMax || nr < kNMin) continue;        // cannot happen: the classify kernel computed the same size
+    if (kGlobalA) A = hd.slots + (int64_t)blockIdx.x * hd.slot_floats;   // the workgroup's own slot
+    // ---- rest of the carve-up: eigenvectors and as many LU slots as fit
+    w.Y = lds_rest;
+    {
+        constexpr int lds_total = direct_lds_bytes<kNMax, kT, kGlobalA>();
+        const int used = (int)((unsigned char *)(w.Y + nr * kYld) - smem);
+        const int left = lds_total - used;
+        int bw = 32;
+        while (bw > 4 && nr * ((bw + 1) * 8 + bw) > left) bw >>= 1;
+        w.bw = bw;
+        w.ldu = bw + 1;
+        w.Ud = w.Y + nr * kYld;
+        w.Us = w.Ud + nr * w.ldu;
+        w.Uf = (uint8_t *)(w.Us + nr * w.ldu);
+    }
     for (int i = tid; i < nr * lda; i += kT) A[i] = 0.f;
     __syncthreads();
     // M' = norm * adj * norm on the kept nodes (data_util.py:273-277), super-leaf couplings scaled by sqrt(t)
@@ -506,9 +624,21 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosArgs a)
         }
     }
     __syncthreads();
+    if (kGlobalA) {
+        uint32_t *dst = (uint32_t *)(A + (int64_t)kNMax * lda);
+        const uint32_t *src = (const uint32_t *)d.tcnt;
+        for (int i = tid; i < kNodeMax * 4; i += kT) dst[i] = src[i];
+        d.tcnt = (int32_t *)dst;
+        d.cbase = d.tcnt + kNodeMax;
+        d.par = (uint16_t *)(d.cbase + kNodeMax);
+        d.rep = d.par + kNodeMax;
+        d.ridx = d.rep + kNodeMax;
+        d.ord = d.ridx + kNodeMax;
+        __syncthreads();
+    }
 
-    tridiagonalize<kNMax, kT>(w, nr);
-    if (tid < nr) w.of2[tid] = w.of[tid] * w.of[tid];
+    tridiagonalize<kCPL, kT, kGlobalA ? 4 : 2>(A, lda, nr, w);
+    for (int i = tid; i < nr; i += kT) w.of2[i] = w.of[i] * w.of[i];
     // ---- the kq largest eigenvalues of T: eigenvalue j (descending) has ascending index nr - 1 - j and lies in
     //      [lo, hi] with count(lo) <= nr - 1 - j < count(hi); every round probes kP interior points
     const int kq = min(k, nr);
@@ -571,41 +701,53 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosArgs a)
     const int na = sh_na, maxpos = sh_maxpos;
     // ---- eigenvectors of T
     int lost = 0;
+    const uint32_t hseed = (uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u);
     for (int it = 0; it < 3; ++it) {
-        if (tid < na) {
-            const bool ok = inverse_iteration_step(w, nr, tid, shiftv[tid], it == 0, (uint32_t)a.seed ^ (uint32_t)(b * 0x9E3779B1u));
-            if (!ok) sh_bad = 1;
+        for (int j0 = 0; j0 < na; j0 += w.bw) {
+            if (tid < w.bw && j0 + tid < na) {
+                const bool ok = inverse_iteration_step(w, nr, j0 + tid, tid, shiftv[j0 + tid], it == 0, hseed);
+                if (!ok) sh_bad = 1;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        lost = cluster_orthonormalize<kNMax, kT>(w, nr, na, cs, posi, maxpos);
+        lost = cluster_orthonormalize<kT>(w, nr, na, cs, posi, maxpos);
     }
     if (tid == 0 && (lost > 0 || sh_bad)) atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
-    // ---- eigenvectors of M': x = H_0 ... H_{nr-3} y, one wave per vector, the vector in registers
-    for (int j = wv; j < na; j += kNW) {
-        float y[kCPL];
+    // ---- eigenvectors of M': x = H_0 ... H_{nr-3} y; one wave per pair of vectors, the vectors in registers
+    for (int j = 2 * wv; j < na; j += 2 * kNW) {
+        const bool two = j + 1 < na;
+        float y0[kCPL], y1[kCPL], v[kCPL], vn[kCPL];
 #pragma unroll
         for (int u = 0; u < kCPL; ++u) {
             const int c = lane + 64 * u;
-            y[u] = c < nr ? w.Y[c * kYld + j] : 0.f;
+            y0[u] = c < nr ? w.Y[c * kYld + j] : 0.f;
+            y1[u] = (c < nr && two) ? w.Y[c * kYld + j + 1] : 0.f;
+            vn[u] = (nr >= 3 && c > nr - 2 && c < nr) ? A[(int64_t)(nr - 3) * lda + c] : 0.f;
         }
         for (int kk = nr - 3; kk >= 0; --kk) {
-            const float t = w.tau[kk];
-            if (t == 0.f) continue;
-            float v[kCPL], s = 0.f;
 #pragma unroll
             for (int u = 0; u < kCPL; ++u) {
                 const int c = lane + 64 * u;
-                v[u] = c == kk + 1 ? 1.0f : ((c > kk + 1 && c < nr) ? A[kk * lda + c] : 0.f);
-                s += v[u] * y[u];
+                v[u] = c == kk + 1 ? 1.0f : (c > kk + 1 ? vn[u] : 0.f);
+                vn[u] = (kk > 0 && c > kk && c < nr) ? A[(int64_t)(kk - 1) * lda + c] : 0.f;   // prefetch reflector kk - 1
             }
-            s = t * wave_sum(s);
+            const float t = w.tau[kk];
+            if (t == 0.f) continue;
+            float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int u = 0; u < kCPL; ++u) y[u] -= s * v[u];
+            for (int u = 0; u < kCPL; ++u) { s0 += v[u] * y0[u]; s1 += v[u] * y1[u]; }
+            s0 = t * wave_sum(s0);
+            s1 = t * wave_sum(s1);
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) { y0[u] -= s0 * v[u]; y1[u] -= s1 * v[u]; }
         }
 #pragma unroll
         for (int u = 0; u < kCPL; ++u) {
             const int c = lane + 64 * u;
-            if (c < nr) w.Y[c * kYld + j] = y[u];
+            if (c < nr) {
+                w.Y[c * kYld + j] = y0[u];
+                if (two) w.Y[c * kYld + j + 1] = y1[u];
+            }
         }
     }
     __syncthreads();
@@ -636,6 +778,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosArgs a)
             if (a.raw) a.raw[(int64_t)(n0 + v) * a.hidden + lane] = val;
         }
     }
+    }   // next item
 }
 
 
@@ -659,8 +802,9 @@ constexpr int kKThreads = 1024;      // 16 waves: the long-vector work is bound 
 constexpr int kKWaves = kKThreads / 64;
 
 struct KryArgs {
-    PosArgs p;
-    float *vws;              // [B][2][(kM + 1) * ldv]   ping-pong basis (the restart rotation is out of place)
+    PosMulti m;
+    PosHead hd;
+    float *vws;              // [workgroups][2][(kM + 1) * ldv]   ping-pong basis (the restart rotation is out of place)
     int32_t ldv;             // column stride (>= max n, multiple of 64)
 };
 
@@ -683,27 +827,20 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
     __shared__ float Aj[kM * (kM + 1)], Yj[kM * (kM + 1)];
     __shared__ float rot[kM], theta[kM], hbuf[kM + 1], red[kKWaves];
     __shared__ int pq[kM], sel[kM], colsrc[kM], longrows[kMaxLong];
-    __shared__ int flag, nlong, done;
-    const PosArgs &a = ka.p;
+    __shared__ int flag, nlong, done, sh_item;
     const int tid = (int)threadIdx.x, lane = tid & 63, wv_id = tid >> 6;
-    const int b = (int)blockIdx.x;
-    if (b >= a.B) return;
+    for (;;) {                                       // items of the Krylov class
+    __syncthreads();
+    if (tid == 0) sh_item = atomicAdd(ka.hd.next + kClsKrylov, 1);
+    __syncthreads();
+    if (sh_item >= ka.hd.count[kClsKrylov]) return;
+    const int gb = ka.hd.list[(int64_t)kClsKrylov * ka.hd.T + sh_item];
+    PosArgs a;
+    int b;
+    item_args(ka.m, gb, a, b);
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
-    if (n <= kJMax) return;                          // handled by the Jacobi kernels
     const int ldv = ka.ldv;
-    if (n <= kNodeMax) {                             // ... which also take it if its leaf-deflated size fits
-        int32_t *tc = (int32_t *)smem;
-        for (int i = tid; i < n; i += kKThreads) tc[i] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += kKThreads)
-            if (a.row_ptr[n0 + i + 1] - a.row_ptr[n0 + i] == 1) atomicAdd(&tc[a.col_idx[a.row_ptr[n0 + i]] - n0], 1);
-        __syncthreads();
-        float zz = 0.f;
-        for (int i = tid; i < n; i += kKThreads) zz += tc[i] >= 2 ? (float)(tc[i] - 1) : 0.f;
-        const int nred = n - (int)(block_sum(zz, red) + 0.5f);
-        if (nred <= kJMax) return;
-    }
-    float *V = ka.vws + (int64_t)b * 2 * (kM + 1) * ldv;
+    float *V = ka.vws + (int64_t)blockIdx.x * 2 * (kM + 1) * ldv;     // the workgroup's own basis storage
     float *Valt = V + (int64_t)(kM + 1) * ldv;
     float *x = (float *)smem, *w = x + ldv, *dinv = w + ldv;
     const int k = min(n - 2, a.hidden);
@@ -725,7 +862,7 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
     float ss = 0.f;
     for (int r = tid; r < n; r += kKThreads) {
         uint32_t rnd[4];
-        philox4x32_10((uint32_t)r, 0u, (uint32_t)b, 0x9E0B5EEDu, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
+        philox4x32_10((uint32_t)r, 0u, (uint32_t)gb, 0x9E0B5EEDu, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
         const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
         w[r] = u;
         ss += u * u;
@@ -798,7 +935,7 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
             if (beta < 1e-6f) {                      // invariant subspace: continue with a fresh direction
                 for (int r = tid; r < n; r += kKThreads) {
                     uint32_t rnd[4];
-                    philox4x32_10((uint32_t)r, (uint32_t)(steps + 1), (uint32_t)b, 0x9E0B5EEDu,
+                    philox4x32_10((uint32_t)r, (uint32_t)(steps + 1), (uint32_t)gb, 0x9E0B5EEDu,
                                   (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
                     w[r] = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f) - 0.5f;
                 }
@@ -922,66 +1059,116 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
         atomicMax(a.status + 1, cycle + 1);
         atomicAdd(a.status + 2, steps);
     }
+    }   // next item
 }
 
 }  // namespace
 
 extern "C" {
 
-int64_t gcc_posemb_workspace_bytes(int32_t batch_size, int64_t node_cap, int32_t hidden)
+struct PosGrids { int32_t small, mid, slot, kry; };
+static PosGrids posemb_grids(int64_t T)
 {
-    if (batch_size < 1 || node_cap < 1 || hidden < 2 || hidden > 64) {
-        snprintf(g_err, kErrLen, "gcc_posemb_workspace_bytes: bad argument");
+    // fixed grids: enough workgroups for the typical class sizes (~73 % / 19 % / 6 % / 2 % of a batch at rw_hops 256);
+    // larger classes loop
+    PosGrids g;
+    g.small = (int32_t)(T < 2048 ? T : 2048);
+    g.mid = (int32_t)((T + 3) / 4 < 1024 ? (T + 3) / 4 : 1024);
+    g.slot = (int32_t)((T + 7) / 8 < 128 ? (T + 7) / 8 : 128);
+    g.kry = (int32_t)((T + 15) / 16 < 64 ? (T + 15) / 16 : 64);
+    return g;
+}
+static int64_t posemb_head_bytes(int64_t T) { return ((16 + kNumCls * T) * 4 + 255) / 256 * 256; }
+static int64_t posemb_slot_floats(void) { return (int64_t)kGMax * kGMax + (int64_t)kNodeMax * 4; }
+static int64_t posemb_ldv(int32_t batch_size, int64_t node_cap) { return ((node_cap / batch_size + 63) / 64) * 64 + 64; }
+
+int64_t gcc_posemb_multi_workspace_bytes(int32_t num_views, int32_t batch_size, int64_t node_cap, int32_t hidden)
+{
+    if (num_views < 1 || num_views > kMaxViews || batch_size < 1 || node_cap < 1 || hidden < 2 || hidden > kMaxVec) {
+        snprintf(g_err, kErrLen, "gcc_posemb_multi_workspace_bytes: bad argument");
         return -1;
     }
-    const int64_t ldv = ((node_cap / batch_size + 63) / 64) * 64 + 64;
-    return (int64_t)batch_size * 2 * (kM + 1) * ldv * (int64_t)sizeof(float) + 256;
+    const int64_t T = (int64_t)num_views * batch_size;
+    const PosGrids g = posemb_grids(T);
+    return posemb_head_bytes(T) + g.slot * posemb_slot_floats() * (int64_t)sizeof(float)
+           + (int64_t)g.kry * 2 * (kM + 1) * posemb_ldv(batch_size, node_cap) * (int64_t)sizeof(float) + 256;
+}
+
+int64_t gcc_posemb_workspace_bytes(int32_t batch_size, int64_t node_cap, int32_t hidden)
+{
+    return gcc_posemb_multi_workspace_bytes(1, batch_size, node_cap, hidden);
+}
+
+int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_t batch_size, int64_t node_cap,
+                         int32_t hidden, uint64_t seed, void *workspace, int64_t workspace_bytes, int32_t *status,
+                         gcc_prof *prof, void *stream)
+{
+    if (!views || !status || num_views < 1 || num_views > kMaxViews || batch_size < 1 || hidden < 2 || hidden > kMaxVec) {
+        snprintf(g_err, kErrLen, "gcc_posemb_multi: bad argument");
+        return -1;
+    }
+    const int64_t need = gcc_posemb_multi_workspace_bytes(num_views, batch_size, node_cap, hidden);
+    if (!workspace || workspace_bytes < need) {
+        snprintf(g_err, kErrLen, "gcc_posemb: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+        return -3;
+    }
+    PosMulti m;
+    memset(&m, 0, sizeof(m));
+    for (int i = 0; i < num_views; ++i) {
+        if (!views[i].g || !views[i].pos) { snprintf(g_err, kErrLen, "gcc_posemb_multi: view %d is incomplete", i); return -1; }
+        m.v[i] = {views[i].g->node_off, views[i].g->row_ptr, views[i].g->col_idx, views[i].pos, views[i].evals, views[i].raw};
+    }
+    m.nviews = num_views; m.B = batch_size; m.hidden = hidden; m.seed = seed; m.status = status;
+    const int64_t T = (int64_t)num_views * batch_size;
+    const PosGrids g = posemb_grids(T);
+    hipStream_t s = (hipStream_t)stream;
+    PosHead hd;
+    hd.count = (int32_t *)workspace;
+    hd.next = hd.count + 8;
+    hd.list = hd.count + 16;
+    hd.slots = (float *)((char *)workspace + posemb_head_bytes(T));
+    hd.T = (int32_t)T;
+    hd.slot_floats = posemb_slot_floats();
+    constexpr int lds_small = direct_lds_bytes<kJSmall, 256, false>();
+    constexpr int lds_big = direct_lds_bytes<kJMax, 1024, false>();
+#ifndef GCC_AMD_HIPEMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsSmall, 0, kJSmall, 256, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_small);
+        (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, 1024, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
+        (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kGLds);
+        attr_set = true;
+    }
+#endif
+    prof_mark(prof, 0, s);
+    (void)hipMemsetAsync(workspace, 0, 64, s);       // class counts + work counters
+    hipLaunchKernelGGL(posemb_classify_kernel, dim3((unsigned)((T + 3) / 4)), dim3(kClsThreads), 0, s, m, hd);
+    KryArgs ka;
+    ka.m = m;
+    ka.hd = hd;
+    ka.vws = hd.slots + g.slot * hd.slot_floats;
+    ka.ldv = (int32_t)posemb_ldv(batch_size, node_cap);
+    // longest items first
+    hipLaunchKernelGGL(posemb_krylov_kernel, dim3(g.kry), dim3(kKThreads), (size_t)3 * ka.ldv * sizeof(float), s, ka);
+    hipLaunchKernelGGL((posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>), dim3(g.slot), dim3(1024), kGLds, s, m, hd);
+    hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, 1024, false>), dim3(g.mid), dim3(1024), lds_big, s, m, hd);
+    hipLaunchKernelGGL((posemb_direct_kernel<kClsSmall, 0, kJSmall, 256, false>), dim3(g.small), dim3(256), lds_small, s, m, hd);
+    prof_mark(prof, 1, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_posemb: %s", hipGetErrorString(e)); return -10; }
+    return 0;
 }
 
 int32_t gcc_posemb(const gcc_batch_out *g, int32_t batch_size, int32_t hidden, float *pos, float *evals,
                    float *raw, uint64_t seed, void *workspace, int64_t workspace_bytes, int32_t *status, gcc_prof *prof,
                    void *stream)
 {
-    if (!g || !pos || !status || batch_size < 1 || hidden < 2 || hidden > 64) {
-        snprintf(g_err, kErrLen, "gcc_posemb: bad argument");
-        return -1;
-    }
-    const int64_t need = gcc_posemb_workspace_bytes(batch_size, g->node_cap, hidden);
-    if (!workspace || workspace_bytes < need) {
-        snprintf(g_err, kErrLen, "gcc_posemb: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
-        return -3;
-    }
-    PosArgs a = {g->node_off, g->row_ptr, g->col_idx, pos, evals, raw, batch_size, hidden, seed, status, nullptr, nullptr};
-    hipStream_t s = (hipStream_t)stream;
-    if (hidden > kMaxVec) {
-        snprintf(g_err, kErrLen, "gcc_posemb: hidden %d > %d", hidden, kMaxVec);
-        return -1;
-    }
-    const size_t lds_tab = (size_t)kNodeMax * (2 * sizeof(int32_t) + 4 * sizeof(uint16_t));
-    const size_t lds_small = tri_lds_bytes<kJSmall, 256>() + lds_tab;
-    const size_t lds_big = tri_lds_bytes<kJMax, 1024>() + lds_tab;
-#ifndef GCC_AMD_HIPEMU
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<0, kJSmall, 256>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
-        (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kJSmall + 1, kJMax, 1024>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
-        attr_set = true;
-    }
-#endif
-    prof_mark(prof, 0, s);
-    hipLaunchKernelGGL((posemb_direct_kernel<0, kJSmall, 256>), dim3(batch_size), dim3(256), lds_small, s, a);
-    hipLaunchKernelGGL((posemb_direct_kernel<kJSmall + 1, kJMax, 1024>), dim3(batch_size), dim3(1024), lds_big, s, a);
-    KryArgs ka;
-    ka.p = a;
-    ka.vws = (float *)workspace;
-    ka.ldv = (int32_t)(((g->node_cap / batch_size + 63) / 64) * 64 + 64);
-    hipLaunchKernelGGL(posemb_krylov_kernel, dim3(batch_size), dim3(kKThreads), (size_t)3 * ka.ldv * sizeof(float), s, ka);
-    prof_mark(prof, 1, s);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_posemb: %s", hipGetErrorString(e)); return -10; }
-    return 0;
+    if (!g) { snprintf(g_err, kErrLen, "gcc_posemb: bad argument"); return -1; }
+    gcc_posemb_view v = {g, pos, evals, raw};
+    return gcc_posemb_multi(&v, 1, batch_size, g->node_cap, hidden, seed, workspace, workspace_bytes, status, prof, stream);
 }
 
 }  // extern "C"

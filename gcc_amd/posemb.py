@@ -28,9 +28,10 @@ class DevicePosEmb:
     batched graph in one launch set (gcc_amd/csrc/posemb.hip).  ``lib``/``ptr`` are
     injectable for the emulator tests only."""
 
-    kind = "device-jacobi+krylov-schur"
+    kind = "device-direct+krylov-schur"
 
-    def __init__(self, batch_size, node_cap, hidden_size=32, device="cuda", seed=0, num_buffers=2, lib=None, ptr=None):
+    def __init__(self, batch_size, node_cap, hidden_size=32, device="cuda", seed=0, num_buffers=2, lib=None, ptr=None,
+                 max_views=1):
         import ctypes
 
         from . import _cabi
@@ -39,7 +40,8 @@ class DevicePosEmb:
         self.lib = lib if lib is not None else _cabi.load()
         self.ptr = ptr if ptr is not None else _cabi.dev_ptr
         self.B, self.hidden, self.seed = int(batch_size), int(hidden_size), int(seed)
-        nbytes = self.lib.gcc_posemb_workspace_bytes(self.B, node_cap, self.hidden)
+        self.node_cap, self.max_views = int(node_cap), int(max_views)
+        nbytes = self.lib.gcc_posemb_multi_workspace_bytes(self.max_views, self.B, node_cap, self.hidden)
         if nbytes < 0:
             raise RuntimeError(self.lib.gcc_last_error().decode())
         self.nbytes = nbytes
@@ -66,6 +68,32 @@ class DevicePosEmb:
             raise RuntimeError(f"gcc_posemb failed ({rc}): {self.lib.gcc_last_error().decode()}")
         graph.pos_undirected = out
         return graph
+
+    def multi(self, graphs, prof=None):
+        """Embed several batched graphs (the views of several future steps) in one set of kernel launches."""
+        if len(graphs) > self.max_views:          # more views than the workspace was sized for: several calls
+            for i in range(0, len(graphs), self.max_views):
+                self.multi(graphs[i:i + self.max_views], prof=prof if i == 0 else None)
+            return graphs
+        views = (self._cabi.GccPosembView * len(graphs))()
+        keep = []
+        for i, graph in enumerate(graphs):
+            out = self._ring[self._next]
+            self._next = (self._next + 1) % len(self._ring)
+            c = self._cabi.GccBatchOut(node_off=self.ptr(graph.node_off), edge_off=0, parent_nid=0, graph_id=0,
+                                       row_ptr=self.ptr(graph.row_ptr), col_idx=self.ptr(graph.col_idx),
+                                       node_cap=out.shape[0], edge_cap=graph.col_idx.numel())
+            keep.append(c)
+            views[i] = self._cabi.GccPosembView(g=self._ct.addressof(c), pos=self.ptr(out), evals=None, raw=None)
+            graph.pos_undirected = out
+        dev = self._ring[0].device
+        st = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+        rc = self.lib.gcc_posemb_multi(views, len(graphs), self.B, self.node_cap, self.hidden, self.seed,
+                                       self.ptr(self.workspace), self.nbytes, self.ptr(self.status),
+                                       prof.handle if prof is not None else None, st)
+        if rc != 0:
+            raise RuntimeError(f"gcc_posemb_multi failed ({rc}): {self.lib.gcc_last_error().decode()}")
+        return graphs
 
     def check_status(self, strict=False):
         """Bit 8 = some large subgraph hit the Krylov restart cap with a Ritz residual above 1e-3 (its

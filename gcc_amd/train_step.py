@@ -65,88 +65,88 @@ def clip_grad_norm(params, max_norm):
 
 
 class BatchProducer:
-    """Runs sampler + positional embedding ahead of the training stream on several HIP streams
-    ("lanes").  Batches are independent, and a producer launch is bound by its slowest subgraph (hub seeds
-    need many eigen-iterations) while most CUs idle, so work from many future steps is kept in flight:
-    lane l owns steps l, l + lanes, ...; each lane has its own stream, sampler/eigensolver workspaces and a
-    ring of ``depth + 1`` output buffers.  This replaces the reference's DataLoader worker pool
-    (train.py:577-586) -- same role, same "prefetch" semantics, no processes."""
+    """Runs sampler + positional embedding ahead of the training stream.  This replaces the reference's DataLoader
+    worker pool (train.py:577-586) -- same role, same "prefetch" semantics, no processes.
 
-    def __init__(self, lanes, first_id_fn, device, depth=2):
-        self.lanes = lanes                      # list of (sampler, posemb) or (sampler, posemb_q, posemb_k)
-        self.first_id = first_id_fn
+    A producer launch is bound by its slowest subgraph (hub seeds need long eigen-iterations) while most CUs idle,
+    so work of many future steps has to be in flight.  The command processor serves FEW queues well: with more than
+    four hardware queues, or with two streams sharing one, the ~75 dependent short kernels of a training step take
+    2-3x longer (tools/contention_probe.py).  So the look-ahead is not spread over many streams; each of a few
+    ``lanes`` (own stream, sampler and eigensolver workspaces) produces a CHUNK of ``chunk`` consecutive steps per
+    turn: ``chunk`` sampler calls, then ONE multi-view positional-embedding call over all 2 * chunk views
+    (gcc_posemb_multi: the eigensolver kernels pull items from work lists over all views).  Chunk c is produced by
+    lane c % lanes into slot (c // lanes) % depth of that lane's buffer rings."""
+
+    def __init__(self, lanes, first_id_fn, device, depth=2, chunk=1):
+        self.lanes = lanes                      # list of (sampler, posemb): sampler ring >= depth * chunk, posemb ring
+        self.first_id = first_id_fn             # >= 2 * depth * chunk buffers, posemb.max_views >= 2 * chunk
         self.dev = device
-        self.depth = depth
+        self.depth, self.chunk = depth, chunk
         self.cuda = torch.device(device).type == "cuda"
         self.streams = [torch.cuda.Stream(device) for _ in lanes] if self.cuda else [None] * len(lanes)
-        # a lane with separate eigensolver workspaces for the two views embeds them on two streams at once
-        self.streams_k = [torch.cuda.Stream(device) if self.cuda and len(l) == 3 else None for l in lanes]
-        self.ready = {}                         # step -> (graphs, event)
-        self.released = {}                      # step -> event recorded on the consumer stream
-        self.next_step = 0
+        self.ready = {}                         # chunk -> (list of (q, k) per step, event)
+        self.released = {}                      # chunk -> event recorded on the consumer stream after its last step
+        self.next_chunk = 0
         self.prof = None
 
-    def _produce(self, step):
-        lane = step % len(self.lanes)
-        sampler, posemb_q = self.lanes[lane][0], self.lanes[lane][1]
-        posemb_k = self.lanes[lane][2] if len(self.lanes[lane]) == 3 else posemb_q
+    def _produce(self, c):
+        sampler, posemb = self.lanes[c % len(self.lanes)][:2]
         pr = self.prof or {}
-        q, k = sampler.sample(self.first_id(step), prof=pr.get("sampler"))
+        if self.prof is not None:
+            self.prof["used"] = True            # this step's marks were recorded (only chunk-launching steps have them)
+        pairs = []
+        for step in range(c * self.chunk, (c + 1) * self.chunk):
+            pairs.append(sampler.sample(self.first_id(step), prof=pr.get("sampler") if step == c * self.chunk else None))
+        views = [g for pair in pairs for g in pair]
         pp = pr.get("posemb")
-        sk = self.streams_k[lane] if self.cuda else None
-        if sk is not None:                      # view k on its own stream, concurrently with view q
-            cur = torch.cuda.current_stream(self.dev)
-            sampled = torch.cuda.Event()
-            sampled.record(cur)
-            with torch.cuda.stream(sk):
-                sk.wait_event(sampled)
-                posemb_k(k)
-                kdone = torch.cuda.Event()
-                kdone.record(sk)
-            posemb_q(q, prof=pp) if pp is not None else posemb_q(q)
-            cur.wait_event(kdone)
-        else:
-            posemb_q(q, prof=pp) if pp is not None else posemb_q(q)
-            posemb_k(k)
-        return q, k
+        if hasattr(posemb, "multi"):
+            posemb.multi(views, prof=pp) if pp is not None else posemb.multi(views)
+        else:                                   # placeholder / CPU stand-ins: one view at a time
+            for g in views:
+                posemb(g)
+        return pairs
 
-    def _launch(self, step):
+    def _launch(self, c):
         if not self.cuda:
-            self.ready[step] = (self._produce(step), None)
+            self.ready[c] = (self._produce(c), None)
             return
-        lane = step % len(self.lanes)
-        ring = self.depth + 1
+        lane = c % len(self.lanes)
         st = self.streams[lane]
         with torch.cuda.stream(st):
-            prev_user = step - len(self.lanes) * ring          # the step whose buffers this one overwrites
+            prev_user = c - len(self.lanes) * self.depth       # the chunk whose buffers this one overwrites
             ev = self.released.pop(prev_user, None)
             if ev is not None:
                 st.wait_event(ev)
-            graphs = self._produce(step)
+            pairs = self._produce(c)
             done = torch.cuda.Event()
             done.record(st)
-        self.ready[step] = (graphs, done)
+        self.ready[c] = (pairs, done)
 
     def get(self, step, prof=None):
-        """Batch of ``step`` (made ready on the current stream); keeps lanes*depth steps in flight."""
+        """Batch of ``step`` (made ready on the current stream); keeps lanes * (depth - 1) chunks in flight."""
         self.prof = prof
-        horizon = step + len(self.lanes) * self.depth
-        if self.next_step < step:
-            self.next_step = step
-        while self.next_step <= horizon:
-            if self.next_step not in self.ready:
-                self._launch(self.next_step)
-            self.next_step += 1
-        graphs, ev = self.ready.pop(step)
+        c = step // self.chunk
+        horizon = c + len(self.lanes) * (self.depth - 1) if self.cuda else c
+        if self.next_chunk < c:
+            self.next_chunk = c
+        while self.next_chunk <= horizon:
+            if self.next_chunk not in self.ready:
+                self._launch(self.next_chunk)
+            self.next_chunk += 1
+        pairs, ev = self.ready[c]
         if ev is not None:
             torch.cuda.current_stream(self.dev).wait_event(ev)
-        return graphs
+            self.ready[c] = (pairs, None)       # later steps of the chunk need no second wait
+        return pairs[step - c * self.chunk]
 
     def release(self, step):
-        if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.dev))
-            self.released[step] = ev
+        c = step // self.chunk
+        if step == (c + 1) * self.chunk - 1:    # last step of its chunk
+            self.ready.pop(c, None)
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.dev))
+                self.released[c] = ev
 
 
 class FlatAdam:
@@ -183,7 +183,7 @@ class FlatAdam:
 class MoCoTrainStep:
     def __init__(self, model: GraphEncoder, model_ema: GraphEncoder, contrast: MemoryMoCo, sampler, posemb,
                  learning_rate=0.005, betas=(0.9, 0.999), weight_decay=1e-5, clip_norm=1.0, alpha=0.999,
-                 world_size=1, rank=0, prefetch=True, extra_lanes=(), depth=2, lanes=None):
+                 world_size=1, rank=0, prefetch=True, extra_lanes=(), depth=2, lanes=None, chunk=1):
         """``sampler``/``posemb``: producer lane 0; ``extra_lanes``: more (sampler, posemb) pairs with their own
         workspaces for multi-stream prefetch (see :class:`BatchProducer`)."""
         self.model, self.ema, self.contrast = model, model_ema, contrast
@@ -219,7 +219,8 @@ class MoCoTrainStep:
         self.main = torch.cuda.Stream(self.dev, priority=-1) if self.prefetch else None
         lanes = list(lanes) if lanes is not None else [(sampler, posemb)] + list(extra_lanes)
         self.producer = BatchProducer(lanes if self.prefetch else lanes[:1], self._first_id,
-                                      self.dev if self.prefetch else "cpu", depth=depth if self.prefetch else 0)
+                                      self.dev if self.prefetch else "cpu", depth=depth if self.prefetch else 1,
+                                      chunk=chunk if self.prefetch else 1)
         if not self.prefetch:
             self.producer.cuda = False
         model.train()                                                    # train.py:357-365

@@ -114,12 +114,16 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p,
  * the k = min(n - 2, hidden) largest-algebraic eigenpairs of D^-1/2 A D^-1/2
  * (D = in-degree clipped at 1), eigenvalues ascending like scipy eigsh(which="LA"),
  * rows L2-normalised, zero-padded to `hidden` columns; k <= 0 gives zeros.
- * Subgraphs with n <= GCC_POSEMB_JACOBI_MAX use a full two-sided Jacobi
- * eigensolver resident in LDS (exact multiplicities); larger ones a thick-restart
- * Krylov-Schur iteration (single start vector, like ARPACK).  Eigenvectors are
- * defined up to sign / rotation inside degenerate eigenspaces; the reference's
- * own output depends on np.random.rand (data_util.py:248). */
+ * Twin leaves are deflated exactly first (their contrasts are null vectors).
+ * Deflated size n' <= GCC_POSEMB_DIRECT_MAX: direct symmetric eigensolver
+ * (tridiagonalisation, bisection, inverse iteration: exact multiplicities), the
+ * matrix in LDS up to GCC_POSEMB_JACOBI_MAX and in a workspace slot above;
+ * larger ones, or when the slots run out, a thick-restart Krylov-Schur iteration
+ * (single start vector, like ARPACK).  Eigenvectors are defined up to sign /
+ * rotation inside degenerate eigenspaces; the reference's own output depends on
+ * np.random.rand (data_util.py:248).  hidden <= 32. */
 #define GCC_POSEMB_JACOBI_MAX 128
+#define GCC_POSEMB_DIRECT_MAX 384
 #define GCC_STATUS_POSEMB_NOT_CONVERGED 8
 int64_t gcc_posemb_workspace_bytes(int32_t batch_size, int64_t node_cap, int32_t hidden);
 /* pos: device [node_cap, hidden] out (rows >= node_off[B] untouched);
@@ -130,6 +134,18 @@ int64_t gcc_posemb_workspace_bytes(int32_t batch_size, int64_t node_cap, int32_t
 int32_t gcc_posemb(const gcc_batch_out *g, int32_t batch_size, int32_t hidden, float *pos, float *evals,
                    float *raw, uint64_t seed, void *workspace, int64_t workspace_bytes, int32_t *status, gcc_prof *prof,
                    void *stream);
+/* The same for several batched graphs (views of several future steps) in ONE set of kernel launches: the
+ * eigensolver kernels pull (view, subgraph) items from per-size-class work lists, so one call keeps the whole
+ * GPU busy and its latency (bound by the slowest subgraph) is paid once.  All views share batch_size and node_cap. */
+#define GCC_POSEMB_MAX_VIEWS 32
+typedef struct gcc_posemb_view {
+    const gcc_batch_out *g;
+    float *pos, *evals, *raw;      /* as for gcc_posemb; evals/raw may be NULL */
+} gcc_posemb_view;
+int64_t gcc_posemb_multi_workspace_bytes(int32_t num_views, int32_t batch_size, int64_t node_cap, int32_t hidden);
+int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_t batch_size, int64_t node_cap,
+                         int32_t hidden, uint64_t seed, void *workspace, int64_t workspace_bytes, int32_t *status,
+                         gcc_prof *prof, void *stream);
 
 /* ------------------------------------------------------------ GIN encoder ---
  * GraphEncoder(gnn_model="gin", degree_input=True).forward of

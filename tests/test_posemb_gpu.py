@@ -1,11 +1,11 @@
-"""Positional embedding on a real MI355X: batched Jacobi (n <= 128) and Krylov-Schur (n > 128)
-kernels vs dense float64 eigendecompositions of every sampled subgraph (invariants, see
-tests/test_posemb_emu.py)."""
+"""Positional embedding on a real MI355X: the direct eigensolver (deflated size <= 384: LDS and workspace
+classes) and the Krylov-Schur fallback vs dense float64 eigendecompositions of every sampled subgraph
+(invariants, see tests/test_posemb_emu.py)."""
 import numpy as np
 import pytest
 import torch
 
-from tests.test_posemb_emu import HID, _check, _check_krylov
+from tests.test_posemb_emu import DIRECT_MAX, HID, _check_krylov, check_by_path, reduced_sizes
 
 pytestmark = pytest.mark.gpu
 
@@ -18,6 +18,7 @@ def _device_posemb(q, B):
     raw = torch.zeros(q.parent_nid.numel(), HID, device="cuda")
     pe(q, evals=evals, raw=raw)
     pe.check_status(strict=True)
+    _device_posemb.arnoldi_steps = int(pe.status[2].item())
     c = q.csr_numpy()
     n = c["node_off"][-1]
     view = dict(node_off=torch.from_numpy(c["node_off"].astype(np.int64)),
@@ -39,22 +40,14 @@ def test_sampled_batch_on_g1_like_graph():
     s.check_status()
     view, x, evals, raw = _device_posemb(q, B)
     sizes = np.diff(view["node_off"].numpy())
-    assert (sizes <= 128).any()
-    small = dict(view)
-    # Jacobi path: strict invariants on the subgraphs with n <= 128 (the helper skips nothing, so mask big ones)
-    keep = sizes <= 128
-    idx = np.where(keep)[0]
-    no = view["node_off"].numpy()
-    for b in idx[:24]:
-        lo, hi = no[b], no[b + 1]
-        sub = dict(node_off=torch.tensor([0, hi - lo]),
-                   row_ptr=view["row_ptr"][lo:hi + 1] - view["row_ptr"][lo],
-                   col_idx=view["col_idx"][view["row_ptr"][lo]:view["row_ptr"][hi]] - lo)
-        _check(sub, x[lo:hi], evals[b:b + 1], raw[lo:hi])
-    _check_krylov(view, x, evals, raw)
+    red = reduced_sizes(view)
+    assert (red <= 64).any() and ((red > 64) & (red <= 128)).any() and ((red > 128) & (red <= DIRECT_MAX)).any(), red
+    # strict invariants (all multiplicities) wherever the direct solver ran: a mix of small and all large subgraphs
+    idx = np.r_[np.where(sizes <= 128)[0][:20], np.where(sizes > 128)[0]]
+    check_by_path(view, x, evals, raw, only=idx)
 
 
-def test_hub_seeds_take_the_krylov_path():
+def test_hub_seeds():
     from gcc_amd.graph import DeviceGraph
     from gcc_amd.graphgen import powerlaw_graph
     from gcc_amd.sampler import DeviceRWRSampler
@@ -67,4 +60,29 @@ def test_hub_seeds_take_the_krylov_path():
     s.check_status()
     view, x, evals, raw = _device_posemb(q, 6)
     assert np.diff(view["node_off"].numpy()).min() > 128
+    check_by_path(view, x, evals, raw)
+
+
+def test_krylov_fallback_on_device():
+    """No twin leaves, n = 700 > GCC_POSEMB_DIRECT_MAX: the Krylov-Schur kernel runs (same case as the emulator test)."""
+    import scipy.sparse as sp
+
+    from gcc_amd.posemb import DevicePosEmb
+    from gcc_amd.sampler import BatchedCSR
+
+    rng = np.random.RandomState(1)
+    n = 700
+    w = 1.0 / np.arange(1, n + 1) ** 0.5
+    pr = np.minimum(1.0, 6.0 * np.outer(w, w) / w.mean())
+    up = np.triu(rng.rand(n, n) < pr, 1)
+    up[np.arange(n - 1), np.arange(1, n)] = True
+    a = sp.csr_matrix((up | up.T).astype(np.float64))
+    a.sort_indices()
+    i32 = dict(dtype=torch.int32, device="cuda")
+    q = BatchedCSR(1, torch.tensor([0, n], **i32), torch.tensor([0, a.nnz], **i32),
+                   torch.zeros(n, **i32), torch.zeros(n, **i32), torch.from_numpy(a.indptr.astype(np.int32)).cuda(),
+                   torch.from_numpy(a.indices.astype(np.int32)).cuda())
+    q.pos_undirected = torch.zeros(n, HID, device="cuda")
+    view, x, evals, raw = _device_posemb(q, 1)
+    assert _device_posemb.arnoldi_steps > 0
     _check_krylov(view, x, evals, raw)

@@ -17,7 +17,7 @@ import argparse
 import os
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # producer lanes (sampler + eigensolver) use their own HIP streams
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")    # few hardware queues: see gcc_amd.train_step.BatchProducer
 
 import numpy as np
 import psutil
