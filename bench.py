@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--posemb", choices=["device", "placeholder"], default="device")
     ap.add_argument("--lanes", type=int, default=3, help="producer streams (sampler + positional embedding)")
+    ap.add_argument("--reserved-cus", type=int, default=0, help="compute units the producer streams are masked off (kept for the training step)")
+    ap.add_argument("--cu-layout", default="interleaved", choices=["interleaved", "block"])
     ap.add_argument("--chunk", type=int, default=8, help="steps a producer lane prepares per turn (one multi-view eigensolver call)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight per producer lane")
     ap.add_argument("--pmc-traffic", type=float, default=None,
@@ -227,7 +229,8 @@ def main():
     # every producer lane: one sampler + one eigensolver workspace, `chunk` steps (2 * chunk views) per turn
     lanes = [(samplers[i], posembs[i]) for i in range(args.lanes)]
     trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank,
-                            lanes=lanes, depth=args.depth, chunk=args.chunk)
+                            lanes=lanes, depth=args.depth, chunk=args.chunk, reserved_cus=args.reserved_cus,
+                            cu_layout=args.cu_layout)
     stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder q+k fwd",
               "moco-infonce fwd", "key all-gather" if world > 1 else "enqueue", "infonce bwd", "gin-encoder bwd",
               "grad all-reduce" if world > 1 else "clip", "adam", "ema"]
@@ -322,7 +325,7 @@ def main():
                        "graph_nodes": int(len(rp) - 1), "graph_edges": int(len(ci)),
                        "batch_size_per_gpu": B, "global_batch": B * world, "nce_k": args.nce_k,
                        "rw_hops": args.rw_hops, "restart_prob": args.restart_prob,
-                       "stages": stages, "producer_lanes": args.lanes, "producer_depth": args.depth, "producer_chunk": args.chunk, "parallelism": f"dp{world} (seed batch sharded, graph replicated)"},
+                       "stages": stages, "producer_lanes": args.lanes, "producer_depth": args.depth, "producer_chunk": args.chunk, "reserved_cus": args.reserved_cus, "parallelism": f"dp{world} (seed batch sharded, graph replicated)"},
             "kernel_ms_isolated": kern_iso, "stage_ms": stage_ms, "final_loss": final_loss, "posemb_status": posemb_status,
             "roofline": {"bound": "hbm", "kernel": dom, "measured": "isolated probe loop after the timed region",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS,

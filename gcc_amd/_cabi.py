@@ -126,6 +126,8 @@ class GccNceArgs(ctypes.Structure):
 SIGNATURES = {
     "gcc_abi_version": (ctypes.c_int32, []),
     "gcc_last_error": (ctypes.c_char_p, []),
+    "gcc_stream_create_cu_mask": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]),
+    "gcc_stream_destroy": (ctypes.c_int32, [ctypes.c_void_p]),
     "gcc_prof_create": (ctypes.c_void_p, [ctypes.c_int32]),
     "gcc_prof_destroy": (None, [ctypes.c_void_p]),
     "gcc_prof_elapsed_ms": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_f32p]),
@@ -135,6 +137,7 @@ SIGNATURES = {
         ctypes.POINTER(GccBatchOut), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
         ctypes.c_void_p]),
     "gcc_posemb_workspace_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32]),
+    "gcc_posemb_debug_ticks": (None, [ctypes.c_void_p]),
     "gcc_posemb_multi_workspace_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32]),
     "gcc_posemb_multi": (ctypes.c_int32, [ctypes.POINTER(GccPosembView), ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                           ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,

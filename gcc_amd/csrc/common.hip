@@ -43,4 +43,37 @@ int32_t gcc_prof_elapsed_ms(gcc_prof *p, int32_t from_mark, int32_t to_mark, flo
     return 0;
 }
 
+int32_t gcc_stream_create_cu_mask(const uint32_t *cu_mask, int32_t words, void **stream)
+{
+    if (!cu_mask || !stream || words < 1 || words > 64) {
+        snprintf(g_err, kErrLen, "gcc_stream_create_cu_mask: bad argument");
+        return -1;
+    }
+#ifdef GCC_AMD_HIPEMU
+    snprintf(g_err, kErrLen, "gcc_stream_create_cu_mask: not available on the emulator");
+    return -2;
+#else
+    hipStream_t s = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, cu_mask);
+    if (e != hipSuccess) {
+        snprintf(g_err, kErrLen, "gcc_stream_create_cu_mask: %s", hipGetErrorString(e));
+        return -10;
+    }
+    *stream = (void *)s;
+    return 0;
+#endif
+}
+
+int32_t gcc_stream_destroy(void *stream)
+{
+#ifndef GCC_AMD_HIPEMU
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) {
+        snprintf(g_err, kErrLen, "gcc_stream_destroy: %s", hipGetErrorString(e));
+        return -10;
+    }
+#endif
+    return 0;
+}
+
 }  // extern "C"

@@ -9,6 +9,8 @@
 
 #ifdef GCC_AMD_HIPEMU
 #define TRAIN_STEP_WAVE_PRIORITY() ((void)0)
+static inline long long device_ticks() { return 0; }
+static inline float fast_rcp(float x) { return 1.0f / x; }
 #include "hipemu.h"
 
 #define DYN_SMEM(name) unsigned char *name = hipemu::g_dyn_smem
@@ -64,12 +66,48 @@ static inline f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c)
     return d;
 }
 
+// ---- wave reductions / scan (shuffle butterflies; the gfx950 build uses DPP row operations)
+// inclusive wave prefix sum (all 64 lanes must call)
+static inline int wave_scan_incl(int v)
+{
+    int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = wave_shfl_up(v, d);
+        if (l >= d) v += t;
+    }
+    return v;
+}
+
+static inline float wave_sum(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += wave_shfl_xor(v, d);
+    return v;
+}
+
+static inline double wave_sum(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += wave_shfl_xor(v, d);
+    return v;
+}
+
+static inline float wave_max(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { float t = wave_shfl_xor(v, d); v = t > v ? t : v; }
+    return v;
+}
+
 #else  // ------------------------------------------------------------ gfx950
 #include <hip/hip_runtime.h>
 
 // Waves of the training step share SIMDs with the data pipeline's long-running eigensolver waves; the
 // step's kernels are short and on the critical path, so their waves take the issue slots first.
 #define TRAIN_STEP_WAVE_PRIORITY() __builtin_amdgcn_s_setprio(3)
+__device__ __forceinline__ long long device_ticks() { return (long long)wall_clock64(); }   // 100 MHz
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }        // v_rcp_f32, 1 ulp
 
 #define DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -93,45 +131,66 @@ __device__ __forceinline__ f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+// ---- wave reductions / scan on DPP row operations (ALU speed; __shfl_* goes through the LDS crossbar, ~60 cycles
+// per step).  row_shr:1,2,4,8 leave an inclusive scan in every row of 16 lanes; row_bcast:15 / row_bcast:31 carry
+// the row totals on.  All 64 lanes must be active.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int dpp_or_zero(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, kCtrl, kRowMask, 0xF, true);
+}
+template <int kCtrl, int kRowMask> __device__ __forceinline__ float dpp_or_zero(float v)
+{
+    return __int_as_float(dpp_or_zero<kCtrl, kRowMask>(__float_as_int(v)));
+}
+template <int kCtrl, int kRowMask> __device__ __forceinline__ double dpp_or_zero(double v)
+{
+    const int lo = dpp_or_zero<kCtrl, kRowMask>(__double2loint(v)), hi = dpp_or_zero<kCtrl, kRowMask>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <class T> __device__ __forceinline__ T wave_scan_incl_dpp(T v)
+{
+    v += dpp_or_zero<0x111, 0xF>(v);      // row_shr:1
+    v += dpp_or_zero<0x112, 0xF>(v);      // row_shr:2
+    v += dpp_or_zero<0x114, 0xF>(v);      // row_shr:4
+    v += dpp_or_zero<0x118, 0xF>(v);      // row_shr:8
+    v += dpp_or_zero<0x142, 0xA>(v);      // row_bcast:15 -> rows 1, 3
+    v += dpp_or_zero<0x143, 0xC>(v);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ int wave_scan_incl(int v) { return wave_scan_incl_dpp(v); }
+__device__ __forceinline__ float wave_sum(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan_incl_dpp(v)), 63));
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v = wave_scan_incl_dpp(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+template <int kCtrl, int kRowMask> __device__ __forceinline__ float dpp_or_self(float v)
+{
+    const int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, kCtrl, kRowMask, 0xF, false));
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+    v = fmaxf(v, dpp_or_self<0x111, 0xF>(v));
+    v = fmaxf(v, dpp_or_self<0x112, 0xF>(v));
+    v = fmaxf(v, dpp_or_self<0x114, 0xF>(v));
+    v = fmaxf(v, dpp_or_self<0x118, 0xF>(v));
+    v = fmaxf(v, dpp_or_self<0x142, 0xA>(v));
+    v = fmaxf(v, dpp_or_self<0x143, 0xC>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 #endif
+
 
 // ------------------------------------------------------------------ common
 __device__ __forceinline__ unsigned long long lanemask_lt()
 {
     return (1ull << lane_id()) - 1ull;
-}
-
-// inclusive wave prefix sum (all 64 lanes must call)
-__device__ __forceinline__ int wave_scan_incl(int v)
-{
-    int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = wave_shfl_up(v, d);
-        if (l >= d) v += t;
-    }
-    return v;
-}
-
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += wave_shfl_xor(v, d);
-    return v;
-}
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += wave_shfl_xor(v, d);
-    return v;
-}
-
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { float t = wave_shfl_xor(v, d); v = t > v ? t : v; }
-    return v;
 }
 
 // Philox4x32-10 (Salmon et al., Random123); identical to oracle/sampler_oracle.c

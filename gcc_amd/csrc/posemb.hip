@@ -34,7 +34,9 @@ struct PosMulti {                    // one launch covers the subgraphs of all v
     int32_t nviews, B, hidden;
     uint64_t seed;
     int32_t *status;
+    long long *ticks;                // diagnostics: [class][phase] wall-clock ticks (NULL = off), gcc_posemb_debug_ticks
 };
+#define PHASE_TICK(ph) do { if (m.ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 
 struct PosArgs {
     const int32_t *node_off, *row_ptr, *col_idx;
@@ -356,8 +358,8 @@ __device__ __forceinline__ int sturm_count(const float *dg, const float *of2, in
     float q = dg[0] - x;
     if (fabsf(q) < 1e-30f) q = -1e-30f;
     int c = q < 0.f ? 1 : 0;
-    for (int i = 1; i < n; ++i) {
-        q = dg[i] - x - of2[i - 1] / q;
+    for (int i = 1; i < n; ++i) {                    // counts tolerate the 1-ulp reciprocal
+        q = dg[i] - x - of2[i - 1] * fast_rcp(q);
         if (fabsf(q) < 1e-30f) q = -1e-30f;
         c += q < 0.f ? 1 : 0;
     }
@@ -381,85 +383,107 @@ __device__ bool inverse_iteration_step(const TriLds &w, int n, int j, int jl, fl
     const int ldu = w.ldu, ldf = w.bw;
     float cd = w.dg[0] - shift, cs = n > 1 ? w.of[0] : 0.f;
     float cy = random_rhs ? hash_unit(hseed, (uint32_t)j, 0u) : Y[0];
+    // forward elimination, branch free: row i is either the running row (cd, cs, 0 | cy) or, when the sub-diagonal
+    // entry is larger, the next row of T - shift (sub, nd, ns | by) and the running row is eliminated instead
+#pragma unroll 4
     for (int i = 0; i + 1 < n; ++i) {
         const float sub = w.of[i], nd = w.dg[i + 1] - shift, ns = i + 2 < n ? w.of[i + 1] : 0.f;
         const float by = random_rhs ? hash_unit(hseed, (uint32_t)j, (uint32_t)(i + 1)) : Y[(i + 1) * kYld];
-        if (fabsf(cd) >= fabsf(sub)) {
-            const float mult = cd != 0.f ? sub / cd : 0.f;
-            Ud[i * ldu] = cd; Us[i * ldu] = cs; Uf[i * ldf] = 0; Y[i * kYld] = cy;
-            cd = nd - mult * cs; cs = ns; cy = by - mult * cy;
-        } else {
-            const float mult = cd / sub;
-            Ud[i * ldu] = sub; Us[i * ldu] = nd; Uf[i * ldf] = 1; Y[i * kYld] = by;
-            cd = cs - mult * nd; cs = -mult * ns; cy = cy - mult * by;
-        }
+        const bool swap = fabsf(cd) < fabsf(sub);
+        const float piv = swap ? sub : cd, oth = swap ? cd : sub;
+        const float mult = piv != 0.f ? oth * fast_rcp(piv) : 0.f;
+        Ud[i * ldu] = piv;
+        Us[i * ldu] = swap ? nd : cs;
+        Uf[i * ldf] = swap ? 1 : 0;
+        Y[i * kYld] = swap ? by : cy;
+        const float ncd = swap ? cs - mult * nd : nd - mult * cs;
+        const float ncs = swap ? -mult * ns : ns;
+        const float ncy = swap ? cy - mult * by : by - mult * cy;
+        cd = ncd; cs = ncs; cy = ncy;
     }
     Ud[(n - 1) * ldu] = cd; Us[(n - 1) * ldu] = 0.f; Uf[(n - 1) * ldf] = 0; Y[(n - 1) * kYld] = cy;
     float x1 = 0.f, x2 = 0.f, ss = 0.f;
+#pragma unroll 4
     for (int i = n - 1; i >= 0; --i) {
         float d = Ud[i * ldu];
         if (fabsf(d) < kPivTiny) d = d < 0.f ? -kPivTiny : kPivTiny;
         const float s2 = (Uf[i * ldf] && i + 2 < n) ? w.of[i + 1] : 0.f;
-        const float x = (Y[i * kYld] - Us[i * ldu] * x1 - s2 * x2) / d;
+        const float x = (Y[i * kYld] - Us[i * ldu] * x1 - s2 * x2) * fast_rcp(d);
         Y[i * kYld] = x;
         x2 = x1; x1 = x;
         ss = fmaf(x, x, ss);
     }
     const bool ok = ss > 0.f && ss < 3.0e38f;
     const float inv = ok ? 1.0f / sqrtf(ss) : 0.f;
+#pragma unroll 4
     for (int i = 0; i < n; ++i) Y[i * kYld] *= inv;
     return ok;
 }
 
-// classical Gram-Schmidt (twice) + normalisation inside every cluster; the t-th members of all clusters are
-// processed together.  Returns (block-uniform) the number of vectors that vanished (were in the span of
-// their predecessors).  All threads call it; ends with a barrier.
+// Gram-Schmidt inside every cluster of close eigenvalues; the t-th members of all clusters are processed together
+// (2 barriers per t).  Vectors stay un-normalised while the sweep runs (projections divide by the squared norms kept
+// in coef[.][32]); a second pass follows only where the first one removed more than half of a vector ("twice is
+// enough", Kahan / Parlett).  Returns (block-uniform) the number of vectors that vanished, i.e. were in the span of
+// their predecessors.  All threads call it; ends with a barrier.
 template <int kT>
 __device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int *cs, const int *posi, int maxpos)
 {
     constexpr int kNW = kT / 64;
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float *Y = w.Y, *coef = w.coef;
+    if (maxpos == 0) return 0;
+    if (tid < na) coef[tid * kYld + 32] = 1.0f;      // squared norms: unit vectors come out of the solves
+    __syncthreads();
     int lost = 0;
     for (int t = 1; t <= maxpos; ++t) {
         for (int pass = 0; pass < 2; ++pass) {
+            // projections on the predecessors in the cluster
             for (int j = 0; j < na; ++j) {
                 if (posi[j] != t) continue;
                 for (int l = cs[j] + wv; l < j; l += kNW) {
                     float s = 0.f;
                     for (int r = lane; r < n; r += 64) s = fmaf(Y[r * kYld + j], Y[r * kYld + l], s);
                     s = wave_sum(s);
-                    if (lane == 0) coef[j * kYld + l] = s;
+                    if (lane == 0) coef[j * kYld + l] = s / fmaxf(coef[l * kYld + 32], 1e-30f);
                 }
             }
             __syncthreads();
+            float *part_sq = (float *)w.cnt;                           // [vector][wave] partial squared norms
             for (int j = 0; j < na; ++j) {
                 if (posi[j] != t) continue;
+                float part = 0.f;
                 for (int i = tid; i < n; i += kT) {
                     float acc = 0.f;
                     for (int l = cs[j]; l < j; ++l) acc = fmaf(coef[j * kYld + l], Y[i * kYld + l], acc);
-                    Y[i * kYld + j] -= acc;
+                    const float y = Y[i * kYld + j] - acc;
+                    Y[i * kYld + j] = y;
+                    part = fmaf(y, y, part);
                 }
+                part = wave_sum(part);
+                if (lane == 0) part_sq[j * kNW + wv] = part;
             }
             __syncthreads();
-        }
-        for (int j = wv; j < na; j += kNW) {
-            if (posi[j] != t) continue;
-            float s = 0.f;
-            for (int r = lane; r < n; r += 64) s = fmaf(Y[r * kYld + j], Y[r * kYld + j], s);
-            s = wave_sum(s);
-            if (lane == 0) coef[j * kYld + 32] = s;
-        }
-        __syncthreads();
-        for (int j = 0; j < na; ++j) {
-            if (posi[j] != t) continue;
-            const float s = coef[j * kYld + 32];
-            if (s < 1e-6f) ++lost;
-            const float inv = 1.0f / sqrtf(fmaxf(s, 1e-30f));
-            for (int i = tid; i < n; i += kT) Y[i * kYld + j] *= inv;
+            // every wave adds the partials up in the same order (lane = vector): identical, deterministic results
+            float now = 0.f;
+            const bool mine = lane < na && posi[lane] == t;
+            if (mine)
+                for (int q = 0; q < kNW; ++q) now += part_sq[lane * kNW + q];
+            // (the vectors enter with unit norm: "before" is 1 in the first pass; nobody reads coef[.][32] of step t here)
+            const bool again = pass == 0 && wave_ballot(mine && now < 0.5f) != 0ull;
+            if (wv == 0 && mine) coef[lane * kYld + 32] = now;
+            if (!again) break;
         }
         __syncthreads();
+        for (int j = 0; j < na; ++j)
+            if (posi[j] == t && coef[j * kYld + 32] < 1e-6f) ++lost;
     }
+    // normalise the members of the clusters
+    for (int j = 0; j < na; ++j) {
+        if (posi[j] == 0) continue;
+        const float inv = 1.0f / sqrtf(fmaxf(coef[j * kYld + 32], 1e-30f));
+        for (int i = tid; i < n; i += kT) Y[i * kYld + j] *= inv;
+    }
+    __syncthreads();
     return lost;
 }
 
@@ -523,6 +547,8 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     item_args(m, gb, a, b);
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
     const int k = min(min(n - 2, a.hidden), kMaxVec);   // data_util.py:278; k >= 1 (classify kernel)
+    long long tick_ = m.ticks ? device_ticks() : 0;
+    if (m.ticks && tid == 0) atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 15], 1ull);   // items
     // ---- LDS carve-up
     TriLds w;
     w.dg = (float *)smem;
@@ -637,7 +663,9 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
         __syncthreads();
     }
 
+    PHASE_TICK(0);                                 // deflation + matrix
     tridiagonalize<kCPL, kT, kGlobalA ? 4 : 2>(A, lda, nr, w);
+    PHASE_TICK(1);
     for (int i = tid; i < nr; i += kT) w.of2[i] = w.of[i] * w.of[i];
     // ---- the kq largest eigenvalues of T: eigenvalue j (descending) has ascending index nr - 1 - j and lies in
     //      [lo, hi] with count(lo) <= nr - 1 - j < count(hi); every round probes kP interior points
@@ -667,6 +695,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
             __syncthreads();
         }
     }
+    PHASE_TICK(2);                                 // bisection
     // ---- ranks (positive, null space = zeros of M' then the z contrasts, negative; eigsh(which="LA") returns the k
     //      largest in ascending order, data_util.py:251), inverse-iteration shifts and clusters
     if (tid < 64) colsrc[tid] = 0;
@@ -710,7 +739,9 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
             }
             __syncthreads();
         }
-        lost = cluster_orthonormalize<kT>(w, nr, na, cs, posi, maxpos);
+        PHASE_TICK(3);                             // inverse iteration
+        if (it > 0) lost = cluster_orthonormalize<kT>(w, nr, na, cs, posi, maxpos);   // the first solve only enters the
+        PHASE_TICK(4);                             // cluster subspaces; Gram-Schmidt after the second and third
     }
     if (tid == 0 && (lost > 0 || sh_bad)) atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
     // ---- eigenvectors of M': x = H_0 ... H_{nr-3} y; one wave per pair of vectors, the vectors in registers
@@ -751,6 +782,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
         }
     }
     __syncthreads();
+    PHASE_TICK(5);                                 // back-transformation
     // ---- expand to the n original nodes; x = normalize(u, "l2") row-wise, zero padded (data_util.py:260-262)
     for (int v = wv; v < n; v += kNW) {
         const int pv = d.par[v];
@@ -778,6 +810,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
             if (a.raw) a.raw[(int64_t)(n0 + v) * a.hidden + lane] = val;
         }
     }
+    PHASE_TICK(6);                                 // expansion
     }   // next item
 }
 
@@ -838,6 +871,10 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
     PosArgs a;
     int b;
     item_args(ka.m, gb, a, b);
+    const PosMulti &m = ka.m;
+    constexpr int kCls = kClsKrylov;
+    long long tick_ = m.ticks ? device_ticks() : 0;
+    if (m.ticks && tid == 0) atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 15], 1ull);   // items
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
     const int ldv = ka.ldv;
     float *V = ka.vws + (int64_t)blockIdx.x * 2 * (kM + 1) * ldv;     // the workgroup's own basis storage
@@ -952,6 +989,7 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
             for (int r = tid; r < n; r += kKThreads) V[(int64_t)(j + 1) * ldv + r] = w[r] / nrm;
             __syncthreads();
         }
+        PHASE_TICK(0);                               // Arnoldi steps
         // Rayleigh-Ritz on the symmetric part of H
         for (int i = tid; i < kM * lda; i += kKThreads) {
             const int r = i / lda, c = i - r * lda;
@@ -963,6 +1001,7 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
         __syncthreads();
         jacobi_lds(Aj, Yj, kM, lda, rot, pq, &flag, 2e-6f);     // Ritz values are only needed to ~1e-5
         __syncthreads();
+        PHASE_TICK(1);                               // Ritz pairs of H
         if (tid < kM) theta[tid] = Aj[tid * lda + tid];
         if (tid == 0) done = 1;
         __syncthreads();
@@ -1017,6 +1056,7 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
             __syncthreads();
             float *tmp = V; V = Valt; Valt = tmp;
             j = keep;
+            PHASE_TICK(2);                           // restart compression
             continue;
         }
         // final: u_t = V Y[:, colsrc[t]] -> raw eigenvectors, then normalize(u, "l2") rows, zero padding
@@ -1055,6 +1095,7 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
         if (a.evals) for (int c = k + tid; c < a.hidden; c += kKThreads) a.evals[(int64_t)b * a.hidden + c] = 0.f;
         break;
     }
+    PHASE_TICK(3);                                   // final Ritz vectors
     if (tid == 0) {                                  // diagnostics: status[1] = max restart cycles, status[2] = Arnoldi steps
         atomicMax(a.status + 1, cycle + 1);
         atomicAdd(a.status + 2, steps);
@@ -1066,6 +1107,7 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
 
 extern "C" {
 
+static long long *g_posemb_ticks = nullptr;
 struct PosGrids { int32_t small, mid, slot, kry; };
 static PosGrids posemb_grids(int64_t T)
 {
@@ -1119,6 +1161,7 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
         m.v[i] = {views[i].g->node_off, views[i].g->row_ptr, views[i].g->col_idx, views[i].pos, views[i].evals, views[i].raw};
     }
     m.nviews = num_views; m.B = batch_size; m.hidden = hidden; m.seed = seed; m.status = status;
+    m.ticks = g_posemb_ticks;
     const int64_t T = (int64_t)num_views * batch_size;
     const PosGrids g = posemb_grids(T);
     hipStream_t s = (hipStream_t)stream;
@@ -1160,6 +1203,11 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_posemb: %s", hipGetErrorString(e)); return -10; }
     return 0;
+}
+
+void gcc_posemb_debug_ticks(long long *device_ticks64)   /* device int64[4 * 16] or NULL; diagnostics only */
+{
+    g_posemb_ticks = device_ticks64;
 }
 
 int32_t gcc_posemb(const gcc_batch_out *g, int32_t batch_size, int32_t hidden, float *pos, float *evals,

@@ -77,13 +77,19 @@ class BatchProducer:
     (gcc_posemb_multi: the eigensolver kernels pull items from work lists over all views).  Chunk c is produced by
     lane c % lanes into slot (c // lanes) % depth of that lane's buffer rings."""
 
-    def __init__(self, lanes, first_id_fn, device, depth=2, chunk=1):
+    def __init__(self, lanes, first_id_fn, device, depth=2, chunk=1, reserved_cus=0, cu_layout="interleaved"):
         self.lanes = lanes                      # list of (sampler, posemb): sampler ring >= depth * chunk, posemb ring
         self.first_id = first_id_fn             # >= 2 * depth * chunk buffers, posemb.max_views >= 2 * chunk
         self.dev = device
         self.depth, self.chunk = depth, chunk
         self.cuda = torch.device(device).type == "cuda"
-        self.streams = [torch.cuda.Stream(device) for _ in lanes] if self.cuda else [None] * len(lanes)
+        self._owners = []
+        if self.cuda and reserved_cus:          # producers stay off `reserved_cus` compute units (gcc_amd/streams.py)
+            from .streams import MaskedStream, producer_cus
+            self._owners = [MaskedStream(device, producer_cus(reserved_cus, cu_layout)) for _ in lanes]
+            self.streams = [o.stream for o in self._owners]
+        else:
+            self.streams = [torch.cuda.Stream(device) for _ in lanes] if self.cuda else [None] * len(lanes)
         self.ready = {}                         # chunk -> (list of (q, k) per step, event)
         self.released = {}                      # chunk -> event recorded on the consumer stream after its last step
         self.next_chunk = 0
@@ -183,7 +189,7 @@ class FlatAdam:
 class MoCoTrainStep:
     def __init__(self, model: GraphEncoder, model_ema: GraphEncoder, contrast: MemoryMoCo, sampler, posemb,
                  learning_rate=0.005, betas=(0.9, 0.999), weight_decay=1e-5, clip_norm=1.0, alpha=0.999,
-                 world_size=1, rank=0, prefetch=True, extra_lanes=(), depth=2, lanes=None, chunk=1):
+                 world_size=1, rank=0, prefetch=True, extra_lanes=(), depth=2, lanes=None, chunk=1, reserved_cus=0, cu_layout="interleaved"):
         """``sampler``/``posemb``: producer lane 0; ``extra_lanes``: more (sampler, posemb) pairs with their own
         workspaces for multi-stream prefetch (see :class:`BatchProducer`)."""
         self.model, self.ema, self.contrast = model, model_ema, contrast
@@ -214,13 +220,11 @@ class MoCoTrainStep:
         self.prefetch = prefetch and self.dev.type == "cuda"
         # the ~75 short training kernels of a step must not queue behind the producers' millisecond-long
         # eigensolver workgroups: the step runs on a high-priority stream
-        # (CU-masked streams were tried to partition the chip instead: with ~25 masked streams the queues get
-        # time-sliced and a step takes 5x longer)
         self.main = torch.cuda.Stream(self.dev, priority=-1) if self.prefetch else None
         lanes = list(lanes) if lanes is not None else [(sampler, posemb)] + list(extra_lanes)
         self.producer = BatchProducer(lanes if self.prefetch else lanes[:1], self._first_id,
                                       self.dev if self.prefetch else "cpu", depth=depth if self.prefetch else 1,
-                                      chunk=chunk if self.prefetch else 1)
+                                      chunk=chunk if self.prefetch else 1, reserved_cus=reserved_cus, cu_layout=cu_layout)
         if not self.prefetch:
             self.producer.cuda = False
         model.train()                                                    # train.py:357-365

@@ -49,6 +49,16 @@ void gcc_prof_destroy(gcc_prof *p);
 /* milliseconds between two recorded marks; synchronises on `to_mark`. */
 int32_t gcc_prof_elapsed_ms(gcc_prof *p, int32_t from_mark, int32_t to_mark, float *ms);
 
+/* -------------------------------------------------------------- streams ---
+ * A HIP stream whose kernels may only run on the compute units set in
+ * `cu_mask` (bit i of word i / 32; `words` 32-bit words, 256 CUs = 8 words).
+ * The host layer gives the (few) data-pipeline streams a mask that leaves some
+ * compute units to the training step alone (the reference gets this isolation
+ * for free: its pipeline runs on CPU workers, train.py:577-586).
+ * Returns 0 and the hipStream_t in *stream. */
+int32_t gcc_stream_create_cu_mask(const uint32_t *cu_mask, int32_t words, void **stream);
+int32_t gcc_stream_destroy(void *stream);
+
 /* ---------------------------------------------------------------- graph ---
  * The parent graph in the layout x2dgl.py:39-62 guarantees (symmetric, no self
  * loops, no duplicates, no zero-degree nodes, rows sorted), resident in HBM.
@@ -146,6 +156,11 @@ int64_t gcc_posemb_multi_workspace_bytes(int32_t num_views, int32_t batch_size, 
 int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_t batch_size, int64_t node_cap,
                          int32_t hidden, uint64_t seed, void *workspace, int64_t workspace_bytes, int32_t *status,
                          gcc_prof *prof, void *stream);
+
+/* diagnostics: subsequent gcc_posemb* calls add wall-clock ticks (100 MHz) per solver class and phase into
+ * device int64[4][16] (phases 0..6 = matrix, tridiagonalise, bisect, inverse iteration, Gram-Schmidt,
+ * back-transform, expand; [15] = items); NULL switches it off. */
+void gcc_posemb_debug_ticks(long long *device_ticks64);
 
 /* ------------------------------------------------------------ GIN encoder ---
  * GraphEncoder(gnn_model="gin", degree_input=True).forward of

@@ -1,0 +1,36 @@
+"""Per-phase wall-clock ticks of the positional-embedding solver classes on a real sampled chunk (isolated GPU)."""
+import sys
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from gcc_amd import _cabi
+from gcc_amd.graph import DeviceGraph
+from gcc_amd.graphgen import powerlaw_graph
+from gcc_amd.posemb import DevicePosEmb
+from gcc_amd.sampler import DeviceRWRSampler
+
+dev = torch.device("cuda:0")
+rp, ci = powerlaw_graph(1_000_000, 10_000_000, seed=0)
+graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False)
+B, S = 256, 8
+sampler = DeviceRWRSampler(graph, B, run_seed=0, num_buffers=S)
+pe = DevicePosEmb(B, sampler.node_cap, 32, device=dev, seed=0, num_buffers=S, max_views=2 * S)
+views = [g for s in range(S) for g in sampler.sample(10_000_000 + s * B)]
+lib = _cabi.load()
+ticks = torch.zeros(64, dtype=torch.int64, device=dev)
+pe.multi(views); torch.cuda.synchronize()
+lib.gcc_posemb_debug_ticks(ticks.data_ptr())
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); pe.multi(views); e1.record(); torch.cuda.synchronize()
+lib.gcc_posemb_debug_ticks(None)
+t = ticks.cpu().numpy().reshape(4, 16)
+print("multi call of %d views: %.2f ms" % (len(views), e0.elapsed_time(e1)))
+names = {0: ["matrix", "tridiag", "bisect", "invit", "gram-schmidt", "backtransf", "expand"], 3: ["arnoldi", "ritz(H)", "restart", "final"]}
+for c, cname in enumerate(["small", "mid", "slot", "krylov"]):
+    items = max(int(t[c, 15]), 1)
+    ph = names[3] if c == 3 else names[0]
+    tot = t[c, :len(ph)].sum() / 100.0          # us
+    print(f"{cname:7s} items {items:5d}  total {tot/1e3:8.2f} CU-ms  per item {tot/items:8.1f} us  | " +
+          "  ".join(f"{n} {t[c, i]/100.0/items:7.1f}" for i, n in enumerate(ph)))
+print("status", pe.status.cpu().tolist())
