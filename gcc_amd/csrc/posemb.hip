@@ -6,23 +6,18 @@
 //
 // Sampled ego-nets are star-like: ~75 % of them have FEWER than 32 positive eigenvalues, the
 // rest of the "top 32" is a large degenerate null space, and exact multiplicities occur among
-// the positive eigenvalues too.  Single-vector Krylov methods cannot resolve multiplicities, so
-// subgraphs that fit in LDS (n <= 128, ~85 % at rw_hops 256) get a FULL symmetric eigensolver:
-//   posemb_jacobi_kernel   one workgroup per subgraph; dense A = D^-1/2 Adj D^-1/2 and the
-//       accumulated rotations V live in LDS (2 x 66 KiB at n = 128, odd row stride -> column
-//       sweeps are bank-conflict free); two-sided Jacobi with round-robin (tournament) ordering:
-//       n/2 disjoint rotations per step, 3 barriers per step, threshold sweeps until no rotation
-//       above 1e-7 ||A||_F remains.  Robust for degenerate spectra, eigenvectors orthonormal to
-//       rounding.
-// Larger subgraphs (hub seeds) use posemb_krylov_kernel (see below).
+// the positive eigenvalues too.  Pipeline of one call (any number of views, see gcc_posemb_multi):
+//   posemb_classify_kernel  deflated size n' of every subgraph (twin leaves collapse) -> work lists
+//   posemb_direct_kernel    n' <= 384: dense symmetric eigensolver (tridiagonalise, bisect, inverse
+//                           iteration): exact multiplicities, deterministic run time; three size classes
+//   posemb_krylov_kernel    larger ones: thick-restart Krylov-Schur, Ritz problem by the same solver core
 #include "host_common.h"
 
 namespace {
 
 constexpr int kJMax = GCC_POSEMB_JACOBI_MAX;
-constexpr int kMaxSweeps = 14;
-constexpr int kJSmall = 64;        // size classes of the Jacobi kernel: n <= 64 needs 33 KiB of LDS (4 workgroups per CU,
-                                   // 256 threads), 65..128 needs 132 KiB (1 per CU, 1024 threads hide the LDS round trips)
+constexpr int kJSmall = 64;        // LDS-resident size classes of the direct solver: n' <= 64 (256 threads, ~60 KiB of LDS)
+                                   // and 65..kJMax (1024 threads, ~150 KiB)
 
 constexpr int kMaxViews = GCC_POSEMB_MAX_VIEWS;
 struct PosView {
@@ -49,118 +44,6 @@ struct PosArgs {
 };
 
 __device__ __forceinline__ void item_args(const PosMulti &m, int item, struct PosArgs &a, int &b);
-
-// ---- symmetric eigen-decomposition of the LDS matrix A (np x np, np even, row stride lda) by
-// two-sided Jacobi; V (same shape) accumulates the rotations (V = I on entry if want_vectors).
-// On exit diag(A) = eigenvalues, columns of V = eigenvectors.  All threads of the block call it.
-__device__ void jacobi_lds(float *A, float *V, int np, int lda, float *rot /* [np] (c,s) pairs */,
-                           int *pq /* [np] (p,q) pairs */, int *flag /* LDS */, float tol)
-{
-    const int tid = (int)threadIdx.x;
-    const int half = np >> 1, ring = np - 1;
-    // division-free task mapping: lanes run along a row/column (rw of them), thread groups over pairs
-    const int rw_log = np <= 64 ? 6 : 7;                 // np <= 128
-    const int r = tid & ((1 << rw_log) - 1), pg = tid >> rw_log, npg = (int)blockDim.x >> rw_log;
-    const bool active = r < np;
-    for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
-        if (tid == 0) *flag = 0;
-        __syncthreads();
-        for (int s = 0; s < ring; ++s) {
-            // (i) the np/2 disjoint pairs of this step (round-robin tournament) and their rotations
-            if (tid < half) {
-                const int p0 = tid == 0 ? ring : (s + tid) % ring;
-                const int q0 = tid == 0 ? s : (s - tid + ring) % ring;
-                const int p = p0 < q0 ? p0 : q0, q = p0 < q0 ? q0 : p0;
-                const float apq = A[p * lda + q];
-                float c = 1.f, sn = 0.f;
-                if (fabsf(apq) > tol) {
-                    const float tau = (A[q * lda + q] - A[p * lda + p]) / (2.f * apq);
-                    const float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
-                    c = 1.f / sqrtf(1.f + t * t);
-                    sn = t * c;
-                    *flag = 1;
-                }
-                rot[2 * tid] = c;
-                rot[2 * tid + 1] = sn;
-                pq[2 * tid] = p;
-                pq[2 * tid + 1] = q;
-            }
-            __syncthreads();
-            // (ii) columns p, q of A and of V:  X <- X J      (lane = row: stride lda is odd, conflict free)
-            // 4 disjoint pairs per iteration so that 16 LDS loads are in flight per lane
-            if (active) {
-                for (int pr0 = pg; pr0 < half; pr0 += 4 * npg) {
-                    float c[4], sn[4], x[4], y[4], vx[4], vy[4];
-                    int p[4], q[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int pr = pr0 + u * npg;
-                        const bool ok = pr < half;
-                        sn[u] = ok ? rot[2 * pr + 1] : 0.f;
-                        c[u] = ok ? rot[2 * pr] : 1.f;
-                        p[u] = ok ? pq[2 * pr] : 0;
-                        q[u] = ok ? pq[2 * pr + 1] : 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        x[u] = A[r * lda + p[u]]; y[u] = A[r * lda + q[u]];
-                        vx[u] = V[r * lda + p[u]]; vy[u] = V[r * lda + q[u]];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (sn[u] != 0.f) {
-                            A[r * lda + p[u]] = c[u] * x[u] - sn[u] * y[u];
-                            A[r * lda + q[u]] = sn[u] * x[u] + c[u] * y[u];
-                            V[r * lda + p[u]] = c[u] * vx[u] - sn[u] * vy[u];
-                            V[r * lda + q[u]] = sn[u] * vx[u] + c[u] * vy[u];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            // (iii) rows p, q of A:  A <- J^T A             (lane = column: contiguous)
-            if (active) {
-                for (int pr0 = pg; pr0 < half; pr0 += 4 * npg) {
-                    float c[4], sn[4], x[4], y[4];
-                    int p[4], q[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int pr = pr0 + u * npg;
-                        const bool ok = pr < half;
-                        sn[u] = ok ? rot[2 * pr + 1] : 0.f;
-                        c[u] = ok ? rot[2 * pr] : 1.f;
-                        p[u] = ok ? pq[2 * pr] : 0;
-                        q[u] = ok ? pq[2 * pr + 1] : 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { x[u] = A[p[u] * lda + r]; y[u] = A[q[u] * lda + r]; }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (sn[u] != 0.f) {
-                            A[p[u] * lda + r] = c[u] * x[u] - sn[u] * y[u];
-                            A[q[u] * lda + r] = sn[u] * x[u] + c[u] * y[u];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        if (*flag == 0) break;      // block-uniform (read after the barrier that ends the last step)
-        __syncthreads();
-    }
-}
-
-// rank of eigenvalue i among `n` (0 = largest; ties by index)
-__device__ __forceinline__ int rank_desc(const float *lam, int n, int i)
-{
-    const float li = lam[i];
-    int r = 0;
-    for (int j = 0; j < n; ++j) {
-        const float lj = lam[j];
-        r += (lj > li || (lj == li && j < i)) ? 1 : 0;
-    }
-    return r;
-}
 
 // ---- exact leaf deflation.  Degree-1 nodes that share a parent p are twins: with t of them, the
 // t - 1 contrast vectors on the leaves are exact null vectors of M = D^-1/2 A D^-1/2, and the rest of
@@ -191,9 +74,11 @@ struct Defl {
 // it in a workspace slot (rows are streamed coalesced, 4 n'^3 bytes in total; one CU sustains ~40 GB/s
 // from beyond its L2, which is what bounds this class and why it stops at 384) with the tridiagonal
 // data and the eigenvectors in LDS.
-constexpr int kYld = 33;             // row stride of Y ([i][j], j < 32): conflict free both for "lane = vector" (solves)
-                                     // and for "lane = row" (dots, back-transformation)
+constexpr int kYld = 33;             // row stride of Y ([i][j], j < 32): odd, so conflict free both for "lane = vector"
+                                     // (solves) and for "lane = row" (dots, back-transformation); the Krylov kernel's
+                                     // Ritz problem wants up to 40 vectors and uses stride 65 (TriLds::ldy)
 constexpr int kMaxVec = 32;          // hidden <= 32 on this path (GCC: positional_embedding_size = 32)
+constexpr int kVecCap = 64;          // most eigenvectors the solver core handles
 constexpr float kOrtol = 1e-3f;      // eigenvalues closer than this are re-orthogonalised against each other
 constexpr float kSep = 2e-6f;        // minimum distance between two inverse-iteration shifts
 constexpr float kPivTiny = 1.2e-7f;  // pivots of T - shift are clamped to eps * ||T||  (||T|| <= 1)
@@ -236,12 +121,19 @@ __host__ __device__ constexpr int direct_lds_bytes()
 struct TriLds {
     float *dg, *of, *of2, *tau;      // [kNMax] diagonal, off-diagonal, its square, reflector scales
     float *pbuf, *vbuf;              // [kNMax]
-    float *coef;                     // [32][kYld] Gram-Schmidt coefficients; column 32 = squared norm
+    float *coef;                     // [nv][ldy] Gram-Schmidt coefficients; column ldy - 1 = squared norm  (nv = ldy - 1 vectors)
     int *cnt;                        // [kT] Sturm counts of one bisection round
-    float *Y;                        // [n'][kYld] eigenvectors
+    float *Y;                        // [n'][ldy] eigenvectors
+    int ldy;
     float *Ud, *Us;                  // [n'][bw + 1] LU factors of the current batch of bw inverse iterations
     uint8_t *Uf;                     // [n'][bw]
     int bw, ldu;
+};
+
+struct EigShared {                   // per-workgroup scratch of the solver core (a __shared__ object of the kernel)
+    float lamv[kVecCap], shiftv[kVecCap], lo[kVecCap], hi[kVecCap];
+    int cs[kVecCap], posi[kVecCap];
+    int na, maxpos, bad;
 };
 
 // A (n x n, symmetric, both triangles kept, row stride lda) -> T = Q^T A Q; Q = H_0 H_1 ... H_{n-3},
@@ -380,7 +272,7 @@ __device__ bool inverse_iteration_step(const TriLds &w, int n, int j, int jl, fl
 {
     float *Y = w.Y + j, *Ud = w.Ud + jl, *Us = w.Us + jl;
     uint8_t *Uf = w.Uf + jl;
-    const int ldu = w.ldu, ldf = w.bw;
+    const int ldu = w.ldu, ldf = w.bw, ldy = w.ldy;
     float cd = w.dg[0] - shift, cs = n > 1 ? w.of[0] : 0.f;
     float cy = random_rhs ? hash_unit(hseed, (uint32_t)j, 0u) : Y[0];
     // forward elimination, branch free: row i is either the running row (cd, cs, 0 | cy) or, when the sub-diagonal
@@ -388,35 +280,35 @@ __device__ bool inverse_iteration_step(const TriLds &w, int n, int j, int jl, fl
 #pragma unroll 4
     for (int i = 0; i + 1 < n; ++i) {
         const float sub = w.of[i], nd = w.dg[i + 1] - shift, ns = i + 2 < n ? w.of[i + 1] : 0.f;
-        const float by = random_rhs ? hash_unit(hseed, (uint32_t)j, (uint32_t)(i + 1)) : Y[(i + 1) * kYld];
+        const float by = random_rhs ? hash_unit(hseed, (uint32_t)j, (uint32_t)(i + 1)) : Y[(i + 1) * ldy];
         const bool swap = fabsf(cd) < fabsf(sub);
         const float piv = swap ? sub : cd, oth = swap ? cd : sub;
         const float mult = piv != 0.f ? oth * fast_rcp(piv) : 0.f;
         Ud[i * ldu] = piv;
         Us[i * ldu] = swap ? nd : cs;
         Uf[i * ldf] = swap ? 1 : 0;
-        Y[i * kYld] = swap ? by : cy;
+        Y[i * ldy] = swap ? by : cy;
         const float ncd = swap ? cs - mult * nd : nd - mult * cs;
         const float ncs = swap ? -mult * ns : ns;
         const float ncy = swap ? cy - mult * by : by - mult * cy;
         cd = ncd; cs = ncs; cy = ncy;
     }
-    Ud[(n - 1) * ldu] = cd; Us[(n - 1) * ldu] = 0.f; Uf[(n - 1) * ldf] = 0; Y[(n - 1) * kYld] = cy;
+    Ud[(n - 1) * ldu] = cd; Us[(n - 1) * ldu] = 0.f; Uf[(n - 1) * ldf] = 0; Y[(n - 1) * ldy] = cy;
     float x1 = 0.f, x2 = 0.f, ss = 0.f;
 #pragma unroll 4
     for (int i = n - 1; i >= 0; --i) {
         float d = Ud[i * ldu];
         if (fabsf(d) < kPivTiny) d = d < 0.f ? -kPivTiny : kPivTiny;
         const float s2 = (Uf[i * ldf] && i + 2 < n) ? w.of[i + 1] : 0.f;
-        const float x = (Y[i * kYld] - Us[i * ldu] * x1 - s2 * x2) * fast_rcp(d);
-        Y[i * kYld] = x;
+        const float x = (Y[i * ldy] - Us[i * ldu] * x1 - s2 * x2) * fast_rcp(d);
+        Y[i * ldy] = x;
         x2 = x1; x1 = x;
         ss = fmaf(x, x, ss);
     }
     const bool ok = ss > 0.f && ss < 3.0e38f;
     const float inv = ok ? 1.0f / sqrtf(ss) : 0.f;
 #pragma unroll 4
-    for (int i = 0; i < n; ++i) Y[i * kYld] *= inv;
+    for (int i = 0; i < n; ++i) Y[i * ldy] *= inv;
     return ok;
 }
 
@@ -431,8 +323,9 @@ __device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int 
     constexpr int kNW = kT / 64;
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float *Y = w.Y, *coef = w.coef;
+    const int ldy = w.ldy, nc = w.ldy - 1;                  // coefficient rows have stride ldy, the norms sit in column nc
     if (maxpos == 0) return 0;
-    if (tid < na) coef[tid * kYld + 32] = 1.0f;      // squared norms: unit vectors come out of the solves
+    if (tid < na) coef[tid * ldy + nc] = 1.0f;      // squared norms: unit vectors come out of the solves
     __syncthreads();
     int lost = 0;
     for (int t = 1; t <= maxpos; ++t) {
@@ -442,9 +335,9 @@ __device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int 
                 if (posi[j] != t) continue;
                 for (int l = cs[j] + wv; l < j; l += kNW) {
                     float s = 0.f;
-                    for (int r = lane; r < n; r += 64) s = fmaf(Y[r * kYld + j], Y[r * kYld + l], s);
+                    for (int r = lane; r < n; r += 64) s = fmaf(Y[r * ldy + j], Y[r * ldy + l], s);
                     s = wave_sum(s);
-                    if (lane == 0) coef[j * kYld + l] = s / fmaxf(coef[l * kYld + 32], 1e-30f);
+                    if (lane == 0) coef[j * ldy + l] = s / fmaxf(coef[l * ldy + nc], 1e-30f);
                 }
             }
             __syncthreads();
@@ -454,9 +347,9 @@ __device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int 
                 float part = 0.f;
                 for (int i = tid; i < n; i += kT) {
                     float acc = 0.f;
-                    for (int l = cs[j]; l < j; ++l) acc = fmaf(coef[j * kYld + l], Y[i * kYld + l], acc);
-                    const float y = Y[i * kYld + j] - acc;
-                    Y[i * kYld + j] = y;
+                    for (int l = cs[j]; l < j; ++l) acc = fmaf(coef[j * ldy + l], Y[i * ldy + l], acc);
+                    const float y = Y[i * ldy + j] - acc;
+                    Y[i * ldy + j] = y;
                     part = fmaf(y, y, part);
                 }
                 part = wave_sum(part);
@@ -470,21 +363,152 @@ __device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int 
                 for (int q = 0; q < kNW; ++q) now += part_sq[lane * kNW + q];
             // (the vectors enter with unit norm: "before" is 1 in the first pass; nobody reads coef[.][32] of step t here)
             const bool again = pass == 0 && wave_ballot(mine && now < 0.5f) != 0ull;
-            if (wv == 0 && mine) coef[lane * kYld + 32] = now;
+            if (wv == 0 && mine) coef[lane * ldy + nc] = now;
             if (!again) break;
         }
         __syncthreads();
         for (int j = 0; j < na; ++j)
-            if (posi[j] == t && coef[j * kYld + 32] < 1e-6f) ++lost;
+            if (posi[j] == t && coef[j * ldy + nc] < 1e-6f) ++lost;
     }
     // normalise the members of the clusters
     for (int j = 0; j < na; ++j) {
         if (posi[j] == 0) continue;
-        const float inv = 1.0f / sqrtf(fmaxf(coef[j * kYld + 32], 1e-30f));
-        for (int i = tid; i < n; i += kT) Y[i * kYld + j] *= inv;
+        const float inv = 1.0f / sqrtf(fmaxf(coef[j * ldy + nc], 1e-30f));
+        for (int i = tid; i < n; i += kT) Y[i * ldy + j] *= inv;
     }
     __syncthreads();
     return lost;
+}
+
+// ---- the kq largest eigenvalues of T: eigenvalue j (descending) has ascending index nr - 1 - j and lies in [lo, hi]
+// with count(lo) <= nr - 1 - j < count(hi); every round probes kT / kVec interior points per eigenvalue.  On exit
+// es.lamv[0..kq) holds them in descending order.  The spectrum must lie inside (-1.001, 1.001) (normalised adjacency
+// matrices and their Rayleigh-Ritz projections).  All threads call it; ends with a barrier.
+template <int kT, int kVec>
+__device__ void eig_top_values(const TriLds &w, int nr, int kq, EigShared &es)
+{
+    constexpr int kP = kT / kVec;
+    constexpr int kRounds = kP >= 32 ? 6 : (kP >= 16 ? 7 : 9);         // 2.002 / (kP + 1)^rounds < 1e-8
+    const int tid = (int)threadIdx.x;
+    for (int i = tid; i < nr; i += kT) w.of2[i] = w.of[i] * w.of[i];
+    if (tid < kVec) { es.lo[tid] = -1.001f; es.hi[tid] = 1.001f; }
+    __syncthreads();
+    const int j = tid / kP, ip = tid - j * kP;
+    for (int round = 0; round < kRounds; ++round) {
+        const float xlo = es.lo[j], xhi = es.hi[j];
+        const float step = (xhi - xlo) * (1.0f / (float)(kP + 1));
+        const float x = xlo + step * (float)(ip + 1);
+        const int c = j < kq ? sturm_count(w.dg, w.of2, nr, x) : 0;
+        w.cnt[tid] = c;
+        __syncthreads();
+        if (j < kq) {
+            const int tgt = nr - 1 - j;
+            const bool above = c > tgt;
+            const bool prev_above = ip > 0 && w.cnt[tid - 1] > tgt;
+            if (above && !prev_above) {
+                es.hi[j] = x;
+                if (ip > 0) es.lo[j] = xlo + step * (float)ip;
+            }
+            if (ip == kP - 1 && !above) es.lo[j] = x;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        for (int q = 0; q < kq; ++q) {
+            float l = 0.5f * (es.lo[q] + es.hi[q]);
+            if (q > 0 && l > es.lamv[q - 1]) l = es.lamv[q - 1];
+            es.lamv[q] = l;
+        }
+        es.bad = 0;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void phase_tick(long long *row, int ph, long long &tick)
+{
+    if (row && threadIdx.x == 0) {
+        const long long now = device_ticks();
+        atomicAdd((unsigned long long *)&row[ph], (unsigned long long)(now - tick));
+        tick = now;
+    }
+}
+
+// ---- eigenvectors 0 .. na-1 (of the eigenvalues es.lamv, descending) of the matrix that tridiagonalize() reduced:
+// inverse iteration on T (shifts at least kSep apart; three solves, Gram-Schmidt inside clusters of eigenvalues closer
+// than kOrtol after the second and third), then x = H_0 ... H_{nr-3} y with one wave per pair of vectors, the vectors in
+// registers.  Result in w.Y[i * ldy + j].  Returns (block-uniform) true if a vector could not be produced.
+template <int kCPL, int kT>
+__device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const TriLds &w, EigShared &es, uint32_t hseed,
+                                long long *tick_row, long long &tick)
+{
+    constexpr int kNW = kT / 64;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ldy = w.ldy;
+    if (tid == 0) {
+        int maxpos = 0;
+        for (int j = 0; j < na; ++j) {
+            const float l = es.lamv[j];
+            es.shiftv[j] = (j > 0 && es.shiftv[j - 1] - l < kSep) ? es.shiftv[j - 1] - kSep : l;
+            es.cs[j] = (j > 0 && es.lamv[j - 1] - l <= kOrtol) ? es.cs[j - 1] : j;
+            es.posi[j] = j - es.cs[j];
+            maxpos = es.posi[j] > maxpos ? es.posi[j] : maxpos;
+        }
+        es.maxpos = maxpos;
+    }
+    __syncthreads();
+    const int maxpos = es.maxpos;
+    int lost = 0;
+    for (int it = 0; it < 3; ++it) {
+        for (int j0 = 0; j0 < na; j0 += w.bw) {
+            if (tid < w.bw && j0 + tid < na) {
+                const bool ok = inverse_iteration_step(w, nr, j0 + tid, tid, es.shiftv[j0 + tid], it == 0, hseed);
+                if (!ok) es.bad = 1;
+            }
+            __syncthreads();
+        }
+        phase_tick(tick_row, 3, tick);             // inverse iteration
+        if (it > 0) lost = cluster_orthonormalize<kT>(w, nr, na, es.cs, es.posi, maxpos);   // the first solve only enters
+        phase_tick(tick_row, 4, tick);             // the cluster subspaces
+    }
+    for (int j = 2 * wv; j < na; j += 2 * kNW) {
+        const bool two = j + 1 < na;
+        float y0[kCPL], y1[kCPL], v[kCPL], vn[kCPL];
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) {
+            const int c = lane + 64 * u;
+            y0[u] = c < nr ? w.Y[c * ldy + j] : 0.f;
+            y1[u] = (c < nr && two) ? w.Y[c * ldy + j + 1] : 0.f;
+            vn[u] = (nr >= 3 && c > nr - 2 && c < nr) ? A[(int64_t)(nr - 3) * lda + c] : 0.f;
+        }
+        for (int kk = nr - 3; kk >= 0; --kk) {
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) {
+                const int c = lane + 64 * u;
+                v[u] = c == kk + 1 ? 1.0f : (c > kk + 1 ? vn[u] : 0.f);
+                vn[u] = (kk > 0 && c > kk && c < nr) ? A[(int64_t)(kk - 1) * lda + c] : 0.f;   // prefetch reflector kk - 1
+            }
+            const float t = w.tau[kk];
+            if (t == 0.f) continue;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) { s0 += v[u] * y0[u]; s1 += v[u] * y1[u]; }
+            s0 = t * wave_sum(s0);
+            s1 = t * wave_sum(s1);
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) { y0[u] -= s0 * v[u]; y1[u] -= s1 * v[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) {
+            const int c = lane + 64 * u;
+            if (c < nr) {
+                w.Y[c * ldy + j] = y0[u];
+                if (two) w.Y[c * ldy + j + 1] = y1[u];
+            }
+        }
+    }
+    __syncthreads();
+    phase_tick(tick_row, 5, tick);                 // back-transformation
+    return lost > 0 || es.bad != 0;
 }
 
 // one wave per subgraph: deflated size -> class list; k <= 0 subgraphs are finished here (zeros, data_util.py:243-244)
@@ -529,11 +553,10 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
 {
     static_assert(kNMax % 64 == 0 && kT % 64 == 0 && kT >= 256, "size class");
     DYN_SMEM(smem);
-    __shared__ float lamv[kMaxVec], shiftv[kMaxVec], lo[kMaxVec], hi[kMaxVec];
-    __shared__ int cs[kMaxVec], posi[kMaxVec];
+    __shared__ EigShared es;
     __shared__ int colsrc[64];                  // per output column: eigenvector j >= 0, or -(c + 1) for contrast c
-    __shared__ int sh_np, sh_z, sh_na, sh_maxpos, sh_bad, sh_item;
-    constexpr int kNW = kT / 64, kCPL = kNMax / 64, kP = kT / 32;
+    __shared__ int sh_np, sh_z, sh_na, sh_item;
+    constexpr int kNW = kT / 64, kCPL = kNMax / 64;
     constexpr int lda = kGlobalA ? kNMax : kNMax + 1;   // LDS: odd stride; workspace: rows start on 256-byte boundaries
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (;;) {                                     // items of this class
@@ -612,7 +635,6 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
         }
         sh_np = r;
         sh_z = c;
-        sh_bad = 0;
     }
     __syncthreads();
     const int nr = sh_np, z = sh_z;                // reduced size n', number of contrast null vectors
@@ -620,6 +642,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     if (kGlobalA) A = hd.slots + (int64_t)blockIdx.x * hd.slot_floats;   // the workgroup's own slot
     // ---- rest of the carve-up: eigenvectors and as many LU slots as fit
     w.Y = lds_rest;
+    w.ldy = kYld;
     {
         constexpr int lds_total = direct_lds_bytes<kNMax, kT, kGlobalA>();
         const int used = (int)((unsigned char *)(w.Y + nr * kYld) - smem);
@@ -666,54 +689,21 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     PHASE_TICK(0);                                 // deflation + matrix
     tridiagonalize<kCPL, kT, kGlobalA ? 4 : 2>(A, lda, nr, w);
     PHASE_TICK(1);
-    for (int i = tid; i < nr; i += kT) w.of2[i] = w.of[i] * w.of[i];
-    // ---- the kq largest eigenvalues of T: eigenvalue j (descending) has ascending index nr - 1 - j and lies in
-    //      [lo, hi] with count(lo) <= nr - 1 - j < count(hi); every round probes kP interior points
     const int kq = min(k, nr);
-    if (tid < kMaxVec) { lo[tid] = -1.001f; hi[tid] = 1.001f; }   // spectrum of a normalised adjacency matrix
-    __syncthreads();
-    {
-        const int j = tid / kP, ip = tid - j * kP;
-        constexpr int kRounds = kP >= 32 ? 6 : 9;                  // 2.002 / (kP + 1)^rounds < 1e-8
-        for (int round = 0; round < kRounds; ++round) {
-            const float xlo = lo[j], xhi = hi[j];
-            const float step = (xhi - xlo) * (1.0f / (float)(kP + 1));
-            const float x = xlo + step * (float)(ip + 1);
-            const int c = j < kq ? sturm_count(w.dg, w.of2, nr, x) : 0;
-            w.cnt[tid] = c;
-            __syncthreads();
-            if (j < kq) {
-                const int tgt = nr - 1 - j;
-                const bool above = c > tgt;
-                const bool prev_above = ip > 0 && w.cnt[tid - 1] > tgt;
-                if (above && !prev_above) {
-                    hi[j] = x;
-                    if (ip > 0) lo[j] = xlo + step * (float)ip;
-                }
-                if (ip == kP - 1 && !above) lo[j] = x;
-            }
-            __syncthreads();
-        }
-    }
+    eig_top_values<kT, kMaxVec>(w, nr, kq, es);
     PHASE_TICK(2);                                 // bisection
-    // ---- ranks (positive, null space = zeros of M' then the z contrasts, negative; eigsh(which="LA") returns the k
-    //      largest in ascending order, data_util.py:251), inverse-iteration shifts and clusters
+    // ---- ranks: positive, null space = zeros of M' then the z contrasts, negative; eigsh(which="LA") returns the k
+    //      largest in ascending order (data_util.py:251)
     if (tid < 64) colsrc[tid] = 0;
     __syncthreads();
     if (tid == 0) {
-        int na = 0, npz = 0, maxpos = 0;
+        int na = 0, npz = 0;
         for (int j = 0; j < kq; ++j) {
-            float l = 0.5f * (lo[j] + hi[j]);
-            if (j > 0 && l > lamv[j - 1]) l = lamv[j - 1];
-            lamv[j] = l;
-            shiftv[j] = (j > 0 && shiftv[j - 1] - l < kSep) ? shiftv[j - 1] - kSep : l;
-            cs[j] = (j > 0 && lamv[j - 1] - l <= kOrtol) ? cs[j - 1] : j;
-            posi[j] = j - cs[j];
+            const float l = es.lamv[j];
             const int r = l < -kZeroEig ? j + z : j;
             if (l >= -kZeroEig) npz = j + 1;
             if (r < k) {
                 na = j + 1;
-                maxpos = posi[j] > maxpos ? posi[j] : maxpos;
                 colsrc[k - 1 - r] = j;
                 if (a.evals) a.evals[(int64_t)b * a.hidden + (k - 1 - r)] = fabsf(l) <= kZeroEig ? 0.f : l;
             }
@@ -723,66 +713,12 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
             if (a.evals) a.evals[(int64_t)b * a.hidden + (k - 1 - (npz + c))] = 0.f;
         }
         sh_na = na;
-        sh_maxpos = maxpos;
     }
     if (a.evals) for (int i = k + tid; i < a.hidden; i += kT) a.evals[(int64_t)b * a.hidden + i] = 0.f;
     __syncthreads();
-    const int na = sh_na, maxpos = sh_maxpos;
-    // ---- eigenvectors of T
-    int lost = 0;
-    const uint32_t hseed = (uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u);
-    for (int it = 0; it < 3; ++it) {
-        for (int j0 = 0; j0 < na; j0 += w.bw) {
-            if (tid < w.bw && j0 + tid < na) {
-                const bool ok = inverse_iteration_step(w, nr, j0 + tid, tid, shiftv[j0 + tid], it == 0, hseed);
-                if (!ok) sh_bad = 1;
-            }
-            __syncthreads();
-        }
-        PHASE_TICK(3);                             // inverse iteration
-        if (it > 0) lost = cluster_orthonormalize<kT>(w, nr, na, cs, posi, maxpos);   // the first solve only enters the
-        PHASE_TICK(4);                             // cluster subspaces; Gram-Schmidt after the second and third
-    }
-    if (tid == 0 && (lost > 0 || sh_bad)) atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
-    // ---- eigenvectors of M': x = H_0 ... H_{nr-3} y; one wave per pair of vectors, the vectors in registers
-    for (int j = 2 * wv; j < na; j += 2 * kNW) {
-        const bool two = j + 1 < na;
-        float y0[kCPL], y1[kCPL], v[kCPL], vn[kCPL];
-#pragma unroll
-        for (int u = 0; u < kCPL; ++u) {
-            const int c = lane + 64 * u;
-            y0[u] = c < nr ? w.Y[c * kYld + j] : 0.f;
-            y1[u] = (c < nr && two) ? w.Y[c * kYld + j + 1] : 0.f;
-            vn[u] = (nr >= 3 && c > nr - 2 && c < nr) ? A[(int64_t)(nr - 3) * lda + c] : 0.f;
-        }
-        for (int kk = nr - 3; kk >= 0; --kk) {
-#pragma unroll
-            for (int u = 0; u < kCPL; ++u) {
-                const int c = lane + 64 * u;
-                v[u] = c == kk + 1 ? 1.0f : (c > kk + 1 ? vn[u] : 0.f);
-                vn[u] = (kk > 0 && c > kk && c < nr) ? A[(int64_t)(kk - 1) * lda + c] : 0.f;   // prefetch reflector kk - 1
-            }
-            const float t = w.tau[kk];
-            if (t == 0.f) continue;
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int u = 0; u < kCPL; ++u) { s0 += v[u] * y0[u]; s1 += v[u] * y1[u]; }
-            s0 = t * wave_sum(s0);
-            s1 = t * wave_sum(s1);
-#pragma unroll
-            for (int u = 0; u < kCPL; ++u) { y0[u] -= s0 * v[u]; y1[u] -= s1 * v[u]; }
-        }
-#pragma unroll
-        for (int u = 0; u < kCPL; ++u) {
-            const int c = lane + 64 * u;
-            if (c < nr) {
-                w.Y[c * kYld + j] = y0[u];
-                if (two) w.Y[c * kYld + j + 1] = y1[u];
-            }
-        }
-    }
-    __syncthreads();
-    PHASE_TICK(5);                                 // back-transformation
+    const bool failed = eig_top_vectors<kCPL, kT>(A, lda, nr, sh_na, w, es, (uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u),
+                                                  m.ticks ? m.ticks + kCls * 16 : nullptr, tick_);
+    if (tid == 0 && failed) atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
     // ---- expand to the n original nodes; x = normalize(u, "l2") row-wise, zero padded (data_util.py:260-262)
     for (int v = wv; v < n; v += kNW) {
         const int pv = d.par[v];
@@ -858,8 +794,9 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
     DYN_SMEM(smem);
     __shared__ float H[(kM + 1) * kM];              // H[i * kM + j], i <= j + 1
     __shared__ float Aj[kM * (kM + 1)], Yj[kM * (kM + 1)];
-    __shared__ float rot[kM], theta[kM], hbuf[kM + 1], red[kKWaves];
-    __shared__ int pq[kM], sel[kM], colsrc[kM], longrows[kMaxLong];
+    __shared__ float theta[kM], hbuf[kM + 1], red[kKWaves];
+    __shared__ int sel[kM], colsrc[kM], longrows[kMaxLong];
+    __shared__ EigShared es;
     __shared__ int flag, nlong, done, sh_item;
     const int tid = (int)threadIdx.x, lane = tid & 63, wv_id = tid >> 6;
     for (;;) {                                       // items of the Krylov class
@@ -880,6 +817,22 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
     float *V = ka.vws + (int64_t)blockIdx.x * 2 * (kM + 1) * ldv;     // the workgroup's own basis storage
     float *Valt = V + (int64_t)(kM + 1) * ldv;
     float *x = (float *)smem, *w = x + ldv, *dinv = w + ldv;
+    TriLds tw;                                       // Rayleigh-Ritz problem (kM x kM) for the direct solver core
+    tw.dg = dinv + ldv;
+    tw.of = tw.dg + kM;
+    tw.of2 = tw.of + kM;
+    tw.tau = tw.of2 + kM;
+    tw.pbuf = tw.tau + kM;
+    tw.vbuf = tw.pbuf + kM;
+    tw.coef = tw.vbuf + kM;
+    tw.cnt = (int *)(tw.coef + kVecCap * (kVecCap + 1));
+    tw.Y = Yj;
+    tw.ldy = kVecCap + 1;
+    tw.bw = kVecCap;
+    tw.ldu = kVecCap + 1;
+    tw.Ud = (float *)(tw.cnt + kKThreads);
+    tw.Us = tw.Ud + kM * tw.ldu;
+    tw.Uf = (uint8_t *)(tw.Us + kM * tw.ldu);
     const int k = min(n - 2, a.hidden);
     const int keep = min(k + kKeepExtra, kM - 8);
     const int lda = kM + 1;
@@ -996,22 +949,27 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
             float v = 0.f;
             if (c < kM) v = r <= c ? H[r * kM + c] : H[c * kM + r];
             Aj[i] = v;
-            Yj[i] = (r == c) ? 1.f : 0.f;
         }
         __syncthreads();
-        jacobi_lds(Aj, Yj, kM, lda, rot, pq, &flag, 2e-6f);     // Ritz values are only needed to ~1e-5
-        __syncthreads();
+        // the `keep` largest Ritz pairs by the direct solver core (tridiagonalise, bisect, inverse iteration): ~4x
+        // cheaper than Jacobi sweeps on the 64 x 64 matrix, and only the pairs that are used are computed
+        tridiagonalize<1, kKThreads, 2>(Aj, lda, kM, tw);
+        eig_top_values<kKThreads, kVecCap>(tw, kM, keep, es);
+        const bool ritz_failed = eig_top_vectors<1, kKThreads>(Aj, lda, kM, keep, tw, es,
+                                                               (uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u) ^ (uint32_t)cycle,
+                                                               nullptr, tick_);
         PHASE_TICK(1);                               // Ritz pairs of H
-        if (tid < kM) theta[tid] = Aj[tid * lda + tid];
-        if (tid == 0) done = 1;
+        if (tid < kM) {
+            theta[tid] = tid < keep ? es.lamv[tid] : -2.f;
+            sel[tid] = tid < keep ? tid : kM;           // Ritz pair tid has rank tid (0 = largest); the others are not computed
+        }
+        if (tid == 0) { done = 1; flag = ritz_failed ? 2 : 0; }
         __syncthreads();
         const float beta_m = H[kM * kM + (kM - 1)];
-        if (tid < kM) {
-            const int r = rank_desc(theta, kM, tid);
-            sel[tid] = r;                           // 0 = largest Ritz value
+        if (tid < k) {
             const float res = fabsf(beta_m * Yj[(kM - 1) * lda + tid]);
-            if (r < k && res > kRitzTol) done = 0;
-            if (r < k && res > 10.f * kRitzTol) flag = 2;     // far from converged (reported if the cycle cap is hit)
+            if (res > kRitzTol) done = 0;
+            if (res > 10.f * kRitzTol) flag = 2;         // far from converged (reported if the cycle cap is hit)
         }
         __syncthreads();
         const bool finished = done != 0 || cycle == kMaxCycles - 1;
@@ -1183,6 +1141,7 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
         (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kGLds);
+        (void)hipFuncSetAttribute((const void *)posemb_krylov_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
         attr_set = true;
     }
 #endif
@@ -1195,7 +1154,9 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     ka.vws = hd.slots + g.slot * hd.slot_floats;
     ka.ldv = (int32_t)posemb_ldv(batch_size, node_cap);
     // longest items first
-    hipLaunchKernelGGL(posemb_krylov_kernel, dim3(g.kry), dim3(kKThreads), (size_t)3 * ka.ldv * sizeof(float), s, ka);
+    const size_t lds_kry = (size_t)3 * ka.ldv * sizeof(float)
+                           + sizeof(float) * (6 * kM + kVecCap * (kVecCap + 1) + kKThreads + 2 * kM * (kVecCap + 1)) + kM * kVecCap;
+    hipLaunchKernelGGL(posemb_krylov_kernel, dim3(g.kry), dim3(kKThreads), lds_kry, s, ka);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>), dim3(g.slot), dim3(1024), kGLds, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, 1024, false>), dim3(g.mid), dim3(1024), lds_big, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsSmall, 0, kJSmall, 256, false>), dim3(g.small), dim3(256), lds_small, s, m, hd);
