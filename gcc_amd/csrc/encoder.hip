@@ -89,7 +89,9 @@ struct InArgs {
     int32_t B, first, kdim, training;
     float eps;
 };
-struct InLaunch { InArgs p[kMaxPass]; };
+struct InLaunch { InArgs p[kMaxPass]; long long *ticks; };
+static long long *g_gin_ticks = nullptr;   // diagnostics (gcc_gin_debug_ticks)
+#define GIN_TICK(ph) do { if (L.ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&L.ticks[(a.first ? 0 : 16) + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 
 __global__ __launch_bounds__(kThreads) void gin_in_kernel(InLaunch L)
 {
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(kThreads) void gin_in_kernel(InLaunch L)
     const double dn = (double)N;
     __shared__ float tabb[2 * H], tabc[2 * H];
     Aff4 ab, ac;
+    long long tick_ = L.ticks ? device_ticks() : 0;
     if (!a.first) {
         bn_table(tabb, a.bnb, 0, dn, a.eps, a.training);
         bn_table(tabc, a.bnc, H, dn, a.eps, a.training);
@@ -117,11 +120,10 @@ __global__ __launch_bounds__(kThreads) void gin_in_kernel(InLaunch L)
         if (!a.first) x = affine_relu(affine_relu(x, ab), ac);   // h = relu(bn_c(relu(bn_b(z2))))  gin.py:56-57,219-220
         return x;
     };
-    F4 wf[4][4];
-    load_w_frags(a.w0, a.kdim, wf);
-
+    GIN_TICK(0);                                  // BatchNorm tables
     for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
         const int nrows = min(kTile, N - tile0);
+        if (L.ticks && tid == 0) atomicAdd((unsigned long long *)&L.ticks[(a.first ? 0 : 16) + 15], 1ull);
         if (tid == 0) nlong = 0;
         // 1. own rows
         for (int r = gi; r < kTile; r += 16) {
@@ -130,17 +132,23 @@ __global__ __launch_bounds__(kThreads) void gin_in_kernel(InLaunch L)
             st4(&T[r * kLdt + 4 * t], x);
         }
         __syncthreads();
+        GIN_TICK(1);
         // 2. SumPooling of hidden_rep[layer] (gin.py:228)
         if (a.pooled) pool_tile(T, tile0, nrows, a.graph_id, a.pooled);
         __syncthreads();
+        GIN_TICK(2);
         // 3. GINConv aggregate: (1 + eps) * h_v + sum_{u -> v} h_u, eps = 0 (gin.py:179-185,218)
         gather_tile(T, part, longrows, &nlong, tile0, nrows, a.row_ptr, a.col_idx, feat);
+        GIN_TICK(3);
         // 4. keep agg for the weight gradient of linears.0
         if (a.agg)
             for (int r = gi; r < nrows; r += 16) st4(a.agg + (int64_t)(tile0 + r) * H + 4 * t, ld4(&T[r * kLdt + 4 * t]));
+        GIN_TICK(4);
         // 5. z1 = agg W0^T + b0 (gin.py:115: linears[0])
         {
             const int j = lane & 15, q = lane >> 4, rl = 16 * wv + j;
+            F4 wf[4][4];                               // (not kept across the gather: it needs the registers)
+            load_w_frags(a.w0, a.kdim, wf);
             F4 xb[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) xb[c] = ld4(&T[rl * kLdt + 16 * c + 4 * q]);
@@ -149,8 +157,10 @@ __global__ __launch_bounds__(kThreads) void gin_in_kernel(InLaunch L)
             epilogue_store_stats(acc, a.b0, a.z1, tile0 + rl, rl < nrows, &red[wv * 2 * H]);
         }
         __syncthreads();
+        GIN_TICK(5);
         flush_stats(red, a.stats_a);
         __syncthreads();
+        GIN_TICK(6);
     }
 }
 
@@ -372,6 +382,8 @@ __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
 
 }  // namespace
 
+extern "C" void gcc_gin_debug_ticks(long long *device_ticks64) { g_gin_ticks = device_ticks64; }   /* diagnostics only */
+
 extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gcc_prof *prof, void *stream)
 {
     if (!passes || npass < 1 || npass > kMaxPass) {
@@ -426,6 +438,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
                 a.training = p.training; a.eps = p.w.bn_eps;
                 L.p[i] = a;
             }
+            L.ticks = g_gin_ticks;
             hipLaunchKernelGGL(gin_in_kernel, grid, block, 0, s, L);
         }
         {

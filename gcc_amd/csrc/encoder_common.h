@@ -11,6 +11,7 @@ constexpr int kLdt = 72;            // LDS row stride in floats (conflict-free d
 constexpr int kThreads = 256;
 constexpr int kGridX = 768;         // tiles are grid-strided
 constexpr int kLongRow = 48;
+constexpr int kGatherJ = 2;         // neighbours per row fetched together (x 4 rows per lane group); more costs occupancy
 constexpr int kMaxPass = 2;
 constexpr int kRep = 32;            // replicas of every atomically accumulated statistics row: a block adds to
                                     // copy (blockIdx.x % kRep), consumers sum the copies -- ~730 workgroups hitting the
@@ -228,23 +229,59 @@ __device__ __forceinline__ void gather_tile(float *T, float *part /* [16 * H] */
                                             int tile0, int nrows, const int32_t *row_ptr,
                                             const int32_t *col_idx, Feat feat)
 {
-    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
-    for (int r = gi; r < nrows; r += 16) {
-        const int v = tile0 + r;
-        const int beg = row_ptr[v], end = row_ptr[v + 1];
-        if (end - beg > kLongRow) {
+    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, gbase = lane_id() & ~15;
+    // A lane group walks its four rows (gi, gi + 16, gi + 32, gi + 48) TOGETHER: the 16 lanes fetch 16 entries of
+    // each neighbour list in one load, and kGatherJ neighbours x 4 rows of features are in flight at a time, so that a tile
+    // costs a handful of memory round trips instead of two per four edges.
+    int beg[4], deg[4], idx[4];
+    F4 acc[4];
+    int md = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = gi + 16 * q;
+        const bool ok = r < nrows;
+        const int b0 = ok ? row_ptr[tile0 + r] : 0, e0 = ok ? row_ptr[tile0 + r + 1] : 0;
+        int d = e0 - b0;
+        if (d > kLongRow) {
             if (t == 0) longrows[atomicAdd(nlong, 1)] = r;
-            continue;
+            d = 0;
         }
-        F4 acc = ld4(&T[r * kLdt + 4 * t]);
-        int e = beg;
-        for (; e + 4 <= end; e += 4) {
-            const int u0 = col_idx[e], u1 = col_idx[e + 1], u2 = col_idx[e + 2], u3 = col_idx[e + 3];
-            const F4 f0 = feat(u0), f1 = feat(u1), f2 = feat(u2), f3 = feat(u3);
-            acc = add4(add4(acc, f0), add4(f1, add4(f2, f3)));
+        beg[q] = b0;
+        deg[q] = d;
+        md = d > md ? d : md;
+        acc[q] = ld4(&T[r * kLdt + 4 * t]);
+    }
+    md = (int)wave_max((float)md);                  // wave-uniform trip counts (the shuffles below need every lane)
+    for (int c = 0; c < md; c += 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) idx[q] = c + t < deg[q] ? col_idx[beg[q] + c + t] : -1;
+        for (int eb = 0; eb < 16 && c + eb < md; eb += kGatherJ) {
+            F4 f[4][kGatherJ];
+            int u[4][kGatherJ];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < kGatherJ; ++j) u[q][j] = wave_shfl(idx[q], gbase + eb + j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < kGatherJ; ++j) f[q][j] = feat(u[q][j] < 0 ? 0 : u[q][j]);   // branch free: loads in flight
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < kGatherJ; ++j) {
+                    const float keep = u[q][j] < 0 ? 0.f : 1.f;
+                    acc[q].x = fmaf(keep, f[q][j].x, acc[q].x);
+                    acc[q].y = fmaf(keep, f[q][j].y, acc[q].y);
+                    acc[q].z = fmaf(keep, f[q][j].z, acc[q].z);
+                    acc[q].w = fmaf(keep, f[q][j].w, acc[q].w);
+                }
         }
-        for (; e < end; ++e) acc = add4(acc, feat(col_idx[e]));
-        st4(&T[r * kLdt + 4 * t], acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = gi + 16 * q;
+        if (r < nrows && deg[q] > 0) st4(&T[r * kLdt + 4 * t], acc[q]);
     }
     __syncthreads();
     const int nl = *nlong;

@@ -44,12 +44,13 @@ struct NceDev {
     int32_t S, R;             // slices and rows per slice (multiple of kChunk)
     float *pm, *ps;           // [S][B] partial max / sum
     float *slabs;             // [S][B][64] partial dq (backward)
+    int32_t *ticket;          // arrival counter of nce_combine_kernel's workgroups (zeroed by the forward slice kernel)
     const float *dloss;
     int32_t by_mem_row;
     float *dq;
 };
 
-struct Plan { int32_t S, R, QB; int64_t off_pm, off_ps, off_slabs, total; };
+struct Plan { int32_t S, R, QB; int64_t off_pm, off_ps, off_slabs, off_ticket, total; };
 
 inline Plan make_plan(int32_t B, int32_t K)
 {
@@ -66,6 +67,7 @@ inline Plan make_plan(int32_t B, int32_t K)
     p.off_pm = o; o = al(o + (int64_t)p.S * B * 4);
     p.off_ps = o; o = al(o + (int64_t)p.S * B * 4);
     p.off_slabs = o; o = al(o + (int64_t)p.S * B * D * 4);
+    p.off_ticket = o; o = al(o + 4);
     p.total = o;
     return p;
 }
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(kThreads) void nce_slice_kernel(NceDev a)
     __shared__ float Ms[kChunk * kLd];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
     const int s = (int)blockIdx.x;
+    if (!kBwd && s == 0 && blockIdx.y == 0 && tid == 0) *a.ticket = 0;     // arrival counter of nce_combine_kernel
     const int qj = (int)blockIdx.y * kQPerBlock + 16 * wv + j;
     const bool qvalid = qj < a.B;
     F4 qf[4];
@@ -180,12 +183,14 @@ __global__ __launch_bounds__(kThreads) void nce_slice_kernel(NceDev a)
 __global__ __launch_bounds__(kThreads) void nce_combine_kernel(NceDev a)
 {
     TRAIN_STEP_WAVE_PRIORITY();
-    // one block; each wave walks over queries, lanes over the 64 feature dims / the slices
+    // one wave per query (lanes over the 64 feature dims / the slices); the workgroup that arrives last adds the
+    // per-query terms up in index order (deterministic) for the mean loss and the mean positive logit
     __shared__ double red[8];
+    __shared__ int last;
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6;
-    double lsum = 0.0, psum = 0.0;
     const int ld_out = a.K + (a.pos_mode == 0 ? 1 : 0);
-    for (int b = wv; b < a.B; b += kThreads >> 6) {
+    const int b = (int)blockIdx.x * (kThreads >> 6) + wv;
+    if (b < a.B) {
         const float *other = a.pos_mode == 0 ? a.k : a.mem;        // l_pos = bmm(q, k) | diagonal of k q^T
         const float pos = wave_sum(a.q[(int64_t)b * D + lane] * other[(int64_t)b * D + lane]) * a.inv_T;
         float m = -INFINITY;
@@ -204,15 +209,28 @@ __global__ __launch_bounds__(kThreads) void nce_combine_kernel(NceDev a)
             a.lse[b] = lse;
             a.pos[b] = pos;
             if (a.pos_mode == 0 && a.out_dense) a.out_dense[(int64_t)b * ld_out] = pos;
-            lsum += (double)(lse - pos);                 // CrossEntropyLoss row term
-            psum += (double)pos;
         }
     }
+    device_fence();                                              // lse / pos of this workgroup are visible device wide
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(a.ticket, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    device_fence();
+    double lsum = 0.0, psum = 0.0;
+    for (int i = tid; i < a.B; i += kThreads) {
+        const float lse = load_fresh(a.lse + i), pos = load_fresh(a.pos + i);
+        lsum += (double)(lse - pos);                             // CrossEntropyLoss row term
+        psum += (double)pos;
+    }
+    lsum = wave_sum(lsum);
+    psum = wave_sum(psum);
     if (lane == 0) { red[wv] = lsum; red[4 + wv] = psum; }
     __syncthreads();
     if (tid == 0) {
         a.loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)a.B);    // reduction="mean"
         a.prob[0] = (float)((red[4] + red[5] + red[6] + red[7]) / (double)a.B);    // out[:, 0].mean(), train.py:394
+        *a.ticket = 0;
     }
 }
 
@@ -333,6 +351,7 @@ inline int fill_dev(const gcc_nce_args *a, void *workspace, int64_t workspace_by
     d.S = pl.S; d.R = pl.R;
     char *base = (char *)workspace;
     d.pm = (float *)(base + pl.off_pm); d.ps = (float *)(base + pl.off_ps); d.slabs = (float *)(base + pl.off_slabs);
+    d.ticket = (int32_t *)(base + pl.off_ticket);
     d.dloss = nullptr; d.by_mem_row = 0; d.dq = nullptr;
     return 0;
 }
@@ -357,7 +376,7 @@ int32_t gcc_nce_forward(const gcc_nce_args *a, void *workspace, int64_t workspac
     hipStream_t s = (hipStream_t)stream;
     prof_mark(prof, 0, s);
     hipLaunchKernelGGL((nce_slice_kernel<false>), dim3(pl.S, pl.QB), dim3(kThreads), 0, s, d);
-    hipLaunchKernelGGL(nce_combine_kernel, dim3(1), dim3(kThreads), 0, s, d);
+    hipLaunchKernelGGL(nce_combine_kernel, dim3((d.B + (kThreads >> 6) - 1) / (kThreads >> 6)), dim3(kThreads), 0, s, d);
     prof_mark(prof, 1, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_nce_forward: %s", hipGetErrorString(e)); return -10; }

@@ -161,6 +161,8 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
  * device int64[4][16] (phases 0..6 = matrix, tridiagonalise, bisect, inverse iteration, Gram-Schmidt,
  * back-transform, expand; [15] = items); NULL switches it off. */
 void gcc_posemb_debug_ticks(long long *device_ticks64);
+/* the same for gin_in_kernel: device int64[2][16] ([0] = first layer, [1] = others; [15] = tiles) */
+void gcc_gin_debug_ticks(long long *device_ticks64);
 
 /* ------------------------------------------------------------ GIN encoder ---
  * GraphEncoder(gnn_model="gin", degree_input=True).forward of

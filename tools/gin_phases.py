@@ -1,0 +1,43 @@
+"""Per-phase wall-clock ticks of gin_in_kernel (training stream alone, placeholder positional embedding)."""
+import sys
+import torch
+
+sys.path.insert(0, ".")
+from gcc_amd import _cabi
+from gcc_amd.contrast import MemoryMoCo
+from gcc_amd.encoder import GraphEncoder
+from gcc_amd.graph import DeviceGraph
+from gcc_amd.graphgen import powerlaw_graph
+from gcc_amd.posemb import PlaceholderPosEmb
+from gcc_amd.sampler import DeviceRWRSampler
+from gcc_amd.train_step import MoCoTrainStep
+
+dev = torch.device("cuda:0")
+rp, ci = powerlaw_graph(1_000_000, 10_000_000, seed=0)
+graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False)
+sampler = DeviceRWRSampler(graph, 256, run_seed=0, num_buffers=3)
+enc_kw = dict(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512, freq_embedding_size=16,
+              degree_embedding_size=16, output_dim=64, node_hidden_dim=64, edge_hidden_dim=64, num_layers=5,
+              num_step_set2set=6, num_layer_set2set=3, norm=True, gnn_model="gin", degree_input=True)
+torch.manual_seed(0)
+model, ema = GraphEncoder(**enc_kw).to(dev), GraphEncoder(**enc_kw).to(dev)
+ema.load_state_dict(model.state_dict())
+contrast = MemoryMoCo(64, None, 16384, 0.07, use_softmax=True).to(dev)
+ph = PlaceholderPosEmb(sampler.node_cap, 32, device=dev)
+trainer = MoCoTrainStep(model, ema, contrast, sampler, ph, lanes=[(sampler, ph)], depth=2)
+for i in range(20):
+    trainer.step(i, 0.005)
+torch.cuda.synchronize()
+lib = _cabi.load()
+ticks = torch.zeros(32, dtype=torch.int64, device=dev)
+lib.gcc_gin_debug_ticks(ticks.data_ptr())
+n = 20
+for i in range(n):
+    trainer.step(20 + i, 0.005)
+torch.cuda.synchronize()
+lib.gcc_gin_debug_ticks(None)
+t = ticks.cpu().numpy().reshape(2, 16)
+names = ["bn-table", "own-rows", "pool", "gather", "agg-store", "mfma+epilogue", "flush-stats"]
+for r, nm in enumerate(["first layer", "other layers"]):
+    tiles = max(int(t[r, 15]), 1)
+    print(f"{nm:13s} tiles {tiles:7d} | " + "  ".join(f"{x} {t[r, i] / 100.0 / tiles:6.2f}us" for i, x in enumerate(names)))

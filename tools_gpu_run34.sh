@@ -1,0 +1,16 @@
+#!/bin/bash
+set -u
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tee gpurun_out/pytest_gpu34.log | tail -3
+timeout 600 python tools/gin_phases.py 2>&1 | grep -v amdgpu.ids | tail -2
+show='import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k:d[k] for k in ("value","ms_per_step","stage_ms")})'
+echo "=== placeholder (training stream alone)"
+timeout 600 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --posemb placeholder --lanes 1 --chunk 1 2>/dev/null | python -c "$show"
+for cfg in "2 16"; do
+  set -- $cfg
+  echo "=== bench lanes=$1 chunk=$2"
+  timeout 900 python bench.py --steps 192 --warmup 48 --no-cpu-baseline --lanes $1 --chunk $2 2>gpurun_out/bench.err | tee gpurun_out/bench_run34_l$1_c$2.json | python -c "$show"
+done
+exit 0
