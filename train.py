@@ -116,6 +116,8 @@ def parse_option(argv=None):
     parser.add_argument("--graph-npz", type=str, default=None, help="npz with row_ptr/col_idx (instead of data/small.bin)")
     parser.add_argument("--synthetic", type=str, default=None, help="V,E of a synthetic power-law graph, e.g. 1000000,10000000")
     parser.add_argument("--max-steps", type=int, default=0, help="stop after this many steps (0 = full schedule)")
+    parser.add_argument("--producer-lanes", type=int, default=2, help="data-pipeline streams (the GPU's command processor serves few queues well)")
+    parser.add_argument("--producer-chunk", type=int, default=16, help="steps a lane prepares per turn (2x as many views per eigensolver call, <= 32)")
     # fmt: on
 
     opt = parser.parse_args(argv)
@@ -261,7 +263,7 @@ def main(args):
             checkpoint = torch.load(args.resume, map_location="cpu", weights_only=False)
             pretrain_args = checkpoint["opt"]
             for name in ("fold_idx", "gpu", "finetune", "resume", "cv", "dataset", "epochs", "num_workers",
-                         "batch_size", "graph_npz", "synthetic", "max_steps"):
+                         "batch_size", "graph_npz", "synthetic", "max_steps", "producer_lanes", "producer_chunk"):
                 setattr(pretrain_args, name, getattr(args, name))
             args = pretrain_args
         else:
@@ -308,10 +310,21 @@ def main(args):
                           device=dev, seed=args.seed)
     trainer, optimizer = None, None
     if args.moco:
-        trainer = MoCoTrainStep(model, model_ema, contrast, train_dataset.sampler, posemb,
+        # data pipeline: `producer_lanes` streams, each preparing `producer_chunk` steps per turn (sampler calls + one
+        # multi-view eigensolver call) -- the role of the reference's --num-workers DataLoader processes
+        from gcc_amd.sampler import DeviceRWRSampler
+
+        lanes, depth = [], 2
+        for _ in range(args.producer_lanes):
+            smp = DeviceRWRSampler(train_dataset.graph, args.batch_size, run_seed=args.seed,
+                                   num_buffers=depth * args.producer_chunk)
+            lanes.append((smp, DevicePosEmb(args.batch_size, smp.node_cap, args.positional_embedding_size, device=dev,
+                                            seed=args.seed, num_buffers=depth * args.producer_chunk,
+                                            max_views=min(2 * args.producer_chunk, 32))))
+        trainer = MoCoTrainStep(model, model_ema, contrast, lanes[0][0], lanes[0][1],
                                 learning_rate=args.learning_rate, betas=(args.beta1, args.beta2),
                                 weight_decay=args.weight_decay, clip_norm=args.clip_norm, alpha=args.alpha,
-                                world_size=world, rank=rank)
+                                world_size=world, rank=rank, lanes=lanes, depth=depth, chunk=args.producer_chunk)
         optimizer = trainer.optimizer
     else:
         optimizer = torch.optim.Adam(model.parameters(), lr=args.learning_rate, betas=(args.beta1, args.beta2),
