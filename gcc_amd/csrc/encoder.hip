@@ -36,7 +36,7 @@ struct FeatArgs {
     const float *pos, *emb;
     float *x0;
     double *pooled0;
-    int32_t B, pos_dim, emb_dim, max_degree;
+    int32_t B, pos_dim, emb_dim, max_degree, mult;
 };
 struct FeatLaunch { FeatArgs p[kMaxPass]; };
 
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kThreads) void gin_feat_kernel(FeatLaunch L)
             F4 x = {0.f, 0.f, 0.f, 0.f};
             if (r < nrows) {
                 const int v = tile0 + r;
-                const int deg = a.row_ptr[v + 1] - a.row_ptr[v];          // g.in_degrees(), :154
+                const int deg = (a.row_ptr[v + 1] - a.row_ptr[v]) * a.mult;          // g.in_degrees(), :154
                 const int dcl = deg < a.max_degree ? deg : a.max_degree;  // clamp(0, max_degree), :161
                 const bool is_seed = v == a.node_off[a.graph_id[v]];      // ndata["seed"], data_util.py:234-238
 #pragma unroll
@@ -87,7 +87,7 @@ struct InArgs {
     double *stats_a;
     double *pooled;           // SumPooling of this layer's input h (hidden_rep[layer]); NULL for layer 0 (done by F0)
     int32_t B, first, kdim, training;
-    float eps;
+    float eps, nbr_weight;    // nbr_weight: edge multiplicity
 };
 struct InLaunch { InArgs p[kMaxPass]; long long *ticks; };
 static long long *g_gin_ticks = nullptr;   // diagnostics (gcc_gin_debug_ticks)
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void gin_in_kernel(InLaunch L)
         __syncthreads();
         GIN_TICK(2);
         // 3. GINConv aggregate: (1 + eps) * h_v + sum_{u -> v} h_u, eps = 0 (gin.py:179-185,218)
-        gather_tile(T, part, longrows, &nlong, tile0, nrows, a.row_ptr, a.col_idx, feat);
+        gather_tile(T, part, longrows, &nlong, tile0, nrows, a.row_ptr, a.col_idx, feat, a.nbr_weight);
         GIN_TICK(3);
         // 4. keep agg for the weight gradient of linears.0
         if (a.agg)
@@ -415,7 +415,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
         for (int i = 0; i < npass; ++i) {
             const gcc_gin_pass &p = passes[i];
             L.p[i] = {p.node_off, p.row_ptr, p.graph_id, p.pos, p.w.degree_embedding, p.x0, p.pooled,
-                      p.batch_size, p.w.pos_dim, p.w.deg_emb_dim, p.w.max_degree};
+                      p.batch_size, p.w.pos_dim, p.w.deg_emb_dim, p.w.max_degree, p.edge_multiplicity > 1 ? p.edge_multiplicity : 1};
         }
         hipLaunchKernelGGL(gin_feat_kernel, grid, block, 0, s, L);
     }
@@ -436,6 +436,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
                 a.B = p.batch_size; a.first = l == 0;
                 a.kdim = l == 0 ? p.w.pos_dim + p.w.deg_emb_dim + 1 : H;
                 a.training = p.training; a.eps = p.w.bn_eps;
+                a.nbr_weight = p.edge_multiplicity > 1 ? (float)p.edge_multiplicity : 1.0f;
                 L.p[i] = a;
             }
             L.ticks = g_gin_ticks;

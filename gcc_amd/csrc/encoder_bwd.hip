@@ -649,6 +649,10 @@ extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat
         return -1;
     }
     const gcc_gin_pass &p = *pass;
+    if (p.edge_multiplicity > 1) {
+        snprintf(g_err, kErrLen, "gcc_gin_backward: edge_multiplicity %d (inference-only feature)", p.edge_multiplicity);
+        return -2;
+    }
     const int L = p.w.num_gin_layers, B = p.batch_size;
     const int kdim0 = p.w.pos_dim + p.w.deg_emb_dim + 1;
     const int emb_elems = (p.w.max_degree + 1) * p.w.deg_emb_dim;

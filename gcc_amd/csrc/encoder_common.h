@@ -227,7 +227,7 @@ __device__ __forceinline__ void flush_stats(const float *red, double *stats)
 template <class Feat>
 __device__ __forceinline__ void gather_tile(float *T, float *part /* [16 * H] */, int *longrows, int *nlong,
                                             int tile0, int nrows, const int32_t *row_ptr,
-                                            const int32_t *col_idx, Feat feat)
+                                            const int32_t *col_idx, Feat feat, float nbr_weight = 1.0f)
 {
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, gbase = lane_id() & ~15;
     // A lane group walks its four rows (gi, gi + 16, gi + 32, gi + 48) TOGETHER: the 16 lanes fetch 16 entries of
@@ -249,7 +249,7 @@ __device__ __forceinline__ void gather_tile(float *T, float *part /* [16 * H] */
         beg[q] = b0;
         deg[q] = d;
         md = d > md ? d : md;
-        acc[q] = ld4(&T[r * kLdt + 4 * t]);
+        acc[q] = F4{0.f, 0.f, 0.f, 0.f};
     }
     md = (int)wave_max((float)md);                  // wave-uniform trip counts (the shuffles below need every lane)
     for (int c = 0; c < md; c += 16) {
@@ -281,7 +281,13 @@ __device__ __forceinline__ void gather_tile(float *T, float *part /* [16 * H] */
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int r = gi + 16 * q;
-        if (r < nrows && deg[q] > 0) st4(&T[r * kLdt + 4 * t], acc[q]);
+        if (r < nrows && deg[q] > 0) {
+            const F4 self = ld4(&T[r * kLdt + 4 * t]);
+            F4 o;
+            o.x = fmaf(nbr_weight, acc[q].x, self.x); o.y = fmaf(nbr_weight, acc[q].y, self.y);
+            o.z = fmaf(nbr_weight, acc[q].z, self.z); o.w = fmaf(nbr_weight, acc[q].w, self.w);
+            st4(&T[r * kLdt + 4 * t], o);
+        }
     }
     __syncthreads();
     const int nl = *nlong;
@@ -299,9 +305,9 @@ __device__ __forceinline__ void gather_tile(float *T, float *part /* [16 * H] */
         st4(&part[gi * H + 4 * t], acc);
         __syncthreads();
         if (tid < H) {
-            float s = T[r * kLdt + tid];
+            float s = 0.f;
             for (int k = 0; k < 16; ++k) s += part[k * H + tid];
-            T[r * kLdt + tid] = s;
+            T[r * kLdt + tid] = fmaf(nbr_weight, s, T[r * kLdt + tid]);
         }
         __syncthreads();
     }

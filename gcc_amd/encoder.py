@@ -160,6 +160,7 @@ class GinEngine:
         for i in range(L):
             p.agg[i], p.z1[i], p.z2[i] = ptr(buf["agg"][i]), ptr(buf["z1"][i]), ptr(buf["z2"][i])
         p.stats, p.pooled, p.score, p.feat = ptr(buf["stats"]), ptr(buf["pooled"]), ptr(buf["score"]), ptr(buf["feat"])
+        p.edge_multiplicity = int(getattr(g, "edge_multiplicity", 1))
         buf = dict(buf)
         buf["_keepalive"] = (g, keep, enc)      # the struct holds raw pointers into these
         return p, buf

@@ -32,6 +32,13 @@ def max_nodes_per_seed_table(max_degree: int, rw_hops: int, restart_prob: float)
                     dtype=np.int32)
 
 
+def max_nodes_out_degree_table(max_degree: int, rw_hops: int, restart_prob: float, multiplicity: int = 1) -> np.ndarray:
+    """max_nodes_per_seed of the GraphDataset family (graph_dataset.py:244-255): the out-degree enters WITHOUT the
+    0.75 power; ``multiplicity`` = copies of every edge in the DGL graph the reference walks on."""
+    c = math.e / (math.e - 1) / restart_prob
+    return np.array([max(rw_hops, int(d * multiplicity * c + 0.5)) for d in range(max_degree + 1)], dtype=np.int32)
+
+
 def restart_threshold(restart_prob: float) -> int:
     """restart <=> 32-bit draw < floor(restart_prob * 2^32)."""
     return min(int(restart_prob * 4294967296.0), 0xFFFFFFFF)
@@ -41,7 +48,7 @@ class DeviceGraph:
     """int32 CSR + seed cdf + max_nodes table on one GPU."""
 
     def __init__(self, row_ptr: np.ndarray, col_idx: np.ndarray, rw_hops: int = 256,
-                 restart_prob: float = 0.8, device="cuda", validate: bool = True):
+                 restart_prob: float = 0.8, device="cuda", validate: bool = True, ltab: np.ndarray = None):
         import torch
 
         row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
@@ -58,7 +65,10 @@ class DeviceGraph:
         self.restart_u32 = restart_threshold(restart_prob)
         deg = np.diff(row_ptr)
         self.max_degree = int(deg.max())
-        ltab = max_nodes_per_seed_table(self.max_degree, rw_hops, restart_prob)
+        if ltab is None:
+            ltab = max_nodes_per_seed_table(self.max_degree, rw_hops, restart_prob)
+        ltab = np.ascontiguousarray(ltab, dtype=np.int32)
+        assert ltab.shape[0] == self.max_degree + 1
         self.lmax = int(ltab.max())
         self.row_ptr = torch.from_numpy(row_ptr).to(self.device)
         self.col_idx = torch.from_numpy(col_idx).to(self.device)

@@ -37,6 +37,7 @@ class BatchedCSR:
         self.row_ptr = row_ptr
         self.col_idx = col_idx
         self.pos_undirected = None      # [node_cap, P] f32, filled by gcc_amd.posemb
+        self.edge_multiplicity = 1      # every CSR edge counts this many times (multigraph parents, gcc_gin_pass)
         self._n = None
         self._e = None
         self.ndata = _NData(self)
@@ -60,7 +61,7 @@ class BatchedCSR:
     def in_degrees(self):
         n = self.number_of_nodes()
         rp = self.row_ptr[: n + 1].long()
-        return rp[1:] - rp[:-1]          # symmetric parent => in-degree == row length
+        return (rp[1:] - rp[:-1]) * self.edge_multiplicity          # symmetric parent => in-degree == row length
 
     def to(self, device):
         return self

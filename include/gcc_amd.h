@@ -219,6 +219,10 @@ typedef struct gcc_gin_pass {    /* one encoder invocation on one batched graph 
     double *pooled;              /* [num_gin_layers+1, B, 64] SumPooling of hidden_rep     */
     float *score;                /* [B, 64] score_over_layer before normalisation          */
     float *feat;                 /* [B, 64] output                                         */
+    int32_t edge_multiplicity;   /* every edge of the CSR counts this many times (0 = 1): in-degree feature and
+                                  * neighbour sum.  The reference's NodeClassificationDataset builds its DGL graph
+                                  * with every undirected edge twice per direction (data_util.py:84-85 +
+                                  * graph_dataset.py:301-302); forward only (backward requires 1). */
 } gcc_gin_pass;
 
 /* Runs `npass` independent passes (e.g. query with model, key with model_ema)

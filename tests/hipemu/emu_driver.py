@@ -35,12 +35,13 @@ def _p(a):
 
 
 class EmuGraph:
-    def __init__(self, row_ptr, col_idx, rw_hops=256, restart_prob=0.8):
+    def __init__(self, row_ptr, col_idx, rw_hops=256, restart_prob=0.8, ltab=None):
         self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
         self.col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
         self.cdf = seed_cdf_table(self.row_ptr)
         deg = np.diff(self.row_ptr)
-        self.ltab = max_nodes_per_seed_table(int(deg.max()), rw_hops, restart_prob)
+        self.ltab = (max_nodes_per_seed_table(int(deg.max()), rw_hops, restart_prob) if ltab is None
+                     else np.ascontiguousarray(ltab, dtype=np.int32))
         self.lmax = int(self.ltab.max())
         self.rw_hops = rw_hops
         self.restart_u32 = restart_threshold(restart_prob)

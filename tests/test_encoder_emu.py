@@ -89,6 +89,49 @@ def test_long_rows_and_ragged_tiles_match_oracle():
     torch.testing.assert_close(buf["feat"], ref.detach(), **TOL)
 
 
+def test_edge_multiplicity_equals_the_doubled_multigraph():
+    """NodeClassificationDataset (graph_dataset.py:296-304 on top of data_util.py:84-85) hands the encoder a graph in
+    which every edge exists twice: in-degrees and neighbour sums double.  edge_multiplicity = 2 on the simple CSR
+    must equal the oracle run on the CSR with every entry duplicated (eval mode, as generate.py:40)."""
+    import numpy as np
+    import scipy.sparse as sp
+
+    torch.manual_seed(5)
+    n0, n1 = 90, 40
+    rng = np.random.RandomState(0)
+    edges = [(0, i) for i in range(1, n0)] + [(int(rng.randint(1, n0)), int(rng.randint(1, n0))) for _ in range(150)]
+    edges += [(n0 + i, n0 + (i + 1) % n1) for i in range(n1)]
+    e = np.array([(i, j) for i, j in edges if i != j])
+    a = sp.csr_matrix((np.ones(2 * len(e)), (np.r_[e[:, 0], e[:, 1]], np.r_[e[:, 1], e[:, 0]])), shape=(n0 + n1,) * 2)
+    a.sum_duplicates()
+    a.data[:] = 1
+    a.sort_indices()
+    rp, ci = a.indptr.astype(np.int64), a.indices.astype(np.int64)
+    pos = torch.randn(n0 + n1, 32)
+    node_off = torch.tensor([0, n0, n0 + n1])
+    oracle = E.OracleGraphEncoder()
+    oracle.degree_embedding.weight.data.normal_()
+    for m in oracle.modules():                       # non-trivial running statistics
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+    oracle.eval()
+    ref = oracle(node_off, torch.from_numpy(2 * rp), torch.from_numpy(np.repeat(ci, 2)), pos)
+    model = reference_encoder()
+    model.load_state_dict(oracle.state_dict())
+    model.eval()
+    b = CpuBatch(dict(node_off=node_off, row_ptr=torch.from_numpy(rp), col_idx=torch.from_numpy(ci), pos_undirected=pos))
+    b.edge_multiplicity = 2
+    eng = emu_engine()
+    p, buf = eng.make_pass(model, b, training=False)
+    eng.forward([p])
+    torch.testing.assert_close(buf["feat"], ref.detach(), **TOL)
+    b.edge_multiplicity = 1
+    p1, buf1 = eng.make_pass(model, b, training=False)
+    eng.forward([p1])
+    assert (buf1["feat"] - ref.detach()).abs().max() > 1e-2          # the multiplicity matters
+
+
 def _grads_after_backward(model):
     return {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
 

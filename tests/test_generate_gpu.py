@@ -1,0 +1,67 @@
+"""generate.py path on a real MI355X: NodeClassificationDataset + positional embedding + eval-mode encoder through the
+C ABI, against the C sampler oracle (bit-exact node sets) and the torch encoder oracle run on the doubled multigraph
+with the device's own positional embeddings."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_generate_path_against_oracles():
+    from gcc_amd.datasets import NodeClassificationDataset
+    from gcc_amd.encoder import GraphEncoder
+    from gcc_amd.generate import test_moco as run_test_moco
+    from gcc_amd.graphgen import powerlaw_graph
+    from gcc_amd.posemb import DevicePosEmb
+    from oracle import encoder as E
+    from oracle import sampler as O
+
+    rp, ci = powerlaw_graph(700, 4000, 3)
+    n, B, mult = len(rp) - 1, 64, 2
+    ds = NodeClassificationDataset("toy", rw_hops=48, restart_prob=0.8, positional_embedding_size=32, graph=(rp, ci),
+                                   edge_multiplicity=mult, batch_size=B, run_seed=5)
+    torch.manual_seed(0)
+    oracle = E.OracleGraphEncoder()
+    for mod in oracle.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.normal_(0, 0.3)
+            mod.running_var.uniform_(0.5, 2.0)
+    model = GraphEncoder(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
+                         freq_embedding_size=16, degree_embedding_size=16, output_dim=64, node_hidden_dim=64,
+                         edge_hidden_dim=64, num_layers=5, num_step_set2set=6, num_layer_set2set=3, norm=True,
+                         gnn_model="gin", degree_input=True).cuda()
+    model.load_state_dict(oracle.state_dict())
+    pe = DevicePosEmb(B, ds.sampler.node_cap, 32, device="cuda", seed=1, max_views=2, num_buffers=2)
+    kept = []
+
+    class Spy:
+        def __iter__(self):
+            for q, k in ds:
+                torch.cuda.synchronize()
+                yield q, k
+                torch.cuda.synchronize()
+                kept.append([(g.csr_numpy(), g.pos_undirected[: g.number_of_nodes()].cpu().clone(), g.valid) for g in (q, k)])
+
+    emb = run_test_moco(Spy(), model, pe)
+    ds.sampler.check_status()
+    pe.check_status()
+    assert emb.shape == (n, 64)
+    c = O.COracle()
+    deg = np.diff(rp)
+    oracle.eval()
+    ref = []
+    for i, pair in enumerate(kept):
+        seeds = np.zeros(B, dtype=np.int32)
+        valid = pair[0][2]
+        seeds[:valid] = np.arange(i * B, i * B + valid)
+        L = ds.ltab[deg[seeds]]
+        fs = []
+        for view, (csr, pos, _) in enumerate(pair):
+            r = c.sample_batch(rp, ci, seeds, L, view, 5, i * B, O.restart_threshold(0.8))
+            assert (csr["parent_nid"] == r["parent_nid"]).all() and (csr["col_idx"] == r["col_idx"]).all()
+            fs.append(oracle(torch.from_numpy(csr["node_off"].astype(np.int64)),
+                             mult * torch.from_numpy(csr["row_ptr"].astype(np.int64)),
+                             torch.repeat_interleave(torch.from_numpy(csr["col_idx"].astype(np.int64)), mult), pos).detach())
+        ref.append(((fs[0] + fs[1]) / 2)[:valid])
+    torch.testing.assert_close(emb, torch.cat(ref), rtol=1e-3, atol=1e-4)
