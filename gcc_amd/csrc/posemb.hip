@@ -981,6 +981,7 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
         }
 #endif
         if (finished && done == 0 && flag == 2 && tid == 0) atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
+        if (finished && done == 0 && tid == 0) atomicAdd(a.status + 3, 1);      // diagnostics: items that stopped at the cycle cap
         const int nout = finished ? k : keep;
         // output column t <- Ritz vector: restart keeps rank t, the final result is ascending (rank k-1-t)
         if (tid < kM) {
