@@ -38,8 +38,8 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s meas
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=192)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch-size", type=int, default=256)
     ap.add_argument("--nce-k", type=int, default=16384)
     ap.add_argument("--rw-hops", type=int, default=256)
@@ -50,10 +50,10 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--posemb", choices=["device", "placeholder"], default="device")
-    ap.add_argument("--lanes", type=int, default=3, help="producer streams (sampler + positional embedding)")
+    ap.add_argument("--lanes", type=int, default=2, help="producer streams (sampler + positional embedding)")
     ap.add_argument("--reserved-cus", type=int, default=0, help="compute units the producer streams are masked off (kept for the training step)")
     ap.add_argument("--cu-layout", default="interleaved", choices=["interleaved", "block"])
-    ap.add_argument("--chunk", type=int, default=8, help="steps a producer lane prepares per turn (one multi-view eigensolver call)")
+    ap.add_argument("--chunk", type=int, default=16, help="steps a producer lane prepares per turn (one multi-view eigensolver call)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight per producer lane")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the roofline kernel from a separate rocprofv3 --pmc pass "
@@ -248,8 +248,14 @@ def main():
     def step_fn(step, prof=None):
         return trainer.step(step, lr_at(step), prof=prof)
 
-    for i in range(args.warmup):
+    # untimed steps: the requested warm-up, extended to a whole number of producer rounds so that the look-ahead pipeline
+    # (lanes x depth chunks) is in steady state when the clock starts -- the timed region then produces exactly as many
+    # chunks as it consumes (otherwise a short run would train on batches prepared before the clock started)
+    fill = args.lanes * args.depth * args.chunk
+    warm = ((max(args.warmup, fill) + args.chunk - 1) // args.chunk) * args.chunk
+    for i in range(warm):
         step_fn(i)
+    args.first_timed_step = warm
     profs = [dict(sampler=Prof(4), **{n: Prof(2) for n in names}) for _ in range(args.steps)]
     if args.posemb == "device":
         for p in profs:
@@ -260,7 +266,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        last = step_fn(args.warmup + i, prof=profs[i])
+        last = step_fn(args.first_timed_step + i, prof=profs[i])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -316,7 +322,7 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         out = {
             "metric": "sampled-subgraphs/sec", "value": 2 * B * world * args.steps / dt, "unit": "subgraphs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_steps": args.first_timed_step, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 sampler / f32 encoder+head (exact-f32 MFMA)",
             "data": "synthetic",
             "steps_per_sec": args.steps / dt,

@@ -106,16 +106,21 @@ struct PosHead {                     // head of the caller's workspace (zeroed p
     int32_t *next;                   // [4] work counters
     int32_t *list;                   // [4][T] item ids, T = views * B
     float *slots;                    // [workgroups of the slot class][slot_floats]: matrix (kGMax x kGMax) + deflation tables
+    float *tabs;                     // [workgroups of the mid class][kNodeMax * 4]: deflation tables
     int32_t T;
     int64_t slot_floats;
 };
 
+// The deflation tables (16 KiB) are built in LDS.  The 1024-thread classes move them to the workspace once the matrix
+// is filled (the eigenvector arrays overlay them; the expansion at the end reads them back): it keeps the mid class
+// at 132 KiB, so that a workgroup of the training step (26 KiB) still fits on the same CU.
+template <int kNMax> __host__ __device__ constexpr bool tables_in_workspace() { return kNMax > 64; }
 template <int kNMax, int kT, bool kGlobalA>
 __host__ __device__ constexpr int direct_lds_bytes()
 {
     return kGlobalA ? kGLds
                     : (int)(sizeof(float) * (6 * kNMax + 32 * kYld + kT + kNMax * (kNMax + 1) + kNMax * kYld)
-                            + kNodeMax * 16 + kNMax * (33 * 8 + 32));
+                            + (tables_in_workspace<kNMax>() ? 0 : kNodeMax * 16) + kNMax * (33 * 8 + 32));
 }
 
 struct TriLds {
@@ -592,7 +597,8 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     // the deflation tables are built in LDS; the workspace class moves them to its slot once the matrix is filled
     // (the eigenvector arrays overlay them)
     d.tcnt = (int32_t *)lds_rest;
-    if (!kGlobalA) lds_rest += kNodeMax * 4;       // 2 int32 + 4 uint16 tables = 16 KiB
+    constexpr bool kTabW = tables_in_workspace<kNMax>();
+    if (!kTabW) lds_rest += kNodeMax * 4;          // 2 int32 + 4 uint16 tables = 16 KiB
     const int32_t *rp = a.row_ptr + n0;
     d.cbase = d.tcnt + kNodeMax;
     d.par = (uint16_t *)(d.cbase + kNodeMax);
@@ -673,8 +679,9 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
         }
     }
     __syncthreads();
-    if (kGlobalA) {
-        uint32_t *dst = (uint32_t *)(A + (int64_t)kNMax * lda);
+    if (kTabW) {
+        uint32_t *dst = kGlobalA ? (uint32_t *)(A + (int64_t)kNMax * lda)
+                                 : (uint32_t *)(hd.tabs + (int64_t)blockIdx.x * kNodeMax * 4);
         const uint32_t *src = (const uint32_t *)d.tcnt;
         for (int i = tid; i < kNodeMax * 4; i += kT) dst[i] = src[i];
         d.tcnt = (int32_t *)dst;
@@ -1092,6 +1099,7 @@ int64_t gcc_posemb_multi_workspace_bytes(int32_t num_views, int32_t batch_size, 
     const int64_t T = (int64_t)num_views * batch_size;
     const PosGrids g = posemb_grids(T);
     return posemb_head_bytes(T) + g.slot * posemb_slot_floats() * (int64_t)sizeof(float)
+           + (int64_t)g.mid * kNodeMax * 16
            + (int64_t)g.kry * 2 * (kM + 1) * posemb_ldv(batch_size, node_cap) * (int64_t)sizeof(float) + 256;
 }
 
@@ -1129,6 +1137,7 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     hd.next = hd.count + 8;
     hd.list = hd.count + 16;
     hd.slots = (float *)((char *)workspace + posemb_head_bytes(T));
+    hd.tabs = hd.slots + g.slot * posemb_slot_floats();
     hd.T = (int32_t)T;
     hd.slot_floats = posemb_slot_floats();
     constexpr int lds_small = direct_lds_bytes<kJSmall, 256, false>();
@@ -1152,7 +1161,7 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     KryArgs ka;
     ka.m = m;
     ka.hd = hd;
-    ka.vws = hd.slots + g.slot * hd.slot_floats;
+    ka.vws = hd.tabs + (int64_t)g.mid * kNodeMax * 4;
     ka.ldv = (int32_t)posemb_ldv(batch_size, node_cap);
     // longest items first
     const size_t lds_kry = (size_t)3 * ka.ldv * sizeof(float)
