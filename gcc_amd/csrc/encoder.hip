@@ -312,14 +312,17 @@ struct ReadLaunch { ReadArgs p[kMaxPass]; };
 __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
 {
     TRAIN_STEP_WAVE_PRIORITY();
+    // 16 graphs per workgroup; the prediction layers are split over the four waves (wave w: layers w, w + 4, ...) and
+    // the partial scores meet in LDS, so the chain of dependent loads is 2 layers long instead of 5
+    __shared__ float part[4][16][H + 4];
     const ReadArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
-    const int b = ((int)blockIdx.x * 4 + wv) * 16 + j;
+    const int b = (int)blockIdx.x * 16 + j;
     const bool valid = b < a.B;
     F4 score[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) { F4 z = {0.f, 0.f, 0.f, 0.f}; score[cb] = z; }
-    for (int i = 0; i <= a.nlayers; ++i) {
+    for (int i = wv; i <= a.nlayers; i += 4) {
         const int kd = i == 0 ? a.kdim0 : H;
         F4 xb[4];
 #pragma unroll
@@ -346,36 +349,46 @@ __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
             score[cb].w += (acc[cb][3] + bias.w) * m.w;
         }
     }
-    float ss = 0.f;
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-        ss += score[cb].x * score[cb].x + score[cb].y * score[cb].y + score[cb].z * score[cb].z + score[cb].w * score[cb].w;
-    ss += wave_shfl_xor(ss, 16);
-    ss += wave_shfl_xor(ss, 32);
-    const float inv = a.normalize ? 1.0f / fmaxf(sqrtf(ss), a.norm_eps) : 1.0f;   // F.normalize(p=2, eps=1e-5)
-    if (valid) {
+    for (int cb = 0; cb < 4; ++cb) st4(&part[wv][j][16 * cb + 4 * q], score[cb]);
+    __syncthreads();
+    if (wv == 0) {                                   // layer order 0, 1, 2, ... inside each wave, then waves 0..3: fixed
+        float ss = 0.f;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
-            const int ch = 16 * cb + 4 * q;
-            st4(a.score + (int64_t)b * H + ch, score[cb]);
-            F4 o = {score[cb].x * inv, score[cb].y * inv, score[cb].z * inv, score[cb].w * inv};
-            st4(a.feat + (int64_t)b * H + ch, o);
+            F4 t = ld4(&part[0][j][16 * cb + 4 * q]);
+            for (int w2 = 1; w2 < 4; ++w2) t = add4(t, ld4(&part[w2][j][16 * cb + 4 * q]));
+            score[cb] = t;
+            ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+        }
+        ss += wave_shfl_xor(ss, 16);
+        ss += wave_shfl_xor(ss, 32);
+        const float inv = a.normalize ? 1.0f / fmaxf(sqrtf(ss), a.norm_eps) : 1.0f;   // F.normalize(p=2, eps=1e-5)
+        if (valid) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int ch = 16 * cb + 4 * q;
+                st4(a.score + (int64_t)b * H + ch, score[cb]);
+                F4 o = {score[cb].x * inv, score[cb].y * inv, score[cb].z * inv, score[cb].w * inv};
+                st4(a.feat + (int64_t)b * H + ch, o);
+            }
         }
     }
-    // BatchNorm running statistics (torch: momentum 0.1, unbiased variance) -- block 0 only
-    if (a.update_running && blockIdx.x == 0 && tid < H) {
+    // BatchNorm running statistics (torch: momentum 0.1, unbiased variance): BatchNorm k by workgroup k % gridDim.x
+    if (a.update_running && tid >= 64 && tid < 64 + H) {
+        const int c = tid - 64;
         const double n = (double)a.node_off[a.B];
-        for (int k = 0; k < 3 * a.nlayers; ++k) {
+        for (int k = (int)blockIdx.x; k < 3 * a.nlayers; k += (int)gridDim.x) {
             const BnDev &bn = a.bn[k];
             double s1 = 0.0, s2 = 0.0;
-            for (int r = 0; r < kRep; ++r) { s1 += bn.stats[r * 2 * H + tid]; s2 += bn.stats[r * 2 * H + H + tid]; }
+            for (int r = 0; r < kRep; ++r) { s1 += bn.stats[r * 2 * H + c]; s2 += bn.stats[r * 2 * H + H + c]; }
             const double mean = s1 / n;
             double var = s2 / n - mean * mean;
             if (var < 0.0) var = 0.0;
             const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-            bn.running_mean[tid] = (float)((1.0 - a.momentum) * (double)bn.running_mean[tid] + a.momentum * mean);
-            bn.running_var[tid] = (float)((1.0 - a.momentum) * (double)bn.running_var[tid] + a.momentum * unb);
-            if (tid == 0 && bn.nbt) bn.nbt[0] += 1;
+            bn.running_mean[c] = (float)((1.0 - a.momentum) * (double)bn.running_mean[c] + a.momentum * mean);
+            bn.running_var[c] = (float)((1.0 - a.momentum) * (double)bn.running_var[c] + a.momentum * unb);
+            if (c == 0 && bn.nbt) bn.nbt[0] += 1;
         }
     }
 }
@@ -491,7 +504,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
             a.norm_eps = p.w.norm_eps; a.momentum = p.w.bn_momentum;
             L.p[i] = a;
         }
-        hipLaunchKernelGGL(gin_readout_kernel, dim3((maxB + 63) / 64, npass), block, 0, s, L);
+        hipLaunchKernelGGL(gin_readout_kernel, dim3((maxB + 15) / 16, npass), block, 0, s, L);
     }
     prof_mark(prof, 1, s);
     hipError_t e = hipGetLastError();

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_lin_kernel(BwdLinArgs a)
 // Many nodes share a (small) degree, so global atomics would serialise on a few cache lines:
 // each block accumulates into an LDS table (column c is owned by thread c: no atomics, fixed order)
 // and writes its table as one partial; the final kernel sums the kEmbBlocks partials.
-constexpr int kEmbBlocks = 64;
+constexpr int kEmbBlocks = 256;
 constexpr int kEmbMaxElems = 10240;      // (max_degree + 1) * deg_emb_dim floats of LDS (40 KiB)
 
 struct EmbArgs {

@@ -56,7 +56,7 @@ inline Plan make_plan(int32_t B, int32_t K)
 {
     Plan p;
     p.QB = (B + kQPerBlock - 1) / kQPerBlock;
-    int s = (128 + p.QB - 1) / p.QB;       // ~128 workgroups: enough to spread the queue, few enough slabs to reduce
+    int s = (256 + p.QB - 1) / p.QB;       // ~256 workgroups (one per CU): enough to spread the queue, few enough slabs to reduce
     const int maxs = (K + kChunk - 1) / kChunk;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
