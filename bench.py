@@ -323,7 +323,7 @@ def main():
         out = {
             "metric": "sampled-subgraphs/sec", "value": 2 * B * world * args.steps / dt, "unit": "subgraphs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_steps": args.first_timed_step, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 sampler / f32 encoder+head (exact-f32 MFMA)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "steps_per_sec": args.steps / dt,
             "config": {"workload": "BASELINE configs[1]: MoCo K=16384 bsz=256 rw_hops=256 restart=0.8, "

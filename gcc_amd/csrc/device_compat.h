@@ -68,6 +68,12 @@ static inline f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c)
     return d;
 }
 
+// sum over each group of 16 consecutive lanes; valid in the LAST lane of the group (lane & 15) == 15
+static inline float row16_sum_last(float v)
+{
+    for (int d = 1; d < 16; d <<= 1) { float t = wave_shfl_up(v, d); if ((lane_id() & 15) >= d) v += t; }
+    return v;
+}
 // ---- wave reductions / scan (shuffle butterflies; the gfx950 build uses DPP row operations)
 // inclusive wave prefix sum (all 64 lanes must call)
 static inline int wave_scan_incl(int v)
@@ -177,6 +183,15 @@ template <int kCtrl, int kRowMask> __device__ __forceinline__ float dpp_or_self(
 {
     const int i = __float_as_int(v);
     return __int_as_float(__builtin_amdgcn_update_dpp(i, i, kCtrl, kRowMask, 0xF, false));
+}
+// sum over each group of 16 consecutive lanes (a DPP row); valid in the LAST lane of the group
+__device__ __forceinline__ float row16_sum_last(float v)
+{
+    v += dpp_or_zero<0x111, 0xF>(v);
+    v += dpp_or_zero<0x112, 0xF>(v);
+    v += dpp_or_zero<0x114, 0xF>(v);
+    v += dpp_or_zero<0x118, 0xF>(v);
+    return v;
 }
 __device__ __forceinline__ float wave_max(float v)
 {

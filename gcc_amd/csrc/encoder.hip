@@ -93,7 +93,7 @@ struct InLaunch { InArgs p[kMaxPass]; long long *ticks; };
 static long long *g_gin_ticks = nullptr;   // diagnostics (gcc_gin_debug_ticks)
 #define GIN_TICK(ph) do { if (L.ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&L.ticks[(a.first ? 0 : 16) + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 
-__global__ __launch_bounds__(kThreads) void gin_in_kernel(InLaunch L)
+__global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
@@ -147,14 +147,10 @@ __global__ __launch_bounds__(kThreads) void gin_in_kernel(InLaunch L)
         // 5. z1 = agg W0^T + b0 (gin.py:115: linears[0])
         {
             const int j = lane & 15, q = lane >> 4, rl = 16 * wv + j;
-            F4 wf[4][4];                               // (not kept across the gather: it needs the registers)
-            load_w_frags(a.w0, a.kdim, wf);
             F4 xb[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) xb[c] = ld4(&T[rl * kLdt + 16 * c + 4 * q]);
-            f32x4 acc[4];
-            mfma_rows16(xb, wf, acc);
-            epilogue_store_stats(acc, a.b0, a.z1, tile0 + rl, rl < nrows, &red[wv * 2 * H]);
+            linear_rows16_store_stats(xb, a.w0, a.kdim, a.b0, a.z1, tile0 + rl, rl < nrows, &red[wv * 2 * H]);
         }
         __syncthreads();
         GIN_TICK(5);
@@ -192,8 +188,6 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
     Aff4 aa[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) aa[c] = aff4_from_table(taba, 16 * c + 4 * q);
-    F4 wf[4][4];
-    load_w_frags(a.w1, H, wf);
     for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
         const int row = tile0 + 16 * wv + j;
         const bool valid = row < N;
@@ -204,9 +198,7 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
             if (valid) x = affine_relu(ld4(a.z1 + (int64_t)row * H + 16 * c + 4 * q), aa[c]);   // gin.py:115
             xb[c] = x;
         }
-        f32x4 acc[4];
-        mfma_rows16(xb, wf, acc);                                                              // gin.py:116
-        epilogue_store_stats(acc, a.b1, a.z2, row, valid, &red[wv * 2 * H]);
+        linear_rows16_store_stats(xb, a.w1, H, a.b1, a.z2, row, valid, &red[wv * 2 * H]);     // gin.py:116
         __syncthreads();
         flush_stats(red, a.stats_b);
         __syncthreads();

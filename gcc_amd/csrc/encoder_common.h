@@ -176,35 +176,70 @@ __device__ __forceinline__ void load_wt_frags(const float *W, int kdim, F4 wf[4]
 
 // bias add, masked store of the 16x64 block and per-channel sum / sum of squares of the
 // valid rows into red[wave][2][64]
+// one 16-channel block cb of the epilogue: + bias, store, per-wave column sums / sums of squares into red
+__device__ __forceinline__ void epilogue_block(int cb, const f32x4 &acc, const float *bias, float *Z, int row,
+                                               bool valid, float *red /* [128] of this wave */)
+{
+    const int lane = lane_id(), q = lane >> 4;
+    const int ch = 16 * cb + 4 * q;
+    F4 z;
+    z.x = acc[0] + (bias ? bias[ch + 0] : 0.f);
+    z.y = acc[1] + (bias ? bias[ch + 1] : 0.f);
+    z.z = acc[2] + (bias ? bias[ch + 2] : 0.f);
+    z.w = acc[3] + (bias ? bias[ch + 3] : 0.f);
+    if (valid) st4(Z + (int64_t)row * H + ch, z);
+    if (red) {
+        float s[4] = {valid ? z.x : 0.f, valid ? z.y : 0.f, valid ? z.z : 0.f, valid ? z.w : 0.f};
+        float ss[4] = {s[0] * s[0], s[1] * s[1], s[2] * s[2], s[3] * s[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                      // the 16 rows of this wave's tile = one DPP row
+            s[e] = row16_sum_last(s[e]);
+            ss[e] = row16_sum_last(ss[e]);
+        }
+        if ((lane & 15) == 15) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[ch + e] = s[e]; red[H + ch + e] = ss[e]; }
+        }
+    }
+}
 __device__ __forceinline__ void epilogue_store_stats(f32x4 acc[4], const float *bias, float *Z, int row,
                                                      bool valid, float *red /* [128] of this wave */)
 {
-    const int lane = lane_id(), q = lane >> 4;
 #pragma unroll
+    for (int cb = 0; cb < 4; ++cb) epilogue_block(cb, acc[cb], bias, Z, row, valid, red);
+}
+
+// Z[16 rows][64] = X W^T + bias with its epilogue, ONE 16-channel block at a time: only 4 weight fragments are live
+// (mfma_rows16 + load_w_frags keep 16: 48 more VGPRs, which costs a wave of occupancy in the forward kernels)
+__device__ __forceinline__ void linear_rows16_store_stats(const F4 xb[4], const float *W, int kdim, const float *bias,
+                                                          float *Z, int row, bool valid, float *red)
+{
+    const int lane = lane_id(), j = lane & 15, q = lane >> 4;
+#pragma unroll 1
     for (int cb = 0; cb < 4; ++cb) {
-        const int ch = 16 * cb + 4 * q;
-        F4 z;
-        z.x = acc[cb][0] + (bias ? bias[ch + 0] : 0.f);
-        z.y = acc[cb][1] + (bias ? bias[ch + 1] : 0.f);
-        z.z = acc[cb][2] + (bias ? bias[ch + 2] : 0.f);
-        z.w = acc[cb][3] + (bias ? bias[ch + 3] : 0.f);
-        if (valid) st4(Z + (int64_t)row * H + ch, z);
-        if (red) {
-            float s[4] = {valid ? z.x : 0.f, valid ? z.y : 0.f, valid ? z.z : 0.f, valid ? z.w : 0.f};
-            float ss[4] = {s[0] * s[0], s[1] * s[1], s[2] * s[2], s[3] * s[3]};
+        F4 wf[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int d = 1; d < 16; d <<= 1) {
-                    s[e] += wave_shfl_xor(s[e], d);
-                    ss[e] += wave_shfl_xor(ss[e], d);
-                }
-            }
-            if ((lane & 15) == 0) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { red[ch + e] = s[e]; red[H + ch + e] = ss[e]; }
+        for (int c = 0; c < 4; ++c) {
+            const int k0 = 16 * c + 4 * q;
+            const float *p = W + (int64_t)(16 * cb + j) * kdim + k0;
+            if ((kdim & 3) == 0 && k0 + 3 < kdim) {
+                wf[c] = ld4(p);
+            } else {
+                wf[c].x = k0 + 0 < kdim ? p[0] : 0.f;
+                wf[c].y = k0 + 1 < kdim ? p[1] : 0.f;
+                wf[c].z = k0 + 2 < kdim ? p[2] : 0.f;
+                wf[c].w = k0 + 3 < kdim ? p[3] : 0.f;
             }
         }
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            a = mfma_16x16x4_f32(wf[c].x, xb[c].x, a);
+            a = mfma_16x16x4_f32(wf[c].y, xb[c].y, a);
+            a = mfma_16x16x4_f32(wf[c].z, xb[c].z, a);
+            a = mfma_16x16x4_f32(wf[c].w, xb[c].w, a);
+        }
+        epilogue_block(cb, a, bias, Z, row, valid, red);
     }
 }
 
