@@ -97,12 +97,8 @@ __device__ __forceinline__ void reduce_groups(float *part /* [16][128] */, F4 s1
 }
 
 // sum over the 16 lanes that share q (= the 16 rows of a wave's block)
-__device__ __forceinline__ float sum_rows16(float v)
-{
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) v += wave_shfl_xor(v, d);
-    return v;
-}
+// sum over the 16 rows of a wave's tile (one DPP row); valid in the lane with (lane & 15) == 15
+__device__ __forceinline__ float sum_rows16(float v) { return row16_sum_last(v); }
 
 // =========================================================================
 // R1: d score, G_i = dscore * keep_i / (1 - p), dpooled_i = G_i W_i      (gin.py:227-230, graph_encoder.py:196)
@@ -192,7 +188,7 @@ struct BwdCArgs {
     float eps;
 };
 
-__global__ __launch_bounds__(kThreads) void gin_bwd_c_kernel(BwdCArgs a)
+__global__ __launch_bounds__(kThreads, 4) void gin_bwd_c_kernel(BwdCArgs a)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
@@ -304,7 +300,7 @@ struct BwdLinArgs {
 };
 
 template <bool kMask>
-__global__ __launch_bounds__(kThreads) void gin_bwd_lin_kernel(BwdLinArgs a)
+__global__ __launch_bounds__(kThreads, 4) void gin_bwd_lin_kernel(BwdLinArgs a)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float Ci[kCoefRows * H], Co[kCoefRows * H];
@@ -314,8 +310,6 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_lin_kernel(BwdLinArgs a)
     fill_coefs(Ci, a.bn_in, a.bst_in, (double)N, a.eps);
     if (kMask) fill_coefs(Co, a.bn_out, nullptr, (double)N, a.eps);
     __syncthreads();
-    F4 wf[4][4];
-    load_wt_frags(a.W, a.kdim, wf);
     float *myred = &red[wv * 3 * H];
     for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
         const int row = tile0 + 16 * wv + j;
@@ -332,14 +326,32 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_lin_kernel(BwdLinArgs a)
             }
             xb[c] = d;
             const float bx = sum_rows16(d.x), by = sum_rows16(d.y), bz = sum_rows16(d.z), bw = sum_rows16(d.w);
-            if (j == 0) { myred[2 * H + col] = bx; myred[2 * H + col + 1] = by; myred[2 * H + col + 2] = bz; myred[2 * H + col + 3] = bw; }
+            if (j == 15) { myred[2 * H + col] = bx; myred[2 * H + col + 1] = by; myred[2 * H + col + 2] = bz; myred[2 * H + col + 3] = bw; }
         }
-        f32x4 acc[4];
-        mfma_rows16(xb, wf, acc);
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll 1
+        for (int cb = 0; cb < 4; ++cb) {               // one 16-channel block at a time: 4 weight fragments live
             const int col = 16 * cb + 4 * q;
-            F4 o = {acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]};
+            F4 wf[4];
+            {
+                const int orow = 16 * cb + j;          // output index = input column of W
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k0 = 16 * c + 4 * q;     // reduction index = output row of W
+                    wf[c].x = orow < a.kdim ? a.W[(int64_t)(k0 + 0) * a.kdim + orow] : 0.f;
+                    wf[c].y = orow < a.kdim ? a.W[(int64_t)(k0 + 1) * a.kdim + orow] : 0.f;
+                    wf[c].z = orow < a.kdim ? a.W[(int64_t)(k0 + 2) * a.kdim + orow] : 0.f;
+                    wf[c].w = orow < a.kdim ? a.W[(int64_t)(k0 + 3) * a.kdim + orow] : 0.f;
+                }
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc = mfma_16x16x4_f32(wf[c].x, xb[c].x, acc);
+                acc = mfma_16x16x4_f32(wf[c].y, xb[c].y, acc);
+                acc = mfma_16x16x4_f32(wf[c].z, xb[c].z, acc);
+                acc = mfma_16x16x4_f32(wf[c].w, xb[c].w, acc);
+            }
+            F4 o = {acc[0], acc[1], acc[2], acc[3]};
             if (kMask) {
                 F4 z = zero4();
                 if (valid) z = ld4(a.zout + (int64_t)row * H + col);
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_lin_kernel(BwdLinArgs a)
                 const float s0 = sum_rows16(o.x), s1 = sum_rows16(o.y), s2 = sum_rows16(o.z), s3 = sum_rows16(o.w);
                 const float t0 = sum_rows16(o.x * xh.x), t1 = sum_rows16(o.y * xh.y), t2 = sum_rows16(o.z * xh.z),
                             t3 = sum_rows16(o.w * xh.w);
-                if (j == 0) {
+                if (j == 15) {
                     myred[col] = s0; myred[col + 1] = s1; myred[col + 2] = s2; myred[col + 3] = s3;
                     myred[H + col] = t0; myred[H + col + 1] = t1; myred[H + col + 2] = t2; myred[H + col + 3] = t3;
                 }
