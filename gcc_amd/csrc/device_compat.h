@@ -13,6 +13,7 @@ static inline long long device_ticks() { return 0; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void device_fence() {}
 static inline float load_fresh(const float *p) { return *p; }
+static inline double load_fresh_f64(const double *p) { return *p; }
 #include "hipemu.h"
 
 #define DYN_SMEM(name) unsigned char *name = hipemu::g_dyn_smem
@@ -117,7 +118,8 @@ static inline float wave_max(float v)
 __device__ __forceinline__ long long device_ticks() { return (long long)wall_clock64(); }   // 100 MHz
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }        // v_rcp_f32, 1 ulp
 __device__ __forceinline__ void device_fence() { __threadfence(); }                            // release + acquire, agent scope
-__device__ __forceinline__ float load_fresh(const float *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float load_fresh(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double load_fresh_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 #define DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -289,19 +289,34 @@ __global__ __launch_bounds__(kThreads) void ema_kernel(float *ema, const float *
 }
 
 // ---- clip_grad_norm_ + Adam over one flat buffer (train.py:409,417)
-__global__ __launch_bounds__(1024) void gradnorm_kernel(const float *g, int64_t n, double *out)
+constexpr int kNormBlocks = 32;
+// sum of squares of the flat gradient: kNormBlocks partial sums; the workgroup that arrives last adds them up in index
+// order (deterministic).  scratch: [0] = result, [1] = ticket (as int), [2 .. 2 + kNormBlocks) = partials.
+__global__ __launch_bounds__(kThreads) void gradnorm_kernel(const float *g, int64_t n, double *scratch)
 {
     TRAIN_STEP_WAVE_PRIORITY();
-    __shared__ double red[16];
+    __shared__ double red[kThreads / 64];
+    __shared__ int last;
+    const int tid = (int)threadIdx.x;
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)g[i] * (double)g[i];
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + tid; i < n; i += (int64_t)gridDim.x * kThreads)
+        s += (double)g[i] * (double)g[i];
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         double t = 0.0;
-        for (int i = 0; i < 16; ++i) t += red[i];
-        out[0] = t;
+        for (int i = 0; i < kThreads / 64; ++i) t += red[i];
+        scratch[2 + blockIdx.x] = t;
+        device_fence();
+        last = atomicAdd((int *)(scratch + 1), 1) == (int)gridDim.x - 1;
+        if (last) {
+            device_fence();
+            double tot = 0.0;
+            for (int i = 0; i < (int)gridDim.x; ++i) tot += load_fresh_f64(scratch + 2 + i);
+            scratch[0] = tot;
+            *(int *)(scratch + 1) = 0;
+        }
     }
 }
 
@@ -428,7 +443,7 @@ int32_t gcc_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_
     hipStream_t s = (hipStream_t)stream;
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(gradnorm_kernel, dim3(1), dim3(1024), 0, s, (const float *)grad, n, scratch);
+    hipLaunchKernelGGL(gradnorm_kernel, dim3(kNormBlocks), dim3(kThreads), 0, s, (const float *)grad, n, scratch);
     int blocks = (int)((n + kThreads - 1) / kThreads);
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(kThreads), 0, s, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,

@@ -168,7 +168,7 @@ class FlatAdam:
         self.exp_avg_sq = torch.zeros_like(param)
         self.steps = 0
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=param.device)
-        self._scratch = torch.zeros(1, dtype=torch.float64, device=param.device)
+        self._scratch = torch.zeros(64, dtype=torch.float64, device=param.device)
 
     def step(self):
         g = self.param_groups[0]

@@ -290,7 +290,7 @@ int32_t gcc_queue_enqueue(float *mem, int32_t K, const float *keys, int32_t nkey
 /* clip_grad_norm_(max_norm) + Adam.step() of train.py:409,417 over one flat buffer (torch.optim.Adam
  * semantics: L2 weight decay added to the gradient, bias correction with `step` >= 1, eps outside the
  * sqrt).  grad_norm: device [1] out (the pre-clip norm); max_norm <= 0 disables clipping.
- * scratch: device double[1]. */
+ * scratch: device double[64], zeroed once by the caller (partial sums and an arrival counter that resets itself). */
 int32_t gcc_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
                       float *grad_norm, double *scratch, void *stream);
