@@ -1078,12 +1078,21 @@ struct PosGrids { int32_t small, mid, slot, kry; };
 static PosGrids posemb_grids(int64_t T)
 {
     // fixed grids: enough workgroups for the typical class sizes (~73 % / 19 % / 6 % / 2 % of a batch at rw_hops 256);
-    // larger classes loop
+    // larger classes loop.  No class may cover more than half of the 256 CUs (small: 2 workgroups per CU): a solver
+    // workgroup holds most of a CU's LDS for milliseconds, and when every CU has one the training step's kernels whose
+    // workgroups do not fit beside it wait for the whole launch to drain (3-5 ms stalls in the kernel trace).
+    static int caps[4] = {0, 0, 0, 0};
+    if (caps[0] == 0) {                              // tuning knob: GCC_POSEMB_GRID_CAPS="small,mid,slot,krylov"
+        int c[4] = {256, 128, 128, 64};
+        const char *e = getenv("GCC_POSEMB_GRID_CAPS");
+        if (e) (void)sscanf(e, "%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3]);
+        for (int i = 0; i < 4; ++i) caps[i] = c[i] < 1 ? 1 : c[i];
+    }
     PosGrids g;
-    g.small = (int32_t)(T < 2048 ? T : 2048);
-    g.mid = (int32_t)((T + 3) / 4 < 1024 ? (T + 3) / 4 : 1024);
-    g.slot = (int32_t)((T + 7) / 8 < 128 ? (T + 7) / 8 : 128);
-    g.kry = (int32_t)((T + 15) / 16 < 64 ? (T + 15) / 16 : 64);
+    g.small = (int32_t)(T < caps[0] ? T : caps[0]);
+    g.mid = (int32_t)((T + 3) / 4 < caps[1] ? (T + 3) / 4 : caps[1]);
+    g.slot = (int32_t)((T + 7) / 8 < caps[2] ? (T + 7) / 8 : caps[2]);
+    g.kry = (int32_t)((T + 15) / 16 < caps[3] ? (T + 15) / 16 : caps[3]);
     return g;
 }
 static int64_t posemb_head_bytes(int64_t T) { return ((16 + kNumCls * T) * 4 + 255) / 256 * 256; }
