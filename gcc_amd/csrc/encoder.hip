@@ -32,7 +32,7 @@ namespace {
 // =========================================================================
 // F0: assemble input features (graph_encoder.py:158-165) + SumPooling of hidden_rep[0]
 struct FeatArgs {
-    const int32_t *node_off, *row_ptr, *graph_id;
+    const int32_t *node_off, *row_ptr, *graph_id, *seed_local;
     const float *pos, *emb;
     float *x0;
     double *pooled0;
@@ -55,7 +55,8 @@ __global__ __launch_bounds__(kThreads) void gin_feat_kernel(FeatLaunch L)
                 const int v = tile0 + r;
                 const int deg = (a.row_ptr[v + 1] - a.row_ptr[v]) * a.mult;          // g.in_degrees(), :154
                 const int dcl = deg < a.max_degree ? deg : a.max_degree;  // clamp(0, max_degree), :161
-                const bool is_seed = v == a.node_off[a.graph_id[v]];      // ndata["seed"], data_util.py:234-238
+                const int gv = a.graph_id[v];
+                const bool is_seed = v == a.node_off[gv] + (a.seed_local ? a.seed_local[gv] : 0);   // ndata["seed"], data_util.py:234-238
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = 4 * t + e;
@@ -419,7 +420,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
         FeatLaunch L;
         for (int i = 0; i < npass; ++i) {
             const gcc_gin_pass &p = passes[i];
-            L.p[i] = {p.node_off, p.row_ptr, p.graph_id, p.pos, p.w.degree_embedding, p.x0, p.pooled,
+            L.p[i] = {p.node_off, p.row_ptr, p.graph_id, p.seed_local, p.pos, p.w.degree_embedding, p.x0, p.pooled,
                       p.batch_size, p.w.pos_dim, p.w.deg_emb_dim, p.w.max_degree, p.edge_multiplicity > 1 ? p.edge_multiplicity : 1};
         }
         hipLaunchKernelGGL(gin_feat_kernel, grid, block, 0, s, L);

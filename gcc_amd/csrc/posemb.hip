@@ -249,6 +249,141 @@ __device__ void tridiagonalize(float *A, int lda, int n, const TriLds &w)
     __syncthreads();
 }
 
+// The same reduction streaming ONLY THE LOWER TRIANGLE (row i: columns <= i): half the memory traffic, which is what
+// bounds the workspace-resident class.  p = A v is assembled from the row part (sum over c <= i of A[i][c] v_c) and the
+// column part (row i adds A[i][c] v_i to p_c for c < i; per-wave partial sums in `slab`, combined in wave order).
+// Column k of the trailing matrix (the next reflector's input) is captured into xcol while the rows are updated, so
+// no strided column read is needed.  Row k's (unused) upper part stores reflector k as in tridiagonalize().
+// slab: LDS [kT / 64][ldslab]; xcol: LDS [n].  All threads call it; ends with a barrier.
+template <int kCPL, int kT, int kR>
+__device__ void tridiagonalize_lower(float *A, int lda, int n, const TriLds &w, float *slab, int ldslab, float *xcol)
+{
+    constexpr int kNW = kT / 64;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < n; i += kT) xcol[i] = i >= 1 ? A[(int64_t)i * lda] : 0.f;        // column 0 below the diagonal
+    __syncthreads();
+    for (int k = 0; k + 2 < n; ++k) {
+        float v[kCPL];
+        float sig = 0.f;
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) {
+            const int c = lane + 64 * u;
+            v[u] = (c > k && c < n) ? xcol[c] : 0.f;
+            sig += c > k + 1 ? v[u] * v[u] : 0.f;
+        }
+        sig = wave_sum(sig);
+        const float x0 = xcol[k + 1];
+        if (sig <= 1e-30f) {                         // block-uniform: the column is already tridiagonal, H_k = I
+            if (tid == 0) { w.dg[k] = A[(int64_t)k * lda + k]; w.of[k] = x0; w.tau[k] = 0.f; }
+            __syncthreads();                         // xcol is rewritten below
+            for (int i = k + 2 + tid; i < n; i += kT) xcol[i] = A[(int64_t)i * lda + k + 1];
+            __syncthreads();
+            continue;
+        }
+        const float mu = sqrtf(x0 * x0 + sig);
+        const float beta = x0 > 0.f ? -mu : mu;
+        const float t = (beta - x0) / beta;
+        const float scale = 1.0f / (x0 - beta);
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) {
+            const int c = lane + 64 * u;
+            v[u] = c == k + 1 ? 1.0f : v[u] * scale;
+        }
+        if (wv == 0) {
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u)
+                if (lane + 64 * u < n) w.vbuf[lane + 64 * u] = v[u];
+        }
+        __syncthreads();                             // vbuf visible (the column part needs v_i of other rows)
+        float colacc[kCPL];
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) colacc[u] = 0.f;
+        for (int i0 = k + 1 + wv * kR; i0 < n; i0 += kNW * kR) {
+            float s[kR];
+#pragma unroll
+            for (int r = 0; r < kR; ++r) {
+                s[r] = 0.f;
+                const int i = i0 + r < n ? i0 + r : n - 1;
+                const float vi = i0 + r < n ? w.vbuf[i] : 0.f;
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) {
+                    const int c = lane + 64 * u;
+                    const float aic = (c > k && c <= i) ? A[(int64_t)i * lda + c] : 0.f;
+                    s[r] = fmaf(aic, v[u], s[r]);
+                    colacc[u] = fmaf(c < i ? aic : 0.f, vi, colacc[u]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kR; ++r) {
+                const float sr = wave_sum(s[r]);
+                if (lane == 0 && i0 + r < n) w.pbuf[i0 + r] = sr;        // row part
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u)
+            if (lane + 64 * u < n) slab[wv * ldslab + lane + 64 * u] = colacc[u];
+        __syncthreads();
+        for (int c = k + 1 + tid; c < n; c += kT) {   // p = tau (row part + column parts in wave order)
+            float pc = w.pbuf[c];
+            for (int q = 0; q < kNW; ++q) pc += slab[q * ldslab + c];
+            w.pbuf[c] = t * pc;
+        }
+        if (wv == 0) {                               // row k is dead now: its upper part stores the reflector
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) {
+                const int c = lane + 64 * u;
+                if (c > k + 1 && c < n) A[(int64_t)k * lda + c] = v[u];
+            }
+            if (lane == 0) { w.dg[k] = A[(int64_t)k * lda + k]; w.of[k] = beta; w.tau[k] = t; }
+        }
+        __syncthreads();
+        float pc[kCPL], pv = 0.f;
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) {
+            const int c = lane + 64 * u;
+            pc[u] = (c > k && c < n) ? w.pbuf[c] : 0.f;
+            pv += pc[u] * v[u];
+        }
+        const float K = 0.5f * t * wave_sum(pv);
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) pc[u] -= K * v[u];          // w = p - K v
+        for (int i0 = k + 1 + wv * kR; i0 < n; i0 += kNW * kR) {    // A -= v w^T + w v^T on the lower triangle
+            float arow[kR][kCPL];
+#pragma unroll
+            for (int r = 0; r < kR; ++r) {
+                const int i = i0 + r < n ? i0 + r : n - 1;
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) {
+                    const int c = lane + 64 * u;
+                    arow[r][u] = (c > k && c <= i) ? A[(int64_t)i * lda + c] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kR; ++r) {
+                const int i = i0 + r;
+                if (i >= n) continue;
+                const float vi = w.vbuf[i], wi = w.pbuf[i] - K * vi;
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) {
+                    const int c = lane + 64 * u;
+                    if (c > k && c <= i) {
+                        const float nv = arow[r][u] - (vi * pc[u] + wi * v[u]);
+                        A[(int64_t)i * lda + c] = nv;
+                        if (c == k + 1) xcol[i] = nv;               // column k + 1: the next reflector's input
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (n >= 2) { w.dg[n - 2] = A[(int64_t)(n - 2) * lda + n - 2]; w.of[n - 2] = A[(int64_t)(n - 1) * lda + n - 2]; }
+        w.dg[n - 1] = A[(int64_t)(n - 1) * lda + n - 1];
+        w.of[n - 1] = 0.f;
+    }
+    __syncthreads();
+}
+
 // number of eigenvalues of T below x (Sturm sequence of the LDL^T pivots, as LAPACK's dlaebz)
 __device__ __forceinline__ int sturm_count(const float *dg, const float *of2, int n, float x)
 {
@@ -694,7 +829,13 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     }
 
     PHASE_TICK(0);                                 // deflation + matrix
-    tridiagonalize<kCPL, kT, kGlobalA ? 4 : 2>(A, lda, nr, w);
+    if (kGlobalA) {
+        // (the eigenvector / LU region of the LDS is free until the bisection: per-wave column sums and the pivot column)
+        float *xcol = lds_rest, *slab = lds_rest + kNMax;
+        tridiagonalize_lower<kCPL, kT, 4>(A, lda, nr, w, slab, kNMax, xcol);
+    } else {
+        tridiagonalize<kCPL, kT, 2>(A, lda, nr, w);
+    }
     PHASE_TICK(1);
     const int kq = min(k, nr);
     eig_top_values<kT, kMaxVec>(w, nr, kq, es);

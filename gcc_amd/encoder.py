@@ -161,6 +161,8 @@ class GinEngine:
             p.agg[i], p.z1[i], p.z2[i] = ptr(buf["agg"][i]), ptr(buf["z1"][i]), ptr(buf["z2"][i])
         p.stats, p.pooled, p.score, p.feat = ptr(buf["stats"]), ptr(buf["pooled"]), ptr(buf["score"]), ptr(buf["feat"])
         p.edge_multiplicity = int(getattr(g, "edge_multiplicity", 1))
+        seed_local = getattr(g, "seed_local", None)
+        p.seed_local = ptr(seed_local) if seed_local is not None else None
         buf = dict(buf)
         buf["_keepalive"] = (g, keep, enc)      # the struct holds raw pointers into these
         return p, buf

@@ -12,10 +12,11 @@ def test_moco(dataset, model, posemb, opt=None):
     emb_list = []
     for graph_q, graph_k in dataset:
         bsz = graph_q.batch_size
-        posemb.multi([graph_q, graph_k]) if hasattr(posemb, "multi") else (posemb(graph_q), posemb(graph_k))
+        views = [graph_q] if graph_k is graph_q else [graph_q, graph_k]       # entire_graph: both views are one graph
+        posemb.multi(views) if hasattr(posemb, "multi") else [posemb(v) for v in views]
         with torch.no_grad():
             feat_q = model(graph_q)
-            feat_k = model(graph_k)
+            feat_k = feat_q if graph_k is graph_q else model(graph_k)
         if opt is not None:
             assert feat_q.shape == (bsz, opt.hidden_size)          # generate.py:51
         emb_list.append(((feat_q + feat_k) / 2)[: graph_q.valid].detach().cpu())

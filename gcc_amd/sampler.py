@@ -94,7 +94,13 @@ class _NData:
         if key == "seed":                       # data_util.py:234-238: one-hot at local node 0
             n = g.number_of_nodes()
             s = torch.zeros(n, dtype=torch.long, device=g.node_off.device)
-            s[g.node_off[: g.batch_size].long()] = 1
+            first = g.node_off[: g.batch_size].long()
+            local = getattr(g, "seed_local", None)
+            if local is not None:                   # entire_graph=True: the seed keeps its own index, data_util.py:236-237
+                keep = (g.node_off[1: g.batch_size + 1] > g.node_off[: g.batch_size])
+                s[(first + local.long())[keep]] = 1
+            else:
+                s[first] = 1
             return s
         if key == "pos_undirected":
             if g.pos_undirected is None:

@@ -5,8 +5,9 @@ node of a graph as (f(q) + f(k)) / 2 over its two RWR views with the eval-mode e
 ``data/<name>/<name>.edgelist`` format, gcc/datasets/data_util.py:61-110) or ``--graph-npz`` (row_ptr/col_idx);
 everything runs on the GPU (sampler, positional embedding, encoder).
 
-Extra flags (not in the reference): --edgelist / --nodelabel / --graph-npz / --edge-multiplicity / --batch-size.
-Graph-classification datasets (entire_graph=True over many small graphs) are not covered yet."""
+Extra flags (not in the reference): --edgelist / --nodelabel / --graph-npz / --graphs-npz / --edge-multiplicity /
+--batch-size.  Graph-classification datasets (entire_graph=True, generate.py:75-82) come as ``--graphs-npz``: node_off
+[G+1], row_ptr [N+1] (per-graph offsets restarting at 0 are rebuilt from node_off), col_idx (local ids)."""
 import argparse
 import os
 
@@ -16,7 +17,7 @@ import torch
 
 def main(args_test):
     from gcc_amd import ingest
-    from gcc_amd.datasets import NodeClassificationDataset
+    from gcc_amd.datasets import GraphClassificationDataset, NodeClassificationDataset
     from gcc_amd.encoder import GraphEncoder
     from gcc_amd.generate import test_moco
     from gcc_amd.posemb import DevicePosEmb
@@ -34,21 +35,35 @@ def main(args_test):
     args.device = torch.device("cuda", args.gpu)
     torch.cuda.set_device(args.device)
 
-    if args_test.edgelist:
+    graphs = None
+    if args_test.graphs_npz:
+        z = np.load(args_test.graphs_npz)
+        no, rp, ci = z["node_off"].astype(np.int64), z["row_ptr"].astype(np.int64), z["col_idx"].astype(np.int64)
+        graphs = [(rp[no[i]:no[i + 1] + 1] - rp[no[i]], ci[rp[no[i]]:rp[no[i + 1]]]) for i in range(len(no) - 1)]
+        graph, mult = None, max(args_test.edge_multiplicity, 1)
+    elif args_test.edgelist:
         d = ingest.read_edgelist(args_test.edgelist, args_test.nodelabel, hindex="hindex" in args_test.dataset)
         graph, mult = (d["row_ptr"], d["col_idx"]), d["edge_multiplicity"]
     elif args_test.graph_npz:
         z = np.load(args_test.graph_npz)
         graph, mult = (z["row_ptr"], z["col_idx"]), args_test.edge_multiplicity
     else:
-        raise SystemExit("pass --edgelist data/<name>/<name>.edgelist or --graph-npz (dataset files are not bundled)")
+        raise SystemExit("pass --edgelist data/<name>/<name>.edgelist, --graph-npz or --graphs-npz (dataset files are not bundled)")
     if args_test.edge_multiplicity:
         mult = args_test.edge_multiplicity
-    train_dataset = NodeClassificationDataset(                       # generate.py:84-91
-        dataset=args_test.dataset, rw_hops=args.rw_hops, subgraph_size=args.subgraph_size,
-        restart_prob=args.restart_prob, positional_embedding_size=args.positional_embedding_size,
-        graph=graph, edge_multiplicity=mult, batch_size=args_test.batch_size, run_seed=getattr(args, "seed", 0),
-        device=args.device)
+    if graphs is not None:
+        train_dataset = GraphClassificationDataset(                  # generate.py:75-82
+            dataset=args_test.dataset, rw_hops=args.rw_hops, subgraph_size=args.subgraph_size,
+            restart_prob=args.restart_prob, positional_embedding_size=args.positional_embedding_size,
+            graphs=graphs, edge_multiplicity=mult, batch_size=args_test.batch_size, device=args.device)
+        node_cap = train_dataset.node_cap
+    else:
+        train_dataset = NodeClassificationDataset(                   # generate.py:84-91
+            dataset=args_test.dataset, rw_hops=args.rw_hops, subgraph_size=args.subgraph_size,
+            restart_prob=args.restart_prob, positional_embedding_size=args.positional_embedding_size,
+            graph=graph, edge_multiplicity=mult, batch_size=args_test.batch_size, run_seed=getattr(args, "seed", 0),
+            device=args.device)
+        node_cap = train_dataset.sampler.node_cap
     model = GraphEncoder(                                            # generate.py:102-118
         positional_embedding_size=args.positional_embedding_size, max_node_freq=args.max_node_freq,
         max_edge_freq=args.max_edge_freq, max_degree=args.max_degree, freq_embedding_size=args.freq_embedding_size,
@@ -58,10 +73,11 @@ def main(args_test):
     model = model.to(args.device)
     model.load_state_dict(checkpoint["model"])
     del checkpoint
-    posemb = DevicePosEmb(args_test.batch_size, train_dataset.sampler.node_cap, args.positional_embedding_size,
+    posemb = DevicePosEmb(args_test.batch_size, node_cap, args.positional_embedding_size,
                           device=args.device, seed=getattr(args, "seed", 0), max_views=2, num_buffers=2)
     emb = test_moco(train_dataset, model, posemb, args)
-    train_dataset.sampler.check_status()
+    if graphs is None:
+        train_dataset.sampler.check_status()
     posemb.check_status()
     os.makedirs(args.model_folder, exist_ok=True)
     out = os.path.join(args.model_folder, args_test.dataset)
@@ -79,6 +95,7 @@ if __name__ == "__main__":
     parser.add_argument("--edgelist", type=str, default=None, help="<name>.edgelist of the reference's data folder")
     parser.add_argument("--nodelabel", type=str, default=None, help="<name>.nodelabel (only read to validate the node set)")
     parser.add_argument("--graph-npz", type=str, default=None, help="npz with row_ptr/col_idx of the simple symmetric graph")
+    parser.add_argument("--graphs-npz", type=str, default=None, help="npz with node_off/row_ptr/col_idx of a list of small graphs (graph classification)")
     parser.add_argument("--edge-multiplicity", type=int, default=0, help="copies of every edge in the reference's DGL graph (edge lists: detected; npz: default 2)")
     parser.add_argument("--batch-size", type=int, default=256)
     # fmt: on

@@ -224,6 +224,9 @@ typedef struct gcc_gin_pass {    /* one encoder invocation on one batched graph 
                                   * neighbour sum.  The reference's NodeClassificationDataset builds its DGL graph
                                   * with every undirected edge twice per direction (data_util.py:84-85 +
                                   * graph_dataset.py:301-302); forward only (backward requires 1). */
+    const int32_t *seed_local;   /* device [B] or NULL: local index of the seed node of every graph (NULL: node 0, as the
+                                  * sampler emits; graph classification marks g.out_degrees().argmax(),
+                                  * data_util.py:236-237 with entire_graph=True) */
 } gcc_gin_pass;
 
 /* Runs `npass` independent passes (e.g. query with model, key with model_ema)

@@ -81,7 +81,7 @@ class OracleGraphEncoder(nn.Module):
         self.p = final_dropout
 
     def forward(self, node_off, row_ptr, col_idx, pos_undirected, dropout_masks=None,
-                return_all_outputs=False):
+                return_all_outputs=False, seed_local=None):
         """dropout_masks: None (eval / no dropout) or float tensor [L, B, out] of keep masks (0/1)."""
         node_off = torch.as_tensor(node_off, dtype=torch.long)
         row_ptr = torch.as_tensor(row_ptr, dtype=torch.long)
@@ -90,8 +90,9 @@ class OracleGraphEncoder(nn.Module):
         src = torch.repeat_interleave(torch.arange(n), row_ptr[1:] - row_ptr[:-1])
         dst = col_idx
         gid = torch.repeat_interleave(torch.arange(B), node_off[1:] - node_off[:-1])
-        seed = torch.zeros(n)
-        seed[node_off[:-1]] = 1.0
+        seed = torch.zeros(n)                                                   # data_util.py:234-238
+        first = node_off[:-1] + (0 if seed_local is None else torch.as_tensor(seed_local, dtype=torch.long))
+        seed[first[node_off[1:] > node_off[:-1]]] = 1.0                        # (empty padding graphs have no seed)
         degrees = torch.bincount(dst, minlength=n)                              # g.in_degrees(), :154
         h = torch.cat((pos_undirected, self.degree_embedding(degrees.clamp(0, self.max_degree)),
                        seed.unsqueeze(1)), dim=-1)                              # :158-165

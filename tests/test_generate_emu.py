@@ -153,3 +153,61 @@ def test_generate_embeddings_match_the_oracle_on_the_multigraph(tmp_path):
                              torch.repeat_interleave(b.col_idx.long(), mult), b.pos_undirected[:n]).detach())
         ref.append(((fs[0] + fs[1]) / 2)[: q.valid])
     torch.testing.assert_close(emb, torch.cat(ref), rtol=1e-4, atol=2e-5)
+
+
+def test_graph_classification_dataset_whole_graphs_and_seed_flag():
+    """GraphClassificationDataset (entire_graph=True): every item is a whole graph in its own node order, the seed flag
+    sits on the max-out-degree node, both views are the same graph; embeddings against the oracle."""
+    from gcc_amd.datasets import GraphClassificationDataset
+
+    rng = np.random.RandomState(4)
+    graphs = []
+    for n in (7, 19, 33, 12, 70):
+        pairs = {(i, i + 1) for i in range(n - 1)}
+        while len(pairs) < 2 * n:
+            a, b = sorted(rng.randint(0, n, 2))
+            if a != b:
+                pairs.add((a, b))
+        rp, ci, m = ingest.csr_from_pairs(np.array(sorted(pairs)), n)
+        assert m == 1
+        graphs.append((rp, ci))
+    ds = GraphClassificationDataset("toy", graphs=graphs, batch_size=4, device="cpu")
+    assert len(ds) == ds.total == 5 and ds.entire_graph
+    batches = list(ds)
+    assert len(batches) == 2 and batches[0][0] is batches[0][1] and batches[1][0].valid == 1
+    g0 = batches[0][0]
+    assert g0.node_off.tolist() == [0, 7, 26, 59, 71]
+    seeds = g0.ndata["seed"].numpy()
+    for b, (rp, ci) in enumerate(graphs[:4]):
+        lo = int(g0.node_off[b])
+        assert np.nonzero(seeds[lo:lo + len(rp) - 1])[0].tolist() == [int(np.argmax(np.diff(rp)))]
+        assert (g0.col_idx[int(g0.edge_off[b]):int(g0.edge_off[b + 1])].numpy() - lo == ci).all()      # own node order
+    torch.manual_seed(2)
+    oracle = E.OracleGraphEncoder()
+    for mod in oracle.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.normal_(0, 0.3)
+            mod.running_var.uniform_(0.5, 2.0)
+    model = reference_encoder()
+    model.load_state_dict(oracle.state_dict())
+    model._engine = emu_engine()
+    pe = DevicePosEmb(4, ds.node_cap, HID, device="cpu", lib=emu_lib(), ptr=lambda t: 0 if t is None else t.data_ptr(),
+                      max_views=2, num_buffers=2)
+    kept = []
+
+    class Spy:
+        def __iter__(self):
+            for q, k in ds:
+                kept.append(q)
+                yield q, k
+
+    emb = run_test_moco(Spy(), model, pe)
+    assert emb.shape == (5, 64)
+    oracle.eval()
+    ref = []
+    for g in kept:
+        n = int(g.node_off[-1])
+        f = oracle(g.node_off.long(), g.row_ptr[: n + 1].long(), g.col_idx.long(), g.pos_undirected[:n],
+                   seed_local=g.seed_local.long()).detach()
+        ref.append(f[: g.valid])
+    torch.testing.assert_close(emb, torch.cat(ref), rtol=1e-4, atol=2e-5)
