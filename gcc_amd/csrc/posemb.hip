@@ -106,15 +106,16 @@ struct PosHead {                     // head of the caller's workspace (zeroed p
     int32_t *next;                   // [4] work counters
     int32_t *list;                   // [4][T] item ids, T = views * B
     float *slots;                    // [workgroups of the slot class][slot_floats]: matrix (kGMax x kGMax) + deflation tables
-    float *tabs;                     // [workgroups of the mid class][kNodeMax * 4]: deflation tables
+    float *tabs;                     // [workgroups of the mid class, then of the small class][kNodeMax * 4]: deflation tables
+    int32_t tabs_small_off;          // first small-class table (= workgroups of the mid class)
     int32_t T;
     int64_t slot_floats;
 };
 
-// The deflation tables (16 KiB) are built in LDS.  The 1024-thread classes move them to the workspace once the matrix
-// is filled (the eigenvector arrays overlay them; the expansion at the end reads them back): it keeps the mid class
-// at 132 KiB, so that a workgroup of the training step (26 KiB) still fits on the same CU.
-template <int kNMax> __host__ __device__ constexpr bool tables_in_workspace() { return kNMax > 64; }
+// The deflation tables (16 KiB) are built in LDS and moved to the workspace once the matrix is filled (the eigenvector
+// arrays overlay them; the expansion at the end reads them back): it keeps the mid class at 132 KiB, so that a
+// workgroup of the training step (26 KiB) still fits on the same CU, and the small class at 44 KiB (3 per CU).
+template <int kNMax> __host__ __device__ constexpr bool tables_in_workspace() { return true; }
 template <int kNMax, int kT, bool kGlobalA>
 __host__ __device__ constexpr int direct_lds_bytes()
 {
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     __syncthreads();
     if (kTabW) {
         uint32_t *dst = kGlobalA ? (uint32_t *)(A + (int64_t)kNMax * lda)
-                                 : (uint32_t *)(hd.tabs + (int64_t)blockIdx.x * kNodeMax * 4);
+                                 : (uint32_t *)(hd.tabs + ((int64_t)(kCls == kClsMid ? 0 : hd.tabs_small_off) + blockIdx.x) * kNodeMax * 4);
         const uint32_t *src = (const uint32_t *)d.tcnt;
         for (int i = tid; i < kNodeMax * 4; i += kT) dst[i] = src[i];
         d.tcnt = (int32_t *)dst;
@@ -1249,7 +1250,7 @@ int64_t gcc_posemb_multi_workspace_bytes(int32_t num_views, int32_t batch_size, 
     const int64_t T = (int64_t)num_views * batch_size;
     const PosGrids g = posemb_grids(T);
     return posemb_head_bytes(T) + g.slot * posemb_slot_floats() * (int64_t)sizeof(float)
-           + (int64_t)g.mid * kNodeMax * 16
+           + (int64_t)(g.mid + g.small) * kNodeMax * 16
            + (int64_t)g.kry * 2 * (kM + 1) * posemb_ldv(batch_size, node_cap) * (int64_t)sizeof(float) + 256;
 }
 
@@ -1288,6 +1289,7 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     hd.list = hd.count + 16;
     hd.slots = (float *)((char *)workspace + posemb_head_bytes(T));
     hd.tabs = hd.slots + g.slot * posemb_slot_floats();
+    hd.tabs_small_off = g.mid;
     hd.T = (int32_t)T;
     hd.slot_floats = posemb_slot_floats();
     constexpr int lds_small = direct_lds_bytes<kJSmall, 256, false>();
@@ -1311,7 +1313,7 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     KryArgs ka;
     ka.m = m;
     ka.hd = hd;
-    ka.vws = hd.tabs + (int64_t)g.mid * kNodeMax * 4;
+    ka.vws = hd.tabs + (int64_t)(g.mid + g.small) * kNodeMax * 4;
     ka.ldv = (int32_t)posemb_ldv(batch_size, node_cap);
     // longest items first
     const size_t lds_kry = (size_t)3 * ka.ldv * sizeof(float)
