@@ -27,6 +27,7 @@ import time
 import numpy as np
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")      # the command processor serves few queues well (tools/contention_probe.py)
+os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")   # RCCL's stream must not share a hardware queue with a producer lane
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

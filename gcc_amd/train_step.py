@@ -189,13 +189,16 @@ class FlatAdam:
 class MoCoTrainStep:
     def __init__(self, model: GraphEncoder, model_ema: GraphEncoder, contrast: MemoryMoCo, sampler, posemb,
                  learning_rate=0.005, betas=(0.9, 0.999), weight_decay=1e-5, clip_norm=1.0, alpha=0.999,
-                 world_size=1, rank=0, prefetch=True, extra_lanes=(), depth=2, lanes=None, chunk=1, reserved_cus=0, cu_layout="interleaved"):
+                 world_size=1, rank=0, prefetch=True, extra_lanes=(), depth=2, lanes=None, chunk=1, reserved_cus=0, cu_layout="interleaved",
+                 collectives=None):
         """``sampler``/``posemb``: producer lane 0; ``extra_lanes``: more (sampler, posemb) pairs with their own
         workspaces for multi-stream prefetch (see :class:`BatchProducer`)."""
         self.model, self.ema, self.contrast = model, model_ema, contrast
         self.sampler, self.posemb = sampler, posemb
         self.clip_norm, self.alpha = clip_norm, alpha
         self.world, self.rank = world_size, rank
+        # collectives run whenever there is more than one rank (``collectives=True`` forces them at world_size 1: tests)
+        self.collectives = world_size > 1 if collectives is None else bool(collectives)
         self.dev = next(model.parameters()).device
         self.flat, self.n_live = flatten_parameters(model)
         self.flat_ema, n2 = flatten_parameters(model_ema)
@@ -215,7 +218,7 @@ class MoCoTrainStep:
         self.dropout_seed = 0x5EED0000
         self.B = sampler.batch_size
         self.L = len(model.gnn.ginlayers)
-        self.keys_all = torch.empty(self.B * world_size, H, device=self.dev) if world_size > 1 else None
+        self.keys_all = torch.empty(self.B * world_size, H, device=self.dev) if self.collectives else None
         self.one = torch.ones(1, device=self.dev)
         self.prefetch = prefetch and self.dev.type == "cuda"
         # the ~75 short training kernels of a step must not queue behind the producers' millisecond-long
@@ -262,7 +265,7 @@ class MoCoTrainStep:
         c = self.contrast
         outs = self.nce.forward(feat_q, feat_k, c.memory, c.T, 0, stream=st, prof=pr.get("nce_fwd"))   # train.py:393,407
         keys = feat_k
-        if self.world > 1:                                               # RCCL all-gather of keys over xGMI
+        if self.collectives:                                             # RCCL all-gather of keys over xGMI
             torch.distributed.all_gather_into_tensor(self.keys_all, feat_k)
             keys = self.keys_all
         index = c.index
@@ -271,7 +274,7 @@ class MoCoTrainStep:
         dq = self.nce.backward(feat_q, feat_k, c.memory, c.T, 0, outs, self.one, patch=saved, patch_index=index,
                                stream=st, prof=pr.get("nce_bwd"))         # loss.backward(), train.py:408
         self.gin.backward(self.model, pq, bufq, dq, targets=self.grad_views, stream=st, prof=pr.get("gin_bwd"))
-        if self.world > 1:
+        if self.collectives:
             torch.distributed.all_reduce(self.flat_grad)                # one flat bucket (248 KiB) over xGMI
             self.flat_grad.mul_(1.0 / self.world)
         for grp in self.optimizer.param_groups:                          # train.py:411-416

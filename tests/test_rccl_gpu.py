@@ -1,0 +1,56 @@
+"""The step's two collectives (all-gather of keys, all-reduce of the flat gradient) through RCCL on the GPU box: a
+1-rank process group is all a single-GPU box allows, but it runs the real NCCL kernels on RCCL's stream next to the
+producer lanes and the high-priority training stream, and must give the same losses as the step without collectives."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(collectives):
+    from gcc_amd.contrast import MemoryMoCo
+    from gcc_amd.encoder import GraphEncoder
+    from gcc_amd.graph import DeviceGraph
+    from gcc_amd.graphgen import powerlaw_graph
+    from gcc_amd.posemb import DevicePosEmb
+    from gcc_amd.sampler import DeviceRWRSampler
+    from gcc_amd.train_step import MoCoTrainStep
+
+    dev = torch.device("cuda:0")
+    rp, ci = powerlaw_graph(50000, 400000, 2)
+    graph = DeviceGraph(rp, ci, rw_hops=64, restart_prob=0.8, device=dev)
+    B, chunk, depth = 32, 2, 2
+    torch.manual_seed(0)
+    kw = dict(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512, freq_embedding_size=16,
+              degree_embedding_size=16, output_dim=64, node_hidden_dim=64, edge_hidden_dim=64, num_layers=5,
+              num_step_set2set=6, num_layer_set2set=3, norm=True, gnn_model="gin", degree_input=True)
+    model, ema = GraphEncoder(**kw).to(dev), GraphEncoder(**kw).to(dev)
+    ema.load_state_dict(model.state_dict())
+    contrast = MemoryMoCo(64, None, 256, 0.07, use_softmax=True).to(dev)
+    lanes = []
+    for _ in range(2):
+        smp = DeviceRWRSampler(graph, B, run_seed=3, num_buffers=depth * chunk)
+        lanes.append((smp, DevicePosEmb(B, smp.node_cap, 32, device=dev, seed=3, num_buffers=depth * chunk, max_views=2 * chunk)))
+    tr = MoCoTrainStep(model, ema, contrast, lanes[0][0], lanes[0][1], lanes=lanes, depth=depth, chunk=chunk,
+                       collectives=collectives)
+    tr.dropout_seed = 11
+    losses = [float(tr.step(i, 0.005)["loss"].item()) for i in range(6)]
+    torch.cuda.synchronize()
+    return losses
+
+
+def test_step_with_rccl_collectives_matches_the_step_without():
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+    ref = _run(False)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        got = _run(True)
+    finally:
+        dist.destroy_process_group()
+    assert got == pytest.approx(ref, rel=1e-5)

@@ -18,6 +18,7 @@ import os
 import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")    # few hardware queues: see gcc_amd.train_step.BatchProducer
+os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")   # RCCL's stream must not share a hardware queue with a producer lane
 
 import numpy as np
 import psutil
