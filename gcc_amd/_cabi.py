@@ -99,6 +99,7 @@ class GccGinPass(ctypes.Structure):
         ("x0", _VP), ("agg", _VP * GIN_MAX_LAYERS), ("z1", _VP * GIN_MAX_LAYERS), ("z2", _VP * GIN_MAX_LAYERS),
         ("stats", _VP), ("pooled", _VP), ("score", _VP), ("feat", _VP),
         ("edge_multiplicity", ctypes.c_int32),
+        ("bn_totals", _VP),
         ("seed_local", _VP),
     ]
 

@@ -86,6 +86,8 @@ struct InArgs {
     float *agg;               // or NULL
     float *z1;
     double *stats_a;
+    double *tot_a;            // totals of stats_a, written by the last workgroup (finalize_stats), or NULL
+    int32_t *tick_a;
     double *pooled;           // SumPooling of this layer's input h (hidden_rep[layer]); NULL for layer 0 (done by F0)
     int32_t B, first, kdim, training;
     float eps, nbr_weight;    // nbr_weight: edge multiplicity
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
         __syncthreads();
         GIN_TICK(6);
     }
+    finalize_stats(a.stats_a, a.tot_a, a.tick_a, (int)gridDim.x);
 }
 
 // =========================================================================
@@ -170,6 +173,8 @@ struct MidArgs {
     const float *w1, *b1;
     float *z2;
     double *stats_b;
+    double *tot_b;
+    int32_t *tick_b;
     int32_t B, training;
     float eps;
 };
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
         flush_stats(red, a.stats_b);
         __syncthreads();
     }
+    finalize_stats(a.stats_b, a.tot_b, a.tick_b, (int)gridDim.x);
 }
 
 // =========================================================================
@@ -213,6 +219,8 @@ struct StatArgs {
     const float *z2;
     BnDev bnb;
     double *stats_c;
+    double *tot_c;
+    int32_t *tick_c;
     int32_t B, training;
     float eps;
 };
@@ -240,15 +248,17 @@ __global__ __launch_bounds__(kThreads) void gin_stat_kernel(StatLaunch L)
             ss.z = fmaf(y.z, y.z, ss.z); ss.w = fmaf(y.w, y.w, ss.w);
         }
     }
-    if (!any) return;     // block-uniform
-    st4(&part[gi * 2 * H + 4 * t], s);
-    st4(&part[gi * 2 * H + H + 4 * t], ss);
-    __syncthreads();
-    if (tid < 2 * H) {
-        double v = 0.0;
-        for (int k = 0; k < 16; ++k) v += (double)part[k * 2 * H + tid];
-        atomicAdd(&a.stats_c[((int)blockIdx.x % kRep) * 2 * H + tid], v);
+    if (any) {            // block-uniform
+        st4(&part[gi * 2 * H + 4 * t], s);
+        st4(&part[gi * 2 * H + H + 4 * t], ss);
+        __syncthreads();
+        if (tid < 2 * H) {
+            double v = 0.0;
+            for (int k = 0; k < 16; ++k) v += (double)part[k * 2 * H + tid];
+            atomicAdd(&a.stats_c[((int)blockIdx.x % kRep) * 2 * H + tid], v);
+        }
     }
+    finalize_stats(a.stats_c, a.tot_c, a.tick_c, (int)gridDim.x);
 }
 
 // =========================================================================
@@ -433,11 +443,12 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
                 InArgs a;
                 a.node_off = p.node_off; a.row_ptr = p.row_ptr; a.col_idx = p.col_idx; a.graph_id = p.graph_id;
                 a.src = l == 0 ? p.x0 : p.z2[l - 1];
-                a.bnb = l == 0 ? BnDev() : bn_dev(p.w.bn_b[l - 1], stats_of(p, l - 1, 1));
-                a.bnc = l == 0 ? BnDev() : bn_dev(p.w.bn_c[l - 1], stats_of(p, l - 1, 2));
+                a.bnb = l == 0 ? BnDev() : bn_of(p, p.w.bn_b[l - 1], l - 1, 1);
+                a.bnc = l == 0 ? BnDev() : bn_of(p, p.w.bn_c[l - 1], l - 1, 2);
                 a.w0 = p.w.lin0_w[l]; a.b0 = p.w.lin0_b[l];
                 a.agg = p.agg[l]; a.z1 = p.z1[l];
                 a.stats_a = stats_of(p, l, 0);
+                a.tot_a = totals_of(p, l, 0); a.tick_a = ticket_of(p, l, 0);
                 a.pooled = l == 0 ? nullptr : p.pooled + (int64_t)l * p.batch_size * H;
                 a.B = p.batch_size; a.first = l == 0;
                 a.kdim = l == 0 ? p.w.pos_dim + p.w.deg_emb_dim + 1 : H;
@@ -452,8 +463,9 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
             MidLaunch L;
             for (int i = 0; i < npass; ++i) {
                 const gcc_gin_pass &p = passes[i];
-                L.p[i] = {p.node_off, p.z1[l], bn_dev(p.w.bn_a[l], stats_of(p, l, 0)), p.w.lin1_w[l], p.w.lin1_b[l],
-                          p.z2[l], stats_of(p, l, 1), p.batch_size, p.training, p.w.bn_eps};
+                L.p[i] = {p.node_off, p.z1[l], bn_of(p, p.w.bn_a[l], l, 0), p.w.lin1_w[l], p.w.lin1_b[l],
+                          p.z2[l], stats_of(p, l, 1), totals_of(p, l, 1), ticket_of(p, l, 1), p.batch_size, p.training,
+                          p.w.bn_eps};
             }
             hipLaunchKernelGGL(gin_mid_kernel, grid, block, 0, s, L);
         }
@@ -462,8 +474,8 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
             bool need = false;
             for (int i = 0; i < npass; ++i) {
                 const gcc_gin_pass &p = passes[i];
-                L.p[i] = {p.node_off, p.z2[l], bn_dev(p.w.bn_b[l], stats_of(p, l, 1)), stats_of(p, l, 2),
-                          p.batch_size, p.training, p.w.bn_eps};
+                L.p[i] = {p.node_off, p.z2[l], bn_of(p, p.w.bn_b[l], l, 1), stats_of(p, l, 2), totals_of(p, l, 2),
+                          ticket_of(p, l, 2), p.batch_size, p.training, p.w.bn_eps};
                 need = need || p.training;
             }
             if (need) hipLaunchKernelGGL(gin_stat_kernel, grid, block, 0, s, L);
@@ -473,8 +485,8 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
         PoolLaunch L;
         for (int i = 0; i < npass; ++i) {
             const gcc_gin_pass &p = passes[i];
-            L.p[i] = {p.node_off, p.graph_id, p.z2[Lg - 1], bn_dev(p.w.bn_b[Lg - 1], stats_of(p, Lg - 1, 1)),
-                      bn_dev(p.w.bn_c[Lg - 1], stats_of(p, Lg - 1, 2)), p.pooled + (int64_t)Lg * p.batch_size * H,
+            L.p[i] = {p.node_off, p.graph_id, p.z2[Lg - 1], bn_of(p, p.w.bn_b[Lg - 1], Lg - 1, 1),
+                      bn_of(p, p.w.bn_c[Lg - 1], Lg - 1, 2), p.pooled + (int64_t)Lg * p.batch_size * H,
                       p.batch_size, p.training, p.w.bn_eps};
         }
         hipLaunchKernelGGL(gin_pool_kernel, grid, block, 0, s, L);
@@ -488,9 +500,9 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
             for (int k = 0; k <= Lg; ++k) { a.pred_w[k] = p.w.pred_w[k]; a.pred_b[k] = p.w.pred_b[k]; }
             a.drop = drop_cfg(p); a.score = p.score; a.feat = p.feat;
             for (int l = 0; l < Lg; ++l) {
-                a.bn[3 * l + 0] = bn_dev(p.w.bn_a[l], stats_of(p, l, 0));
-                a.bn[3 * l + 1] = bn_dev(p.w.bn_b[l], stats_of(p, l, 1));
-                a.bn[3 * l + 2] = bn_dev(p.w.bn_c[l], stats_of(p, l, 2));
+                a.bn[3 * l + 0] = bn_of(p, p.w.bn_a[l], l, 0);
+                a.bn[3 * l + 1] = bn_of(p, p.w.bn_b[l], l, 1);
+                a.bn[3 * l + 2] = bn_of(p, p.w.bn_c[l], l, 2);
             }
             a.B = p.batch_size; a.nlayers = Lg; a.kdim0 = p.w.pos_dim + p.w.deg_emb_dim + 1;
             a.normalize = p.normalize; a.update_running = p.training && p.update_running_stats;

@@ -25,7 +25,12 @@ struct BnCol { float mean, rstd, gamma, beta; };
 __device__ __forceinline__ BnCol bn_col(const BnDev &bn, int c, double n, float eps)
 {
     double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < kRep; ++r) { s1 += bn.stats[r * 2 * H + c]; s2 += bn.stats[r * 2 * H + H + c]; }
+    if (bn.totals) {
+        s1 = bn.totals[c];
+        s2 = bn.totals[H + c];
+    } else {
+        for (int r = 0; r < kRep; ++r) { s1 += bn.stats[r * 2 * H + c]; s2 += bn.stats[r * 2 * H + H + c]; }
+    }
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -694,9 +699,9 @@ extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat
         hipLaunchKernelGGL(gin_bwd_readout_kernel, dim3((B + 63) / 64), block, 0, s, a);
     }
     for (int l = L - 1; l >= 0; --l) {
-        const BnDev bna = bn_dev(p.w.bn_a[l], stats_of(p, l, 0));
-        const BnDev bnb = bn_dev(p.w.bn_b[l], stats_of(p, l, 1));
-        const BnDev bnc = bn_dev(p.w.bn_c[l], stats_of(p, l, 2));
+        const BnDev bna = bn_of(p, p.w.bn_a[l], l, 0);
+        const BnDev bnb = bn_of(p, p.w.bn_b[l], l, 1);
+        const BnDev bnc = bn_of(p, p.w.bn_c[l], l, 2);
         {
             BwdCArgs a = {p.node_off, p.row_ptr, p.col_idx, p.graph_id, l == L - 1 ? nullptr : w.D,
                           w.dpooled + (int64_t)(l + 1) * B * H, p.z2[l], bnb, bnc, w.U, bst(l, 2), B, p.w.bn_eps};
@@ -727,7 +732,7 @@ extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat
         a.node_off = p.node_off; a.slabs = w.slabs; a.bias_slabs = w.bias_slabs; a.B = B; a.eps = p.w.bn_eps;
         for (int l = 0; l < L; ++l) {
             a.job[2 * l + 0] = {w.dz1[l], p.agg[l], nullptr, BnDev(), 0};
-            a.job[2 * l + 1] = {w.dz2[l], p.z1[l], nullptr, bn_dev(p.w.bn_a[l], stats_of(p, l, 0)), 0};
+            a.job[2 * l + 1] = {w.dz2[l], p.z1[l], nullptr, bn_of(p, p.w.bn_a[l], l, 0), 0};
         }
         for (int i = 0; i <= L; ++i)      // linears_prediction[i]: dW = G_i^T pooled_i over the B graphs
             a.job[2 * L + i] = {w.G + (int64_t)i * B * H, nullptr, p.pooled + (int64_t)i * B * H, BnDev(), B};

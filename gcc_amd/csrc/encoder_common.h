@@ -49,6 +49,7 @@ struct BnDev {
     float *running_mean, *running_var;
     int64_t *nbt;
     const double *stats;    // [kRep][2][64] column sum / sum of squares of this BN's input (training mode)
+    const double *totals;   // [2][64] the replicas added up by the producing kernel's last workgroup, or NULL
 };
 
 // BatchNorm1d as y = x * scale + shift for channel c.  training: biased batch variance
@@ -59,7 +60,12 @@ __device__ __forceinline__ void bn_scale_shift(const BnDev &bn, int c, double n,
     double mean, var;
     if (training) {
         double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < kRep; ++r) { s1 += bn.stats[r * 2 * H + c]; s2 += bn.stats[r * 2 * H + H + c]; }
+        if (bn.totals) {
+            s1 = bn.totals[c];
+            s2 = bn.totals[H + c];
+        } else {
+            for (int r = 0; r < kRep; ++r) { s1 += bn.stats[r * 2 * H + c]; s2 += bn.stats[r * 2 * H + H + c]; }
+        }
         mean = s1 / n;
         var = s2 / n - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -254,6 +260,28 @@ __device__ __forceinline__ void flush_stats(const float *red, double *stats)
 }
 
 
+// Every workgroup of a pass calls this once after its last flush_stats(): the one that arrives last adds the replicas
+// up in replica order into totals[2][64] (and re-arms the counter).  Ends with nothing pending; block-uniform.
+__device__ __forceinline__ void finalize_stats(const double *stats, double *totals, int32_t *ticket, int nblocks)
+{
+    __shared__ int last_arrival;
+    if (!totals) return;
+    // No cache maintenance here (a __threadfence() per workgroup writes back / invalidates L2 some 1500 times per kernel
+    // and made the forward pass 4x slower): the statistics are device-scope atomics performed at the coherence point, the
+    // barrier waits for this workgroup's to be acknowledged (s_waitcnt vmcnt(0)) before its ticket -- another device-scope
+    // atomic -- is issued, and the last arrival reads the replicas with device-scope loads.
+    __syncthreads();
+    if (threadIdx.x == 0) last_arrival = atomicAdd(ticket, 1) == nblocks - 1;
+    __syncthreads();
+    if (!last_arrival) return;
+    if (threadIdx.x < 2 * H) {
+        double s = 0.0;
+        for (int r = 0; r < kRep; ++r) s += load_fresh_f64(stats + r * 2 * H + threadIdx.x);
+        totals[threadIdx.x] = s;
+    }
+    if (threadIdx.x == 0) *ticket = 0;
+}
+
 // ---- neighbourhood sum over an LDS tile.  Precondition: T rows [0, nrows) hold the self term,
 // *nlong == 0, and a __syncthreads() separates those writes from this call.  Postcondition:
 // T[r] = self + sum_{u in row(tile0 + r)} feat(u); ends with a __syncthreads().
@@ -381,10 +409,23 @@ inline DropCfg drop_cfg(const gcc_gin_pass &p)
     return d;
 }
 
-inline BnDev bn_dev(const gcc_bn &b, const double *stats)
+inline BnDev bn_dev(const gcc_bn &b, const double *stats, const double *totals = nullptr)
 {
-    BnDev d = {b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked, stats};
+    BnDev d = {b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked, stats, totals};
     return d;
+}
+inline double *totals_of(const gcc_gin_pass &p, int layer, int which)   // [layer][bn a|b|c][2][64] or NULL
+{
+    return p.bn_totals ? p.bn_totals + ((int64_t)layer * 3 + which) * 2 * H : nullptr;
+}
+inline int32_t *ticket_of(const gcc_gin_pass &p, int layer, int which)
+{
+    return p.bn_totals ? (int32_t *)(p.bn_totals + (int64_t)p.w.num_gin_layers * 3 * 2 * H) + layer * 3 + which : nullptr;
+}
+// BnDev of BatchNorm `which` (0 = mlp bn, 1 = apply_func bn, 2 = outer bn) of GIN layer `layer`
+inline BnDev bn_of(const gcc_gin_pass &p, const gcc_bn &b, int layer, int which)
+{
+    return bn_dev(b, p.stats + ((int64_t)layer * 3 + which) * kRep * 2 * H, totals_of(p, layer, which));
 }
 
 inline double *stats_of(const gcc_gin_pass &p, int layer, int which)   // [layer][bn a|b|c][kRep][2][64]

@@ -133,6 +133,8 @@ class GinEngine:
                 z1=[torch.zeros(node_cap, H, **f32) for _ in range(L)],
                 z2=[torch.zeros(node_cap, H, **f32) for _ in range(L)],
                 stats=torch.zeros(L, 3, STATS_REPLICAS, 2, H, dtype=torch.float64, device=device),
+                # [L][3][2][64] totals of the replicas + int32 arrival counters (gcc_gin_pass.bn_totals)
+                bn_totals=torch.zeros(L * 3 * 2 * H + (L * 3 + 1) // 2 + 1, dtype=torch.float64, device=device),
                 pooled=torch.zeros(L + 1, B, H, dtype=torch.float64, device=device),
                 score=torch.zeros(B, H, **f32), feat=torch.zeros(B, H, **f32))
         return self._bufs[k]
@@ -161,6 +163,7 @@ class GinEngine:
             p.agg[i], p.z1[i], p.z2[i] = ptr(buf["agg"][i]), ptr(buf["z1"][i]), ptr(buf["z2"][i])
         p.stats, p.pooled, p.score, p.feat = ptr(buf["stats"]), ptr(buf["pooled"]), ptr(buf["score"]), ptr(buf["feat"])
         p.edge_multiplicity = int(getattr(g, "edge_multiplicity", 1))
+        p.bn_totals = ptr(buf["bn_totals"]) if training else None
         seed_local = getattr(g, "seed_local", None)
         p.seed_local = ptr(seed_local) if seed_local is not None else None
         buf = dict(buf)
