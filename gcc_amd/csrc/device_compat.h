@@ -12,6 +12,7 @@
 static inline long long device_ticks() { return 0; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void device_fence() {}
+#define lds_barrier() __syncthreads()
 static inline float load_fresh(const float *p) { return *p; }
 static inline double load_fresh_f64(const double *p) { return *p; }
 #include "hipemu.h"
@@ -118,6 +119,14 @@ static inline float wave_max(float v)
 __device__ __forceinline__ long long device_ticks() { return (long long)wall_clock64(); }   // 100 MHz
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }        // v_rcp_f32, 1 ulp
 __device__ __forceinline__ void device_fence() { __threadfence(); }                            // release + acquire, agent scope
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for outstanding global
+// stores / atomics (s_waitcnt vmcnt(0)), whose acknowledgement takes microseconds for device-scope fp64 atomics
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 __device__ __forceinline__ float load_fresh(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double load_fresh_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 

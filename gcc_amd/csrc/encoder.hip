@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kThreads) void gin_feat_kernel(FeatLaunch L)
         }
         __syncthreads();
         pool_tile(T, tile0, nrows, a.graph_id, a.pooled0);
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
         GIN_TICK(1);
         // 2. SumPooling of hidden_rep[layer] (gin.py:228)
         if (a.pooled) pool_tile(T, tile0, nrows, a.graph_id, a.pooled);
-        __syncthreads();
+        lds_barrier();                             // (the pooling atomics stay in flight)
         GIN_TICK(2);
         // 3. GINConv aggregate: (1 + eps) * h_v + sum_{u -> v} h_u, eps = 0 (gin.py:179-185,218)
         gather_tile(T, part, longrows, &nlong, tile0, nrows, a.row_ptr, a.col_idx, feat, a.nbr_weight);
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
         __syncthreads();
         GIN_TICK(5);
         flush_stats(red, a.stats_a);
-        __syncthreads();
+        lds_barrier();
         GIN_TICK(6);
     }
     finalize_stats(a.stats_a, a.tot_a, a.tick_a, (int)gridDim.x);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
         linear_rows16_store_stats(xb, a.w1, H, a.b1, a.z2, row, valid, &red[wv * 2 * H]);     // gin.py:116
         __syncthreads();
         flush_stats(red, a.stats_b);
-        __syncthreads();
+        lds_barrier();
     }
     finalize_stats(a.stats_b, a.tot_b, a.tick_b, (int)gridDim.x);
 }

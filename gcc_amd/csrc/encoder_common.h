@@ -104,20 +104,29 @@ __device__ __forceinline__ Aff4 bn_aff4(const BnDev &bn, int c0, double n, float
 
 // ---- SumPooling of an LDS tile (rows tile0 .. tile0+nrows of the batched graph) into
 // pooled[graph][64] (fp64 atomics; one flush per run of equal graph ids per thread)
+// gid_lds (optional): the tile's graph ids already staged in LDS by the caller (fetched together with the rows)
 __device__ __forceinline__ void pool_tile(const float *T, int tile0, int nrows, const int32_t *graph_id,
-                                          double *pooled)
+                                          double *pooled, const int *gid_lds = nullptr)
 {
     const int c = (int)threadIdx.x & 63, part = (int)threadIdx.x >> 6;
+    int gids[16];                                    // the 16 graph ids first: one round trip instead of 16 in a row
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int r = part * 16 + k;
+        gids[k] = r < nrows ? (gid_lds ? gid_lds[r] : graph_id[tile0 + r]) : -1;
+    }
     double acc = 0.0;
     int cur = -1;
-    for (int r = part * 16; r < part * 16 + 16 && r < nrows; ++r) {
-        const int g = graph_id[tile0 + r];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int g = gids[k];
+        if (g < 0) break;
         if (g != cur) {
             if (cur >= 0) atomicAdd(&pooled[(int64_t)cur * H + c], acc);
             cur = g;
             acc = 0.0;
         }
-        acc += (double)T[r * kLdt + c];
+        acc += (double)T[(part * 16 + k) * kLdt + c];
     }
     if (cur >= 0) atomicAdd(&pooled[(int64_t)cur * H + c], acc);
 }
@@ -290,7 +299,8 @@ __device__ __forceinline__ void finalize_stats(const double *stats, double *tota
 template <class Feat>
 __device__ __forceinline__ void gather_tile(float *T, float *part /* [16 * H] */, int *longrows, int *nlong,
                                             int tile0, int nrows, const int32_t *row_ptr,
-                                            const int32_t *col_idx, Feat feat, float nbr_weight = 1.0f)
+                                            const int32_t *col_idx, Feat feat, float nbr_weight = 1.0f,
+                                            const int *rp_lds = nullptr /* [nrows + 1] row_ptr of the tile, in LDS */)
 {
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, gbase = lane_id() & ~15;
     // A lane group walks its four rows (gi, gi + 16, gi + 32, gi + 48) TOGETHER: the 16 lanes fetch 16 entries of
@@ -303,7 +313,8 @@ __device__ __forceinline__ void gather_tile(float *T, float *part /* [16 * H] */
     for (int q = 0; q < 4; ++q) {
         const int r = gi + 16 * q;
         const bool ok = r < nrows;
-        const int b0 = ok ? row_ptr[tile0 + r] : 0, e0 = ok ? row_ptr[tile0 + r + 1] : 0;
+        const int b0 = ok ? (rp_lds ? rp_lds[r] : row_ptr[tile0 + r]) : 0;
+        const int e0 = ok ? (rp_lds ? rp_lds[r + 1] : row_ptr[tile0 + r + 1]) : 0;
         int d = e0 - b0;
         if (d > kLongRow) {
             if (t == 0) longrows[atomicAdd(nlong, 1)] = r;
@@ -356,7 +367,7 @@ __device__ __forceinline__ void gather_tile(float *T, float *part /* [16 * H] */
     const int nl = *nlong;
     for (int i = 0; i < nl; ++i) {
         const int r = longrows[i], v = tile0 + r;
-        const int beg = row_ptr[v], end = row_ptr[v + 1];
+        const int beg = rp_lds ? rp_lds[r] : row_ptr[v], end = rp_lds ? rp_lds[r + 1] : row_ptr[v + 1];
         F4 acc = {0.f, 0.f, 0.f, 0.f};
         int e = beg + gi;
         for (; e + 48 < end; e += 64) {
