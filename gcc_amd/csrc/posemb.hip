@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int kJMax = GCC_POSEMB_JACOBI_MAX;
+constexpr int kJMax = GCC_POSEMB_LDS_MAX;
 constexpr int kJSmall = 64;        // LDS-resident size classes of the direct solver: n' <= 64 (256 threads, ~60 KiB of LDS)
                                    // and 65..kJMax (1024 threads, ~150 KiB)
 
@@ -49,10 +49,10 @@ __device__ __forceinline__ void item_args(const PosMulti &m, int item, struct Po
 // t - 1 contrast vectors on the leaves are exact null vectors of M = D^-1/2 A D^-1/2, and the rest of
 // the spectrum is that of the quotient matrix M' in which the t leaves are one "super-leaf" coupled
 // to p with sqrt(t / d_p).  Sampled ego-nets are star-like (a typical n = 92 has ~35 such null
-// vectors), so M' is ~40 % smaller and the O(n^3) Jacobi ~5x cheaper; an eigenvector y of M' expands
+// vectors), so M' is ~40 % smaller and the O(n^3) dense solve ~5x cheaper; an eigenvector y of M' expands
 // to the leaves as y[super-leaf] / sqrt(t).  Any orthonormal basis of a degenerate eigenspace is
 // as good as ARPACK's, so when the top-k reaches into the null space the contrasts are used.
-constexpr int kNodeMax = 1024;       // largest subgraph the deflating Jacobi kernels look at (per-node LDS tables)
+constexpr int kNodeMax = 1024;       // largest subgraph the deflating direct kernels look at (per-node LDS tables)
 constexpr uint16_t kNone = 0xFFFFu;
 constexpr float kZeroEig = 1e-5f;    // |lambda| below this is "the null space" when ranking
 
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
 // Large subgraphs (n > 128; hub seeds, graph_dataset.py:113-124 lets L grow with the seed degree):
 // thick-restart Krylov-Schur.  A symmetric Arnoldi process with classical Gram-Schmidt applied
 // twice builds V (n x (m+1), column-major in HBM/L2) and the dense projected matrix H = V^T M V
-// (LDS); every m = 64 columns the Ritz pairs of H come from jacobi_lds, convergence is judged by
+// (LDS); every m = 64 columns the Ritz pairs of H come from the direct solver core, convergence is judged by
 // |beta_m * y_{m,i}| for the k wanted pairs, and the basis is compressed to the k + 8 best Ritz
 // vectors plus the residual direction (the coupling entries of H are regenerated by the next
 // projection, so no arrowhead bookkeeping is needed).  One start vector ~ U[0,1)^n like the

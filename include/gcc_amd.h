@@ -127,12 +127,12 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p,
  * Twin leaves are deflated exactly first (their contrasts are null vectors).
  * Deflated size n' <= GCC_POSEMB_DIRECT_MAX: direct symmetric eigensolver
  * (tridiagonalisation, bisection, inverse iteration: exact multiplicities), the
- * matrix in LDS up to GCC_POSEMB_JACOBI_MAX and in a workspace slot above;
- * larger ones, or when the slots run out, a thick-restart Krylov-Schur iteration
+ * matrix in LDS up to GCC_POSEMB_LDS_MAX and in a workspace slot above;
+ * larger ones a thick-restart Krylov-Schur iteration
  * (single start vector, like ARPACK).  Eigenvectors are defined up to sign /
  * rotation inside degenerate eigenspaces; the reference's own output depends on
  * np.random.rand (data_util.py:248).  hidden <= 32. */
-#define GCC_POSEMB_JACOBI_MAX 128
+#define GCC_POSEMB_LDS_MAX 128
 #define GCC_POSEMB_DIRECT_MAX 384
 #define GCC_STATUS_POSEMB_NOT_CONVERGED 8
 int64_t gcc_posemb_workspace_bytes(int32_t batch_size, int64_t node_cap, int32_t hidden);

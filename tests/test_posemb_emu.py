@@ -109,7 +109,7 @@ def _sampled_views(rw_hops, B, run_seed):
                 col_idx=torch.from_numpy(r["col_idx"].astype(np.int64)))
 
 
-def test_sampled_subgraphs_jacobi_path():
+def test_sampled_subgraphs_lds_direct_path():
     view = _sampled_views(rw_hops=48, B=6, run_seed=4)
     assert np.diff(view["node_off"].numpy()).max() <= 128
     _check(view, *_run(view))
@@ -210,7 +210,7 @@ def test_krylov_fallback_above_the_direct_limit():
 
 def test_leafy_large_subgraph_is_solved_exactly_by_deflation():
     """n = 331 original nodes, but 290 of them are leaves of 3 hubs: the deflated problem has ~45 nodes and
-    goes through the full Jacobi solver, so the STRICT invariants (all multiplicities) must hold."""
+    goes through the dense direct solver, so the STRICT invariants (all multiplicities) must hold."""
     import scipy.sparse as sp
 
     rng = np.random.RandomState(0)
