@@ -341,7 +341,7 @@ def main():
                          "traffic_source": committed_pmc_traffic(args)[1]},
             "algorithmic_bytes_per_step": acc,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(rp, ci, args)
         print(json.dumps(out))
     if world > 1:
