@@ -455,7 +455,7 @@ struct WgradArgs {
     float eps;
 };
 
-__global__ __launch_bounds__(kThreads) void gin_wgrad_kernel(WgradArgs a)
+__global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float S[H * H];
