@@ -65,3 +65,53 @@ def test_generate_path_against_oracles():
                              torch.repeat_interleave(torch.from_numpy(csr["col_idx"].astype(np.int64)), mult), pos).detach())
         ref.append(((fs[0] + fs[1]) / 2)[:valid])
     torch.testing.assert_close(emb, torch.cat(ref), rtol=1e-3, atol=1e-4)
+
+
+def test_graph_classification_dataset_on_device():
+    from gcc_amd import ingest
+    from gcc_amd.datasets import GraphClassificationDataset
+    from gcc_amd.encoder import GraphEncoder
+    from gcc_amd.generate import test_moco as run_test_moco
+    from gcc_amd.posemb import DevicePosEmb
+    from oracle import encoder as E
+
+    rng = np.random.RandomState(7)
+    graphs = []
+    for n in (9, 24, 61, 15, 150, 33, 420):
+        pairs = {(i, i + 1) for i in range(n - 1)}
+        while len(pairs) < 2 * n:
+            a, b = sorted(rng.randint(0, n, 2))
+            if a != b:
+                pairs.add((a, b))
+        rp, ci, _ = ingest.csr_from_pairs(np.array(sorted(pairs)), n)
+        graphs.append((rp, ci))
+    ds = GraphClassificationDataset("toy", graphs=graphs, batch_size=4, device="cuda")
+    torch.manual_seed(3)
+    oracle = E.OracleGraphEncoder()
+    for mod in oracle.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.normal_(0, 0.3)
+            mod.running_var.uniform_(0.5, 2.0)
+    model = GraphEncoder(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
+                         freq_embedding_size=16, degree_embedding_size=16, output_dim=64, node_hidden_dim=64,
+                         edge_hidden_dim=64, num_layers=5, num_step_set2set=6, num_layer_set2set=3, norm=True,
+                         gnn_model="gin", degree_input=True).cuda()
+    model.load_state_dict(oracle.state_dict())
+    pe = DevicePosEmb(4, ds.node_cap, 32, device="cuda", seed=1, max_views=2, num_buffers=2)
+    kept = []
+
+    class Spy:
+        def __iter__(self):
+            for q, k in ds:
+                yield q, k
+                torch.cuda.synchronize()
+                n = q.number_of_nodes()
+                kept.append((q.node_off.cpu().long(), q.row_ptr[: n + 1].cpu().long(), q.col_idx.cpu().long(),
+                             q.pos_undirected[:n].cpu().clone(), q.seed_local.cpu().long(), q.valid))
+
+    emb = run_test_moco(Spy(), model, pe)
+    pe.check_status()
+    assert emb.shape == (7, 64)
+    oracle.eval()
+    ref = [oracle(no, rp, ci, pos, seed_local=sl).detach()[:valid] for no, rp, ci, pos, sl, valid in kept]
+    torch.testing.assert_close(emb, torch.cat(ref), rtol=1e-3, atol=1e-4)
