@@ -109,6 +109,7 @@ struct PosHead {                     // head of the caller's workspace (zeroed p
     float *tabs;                     // [workgroups of the mid class, then of the small class][kNodeMax * 4]: deflation tables
     int32_t tabs_small_off;          // first small-class table (= workgroups of the mid class)
     int32_t T;
+    int32_t ldv;                     // longest subgraph the Krylov class has room for (node_cap / batch_size, rounded up)
     int64_t slot_floats;
 };
 
@@ -686,6 +687,12 @@ __global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m
         const int nr = n - zz;                         // t >= 2 leaves of one parent count once
         cls = nr <= kJSmall ? kClsSmall : nr <= kJMax ? kClsMid : nr <= kGMax ? kClsSlot : kClsKrylov;
     }
+    if (cls == kClsKrylov && n >= hd.ldv) {          // no room: the caller's node_cap / batch_size must bound every subgraph
+        for (int i = lane; i < n * a.hidden; i += 64) a.pos[(int64_t)n0 * a.hidden + i] = 0.f;
+        if (a.evals) for (int i = lane; i < a.hidden; i += 64) a.evals[(int64_t)b * a.hidden + i] = 0.f;
+        if (lane == 0) atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_TOO_LARGE);
+        return;
+    }
     if (lane == 0) hd.list[(int64_t)cls * hd.T + atomicAdd(hd.count + cls, 1)] = item;
 }
 
@@ -916,6 +923,7 @@ constexpr int kMaxCycles = 16;        // restarts; pairs next to a tiny spectral
 constexpr float kRitzTol = 1e-4f;     // |beta_m y_mi| of the wanted pairs (ARPACK: machine eps; tests: 1e-3)
 constexpr int kLongDeg = 32;
 constexpr int kMaxLong = 512;
+constexpr int kCsrCap = 10240;        // edges of a subgraph kept in LDS (uint16 local ids) for the matrix-vector products
 constexpr int kKThreads = 1024;      // 16 waves: the long-vector work is bound by L2 latency, not by FLOPs
 constexpr int kKWaves = kKThreads / 64;
 
@@ -982,6 +990,8 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
     tw.Ud = (float *)(tw.cnt + kKThreads);
     tw.Us = tw.Ud + kM * tw.ldu;
     tw.Uf = (uint8_t *)(tw.Us + kM * tw.ldu);
+    uint16_t *ccol = (uint16_t *)(tw.Uf + kM * kVecCap);    // [kCsrCap] local column ids of the subgraph's CSR
+    uint16_t *crow = ccol + kCsrCap;                        // [ldv] row offsets
     const int k = min(n - 2, a.hidden);
     const int keep = min(k + kKeepExtra, kM - 8);
     const int lda = kM + 1;
@@ -1008,7 +1018,18 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
     }
     __syncthreads();
     float nrm = sqrtf(block_sum(ss, red));
-    for (int r = tid; r < n; r += kKThreads) V[r] = w[r] / nrm;
+    for (int r = tid; r < n; r += kKThreads) {
+        const float vn = w[r] / nrm;
+        V[r] = vn;
+        x[r] = vn * dinv[r];                         // x = D^-1/2 v_j is kept up to date where v_j is written
+    }
+    // the subgraph's CSR in LDS (two dependent global round trips per matrix-vector product otherwise)
+    const int rp0 = a.row_ptr[n0], nnz = a.row_ptr[n0 + n] - rp0;
+    const bool csr_lds = nnz <= kCsrCap && nnz < 65536 && n < ldv;
+    if (csr_lds) {
+        for (int e = tid; e < nnz; e += kKThreads) ccol[e] = (uint16_t)(a.col_idx[rp0 + e] - n0);
+        for (int r = tid; r <= n; r += kKThreads) crow[r] = (uint16_t)(a.row_ptr[n0 + r] - rp0);
+    }
     __syncthreads();
     const int nl = nlong < kMaxLong ? nlong : kMaxLong;
     const bool long_overflow = nlong > kMaxLong;
@@ -1046,22 +1067,24 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
     int j = 0, steps = 0, cycle = 0;
     for (; cycle < kMaxCycles; ++cycle) {
         for (; j < kM; ++j, ++steps) {
-            for (int r = tid; r < n; r += kKThreads) x[r] = V[(int64_t)j * ldv + r] * dinv[r];
-            __syncthreads();
             // w = D^-1/2 A D^-1/2 v_j   (short rows: one thread per row; long rows: one wave per row)
             for (int r = tid; r < n; r += kKThreads) {
-                const int beg = a.row_ptr[n0 + r], end = a.row_ptr[n0 + r + 1];
+                const int beg = csr_lds ? (int)crow[r] : a.row_ptr[n0 + r] - rp0;
+                const int end = csr_lds ? (int)crow[r + 1] : a.row_ptr[n0 + r + 1] - rp0;
                 if (end - beg > kLongDeg && !long_overflow) continue;
                 float s = 0.f;
-                for (int e = beg; e < end; ++e) s += x[a.col_idx[e] - n0];
+                if (csr_lds) for (int e = beg; e < end; ++e) s += x[ccol[e]];
+                else for (int e = beg; e < end; ++e) s += x[a.col_idx[rp0 + e] - n0];
                 w[r] = s * dinv[r];
             }
             if (!long_overflow) {
                 for (int i = wv_id; i < nl; i += kKWaves) {
                     const int r = longrows[i];
-                    const int beg = a.row_ptr[n0 + r], end = a.row_ptr[n0 + r + 1];
+                    const int beg = csr_lds ? (int)crow[r] : a.row_ptr[n0 + r] - rp0;
+                    const int end = csr_lds ? (int)crow[r + 1] : a.row_ptr[n0 + r + 1] - rp0;
                     float s = 0.f;
-                    for (int e = beg + lane; e < end; e += 64) s += x[a.col_idx[e] - n0];
+                    if (csr_lds) for (int e = beg + lane; e < end; e += 64) s += x[ccol[e]];
+                    else for (int e = beg + lane; e < end; e += 64) s += x[a.col_idx[rp0 + e] - n0];
                     s = wave_sum(s);
                     if (lane == 0) w[r] = s * dinv[r];
                 }
@@ -1088,7 +1111,11 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
                 nrm = beta;
             }
             if (tid == 0) H[(j + 1) * kM + j] = beta;
-            for (int r = tid; r < n; r += kKThreads) V[(int64_t)(j + 1) * ldv + r] = w[r] / nrm;
+            for (int r = tid; r < n; r += kKThreads) {
+                const float vn = w[r] / nrm;
+                V[(int64_t)(j + 1) * ldv + r] = vn;
+                x[r] = vn * dinv[r];                 // for the next product (after a restart the next v_j is this vector too)
+            }
             __syncthreads();
         }
         PHASE_TICK(0);                               // Arnoldi steps
@@ -1292,6 +1319,7 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     hd.tabs_small_off = g.mid;
     hd.T = (int32_t)T;
     hd.slot_floats = posemb_slot_floats();
+    hd.ldv = (int32_t)posemb_ldv(batch_size, node_cap);
     constexpr int lds_small = direct_lds_bytes<kJSmall, 256, false>();
     constexpr int lds_big = direct_lds_bytes<kJMax, 1024, false>();
 #ifndef GCC_AMD_HIPEMU
@@ -1303,7 +1331,6 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
         (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kGLds);
-        (void)hipFuncSetAttribute((const void *)posemb_krylov_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
         attr_set = true;
     }
 #endif
@@ -1317,7 +1344,15 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     ka.ldv = (int32_t)posemb_ldv(batch_size, node_cap);
     // longest items first
     const size_t lds_kry = (size_t)3 * ka.ldv * sizeof(float)
-                           + sizeof(float) * (6 * kM + kVecCap * (kVecCap + 1) + kKThreads + 2 * kM * (kVecCap + 1)) + kM * kVecCap;
+                           + sizeof(float) * (6 * kM + kVecCap * (kVecCap + 1) + kKThreads + 2 * kM * (kVecCap + 1)) + kM * kVecCap
+                           + sizeof(uint16_t) * ((size_t)kCsrCap + ka.ldv);
+#ifndef GCC_AMD_HIPEMU
+    static size_t kry_lds_opt_in = 0;
+    if (lds_kry > kry_lds_opt_in) {                  // more than 64 KiB of dynamic LDS has to be opted into
+        (void)hipFuncSetAttribute((const void *)posemb_krylov_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kry);
+        kry_lds_opt_in = lds_kry;
+    }
+#endif
     hipLaunchKernelGGL(posemb_krylov_kernel, dim3(g.kry), dim3(kKThreads), lds_kry, s, ka);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>), dim3(g.slot), dim3(1024), kGLds, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, 1024, false>), dim3(g.mid), dim3(1024), lds_big, s, m, hd);

@@ -91,8 +91,9 @@ class GraphClassificationDataset:
         self.edge_multiplicity = int(edge_multiplicity)
         self.batch_size = int(batch_size)
         self.device = device
-        self.node_cap = max(sum(len(rp) - 1 for rp, _ in self.graphs[i:i + self.batch_size])
-                            for i in range(0, self.length, self.batch_size))
+        # capacity convention of the pipeline (as DeviceRWRSampler: B * (largest subgraph + 1)): the eigensolver sizes its
+        # per-subgraph workspace as node_cap / batch_size
+        self.node_cap = self.batch_size * (max(len(rp) - 1 for rp, _ in self.graphs) + 1)
 
     def __len__(self):
         return self.length

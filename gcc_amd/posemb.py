@@ -100,6 +100,9 @@ class DevicePosEmb:
         embedding is still written).  The reference swallows ARPACK failures too (data_util.py:249-259:
         retry, then zeros), so this only raises with ``strict=True``; returns the flag word."""
         s = int(self.status[0].item())
+        if s & 16:                                   # zeros were written for a subgraph: a sizing error, never silent
+            raise RuntimeError("gcc_posemb: a large subgraph has more nodes than node_cap / batch_size (size node_cap as "
+                               "batch_size * (largest subgraph + 1))")
         if s and strict:
             raise RuntimeError(f"gcc_posemb: status {s} (8 = an eigen-iteration hit its restart cap)")
         return s

@@ -135,6 +135,8 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p,
 #define GCC_POSEMB_LDS_MAX 128
 #define GCC_POSEMB_DIRECT_MAX 384
 #define GCC_STATUS_POSEMB_NOT_CONVERGED 8
+#define GCC_STATUS_POSEMB_TOO_LARGE 16   /* a subgraph with deflated size > GCC_POSEMB_DIRECT_MAX has more than
+                                          * node_cap / batch_size nodes: zeros written (size node_cap accordingly) */
 int64_t gcc_posemb_workspace_bytes(int32_t batch_size, int64_t node_cap, int32_t hidden);
 /* pos: device [node_cap, hidden] out (rows >= node_off[B] untouched);
  * evals: device [B, hidden] out or NULL (eigenvalues, ascending, zero-padded);

@@ -264,3 +264,28 @@ def test_multi_view_call_matches_per_view_invariants():
             lo, hi = no[i], no[i + 1]
             assert np.abs(x[lo:hi] @ x[lo:hi].T - xs[lo:hi] @ xs[lo:hi].T).max() < 5e-3
         _check(v, xs, ev.numpy(), raw[:n].numpy())
+
+
+def test_subgraph_larger_than_its_share_of_node_cap_is_refused_loudly():
+    """The Krylov class sizes its vectors as node_cap / batch_size: a large subgraph beyond that gets zeros and status
+    bit 16, and check_status() raises (never a silent wrong answer or an out-of-bounds access)."""
+    import scipy.sparse as sp
+
+    rng = np.random.RandomState(5)
+    n = 500                                                   # no twin leaves: deflated size 500 > 384 -> Krylov class
+    up = np.triu(rng.rand(n, n) < 0.02, 1)
+    up[np.arange(n - 1), np.arange(1, n)] = True
+    a = sp.csr_matrix((up | up.T).astype(np.float64))
+    a.sort_indices()
+    small = sp.csr_matrix(np.array([[0, 1, 0], [1, 0, 1], [0, 1, 0]], dtype=np.float64))
+    blk = sp.block_diag([a, small, small, small], format="csr")
+    blk.sort_indices()
+    view = dict(node_off=torch.tensor([0, n, n + 3, n + 6, n + 9]), row_ptr=torch.from_numpy(blk.indptr.astype(np.int64)),
+                col_idx=torch.from_numpy(blk.indices.astype(np.int64)))
+    b = CpuBatch(dict(view, pos_undirected=torch.ones(n + 9, HID)), node_cap=n + 9)
+    pe = DevicePosEmb(4, n + 9, HID, device="cpu", lib=emu_lib(), ptr=lambda t: 0 if t is None else t.data_ptr())
+    pe(b)
+    assert int(pe.status[0]) & 16
+    assert not b.pos_undirected[:n].any()                    # zeros, not garbage
+    with pytest.raises(RuntimeError):
+        pe.check_status()
