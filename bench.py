@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--cu-layout", default="interleaved", choices=["interleaved", "block"])
     ap.add_argument("--chunk", type=int, default=16, help="steps a producer lane prepares per turn (one multi-view eigensolver call)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight per producer lane")
+    ap.add_argument("--scratch-entries", type=int, default=0, help="induction scratch of the sampler (int32 slots); 0 = default")
+    ap.add_argument("--edge-cap", type=int, default=0, help="edge capacity of a batch view; 0 = default")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the roofline kernel from a separate rocprofv3 --pmc pass "
                          "(default: the committed profiles/r1_pmc_sampler.json, if the workload is the default one)")
@@ -212,7 +214,8 @@ def main():
     B = args.batch_size
     torch.manual_seed(0)
     nbuf = args.depth * args.chunk
-    samplers = [DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=nbuf) for _ in range(args.lanes)]
+    samplers = [DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=nbuf, scratch_entries=args.scratch_entries or None,
+                                 edge_cap=args.edge_cap or None) for _ in range(args.lanes)]
     sampler = samplers[0]
     enc_kw = dict(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
                   freq_embedding_size=16, degree_embedding_size=16, output_dim=64, node_hidden_dim=64,

@@ -65,6 +65,8 @@ class DeviceGraph:
         self.restart_u32 = restart_threshold(restart_prob)
         deg = np.diff(row_ptr)
         self.max_degree = int(deg.max())
+        d64 = deg.astype(np.float64)
+        self.sb_degree = float((d64 * d64).sum() / d64.sum())   # size-biased mean degree: what a random-walk visit sees
         if ltab is None:
             ltab = max_nodes_per_seed_table(self.max_degree, rw_hops, restart_prob)
         ltab = np.ascontiguousarray(ltab, dtype=np.int32)

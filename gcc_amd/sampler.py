@@ -127,10 +127,12 @@ class DeviceRWRSampler:
         B = self.batch_size
         self.node_cap = B * (graph.lmax + 1)
         self.edge_cap = int(edge_cap) if edge_cap else max(64 * B * (graph.rw_hops + 1), 2 * (graph.lmax + 1) ** 2)
-        # induction scratch: sum over subgraphs of sum_i min(deg_i, n) <= sum n^2; sized generously
-        # (HBM is 288 GB) and guarded by the device status word
+        # induction scratch: sum over subgraphs of sum_i min(deg_i, n) <= sum n^2.  A walk visits nodes in proportion to
+        # their degree, so a view scans about n * (size-biased mean degree) parent edges per subgraph (n ~ rw_hops / 2.5);
+        # sized 3x that for both views (HBM is 288 GB) and guarded by the device status word
+        expected = int(3 * 2 * B * (graph.rw_hops / 2.5) * getattr(graph, "sb_degree", 0.0))
         self.scratch_entries = int(scratch_entries) if scratch_entries else max(
-            32 << 20, 512 * B * (graph.rw_hops + 1), 8 * (graph.lmax + 1) ** 2)
+            32 << 20, 512 * B * (graph.rw_hops + 1), 8 * (graph.lmax + 1) ** 2, expected)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self._alloc_workspace()
         i32 = dict(dtype=torch.int32, device=dev)
