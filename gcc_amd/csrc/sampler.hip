@@ -341,9 +341,11 @@ __device__ __forceinline__ int upper_slot(const int32_t *arr, int count, int key
 }
 
 // ------------------------------------------------------------------ K2 ----
+static long long *g_induce_ticks = nullptr;      // diagnostics (gcc_sampler_debug_ticks): [0..3] phase ticks, [15] workgroups
+#define IND_TICK(ph) do { if (ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&ticks[ph], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
     const int32_t *__restrict__ col_idx, int32_t hcap_log2, int32_t G, int64_t scratch_entries, Work w,
-    int32_t *__restrict__ status)
+    int32_t *__restrict__ status, long long *ticks)
 {
     DYN_SMEM(smem);
     __shared__ long long wsum64[5];
@@ -356,8 +358,11 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
     int32_t *vbp = capoff + (w.ncap + 1);                    // [G + 1]   exclusive prefix of virtual blocks
     long long *sbp = (long long *)(vbp + ((G + 2) & ~1));    // [G + 1]   exclusive prefix of scratch slots
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    long long tick_ = ticks ? device_ticks() : 0;
+    if (ticks && tid == 0) atomicAdd((unsigned long long *)&ticks[15], 1ull);
     block_exclusive_scan<int32_t>(vbp, G, [&](int g) { return (w.sub_seg[g] + kSegPerWg - 1) / kSegPerWg; }, wsum32);
     block_exclusive_scan<long long>(sbp, G, [&](int g) { return (long long)w.sub_cap[g]; }, wsum64);
+    IND_TICK(0);
     const int total_vb = vbp[G];
     const int shift = 32 - hcap_log2;
     int cur_g = -1;
@@ -389,6 +394,7 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
             block_exclusive_scan<int32_t>(segoff, n, [&](int i) { return (rowdeg[i] + kSeg - 1) / kSeg; }, wsum32);
             block_exclusive_scan<int32_t>(capoff, n, [&](int i) { return row_slots(rowdeg[i], n); }, wsum32);
             cur_g = g;
+            IND_TICK(1);
         }
         const int stride = 1 + (n < kSeg ? n : kSeg);
         int my_nnz = 0;
@@ -428,6 +434,8 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
             my_nnz += cnt;
         }
         if (lane == 0 && my_nnz) atomicAdd(&w.sub_nnz[g], my_nnz);
+        __syncthreads();
+        IND_TICK(2);
     }
 }
 
@@ -518,6 +526,9 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
 
 extern "C" {
 
+void gcc_sampler_debug_ticks(long long *device_ticks64) { g_induce_ticks = device_ticks64; }   /* diagnostics only */
+
+
 int64_t gcc_sampler_workspace_bytes(const gcc_graph *g, int32_t batch_size, int64_t scratch_entries)
 {
     if (!g || batch_size <= 0 || scratch_entries <= 0 || g->lmax <= 0) {
@@ -592,7 +603,7 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
                        p->restart_u32, p->seeds, w);
     prof_mark(p->prof, 1, s);
     hipLaunchKernelGGL(induce_kernel, dim3(G * 8), dim3(kInduceThreads), lds2, s, g->col_idx, hlog, G,
-                       scratch_entries, w, status);
+                       scratch_entries, w, status, g_induce_ticks);
     prof_mark(p->prof, 2, s);
     hipLaunchKernelGGL(pack_kernel, dim3(G * kPackParts), dim3(256), lds3, s, B, w, oq, ok, scratch_entries, status);
     prof_mark(p->prof, 3, s);

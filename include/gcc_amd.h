@@ -112,6 +112,10 @@ typedef struct gcc_batch_out {
  * sum_i min(deg_i, n); 64 * batch_size * (lmax+1) is generous). */
 int64_t gcc_sampler_workspace_bytes(const gcc_graph *g, int32_t batch_size, int64_t scratch_entries);
 
+/* diagnostics: subsequent gcc_sample_batch calls add wall-clock ticks (100 MHz) of induce_kernel's phases into device
+ * int64[16] ([0] prefix sums over the subgraphs, [1] hash map + row prefix sums, [2] segment scans, [15] workgroups). */
+void gcc_sampler_debug_ticks(long long *device_ticks64);
+
 /* status: device int32[1], OR-ed with GCC_STATUS_* bits (caller zeroes it). */
 int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p,
                          const gcc_batch_out *out_q, const gcc_batch_out *out_k,

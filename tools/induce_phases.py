@@ -1,0 +1,29 @@
+"""Per-phase wall-clock ticks of induce_kernel on the default bench workload (isolated GPU)."""
+import sys
+import torch
+
+sys.path.insert(0, ".")
+from gcc_amd import _cabi
+from gcc_amd.graph import DeviceGraph
+from gcc_amd.graphgen import powerlaw_graph
+from gcc_amd.sampler import DeviceRWRSampler
+
+dev = torch.device("cuda:0")
+rp, ci = powerlaw_graph(1_000_000, 10_000_000, seed=0)
+graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False)
+sampler = DeviceRWRSampler(graph, 256, run_seed=0, num_buffers=2)
+for i in range(5):
+    sampler.sample(10_000_000 + i * 256)
+torch.cuda.synchronize()
+lib = _cabi.load()
+ticks = torch.zeros(16, dtype=torch.int64, device=dev)
+lib.gcc_sampler_debug_ticks(ticks.data_ptr())
+n = 20
+for i in range(n):
+    sampler.sample(10_000_000 + (5 + i) * 256)
+torch.cuda.synchronize()
+lib.gcc_sampler_debug_ticks(None)
+t = ticks.cpu().numpy()
+wgs = max(int(t[15]), 1)
+print(f"workgroups per launch {wgs / n:.0f}; per workgroup: subgraph prefix sums {t[0] / 100 / wgs:.2f} us, hash map + row sums "
+      f"{t[1] / 100 / wgs:.2f} us, segment scans {t[2] / 100 / wgs:.2f} us")
