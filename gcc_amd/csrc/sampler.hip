@@ -59,15 +59,20 @@ struct Work {
     int32_t *nodes;       // [G][ncap]   parent ids, seed first
     int32_t *rowbeg;      // [G][ncap]   row_ptr[node]
     int32_t *rowdeg;      // [G][ncap]   parent degree
-    int32_t *rowoff;      // [G][ncap]   exclusive prefix of min(deg, n) within the subgraph
+    int32_t *rowoff;      // [G][ncap]   exclusive prefix of the rows' segment counts within the subgraph (walk kernel)
+    int32_t *rowcap;      // [G][ncap]   exclusive prefix of the rows' scratch slots within the subgraph (walk kernel)
     int32_t *rowcnt;      // [G][ncap]   induced degree
+    int32_t *vbp;         // [G + 1]     exclusive prefix of the subgraphs' virtual workgroups   (prefix kernel A)
+    long long *sbp;       // [G + 1]     exclusive prefix of the subgraphs' scratch slots        (prefix kernel A)
+    int32_t *nbp;         // [G + 1]     node offset of a subgraph inside its view's batch       (prefix kernel A)
+    int32_t *ebp;         // [G + 1]     edge offset of a subgraph inside its view's batch       (prefix kernel B)
     int32_t *scratch;     // [scratch_entries] local col ids, row-sparse
     int32_t ncap;
 };
 
 struct WorkLayout {
-    int64_t off_seeds, off_n, off_cap, off_seg, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowoff, off_rowcnt,
-        off_scratch, total;
+    int64_t off_seeds, off_n, off_cap, off_seg, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowoff, off_rowcap,
+        off_rowcnt, off_vbp, off_sbp, off_nbp, off_ebp, off_scratch, total;
     int32_t ncap;
 };
 
@@ -87,7 +92,12 @@ inline WorkLayout work_layout(int32_t lmax, int32_t B, int64_t scratch_entries)
     w.off_rowbeg = o; o = al(o + 4 * G * w.ncap);
     w.off_rowdeg = o; o = al(o + 4 * G * w.ncap);
     w.off_rowoff = o; o = al(o + 4 * G * w.ncap);
+    w.off_rowcap = o; o = al(o + 4 * G * w.ncap);
     w.off_rowcnt = o; o = al(o + 4 * G * w.ncap);
+    w.off_vbp = o;    o = al(o + 4 * (G + 1));
+    w.off_sbp = o;    o = al(o + 8 * (G + 1));
+    w.off_nbp = o;    o = al(o + 4 * (G + 1));
+    w.off_ebp = o;    o = al(o + 4 * (G + 1));
     w.off_scratch = o; o = al(o + 4 * scratch_entries);
     w.total = o;
     return w;
@@ -258,13 +268,21 @@ __global__ __launch_bounds__(64) void rwr_walk_kernel(
     }
     wave_sync();
     // induction work units: row i contributes ceil(deg_i / kSeg) segments and row_slots() scratch slots
+    // (the per-row exclusive prefixes are kept: induce_kernel and pack_kernel would otherwise redo these scans in
+    // every workgroup)
     int run = 0, slots = 0;
+    int32_t *rowoff = w.rowoff + (int64_t)g * w.ncap, *rowcap = w.rowcap + (int64_t)g * w.ncap;
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
         const int c = i < n ? (ldeg[i] + kSeg - 1) / kSeg : 0;
         const int sl = i < n ? row_slots(ldeg[i], n) : 0;
-        run += wave_shfl(wave_scan_incl(c), 63);
-        slots += wave_shfl(wave_scan_incl(sl), 63);
+        const int ci = wave_scan_incl(c), si = wave_scan_incl(sl);
+        if (i < n) {
+            rowoff[i] = run + ci - c;
+            rowcap[i] = slots + si - sl;
+        }
+        run += wave_shfl(ci, 63);
+        slots += wave_shfl(si, 63);
     }
     if (lane == 0) {
         w.sub_n[g] = n;
@@ -340,6 +358,34 @@ __device__ __forceinline__ int upper_slot(const int32_t *arr, int count, int key
     return lo;
 }
 
+// ------------------------------------------------------------------ K1b / K2b ----
+// One workgroup: exclusive prefixes over the G = 2 B subgraphs that every workgroup of induce_kernel / pack_kernel
+// needs (they used to recompute them: 19 % of induce_kernel's time).  kAfterInduce = false: virtual workgroups,
+// scratch slots, node offsets (per view); true: edge offsets (per view; the induced edge counts exist only then).
+template <bool kAfterInduce>
+__global__ __launch_bounds__(256) void subgraph_prefix_kernel(int32_t B, Work w)
+{
+    DYN_SMEM(smem);
+    __shared__ long long wsum64[5];
+    __shared__ int32_t wsum32[5];
+    const int G = 2 * B, tid = (int)threadIdx.x;
+    int32_t *tmp = (int32_t *)smem;                  // [G + 1]
+    if (!kAfterInduce) {
+        long long *tmp64 = (long long *)(tmp + ((G + 2) & ~1));
+        block_exclusive_scan<int32_t>(tmp, G, [&](int g) { return (w.sub_seg[g] + kSegPerWg - 1) / kSegPerWg; }, wsum32);
+        for (int g = tid; g <= G; g += 256) w.vbp[g] = tmp[g];
+        __syncthreads();
+        block_exclusive_scan<long long>(tmp64, G, [&](int g) { return (long long)w.sub_cap[g]; }, wsum64);
+        for (int g = tid; g <= G; g += 256) w.sbp[g] = tmp64[g];
+        __syncthreads();
+        block_exclusive_scan<int32_t>(tmp, G, [&](int g) { return w.sub_n[g]; }, wsum32);
+        for (int g = tid; g <= G; g += 256) w.nbp[g] = tmp[g] - (g >= B && g < G ? tmp[B] : 0);   // restart at view k
+    } else {
+        block_exclusive_scan<int32_t>(tmp, G, [&](int g) { return w.sub_nnz[g]; }, wsum32);
+        for (int g = tid; g <= G; g += 256) w.ebp[g] = tmp[g] - (g >= B && g < G ? tmp[B] : 0);
+    }
+}
+
 // ------------------------------------------------------------------ K2 ----
 static long long *g_induce_ticks = nullptr;      // diagnostics (gcc_sampler_debug_ticks): [0..3] phase ticks, [15] workgroups
 #define IND_TICK(ph) do { if (ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&ticks[ph], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
@@ -348,8 +394,6 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
     int32_t *__restrict__ status, long long *ticks)
 {
     DYN_SMEM(smem);
-    __shared__ long long wsum64[5];
-    __shared__ int32_t wsum32[5];
     const int hcap = 1 << hcap_log2;
     uint32_t *hkey = (uint32_t *)smem;                       // [hcap]
     uint16_t *hval = (uint16_t *)(hkey + hcap);              // [hcap]
@@ -360,8 +404,8 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
     long long tick_ = ticks ? device_ticks() : 0;
     if (ticks && tid == 0) atomicAdd((unsigned long long *)&ticks[15], 1ull);
-    block_exclusive_scan<int32_t>(vbp, G, [&](int g) { return (w.sub_seg[g] + kSegPerWg - 1) / kSegPerWg; }, wsum32);
-    block_exclusive_scan<long long>(sbp, G, [&](int g) { return (long long)w.sub_cap[g]; }, wsum64);
+    for (int g = tid; g <= G; g += kInduceThreads) { vbp[g] = w.vbp[g]; sbp[g] = w.sbp[g]; }   // (subgraph_prefix_kernel)
+    __syncthreads();
     IND_TICK(0);
     const int total_vb = vbp[G];
     const int shift = 32 - hcap_log2;
@@ -391,8 +435,14 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
                     h = (h + 1) & (uint32_t)(hcap - 1);
                 }
             }
-            block_exclusive_scan<int32_t>(segoff, n, [&](int i) { return (rowdeg[i] + kSeg - 1) / kSeg; }, wsum32);
-            block_exclusive_scan<int32_t>(capoff, n, [&](int i) { return row_slots(rowdeg[i], n); }, wsum32);
+            {                                                // per-row prefixes: written by the walk kernel
+                const int32_t *ro = w.rowoff + (int64_t)g * w.ncap, *rc = w.rowcap + (int64_t)g * w.ncap;
+                for (int i = tid; i <= n; i += kInduceThreads) {
+                    segoff[i] = i < n ? ro[i] : totseg;
+                    capoff[i] = i < n ? rc[i] : w.sub_cap[g];
+                }
+                __syncthreads();
+            }
             cur_g = g;
             IND_TICK(1);
         }
@@ -444,7 +494,6 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
                                                     int64_t scratch_entries, int32_t *__restrict__ status)
 {
     DYN_SMEM(smem);
-    __shared__ long long red[256];
     __shared__ int32_t wsum32[5];
     int32_t *segoff = (int32_t *)smem;            // [ncap + 1] exclusive prefix of segments per row
     int32_t *capoff = segoff + (w.ncap + 1);      // [ncap + 1] exclusive prefix of scratch slots per row
@@ -455,9 +504,9 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
     const BatchOutDev o = view ? ok : oq;
     const int n = w.sub_n[g];
     const int nnz = w.sub_nnz[g];
-    const long long node_base = block_range_sum(w.sub_n, view * B, g, red);
-    const long long edge_base = block_range_sum(w.sub_nnz, view * B, g, red);
-    const long long sbase = block_range_sum(w.sub_cap, 0, g, red);
+    const long long node_base = w.nbp[g];            // (subgraph_prefix_kernel<false / true>)
+    const long long edge_base = w.ebp[g];
+    const long long sbase = w.sbp[g];
     if (tid == 0 && part == 0) {
         o.node_off[b] = (int32_t)node_base;
         o.edge_off[b] = (int32_t)edge_base;
@@ -488,12 +537,17 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
         if (b == B - 1 && tid == 0 && part == 0 && node_base + n <= o.node_cap) o.row_ptr[node_base + n] = (int32_t)ecl;
         return;
     }
-    const int32_t *rowdeg = w.rowdeg + (int64_t)g * w.ncap;
     const int32_t *scratch = w.scratch + sbase;
     const int stride = 1 + (n < kSeg ? n : kSeg);
 
-    block_exclusive_scan<int32_t>(segoff, n, [&](int i) { return (rowdeg[i] + kSeg - 1) / kSeg; }, wsum32);
-    block_exclusive_scan<int32_t>(capoff, n, [&](int i) { return row_slots(rowdeg[i], n); }, wsum32);
+    {                                                        // per-row prefixes: written by the walk kernel
+        const int32_t *ro = w.rowoff + (int64_t)g * w.ncap, *rc = w.rowcap + (int64_t)g * w.ncap;
+        for (int i = tid; i <= n; i += 256) {
+            segoff[i] = i < n ? ro[i] : w.sub_seg[g];
+            capoff[i] = i < n ? rc[i] : w.sub_cap[g];
+        }
+        __syncthreads();
+    }
     // induced degree of row i = sum of its segments' hit counts
     block_exclusive_scan<int32_t>(excl, n, [&](int i) {
         int c = 0;
@@ -569,7 +623,12 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     w.rowbeg = (int32_t *)(base + wl.off_rowbeg);
     w.rowdeg = (int32_t *)(base + wl.off_rowdeg);
     w.rowoff = (int32_t *)(base + wl.off_rowoff);
+    w.rowcap = (int32_t *)(base + wl.off_rowcap);
     w.rowcnt = (int32_t *)(base + wl.off_rowcnt);
+    w.vbp = (int32_t *)(base + wl.off_vbp);
+    w.sbp = (long long *)(base + wl.off_sbp);
+    w.nbp = (int32_t *)(base + wl.off_nbp);
+    w.ebp = (int32_t *)(base + wl.off_ebp);
     w.scratch = (int32_t *)(base + wl.off_scratch);
     w.ncap = wl.ncap;
 
@@ -602,9 +661,12 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
                        g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, B,
                        p->restart_u32, p->seeds, w);
     prof_mark(p->prof, 1, s);
+    const size_t lds_pref = (size_t)(G + 2) * 4 + (size_t)(G + 1) * 8 + 16;
+    hipLaunchKernelGGL((subgraph_prefix_kernel<false>), dim3(1), dim3(256), lds_pref, s, B, w);
     hipLaunchKernelGGL(induce_kernel, dim3(G * 8), dim3(kInduceThreads), lds2, s, g->col_idx, hlog, G,
                        scratch_entries, w, status, g_induce_ticks);
     prof_mark(p->prof, 2, s);
+    hipLaunchKernelGGL((subgraph_prefix_kernel<true>), dim3(1), dim3(256), lds_pref, s, B, w);
     hipLaunchKernelGGL(pack_kernel, dim3(G * kPackParts), dim3(256), lds3, s, B, w, oq, ok, scratch_entries, status);
     prof_mark(p->prof, 3, s);
     hipError_t e = hipGetLastError();
