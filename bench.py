@@ -337,7 +337,7 @@ def main():
                        "rw_hops": args.rw_hops, "restart_prob": args.restart_prob,
                        "stages": stages, "producer_lanes": args.lanes, "producer_depth": args.depth, "producer_chunk": args.chunk, "reserved_cus": args.reserved_cus, "parallelism": f"dp{world} (seed batch sharded, graph replicated)"},
             "kernel_ms_isolated": kern_iso, "stage_ms": stage_ms, "final_loss": final_loss, "posemb_status": posemb_status,
-            "roofline": {"bound": "hbm", "kernel": dom, "measured": "isolated probe loop after the timed region",
+            "roofline": {"bound": "hbm", "kernel": dom, "measured": "isolated probe loop after the timed region: HIP events around subgraph_prefix_kernel<false> + induce_kernel (rocprof of the same kernels alone: profiles/r1_kernel_stats_sampler_alone.csv)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": acc["induce"], "traffic": committed_pmc_traffic(args)[0],

@@ -6,7 +6,7 @@ import numpy as np
 import scipy.sparse as sp
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from gcc_amd.contrast import MemoryMoCo
 from gcc_amd.encoder import GraphEncoder
 from gcc_amd.graph import DeviceGraph

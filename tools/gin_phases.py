@@ -2,7 +2,7 @@
 import sys
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from gcc_amd import _cabi
 from gcc_amd.contrast import MemoryMoCo
 from gcc_amd.encoder import GraphEncoder
