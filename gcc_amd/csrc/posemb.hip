@@ -1037,20 +1037,44 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
     // orthogonalise w against V[:, 0..ncols) twice (CGS2); optionally accumulate the coefficients into H[:, hcol]
     auto orth = [&](int ncols, int hcol) {
         for (int pass = 0; pass < 2; ++pass) {
-            for (int i = wv_id; i < ncols; i += kKWaves) {
-                const float *vc = V + (int64_t)i * ldv;
-                float s0 = 0.f, s1 = 0.f;
-                int r = lane;
-                for (; r + 64 < n; r += 128) { s0 = fmaf(vc[r], w[r], s0); s1 = fmaf(vc[r + 64], w[r + 64], s1); }
-                if (r < n) s0 = fmaf(vc[r], w[r], s0);
-                const float s = wave_sum(s0 + s1);
-                if (lane == 0) hbuf[i] = s;
+            // two basis columns per wave at a time, four 64-row slices each: 8 loads in flight per lane (the basis
+            // lives in L2: the passes are bound by the latency of these reads)
+            for (int i = 2 * wv_id; i < ncols; i += 2 * kKWaves) {
+                const float *va = V + (int64_t)i * ldv;
+                const bool two = i + 1 < ncols;
+                const float *vb = two ? va + ldv : va;
+                float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+                for (int r = lane; r < n; r += 256) {
+                    const int r1 = r + 64, r2 = r + 128, r3 = r + 192;
+                    const float x0 = va[r], y0 = vb[r];
+                    const float x1 = r1 < n ? va[r1] : 0.f, y1 = r1 < n ? vb[r1] : 0.f;
+                    const float x2 = r2 < n ? va[r2] : 0.f, y2 = r2 < n ? vb[r2] : 0.f;
+                    const float x3 = r3 < n ? va[r3] : 0.f, y3 = r3 < n ? vb[r3] : 0.f;
+                    const float w0 = w[r], w1 = r1 < n ? w[r1] : 0.f, w2 = r2 < n ? w[r2] : 0.f, w3 = r3 < n ? w[r3] : 0.f;
+                    a0 = fmaf(x0, w0, a0); a1 = fmaf(x1, w1, a1); a0 = fmaf(x2, w2, a0); a1 = fmaf(x3, w3, a1);
+                    b0 = fmaf(y0, w0, b0); b1 = fmaf(y1, w1, b1); b0 = fmaf(y2, w2, b0); b1 = fmaf(y3, w3, b1);
+                }
+                const float sa = wave_sum(a0 + a1), sb = wave_sum(b0 + b1);
+                if (lane == 0) {
+                    hbuf[i] = sa;
+                    if (two) hbuf[i + 1] = sb;
+                }
             }
             __syncthreads();
             if (hcol >= 0 && tid < ncols) H[tid * kM + hcol] += hbuf[tid];
             for (int r = tid; r < n; r += kKThreads) {
                 float a0 = w[r], a1 = 0.f, a2 = 0.f, a3 = 0.f;
                 int i = 0;
+                for (; i + 8 <= ncols; i += 8) {             // 8 basis reads in flight
+                    const float v0 = V[(int64_t)i * ldv + r], v1 = V[(int64_t)(i + 1) * ldv + r];
+                    const float v2 = V[(int64_t)(i + 2) * ldv + r], v3 = V[(int64_t)(i + 3) * ldv + r];
+                    const float v4 = V[(int64_t)(i + 4) * ldv + r], v5 = V[(int64_t)(i + 5) * ldv + r];
+                    const float v6 = V[(int64_t)(i + 6) * ldv + r], v7 = V[(int64_t)(i + 7) * ldv + r];
+                    a0 = fmaf(-v0, hbuf[i], a0); a1 = fmaf(-v1, hbuf[i + 1], a1);
+                    a2 = fmaf(-v2, hbuf[i + 2], a2); a3 = fmaf(-v3, hbuf[i + 3], a3);
+                    a0 = fmaf(-v4, hbuf[i + 4], a0); a1 = fmaf(-v5, hbuf[i + 5], a1);
+                    a2 = fmaf(-v6, hbuf[i + 6], a2); a3 = fmaf(-v7, hbuf[i + 7], a3);
+                }
                 for (; i + 4 <= ncols; i += 4) {
                     a0 = fmaf(-V[(int64_t)i * ldv + r], hbuf[i], a0);
                     a1 = fmaf(-V[(int64_t)(i + 1) * ldv + r], hbuf[i + 1], a1);
