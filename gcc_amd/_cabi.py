@@ -125,6 +125,18 @@ class GccNceArgs(ctypes.Structure):
     ]
 
 
+class GccGinwLayer(ctypes.Structure):
+    _fields_ = [("w0", _VP), ("w1", _VP), ("s0", _VP), ("t0", _VP), ("s1", _VP), ("t1", _VP), ("s2", _VP), ("t2", _VP)]
+
+
+class GccGinwArgs(ctypes.Structure):
+    _fields_ = [
+        ("node_off", _VP), ("row_ptr", _VP), ("col_idx", _VP), ("x_in", _VP), ("x_out", _VP), ("pooled", _VP),
+        ("batch_size", ctypes.c_int32), ("num_layers", ctypes.c_int32),
+        ("layers", GccGinwLayer * 8),
+    ]
+
+
 # name -> (restype, argtypes); the single source of truth for the symbol test
 SIGNATURES = {
     "gcc_abi_version": (ctypes.c_int32, []),
@@ -156,6 +168,7 @@ SIGNATURES = {
     "gcc_gin_backward": (ctypes.c_int32, [ctypes.POINTER(GccGinPass), ctypes.c_void_p, ctypes.POINTER(GccGinGrads),
                                           ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_ginw_forward": (ctypes.c_int32, [ctypes.POINTER(GccGinwArgs), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_nce_workspace_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32]),
     "gcc_nce_forward": (ctypes.c_int32, [ctypes.POINTER(GccNceArgs), ctypes.c_void_p, ctypes.c_int64,
                                          ctypes.c_void_p, ctypes.c_void_p]),

@@ -13,6 +13,7 @@ static inline long long device_ticks() { return 0; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void device_fence() {}
 #define lds_barrier() __syncthreads()
+#define SCHED_FENCE() ((void)0)
 static inline float load_fresh(const float *p) { return *p; }
 static inline double load_fresh_f64(const double *p) { return *p; }
 #include "hipemu.h"
@@ -70,6 +71,35 @@ static inline f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c)
     return d;
 }
 
+// D(16x16) = A(16x32) * B(32x16) + C with bf16 operands: lane l passes 8 bf16 of row (l & 15) of A and of COLUMN
+// (l & 15) of B, both for the same 8 values of k (the (l >> 4)-th group); c/d as mfma_16x16x4_f32.
+typedef unsigned u32x4 __attribute__((vector_size(16)));
+typedef unsigned u32x2 __attribute__((vector_size(8)));
+static inline f32x4 mfma_16x16x32_bf16(u32x4 a, u32x4 b, f32x4 c)
+{
+    struct AB { unsigned a[4], b[4]; } ab;
+    for (int i = 0; i < 4; ++i) { ab.a[i] = a[i]; ab.b[i] = b[i]; }
+    const unsigned char *t = hipemu::wave_gather(&ab, sizeof(ab), 0xBF16u);
+    int l = lane_id();
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r, col = l & 15;
+        float acc = c[r];
+        for (int g = 0; g < 4; ++g) {
+            AB x = hipemu::gather_at<AB>(t, g * 16 + row);
+            AB y = hipemu::gather_at<AB>(t, g * 16 + col);
+            for (int e = 0; e < 8; ++e) {
+                unsigned ua = (x.a[e >> 1] >> ((e & 1) * 16)) << 16, ub = (y.b[e >> 1] >> ((e & 1) * 16)) << 16;
+                float fa, fb;
+                memcpy(&fa, &ua, 4); memcpy(&fb, &ub, 4);
+                acc = fmaf(fa, fb, acc);
+            }
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+
 // sum over each group of 16 consecutive lanes; valid in the LAST lane of the group (lane & 15) == 15
 static inline float row16_sum_last(float v)
 {
@@ -116,6 +146,8 @@ static inline float wave_max(float v)
 // Waves of the training step share SIMDs with the data pipeline's long-running eigensolver waves; the
 // step's kernels are short and on the critical path, so their waves take the issue slots first.
 #define TRAIN_STEP_WAVE_PRIORITY() __builtin_amdgcn_s_setprio(3)
+// the instruction scheduler moves nothing across this point
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ long long device_ticks() { return (long long)wall_clock64(); }   // 100 MHz
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }        // v_rcp_f32, 1 ulp
 __device__ __forceinline__ void device_fence() { __threadfence(); }                            // release + acquire, agent scope
@@ -151,6 +183,16 @@ template <class T> __device__ __forceinline__ T wave_bcast_first(T v) { return _
 __device__ __forceinline__ f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_16x16x32_bf16: lane l passes 8 bf16 of row (l & 15) of A and of column (l & 15) of B for the k-group
+// (l >> 4); the products pair element e of group g of A with element e of group g of B, so any operand layout
+// with k contiguous per lane works as long as A and B use the same one.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_16x16x32_bf16(u32x4 a, u32x4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
 // ---- wave reductions / scan on DPP row operations (ALU speed; __shfl_* goes through the LDS crossbar, ~60 cycles
@@ -240,3 +282,13 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+
+// bf16 <-> f32 bit helpers: round to nearest even, the same integer formula in the kernels, in the emulator and
+// in oracle/gin_wide.py (finite inputs only)
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float x)
+{
+    uint32_t u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }

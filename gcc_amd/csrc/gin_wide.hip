@@ -1,0 +1,295 @@
+// gcc_amd/csrc/gin_wide.hip -- wide (hidden 256) GIN layers in bf16 on the matrix cores, one subgraph per
+// workgroup, resident in LDS across all layers: BASELINE.json configs[4] ("GIN hid=256 layers=8 deg=32 bf16,
+// SpMM+MFMA-MLP roofline run on batched subgraphs").  Reference: UnsupervisedGIN.forward gcc/models/gin.py:213-221
+// with the modules of gin.py:42-58,107-116 in eval mode (generate.py:71); see include/gcc_amd.h.
+//
+// A subgraph has at most 128 nodes, so its adjacency (plus the identity: GINConv adds h_v itself, eps = 0) is a
+// dense 128x128 block and all three products of a layer run on v_mfma_f32_16x16x32_bf16 with every operand read
+// k-contiguous and every result stored 8 bytes at a time:
+//     AGG [node][ch]  = sum_u  H^T[ch][u]  * ADJ[node][u]      A = H^T rows (LDS),  B = ADJ rows (16 registers, kept for all layers)
+//     Z1  [node][ch]  = sum_k  W0[ch][k]   * AGG[node][k]      A = W0 rows (L2),    B = AGG rows (LDS)      + scale/shift/ReLU
+//     H'^T[ch][node]  = sum_k  Z1[node][k] * W1[ch][k]         A = Z1 rows (LDS),   B = W1 rows (L2)        + 2x scale/shift/ReLU
+// (D[row][col] = sum_k A[row][k] B[col][k]; a lane ends with 4 consecutive ROWS of one column, so the operand
+// order of each product is chosen to make those 4 values contiguous in the layout the next product reads.)
+// The two LDS regions swap roles: H^T -> AGG in the other -> Z1 over H^T -> H'^T over AGG.
+#include "host_common.h"
+
+namespace {
+
+constexpr int kD = GCC_GINW_HIDDEN;
+constexpr int kNodes = GCC_GINW_MAX_NODES;
+constexpr int kThreads = 512;              // 8 waves, 2 per SIMD: up to 256 VGPRs each for 64x64 register tiles
+constexpr int kStrideT = kNodes * 2 + 16;   // bytes per row of the channel-major layout [256 ch][128 nodes] (+16: bank spread)
+constexpr int kStrideN = kD * 2 + 16;       // bytes per row of the node-major layout    [128 nodes][256 ch]
+constexpr int kRegion = kD * kStrideT;      // 69,632 B >= kNodes * kStrideN
+constexpr int kLdsBytes = 2 * kRegion;
+static_assert(kNodes * kStrideN <= kRegion, "node-major layout must fit a region");
+static_assert(kD == 256 && kNodes == 128, "the wave tilings below are written for 256 channels x 128 nodes");
+
+struct WideArgs {
+    const int32_t *node_off, *row_ptr, *col_idx;
+    const uint16_t *x_in;
+    uint16_t *x_out;
+    float *pooled;
+    int32_t *status;
+    int32_t batch_size, num_layers;
+    gcc_ginw_layer layers[GCC_GIN_MAX_LAYERS];
+};
+
+__device__ __forceinline__ u32x4 lds16(const unsigned char *p) { return *(const u32x4 *)p; }
+
+__device__ __forceinline__ u32x2 pack4_bf16(float a, float b, float c, float d)
+{
+    u32x2 r;
+    r[0] = f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16);
+    r[1] = f32_to_bf16_bits(c) | (f32_to_bf16_bits(d) << 16);
+    return r;
+}
+__device__ __forceinline__ float sum4_bf16(u32x2 v)
+{
+    return (bf16_bits_to_f32(v[0] & 0xFFFFu) + bf16_bits_to_f32(v[0] >> 16))
+         + (bf16_bits_to_f32(v[1] & 0xFFFFu) + bf16_bits_to_f32(v[1] >> 16));
+}
+
+// the 16 weight fragments a wave needs for one Linear layer (its 32 output channels x all 256 inputs), issued one
+// product ahead so that the L2 latency is covered by the arithmetic in between
+__device__ __forceinline__ void load_weights(u32x4 (&wf)[2][8], const uint16_t *wmat, int w, int lr, int lg)
+{
+    const uint16_t *wp = wmat + (int64_t)(w * 32 + lr) * kD + lg * 8;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ks = 0; ks < kD / 32; ++ks) wf[m][ks] = *(const u32x4 *)(wp + m * 16 * kD + ks * 32);
+}
+
+__global__ __launch_bounds__(kThreads) void gin_wide_kernel(WideArgs a)
+{
+    DYN_SMEM(smem);
+    unsigned char *P = smem, *Q = smem + kRegion;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int L = a.num_layers;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int b = blockIdx.x; b < a.batch_size; b += gridDim.x) {
+        __syncthreads();                                     // the previous subgraph's output pass is done with P
+        const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+        if (n <= 0 || n > kNodes) {                          // (uniform over the workgroup)
+            if (n > kNodes) {
+                if (tid == 0) atomicOr(a.status, (int32_t)GCC_STATUS_GINW_TOO_LARGE);
+                if (a.x_out)
+                    for (int64_t i = tid; i < (int64_t)n * (kD / 2); i += kThreads) ((uint32_t *)(a.x_out + (int64_t)n0 * kD))[i] = 0u;
+            }
+            if (a.pooled)
+                for (int i = tid; i < (L + 1) * kD; i += kThreads) a.pooled[(int64_t)b * (L + 1) * kD + i] = 0.f;
+            continue;
+        }
+        // ---- the subgraph's input rows -> P, channel-major; neighbour counts -> Q (16-bit counters, [node][u])
+        for (int i = tid; i < kNodes * kStrideT / 4; i += kThreads) ((uint32_t *)Q)[i] = 0u;
+        for (int idx = tid; idx < kNodes * (kD / 8); idx += kThreads) {
+            const int node = idx & (kNodes - 1), chunk = idx >> 7;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (node < n) v = *(const u32x4 *)(a.x_in + (int64_t)(n0 + node) * kD + chunk * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                *(uint16_t *)(P + (chunk * 8 + e) * kStrideT + node * 2) = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
+        }
+        __syncthreads();
+        for (int i = w; i < n; i += kThreads / 64) {
+            const int e0 = a.row_ptr[n0 + i], e1 = a.row_ptr[n0 + i + 1];
+            for (int e = e0 + lane; e < e1; e += 64) {
+                const int u = a.col_idx[e] - n0;
+                if ((unsigned)u < (unsigned)n) atomicAdd((uint32_t *)(Q + i * kStrideT + (u >> 1) * 4), (u & 1) ? 0x10000u : 1u);
+                else atomicOr(a.status, (int32_t)GCC_STATUS_GINW_BAD_EDGE);
+            }
+            if (lane == 0) atomicAdd((uint32_t *)(Q + i * kStrideT + (i >> 1) * 4), (i & 1) ? 0x10000u : 1u);   // + h_v itself
+        }
+        __syncthreads();
+        if (a.pooled && tid < kD) {                          // hidden_rep[0] = the input (gin.py:216)
+            float s = 0.f;
+            for (int j = 0; j < kNodes / 8; ++j) {
+                const u32x4 v = lds16(P + tid * kStrideT + j * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s += bf16_bits_to_f32(v[q] & 0xFFFFu) + bf16_bits_to_f32(v[q] >> 16);
+            }
+            a.pooled[((int64_t)b * (L + 1)) * kD + tid] = s;
+        }
+        // this wave's share of ADJ (its 16 nodes x all neighbours) as B fragments, kept in registers for every layer
+        u32x4 adj[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const u32x4 c = lds16(Q + (w * 16 + lr) * kStrideT + (ks * 32 + lg * 8) * 2);
+            u32x4 f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                f[q] = f32_to_bf16_bits((float)(c[q] & 0xFFFFu)) | (f32_to_bf16_bits((float)(c[q] >> 16)) << 16);
+            adj[ks] = f;
+        }
+        __syncthreads();
+        const int ksn = (n + 31) >> 5;
+        u32x4 wf[2][8];
+        if (L > 0) load_weights(wf, a.layers[0].w0, w, lr, lg);
+
+        for (int layer = 0; layer < L; ++layer) {
+            const gcc_ginw_layer ly = a.layers[layer];
+            // ---- AGG[node][ch] -> Q (node-major); wave w: nodes 16w .. 16w+15, all channels
+            if (w * 16 < n) {
+                f32x4 acc[16];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) acc[m] = zero4;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks < ksn) {
+#pragma unroll
+                        for (int m = 0; m < 16; ++m) {
+                            const u32x4 af = lds16(P + (m * 16 + lr) * kStrideT + (ks * 32 + lg * 8) * 2);
+                            acc[m] = mfma_16x16x32_bf16(af, adj[ks], acc[m]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 16; ++m)
+                    *(u32x2 *)(Q + (w * 16 + lr) * kStrideN + (m * 16 + lg * 4) * 2) = pack4_bf16(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+            }
+            __syncthreads();
+            // ---- Z1[node][ch] = relu(s0 * (AGG W0^T) + t0) -> P (node-major); wave w: channels 32w .. 32w+31, all nodes
+            {
+                const int nbn = (n + 15) >> 4;
+                f32x4 acc[2][8];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int nb = 0; nb < 8; ++nb) acc[m][nb] = zero4;
+#pragma unroll
+                for (int ks = 0; ks < kD / 32; ++ks) {
+#pragma unroll
+                    for (int nb = 0; nb < 8; ++nb) {
+                        if (nb < nbn) {
+                            const u32x4 bf = lds16(Q + (nb * 16 + lr) * kStrideN + (ks * 32 + lg * 8) * 2);
+                            acc[0][nb] = mfma_16x16x32_bf16(wf[0][ks], bf, acc[0][nb]);
+                            acc[1][nb] = mfma_16x16x32_bf16(wf[1][ks], bf, acc[1][nb]);
+                        }
+                    }
+                }
+                SCHED_FENCE();                               // (not earlier: the fragments of this product are still in use)
+                load_weights(wf, ly.w1, w, lr, lg);          // in flight during the epilogue and the barrier
+                SCHED_FENCE();
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int c = w * 32 + m * 16 + lg * 4;
+                    const float4 s = *(const float4 *)(ly.s0 + c), t = *(const float4 *)(ly.t0 + c);
+#pragma unroll
+                    for (int nb = 0; nb < 8; ++nb) {
+                        if (nb < nbn) {
+                            const int node = nb * 16 + lr;
+                            *(u32x2 *)(P + node * kStrideN + c * 2) =
+                                pack4_bf16(fmaxf(fmaf(acc[m][nb][0], s.x, t.x), 0.f), fmaxf(fmaf(acc[m][nb][1], s.y, t.y), 0.f),
+                                           fmaxf(fmaf(acc[m][nb][2], s.z, t.z), 0.f), fmaxf(fmaf(acc[m][nb][3], s.w, t.w), 0.f));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- H'^T[ch][node] = relu(s2 * relu(s1 * (Z1 W1^T) + t1) + t2) -> Q (channel-major); wave w: channels 32w .. 32w+31, all nodes
+            {
+                const int mbn = (n + 15) >> 4;
+                f32x4 acc[8][2];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { acc[m][0] = zero4; acc[m][1] = zero4; }
+#pragma unroll
+                for (int ks = 0; ks < kD / 32; ++ks) {
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        if (m < mbn) {
+                            const u32x4 af = lds16(P + (m * 16 + lr) * kStrideN + (ks * 32 + lg * 8) * 2);
+                            acc[m][0] = mfma_16x16x32_bf16(af, wf[0][ks], acc[m][0]);
+                            acc[m][1] = mfma_16x16x32_bf16(af, wf[1][ks], acc[m][1]);
+                        }
+                    }
+                }
+                SCHED_FENCE();
+                if (layer + 1 < L) load_weights(wf, a.layers[layer + 1].w0, w, lr, lg);
+                SCHED_FENCE();
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int c = w * 32 + nb * 16 + lr;
+                    const float s1 = ly.s1[c], t1 = ly.t1[c], s2 = ly.s2[c], t2 = ly.t2[c];
+                    float psum = 0.f;
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const int node = m * 16 + lg * 4;
+                        u32x2 hv;
+                        hv[0] = 0u; hv[1] = 0u;
+                        if (m < mbn) {
+                            float h[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float y = fmaxf(fmaf(acc[m][nb][r], s1, t1), 0.f);        // apply_func: relu(bn(mlp))
+                                h[r] = node + r < n ? fmaxf(fmaf(y, s2, t2), 0.f) : 0.f;        // relu(batch_norms[i](.)); padding nodes stay 0
+                            }
+                            hv = pack4_bf16(h[0], h[1], h[2], h[3]);
+                            psum += sum4_bf16(hv);
+                        }
+                        *(u32x2 *)(Q + c * kStrideT + node * 2) = hv;
+                    }
+                    psum += wave_shfl_xor(psum, 16);
+                    psum += wave_shfl_xor(psum, 32);
+                    if (lg == 0 && a.pooled) a.pooled[((int64_t)b * (L + 1) + layer + 1) * kD + c] = psum;
+                }
+            }
+            __syncthreads();
+            unsigned char *t = P; P = Q; Q = t;
+        }
+        // ---- the last layer's rows back to node-major global memory
+        if (a.x_out)
+            for (int idx = tid; idx < kNodes * (kD / 8); idx += kThreads) {
+                const int node = idx & (kNodes - 1), chunk = idx >> 7;
+                if (node < n) {
+                    u32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        v[q] = (uint32_t)*(const uint16_t *)(P + (chunk * 8 + 2 * q) * kStrideT + node * 2)
+                             | ((uint32_t)*(const uint16_t *)(P + (chunk * 8 + 2 * q + 1) * kStrideT + node * 2) << 16);
+                    *(u32x4 *)(a.x_out + (int64_t)(n0 + node) * kD + chunk * 8) = v;
+                }
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t gcc_ginw_forward(const gcc_ginw_args *g, int32_t *status, gcc_prof *prof, void *stream)
+{
+    if (!g || !status || !g->node_off || !g->row_ptr || !g->col_idx || !g->x_in || g->batch_size < 1 || g->num_layers < 0 ||
+        g->num_layers > GCC_GIN_MAX_LAYERS || (!g->x_out && !g->pooled)) {
+        snprintf(g_err, kErrLen, "gcc_ginw_forward: bad argument");
+        return -1;
+    }
+    WideArgs a;
+    a.node_off = g->node_off; a.row_ptr = g->row_ptr; a.col_idx = g->col_idx;
+    a.x_in = g->x_in; a.x_out = g->x_out; a.pooled = g->pooled; a.status = status;
+    a.batch_size = g->batch_size; a.num_layers = g->num_layers;
+    for (int i = 0; i < GCC_GIN_MAX_LAYERS; ++i) {
+        a.layers[i] = g->layers[i];
+        const gcc_ginw_layer &l = g->layers[i];
+        if (i < g->num_layers && (!l.w0 || !l.w1 || !l.s0 || !l.t0 || !l.s1 || !l.t1 || !l.s2 || !l.t2)) {
+            snprintf(g_err, kErrLen, "gcc_ginw_forward: layer %d has a NULL parameter", i);
+            return -1;
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+#ifndef GCC_AMD_HIPEMU
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {                                       // more than 64 KiB of dynamic LDS has to be opted into
+        (void)hipFuncSetAttribute((const void *)gin_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        lds_opt_in = true;
+    }
+#endif
+    prof_mark(prof, 0, s);
+    // one workgroup per CU (141 KB of LDS each), walking the subgraphs with a stride of the grid
+    hipLaunchKernelGGL(gin_wide_kernel, dim3(min(g->batch_size, 256)), dim3(kThreads), kLdsBytes, s, a);
+    prof_mark(prof, 1, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_ginw_forward: %s", hipGetErrorString(e)); return -10; }
+    return 0;
+}

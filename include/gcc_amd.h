@@ -264,6 +264,38 @@ int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat, const gcc
                          int32_t accumulate, void *workspace, int64_t workspace_bytes, int64_t node_cap,
                          gcc_prof *prof, void *stream);
 
+/* ------------------------------------------ wide GIN layers, bf16 (config 5) ---
+ * BASELINE.json configs[4]: "GIN hid=256 layers=8 deg=32 bf16, SpMM+MFMA-MLP roofline run on batched
+ * subgraphs".  The layer stack of UnsupervisedGIN.forward (gcc/models/gin.py:213-221) with hidden 256 and
+ * BatchNorm in eval mode (generate.py:71 model.eval()), i.e. per layer
+ *     agg = h + sum_{u in row v} h_u                                   (GINConv sum, eps = 0; gin.py:179-185)
+ *     z1  = relu(s0 * (agg W0^T) + t0)                                 (mlp.linears.0 + mlp.batch_norms.0; gin.py:113-116)
+ *     h'  = relu(s2 * relu(s1 * (z1 W1^T) + t1) + t2)                  (linears.1, apply_func.bn, gin.batch_norms; gin.py:55-57,219-220)
+ * with the Linear biases and BatchNorm running statistics folded into the per-channel scale/shift pairs by
+ * the caller.  Activations and weights are bf16 (stored as their 16 bits), every product accumulates in
+ * f32 on the matrix cores, activations are rounded to bf16 (nearest even) where they are stored: agg, z1, h'.
+ * One workgroup keeps one subgraph (<= 128 nodes) in LDS across all `num_layers` layers; pooled[b][i] is the
+ * SumPooling of hidden_rep[i] (gin.py:205,228), i = 0 being the input. */
+#define GCC_GINW_HIDDEN 256
+#define GCC_GINW_MAX_NODES 128
+#define GCC_STATUS_GINW_TOO_LARGE 32     /* a subgraph has more than GCC_GINW_MAX_NODES nodes: its outputs are 0 */
+#define GCC_STATUS_GINW_BAD_EDGE 64      /* a neighbour id outside its own subgraph was skipped                 */
+typedef struct gcc_ginw_layer {
+    const uint16_t *w0, *w1;             /* device [256, 256] bf16, torch Linear layout [out, in]               */
+    const float *s0, *t0, *s1, *t1, *s2, *t2;   /* device [256] folded scale / shift                             */
+} gcc_ginw_layer;
+typedef struct gcc_ginw_args {
+    const int32_t *node_off;             /* device [B + 1]                                                       */
+    const int32_t *row_ptr, *col_idx;    /* device batched CSR, global node ids; row v lists the in-neighbours   */
+    const uint16_t *x_in;                /* device [N, 256] bf16                                                 */
+    uint16_t *x_out;                     /* device [N, 256] bf16 output of the last layer, or NULL               */
+    float *pooled;                       /* device [B, num_layers + 1, 256] or NULL                              */
+    int32_t batch_size, num_layers;      /* num_layers <= GCC_GIN_MAX_LAYERS                                     */
+    gcc_ginw_layer layers[GCC_GIN_MAX_LAYERS];
+} gcc_ginw_args;
+/* status: device int32[1], OR of GCC_STATUS_GINW_* (zeroed by the caller).  prof marks: 0 before, 1 after. */
+int32_t gcc_ginw_forward(const gcc_ginw_args *a, int32_t *status, gcc_prof *prof, void *stream);
+
 /* ------------------------------------------------------- MoCo / InfoNCE head ---
  * MemoryMoCo.forward (gcc/contrastive/memory_moco.py:26-63, use_softmax=True) fused
  * with NCESoftmaxLoss (gcc/contrastive/criterions.py:12-17), and the E2E variant

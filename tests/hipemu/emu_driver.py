@@ -84,3 +84,33 @@ def emu_sample_batch(g: EmuGraph, B, run_seed, first_sample_id, seeds=None, edge
         res.append(dict(node_off=o["node_off"], edge_off=o["edge_off"], parent_nid=o["parent_nid"][:n],
                         graph_id=o["graph_id"][:n], row_ptr=o["row_ptr"][: n + 1], col_idx=o["col_idx"][:e]))
     return res, int(status[0]), ws[: 4 * B].view(np.int32).copy()
+
+
+def emu_ginw_forward(node_off, row_ptr, col_idx, x_bits, layers):
+    """gcc_ginw_forward on the emulator.  x_bits: uint16 [N, 256] bf16 patterns; layers: dicts of numpy arrays with
+    w0/w1 as uint16 bf16 patterns [256, 256] and s0..t2 float32 [256].  Returns (rows uint16, pooled f32, status)."""
+    lib = emu_lib()
+    node_off = np.ascontiguousarray(node_off, dtype=np.int32)
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+    x_bits = np.ascontiguousarray(x_bits, dtype=np.uint16)
+    B, L = len(node_off) - 1, len(layers)
+    rows = np.full_like(x_bits, 0xFFFF)
+    pooled = np.full((B, L + 1, 256), np.nan, dtype=np.float32)
+    status = np.zeros(1, dtype=np.int32)
+    a = _cabi.GccGinwArgs(node_off=_p(node_off), row_ptr=_p(row_ptr), col_idx=_p(col_idx), x_in=_p(x_bits),
+                          x_out=_p(rows), pooled=_p(pooled), batch_size=B, num_layers=L)
+    keep = []
+    for i, ly in enumerate(layers):
+        for k in ("w0", "w1"):
+            v = np.ascontiguousarray(ly[k], dtype=np.uint16)
+            keep.append(v)
+            setattr(a.layers[i], k, _p(v))
+        for k in ("s0", "t0", "s1", "t1", "s2", "t2"):
+            v = np.ascontiguousarray(ly[k], dtype=np.float32)
+            keep.append(v)
+            setattr(a.layers[i], k, _p(v))
+    rc = lib.gcc_ginw_forward(ctypes.byref(a), _p(status), None, None)
+    if rc != 0:
+        raise RuntimeError(lib.gcc_last_error().decode())
+    return rows, pooled, int(status[0])

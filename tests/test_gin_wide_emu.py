@@ -1,0 +1,136 @@
+"""Wide bf16 GIN layers (gcc_ginw_forward, BASELINE.json configs[4]) on the lock-step emulator vs oracle/gin_wide.py,
+and the oracle's folded eval-mode algebra vs the torch modules of oracle/encoder.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gin_wide as ow
+from oracle.encoder import _GIN
+from tests.hipemu.emu_driver import emu_ginw_forward
+
+D = 256
+
+
+def random_layers(rng, L):
+    layers = []
+    for _ in range(L):
+        ly = dict(w0=(rng.standard_normal((D, D)) / np.sqrt(D * 8)).astype(np.float32),
+                  w1=(rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32))
+        for k in ("s0", "s1", "s2"):
+            ly[k] = rng.uniform(0.5, 1.5, D).astype(np.float32)
+        for k in ("t0", "t1", "t2"):
+            ly[k] = rng.uniform(-0.3, 0.6, D).astype(np.float32)
+        layers.append(ly)
+    return layers
+
+
+def random_batch(rng, sizes, deg, symmetric=False):
+    """in-neighbour lists: `deg` random in-block neighbours per node (duplicates allowed -> multi-edges)"""
+    node_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    rows = []
+    for b, n in enumerate(sizes):
+        nb = [[] for _ in range(n)]
+        for v in range(n):
+            for u in rng.integers(0, n, size=min(deg, 4 * n)):
+                nb[v].append(int(u))
+                if symmetric:
+                    nb[int(u)].append(v)
+        rows += [np.asarray(sorted(r), dtype=np.int64) + node_off[b] for r in nb]
+    row_ptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    col_idx = (np.concatenate(rows) if len(rows) else np.zeros(0)).astype(np.int32)
+    return node_off, row_ptr, col_idx
+
+
+def bits_layers(layers):
+    return [dict(ly, w0=ow.to_bf16_bits(ly["w0"]), w1=ow.to_bf16_bits(ly["w1"])) for ly in layers]
+
+
+def rel_err(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def test_folded_algebra_matches_the_torch_modules():
+    """oracle/gin_wide.py (float64, no rounding) == eval-mode ginlayers of oracle/encoder.py at hidden 256"""
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+    gin = _GIN(3, D, D, D).eval()
+    with torch.no_grad():
+        for m in gin.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.uniform_(-0.5, 0.5)
+                m.running_var.uniform_(0.5, 2.0)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.4)
+    node_off, row_ptr, col_idx = random_batch(rng, [9, 30, 1], 5, symmetric=True)
+    N = int(node_off[-1])
+    x = rng.standard_normal((N, D)).astype(np.float32)
+    layers = []
+    for i, layer in enumerate(gin.ginlayers):
+        mlp = layer.apply_func.mlp
+        bn = lambda m: (m.weight.detach().numpy(), m.bias.detach().numpy(), m.running_mean.numpy(), m.running_var.numpy())
+        layers.append(ow.fold_layer(mlp.linears[0].weight.detach().numpy(), mlp.linears[0].bias.detach().numpy(),
+                                    bn(mlp.batch_norms[0]), mlp.linears[1].weight.detach().numpy(),
+                                    mlp.linears[1].bias.detach().numpy(), bn(layer.apply_func.bn), bn(gin.batch_norms[i])))
+    got, pooled = ow.gin_wide_forward(node_off, row_ptr, col_idx, x, layers, bf16=False)
+    # the layer loop of OracleGraphEncoder.forward (oracle/encoder.py; gin.py:217-221) on these modules
+    h = torch.from_numpy(x).double()
+    gin = gin.double()
+    src = torch.repeat_interleave(torch.arange(N), torch.from_numpy(np.diff(row_ptr)).long())
+    dst = torch.from_numpy(col_idx).long()
+    F = torch.nn.functional
+    with torch.no_grad():
+        for i, layer in enumerate(gin.ginlayers):
+            neigh = torch.zeros_like(h).index_add_(0, dst, h[src])
+            z = (1 + layer.eps) * h + neigh
+            mlp = layer.apply_func.mlp
+            z = mlp.linears[1](F.relu(mlp.batch_norms[0](mlp.linears[0](z))))
+            z = F.relu(layer.apply_func.bn(z))
+            h = F.relu(gin.batch_norms[i](z))
+    assert rel_err(got, h.numpy()) < 1e-5
+    gid = np.repeat(np.arange(3), np.diff(node_off))
+    want = np.zeros((3, D))
+    np.add.at(want, gid, h.numpy())
+    assert rel_err(pooled[:, -1], want) < 1e-5
+
+
+@pytest.mark.parametrize("sizes,deg,L", [([128, 37, 1, 0, 64], 32, 2), ([5], 3, 1)])
+def test_emulated_kernel_matches_the_oracle(sizes, deg, L):
+    rng = np.random.default_rng(len(sizes) + L)
+    layers = random_layers(rng, L)
+    node_off, row_ptr, col_idx = random_batch(rng, sizes, deg)
+    N = int(node_off[-1])
+    x = ow.bf16_round(rng.standard_normal((N, D)).astype(np.float32))
+    rows, pooled, status = emu_ginw_forward(node_off, row_ptr, col_idx, ow.to_bf16_bits(x), bits_layers(layers))
+    assert status == 0
+    want_rows, want_pooled = ow.gin_wide_forward(node_off, row_ptr, col_idx, x, layers, bf16=True)
+    got = ow.from_bf16_bits(rows)
+    # same rounding points, f32 (matrix core) vs f64 accumulation: a few results land on the other side of a bf16
+    # rounding boundary (2^-8 relative) and perturb what follows; identical otherwise
+    assert rel_err(got, want_rows) < 2e-3
+    assert np.max(np.abs(got - want_rows)) <= 2.0 ** -6 * np.max(np.abs(want_rows))
+    assert rel_err(pooled, want_pooled) < 1e-3
+    for b, n in enumerate(sizes):
+        if n == 0:
+            assert not pooled[b].any()
+    # bf16 storage vs unrounded float64 arithmetic with the same (bf16) weights
+    truth, _ = ow.gin_wide_forward(node_off, row_ptr, col_idx, x,
+                                   [dict(ly, w0=ow.bf16_round(ly["w0"]), w1=ow.bf16_round(ly["w1"])) for ly in layers], bf16=False)
+    assert rel_err(got, truth) < 2e-2
+
+
+def test_input_pooling_layers_zero_and_refusals():
+    rng = np.random.default_rng(7)
+    node_off, row_ptr, col_idx = random_batch(rng, [20, 130], 4)
+    N = int(node_off[-1])
+    x = ow.bf16_round(rng.standard_normal((N, D)).astype(np.float32))
+    rows, pooled, status = emu_ginw_forward(node_off, row_ptr, col_idx, ow.to_bf16_bits(x), [])
+    assert status == 32                                     # the 130-node subgraph is refused, loudly
+    np.testing.assert_array_equal(rows[:20], ow.to_bf16_bits(x)[:20])     # zero layers: rows pass through LDS unchanged
+    assert not rows[20:].any() and not pooled[1].any()
+    np.testing.assert_allclose(pooled[0, 0], x[:20].astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
+    # a neighbour outside its subgraph is skipped and flagged
+    node_off, row_ptr, col_idx = random_batch(rng, [6, 6], 2)
+    col_idx = col_idx.copy()
+    col_idx[0] = 9
+    _, _, status = emu_ginw_forward(node_off, row_ptr, col_idx, ow.to_bf16_bits(x[:12]), [])
+    assert status == 64
