@@ -155,6 +155,7 @@ SIGNATURES = {
     "gcc_posemb_debug_ticks": (None, [ctypes.c_void_p]),
     "gcc_sampler_debug_ticks": (None, [ctypes.c_void_p]),
     "gcc_gin_debug_ticks": (None, [ctypes.c_void_p]),
+    "gcc_ginw_debug_ticks": (None, [ctypes.c_void_p]),
     "gcc_posemb_multi_workspace_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32]),
     "gcc_posemb_multi": (ctypes.c_int32, [ctypes.POINTER(GccPosembView), ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                           ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,

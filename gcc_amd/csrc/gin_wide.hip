@@ -13,6 +13,7 @@
 // order of each product is chosen to make those 4 values contiguous in the layout the next product reads.)
 // The two LDS regions swap roles: H^T -> AGG in the other -> Z1 over H^T -> H'^T over AGG.
 #include "host_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -22,7 +23,8 @@ constexpr int kThreads = 512;              // 8 waves, 2 per SIMD: up to 256 VGP
 constexpr int kStrideT = kNodes * 2 + 16;   // bytes per row of the channel-major layout [256 ch][128 nodes] (+16: bank spread)
 constexpr int kStrideN = kD * 2 + 16;       // bytes per row of the node-major layout    [128 nodes][256 ch]
 constexpr int kRegion = kD * kStrideT;      // 69,632 B >= kNodes * kStrideN
-constexpr int kLdsBytes = 2 * kRegion;
+constexpr int kAhead = 3;                   // k-steps the LDS reads of the Linear products run ahead of the matrix instructions
+constexpr int kLdsBytes = 2 * kRegion + (kNodes + 1 + 3) / 4 * 16;
 static_assert(kNodes * kStrideN <= kRegion, "node-major layout must fit a region");
 static_assert(kD == 256 && kNodes == 128, "the wave tilings below are written for 256 channels x 128 nodes");
 
@@ -33,8 +35,22 @@ struct WideArgs {
     float *pooled;
     int32_t *status;
     int32_t batch_size, num_layers;
+    int32_t late_w0;                 // tuning knob (env GCC_GINW_LATE_W0=1): fetch the first Linear's weight fragments after the
+                                     // aggregation instead of before it (same results)
+    long long *ticks;                // diagnostics (gcc_ginw_debug_ticks): wall-clock ticks per phase, or NULL
     gcc_ginw_layer layers[GCC_GIN_MAX_LAYERS];
 };
+
+long long *g_ticks = nullptr;
+
+__device__ __forceinline__ void phase_tick(long long *row, int ph, long long &tick)
+{
+    if (row && threadIdx.x == 0) {
+        const long long now = device_ticks();
+        atomicAdd((unsigned long long *)&row[ph], (unsigned long long)(now - tick));
+        tick = now;
+    }
+}
 
 __device__ __forceinline__ u32x4 lds16(const unsigned char *p) { return *(const u32x4 *)p; }
 
@@ -62,10 +78,123 @@ __device__ __forceinline__ void load_weights(u32x4 (&wf)[2][8], const uint16_t *
         for (int ks = 0; ks < kD / 32; ++ks) wf[m][ks] = *(const u32x4 *)(wp + m * 16 * kD + ks * 32);
 }
 
+// Z1[node][ch] = relu(s0 * (AGG W0^T) + t0) for the wave's 32 channels and the first 16 * kNB nodes.  No branches
+// inside: the LDS reads of the whole product are scheduled ahead of the matrix instructions that consume them.
+// Rows of padding nodes hold finite leftovers or anything at all; every result depends on its own node's row only.
+template <int kNB>
+__device__ __forceinline__ void linear0_tile(const unsigned char *Q, unsigned char *P, u32x4 (&wf)[2][8], const gcc_ginw_layer &ly,
+                                             const uint16_t *wnext, int f0, int w, int lr, int lg)
+{
+    Q += f0 * 16 * kStrideN;                     // node fragments f0 .. f0 + kNB - 1
+    P += f0 * 16 * kStrideN;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][kNB];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nb = 0; nb < kNB; ++nb) acc[m][nb] = zero4;
+    // software pipeline: the LDS reads of k-step ks + kAhead are issued before the matrix instructions of step ks (the
+    // fences keep the scheduler from hoisting every read of the product to the top, which spills, and from sinking them)
+    const unsigned char *src = Q + lr * kStrideN + lg * 16;
+    u32x4 ring[kAhead + 1][kNB];
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j)
+#pragma unroll
+        for (int nb = 0; nb < kNB; ++nb) ring[j][nb] = lds16(src + nb * 16 * kStrideN + j * 64);
+#pragma unroll
+    for (int ks = 0; ks < kD / 32; ++ks) {
+        if (ks + kAhead < kD / 32) {
+#pragma unroll
+            for (int nb = 0; nb < kNB; ++nb) ring[(ks + kAhead) % (kAhead + 1)][nb] = lds16(src + nb * 16 * kStrideN + (ks + kAhead) * 64);
+        }
+        SCHED_FENCE();
+#pragma unroll
+        for (int nb = 0; nb < kNB; ++nb) {
+            acc[0][nb] = mfma_16x16x32_bf16(wf[0][ks], ring[ks % (kAhead + 1)][nb], acc[0][nb]);
+            acc[1][nb] = mfma_16x16x32_bf16(wf[1][ks], ring[ks % (kAhead + 1)][nb], acc[1][nb]);
+        }
+        SCHED_FENCE();
+    }
+    SCHED_FENCE();                               // (not earlier: the fragments of this product are still in use)
+    if (wnext) load_weights(wf, wnext, w, lr, lg);   // in flight during the epilogue and the barrier
+    SCHED_FENCE();
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int c = w * 32 + m * 16 + lg * 4;
+        const float4 s = *(const float4 *)(ly.s0 + c), t = *(const float4 *)(ly.t0 + c);
+#pragma unroll
+        for (int nb = 0; nb < kNB; ++nb)
+            *(u32x2 *)(P + (nb * 16 + lr) * kStrideN + c * 2) =
+                pack4_bf16(fmaxf(fmaf(acc[m][nb][0], s.x, t.x), 0.f), fmaxf(fmaf(acc[m][nb][1], s.y, t.y), 0.f),
+                           fmaxf(fmaf(acc[m][nb][2], s.z, t.z), 0.f), fmaxf(fmaf(acc[m][nb][3], s.w, t.w), 0.f));
+    }
+}
+
+// H'^T[ch][node] = relu(s2 * relu(s1 * (Z1 W1^T) + t1) + t2) for the wave's 32 channels; nodes >= n are written as 0
+// (the aggregation multiplies them by ADJ's zeros, which only works for finite values); SumPooling of the result.
+template <int kNB>
+__device__ __forceinline__ void linear1_tile(const unsigned char *P, unsigned char *Q, u32x4 (&wf)[2][8], const gcc_ginw_layer &ly,
+                                             const uint16_t *wnext, float (&pool_part)[2], int n, int f0, int w, int lr, int lg)
+{
+    P += f0 * 16 * kStrideN;                     // node fragments f0 .. f0 + kNB - 1
+    Q += f0 * 32;
+    n -= f0 * 16;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[kNB][2];
+#pragma unroll
+    for (int m = 0; m < kNB; ++m) { acc[m][0] = zero4; acc[m][1] = zero4; }
+    const unsigned char *src = P + lr * kStrideN + lg * 16;          // pipelined as in linear0_tile
+    u32x4 ring[kAhead + 1][kNB];
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j)
+#pragma unroll
+        for (int m = 0; m < kNB; ++m) ring[j][m] = lds16(src + m * 16 * kStrideN + j * 64);
+#pragma unroll
+    for (int ks = 0; ks < kD / 32; ++ks) {
+        if (ks + kAhead < kD / 32) {
+#pragma unroll
+            for (int m = 0; m < kNB; ++m) ring[(ks + kAhead) % (kAhead + 1)][m] = lds16(src + m * 16 * kStrideN + (ks + kAhead) * 64);
+        }
+        SCHED_FENCE();
+#pragma unroll
+        for (int m = 0; m < kNB; ++m) {
+            acc[m][0] = mfma_16x16x32_bf16(ring[ks % (kAhead + 1)][m], wf[0][ks], acc[m][0]);
+            acc[m][1] = mfma_16x16x32_bf16(ring[ks % (kAhead + 1)][m], wf[1][ks], acc[m][1]);
+        }
+        SCHED_FENCE();
+    }
+    SCHED_FENCE();
+    if (wnext) load_weights(wf, wnext, w, lr, lg);
+    SCHED_FENCE();
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int c = w * 32 + nb * 16 + lr;
+        const float s1 = ly.s1[c], t1 = ly.t1[c], s2 = ly.s2[c], t2 = ly.t2[c];
+        float psum = 0.f;
+#pragma unroll
+        for (int m = 0; m < kNB; ++m) {
+            const int node = m * 16 + lg * 4;
+            float h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float y = fmaxf(fmaf(acc[m][nb][r], s1, t1), 0.f);            // apply_func: relu(bn(mlp))
+                h[r] = node + r < n ? fmaxf(fmaf(y, s2, t2), 0.f) : 0.f;            // relu(batch_norms[i](.)); padding nodes stay 0
+            }
+            const u32x2 hv = pack4_bf16(h[0], h[1], h[2], h[3]);
+            psum += sum4_bf16(hv);
+            *(u32x2 *)(Q + c * kStrideT + node * 2) = hv;
+        }
+        psum += wave_shfl_xor(psum, 16);
+        psum += wave_shfl_xor(psum, 32);
+        pool_part[nb] += psum;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void gin_wide_kernel(WideArgs a)
 {
     DYN_SMEM(smem);
     unsigned char *P = smem, *Q = smem + kRegion;
+    int32_t *rp = (int32_t *)(smem + 2 * kRegion);           // [129] row pointers of the subgraph
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const int L = a.num_layers;
@@ -73,6 +202,7 @@ __global__ __launch_bounds__(kThreads) void gin_wide_kernel(WideArgs a)
 
     for (int b = blockIdx.x; b < a.batch_size; b += gridDim.x) {
         __syncthreads();                                     // the previous subgraph's output pass is done with P
+        long long tick = a.ticks ? device_ticks() : 0;
         const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
         if (n <= 0 || n > kNodes) {                          // (uniform over the workgroup)
             if (n > kNodes) {
@@ -86,6 +216,7 @@ __global__ __launch_bounds__(kThreads) void gin_wide_kernel(WideArgs a)
         }
         // ---- the subgraph's input rows -> P, channel-major; neighbour counts -> Q (16-bit counters, [node][u])
         for (int i = tid; i < kNodes * kStrideT / 4; i += kThreads) ((uint32_t *)Q)[i] = 0u;
+        if (tid <= n) rp[tid] = a.row_ptr[n0 + tid];
         for (int idx = tid; idx < kNodes * (kD / 8); idx += kThreads) {
             const int node = idx & (kNodes - 1), chunk = idx >> 7;
             u32x4 v = {0u, 0u, 0u, 0u};
@@ -95,16 +226,24 @@ __global__ __launch_bounds__(kThreads) void gin_wide_kernel(WideArgs a)
                 *(uint16_t *)(P + (chunk * 8 + e) * kStrideT + node * 2) = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
         }
         __syncthreads();
-        for (int i = w; i < n; i += kThreads / 64) {
-            const int e0 = a.row_ptr[n0 + i], e1 = a.row_ptr[n0 + i + 1];
-            for (int e = e0 + lane; e < e1; e += 64) {
+        phase_tick(a.ticks, 0, tick);                        // rows in
+        {   // every edge of the subgraph by one thread (loads of 8 edges per thread in flight at once); its row by
+            // bisection of the row pointers staged by the pass above
+            const int e0 = rp[0], e1 = rp[n];
+            for (int e = e0 + tid; e < e1; e += kThreads) {
                 const int u = a.col_idx[e] - n0;
-                if ((unsigned)u < (unsigned)n) atomicAdd((uint32_t *)(Q + i * kStrideT + (u >> 1) * 4), (u & 1) ? 0x10000u : 1u);
+                int lo = 0, hi = n;                          // largest i with rp[i] <= e
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (rp[mid] <= e) lo = mid; else hi = mid;
+                }
+                if ((unsigned)u < (unsigned)n) atomicAdd((uint32_t *)(Q + lo * kStrideT + (u >> 1) * 4), (u & 1) ? 0x10000u : 1u);
                 else atomicOr(a.status, (int32_t)GCC_STATUS_GINW_BAD_EDGE);
             }
-            if (lane == 0) atomicAdd((uint32_t *)(Q + i * kStrideT + (i >> 1) * 4), (i & 1) ? 0x10000u : 1u);   // + h_v itself
+            if (tid < n) atomicAdd((uint32_t *)(Q + tid * kStrideT + (tid >> 1) * 4), (tid & 1) ? 0x10000u : 1u);   // + h_v itself
         }
         __syncthreads();
+        phase_tick(a.ticks, 1, tick);                        // neighbour counts
         if (a.pooled && tid < kD) {                          // hidden_rep[0] = the input (gin.py:216)
             float s = 0.f;
             for (int j = 0; j < kNodes / 8; ++j) {
@@ -126,9 +265,10 @@ __global__ __launch_bounds__(kThreads) void gin_wide_kernel(WideArgs a)
             adj[ks] = f;
         }
         __syncthreads();
-        const int ksn = (n + 31) >> 5;
+        phase_tick(a.ticks, 2, tick);                        // input pooling, adjacency fragments
+        const int ksn = (n + 31) >> 5, nfrag = (n + 15) >> 4;
         u32x4 wf[2][8];
-        if (L > 0) load_weights(wf, a.layers[0].w0, w, lr, lg);
+        if (L > 0 && !a.late_w0) load_weights(wf, a.layers[0].w0, w, lr, lg);
 
         for (int layer = 0; layer < L; ++layer) {
             const gcc_ginw_layer ly = a.layers[layer];
@@ -137,107 +277,73 @@ __global__ __launch_bounds__(kThreads) void gin_wide_kernel(WideArgs a)
                 f32x4 acc[16];
 #pragma unroll
                 for (int m = 0; m < 16; ++m) acc[m] = zero4;
+                const unsigned char *src = P + lr * kStrideT + lg * 16;
+                u32x4 ring[3][4];                            // quarter k-steps (4 channel blocks each), two ahead
+                const int nstep = 4 * ksn;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    if (ks < ksn) {
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int m = 0; m < 16; ++m) {
-                            const u32x4 af = lds16(P + (m * 16 + lr) * kStrideT + (ks * 32 + lg * 8) * 2);
-                            acc[m] = mfma_16x16x32_bf16(af, adj[ks], acc[m]);
+                    for (int m = 0; m < 4; ++m) ring[j][m] = lds16(src + ((j & 3) * 4 + m) * 16 * kStrideT + (j >> 2) * 64);
+#pragma unroll
+                for (int step = 0; step < 16; ++step) {      // step = 4 * ks + quarter
+                    if (step < nstep) {
+                        if (step + 2 < nstep) {
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+                                ring[(step + 2) % 3][m] = lds16(src + (((step + 2) & 3) * 4 + m) * 16 * kStrideT + ((step + 2) >> 2) * 64);
                         }
+                        SCHED_FENCE();
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            acc[(step & 3) * 4 + m] = mfma_16x16x32_bf16(ring[step % 3][m], adj[step >> 2], acc[(step & 3) * 4 + m]);
+                        SCHED_FENCE();
                     }
                 }
 #pragma unroll
                 for (int m = 0; m < 16; ++m)
                     *(u32x2 *)(Q + (w * 16 + lr) * kStrideN + (m * 16 + lg * 4) * 2) = pack4_bf16(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
             }
-            __syncthreads();
-            // ---- Z1[node][ch] = relu(s0 * (AGG W0^T) + t0) -> P (node-major); wave w: channels 32w .. 32w+31, all nodes
-            {
-                const int nbn = (n + 15) >> 4;
-                f32x4 acc[2][8];
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int nb = 0; nb < 8; ++nb) acc[m][nb] = zero4;
-#pragma unroll
-                for (int ks = 0; ks < kD / 32; ++ks) {
-#pragma unroll
-                    for (int nb = 0; nb < 8; ++nb) {
-                        if (nb < nbn) {
-                            const u32x4 bf = lds16(Q + (nb * 16 + lr) * kStrideN + (ks * 32 + lg * 8) * 2);
-                            acc[0][nb] = mfma_16x16x32_bf16(wf[0][ks], bf, acc[0][nb]);
-                            acc[1][nb] = mfma_16x16x32_bf16(wf[1][ks], bf, acc[1][nb]);
-                        }
-                    }
-                }
-                SCHED_FENCE();                               // (not earlier: the fragments of this product are still in use)
-                load_weights(wf, ly.w1, w, lr, lg);          // in flight during the epilogue and the barrier
+            if (a.late_w0) {
                 SCHED_FENCE();
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int c = w * 32 + m * 16 + lg * 4;
-                    const float4 s = *(const float4 *)(ly.s0 + c), t = *(const float4 *)(ly.t0 + c);
-#pragma unroll
-                    for (int nb = 0; nb < 8; ++nb) {
-                        if (nb < nbn) {
-                            const int node = nb * 16 + lr;
-                            *(u32x2 *)(P + node * kStrideN + c * 2) =
-                                pack4_bf16(fmaxf(fmaf(acc[m][nb][0], s.x, t.x), 0.f), fmaxf(fmaf(acc[m][nb][1], s.y, t.y), 0.f),
-                                           fmaxf(fmaf(acc[m][nb][2], s.z, t.z), 0.f), fmaxf(fmaf(acc[m][nb][3], s.w, t.w), 0.f));
-                        }
-                    }
-                }
+                load_weights(wf, ly.w0, w, lr, lg);
+                SCHED_FENCE();
             }
             __syncthreads();
+            phase_tick(a.ticks, 3, tick);                    // aggregation
+            // ---- Z1[node][ch] = relu(s0 * (AGG W0^T) + t0) -> P (node-major); wave w: channels 32w .. 32w+31, all nodes
+            // (two passes over at most 4 node fragments each: 32 accumulator registers at a time, the weights stay)
+            if (nfrag > 4) {
+                linear0_tile<4>(Q, P, wf, ly, nullptr, 0, w, lr, lg);
+                if (nfrag > 6) linear0_tile<4>(Q, P, wf, ly, ly.w1, 4, w, lr, lg);
+                else linear0_tile<2>(Q, P, wf, ly, ly.w1, 4, w, lr, lg);
+            } else if (nfrag > 2) linear0_tile<4>(Q, P, wf, ly, ly.w1, 0, w, lr, lg);
+            else linear0_tile<2>(Q, P, wf, ly, ly.w1, 0, w, lr, lg);
+            __syncthreads();
+            phase_tick(a.ticks, 4, tick);                    // first Linear
             // ---- H'^T[ch][node] = relu(s2 * relu(s1 * (Z1 W1^T) + t1) + t2) -> Q (channel-major); wave w: channels 32w .. 32w+31, all nodes
             {
-                const int mbn = (n + 15) >> 4;
-                f32x4 acc[8][2];
-#pragma unroll
-                for (int m = 0; m < 8; ++m) { acc[m][0] = zero4; acc[m][1] = zero4; }
-#pragma unroll
-                for (int ks = 0; ks < kD / 32; ++ks) {
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) {
-                        if (m < mbn) {
-                            const u32x4 af = lds16(P + (m * 16 + lr) * kStrideN + (ks * 32 + lg * 8) * 2);
-                            acc[m][0] = mfma_16x16x32_bf16(af, wf[0][ks], acc[m][0]);
-                            acc[m][1] = mfma_16x16x32_bf16(af, wf[1][ks], acc[m][1]);
-                        }
-                    }
+                const uint16_t *wnext = (layer + 1 < L && !a.late_w0) ? a.layers[layer + 1].w0 : nullptr;
+                float pool_part[2] = {0.f, 0.f};
+                if (nfrag > 4) {
+                    linear1_tile<4>(P, Q, wf, ly, nullptr, pool_part, n, 0, w, lr, lg);
+                    if (nfrag > 6) linear1_tile<4>(P, Q, wf, ly, wnext, pool_part, n, 4, w, lr, lg);
+                    else linear1_tile<2>(P, Q, wf, ly, wnext, pool_part, n, 4, w, lr, lg);
+                } else if (nfrag > 2) linear1_tile<4>(P, Q, wf, ly, wnext, pool_part, n, 0, w, lr, lg);
+                else linear1_tile<2>(P, Q, wf, ly, wnext, pool_part, n, 0, w, lr, lg);
+                // node fragments past the last one computed: zeros (read by the next aggregation as multiplicands of 0)
+                const int fdone = nfrag > 6 ? 8 : nfrag > 4 ? 6 : nfrag > 2 ? 4 : 2;
+                for (int i = lane; i < 32 * (8 - fdone) * 4; i += 64) {
+                    const int c = w * 32 + i / ((8 - fdone) * 4), j = i % ((8 - fdone) * 4);
+                    *(u32x2 *)(Q + c * kStrideT + fdone * 32 + j * 8) = u32x2{0u, 0u};
                 }
-                SCHED_FENCE();
-                if (layer + 1 < L) load_weights(wf, a.layers[layer + 1].w0, w, lr, lg);
-                SCHED_FENCE();
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const int c = w * 32 + nb * 16 + lr;
-                    const float s1 = ly.s1[c], t1 = ly.t1[c], s2 = ly.s2[c], t2 = ly.t2[c];
-                    float psum = 0.f;
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) {
-                        const int node = m * 16 + lg * 4;
-                        u32x2 hv;
-                        hv[0] = 0u; hv[1] = 0u;
-                        if (m < mbn) {
-                            float h[4];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float y = fmaxf(fmaf(acc[m][nb][r], s1, t1), 0.f);        // apply_func: relu(bn(mlp))
-                                h[r] = node + r < n ? fmaxf(fmaf(y, s2, t2), 0.f) : 0.f;        // relu(batch_norms[i](.)); padding nodes stay 0
-                            }
-                            hv = pack4_bf16(h[0], h[1], h[2], h[3]);
-                            psum += sum4_bf16(hv);
-                        }
-                        *(u32x2 *)(Q + c * kStrideT + node * 2) = hv;
-                    }
-                    psum += wave_shfl_xor(psum, 16);
-                    psum += wave_shfl_xor(psum, 32);
-                    if (lg == 0 && a.pooled) a.pooled[((int64_t)b * (L + 1) + layer + 1) * kD + c] = psum;
+                if (lg == 0 && a.pooled) {
+                    float *pool = a.pooled + ((int64_t)b * (L + 1) + layer + 1) * kD + w * 32 + lr;
+                    pool[0] = pool_part[0];
+                    pool[16] = pool_part[1];
                 }
             }
             __syncthreads();
+            phase_tick(a.ticks, 5, tick);                    // second Linear
             unsigned char *t = P; P = Q; Q = t;
         }
         // ---- the last layer's rows back to node-major global memory
@@ -253,10 +359,14 @@ __global__ __launch_bounds__(kThreads) void gin_wide_kernel(WideArgs a)
                     *(u32x4 *)(a.x_out + (int64_t)(n0 + node) * kD + chunk * 8) = v;
                 }
             }
+        phase_tick(a.ticks, 6, tick);                        // rows out
+        if (a.ticks && tid == 0) atomicAdd((unsigned long long *)&a.ticks[15], 1ull);
     }
 }
 
 }  // namespace
+
+extern "C" void gcc_ginw_debug_ticks(long long *device_ticks64) { g_ticks = device_ticks64; }
 
 extern "C" int32_t gcc_ginw_forward(const gcc_ginw_args *g, int32_t *status, gcc_prof *prof, void *stream)
 {
@@ -269,6 +379,9 @@ extern "C" int32_t gcc_ginw_forward(const gcc_ginw_args *g, int32_t *status, gcc
     a.node_off = g->node_off; a.row_ptr = g->row_ptr; a.col_idx = g->col_idx;
     a.x_in = g->x_in; a.x_out = g->x_out; a.pooled = g->pooled; a.status = status;
     a.batch_size = g->batch_size; a.num_layers = g->num_layers;
+    a.ticks = g_ticks;
+    const char *e = getenv("GCC_GINW_LATE_W0");
+    a.late_w0 = e && atoi(e) != 0;
     for (int i = 0; i < GCC_GIN_MAX_LAYERS; ++i) {
         a.layers[i] = g->layers[i];
         const gcc_ginw_layer &l = g->layers[i];

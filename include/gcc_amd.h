@@ -295,6 +295,9 @@ typedef struct gcc_ginw_args {
 } gcc_ginw_args;
 /* status: device int32[1], OR of GCC_STATUS_GINW_* (zeroed by the caller).  prof marks: 0 before, 1 after. */
 int32_t gcc_ginw_forward(const gcc_ginw_args *a, int32_t *status, gcc_prof *prof, void *stream);
+/* diagnostics, as gcc_posemb_debug_ticks: device int64[16] (rows in, neighbour counts, fragments, aggregation, first
+ * Linear, second Linear, rows out; [15] = subgraphs); NULL switches it off. */
+void gcc_ginw_debug_ticks(long long *device_ticks64);
 
 /* ------------------------------------------------------- MoCo / InfoNCE head ---
  * MemoryMoCo.forward (gcc/contrastive/memory_moco.py:26-63, use_softmax=True) fused

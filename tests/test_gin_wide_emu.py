@@ -93,7 +93,7 @@ def test_folded_algebra_matches_the_torch_modules():
     assert rel_err(pooled[:, -1], want) < 1e-5
 
 
-@pytest.mark.parametrize("sizes,deg,L", [([128, 37, 1, 0, 64], 32, 2), ([5], 3, 1)])
+@pytest.mark.parametrize("sizes,deg,L", [([128, 37, 1, 0, 64], 32, 2), ([5], 3, 1), ([90, 100, 17, 33, 113], 6, 3)])
 def test_emulated_kernel_matches_the_oracle(sizes, deg, L):
     rng = np.random.default_rng(len(sizes) + L)
     layers = random_layers(rng, L)

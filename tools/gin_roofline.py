@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--phases", action="store_true", help="also report per-phase wall-clock of the fused launch")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
@@ -93,7 +94,18 @@ def main():
                                    "frac": bytes_layer * L / ms_l / 1e6 / PEAK_HBM_GBS,
                                    "algorithmic_bytes_per_launch": bytes_layer}},
         "algorithmic_flops_per_layer": flops_layer, "iters": args.iters,
+        "late_w0": bool(int(os.environ.get("GCC_GINW_LATE_W0", "0"))),
     }
+    if args.phases:
+        from gcc_amd import _cabi
+        ticks = torch.zeros(16, dtype=torch.int64, device=dev)
+        _cabi.load().gcc_ginw_debug_ticks(ticks.data_ptr())
+        fused()
+        torch.cuda.synchronize()
+        _cabi.load().gcc_ginw_debug_ticks(None)
+        t = ticks.cpu().numpy()
+        names = ["rows-in", "neighbour-counts", "fragments+pool0", "aggregation", "linear0", "linear1", "rows-out"]
+        out["fused_phase_us_per_subgraph"] = {nm: float(t[i]) / 100.0 / max(int(t[15]), 1) for i, nm in enumerate(names)}
     print(json.dumps(out))
 
 
