@@ -380,8 +380,8 @@ extern "C" int32_t gcc_ginw_forward(const gcc_ginw_args *g, int32_t *status, gcc
     a.x_in = g->x_in; a.x_out = g->x_out; a.pooled = g->pooled; a.status = status;
     a.batch_size = g->batch_size; a.num_layers = g->num_layers;
     a.ticks = g_ticks;
-    const char *e = getenv("GCC_GINW_LATE_W0");
-    a.late_w0 = e && atoi(e) != 0;
+    const char *late = getenv("GCC_GINW_LATE_W0");
+    a.late_w0 = late && atoi(late) != 0;
     for (int i = 0; i < GCC_GIN_MAX_LAYERS; ++i) {
         a.layers[i] = g->layers[i];
         const gcc_ginw_layer &l = g->layers[i];
