@@ -13,7 +13,6 @@
 // order of each product is chosen to make those 4 values contiguous in the layout the next product reads.)
 // The two LDS regions swap roles: H^T -> AGG in the other -> Z1 over H^T -> H'^T over AGG.
 #include "host_common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -23,7 +22,7 @@ constexpr int kThreads = 512;              // 8 waves, 2 per SIMD: up to 256 VGP
 constexpr int kStrideT = kNodes * 2 + 16;   // bytes per row of the channel-major layout [256 ch][128 nodes] (+16: bank spread)
 constexpr int kStrideN = kD * 2 + 16;       // bytes per row of the node-major layout    [128 nodes][256 ch]
 constexpr int kRegion = kD * kStrideT;      // 69,632 B >= kNodes * kStrideN
-constexpr int kAhead = 3;                   // k-steps the LDS reads of the Linear products run ahead of the matrix instructions
+constexpr int kAhead = 1;                   // k-steps the LDS reads of the Linear products run ahead of the matrix instructions
 constexpr int kLdsBytes = 2 * kRegion + (kNodes + 1 + 3) / 4 * 16;
 static_assert(kNodes * kStrideN <= kRegion, "node-major layout must fit a region");
 static_assert(kD == 256 && kNodes == 128, "the wave tilings below are written for 256 channels x 128 nodes");
@@ -35,8 +34,6 @@ struct WideArgs {
     float *pooled;
     int32_t *status;
     int32_t batch_size, num_layers;
-    int32_t late_w0;                 // tuning knob (env GCC_GINW_LATE_W0=1): fetch the first Linear's weight fragments after the
-                                     // aggregation instead of before it (same results)
     long long *ticks;                // diagnostics (gcc_ginw_debug_ticks): wall-clock ticks per phase, or NULL
     gcc_ginw_layer layers[GCC_GIN_MAX_LAYERS];
 };
@@ -67,24 +64,43 @@ __device__ __forceinline__ float sum4_bf16(u32x2 v)
          + (bf16_bits_to_f32(v[1] & 0xFFFFu) + bf16_bits_to_f32(v[1] >> 16));
 }
 
-// the 16 weight fragments a wave needs for one Linear layer (its 32 output channels x all 256 inputs), issued one
-// product ahead so that the L2 latency is covered by the arithmetic in between
-__device__ __forceinline__ void load_weights(u32x4 (&wf)[2][8], const uint16_t *wmat, int w, int lr, int lg)
+// The 16 weight fragments a wave needs for one Linear layer (its 32 output channels x all 256 inputs) come in two
+// requests so that L2's latency hides behind arithmetic: k-steps 0..3 are requested before the last pass of the product
+// before (into `early`, moved to wf[.][0..3] when that product's own fragments are dead), k-steps 4..7 right after it.
+__device__ __forceinline__ void request_early(u32x4 (&early)[2][4], const uint16_t *wmat, int w, int lr, int lg)
 {
     const uint16_t *wp = wmat + (int64_t)(w * 32 + lr) * kD + lg * 8;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int ks = 0; ks < kD / 32; ++ks) wf[m][ks] = *(const u32x4 *)(wp + m * 16 * kD + ks * 32);
+        for (int ks = 0; ks < 4; ++ks) early[m][ks] = *(const u32x4 *)(wp + m * 16 * kD + ks * 32);
+}
+__device__ __forceinline__ void request_late(u32x4 (&wf)[2][8], const uint16_t *wmat, int w, int lr, int lg)
+{
+    const uint16_t *wp = wmat + (int64_t)(w * 32 + lr) * kD + lg * 8;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ks = 4; ks < 8; ++ks) wf[m][ks] = *(const u32x4 *)(wp + m * 16 * kD + ks * 32);
+}
+__device__ __forceinline__ void adopt_early(u32x4 (&wf)[2][8], const u32x4 (&early)[2][4])
+{
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wf[m][ks] = early[m][ks];
 }
 
 // Z1[node][ch] = relu(s0 * (AGG W0^T) + t0) for the wave's 32 channels and the first 16 * kNB nodes.  No branches
 // inside: the LDS reads of the whole product are scheduled ahead of the matrix instructions that consume them.
 // Rows of padding nodes hold finite leftovers or anything at all; every result depends on its own node's row only.
-template <int kNB>
+template <int kNB, bool kLastPass>
 __device__ __forceinline__ void linear0_tile(const unsigned char *Q, unsigned char *P, u32x4 (&wf)[2][8], const gcc_ginw_layer &ly,
-                                             const uint16_t *wnext, int f0, int w, int lr, int lg)
+                                             const uint16_t *wnext /* last pass: the next product's matrix */, int f0, int w, int lr, int lg)
 {
+    u32x4 early[2][4];
+    if (kLastPass) request_early(early, wnext, w, lr, lg);
+    SCHED_FENCE();
     Q += f0 * 16 * kStrideN;                     // node fragments f0 .. f0 + kNB - 1
     P += f0 * 16 * kStrideN;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -116,7 +132,10 @@ __device__ __forceinline__ void linear0_tile(const unsigned char *Q, unsigned ch
         SCHED_FENCE();
     }
     SCHED_FENCE();                               // (not earlier: the fragments of this product are still in use)
-    if (wnext) load_weights(wf, wnext, w, lr, lg);   // in flight during the epilogue and the barrier
+    if (kLastPass) {
+        adopt_early(wf, early);
+        request_late(wf, wnext, w, lr, lg);      // in flight during the epilogue, the barrier and the first four k-steps
+    }
     SCHED_FENCE();
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -132,10 +151,14 @@ __device__ __forceinline__ void linear0_tile(const unsigned char *Q, unsigned ch
 
 // H'^T[ch][node] = relu(s2 * relu(s1 * (Z1 W1^T) + t1) + t2) for the wave's 32 channels; nodes >= n are written as 0
 // (the aggregation multiplies them by ADJ's zeros, which only works for finite values); SumPooling of the result.
-template <int kNB>
+template <int kNB, bool kLastPass>
 __device__ __forceinline__ void linear1_tile(const unsigned char *P, unsigned char *Q, u32x4 (&wf)[2][8], const gcc_ginw_layer &ly,
-                                             const uint16_t *wnext, float (&pool_part)[2], int n, int f0, int w, int lr, int lg)
+                                             const uint16_t *wnext /* last pass: the next layer's first matrix */, float (&pool_part)[2],
+                                             int n, int f0, int w, int lr, int lg)
 {
+    u32x4 early[2][4];
+    if (kLastPass) request_early(early, wnext, w, lr, lg);
+    SCHED_FENCE();
     P += f0 * 16 * kStrideN;                     // node fragments f0 .. f0 + kNB - 1
     Q += f0 * 32;
     n -= f0 * 16;
@@ -164,7 +187,7 @@ __device__ __forceinline__ void linear1_tile(const unsigned char *P, unsigned ch
         SCHED_FENCE();
     }
     SCHED_FENCE();
-    if (wnext) load_weights(wf, wnext, w, lr, lg);
+    if (kLastPass) adopt_early(wf, early);       // (k-steps 4..7 follow after the aggregation, which needs the registers)
     SCHED_FENCE();
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -253,83 +276,94 @@ __global__ __launch_bounds__(kThreads) void gin_wide_kernel(WideArgs a)
             }
             a.pooled[((int64_t)b * (L + 1)) * kD + tid] = s;
         }
-        // this wave's share of ADJ (its 16 nodes x all neighbours) as B fragments, kept in registers for every layer
-        u32x4 adj[4];
+        // this wave's share of ADJ (32 nodes x all neighbours) as B fragments, kept in registers for every layer
+        const int nblk = w & 3, chalf = w >> 2;              // aggregation: 4 node blocks of 32 x 2 channel halves of 128
+        u32x4 adj[2][4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const u32x4 c = lds16(Q + (w * 16 + lr) * kStrideT + (ks * 32 + lg * 8) * 2);
-            u32x4 f;
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                f[q] = f32_to_bf16_bits((float)(c[q] & 0xFFFFu)) | (f32_to_bf16_bits((float)(c[q] >> 16)) << 16);
-            adj[ks] = f;
-        }
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 c = lds16(Q + (nblk * 32 + nb * 16 + lr) * kStrideT + (ks * 32 + lg * 8) * 2);
+                u32x4 f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    f[q] = f32_to_bf16_bits((float)(c[q] & 0xFFFFu)) | (f32_to_bf16_bits((float)(c[q] >> 16)) << 16);
+                adj[nb][ks] = f;
+            }
         __syncthreads();
         phase_tick(a.ticks, 2, tick);                        // input pooling, adjacency fragments
-        const int ksn = (n + 31) >> 5, nfrag = (n + 15) >> 4;
+        const int nfrag = (n + 15) >> 4;
         u32x4 wf[2][8];
-        if (L > 0 && !a.late_w0) load_weights(wf, a.layers[0].w0, w, lr, lg);
+        {
+            u32x4 early[2][4];
+            request_early(early, a.layers[0].w0, w, lr, lg);
+            adopt_early(wf, early);
+        }
 
         for (int layer = 0; layer < L; ++layer) {
             const gcc_ginw_layer ly = a.layers[layer];
-            // ---- AGG[node][ch] -> Q (node-major); wave w: nodes 16w .. 16w+15, all channels
-            if (w * 16 < n) {
-                f32x4 acc[16];
+            // ---- AGG[node][ch] -> Q (node-major); wave w: 32 nodes x 128 channels (every LDS fragment feeds two matrix
+            // instructions); afterwards the first Linear's weight fragments are requested: they travel during the epilogue
+            // and the barrier (an LDS-only barrier: __syncthreads() would wait for them)
+            {
+                // (no branches on the subgraph's size in here -- data-dependent branches around blocks of matrix instructions
+                // make the register allocator spill hundreds of values; rows and columns of padding nodes are zeros anyway)
+                f32x4 acc[8][2];
 #pragma unroll
-                for (int m = 0; m < 16; ++m) acc[m] = zero4;
-                const unsigned char *src = P + lr * kStrideT + lg * 16;
-                u32x4 ring[3][4];                            // quarter k-steps (4 channel blocks each), two ahead
-                const int nstep = 4 * ksn;
+                for (int m = 0; m < 8; ++m) { acc[m][0] = zero4; acc[m][1] = zero4; }
+                const unsigned char *src = P + (chalf * 128 + lr) * kStrideT + lg * 16;
+                u32x4 ring[3][4];                            // half k-steps (4 channel blocks each), two ahead
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) ring[j][m] = lds16(src + ((j & 3) * 4 + m) * 16 * kStrideT + (j >> 2) * 64);
+                    for (int m = 0; m < 4; ++m) ring[j][m] = lds16(src + ((j & 1) * 4 + m) * 16 * kStrideT + (j >> 1) * 64);
 #pragma unroll
-                for (int step = 0; step < 16; ++step) {      // step = 4 * ks + quarter
-                    if (step < nstep) {
-                        if (step + 2 < nstep) {
-#pragma unroll
-                            for (int m = 0; m < 4; ++m)
-                                ring[(step + 2) % 3][m] = lds16(src + (((step + 2) & 3) * 4 + m) * 16 * kStrideT + ((step + 2) >> 2) * 64);
-                        }
-                        SCHED_FENCE();
+                for (int step = 0; step < 8; ++step) {       // step = 2 * ks + half
+                    if (step + 2 < 8) {
 #pragma unroll
                         for (int m = 0; m < 4; ++m)
-                            acc[(step & 3) * 4 + m] = mfma_16x16x32_bf16(ring[step % 3][m], adj[step >> 2], acc[(step & 3) * 4 + m]);
-                        SCHED_FENCE();
+                            ring[(step + 2) % 3][m] = lds16(src + (((step + 2) & 1) * 4 + m) * 16 * kStrideT + ((step + 2) >> 1) * 64);
                     }
-                }
+                    SCHED_FENCE();
 #pragma unroll
-                for (int m = 0; m < 16; ++m)
-                    *(u32x2 *)(Q + (w * 16 + lr) * kStrideN + (m * 16 + lg * 4) * 2) = pack4_bf16(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
-            }
-            if (a.late_w0) {
+                    for (int m = 0; m < 4; ++m) {
+                        acc[(step & 1) * 4 + m][0] = mfma_16x16x32_bf16(ring[step % 3][m], adj[0][step >> 1], acc[(step & 1) * 4 + m][0]);
+                        acc[(step & 1) * 4 + m][1] = mfma_16x16x32_bf16(ring[step % 3][m], adj[1][step >> 1], acc[(step & 1) * 4 + m][1]);
+                    }
+                    SCHED_FENCE();
+                }
+                request_late(wf, ly.w0, w, lr, lg);
                 SCHED_FENCE();
-                load_weights(wf, ly.w0, w, lr, lg);
-                SCHED_FENCE();
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        *(u32x2 *)(Q + (nblk * 32 + nb * 16 + lr) * kStrideN + (chalf * 128 + m * 16 + lg * 4) * 2) =
+                            pack4_bf16(acc[m][nb][0], acc[m][nb][1], acc[m][nb][2], acc[m][nb][3]);
             }
-            __syncthreads();
+            lds_barrier();
             phase_tick(a.ticks, 3, tick);                    // aggregation
             // ---- Z1[node][ch] = relu(s0 * (AGG W0^T) + t0) -> P (node-major); wave w: channels 32w .. 32w+31, all nodes
             // (two passes over at most 4 node fragments each: 32 accumulator registers at a time, the weights stay)
             if (nfrag > 4) {
-                linear0_tile<4>(Q, P, wf, ly, nullptr, 0, w, lr, lg);
-                if (nfrag > 6) linear0_tile<4>(Q, P, wf, ly, ly.w1, 4, w, lr, lg);
-                else linear0_tile<2>(Q, P, wf, ly, ly.w1, 4, w, lr, lg);
-            } else if (nfrag > 2) linear0_tile<4>(Q, P, wf, ly, ly.w1, 0, w, lr, lg);
-            else linear0_tile<2>(Q, P, wf, ly, ly.w1, 0, w, lr, lg);
-            __syncthreads();
+                linear0_tile<4, false>(Q, P, wf, ly, nullptr, 0, w, lr, lg);
+                if (nfrag > 6) linear0_tile<4, true>(Q, P, wf, ly, ly.w1, 4, w, lr, lg);
+                else linear0_tile<2, true>(Q, P, wf, ly, ly.w1, 4, w, lr, lg);
+            } else if (nfrag > 2) linear0_tile<4, true>(Q, P, wf, ly, ly.w1, 0, w, lr, lg);
+            else linear0_tile<2, true>(Q, P, wf, ly, ly.w1, 0, w, lr, lg);
+            lds_barrier();
             phase_tick(a.ticks, 4, tick);                    // first Linear
             // ---- H'^T[ch][node] = relu(s2 * relu(s1 * (Z1 W1^T) + t1) + t2) -> Q (channel-major); wave w: channels 32w .. 32w+31, all nodes
             {
-                const uint16_t *wnext = (layer + 1 < L && !a.late_w0) ? a.layers[layer + 1].w0 : nullptr;
+                // (after the last layer the request is a dummy: no branch around it, see the note on branches below)
+                const uint16_t *wnext = a.layers[layer + 1 < L ? layer + 1 : layer].w0;
                 float pool_part[2] = {0.f, 0.f};
                 if (nfrag > 4) {
-                    linear1_tile<4>(P, Q, wf, ly, nullptr, pool_part, n, 0, w, lr, lg);
-                    if (nfrag > 6) linear1_tile<4>(P, Q, wf, ly, wnext, pool_part, n, 4, w, lr, lg);
-                    else linear1_tile<2>(P, Q, wf, ly, wnext, pool_part, n, 4, w, lr, lg);
-                } else if (nfrag > 2) linear1_tile<4>(P, Q, wf, ly, wnext, pool_part, n, 0, w, lr, lg);
-                else linear1_tile<2>(P, Q, wf, ly, wnext, pool_part, n, 0, w, lr, lg);
+                    linear1_tile<4, false>(P, Q, wf, ly, nullptr, pool_part, n, 0, w, lr, lg);
+                    if (nfrag > 6) linear1_tile<4, true>(P, Q, wf, ly, wnext, pool_part, n, 4, w, lr, lg);
+                    else linear1_tile<2, true>(P, Q, wf, ly, wnext, pool_part, n, 4, w, lr, lg);
+                } else if (nfrag > 2) linear1_tile<4, true>(P, Q, wf, ly, wnext, pool_part, n, 0, w, lr, lg);
+                else linear1_tile<2, true>(P, Q, wf, ly, wnext, pool_part, n, 0, w, lr, lg);
                 // node fragments past the last one computed: zeros (read by the next aggregation as multiplicands of 0)
                 const int fdone = nfrag > 6 ? 8 : nfrag > 4 ? 6 : nfrag > 2 ? 4 : 2;
                 for (int i = lane; i < 32 * (8 - fdone) * 4; i += 64) {
@@ -342,7 +376,7 @@ __global__ __launch_bounds__(kThreads) void gin_wide_kernel(WideArgs a)
                     pool[16] = pool_part[1];
                 }
             }
-            __syncthreads();
+            lds_barrier();
             phase_tick(a.ticks, 5, tick);                    // second Linear
             unsigned char *t = P; P = Q; Q = t;
         }
@@ -370,7 +404,7 @@ extern "C" void gcc_ginw_debug_ticks(long long *device_ticks64) { g_ticks = devi
 
 extern "C" int32_t gcc_ginw_forward(const gcc_ginw_args *g, int32_t *status, gcc_prof *prof, void *stream)
 {
-    if (!g || !status || !g->node_off || !g->row_ptr || !g->col_idx || !g->x_in || g->batch_size < 1 || g->num_layers < 0 ||
+    if (!g || !status || !g->node_off || !g->row_ptr || !g->col_idx || !g->x_in || g->batch_size < 1 || g->num_layers < 1 ||
         g->num_layers > GCC_GIN_MAX_LAYERS || (!g->x_out && !g->pooled)) {
         snprintf(g_err, kErrLen, "gcc_ginw_forward: bad argument");
         return -1;
@@ -380,8 +414,6 @@ extern "C" int32_t gcc_ginw_forward(const gcc_ginw_args *g, int32_t *status, gcc
     a.x_in = g->x_in; a.x_out = g->x_out; a.pooled = g->pooled; a.status = status;
     a.batch_size = g->batch_size; a.num_layers = g->num_layers;
     a.ticks = g_ticks;
-    const char *late = getenv("GCC_GINW_LATE_W0");
-    a.late_w0 = late && atoi(late) != 0;
     for (int i = 0; i < GCC_GIN_MAX_LAYERS; ++i) {
         a.layers[i] = g->layers[i];
         const gcc_ginw_layer &l = g->layers[i];

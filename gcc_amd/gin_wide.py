@@ -30,8 +30,8 @@ class FoldedWideGIN:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("gcc_amd kernels run on the GPU only; there is no CPU path")
-        if not 0 <= len(layers) <= 8:
-            raise ValueError("at most 8 layers")
+        if not 1 <= len(layers) <= 8:
+            raise ValueError("1 to 8 layers")
         self.lib = _cabi.load()
         self.layers = []
         for ly in layers:
@@ -69,7 +69,7 @@ class FoldedWideGIN:
         of v, global ids).  Runs layers first_layer .. first_layer + num_layers - 1 in one launch.  Returns (rows bf16 [N, 256] or None, pooled f32 [B, L + 1, 256] or None); call
         ``check_status()`` after synchronising."""
         L = len(self.layers) - first_layer if num_layers is None else int(num_layers)
-        if not (0 <= first_layer and 0 <= L and first_layer + L <= len(self.layers)):
+        if not (0 <= first_layer and 1 <= L and first_layer + L <= len(self.layers)):
             raise ValueError("layer range out of bounds")
         if x.dtype != torch.bfloat16 or x.dim() != 2 or x.shape[1] != HIDDEN:
             raise TypeError(f"x must be bfloat16 [N, {HIDDEN}]")

@@ -290,7 +290,7 @@ typedef struct gcc_ginw_args {
     const uint16_t *x_in;                /* device [N, 256] bf16                                                 */
     uint16_t *x_out;                     /* device [N, 256] bf16 output of the last layer, or NULL               */
     float *pooled;                       /* device [B, num_layers + 1, 256] or NULL                              */
-    int32_t batch_size, num_layers;      /* num_layers <= GCC_GIN_MAX_LAYERS                                     */
+    int32_t batch_size, num_layers;      /* 1 <= num_layers <= GCC_GIN_MAX_LAYERS                                */
     gcc_ginw_layer layers[GCC_GIN_MAX_LAYERS];
 } gcc_ginw_args;
 /* status: device int32[1], OR of GCC_STATUS_GINW_* (zeroed by the caller).  prof marks: 0 before, 1 after. */

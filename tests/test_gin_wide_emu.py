@@ -118,19 +118,23 @@ def test_emulated_kernel_matches_the_oracle(sizes, deg, L):
     assert rel_err(got, truth) < 2e-2
 
 
-def test_input_pooling_layers_zero_and_refusals():
+def test_input_pooling_and_refusals():
     rng = np.random.default_rng(7)
+    layers = random_layers(rng, 1)
     node_off, row_ptr, col_idx = random_batch(rng, [20, 130], 4)
     N = int(node_off[-1])
     x = ow.bf16_round(rng.standard_normal((N, D)).astype(np.float32))
-    rows, pooled, status = emu_ginw_forward(node_off, row_ptr, col_idx, ow.to_bf16_bits(x), [])
+    rows, pooled, status = emu_ginw_forward(node_off, row_ptr, col_idx, ow.to_bf16_bits(x), bits_layers(layers))
     assert status == 32                                     # the 130-node subgraph is refused, loudly
-    np.testing.assert_array_equal(rows[:20], ow.to_bf16_bits(x)[:20])     # zero layers: rows pass through LDS unchanged
     assert not rows[20:].any() and not pooled[1].any()
     np.testing.assert_allclose(pooled[0, 0], x[:20].astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
+    want_rows, _ = ow.gin_wide_forward(node_off[:2], row_ptr[:21], col_idx[:row_ptr[20]], x[:20], layers, bf16=True)
+    assert rel_err(ow.from_bf16_bits(rows[:20]), want_rows) < 2e-3
     # a neighbour outside its subgraph is skipped and flagged
     node_off, row_ptr, col_idx = random_batch(rng, [6, 6], 2)
     col_idx = col_idx.copy()
     col_idx[0] = 9
-    _, _, status = emu_ginw_forward(node_off, row_ptr, col_idx, ow.to_bf16_bits(x[:12]), [])
+    _, _, status = emu_ginw_forward(node_off, row_ptr, col_idx, ow.to_bf16_bits(x[:12]), bits_layers(layers))
     assert status == 64
+    with pytest.raises(RuntimeError):                       # at least one layer
+        emu_ginw_forward(node_off, row_ptr, col_idx, ow.to_bf16_bits(x[:12]), [])
