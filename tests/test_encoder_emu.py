@@ -2,7 +2,6 @@
 the wave64 emulator vs the reference-generated golden vectors and the oracle."""
 import os
 
-import pytest
 import torch
 
 from oracle import encoder as E

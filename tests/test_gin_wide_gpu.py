@@ -57,3 +57,42 @@ def test_layerwise_launches_equal_the_fused_launch():
     b, pb, _ = _run(sizes, 32, 4, seed=3, split=1)
     np.testing.assert_array_equal(a, b)                  # rows are bf16 in LDS exactly as in HBM
     np.testing.assert_array_equal(pa, pb)
+
+
+def test_config5_full_size_properties():
+    """BASELINE configs[4] at full size (4096 subgraphs x 128 nodes, 32 in-neighbours each, 8 layers): too large for the
+    oracle in seconds, so size-independent properties: one-layer launches == the fused launch bit for bit, the pooled
+    output is the per-subgraph sum of the rows, a permutation of the subgraphs permutes the results."""
+    from gcc_amd.gin_wide import FoldedWideGIN
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    B, n, deg, L = 4096, 128, 32, 8
+    N = B * n
+    rng = np.random.default_rng(5)
+    net = FoldedWideGIN([{k: torch.from_numpy(v) for k, v in ly.items()} for ly in random_layers(rng, L)], dev)
+    node_off = (torch.arange(B + 1, dtype=torch.int32) * n).to(dev)
+    row_ptr = (torch.arange(N + 1, dtype=torch.int32) * deg).to(dev)
+    local = torch.randint(0, n, (N, deg), generator=g, dtype=torch.int32)
+    base = (torch.arange(N, dtype=torch.int32) // n * n).unsqueeze(1)
+    col_idx = (local + base).reshape(-1).contiguous().to(dev)
+    x = torch.randn(N, D, generator=g).to(dev).to(torch.bfloat16)
+    rows, pooled = net.forward(node_off, row_ptr, col_idx, x)
+    step = x
+    for i in range(L):
+        step, _ = net.forward(node_off, row_ptr, col_idx, step, num_layers=1, first_layer=i)
+    torch.cuda.synchronize()
+    assert net.check_status() == 0
+    assert torch.equal(rows, step)
+    assert bool(torch.isfinite(pooled).all()) and float(rows.float().abs().max()) > 0
+    sums = rows.float().view(B, n, D).sum(1)
+    assert float((pooled[:, -1] - sums).abs().max()) <= 1e-3 * float(sums.abs().max())
+    # subgraphs are independent: reversing their order reverses the results and changes nothing else
+    perm = torch.arange(B - 1, -1, -1, device=dev)
+    xp = x.view(B, n, D)[perm].reshape(N, D).contiguous()
+    localp = local.view(B, n, deg)[perm.cpu()].reshape(N, deg)
+    colp = (localp + base).reshape(-1).contiguous().to(dev)
+    rows_p, pooled_p = net.forward(node_off, row_ptr, colp, xp)
+    torch.cuda.synchronize()
+    assert torch.equal(rows_p.view(B, n, D)[perm].reshape(N, D), rows)
+    assert torch.equal(pooled_p[perm], pooled)

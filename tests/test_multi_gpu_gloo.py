@@ -7,7 +7,6 @@ different seed-batch shards; checks the RCCL-side contract of SURVEY.md §8(e):
 import os
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

@@ -11,7 +11,6 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-import numpy as np
 import torch
 
 from gcc_amd.gin_wide import FoldedWideGIN

@@ -1,6 +1,5 @@
 """Per-phase wall-clock ticks of the positional-embedding solver classes on a real sampled chunk (isolated GPU)."""
 import sys
-import numpy as np
 import torch
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
