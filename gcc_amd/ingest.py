@@ -6,7 +6,12 @@ inserts every pair in both directions (data_util.py:84-85) and its dataset class
 (graph_dataset.py:301-302), so its DGL graph is a multigraph in which every undirected edge of the file exists
 ``2 x (times the pair is listed, in either order)`` times per direction.  The HIP path keeps a simple CSR plus ONE
 uniform multiplicity (gcc_gin_pass.edge_multiplicity); files whose pairs repeat a non-uniform number of times, and self
-loops, are rejected rather than approximated."""
+loops, are rejected rather than approximated.
+
+``read_tudataset``: the raw TU Dortmund collection layout (``<NAME>_A.txt``, ``<NAME>_graph_indicator.txt``,
+``<NAME>_graph_labels.txt``) that DGL's ``TUDataset`` downloads for ``create_graph_classification_dataset``
+(data_util.py:47-58: imdb-binary, imdb-multi, rdt-b, rdt-5k, collab) -> the list of small graphs
+``GraphClassificationDataset(graphs=...)`` takes, plus the graph labels."""
 from __future__ import annotations
 
 import numpy as np
@@ -67,3 +72,52 @@ def read_edgelist(edgelist_path: str, nodelabel_path: str = None, hindex: bool =
         y[nodes, labels] = 1
         out["y"] = y
     return out
+
+
+TU_NAMES = {"imdb-binary": "IMDB-BINARY", "imdb-multi": "IMDB-MULTI", "rdt-b": "REDDIT-BINARY",
+            "rdt-5k": "REDDIT-MULTI-5K", "collab": "COLLAB"}                      # data_util.py:48-54
+
+
+def read_tudataset(folder: str, name: str):
+    """-> dict(graphs=[(row_ptr, col_idx), ...], graph_labels int64 [G], num_labels).  ``name`` is the reference's
+    dataset name (``imdb-binary`` ...) or the TU name itself.  Nodes of a graph keep their file order (DGL builds each
+    graph as the subgraph of its ascending node ids); labels are re-indexed 0..C-1 in ascending order of the file's
+    values, as DGL's TUDataset does.  The adjacency must be symmetric without self loops or repeated entries."""
+    import os
+
+    tu = TU_NAMES.get(name, name)
+    base = os.path.join(folder, tu + "_")
+    edges = np.loadtxt(base + "A.txt", delimiter=",", dtype=np.int64, ndmin=2) - 1
+    indicator = np.loadtxt(base + "graph_indicator.txt", dtype=np.int64, ndmin=1)
+    labels = np.loadtxt(base + "graph_labels.txt", dtype=np.int64, ndmin=1)
+    num_nodes = len(indicator)
+    if (np.diff(indicator) < 0).any():
+        raise ValueError("graph_indicator must be non-decreasing (nodes of a graph are contiguous in the TU format)")
+    gids, first = np.unique(indicator, return_index=True)
+    if len(gids) != len(labels):
+        raise ValueError(f"{len(gids)} graphs in graph_indicator but {len(labels)} graph labels")
+    src, dst = edges[:, 0], edges[:, 1]
+    if len(src) and (min(src.min(), dst.min()) < 0 or max(src.max(), dst.max()) >= num_nodes):
+        raise ValueError("node id out of range in A.txt")
+    if (src == dst).any():
+        raise ValueError("self loops are not supported by the sampler contract (x2dgl.py:41-42 removes them)")
+    if (indicator[src] != indicator[dst]).any():
+        raise ValueError("an edge connects two different graphs")
+    key = src * num_nodes + dst
+    if len(np.unique(key)) != len(key):
+        raise ValueError("repeated adjacency entries: a general multigraph is not supported")
+    if not np.array_equal(np.sort(key), np.sort(dst * num_nodes + src)):
+        raise ValueError("the adjacency is not symmetric")
+    order = np.lexsort((dst, src))
+    src, dst = src[order], dst[order]
+    row_ptr = np.zeros(num_nodes + 1, dtype=np.int64)
+    np.add.at(row_ptr, src + 1, 1)
+    row_ptr = np.cumsum(row_ptr)
+    bounds = np.append(first, num_nodes)
+    graphs = []
+    for g in range(len(gids)):
+        lo, hi = int(bounds[g]), int(bounds[g + 1])
+        rp = row_ptr[lo:hi + 1] - row_ptr[lo]
+        graphs.append((rp.astype(np.int32), (dst[row_ptr[lo]:row_ptr[hi]] - lo).astype(np.int32)))
+    values = np.unique(labels)
+    return dict(graphs=graphs, graph_labels=np.searchsorted(values, labels).astype(np.int64), num_labels=len(values))

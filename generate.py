@@ -5,7 +5,7 @@ node of a graph as (f(q) + f(k)) / 2 over its two RWR views with the eval-mode e
 ``data/<name>/<name>.edgelist`` format, gcc/datasets/data_util.py:61-110) or ``--graph-npz`` (row_ptr/col_idx);
 everything runs on the GPU (sampler, positional embedding, encoder).
 
-Extra flags (not in the reference): --edgelist / --nodelabel / --graph-npz / --graphs-npz / --edge-multiplicity /
+Extra flags (not in the reference): --edgelist / --nodelabel / --graph-npz / --graphs-npz / --tudataset / --edge-multiplicity /
 --batch-size.  Graph-classification datasets (entire_graph=True, generate.py:75-82) come as ``--graphs-npz``: node_off
 [G+1], row_ptr [N+1] (per-graph offsets restarting at 0 are rebuilt from node_off), col_idx (local ids)."""
 import argparse
@@ -36,7 +36,10 @@ def main(args_test):
     torch.cuda.set_device(args.device)
 
     graphs = None
-    if args_test.graphs_npz:
+    if args_test.tudataset:
+        graphs = ingest.read_tudataset(args_test.tudataset, args_test.dataset)["graphs"]
+        graph, mult = None, max(args_test.edge_multiplicity, 1)
+    elif args_test.graphs_npz:
         z = np.load(args_test.graphs_npz)
         no, rp, ci = z["node_off"].astype(np.int64), z["row_ptr"].astype(np.int64), z["col_idx"].astype(np.int64)
         graphs = [(rp[no[i]:no[i + 1] + 1] - rp[no[i]], ci[rp[no[i]]:rp[no[i + 1]]]) for i in range(len(no) - 1)]
@@ -48,7 +51,7 @@ def main(args_test):
         z = np.load(args_test.graph_npz)
         graph, mult = (z["row_ptr"], z["col_idx"]), args_test.edge_multiplicity
     else:
-        raise SystemExit("pass --edgelist data/<name>/<name>.edgelist, --graph-npz or --graphs-npz (dataset files are not bundled)")
+        raise SystemExit("pass --edgelist data/<name>/<name>.edgelist, --graph-npz, --graphs-npz or --tudataset (dataset files are not bundled)")
     if args_test.edge_multiplicity:
         mult = args_test.edge_multiplicity
     if graphs is not None:
@@ -96,6 +99,7 @@ if __name__ == "__main__":
     parser.add_argument("--nodelabel", type=str, default=None, help="<name>.nodelabel (only read to validate the node set)")
     parser.add_argument("--graph-npz", type=str, default=None, help="npz with row_ptr/col_idx of the simple symmetric graph")
     parser.add_argument("--graphs-npz", type=str, default=None, help="npz with node_off/row_ptr/col_idx of a list of small graphs (graph classification)")
+    parser.add_argument("--tudataset", type=str, default=None, help="folder with the raw TU files <NAME>_A.txt, <NAME>_graph_indicator.txt, <NAME>_graph_labels.txt of --dataset (imdb-binary, imdb-multi, rdt-b, rdt-5k, collab)")
     parser.add_argument("--edge-multiplicity", type=int, default=0, help="copies of every edge in the reference's DGL graph (edge lists: detected; npz: default 2)")
     parser.add_argument("--batch-size", type=int, default=256)
     # fmt: on

@@ -211,3 +211,33 @@ def test_graph_classification_dataset_whole_graphs_and_seed_flag():
                    seed_local=g.seed_local.long()).detach()
         ref.append(f[: g.valid])
     torch.testing.assert_close(emb, torch.cat(ref), rtol=1e-4, atol=2e-5)
+
+
+def test_tudataset_reader(tmp_path):
+    """raw TU layout -> per-graph CSR in file node order, labels re-indexed in ascending order; malformed input refused"""
+    from gcc_amd import ingest
+
+    # graph 1: path 1-2-3 (nodes 1..3), graph 2: triangle 4-5-6 plus pendant 7, graph 3: single edge 8-9; labels -1, 1, -1
+    und = [(1, 2), (2, 3), (4, 5), (5, 6), (4, 6), (6, 7), (8, 9)]
+    lines = [f"{u}, {v}" for u, v in und] + [f"{v}, {u}" for u, v in und]
+    rng = np.random.default_rng(0)
+    rng.shuffle(lines)
+    (tmp_path / "IMDB-BINARY_A.txt").write_text("\n".join(lines) + "\n")
+    (tmp_path / "IMDB-BINARY_graph_indicator.txt").write_text("\n".join(map(str, [1, 1, 1, 2, 2, 2, 2, 3, 3])) + "\n")
+    (tmp_path / "IMDB-BINARY_graph_labels.txt").write_text("-1\n1\n-1\n")
+    d = ingest.read_tudataset(str(tmp_path), "imdb-binary")
+    assert d["num_labels"] == 2 and d["graph_labels"].tolist() == [0, 1, 0]
+    want = [([0, 1, 3, 4], [1, 0, 2, 1]), ([0, 2, 4, 7, 8], [1, 2, 0, 2, 0, 1, 3, 2]), ([0, 1, 2], [1, 0])]
+    assert len(d["graphs"]) == 3
+    for (rp, ci), (wrp, wci) in zip(d["graphs"], want):
+        assert rp.tolist() == wrp and ci.tolist() == wci and rp.dtype == np.int32
+    # malformed files are refused, not repaired
+    (tmp_path / "IMDB-BINARY_A.txt").write_text("\n".join(lines[:-1]) + "\n")
+    with pytest.raises(ValueError, match="symmetric"):
+        ingest.read_tudataset(str(tmp_path), "IMDB-BINARY")
+    (tmp_path / "IMDB-BINARY_A.txt").write_text("\n".join(lines + ["3, 4", "4, 3"]) + "\n")
+    with pytest.raises(ValueError, match="different graphs"):
+        ingest.read_tudataset(str(tmp_path), "imdb-binary")
+    (tmp_path / "IMDB-BINARY_A.txt").write_text("\n".join(lines + ["1, 2"]) + "\n")
+    with pytest.raises(ValueError, match="repeated"):
+        ingest.read_tudataset(str(tmp_path), "imdb-binary")
