@@ -138,3 +138,31 @@ def test_input_pooling_and_refusals():
     assert status == 64
     with pytest.raises(RuntimeError):                       # at least one layer
         emu_ginw_forward(node_off, row_ptr, col_idx, ow.to_bf16_bits(x[:12]), [])
+
+
+def test_host_side_folding_equals_the_oracle_folding():
+    """gcc_amd.gin_wide.fold_bn (what FoldedWideGIN.from_gin applies to a module with the reference's attribute names)
+    == oracle/gin_wide.fold_layer; the product refuses to run without a GPU"""
+    from gcc_amd.gin_wide import FoldedWideGIN, fold_bn
+
+    torch.manual_seed(1)
+    gin = _GIN(2, D, D, D).eval()
+    with torch.no_grad():
+        for m in gin.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.uniform_(-0.5, 0.5)
+                m.running_var.uniform_(0.5, 2.0)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.4)
+    layer = gin.ginlayers[0]
+    mlp = layer.apply_func.mlp
+    bn = lambda m: (m.weight.detach().numpy(), m.bias.detach().numpy(), m.running_mean.numpy(), m.running_var.numpy())
+    want = ow.fold_layer(mlp.linears[0].weight.detach().numpy(), mlp.linears[0].bias.detach().numpy(), bn(mlp.batch_norms[0]),
+                         mlp.linears[1].weight.detach().numpy(), mlp.linears[1].bias.detach().numpy(), bn(layer.apply_func.bn),
+                         bn(gin.batch_norms[0]))
+    for (s, t), (ks, kt) in zip((fold_bn(mlp.batch_norms[0], mlp.linears[0].bias), fold_bn(layer.apply_func.bn, mlp.linears[1].bias),
+                                 fold_bn(gin.batch_norms[0])), (("s0", "t0"), ("s1", "t1"), ("s2", "t2"))):
+        np.testing.assert_allclose(s.numpy(), want[ks], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(t.numpy(), want[kt], rtol=1e-6, atol=1e-7)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        FoldedWideGIN.from_gin(gin, "cpu")
