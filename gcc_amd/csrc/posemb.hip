@@ -84,6 +84,11 @@ constexpr float kSep = 2e-6f;        // minimum distance between two inverse-ite
 constexpr float kPivTiny = 1.2e-7f;  // pivots of T - shift are clamped to eps * ||T||  (||T|| <= 1)
 constexpr int kGMax = GCC_POSEMB_DIRECT_MAX;   // largest deflated size of the workspace-resident class
 constexpr int kGLds = 128 * 1024;    // dynamic LDS of that class (of 160 KiB per CU)
+constexpr int kBMax = GCC_POSEMB_BIG_MAX;      // second workspace-resident class: kGMax < n' <= kBMax (hub seeds; a handful per
+                                               // batch view at rw_hops 256 on a 1M-node power-law graph) -- exact multiplicities
+                                               // (1/sqrt(2) occurs 30+ times in such ego-nets) are beyond a single-vector Krylov
+                                               // iteration, ARPACK included
+constexpr int kBLds = 160 * 1024 - 2048;       // its dynamic LDS: the whole CU minus the kernel's static __shared__ objects
 
 __device__ __forceinline__ void item_args(const PosMulti &m, int item, PosArgs &a, int &b)
 {
@@ -100,12 +105,14 @@ __device__ __forceinline__ void item_args(const PosMulti &m, int item, PosArgs &
 // solver kernel is launched with a SMALL fixed grid whose workgroups pull items from their class list.  (A grid of
 // one fat workgroup per subgraph that exits early when the class does not match keeps the workgroup dispatcher
 // busy placing 160-KiB-LDS / 1024-thread workgroups that do nothing, which delays every other queue.)
-enum { kClsSmall = 0, kClsMid = 1, kClsSlot = 2, kClsKrylov = 3, kNumCls = 4 };
+enum { kClsSmall = 0, kClsMid = 1, kClsSlot = 2, kClsKrylov = 3, kClsBig = 4, kNumCls = 5 };
 struct PosHead {                     // head of the caller's workspace (zeroed per call)
     int32_t *count;                  // [4] items per class
     int32_t *next;                   // [4] work counters
     int32_t *list;                   // [4][T] item ids, T = views * B
     float *slots;                    // [workgroups of the slot class][slot_floats]: matrix (kGMax x kGMax) + deflation tables
+    float *bslots;                   // [workgroups of the big class][bslot_floats]: matrix (kBMax x kBMax) + deflation tables
+    int64_t bslot_floats;
     float *tabs;                     // [workgroups of the mid class, then of the small class][kNodeMax * 4]: deflation tables
     int32_t tabs_small_off;          // first small-class table (= workgroups of the mid class)
     int32_t T;
@@ -120,7 +127,7 @@ template <int kNMax> __host__ __device__ constexpr bool tables_in_workspace() { 
 template <int kNMax, int kT, bool kGlobalA>
 __host__ __device__ constexpr int direct_lds_bytes()
 {
-    return kGlobalA ? kGLds
+    return kGlobalA ? (kNMax > kGMax ? kBLds : kGLds)
                     : (int)(sizeof(float) * (6 * kNMax + 32 * kYld + kT + kNMax * (kNMax + 1) + kNMax * kYld)
                             + (tables_in_workspace<kNMax>() ? 0 : kNodeMax * 16) + kNMax * (33 * 8 + 32));
 }
@@ -685,7 +692,7 @@ __global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m
         for (int i = lane; i < n; i += 64) zz += t[i] >= 2 ? t[i] - 1 : 0;
         for (int dd = 32; dd >= 1; dd >>= 1) zz += wave_shfl_xor(zz, dd);
         const int nr = n - zz;                         // t >= 2 leaves of one parent count once
-        cls = nr <= kJSmall ? kClsSmall : nr <= kJMax ? kClsMid : nr <= kGMax ? kClsSlot : kClsKrylov;
+        cls = nr <= kJSmall ? kClsSmall : nr <= kJMax ? kClsMid : nr <= kGMax ? kClsSlot : nr <= kBMax ? kClsBig : kClsKrylov;
     }
     if (cls == kClsKrylov && n >= hd.ldv) {          // no room: the caller's node_cap / batch_size must bound every subgraph
         for (int i = lane; i < n * a.hidden; i += 64) a.pos[(int64_t)n0 * a.hidden + i] = 0.f;
@@ -788,12 +795,15 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     __syncthreads();
     const int nr = sh_np, z = sh_z;                // reduced size n', number of contrast null vectors
     if (nr > kNMax || nr < kNMin) continue;        // cannot happen: the classify kernel computed the same size
-    if (kGlobalA) A = hd.slots + (int64_t)blockIdx.x * hd.slot_floats;   // the workgroup's own slot
+    if (kGlobalA) A = kCls == kClsBig ? hd.bslots + (int64_t)blockIdx.x * hd.bslot_floats
+                                      : hd.slots + (int64_t)blockIdx.x * hd.slot_floats;   // the workgroup's own slot
     // ---- rest of the carve-up: eigenvectors and as many LU slots as fit
     w.Y = lds_rest;
     w.ldy = kYld;
     {
         constexpr int lds_total = direct_lds_bytes<kNMax, kT, kGlobalA>();
+        static_assert(!kGlobalA || (int)sizeof(float) * (6 * kNMax + 32 * kYld + kT + kNMax * kYld) + kNMax * (5 * 8 + 4) <= lds_total,
+                      "eigenvectors + the narrowest LU batch must fit");
         const int used = (int)((unsigned char *)(w.Y + nr * kYld) - smem);
         const int left = lds_total - used;
         int bw = 32;
@@ -1267,29 +1277,31 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
 extern "C" {
 
 static long long *g_posemb_ticks = nullptr;
-struct PosGrids { int32_t small, mid, slot, kry; };
+struct PosGrids { int32_t small, mid, slot, kry, big; };
 static PosGrids posemb_grids(int64_t T)
 {
     // fixed grids: enough workgroups for the typical class sizes (~73 % / 19 % / 6 % / 2 % of a batch at rw_hops 256);
     // larger classes loop.  No class may cover more than half of the 256 CUs (small: 2 workgroups per CU): a solver
     // workgroup holds most of a CU's LDS for milliseconds, and when every CU has one the training step's kernels whose
     // workgroups do not fit beside it wait for the whole launch to drain (3-5 ms stalls in the kernel trace).
-    static int caps[4] = {0, 0, 0, 0};
-    if (caps[0] == 0) {                              // tuning knob: GCC_POSEMB_GRID_CAPS="small,mid,slot,krylov"
-        int c[4] = {256, 128, 128, 64};
+    static int caps[5] = {0, 0, 0, 0, 0};
+    if (caps[0] == 0) {                              // tuning knob: GCC_POSEMB_GRID_CAPS="small,mid,slot,krylov,big"
+        int c[5] = {256, 128, 128, 64, 64};
         const char *e = getenv("GCC_POSEMB_GRID_CAPS");
-        if (e) (void)sscanf(e, "%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3]);
-        for (int i = 0; i < 4; ++i) caps[i] = c[i] < 1 ? 1 : c[i];
+        if (e) (void)sscanf(e, "%d,%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3], &c[4]);
+        for (int i = 0; i < 5; ++i) caps[i] = c[i] < 1 ? 1 : c[i];
     }
     PosGrids g;
     g.small = (int32_t)(T < caps[0] ? T : caps[0]);
     g.mid = (int32_t)((T + 3) / 4 < caps[1] ? (T + 3) / 4 : caps[1]);
     g.slot = (int32_t)((T + 7) / 8 < caps[2] ? (T + 7) / 8 : caps[2]);
     g.kry = (int32_t)((T + 15) / 16 < caps[3] ? (T + 15) / 16 : caps[3]);
+    g.big = (int32_t)((T + 15) / 16 < caps[4] ? (T + 15) / 16 : caps[4]);
     return g;
 }
 static int64_t posemb_head_bytes(int64_t T) { return ((16 + kNumCls * T) * 4 + 255) / 256 * 256; }
 static int64_t posemb_slot_floats(void) { return (int64_t)kGMax * kGMax + (int64_t)kNodeMax * 4; }
+static int64_t posemb_bslot_floats(void) { return (int64_t)kBMax * kBMax + (int64_t)kNodeMax * 4; }
 static int64_t posemb_ldv(int32_t batch_size, int64_t node_cap) { return ((node_cap / batch_size + 63) / 64) * 64 + 64; }
 
 int64_t gcc_posemb_multi_workspace_bytes(int32_t num_views, int32_t batch_size, int64_t node_cap, int32_t hidden)
@@ -1301,6 +1313,7 @@ int64_t gcc_posemb_multi_workspace_bytes(int32_t num_views, int32_t batch_size, 
     const int64_t T = (int64_t)num_views * batch_size;
     const PosGrids g = posemb_grids(T);
     return posemb_head_bytes(T) + g.slot * posemb_slot_floats() * (int64_t)sizeof(float)
+           + g.big * posemb_bslot_floats() * (int64_t)sizeof(float)
            + (int64_t)(g.mid + g.small) * kNodeMax * 16
            + (int64_t)g.kry * 2 * (kM + 1) * posemb_ldv(batch_size, node_cap) * (int64_t)sizeof(float) + 256;
 }
@@ -1339,7 +1352,9 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     hd.next = hd.count + 8;
     hd.list = hd.count + 16;
     hd.slots = (float *)((char *)workspace + posemb_head_bytes(T));
-    hd.tabs = hd.slots + g.slot * posemb_slot_floats();
+    hd.bslots = hd.slots + g.slot * posemb_slot_floats();
+    hd.bslot_floats = posemb_bslot_floats();
+    hd.tabs = hd.bslots + g.big * posemb_bslot_floats();
     hd.tabs_small_off = g.mid;
     hd.T = (int32_t)T;
     hd.slot_floats = posemb_slot_floats();
@@ -1355,6 +1370,8 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
         (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kGLds);
+        (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsBig, kGMax + 1, kBMax, 1024, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kBLds);
         attr_set = true;
     }
 #endif
@@ -1378,6 +1395,7 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     }
 #endif
     hipLaunchKernelGGL(posemb_krylov_kernel, dim3(g.kry), dim3(kKThreads), lds_kry, s, ka);
+    hipLaunchKernelGGL((posemb_direct_kernel<kClsBig, kGMax + 1, kBMax, 1024, true>), dim3(g.big), dim3(1024), kBLds, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>), dim3(g.slot), dim3(1024), kGLds, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, 1024, false>), dim3(g.mid), dim3(1024), lds_big, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsSmall, 0, kJSmall, 256, false>), dim3(g.small), dim3(256), lds_small, s, m, hd);

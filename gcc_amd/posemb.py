@@ -69,11 +69,13 @@ class DevicePosEmb:
         graph.pos_undirected = out
         return graph
 
-    def multi(self, graphs, prof=None):
+    def multi(self, graphs, prof=None, evals=None, raws=None):
         """Embed several batched graphs (the views of several future steps) in one set of kernel launches."""
         if len(graphs) > self.max_views:          # more views than the workspace was sized for: several calls
             for i in range(0, len(graphs), self.max_views):
-                self.multi(graphs[i:i + self.max_views], prof=prof if i == 0 else None)
+                self.multi(graphs[i:i + self.max_views], prof=prof if i == 0 else None,
+                           evals=evals[i:i + self.max_views] if evals is not None else None,
+                           raws=raws[i:i + self.max_views] if raws is not None else None)
             return graphs
         views = (self._cabi.GccPosembView * len(graphs))()
         keep = []
@@ -84,7 +86,9 @@ class DevicePosEmb:
                                        row_ptr=self.ptr(graph.row_ptr), col_idx=self.ptr(graph.col_idx),
                                        node_cap=out.shape[0], edge_cap=graph.col_idx.numel())
             keep.append(c)
-            views[i] = self._cabi.GccPosembView(g=self._ct.addressof(c), pos=self.ptr(out), evals=None, raw=None)
+            views[i] = self._cabi.GccPosembView(g=self._ct.addressof(c), pos=self.ptr(out),
+                                                evals=self.ptr(evals[i]) if evals is not None else None,
+                                                raw=self.ptr(raws[i]) if raws is not None else None)
             graph.pos_undirected = out
         dev = self._ring[0].device
         st = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None

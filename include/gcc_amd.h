@@ -131,13 +131,15 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p,
  * Twin leaves are deflated exactly first (their contrasts are null vectors).
  * Deflated size n' <= GCC_POSEMB_DIRECT_MAX: direct symmetric eigensolver
  * (tridiagonalisation, bisection, inverse iteration: exact multiplicities), the
- * matrix in LDS up to GCC_POSEMB_LDS_MAX and in a workspace slot above;
+ * matrix in LDS up to GCC_POSEMB_LDS_MAX and in a workspace slot above (a second
+ * workspace class reaches GCC_POSEMB_BIG_MAX);
  * larger ones a thick-restart Krylov-Schur iteration
  * (single start vector, like ARPACK).  Eigenvectors are defined up to sign /
  * rotation inside degenerate eigenspaces; the reference's own output depends on
  * np.random.rand (data_util.py:248).  hidden <= 32. */
 #define GCC_POSEMB_LDS_MAX 128
 #define GCC_POSEMB_DIRECT_MAX 384
+#define GCC_POSEMB_BIG_MAX 704      /* direct solver with the whole LDS of a CU up to this deflated size; Krylov-Schur above */
 #define GCC_STATUS_POSEMB_NOT_CONVERGED 8
 #define GCC_STATUS_POSEMB_TOO_LARGE 16   /* a subgraph with deflated size > GCC_POSEMB_DIRECT_MAX has more than
                                           * node_cap / batch_size nodes: zeros written (size node_cap accordingly) */
@@ -165,7 +167,7 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
                          gcc_prof *prof, void *stream);
 
 /* diagnostics: subsequent gcc_posemb* calls add wall-clock ticks (100 MHz) per solver class and phase into
- * device int64[4][16] (phases 0..6 = matrix, tridiagonalise, bisect, inverse iteration, Gram-Schmidt,
+ * device int64[5][16] (classes small, mid, slot, Krylov, big; phases 0..6 = matrix, tridiagonalise, bisect, inverse iteration, Gram-Schmidt,
  * back-transform, expand; [15] = items); NULL switches it off. */
 void gcc_posemb_debug_ticks(long long *device_ticks64);
 /* the same for gin_in_kernel: device int64[2][16] ([0] = first layer, [1] = others; [15] = tiles) */

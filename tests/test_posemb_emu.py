@@ -62,7 +62,8 @@ def _check(view, x, evals, raw, tol=2e-4):
                 assert np.abs(xb @ xb.T - xr @ xr.T).max() < 5e-3, (b, n)
 
 
-DIRECT_MAX = 384          # GCC_POSEMB_DIRECT_MAX
+DIRECT_MAX = 704          # GCC_POSEMB_BIG_MAX: the direct solver's last size class
+SLOT_MAX = 384            # GCC_POSEMB_DIRECT_MAX: 128 KiB-of-LDS workspace class
 
 
 def reduced_sizes(view):
@@ -181,18 +182,18 @@ def test_large_subgraphs_workspace_resident_direct_path():
                 row_ptr=torch.from_numpy(r["row_ptr"].astype(np.int64)),
                 col_idx=torch.from_numpy(r["col_idx"].astype(np.int64)))
     red = reduced_sizes(view)
-    assert ((red > 128) & (red <= DIRECT_MAX)).all(), red
+    assert ((red > 128) & (red <= SLOT_MAX)).all(), red
     x, evals, raw = _run(view)
     assert _run.arnoldi_steps == 0
     _check(view, x, evals, raw)
 
 
 def test_krylov_fallback_above_the_direct_limit():
-    """Deflated size > 384 (no twin leaves at all): thick-restart Krylov-Schur."""
+    """Deflated size > 704 (no twin leaves at all): thick-restart Krylov-Schur."""
     import scipy.sparse as sp
 
     rng = np.random.RandomState(1)
-    n = 700
+    n = 760
     w = 1.0 / np.arange(1, n + 1) ** 0.5                        # skewed degrees, like an ego-net
     pr = np.minimum(1.0, 6.0 * np.outer(w, w) / w.mean())
     up = np.triu(rng.rand(n, n) < pr, 1)
@@ -206,6 +207,34 @@ def test_krylov_fallback_above_the_direct_limit():
     x, evals, raw = _run(view)
     assert _run.arnoldi_steps > 0
     _check_krylov(view, x, evals, raw)
+
+
+def test_hub_ego_net_with_repeated_eigenvalues_goes_through_the_big_direct_class():
+    """The shape of a hub seed's ego-net at rw_hops 256 on the 1M-node graph (n ~ 850, deflated ~ 400..610): a hub
+    with hundreds of pendant two-paths (hub - a_i - leaf_i), which puts 1/sqrt(2) into the spectrum hundreds of times.
+    Exact multiplicities are out of reach of a single-vector Krylov iteration (ARPACK returns other, smaller
+    eigenvalues for the copies it cannot see); 384 < n' <= 704 is solved by the dense direct solver: STRICT invariants."""
+    import scipy.sparse as sp
+
+    rng = np.random.RandomState(3)
+    t = 210
+    edges = [(0, 1 + i) for i in range(t)] + [(1 + i, 1 + t + i) for i in range(t)]
+    core0 = 1 + 2 * t
+    core = 60
+    edges += [(0, core0 + i) for i in range(core)]
+    edges += [(core0 + i, core0 + j) for i in range(core) for j in range(i + 1, core) if rng.rand() < 0.1]
+    n = core0 + core
+    e = np.array(edges)
+    a = sp.csr_matrix((np.ones(2 * len(e)), (np.r_[e[:, 0], e[:, 1]], np.r_[e[:, 1], e[:, 0]])), shape=(n, n))
+    a.sort_indices()
+    view = dict(node_off=torch.tensor([0, n]), row_ptr=torch.from_numpy(a.indptr.astype(np.int64)),
+                col_idx=torch.from_numpy(a.indices.astype(np.int64)))
+    red = reduced_sizes(view)
+    assert SLOT_MAX < red[0] <= DIRECT_MAX, red
+    x, evals, raw = _run(view)
+    assert _run.arnoldi_steps == 0
+    assert np.sum(np.abs(evals[0] - 2 ** -0.5) < 1e-4) >= 25          # the repeated eigenvalue fills the top 32
+    _check(view, x, evals, raw)
 
 
 def test_leafy_large_subgraph_is_solved_exactly_by_deflation():
@@ -272,7 +301,7 @@ def test_subgraph_larger_than_its_share_of_node_cap_is_refused_loudly():
     import scipy.sparse as sp
 
     rng = np.random.RandomState(5)
-    n = 500                                                   # no twin leaves: deflated size 500 > 384 -> Krylov class
+    n = 720                                                   # no twin leaves: deflated size 720 > 704 -> Krylov class
     up = np.triu(rng.rand(n, n) < 0.02, 1)
     up[np.arange(n - 1), np.arange(1, n)] = True
     a = sp.csr_matrix((up | up.T).astype(np.float64))

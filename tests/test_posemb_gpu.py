@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.test_posemb_emu import DIRECT_MAX, HID, _check_krylov, check_by_path, reduced_sizes
+from tests.test_posemb_emu import DIRECT_MAX, HID, SLOT_MAX, _check_krylov, check_by_path, reduced_sizes
 
 pytestmark = pytest.mark.gpu
 
@@ -41,7 +41,7 @@ def test_sampled_batch_on_g1_like_graph():
     view, x, evals, raw = _device_posemb(q, B)
     sizes = np.diff(view["node_off"].numpy())
     red = reduced_sizes(view)
-    assert (red <= 64).any() and ((red > 64) & (red <= 128)).any() and ((red > 128) & (red <= DIRECT_MAX)).any(), red
+    assert (red <= 64).any() and ((red > 64) & (red <= 128)).any() and ((red > 128) & (red <= SLOT_MAX)).any(), red
     # strict invariants (all multiplicities) wherever the direct solver ran: a mix of small and all large subgraphs
     idx = np.r_[np.where(sizes <= 128)[0][:20], np.where(sizes > 128)[0]]
     check_by_path(view, x, evals, raw, only=idx)
@@ -64,14 +64,14 @@ def test_hub_seeds():
 
 
 def test_krylov_fallback_on_device():
-    """No twin leaves, n = 700 > GCC_POSEMB_DIRECT_MAX: the Krylov-Schur kernel runs (same case as the emulator test)."""
+    """No twin leaves, n = 760 > GCC_POSEMB_BIG_MAX: the Krylov-Schur kernel runs (same case as the emulator test)."""
     import scipy.sparse as sp
 
     from gcc_amd.posemb import DevicePosEmb
     from gcc_amd.sampler import BatchedCSR
 
     rng = np.random.RandomState(1)
-    n = 700
+    n = 760
     w = 1.0 / np.arange(1, n + 1) ** 0.5
     pr = np.minimum(1.0, 6.0 * np.outer(w, w) / w.mean())
     up = np.triu(rng.rand(n, n) < pr, 1)
@@ -86,3 +86,47 @@ def test_krylov_fallback_on_device():
     view, x, evals, raw = _device_posemb(q, 1)
     assert _device_posemb.arnoldi_steps > 0
     _check_krylov(view, x, evals, raw)
+
+
+def test_c2_chunk_of_32_views_runs_clean_and_every_hub_item_passes_the_strict_invariants():
+    """BASELINE configs[1] as bench.py / train.py run it: G1 (1M nodes / 10M edges), bsz 256, rw_hops 256 -- one
+    gcc_posemb_multi call over the 32 views of 16 steps.  The status word must stay 0 (no restart cap, nothing
+    refused), and every subgraph of the two largest solver classes (deflated size > 128: workspace classes; hub
+    seeds reach ~600 here) satisfies the strict invariants against a dense float64 decomposition."""
+    from gcc_amd.graph import DeviceGraph
+    from gcc_amd.graphgen import powerlaw_graph
+    from gcc_amd.posemb import DevicePosEmb
+    from gcc_amd.sampler import DeviceRWRSampler
+    from tests.test_posemb_emu import _check, _sub
+
+    rp, ci = powerlaw_graph(1_000_000, 10_000_000, 0)
+    g = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, validate=False)
+    B, S = 256, 16
+    s = DeviceRWRSampler(g, B, run_seed=0, num_buffers=S)
+    pe = DevicePosEmb(B, s.node_cap, HID, device="cuda", seed=0, num_buffers=S, max_views=2 * S)
+    views = [v for step in range(S) for v in s.sample(step * B)]
+    s.check_status()
+    evals = [torch.zeros(B, HID, device="cuda") for _ in views]
+    raws = [torch.zeros(s.node_cap, HID, device="cuda") for _ in views]
+    pe.multi(views, evals=evals, raws=raws)
+    torch.cuda.synchronize()
+    assert pe.status.cpu().tolist()[0] == 0, pe.status.cpu().tolist()
+    pe.check_status(strict=True)
+    nbig = nkry = 0
+    for vi in (0, 1, 17, 30):                                 # q and k views of different steps
+        c = views[vi].csr_numpy()
+        view = dict(node_off=torch.from_numpy(c["node_off"].astype(np.int64)),
+                    row_ptr=torch.from_numpy(c["row_ptr"].astype(np.int64)),
+                    col_idx=torch.from_numpy(c["col_idx"].astype(np.int64)))
+        n = int(c["node_off"][-1])
+        x = views[vi].pos_undirected[:n].cpu().numpy()
+        ev, raw = evals[vi].cpu().numpy(), raws[vi][:n].cpu().numpy()
+        red = reduced_sizes(view)
+        assert red.max() <= DIRECT_MAX, red.max()             # nothing falls to the Krylov class at this config
+        nkry += int((red > DIRECT_MAX).sum())
+        idx = np.r_[np.where(red > 128)[0], np.where(red <= 128)[0][:6]]
+        for b in idx:
+            lo, hi, sub = _sub(view, int(b))
+            _check(sub, x[lo:hi], ev[b:b + 1], raw[lo:hi])
+        nbig += int((red > SLOT_MAX).sum())
+    assert nbig > 0 and nkry == 0
