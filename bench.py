@@ -1,26 +1,29 @@
 #!/usr/bin/env python
 """bench.py -- GCC pre-training hot path on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch of bsz samples
-(2*bsz sampled subgraphs): draw seeds -> RWR walks -> induced subgraphs ->
-batched CSR [-> positional embedding -> GIN encoder q/k -> MoCo/InfoNCE ->
-backward -> Adam -> EMA as those stages land; `config.stages` lists what the
-timed region contains].  Workload = BASELINE.json configs[1]: MoCo K=16384,
-bsz 256, rw_hops 256, restart 0.8 on the synthetic 1M-node/10M-edge power-law
-graph G1, all inputs resident in HBM before the timed region.
+    python bench.py --gpus N --steps K --warmup W [--mode train|sampler]
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+--mode train (default; BASELINE configs[1], configs[2] at N = 8): one "step" = one pass of the hot path over one
+batch of bsz samples per GPU (2*bsz sampled subgraphs): draw seeds -> RWR walks -> induced subgraphs -> batched CSR
+-> positional embedding -> GIN encoder q/k -> MoCo/InfoNCE -> backward -> clip + Adam -> EMA.  Default workload:
+MoCo K=16384, bsz 256, rw_hops 256, restart 0.8 on the synthetic 1M-node/10M-edge power-law graph G1 (SURVEY.md
+§8d), everything resident in HBM before the timed region.
+--mode sampler (BASELINE configs[3]): the sampler alone (seed draw, walks, induction, batch packing) on the
+10M-node/200M-edge graph G2; no collective.
 
-Prints ONE JSON line on rank 0.  Multi-GPU: the seed batch is sharded by rank
-(rank r owns samples [step*N*bsz + r*bsz, +bsz)), the graph is replicated in
-every GPU's HBM, weak scaling.
+Prints ONE JSON line on rank 0.  Multi-GPU: one process per GPU; when WORLD_SIZE is not set and --gpus N > 1 this
+script re-launches itself under torch.distributed.run (rendezvous on 127.0.0.1).  The seed batch is sharded by rank
+(rank r owns samples [step*N*bsz + r*bsz, +bsz)), the graph is replicated in every GPU's HBM, weak scaling.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,25 +31,29 @@ import numpy as np
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")      # the command processor serves few queues well (tools/contention_probe.py)
 os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")   # RCCL's stream must not share a hardware queue with a producer lane
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_sampler.json")
+SAMPLER_SRC = os.path.join(ROOT, "gcc_amd", "csrc", "sampler.hip")
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--mode", choices=["train", "sampler"], default="train")
     ap.add_argument("--batch-size", type=int, default=256)
     ap.add_argument("--nce-k", type=int, default=16384)
     ap.add_argument("--rw-hops", type=int, default=256)
     ap.add_argument("--restart-prob", type=float, default=0.8)
-    ap.add_argument("--nodes", type=int, default=1_000_000)
-    ap.add_argument("--edges", type=int, default=10_000_000)
+    ap.add_argument("--nodes", type=int, default=None, help="default 1,000,000 (train) / 10,000,000 (sampler)")
+    ap.add_argument("--edges", type=int, default=None, help="default 10,000,000 (train) / 200,000,000 (sampler)")
     ap.add_argument("--run-seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -54,14 +61,51 @@ def parse_args():
     ap.add_argument("--lanes", type=int, default=3, help="producer streams (sampler + positional embedding)")
     ap.add_argument("--reserved-cus", type=int, default=0, help="compute units the producer streams are masked off (kept for the training step)")
     ap.add_argument("--cu-layout", default="interleaved", choices=["interleaved", "block"])
-    ap.add_argument("--chunk", type=int, default=16, help="steps a producer lane prepares per turn (one multi-view eigensolver call)")
-    ap.add_argument("--depth", type=int, default=2, help="batches in flight per producer lane")
+    ap.add_argument("--chunk", type=int, default=4, help="steps a producer lane prepares per turn (one multi-view eigensolver call); "
+                                                         "reduced to gcd(chunk, steps) so that the timed region produces what it consumes")
+    ap.add_argument("--depth", type=int, default=2, help="chunks in flight per producer lane")
+    ap.add_argument("--ahead", type=int, default=None, help="chunks launched beyond the one being consumed (default lanes * (depth - 1))")
     ap.add_argument("--scratch-entries", type=int, default=0, help="induction scratch of the sampler (int32 slots); 0 = default")
     ap.add_argument("--edge-cap", type=int, default=0, help="edge capacity of a batch view; 0 = default")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the roofline kernel from a separate rocprofv3 --pmc pass "
-                         "(default: the committed profiles/r1_pmc_sampler.json, if the workload is the default one)")
-    return ap.parse_args()
+                         "(default: profiles/pmc_sampler.json if it was collected from this build of sampler.hip)")
+    ap.add_argument("--allow-posemb-flags", action="store_true",
+                    help="do not fail when an eigen-iteration hit its restart cap (status bit 8); the count is reported either way")
+    args = ap.parse_args(argv)
+    if args.nodes is None:
+        args.nodes = 10_000_000 if args.mode == "sampler" else 1_000_000
+    if args.edges is None:
+        args.edges = 200_000_000 if args.mode == "sampler" else 10_000_000
+    return args
+
+
+# ------------------------------------------------------------------ launcher ----
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(n, argv, port=None, script=None):
+    """`python bench.py --gpus N` without a launcher: the command that runs N ranks of this script on this node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()),
+            script or os.path.abspath(__file__)] + list(argv)
+
+
+def workload_name(args, world, v, e):
+    """config.workload from what actually runs (not a fixed string)."""
+    graph = f"synthetic power-law graph {args.nodes:,}-node/{args.edges:,}-edge requested ({v:,}/{e:,} after dedup and isolated-node removal)"
+    if args.mode == "sampler":
+        tag = "BASELINE configs[3]: " if (args.nodes, args.edges, args.rw_hops) == (10_000_000, 200_000_000, 256) \
+            and abs(args.restart_prob - 0.8) < 1e-12 else ""
+        return f"{tag}sampler-only rw_hops={args.rw_hops} restart={args.restart_prob} bsz={args.batch_size}/GPU, {graph}, {world}xMI355X"
+    tag = ""
+    if (args.nodes, args.edges, args.batch_size, args.nce_k, args.rw_hops) == (1_000_000, 10_000_000, 256, 16384, 256):
+        tag = "BASELINE configs[1]: " if world == 1 else ("BASELINE configs[2]: " if world == 8 else "BASELINE configs[1] per GPU: ")
+    return (f"{tag}MoCo K={args.nce_k} m=0.999 bsz={args.batch_size}/GPU (global {args.batch_size * world}) rw_hops={args.rw_hops} "
+            f"restart={args.restart_prob}, {graph}, {world}xMI355X")
 
 
 def sampler_algorithmic_bytes(rp, views):
@@ -89,6 +133,35 @@ def _posemb_chunk(job):
 
     node_off, row_ptr, col_idx, seed = job
     return P.batched_positional_embedding(node_off, row_ptr, col_idx, 32, seed=seed)
+
+
+def cpu_baseline_sampler(rp, ci, args):
+    """BASELINE configs[3] on the host cores ("port"): the C oracle of the sampler (seed draw, RWR walks, node set,
+    induced subgraph, batching), OpenMP over subgraphs."""
+    from oracle import sampler as O
+
+    c = O.COracle()
+    cores = os.cpu_count() or 1
+    threads = min(c.max_threads(), cores)
+    cdf = O.seed_cdf(rp)
+    lt = O.max_nodes_table(int(np.diff(rp).max()), args.rw_hops, args.restart_prob)
+    thr = O.restart_threshold(args.restart_prob)
+    B = args.batch_size
+    deg = np.diff(rp)
+    done, first = 0, 10_000_000
+    t0 = time.perf_counter()
+    while True:
+        seeds = c.draw_seeds(cdf, args.run_seed, first, B)
+        L = lt[deg[seeds]]
+        for view in range(2):
+            c.sample_batch(rp, ci, seeds, L, view, args.run_seed, first, thr, threads=threads)
+        done += 2 * B
+        first += B
+        dt = time.perf_counter() - t0
+        if dt >= args.cpu_seconds:
+            break
+    return dict(value=done / dt, unit="subgraphs/s", cores=threads, kind="port",
+                sample=f"{done} subgraphs ({done // (2 * B)} batches of bsz {B}, both views) in {dt:.1f}s: C sampler oracle, OpenMP x{threads}")
 
 
 def cpu_baseline(rp, ci, args):
@@ -168,20 +241,59 @@ def cpu_baseline(rp, ci, args):
                        f"encoder/MoCo/Adam/EMA oracle ({torch.get_num_threads()} threads)")
 
 
-def committed_pmc_traffic(args):
-    """PMC counters cannot be collected from inside the benchmarked process; the figure comes from the
-    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes committed under profiles/."""
+def sampler_source_hash():
+    h = hashlib.sha256()
+    for name in ("sampler.hip", "device_compat.h", "host_common.h"):
+        with open(os.path.join(ROOT, "gcc_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def committed_pmc_traffic(args, v, e):
+    """PMC counters cannot be collected from inside the benchmarked process; the figure comes from the separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes summarised by tools/pmc_sampler.py into
+    profiles/pmc_sampler.json.  That file records the hash of the kernel source and the workload it was collected
+    on; a file from another build or workload is refused (traffic = null) instead of quoted."""
     if args.pmc_traffic is not None:
         return args.pmc_traffic, "--pmc-traffic"
-    path = os.path.join(ROOT, "profiles", "r1_pmc_sampler.json")
-    default_workload = (args.batch_size, args.rw_hops, args.nodes, args.edges) == (256, 256, 1_000_000, 10_000_000)
-    if default_workload and os.path.exists(path):
-        return json.load(open(path))["induce_kernel_hbm_bytes_per_launch_raw"], "profiles/r1_pmc_sampler.json"
-    return None, None
+    if not os.path.exists(PMC_FILE):
+        return None, "no profiles/pmc_sampler.json"
+    rec = json.load(open(PMC_FILE))
+    if rec.get("source_sha256") != sampler_source_hash():
+        return None, "profiles/pmc_sampler.json is stale (collected from another build of sampler.hip): refused"
+    key = f"{v}/{e}/bsz{args.batch_size}/hops{args.rw_hops}"
+    ent = rec.get("workloads", {}).get(key)
+    if ent is None:
+        return None, f"profiles/pmc_sampler.json has no entry for workload {key}"
+    return ent["induce_kernel_hbm_bytes_per_launch"], f"profiles/pmc_sampler.json[{key}] ({ent.get('correction', 'raw')})"
+
+
+def sampler_probe(sampler, rp, first_id, args, nsample, lt, Prof, torch):
+    """Isolated probe loop: HIP-event durations of the three sampler kernels and the exact algorithmic bytes of the
+    batches they produced (same kernels, same batch ids as the timed steps, GPU otherwise idle)."""
+    acc = dict(walk=0, induce=0, pack=0, total=0)
+    iso = np.zeros(3)
+    deg = np.diff(rp)
+    for i in range(-2, nsample):                  # two untimed probe warm-ups
+        pr = Prof(4)
+        q, k = sampler.sample(first_id(max(i, 0)), prof=pr)
+        torch.cuda.synchronize()
+        if i < 0:
+            continue
+        iso += np.array([pr.elapsed_ms(j, j + 1) for j in range(3)]) / nsample
+        seeds = sampler.last_seeds().cpu().numpy()
+        L = lt[deg[seeds]]
+        bts = sampler_algorithmic_bytes(rp, [(q.csr_numpy(), L), (k.csr_numpy(), L)])
+        for key in acc:
+            acc[key] += bts[key] / nsample
+    return dict(rwr_walk_kernel=float(iso[0]), induce_kernel=float(iso[1]), pack_kernel=float(iso[2])), acc
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(subprocess.call(launcher_command(args.gpus, sys.argv[1:])))
+
     import torch
     import torch.distributed as dist
 
@@ -189,163 +301,186 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (run through gpurun)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    oversubscribed = ndev < world              # fewer devices than ranks (a 1-GPU box): ranks share devices, correctness only
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if oversubscribed:                     # RCCL refuses two ranks on one device; gloo moves the same buffers
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from gcc_amd.graph import DeviceGraph
     from gcc_amd.graphgen import powerlaw_graph
     from gcc_amd.prof import Prof
     from gcc_amd.sampler import DeviceRWRSampler
 
-    from gcc_amd.contrast import MemoryMoCo
-    from gcc_amd.encoder import GraphEncoder
-    from gcc_amd.misc import warmup_linear
-    from gcc_amd.posemb import DevicePosEmb, PlaceholderPosEmb
-    from gcc_amd.train_step import MoCoTrainStep
-
     rp, ci = powerlaw_graph(args.nodes, args.edges, seed=0)
+    V, E = int(len(rp) - 1), int(len(ci))
     graph = DeviceGraph(rp, ci, rw_hops=args.rw_hops, restart_prob=args.restart_prob, device=dev, validate=False)
     B = args.batch_size
     torch.manual_seed(0)
-    nbuf = args.depth * args.chunk
-    samplers = [DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=nbuf, scratch_entries=args.scratch_entries or None,
-                                 edge_cap=args.edge_cap or None) for _ in range(args.lanes)]
-    sampler = samplers[0]
-    enc_kw = dict(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
-                  freq_embedding_size=16, degree_embedding_size=16, output_dim=64, node_hidden_dim=64,
-                  edge_hidden_dim=64, num_layers=5, num_step_set2set=6, num_layer_set2set=3, norm=True,
-                  gnn_model="gin", degree_input=True)                 # train.py:601-618 with default flags
-    model, model_ema = GraphEncoder(**enc_kw).to(dev), GraphEncoder(**enc_kw).to(dev)
-    model_ema.load_state_dict(model.state_dict())                     # moment_update(model, model_ema, 0), train.py:624
-    contrast = MemoryMoCo(64, None, args.nce_k, 0.07, use_softmax=True).to(dev)
-    if args.posemb == "device":
-        posembs = [DevicePosEmb(B, sampler.node_cap, 32, device=dev, seed=args.run_seed, num_buffers=nbuf,
-                                max_views=min(2 * args.chunk, 32)) for _ in range(args.lanes)]
-    else:
-        posembs = [PlaceholderPosEmb(sampler.node_cap, 32, device=dev)] * args.lanes
-    posemb = posembs[0]
-    # every producer lane: one sampler + one eigensolver workspace, `chunk` steps (2 * chunk views) per turn
-    lanes = [(samplers[i], posembs[i]) for i in range(args.lanes)]
-    trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank,
-                            lanes=lanes, depth=args.depth, chunk=args.chunk, reserved_cus=args.reserved_cus,
-                            cu_layout=args.cu_layout)
-    stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder q+k fwd",
-              "moco-infonce fwd", "key all-gather" if world > 1 else "enqueue", "infonce bwd", "gin-encoder bwd",
-              "grad all-reduce" if world > 1 else "clip", "adam", "ema"]
-    n_batch = 2000 * 12 // 32                                          # train.py:356 with default flags
-    total_steps = 100 * n_batch
-
-    def lr_at(step):
-        return 0.005 * warmup_linear(step / total_steps, 0.1)          # train.py:411-414
-
-    names = ("gin_fwd", "nce_fwd", "nce_bwd", "gin_bwd")
 
     def first_id(step):
         return (step * world + rank) * B
 
-    def step_fn(step, prof=None):
-        return trainer.step(step, lr_at(step), prof=prof)
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    # untimed steps: the requested warm-up, extended to a whole number of producer rounds so that the look-ahead pipeline
-    # (lanes x depth chunks) is in steady state when the clock starts -- the timed region then produces exactly as many
-    # chunks as it consumes (otherwise a short run would train on batches prepared before the clock started)
-    fill = args.lanes * args.depth * args.chunk
-    warm = ((max(args.warmup, fill) + args.chunk - 1) // args.chunk) * args.chunk
-    for i in range(warm):
-        step_fn(i)
-    args.first_timed_step = warm
-    profs = [dict(sampler=Prof(4), **{n: Prof(2) for n in names}) for _ in range(args.steps)]
-    if args.posemb == "device":
-        for p in profs:
-            p["posemb"] = Prof(2)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        last = step_fn(args.first_timed_step + i, prof=profs[i])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    extra = {}
+    if args.mode == "sampler":
+        sampler = DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=2, scratch_entries=args.scratch_entries or None,
+                                   edge_cap=args.edge_cap or None)
+        samplers = [sampler]
+        for i in range(args.warmup):
+            sampler.sample(first_id(i))
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            sampler.sample(first_id(args.warmup + i))
+        barrier()
+        dt = time.perf_counter() - t0
+        stages = ["seed-draw", "rwr-walk", "induce", "batch-pack"]
+        produced = consumed = args.steps
+        first_timed = args.warmup
+        chunk = 1
+    else:
+        from gcc_amd.contrast import MemoryMoCo
+        from gcc_amd.encoder import GraphEncoder
+        from gcc_amd.misc import warmup_linear
+        from gcc_amd.posemb import DevicePosEmb, PlaceholderPosEmb
+        from gcc_amd.train_step import MoCoTrainStep
+
+        # the timed region must produce exactly what it consumes: whole chunks only
+        chunk = math.gcd(args.chunk, args.steps)
+        nbuf = args.depth * chunk
+        samplers = [DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=nbuf, scratch_entries=args.scratch_entries or None,
+                                     edge_cap=args.edge_cap or None) for _ in range(args.lanes)]
+        sampler = samplers[0]
+        enc_kw = dict(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
+                      freq_embedding_size=16, degree_embedding_size=16, output_dim=64, node_hidden_dim=64,
+                      edge_hidden_dim=64, num_layers=5, num_step_set2set=6, num_layer_set2set=3, norm=True,
+                      gnn_model="gin", degree_input=True)                 # train.py:601-618 with default flags
+        model, model_ema = GraphEncoder(**enc_kw).to(dev), GraphEncoder(**enc_kw).to(dev)
+        model_ema.load_state_dict(model.state_dict())                     # moment_update(model, model_ema, 0), train.py:624
+        contrast = MemoryMoCo(64, None, args.nce_k, 0.07, use_softmax=True).to(dev)
+        if args.posemb == "device":
+            posembs = [DevicePosEmb(B, sampler.node_cap, 32, device=dev, seed=args.run_seed, num_buffers=nbuf,
+                                    max_views=min(2 * chunk, 32)) for _ in range(args.lanes)]
+        else:
+            posembs = [PlaceholderPosEmb(sampler.node_cap, 32, device=dev)] * args.lanes
+        posemb = posembs[0]
+        # every producer lane: one sampler + one eigensolver workspace, `chunk` steps (2 * chunk views) per turn
+        lanes = [(samplers[i], posembs[i]) for i in range(args.lanes)]
+        trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank,
+                                lanes=lanes, depth=args.depth, chunk=chunk, reserved_cus=args.reserved_cus,
+                                cu_layout=args.cu_layout, ahead=args.ahead)
+        stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder q+k fwd",
+                  "moco-infonce fwd", "key all-gather" if world > 1 else "enqueue", "infonce bwd", "gin-encoder bwd",
+                  "grad all-reduce" if world > 1 else "clip", "adam", "ema"]
+        n_batch = 2000 * 12 // 32                                          # train.py:356 with default flags
+        total_steps = 100 * n_batch
+
+        def lr_at(step):
+            return 0.005 * warmup_linear(step / total_steps, 0.1)          # train.py:411-414
+
+        names = ("gin_fwd", "nce_fwd", "nce_bwd", "gin_bwd")
+
+        # untimed steps: the requested warm-up, extended to a whole number of producer rounds so that the look-ahead
+        # pipeline (lanes x depth chunks) is in steady state when the clock starts; `steps` is a multiple of `chunk`, so the
+        # timed region launches exactly as many chunks as it consumes (checked below: produced_steps == consumed_steps)
+        fill = args.lanes * args.depth * chunk
+        warm = ((max(args.warmup, fill) + chunk - 1) // chunk) * chunk
+        for i in range(warm):
+            trainer.step(i, lr_at(i))
+        first_timed = warm
+        profs = [dict(sampler=Prof(4), **{n: Prof(2) for n in names}) for _ in range(args.steps)]
+        if args.posemb == "device":
+            for p in profs:
+                p["posemb"] = Prof(2)
+        barrier()
+        launched0 = trainer.producer.launched
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            last = trainer.step(first_timed + i, lr_at(first_timed + i), prof=profs[i])
+        barrier()
+        dt = time.perf_counter() - t0
+        produced = (trainer.producer.launched - launched0) * chunk
+        consumed = args.steps
+        extra["final_loss"] = float(last["loss"].item())
+        if hasattr(posemb, "status"):
+            sts = [p.status.cpu().tolist() for p in posembs]
+            flags = 0
+            for st in sts:
+                flags |= int(st[0])
+            extra["posemb_status"] = dict(flags=flags, max_restart_cycles=int(max(st[1] for st in sts)),
+                                          arnoldi_steps=int(sum(st[2] for st in sts)),
+                                          items_stopped_at_restart_cap=int(sum(st[3] for st in sts)))
+            for p in posembs:
+                p.check_status(strict=not args.allow_posemb_flags)         # raises: a flagged eigen-solve is not a valid bench run
+
     for smp in samplers:
         smp.check_status()
-    posemb_status = [int(x) for x in sum(p.status.cpu() for p in posembs).tolist()] if hasattr(posemb, "status") else [0]
-    final_loss = float(last["loss"].item())
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if not oversubscribed else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     if rank == 0:
-        # live per-kernel durations (HIP events recorded on the launch stream inside the timed region)
-        # (the sampler marks of timed step i belong to the batch prefetched for step i + 1)
-        # (producer marks exist only for the steps whose get() launched a chunk: the first sampler call and the
-        # multi-view eigensolver call of that chunk)
-        used = [p for p in profs if p.get("used")]
-        stage_ms = {n: float(np.mean([p[n].elapsed_ms(0, 1) for p in profs])) for n in names}
-        if used:
-            k_ms = np.array([[p["sampler"].elapsed_ms(j, j + 1) for j in range(3)] for p in used])
-            stage_ms["sampler"] = float(k_ms.sum(axis=1).mean())
-            if args.posemb == "device":
-                stage_ms["posemb_chunk_of_%d_views" % min(2 * args.chunk, 32)] = float(
-                    np.mean([p["posemb"].elapsed_ms(0, 1) for p in used]))
-        # algorithmic bytes of the timed steps (recomputed post hoc: sampling is deterministic)
-        from oracle import sampler as O   # checker side only: L table for the byte count
+        from oracle import sampler as O   # checker side only: L table for the byte count (after the clock)
         lt = O.max_nodes_table(int(np.diff(rp).max()), args.rw_hops, args.restart_prob)
         # roofline of the HBM-bound sampler kernel: durations AND byte counts from an ISOLATED probe loop (same
-        # kernels, same batches as the timed steps, GPU otherwise idle).  Inside the timed region 12 producer
-        # streams overlap several sampler / eigensolver launches, so the in-step marks above measure contention
-        # rather than the kernel.
+        # kernels, same batches as the timed steps, GPU otherwise idle).  Inside the timed region of --mode train the
+        # producer streams overlap several sampler / eigensolver launches, so in-step marks measure contention.
         nsample = min(args.steps, 12)
-        acc = dict(walk=0, induce=0, pack=0, total=0)
-        iso = np.zeros(3)
-        for i in range(-2, nsample):                  # two untimed probe warm-ups
-            pr = Prof(4)
-            q, k = sampler.sample(first_id(args.warmup + max(i, 0)), prof=pr)
-            torch.cuda.synchronize()
-            if i < 0:
-                continue
-            iso += np.array([pr.elapsed_ms(j, j + 1) for j in range(3)]) / nsample
-            seeds = sampler.last_seeds().cpu().numpy()
-            L = lt[np.diff(rp)[seeds]]
-            bts = sampler_algorithmic_bytes(rp, [(q.csr_numpy(), L), (k.csr_numpy(), L)])
-            for key in acc:
-                acc[key] += bts[key] / nsample
-        kern_iso = dict(rwr_walk_kernel=float(iso[0]), induce_kernel=float(iso[1]), pack_kernel=float(iso[2]))
+        kern_iso, acc = sampler_probe(sampler, rp, lambda i: first_id(first_timed + i), args, nsample, lt, Prof, torch)
+        sampler.check_status()
         dom = "induce_kernel"
         achieved = acc["induce"] / (kern_iso[dom] * 1e-3) / 1e9
+        traffic, traffic_src = committed_pmc_traffic(args, V, E)
         ms_per_step = dt / args.steps * 1e3
         out = {
             "metric": "sampled-subgraphs/sec", "value": 2 * B * world * args.steps / dt, "unit": "subgraphs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_steps": args.first_timed_step, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_steps": first_timed, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32" if args.mode == "sampler" else "f32", "data": "synthetic",
             "steps_per_sec": args.steps / dt,
-            "config": {"workload": "BASELINE configs[1]: MoCo K=16384 bsz=256 rw_hops=256 restart=0.8, "
-                                   "synthetic power-law G1 1M-node/10M-edge, 1xMI355X",
-                       "graph_nodes": int(len(rp) - 1), "graph_edges": int(len(ci)),
-                       "batch_size_per_gpu": B, "global_batch": B * world, "nce_k": args.nce_k,
-                       "rw_hops": args.rw_hops, "restart_prob": args.restart_prob,
-                       "stages": stages, "producer_lanes": args.lanes, "producer_depth": args.depth, "producer_chunk": args.chunk, "reserved_cus": args.reserved_cus, "parallelism": f"dp{world} (seed batch sharded, graph replicated)"},
-            "kernel_ms_isolated": kern_iso, "stage_ms": stage_ms, "final_loss": final_loss, "posemb_status": posemb_status,
-            "roofline": {"bound": "hbm", "kernel": dom, "measured": "isolated probe loop after the timed region: HIP events around subgraph_prefix_kernel<false> + induce_kernel (rocprof of the same kernels alone: profiles/r1_kernel_stats_sampler_alone.csv)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "algorithmic_bytes_per_launch": acc["induce"], "traffic": committed_pmc_traffic(args)[0],
-                         "traffic_source": committed_pmc_traffic(args)[1]},
+            "produced_steps": produced, "consumed_steps": consumed,
+            "config": {"workload": workload_name(args, world, V, E), "mode": args.mode,
+                       "graph_nodes": V, "graph_edges": E,
+                       "batch_size_per_gpu": B, "global_batch": B * world, "nce_k": args.nce_k if args.mode == "train" else None,
+                       "rw_hops": args.rw_hops, "restart_prob": args.restart_prob, "stages": stages,
+                       "parallelism": f"dp{world} (seed batch sharded, graph replicated)" + ("; OVERSUBSCRIBED: %d ranks on %d device(s), gloo, correctness only" % (world, ndev) if oversubscribed else "")},
+            "kernel_ms_isolated": kern_iso,
+            "roofline": {"bound": "hbm", "kernel": dom,
+                         "measured": "isolated probe loop after the timed region: HIP events (gcc_prof marks on the launch stream) around the "
+                                     "induction launches of gcc_sample_batch; rocprof of the same kernels alone under profiles/",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "algorithmic_bytes_per_launch": acc["induce"], "traffic": traffic, "traffic_source": traffic_src},
             "algorithmic_bytes_per_step": acc,
         }
+        if args.mode == "train":
+            out["config"].update(producer_lanes=args.lanes, producer_depth=args.depth, producer_chunk=chunk,
+                                 producer_ahead=trainer.producer.ahead, reserved_cus=args.reserved_cus)
+            used = [p for p in profs if p.get("used")]
+            stage_ms = {n: float(np.mean([p[n].elapsed_ms(0, 1) for p in profs])) for n in names}
+            if used:
+                k_ms = np.array([[p["sampler"].elapsed_ms(j, j + 1) for j in range(3)] for p in used])
+                stage_ms["sampler"] = float(k_ms.sum(axis=1).mean())
+                if args.posemb == "device":
+                    stage_ms["posemb_chunk_of_%d_views" % min(2 * chunk, 32)] = float(
+                        np.mean([p["posemb"].elapsed_ms(0, 1) for p in used]))
+            out["stage_ms"] = stage_ms
+        out.update(extra)
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(rp, ci, args)
+            out["cpu_baseline"] = cpu_baseline_sampler(rp, ci, args) if args.mode == "sampler" else cpu_baseline(rp, ci, args)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

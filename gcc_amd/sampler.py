@@ -219,10 +219,10 @@ class LoadBalanceGraphDataset:
     ``num_samples``) as graph_dataset.py:33-80; iteration yields already-batched
     ``(graph_q, graph_k)`` of ``batch_size`` samples each.
 
-    ``graph`` replaces the DGL ``.bin`` file (ingestion of DGL files is
-    SURVEY.md §8f#3): a :class:`DeviceGraph`, or ``(row_ptr, col_idx)`` arrays,
-    or a list of such pairs (disjoint graphs are unioned, which is what sampling
-    a node uniformly over all workers' graphs amounts to).
+    ``dgl_graphs_file`` is read without DGL (gcc_amd/ingest.py: read_dgl_graphs);
+    ``graph`` overrides it: a :class:`DeviceGraph`, or ``(row_ptr, col_idx)``
+    arrays, or a list of such pairs (disjoint graphs are unioned, which is what
+    sampling a node over all workers' graphs amounts to).
     """
 
     def __init__(self, rw_hops=64, restart_prob=0.8, positional_embedding_size=32,
@@ -247,15 +247,17 @@ class LoadBalanceGraphDataset:
         self.aug = aug
         self.dgl_graphs_file = dgl_graphs_file
         self.graph_transform = graph_transform
+        sizes = None
         if graph is None:
-            graph = _load_npz_graphs(dgl_graphs_file)
+            graph, sizes = _load_graph_file(dgl_graphs_file)
         graphs = graph if isinstance(graph, list) else [graph]
         if isinstance(graphs[0], DeviceGraph):
             assert len(graphs) == 1
             self.graph = graphs[0]
             sizes = [self.graph.num_nodes]
         else:
-            sizes = [len(rp) - 1 for rp, _ in graphs]
+            if sizes is None:
+                sizes = [len(rp) - 1 for rp, _ in graphs]
             rp, ci = _disjoint_union(graphs)
             self.graph = DeviceGraph(rp, ci, rw_hops=rw_hops, restart_prob=restart_prob, device=device)
         # greedy LPT load balance of graph_dataset.py:63-77, kept for its attributes
@@ -270,8 +272,20 @@ class LoadBalanceGraphDataset:
         self.jobs = jobs * num_copies
         self.total = self.num_samples * num_workers
         self.batch_size = batch_size
-        self.sampler = DeviceRWRSampler(self.graph, batch_size, run_seed=run_seed)
+        self.run_seed = run_seed
+        self._sampler = None          # built on first use: the MoCo path samples through its producer lanes instead
         self._epoch = 0
+
+    @property
+    def sampler(self):
+        if self._sampler is None:
+            self._sampler = DeviceRWRSampler(self.graph, self.batch_size, run_seed=self.run_seed)
+        return self._sampler
+
+    @property
+    def node_cap(self):
+        """Node capacity of one batch view (batch_size * (longest trace + 1)); known without allocating a sampler."""
+        return self.batch_size * (self.graph.lmax + 1)
 
     def __len__(self):
         return self.total
@@ -295,10 +309,14 @@ def _disjoint_union(graphs):
     return np.concatenate(rps).astype(np.int32), np.concatenate(cis).astype(np.int32)
 
 
-def _load_npz_graphs(path):
-    if not str(path).endswith(".npz"):
-        raise NotImplementedError(
-            f"{path}: reading DGL .bin files needs DGL (SURVEY.md §8f#3); pass graph=(row_ptr, col_idx) "
-            "or an .npz with row_ptr/col_idx")
-    z = np.load(path)
-    return [(z["row_ptr"], z["col_idx"])]
+def _load_graph_file(path):
+    """``dgl_graphs_file``: a DGL graph file as written by x2dgl.py (graph_dataset.py:26-29,58-60; container restated in
+    gcc_amd/ingest.py, format DGL-recalled) or an .npz with row_ptr/col_idx.  -> (graphs, graph sizes for the LPT split)."""
+    if str(path).endswith(".npz"):
+        z = np.load(path)
+        return [(z["row_ptr"], z["col_idx"])], None
+    from .ingest import read_dgl_graphs
+
+    graphs, labels = read_dgl_graphs(str(path))
+    sizes = labels["graph_sizes"].tolist() if "graph_sizes" in labels else None      # graph_dataset.py:58-60
+    return graphs, sizes

@@ -77,11 +77,16 @@ class BatchProducer:
     (gcc_posemb_multi: the eigensolver kernels pull items from work lists over all views).  Chunk c is produced by
     lane c % lanes into slot (c // lanes) % depth of that lane's buffer rings."""
 
-    def __init__(self, lanes, first_id_fn, device, depth=2, chunk=1, reserved_cus=0, cu_layout="interleaved"):
+    def __init__(self, lanes, first_id_fn, device, depth=2, chunk=1, reserved_cus=0, cu_layout="interleaved", ahead=None):
         self.lanes = lanes                      # list of (sampler, posemb): sampler ring >= depth * chunk, posemb ring
         self.first_id = first_id_fn             # >= 2 * depth * chunk buffers, posemb.max_views >= 2 * chunk
         self.dev = device
         self.depth, self.chunk = depth, chunk
+        # chunks kept launched beyond the one being consumed: at most lanes * depth - 1 (every ring slot but the
+        # consumed chunk's), at least 1
+        cap = len(lanes) * depth - 1
+        self.ahead = max(1, min(cap, ahead if ahead is not None else len(lanes) * (depth - 1)))
+        self.launched = 0                       # chunks launched so far (bench.py: produced == consumed in the window)
         self.cuda = torch.device(device).type == "cuda"
         self._owners = []
         if self.cuda and reserved_cus:          # producers stay off `reserved_cus` compute units (gcc_amd/streams.py)
@@ -113,6 +118,7 @@ class BatchProducer:
         return pairs
 
     def _launch(self, c):
+        self.launched += 1
         if not self.cuda:
             self.ready[c] = (self._produce(c), None)
             return
@@ -132,7 +138,7 @@ class BatchProducer:
         """Batch of ``step`` (made ready on the current stream); keeps lanes * (depth - 1) chunks in flight."""
         self.prof = prof
         c = step // self.chunk
-        horizon = c + len(self.lanes) * (self.depth - 1) if self.cuda else c
+        horizon = c + self.ahead if self.cuda else c
         if self.next_chunk < c:
             self.next_chunk = c
         while self.next_chunk <= horizon:
@@ -190,7 +196,7 @@ class MoCoTrainStep:
     def __init__(self, model: GraphEncoder, model_ema: GraphEncoder, contrast: MemoryMoCo, sampler, posemb,
                  learning_rate=0.005, betas=(0.9, 0.999), weight_decay=1e-5, clip_norm=1.0, alpha=0.999,
                  world_size=1, rank=0, prefetch=True, extra_lanes=(), depth=2, lanes=None, chunk=1, reserved_cus=0, cu_layout="interleaved",
-                 collectives=None):
+                 collectives=None, ahead=None):
         """``sampler``/``posemb``: producer lane 0; ``extra_lanes``: more (sampler, posemb) pairs with their own
         workspaces for multi-stream prefetch (see :class:`BatchProducer`)."""
         self.model, self.ema, self.contrast = model, model_ema, contrast
@@ -217,6 +223,11 @@ class MoCoTrainStep:
         self.mask_fn = None          # tests inject explicit dropout keep-masks here; default = in-kernel Philox
         self.dropout_seed = 0x5EED0000
         self.B = sampler.batch_size
+        if contrast.queueSize < self.B * world_size:
+            # memory_moco.py:55-61 enqueues all keys of a step with fmod indices; more keys than queue rows would make
+            # rows collide (the reference's index_copy_ result is then order dependent), gcc_queue_enqueue refuses it
+            raise ValueError(f"nce_k = {contrast.queueSize} is smaller than the {self.B * world_size} keys enqueued per step "
+                             f"(batch_size {self.B} x world {world_size}): raise --nce-k")
         self.L = len(model.gnn.ginlayers)
         self.keys_all = torch.empty(self.B * world_size, H, device=self.dev) if self.collectives else None
         self.one = torch.ones(1, device=self.dev)
@@ -227,7 +238,8 @@ class MoCoTrainStep:
         lanes = list(lanes) if lanes is not None else [(sampler, posemb)] + list(extra_lanes)
         self.producer = BatchProducer(lanes if self.prefetch else lanes[:1], self._first_id,
                                       self.dev if self.prefetch else "cpu", depth=depth if self.prefetch else 1,
-                                      chunk=chunk if self.prefetch else 1, reserved_cus=reserved_cus, cu_layout=cu_layout)
+                                      chunk=chunk if self.prefetch else 1, reserved_cus=reserved_cus, cu_layout=cu_layout,
+                                      ahead=ahead)
         if not self.prefetch:
             self.producer.cuda = False
         model.train()                                                    # train.py:357-365
@@ -238,6 +250,41 @@ class MoCoTrainStep:
 
     def _first_id(self, step):
         return (step * self.world + self.rank) * self.B
+
+    def check_status(self, strict_posemb=False):
+        """Synchronising check of the device status words of EVERY producer lane: sampler overflows (scratch / node /
+        edge capacity) and refused positional embeddings raise -- the pack kernel leaves a valid but truncated
+        subgraph behind and the eigensolver zeros, so training on them would be silent otherwise.  Returns the OR of
+        the positional-embedding flag words (bit 8 = an eigen-iteration stopped at its restart cap)."""
+        flags = 0
+        for lane in self.producer.lanes:
+            smp, pe = lane[0], lane[1]
+            if hasattr(smp, "check_status"):
+                smp.check_status()
+            if hasattr(pe, "check_status"):
+                flags |= int(pe.check_status(strict=strict_posemb) or 0)
+        return flags
+
+    # collectives: RCCL on device buffers.  Only when several ranks share one device (bench.py --gpus N on a box with
+    # fewer GPUs: a correctness run over gloo) are the same buffers staged through the host.
+    def _staged(self):
+        return self.dev.type == "cuda" and torch.distributed.get_backend() == "gloo"
+
+    def _all_gather(self, out, x):
+        if self._staged():
+            o, xi = out.cpu(), x.cpu()
+            torch.distributed.all_gather_into_tensor(o, xi)
+            out.copy_(o)
+        else:
+            torch.distributed.all_gather_into_tensor(out, x)
+
+    def _all_reduce(self, x):
+        if self._staged():
+            xi = x.cpu()
+            torch.distributed.all_reduce(xi)
+            x.copy_(xi)
+        else:
+            torch.distributed.all_reduce(x)
 
     # ---- one step
     def step(self, step, lr, prof=None):
@@ -266,7 +313,7 @@ class MoCoTrainStep:
         outs = self.nce.forward(feat_q, feat_k, c.memory, c.T, 0, stream=st, prof=pr.get("nce_fwd"))   # train.py:393,407
         keys = feat_k
         if self.collectives:                                             # RCCL all-gather of keys over xGMI
-            torch.distributed.all_gather_into_tensor(self.keys_all, feat_k)
+            self._all_gather(self.keys_all, feat_k)
             keys = self.keys_all
         index = c.index
         saved = self.nce.enqueue(c.memory, keys, index, save=True, stream=st)
@@ -275,7 +322,7 @@ class MoCoTrainStep:
                                stream=st, prof=pr.get("nce_bwd"))         # loss.backward(), train.py:408
         self.gin.backward(self.model, pq, bufq, dq, targets=self.grad_views, stream=st, prof=pr.get("gin_bwd"))
         if self.collectives:
-            torch.distributed.all_reduce(self.flat_grad)                # one flat bucket (248 KiB) over xGMI
+            self._all_reduce(self.flat_grad)                             # one flat bucket (248 KiB) over xGMI
             self.flat_grad.mul_(1.0 / self.world)
         for grp in self.optimizer.param_groups:                          # train.py:411-416
             grp["lr"] = lr

@@ -8,8 +8,9 @@ same per-step semantics (train.py:378-434), executed by the MI355X-native hot
 path of gcc_amd.  Out of scope: --finetune / --cv (downstream
 supervised loops) and the non-"dgl" evaluation datasets.
 
-Extra flags (not in the reference): --graph-npz / --synthetic choose the
-pre-training graph because DGL .bin ingestion is a later row.
+The pre-training corpus ./data/small.bin (a DGL graph file, train.py:552) is read
+without DGL (gcc_amd/ingest.py).  Extra flags (not in the reference): --dgl-file,
+--graph-npz / --synthetic choose another pre-training graph.
 Multi-GPU: launch with torch.distributed.run; the seed batch is sharded by rank,
 keys are all-gathered before the enqueue, gradients are all-reduced (RCCL).
 """
@@ -114,11 +115,12 @@ def parse_option(argv=None):
     parser.add_argument("--cv", action="store_true")
 
     # ---- not in the reference: where the pre-training graph comes from
+    parser.add_argument("--dgl-file", type=str, default="./data/small.bin", help="DGL graph file of the pre-training corpus (train.py:552 hard-codes this path)")
     parser.add_argument("--graph-npz", type=str, default=None, help="npz with row_ptr/col_idx (instead of data/small.bin)")
     parser.add_argument("--synthetic", type=str, default=None, help="V,E of a synthetic power-law graph, e.g. 1000000,10000000")
     parser.add_argument("--max-steps", type=int, default=0, help="stop after this many steps (0 = full schedule)")
     parser.add_argument("--producer-lanes", type=int, default=3, help="data-pipeline streams (the GPU's command processor serves few queues well)")
-    parser.add_argument("--producer-chunk", type=int, default=16, help="steps a lane prepares per turn (2x as many views per eigensolver call, <= 32)")
+    parser.add_argument("--producer-chunk", type=int, default=4, help="steps a lane prepares per turn (2x as many views per eigensolver call, <= 32)")
     # fmt: on
 
     opt = parser.parse_args(argv)
@@ -173,7 +175,7 @@ def _load_graph(args):
     if args.synthetic:
         v, e = (int(x) for x in args.synthetic.split(","))
         return powerlaw_graph(v, e, seed=0)
-    raise SystemExit("./data/small.bin is a DGL file (needs DGL, not installed): pass --graph-npz or --synthetic V,E")
+    return None                                           # ./data/small.bin, read by LoadBalanceGraphDataset (train.py:552)
 
 
 def train_moco(epoch, dataset, trainer, model, model_ema, contrast, criterion, optimizer, sw, opt, posemb):
@@ -185,6 +187,12 @@ def train_moco(epoch, dataset, trainer, model, model_ema, contrast, criterion, o
     max_num_nodes = max_num_edges = 0
     end = time.time()
     it = None if trainer is not None else iter(dataset)
+    # every step's loss / prob / gnorm / graph sizes are accumulated ON THE DEVICE (no host sync) and read back when
+    # a log line is due, so the meters cover all steps like the reference's (which synchronises every step, :433)
+    dev = next(model.parameters()).device
+    acc = torch.zeros(6, dtype=torch.float64, device=dev)      # sums: loss, prob, gnorm, nodes(q+k), steps; [5] unused
+    mx = torch.zeros(2, dtype=torch.int32, device=dev)         # max nodes, max edges of a q view
+    one = torch.ones(1, dtype=torch.float64, device=dev)
     for idx in range(n_batch):
         global_step = epoch * n_batch + idx
         lr_this_step = opt.learning_rate * warmup_linear(global_step / (opt.epochs * n_batch), 0.1)   # :411-414
@@ -209,17 +217,26 @@ def train_moco(epoch, dataset, trainer, model, model_ema, contrast, criterion, o
             for param_group in optimizer.param_groups:
                 param_group["lr"] = lr_this_step
             optimizer.step()
-        want_log = (idx + 1) % opt.print_freq == 0 or (idx + 1) % opt.tb_freq == 0
-        if want_log:                                     # the reference synchronises every step (train.py:433)
-            torch.cuda.synchronize()
-            loss_meter.update(float(loss), bsz)
-            epoch_loss_meter.update(float(loss), bsz)
-            prob_meter.update(float(prob), bsz)
-            nq, nk = graph_q.number_of_nodes(), graph_k.number_of_nodes()
-            graph_size.update((nq + nk) / 2.0 / bsz, 2 * bsz)
-            gnorm_meter.update(float(grad_norm), 1)
-            max_num_nodes = max(max_num_nodes, nq)
-            max_num_edges = max(max_num_edges, graph_q.number_of_edges())
+        B_ = graph_q.batch_size
+        nodes_qk = (graph_q.node_off[B_] + graph_k.node_off[B_]).to(torch.float64).reshape(1)
+        acc[:5] += torch.cat([loss.detach().reshape(1).double(), prob.detach().reshape(1).double(),
+                              torch.as_tensor(grad_norm, device=dev).detach().reshape(1).double(), nodes_qk, one])
+        mx.copy_(torch.maximum(mx, torch.stack([graph_q.node_off[B_], graph_q.edge_off[B_]])))
+        want_log = (idx + 1) % opt.print_freq == 0 or (idx + 1) % opt.tb_freq == 0 or idx + 1 == n_batch \
+            or (opt.max_steps and (epoch - 1) * n_batch + idx + 1 >= opt.max_steps)
+        if want_log:                                     # one read-back per log line
+            a = acc.tolist()
+            m = mx.tolist()
+            acc.zero_()
+            mx.zero_()
+            cnt = max(int(a[4]), 1)
+            loss_meter.update(a[0] / cnt, bsz * cnt)
+            epoch_loss_meter.update(a[0] / cnt, bsz * cnt)
+            prob_meter.update(a[1] / cnt, bsz * cnt)
+            graph_size.update(a[3] / cnt / 2.0 / bsz, 2 * bsz * cnt)
+            gnorm_meter.update(a[2] / cnt, cnt)
+            max_num_nodes = max(max_num_nodes, m[0])
+            max_num_edges = max(max_num_edges, m[1])
         batch_time.update(time.time() - end)
         end = time.time()
         if (idx + 1) % opt.print_freq == 0:
@@ -257,6 +274,9 @@ def main(args):
                                   "pre-training path (SURVEY.md §2.1 #5, #7)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not args.moco:
+        raise NotImplementedError("only the MoCo step is data parallel (seed batch sharded by rank, key all-gather, gradient "
+                                  "all-reduce); the E2E / --nce-k 0 path would train N identical replicas: run it on one GPU")
     checkpoint = None
     if args.resume:                                       # train.py:487-506
         if os.path.isfile(args.resume):
@@ -264,7 +284,7 @@ def main(args):
             checkpoint = torch.load(args.resume, map_location="cpu", weights_only=False)
             pretrain_args = checkpoint["opt"]
             for name in ("fold_idx", "gpu", "finetune", "resume", "cv", "dataset", "epochs", "num_workers",
-                         "batch_size", "graph_npz", "synthetic", "max_steps", "producer_lanes", "producer_chunk"):
+                         "batch_size", "dgl_file", "graph_npz", "synthetic", "max_steps", "producer_lanes", "producer_chunk"):
                 setattr(pretrain_args, name, getattr(args, name))
             args = pretrain_args
         else:
@@ -280,12 +300,11 @@ def main(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=dev)
 
-    row_ptr, col_idx = _load_graph(args)
     train_dataset = LoadBalanceGraphDataset(                 # train.py:547-556
         rw_hops=args.rw_hops, restart_prob=args.restart_prob,
         positional_embedding_size=args.positional_embedding_size, num_workers=args.num_workers,
-        num_samples=args.num_samples, dgl_graphs_file="./data/small.bin", num_copies=args.num_copies,
-        graph=(row_ptr, col_idx), batch_size=args.batch_size, run_seed=args.seed, device=dev)
+        num_samples=args.num_samples, dgl_graphs_file=args.dgl_file, num_copies=args.num_copies,
+        graph=_load_graph(args), batch_size=args.batch_size, run_seed=args.seed, device=dev)
 
     model, model_ema = [
         GraphEncoder(                                      # train.py:601-620
@@ -307,8 +326,7 @@ def main(args):
         raise NotImplementedError("the fused step implements the default optimizer (adam, train.py:55)")
     from gcc_amd.posemb import DevicePosEmb
 
-    posemb = DevicePosEmb(args.batch_size, train_dataset.sampler.node_cap, args.positional_embedding_size,
-                          device=dev, seed=args.seed)
+    posemb = None                                         # E2E path only; the MoCo path embeds in its producer lanes
     trainer, optimizer = None, None
     if args.moco:
         # data pipeline: `producer_lanes` streams, each preparing `producer_chunk` steps per turn (sampler calls + one
@@ -328,6 +346,8 @@ def main(args):
                                 world_size=world, rank=rank, lanes=lanes, depth=depth, chunk=args.producer_chunk)
         optimizer = trainer.optimizer
     else:
+        posemb = DevicePosEmb(args.batch_size, train_dataset.node_cap, args.positional_embedding_size,
+                              device=dev, seed=args.seed)
         optimizer = torch.optim.Adam(model.parameters(), lr=args.learning_rate, betas=(args.beta1, args.beta2),
                                      weight_decay=args.weight_decay)
         model.train()
@@ -351,6 +371,13 @@ def main(args):
                           posemb)
         torch.cuda.synchronize()
         print("epoch {}, total time {:.2f}".format(epoch, time.time() - time1))
+        # overflow / refusal flags of everything that produced this epoch's batches, BEFORE the checkpoint is written:
+        # "raises, never truncates"
+        if trainer is not None:
+            trainer.check_status()
+        else:
+            train_dataset.sampler.check_status()
+            posemb.check_status()
         if rank == 0:                                     # train.py:748-786
             state = {"opt": args, "model": model.state_dict(), "contrast": contrast.state_dict(),
                      "optimizer": optimizer.state_dict(), "epoch": epoch}
@@ -362,7 +389,6 @@ def main(args):
             del state
         if args.max_steps:
             break
-    train_dataset.sampler.check_status()
     if world > 1:
         torch.distributed.destroy_process_group()
     return loss
