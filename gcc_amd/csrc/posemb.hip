@@ -466,9 +466,17 @@ __device__ bool inverse_iteration_step(const TriLds &w, int n, int j, int jl, fl
 // in coef[.][32]); a second pass follows only where the first one removed more than half of a vector ("twice is
 // enough", Kahan / Parlett).  Returns (block-uniform) the number of vectors that vanished, i.e. were in the span of
 // their predecessors.  All threads call it; ends with a barrier.
+constexpr float kVanish = 1e-4f;     // squared norm left of a unit vector below which it counts as "in the span of its predecessors"
+constexpr float kHeavy = 1e-2f;      // ... below which what is left is too noisy to be final
+
+// Returns (block-uniform) the number of vectors that vanished, i.e. were in the span of their predecessors; those are
+// refilled with fresh pseudo-random numbers (LAPACK stein restarts them the same way) and *min_left is the smallest
+// squared norm any member kept (1 = nothing removed).  All threads call it; ends with a barrier.
 template <int kT>
-__device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int *cs, const int *posi, int maxpos)
+__device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int *cs, const int *posi, int maxpos,
+                                      float *min_left, uint32_t hseed)
 {
+    *min_left = 1.0f;
     constexpr int kNW = kT / 64;
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float *Y = w.Y, *coef = w.coef;
@@ -477,16 +485,18 @@ __device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int 
     if (tid < na) coef[tid * ldy + nc] = 1.0f;      // squared norms: unit vectors come out of the solves
     __syncthreads();
     int lost = 0;
+    float left = 1.0f;
     for (int t = 1; t <= maxpos; ++t) {
         for (int pass = 0; pass < 2; ++pass) {
-            // projections on the predecessors in the cluster
+            // projections on the predecessors in the cluster (a vanished predecessor spans nothing)
             for (int j = 0; j < na; ++j) {
                 if (posi[j] != t) continue;
                 for (int l = cs[j] + wv; l < j; l += kNW) {
                     float s = 0.f;
                     for (int r = lane; r < n; r += 64) s = fmaf(Y[r * ldy + j], Y[r * ldy + l], s);
                     s = wave_sum(s);
-                    if (lane == 0) coef[j * ldy + l] = s / fmaxf(coef[l * ldy + nc], 1e-30f);
+                    const float nl = coef[l * ldy + nc];
+                    if (lane == 0) coef[j * ldy + l] = nl >= kVanish ? s / nl : 0.f;
                 }
             }
             __syncthreads();
@@ -516,16 +526,26 @@ __device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int 
             if (!again) break;
         }
         __syncthreads();
-        for (int j = 0; j < na; ++j)
-            if (posi[j] == t && coef[j * ldy + nc] < 1e-6f) ++lost;
+        for (int j = 0; j < na; ++j) {
+            if (posi[j] != t) continue;
+            const float c = coef[j * ldy + nc];
+            left = c < left ? c : left;
+            if (c < kVanish) ++lost;
+        }
     }
-    // normalise the members of the clusters
+    // normalise the members of the clusters; vanished ones restart from pseudo-random numbers
     for (int j = 0; j < na; ++j) {
         if (posi[j] == 0) continue;
-        const float inv = 1.0f / sqrtf(fmaxf(coef[j * ldy + nc], 1e-30f));
-        for (int i = tid; i < n; i += kT) Y[i * ldy + j] *= inv;
+        const float c = coef[j * ldy + nc];
+        if (c < kVanish) {
+            for (int i = tid; i < n; i += kT) Y[i * ldy + j] = hash_unit(hseed, (uint32_t)j, (uint32_t)i);
+        } else {
+            const float inv = 1.0f / sqrtf(c);
+            for (int i = tid; i < n; i += kT) Y[i * ldy + j] *= inv;
+        }
     }
     __syncthreads();
+    *min_left = left;
     return lost;
 }
 
@@ -607,7 +627,14 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
     __syncthreads();
     const int maxpos = es.maxpos;
     int lost = 0;
-    for (int it = 0; it < 3; ++it) {
+    // Three solves as a rule.  A Gram-Schmidt sweep that cancels most of a cluster member leaves the other eigenvectors'
+    // admixture (one factor displacement / gap ~ 1e-2 per solve) magnified by the cancellation: the last of 16 copies of
+    // 1/sqrt(2) in a hub ego-net came out with 1.5e-3 of an eigenvector 3e-3 away.  So a member that kept less than 1 %
+    // of its squared norm buys one more solve + sweep round, and a vanished one (span of its predecessors: the 16 start
+    // vectors of a 16-dimensional eigenspace are never well conditioned) restarts from random numbers and buys three --
+    // LAPACK's stein iterates on the same criterion.
+    int need_until = 2;
+    for (int it = 0; it < 8; ++it) {
         for (int j0 = 0; j0 < na; j0 += w.bw) {
             if (tid < w.bw && j0 + tid < na) {
                 const bool ok = inverse_iteration_step(w, nr, j0 + tid, tid, es.shiftv[j0 + tid], it == 0, hseed);
@@ -616,8 +643,14 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
             __syncthreads();
         }
         phase_tick(tick_row, 3, tick);             // inverse iteration
-        if (it > 0) lost = cluster_orthonormalize<kT>(w, nr, na, es.cs, es.posi, maxpos);   // the first solve only enters
-        phase_tick(tick_row, 4, tick);             // the cluster subspaces
+        if (it > 0) {                              // the first solve only enters the cluster subspaces
+            float left;
+            lost = cluster_orthonormalize<kT>(w, nr, na, es.cs, es.posi, maxpos, &left, hseed ^ (0x51ED27u * (uint32_t)(it + 1)));
+            if (lost > 0) need_until = it + 3 > need_until ? it + 3 : need_until;
+            else if (left < kHeavy) need_until = it + 1 > need_until ? it + 1 : need_until;
+        }
+        phase_tick(tick_row, 4, tick);
+        if (it >= need_until) break;
     }
     for (int j = 2 * wv; j < na; j += 2 * kNW) {
         const bool two = j + 1 < na;

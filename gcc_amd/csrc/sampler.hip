@@ -9,25 +9,28 @@
 // bit-exact against that oracle.
 //
 // Kernels (G = 2B subgraphs, g = view * B + b):
-//   rwr_walk_kernel   1 wave per subgraph.  Walk lengths depend on the RNG only
-//                     (no dead ends by contract), so 64 lanes run 64 walks at a
-//                     time and a wave prefix sum over the lengths reproduces the
-//                     sequential "stop after exactly L visited nodes" rule
-//                     exactly.  Trace in LDS -> bitonic sort -> unique -> seed
-//                     first; row extents of every member are fetched here.
-//   induce_kernel     work unit = a 256-edge SEGMENT of a member's parent row (4
-//                     coalesced dword loads per lane in flight); a subgraph gets
-//                     ceil(segments / 16) virtual workgroups (device-side prefix +
-//                     binary search), so hub-seed subgraphs with 10x the edges get
-//                     10x the workgroups and every wave does <= 4 segments.  LDS hash
-//                     map parent id -> local id; hits are ballot-compacted per
-//                     segment in parent-row order (DGL VertexSubgraph) into that
-//                     segment's scratch slot.  (Round-1 profile: the previous
-//                     row-per-wave version was bound by one wave doing 78 iterations
-//                     vs 5.5 on average: 2 % of the HBM roof.)
-//   pack_kernel       1 workgroup per subgraph: prefix sums over subgraphs
-//                     (dgl.batch offsets), row_ptr/col_idx with batched ids,
-//                     parent_nid, graph_id.
+//   rwr_walk_kernel   1 workgroup of 4 waves per subgraph.  Walk lengths depend on
+//                     the RNG only (no dead ends by contract), so 256 threads run
+//                     256 walks at a time and a block prefix sum over the lengths
+//                     reproduces the sequential "stop after exactly L visited
+//                     nodes" rule exactly.  Trace in LDS -> bitonic sort -> unique
+//                     -> seed first; row extents of every member and the prefix of
+//                     the rows' 16-byte QUADS of col_idx are written here.
+//   induce_kernel     DGL VertexSubgraph = scan every member's parent row for
+//                     members (a sub-scan by binary search would touch the same
+//                     cache lines: a subgraph has more members than a hub row has
+//                     128-byte lines).  The rows of a subgraph form one flat space
+//                     of aligned quads; a UNIT = 256 consecutive quads (1024 edges)
+//                     = one wave x 4 coalesced dwordx4 loads per lane, all in
+//                     flight together; a virtual workgroup = 8 units.  Members sit
+//                     in an LDS Bloom bitmap (>= 64 bits per member): 98.5 % of the
+//                     neighbours are non-members and cost one LDS word; survivors
+//                     are queued per wave and looked up exactly (binary search in
+//                     the sorted member list) in dense passes; hits go, in parent
+//                     order, to the unit's private scratch slot.  No barrier and no
+//                     atomics on shared counters inside the scan.
+//   pack_kernel       prefix sums over subgraphs and units (dgl.batch offsets),
+//                     row_ptr/col_idx with batched ids, parent_nid, graph_id.
 // HBM-bound integer work; no MFMA anywhere in this file.
 #include "device_compat.h"
 #include "../../include/gcc_amd.h"
@@ -37,10 +40,14 @@
 namespace {
 
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-constexpr int kSeg = 256;           // parent edges per segment (64 lanes x 4 loads)
-constexpr int kSegPerWg = 16;      // segments per virtual workgroup (4 per wave)
+constexpr int kWalkThreads = 256;  // 4 waves per subgraph
+constexpr int kUnitQuads = 256;    // 16-byte quads of col_idx per unit: 64 lanes x 4 dwordx4 loads
+constexpr int kUnitElems = 4 * kUnitQuads;
+constexpr int kUnitsPerVwg = 8;    // units per virtual workgroup (2 per wave)
 constexpr int kInduceThreads = 256;
-constexpr int kPackParts = 4;      // pack workgroups per subgraph (hub-seed subgraphs have 10x the rows/edges)
+constexpr int kCandCap = 512;      // per-wave queue of Bloom survivors (drained when the next 256 might not fit)
+constexpr int kPackParts = 4;      // pack workgroups per subgraph (hub-seed subgraphs have 100x the units)
+constexpr uint32_t kHashMul = 0x9E3779B1u;
 
 __device__ __forceinline__ int pow2_ceil(int v)
 {
@@ -53,26 +60,26 @@ __device__ __forceinline__ int pow2_ceil(int v)
 struct Work {
     int32_t *seeds;       // [B]
     int32_t *sub_n;       // [G]
-    int32_t *sub_cap;     // [G]   scratch slots: sum_i row_slots(deg_i, n)
-    int32_t *sub_seg;     // [G]   number of row segments
+    int32_t *sub_quads;   // [G]   aligned quads of col_idx covered by the member rows
     int32_t *sub_nnz;     // [G]
     int32_t *nodes;       // [G][ncap]   parent ids, seed first
     int32_t *rowbeg;      // [G][ncap]   row_ptr[node]
     int32_t *rowdeg;      // [G][ncap]   parent degree
-    int32_t *rowoff;      // [G][ncap]   exclusive prefix of the rows' segment counts within the subgraph (walk kernel)
-    int32_t *rowcap;      // [G][ncap]   exclusive prefix of the rows' scratch slots within the subgraph (walk kernel)
-    int32_t *rowcnt;      // [G][ncap]   induced degree
+    int32_t *rowq;        // [G][ncap]   exclusive prefix of the rows' quads within the subgraph (walk kernel)
     int32_t *vbp;         // [G + 1]     exclusive prefix of the subgraphs' virtual workgroups   (prefix kernel A)
+    int32_t *ubp;         // [G + 1]     exclusive prefix of the subgraphs' units                (prefix kernel A)
     long long *sbp;       // [G + 1]     exclusive prefix of the subgraphs' scratch slots        (prefix kernel A)
     int32_t *nbp;         // [G + 1]     node offset of a subgraph inside its view's batch       (prefix kernel A)
     int32_t *ebp;         // [G + 1]     edge offset of a subgraph inside its view's batch       (prefix kernel B)
-    int32_t *scratch;     // [scratch_entries] local col ids, row-sparse
+    int32_t *ucnt;        // [unit_cap]  hits of every unit
+    int32_t *scratch;     // [scratch_entries] hits: (row << 16) | local column, one slot of 1024 per unit
     int32_t ncap;
+    int64_t unit_cap;
 };
 
 struct WorkLayout {
-    int64_t off_seeds, off_n, off_cap, off_seg, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowoff, off_rowcap,
-        off_rowcnt, off_vbp, off_sbp, off_nbp, off_ebp, off_scratch, total;
+    int64_t off_seeds, off_n, off_quads, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowq,
+        off_vbp, off_ubp, off_sbp, off_nbp, off_ebp, off_ucnt, off_scratch, total, unit_cap;
     int32_t ncap;
 };
 
@@ -82,22 +89,22 @@ inline WorkLayout work_layout(int32_t lmax, int32_t B, int64_t scratch_entries)
     auto al = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
     const int64_t G = 2 * (int64_t)B;
     w.ncap = ((lmax + 1 + 63) / 64) * 64;
+    w.unit_cap = scratch_entries / kUnitElems + G + 1;    // a unit owns up to 1024 scratch slots; the last unit of a subgraph fewer
     int64_t o = 0;
     w.off_seeds = o;  o = al(o + 4 * (int64_t)B);
     w.off_n = o;      o = al(o + 4 * G);
-    w.off_cap = o;    o = al(o + 4 * G);
-    w.off_seg = o;    o = al(o + 4 * G);
+    w.off_quads = o;  o = al(o + 4 * G);
     w.off_nnz = o;    o = al(o + 4 * G);
     w.off_nodes = o;  o = al(o + 4 * G * w.ncap);
     w.off_rowbeg = o; o = al(o + 4 * G * w.ncap);
     w.off_rowdeg = o; o = al(o + 4 * G * w.ncap);
-    w.off_rowoff = o; o = al(o + 4 * G * w.ncap);
-    w.off_rowcap = o; o = al(o + 4 * G * w.ncap);
-    w.off_rowcnt = o; o = al(o + 4 * G * w.ncap);
+    w.off_rowq = o;   o = al(o + 4 * G * w.ncap);
     w.off_vbp = o;    o = al(o + 4 * (G + 1));
+    w.off_ubp = o;    o = al(o + 4 * (G + 1));
     w.off_sbp = o;    o = al(o + 8 * (G + 1));
     w.off_nbp = o;    o = al(o + 4 * (G + 1));
     w.off_ebp = o;    o = al(o + 4 * (G + 1));
+    w.off_ucnt = o;   o = al(o + 4 * w.unit_cap);
     w.off_scratch = o; o = al(o + 4 * scratch_entries);
     w.total = o;
     return w;
@@ -108,19 +115,39 @@ struct BatchOutDev {
     int64_t node_cap, edge_cap;
 };
 
-__device__ __forceinline__ int row_slots(int deg, int n);
+// inclusive prefix sum over the workgroup's threads (thread order); *total = sum.  All threads call; wsum: LDS [5].
+__device__ __forceinline__ int block_scan_incl(int v, int *total, int32_t *wsum)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int incl = wave_scan_incl(v);
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int base = 0, all = 0;
+    const int nw = (int)blockDim.x >> 6;
+    for (int k = 0; k < nw; ++k) {
+        const int t = wsum[k];
+        base += k < wv ? t : 0;
+        all += t;
+    }
+    __syncthreads();
+    *total = all;
+    return base + incl;
+}
+
+__device__ __forceinline__ int row_quads(int rb, int d) { return ((rb + d + 3) >> 2) - (rb >> 2); }
 
 // ------------------------------------------------------------------ K1 ----
-__global__ __launch_bounds__(64) void rwr_walk_kernel(
+__global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
     const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
     const double *__restrict__ seed_cdf, const int32_t *__restrict__ ltab, int64_t num_nodes,
     int32_t ltab_len, int32_t p2max, uint64_t run_seed, int64_t first_sample_id, int32_t B,
     uint32_t restart_u32, const int32_t *__restrict__ seeds_in, Work w)
 {
     DYN_SMEM(smem);
-    uint32_t *buf = (uint32_t *)smem;        // [p2max] trace -> sorted trace
-    int32_t *ldeg = (int32_t *)smem + p2max; // [p2max + 64] parent degree of kept nodes (n <= L + 1)
-    const int lane = lane_id();
+    __shared__ int32_t wsum[5];
+    uint32_t *buf = (uint32_t *)smem;          // [p2max] trace -> sorted trace
+    int32_t *lq = (int32_t *)smem + p2max;     // [p2max + 64] quads of the kept rows (n <= L + 1)
+    const int tid = (int)threadIdx.x;
     const int g = (int)blockIdx.x;
     const int view = g / B, b = g - view * B;
     const uint64_t sid = (uint64_t)(first_sample_id + b);
@@ -135,14 +162,15 @@ __global__ __launch_bounds__(64) void rwr_walk_kernel(
                       (uint32_t)(run_seed >> 32) ^ 0x00A11CE5u, x);
         const uint64_t u53 = ((uint64_t)x[0] << 21) | (uint64_t)(x[1] >> 11);
         const double u = (double)u53 * (1.0 / 9007199254740992.0);
-        // wave-cooperative 64-ary upper bound: first index with cdf[i] > u
+        // workgroup-cooperative 256-ary upper bound: first index with cdf[i] > u (1M entries: 3 rounds)
         int64_t lo = 0, hi = num_nodes;
         while (lo < hi) {
             const int64_t len = hi - lo;
-            const int64_t step = (len + 63) >> 6;
-            const int64_t idx = lo + (int64_t)lane * step;
+            const int64_t step = (len + kWalkThreads - 1) / kWalkThreads;
+            const int64_t idx = lo + (int64_t)tid * step;
             const bool le = (idx < hi) && (seed_cdf[idx] <= u);
-            const int k = __popcll(wave_ballot(le));   // monotone: first k lanes true
+            int k;
+            (void)block_scan_incl(le ? 1 : 0, &k, wsum);       // monotone: the first k threads are true
             if (k == 0) { hi = lo; break; }
             const int64_t nhi = lo + (int64_t)k * step;
             lo = lo + (int64_t)(k - 1) * step + 1;
@@ -150,96 +178,77 @@ __global__ __launch_bounds__(64) void rwr_walk_kernel(
         }
         seed = (int32_t)(lo < num_nodes ? lo : num_nodes - 1);
     }
-    if (view == 0 && lane == 0) w.seeds[b] = seed;
+    if (view == 0 && tid == 0) w.seeds[b] = seed;
 
     const int32_t rp0 = row_ptr[seed];
     const int32_t deg0 = row_ptr[seed + 1] - rp0;
     const int32_t L = ltab[deg0 < ltab_len ? deg0 : ltab_len - 1];   // graph_dataset.py:113-124
     const int p2 = pow2_ceil(L);
 
-    for (int i = lane; i < p2; i += 64) buf[i] = kEmpty;
-    wave_sync();
+    for (int i = tid; i < p2; i += kWalkThreads) buf[i] = kEmpty;
+    __syncthreads();
 
-    // ---- walks: graph_dataset.py:125-130 (DGL random_walk_with_restart)
+    // ---- walks: graph_dataset.py:125-130 (DGL random_walk_with_restart); walk id = base + thread
     const uint64_t gid = sid * 2u + (uint64_t)view;
     const uint32_t k0 = (uint32_t)run_seed, k1 = (uint32_t)(run_seed >> 32);
     const uint32_t g0 = (uint32_t)gid, g1 = (uint32_t)(gid >> 32);
-    int total = 0;   // wave-uniform: trace entries assigned so far
-    for (int base = 0; total < L; base += 256) {
-        uint32_t x0[4][4];
-        int len[4], off[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t walk = (uint32_t)(base + j * 64 + lane);
-            philox4x32_10(walk, 0u, g0, g1, k0, k1, x0[j]);
-            // len = min{t >= 1 : word[2t-1] < restart_u32}, capped at L
-            int l = 1;
-            if (x0[j][1] >= restart_u32) {
-                l = 2;
-                if (x0[j][3] >= restart_u32) {
-                    l = 3;
-                    uint32_t y[4];
-                    for (uint32_t blk = 1; l < L; ++blk) {
-                        philox4x32_10(walk, blk, g0, g1, k0, k1, y);
-                        if (y[1] < restart_u32) break;
-                        ++l;
-                        if (l >= L || y[3] < restart_u32) break;
-                        ++l;
-                    }
+    int total = 0;   // block-uniform: trace entries assigned so far
+    for (int base = 0; total < L; base += kWalkThreads) {
+        const uint32_t walk = (uint32_t)(base + tid);
+        uint32_t x0[4];
+        philox4x32_10(walk, 0u, g0, g1, k0, k1, x0);
+        // len = min{t >= 1 : word[2t-1] < restart_u32}, capped at L
+        int len = 1;
+        if (x0[1] >= restart_u32) {
+            len = 2;
+            if (x0[3] >= restart_u32) {
+                len = 3;
+                uint32_t y[4];
+                for (uint32_t blk = 1; len < L; ++blk) {
+                    philox4x32_10(walk, blk, g0, g1, k0, k1, y);
+                    if (y[1] < restart_u32) break;
+                    ++len;
+                    if (len >= L || y[3] < restart_u32) break;
+                    ++len;
                 }
             }
-            len[j] = l;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int incl = wave_scan_incl(len[j]);
-            off[j] = total + incl - len[j];
-            total += wave_shfl(incl, 63);
-        }
-        // first step of every walk that is (at least partly) inside the budget
-        int32_t cur[4];
-        int allowed[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int a = L - off[j];
-            a = a < 0 ? 0 : (a > len[j] ? len[j] : a);
-            allowed[j] = a;
-            cur[j] = seed;
-            if (a > 0) cur[j] = col_idx[rp0 + (int32_t)__umulhi(x0[j][0], (uint32_t)deg0)];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (allowed[j] > 0) buf[off[j]] = (uint32_t)cur[j];
-            if (allowed[j] > 1) {
-                const uint32_t walk = (uint32_t)(base + j * 64 + lane);
-                uint32_t y[4] = {x0[j][0], x0[j][1], x0[j][2], x0[j][3]};
-                uint32_t yblk = 0;
-                int32_t c = cur[j];
-                for (int t = 1; t < allowed[j]; ++t) {
-                    const uint32_t blk = (uint32_t)t >> 1;      // word 2t lives in block t/2
-                    if (blk != yblk) { philox4x32_10(walk, blk, g0, g1, k0, k1, y); yblk = blk; }
-                    const uint32_t r = (t & 1) ? y[2] : y[0];
-                    const int32_t beg = row_ptr[c];
-                    const int32_t d = row_ptr[c + 1] - beg;
-                    c = col_idx[beg + (int32_t)__umulhi(r, (uint32_t)d)];
-                    buf[off[j] + t] = (uint32_t)c;
-                }
+        int sum;
+        const int incl = block_scan_incl(len, &sum, wsum);
+        const int off = total + incl - len;
+        total += sum;
+        // the part of this walk that is inside the budget
+        int allowed = L - off;
+        allowed = allowed < 0 ? 0 : (allowed > len ? len : allowed);
+        if (allowed > 0) {
+            int32_t c = col_idx[rp0 + (int32_t)__umulhi(x0[0], (uint32_t)deg0)];
+            buf[off] = (uint32_t)c;
+            uint32_t y[4] = {x0[0], x0[1], x0[2], x0[3]};
+            uint32_t yblk = 0;
+            for (int t = 1; t < allowed; ++t) {
+                const uint32_t blk = (uint32_t)t >> 1;      // word 2t lives in block t/2
+                if (blk != yblk) { philox4x32_10(walk, blk, g0, g1, k0, k1, y); yblk = blk; }
+                const uint32_t r = (t & 1) ? y[2] : y[0];
+                const int32_t beg = row_ptr[c];
+                const int32_t d = row_ptr[c + 1] - beg;
+                c = col_idx[beg + (int32_t)__umulhi(r, (uint32_t)d)];
+                buf[off + t] = (uint32_t)c;
             }
         }
     }
-    wave_sync();
+    __syncthreads();
 
-    // ---- torch.unique (data_util.py:221): bitonic sort of the padded trace
+    // ---- torch.unique (data_util.py:221): bitonic sort of the padded trace, all four waves
     for (int k = 2; k <= p2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < (p2 >> 1); i += 64) {
+            for (int i = tid; i < (p2 >> 1); i += kWalkThreads) {
                 const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
                 const int hi = lo + j;
                 const bool up = (lo & k) == 0;
                 const uint32_t a = buf[lo], c = buf[hi];
                 if ((a > c) == up) { buf[lo] = c; buf[hi] = a; }
             }
-            wave_sync();
+            __syncthreads();
         }
     }
 
@@ -247,74 +256,43 @@ __global__ __launch_bounds__(64) void rwr_walk_kernel(
     int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
     int32_t *rowbeg = w.rowbeg + (int64_t)g * w.ncap;
     int32_t *rowdeg = w.rowdeg + (int64_t)g * w.ncap;
-    if (lane == 0) { nodes[0] = seed; rowbeg[0] = rp0; rowdeg[0] = deg0; ldeg[0] = deg0; }
-    int n = 1;   // wave-uniform
-    for (int i0 = 0; i0 < L; i0 += 64) {
-        const int i = i0 + lane;
+    if (tid == 0) { nodes[0] = seed; rowbeg[0] = rp0; rowdeg[0] = deg0; lq[0] = row_quads(rp0, deg0); }
+    int n = 1;   // block-uniform
+    for (int i0 = 0; i0 < L; i0 += kWalkThreads) {
+        const int i = i0 + tid;
         uint32_t v = kEmpty, prev = kEmpty;
         if (i < L) { v = buf[i]; if (i > 0) prev = buf[i - 1]; }
         const bool keep = (i < L) && (v != (uint32_t)seed) && (i == 0 || v != prev);
-        const unsigned long long m = wave_ballot(keep);
+        int kept;
+        const int incl = block_scan_incl(keep ? 1 : 0, &kept, wsum);
         if (keep) {
-            const int pos = n + __popcll(m & lanemask_lt());
+            const int pos = n + incl - 1;
             const int32_t rb = row_ptr[v];
             const int32_t d = row_ptr[v + 1] - rb;
             nodes[pos] = (int32_t)v;
             rowbeg[pos] = rb;
             rowdeg[pos] = d;
-            ldeg[pos] = d;
+            lq[pos] = row_quads(rb, d);
         }
-        n += __popcll(m);
+        n += kept;
     }
-    wave_sync();
-    // induction work units: row i contributes ceil(deg_i / kSeg) segments and row_slots() scratch slots
-    // (the per-row exclusive prefixes are kept: induce_kernel and pack_kernel would otherwise redo these scans in
-    // every workgroup)
-    int run = 0, slots = 0;
-    int32_t *rowoff = w.rowoff + (int64_t)g * w.ncap, *rowcap = w.rowcap + (int64_t)g * w.ncap;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int i = i0 + lane;
-        const int c = i < n ? (ldeg[i] + kSeg - 1) / kSeg : 0;
-        const int sl = i < n ? row_slots(ldeg[i], n) : 0;
-        const int ci = wave_scan_incl(c), si = wave_scan_incl(sl);
-        if (i < n) {
-            rowoff[i] = run + ci - c;
-            rowcap[i] = slots + si - sl;
-        }
-        run += wave_shfl(ci, 63);
-        slots += wave_shfl(si, 63);
+    __syncthreads();
+    // induction work: row i covers row_quads() aligned quads of col_idx; exclusive prefix per row
+    int run = 0;
+    int32_t *rowq = w.rowq + (int64_t)g * w.ncap;
+    for (int i0 = 0; i0 < n; i0 += kWalkThreads) {
+        const int i = i0 + tid;
+        const int c = i < n ? lq[i] : 0;
+        int sum;
+        const int incl = block_scan_incl(c, &sum, wsum);
+        if (i < n) rowq[i] = run + incl - c;
+        run += sum;
     }
-    if (lane == 0) {
+    if (tid == 0) {
         w.sub_n[g] = n;
-        w.sub_seg[g] = run;
-        w.sub_cap[g] = slots;
+        w.sub_quads[g] = run;
         w.sub_nnz[g] = 0;
     }
-}
-
-// sum of arr[begin, end) by the whole workgroup (all threads get the result)
-__device__ __forceinline__ long long block_range_sum(const int32_t *arr, int begin, int end, long long *red)
-{
-    long long s = 0;
-    for (int i = begin + (int)threadIdx.x; i < end; i += (int)blockDim.x) s += arr[i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int d = (int)blockDim.x >> 1; d > 0; d >>= 1) {
-        if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
-        __syncthreads();
-    }
-    const long long r = red[0];
-    __syncthreads();
-    return r;
-}
-
-// scratch slots of one member row: every segment = 1 count header + at most min(segment length, n) hits
-__device__ __forceinline__ int row_slots(int deg, int n)
-{
-    const int nseg = (deg + kSeg - 1) / kSeg;
-    const int full = n < kSeg ? n : kSeg;
-    const int rem = deg - (nseg - 1) * kSeg;
-    return nseg + (nseg - 1) * full + (rem < n ? rem : n);
 }
 
 // block-wide exclusive scan of vals over [0, count) into LDS out[0..count] (out[count] = total);
@@ -358,10 +336,12 @@ __device__ __forceinline__ int upper_slot(const int32_t *arr, int count, int key
     return lo;
 }
 
+__device__ __forceinline__ int units_of(int quads) { return (quads + kUnitQuads - 1) / kUnitQuads; }
+
 // ------------------------------------------------------------------ K1b / K2b ----
 // One workgroup: exclusive prefixes over the G = 2 B subgraphs that every workgroup of induce_kernel / pack_kernel
-// needs (they used to recompute them: 19 % of induce_kernel's time).  kAfterInduce = false: virtual workgroups,
-// scratch slots, node offsets (per view); true: edge offsets (per view; the induced edge counts exist only then).
+// needs.  kAfterInduce = false: virtual workgroups, units, scratch slots, node offsets (per view); true: edge offsets
+// (per view; the induced edge counts exist only then).
 template <bool kAfterInduce>
 __global__ __launch_bounds__(256) void subgraph_prefix_kernel(int32_t B, Work w)
 {
@@ -372,10 +352,13 @@ __global__ __launch_bounds__(256) void subgraph_prefix_kernel(int32_t B, Work w)
     int32_t *tmp = (int32_t *)smem;                  // [G + 1]
     if (!kAfterInduce) {
         long long *tmp64 = (long long *)(tmp + ((G + 2) & ~1));
-        block_exclusive_scan<int32_t>(tmp, G, [&](int g) { return (w.sub_seg[g] + kSegPerWg - 1) / kSegPerWg; }, wsum32);
+        block_exclusive_scan<int32_t>(tmp, G, [&](int g) { return (units_of(w.sub_quads[g]) + kUnitsPerVwg - 1) / kUnitsPerVwg; }, wsum32);
         for (int g = tid; g <= G; g += 256) w.vbp[g] = tmp[g];
         __syncthreads();
-        block_exclusive_scan<long long>(tmp64, G, [&](int g) { return (long long)w.sub_cap[g]; }, wsum64);
+        block_exclusive_scan<int32_t>(tmp, G, [&](int g) { return units_of(w.sub_quads[g]); }, wsum32);
+        for (int g = tid; g <= G; g += 256) w.ubp[g] = tmp[g];
+        __syncthreads();
+        block_exclusive_scan<long long>(tmp64, G, [&](int g) { return 4ll * (long long)w.sub_quads[g]; }, wsum64);
         for (int g = tid; g <= G; g += 256) w.sbp[g] = tmp64[g];
         __syncthreads();
         block_exclusive_scan<int32_t>(tmp, G, [&](int g) { return w.sub_n[g]; }, wsum32);
@@ -386,105 +369,162 @@ __global__ __launch_bounds__(256) void subgraph_prefix_kernel(int32_t B, Work w)
     }
 }
 
+__device__ __forceinline__ bool scratch_overflows(const Work &w, int g, int64_t scratch_entries)
+{
+    return w.sbp[g] + 4ll * (long long)w.sub_quads[g] > scratch_entries ||
+           (int64_t)w.ubp[g] + units_of(w.sub_quads[g]) > w.unit_cap;
+}
+
 // ------------------------------------------------------------------ K2 ----
-static long long *g_induce_ticks = nullptr;      // diagnostics (gcc_sampler_debug_ticks): [0..3] phase ticks, [15] workgroups
+static long long *g_induce_ticks = nullptr;      // diagnostics (gcc_sampler_debug_ticks): [0..2] phase ticks, [15] workgroups
 #define IND_TICK(ph) do { if (ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&ticks[ph], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
-    const int32_t *__restrict__ col_idx, int32_t hcap_log2, int32_t G, int64_t scratch_entries, Work w,
-    int32_t *__restrict__ status, long long *ticks)
+    const int32_t *__restrict__ col_idx, int64_t num_edges, int32_t bm_log2_cap, int32_t G, int64_t scratch_entries,
+    Work w, int32_t *__restrict__ status, long long *ticks)
 {
     DYN_SMEM(smem);
-    const int hcap = 1 << hcap_log2;
-    uint32_t *hkey = (uint32_t *)smem;                       // [hcap]
-    uint16_t *hval = (uint16_t *)(hkey + hcap);              // [hcap]
-    int32_t *segoff = (int32_t *)(hval + hcap);              // [ncap + 1] exclusive prefix of segments per row
-    int32_t *capoff = segoff + (w.ncap + 1);                 // [ncap + 1] exclusive prefix of scratch slots per row
-    int32_t *vbp = capoff + (w.ncap + 1);                    // [G + 1]   exclusive prefix of virtual blocks
-    long long *sbp = (long long *)(vbp + ((G + 2) & ~1));    // [G + 1]   exclusive prefix of scratch slots
+    const int ncap = w.ncap;
+    uint32_t *snodes = (uint32_t *)smem;                     // [ncap]     members (seed first, the rest ascending)
+    int32_t *sq = (int32_t *)(snodes + ncap);                // [ncap + 1] exclusive prefix of quads per row
+    int32_t *srb = sq + (ncap + 1);                          // [ncap]     row begin
+    int32_t *srd = srb + ncap;                               // [ncap]     row degree
+    int32_t *vbp = srd + ncap;                               // [G + 1]    exclusive prefix of virtual workgroups
+    uint32_t *bm = (uint32_t *)(vbp + (G + 1));              // [1 << (bm_log2_cap - 5)] Bloom bitmap of the members
+    uint32_t *candv_all = bm + (1u << (bm_log2_cap - 5));    // [4][kCandCap] Bloom survivors (parent ids) ...
+    uint16_t *candr_all = (uint16_t *)(candv_all + 4 * kCandCap);   // [4][kCandCap] ... and their row
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    uint32_t *candv = candv_all + wave * kCandCap;
+    uint16_t *candr = candr_all + wave * kCandCap;
     long long tick_ = ticks ? device_ticks() : 0;
     if (ticks && tid == 0) atomicAdd((unsigned long long *)&ticks[15], 1ull);
-    for (int g = tid; g <= G; g += kInduceThreads) { vbp[g] = w.vbp[g]; sbp[g] = w.sbp[g]; }   // (subgraph_prefix_kernel)
+    for (int g = tid; g <= G; g += kInduceThreads) vbp[g] = w.vbp[g];      // (subgraph_prefix_kernel)
     __syncthreads();
     IND_TICK(0);
     const int total_vb = vbp[G];
-    const int shift = 32 - hcap_log2;
-    int cur_g = -1;
+    int cur_g = -1, bshift = 0;
     for (int vb = (int)blockIdx.x; vb < total_vb; vb += (int)gridDim.x) {
         const int g = upper_slot(vbp, G, vb);
         const int part = vb - vbp[g];
-        const int n = w.sub_n[g], totseg = w.sub_seg[g];
-        const long long sbase = sbp[g];
-        if (sbase + (long long)w.sub_cap[g] > scratch_entries) {
+        const int n = w.sub_n[g], totq = w.sub_quads[g];
+        const int nunits = units_of(totq);
+        if (scratch_overflows(w, g, scratch_entries)) {      // block-uniform
             if (tid == 0) atomicOr(status, (int32_t)GCC_STATUS_SCRATCH_OVERFLOW);
             continue;
         }
-        const int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
-        const int32_t *rowbeg = w.rowbeg + (int64_t)g * w.ncap;
-        const int32_t *rowdeg = w.rowdeg + (int64_t)g * w.ncap;
+        const long long sbase = w.sbp[g];
+        const int ubase = w.ubp[g];
         if (g != cur_g) {                                    // block-uniform
-            __syncthreads();
-            for (int i = tid; i < hcap; i += kInduceThreads) hkey[i] = kEmpty;
+            __syncthreads();                                 // the previous subgraph's tables are no longer read
+            int bl = 11;                                     // >= 64 bits per member, >= 2048 bits
+            while ((1 << bl) < 64 * n && bl < bm_log2_cap) ++bl;
+            bshift = 32 - bl;
+            for (int i = tid; i < (1 << (bl - 5)); i += kInduceThreads) bm[i] = 0u;
+            const int32_t *nodes = w.nodes + (int64_t)g * ncap;
+            const int32_t *rq = w.rowq + (int64_t)g * ncap;
+            const int32_t *rb = w.rowbeg + (int64_t)g * ncap;
+            const int32_t *rd = w.rowdeg + (int64_t)g * ncap;
+            for (int i = tid; i < n; i += kInduceThreads) {
+                snodes[i] = (uint32_t)nodes[i];
+                sq[i] = rq[i];
+                srb[i] = rb[i];
+                srd[i] = rd[i];
+            }
+            if (tid == 0) sq[n] = totq;
             __syncthreads();
             for (int i = tid; i < n; i += kInduceThreads) {
-                const uint32_t key = (uint32_t)nodes[i];
-                uint32_t h = (key * 0x9E3779B1u) >> shift;
-                for (;;) {
-                    const uint32_t old = atomicCAS(&hkey[h], kEmpty, key);
-                    if (old == kEmpty) { hval[h] = (uint16_t)i; break; }
-                    h = (h + 1) & (uint32_t)(hcap - 1);
-                }
+                const uint32_t h = (snodes[i] * kHashMul) >> bshift;
+                atomicOr(&bm[h >> 5], 1u << (h & 31));
             }
-            {                                                // per-row prefixes: written by the walk kernel
-                const int32_t *ro = w.rowoff + (int64_t)g * w.ncap, *rc = w.rowcap + (int64_t)g * w.ncap;
-                for (int i = tid; i <= n; i += kInduceThreads) {
-                    segoff[i] = i < n ? ro[i] : totseg;
-                    capoff[i] = i < n ? rc[i] : w.sub_cap[g];
-                }
-                __syncthreads();
-            }
+            __syncthreads();
             cur_g = g;
             IND_TICK(1);
         }
-        const int stride = 1 + (n < kSeg ? n : kSeg);
         int my_nnz = 0;
 #pragma unroll 1
-        for (int k = 0; k < kSegPerWg / 4; ++k) {
-            const int s = part * kSegPerWg + wave * (kSegPerWg / 4) + k;
-            if (s >= totseg) break;                          // wave-uniform
-            const int i = upper_slot(segoff, n, s);
-            const int e0 = (s - segoff[i]) * kSeg;
-            const int32_t beg = rowbeg[i] + e0;
-            const int len = min(kSeg, rowdeg[i] - e0);
-            int32_t *out = w.scratch + sbase + capoff[i] + (s - segoff[i]) * stride;
-            uint32_t v[4];
+        for (int k = 0; k < kUnitsPerVwg / 4; ++k) {
+            const int unit = part * kUnitsPerVwg + k * 4 + wave;     // consecutive units go to different waves
+            if (unit >= nunits) break;                               // wave-uniform
+            int32_t *out = w.scratch + sbase + (long long)unit * kUnitElems;
+            // ---- the unit's 4 x 64 quads: row of every quad (binary search in the LDS prefix), then all loads in flight
+            uint4 v[4];
+            int lo_[4], hi_[4], a0_[4], r_[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int e = u * 64 + lane;
-                v[u] = e < len ? (uint32_t)col_idx[beg + e] : kEmpty;
+                const int fq = unit * kUnitQuads + u * 64 + lane;
+                const bool ok = fq < totq;
+                const int r = ok ? upper_slot(sq, n, fq) : 0;
+                const int rbv = srb[r], dv = srd[r];
+                const int a0 = (((rbv >> 2) + (fq - sq[r])) << 2);   // element index of the aligned quad
+                r_[u] = r;
+                a0_[u] = a0;
+                lo_[u] = ok ? rbv : 0x7FFFFFFF;                      // elements outside [lo, hi) belong to other rows
+                hi_[u] = ok ? rbv + dv : 0;
+                if (ok && (int64_t)a0 + 4 <= num_edges) {
+                    v[u] = *(const uint4 *)(col_idx + a0);
+                } else {                                             // the array's last quad may be partial
+                    uint32_t t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = (ok && (int64_t)a0 + e < num_edges) ? (uint32_t)col_idx[a0 + e] : kEmpty;
+                    v[u] = make_uint4(t[0], t[1], t[2], t[3]);
+                }
             }
-            int cnt = 0;
+            int ncand = 0, nout = 0;                                 // wave-uniform
+            auto drain = [&]() {
+                wave_sync();
+                for (int c0 = 0; c0 < ncand; c0 += 64) {
+                    const int c = c0 + lane;
+                    int loc = -1;
+                    if (c < ncand) {
+                        const uint32_t val = candv[c];
+                        if (val == snodes[0]) {
+                            loc = 0;
+                        } else {
+                            int lo = 1, hi = n;                      // first index in [1, n) with snodes[idx] >= val
+                            while (lo < hi) {
+                                const int mid = (lo + hi) >> 1;
+                                if (snodes[mid] < val) lo = mid + 1; else hi = mid;
+                            }
+                            if (lo < n && snodes[lo] == val) loc = lo;
+                        }
+                    }
+                    const unsigned long long m = wave_ballot(loc >= 0);
+                    if (loc >= 0) out[nout + __popcll(m & lanemask_lt())] = (int32_t)(((uint32_t)candr[c] << 16) | (uint32_t)loc);
+                    nout += __popcll(m);
+                }
+                wave_sync();
+                ncand = 0;
+            };
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                int loc = -1;
-                if (v[u] != kEmpty) {
-                    uint32_t h = (v[u] * 0x9E3779B1u) >> shift;
-                    for (;;) {
-                        const uint32_t key = hkey[h];
-                        if (key == v[u]) { loc = (int)hval[h]; break; }
-                        if (key == kEmpty) break;
-                        h = (h + 1) & (uint32_t)(hcap - 1);
+                if (ncand + 4 * 64 > kCandCap) drain();              // wave-uniform
+                const uint32_t vals[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                uint32_t pass = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int a = a0_[u] + e;
+                    const uint32_t h = (vals[e] * kHashMul) >> bshift;
+                    const bool in_row = a >= lo_[u] && a < hi_[u];
+                    const uint32_t bit = in_row ? (bm[h >> 5] >> (h & 31)) & 1u : 0u;
+                    pass |= bit << e;
+                }
+                const int cnt = __popc(pass);
+                const int incl = wave_scan_incl(cnt);
+                int at = ncand + incl - cnt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (pass & (1u << e)) {
+                        candv[at] = vals[e];
+                        candr[at] = (uint16_t)r_[u];
+                        ++at;
                     }
                 }
-                const unsigned long long m = wave_ballot(loc >= 0);
-                if (loc >= 0) out[1 + cnt + __popcll(m & lanemask_lt())] = loc;
-                cnt += __popcll(m);
+                ncand += wave_shfl(incl, 63);
             }
-            if (lane == 0) out[0] = cnt;
-            my_nnz += cnt;
+            drain();
+            if (lane == 0) w.ucnt[ubase + unit] = nout;
+            my_nnz += nout;
         }
         if (lane == 0 && my_nnz) atomicAdd(&w.sub_nnz[g], my_nnz);
-        __syncthreads();
         IND_TICK(2);
     }
 }
@@ -493,11 +533,9 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
 __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDev oq, BatchOutDev ok,
                                                     int64_t scratch_entries, int32_t *__restrict__ status)
 {
-    DYN_SMEM(smem);
-    __shared__ int32_t wsum32[5];
-    int32_t *segoff = (int32_t *)smem;            // [ncap + 1] exclusive prefix of segments per row
-    int32_t *capoff = segoff + (w.ncap + 1);      // [ncap + 1] exclusive prefix of scratch slots per row
-    int32_t *excl = capoff + (w.ncap + 1);        // [ncap + 1] exclusive prefix of induced degrees
+    __shared__ int32_t wsum[5];
+    __shared__ int32_t uoff[257];                 // exclusive prefix of the hit counts of a chunk of 256 units
+    __shared__ int32_t sh_base, sh_carry;
     const int tid = (int)threadIdx.x;
     const int g = (int)blockIdx.x / kPackParts, part = (int)blockIdx.x % kPackParts;
     const int view = g / B, b = g - view * B;
@@ -507,6 +545,8 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
     const long long node_base = w.nbp[g];            // (subgraph_prefix_kernel<false / true>)
     const long long edge_base = w.ebp[g];
     const long long sbase = w.sbp[g];
+    const int ubase = w.ubp[g];
+    const int nunits = units_of(w.sub_quads[g]);
     if (tid == 0 && part == 0) {
         o.node_off[b] = (int32_t)node_base;
         o.edge_off[b] = (int32_t)edge_base;
@@ -515,7 +555,7 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
             o.edge_off[B] = (int32_t)(edge_base + nnz);
         }
     }
-    const bool bad_scratch = sbase + (long long)w.sub_cap[g] > scratch_entries;
+    const bool bad_scratch = scratch_overflows(w, g, scratch_entries);
     const bool bad_nodes = node_base + n > o.node_cap;
     const bool bad_edges = edge_base + nnz > o.edge_cap;
     const int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
@@ -537,42 +577,77 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
         if (b == B - 1 && tid == 0 && part == 0 && node_base + n <= o.node_cap) o.row_ptr[node_base + n] = (int32_t)ecl;
         return;
     }
-    const int32_t *scratch = w.scratch + sbase;
-    const int stride = 1 + (n < kSeg ? n : kSeg);
-
-    {                                                        // per-row prefixes: written by the walk kernel
-        const int32_t *ro = w.rowoff + (int64_t)g * w.ncap, *rc = w.rowcap + (int64_t)g * w.ncap;
-        for (int i = tid; i <= n; i += 256) {
-            segoff[i] = i < n ? ro[i] : w.sub_seg[g];
-            capoff[i] = i < n ? rc[i] : w.sub_cap[g];
-        }
-        __syncthreads();
-    }
-    // induced degree of row i = sum of its segments' hit counts
-    block_exclusive_scan<int32_t>(excl, n, [&](int i) {
-        int c = 0;
-        for (int k = 0; k < segoff[i + 1] - segoff[i]; ++k) c += scratch[capoff[i] + k * stride];
-        return c;
-    }, wsum32);
-
     for (int i = part * 256 + tid; i < n; i += 256 * kPackParts) {
         o.parent_nid[node_base + i] = nodes[i];
         o.graph_id[node_base + i] = b;
-        o.row_ptr[node_base + i] = (int32_t)(edge_base + excl[i]);
     }
     if (b == B - 1 && tid == 0 && part == 0) o.row_ptr[node_base + n] = (int32_t)(edge_base + nnz);
-    // one thread per output edge: its row by binary search, then its segment inside the row
-    for (int e = part * 256 + tid; e < nnz; e += 256 * kPackParts) {
-        const int i = upper_slot(excl, n, e);
-        int off = e - excl[i];
-        int at = capoff[i];
-        for (;;) {
-            const int c = scratch[at];
-            if (off < c) break;
-            off -= c;
-            at += stride;
+
+    // this part's units; hits before them and the row of the last of those hits
+    const int u0 = (int)((long long)nunits * part / kPackParts), u1 = (int)((long long)nunits * (part + 1) / kPackParts);
+    const int32_t *ucnt = w.ucnt + ubase;
+    const int32_t *scratch = w.scratch + sbase;
+    {
+        int s = 0, last = -1;
+        for (int j = tid; j < u0; j += 256) {
+            const int c = ucnt[j];
+            s += c;
+            if (c > 0) last = j;
         }
-        o.col_idx[edge_base + e] = (int32_t)node_base + scratch[at + 1 + off];
+        int tot;
+        (void)block_scan_incl(s, &tot, wsum);
+        // block max of `last`
+        for (int d = 32; d >= 1; d >>= 1) { const int t = wave_shfl_xor(last, d); last = t > last ? t : last; }
+        if ((tid & 63) == 0) wsum[tid >> 6] = last;
+        __syncthreads();
+        if (tid == 0) {
+            int m = wsum[0];
+            for (int k = 1; k < 4; ++k) m = wsum[k] > m ? wsum[k] : m;
+            sh_base = tot;
+            sh_carry = m >= 0 ? (int)((uint32_t)scratch[(long long)m * kUnitElems + ucnt[m] - 1] >> 16) : -1;
+        }
+        __syncthreads();
+    }
+    int e_base = sh_base;                              // block-uniform: hits before the current chunk
+    for (int c0 = u0; c0 < u1; c0 += 256) {
+        const int j = c0 + tid;
+        const int cnt = j < u1 ? ucnt[j] : 0;
+        int chunk_total;
+        const int incl = block_scan_incl(cnt, &chunk_total, wsum);
+        uoff[tid] = incl - cnt;
+        if (tid == 0) uoff[256] = chunk_total;
+        __syncthreads();
+        const int carry = sh_carry;
+        for (int x = tid; x < chunk_total; x += 256) {
+            const int jj = upper_slot(uoff, 256, x);   // among equal offsets the last one owns x (the others are empty)
+            const int kk = x - uoff[jj];
+            const int32_t *slot = scratch + (long long)(c0 + jj) * kUnitElems;
+            const uint32_t hv = (uint32_t)slot[kk];
+            const int row = (int)(hv >> 16);
+            const long long e = (long long)e_base + x;
+            o.col_idx[edge_base + e] = (int32_t)node_base + (int32_t)(hv & 0xFFFFu);
+            int prow;
+            if (kk > 0) {
+                prow = (int)((uint32_t)slot[kk - 1] >> 16);
+            } else if (x > 0) {
+                const int pj = upper_slot(uoff, 256, x - 1);
+                prow = (int)((uint32_t)scratch[(long long)(c0 + pj) * kUnitElems + (x - 1 - uoff[pj])] >> 16);
+            } else {
+                prow = carry;
+            }
+            for (int i = prow + 1; i <= row; ++i) o.row_ptr[node_base + i] = (int32_t)(edge_base + e);
+        }
+        __syncthreads();
+        if (tid == 0 && chunk_total > 0) {
+            const int pj = upper_slot(uoff, 256, chunk_total - 1);
+            sh_carry = (int)((uint32_t)scratch[(long long)(c0 + pj) * kUnitElems + (chunk_total - 1 - uoff[pj])] >> 16);
+        }
+        e_base += chunk_total;
+        __syncthreads();
+    }
+    if (part == kPackParts - 1) {                      // rows after the last hit have no induced edges
+        const int carry = sh_carry;
+        for (int i = carry + 1 + tid; i < n; i += 256) o.row_ptr[node_base + i] = (int32_t)(edge_base + nnz);
     }
 }
 
@@ -612,36 +687,39 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
                  (long long)workspace_bytes, (long long)wl.total);
         return -3;
     }
+    if (((uintptr_t)g->col_idx & 15u) != 0) {
+        snprintf(g_err, kErrLen, "gcc_sample_batch: col_idx must be 16-byte aligned (the induction streams it in dwordx4 quads)");
+        return -5;
+    }
     char *base = (char *)workspace;
     Work w;
     w.seeds = (int32_t *)(base + wl.off_seeds);
     w.sub_n = (int32_t *)(base + wl.off_n);
-    w.sub_cap = (int32_t *)(base + wl.off_cap);
-    w.sub_seg = (int32_t *)(base + wl.off_seg);
+    w.sub_quads = (int32_t *)(base + wl.off_quads);
     w.sub_nnz = (int32_t *)(base + wl.off_nnz);
     w.nodes = (int32_t *)(base + wl.off_nodes);
     w.rowbeg = (int32_t *)(base + wl.off_rowbeg);
     w.rowdeg = (int32_t *)(base + wl.off_rowdeg);
-    w.rowoff = (int32_t *)(base + wl.off_rowoff);
-    w.rowcap = (int32_t *)(base + wl.off_rowcap);
-    w.rowcnt = (int32_t *)(base + wl.off_rowcnt);
+    w.rowq = (int32_t *)(base + wl.off_rowq);
     w.vbp = (int32_t *)(base + wl.off_vbp);
+    w.ubp = (int32_t *)(base + wl.off_ubp);
     w.sbp = (long long *)(base + wl.off_sbp);
     w.nbp = (int32_t *)(base + wl.off_nbp);
     w.ebp = (int32_t *)(base + wl.off_ebp);
+    w.ucnt = (int32_t *)(base + wl.off_ucnt);
     w.scratch = (int32_t *)(base + wl.off_scratch);
     w.ncap = wl.ncap;
+    w.unit_cap = wl.unit_cap;
 
     const int B = p->batch_size, G = 2 * B;
     hipStream_t s = (hipStream_t)stream;
     int p2max = 64;
     while (p2max < g->lmax) p2max <<= 1;
-    int hlog = 7;
-    while ((1 << hlog) < 2 * (g->lmax + 1)) ++hlog;
+    int bmlog = 11;                                  // Bloom bitmap: >= 64 bits per member of the largest subgraph
+    while ((1 << bmlog) < 64 * (g->lmax + 1) && bmlog < 20) ++bmlog;
     const size_t lds1 = ((size_t)p2max * 2 + 64) * 4;
-    const size_t lds2 = (size_t)(1 << hlog) * 6 + (size_t)(wl.ncap + 1) * 8 + (size_t)(G + 2) * 4 + (size_t)(G + 1) * 8 + 16;
-    const size_t lds3 = (size_t)(wl.ncap + 1) * 12;
-    if (lds1 > 160 * 1024 || lds2 > 160 * 1024 || lds3 > 160 * 1024) {
+    const size_t lds2 = (size_t)wl.ncap * 16 + 4 + (size_t)(G + 1) * 4 + ((size_t)1 << (bmlog - 3)) + (size_t)4 * kCandCap * 6 + 16;
+    if (lds1 > 160 * 1024 || lds2 > 160 * 1024 - 256) {
         snprintf(g_err, kErrLen, "gcc_sample_batch: lmax=%d / batch too large for 160 KiB of LDS", g->lmax);
         return -4;
     }
@@ -655,19 +733,18 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     // more than 64 KiB of dynamic LDS has to be opted into per kernel
     if (lds1 > 64 * 1024) (void)hipFuncSetAttribute((const void *)rwr_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     if (lds2 > 64 * 1024) (void)hipFuncSetAttribute((const void *)induce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    if (lds3 > 64 * 1024) (void)hipFuncSetAttribute((const void *)pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
 #endif
-    hipLaunchKernelGGL(rwr_walk_kernel, dim3(G), dim3(64), lds1, s, g->row_ptr, g->col_idx, g->seed_cdf,
+    hipLaunchKernelGGL(rwr_walk_kernel, dim3(G), dim3(kWalkThreads), lds1, s, g->row_ptr, g->col_idx, g->seed_cdf,
                        g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, B,
                        p->restart_u32, p->seeds, w);
     prof_mark(p->prof, 1, s);
     const size_t lds_pref = (size_t)(G + 2) * 4 + (size_t)(G + 1) * 8 + 16;
     hipLaunchKernelGGL((subgraph_prefix_kernel<false>), dim3(1), dim3(256), lds_pref, s, B, w);
-    hipLaunchKernelGGL(induce_kernel, dim3(G * 8), dim3(kInduceThreads), lds2, s, g->col_idx, hlog, G,
+    hipLaunchKernelGGL(induce_kernel, dim3(G * 8), dim3(kInduceThreads), lds2, s, g->col_idx, g->num_edges, bmlog, G,
                        scratch_entries, w, status, g_induce_ticks);
     prof_mark(p->prof, 2, s);
     hipLaunchKernelGGL((subgraph_prefix_kernel<true>), dim3(1), dim3(256), lds_pref, s, B, w);
-    hipLaunchKernelGGL(pack_kernel, dim3(G * kPackParts), dim3(256), lds3, s, B, w, oq, ok, scratch_entries, status);
+    hipLaunchKernelGGL(pack_kernel, dim3(G * kPackParts), dim3(256), 0, s, B, w, oq, ok, scratch_entries, status);
     prof_mark(p->prof, 3, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

