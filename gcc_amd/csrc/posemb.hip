@@ -105,7 +105,7 @@ __device__ __forceinline__ void item_args(const PosMulti &m, int item, PosArgs &
 // solver kernel is launched with a SMALL fixed grid whose workgroups pull items from their class list.  (A grid of
 // one fat workgroup per subgraph that exits early when the class does not match keeps the workgroup dispatcher
 // busy placing 160-KiB-LDS / 1024-thread workgroups that do nothing, which delays every other queue.)
-enum { kClsSmall = 0, kClsMid = 1, kClsSlot = 2, kClsKrylov = 3, kClsBig = 4, kNumCls = 5 };
+enum { kClsSmall = 0, kClsMid = 1, kClsSlot = 2, kClsKrylov = 3, kClsBig = 4, kClsCheb = 5, kNumCls = 6 };
 struct PosHead {                     // head of the caller's workspace (zeroed per call)
     int32_t *count;                  // [4] items per class
     int32_t *next;                   // [4] work counters
@@ -117,6 +117,7 @@ struct PosHead {                     // head of the caller's workspace (zeroed p
     int32_t tabs_small_off;          // first small-class table (= workgroups of the mid class)
     int32_t T;
     int32_t ldv;                     // longest subgraph the Krylov class has room for (node_cap / batch_size, rounded up)
+    int32_t use_cheb;                // deflated sizes above GCC_POSEMB_LDS_MAX try the sparse Chebyshev class first
     int64_t slot_floats;
 };
 
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m
         for (int i = lane; i < n; i += 64) zz += t[i] >= 2 ? t[i] - 1 : 0;
         for (int dd = 32; dd >= 1; dd >>= 1) zz += wave_shfl_xor(zz, dd);
         const int nr = n - zz;                         // t >= 2 leaves of one parent count once
-        cls = nr <= kJSmall ? kClsSmall : nr <= kJMax ? kClsMid : nr <= kGMax ? kClsSlot : nr <= kBMax ? kClsBig : kClsKrylov;
+        cls = nr <= kJSmall ? kClsSmall : nr <= kJMax ? kClsMid : hd.use_cheb ? kClsCheb : nr <= kGMax ? kClsSlot : nr <= kBMax ? kClsBig : kClsKrylov;
     }
     if (cls == kClsKrylov && n >= hd.ldv) {          // no room: the caller's node_cap / batch_size must bound every subgraph
         for (int i = lane; i < n * a.hidden; i += 64) a.pos[(int64_t)n0 * a.hidden + i] = 0.f;
@@ -1305,24 +1306,619 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
     }   // next item
 }
 
+
+// =========================================================================
+// Large deflated subgraphs (n' > 128), first choice: Chebyshev-filtered subspace iteration on the SPARSE deflated
+// matrix with a guard block.  A dense reduction streams the matrix once or twice per column (the workspace classes
+// above: 2.4 ms at n' = 250, 19 ms at n' = 580, bound by one CU's path to L2), but M' has ~6 entries per row and the
+// ego-net spectra are spread: with 64 block vectors (k <= 32 wanted + guards) a degree-d Chebyshev polynomial on
+// [-1, cut] separates the wanted end by exp(-0.4 d .. -0.6 d) on the hub ego-nets of the 1M-node graph, so ~26 sparse
+// products converge to 1e-5.  A block also takes exact multiplicities in its stride: whatever it holds of a repeated
+// eigenvalue's eigenspace are eigenvectors (the 30+ copies of 1/sqrt(2) that defeat single-vector Krylov/ARPACK).
+//   round: X <- p_d(M') X (scaled three-term recurrence, two n' x 64 buffers in L2, in place) ; W = M' X ;
+//          G = X^T X, K = X^T W (fp64 accumulation) ; G = R^T R (Jacobi-scaled Cholesky) ; H = R^-T K R^-1 ;
+//          H = Y Theta Y^T (the dense solver core, all 64 pairs) ; X <- X R^-1 Y, W <- W R^-1 Y ; residuals
+//          ||W_i - theta_i X_i|| of the wanted pairs ; cut <- theta_64 - 0.02.
+// Items that do not converge in kChRounds, whose top k reaches the null space (the contrast bookkeeping of the
+// direct solver is needed then), or whose edges do not fit the LDS are appended to the work lists of the dense
+// classes, which run afterwards in the same stream: the exact solver remains the reference for every corner.
+constexpr int kChP = 64;             // block size
+constexpr int kChThreads = 1024;
+constexpr int kChCsrCap = 12288;     // directed edges of the deflated subgraph (uint16 column ids in LDS)
+constexpr int kChLongDeg = 96;       // longer rows are cut into chunks of this many entries, summed in chunk order
+constexpr int kChMaxChunks = 96;
+constexpr int kChMaxLong = 64;
+constexpr int kChRounds = 16;      // filter rounds of an item
+constexpr int kChMaxRitz = 4;      // Rayleigh-Ritz steps of an item
+constexpr float kChTol = 2e-5f;      // residual norm of the wanted Ritz pairs
+constexpr double kChShift = 1e-8;
+constexpr int kChLdy = kChP + 1;
+constexpr int kChBw = 32;            // inverse iterations of the Ritz problem per batch
+
+struct ChebArgs {
+    PosMulti m;
+    PosHead hd;
+    float *xws;              // [workgroups][3][kNodeMax * kChP]  the block buffers
+    uint32_t *tabs;          // [workgroups][kNodeMax * 4]        deflation tables once the matrix is built
+};
+
+__host__ __device__ constexpr int cheb_region_bytes()
+{
+    // the largest of: deflation tables (16 KiB) | two fp64 64 x 64 matrices (64 KiB) | the Ritz problem: L, H/C, Y and the
+    // Gram-Schmidt coefficients (64 x 65 each), the solver's vectors, Sturm counts, LU slots
+    constexpr int ritz = (int)sizeof(float) * (4 * kChP * kChLdy + 7 * kChP + kChThreads + 2 * kChP * (kChBw + 1)) + kChP * kChBw;
+    return ritz > 65536 ? ritz : 65536;
+}
+__host__ __device__ constexpr int cheb_lds_bytes()
+{
+    return 2 * (kNodeMax + 8) + 2 * kChCsrCap + 4 * kNodeMax + 4 * kChMaxChunks * kChP + cheb_region_bytes();
+}
+
+__global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
+{
+    DYN_SMEM(smem);
+    __shared__ EigShared es;
+    __shared__ float theta[kChP], resid[kChP], dsc[kChP];
+    __shared__ double dscd[kChP];
+    __shared__ int longrow[kChMaxLong], longfirst[kChMaxLong + 1];
+    __shared__ int chunk_beg[kChMaxChunks + 1];
+    __shared__ int wsum[kChThreads / 64 + 1];
+    __shared__ int sh_item, sh_np, sh_nlong, sh_nchunk, sh_fail;
+    constexpr int kCls = kClsCheb;
+    const PosMulti &m = ca.m;
+    const PosHead &hd = ca.hd;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int kNW = kChThreads / 64;
+    uint16_t *crow = (uint16_t *)smem;                       // [kNodeMax + 1] row offsets of the deflated CSR
+    uint16_t *ccol = crow + (kNodeMax + 8);                  // [kChCsrCap]
+    float *scale = (float *)(ccol + kChCsrCap);              // [kNodeMax] M' = diag(scale) A' diag(scale)
+    float *slab = scale + kNodeMax;                          // [kChMaxChunks][kChP] partial sums of the long rows
+    unsigned char *region = (unsigned char *)(slab + kChMaxChunks * kChP);
+    for (;;) {                                               // items of this class
+    __syncthreads();
+    if (tid == 0) sh_item = atomicAdd(hd.next + kCls, 1);
+    __syncthreads();
+    if (sh_item >= hd.count[kCls]) return;
+    const int gb = hd.list[(int64_t)kCls * hd.T + sh_item];
+    PosArgs a;
+    int b;
+    item_args(m, gb, a, b);
+    const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+    const int k = min(min(n - 2, a.hidden), kMaxVec);
+    long long tick_ = m.ticks ? device_ticks() : 0;
+    if (m.ticks && tid == 0) atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 15], 1ull);
+    const int32_t *rp = a.row_ptr + n0;
+    // three block buffers in the workspace (L2-resident): X, W = M' X or filter scratch, rotation target
+    float *XA = ca.xws + (int64_t)blockIdx.x * 3 * kNodeMax * kChP, *XB = XA + (int64_t)kNodeMax * kChP, *XC = XB + (int64_t)kNodeMax * kChP;
+
+    // ---- leaf groups (as posemb_direct_kernel)
+    Defl d;
+    d.tcnt = (int32_t *)region;
+    d.cbase = d.tcnt + kNodeMax;
+    d.par = (uint16_t *)(d.cbase + kNodeMax);
+    d.rep = d.par + kNodeMax;
+    d.ridx = d.rep + kNodeMax;
+    d.ord = d.ridx + kNodeMax;
+    for (int i = tid; i < n; i += kChThreads) {
+        const int dg = rp[i + 1] - rp[i];
+        d.par[i] = dg == 1 ? (uint16_t)(a.col_idx[rp[i]] - n0) : kNone;
+        d.tcnt[i] = 0;
+        d.rep[i] = kNone;
+        d.ord[i] = 0;
+    }
+    if (tid == 0) { sh_fail = 0; sh_nlong = 0; sh_nchunk = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += kChThreads)
+        if (d.par[i] != kNone) atomicAdd(&d.tcnt[d.par[i]], 1);
+    __syncthreads();
+    for (int p = tid; p < n; p += kChThreads) {
+        if (d.tcnt[p] >= 2) {
+            int o = 0;
+            for (int e = rp[p]; e < rp[p + 1]; ++e) {
+                const int j = a.col_idx[e] - n0;
+                if (d.par[j] == (uint16_t)p) {
+                    if (o == 0) d.rep[p] = (uint16_t)j;
+                    d.ord[j] = (uint16_t)o++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int r = 0, c = 0;
+        for (int i = 0; i < n; ++i) {
+            d.cbase[i] = c;
+            if (d.tcnt[i] >= 2) c += d.tcnt[i] - 1;
+            const bool collapsed = d.par[i] != kNone && d.tcnt[d.par[i]] >= 2 && d.rep[d.par[i]] != (uint16_t)i;
+            d.ridx[i] = collapsed ? kNone : (uint16_t)r++;
+        }
+        sh_np = r;
+    }
+    __syncthreads();
+    const int nr = sh_np;
+    // ---- sparse M' = diag(scale) A' diag(scale): rows of the kept nodes, columns ascending; a super-leaf standing for t
+    //      twins carries sqrt(t) (its coupling to the parent is sqrt(t / d_p), data_util.py:273-277 on the quotient)
+    for (int i = tid; i < n; i += kChThreads) {
+        if (d.ridx[i] == kNone) continue;
+        const int di = rp[i + 1] - rp[i];
+        const bool superleaf = d.par[i] != kNone && d.tcnt[d.par[i]] >= 2;
+        scale[d.ridx[i]] = superleaf ? sqrtf((float)d.tcnt[d.par[i]]) : 1.0f / sqrtf((float)(di < 1 ? 1 : di));
+    }
+    if (tid <= nr) crow[tid] = 0;                            // nr <= kNodeMax = kChThreads
+    __syncthreads();
+    for (int i = wv; i < n; i += kNW) {                      // kept neighbours per kept row
+        if (d.ridx[i] == kNone) continue;                    // wave-uniform
+        int c = 0;
+        for (int e0 = rp[i]; e0 < rp[i + 1]; e0 += 64) {
+            const int e = e0 + lane;
+            const bool keep = e < rp[i + 1] && d.ridx[a.col_idx[e] - n0] != kNone;
+            c += __popcll(wave_ballot(keep));
+        }
+        if (lane == 0) crow[d.ridx[i] + 1] = (uint16_t)(c > 65535 ? 65535 : c);
+    }
+    __syncthreads();
+    {                                                        // exclusive prefix: one row per thread
+        const int c = tid < nr ? (int)crow[tid + 1] : 0;
+        int incl = wave_scan_incl(c);
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int q = 0; q < wv; ++q) base += wsum[q];
+        incl += base;
+        __syncthreads();
+        if (tid < nr) {
+            if (incl > kChCsrCap) sh_fail = 1;               // does not fit: dense classes
+            crow[tid + 1] = (uint16_t)(incl > 65535 ? 65535 : incl);
+            if (c > kChLongDeg) {
+                const int slot = atomicAdd(&sh_nlong, 1);
+                if (slot < kChMaxLong) longrow[slot] = tid; else sh_fail = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (!sh_fail) {
+        for (int i = wv; i < n; i += kNW) {
+            if (d.ridx[i] == kNone) continue;
+            int at = (int)crow[d.ridx[i]];
+            for (int e0 = rp[i]; e0 < rp[i + 1]; e0 += 64) {
+                const int e = e0 + lane;
+                const int rj = e < rp[i + 1] ? (int)d.ridx[a.col_idx[e] - n0] : (int)kNone;
+                const unsigned long long mk = wave_ballot(rj != (int)kNone);
+                if (rj != (int)kNone) ccol[at + __popcll(mk & lanemask_lt())] = (uint16_t)rj;
+                at += __popcll(mk);
+            }
+        }
+        if (tid == 0) {                                      // chunks of the long rows, rows in index order
+            const int nl = sh_nlong;
+            for (int x = 1; x < nl; ++x) {                   // insertion sort: nl <= 32
+                const int v = longrow[x];
+                int y = x - 1;
+                while (y >= 0 && longrow[y] > v) { longrow[y + 1] = longrow[y]; --y; }
+                longrow[y + 1] = v;
+            }
+            int nc = 0;
+            for (int x = 0; x < nl && !sh_fail; ++x) {
+                longfirst[x] = nc;
+                const int r = longrow[x];
+                for (int e = (int)crow[r]; e < (int)crow[r + 1]; e += kChLongDeg) {
+                    if (nc >= kChMaxChunks) { sh_fail = 1; break; }
+                    chunk_beg[nc++] = e;
+                }
+            }
+            longfirst[nl] = nc;
+            sh_nchunk = nc;
+        }
+    }
+    __syncthreads();
+    // deflation tables -> workspace (the dense matrices overlay them); the expansion at the end reads them there
+    {
+        uint32_t *dst = ca.tabs + (int64_t)blockIdx.x * kNodeMax * 4;
+        const uint32_t *src = (const uint32_t *)d.tcnt;
+        for (int i = tid; i < kNodeMax * 4; i += kChThreads) dst[i] = src[i];
+        d.tcnt = (int32_t *)dst;
+        d.cbase = d.tcnt + kNodeMax;
+        d.par = (uint16_t *)(d.cbase + kNodeMax);
+        d.rep = d.par + kNodeMax;
+        d.ridx = d.rep + kNodeMax;
+        d.ord = d.ridx + kNodeMax;
+        __syncthreads();
+    }
+    PHASE_TICK(0);                                           // deflation + sparse matrix
+    const int nchunk = sh_nchunk;
+    bool failed = sh_fail != 0;
+#ifdef GCC_AMD_HIPEMU
+    if (getenv("GCC_POSEMB_DEBUG") && tid == 0) fprintf(stderr, "cheb item b=%d n=%d nr=%d nnz=%d nlong=%d nchunk=%d fail=%d\n", b, n, nr, (int)crow[nr], sh_nlong, nchunk, sh_fail);
+#endif
+    const int kq = min(k, nr);
+
+    // dst = alpha * (M' src - center * src) - gamma * dst   (rows of 64 floats; 16 threads x float4 per row)
+    auto spmm = [&](const float *src, float *dst, float alpha, float center, float gamma) {
+        const int q4 = 4 * (tid & 15), g16 = tid >> 4;
+        for (int c = g16; c < nchunk; c += kChThreads / 16) {            // chunks of the long rows -> slab
+            int x = 0;
+            while (longfirst[x + 1] <= c) ++x;
+            const int r = longrow[x];
+            const int e1 = min(chunk_beg[c] + kChLongDeg, (int)crow[r + 1]);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int e = chunk_beg[c]; e < e1; ++e) {
+                const int cj = (int)ccol[e];
+                const float sc = scale[cj];
+                const float4 xv = *(const float4 *)(src + (int64_t)cj * kChP + q4);
+                s0 = fmaf(sc, xv.x, s0); s1 = fmaf(sc, xv.y, s1); s2 = fmaf(sc, xv.z, s2); s3 = fmaf(sc, xv.w, s3);
+            }
+            *(float4 *)(slab + c * kChP + q4) = make_float4(s0, s1, s2, s3);
+        }
+        if (nchunk) __syncthreads();
+        for (int r = g16; r < nr; r += kChThreads / 16) {
+            const int e0 = (int)crow[r], e1 = (int)crow[r + 1];
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            if (e1 - e0 > kChLongDeg) {
+                int x = 0;
+                while (longrow[x] != r) ++x;
+                for (int c = longfirst[x]; c < longfirst[x + 1]; ++c) {
+                    const float4 pv = *(const float4 *)(slab + c * kChP + q4);
+                    s0 += pv.x; s1 += pv.y; s2 += pv.z; s3 += pv.w;
+                }
+            } else {
+                for (int e = e0; e < e1; ++e) {
+                    const int cj = (int)ccol[e];
+                    const float sc = scale[cj];
+                    const float4 xv = *(const float4 *)(src + (int64_t)cj * kChP + q4);
+                    s0 = fmaf(sc, xv.x, s0); s1 = fmaf(sc, xv.y, s1); s2 = fmaf(sc, xv.z, s2); s3 = fmaf(sc, xv.w, s3);
+                }
+            }
+            const float sr = scale[r];
+            const float4 own = *(const float4 *)(src + (int64_t)r * kChP + q4);
+            float4 o = make_float4(alpha * (sr * s0 - center * own.x), alpha * (sr * s1 - center * own.y),
+                                   alpha * (sr * s2 - center * own.z), alpha * (sr * s3 - center * own.w));
+            if (gamma != 0.f) {
+                const float4 old = *(const float4 *)(dst + (int64_t)r * kChP + q4);
+                o.x -= gamma * old.x; o.y -= gamma * old.y; o.z -= gamma * old.z; o.w -= gamma * old.w;
+            }
+            *(float4 *)(dst + (int64_t)r * kChP + q4) = o;
+        }
+        __syncthreads();
+    };
+
+    double *G = (double *)region, *K = G + kChP * kChP;      // fp64 [64][64] each
+    float cut = 0.2f;
+    int deg = 6, remaining = 6, round = 0, nrr = 0;
+    bool converged = false;
+    if (!failed) {
+        for (int i = tid; i < nr * kChP; i += kChThreads)    // start block: U(-1, 1), np.random.rand's role
+            XA[i] = hash_unit((uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u), (uint32_t)(i & (kChP - 1)), (uint32_t)(i / kChP));
+        __syncthreads();
+    }
+    // A round = filter of degree `deg`, then either a cheap re-orthonormalisation (X <- X R^-1) or, when the degrees
+    // planned after the last Ritz step are spent, a Rayleigh-Ritz step with the convergence test.
+    for (; round < kChRounds && !failed; ++round) {
+        remaining -= deg;
+#ifdef GCC_AMD_HIPEMU
+        if (getenv("GCC_POSEMB_RR_ALWAYS")) remaining = 0;
+#endif
+        const bool rr = remaining <= 0;                      // block-uniform
+        // ---- filter: scaled Chebyshev polynomial of degree `deg` (even) for [-1, cut], p(1) = 1
+        {
+            const float e = 0.5f * (cut + 1.0f), cen = 0.5f * (cut - 1.0f);
+            float sigma = e / (1.0f - cen);
+            const float tau = 2.0f / sigma;
+            spmm(XA, XB, sigma / e, cen, 0.f);                           // Y_1 -> B
+            float *prev = XA, *cur = XB;
+            for (int i = 2; i <= deg; ++i) {
+                const float sn = 1.0f / (tau - sigma);
+                spmm(cur, prev, 2.0f * sn / e, cen, sigma * sn);          // Y_i overwrites Y_{i-2}
+                float *t = prev; prev = cur; cur = t;
+                sigma = sn;
+            }                                                            // deg even: the result is in XA
+        }
+        if (rr) spmm(XA, XB, 1.0f, 0.f, 0.f);                            // W = M' X
+        PHASE_TICK(1);                                                   // sparse products
+        // ---- G = X^T X (and K = X^T W)
+        {
+            const int i = tid >> 4, j4 = 4 * (tid & 15);
+            double g0 = 0, g1 = 0, g2 = 0, g3 = 0, k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+            if (rr) {
+                for (int r = 0; r < nr; ++r) {
+                    const double xi = (double)XA[(int64_t)r * kChP + i];
+                    const float4 xj = *(const float4 *)(XA + (int64_t)r * kChP + j4);
+                    const float4 wj = *(const float4 *)(XB + (int64_t)r * kChP + j4);
+                    g0 += xi * xj.x; g1 += xi * xj.y; g2 += xi * xj.z; g3 += xi * xj.w;
+                    k0 += xi * wj.x; k1 += xi * wj.y; k2 += xi * wj.z; k3 += xi * wj.w;
+                }
+            } else {
+                for (int r = 0; r < nr; ++r) {
+                    const double xi = (double)XA[(int64_t)r * kChP + i];
+                    const float4 xj = *(const float4 *)(XA + (int64_t)r * kChP + j4);
+                    g0 += xi * xj.x; g1 += xi * xj.y; g2 += xi * xj.z; g3 += xi * xj.w;
+                }
+            }
+            double *gp = G + i * kChP + j4, *kp = K + i * kChP + j4;
+            gp[0] = g0; gp[1] = g1; gp[2] = g2; gp[3] = g3;
+            kp[0] = k0; kp[1] = k1; kp[2] = k2; kp[3] = k3;
+        }
+        __syncthreads();
+        // ---- wave 0: Jacobi scaling, Cholesky G^ = L L^T (lower, in place), H = L^-1 K^ L^-T (in K)
+        if (wv == 0) {
+            const double dd = G[lane * kChP + lane];
+            const double di = dd > 1e-300 ? 1.0 / sqrt(dd) : 0.0;
+            dsc[lane] = (float)di;
+            dscd[lane] = di;                                             // (an fp32 copy here would break the congruence D G D by 1e-7)
+            wave_sync();
+            for (int j = 0; j < kChP; ++j) G[lane * kChP + j] *= dscd[j] * di;
+            // shifted Cholesky: guard columns that have collapsed onto the span of the others (squared relative norm
+            // ~1e-11 after two filters) are damped instead of breaking the factorisation; directions the block
+            // represents at all (>= 1e-3) lose 1e-5 of orthonormality at most, a converged block (unit pivots) nothing
+            G[lane * kChP + lane] += kChShift;
+            for (int j = 0; j <= lane; ++j)                              // lower part: symmetrised and scaled
+                K[lane * kChP + j] = 0.5 * (K[lane * kChP + j] + K[j * kChP + lane]) * (dscd[j] * di);
+            wave_sync();
+            for (int j = lane + 1; j < kChP; ++j) K[lane * kChP + j] = K[j * kChP + lane];
+            wave_sync();
+            bool bad = !(dd > 1e-300);
+            for (int kk = 0; kk < kChP; ++kk) {
+                const double piv = G[kk * kChP + kk];
+                if (!(piv > 0.1 * kChShift)) {                           // wave-uniform: the block lost its numerical rank
+#ifdef GCC_AMD_HIPEMU
+                    if (getenv("GCC_POSEMB_DEBUG") && lane == 0) fprintf(stderr, "cheb chol fail round=%d kk=%d piv=%g dd=%g\n", round, kk, piv, dd);
+#endif
+                    bad = true;
+                    break;
+                }
+                const double rs = 1.0 / sqrt(piv);
+                wave_sync();                                             // every lane has read the pivot before lane kk overwrites it
+                if (lane >= kk) G[lane * kChP + kk] *= rs;               // column kk of L
+                wave_sync();
+                if (lane > kk) {
+                    const double lik = G[lane * kChP + kk];
+                    for (int j = kk + 1; j <= lane; ++j) G[lane * kChP + j] -= lik * G[j * kChP + kk];
+                }
+                wave_sync();
+            }
+            if (bad) {
+                if (lane == 0) sh_fail = 1;
+            } else if (rr) {
+                // T = L^-1 K^ : lane = column, forward substitution
+                for (int i = 0; i < kChP; ++i) {
+                    double v = K[i * kChP + lane];
+                    for (int p = 0; p < i; ++p) v -= G[i * kChP + p] * K[p * kChP + lane];
+                    K[i * kChP + lane] = v / G[i * kChP + i];
+                }
+                wave_sync();
+                // H = T L^-T : lane = row, H[lane][j] = (T[lane][j] - sum_{p<j} H[lane][p] L[j][p]) / L[j][j]
+                for (int j = 0; j < kChP; ++j) {
+                    double v = K[lane * kChP + j];
+                    for (int p = 0; p < j; ++p) v -= K[lane * kChP + p] * G[j * kChP + p];
+                    K[lane * kChP + j] = v / G[j * kChP + j];
+                }
+                wave_sync();
+            }
+        }
+        __syncthreads();
+        if (sh_fail) { failed = true; break; }
+        // ---- LDS region from here on: Lf (L, fp32) | Af (H, later C = D^-1 L^-T Y with stride 64) | Y | solver arrays.
+        //      G and K are dead once L and H have been copied out (through registers: the fp32 copies overlay them)
+        float *Lf = (float *)region, *Af = Lf + kChP * kChLdy;
+        {
+            float lrow[4], hrow[4];
+            const int i = tid >> 4, j4 = 4 * (tid & 15);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                lrow[u] = (float)G[i * kChP + j4 + u];
+                hrow[u] = (float)(0.5 * (K[i * kChP + j4 + u] + K[(j4 + u) * kChP + i]));
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                Lf[i * kChLdy + j4 + u] = lrow[u];
+                Af[i * kChLdy + j4 + u] = hrow[u];
+            }
+        }
+        TriLds tw;
+        tw.Y = Af + kChP * kChLdy;
+        tw.ldy = kChLdy;
+        tw.dg = tw.Y + kChP * kChLdy;
+        tw.of = tw.dg + kChP;
+        tw.of2 = tw.of + kChP;
+        tw.tau = tw.of2 + kChP;
+        tw.pbuf = tw.tau + kChP;
+        tw.vbuf = tw.pbuf + kChP;
+        tw.coef = tw.vbuf + kChP;
+        tw.cnt = (int *)(tw.coef + kChP * kChLdy);
+        tw.bw = kChBw;
+        tw.ldu = kChBw + 1;
+        tw.Ud = (float *)(tw.cnt + kChThreads);
+        tw.Us = tw.Ud + kChP * tw.ldu;
+        tw.Uf = (uint8_t *)(tw.Us + kChP * tw.ldu);
+        __syncthreads();
+        if (rr) {
+            // Ritz problem: all 64 pairs of H by the dense solver core
+            tridiagonalize<1, kChThreads, 2>(Af, kChLdy, kChP, tw);
+            eig_top_values<kChThreads, kVecCap>(tw, kChP, kChP, es);
+            const bool ritz_failed = eig_top_vectors<1, kChThreads>(Af, kChLdy, kChP, kChP, tw, es,
+                                                                    (uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u) ^ (uint32_t)(round + 77),
+                                                                    nullptr, tick_);
+#ifdef GCC_AMD_HIPEMU
+            if (getenv("GCC_POSEMB_DEBUG") && tid == 0 && ritz_failed) fprintf(stderr, "cheb ritz failed round=%d\n", round);
+#endif
+            if (ritz_failed) { failed = true; break; }           // block-uniform
+            ++nrr;
+        }
+        PHASE_TICK(2);                                           // Gram matrices + Ritz problem
+        // ---- C = D^-1 L^-T Y (Y = I without a Ritz step); wave 0: lane = column, backward substitution; stride 64 over H
+        if (wv == 0) {
+            float *Yc = tw.Y;                                            // lane = column: stride 65 is conflict free
+            if (!rr) {
+#pragma unroll 1
+                for (int i = 0; i < kChP; ++i) Yc[i * kChLdy + lane] = i == lane ? 1.0f : 0.0f;
+            }
+#pragma unroll 1
+            for (int i = kChP - 1; i >= 0; --i) {
+                float v = Yc[i * kChLdy + lane];
+#pragma unroll 4
+                for (int p = i + 1; p < kChP; ++p) v = fmaf(-Lf[p * kChLdy + i], Yc[p * kChLdy + lane], v);
+                Yc[i * kChLdy + lane] = v / Lf[i * kChLdy + i];
+            }
+#pragma unroll 4
+            for (int i = 0; i < kChP; ++i) Af[i * kChP + lane] = Yc[i * kChLdy + lane] * dsc[i];
+            if (rr) theta[lane] = es.lamv[lane];
+        }
+        __syncthreads();
+        // ---- X <- X C into the free buffer (W C stays in registers); residuals ||W_i - theta_i X_i||^2 accumulated per
+        //      thread, then over the 64 row groups
+        {
+            const int q4 = 4 * (tid & 15), g16 = tid >> 4;
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+            const float t0 = theta[q4], t1 = theta[q4 + 1], t2 = theta[q4 + 2], t3 = theta[q4 + 3];
+            for (int r = g16; r < nr; r += kChThreads / 16) {
+                float xn[4] = {0.f, 0.f, 0.f, 0.f}, wn[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int which = 0; which < (rr ? 2 : 1); ++which) {
+                    const float *src = (which ? XB : XA) + (int64_t)r * kChP;
+                    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll 4
+                    for (int p = 0; p < kChP / 4; ++p) {
+                        const float4 rv = *(const float4 *)(src + 4 * p);
+                        const float xs[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float4 cv = *(const float4 *)(Af + (4 * p + u) * kChP + q4);
+                            o0 = fmaf(xs[u], cv.x, o0); o1 = fmaf(xs[u], cv.y, o1);
+                            o2 = fmaf(xs[u], cv.z, o2); o3 = fmaf(xs[u], cv.w, o3);
+                        }
+                    }
+                    if (which) {                                         // the rotated W is only needed for the residual
+                        wn[0] = o0; wn[1] = o1; wn[2] = o2; wn[3] = o3;
+                    } else {
+                        *(float4 *)(XC + (int64_t)r * kChP + q4) = make_float4(o0, o1, o2, o3);
+                        xn[0] = o0; xn[1] = o1; xn[2] = o2; xn[3] = o3;
+                    }
+                }
+                const float d0 = wn[0] - t0 * xn[0], d1 = wn[1] - t1 * xn[1], d2 = wn[2] - t2 * xn[2], d3 = wn[3] - t3 * xn[3];
+                r0 = fmaf(d0, d0, r0); r1 = fmaf(d1, d1, r1); r2 = fmaf(d2, d2, r2); r3 = fmaf(d3, d3, r3);
+            }
+            __syncthreads();
+            { float *t = XA; XA = XC; XC = t; }                          // block-uniform: the rotated block is X now
+            if (rr) {
+                *(float4 *)(slab + g16 * kChP + q4) = make_float4(r0, r1, r2, r3);     // 64 groups x 64 columns
+                __syncthreads();
+                if (tid < kChP) {
+                    float sres = 0.f;
+                    for (int g = 0; g < kChThreads / 16; ++g) sres += slab[g * kChP + tid];
+                    resid[tid] = sqrtf(sres);
+                }
+                __syncthreads();
+            }
+        }
+#ifdef GCC_AMD_HIPEMU
+        if (getenv("GCC_POSEMB_DEBUG") && tid == 0) {
+            double worst_off = 0, dmin = 1e9, dmax2 = 0, wmax = 0;
+            for (int i = 0; i < kChP; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    double sdot = 0;
+                    for (int r = 0; r < nr; ++r) sdot += (double)XA[(int64_t)r * kChP + i] * XA[(int64_t)r * kChP + j];
+                    if (i == j) { dmin = sdot < dmin ? sdot : dmin; dmax2 = sdot > dmax2 ? sdot : dmax2; }
+                    else worst_off = fabs(sdot) > worst_off ? fabs(sdot) : worst_off;
+                }
+            for (int i = 0; i < kChP; ++i) { double sw = 0; for (int r = 0; r < nr; ++r) sw += (double)XB[(int64_t)r * kChP + i] * XB[(int64_t)r * kChP + i]; wmax = sw > wmax ? sw : wmax; }
+            fprintf(stderr, "cheb gram-after-rotate round=%d rr=%d: diag [%g, %g] offdiag %g  max|W col|^2 %g\n", round, (int)rr, dmin, dmax2, worst_off, wmax);
+        }
+        __syncthreads();
+#endif
+        PHASE_TICK(3);                                           // rotation + residuals
+        // the degree of one filter is bounded: fp32 keeps ~1e-7 of the dominant eigenvectors in every column and an
+        // unconverged guard column much more; the filter magnifies that by T_deg(x(1)) relative to a column at the cut,
+        // so beyond ~1e3 the block loses its numerical rank.  T_2m = 2 T_m^2 - 1: consecutive rounds with a
+        // re-orthonormalisation in between multiply up like one long filter.
+        if (rr) {
+            float worst = 0.f;
+            for (int i = 0; i < kq; ++i) worst = fmaxf(worst, resid[i]);
+#ifdef GCC_AMD_HIPEMU
+            if (getenv("GCC_POSEMB_DEBUG") && tid == 0)
+                fprintf(stderr, "cheb b=%d n=%d nr=%d round=%d deg=%d cut=%.4f worst=%.2e theta[kq-1]=%.5f theta[63]=%.5f\n", b, n, nr, round,
+                        deg, cut, worst, theta[kq - 1], theta[kChP - 1]);
+#endif
+            if (worst <= kChTol) { converged = true; ++round; break; }
+            if (nrr >= kChMaxRitz) break;
+            cut = fminf(fmaxf(theta[kChP - 1] - 0.02f, -0.9f), 0.9f);
+            const float e = 0.5f * (cut + 1.0f), cen = 0.5f * (cut - 1.0f);
+            const float xk = fmaxf((theta[kq - 1] - cen) / e, 1.0001f);
+            const float rate = logf(xk + sqrtf(xk * xk - 1.0f));        // the wanted end grows by exp(rate) per degree
+            int need = (int)(2.3f * logf(fmaxf(worst, 1e-3f) / (0.5f * kChTol)) / rate) + 4;   // a Ritz step costs ~30 degrees: overshoot
+            remaining = need < 4 ? 4 : (need > 60 ? 60 : need);
+        }
+        {
+            const float x1 = (1.0f - 0.5f * (cut - 1.0f)) / (0.5f * (cut + 1.0f));
+            const float ach = logf(x1 + sqrtf(x1 * x1 - 1.0f));
+            int dmax = (int)(9.2f / ach) & ~1;                          // T_dmax(x(1)) <= ~1e4
+            dmax = dmax < 4 ? 4 : (dmax > 16 ? 16 : dmax);
+            deg = ((remaining + 1) & ~1) < dmax ? ((remaining + 1) & ~1) : dmax;
+            if (deg < 2) deg = 2;
+        }
+    }
+    // the top k must be strictly positive eigenvalues: the null space needs the direct solver's contrast bookkeeping
+    if (converged && !(theta[kq - 1] > 10.f * kZeroEig)) converged = false;
+    if (!converged) {
+        // ---- hand the item to the dense classes (they run after this kernel in the stream)
+        if (tid == 0) {
+            int cls = nr <= kGMax ? kClsSlot : (nr <= kBMax ? kClsBig : kClsKrylov);
+            if (n > kNodeMax) cls = kClsKrylov;
+            if (cls == kClsKrylov && n >= hd.ldv) {
+                atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_TOO_LARGE);
+                cls = -1;
+            }
+            if (cls >= 0) hd.list[(int64_t)cls * hd.T + atomicAdd(hd.count + cls, 1)] = gb;
+            atomicAdd(a.status + 3, 1);                          // diagnostics: items that left their first-choice solver
+            sh_fail = cls < 0 ? 2 : 1;
+        }
+        __syncthreads();
+        if (sh_fail == 2) {                                      // no room anywhere: zeros + flag, as the classify kernel does
+            for (int i = tid; i < n * a.hidden; i += kChThreads) a.pos[(int64_t)n0 * a.hidden + i] = 0.f;
+            if (a.evals) for (int i = tid; i < a.hidden; i += kChThreads) a.evals[(int64_t)b * a.hidden + i] = 0.f;
+        }
+        continue;
+    }
+    // ---- eigenvalues ascending like eigsh(which="LA") (data_util.py:251); expand to the n original nodes;
+    //      x = normalize(u, "l2") row-wise, zero padded (data_util.py:260-262)
+    if (a.evals) {
+        for (int i = tid; i < a.hidden; i += kChThreads)
+            a.evals[(int64_t)b * a.hidden + i] = i < k ? theta[k - 1 - i] : 0.f;
+    }
+    for (int v = wv; v < n; v += kNW) {
+        const int pv = d.par[v];
+        const bool grouped = pv != kNone && d.tcnt[pv] >= 2;
+        const int rsrc = grouped ? d.ridx[d.rep[pv]] : d.ridx[v];
+        const float sc = grouped ? 1.0f / sqrtf((float)d.tcnt[pv]) : 1.0f;
+        float val = 0.f;
+        if (lane < k) val = XA[(int64_t)rsrc * kChP + (k - 1 - lane)] * sc;
+        const float s2 = wave_sum(val * val);
+        const float inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
+        if (lane < a.hidden) {
+            a.pos[(int64_t)(n0 + v) * a.hidden + lane] = val * inv;
+            if (a.raw) a.raw[(int64_t)(n0 + v) * a.hidden + lane] = val;
+        }
+    }
+    PHASE_TICK(4);                                               // expansion
+    if (tid == 0) atomicMax(a.status + 1, round);                // diagnostics: most filter rounds of an item
+    }   // next item
+}
+
 }  // namespace
 
 extern "C" {
 
 static long long *g_posemb_ticks = nullptr;
-struct PosGrids { int32_t small, mid, slot, kry, big; };
+struct PosGrids { int32_t small, mid, slot, kry, big, cheb; };
 static PosGrids posemb_grids(int64_t T)
 {
     // fixed grids: enough workgroups for the typical class sizes (~73 % / 19 % / 6 % / 2 % of a batch at rw_hops 256);
     // larger classes loop.  No class may cover more than half of the 256 CUs (small: 2 workgroups per CU): a solver
     // workgroup holds most of a CU's LDS for milliseconds, and when every CU has one the training step's kernels whose
     // workgroups do not fit beside it wait for the whole launch to drain (3-5 ms stalls in the kernel trace).
-    static int caps[5] = {0, 0, 0, 0, 0};
-    if (caps[0] == 0) {                              // tuning knob: GCC_POSEMB_GRID_CAPS="small,mid,slot,krylov,big"
-        int c[5] = {256, 128, 128, 64, 64};
+    static int caps[6] = {0, 0, 0, 0, 0, 0};
+    if (caps[0] == 0) {                              // tuning knob: GCC_POSEMB_GRID_CAPS="small,mid,slot,krylov,big,cheb"
+        int c[6] = {256, 128, 128, 64, 64, 128};
         const char *e = getenv("GCC_POSEMB_GRID_CAPS");
-        if (e) (void)sscanf(e, "%d,%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3], &c[4]);
-        for (int i = 0; i < 5; ++i) caps[i] = c[i] < 1 ? 1 : c[i];
+        if (e) (void)sscanf(e, "%d,%d,%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3], &c[4], &c[5]);
+        for (int i = 0; i < 6; ++i) caps[i] = c[i] < 1 ? 1 : c[i];
     }
     PosGrids g;
     g.small = (int32_t)(T < caps[0] ? T : caps[0]);
@@ -1330,6 +1926,7 @@ static PosGrids posemb_grids(int64_t T)
     g.slot = (int32_t)((T + 7) / 8 < caps[2] ? (T + 7) / 8 : caps[2]);
     g.kry = (int32_t)((T + 15) / 16 < caps[3] ? (T + 15) / 16 : caps[3]);
     g.big = (int32_t)((T + 15) / 16 < caps[4] ? (T + 15) / 16 : caps[4]);
+    g.cheb = (int32_t)((T + 7) / 8 < caps[5] ? (T + 7) / 8 : caps[5]);
     return g;
 }
 static int64_t posemb_head_bytes(int64_t T) { return ((16 + kNumCls * T) * 4 + 255) / 256 * 256; }
@@ -1348,7 +1945,8 @@ int64_t gcc_posemb_multi_workspace_bytes(int32_t num_views, int32_t batch_size, 
     return posemb_head_bytes(T) + g.slot * posemb_slot_floats() * (int64_t)sizeof(float)
            + g.big * posemb_bslot_floats() * (int64_t)sizeof(float)
            + (int64_t)(g.mid + g.small) * kNodeMax * 16
-           + (int64_t)g.kry * 2 * (kM + 1) * posemb_ldv(batch_size, node_cap) * (int64_t)sizeof(float) + 256;
+           + (int64_t)g.kry * 2 * (kM + 1) * posemb_ldv(batch_size, node_cap) * (int64_t)sizeof(float)
+           + (int64_t)g.cheb * (3 * (int64_t)kNodeMax * kChP * (int64_t)sizeof(float) + (int64_t)kNodeMax * 16) + 512;
 }
 
 int64_t gcc_posemb_workspace_bytes(int32_t batch_size, int64_t node_cap, int32_t hidden)
@@ -1392,6 +1990,10 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     hd.T = (int32_t)T;
     hd.slot_floats = posemb_slot_floats();
     hd.ldv = (int32_t)posemb_ldv(batch_size, node_cap);
+    {
+        const char *e = getenv("GCC_POSEMB_CHEB");
+        hd.use_cheb = e ? atoi(e) != 0 : 1;
+    }
     constexpr int lds_small = direct_lds_bytes<kJSmall, 256, false>();
     constexpr int lds_big = direct_lds_bytes<kJMax, 1024, false>();
 #ifndef GCC_AMD_HIPEMU
@@ -1427,6 +2029,23 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
         kry_lds_opt_in = lds_kry;
     }
 #endif
+    if (hd.use_cheb) {
+        ChebArgs ca;
+        ca.m = m;
+        ca.hd = hd;
+        char *after_kry = (char *)(ka.vws + (int64_t)g.kry * 2 * (kM + 1) * ka.ldv);
+        after_kry = (char *)(((uintptr_t)after_kry + 255) & ~(uintptr_t)255);
+        ca.xws = (float *)after_kry;
+        ca.tabs = (uint32_t *)(ca.xws + (int64_t)g.cheb * 3 * kNodeMax * kChP);
+#ifndef GCC_AMD_HIPEMU
+        static bool cheb_attr = false;
+        if (!cheb_attr) {
+            (void)hipFuncSetAttribute((const void *)posemb_cheb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cheb_lds_bytes());
+            cheb_attr = true;
+        }
+#endif
+        hipLaunchKernelGGL(posemb_cheb_kernel, dim3(g.cheb), dim3(kChThreads), cheb_lds_bytes(), s, ca);
+    }
     hipLaunchKernelGGL(posemb_krylov_kernel, dim3(g.kry), dim3(kKThreads), lds_kry, s, ka);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsBig, kGMax + 1, kBMax, 1024, true>), dim3(g.big), dim3(1024), kBLds, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>), dim3(g.slot), dim3(1024), kGLds, s, m, hd);

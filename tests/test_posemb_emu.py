@@ -26,6 +26,7 @@ def _run(view):
     pe(b, evals=evals, raw=raw)
     assert int(pe.status[0]) == 0
     _run.arnoldi_steps = int(pe.status[2])
+    _run.status = [int(v) for v in pe.status]
     return b.pos_undirected.numpy(), evals.numpy(), raw.numpy()
 
 
@@ -167,9 +168,12 @@ def _check_krylov(view, x, evals, raw, tol=1e-3):
         assert np.all(np.abs(norms - 1) < 1e-4)
 
 
-def test_large_subgraphs_workspace_resident_direct_path():
-    """128 < n' <= 384: the matrix lives in a workspace slot, everything else as in the LDS classes -- the STRICT
-    invariants hold (all multiplicities), no Krylov iteration runs."""
+@pytest.mark.parametrize("cheb", ["0", "1"])
+def test_large_subgraphs_workspace_resident_direct_path(cheb, monkeypatch):
+    """128 < n' <= 384.  cheb=0: the dense workspace class (the matrix lives in a workspace slot, everything else as in
+    the LDS classes); cheb=1 (the default): the sparse Chebyshev class takes them first.  Either way the STRICT
+    invariants hold (all multiplicities) and no Krylov iteration runs."""
+    monkeypatch.setenv("GCC_POSEMB_CHEB", cheb)
     rp, ci = powerlaw_graph(20000, 400000, 1)
     c = O.COracle()
     deg = np.diff(rp)
@@ -188,10 +192,13 @@ def test_large_subgraphs_workspace_resident_direct_path():
     _check(view, x, evals, raw)
 
 
-def test_krylov_fallback_above_the_direct_limit():
-    """Deflated size > 704 (no twin leaves at all): thick-restart Krylov-Schur."""
+@pytest.mark.parametrize("cheb", ["0", "1"])
+def test_krylov_fallback_above_the_direct_limit(cheb, monkeypatch):
+    """Deflated size > 704 (no twin leaves at all).  cheb=0: thick-restart Krylov-Schur (single vector, ARPACK-like
+    invariants); cheb=1: the sparse block class is tried first and hands this (dense) graph on."""
     import scipy.sparse as sp
 
+    monkeypatch.setenv("GCC_POSEMB_CHEB", cheb)
     rng = np.random.RandomState(1)
     n = 760
     w = 1.0 / np.arange(1, n + 1) ** 0.5                        # skewed degrees, like an ego-net
@@ -205,17 +212,22 @@ def test_krylov_fallback_above_the_direct_limit():
     view = dict(node_off=torch.tensor([0, n]), row_ptr=torch.from_numpy(a.indptr.astype(np.int64)),
                 col_idx=torch.from_numpy(a.indices.astype(np.int64)))
     x, evals, raw = _run(view)
-    assert _run.arnoldi_steps > 0
+    # 30k undirected edges do not fit the block class's LDS edge list (12288 directed): with cheb=1 the item is handed
+    # on (status[3] counts it) and, being larger than the dense classes too, ends in the Krylov class either way
+    assert _run.arnoldi_steps > 0 and _run.status[3] == (1 if cheb == "1" else 0)
     _check_krylov(view, x, evals, raw)
 
 
-def test_hub_ego_net_with_repeated_eigenvalues_goes_through_the_big_direct_class():
+@pytest.mark.parametrize("cheb", ["0", "1"])
+def test_hub_ego_net_with_repeated_eigenvalues_goes_through_the_big_direct_class(cheb, monkeypatch):
     """The shape of a hub seed's ego-net at rw_hops 256 on the 1M-node graph (n ~ 850, deflated ~ 400..610): a hub
     with hundreds of pendant two-paths (hub - a_i - leaf_i), which puts 1/sqrt(2) into the spectrum hundreds of times.
     Exact multiplicities are out of reach of a single-vector Krylov iteration (ARPACK returns other, smaller
-    eigenvalues for the copies it cannot see); 384 < n' <= 704 is solved by the dense direct solver: STRICT invariants."""
+    eigenvalues for the copies it cannot see).  cheb=1: the block Chebyshev class (whatever a block holds of a repeated
+    eigenvalue's eigenspace are eigenvectors); cheb=0: 384 < n' <= 704 by the dense direct solver.  STRICT invariants."""
     import scipy.sparse as sp
 
+    monkeypatch.setenv("GCC_POSEMB_CHEB", cheb)
     rng = np.random.RandomState(3)
     t = 210
     edges = [(0, 1 + i) for i in range(t)] + [(1 + i, 1 + t + i) for i in range(t)]
@@ -232,8 +244,33 @@ def test_hub_ego_net_with_repeated_eigenvalues_goes_through_the_big_direct_class
     red = reduced_sizes(view)
     assert SLOT_MAX < red[0] <= DIRECT_MAX, red
     x, evals, raw = _run(view)
-    assert _run.arnoldi_steps == 0
+    assert _run.arnoldi_steps == 0 and _run.status[3] == 0
+    assert (_run.status[1] >= 2) == (cheb == "1")                       # filter rounds of the block class
     assert np.sum(np.abs(evals[0] - 2 ** -0.5) < 1e-4) >= 25          # the repeated eigenvalue fills the top 32
+    _check(view, x, evals, raw)
+
+
+def test_sparse_graph_beyond_the_dense_classes_is_solved_by_the_block_class():
+    """n' = 900 > GCC_POSEMB_BIG_MAX, no twin leaves, ~6 edges per node: only the sparse Chebyshev block class (up to
+    1024 nodes) and the Krylov class reach this size; the block class runs (status[1] = its filter rounds, no Arnoldi
+    steps, nothing handed on) and the STRICT invariants hold."""
+    import scipy.sparse as sp
+
+    rng = np.random.RandomState(7)
+    n = 900
+    w = 1.0 / np.arange(1, n + 1) ** 0.6
+    pr = np.minimum(1.0, 3.0 * np.outer(w, w) / (w.mean() ** 2 * n))
+    up = np.triu(rng.rand(n, n) < pr, 1)
+    up[np.arange(n - 1), np.arange(1, n)] = True
+    a = sp.csr_matrix((up | up.T).astype(np.float64))
+    a.sort_indices()
+    deg = np.diff(a.indptr)
+    assert a.nnz < 12000 and ((deg >= 2).all() or np.bincount(a.indices[a.indptr[:-1][deg == 1]]).max() < 2)
+    view = dict(node_off=torch.tensor([0, n]), row_ptr=torch.from_numpy(a.indptr.astype(np.int64)),
+                col_idx=torch.from_numpy(a.indices.astype(np.int64)))
+    assert reduced_sizes(view)[0] > DIRECT_MAX
+    x, evals, raw = _run(view)
+    assert _run.arnoldi_steps == 0 and _run.status[1] >= 2 and _run.status[3] == 0, _run.status
     _check(view, x, evals, raw)
 
 
@@ -301,7 +338,7 @@ def test_subgraph_larger_than_its_share_of_node_cap_is_refused_loudly():
     import scipy.sparse as sp
 
     rng = np.random.RandomState(5)
-    n = 720                                                   # no twin leaves: deflated size 720 > 704 -> Krylov class
+    n = 1100                                                  # more nodes than any block / dense class takes -> Krylov class
     up = np.triu(rng.rand(n, n) < 0.02, 1)
     up[np.arange(n - 1), np.arange(1, n)] = True
     a = sp.csr_matrix((up | up.T).astype(np.float64))
