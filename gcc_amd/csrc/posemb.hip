@@ -918,7 +918,12 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     __syncthreads();
     const bool failed = eig_top_vectors<kCPL, kT>(A, lda, nr, sh_na, w, es, (uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u),
                                                   m.ticks ? m.ticks + kCls * 16 : nullptr, tick_);
-    if (tid == 0 && failed) atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
+    if (tid == 0 && failed) {
+        atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
+        if (atomicAdd(a.status + 4, 1) == 0) {               // diagnostics: the first item that failed
+            a.status[5] = gb; a.status[6] = kCls; a.status[7] = nr; a.status[8] = es.bad; a.status[9] = n;
+        }
+    }
     // ---- expand to the n original nodes; x = normalize(u, "l2") row-wise, zero padded (data_util.py:260-262)
     for (int v = wv; v < n; v += kNW) {
         const int pv = d.par[v];
@@ -1224,7 +1229,10 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
             fprintf(stderr, "kry b=%d n=%d cycle=%d worst=%.2e nbad=%d theta_k=%.4f\n", b, n, cycle + 1, worst, nbad, 0.f);
         }
 #endif
-        if (finished && done == 0 && flag == 2 && tid == 0) atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
+        if (finished && done == 0 && flag == 2 && tid == 0) {
+            atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
+            if (atomicAdd(a.status + 4, 1) == 0) { a.status[5] = gb; a.status[6] = kClsKrylov; a.status[7] = n; a.status[8] = -1; a.status[9] = n; }
+        }
         if (finished && done == 0 && tid == 0) atomicAdd(a.status + 3, 1);      // diagnostics: items that stopped at the cycle cap
         const int nout = finished ? k : keep;
         // output column t <- Ritz vector: restart keeps rank t, the final result is ascending (rank k-1-t)
@@ -1326,7 +1334,7 @@ constexpr int kChP = 64;             // block size
 constexpr int kChThreads = 1024;
 constexpr int kChCsrCap = 12288;     // directed edges of the deflated subgraph (uint16 column ids in LDS)
 constexpr int kChLongDeg = 96;       // longer rows are cut into chunks of this many entries, summed in chunk order
-constexpr int kChMaxChunks = 96;
+constexpr int kChMaxChunks = 64;
 constexpr int kChMaxLong = 64;
 constexpr int kChRounds = 16;      // filter rounds of an item
 constexpr int kChMaxRitz = 4;      // Rayleigh-Ritz steps of an item
@@ -1347,7 +1355,7 @@ __host__ __device__ constexpr int cheb_region_bytes()
     // the largest of: deflation tables (16 KiB) | two fp64 64 x 64 matrices (64 KiB) | the Ritz problem: L, H/C, Y and the
     // Gram-Schmidt coefficients (64 x 65 each), the solver's vectors, Sturm counts, LU slots
     constexpr int ritz = (int)sizeof(float) * (4 * kChP * kChLdy + 7 * kChP + kChThreads + 2 * kChP * (kChBw + 1)) + kChP * kChBw;
-    return ritz > 65536 ? ritz : 65536;
+    return ritz > 3 * 32768 ? ritz : 3 * 32768;              // ... | three fp64 64 x 64 matrices (G, K, L^-1)
 }
 __host__ __device__ constexpr int cheb_lds_bytes()
 {
@@ -1540,11 +1548,23 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             const int r = longrow[x];
             const int e1 = min(chunk_beg[c] + kChLongDeg, (int)crow[r + 1]);
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (int e = chunk_beg[c]; e < e1; ++e) {
-                const int cj = (int)ccol[e];
-                const float sc = scale[cj];
-                const float4 xv = *(const float4 *)(src + (int64_t)cj * kChP + q4);
-                s0 = fmaf(sc, xv.x, s0); s1 = fmaf(sc, xv.y, s1); s2 = fmaf(sc, xv.z, s2); s3 = fmaf(sc, xv.w, s3);
+            for (int e = chunk_beg[c]; e < e1; e += 4) {
+                int cj[4];
+                float sc[4];
+                float4 xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool in = e + u < e1;
+                    cj[u] = (int)ccol[in ? e + u : chunk_beg[c]];
+                    sc[u] = in ? scale[cj[u]] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xv[u] = *(const float4 *)(src + (int64_t)cj[u] * kChP + q4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s0 = fmaf(sc[u], xv[u].x, s0); s1 = fmaf(sc[u], xv[u].y, s1);
+                    s2 = fmaf(sc[u], xv[u].z, s2); s3 = fmaf(sc[u], xv[u].w, s3);
+                }
             }
             *(float4 *)(slab + c * kChP + q4) = make_float4(s0, s1, s2, s3);
         }
@@ -1560,11 +1580,23 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
                     s0 += pv.x; s1 += pv.y; s2 += pv.z; s3 += pv.w;
                 }
             } else {
-                for (int e = e0; e < e1; ++e) {
-                    const int cj = (int)ccol[e];
-                    const float sc = scale[cj];
-                    const float4 xv = *(const float4 *)(src + (int64_t)cj * kChP + q4);
-                    s0 = fmaf(sc, xv.x, s0); s1 = fmaf(sc, xv.y, s1); s2 = fmaf(sc, xv.z, s2); s3 = fmaf(sc, xv.w, s3);
+                for (int e = e0; e < e1; e += 4) {               // four gathers in flight (the block lives in L2)
+                    int cj[4];
+                    float sc[4];
+                    float4 xv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool in = e + u < e1;
+                        cj[u] = (int)ccol[in ? e + u : e0];
+                        sc[u] = in ? scale[cj[u]] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) xv[u] = *(const float4 *)(src + (int64_t)cj[u] * kChP + q4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        s0 = fmaf(sc[u], xv[u].x, s0); s1 = fmaf(sc[u], xv[u].y, s1);
+                        s2 = fmaf(sc[u], xv[u].z, s2); s3 = fmaf(sc[u], xv[u].w, s3);
+                    }
                 }
             }
             const float sr = scale[r];
@@ -1618,6 +1650,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             const int i = tid >> 4, j4 = 4 * (tid & 15);
             double g0 = 0, g1 = 0, g2 = 0, g3 = 0, k0 = 0, k1 = 0, k2 = 0, k3 = 0;
             if (rr) {
+#pragma unroll 4
                 for (int r = 0; r < nr; ++r) {
                     const double xi = (double)XA[(int64_t)r * kChP + i];
                     const float4 xj = *(const float4 *)(XA + (int64_t)r * kChP + j4);
@@ -1626,6 +1659,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
                     k0 += xi * wj.x; k1 += xi * wj.y; k2 += xi * wj.z; k3 += xi * wj.w;
                 }
             } else {
+#pragma unroll 8
                 for (int r = 0; r < nr; ++r) {
                     const double xi = (double)XA[(int64_t)r * kChP + i];
                     const float4 xj = *(const float4 *)(XA + (int64_t)r * kChP + j4);
@@ -1637,73 +1671,126 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             kp[0] = k0; kp[1] = k1; kp[2] = k2; kp[3] = k3;
         }
         __syncthreads();
-        // ---- wave 0: Jacobi scaling, Cholesky G^ = L L^T (lower, in place), H = L^-1 K^ L^-T (in K)
-        if (wv == 0) {
-            const double dd = G[lane * kChP + lane];
+        // ---- small dense algebra, all 16 waves, fp64 in LDS: Jacobi scaling G^ = D G D; shifted Cholesky G^ = L L^T
+        //      (right-looking, two barriers per column); Linv = L^-1 by recursive doubling over the diagonal blocks
+        //      (inv [A 0; B C] = [A^-1 0; -C^-1 B A^-1  C^-1]: 6 levels); with a Ritz step H = Linv K^ Linv^T
+        double *Li = K + kChP * kChP;                            // [64][64] L^-1 (lower); upper triangle = scratch
+        if (tid < kChP) {
+            const double dd = G[tid * kChP + tid];
             const double di = dd > 1e-300 ? 1.0 / sqrt(dd) : 0.0;
-            dsc[lane] = (float)di;
-            dscd[lane] = di;                                             // (an fp32 copy here would break the congruence D G D by 1e-7)
-            wave_sync();
-            for (int j = 0; j < kChP; ++j) G[lane * kChP + j] *= dscd[j] * di;
-            // shifted Cholesky: guard columns that have collapsed onto the span of the others (squared relative norm
-            // ~1e-11 after two filters) are damped instead of breaking the factorisation; directions the block
-            // represents at all (>= 1e-3) lose 1e-5 of orthonormality at most, a converged block (unit pivots) nothing
-            G[lane * kChP + lane] += kChShift;
-            for (int j = 0; j <= lane; ++j)                              // lower part: symmetrised and scaled
-                K[lane * kChP + j] = 0.5 * (K[lane * kChP + j] + K[j * kChP + lane]) * (dscd[j] * di);
-            wave_sync();
-            for (int j = lane + 1; j < kChP; ++j) K[lane * kChP + j] = K[j * kChP + lane];
-            wave_sync();
-            bool bad = !(dd > 1e-300);
+            if (!(dd > 1e-300)) sh_fail = 1;
+            dsc[tid] = (float)di;
+            dscd[tid] = di;                                      // (an fp32 copy here would break the congruence D G D by 1e-7)
+        }
+        __syncthreads();
+        {
+            const int i = tid >> 4, j4 = 4 * (tid & 15);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j4 + u;
+                const double sc = dscd[i] * dscd[j];
+                // shifted Cholesky: guard columns that have collapsed onto the span of the others are damped instead of
+                // breaking the factorisation; a converged block (unit pivots) is not affected
+                G[i * kChP + j] = G[i * kChP + j] * sc + (i == j ? kChShift : 0.0);
+                if (j <= i) {                                    // K^ lower part, symmetrised
+                    const double kv = 0.5 * (K[i * kChP + j] + K[j * kChP + i]) * sc;
+                    Li[i * kChP + j] = kv;                       // (parked in Li until K's upper part has been read)
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int i = tid >> 4, j4 = 4 * (tid & 15);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j4 + u;
+                K[i * kChP + j] = j <= i ? Li[i * kChP + j] : Li[j * kChP + i];
+            }
+        }
+        __syncthreads();
+        {
+            double *colbuf = (double *)slab;                     // [2][64]
+            const int i = tid >> 4, j4 = 4 * (tid & 15);
             for (int kk = 0; kk < kChP; ++kk) {
                 const double piv = G[kk * kChP + kk];
-                if (!(piv > 0.1 * kChShift)) {                           // wave-uniform: the block lost its numerical rank
+                if (!(piv > 0.1 * kChShift)) {                   // block-uniform: the block lost its numerical rank
 #ifdef GCC_AMD_HIPEMU
-                    if (getenv("GCC_POSEMB_DEBUG") && lane == 0) fprintf(stderr, "cheb chol fail round=%d kk=%d piv=%g dd=%g\n", round, kk, piv, dd);
+                    if (getenv("GCC_POSEMB_DEBUG") && tid == 0) fprintf(stderr, "cheb chol fail round=%d kk=%d piv=%g\n", round, kk, piv);
 #endif
-                    bad = true;
+                    sh_fail = 1;
                     break;
                 }
                 const double rs = 1.0 / sqrt(piv);
-                wave_sync();                                             // every lane has read the pivot before lane kk overwrites it
-                if (lane >= kk) G[lane * kChP + kk] *= rs;               // column kk of L
-                wave_sync();
-                if (lane > kk) {
-                    const double lik = G[lane * kChP + kk];
-                    for (int j = kk + 1; j <= lane; ++j) G[lane * kChP + j] -= lik * G[j * kChP + kk];
+                double *cb = colbuf + (kk & 1) * kChP;
+                if (tid >= kk && tid < kChP) cb[tid] = G[tid * kChP + kk] * rs;      // column kk of L
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j4 + u;
+                    if (j == kk && i >= kk) G[i * kChP + kk] = cb[i];
+                    else if (j > kk && j <= i) G[i * kChP + j] -= cb[i] * cb[j];
                 }
-                wave_sync();
-            }
-            if (bad) {
-                if (lane == 0) sh_fail = 1;
-            } else if (rr) {
-                // T = L^-1 K^ : lane = column, forward substitution
-                for (int i = 0; i < kChP; ++i) {
-                    double v = K[i * kChP + lane];
-                    for (int p = 0; p < i; ++p) v -= G[i * kChP + p] * K[p * kChP + lane];
-                    K[i * kChP + lane] = v / G[i * kChP + i];
-                }
-                wave_sync();
-                // H = T L^-T : lane = row, H[lane][j] = (T[lane][j] - sum_{p<j} H[lane][p] L[j][p]) / L[j][j]
-                for (int j = 0; j < kChP; ++j) {
-                    double v = K[lane * kChP + j];
-                    for (int p = 0; p < j; ++p) v -= K[lane * kChP + p] * G[j * kChP + p];
-                    K[lane * kChP + j] = v / G[j * kChP + j];
-                }
-                wave_sync();
+                __syncthreads();
             }
         }
         __syncthreads();
         if (sh_fail) { failed = true; break; }
-        // ---- LDS region from here on: Lf (L, fp32) | Af (H, later C = D^-1 L^-T Y with stride 64) | Y | solver arrays.
-        //      G and K are dead once L and H have been copied out (through registers: the fp32 copies overlay them)
+        {   // Li = L with inverted diagonal; then the doubling levels
+            const int i = tid >> 4, j4 = 4 * (tid & 15);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j4 + u;
+                Li[i * kChP + j] = j < i ? G[i * kChP + j] : (j == i ? 1.0 / G[i * kChP + i] : 0.0);
+            }
+            __syncthreads();
+            for (int sz = 1; sz < kChP; sz <<= 1) {
+                const int per = sz * sz, pairs = kChP / (2 * sz);
+                // T = B A, stored transposed in the (free) upper triangle
+                for (int e = tid; e < pairs * per; e += kChThreads) {
+                    const int pr = e / per, ii = (e - pr * per) / sz, jj = e % sz, r0 = 2 * sz * pr;
+                    double acc = 0.0;
+                    for (int q = jj; q < sz; ++q) acc += Li[(r0 + sz + ii) * kChP + r0 + q] * Li[(r0 + q) * kChP + r0 + jj];
+                    Li[(r0 + jj) * kChP + r0 + sz + ii] = acc;
+                }
+                __syncthreads();
+                // B' = -C T
+                for (int e = tid; e < pairs * per; e += kChThreads) {
+                    const int pr = e / per, ii = (e - pr * per) / sz, jj = e % sz, r0 = 2 * sz * pr;
+                    double acc = 0.0;
+                    for (int q = 0; q <= ii; ++q) acc += Li[(r0 + sz + ii) * kChP + r0 + sz + q] * Li[(r0 + jj) * kChP + r0 + sz + q];
+                    Li[(r0 + sz + ii) * kChP + r0 + jj] = -acc;          // (B itself is not read in this phase)
+                }
+                __syncthreads();
+            }
+            if (rr) {
+                // T1 = Linv K^ (into G), H = T1 Linv^T (into K)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j4 + u;
+                    double acc = 0.0;
+                    for (int q = 0; q <= i; ++q) acc += Li[i * kChP + q] * K[q * kChP + j];
+                    G[i * kChP + j] = acc;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j4 + u;
+                    double acc = 0.0;
+                    for (int q = 0; q <= j; ++q) acc += G[i * kChP + q] * Li[j * kChP + q];
+                    K[i * kChP + j] = acc;
+                }
+                __syncthreads();
+            }
+        }
+        // ---- LDS region from here on: Lf (Linv, fp32) | Af (H, later C with stride 64) | Y | solver arrays.  G, K and Li
+        //      are dead once Linv and H have been copied out (through registers: the fp32 copies overlay them)
         float *Lf = (float *)region, *Af = Lf + kChP * kChLdy;
         {
             float lrow[4], hrow[4];
             const int i = tid >> 4, j4 = 4 * (tid & 15);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                lrow[u] = (float)G[i * kChP + j4 + u];
+                lrow[u] = j4 + u <= i ? (float)Li[i * kChP + j4 + u] : 0.f;
                 hrow[u] = (float)(0.5 * (K[i * kChP + j4 + u] + K[(j4 + u) * kChP + i]));
             }
             __syncthreads();
@@ -1742,25 +1829,28 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
 #endif
             if (ritz_failed) { failed = true; break; }           // block-uniform
             ++nrr;
+            if (tid < kChP) theta[tid] = es.lamv[tid];
         }
         PHASE_TICK(2);                                           // Gram matrices + Ritz problem
-        // ---- C = D^-1 L^-T Y (Y = I without a Ritz step); wave 0: lane = column, backward substitution; stride 64 over H
-        if (wv == 0) {
-            float *Yc = tw.Y;                                            // lane = column: stride 65 is conflict free
-            if (!rr) {
-#pragma unroll 1
-                for (int i = 0; i < kChP; ++i) Yc[i * kChLdy + lane] = i == lane ? 1.0f : 0.0f;
+        // ---- C = D Linv^T Y (Y = I without a Ritz step), stride 64, over H
+        {
+            const int i = tid >> 4, j4 = 4 * (tid & 15);
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+            if (rr) {
+                for (int q = i; q < kChP; ++q) {                 // Linv^T[i][q] = Linv[q][i], q >= i
+                    const float l = Lf[q * kChLdy + i];
+                    c0 = fmaf(l, tw.Y[q * kChLdy + j4], c0); c1 = fmaf(l, tw.Y[q * kChLdy + j4 + 1], c1);
+                    c2 = fmaf(l, tw.Y[q * kChLdy + j4 + 2], c2); c3 = fmaf(l, tw.Y[q * kChLdy + j4 + 3], c3);
+                }
+            } else {
+                c0 = j4 >= i ? Lf[j4 * kChLdy + i] : 0.f;
+                c1 = j4 + 1 >= i ? Lf[(j4 + 1) * kChLdy + i] : 0.f;
+                c2 = j4 + 2 >= i ? Lf[(j4 + 2) * kChLdy + i] : 0.f;
+                c3 = j4 + 3 >= i ? Lf[(j4 + 3) * kChLdy + i] : 0.f;
             }
-#pragma unroll 1
-            for (int i = kChP - 1; i >= 0; --i) {
-                float v = Yc[i * kChLdy + lane];
-#pragma unroll 4
-                for (int p = i + 1; p < kChP; ++p) v = fmaf(-Lf[p * kChLdy + i], Yc[p * kChLdy + lane], v);
-                Yc[i * kChLdy + lane] = v / Lf[i * kChLdy + i];
-            }
-#pragma unroll 4
-            for (int i = 0; i < kChP; ++i) Af[i * kChP + lane] = Yc[i * kChLdy + lane] * dsc[i];
-            if (rr) theta[lane] = es.lamv[lane];
+            const float di = dsc[i];
+            __syncthreads();                                     // H (Af) and the reflectors in it are dead: C goes there
+            *(float4 *)(Af + i * kChP + j4) = make_float4(c0 * di, c1 * di, c2 * di, c3 * di);
         }
         __syncthreads();
         // ---- X <- X C into the free buffer (W C stays in registers); residuals ||W_i - theta_i X_i||^2 accumulated per
@@ -1774,15 +1864,21 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
                 for (int which = 0; which < (rr ? 2 : 1); ++which) {
                     const float *src = (which ? XB : XA) + (int64_t)r * kChP;
                     float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-#pragma unroll 4
-                    for (int p = 0; p < kChP / 4; ++p) {
-                        const float4 rv = *(const float4 *)(src + 4 * p);
-                        const float xs[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll 1
+                    for (int half = 0; half < 2; ++half) {               // half a row (8 x 16 bytes) in flight at once
+                        float4 rowv[kChP / 8];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const float4 cv = *(const float4 *)(Af + (4 * p + u) * kChP + q4);
-                            o0 = fmaf(xs[u], cv.x, o0); o1 = fmaf(xs[u], cv.y, o1);
-                            o2 = fmaf(xs[u], cv.z, o2); o3 = fmaf(xs[u], cv.w, o3);
+                        for (int p = 0; p < kChP / 8; ++p) rowv[p] = *(const float4 *)(src + 32 * half + 4 * p);
+#pragma unroll
+                        for (int p = 0; p < kChP / 8; ++p) {
+                            const float4 rv = rowv[p];
+                            const float xs[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float4 cv = *(const float4 *)(Af + (32 * half + 4 * p + u) * kChP + q4);
+                                o0 = fmaf(xs[u], cv.x, o0); o1 = fmaf(xs[u], cv.y, o1);
+                                o2 = fmaf(xs[u], cv.z, o2); o3 = fmaf(xs[u], cv.w, o3);
+                            }
                         }
                     }
                     if (which) {                                         // the rotated W is only needed for the residual

@@ -46,7 +46,7 @@ class DevicePosEmb:
             raise RuntimeError(self.lib.gcc_last_error().decode())
         self.nbytes = nbytes
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        self.status = torch.zeros(4, dtype=torch.int32, device=device)    # [flags, max cycles, arnoldi steps, -]
+        self.status = torch.zeros(16, dtype=torch.int32, device=device)   # [flags, max cycles, arnoldi steps, handed on, failed, first failed item ...]
         # one output buffer per in-flight batch view (q and k of each ring slot)
         self._ring = [torch.zeros(node_cap, self.hidden, dtype=torch.float32, device=device)
                       for _ in range(2 * num_buffers)]

@@ -148,8 +148,10 @@ int64_t gcc_posemb_workspace_bytes(int32_t batch_size, int64_t node_cap, int32_t
  * evals: device [B, hidden] out or NULL (eigenvalues, ascending, zero-padded);
  * raw:   device [node_cap, hidden] out or NULL (the eigenvectors before row normalisation);
  * seed: start vectors of the Krylov path are Philox(seed, subgraph) uniforms.
- * status: device int32[4]: [0] |= GCC_STATUS_*, [1] = max restart cycles, [2] += Arnoldi steps,
- *         [3] += Krylov items that stopped at the restart cap (diagnostics). */
+ * status: device int32[16]: [0] |= GCC_STATUS_*; diagnostics: [1] = most Krylov restart cycles / block filter rounds of
+ *         an item, [2] += Arnoldi steps, [3] += items that left their first-choice solver (Krylov restart cap, block
+ *         class handing on to the dense classes), [4] += items that set GCC_STATUS_POSEMB_NOT_CONVERGED, [5..9] = the
+ *         first of them: item id (view * batch_size + subgraph), solver class, deflated size, reason, nodes. */
 int32_t gcc_posemb(const gcc_batch_out *g, int32_t batch_size, int32_t hidden, float *pos, float *evals,
                    float *raw, uint64_t seed, void *workspace, int64_t workspace_bytes, int32_t *status, gcc_prof *prof,
                    void *stream);

@@ -30,7 +30,7 @@ def test_pretrain_resume_generate(tmp_path, capsys):
 
     corpus, gs = _corpus(tmp_path)
     common = ["--exp", "Pretrain", "--model-path", str(tmp_path / "saved"), "--tb-path", str(tmp_path / "tb"),
-              "--gpu", "0", "--moco", "--nce-k", "256", "--batch-size", "32", "--num-workers", "4", "--num-samples", "64",
+              "--gpu", "0", "--moco", "--nce-k", "256", "--batch-size", "32", "--num-workers", "4", "--num-copies", "2", "--num-samples", "64",
               "--rw-hops", "64", "--dgl-file", corpus, "--print-freq", "2", "--tb-freq", "4", "--save-freq", "1",
               "--producer-lanes", "2", "--producer-chunk", "2"]
     args = train.parse_option(common + ["--epochs", "2"])
@@ -78,7 +78,7 @@ def test_moco_loss_stays_sane_over_an_epoch_and_every_step_is_metered(tmp_path):
 
     corpus, _ = _corpus(tmp_path)
     args = train.parse_option(["--exp", "T", "--model-path", str(tmp_path / "s"), "--tb-path", str(tmp_path / "t"), "--gpu", "0",
-                               "--moco", "--nce-k", "256", "--batch-size", "32", "--num-workers", "1", "--num-samples", "1536",
+                               "--moco", "--nce-k", "256", "--batch-size", "32", "--num-workers", "1", "--num-copies", "1", "--num-samples", "1536",
                                "--rw-hops", "64", "--dgl-file", corpus, "--epochs", "1", "--print-freq", "8", "--tb-freq", "1000",
                                "--producer-lanes", "2", "--producer-chunk", "2", "--learning_rate", "0.005"])
     args.gpu = args.gpu[0]

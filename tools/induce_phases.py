@@ -25,5 +25,5 @@ torch.cuda.synchronize()
 lib.gcc_sampler_debug_ticks(None)
 t = ticks.cpu().numpy()
 wgs = max(int(t[15]), 1)
-print(f"workgroups per launch {wgs / n:.0f}; per workgroup: subgraph prefix sums {t[0] / 100 / wgs:.2f} us, hash map + row sums "
-      f"{t[1] / 100 / wgs:.2f} us, segment scans {t[2] / 100 / wgs:.2f} us")
+print(f"workgroups per launch {wgs / n:.0f}; per workgroup: virtual-workgroup prefix copy {t[0] / 100 / wgs:.2f} us, member tables + Bloom "
+      f"bitmap {t[1] / 100 / wgs:.2f} us, unit scans {t[2] / 100 / wgs:.2f} us")
