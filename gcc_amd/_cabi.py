@@ -122,6 +122,7 @@ class GccNceArgs(ctypes.Structure):
         ("patch_index", ctypes.c_int32), ("patch_rows", ctypes.c_int32),
         ("B", ctypes.c_int32), ("K", ctypes.c_int32), ("pos_mode", ctypes.c_int32), ("inv_T", ctypes.c_float),
         ("lse", _VP), ("pos", _VP), ("loss", _VP), ("prob", _VP), ("out_dense", _VP),
+        ("dtype", ctypes.c_int32),
     ]
 
 

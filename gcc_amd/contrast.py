@@ -24,10 +24,11 @@ D = 64
 class NceEngine:
     """C-ABI calls of the head.  ``lib``/``ptr`` are injectable for the emulator tests only."""
 
-    def __init__(self, lib=None, ptr=None):
+    def __init__(self, lib=None, ptr=None, dtype="f32"):
         self.lib = lib if lib is not None else _cabi.load()
         self.ptr = ptr if ptr is not None else _cabi.dev_ptr
         self._ws = {}
+        self.dtype = dtype            # "f32": exact-fp32 MFMA (parity mode); "bf16": operands rounded to bf16 (GCC_NCE_BF16)
 
     def _workspace(self, B, K, device):
         nbytes = self.lib.gcc_nce_workspace_bytes(B, K)
@@ -46,6 +47,7 @@ class NceEngine:
         a.B, a.K, a.pos_mode, a.inv_T = q.shape[0], mem.shape[0], pos_mode, inv_T
         a.lse, a.pos, a.loss, a.prob = ptr(outs["lse"]), ptr(outs["pos"]), ptr(outs["loss"]), ptr(outs["prob"])
         a.out_dense = ptr(dense) if dense is not None else None
+        a.dtype = {"f32": 0, "bf16": 1}[self.dtype]
         return a
 
     def forward(self, q, k, mem, T, pos_mode, dense=False, lse_rows=None, patch=None, patch_index=0, stream=None,
@@ -165,8 +167,9 @@ class NCELogits:
 class MemoryMoCo(nn.Module):
     """memory_moco.py:7-24: fixed-size queue; buffers ``params`` and ``memory`` (checkpoint["contrast"])."""
 
-    def __init__(self, inputSize, outputSize, K, T=0.07, use_softmax=False):
+    def __init__(self, inputSize, outputSize, K, T=0.07, use_softmax=False, nce_dtype="f32"):
         super().__init__()
+        self.nce_dtype = nce_dtype         # not in the reference: "bf16" selects the throughput mode of the head
         if inputSize != D:
             raise NotImplementedError("feature size is fixed at 64 (train.py:93 default)")
         if not use_softmax:
@@ -186,7 +189,7 @@ class MemoryMoCo(nn.Module):
 
     def engine(self) -> NceEngine:
         if self._engine is None:
-            self._engine = NceEngine()
+            self._engine = NceEngine(dtype=self.nce_dtype)
         return self._engine
 
     def forward(self, q, k):

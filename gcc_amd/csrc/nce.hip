@@ -4,6 +4,8 @@
 // clone/index_copy_), NCESoftmaxLoss / NCESoftmaxLossNS (gcc/contrastive/criterions.py:5-33:
 // CrossEntropyLoss over [B, K+1]) and moment_update (train.py:169-172).
 //
+//   (dtype GCC_NCE_BF16: the same kernels with q / k / queue rounded to bf16 on load -- the forward logits then run on
+//   v_mfma_f32_16x16x32_bf16, 2 instructions per 16 x 16 tile instead of 16; accumulation and softmax stay fp32)
 //   nce_slice_kernel<false>  grid (S slices of the queue, B/64 query blocks).  The slice's rows
 //       are staged through LDS in 64-row chunks shared by the 4 waves; each wave owns 16 queries:
 //       logits tile = exact-f32 MFMA (queue rows x queries), online row-softmax (running max /
@@ -39,6 +41,7 @@ __device__ __forceinline__ void st4(float *p, F4 v) { *reinterpret_cast<float4 *
 struct NceDev {
     const float *q, *k, *mem, *patch;
     int32_t patch_index, patch_rows, B, K, pos_mode;
+    int32_t bf16;            // operands rounded to bf16 (f32 accumulation): gcc_nce_args.dtype
     float inv_T;
     float *lse, *pos, *loss, *prob, *out_dense;
     int32_t S, R;             // slices and rows per slice (multiple of kChunk)
@@ -72,7 +75,18 @@ inline Plan make_plan(int32_t B, int32_t K)
     return p;
 }
 
-__device__ __forceinline__ F4 load_mem4(const NceDev &a, int r, int c4)
+__device__ __forceinline__ float rnd_bf16(float x) { return bf16_bits_to_f32(f32_to_bf16_bits(x)); }
+__device__ __forceinline__ F4 rnd4(F4 v, bool on)
+{
+    if (on) { v.x = rnd_bf16(v.x); v.y = rnd_bf16(v.y); v.z = rnd_bf16(v.z); v.w = rnd_bf16(v.w); }
+    return v;
+}
+// two fp32 values that are exactly representable in bf16 -> one packed pair (low half = first)
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u); }
+
+__device__ __forceinline__ F4 load_mem4_raw(const NceDev &a, int r, int c4);
+__device__ __forceinline__ F4 load_mem4(const NceDev &a, int r, int c4) { return rnd4(load_mem4_raw(a, r, c4), a.bf16 != 0); }
+__device__ __forceinline__ F4 load_mem4_raw(const NceDev &a, int r, int c4)
 {
     if (r >= a.K) { F4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
     if (a.patch) {
@@ -83,7 +97,7 @@ __device__ __forceinline__ F4 load_mem4(const NceDev &a, int r, int c4)
     return ld4(a.mem + (int64_t)r * D + c4);
 }
 
-template <bool kBwd>
+template <bool kBwd, bool kBf16>
 __global__ __launch_bounds__(kThreads) void nce_slice_kernel(NceDev a)
 {
     TRAIN_STEP_WAVE_PRIORITY();
@@ -97,7 +111,21 @@ __global__ __launch_bounds__(kThreads) void nce_slice_kernel(NceDev a)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         F4 z = {0.f, 0.f, 0.f, 0.f};
-        qf[c] = qvalid ? ld4(a.q + (int64_t)qj * D + 16 * c + 4 * q) : z;
+        qf[c] = qvalid ? rnd4(ld4(a.q + (int64_t)qj * D + 16 * c + 4 * q), kBf16) : z;
+    }
+    // bf16 mode, forward logits on v_mfma_f32_16x16x32_bf16: lane (j, q) supplies 8 consecutive k of query j for the k-group q of
+    // each 32-wide slab (the queue rows come from LDS the same way); the products of bf16 values are exact in fp32, so the
+    // result differs from the fp32-MFMA path on the rounded operands (what the backward recomputes) by summation order only
+    u32x4 qb[2];
+    if (kBf16 && !kBwd) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            F4 z = {0.f, 0.f, 0.f, 0.f};
+            const F4 lo = qvalid ? rnd4(ld4(a.q + (int64_t)qj * D + 32 * sl + 8 * q), true) : z;
+            const F4 hi = qvalid ? rnd4(ld4(a.q + (int64_t)qj * D + 32 * sl + 8 * q + 4), true) : z;
+            qb[sl][0] = pack_bf16(lo.x, lo.y); qb[sl][1] = pack_bf16(lo.z, lo.w);
+            qb[sl][2] = pack_bf16(hi.x, hi.y); qb[sl][3] = pack_bf16(hi.z, hi.w);
+        }
     }
     const int row_beg = s * a.R, row_end = min(a.K, row_beg + a.R);
     const int ld_out = a.K + (a.pos_mode == 0 ? 1 : 0), off_out = a.pos_mode == 0 ? 1 : 0;
@@ -119,13 +147,24 @@ __global__ __launch_bounds__(kThreads) void nce_slice_kernel(NceDev a)
         for (int t = 0; t < 4; ++t) {
             if (c0 + 16 * t >= row_end) break;      // block-uniform
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (kBf16 && !kBwd) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const F4 mf = ld4(&Ms[(16 * t + j) * kLd + 16 * c + 4 * q]);
-                acc = mfma_16x16x4_f32(mf.x, qf[c].x, acc);
-                acc = mfma_16x16x4_f32(mf.y, qf[c].y, acc);
-                acc = mfma_16x16x4_f32(mf.z, qf[c].z, acc);
-                acc = mfma_16x16x4_f32(mf.w, qf[c].w, acc);
+                for (int sl = 0; sl < 2; ++sl) {
+                    const F4 lo = ld4(&Ms[(16 * t + j) * kLd + 32 * sl + 8 * q]), hi = ld4(&Ms[(16 * t + j) * kLd + 32 * sl + 8 * q + 4]);
+                    u32x4 mb;
+                    mb[0] = pack_bf16(lo.x, lo.y); mb[1] = pack_bf16(lo.z, lo.w);
+                    mb[2] = pack_bf16(hi.x, hi.y); mb[3] = pack_bf16(hi.z, hi.w);
+                    acc = mfma_16x16x32_bf16(mb, qb[sl], acc);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const F4 mf = ld4(&Ms[(16 * t + j) * kLd + 16 * c + 4 * q]);
+                    acc = mfma_16x16x4_f32(mf.x, qf[c].x, acc);
+                    acc = mfma_16x16x4_f32(mf.y, qf[c].y, acc);
+                    acc = mfma_16x16x4_f32(mf.z, qf[c].z, acc);
+                    acc = mfma_16x16x4_f32(mf.w, qf[c].w, acc);
+                }
             }
             // acc[r] = mem[row0 + r] . q[qj], row0 = c0 + 16 t + 4 q
             const int row0 = c0 + 16 * t + 4 * q;
@@ -192,7 +231,9 @@ __global__ __launch_bounds__(kThreads) void nce_combine_kernel(NceDev a)
     const int b = (int)blockIdx.x * (kThreads >> 6) + wv;
     if (b < a.B) {
         const float *other = a.pos_mode == 0 ? a.k : a.mem;        // l_pos = bmm(q, k) | diagonal of k q^T
-        const float pos = wave_sum(a.q[(int64_t)b * D + lane] * other[(int64_t)b * D + lane]) * a.inv_T;
+        float qv = a.q[(int64_t)b * D + lane], ov = other[(int64_t)b * D + lane];
+        if (a.bf16) { qv = rnd_bf16(qv); ov = rnd_bf16(ov); }
+        const float pos = wave_sum(qv * ov) * a.inv_T;
         float m = -INFINITY;
         for (int s = lane; s < a.S; s += 64) m = fmaxf(m, a.pm[(int64_t)s * a.B + b]);
         m = wave_max(m);
@@ -258,11 +299,11 @@ __global__ __launch_bounds__(kThreads) void nce_dq_kernel(NceDev a)
     F4 o;
     if (a.pos_mode == 0) {
         const float pp = expf(a.pos[b] - a.lse[b]) - 1.f;
-        const F4 kv = ld4(a.k + (int64_t)b * D + c4);
+        const F4 kv = rnd4(ld4(a.k + (int64_t)b * D + c4), a.bf16 != 0);
         o.x = coef * (s.x + pp * kv.x); o.y = coef * (s.y + pp * kv.y);
         o.z = coef * (s.z + pp * kv.z); o.w = coef * (s.w + pp * kv.w);
     } else {
-        const F4 mv = ld4(a.mem + (int64_t)b * D + c4);
+        const F4 mv = rnd4(ld4(a.mem + (int64_t)b * D + c4), a.bf16 != 0);
         o.x = coef * (s.x - mv.x); o.y = coef * (s.y - mv.y); o.z = coef * (s.z - mv.z); o.w = coef * (s.w - mv.w);
     }
     st4(a.dq + (int64_t)b * D + c4, o);
@@ -362,6 +403,7 @@ inline int fill_dev(const gcc_nce_args *a, void *workspace, int64_t workspace_by
     d.q = a->q; d.k = a->k; d.mem = a->mem; d.patch = a->patch;
     d.patch_index = a->patch_index; d.patch_rows = a->patch ? a->patch_rows : 0;
     d.B = a->B; d.K = a->K; d.pos_mode = a->pos_mode; d.inv_T = a->inv_T;
+    d.bf16 = a->dtype == GCC_NCE_BF16 ? 1 : 0;
     d.lse = a->lse; d.pos = a->pos; d.loss = a->loss; d.prob = a->prob; d.out_dense = a->out_dense;
     d.S = pl.S; d.R = pl.R;
     char *base = (char *)workspace;
@@ -390,7 +432,8 @@ int32_t gcc_nce_forward(const gcc_nce_args *a, void *workspace, int64_t workspac
     if (!a->loss || !a->prob) { snprintf(g_err, kErrLen, "gcc_nce_forward: loss/prob are required"); return -1; }
     hipStream_t s = (hipStream_t)stream;
     prof_mark(prof, 0, s);
-    hipLaunchKernelGGL((nce_slice_kernel<false>), dim3(pl.S, pl.QB), dim3(kThreads), 0, s, d);
+    if (d.bf16) hipLaunchKernelGGL((nce_slice_kernel<false, true>), dim3(pl.S, pl.QB), dim3(kThreads), 0, s, d);
+    else hipLaunchKernelGGL((nce_slice_kernel<false, false>), dim3(pl.S, pl.QB), dim3(kThreads), 0, s, d);
     hipLaunchKernelGGL(nce_combine_kernel, dim3((d.B + (kThreads >> 6) - 1) / (kThreads >> 6)), dim3(kThreads), 0, s, d);
     prof_mark(prof, 1, s);
     hipError_t e = hipGetLastError();
@@ -412,7 +455,8 @@ int32_t gcc_nce_backward(const gcc_nce_args *a, const float *dloss, int32_t by_m
     d.dloss = dloss; d.by_mem_row = by_mem_row; d.dq = dq;
     hipStream_t s = (hipStream_t)stream;
     prof_mark(prof, 0, s);
-    hipLaunchKernelGGL((nce_slice_kernel<true>), dim3(pl.S, pl.QB), dim3(kThreads), 0, s, d);
+    if (d.bf16) hipLaunchKernelGGL((nce_slice_kernel<true, true>), dim3(pl.S, pl.QB), dim3(kThreads), 0, s, d);
+    else hipLaunchKernelGGL((nce_slice_kernel<true, false>), dim3(pl.S, pl.QB), dim3(kThreads), 0, s, d);
     hipLaunchKernelGGL(nce_dq_kernel, dim3((a->B * 16 + kThreads - 1) / kThreads), dim3(kThreads), 0, s, d);
     prof_mark(prof, 1, s);
     hipError_t e = hipGetLastError();

@@ -1540,74 +1540,74 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     const int kq = min(k, nr);
 
     // dst = alpha * (M' src - center * src) - gamma * dst   (rows of 64 floats; 16 threads x float4 per row)
+    // 8 threads per row (8 block vectors = 2 x float4 each), 128 rows at a time, four gathers per vector pair in flight:
+    // the block lives in L2 and a product is bound by the latency of its gathers
+    auto gather = [&](const float *src, int e0, int e1, float *acc) {
+        const int q8 = 8 * (tid & 7);
+        for (int e = e0; e < e1; e += 4) {
+            int cj[4];
+            float sc[4];
+            float4 xa[4], xb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = e + u < e1;
+                cj[u] = (int)ccol[in ? e + u : e0];
+                sc[u] = in ? scale[cj[u]] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xa[u] = *(const float4 *)(src + (int64_t)cj[u] * kChP + q8);
+                xb[u] = *(const float4 *)(src + (int64_t)cj[u] * kChP + q8 + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] = fmaf(sc[u], xa[u].x, acc[0]); acc[1] = fmaf(sc[u], xa[u].y, acc[1]);
+                acc[2] = fmaf(sc[u], xa[u].z, acc[2]); acc[3] = fmaf(sc[u], xa[u].w, acc[3]);
+                acc[4] = fmaf(sc[u], xb[u].x, acc[4]); acc[5] = fmaf(sc[u], xb[u].y, acc[5]);
+                acc[6] = fmaf(sc[u], xb[u].z, acc[6]); acc[7] = fmaf(sc[u], xb[u].w, acc[7]);
+            }
+        }
+    };
+    // dst = alpha * (M' src - center * src) - gamma * dst   (rows of 64 floats)
     auto spmm = [&](const float *src, float *dst, float alpha, float center, float gamma) {
-        const int q4 = 4 * (tid & 15), g16 = tid >> 4;
-        for (int c = g16; c < nchunk; c += kChThreads / 16) {            // chunks of the long rows -> slab
+        const int q8 = 8 * (tid & 7), g8 = tid >> 3;
+        for (int c = g8; c < nchunk; c += kChThreads / 8) {              // chunks of the long rows -> slab
             int x = 0;
             while (longfirst[x + 1] <= c) ++x;
             const int r = longrow[x];
-            const int e1 = min(chunk_beg[c] + kChLongDeg, (int)crow[r + 1]);
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (int e = chunk_beg[c]; e < e1; e += 4) {
-                int cj[4];
-                float sc[4];
-                float4 xv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool in = e + u < e1;
-                    cj[u] = (int)ccol[in ? e + u : chunk_beg[c]];
-                    sc[u] = in ? scale[cj[u]] : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) xv[u] = *(const float4 *)(src + (int64_t)cj[u] * kChP + q4);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    s0 = fmaf(sc[u], xv[u].x, s0); s1 = fmaf(sc[u], xv[u].y, s1);
-                    s2 = fmaf(sc[u], xv[u].z, s2); s3 = fmaf(sc[u], xv[u].w, s3);
-                }
-            }
-            *(float4 *)(slab + c * kChP + q4) = make_float4(s0, s1, s2, s3);
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            gather(src, chunk_beg[c], min(chunk_beg[c] + kChLongDeg, (int)crow[r + 1]), acc);
+            *(float4 *)(slab + c * kChP + q8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *(float4 *)(slab + c * kChP + q8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
         }
         if (nchunk) __syncthreads();
-        for (int r = g16; r < nr; r += kChThreads / 16) {
+        for (int r = g8; r < nr; r += kChThreads / 8) {
             const int e0 = (int)crow[r], e1 = (int)crow[r + 1];
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (e1 - e0 > kChLongDeg) {
                 int x = 0;
                 while (longrow[x] != r) ++x;
                 for (int c = longfirst[x]; c < longfirst[x + 1]; ++c) {
-                    const float4 pv = *(const float4 *)(slab + c * kChP + q4);
-                    s0 += pv.x; s1 += pv.y; s2 += pv.z; s3 += pv.w;
+                    const float4 pa = *(const float4 *)(slab + c * kChP + q8), pb = *(const float4 *)(slab + c * kChP + q8 + 4);
+                    acc[0] += pa.x; acc[1] += pa.y; acc[2] += pa.z; acc[3] += pa.w;
+                    acc[4] += pb.x; acc[5] += pb.y; acc[6] += pb.z; acc[7] += pb.w;
                 }
             } else {
-                for (int e = e0; e < e1; e += 4) {               // four gathers in flight (the block lives in L2)
-                    int cj[4];
-                    float sc[4];
-                    float4 xv[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool in = e + u < e1;
-                        cj[u] = (int)ccol[in ? e + u : e0];
-                        sc[u] = in ? scale[cj[u]] : 0.f;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) xv[u] = *(const float4 *)(src + (int64_t)cj[u] * kChP + q4);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        s0 = fmaf(sc[u], xv[u].x, s0); s1 = fmaf(sc[u], xv[u].y, s1);
-                        s2 = fmaf(sc[u], xv[u].z, s2); s3 = fmaf(sc[u], xv[u].w, s3);
-                    }
-                }
+                gather(src, e0, e1, acc);
             }
             const float sr = scale[r];
-            const float4 own = *(const float4 *)(src + (int64_t)r * kChP + q4);
-            float4 o = make_float4(alpha * (sr * s0 - center * own.x), alpha * (sr * s1 - center * own.y),
-                                   alpha * (sr * s2 - center * own.z), alpha * (sr * s3 - center * own.w));
+            const float4 oa = *(const float4 *)(src + (int64_t)r * kChP + q8), ob = *(const float4 *)(src + (int64_t)r * kChP + q8 + 4);
+            float o[8] = {alpha * (sr * acc[0] - center * oa.x), alpha * (sr * acc[1] - center * oa.y),
+                          alpha * (sr * acc[2] - center * oa.z), alpha * (sr * acc[3] - center * oa.w),
+                          alpha * (sr * acc[4] - center * ob.x), alpha * (sr * acc[5] - center * ob.y),
+                          alpha * (sr * acc[6] - center * ob.z), alpha * (sr * acc[7] - center * ob.w)};
             if (gamma != 0.f) {
-                const float4 old = *(const float4 *)(dst + (int64_t)r * kChP + q4);
-                o.x -= gamma * old.x; o.y -= gamma * old.y; o.z -= gamma * old.z; o.w -= gamma * old.w;
+                const float4 da = *(const float4 *)(dst + (int64_t)r * kChP + q8), db = *(const float4 *)(dst + (int64_t)r * kChP + q8 + 4);
+                o[0] -= gamma * da.x; o[1] -= gamma * da.y; o[2] -= gamma * da.z; o[3] -= gamma * da.w;
+                o[4] -= gamma * db.x; o[5] -= gamma * db.y; o[6] -= gamma * db.z; o[7] -= gamma * db.w;
             }
-            *(float4 *)(dst + (int64_t)r * kChP + q4) = o;
+            *(float4 *)(dst + (int64_t)r * kChP + q8) = make_float4(o[0], o[1], o[2], o[3]);
+            *(float4 *)(dst + (int64_t)r * kChP + q8 + 4) = make_float4(o[4], o[5], o[6], o[7]);
         }
         __syncthreads();
     };
@@ -1645,26 +1645,41 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         }
         if (rr) spmm(XA, XB, 1.0f, 0.f, 0.f);                            // W = M' X
         PHASE_TICK(1);                                                   // sparse products
-        // ---- G = X^T X (and K = X^T W)
+        // ---- G = X^T X (and K = X^T W), fp64 accumulation.  Tiles of 32 rows of X and of W go through LDS (the slab):
+        //      one coalesced 16-byte load per thread and tile, requested a tile ahead, instead of a chain of L2 round trips
         {
             const int i = tid >> 4, j4 = 4 * (tid & 15);
             double g0 = 0, g1 = 0, g2 = 0, g3 = 0, k0 = 0, k1 = 0, k2 = 0, k3 = 0;
-            if (rr) {
-#pragma unroll 4
-                for (int r = 0; r < nr; ++r) {
-                    const double xi = (double)XA[(int64_t)r * kChP + i];
-                    const float4 xj = *(const float4 *)(XA + (int64_t)r * kChP + j4);
-                    const float4 wj = *(const float4 *)(XB + (int64_t)r * kChP + j4);
-                    g0 += xi * xj.x; g1 += xi * xj.y; g2 += xi * xj.z; g3 += xi * xj.w;
-                    k0 += xi * wj.x; k1 += xi * wj.y; k2 += xi * wj.z; k3 += xi * wj.w;
+            float *tx = slab, *twv = slab + 32 * kChP;           // [32][64] each
+            const bool isw = tid >= kChThreads / 2;
+            const int lt = tid & (kChThreads / 2 - 1);            // float4 index inside a tile: row lt >> 4, quad lt & 15
+            const float *gsrc = isw ? XB : XA;
+            auto fetch = [&](int t0) -> float4 {
+                const int r = t0 + (lt >> 4);
+                return (r < nr && (!isw || rr)) ? *(const float4 *)(gsrc + (int64_t)r * kChP + 4 * (lt & 15)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            };
+            float4 nxt = fetch(0);
+            for (int t0 = 0; t0 < nr; t0 += 32) {
+                *(float4 *)((isw ? twv : tx) + 4 * lt) = nxt;
+                __syncthreads();
+                if (t0 + 32 < nr) nxt = fetch(t0 + 32);
+                const int rows = min(32, nr - t0);
+                if (rr) {
+                    for (int r = 0; r < rows; ++r) {
+                        const double xi = (double)tx[r * kChP + i];
+                        const float4 xj = *(const float4 *)(tx + r * kChP + j4);
+                        const float4 wj = *(const float4 *)(twv + r * kChP + j4);
+                        g0 += xi * xj.x; g1 += xi * xj.y; g2 += xi * xj.z; g3 += xi * xj.w;
+                        k0 += xi * wj.x; k1 += xi * wj.y; k2 += xi * wj.z; k3 += xi * wj.w;
+                    }
+                } else {
+                    for (int r = 0; r < rows; ++r) {
+                        const double xi = (double)tx[r * kChP + i];
+                        const float4 xj = *(const float4 *)(tx + r * kChP + j4);
+                        g0 += xi * xj.x; g1 += xi * xj.y; g2 += xi * xj.z; g3 += xi * xj.w;
+                    }
                 }
-            } else {
-#pragma unroll 8
-                for (int r = 0; r < nr; ++r) {
-                    const double xi = (double)XA[(int64_t)r * kChP + i];
-                    const float4 xj = *(const float4 *)(XA + (int64_t)r * kChP + j4);
-                    g0 += xi * xj.x; g1 += xi * xj.y; g2 += xi * xj.z; g3 += xi * xj.w;
-                }
+                __syncthreads();
             }
             double *gp = G + i * kChP + j4, *kp = K + i * kChP + j4;
             gp[0] = g0; gp[1] = g1; gp[2] = g2; gp[3] = g3;

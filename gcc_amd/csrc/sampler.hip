@@ -72,14 +72,16 @@ struct Work {
     int32_t *nbp;         // [G + 1]     node offset of a subgraph inside its view's batch       (prefix kernel A)
     int32_t *ebp;         // [G + 1]     edge offset of a subgraph inside its view's batch       (prefix kernel B)
     int32_t *ucnt;        // [unit_cap]  hits of every unit
+    int32_t *vdesc;       // [vwg_cap]   subgraph of every virtual workgroup                    (prefix step A)
+    int32_t *ticket;      // [2]         arrival counters: walk kernel, induce kernel (zero between calls)
     int32_t *scratch;     // [scratch_entries] hits: (row << 16) | local column, one slot of 1024 per unit
     int32_t ncap;
-    int64_t unit_cap;
+    int64_t unit_cap, vwg_cap;
 };
 
 struct WorkLayout {
     int64_t off_seeds, off_n, off_quads, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowq,
-        off_vbp, off_ubp, off_sbp, off_nbp, off_ebp, off_ucnt, off_scratch, total, unit_cap;
+        off_vbp, off_ubp, off_sbp, off_nbp, off_ebp, off_ucnt, off_vdesc, off_ticket, off_scratch, total, unit_cap, vwg_cap;
     int32_t ncap;
 };
 
@@ -105,6 +107,9 @@ inline WorkLayout work_layout(int32_t lmax, int32_t B, int64_t scratch_entries)
     w.off_nbp = o;    o = al(o + 4 * (G + 1));
     w.off_ebp = o;    o = al(o + 4 * (G + 1));
     w.off_ucnt = o;   o = al(o + 4 * w.unit_cap);
+    w.vwg_cap = w.unit_cap / kUnitsPerVwg + G + 1;
+    w.off_vdesc = o;  o = al(o + 4 * w.vwg_cap);
+    w.off_ticket = o; o = al(o + 8);
     w.off_scratch = o; o = al(o + 4 * scratch_entries);
     w.total = o;
     return w;
@@ -135,6 +140,8 @@ __device__ __forceinline__ int block_scan_incl(int v, int *total, int32_t *wsum)
 }
 
 __device__ __forceinline__ int row_quads(int rb, int d) { return ((rb + d + 3) >> 2) - (rb >> 2); }
+__device__ __forceinline__ bool last_workgroup(int32_t *ticket, int32_t *flag_lds);
+__device__ void prefix_step_a(int32_t B, const Work &w, int32_t *wsum, long long *wsum64);
 
 // ------------------------------------------------------------------ K1 ----
 __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
@@ -293,6 +300,14 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
         w.sub_quads[g] = run;
         w.sub_nnz[g] = 0;
     }
+    // ---- the last workgroup to finish computes the prefixes the induction needs (no separate launch)
+    __shared__ int32_t last_flag;
+    __shared__ int32_t wsum16[16];
+    __shared__ long long wsum64[4];
+    if (last_workgroup(w.ticket, &last_flag)) {
+        prefix_step_a(B, w, wsum16, wsum64);
+        if (tid == 0) w.ticket[0] = 0;                    // ready for the next call
+    }
 }
 
 // block-wide exclusive scan of vals over [0, count) into LDS out[0..count] (out[count] = total);
@@ -338,35 +353,86 @@ __device__ __forceinline__ int upper_slot(const int32_t *arr, int count, int key
 
 __device__ __forceinline__ int units_of(int quads) { return (quads + kUnitQuads - 1) / kUnitQuads; }
 
-// ------------------------------------------------------------------ K1b / K2b ----
-// One workgroup: exclusive prefixes over the G = 2 B subgraphs that every workgroup of induce_kernel / pack_kernel
-// needs.  kAfterInduce = false: virtual workgroups, units, scratch slots, node offsets (per view); true: edge offsets
-// (per view; the induced edge counts exist only then).
-template <bool kAfterInduce>
-__global__ __launch_bounds__(256) void subgraph_prefix_kernel(int32_t B, Work w)
+// ------------------------------------------------------------------ prefix steps ----
+// Exclusive prefixes over the G = 2 B subgraphs that every workgroup of induce_kernel / pack_kernel needs, computed by
+// the LAST workgroup of the kernel before (arrival ticket; the other workgroups' results are read with agent-scope
+// loads after the acquire): step A after the walks (virtual workgroups, units, scratch slots, node offsets per view,
+// subgraph of every virtual workgroup), step B after the induction (edge offsets per view).
+// Returns true in the workgroup that arrives last.  All threads call.
+__device__ __forceinline__ bool last_workgroup(int32_t *ticket, int32_t *flag_lds)
 {
-    DYN_SMEM(smem);
-    __shared__ long long wsum64[5];
-    __shared__ int32_t wsum32[5];
-    const int G = 2 * B, tid = (int)threadIdx.x;
-    int32_t *tmp = (int32_t *)smem;                  // [G + 1]
-    if (!kAfterInduce) {
-        long long *tmp64 = (long long *)(tmp + ((G + 2) & ~1));
-        block_exclusive_scan<int32_t>(tmp, G, [&](int g) { return (units_of(w.sub_quads[g]) + kUnitsPerVwg - 1) / kUnitsPerVwg; }, wsum32);
-        for (int g = tid; g <= G; g += 256) w.vbp[g] = tmp[g];
-        __syncthreads();
-        block_exclusive_scan<int32_t>(tmp, G, [&](int g) { return units_of(w.sub_quads[g]); }, wsum32);
-        for (int g = tid; g <= G; g += 256) w.ubp[g] = tmp[g];
-        __syncthreads();
-        block_exclusive_scan<long long>(tmp64, G, [&](int g) { return 4ll * (long long)w.sub_quads[g]; }, wsum64);
-        for (int g = tid; g <= G; g += 256) w.sbp[g] = tmp64[g];
-        __syncthreads();
-        block_exclusive_scan<int32_t>(tmp, G, [&](int g) { return w.sub_n[g]; }, wsum32);
-        for (int g = tid; g <= G; g += 256) w.nbp[g] = tmp[g] - (g >= B && g < G ? tmp[B] : 0);   // restart at view k
-    } else {
-        block_exclusive_scan<int32_t>(tmp, G, [&](int g) { return w.sub_nnz[g]; }, wsum32);
-        for (int g = tid; g <= G; g += 256) w.ebp[g] = tmp[g] - (g >= B && g < G ? tmp[B] : 0);
+    device_fence();                                       // this workgroup's results are visible device wide
+    __syncthreads();
+    if (threadIdx.x == 0) *flag_lds = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    const bool last = *flag_lds != 0;
+    if (last) device_fence();
+    return last;
+}
+
+// dst[view * B + b] = exclusive prefix of src within each view (dgl.batch offsets restart per view).  All threads call.
+__device__ void view_prefix(int32_t B, const int32_t *src, int32_t *dst, int32_t *wsum /* LDS [4] */)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int view = 0; view < 2; ++view) {
+        int carry = 0;                                   // block-uniform
+        for (int b0 = 0; b0 < B; b0 += (int)blockDim.x) {
+            const int b = b0 + tid;
+            const int v = b < B ? load_fresh_i32(src + view * B + b) : 0;
+            const int incl = wave_scan_incl(v);
+            if (lane == 63) wsum[wv] = incl;
+            __syncthreads();
+            int base = carry, tot = 0;
+            for (int k = 0; k < ((int)blockDim.x >> 6); ++k) {
+                if (k < wv) base += wsum[k];
+                tot += wsum[k];
+            }
+            if (b < B) dst[view * B + b] = base + incl - v;
+            carry += tot;
+            __syncthreads();
+        }
     }
+}
+
+// step A, one pass: thread t owns subgraphs t, t + 256, ... ; carries in registers (block-uniform)
+__device__ void prefix_step_a(int32_t B, const Work &w, int32_t *wsum /* LDS [4][4] */, long long *wsum64 /* LDS [4] */)
+{
+    const int G = 2 * B, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int cv = 0, cu = 0;
+    long long cs = 0;
+    for (int g0 = 0; g0 < G; g0 += (int)blockDim.x) {
+        const int g = g0 + tid;
+        const bool in = g < G;
+        const int q = in ? load_fresh_i32(w.sub_quads + g) : 0;
+        const int u = units_of(q), v = (u + kUnitsPerVwg - 1) / kUnitsPerVwg;
+        const int iv = wave_scan_incl(v), iu = wave_scan_incl(u);
+        long long is = 4ll * q;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long t = wave_shfl_up(is, d);
+            if (lane >= d) is += t;
+        }
+        if (lane == 63) { wsum[wv * 4 + 0] = iv; wsum[wv * 4 + 1] = iu; wsum64[wv] = is; }
+        __syncthreads();
+        int bv = cv, bu = cu, tv = 0, tu = 0;
+        long long bs = cs, ts = 0;
+        for (int k = 0; k < ((int)blockDim.x >> 6); ++k) {
+            if (k < wv) { bv += wsum[k * 4]; bu += wsum[k * 4 + 1]; bs += wsum64[k]; }
+            tv += wsum[k * 4]; tu += wsum[k * 4 + 1]; ts += wsum64[k];
+        }
+        if (in) {
+            const int v0 = bv + iv - v;
+            w.vbp[g] = v0;
+            w.ubp[g] = bu + iu - u;
+            w.sbp[g] = bs + is - 4ll * q;
+            for (int p = 0; p < v; ++p)
+                if (v0 + p < w.vwg_cap) w.vdesc[v0 + p] = g;
+        }
+        cv += tv; cu += tu; cs += ts;
+        __syncthreads();
+    }
+    if (tid == 0) { w.vbp[G] = cv; w.ubp[G] = cu; w.sbp[G] = cs; }
+    view_prefix(B, w.sub_n, w.nbp, wsum);
 }
 
 __device__ __forceinline__ bool scratch_overflows(const Work &w, int g, int64_t scratch_entries)
@@ -379,17 +445,18 @@ __device__ __forceinline__ bool scratch_overflows(const Work &w, int g, int64_t 
 static long long *g_induce_ticks = nullptr;      // diagnostics (gcc_sampler_debug_ticks): [0..2] phase ticks, [15] workgroups
 #define IND_TICK(ph) do { if (ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&ticks[ph], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
-    const int32_t *__restrict__ col_idx, int64_t num_edges, int32_t bm_log2_cap, int32_t G, int64_t scratch_entries,
+    const int32_t *__restrict__ col_idx, int64_t num_edges, int32_t bm_log2_cap, int32_t B, int64_t scratch_entries,
     Work w, int32_t *__restrict__ status, long long *ticks)
 {
     DYN_SMEM(smem);
-    const int ncap = w.ncap;
+    __shared__ int32_t last_flag;
+    __shared__ int32_t wsum[4];
+    const int ncap = w.ncap, G = 2 * B;
     uint32_t *snodes = (uint32_t *)smem;                     // [ncap]     members (seed first, the rest ascending)
     int32_t *sq = (int32_t *)(snodes + ncap);                // [ncap + 1] exclusive prefix of quads per row
     int32_t *srb = sq + (ncap + 1);                          // [ncap]     row begin
     int32_t *srd = srb + ncap;                               // [ncap]     row degree
-    int32_t *vbp = srd + ncap;                               // [G + 1]    exclusive prefix of virtual workgroups
-    uint32_t *bm = (uint32_t *)(vbp + (G + 1));              // [1 << (bm_log2_cap - 5)] Bloom bitmap of the members
+    uint32_t *bm = (uint32_t *)(srd + ncap);                 // [1 << (bm_log2_cap - 5)] Bloom bitmap of the members
     uint32_t *candv_all = bm + (1u << (bm_log2_cap - 5));    // [4][kCandCap] Bloom survivors (parent ids) ...
     uint16_t *candr_all = (uint16_t *)(candv_all + 4 * kCandCap);   // [4][kCandCap] ... and their row
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
@@ -397,14 +464,11 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
     uint16_t *candr = candr_all + wave * kCandCap;
     long long tick_ = ticks ? device_ticks() : 0;
     if (ticks && tid == 0) atomicAdd((unsigned long long *)&ticks[15], 1ull);
-    for (int g = tid; g <= G; g += kInduceThreads) vbp[g] = w.vbp[g];      // (subgraph_prefix_kernel)
-    __syncthreads();
-    IND_TICK(0);
-    const int total_vb = vbp[G];
+    const int total_vb = w.vbp[G];                           // (prefix step A, last workgroup of the walk kernel)
     int cur_g = -1, bshift = 0;
     for (int vb = (int)blockIdx.x; vb < total_vb; vb += (int)gridDim.x) {
-        const int g = upper_slot(vbp, G, vb);
-        const int part = vb - vbp[g];
+        const int g = w.vdesc[vb];
+        const int part = vb - w.vbp[g];
         const int n = w.sub_n[g], totq = w.sub_quads[g];
         const int nunits = units_of(totq);
         if (scratch_overflows(w, g, scratch_entries)) {      // block-uniform
@@ -413,6 +477,7 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
         }
         const long long sbase = w.sbp[g];
         const int ubase = w.ubp[g];
+        IND_TICK(0);
         if (g != cur_g) {                                    // block-uniform
             __syncthreads();                                 // the previous subgraph's tables are no longer read
             int bl = 11;                                     // >= 64 bits per member, >= 2048 bits
@@ -439,35 +504,41 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
             cur_g = g;
             IND_TICK(1);
         }
-        int my_nnz = 0;
-#pragma unroll 1
-        for (int k = 0; k < kUnitsPerVwg / 4; ++k) {
-            const int unit = part * kUnitsPerVwg + k * 4 + wave;     // consecutive units go to different waves
-            if (unit >= nunits) break;                               // wave-uniform
-            int32_t *out = w.scratch + sbase + (long long)unit * kUnitElems;
-            // ---- the unit's 4 x 64 quads: row of every quad (binary search in the LDS prefix), then all loads in flight
-            uint4 v[4];
-            int lo_[4], hi_[4], a0_[4], r_[4];
+        // ---- this wave's units (consecutive units go to different waves): the rows of all their quads (binary search
+        //      in the LDS prefix), then ALL loads in flight together (kUnitsPerVwg / 4 x 4 dwordx4 per lane)
+        constexpr int kPer = kUnitsPerVwg / 4;
+        uint4 v[kPer][4];
+        int lo_[kPer][4], hi_[kPer][4], a0_[kPer][4], r_[kPer][4];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int unit = part * kUnitsPerVwg + k * 4 + wave;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int fq = unit * kUnitQuads + u * 64 + lane;
-                const bool ok = fq < totq;
+                const bool ok = unit < nunits && fq < totq;
                 const int r = ok ? upper_slot(sq, n, fq) : 0;
                 const int rbv = srb[r], dv = srd[r];
                 const int a0 = (((rbv >> 2) + (fq - sq[r])) << 2);   // element index of the aligned quad
-                r_[u] = r;
-                a0_[u] = a0;
-                lo_[u] = ok ? rbv : 0x7FFFFFFF;                      // elements outside [lo, hi) belong to other rows
-                hi_[u] = ok ? rbv + dv : 0;
+                r_[k][u] = r;
+                a0_[k][u] = a0;
+                lo_[k][u] = ok ? rbv : 0x7FFFFFFF;                   // elements outside [lo, hi) belong to other rows
+                hi_[k][u] = ok ? rbv + dv : 0;
                 if (ok && (int64_t)a0 + 4 <= num_edges) {
-                    v[u] = *(const uint4 *)(col_idx + a0);
+                    v[k][u] = *(const uint4 *)(col_idx + a0);
                 } else {                                             // the array's last quad may be partial
                     uint32_t t[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) t[e] = (ok && (int64_t)a0 + e < num_edges) ? (uint32_t)col_idx[a0 + e] : kEmpty;
-                    v[u] = make_uint4(t[0], t[1], t[2], t[3]);
+                    v[k][u] = make_uint4(t[0], t[1], t[2], t[3]);
                 }
             }
+        }
+        int my_nnz = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int unit = part * kUnitsPerVwg + k * 4 + wave;
+            if (unit >= nunits) break;                               // wave-uniform
+            int32_t *out = w.scratch + sbase + (long long)unit * kUnitElems;
             int ncand = 0, nout = 0;                                 // wave-uniform
             auto drain = [&]() {
                 wave_sync();
@@ -497,13 +568,13 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (ncand + 4 * 64 > kCandCap) drain();              // wave-uniform
-                const uint32_t vals[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                const uint32_t vals[4] = {v[k][u].x, v[k][u].y, v[k][u].z, v[k][u].w};
                 uint32_t pass = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int a = a0_[u] + e;
+                    const int a = a0_[k][u] + e;
                     const uint32_t h = (vals[e] * kHashMul) >> bshift;
-                    const bool in_row = a >= lo_[u] && a < hi_[u];
+                    const bool in_row = a >= lo_[k][u] && a < hi_[k][u];
                     const uint32_t bit = in_row ? (bm[h >> 5] >> (h & 31)) & 1u : 0u;
                     pass |= bit << e;
                 }
@@ -514,7 +585,7 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
                 for (int e = 0; e < 4; ++e) {
                     if (pass & (1u << e)) {
                         candv[at] = vals[e];
-                        candr[at] = (uint16_t)r_[u];
+                        candr[at] = (uint16_t)r_[k][u];
                         ++at;
                     }
                 }
@@ -526,6 +597,11 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
         }
         if (lane == 0 && my_nnz) atomicAdd(&w.sub_nnz[g], my_nnz);
         IND_TICK(2);
+    }
+    // ---- the last workgroup to finish computes the edge offsets the pack kernel needs (no separate launch)
+    if (last_workgroup(w.ticket + 1, &last_flag)) {
+        view_prefix(B, w.sub_nnz, w.ebp, wsum);
+        if (tid == 0) w.ticket[1] = 0;
     }
 }
 
@@ -542,7 +618,7 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
     const BatchOutDev o = view ? ok : oq;
     const int n = w.sub_n[g];
     const int nnz = w.sub_nnz[g];
-    const long long node_base = w.nbp[g];            // (subgraph_prefix_kernel<false / true>)
+    const long long node_base = w.nbp[g];            // (prefix steps A / B)
     const long long edge_base = w.ebp[g];
     const long long sbase = w.sbp[g];
     const int ubase = w.ubp[g];
@@ -707,6 +783,9 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     w.nbp = (int32_t *)(base + wl.off_nbp);
     w.ebp = (int32_t *)(base + wl.off_ebp);
     w.ucnt = (int32_t *)(base + wl.off_ucnt);
+    w.vdesc = (int32_t *)(base + wl.off_vdesc);
+    w.ticket = (int32_t *)(base + wl.off_ticket);
+    w.vwg_cap = wl.vwg_cap;
     w.scratch = (int32_t *)(base + wl.off_scratch);
     w.ncap = wl.ncap;
     w.unit_cap = wl.unit_cap;
@@ -718,7 +797,7 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     int bmlog = 11;                                  // Bloom bitmap: >= 64 bits per member of the largest subgraph
     while ((1 << bmlog) < 64 * (g->lmax + 1) && bmlog < 20) ++bmlog;
     const size_t lds1 = ((size_t)p2max * 2 + 64) * 4;
-    const size_t lds2 = (size_t)wl.ncap * 16 + 4 + (size_t)(G + 1) * 4 + ((size_t)1 << (bmlog - 3)) + (size_t)4 * kCandCap * 6 + 16;
+    const size_t lds2 = (size_t)wl.ncap * 16 + 4 + ((size_t)1 << (bmlog - 3)) + (size_t)4 * kCandCap * 6 + 16;
     if (lds1 > 160 * 1024 || lds2 > 160 * 1024 - 256) {
         snprintf(g_err, kErrLen, "gcc_sample_batch: lmax=%d / batch too large for 160 KiB of LDS", g->lmax);
         return -4;
@@ -738,12 +817,9 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
                        g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, B,
                        p->restart_u32, p->seeds, w);
     prof_mark(p->prof, 1, s);
-    const size_t lds_pref = (size_t)(G + 2) * 4 + (size_t)(G + 1) * 8 + 16;
-    hipLaunchKernelGGL((subgraph_prefix_kernel<false>), dim3(1), dim3(256), lds_pref, s, B, w);
-    hipLaunchKernelGGL(induce_kernel, dim3(G * 8), dim3(kInduceThreads), lds2, s, g->col_idx, g->num_edges, bmlog, G,
+    hipLaunchKernelGGL(induce_kernel, dim3(G * 8), dim3(kInduceThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,
                        scratch_entries, w, status, g_induce_ticks);
     prof_mark(p->prof, 2, s);
-    hipLaunchKernelGGL((subgraph_prefix_kernel<true>), dim3(1), dim3(256), lds_pref, s, B, w);
     hipLaunchKernelGGL(pack_kernel, dim3(G * kPackParts), dim3(256), 0, s, B, w, oq, ok, scratch_entries, status);
     prof_mark(p->prof, 3, s);
     hipError_t e = hipGetLastError();

@@ -324,7 +324,13 @@ typedef struct gcc_nce_args {
     float *lse, *pos;        /* device [B] out: row log-sum-exp and positive logit               */
     float *loss, *prob;      /* device [1] out: mean(lse - pos) and mean(pos) (train.py:394,407) */
     float *out_dense;        /* device [B, K + (pos_mode == 0)] or NULL                         */
+    int32_t dtype;           /* GCC_NCE_F32: exact fp32 MFMA (parity mode, 1e-3 of the reference)  */
+                             /* GCC_NCE_BF16: q, k and the queue rounded to bf16 on load, fp32     */
+                             /*   accumulation and softmax (throughput mode of north_star; the     */
+                             /*   queue itself stays fp32 in HBM / in the checkpoint)              */
 } gcc_nce_args;
+#define GCC_NCE_F32 0
+#define GCC_NCE_BF16 1
 
 int64_t gcc_nce_workspace_bytes(int32_t B, int32_t K);
 int32_t gcc_nce_forward(const gcc_nce_args *a, void *workspace, int64_t workspace_bytes, gcc_prof *prof,

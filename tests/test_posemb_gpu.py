@@ -110,7 +110,7 @@ def test_c2_chunk_of_32_views_runs_clean_and_every_hub_item_passes_the_strict_in
     raws = [torch.zeros(s.node_cap, HID, device="cuda") for _ in views]
     pe.multi(views, evals=evals, raws=raws)
     torch.cuda.synchronize()
-    assert pe.status.cpu().tolist()[0] == 0, pe.status.cpu().tolist()
+    assert pe.status.cpu().tolist()[0] == 0, "status words: " + " ".join(str(v) for v in pe.status.cpu().tolist())
     pe.check_status(strict=True)
     nbig = nkry = 0
     for vi in (0, 1, 17, 30):                                 # q and k views of different steps
@@ -130,3 +130,33 @@ def test_c2_chunk_of_32_views_runs_clean_and_every_hub_item_passes_the_strict_in
             _check(sub, x[lo:hi], ev[b:b + 1], raw[lo:hi])
         nbig += int((red > SLOT_MAX).sum())
     assert nbig > 0 and nkry == 0
+
+
+def test_ego_net_that_was_flagged_on_the_device_only():
+    """Subgraph 126 of the k view of step 4 of the bench workload (54 nodes, deflated 47): clean on the emulator, but the
+    device build set GCC_STATUS_POSEMB_NOT_CONVERGED for it inside 32-view calls.  Single-item calls with many start
+    seeds, strict invariants, and the diagnostics words printed on failure."""
+    import os
+
+    from gcc_amd.posemb import DevicePosEmb
+    from gcc_amd.sampler import BatchedCSR
+    from tests.test_posemb_emu import _check
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "posemb_item_s4_v1_b126.npz"))
+    rp, ci = z["row_ptr"], z["col_idx"]
+    n = len(rp) - 1
+    i32 = dict(dtype=torch.int32, device="cuda")
+    view = dict(node_off=torch.tensor([0, n]), row_ptr=torch.from_numpy(rp.astype(np.int64)), col_idx=torch.from_numpy(ci.astype(np.int64)))
+    bad = []
+    for seed in range(24):
+        q = BatchedCSR(1, torch.tensor([0, n], **i32), torch.tensor([0, len(ci)], **i32), torch.zeros(n, **i32),
+                       torch.zeros(n, **i32), torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda())
+        pe = DevicePosEmb(1, n, HID, device="cuda", seed=seed)
+        evals, raw = torch.zeros(1, HID, device="cuda"), torch.zeros(n, HID, device="cuda")
+        pe(q, evals=evals, raw=raw)
+        st = pe.status.cpu().tolist()
+        if st[0]:
+            bad.append((seed, st))
+            continue
+        _check(view, q.pos_undirected[:n].cpu().numpy(), evals.cpu().numpy(), raw.cpu().numpy())
+    assert not bad, "status words of the flagged runs: " + "; ".join(f"seed {s}: {st}" for s, st in bad)

@@ -48,7 +48,9 @@ def test_pretrain_resume_generate(tmp_path, capsys):
     w_before = ckpt["model"]["gnn.ginlayers.0.apply_func.mlp.linears.0.weight"].clone()
 
     # --resume: weights / queue / EMA come from the checkpoint, training continues (train.py:487-506,685-702)
-    args2 = train.parse_option(common + ["--epochs", "1", "--resume", os.path.join(folder, "current.pth")])
+    # (4 epochs: the reference's schedule lr * warmup_linear((epoch * n_batch + idx) / (epochs * n_batch)) starts the count
+    #  at epoch 1 and is 0 throughout a 1-epoch run)
+    args2 = train.parse_option(common + ["--epochs", "4", "--resume", os.path.join(folder, "current.pth")])
     args2.gpu = args2.gpu[0]
     loss2 = train.main(args2)
     out2 = capsys.readouterr().out
