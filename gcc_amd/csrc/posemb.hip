@@ -149,6 +149,7 @@ struct EigShared {                   // per-workgroup scratch of the solver core
     float lamv[kVecCap], shiftv[kVecCap], lo[kVecCap], hi[kVecCap];
     int cs[kVecCap], posi[kVecCap];
     int na, maxpos, bad;
+    int diag_lost, diag_its;         // diagnostics of the last eig_top_vectors call
 };
 
 // A (n x n, symmetric, both triangles kept, row stride lda) -> T = Q^T A Q; Q = H_0 H_1 ... H_{n-3},
@@ -467,6 +468,7 @@ __device__ bool inverse_iteration_step(const TriLds &w, int n, int j, int jl, fl
 // in coef[.][32]); a second pass follows only where the first one removed more than half of a vector ("twice is
 // enough", Kahan / Parlett).  Returns (block-uniform) the number of vectors that vanished, i.e. were in the span of
 // their predecessors.  All threads call it; ends with a barrier.
+constexpr int kMaxInvIt = 12;         // solve + sweep rounds of eig_top_vectors (3 as a rule)
 constexpr float kVanish = 1e-4f;     // squared norm left of a unit vector below which it counts as "in the span of its predecessors"
 constexpr float kHeavy = 1e-2f;      // ... below which what is left is too noisy to be final
 
@@ -635,7 +637,7 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
     // vectors of a 16-dimensional eigenspace are never well conditioned) restarts from random numbers and buys three --
     // LAPACK's stein iterates on the same criterion.
     int need_until = 2;
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < kMaxInvIt; ++it) {
         for (int j0 = 0; j0 < na; j0 += w.bw) {
             if (tid < w.bw && j0 + tid < na) {
                 const bool ok = inverse_iteration_step(w, nr, j0 + tid, tid, es.shiftv[j0 + tid], it == 0, hseed);
@@ -651,6 +653,7 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
             else if (left < kHeavy) need_until = it + 1 > need_until ? it + 1 : need_until;
         }
         phase_tick(tick_row, 4, tick);
+        if (tid == 0) { es.diag_lost = lost; es.diag_its = it + 1; }
         if (it >= need_until) break;
     }
     for (int j = 2 * wv; j < na; j += 2 * kNW) {
@@ -922,6 +925,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
         atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
         if (atomicAdd(a.status + 4, 1) == 0) {               // diagnostics: the first item that failed
             a.status[5] = gb; a.status[6] = kCls; a.status[7] = nr; a.status[8] = es.bad; a.status[9] = n;
+            a.status[10] = es.diag_lost; a.status[11] = es.diag_its; a.status[12] = es.maxpos; a.status[13] = sh_na;
         }
     }
     // ---- expand to the n original nodes; x = normalize(u, "l2") row-wise, zero padded (data_util.py:260-262)
@@ -1686,6 +1690,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             kp[0] = k0; kp[1] = k1; kp[2] = k2; kp[3] = k3;
         }
         __syncthreads();
+        PHASE_TICK(5);                                           // Gram matrices
         // ---- small dense algebra, all 16 waves, fp64 in LDS: Jacobi scaling G^ = D G D; shifted Cholesky G^ = L L^T
         //      (right-looking, two barriers per column); Linv = L^-1 by recursive doubling over the diagonal blocks
         //      (inv [A 0; B C] = [A^-1 0; -C^-1 B A^-1  C^-1]: 6 levels); with a Ritz step H = Linv K^ Linv^T
@@ -1750,6 +1755,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         }
         __syncthreads();
         if (sh_fail) { failed = true; break; }
+        PHASE_TICK(6);                                           // Cholesky
         {   // Li = L with inverted diagonal; then the doubling levels
             const int i = tid >> 4, j4 = 4 * (tid & 15);
 #pragma unroll
@@ -1815,6 +1821,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
                 Af[i * kChLdy + j4 + u] = hrow[u];
             }
         }
+        PHASE_TICK(7);                                           // triangular inverse, projected matrix
         TriLds tw;
         tw.Y = Af + kChP * kChLdy;
         tw.ldy = kChLdy;
@@ -1846,7 +1853,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             ++nrr;
             if (tid < kChP) theta[tid] = es.lamv[tid];
         }
-        PHASE_TICK(2);                                           // Gram matrices + Ritz problem
+        PHASE_TICK(2);                                           // Ritz problem
         // ---- C = D Linv^T Y (Y = I without a Ritz step), stride 64, over H
         {
             const int i = tid >> 4, j4 = 4 * (tid & 15);

@@ -43,7 +43,8 @@ constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 constexpr int kWalkThreads = 256;  // 4 waves per subgraph
 constexpr int kUnitQuads = 256;    // 16-byte quads of col_idx per unit: 64 lanes x 4 dwordx4 loads
 constexpr int kUnitElems = 4 * kUnitQuads;
-constexpr int kUnitsPerVwg = 8;    // units per virtual workgroup (2 per wave)
+constexpr int kUnitsPerVwg = 16;   // units per virtual workgroup (4 per wave, two in flight at a time)
+constexpr int kUnitsInFlight = 2;  // per wave
 constexpr int kInduceThreads = 256;
 constexpr int kCandCap = 512;      // per-wave queue of Bloom survivors (drained when the next 256 might not fit)
 constexpr int kPackParts = 4;      // pack workgroups per subgraph (hub-seed subgraphs have 100x the units)
@@ -73,7 +74,6 @@ struct Work {
     int32_t *ebp;         // [G + 1]     edge offset of a subgraph inside its view's batch       (prefix kernel B)
     int32_t *ucnt;        // [unit_cap]  hits of every unit
     int32_t *vdesc;       // [vwg_cap]   subgraph of every virtual workgroup                    (prefix step A)
-    int32_t *ticket;      // [2]         arrival counters: walk kernel, induce kernel (zero between calls)
     int32_t *scratch;     // [scratch_entries] hits: (row << 16) | local column, one slot of 1024 per unit
     int32_t ncap;
     int64_t unit_cap, vwg_cap;
@@ -81,7 +81,7 @@ struct Work {
 
 struct WorkLayout {
     int64_t off_seeds, off_n, off_quads, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowq,
-        off_vbp, off_ubp, off_sbp, off_nbp, off_ebp, off_ucnt, off_vdesc, off_ticket, off_scratch, total, unit_cap, vwg_cap;
+        off_vbp, off_ubp, off_sbp, off_nbp, off_ebp, off_ucnt, off_vdesc, off_scratch, total, unit_cap, vwg_cap;
     int32_t ncap;
 };
 
@@ -109,7 +109,6 @@ inline WorkLayout work_layout(int32_t lmax, int32_t B, int64_t scratch_entries)
     w.off_ucnt = o;   o = al(o + 4 * w.unit_cap);
     w.vwg_cap = w.unit_cap / kUnitsPerVwg + G + 1;
     w.off_vdesc = o;  o = al(o + 4 * w.vwg_cap);
-    w.off_ticket = o; o = al(o + 8);
     w.off_scratch = o; o = al(o + 4 * scratch_entries);
     w.total = o;
     return w;
@@ -140,8 +139,7 @@ __device__ __forceinline__ int block_scan_incl(int v, int *total, int32_t *wsum)
 }
 
 __device__ __forceinline__ int row_quads(int rb, int d) { return ((rb + d + 3) >> 2) - (rb >> 2); }
-__device__ __forceinline__ bool last_workgroup(int32_t *ticket, int32_t *flag_lds);
-__device__ void prefix_step_a(int32_t B, const Work &w, int32_t *wsum, long long *wsum64);
+
 
 // ------------------------------------------------------------------ K1 ----
 __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
@@ -300,14 +298,6 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
         w.sub_quads[g] = run;
         w.sub_nnz[g] = 0;
     }
-    // ---- the last workgroup to finish computes the prefixes the induction needs (no separate launch)
-    __shared__ int32_t last_flag;
-    __shared__ int32_t wsum16[16];
-    __shared__ long long wsum64[4];
-    if (last_workgroup(w.ticket, &last_flag)) {
-        prefix_step_a(B, w, wsum16, wsum64);
-        if (tid == 0) w.ticket[0] = 0;                    // ready for the next call
-    }
 }
 
 // block-wide exclusive scan of vals over [0, count) into LDS out[0..count] (out[count] = total);
@@ -354,22 +344,11 @@ __device__ __forceinline__ int upper_slot(const int32_t *arr, int count, int key
 __device__ __forceinline__ int units_of(int quads) { return (quads + kUnitQuads - 1) / kUnitQuads; }
 
 // ------------------------------------------------------------------ prefix steps ----
-// Exclusive prefixes over the G = 2 B subgraphs that every workgroup of induce_kernel / pack_kernel needs, computed by
-// the LAST workgroup of the kernel before (arrival ticket; the other workgroups' results are read with agent-scope
-// loads after the acquire): step A after the walks (virtual workgroups, units, scratch slots, node offsets per view,
-// subgraph of every virtual workgroup), step B after the induction (edge offsets per view).
-// Returns true in the workgroup that arrives last.  All threads call.
-__device__ __forceinline__ bool last_workgroup(int32_t *ticket, int32_t *flag_lds)
-{
-    device_fence();                                       // this workgroup's results are visible device wide
-    __syncthreads();
-    if (threadIdx.x == 0) *flag_lds = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    const bool last = *flag_lds != 0;
-    if (last) device_fence();
-    return last;
-}
-
+// Exclusive prefixes over the G = 2 B subgraphs that every workgroup of induce_kernel / pack_kernel needs, one small
+// workgroup each: step A after the walks (virtual workgroups, units, scratch slots, node offsets per view, subgraph of
+// every virtual workgroup), step B after the induction (edge offsets per view).  (Folding them into the last workgroup
+// of the kernel before was measured: the agent-scope release every workgroup needs for the hand-off writes back L2 on
+// this multi-die part, 4096 times per launch -- the induction went from 45 to 305 us.  A kernel boundary is cheaper.)
 // dst[view * B + b] = exclusive prefix of src within each view (dgl.batch offsets restart per view).  All threads call.
 __device__ void view_prefix(int32_t B, const int32_t *src, int32_t *dst, int32_t *wsum /* LDS [4] */)
 {
@@ -378,7 +357,7 @@ __device__ void view_prefix(int32_t B, const int32_t *src, int32_t *dst, int32_t
         int carry = 0;                                   // block-uniform
         for (int b0 = 0; b0 < B; b0 += (int)blockDim.x) {
             const int b = b0 + tid;
-            const int v = b < B ? load_fresh_i32(src + view * B + b) : 0;
+            const int v = b < B ? src[view * B + b] : 0;
             const int incl = wave_scan_incl(v);
             if (lane == 63) wsum[wv] = incl;
             __syncthreads();
@@ -403,7 +382,7 @@ __device__ void prefix_step_a(int32_t B, const Work &w, int32_t *wsum /* LDS [4]
     for (int g0 = 0; g0 < G; g0 += (int)blockDim.x) {
         const int g = g0 + tid;
         const bool in = g < G;
-        const int q = in ? load_fresh_i32(w.sub_quads + g) : 0;
+        const int q = in ? w.sub_quads[g] : 0;
         const int u = units_of(q), v = (u + kUnitsPerVwg - 1) / kUnitsPerVwg;
         const int iv = wave_scan_incl(v), iu = wave_scan_incl(u);
         long long is = 4ll * q;
@@ -435,6 +414,18 @@ __device__ void prefix_step_a(int32_t B, const Work &w, int32_t *wsum /* LDS [4]
     view_prefix(B, w.sub_n, w.nbp, wsum);
 }
 
+__global__ __launch_bounds__(256) void prefix_a_kernel(int32_t B, Work w)
+{
+    __shared__ int32_t wsum[16];
+    __shared__ long long wsum64[4];
+    prefix_step_a(B, w, wsum, wsum64);
+}
+__global__ __launch_bounds__(256) void prefix_b_kernel(int32_t B, Work w)
+{
+    __shared__ int32_t wsum[4];
+    view_prefix(B, w.sub_nnz, w.ebp, wsum);
+}
+
 __device__ __forceinline__ bool scratch_overflows(const Work &w, int g, int64_t scratch_entries)
 {
     return w.sbp[g] + 4ll * (long long)w.sub_quads[g] > scratch_entries ||
@@ -449,8 +440,6 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
     Work w, int32_t *__restrict__ status, long long *ticks)
 {
     DYN_SMEM(smem);
-    __shared__ int32_t last_flag;
-    __shared__ int32_t wsum[4];
     const int ncap = w.ncap, G = 2 * B;
     uint32_t *snodes = (uint32_t *)smem;                     // [ncap]     members (seed first, the rest ascending)
     int32_t *sq = (int32_t *)(snodes + ncap);                // [ncap + 1] exclusive prefix of quads per row
@@ -504,14 +493,18 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
             cur_g = g;
             IND_TICK(1);
         }
-        // ---- this wave's units (consecutive units go to different waves): the rows of all their quads (binary search
-        //      in the LDS prefix), then ALL loads in flight together (kUnitsPerVwg / 4 x 4 dwordx4 per lane)
-        constexpr int kPer = kUnitsPerVwg / 4;
+        // ---- this wave's units (consecutive units go to different waves), kUnitsInFlight at a time: the rows of all
+        //      their quads (binary search in the LDS prefix), then all loads in flight together (2 x 4 dwordx4 per lane)
+        constexpr int kPer = kUnitsInFlight;
+        int my_nnz = 0;
+#pragma unroll 1
+        for (int batch = 0; batch < kUnitsPerVwg / 4 / kPer; ++batch) {
+        if (part * kUnitsPerVwg + batch * kPer * 4 + wave >= nunits) break;      // wave-uniform
         uint4 v[kPer][4];
         int lo_[kPer][4], hi_[kPer][4], a0_[kPer][4], r_[kPer][4];
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
-            const int unit = part * kUnitsPerVwg + k * 4 + wave;
+            const int unit = part * kUnitsPerVwg + (batch * kPer + k) * 4 + wave;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int fq = unit * kUnitQuads + u * 64 + lane;
@@ -533,10 +526,9 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
                 }
             }
         }
-        int my_nnz = 0;
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
-            const int unit = part * kUnitsPerVwg + k * 4 + wave;
+            const int unit = part * kUnitsPerVwg + (batch * kPer + k) * 4 + wave;
             if (unit >= nunits) break;                               // wave-uniform
             int32_t *out = w.scratch + sbase + (long long)unit * kUnitElems;
             int ncand = 0, nout = 0;                                 // wave-uniform
@@ -595,13 +587,9 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
             if (lane == 0) w.ucnt[ubase + unit] = nout;
             my_nnz += nout;
         }
+        }   // batch
         if (lane == 0 && my_nnz) atomicAdd(&w.sub_nnz[g], my_nnz);
         IND_TICK(2);
-    }
-    // ---- the last workgroup to finish computes the edge offsets the pack kernel needs (no separate launch)
-    if (last_workgroup(w.ticket + 1, &last_flag)) {
-        view_prefix(B, w.sub_nnz, w.ebp, wsum);
-        if (tid == 0) w.ticket[1] = 0;
     }
 }
 
@@ -784,7 +772,6 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     w.ebp = (int32_t *)(base + wl.off_ebp);
     w.ucnt = (int32_t *)(base + wl.off_ucnt);
     w.vdesc = (int32_t *)(base + wl.off_vdesc);
-    w.ticket = (int32_t *)(base + wl.off_ticket);
     w.vwg_cap = wl.vwg_cap;
     w.scratch = (int32_t *)(base + wl.off_scratch);
     w.ncap = wl.ncap;
@@ -817,9 +804,11 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
                        g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, B,
                        p->restart_u32, p->seeds, w);
     prof_mark(p->prof, 1, s);
+    hipLaunchKernelGGL(prefix_a_kernel, dim3(1), dim3(256), 0, s, B, w);
     hipLaunchKernelGGL(induce_kernel, dim3(G * 8), dim3(kInduceThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,
                        scratch_entries, w, status, g_induce_ticks);
     prof_mark(p->prof, 2, s);
+    hipLaunchKernelGGL(prefix_b_kernel, dim3(1), dim3(256), 0, s, B, w);
     hipLaunchKernelGGL(pack_kernel, dim3(G * kPackParts), dim3(256), 0, s, B, w, oq, ok, scratch_entries, status);
     prof_mark(p->prof, 3, s);
     hipError_t e = hipGetLastError();

@@ -153,7 +153,7 @@ class DeviceRWRSampler:
         nbytes = self.lib.gcc_sampler_workspace_bytes(self.graph.byref(), self.batch_size, self.scratch_entries)
         if nbytes < 0:
             raise RuntimeError(self.lib.gcc_last_error().decode())
-        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.graph.device)   # arrival counters start at 0
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.graph.device)
 
     def sample(self, first_sample_id: int, seeds=None, prof=None):
         """-> (BatchedCSR q, BatchedCSR k) for samples first_sample_id .. +B-1.

@@ -26,7 +26,7 @@ lib.gcc_posemb_debug_ticks(None)
 t = ticks.cpu().numpy().reshape(6, 16)
 print("multi call of %d views: %.2f ms" % (len(views), e0.elapsed_time(e1)))
 names = {0: ["matrix", "tridiag", "bisect", "invit", "gram-schmidt", "backtransf", "expand"], 3: ["arnoldi", "ritz(H)", "restart", "final"],
-         5: ["matrix", "sparse-products", "gram+ritz", "rotate", "expand"]}
+         5: ["matrix", "sparse-products", "ritz", "rotate", "expand", "gram", "cholesky", "inverse+H"]}
 for c, cname in enumerate(["small", "mid", "slot", "krylov", "big", "cheb"]):
     items = max(int(t[c, 15]), 1)
     ph = names.get(c, names[0])

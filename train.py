@@ -118,6 +118,7 @@ def parse_option(argv=None):
     parser.add_argument("--dgl-file", type=str, default="./data/small.bin", help="DGL graph file of the pre-training corpus (train.py:552 hard-codes this path)")
     parser.add_argument("--graph-npz", type=str, default=None, help="npz with row_ptr/col_idx (instead of data/small.bin)")
     parser.add_argument("--synthetic", type=str, default=None, help="V,E of a synthetic power-law graph, e.g. 1000000,10000000")
+    parser.add_argument("--nce-dtype", type=str, default="f32", choices=["f32", "bf16"], help="operands of the MoCo head: f32 = exact (1e-3 parity with the reference), bf16 = matrix-core throughput mode")
     parser.add_argument("--max-steps", type=int, default=0, help="stop after this many steps (0 = full schedule)")
     parser.add_argument("--producer-lanes", type=int, default=3, help="data-pipeline streams (the GPU's command processor serves few queues well)")
     parser.add_argument("--producer-chunk", type=int, default=4, help="steps a lane prepares per turn (2x as many views per eigensolver call, <= 32)")
@@ -320,7 +321,8 @@ def main(args):
     flatten_parameters(model_ema)
     if args.moco:
         moment_update(model, model_ema, 0)                # copy weights, train.py:623-624
-    contrast = MemoryMoCo(args.hidden_size, None, args.nce_k, args.nce_t, use_softmax=True).to(dev)   # :627-629
+    contrast = MemoryMoCo(args.hidden_size, None, args.nce_k, args.nce_t, use_softmax=True,
+                          nce_dtype=getattr(args, "nce_dtype", "f32")).to(dev)                                # :627-629
     criterion = NCESoftmaxLoss() if args.moco else NCESoftmaxLossNS()                                 # :634
     if args.optimizer != "adam":
         raise NotImplementedError("the fused step implements the default optimizer (adam, train.py:55)")
