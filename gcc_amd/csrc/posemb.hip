@@ -526,6 +526,9 @@ __device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int 
             // (the vectors enter with unit norm: "before" is 1 in the first pass; nobody reads coef[.][32] of step t here)
             const bool again = pass == 0 && wave_ballot(mine && now < 0.5f) != 0ull;
             if (wv == 0 && mine) coef[lane * ldy + nc] = now;
+#ifdef GCC_POSEMB_DEVDEBUG
+            if (wv == 0 && mine) printf("gs t=%d pass=%d j=%d now=%.6f\n", t, pass, lane, now);
+#endif
             if (!again) break;
         }
         __syncthreads();
@@ -628,6 +631,12 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
         es.maxpos = maxpos;
     }
     __syncthreads();
+#ifdef GCC_POSEMB_DEVDEBUG
+    if (tid == 0) {
+        printf("eig nr=%d na=%d maxpos=%d\n", nr, na, es.maxpos);
+        for (int j = 0; j < na; ++j) printf("  j=%d lam=%.7f shift=%.7f cs=%d posi=%d\n", j, es.lamv[j], es.shiftv[j], es.cs[j], es.posi[j]);
+    }
+#endif
     const int maxpos = es.maxpos;
     int lost = 0;
     // Three solves as a rule.  A Gram-Schmidt sweep that cancels most of a cluster member leaves the other eigenvectors'
@@ -640,12 +649,29 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
     for (int it = 0; it < kMaxInvIt; ++it) {
         for (int j0 = 0; j0 < na; j0 += w.bw) {
             if (tid < w.bw && j0 + tid < na) {
-                const bool ok = inverse_iteration_step(w, nr, j0 + tid, tid, es.shiftv[j0 + tid], it == 0, hseed);
-                if (!ok) es.bad = 1;
+                // The head of a cluster keeps its own eigenvalue as shift.  When the cluster is a numerically multiple
+                // eigenvalue (copies within a few ulp), T - shift is singular to working precision in several directions at
+                // once and every further solve returns a DIFFERENT vector of that eigenspace (pivot clamping / rounding
+                // decide): the members, orthonormal against the old head, then lose most of themselves against the new one,
+                // round after round (device trace of a 54-node ego-net with six copies of 1/sqrt(2): the sixth member kept
+                // 3e-4 of its squared norm in every sweep).  Two solves make the head an eigenvector to 1e-14; it is frozen
+                // from the third round on and the members converge against a fixed reference.
+                const int j = j0 + tid;
+                const bool frozen = it >= 2 && es.posi[j] == 0 && j + 1 < na && es.cs[j + 1] == j;
+                if (!frozen) {
+                    const bool ok = inverse_iteration_step(w, nr, j, tid, es.shiftv[j], it == 0, hseed);
+                    if (!ok) es.bad = 1;
+                }
             }
             __syncthreads();
         }
         phase_tick(tick_row, 3, tick);             // inverse iteration
+#ifdef GCC_POSEMB_DEVDEBUG
+        if (tid == 0 && (it == 1 || it == 2))
+            for (int j = 10; j < 16 && j < na; ++j)
+                for (int i = 0; i < nr; ++i) printf("P it=%d j=%d i=%d %.9g\n", it, j, i, w.Y[i * ldy + j]);
+        __syncthreads();
+#endif
         if (it > 0) {                              // the first solve only enters the cluster subspaces
             float left;
             lost = cluster_orthonormalize<kT>(w, nr, na, es.cs, es.posi, maxpos, &left, hseed ^ (0x51ED27u * (uint32_t)(it + 1)));
@@ -654,6 +680,18 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
         }
         phase_tick(tick_row, 4, tick);
         if (tid == 0) { es.diag_lost = lost; es.diag_its = it + 1; }
+#ifdef GCC_POSEMB_DEVDEBUG
+        if (tid == 0) printf("it=%d lost=%d need_until=%d bad=%d\n", it, lost, need_until, es.bad);
+        if (tid == 0 && it == 1)
+            for (int j = 10; j < 16 && j < na; ++j)
+                for (int l = 10; l < j; ++l) printf("C j=%d l=%d %.9g norm=%.9g\n", j, l, w.coef[j * ldy + l], w.coef[l * ldy + ldy - 1]);
+        if (tid == 0 && it <= 1) {
+            if (it == 0) for (int i = 0; i < nr; ++i) printf("T %d %.9g %.9g\n", i, w.dg[i], w.of[i]);
+            for (int j = 10; j < 16 && j < na; ++j)
+                for (int i = 0; i < nr; ++i) printf("Y it=%d j=%d i=%d %.9g\n", it, j, i, w.Y[i * ldy + j]);
+        }
+        __syncthreads();
+#endif
         if (it >= need_until) break;
     }
     for (int j = 2 * wv; j < na; j += 2 * kNW) {
@@ -1344,6 +1382,7 @@ constexpr int kChRounds = 16;      // filter rounds of an item
 constexpr int kChMaxRitz = 4;      // Rayleigh-Ritz steps of an item
 constexpr float kChTol = 2e-5f;      // residual norm of the wanted Ritz pairs
 constexpr double kChShift = 1e-8;
+constexpr float kChAmpLog = 13.8f;  // ln of the largest filter amplification between two re-orthonormalisations (1e6)
 constexpr int kChLdy = kChP + 1;
 constexpr int kChBw = 32;            // inverse iterations of the Ritz problem per batch
 
@@ -1966,8 +2005,8 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         {
             const float x1 = (1.0f - 0.5f * (cut - 1.0f)) / (0.5f * (cut + 1.0f));
             const float ach = logf(x1 + sqrtf(x1 * x1 - 1.0f));
-            int dmax = (int)(9.2f / ach) & ~1;                          // T_dmax(x(1)) <= ~1e4
-            dmax = dmax < 4 ? 4 : (dmax > 16 ? 16 : dmax);
+            int dmax = (int)(kChAmpLog / ach) & ~1;                     // T_dmax(x(1)) <= exp(kChAmpLog)
+            dmax = dmax < 4 ? 4 : (dmax > 24 ? 24 : dmax);
             deg = ((remaining + 1) & ~1) < dmax ? ((remaining + 1) & ~1) : dmax;
             if (deg < 2) deg = 2;
         }

@@ -56,10 +56,10 @@ def _check(view, x, evals, raw, tol=2e-4):
             xd = ud / np.maximum(np.linalg.norm(ud, axis=1, keepdims=True), 1e-300)
             assert np.abs(xb @ xb.T - xd @ xd.T).max() < 5e-3, (b, n)          # same rows up to a rotation
             # the reference's own solver (ARPACK, random start): single-vector Krylov may miss copies of a repeated
-            # eigenvalue on large subgraphs, so it is only compared where it found the dense answer itself
+            # eigenvalue (seen at n = 101 on the 1M-node graph), so it is only compared where it found the dense answer itself
             xr, _ = P.eigen_decomposition(n, k, __import__("scipy.sparse").sparse.csr_matrix(M), HID,
                                           rng=np.random.RandomState(b))
-            if np.abs(xr @ xr.T - xd @ xd.T).max() < 1e-6 or n <= 128:
+            if np.abs(xr @ xr.T - xd @ xd.T).max() < 1e-6:
                 assert np.abs(xb @ xb.T - xr @ xr.T).max() < 5e-3, (b, n)
 
 

@@ -31,8 +31,11 @@ def per_kernel(folder, counter):
             for row in csv.DictReader(f):
                 if row.get("Counter_Name") != counter:
                     continue
-                name = row["Kernel_Name"].split("(")[0].split("::")[-1]
-                name = name.replace("(anonymous namespace)", "").strip()
+                full = row["Kernel_Name"]
+                name = next((k for k in ("rwr_walk_kernel", "induce_kernel", "pack_kernel", "prefix_a_kernel", "prefix_b_kernel")
+                             if k in full), None)
+                if name is None:
+                    continue
                 s, n = acc.get(name, (0.0, 0))
                 acc[name] = (s + float(row["Counter_Value"]), n + 1)
     return {k: (s / n, n) for k, (s, n) in acc.items()}
@@ -51,8 +54,6 @@ def main():
     rec["units"] = "KiB per launch as rocprofv3 reports them; *_bytes fields are bytes per launch"
     kernels = {}
     for name in sorted(set(fetch) | set(write)):
-        if not any(t in name for t in ("walk", "induce", "pack", "subgraph_prefix")):
-            continue
         f, nf = fetch.get(name, (0.0, 0))
         w, nw = write.get(name, (0.0, 0))
         wide = any(t in name for t in WIDE)
