@@ -422,7 +422,9 @@ def main():
                 flags |= int(st[0])
             extra["posemb_status"] = dict(flags=flags, max_restart_cycles=int(max(st[1] for st in sts)),
                                           arnoldi_steps=int(sum(st[2] for st in sts)),
-                                          items_stopped_at_restart_cap=int(sum(st[3] for st in sts)))
+                                          items_handed_on=int(sum(st[3] for st in sts)),
+                                          items_failed=int(sum(st[4] for st in sts)),
+                                          first_failed=[st[5:14] for st in sts if st[4]][:1])
             for p in posembs:
                 p.check_status(strict=not args.allow_posemb_flags)         # raises: a flagged eigen-solve is not a valid bench run
 
