@@ -654,10 +654,11 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
                 // once and every further solve returns a DIFFERENT vector of that eigenspace (pivot clamping / rounding
                 // decide): the members, orthonormal against the old head, then lose most of themselves against the new one,
                 // round after round (device trace of a 54-node ego-net with six copies of 1/sqrt(2): the sixth member kept
-                // 3e-4 of its squared norm in every sweep).  Two solves make the head an eigenvector to 1e-14; it is frozen
-                // from the third round on and the members converge against a fixed reference.
+                // 3e-4 of its squared norm in every sweep).  The same holds for the first copy of a second multiple eigenvalue
+                // inside one chain of close eigenvalues.  Two solves make such a vector an eigenvector to 1e-14; it is frozen
+                // from the third round on and the others converge against a fixed reference.
                 const int j = j0 + tid;
-                const bool frozen = it >= 2 && es.posi[j] == 0 && j + 1 < na && es.cs[j + 1] == j;
+                const bool frozen = it >= 2 && es.shiftv[j] == es.lamv[j] && j + 1 < na && es.lamv[j] - es.lamv[j + 1] < kSep;
                 if (!frozen) {
                     const bool ok = inverse_iteration_step(w, nr, j, tid, es.shiftv[j], it == 0, hseed);
                     if (!ok) es.bad = 1;
@@ -1583,77 +1584,75 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     const int kq = min(k, nr);
 
     // dst = alpha * (M' src - center * src) - gamma * dst   (rows of 64 floats; 16 threads x float4 per row)
-    // 4 threads per row (16 block vectors = 4 x float4 each), 256 rows at a time, two gathers (8 x 16 bytes) in flight per
-    // thread: the block lives in L2 and a product is bound by the latency of its gathers
+    // 8 threads per row (8 block vectors = 2 x float4 each), 128 rows at a time, four gathers per vector pair in flight:
+    // the block lives in L2 and a product is bound by the latency of its gathers (4 threads per row with 16 vectors each
+    // was measured slower: 1.27 against 0.86 ms of products per item)
     auto gather = [&](const float *src, int e0, int e1, float *acc) {
-        const int q16 = 16 * (tid & 3);
-        for (int e = e0; e < e1; e += 2) {
-            const bool in1 = e + 1 < e1;
-            const int c0 = (int)ccol[e], c1 = (int)ccol[in1 ? e + 1 : e];
-            const float s0 = scale[c0], s1 = in1 ? scale[c1] : 0.f;
-            float4 x0[4], x1[4];
+        const int q8 = 8 * (tid & 7);
+        for (int e = e0; e < e1; e += 4) {
+            int cj[4];
+            float sc[4];
+            float4 xa[4], xb[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                x0[u] = *(const float4 *)(src + (int64_t)c0 * kChP + q16 + 4 * u);
-                x1[u] = *(const float4 *)(src + (int64_t)c1 * kChP + q16 + 4 * u);
+                const bool in = e + u < e1;
+                cj[u] = (int)ccol[in ? e + u : e0];
+                sc[u] = in ? scale[cj[u]] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                acc[4 * u + 0] = fmaf(s0, x0[u].x, acc[4 * u + 0]); acc[4 * u + 1] = fmaf(s0, x0[u].y, acc[4 * u + 1]);
-                acc[4 * u + 2] = fmaf(s0, x0[u].z, acc[4 * u + 2]); acc[4 * u + 3] = fmaf(s0, x0[u].w, acc[4 * u + 3]);
+                xa[u] = *(const float4 *)(src + (int64_t)cj[u] * kChP + q8);
+                xb[u] = *(const float4 *)(src + (int64_t)cj[u] * kChP + q8 + 4);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                acc[4 * u + 0] = fmaf(s1, x1[u].x, acc[4 * u + 0]); acc[4 * u + 1] = fmaf(s1, x1[u].y, acc[4 * u + 1]);
-                acc[4 * u + 2] = fmaf(s1, x1[u].z, acc[4 * u + 2]); acc[4 * u + 3] = fmaf(s1, x1[u].w, acc[4 * u + 3]);
+                acc[0] = fmaf(sc[u], xa[u].x, acc[0]); acc[1] = fmaf(sc[u], xa[u].y, acc[1]);
+                acc[2] = fmaf(sc[u], xa[u].z, acc[2]); acc[3] = fmaf(sc[u], xa[u].w, acc[3]);
+                acc[4] = fmaf(sc[u], xb[u].x, acc[4]); acc[5] = fmaf(sc[u], xb[u].y, acc[5]);
+                acc[6] = fmaf(sc[u], xb[u].z, acc[6]); acc[7] = fmaf(sc[u], xb[u].w, acc[7]);
             }
         }
     };
     // dst = alpha * (M' src - center * src) - gamma * dst   (rows of 64 floats)
     auto spmm = [&](const float *src, float *dst, float alpha, float center, float gamma) {
-        const int q16 = 16 * (tid & 3), g4 = tid >> 2;
-        for (int c = g4; c < nchunk; c += kChThreads / 4) {              // chunks of the long rows -> slab
+        const int q8 = 8 * (tid & 7), g8 = tid >> 3;
+        for (int c = g8; c < nchunk; c += kChThreads / 8) {              // chunks of the long rows -> slab
             int x = 0;
             while (longfirst[x + 1] <= c) ++x;
             const int r = longrow[x];
-            float acc[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             gather(src, chunk_beg[c], min(chunk_beg[c] + kChLongDeg, (int)crow[r + 1]), acc);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) *(float4 *)(slab + c * kChP + q16 + 4 * u) = make_float4(acc[4 * u], acc[4 * u + 1], acc[4 * u + 2], acc[4 * u + 3]);
+            *(float4 *)(slab + c * kChP + q8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *(float4 *)(slab + c * kChP + q8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
         }
         if (nchunk) __syncthreads();
-        for (int r = g4; r < nr; r += kChThreads / 4) {
+        for (int r = g8; r < nr; r += kChThreads / 8) {
             const int e0 = (int)crow[r], e1 = (int)crow[r + 1];
-            float acc[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (e1 - e0 > kChLongDeg) {
                 int x = 0;
                 while (longrow[x] != r) ++x;
                 for (int c = longfirst[x]; c < longfirst[x + 1]; ++c) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float4 pv = *(const float4 *)(slab + c * kChP + q16 + 4 * u);
-                        acc[4 * u] += pv.x; acc[4 * u + 1] += pv.y; acc[4 * u + 2] += pv.z; acc[4 * u + 3] += pv.w;
-                    }
+                    const float4 pa = *(const float4 *)(slab + c * kChP + q8), pb = *(const float4 *)(slab + c * kChP + q8 + 4);
+                    acc[0] += pa.x; acc[1] += pa.y; acc[2] += pa.z; acc[3] += pa.w;
+                    acc[4] += pb.x; acc[5] += pb.y; acc[6] += pb.z; acc[7] += pb.w;
                 }
             } else {
                 gather(src, e0, e1, acc);
             }
             const float sr = scale[r];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 own = *(const float4 *)(src + (int64_t)r * kChP + q16 + 4 * u);
-                float4 o = make_float4(alpha * (sr * acc[4 * u] - center * own.x), alpha * (sr * acc[4 * u + 1] - center * own.y),
-                                       alpha * (sr * acc[4 * u + 2] - center * own.z), alpha * (sr * acc[4 * u + 3] - center * own.w));
-                if (gamma != 0.f) {
-                    const float4 old = *(const float4 *)(dst + (int64_t)r * kChP + q16 + 4 * u);
-                    o.x -= gamma * old.x; o.y -= gamma * old.y; o.z -= gamma * old.z; o.w -= gamma * old.w;
-                }
-                *(float4 *)(dst + (int64_t)r * kChP + q16 + 4 * u) = o;
+            const float4 oa = *(const float4 *)(src + (int64_t)r * kChP + q8), ob = *(const float4 *)(src + (int64_t)r * kChP + q8 + 4);
+            float o[8] = {alpha * (sr * acc[0] - center * oa.x), alpha * (sr * acc[1] - center * oa.y),
+                          alpha * (sr * acc[2] - center * oa.z), alpha * (sr * acc[3] - center * oa.w),
+                          alpha * (sr * acc[4] - center * ob.x), alpha * (sr * acc[5] - center * ob.y),
+                          alpha * (sr * acc[6] - center * ob.z), alpha * (sr * acc[7] - center * ob.w)};
+            if (gamma != 0.f) {
+                const float4 da = *(const float4 *)(dst + (int64_t)r * kChP + q8), db = *(const float4 *)(dst + (int64_t)r * kChP + q8 + 4);
+                o[0] -= gamma * da.x; o[1] -= gamma * da.y; o[2] -= gamma * da.z; o[3] -= gamma * da.w;
+                o[4] -= gamma * db.x; o[5] -= gamma * db.y; o[6] -= gamma * db.z; o[7] -= gamma * db.w;
             }
+            *(float4 *)(dst + (int64_t)r * kChP + q8) = make_float4(o[0], o[1], o[2], o[3]);
+            *(float4 *)(dst + (int64_t)r * kChP + q8 + 4) = make_float4(o[4], o[5], o[6], o[7]);
         }
         __syncthreads();
     };

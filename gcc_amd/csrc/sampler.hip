@@ -46,7 +46,6 @@ constexpr int kUnitElems = 4 * kUnitQuads;
 constexpr int kUnitsPerVwg = 8;    // units per virtual workgroup (2 per wave, both in flight together)
 constexpr int kUnitsInFlight = 2;  // per wave
 constexpr int kInduceThreads = 256;
-constexpr int kInduceGrid = 1024;  // 4 workgroups per CU (LDS and registers): all resident, work handed out dynamically
 constexpr int kCandCap = 512;      // per-wave queue of Bloom survivors (drained when the next 256 might not fit)
 constexpr int kPackParts = 4;      // pack workgroups per subgraph (hub-seed subgraphs have 100x the units)
 constexpr uint32_t kHashMul = 0x9E3779B1u;
@@ -75,7 +74,6 @@ struct Work {
     int32_t *ebp;         // [G + 1]     edge offset of a subgraph inside its view's batch       (prefix kernel B)
     int32_t *ucnt;        // [unit_cap]  hits of every unit
     int32_t *vdesc;       // [vwg_cap]   subgraph of every virtual workgroup                    (prefix step A)
-    int32_t *vnext;       // [1]         next virtual workgroup to hand out (zeroed by prefix step A)
     int32_t *scratch;     // [scratch_entries] hits: (row << 16) | local column, one slot of 1024 per unit
     int32_t ncap;
     int64_t unit_cap, vwg_cap;
@@ -83,7 +81,7 @@ struct Work {
 
 struct WorkLayout {
     int64_t off_seeds, off_n, off_quads, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowq,
-        off_vbp, off_ubp, off_sbp, off_nbp, off_ebp, off_ucnt, off_vdesc, off_vnext, off_scratch, total, unit_cap, vwg_cap;
+        off_vbp, off_ubp, off_sbp, off_nbp, off_ebp, off_ucnt, off_vdesc, off_scratch, total, unit_cap, vwg_cap;
     int32_t ncap;
 };
 
@@ -111,7 +109,6 @@ inline WorkLayout work_layout(int32_t lmax, int32_t B, int64_t scratch_entries)
     w.off_ucnt = o;   o = al(o + 4 * w.unit_cap);
     w.vwg_cap = w.unit_cap / kUnitsPerVwg + G + 1;
     w.off_vdesc = o;  o = al(o + 4 * w.vwg_cap);
-    w.off_vnext = o;  o = al(o + 4);
     w.off_scratch = o; o = al(o + 4 * scratch_entries);
     w.total = o;
     return w;
@@ -413,7 +410,7 @@ __device__ void prefix_step_a(int32_t B, const Work &w, int32_t *wsum /* LDS [4]
         cv += tv; cu += tu; cs += ts;
         __syncthreads();
     }
-    if (tid == 0) { w.vbp[G] = cv; w.ubp[G] = cu; w.sbp[G] = cs; *w.vnext = 0; }
+    if (tid == 0) { w.vbp[G] = cv; w.ubp[G] = cu; w.sbp[G] = cs; }
     view_prefix(B, w.sub_n, w.nbp, wsum);
 }
 
@@ -456,17 +453,10 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
     uint16_t *candr = candr_all + wave * kCandCap;
     long long tick_ = ticks ? device_ticks() : 0;
     if (ticks && tid == 0) atomicAdd((unsigned long long *)&ticks[15], 1ull);
-    __shared__ int32_t sh_vb;
     const int total_vb = w.vbp[G];                           // (prefix step A)
     int cur_g = -1, bshift = 0;
-    // as many workgroups as the GPU holds at once; virtual workgroups are handed out through a counter (hub-seed
-    // subgraphs make them very unequal: a static assignment leaves most CUs waiting for a few)
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) sh_vb = atomicAdd(w.vnext, 1);
-        __syncthreads();
-        const int vb = sh_vb;
-        if (vb >= total_vb) break;
+    // (a resident grid with virtual workgroups handed out through a counter was measured slower: 52 against 45 us)
+    for (int vb = (int)blockIdx.x; vb < total_vb; vb += (int)gridDim.x) {
         const int g = w.vdesc[vb];
         const int part = vb - w.vbp[g];
         const int n = w.sub_n[g], totq = w.sub_quads[g];
@@ -783,7 +773,6 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     w.ebp = (int32_t *)(base + wl.off_ebp);
     w.ucnt = (int32_t *)(base + wl.off_ucnt);
     w.vdesc = (int32_t *)(base + wl.off_vdesc);
-    w.vnext = (int32_t *)(base + wl.off_vnext);
     w.vwg_cap = wl.vwg_cap;
     w.scratch = (int32_t *)(base + wl.off_scratch);
     w.ncap = wl.ncap;
@@ -817,7 +806,7 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
                        p->restart_u32, p->seeds, w);
     prof_mark(p->prof, 1, s);
     hipLaunchKernelGGL(prefix_a_kernel, dim3(1), dim3(256), 0, s, B, w);
-    hipLaunchKernelGGL(induce_kernel, dim3(kInduceGrid), dim3(kInduceThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,
+    hipLaunchKernelGGL(induce_kernel, dim3(G * 8), dim3(kInduceThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,
                        scratch_entries, w, status, g_induce_ticks);
     prof_mark(p->prof, 2, s);
     hipLaunchKernelGGL(prefix_b_kernel, dim3(1), dim3(256), 0, s, B, w);
