@@ -79,7 +79,8 @@ constexpr int kYld = 33;             // row stride of Y ([i][j], j < 32): odd, s
                                      // Ritz problem wants up to 40 vectors and uses stride 65 (TriLds::ldy)
 constexpr int kMaxVec = 32;          // hidden <= 32 on this path (GCC: positional_embedding_size = 32)
 constexpr int kVecCap = 64;          // most eigenvectors the solver core handles
-constexpr float kOrtol = 1e-3f;      // eigenvalues closer than this are re-orthogonalised against each other
+constexpr float kOrtol = 4e-3f;      // eigenvalues closer than this are re-orthogonalised against each other (LAPACK stein: 1e-3; in fp32 an
+                                     // inverse-iteration residual of ~3e-7 over a gap of 3e-3 already leaves 1e-4..2.4e-4 between two vectors)
 constexpr float kSep = 2e-6f;        // minimum distance between two inverse-iteration shifts
 constexpr float kPivTiny = 1.2e-7f;  // pivots of T - shift are clamped to eps * ||T||  (||T|| <= 1)
 constexpr int kGMax = GCC_POSEMB_DIRECT_MAX;   // largest deflated size of the workspace-resident class
@@ -620,13 +621,34 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ldy = w.ldy;
     if (tid == 0) {
+        // Orthogonalisation clusters: chains of eigenvalues closer than kOrtol.  Shifts: an eigenvalue keeps its own
+        // value unless it belongs to a CLUMP (a numerically multiple eigenvalue: copies closer than kSep); the first
+        // copy keeps the value, the others are displaced by multiples of kSep AWAY from the nearest other eigenvalue --
+        // displaced towards it they amplify that neighbour more than their own eigenspace (device trace: 12 copies of
+        // 1/sqrt(2) with an eigenvalue 3.5e-5 below; the last four members all converged to the neighbour's
+        // eigenvector and cancelled each other in every sweep).  The step shrinks when there is little room.
         int maxpos = 0;
         for (int j = 0; j < na; ++j) {
-            const float l = es.lamv[j];
-            es.shiftv[j] = (j > 0 && es.shiftv[j - 1] - l < kSep) ? es.shiftv[j - 1] - kSep : l;
-            es.cs[j] = (j > 0 && es.lamv[j - 1] - l <= kOrtol) ? es.cs[j - 1] : j;
+            es.shiftv[j] = es.lamv[j];
+            es.cs[j] = (j > 0 && es.lamv[j - 1] - es.lamv[j] <= kOrtol) ? es.cs[j - 1] : j;
             es.posi[j] = j - es.cs[j];
             maxpos = es.posi[j] > maxpos ? es.posi[j] : maxpos;
+        }
+        for (int j = 0; j < na;) {
+            int b = j;
+            while (b + 1 < na && es.lamv[b] - es.lamv[b + 1] < kSep) ++b;
+            const int c = b - j + 1;
+            if (c > 1) {
+                float room_up = 2.0f;
+                if (j > 0) room_up = fminf(es.lamv[j - 1], es.shiftv[j - 1]) - es.lamv[j];
+                const float room_dn = b + 1 < na ? es.lamv[b] - es.lamv[b + 1] : (na >= nr ? 2.0f : 0.0f);   // below the computed ones: unknown
+                const bool up = room_up >= room_dn;
+                const float room = up ? room_up : room_dn;
+                float step = kSep;
+                if ((float)c * step > 0.5f * room) step = fmaxf(0.5f * room / (float)c, 2.5e-7f);
+                for (int m = 1; m < c; ++m) es.shiftv[j + m] = up ? es.lamv[j] + (float)m * step : es.lamv[b] - (float)m * step;
+            }
+            j = b + 1;
         }
         es.maxpos = maxpos;
     }
