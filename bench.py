@@ -61,8 +61,9 @@ def parse_args(argv=None):
     ap.add_argument("--lanes", type=int, default=3, help="producer streams (sampler + positional embedding)")
     ap.add_argument("--reserved-cus", type=int, default=0, help="compute units the producer streams are masked off (kept for the training step)")
     ap.add_argument("--cu-layout", default="interleaved", choices=["interleaved", "block"])
-    ap.add_argument("--chunk", type=int, default=4, help="steps a producer lane prepares per turn (one multi-view eigensolver call); "
-                                                         "reduced to gcd(chunk, steps) so that the timed region produces what it consumes")
+    ap.add_argument("--chunk", type=int, default=16, help="most steps a producer lane prepares per turn (one multi-view eigensolver call); "
+                                                          "the largest divisor of --steps not above it is used, so that the timed region "
+                                                          "launches exactly the chunks it consumes")
     ap.add_argument("--depth", type=int, default=2, help="chunks in flight per producer lane")
     ap.add_argument("--ahead", type=int, default=None, help="chunks launched beyond the one being consumed (default lanes * (depth - 1))")
     ap.add_argument("--scratch-entries", type=int, default=0, help="induction scratch of the sampler (int32 slots); 0 = default")
@@ -359,7 +360,7 @@ def main():
         from gcc_amd.train_step import MoCoTrainStep
 
         # the timed region must produce exactly what it consumes: whole chunks only
-        chunk = math.gcd(args.chunk, args.steps)
+        chunk = max(d for d in range(1, min(args.chunk, args.steps) + 1) if args.steps % d == 0)
         nbuf = args.depth * chunk
         samplers = [DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=nbuf, scratch_entries=args.scratch_entries or None,
                                      edge_cap=args.edge_cap or None) for _ in range(args.lanes)]

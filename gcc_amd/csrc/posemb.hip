@@ -1402,7 +1402,7 @@ constexpr int kChLongDeg = 96;       // longer rows are cut into chunks of this 
 constexpr int kChMaxChunks = 64;
 constexpr int kChMaxLong = 64;
 constexpr int kChRounds = 16;      // filter rounds of an item
-constexpr int kChMaxRitz = 4;      // Rayleigh-Ritz steps of an item
+constexpr int kChMaxRitz = 5;      // Ritz steps of an item (the first one: values only)
 constexpr float kChTol = 2e-5f;      // residual norm of the wanted Ritz pairs
 constexpr double kChShift = 1e-8;
 constexpr float kChAmpLog = 12.9f;  // ln of the largest filter amplification between two re-orthonormalisations (4e5; at 1e7 fp32 loses the guard end and one hub ego-net in 29 misses the strict invariants)
@@ -1696,6 +1696,9 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         if (getenv("GCC_POSEMB_RR_ALWAYS")) remaining = 0;
 #endif
         const bool rr = remaining <= 0;                      // block-uniform
+        // the first Ritz step only needs the Ritz VALUES (cut-off and rate of the filter rounds to come): tridiagonalisation
+        // and bisection of the projected matrix, no vectors -- the block is just re-orthonormalised
+        const bool vals_only = rr && nrr == 0, fullrr = rr && !vals_only;
         // ---- filter: scaled Chebyshev polynomial of degree `deg` (even) for [-1, cut], p(1) = 1
         {
             const float e = 0.5f * (cut + 1.0f), cen = 0.5f * (cut - 1.0f);
@@ -1925,9 +1928,9 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             // Ritz problem: all 64 pairs of H by the dense solver core
             tridiagonalize<1, kChThreads, 2>(Af, kChLdy, kChP, tw);
             eig_top_values<kChThreads, kVecCap>(tw, kChP, kChP, es);
-            const bool ritz_failed = eig_top_vectors<1, kChThreads>(Af, kChLdy, kChP, kChP, tw, es,
-                                                                    (uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u) ^ (uint32_t)(round + 77),
-                                                                    nullptr, tick_);
+            const bool ritz_failed = vals_only ? false
+                : eig_top_vectors<1, kChThreads>(Af, kChLdy, kChP, kChP, tw, es,
+                                                 (uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u) ^ (uint32_t)(round + 77), nullptr, tick_);
 #ifdef GCC_AMD_HIPEMU
             if (getenv("GCC_POSEMB_DEBUG") && tid == 0 && ritz_failed) fprintf(stderr, "cheb ritz failed round=%d\n", round);
 #endif
@@ -1940,7 +1943,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         {
             const int i = tid >> 4, j4 = 4 * (tid & 15);
             float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-            if (rr) {
+            if (fullrr) {
                 for (int q = i; q < kChP; ++q) {                 // Linv^T[i][q] = Linv[q][i], q >= i
                     const float l = Lf[q * kChLdy + i];
                     c0 = fmaf(l, tw.Y[q * kChLdy + j4], c0); c1 = fmaf(l, tw.Y[q * kChLdy + j4 + 1], c1);
@@ -1965,7 +1968,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             const float t0 = theta[q4], t1 = theta[q4 + 1], t2 = theta[q4 + 2], t3 = theta[q4 + 3];
             for (int r = g16; r < nr; r += kChThreads / 16) {
                 float xn[4] = {0.f, 0.f, 0.f, 0.f}, wn[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int which = 0; which < (rr ? 2 : 1); ++which) {
+                for (int which = 0; which < (fullrr ? 2 : 1); ++which) {
                     const float *src = (which ? XB : XA) + (int64_t)r * kChP;
                     float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll 1
@@ -1997,7 +2000,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             }
             __syncthreads();
             { float *t = XA; XA = XC; XC = t; }                          // block-uniform: the rotated block is X now
-            if (rr) {
+            if (fullrr) {
                 *(float4 *)(slab + g16 * kChP + q4) = make_float4(r0, r1, r2, r3);     // 64 groups x 64 columns
                 __syncthreads();
                 if (tid < kChP) {
@@ -2029,14 +2032,17 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         // so beyond ~1e3 the block loses its numerical rank.  T_2m = 2 T_m^2 - 1: consecutive rounds with a
         // re-orthonormalisation in between multiply up like one long filter.
         if (rr) {
-            float worst = 0.f;
-            for (int i = 0; i < kq; ++i) worst = fmaxf(worst, resid[i]);
+            float worst = 0.1f;                                  // (values only: nothing measured yet)
+            if (fullrr) {
+                worst = 0.f;
+                for (int i = 0; i < kq; ++i) worst = fmaxf(worst, resid[i]);
+            }
 #ifdef GCC_AMD_HIPEMU
             if (getenv("GCC_POSEMB_DEBUG") && tid == 0)
                 fprintf(stderr, "cheb b=%d n=%d nr=%d round=%d deg=%d cut=%.4f worst=%.2e theta[kq-1]=%.5f theta[63]=%.5f\n", b, n, nr, round,
                         deg, cut, worst, theta[kq - 1], theta[kChP - 1]);
 #endif
-            if (worst <= kChTol) { converged = true; ++round; break; }
+            if (fullrr && worst <= kChTol) { converged = true; ++round; break; }
             if (nrr >= kChMaxRitz) break;
             cut = fminf(fmaxf(theta[kChP - 1] - 0.02f, -0.9f), 0.9f);
             const float e = 0.5f * (cut + 1.0f), cen = 0.5f * (cut - 1.0f);
