@@ -463,8 +463,9 @@ def main():
                        "parallelism": f"dp{world} (seed batch sharded, graph replicated)" + ("; OVERSUBSCRIBED: %d ranks on %d device(s), gloo, correctness only" % (world, ndev) if oversubscribed else "")},
             "kernel_ms_isolated": kern_iso,
             "roofline": {"bound": "hbm", "kernel": dom,
-                         "measured": "isolated probe loop after the timed region: HIP events (gcc_prof marks on the launch stream) around the "
-                                     "induction launches of gcc_sample_batch; rocprof of the same kernels alone under profiles/",
+                         "measured": "isolated probe loop after the timed region: HIP events (gcc_prof marks on the launch stream) right "
+                                     "before and after induce_kernel inside gcc_sample_batch; rocprofv3 --kernel-trace --stats of the same "
+                                     "kernels alone: profiles/r2_kernel_stats_sampler_alone.csv",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": acc["induce"], "traffic": traffic, "traffic_source": traffic_src},
             "algorithmic_bytes_per_step": acc,

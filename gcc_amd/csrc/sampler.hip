@@ -804,8 +804,8 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     hipLaunchKernelGGL(rwr_walk_kernel, dim3(G), dim3(kWalkThreads), lds1, s, g->row_ptr, g->col_idx, g->seed_cdf,
                        g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, B,
                        p->restart_u32, p->seeds, w);
-    prof_mark(p->prof, 1, s);
     hipLaunchKernelGGL(prefix_a_kernel, dim3(1), dim3(256), 0, s, B, w);
+    prof_mark(p->prof, 1, s);                        // marks 1 -> 2 bracket induce_kernel alone (bench.py's roofline interval)
     hipLaunchKernelGGL(induce_kernel, dim3(G * 8), dim3(kInduceThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,
                        scratch_entries, w, status, g_induce_ticks);
     prof_mark(p->prof, 2, s);
