@@ -51,6 +51,9 @@ template <class T> static inline T wave_shfl_down(T v, int delta)
     return src > 63 ? v : r;
 }
 template <class T> static inline T wave_bcast_first(T v) { return wave_shfl(v, 0); }
+// a value the caller knows to be wave-uniform (device: moved to a scalar register) / lane 63's value as a uniform
+static inline int wave_uniform(int v) { return v; }
+static inline int wave_last(int v) { return wave_shfl(v, 63); }
 // D = A(16x4) * B(4x16) + C; lane l: a = A[l&15][l>>4], b = B[l>>4][l&15],
 // c/d[r] = C[(l>>4)*4 + r][l&15]  (cdna_hip_programming.md §3)
 static inline f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c)
@@ -120,6 +123,18 @@ static inline int wave_scan_incl(int v)
     return v;
 }
 
+// inclusive wave prefix maximum of non-negative values
+static inline int wave_scan_max_incl(int v)
+{
+    int l = lane_id();
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = wave_shfl_up(v, d);
+        if (l >= d) v = t > v ? t : v;
+    }
+    return v;
+}
+static inline uint32_t umul24(uint32_t a, uint32_t b) { return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)); }
+
 static inline float wave_sum(float v)
 {
 #pragma unroll
@@ -182,6 +197,10 @@ template <class T> __device__ __forceinline__ T wave_shfl_xor(T v, int mask) { r
 template <class T> __device__ __forceinline__ T wave_shfl_up(T v, int delta) { return __shfl_up(v, delta, 64); }
 template <class T> __device__ __forceinline__ T wave_shfl_down(T v, int delta) { return __shfl_down(v, delta, 64); }
 template <class T> __device__ __forceinline__ T wave_bcast_first(T v) { return __shfl(v, 0, 64); }
+// a value the caller knows to be wave-uniform, moved to a scalar register (the compiler cannot tell for values that
+// come from threadIdx or a vector load: everything derived from them would stay in VGPRs and on the VALU)
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int wave_last(int v) { return __builtin_amdgcn_readlane(v, 63); }
 __device__ __forceinline__ f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -225,6 +244,18 @@ template <class T> __device__ __forceinline__ T wave_scan_incl_dpp(T v)
     return v;
 }
 __device__ __forceinline__ int wave_scan_incl(int v) { return wave_scan_incl_dpp(v); }
+// inclusive wave prefix maximum of non-negative values (the lanes a DPP step does not reach read 0)
+__device__ __forceinline__ int wave_scan_max_incl(int v)
+{
+    v = max(v, dpp_or_zero<0x111, 0xF>(v));
+    v = max(v, dpp_or_zero<0x112, 0xF>(v));
+    v = max(v, dpp_or_zero<0x114, 0xF>(v));
+    v = max(v, dpp_or_zero<0x118, 0xF>(v));
+    v = max(v, dpp_or_zero<0x142, 0xA>(v));
+    v = max(v, dpp_or_zero<0x143, 0xC>(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t umul24(uint32_t a, uint32_t b) { return __umul24(a, b); }   // v_mul_u32_u24: full rate
 __device__ __forceinline__ float wave_sum(float v)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan_incl_dpp(v)), 63));

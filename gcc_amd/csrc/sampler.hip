@@ -21,14 +21,20 @@
 //                     cache lines: a subgraph has more members than a hub row has
 //                     128-byte lines).  The rows of a subgraph form one flat space
 //                     of aligned quads; a UNIT = 256 consecutive quads (1024 edges)
-//                     = one wave x 4 coalesced dwordx4 loads per lane, all in
-//                     flight together; a virtual workgroup = 8 units.  Members sit
-//                     in an LDS Bloom bitmap (>= 64 bits per member): 98.5 % of the
-//                     neighbours are non-members and cost one LDS word; survivors
-//                     are queued per wave and looked up exactly (binary search in
-//                     the sorted member list) in dense passes; hits go, in parent
-//                     order, to the unit's private scratch slot.  No barrier and no
-//                     atomics on shared counters inside the scan.
+//                     = one wave x 4 coalesced dwordx4 loads per lane; a virtual
+//                     workgroup = 16 units (8 waves x 2).  The row of every quad of
+//                     a unit comes from a 256-entry LDS strip (rows mark their first
+//                     quad, a prefix maximum spreads the marks), not from a search
+//                     per quad.  Members sit in an LDS Bloom bitmap (>= 64 bits per
+//                     member): 98.5 % of the neighbours are non-members and cost one
+//                     LDS word; survivors are queued per wave and looked up exactly
+//                     (binary search in the sorted member list) in dense passes;
+//                     hits go, in parent order, to the unit's private scratch slot.
+//                     No atomics on shared counters inside the scan.  The kernel is
+//                     VALU-bound: everything wave-uniform is
+//                     kept in scalar registers on purpose.
+//   prefix_a_kernel   one workgroup between the two: prefixes over the subgraphs
+//                     and the start record of every induce workgroup.
 //   pack_kernel       prefix sums over subgraphs and units (dgl.batch offsets),
 //                     row_ptr/col_idx with batched ids, parent_nid, graph_id.
 // HBM-bound integer work; no MFMA anywhere in this file.
@@ -43,12 +49,28 @@ constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 constexpr int kWalkThreads = 256;  // 4 waves per subgraph
 constexpr int kUnitQuads = 256;    // 16-byte quads of col_idx per unit: 64 lanes x 4 dwordx4 loads
 constexpr int kUnitElems = 4 * kUnitQuads;
-constexpr int kUnitsPerVwg = 8;    // units per virtual workgroup (2 per wave, both in flight together)
-constexpr int kUnitsInFlight = 2;  // per wave
-constexpr int kInduceThreads = 256;
-constexpr int kCandCap = 512;      // per-wave queue of Bloom survivors (drained when the next 256 might not fit)
+#ifndef GCC_INDUCE_THREADS
+#define GCC_INDUCE_THREADS 512
+#endif
+#ifndef GCC_INDUCE_VWG_UNITS
+#define GCC_INDUCE_VWG_UNITS (GCC_INDUCE_THREADS / 32)
+#endif
+constexpr int kUnitsPerVwg = GCC_INDUCE_VWG_UNITS;    // units per virtual workgroup (2 per wave, one after the other)
+#ifndef GCC_INDUCE_GRID_MULT
+#define GCC_INDUCE_GRID_MULT 8
+#endif
+#ifndef GCC_INDUCE_OCC
+#define GCC_INDUCE_OCC
+#endif
+constexpr int kInduceThreads = GCC_INDUCE_THREADS;
+constexpr int kInduceWaves = kInduceThreads / 64;
+constexpr int kGridMult = GCC_INDUCE_GRID_MULT;   // induce workgroups per subgraph (a static grid; see induce_kernel)
+constexpr int kRecInts = 12;       // per induce workgroup: {count, g, part, n, quads, unit base, scratch base (2), pad}
+constexpr int kPrefixThreads = 1024;
+constexpr int kCandCap = 256;      // per-wave queue of Bloom survivors (drained before every round of 256 that might not fit)
 constexpr int kPackParts = 4;      // pack workgroups per subgraph (hub-seed subgraphs have 100x the units)
-constexpr uint32_t kHashMul = 0x9E3779B1u;
+constexpr uint32_t kHashMul = 0x9E3779u;    // 24-bit multiply (full rate; the 32-bit one is quarter rate): ids differing
+                                            // only above bit 23 share a Bloom bit, which costs a look-up, not a result
 
 __device__ __forceinline__ int pow2_ceil(int v)
 {
@@ -67,21 +89,20 @@ struct Work {
     int32_t *rowbeg;      // [G][ncap]   row_ptr[node]
     int32_t *rowdeg;      // [G][ncap]   parent degree
     int32_t *rowq;        // [G][ncap]   exclusive prefix of the rows' quads within the subgraph (walk kernel)
-    int32_t *vbp;         // [G + 1]     exclusive prefix of the subgraphs' virtual workgroups   (prefix kernel A)
     int32_t *ubp;         // [G + 1]     exclusive prefix of the subgraphs' units                (prefix kernel A)
     long long *sbp;       // [G + 1]     exclusive prefix of the subgraphs' scratch slots        (prefix kernel A)
     int32_t *nbp;         // [G + 1]     node offset of a subgraph inside its view's batch       (prefix kernel A)
     int32_t *ebp;         // [G + 1]     edge offset of a subgraph inside its view's batch       (prefix kernel B)
     int32_t *ucnt;        // [unit_cap]  hits of every unit
-    int32_t *vdesc;       // [vwg_cap]   subgraph of every virtual workgroup                    (prefix step A)
+    int32_t *wrec;        // [G * kGridMult][kRecInts] where each induce workgroup starts        (prefix step A)
     int32_t *scratch;     // [scratch_entries] hits: (row << 16) | local column, one slot of 1024 per unit
     int32_t ncap;
-    int64_t unit_cap, vwg_cap;
+    int64_t unit_cap;
 };
 
 struct WorkLayout {
     int64_t off_seeds, off_n, off_quads, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowq,
-        off_vbp, off_ubp, off_sbp, off_nbp, off_ebp, off_ucnt, off_vdesc, off_scratch, total, unit_cap, vwg_cap;
+        off_ubp, off_sbp, off_nbp, off_ebp, off_ucnt, off_wrec, off_scratch, total, unit_cap;
     int32_t ncap;
 };
 
@@ -101,14 +122,12 @@ inline WorkLayout work_layout(int32_t lmax, int32_t B, int64_t scratch_entries)
     w.off_rowbeg = o; o = al(o + 4 * G * w.ncap);
     w.off_rowdeg = o; o = al(o + 4 * G * w.ncap);
     w.off_rowq = o;   o = al(o + 4 * G * w.ncap);
-    w.off_vbp = o;    o = al(o + 4 * (G + 1));
     w.off_ubp = o;    o = al(o + 4 * (G + 1));
     w.off_sbp = o;    o = al(o + 8 * (G + 1));
     w.off_nbp = o;    o = al(o + 4 * (G + 1));
     w.off_ebp = o;    o = al(o + 4 * (G + 1));
     w.off_ucnt = o;   o = al(o + 4 * w.unit_cap);
-    w.vwg_cap = w.unit_cap / kUnitsPerVwg + G + 1;
-    w.off_vdesc = o;  o = al(o + 4 * w.vwg_cap);
+    w.off_wrec = o;   o = al(o + 4 * G * kGridMult * kRecInts);
     w.off_scratch = o; o = al(o + 4 * scratch_entries);
     w.total = o;
     return w;
@@ -373,10 +392,14 @@ __device__ void view_prefix(int32_t B, const int32_t *src, int32_t *dst, int32_t
     }
 }
 
-// step A, one pass: thread t owns subgraphs t, t + 256, ... ; carries in registers (block-uniform)
-__device__ void prefix_step_a(int32_t B, const Work &w, int32_t *wsum /* LDS [4][4] */, long long *wsum64 /* LDS [4] */)
+// step A, one pass: thread t owns subgraphs t, t + blockDim, ... ; carries in registers (block-uniform).  Then the start
+// record of every induce workgroup: workgroup b takes the `chunk` CONSECUTIVE virtual workgroups from b * chunk on
+// (chunk = 1 unless there are more virtual workgroups than workgroups), and its record holds everything it would
+// otherwise fetch through three dependent loads (measured 6.3 of its 20 us on G1).
+__device__ void prefix_step_a(int32_t B, const Work &w, int32_t *wsum /* LDS [16][4] */, long long *wsum64 /* LDS [16] */,
+                              int32_t *lvbp /* LDS [G + 1] */)
 {
-    const int G = 2 * B, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int G = 2 * B, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = (int)blockDim.x >> 6;
     int cv = 0, cu = 0;
     long long cs = 0;
     for (int g0 = 0; g0 < G; g0 += (int)blockDim.x) {
@@ -395,30 +418,52 @@ __device__ void prefix_step_a(int32_t B, const Work &w, int32_t *wsum /* LDS [4]
         __syncthreads();
         int bv = cv, bu = cu, tv = 0, tu = 0;
         long long bs = cs, ts = 0;
-        for (int k = 0; k < ((int)blockDim.x >> 6); ++k) {
+        for (int k = 0; k < nw; ++k) {
             if (k < wv) { bv += wsum[k * 4]; bu += wsum[k * 4 + 1]; bs += wsum64[k]; }
             tv += wsum[k * 4]; tu += wsum[k * 4 + 1]; ts += wsum64[k];
         }
         if (in) {
-            const int v0 = bv + iv - v;
-            w.vbp[g] = v0;
+            lvbp[g] = bv + iv - v;
             w.ubp[g] = bu + iu - u;
             w.sbp[g] = bs + is - 4ll * q;
-            for (int p = 0; p < v; ++p)
-                if (v0 + p < w.vwg_cap) w.vdesc[v0 + p] = g;
         }
         cv += tv; cu += tu; cs += ts;
         __syncthreads();
     }
-    if (tid == 0) { w.vbp[G] = cv; w.ubp[G] = cu; w.sbp[G] = cs; }
+    if (tid == 0) { lvbp[G] = cv; w.ubp[G] = cu; w.sbp[G] = cs; }
+    __syncthreads();                                      // ubp / sbp (written above by this workgroup) are read back below
+    const int nwg = G * kGridMult;
+    const int chunk = (cv + nwg - 1) / nwg;
+    for (int b = tid; b < nwg; b += (int)blockDim.x) {
+        const int vb0 = b * chunk;
+        int32_t *rec = w.wrec + (int64_t)b * kRecInts;
+        const int count = min(chunk, cv - vb0);
+        if (count <= 0) { rec[0] = 0; continue; }
+        int lo = 0, hi = G;                               // last g with vbp[g] <= vb0 (it has virtual workgroups: vbp[g + 1] > vb0)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (lvbp[mid] <= vb0) lo = mid; else hi = mid;
+        }
+        const long long sb = w.sbp[lo];
+        rec[0] = count;
+        rec[1] = lo;
+        rec[2] = vb0 - lvbp[lo];
+        rec[3] = w.sub_n[lo];
+        rec[4] = w.sub_quads[lo];
+        rec[5] = w.ubp[lo];
+        rec[6] = (int32_t)(sb & 0xFFFFFFFFll);
+        rec[7] = (int32_t)(sb >> 32);
+    }
+    __syncthreads();
     view_prefix(B, w.sub_n, w.nbp, wsum);
 }
 
-__global__ __launch_bounds__(256) void prefix_a_kernel(int32_t B, Work w)
+__global__ __launch_bounds__(kPrefixThreads) void prefix_a_kernel(int32_t B, Work w)
 {
-    __shared__ int32_t wsum[16];
-    __shared__ long long wsum64[4];
-    prefix_step_a(B, w, wsum, wsum64);
+    DYN_SMEM(smem);
+    __shared__ int32_t wsum[64];
+    __shared__ long long wsum64[16];
+    prefix_step_a(B, w, wsum, wsum64, (int32_t *)smem);
 }
 __global__ __launch_bounds__(256) void prefix_b_kernel(int32_t B, Work w)
 {
@@ -435,7 +480,7 @@ __device__ __forceinline__ bool scratch_overflows(const Work &w, int g, int64_t 
 // ------------------------------------------------------------------ K2 ----
 static long long *g_induce_ticks = nullptr;      // diagnostics (gcc_sampler_debug_ticks): [0..2] phase ticks, [15] workgroups
 #define IND_TICK(ph) do { if (ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&ticks[ph], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
-__global__ __launch_bounds__(kInduceThreads) void induce_kernel(
+__global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
     const int32_t *__restrict__ col_idx, int64_t num_edges, int32_t bm_log2_cap, int32_t B, int64_t scratch_entries,
     Work w, int32_t *__restrict__ status, long long *ticks)
 {
@@ -443,31 +488,113 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
     const int ncap = w.ncap, G = 2 * B;
     uint32_t *snodes = (uint32_t *)smem;                     // [ncap]     members (seed first, the rest ascending)
     int32_t *sq = (int32_t *)(snodes + ncap);                // [ncap + 1] exclusive prefix of quads per row
-    int32_t *srb = sq + (ncap + 1);                          // [ncap]     row begin
+    int32_t *srb = sq + (ncap + 2);                          // [ncap]     row begin  (sq padded: what follows stays 8-byte aligned)
     int32_t *srd = srb + ncap;                               // [ncap]     row degree
     uint32_t *bm = (uint32_t *)(srd + ncap);                 // [1 << (bm_log2_cap - 5)] Bloom bitmap of the members
     uint32_t *candv_all = bm + (1u << (bm_log2_cap - 5));    // [4][kCandCap] Bloom survivors (parent ids) ...
-    uint16_t *candr_all = (uint16_t *)(candv_all + 4 * kCandCap);   // [4][kCandCap] ... and their row
-    const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    uint16_t *candr_all = (uint16_t *)(candv_all + kInduceWaves * kCandCap);   // [waves][kCandCap] ... and their row
+    const int tid = (int)threadIdx.x, lane = lane_id(), wave = wave_uniform(tid >> 6);
     uint32_t *candv = candv_all + wave * kCandCap;
     uint16_t *candr = candr_all + wave * kCandCap;
+    uint16_t *rowl = candr_all + kInduceWaves * kCandCap + wave * kUnitQuads;   // [waves][256] row of every quad of a unit
     long long tick_ = ticks ? device_ticks() : 0;
     if (ticks && tid == 0) atomicAdd((unsigned long long *)&ticks[15], 1ull);
-    const int total_vb = w.vbp[G];                           // (prefix step A)
+    const uint4 *recp = (const uint4 *)(w.wrec + (int64_t)blockIdx.x * kRecInts);   // (prefix step A)
+    const uint4 ra = recp[0], rb4 = recp[1];
+    const int count = wave_uniform((int)ra.x);               // (uniform by construction: into scalar registers)
+    int g = wave_uniform((int)ra.y), part = wave_uniform((int)ra.z), n = wave_uniform((int)ra.w);
+    int totq = wave_uniform((int)rb4.x), ubase = wave_uniform((int)rb4.y);
+    long long sbase = (long long)(((unsigned long long)(uint32_t)wave_uniform((int)rb4.w) << 32) |
+                                  (unsigned long long)(uint32_t)wave_uniform((int)rb4.z));
     int cur_g = -1, bshift = 0;
-    // (a resident grid with virtual workgroups handed out through a counter was measured slower: 52 against 45 us)
-    for (int vb = (int)blockIdx.x; vb < total_vb; vb += (int)gridDim.x) {
-        const int g = w.vdesc[vb];
-        const int part = vb - w.vbp[g];
-        const int n = w.sub_n[g], totq = w.sub_quads[g];
+    // A workgroup takes CONSECUTIVE virtual workgroups when there are more of them than workgroups (the 10M/200M graph:
+    // 2.5 x), so that the member tables are rebuilt only at a subgraph boundary.  (A resident grid with virtual
+    // workgroups handed out through a counter was measured slower: 52 against 45 us.)
+    for (int it = 0; it < count; ++it) {
+        if (it) {
+            if (++part * kUnitsPerVwg >= units_of(totq)) {   // on to the next subgraph that has edges (block-uniform)
+                part = 0;
+                do { ++g; totq = g < G ? wave_uniform(w.sub_quads[g]) : 1; } while (totq == 0);
+                if (g >= G) break;                           // (the records and the prefixes come from the same pass)
+                n = wave_uniform(w.sub_n[g]);
+                ubase = wave_uniform(w.ubp[g]);
+                const long long sb = w.sbp[g];
+                sbase = (long long)(((unsigned long long)(uint32_t)wave_uniform((int)(sb >> 32)) << 32) |
+                                    (unsigned long long)(uint32_t)wave_uniform((int)(sb & 0xFFFFFFFFll)));
+            }
+        }
         const int nunits = units_of(totq);
-        if (scratch_overflows(w, g, scratch_entries)) {      // block-uniform
+        if (sbase + 4ll * (long long)totq > scratch_entries || (int64_t)ubase + nunits > w.unit_cap) {   // block-uniform
             if (tid == 0) atomicOr(status, (int32_t)GCC_STATUS_SCRATCH_OVERFLOW);
             continue;
         }
-        const long long sbase = w.sbp[g];
-        const int ubase = w.ubp[g];
         IND_TICK(0);
+        // this wave's units are wave, wave + 4, ... of the virtual workgroup's kUnitsPerVwg.  issue(): the rows of a
+        // unit's quads (binary search in the LDS prefix), then its 4 dwordx4 loads per lane.  (Two units in flight per
+        // wave were measured: 112 VGPRs, 4 workgroups per CU instead of 6, 42 against 37 us.)
+        uint4 v[4];
+        int r_[4];                                          // (row bounds, quad address: re-derived from LDS when the data is in)
+        auto issue = [&](int unit) {
+            // Rows of the unit's 256 consecutive quads without a search per quad (4 searches x 10 dependent steps per
+            // lane were a third of the kernel's instructions, and the kernel is VALU-bound): the wave finds the row of
+            // the unit's first quad together (64-ary, two rounds up to 4096 members), the rows that START inside the
+            // unit mark their first quad in a 256-entry LDS strip, and a prefix maximum spreads the marks.
+            const int qb = unit * kUnitQuads;
+            {
+                int r0 = 0, span = n;                                // last slot with sq[slot] <= qb is in [r0, r0 + span)
+                while (span > 1) {
+                    const int stride = (span + 63) >> 6;
+                    const int idx = r0 + lane * stride;
+                    const bool le = lane * stride < span && sq[idx] <= qb;   // true for lane 0, monotone in the lane
+                    const int c = __popcll(wave_ballot(le));
+                    const int adv = (c - 1) * stride;
+                    r0 += adv;
+                    span = min(stride, span - adv);
+                }
+                ((uint2 *)rowl)[lane] = make_uint2(0u, 0u);          // entries 4 lane .. 4 lane + 3
+                wave_sync();
+                for (int i0 = r0 + 1;; i0 += 64) {                   // rows r0 + 1 ... start after qb (sq ascends strictly)
+                    const int i = i0 + lane;
+                    const int q = i < n ? sq[i] : 0x7FFFFFFF;
+                    const bool in = q < qb + kUnitQuads;
+                    if (in) rowl[q - qb] = (uint16_t)(i - r0);       // <= 256: every row has at least one quad
+                    if (wave_ballot(in) != ~0ull) break;             // wave-uniform
+                }
+                wave_sync();
+                const uint2 mk = ((const uint2 *)rowl)[lane];
+                int e0 = (int)(mk.x & 0xFFFFu), e1 = (int)(mk.x >> 16), e2 = (int)(mk.y & 0xFFFFu), e3 = (int)(mk.y >> 16);
+                e1 = max(e1, e0);
+                e2 = max(e2, e1);
+                e3 = max(e3, e2);
+                const int incl = wave_scan_max_incl(e3);
+                int before = wave_shfl_up(incl, 1);
+                if (lane == 0) before = 0;
+                e0 = max(e0, before);
+                e1 = max(e1, before);
+                e2 = max(e2, before);
+                e3 = max(e3, before);
+                ((uint2 *)rowl)[lane] = make_uint2((uint32_t)e0 | ((uint32_t)e1 << 16), (uint32_t)e2 | ((uint32_t)e3 << 16));
+                wave_sync();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int fq = qb + u * 64 + lane;
+                    const bool ok = fq < totq;
+                    const int r = r0 + (int)rowl[u * 64 + lane];
+                    const int rbv = srb[r];
+                    const int a0 = (((rbv >> 2) + (fq - sq[r])) << 2);   // element index of the aligned quad
+                    r_[u] = ok ? r : -1;
+                    if (ok && (int64_t)a0 + 4 <= num_edges) {
+                        v[u] = *(const uint4 *)(col_idx + a0);
+                    } else {                                         // the array's last quad may be partial
+                        uint32_t t[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = (ok && (int64_t)a0 + e < num_edges) ? (uint32_t)col_idx[a0 + e] : kEmpty;
+                        v[u] = make_uint4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+            }
+        };
+        const int unit0 = part * kUnitsPerVwg + wave;
         if (g != cur_g) {                                    // block-uniform
             __syncthreads();                                 // the previous subgraph's tables are no longer read
             int bl = 11;                                     // >= 64 bits per member, >= 2048 bits
@@ -486,51 +613,22 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
             }
             if (tid == 0) sq[n] = totq;
             __syncthreads();
-            for (int i = tid; i < n; i += kInduceThreads) {
-                const uint32_t h = (snodes[i] * kHashMul) >> bshift;
-                atomicOr(&bm[h >> 5], 1u << (h & 31));
-            }
-            __syncthreads();
-            cur_g = g;
-            IND_TICK(1);
         }
-        // ---- this wave's units (consecutive units go to different waves), kUnitsInFlight at a time: the rows of all
-        //      their quads (binary search in the LDS prefix), then all loads in flight together (2 x 4 dwordx4 per lane)
-        constexpr int kPer = kUnitsInFlight;
         int my_nnz = 0;
+        const int unit_end = min(nunits, (part + 1) * kUnitsPerVwg);
 #pragma unroll 1
-        for (int batch = 0; batch < kUnitsPerVwg / 4 / kPer; ++batch) {
-        if (part * kUnitsPerVwg + batch * kPer * 4 + wave >= nunits) break;      // wave-uniform
-        uint4 v[kPer][4];
-        int lo_[kPer][4], hi_[kPer][4], a0_[kPer][4], r_[kPer][4];
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int unit = part * kUnitsPerVwg + (batch * kPer + k) * 4 + wave;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int fq = unit * kUnitQuads + u * 64 + lane;
-                const bool ok = unit < nunits && fq < totq;
-                const int r = ok ? upper_slot(sq, n, fq) : 0;
-                const int rbv = srb[r], dv = srd[r];
-                const int a0 = (((rbv >> 2) + (fq - sq[r])) << 2);   // element index of the aligned quad
-                r_[k][u] = r;
-                a0_[k][u] = a0;
-                lo_[k][u] = ok ? rbv : 0x7FFFFFFF;                   // elements outside [lo, hi) belong to other rows
-                hi_[k][u] = ok ? rbv + dv : 0;
-                if (ok && (int64_t)a0 + 4 <= num_edges) {
-                    v[k][u] = *(const uint4 *)(col_idx + a0);
-                } else {                                             // the array's last quad may be partial
-                    uint32_t t[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = (ok && (int64_t)a0 + e < num_edges) ? (uint32_t)col_idx[a0 + e] : kEmpty;
-                    v[k][u] = make_uint4(t[0], t[1], t[2], t[3]);
+        for (int unit = unit0;; unit += kInduceWaves) {              // wave-uniform; every wave enters once
+            if (unit < unit_end) issue(unit);                        // (one call site: the body is large)
+            if (g != cur_g) {                                        // block-uniform, first pass only: the first unit's
+                for (int i = tid; i < n; i += kInduceThreads) {      // loads fly while the bitmap is built
+                    const uint32_t h = umul24(snodes[i], kHashMul) >> bshift;
+                    atomicOr(&bm[h >> 5], 1u << (h & 31));
                 }
+                __syncthreads();
+                cur_g = g;
+                IND_TICK(1);
             }
-        }
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int unit = part * kUnitsPerVwg + (batch * kPer + k) * 4 + wave;
-            if (unit >= nunits) break;                               // wave-uniform
+            if (unit >= unit_end) break;
             int32_t *out = w.scratch + sbase + (long long)unit * kUnitElems;
             int ncand = 0, nout = 0;                                 // wave-uniform
             auto drain = [&]() {
@@ -560,35 +658,39 @@ __global__ __launch_bounds__(kInduceThreads) void induce_kernel(
             };
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (ncand + 4 * 64 > kCandCap) drain();              // wave-uniform
-                const uint32_t vals[4] = {v[k][u].x, v[k][u].y, v[k][u].z, v[k][u].w};
+                const uint32_t vals[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                const int rr = r_[u];
+                const int rc = max(rr, 0);
+                const int rbv = srb[rc];
+                const int a0 = (((rbv >> 2) + (unit * kUnitQuads + u * 64 + lane - sq[rc])) << 2);
+                const int d0 = a0 - rbv;                             // elements outside the row belong to other rows:
+                const uint32_t deg = rr >= 0 ? (uint32_t)srd[rc] : 0u;   // 0 <= d0 + e < deg, one unsigned compare
                 uint32_t pass = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int a = a0_[k][u] + e;
-                    const uint32_t h = (vals[e] * kHashMul) >> bshift;
-                    const bool in_row = a >= lo_[k][u] && a < hi_[k][u];
-                    const uint32_t bit = in_row ? (bm[h >> 5] >> (h & 31)) & 1u : 0u;
-                    pass |= bit << e;
+                    const uint32_t h = umul24(vals[e], kHashMul) >> bshift;
+                    const uint32_t in_row = (uint32_t)(d0 + e) < deg ? 1u : 0u;
+                    pass |= ((bm[h >> 5] >> (h & 31)) & in_row) << e;     // (always read: no branch per element)
                 }
                 const int cnt = __popc(pass);
                 const int incl = wave_scan_incl(cnt);
+                const int tot = wave_last(incl);
+                if (ncand + tot > kCandCap) drain();                 // wave-uniform; a round adds at most 256 = kCandCap
                 int at = ncand + incl - cnt;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (pass & (1u << e)) {
                         candv[at] = vals[e];
-                        candr[at] = (uint16_t)r_[k][u];
+                        candr[at] = (uint16_t)r_[u];
                         ++at;
                     }
                 }
-                ncand += wave_shfl(incl, 63);
+                ncand += tot;
             }
             drain();
             if (lane == 0) w.ucnt[ubase + unit] = nout;
             my_nnz += nout;
         }
-        }   // batch
         if (lane == 0 && my_nnz) atomicAdd(&w.sub_nnz[g], my_nnz);
         IND_TICK(2);
     }
@@ -766,14 +868,12 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     w.rowbeg = (int32_t *)(base + wl.off_rowbeg);
     w.rowdeg = (int32_t *)(base + wl.off_rowdeg);
     w.rowq = (int32_t *)(base + wl.off_rowq);
-    w.vbp = (int32_t *)(base + wl.off_vbp);
     w.ubp = (int32_t *)(base + wl.off_ubp);
     w.sbp = (long long *)(base + wl.off_sbp);
     w.nbp = (int32_t *)(base + wl.off_nbp);
     w.ebp = (int32_t *)(base + wl.off_ebp);
     w.ucnt = (int32_t *)(base + wl.off_ucnt);
-    w.vdesc = (int32_t *)(base + wl.off_vdesc);
-    w.vwg_cap = wl.vwg_cap;
+    w.wrec = (int32_t *)(base + wl.off_wrec);
     w.scratch = (int32_t *)(base + wl.off_scratch);
     w.ncap = wl.ncap;
     w.unit_cap = wl.unit_cap;
@@ -782,10 +882,10 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     hipStream_t s = (hipStream_t)stream;
     int p2max = 64;
     while (p2max < g->lmax) p2max <<= 1;
-    int bmlog = 11;                                  // Bloom bitmap: >= 64 bits per member of the largest subgraph
-    while ((1 << bmlog) < 64 * (g->lmax + 1) && bmlog < 20) ++bmlog;
+    int bmlog = 11;                                  // Bloom bitmap: 64 bits per member up to 1024 members, 8 KiB at most (LDS per
+    while ((1 << bmlog) < 64 * (g->lmax + 1) && bmlog < 16) ++bmlog;   // workgroup decides how many are resident: 82 KiB at lmax 2360 left one per CU)
     const size_t lds1 = ((size_t)p2max * 2 + 64) * 4;
-    const size_t lds2 = (size_t)wl.ncap * 16 + 4 + ((size_t)1 << (bmlog - 3)) + (size_t)4 * kCandCap * 6 + 16;
+    const size_t lds2 = (size_t)wl.ncap * 16 + 8 + ((size_t)1 << (bmlog - 3)) + (size_t)kInduceWaves * (kCandCap * 6 + kUnitQuads * 2) + 16;
     if (lds1 > 160 * 1024 || lds2 > 160 * 1024 - 256) {
         snprintf(g_err, kErrLen, "gcc_sample_batch: lmax=%d / batch too large for 160 KiB of LDS", g->lmax);
         return -4;
@@ -804,9 +904,9 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     hipLaunchKernelGGL(rwr_walk_kernel, dim3(G), dim3(kWalkThreads), lds1, s, g->row_ptr, g->col_idx, g->seed_cdf,
                        g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, B,
                        p->restart_u32, p->seeds, w);
-    hipLaunchKernelGGL(prefix_a_kernel, dim3(1), dim3(256), 0, s, B, w);
+    hipLaunchKernelGGL(prefix_a_kernel, dim3(1), dim3(kPrefixThreads), (size_t)(G + 1) * 4, s, B, w);
     prof_mark(p->prof, 1, s);                        // marks 1 -> 2 bracket induce_kernel alone (bench.py's roofline interval)
-    hipLaunchKernelGGL(induce_kernel, dim3(G * 8), dim3(kInduceThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,
+    hipLaunchKernelGGL(induce_kernel, dim3(G * kGridMult), dim3(kInduceThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,
                        scratch_entries, w, status, g_induce_ticks);
     prof_mark(p->prof, 2, s);
     hipLaunchKernelGGL(prefix_b_kernel, dim3(1), dim3(256), 0, s, B, w);

@@ -1,0 +1,25 @@
+#!/bin/bash
+# induction on the 10M/200M graph: consecutive virtual workgroups per workgroup; grid 8 G vs 4 G vs 16 G; phases
+set -u
+O=gpurun_out/r2ab3
+mkdir -p $O
+export TMPDIR=/tmp GCC_AMD_GRAPH_CACHE=/tmp/graphs
+run() {
+  cd /tmp && (timeout 400 rocprofv3 --output-format csv --kernel-trace --stats -d /tmp/prof_$1 -o s -- python $GRAFT_REPO_ROOT/tools/sampler_alone.py $2 2>&1 | tail -1) > $GRAFT_REPO_ROOT/$O/log_$1.txt; cd $GRAFT_REPO_ROOT
+  find /tmp/prof_$1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_$1.csv
+}
+build() {
+  (cd gcc_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $1 -o libgcc_amd.so common.hip sampler.hip encoder.hip encoder_bwd.hip nce.hip posemb.hip gin_wide.hip 2>&1 | grep " error")
+}
+G2="--nodes 10000000 --edges 200000000 --launches 40"
+run m8_g1 "--launches 60"
+run m8_g2 "$G2"
+(timeout 300 python tools/induce_phases.py --nodes 10000000 --edges 200000000 2>&1 | tail -1) > $O/phases_g2.txt
+(timeout 300 python tools/induce_phases.py 2>&1 | tail -1) > $O/phases_g1.txt
+build "-DGCC_INDUCE_GRID_MULT=4"
+run m4_g2 "$G2"
+build "-DGCC_INDUCE_GRID_MULT=16"
+run m16_g2 "$G2"
+build "-DGCC_INDUCE_GRID_MULT=8 -DGCC_INDUCE_VWG_UNITS=16"
+run m8v16_g2 "$G2"
+cat $O/phases_g2.txt $O/phases_g1.txt

@@ -98,7 +98,7 @@ def _dense_graph(n, p, seed):
 
 def test_dense_subgraphs_drain_the_candidate_queue(coracle):
     """Almost every neighbour is a member (hit rate ~100 % instead of ~1.5 %): the per-wave queue of Bloom survivors
-    (512 entries) is drained several times per unit and every unit's scratch slot fills up."""
+    (256 entries) is drained several times per unit and every unit's scratch slot fills up."""
     rp, ci = _dense_graph(300, 0.6, 2)
     g = EmuGraph(rp, ci, rw_hops=64, ltab=np.full(int(np.diff(rp).max()) + 1, 900, dtype=np.int32))
     res = _compare(coracle, rp, ci, g, 2, 3, 0)
@@ -115,6 +115,19 @@ def test_many_units_per_subgraph_and_odd_row_alignment(coracle):
     n = int(res[0]["node_off"][-1])
     quads = sum((int(rp[v + 1]) + 3) // 4 - int(rp[v]) // 4 for v in res[0]["parent_nid"])
     assert n > 600 and quads > 256 * 256
+
+
+def test_workgroups_cross_subgraph_boundaries(coracle):
+    """More virtual workgroups than induce workgroups (G * 8): each workgroup takes several consecutive ones and walks
+    from one subgraph into the next (subgraphs of unequal size, so that the boundaries fall inside the chunks)."""
+    rp, ci = _dense_graph(701, 0.9, 5)
+    deg = np.diff(rp)
+    ltab = np.where(np.arange(deg.max() + 1) % 2 == 0, 2500, 40).astype(np.int32)   # long and short walks by seed degree
+    g = EmuGraph(rp, ci, rw_hops=64, ltab=ltab)
+    res = _compare(coracle, rp, ci, g, 3, 9, 0, seeds=[3, 600, 44])
+    quads = [sum((int(rp[v + 1]) + 3) // 4 - int(rp[v]) // 4 for v in res[view]["parent_nid"][a:b])
+             for view in range(2) for a, b in zip(res[view]["node_off"][:-1], res[view]["node_off"][1:])]
+    assert sum(-(-q // 2048) for q in quads) > 2 * 6 * 8 and len(set(quads)) == 6      # chunk >= 3
 
 
 def test_last_quad_of_col_idx_is_partial(coracle):

@@ -1,4 +1,5 @@
 """Per-phase wall-clock ticks of induce_kernel on the default bench workload (isolated GPU)."""
+import argparse
 import sys
 import torch
 
@@ -8,8 +9,12 @@ from gcc_amd.graph import DeviceGraph
 from gcc_amd.graphgen import powerlaw_graph
 from gcc_amd.sampler import DeviceRWRSampler
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--nodes", type=int, default=1_000_000)
+ap.add_argument("--edges", type=int, default=10_000_000)
+args = ap.parse_args()
 dev = torch.device("cuda:0")
-rp, ci = powerlaw_graph(1_000_000, 10_000_000, seed=0)
+rp, ci = powerlaw_graph(args.nodes, args.edges, seed=0)
 graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False)
 sampler = DeviceRWRSampler(graph, 256, run_seed=0, num_buffers=2)
 for i in range(5):
