@@ -287,7 +287,9 @@ def sampler_probe(sampler, rp, first_id, args, nsample, lt, Prof, torch):
         bts = sampler_algorithmic_bytes(rp, [(q.csr_numpy(), L), (k.csr_numpy(), L)])
         for key in acc:
             acc[key] += bts[key] / nsample
-    return dict(rwr_walk_kernel=float(iso[0]), induce_kernel=float(iso[1]), pack_kernel=float(iso[2])), acc
+    # the event marks sit around groups of launches: walk + prefix step A | induction alone | prefix step B + pack
+    return {"rwr_walk_kernel+prefix_a_kernel": float(iso[0]), "induce_kernel": float(iso[1]),
+            "prefix_b_kernel+pack_kernel": float(iso[2])}, acc
 
 
 def main():
