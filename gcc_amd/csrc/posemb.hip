@@ -16,6 +16,10 @@
 namespace {
 
 constexpr int kJMax = GCC_POSEMB_LDS_MAX;
+#ifndef GCC_POSEMB_SMALL_T
+#define GCC_POSEMB_SMALL_T 256
+#endif
+constexpr int kSmallT = GCC_POSEMB_SMALL_T;   // threads of a small-class workgroup
 constexpr int kJSmall = 64;        // LDS-resident size classes of the direct solver: n' <= 64 (256 threads, ~60 KiB of LDS)
                                    // and 65..kJMax (1024 threads, ~150 KiB)
 
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m
 template <int kCls, int kNMin, int kNMax, int kT, bool kGlobalA>
 __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead hd)
 {
-    static_assert(kNMax % 64 == 0 && kT % 64 == 0 && kT >= 256, "size class");
+    static_assert(kNMax % 64 == 0 && kT % 64 == 0 && kT >= 64, "size class");
     DYN_SMEM(smem);
     __shared__ EigShared es;
     __shared__ int colsrc[64];                  // per output column: eigenvector j >= 0, or -(c + 1) for contrast c
@@ -2200,12 +2204,12 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
         const char *e = getenv("GCC_POSEMB_CHEB");
         hd.use_cheb = e ? atoi(e) != 0 : 1;
     }
-    constexpr int lds_small = direct_lds_bytes<kJSmall, 256, false>();
+    constexpr int lds_small = direct_lds_bytes<kJSmall, kSmallT, false>();
     constexpr int lds_big = direct_lds_bytes<kJMax, 1024, false>();
 #ifndef GCC_AMD_HIPEMU
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsSmall, 0, kJSmall, 256, false>,
+        (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsSmall, 0, kJSmall, kSmallT, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_small);
         (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, 1024, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
@@ -2256,7 +2260,7 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     hipLaunchKernelGGL((posemb_direct_kernel<kClsBig, kGMax + 1, kBMax, 1024, true>), dim3(g.big), dim3(1024), kBLds, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>), dim3(g.slot), dim3(1024), kGLds, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, 1024, false>), dim3(g.mid), dim3(1024), lds_big, s, m, hd);
-    hipLaunchKernelGGL((posemb_direct_kernel<kClsSmall, 0, kJSmall, 256, false>), dim3(g.small), dim3(256), lds_small, s, m, hd);
+    hipLaunchKernelGGL((posemb_direct_kernel<kClsSmall, 0, kJSmall, kSmallT, false>), dim3(g.small), dim3(kSmallT), lds_small, s, m, hd);
     prof_mark(prof, 1, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_posemb: %s", hipGetErrorString(e)); return -10; }
