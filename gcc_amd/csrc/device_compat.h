@@ -53,6 +53,7 @@ template <class T> static inline T wave_shfl_down(T v, int delta)
 template <class T> static inline T wave_bcast_first(T v) { return wave_shfl(v, 0); }
 // a value the caller knows to be wave-uniform (device: moved to a scalar register) / lane 63's value as a uniform
 static inline int wave_uniform(int v) { return v; }
+static inline void keep_alive(double) {}
 static inline int wave_last(int v) { return wave_shfl(v, 63); }
 // D = A(16x4) * B(4x16) + C; lane l: a = A[l&15][l>>4], b = B[l>>4][l&15],
 // c/d[r] = C[(l>>4)*4 + r][l&15]  (cdna_hip_programming.md §3)
@@ -200,6 +201,8 @@ template <class T> __device__ __forceinline__ T wave_bcast_first(T v) { return _
 // a value the caller knows to be wave-uniform, moved to a scalar register (the compiler cannot tell for values that
 // come from threadIdx or a vector load: everything derived from them would stay in VGPRs and on the VALU)
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// forces a value (e.g. the result of a returning atomic) to be waited for
+__device__ __forceinline__ void keep_alive(double v) { asm volatile("" ::"v"(v)); }
 __device__ __forceinline__ int wave_last(int v) { return __builtin_amdgcn_readlane(v, 63); }
 __device__ __forceinline__ f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c)
 {

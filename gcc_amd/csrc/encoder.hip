@@ -93,6 +93,9 @@ struct InArgs {
     float eps, nbr_weight;    // nbr_weight: edge multiplicity
 };
 struct InLaunch { InArgs p[kMaxPass]; long long *ticks; };
+#ifndef GIN_DBG_SKIP
+#define GIN_DBG_SKIP 0       // timing experiments only (wrong results): 1 no pooling, 2 no statistics flush, 4 no gather
+#endif
 static long long *g_gin_ticks = nullptr;   // diagnostics (gcc_gin_debug_ticks)
 #define GIN_TICK(ph) do { if (L.ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&L.ticks[(a.first ? 0 : 16) + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 
@@ -100,10 +103,10 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
-    __shared__ float part[16 * H];
+    __shared__ float part[32 * H];
     __shared__ float red[4 * 2 * H];
-    __shared__ int longrows[kTile];
-    __shared__ int nlong;
+    __shared__ int prow[32];
+    __shared__ int rpl[kTile + 1], gidl[kTile];
     const InArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
     const int N = a.node_off[a.B];
@@ -127,8 +130,10 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
     for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
         const int nrows = min(kTile, N - tile0);
         if (L.ticks && tid == 0) atomicAdd((unsigned long long *)&L.ticks[(a.first ? 0 : 16) + 15], 1ull);
-        if (tid == 0) nlong = 0;
-        // 1. own rows
+        // 1. own rows; the tile's row pointers and graph ids ride in the same round trip (the pooling and the gather
+        //    would otherwise each start with one of their own)
+        if (tid <= nrows) rpl[tid] = a.row_ptr[tile0 + tid];
+        if (tid >= 128 && tid - 128 < nrows) gidl[tid - 128] = a.graph_id[tile0 + tid - 128];
         for (int r = gi; r < kTile; r += 16) {
             F4 x = {0.f, 0.f, 0.f, 0.f};
             if (r < nrows) x = feat(tile0 + r);
@@ -137,11 +142,15 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
         __syncthreads();
         GIN_TICK(1);
         // 2. SumPooling of hidden_rep[layer] (gin.py:228)
-        if (a.pooled) pool_tile(T, tile0, nrows, a.graph_id, a.pooled);
+#if !(GIN_DBG_SKIP & 1)
+        if (a.pooled) pool_tile(T, tile0, nrows, a.graph_id, a.pooled, gidl);
+#endif
         lds_barrier();                             // (the pooling atomics stay in flight)
         GIN_TICK(2);
         // 3. GINConv aggregate: (1 + eps) * h_v + sum_{u -> v} h_u, eps = 0 (gin.py:179-185,218)
-        gather_tile(T, part, longrows, &nlong, tile0, nrows, a.row_ptr, a.col_idx, feat, a.nbr_weight);
+#if !(GIN_DBG_SKIP & 4)
+        gather_tile(T, part, prow, nrows, a.col_idx, feat, a.nbr_weight, rpl);
+#endif
         GIN_TICK(3);
         // 4. keep agg for the weight gradient of linears.0
         if (a.agg)
@@ -157,7 +166,9 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
         }
         __syncthreads();
         GIN_TICK(5);
+#if !(GIN_DBG_SKIP & 2)
         flush_stats(red, a.stats_a);
+#endif
         lds_barrier();
         GIN_TICK(6);
     }

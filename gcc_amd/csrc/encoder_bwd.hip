@@ -199,8 +199,8 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_c_kernel(BwdCArgs a)
     __shared__ float T[kTile * kLdt];
     __shared__ float part[16 * 2 * H];
     __shared__ float Cb[kCoefRows * H], Cc[kCoefRows * H];
-    __shared__ int longrows[kTile];
-    __shared__ int nlong;
+    __shared__ int prow[32];
+    __shared__ int rpl[kTile + 1];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
     const int N = a.node_off[a.B];
     fill_coefs(Cb, a.bnb, nullptr, (double)N, a.eps);
@@ -216,10 +216,10 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_c_kernel(BwdCArgs a)
         any = true;
         const int nrows = min(kTile, N - tile0);
         if (a.D) {
-            if (tid == 0) nlong = 0;
+            if (tid <= nrows) rpl[tid] = a.row_ptr[tile0 + tid];      // (same round trip as the rows)
             for (int r = gi; r < kTile; r += 16) st4(&T[r * kLdt + 4 * t], r < nrows ? ident(tile0 + r) : zero4());
             __syncthreads();
-            gather_tile(T, part, longrows, &nlong, tile0, nrows, a.row_ptr, a.col_idx, ident);
+            gather_tile(T, part, prow, nrows, a.col_idx, ident, 1.0f, rpl);
         }
         for (int r = gi; r < nrows; r += 16) {
             const int v = tile0 + r;
@@ -402,11 +402,11 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
-    __shared__ float part[16 * H];
+    __shared__ float part[32 * H];
     __shared__ float E[kEmbMaxElems];
     __shared__ int dclrow[kTile];
-    __shared__ int longrows[kTile];
-    __shared__ int nlong;
+    __shared__ int prow[32];
+    __shared__ int rpl[kTile + 1];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
     const int N = a.node_off[a.B];
     const int elems = (a.max_degree + 1) * a.emb_dim;
@@ -414,14 +414,13 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
     auto ident = [&](int u) -> F4 { return ld4(a.D + (int64_t)u * H + 4 * t); };
     for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
         const int nrows = min(kTile, N - tile0);
-        if (tid == 0) nlong = 0;
+        if (tid <= nrows) rpl[tid] = a.row_ptr[tile0 + tid];          // (same round trip as the rows)
         for (int r = gi; r < kTile; r += 16) st4(&T[r * kLdt + 4 * t], r < nrows ? ident(tile0 + r) : zero4());
         __syncthreads();
-        gather_tile(T, part, longrows, &nlong, tile0, nrows, a.row_ptr, a.col_idx, ident);
+        gather_tile(T, part, prow, nrows, a.col_idx, ident, 1.0f, rpl);
         // all threads: add the pooled-path gradient and look the clamped degree up (global loads in parallel) ...
         if (tid < nrows) {
-            const int v = tile0 + tid;
-            const int deg = a.row_ptr[v + 1] - a.row_ptr[v];
+            const int deg = rpl[tid + 1] - rpl[tid];
             dclrow[tid] = deg < a.max_degree ? deg : a.max_degree;
         }
         for (int idx = tid; idx < nrows * a.emb_dim; idx += kThreads) {

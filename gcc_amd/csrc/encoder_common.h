@@ -10,8 +10,7 @@ constexpr int kTile = 64;           // rows per workgroup tile
 constexpr int kLdt = 72;            // LDS row stride in floats (conflict-free ds_read_b128 fragments)
 constexpr int kThreads = 256;
 constexpr int kGridX = 768;         // tiles are grid-strided
-constexpr int kLongRow = 48;
-constexpr int kGatherJ = 2;         // neighbours per row fetched together (x 4 rows per lane group); more costs occupancy
+constexpr int kGatherJ = 8;         // feature rows a lane group has in flight (32 VGPRs)
 constexpr int kMaxPass = 2;
 constexpr int kRep = 32;            // replicas of every atomically accumulated statistics row: a block adds to
                                     // copy (blockIdx.x % kRep), consumers sum the copies -- ~730 workgroups hitting the
@@ -271,14 +270,18 @@ __device__ __forceinline__ void flush_stats(const float *red, double *stats)
 
 // Every workgroup of a pass calls this once after its last flush_stats(): the one that arrives last adds the replicas
 // up in replica order into totals[2][64] (and re-arms the counter).  Ends with nothing pending; block-uniform.
-__device__ __forceinline__ void finalize_stats(const double *stats, double *totals, int32_t *ticket, int nblocks)
+__device__ __forceinline__ void finalize_stats(double *stats, double *totals, int32_t *ticket, int nblocks)
 {
     __shared__ int last_arrival;
     if (!totals) return;
     // No cache maintenance here (a __threadfence() per workgroup writes back / invalidates L2 some 1500 times per kernel
-    // and made the forward pass 4x slower): the statistics are device-scope atomics performed at the coherence point, the
-    // barrier waits for this workgroup's to be acknowledged (s_waitcnt vmcnt(0)) before its ticket -- another device-scope
-    // atomic -- is issued, and the last arrival reads the replicas with device-scope loads.
+    // and made the forward pass 4x slower): the statistics are device-scope atomics performed at the coherence point and
+    // the last arrival reads the replicas with device-scope loads.  What the ticket needs is that this workgroup's
+    // atomics have been PERFORMED, not merely accepted: they return nothing, so s_waitcnt alone does not say that
+    // (seen on freshly started devices: a total missing one workgroup, 1 run in ~4).  A returning atomic on each
+    // address this workgroup added to comes back only after the earlier ones to that address -- one round trip per
+    // workgroup, once per kernel.
+    if (threadIdx.x < 2 * H) keep_alive(atomicAdd(&stats[((int)blockIdx.x % kRep) * 2 * H + threadIdx.x], 0.0));
     __syncthreads();
     if (threadIdx.x == 0) last_arrival = atomicAdd(ticket, 1) == nblocks - 1;
     __syncthreads();
@@ -291,100 +294,86 @@ __device__ __forceinline__ void finalize_stats(const double *stats, double *tota
     if (threadIdx.x == 0) *ticket = 0;
 }
 
-// ---- neighbourhood sum over an LDS tile.  Precondition: T rows [0, nrows) hold the self term,
-// *nlong == 0, and a __syncthreads() separates those writes from this call.  Postcondition:
-// T[r] = self + sum_{u in row(tile0 + r)} feat(u); ends with a __syncthreads().
-// Lane groups of 16 own rows (16 B per lane = one 256 B feature row per load); rows longer than
-// kLongRow are summed by all 16 groups together so that a hub row does not serialise one group.
+// ---- neighbourhood sum over an LDS tile.  Precondition: T rows [0, nrows) hold the self term, rp_lds[0 .. nrows] the
+// tile's row pointers, and a __syncthreads() separates those writes from this call.  Postcondition:
+// T[r] = self + nbr_weight * sum_{u in row(tile0 + r)} feat(u); ends with a __syncthreads().
+// The tile's EDGES, not its rows, are split evenly over the 16 lane groups (16 lanes x 16 B = one 256 B feature row per
+// load): with rows per group the wave ran as many rounds as its longest row (ego-nets have hubs: 12-15 dependent round
+// trips per tile for an average degree of 5; the gather was 49 of gin_in_kernel's 79 us).  A group sums its chunk in
+// edge order; rows that lie inside the chunk are finished there, the chunk's first and last row go to side slots that
+// one wave adds in group order afterwards -- a fixed order, so the result does not depend on timing.
 template <class Feat>
-__device__ __forceinline__ void gather_tile(float *T, float *part /* [16 * H] */, int *longrows, int *nlong,
-                                            int tile0, int nrows, const int32_t *row_ptr,
-                                            const int32_t *col_idx, Feat feat, float nbr_weight = 1.0f,
-                                            const int *rp_lds = nullptr /* [nrows + 1] row_ptr of the tile, in LDS */)
+__device__ __forceinline__ void gather_tile(float *T, float *part /* [32 * H] */, int *prow /* [32] */, int nrows,
+                                            const int32_t *col_idx, Feat feat, float nbr_weight,
+                                            const int *rp_lds /* [nrows + 1] */)
 {
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, gbase = lane_id() & ~15;
-    // A lane group walks its four rows (gi, gi + 16, gi + 32, gi + 48) TOGETHER: the 16 lanes fetch 16 entries of
-    // each neighbour list in one load, and kGatherJ neighbours x 4 rows of features are in flight at a time, so that a tile
-    // costs a handful of memory round trips instead of two per four edges.
-    int beg[4], deg[4], idx[4];
-    F4 acc[4];
-    int md = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = gi + 16 * q;
-        const bool ok = r < nrows;
-        const int b0 = ok ? (rp_lds ? rp_lds[r] : row_ptr[tile0 + r]) : 0;
-        const int e0 = ok ? (rp_lds ? rp_lds[r + 1] : row_ptr[tile0 + r + 1]) : 0;
-        int d = e0 - b0;
-        if (d > kLongRow) {
-            if (t == 0) longrows[atomicAdd(nlong, 1)] = r;
-            d = 0;
-        }
-        beg[q] = b0;
-        deg[q] = d;
-        md = d > md ? d : md;
-        acc[q] = F4{0.f, 0.f, 0.f, 0.f};
-    }
-    md = (int)wave_max((float)md);                  // wave-uniform trip counts (the shuffles below need every lane)
-    for (int c = 0; c < md; c += 16) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) idx[q] = c + t < deg[q] ? col_idx[beg[q] + c + t] : -1;
-        for (int eb = 0; eb < 16 && c + eb < md; eb += kGatherJ) {
-            F4 f[4][kGatherJ];
-            int u[4][kGatherJ];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int j = 0; j < kGatherJ; ++j) u[q][j] = wave_shfl(idx[q], gbase + eb + j);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int j = 0; j < kGatherJ; ++j) f[q][j] = feat(u[q][j] < 0 ? 0 : u[q][j]);   // branch free: loads in flight
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int j = 0; j < kGatherJ; ++j) {
-                    const float keep = u[q][j] < 0 ? 0.f : 1.f;
-                    acc[q].x = fmaf(keep, f[q][j].x, acc[q].x);
-                    acc[q].y = fmaf(keep, f[q][j].y, acc[q].y);
-                    acc[q].z = fmaf(keep, f[q][j].z, acc[q].z);
-                    acc[q].w = fmaf(keep, f[q][j].w, acc[q].w);
-                }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = gi + 16 * q;
-        if (r < nrows && deg[q] > 0) {
-            const F4 self = ld4(&T[r * kLdt + 4 * t]);
+    const int ebeg = rp_lds[0], eend = rp_lds[nrows];
+    const int chunk = (eend - ebeg + 15) >> 4;          // edges per group (block-uniform)
+    const int e0 = ebeg + gi * chunk, e1 = min(e0 + chunk, eend);
+    if (t < 2) prow[gi * 2 + t] = -1;
+    F4 acc = {0.f, 0.f, 0.f, 0.f};
+    int cur = -1, first = -1;                            // group-uniform: row being summed, the chunk's first row
+    auto flush = [&](bool last) {
+        if (cur < 0) return;
+        if (cur == first || last) {
+            const int slot = gi * 2 + (cur == first ? 0 : 1);
+            st4(&part[slot * H + 4 * t], acc);
+            if (t == 0) prow[slot] = cur;
+        } else {                                         // every edge of this row is in this group's chunk
+            float *dst = &T[cur * kLdt + 4 * t];
+            const F4 self = ld4(dst);
             F4 o;
-            o.x = fmaf(nbr_weight, acc[q].x, self.x); o.y = fmaf(nbr_weight, acc[q].y, self.y);
-            o.z = fmaf(nbr_weight, acc[q].z, self.z); o.w = fmaf(nbr_weight, acc[q].w, self.w);
-            st4(&T[r * kLdt + 4 * t], o);
+            o.x = fmaf(nbr_weight, acc.x, self.x); o.y = fmaf(nbr_weight, acc.y, self.y);
+            o.z = fmaf(nbr_weight, acc.z, self.z); o.w = fmaf(nbr_weight, acc.w, self.w);
+            st4(dst, o);
+        }
+    };
+    for (int c = 0; c < chunk; c += 16) {                // block-uniform trip counts (the shuffles need every lane)
+        const int e = e0 + c + t;
+        const bool valid = e < e1;
+        const int idx = valid ? col_idx[e] : -1;
+        int rid = 0;                                     // last r with rp_lds[r] <= e
+        if (valid) {
+            int hi = nrows;
+            while (hi - rid > 1) {
+                const int mid = (rid + hi) >> 1;
+                if (rp_lds[mid] <= e) rid = mid; else hi = mid;
+            }
+        }
+        if (c == 0) first = wave_shfl(rid, gbase);       // (an empty chunk never flushes)
+        for (int eb = 0; eb < 16 && c + eb < chunk; eb += kGatherJ) {
+            F4 f[kGatherJ];
+            int u[kGatherJ], rj[kGatherJ];
+#pragma unroll
+            for (int j = 0; j < kGatherJ; ++j) {
+                u[j] = wave_shfl(idx, gbase + eb + j);
+                rj[j] = wave_shfl(rid, gbase + eb + j);
+            }
+#pragma unroll
+            for (int j = 0; j < kGatherJ; ++j) f[j] = feat(u[j] < 0 ? 0 : u[j]);   // branch free: all loads in flight
+#pragma unroll
+            for (int j = 0; j < kGatherJ; ++j) {
+                if (u[j] >= 0) {                         // group-uniform
+                    if (rj[j] != cur) {
+                        flush(false);
+                        acc = F4{0.f, 0.f, 0.f, 0.f};
+                        cur = rj[j];
+                    }
+                    acc = add4(acc, f[j]);
+                }
+            }
+        }
+    }
+    flush(true);
+    __syncthreads();
+    if (tid < H) {                                       // one wave, channel per lane: the side slots in group order
+        for (int slot = 0; slot < 32; ++slot) {
+            const int r = prow[slot];
+            if (r >= 0) T[r * kLdt + tid] = fmaf(nbr_weight, part[slot * H + tid], T[r * kLdt + tid]);
         }
     }
     __syncthreads();
-    const int nl = *nlong;
-    for (int i = 0; i < nl; ++i) {
-        const int r = longrows[i], v = tile0 + r;
-        const int beg = rp_lds ? rp_lds[r] : row_ptr[v], end = rp_lds ? rp_lds[r + 1] : row_ptr[v + 1];
-        F4 acc = {0.f, 0.f, 0.f, 0.f};
-        int e = beg + gi;
-        for (; e + 48 < end; e += 64) {
-            const int u0 = col_idx[e], u1 = col_idx[e + 16], u2 = col_idx[e + 32], u3 = col_idx[e + 48];
-            const F4 f0 = feat(u0), f1 = feat(u1), f2 = feat(u2), f3 = feat(u3);
-            acc = add4(add4(acc, f0), add4(f1, add4(f2, f3)));
-        }
-        for (; e < end; e += 16) acc = add4(acc, feat(col_idx[e]));
-        st4(&part[gi * H + 4 * t], acc);
-        __syncthreads();
-        if (tid < H) {
-            float s = 0.f;
-            for (int k = 0; k < 16; ++k) s += part[k * H + tid];
-            T[r * kLdt + tid] = fmaf(nbr_weight, s, T[r * kLdt + tid]);
-        }
-        __syncthreads();
-    }
 }
 
 // ---- dropout multiplier of linears_prediction[layer](pooled)[b][ch .. ch+3] (gin.py:230):
