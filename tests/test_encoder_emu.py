@@ -62,7 +62,8 @@ def test_eval_mode_matches_oracle():
 
 
 def test_long_rows_and_ragged_tiles_match_oracle():
-    """a star-like batch: one hub row far above kLongRow, N not a multiple of the tile."""
+    """a star-like batch: the hub row's edges are split over seven lane groups of the edge-balanced gather (side slots,
+    combined in group order), rows inside a group's chunk finish there; N is not a multiple of the tile."""
     import numpy as np
 
     torch.manual_seed(3)
