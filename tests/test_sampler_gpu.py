@@ -28,13 +28,13 @@ def _oracle_views(coracle, rp, ci, seeds, L, run_seed, first, thr):
     return out
 
 
-def _check(coracle, torch, rp, ci, B, rw_hops, run_seed, first, restart_prob=0.8, seeds=None):
+def _check(coracle, torch, rp, ci, B, rw_hops, run_seed, first, restart_prob=0.8, seeds=None, **sampler_kw):
     from gcc_amd.graph import DeviceGraph
     from gcc_amd.sampler import DeviceRWRSampler
     from oracle import sampler as O
 
     g = DeviceGraph(rp, ci, rw_hops=rw_hops, restart_prob=restart_prob)
-    s = DeviceRWRSampler(g, B, run_seed=run_seed)
+    s = DeviceRWRSampler(g, B, run_seed=run_seed, **sampler_kw)
     dseeds = None if seeds is None else torch.tensor(seeds, dtype=torch.int32, device="cuda")
     q, k = s.sample(first, seeds=dseeds)
     s.check_status()
@@ -131,6 +131,24 @@ def test_full_size_g1_bit_exact_and_properties(coracle, torch_cuda):
             for b in range(0, 256, 37):                      # seed first, rest sorted ascending
                 seg = c["parent_nid"][c["node_off"][b]:c["node_off"][b + 1]]
                 assert np.all(np.diff(seg[1:]) > 0) and seg[0] not in seg[1:]
+
+
+def test_config4_like_dense_graph_bit_exact(coracle, torch_cuda):
+    """BASELINE configs[3]'s regime at a fifth of its size (2M nodes / 40M edges, average degree 40): a full batch drawn
+    as the product draws it, and a batch of hub seeds -- several consecutive virtual workgroups per induce workgroup,
+    subgraphs with > 1000 members and hundreds of units each."""
+    from gcc_amd.graphgen import powerlaw_graph
+
+    rp, ci = powerlaw_graph(2_000_000, 40_000_000, 0)
+    _check(coracle, torch_cuda, rp, ci, 256, 256, 3, 256 * 41)
+    hubs = np.argsort(np.diff(rp))[-512::8].astype(np.int32)     # 64 of the 512 largest degrees
+    # (a batch of nothing but hubs is 3x what the default scratch is sized for: the status word says so, see test_overflow_flag)
+    q, k, ref = _check(coracle, torch_cuda, rp, ci, 64, 256, 9, 0, seeds=hubs.tolist(), scratch_entries=160 << 20,
+                       edge_cap=64 << 20)
+    units = [int(((rp[m + 1] + 3) // 4 - rp[m] // 4).sum() + 255) // 256
+             for r in ref for m in (r["parent_nid"][a:b] for a, b in zip(r["node_off"][:-1], r["node_off"][1:]))]
+    assert sum((u + 15) // 16 for u in units) > 2 * 128 * 8      # > 2 virtual workgroups per induce workgroup
+    assert max(np.diff(ref[0]["node_off"])) > 1000
 
 
 def test_overflow_flag(torch_cuda):
