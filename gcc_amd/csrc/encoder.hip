@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
         GIN_TICK(2);
         // 3. GINConv aggregate: (1 + eps) * h_v + sum_{u -> v} h_u, eps = 0 (gin.py:179-185,218)
 #if !(GIN_DBG_SKIP & 4)
-        gather_tile(T, part, prow, nrows, a.col_idx, feat, a.nbr_weight, rpl);
+        gather_tile<4>(T, part, prow, nrows, a.col_idx, feat, a.nbr_weight, rpl);
 #endif
         GIN_TICK(3);
         // 4. keep agg for the weight gradient of linears.0

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_c_kernel(BwdCArgs a)
             if (tid <= nrows) rpl[tid] = a.row_ptr[tile0 + tid];      // (same round trip as the rows)
             for (int r = gi; r < kTile; r += 16) st4(&T[r * kLdt + 4 * t], r < nrows ? ident(tile0 + r) : zero4());
             __syncthreads();
-            gather_tile(T, part, prow, nrows, a.col_idx, ident, 1.0f, rpl);
+            gather_tile<8>(T, part, prow, nrows, a.col_idx, ident, 1.0f, rpl);
         }
         for (int r = gi; r < nrows; r += 16) {
             const int v = tile0 + r;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
         if (tid <= nrows) rpl[tid] = a.row_ptr[tile0 + tid];          // (same round trip as the rows)
         for (int r = gi; r < kTile; r += 16) st4(&T[r * kLdt + 4 * t], r < nrows ? ident(tile0 + r) : zero4());
         __syncthreads();
-        gather_tile(T, part, prow, nrows, a.col_idx, ident, 1.0f, rpl);
+        gather_tile<8>(T, part, prow, nrows, a.col_idx, ident, 1.0f, rpl);
         // all threads: add the pooled-path gradient and look the clamped degree up (global loads in parallel) ...
         if (tid < nrows) {
             const int deg = rpl[tid + 1] - rpl[tid];

@@ -10,7 +10,6 @@ constexpr int kTile = 64;           // rows per workgroup tile
 constexpr int kLdt = 72;            // LDS row stride in floats (conflict-free ds_read_b128 fragments)
 constexpr int kThreads = 256;
 constexpr int kGridX = 768;         // tiles are grid-strided
-constexpr int kGatherJ = 8;         // feature rows a lane group has in flight (32 VGPRs)
 constexpr int kMaxPass = 2;
 constexpr int kRep = 32;            // replicas of every atomically accumulated statistics row: a block adds to
                                     // copy (blockIdx.x % kRep), consumers sum the copies -- ~730 workgroups hitting the
@@ -302,7 +301,10 @@ __device__ __forceinline__ void finalize_stats(double *stats, double *totals, in
 // trips per tile for an average degree of 5; the gather was 49 of gin_in_kernel's 79 us).  A group sums its chunk in
 // edge order; rows that lie inside the chunk are finished there, the chunk's first and last row go to side slots that
 // one wave adds in group order afterwards -- a fixed order, so the result does not depend on timing.
-template <class Feat>
+// kGatherJ = feature rows a lane group has in flight (4 VGPRs each): 8 where the registers are there (backward kernels:
+// 19 / 34 us against 20.5 / 36.5 with 4), 4 in gin_in_kernel, whose feat() carries two BatchNorm affines (8 spills 23
+// VGPRs there: 59.5 against 53.6 us).
+template <int kGatherJ, class Feat>
 __device__ __forceinline__ void gather_tile(float *T, float *part /* [32 * H] */, int *prow /* [32] */, int nrows,
                                             const int32_t *col_idx, Feat feat, float nbr_weight,
                                             const int *rp_lds /* [nrows + 1] */)
