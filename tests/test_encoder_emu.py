@@ -89,6 +89,36 @@ def test_long_rows_and_ragged_tiles_match_oracle():
     torch.testing.assert_close(buf["feat"], ref.detach(), **TOL)
 
 
+def test_rows_without_edges_inside_a_tile_match_oracle():
+    """nodes without induced edges between rows that have some (generate.py's whole-graph batches can hold them): the
+    edge-balanced gather finds the row of an edge by searching the tile's row pointers, where such rows repeat a value."""
+    import numpy as np
+    import scipy.sparse as sp
+
+    torch.manual_seed(5)
+    n = 70                                                  # two tiles; rows 3, 4, 40 and the last one have no edges
+    iso = {3, 4, 40, n - 1}
+    keep = [i for i in range(n) if i not in iso]
+    edges = [(keep[i], keep[i + 1]) for i in range(len(keep) - 1)] + [(keep[0], k) for k in keep[2:30]]
+    e = np.array(edges)
+    a = sp.csr_matrix((np.ones(2 * len(e)), (np.r_[e[:, 0], e[:, 1]], np.r_[e[:, 1], e[:, 0]])), shape=(n, n))
+    a.sort_indices()
+    assert all(a.indptr[i] == a.indptr[i + 1] for i in iso)
+    view = dict(node_off=torch.tensor([0, 45, n]), row_ptr=torch.from_numpy(a.indptr.astype(np.int64)),
+                col_idx=torch.from_numpy(a.indices.astype(np.int64)), pos_undirected=torch.randn(n, 32))
+    oracle = E.OracleGraphEncoder()
+    model = reference_encoder()
+    model.load_state_dict(oracle.state_dict())
+    oracle.train()
+    model.train()
+    keep_mask = (torch.rand(5, 2, 64) > 0.5).float()
+    ref = oracle(view["node_off"], view["row_ptr"], view["col_idx"], view["pos_undirected"], dropout_masks=keep_mask)
+    eng = emu_engine()
+    p_, buf = eng.make_pass(model, CpuBatch(view), training=True, keep=keep_mask)
+    eng.forward([p_])
+    torch.testing.assert_close(buf["feat"], ref.detach(), **TOL)
+
+
 def test_edge_multiplicity_equals_the_doubled_multigraph():
     """NodeClassificationDataset (graph_dataset.py:296-304 on top of data_util.py:84-85) hands the encoder a graph in
     which every edge exists twice: in-degrees and neighbour sums double.  edge_multiplicity = 2 on the simple CSR
