@@ -1,7 +1,7 @@
 """SURVEY.md section 8(d) baseline (i): the reference's data pipeline the way the reference runs it -- a Python loop per
 sample mirroring graph_dataset.py:94-179 call for call, in DataLoader-style worker processes -- timed on the host cores.
 
-    python tools/cpu_baseline_reference_shaped.py [--nodes 1000000 --edges 10000000] [--samples 256] [--procs 1,8]
+    python tests/tools/cpu_baseline_reference_shaped.py [--nodes 1000000 --edges 10000000] [--samples 256] [--procs 1,8]
 
 Per sample (both views, graph_dataset.py:104-106): seed drawn from deg^0.75 (:85-92); max_nodes_per_seed (:113-124);
 the walker -- DGL's C++ random_walk_with_restart in the reference, here the C helper of oracle/sampler_oracle.c called
@@ -21,7 +21,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 _G = {}

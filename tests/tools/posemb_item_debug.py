@@ -1,12 +1,12 @@
 """Device-side trace of one ego-net through the direct solver (a libgcc_amd.so built with -DGCC_POSEMB_DEVDEBUG prints the
-Gram-Schmidt sweeps).  python tools/posemb_item_debug.py tests/golden/posemb_item_s4_v1_b126.npz <seed>"""
+Gram-Schmidt sweeps).  python tests/tools/posemb_item_debug.py tests/golden/posemb_item_s4_v1_b126.npz <seed>"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gcc_amd.posemb import DevicePosEmb
 from gcc_amd.sampler import BatchedCSR
 from oracle import posemb as P
