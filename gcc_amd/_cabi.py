@@ -181,8 +181,9 @@ SIGNATURES = {
                                            ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_adam_step": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                       ctypes.c_float, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
-                                       ctypes.c_void_p]),
+                                       ctypes.c_float, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_step_meters": (ctypes.c_int32, [ctypes.c_void_p] * 8 + [ctypes.c_int32, ctypes.c_void_p]),
     "gcc_ema_update": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,
                                         ctypes.c_void_p]),
 }

@@ -87,13 +87,20 @@ class NceEngine:
         return saved
 
     def adam(self, param, grad, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, step, max_norm, grad_norm,
-             scratch, stream=None):
+             scratch, stream=None, grad_scale=1.0):
         rc = self.lib.gcc_adam_step(self.ptr(param), self.ptr(grad), self.ptr(exp_avg), self.ptr(exp_avg_sq),
                                     param.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
-                                    float(weight_decay), int(step), float(max_norm), self.ptr(grad_norm),
+                                    float(weight_decay), int(step), float(max_norm), float(grad_scale), self.ptr(grad_norm),
                                     self.ptr(scratch), stream)
         if rc != 0:
             raise RuntimeError(f"gcc_adam_step failed ({rc}): {self.lib.gcc_last_error().decode()}")
+
+    def meters(self, acc, mx, loss, prob, grad_norm, q, k, stream=None):
+        rc = self.lib.gcc_step_meters(self.ptr(acc), self.ptr(mx), self.ptr(loss), self.ptr(prob), self.ptr(grad_norm),
+                                      self.ptr(q.node_off), self.ptr(q.edge_off), self.ptr(k.node_off),
+                                      int(q.batch_size), stream)
+        if rc != 0:
+            raise RuntimeError(f"gcc_step_meters failed ({rc}): {self.lib.gcc_last_error().decode()}")
 
     def ema(self, ema, p, m, stream=None):
         rc = self.lib.gcc_ema_update(self.ptr(ema), self.ptr(p), ema.numel(), float(m), stream)

@@ -21,8 +21,9 @@
 //     one node (16-byte stores), and with a K permutation so that A/B fragments
 //     are plain 16-byte row loads.
 //   * node tiles (64 rows per workgroup, grid-strided because N lives on the
-//     device); rows longer than kLongRow neighbours are gathered cooperatively
-//     by the whole workgroup so that hub rows do not serialise one wave.
+//     device); the gather splits a tile's EDGES (not its rows) evenly over the
+//     workgroup's 16 lane groups, so hub rows do not serialise one wave
+//     (encoder_common.h: gather_tile).
 //   * several passes (query with model, key with model_ema) share each launch
 //     (blockIdx.y = pass).
 #include "encoder_common.h"

@@ -363,17 +363,19 @@ __global__ __launch_bounds__(kThreads) void gradnorm_kernel(const float *g, int6
 
 __global__ __launch_bounds__(kThreads) void adam_kernel(float *p, float *g, float *m, float *v, int64_t n, float lr,
                                                         float b1, float b2, float eps, float wd, float bc1,
-                                                        float bc2_sqrt, float max_norm, const double *sumsq,
-                                                        float *grad_norm)
+                                                        float bc2_sqrt, float max_norm, float grad_scale,
+                                                        const double *sumsq, float *grad_norm)
 {
     TRAIN_STEP_WAVE_PRIORITY();
-    const float norm = (float)sqrt(sumsq[0]);
+    // grad_scale: the 1 / world of a summed (all-reduced) gradient, folded in here instead of a launch of its own
+    const float norm = grad_scale * (float)sqrt(sumsq[0]);
     float coef = 1.f;
     if (max_norm > 0.f) {                                      // torch.nn.utils.clip_grad_norm_
         coef = max_norm / (norm + 1e-6f);
         coef = coef > 1.f ? 1.f : coef;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) grad_norm[0] = norm;
+    coef *= grad_scale;
     const int64_t stride = (int64_t)gridDim.x * kThreads;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
         const float gc = g[i] * coef;
@@ -386,6 +388,23 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(float *p, float *g, floa
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         p[i] -= (lr / bc1) * (mi / denom);
     }
+}
+
+// ---- per-step meters of train.py:418-428 (loss / prob / gnorm / graph sizes) accumulated on the device: one thread
+__global__ void step_meters_kernel(double *acc, int32_t *mx, const float *loss, const float *prob, const float *gnorm,
+                                   const int32_t *node_off_q, const int32_t *edge_off_q, const int32_t *node_off_k,
+                                   int32_t B)
+{
+    TRAIN_STEP_WAVE_PRIORITY();
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int32_t nq = node_off_q[B], nk = node_off_k[B], eq = edge_off_q[B];
+    acc[0] += (double)loss[0];
+    acc[1] += (double)prob[0];
+    acc[2] += (double)gnorm[0];
+    acc[3] += (double)nq + (double)nk;
+    acc[4] += 1.0;
+    mx[0] = nq > mx[0] ? nq : mx[0];
+    mx[1] = eq > mx[1] ? eq : mx[1];
 }
 
 inline int fill_dev(const gcc_nce_args *a, void *workspace, int64_t workspace_bytes, NceDev &d, Plan &pl)
@@ -478,9 +497,9 @@ int32_t gcc_queue_enqueue(float *mem, int32_t K, const float *keys, int32_t nkey
 
 int32_t gcc_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
-                      float *grad_norm, double *scratch, void *stream)
+                      float grad_scale, float *grad_norm, double *scratch, void *stream)
 {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || !grad_norm || !scratch || n < 1 || step < 1) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !grad_norm || !scratch || n < 1 || step < 1 || !(grad_scale > 0.f)) {
         snprintf(g_err, kErrLen, "gcc_adam_step: bad argument");
         return -1;
     }
@@ -491,7 +510,20 @@ int32_t gcc_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_
     int blocks = (int)((n + kThreads - 1) / kThreads);
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(kThreads), 0, s, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                       beta2, eps, weight_decay, bc1, bc2_sqrt, max_norm, (const double *)scratch, grad_norm);
+                       beta2, eps, weight_decay, bc1, bc2_sqrt, max_norm, grad_scale, (const double *)scratch, grad_norm);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
+int32_t gcc_step_meters(double *acc, int32_t *mx, const float *loss, const float *prob, const float *grad_norm,
+                        const int32_t *node_off_q, const int32_t *edge_off_q, const int32_t *node_off_k,
+                        int32_t batch_size, void *stream)
+{
+    if (!acc || !mx || !loss || !prob || !grad_norm || !node_off_q || !edge_off_q || !node_off_k || batch_size < 1) {
+        snprintf(g_err, kErrLen, "gcc_step_meters: bad argument");
+        return -1;
+    }
+    hipLaunchKernelGGL(step_meters_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, mx, loss, prob, grad_norm,
+                       node_off_q, edge_off_q, node_off_k, batch_size);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 

@@ -111,6 +111,7 @@ __device__ __forceinline__ void item_args(const PosMulti &m, int item, PosArgs &
 // one fat workgroup per subgraph that exits early when the class does not match keeps the workgroup dispatcher
 // busy placing 160-KiB-LDS / 1024-thread workgroups that do nothing, which delays every other queue.)
 enum { kClsSmall = 0, kClsMid = 1, kClsSlot = 2, kClsKrylov = 3, kClsBig = 4, kClsCheb = 5, kNumCls = 6 };
+static_assert(kNumCls == GCC_POSEMB_TICK_CLASSES, "include/gcc_amd.h: tick buffer classes");
 struct PosHead {                     // head of the caller's workspace (zeroed per call)
     int32_t *count;                  // [4] items per class
     int32_t *next;                   // [4] work counters
@@ -2267,7 +2268,7 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     return 0;
 }
 
-void gcc_posemb_debug_ticks(long long *device_ticks64)   /* device int64[4 * 16] or NULL; diagnostics only */
+void gcc_posemb_debug_ticks(long long *device_ticks64)   /* device int64[GCC_POSEMB_TICK_CLASSES][16] or NULL; diagnostics only */
 {
     g_posemb_ticks = device_ticks64;
 }

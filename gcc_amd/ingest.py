@@ -241,12 +241,21 @@ def read_dgl_graphs(path: str, idx_list=None, validate: bool = True):
             raise ValueError(f"{path}: graph {i} does not fit int32 ids")
         rp, ci = indptr.astype(np.int32), indices.astype(np.int32)
         if validate:
-            order_ok = all(np.all(np.diff(ci[rp[v]:rp[v + 1]]) > 0) for v in range(min(len(rp) - 1, 1000)))
-            if not order_ok:                               # DGL does not promise sorted rows; the sampler does
-                order = np.lexsort((ci, np.repeat(np.arange(len(rp) - 1), np.diff(rp))))
-                ci = ci[order]
+            # DGL does not promise sorted rows (an in-CSR materialised from COO input keeps insertion order and carries a
+            # permutation in edge_ids); the sampler does.  One vectorised pass over ALL rows: a descent is only allowed
+            # where a new row starts.
+            if len(ci) > 1:
+                descent = np.flatnonzero(np.diff(ci.astype(np.int64)) <= 0) + 1       # positions whose predecessor is >= them
+                starts = np.zeros(len(ci) + 1, dtype=bool)
+                starts[rp[:-1]] = True
+                if not np.all(starts[descent]):
+                    order = np.lexsort((ci, np.repeat(np.arange(len(rp) - 1), np.diff(rp))))
+                    ci = ci[order]
             check_contract(rp, ci)
         graphs.append((rp, ci))
+    if idx_list is None and "graph_sizes" in labels and len(labels["graph_sizes"]) != len(graphs):
+        raise ValueError(f"{path}: label graph_sizes has {len(labels['graph_sizes'])} entries for {len(graphs)} graphs "
+                         "(x2dgl.py:120,129-131 writes one node count per graph)")
     return graphs, labels
 
 

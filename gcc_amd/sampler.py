@@ -127,9 +127,13 @@ class DeviceRWRSampler:
         B = self.batch_size
         self.node_cap = B * (graph.lmax + 1)
         self.edge_cap = int(edge_cap) if edge_cap else max(64 * B * (graph.rw_hops + 1), 2 * (graph.lmax + 1) ** 2)
-        # induction scratch: sum over subgraphs of sum_i min(deg_i, n) <= sum n^2.  A walk visits nodes in proportion to
-        # their degree, so a view scans about n * (size-biased mean degree) parent edges per subgraph (n ~ rw_hops / 2.5);
-        # sized 3x that for both views (HBM is 288 GB) and guarded by the device status word
+        # induction scratch (hit slots): induce_kernel reserves one 1024-entry slot per unit of 256 aligned quads of
+        # the members' parent rows, i.e. ~ the SUM OF THE MEMBERS' PARENT DEGREES per subgraph (not min(deg, n) as the
+        # first induction did) -- unbounded by n: a hub-only batch needs several times the average.  A walk visits nodes
+        # in proportion to their degree, so a view scans about n * (size-biased mean degree) parent edges per subgraph
+        # (n ~ rw_hops / 2.5); sized 3x that for both views (HBM is 288 GB).  An overflow never writes out of bounds: it
+        # sets bit 0 of the device status word and leaves a truncated subgraph, which check_status() turns into an error
+        # (train.py polls it at every log line, bench.py after the timed region).
         expected = int(3 * 2 * B * (graph.rw_hops / 2.5) * getattr(graph, "sb_degree", 0.0))
         self.scratch_entries = int(scratch_entries) if scratch_entries else max(
             32 << 20, 512 * B * (graph.rw_hops + 1), 8 * (graph.lmax + 1) ** 2, expected)

@@ -161,6 +161,20 @@ class BatchProducer:
                 self.released[c] = ev
 
 
+def _meter_buffers(dev):
+    """(acc double[5]: sums of loss, prob, gnorm, nodes(q + k), steps; mx int32[2]: max nodes / edges of a q view)
+    -- gcc_step_meters adds one step; :func:`read_meters` reads and zeroes them when a log line is due."""
+    return torch.zeros(5, dtype=torch.float64, device=dev), torch.zeros(2, dtype=torch.int32, device=dev)
+
+
+def read_meters(trainer):
+    """-> (acc list[5], mx list[2]); synchronises (call once per log line, train.py:418-460)."""
+    a, m = trainer.meter_acc.tolist(), trainer.meter_max.tolist()
+    trainer.meter_acc.zero_()
+    trainer.meter_max.zero_()
+    return a, m
+
+
 class FlatAdam:
     """clip_grad_norm_ + torch.optim.Adam(lr, betas, eps=1e-8, weight_decay) (train.py:409,667-672) over one flat
     parameter buffer, as two HIP launches (gcc_adam_step).  ``param_groups`` / ``state_dict`` keep the shape
@@ -176,12 +190,14 @@ class FlatAdam:
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=param.device)
         self._scratch = torch.zeros(64, dtype=torch.float64, device=param.device)
 
-    def step(self):
+    def step(self, grad_scale=1.0):
+        """``grad_scale``: 1 / world when ``grad`` holds the SUM over ranks (folded into the two launches)."""
         g = self.param_groups[0]
         self.steps += 1
         st = torch.cuda.current_stream(self.param.device).cuda_stream if self.param.is_cuda else None
         self.engine.adam(self.param, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"], g["eps"],
-                         g["weight_decay"], self.steps, self.clip_norm, self.grad_norm, self._scratch, stream=st)
+                         g["weight_decay"], self.steps, self.clip_norm, self.grad_norm, self._scratch, stream=st,
+                         grad_scale=grad_scale)
         return self.grad_norm
 
     def zero_grad(self):
@@ -231,6 +247,7 @@ class MoCoTrainStep:
         self.L = len(model.gnn.ginlayers)
         self.keys_all = torch.empty(self.B * world_size, H, device=self.dev) if self.collectives else None
         self.one = torch.ones(1, device=self.dev)
+        self.meter_acc, self.meter_max = _meter_buffers(self.dev)
         self.prefetch = prefetch and self.dev.type == "cuda"
         # the ~75 short training kernels of a step must not queue behind the producers' millisecond-long
         # eigensolver workgroups: the step runs on a high-priority stream
@@ -256,13 +273,25 @@ class MoCoTrainStep:
         edge capacity) and refused positional embeddings raise -- the pack kernel leaves a valid but truncated
         subgraph behind and the eigensolver zeros, so training on them would be silent otherwise.  Returns the OR of
         the positional-embedding flag words (bit 8 = an eigen-iteration stopped at its restart cap)."""
-        flags = 0
+        flags, err = 0, None
         for lane in self.producer.lanes:
             smp, pe = lane[0], lane[1]
-            if hasattr(smp, "check_status"):
-                smp.check_status()
-            if hasattr(pe, "check_status"):
-                flags |= int(pe.check_status(strict=strict_posemb) or 0)
+            try:
+                if hasattr(smp, "check_status"):
+                    smp.check_status()
+                if hasattr(pe, "check_status"):
+                    flags |= int(pe.check_status(strict=strict_posemb) or 0)
+            except RuntimeError as e:           # keep going: every rank must reach the agreement below
+                err = err or e
+        if self.collectives and torch.distributed.is_initialized():
+            # a rank that raised alone would leave the others waiting in their next collective
+            t = torch.tensor([1 if err is not None else 0, flags], dtype=torch.int64,
+                             device="cpu" if self._staged() or self.dev.type != "cuda" else self.dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            if err is None and int(t[0]):
+                err = RuntimeError("another rank reported a sampler / positional-embedding overflow (see its log)")
+        if err is not None:
+            raise err
         return flags
 
     # collectives: RCCL on device buffers.  Only when several ranks share one device (bench.py --gpus N on a box with
@@ -270,13 +299,23 @@ class MoCoTrainStep:
     def _staged(self):
         return self.dev.type == "cuda" and torch.distributed.get_backend() == "gloo"
 
-    def _all_gather(self, out, x):
+    def _all_gather_begin(self, out, x):
+        """Key all-gather issued right after the encoder forward: RCCL runs it on its own stream (after the
+        work queued on the current one so far); nothing on the training stream waits for it until
+        :meth:`_all_gather_end`, just before the enqueue -- the InfoNCE forward / backward and the whole encoder
+        backward do not need ``keys_all`` (they read the queue as it was before the enqueue)."""
         if self._staged():
+            return ("staged", out, x)
+        return ("rccl", torch.distributed.all_gather_into_tensor(out, x, async_op=True))
+
+    def _all_gather_end(self, pending):
+        if pending[0] == "staged":
+            _, out, x = pending
             o, xi = out.cpu(), x.cpu()
             torch.distributed.all_gather_into_tensor(o, xi)
             out.copy_(o)
         else:
-            torch.distributed.all_gather_into_tensor(out, x)
+            pending[1].wait()                   # the current stream waits for RCCL's stream; the host does not
 
     def _all_reduce(self, x):
         if self._staged():
@@ -310,23 +349,102 @@ class MoCoTrainStep:
         self.gin.forward([pq, pk], stream=st, prof=pr.get("gin_fwd"))      # train.py:389-391
         feat_q, feat_k = bufq["feat"], bufk["feat"]
         c = self.contrast
+        gathering = self._all_gather_begin(self.keys_all, feat_k) if self.collectives else None   # RCCL, overlapped
         outs = self.nce.forward(feat_q, feat_k, c.memory, c.T, 0, stream=st, prof=pr.get("nce_fwd"))   # train.py:393,407
-        keys = feat_k
-        if self.collectives:                                             # RCCL all-gather of keys over xGMI
-            self._all_gather(self.keys_all, feat_k)
-            keys = self.keys_all
-        index = c.index
-        saved = self.nce.enqueue(c.memory, keys, index, save=True, stream=st)
-        c.index = (index + keys.shape[0]) % c.queueSize
-        dq = self.nce.backward(feat_q, feat_k, c.memory, c.T, 0, outs, self.one, patch=saved, patch_index=index,
-                               stream=st, prof=pr.get("nce_bwd"))         # loss.backward(), train.py:408
+        # The enqueue (memory_moco.py:55-61) is the LAST thing the step does with the queue: logits and their backward
+        # are taken against the queue before the update (the reference clones it, memory_moco.py:31), so deferring the
+        # update is the same computation -- and it takes the key all-gather off the critical chain.
+        dq = self.nce.backward(feat_q, feat_k, c.memory, c.T, 0, outs, self.one, stream=st,
+                               prof=pr.get("nce_bwd"))                    # loss.backward(), train.py:408
         self.gin.backward(self.model, pq, bufq, dq, targets=self.grad_views, stream=st, prof=pr.get("gin_bwd"))
         if self.collectives:
-            self._all_reduce(self.flat_grad)                             # one flat bucket (248 KiB) over xGMI
-            self.flat_grad.mul_(1.0 / self.world)
+            self._all_reduce(self.flat_grad)                             # SUM of one flat bucket (248 KiB) over xGMI
+        for grp in self.optimizer.param_groups:                          # train.py:411-416
+            grp["lr"] = lr
+        # clip (train.py:409) + Adam (train.py:417); the mean over ranks is folded into the two launches
+        gnorm = self.optimizer.step(grad_scale=1.0 / self.world if self.collectives else 1.0)
+        moment_update(self.model, self.ema, self.alpha, engine=self.nce)  # train.py:430-431
+        keys = feat_k
+        if self.collectives:
+            self._all_gather_end(gathering)
+            keys = self.keys_all
+        self.nce.enqueue(c.memory, keys, c.index, save=False, stream=st)
+        c.index = (c.index + keys.shape[0]) % c.queueSize
+        # train.py:418-428's meters, on the device and BEFORE the ring slot of this batch is handed back
+        self.nce.meters(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], gnorm, q, k, stream=st)
+        self.producer.release(step)
+        return dict(loss=outs["loss"], prob=outs["prob"], grad_norm=gnorm, graph_q=q, graph_k=k)
+
+
+class E2ETrainStep:
+    """The E2E / in-batch-negatives step of train.py:396-417 (``--nce-k = batch_size - 1`` without ``--moco``,
+    BASELINE configs[0]) as a fixed sequence of launches: both views go through ``model`` (two forward launch sets,
+    one after the other, so that the BatchNorm running statistics are updated in the reference's order),
+    ``out = feat_k feat_q^T / T`` with labels on the diagonal (``NCESoftmaxLossNS``, criterions.py:20-33), gradients of
+    both passes accumulated into one flat buffer, clip + Adam as two launches.  Same producer pipeline as
+    :class:`MoCoTrainStep`; single GPU (the reference has no data-parallel E2E mode)."""
+
+    def __init__(self, model: GraphEncoder, sampler, posemb, nce_t=0.07, learning_rate=0.005, betas=(0.9, 0.999),
+                 weight_decay=1e-5, clip_norm=1.0, prefetch=True, depth=2, lanes=None, chunk=1, ahead=None, engine=None):
+        self.model = model
+        self.sampler, self.posemb = sampler, posemb
+        self.T, self.clip_norm = nce_t, clip_norm
+        self.world, self.rank, self.collectives = 1, 0, False
+        self.dev = next(model.parameters()).device
+        self.flat, self.n_live = flatten_parameters(model)
+        self.flat_grad = torch.zeros(self.n_live, dtype=torch.float32, device=self.dev)
+        self.grad_views, off = [], 0
+        for _, _, p in grad_params(model):
+            self.grad_views.append(self.flat_grad[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.live = self.flat[: self.n_live]
+        self.gin = model.engine()
+        self.nce = engine if engine is not None else NceEngine()
+        self.optimizer = FlatAdam(self.live, self.flat_grad, learning_rate, betas, weight_decay, clip_norm, self.nce)
+        self.mask_fn = None          # tests: () -> (keep_q, keep_k); default = in-kernel Philox
+        self.dropout_seed = 0x5EED0000
+        self.B = sampler.batch_size
+        self.one = torch.ones(1, device=self.dev)
+        self.meter_acc, self.meter_max = _meter_buffers(self.dev)
+        self.prefetch = prefetch and self.dev.type == "cuda"
+        self.main = torch.cuda.Stream(self.dev, priority=-1) if self.prefetch else None
+        lanes = list(lanes) if lanes is not None else [(sampler, posemb)]
+        self.producer = BatchProducer(lanes if self.prefetch else lanes[:1], self._first_id,
+                                      self.dev if self.prefetch else "cpu", depth=depth if self.prefetch else 1,
+                                      chunk=chunk if self.prefetch else 1, ahead=ahead)
+        if not self.prefetch:
+            self.producer.cuda = False
+        model.train()
+
+    def _first_id(self, step):
+        return step * self.B
+
+    _staged = MoCoTrainStep._staged
+    check_status = MoCoTrainStep.check_status
+    step = MoCoTrainStep.step
+
+    def _step(self, step, lr, prof=None):
+        pr = prof or {}
+        q, k = self.producer.get(step, prof=prof)
+        st = torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else None
+        p_drop = self.model.gnn.drop.p
+        keep_q, keep_k = self.mask_fn() if self.mask_fn is not None else (None, None)
+        s0 = (self.dropout_seed + 2 * step * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF if p_drop > 0 else None
+        s1 = (s0 + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF if s0 is not None else None
+        pq, bufq = self.gin.make_pass(self.model, q, training=True, keep=keep_q, slot=("e2e", 0), dropout_seed=s0)
+        pk, bufk = self.gin.make_pass(self.model, k, training=True, keep=keep_k, slot=("e2e", 1), dropout_seed=s1)
+        self.gin.forward([pq], stream=st, prof=pr.get("gin_fwd"))          # feat_q = model(graph_q), train.py:397
+        self.gin.forward([pk], stream=st)                                  # feat_k = model(graph_k), train.py:398
+        feat_q, feat_k = bufq["feat"], bufk["feat"]
+        # out = feat_k feat_q^T / T, CE against arange (train.py:400, criterions.py:27-33): rows = feat_k
+        outs = self.nce.forward(feat_k, None, feat_q, self.T, 1, stream=st, prof=pr.get("nce_fwd"))
+        dk = self.nce.backward(feat_k, None, feat_q, self.T, 1, outs, self.one, stream=st, prof=pr.get("nce_bwd"))
+        dq = self.nce.backward(feat_q, None, feat_k, self.T, 1, outs, self.one, by_mem_row=True, stream=st)
+        self.gin.backward(self.model, pq, bufq, dq, targets=self.grad_views, stream=st, prof=pr.get("gin_bwd"))
+        self.gin.backward(self.model, pk, bufk, dk, targets=self.grad_views, accumulate=True, stream=st)
         for grp in self.optimizer.param_groups:                          # train.py:411-416
             grp["lr"] = lr
         gnorm = self.optimizer.step()                                    # clip (train.py:409) + Adam (train.py:417)
-        moment_update(self.model, self.ema, self.alpha, engine=self.nce)  # train.py:430-431
+        self.nce.meters(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], gnorm, q, k, stream=st)
         self.producer.release(step)
         return dict(loss=outs["loss"], prob=outs["prob"], grad_norm=gnorm, graph_q=q, graph_k=k)

@@ -169,8 +169,10 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
                          gcc_prof *prof, void *stream);
 
 /* diagnostics: subsequent gcc_posemb* calls add wall-clock ticks (100 MHz) per solver class and phase into
- * device int64[5][16] (classes small, mid, slot, Krylov, big; phases 0..6 = matrix, tridiagonalise, bisect, inverse iteration, Gram-Schmidt,
- * back-transform, expand; [15] = items); NULL switches it off. */
+ * device int64[GCC_POSEMB_TICK_CLASSES][16] -- SIX classes: small, mid, slot, Krylov, big, sparse block (Chebyshev);
+ * phases of the dense classes 0..6 = matrix, tridiagonalise, bisect, inverse iteration, Gram-Schmidt, back-transform,
+ * expand; [15] = items; NULL switches it off.  A buffer sized for fewer classes is written out of bounds. */
+#define GCC_POSEMB_TICK_CLASSES 6
 void gcc_posemb_debug_ticks(long long *device_ticks64);
 /* the same for gin_in_kernel: device int64[2][16] ([0] = first layer, [1] = others; [15] = tiles) */
 void gcc_gin_debug_ticks(long long *device_ticks64);
@@ -349,10 +351,20 @@ int32_t gcc_queue_enqueue(float *mem, int32_t K, const float *keys, int32_t nkey
 /* clip_grad_norm_(max_norm) + Adam.step() of train.py:409,417 over one flat buffer (torch.optim.Adam
  * semantics: L2 weight decay added to the gradient, bias correction with `step` >= 1, eps outside the
  * sqrt).  grad_norm: device [1] out (the pre-clip norm); max_norm <= 0 disables clipping.
+ * grad_scale > 0 multiplies the gradient first (1 / world for a gradient that was SUMMED over ranks:
+ * norm, clipping and the stored clipped gradient all see grad * grad_scale); 1 on a single GPU.
  * scratch: device double[64], zeroed once by the caller (partial sums and an arrival counter that resets itself). */
 int32_t gcc_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
-                      float *grad_norm, double *scratch, void *stream);
+                      float grad_scale, float *grad_norm, double *scratch, void *stream);
+
+/* The meters train.py:418-428 updates every step (loss, prob, gnorm, graph size; max nodes / edges of a q view),
+ * accumulated on the device so that a step never synchronises with the host (the reference does, train.py:433):
+ * acc: device double[5] += {loss, prob, grad_norm, nodes(q) + nodes(k), 1}; mx: device int32[2] = max with
+ * {nodes(q), edges(q)}.  The caller reads and zeroes them when a log line is due. */
+int32_t gcc_step_meters(double *acc, int32_t *mx, const float *loss, const float *prob, const float *grad_norm,
+                        const int32_t *node_off_q, const int32_t *edge_off_q, const int32_t *node_off_k,
+                        int32_t batch_size, void *stream);
 
 /* moment_update of train.py:169-172 over one flat parameter buffer: ema = m * ema + (1 - m) * p */
 int32_t gcc_ema_update(float *ema, const float *p, int64_t n, float m, void *stream);

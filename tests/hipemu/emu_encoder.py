@@ -17,6 +17,7 @@ class CpuBatch:
         self.row_ptr = torch.zeros(cap + 1, dtype=torch.int32)
         self.row_ptr[: n + 1] = view["row_ptr"].to(torch.int32)
         self.col_idx = view["col_idx"].to(torch.int32).contiguous()
+        self.edge_off = view["row_ptr"].to(torch.int32)[view["node_off"].long()].contiguous()   # dgl.batch edge offsets
         self.graph_id = torch.zeros(cap, dtype=torch.int32)
         self.graph_id[:n] = torch.repeat_interleave(torch.arange(self.batch_size, dtype=torch.int32),
                                                     (view["node_off"][1:] - view["node_off"][:-1]))

@@ -111,3 +111,23 @@ def test_load_balance_dataset_attributes_and_iteration(tmp_path, monkeypatch):
     assert S.worker_init_fn(0) is None
     with pytest.raises(NotImplementedError):
         S.LoadBalanceGraphDataset(dgl_graphs_file=str(f), aug="ns")
+
+
+def test_rows_unsorted_far_into_the_file_are_sorted_and_label_count_is_checked(tmp_path):
+    """DGL does not promise sorted rows: a file whose only unsorted rows come after the first thousand is sorted (every
+    row is looked at), not refused; a graph_sizes label of the wrong length is refused."""
+    rp, ci = powerlaw_graph(4000, 30000, 4)
+    shuffled = ci.copy()
+    rng = np.random.default_rng(0)
+    for v in range(3000, 4000):                                  # only late rows lose their order
+        seg = shuffled[rp[v]:rp[v + 1]]
+        if len(seg) > 1:
+            seg[:] = seg[::-1] if np.all(np.diff(seg) > 0) else rng.permutation(seg)
+    assert not np.array_equal(shuffled, ci)
+    f = tmp_path / "late.bin"
+    ingest.write_dgl_graphs(str(f), [(rp, shuffled)], labels={"graph_sizes": np.array([len(rp) - 1])})
+    graphs, _ = ingest.read_dgl_graphs(str(f))
+    assert np.array_equal(graphs[0][0], rp) and np.array_equal(graphs[0][1], ci)
+    ingest.write_dgl_graphs(str(f), [(rp, ci)], labels={"graph_sizes": np.array([len(rp) - 1, 7])})
+    with pytest.raises(ValueError, match="graph_sizes"):
+        ingest.read_dgl_graphs(str(f))

@@ -17,7 +17,7 @@ TOL = dict(rtol=1e-4, atol=2e-5)
 
 def gpu_batch(view, node_cap=None):
     b = CpuBatch(view, node_cap)
-    for name in ("node_off", "row_ptr", "col_idx", "graph_id", "parent_nid", "pos_undirected"):
+    for name in ("node_off", "edge_off", "row_ptr", "col_idx", "graph_id", "parent_nid", "pos_undirected"):
         setattr(b, name, getattr(b, name).cuda())
     return b
 

@@ -29,7 +29,7 @@ from gcc_amd.contrast import MemoryMoCo, NCESoftmaxLoss, NCESoftmaxLossNS, e2e_l
 from gcc_amd.encoder import GraphEncoder
 from gcc_amd.misc import AverageMeter, adjust_learning_rate, warmup_linear
 from gcc_amd.sampler import LoadBalanceGraphDataset
-from gcc_amd.train_step import MoCoTrainStep, clip_grad_norm, flatten_parameters, moment_update
+from gcc_amd.train_step import E2ETrainStep, MoCoTrainStep, clip_grad_norm, flatten_parameters, moment_update, read_meters
 
 GRAPH_CLASSIFICATION_DSETS = ["collab", "imdb-binary", "imdb-multi", "rdt-b", "rdt-5k"]
 
@@ -189,7 +189,8 @@ def train_moco(epoch, dataset, trainer, model, model_ema, contrast, criterion, o
     end = time.time()
     it = None if trainer is not None else iter(dataset)
     # every step's loss / prob / gnorm / graph sizes are accumulated ON THE DEVICE (no host sync) and read back when
-    # a log line is due, so the meters cover all steps like the reference's (which synchronises every step, :433)
+    # a log line is due, so the meters cover all steps like the reference's (which synchronises every step, :433).
+    # Fused steps do it inside the step, before the batch's ring slot is released (gcc_step_meters).
     dev = next(model.parameters()).device
     acc = torch.zeros(6, dtype=torch.float64, device=dev)      # sums: loss, prob, gnorm, nodes(q+k), steps; [5] unused
     mx = torch.zeros(2, dtype=torch.int32, device=dev)         # max nodes, max edges of a q view
@@ -198,38 +199,46 @@ def train_moco(epoch, dataset, trainer, model, model_ema, contrast, criterion, o
         global_step = epoch * n_batch + idx
         lr_this_step = opt.learning_rate * warmup_linear(global_step / (opt.epochs * n_batch), 0.1)   # :411-414
         bsz = opt.batch_size
-        if trainer is not None:                          # MoCo: fused step (train.py:387-431)
-            out = trainer.step((epoch - 1) * n_batch + idx, lr_this_step)
-            loss, prob, grad_norm = out["loss"], out["prob"], out["grad_norm"]
-            graph_q, graph_k = out["graph_q"], out["graph_k"]
-        else:                                            # E2E / negative sampling (train.py:396-401)
+        if trainer is not None:                          # fused step: MoCo (train.py:387-431) or E2E (:396-417)
+            trainer.step((epoch - 1) * n_batch + idx, lr_this_step)
+        else:                                            # API path (autograd + a torch optimizer): --optimizer sgd / adagrad
             graph_q, graph_k = next(it)
             posemb(graph_q)
             posemb(graph_k)
             data_time.update(time.time() - end)
             feat_q = model(graph_q)
-            feat_k = model(graph_k)
-            out = e2e_logits(feat_q, feat_k, opt.nce_t)
+            if opt.moco:                                 # train.py:388-394
+                with torch.no_grad():
+                    feat_k = model_ema(graph_k)
+                out = contrast(feat_q, feat_k)
+            else:                                        # train.py:396-401
+                feat_k = model(graph_k)
+                out = e2e_logits(feat_q, feat_k, opt.nce_t)
             prob = out.prob
             optimizer.zero_grad()
             loss = criterion(out)
             loss.backward()
-            grad_norm = clip_grad_norm(model.parameters(), opt.clip_norm)
+            grad_norm = clip_grad_norm(list(model.parameters()), opt.clip_norm)
             for param_group in optimizer.param_groups:
                 param_group["lr"] = lr_this_step
             optimizer.step()
-        B_ = graph_q.batch_size
-        nodes_qk = (graph_q.node_off[B_] + graph_k.node_off[B_]).to(torch.float64).reshape(1)
-        acc[:5] += torch.cat([loss.detach().reshape(1).double(), prob.detach().reshape(1).double(),
-                              torch.as_tensor(grad_norm, device=dev).detach().reshape(1).double(), nodes_qk, one])
-        mx.copy_(torch.maximum(mx, torch.stack([graph_q.node_off[B_], graph_q.edge_off[B_]])))
+            if opt.moco:
+                moment_update(model, model_ema, opt.alpha)   # train.py:430-431
+            B_ = graph_q.batch_size
+            nodes_qk = (graph_q.node_off[B_] + graph_k.node_off[B_]).to(torch.float64).reshape(1)
+            acc[:5] += torch.cat([loss.detach().reshape(1).double(), prob.detach().reshape(1).double(),
+                                  torch.as_tensor(grad_norm, device=dev).detach().reshape(1).double(), nodes_qk, one])
+            mx.copy_(torch.maximum(mx, torch.stack([graph_q.node_off[B_], graph_q.edge_off[B_]])))
         want_log = (idx + 1) % opt.print_freq == 0 or (idx + 1) % opt.tb_freq == 0 or idx + 1 == n_batch \
             or (opt.max_steps and (epoch - 1) * n_batch + idx + 1 >= opt.max_steps)
         if want_log:                                     # one read-back per log line
-            a = acc.tolist()
-            m = mx.tolist()
-            acc.zero_()
-            mx.zero_()
+            if trainer is not None:
+                a, m = read_meters(trainer)
+                trainer.check_status()                   # overflow / refusal flags: never train on for an epoch unseen
+            else:
+                a, m = acc.tolist(), mx.tolist()
+                acc.zero_()
+                mx.zero_()
             cnt = max(int(a[4]), 1)
             loss_meter.update(a[0] / cnt, bsz * cnt)
             epoch_loss_meter.update(a[0] / cnt, bsz * cnt)
@@ -324,17 +333,14 @@ def main(args):
     contrast = MemoryMoCo(args.hidden_size, None, args.nce_k, args.nce_t, use_softmax=True,
                           nce_dtype=getattr(args, "nce_dtype", "f32")).to(dev)                                # :627-629
     criterion = NCESoftmaxLoss() if args.moco else NCESoftmaxLossNS()                                 # :634
-    if args.optimizer != "adam":
-        raise NotImplementedError("the fused step implements the default optimizer (adam, train.py:55)")
     from gcc_amd.posemb import DevicePosEmb
+    from gcc_amd.sampler import DeviceRWRSampler
 
-    posemb = None                                         # E2E path only; the MoCo path embeds in its producer lanes
+    posemb = None                                         # API path only; the fused steps embed in their producer lanes
     trainer, optimizer = None, None
-    if args.moco:
+    if args.optimizer == "adam":
         # data pipeline: `producer_lanes` streams, each preparing `producer_chunk` steps per turn (sampler calls + one
         # multi-view eigensolver call) -- the role of the reference's --num-workers DataLoader processes
-        from gcc_amd.sampler import DeviceRWRSampler
-
         lanes, depth = [], 2
         for _ in range(args.producer_lanes):
             smp = DeviceRWRSampler(train_dataset.graph, args.batch_size, run_seed=args.seed,
@@ -342,17 +348,34 @@ def main(args):
             lanes.append((smp, DevicePosEmb(args.batch_size, smp.node_cap, args.positional_embedding_size, device=dev,
                                             seed=args.seed, num_buffers=depth * args.producer_chunk,
                                             max_views=min(2 * args.producer_chunk, 32))))
-        trainer = MoCoTrainStep(model, model_ema, contrast, lanes[0][0], lanes[0][1],
-                                learning_rate=args.learning_rate, betas=(args.beta1, args.beta2),
-                                weight_decay=args.weight_decay, clip_norm=args.clip_norm, alpha=args.alpha,
-                                world_size=world, rank=rank, lanes=lanes, depth=depth, chunk=args.producer_chunk)
+        if args.moco:
+            trainer = MoCoTrainStep(model, model_ema, contrast, lanes[0][0], lanes[0][1],
+                                    learning_rate=args.learning_rate, betas=(args.beta1, args.beta2),
+                                    weight_decay=args.weight_decay, clip_norm=args.clip_norm, alpha=args.alpha,
+                                    world_size=world, rank=rank, lanes=lanes, depth=depth, chunk=args.producer_chunk)
+        else:
+            trainer = E2ETrainStep(model, lanes[0][0], lanes[0][1], nce_t=args.nce_t, learning_rate=args.learning_rate,
+                                   betas=(args.beta1, args.beta2), weight_decay=args.weight_decay,
+                                   clip_norm=args.clip_norm, lanes=lanes, depth=depth, chunk=args.producer_chunk)
         optimizer = trainer.optimizer
     else:
+        # train.py:658-679: SGD(momentum) / Adagrad through autograd and torch.optim -- the API path of the same kernels
+        if world > 1:
+            raise NotImplementedError("--optimizer sgd/adagrad runs the single-GPU API path; the data-parallel step is fused Adam")
         posemb = DevicePosEmb(args.batch_size, train_dataset.node_cap, args.positional_embedding_size,
                               device=dev, seed=args.seed)
-        optimizer = torch.optim.Adam(model.parameters(), lr=args.learning_rate, betas=(args.beta1, args.beta2),
-                                     weight_decay=args.weight_decay)
+        if args.optimizer == "sgd":
+            optimizer = torch.optim.SGD(model.parameters(), lr=args.learning_rate, momentum=args.momentum,
+                                        weight_decay=args.weight_decay)
+        else:
+            optimizer = torch.optim.Adagrad(model.parameters(), lr=args.learning_rate, lr_decay=args.lr_decay_rate,
+                                            weight_decay=args.weight_decay)
         model.train()
+        if args.moco:                                     # train.py:357-365
+            model_ema.eval()
+            for mod in model_ema.modules():
+                if isinstance(mod, torch.nn.BatchNorm1d):
+                    mod.train()
 
     args.start_epoch = 1
     if checkpoint is not None:                            # train.py:685-702 (optimizer state deliberately not restored)
