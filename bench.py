@@ -10,6 +10,9 @@ MoCo K=16384, bsz 256, rw_hops 256, restart 0.8 on the synthetic 1M-node/10M-edg
 §8d), everything resident in HBM before the timed region.
 --mode sampler (BASELINE configs[3]): the sampler alone (seed draw, walks, induction, batch packing) on the
 10M-node/200M-edge graph G2; no collective.
+--mode e2e (BASELINE configs[0], train.py:396-401): in-batch negatives (K = bsz - 1, NCESoftmaxLossNS), both views
+through `model`, fused clip + Adam, on G1 (small.bin is not obtainable offline); --batch-size 32 is the reference's
+README setting, 256 the default here.  Single GPU (the reference has no data-parallel E2E mode).
 
 Prints ONE JSON line on rank 0.  Multi-GPU: one process per GPU; when WORLD_SIZE is not set and --gpus N > 1 this
 script re-launches itself under torch.distributed.run (rendezvous on 127.0.0.1).  The seed batch is sharded by rank
@@ -47,7 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--mode", choices=["train", "sampler"], default="train")
+    ap.add_argument("--mode", choices=["train", "sampler", "e2e"], default="train")
     ap.add_argument("--batch-size", type=int, default=256)
     ap.add_argument("--nce-k", type=int, default=16384)
     ap.add_argument("--rw-hops", type=int, default=256)
@@ -102,6 +105,9 @@ def workload_name(args, world, v, e):
         tag = "BASELINE configs[3]: " if (args.nodes, args.edges, args.rw_hops) == (10_000_000, 200_000_000, 256) \
             and abs(args.restart_prob - 0.8) < 1e-12 else ""
         return f"{tag}sampler-only rw_hops={args.rw_hops} restart={args.restart_prob} bsz={args.batch_size}/GPU, {graph}, {world}xMI355X"
+    if args.mode == "e2e":
+        return (f"BASELINE configs[0] on G1: E2E K={args.batch_size - 1} (in-batch negatives, NCESoftmaxLossNS) bsz={args.batch_size} "
+                f"hid=64 rw_hops={args.rw_hops} restart={args.restart_prob}, {graph}, {world}xMI355X")
     tag = ""
     if (args.nodes, args.edges, args.batch_size, args.nce_k, args.rw_hops) == (1_000_000, 10_000_000, 256, 16384, 256):
         tag = "BASELINE configs[1]: " if world == 1 else ("BASELINE configs[2]: " if world == 8 else "BASELINE configs[1] per GPU: ")
@@ -219,16 +225,23 @@ def cpu_baseline(rp, ci, args):
             (rq, pq), (rk, pk) = views
             fq = model(rq["node_off"].astype(np.int64), rq["row_ptr"].astype(np.int64),
                        rq["col_idx"].astype(np.int64), pq, dropout_masks=keep)
-            with torch.no_grad():
-                fk = ema(rk["node_off"].astype(np.int64), rk["row_ptr"].astype(np.int64),
-                         rk["col_idx"].astype(np.int64), pk)
-            out, index = E.moco_forward(memory, index, fq, fk, 0.07)
-            loss = E.nce_softmax_loss(out)
+            if args.mode == "e2e":                           # train.py:396-401
+                keep_k = (torch.rand(5, B, 64) >= 0.5).float()
+                fk = model(rk["node_off"].astype(np.int64), rk["row_ptr"].astype(np.int64),
+                           rk["col_idx"].astype(np.int64), pk, dropout_masks=keep_k)
+                loss = E.nce_softmax_loss_ns(fk @ fq.t() / 0.07)
+            else:
+                with torch.no_grad():
+                    fk = ema(rk["node_off"].astype(np.int64), rk["row_ptr"].astype(np.int64),
+                             rk["col_idx"].astype(np.int64), pk)
+                out, index = E.moco_forward(memory, index, fq, fk, 0.07)
+                loss = E.nce_softmax_loss(out)
             opt.zero_grad()
             loss.backward()
             torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
             opt.step()
-            E.moment_update(model, ema, 0.999)
+            if args.mode != "e2e":
+                E.moment_update(model, ema, 0.999)
             done += 2 * B
             first += B
             dt = time.perf_counter() - t0
@@ -236,10 +249,34 @@ def cpu_baseline(rp, ci, args):
                 break
     finally:
         pool.terminate()
-    return dict(value=done / dt, unit="subgraphs/s", cores=cores, kind="port",
-                sample=f"{done // (2 * B)} full steps of bsz {B} ({done} subgraphs) in {dt:.1f}s: C sampler oracle "
-                       f"(OpenMP x{threads}) + SciPy eigsh pos-emb ({workers} processes) + torch-CPU "
-                       f"encoder/MoCo/Adam/EMA oracle ({torch.get_num_threads()} threads)")
+    head = "encoder/E2E-NS/Adam" if args.mode == "e2e" else "encoder/MoCo/Adam/EMA"
+    res = dict(value=done / dt, unit="subgraphs/s", cores=cores, kind="port",
+               sample=f"{done // (2 * B)} full steps of bsz {B} ({done} subgraphs) in {dt:.1f}s: C sampler oracle "
+                      f"(OpenMP x{threads}) + SciPy eigsh pos-emb ({workers} processes) + torch-CPU "
+                      f"{head} oracle ({torch.get_num_threads()} threads)")
+    res["reference_shaped"] = cpu_baseline_reference_shaped(rp, ci, args)
+    return res
+
+
+def cpu_baseline_reference_shaped(rp, ci, args):
+    """SURVEY.md 8(d) baseline (i), the WEAKER one: the reference's data pipeline the way the reference runs it -- a
+    Python loop per sample mirroring graph_dataset.py:94-179 call for call (walker in C standing in for DGL's C++
+    one, torch.unique, SciPy slicing for g.subgraph, SciPy ARPACK exactly as data_util.py:242-281), in as many worker
+    processes as train.py:49's default (--num-workers 12) -- sample-ready subgraphs/s, no encoder step.  Spawned
+    processes (a forked child of a process holding a HIP context is unsafe)."""
+    from tests.tools.cpu_baseline_reference_shaped import run_timed
+
+    cores = os.cpu_count() or 1
+    procs = min(12, cores)
+    try:
+        v, dt, n = run_timed(rp, ci, procs, max(4.0, 0.6 * args.cpu_seconds), clear=True, rw_hops=args.rw_hops,
+                             restart=args.restart_prob, start="spawn")
+    except Exception as e:                                   # the stronger "port" figure above stands on its own
+        return dict(value=None, error=repr(e)[:200])
+    return dict(value=v, unit="subgraphs/s", cores=procs, host_cores=cores, kind="port",
+                sample=f"{n} samples (2 views each) in {dt:.1f}s: per-sample Python loop of graph_dataset.py:94-179 in {procs} "
+                       f"worker processes (train.py:49 default num_workers=12), C walker + per-seed O(|V|) visit-count clear "
+                       f"(DGL-recalled) + torch.unique + SciPy subgraph slicing + SciPy ARPACK pos-emb; data pipeline only")
 
 
 def sampler_source_hash():
@@ -275,6 +312,7 @@ def sampler_probe(sampler, rp, first_id, args, nsample, lt, Prof, torch):
     acc = dict(walk=0, induce=0, pack=0, total=0)
     iso = np.zeros(3)
     deg = np.diff(rp)
+    shape = dict(nodes_q=0.0, nodes_k=0.0, edges_q=0.0, edges_k=0.0)
     for i in range(-2, nsample):                  # two untimed probe warm-ups
         pr = Prof(4)
         q, k = sampler.sample(first_id(max(i, 0)), prof=pr)
@@ -284,12 +322,96 @@ def sampler_probe(sampler, rp, first_id, args, nsample, lt, Prof, torch):
         iso += np.array([pr.elapsed_ms(j, j + 1) for j in range(3)]) / nsample
         seeds = sampler.last_seeds().cpu().numpy()
         L = lt[deg[seeds]]
-        bts = sampler_algorithmic_bytes(rp, [(q.csr_numpy(), L), (k.csr_numpy(), L)])
+        cq, ck = q.csr_numpy(), k.csr_numpy()
+        bts = sampler_algorithmic_bytes(rp, [(cq, L), (ck, L)])
         for key in acc:
             acc[key] += bts[key] / nsample
+        shape["nodes_q"] += len(cq["parent_nid"]) / nsample
+        shape["nodes_k"] += len(ck["parent_nid"]) / nsample
+        shape["edges_q"] += len(cq["col_idx"]) / nsample
+        shape["edges_k"] += len(ck["col_idx"]) / nsample
     # the event marks sit around groups of launches: walk + prefix step A | induction alone | prefix step B + pack
     return {"rwr_walk_kernel+prefix_a_kernel": float(iso[0]), "induce_kernel": float(iso[1]),
-            "prefix_b_kernel+pack_kernel": float(iso[2])}, acc
+            "prefix_b_kernel+pack_kernel": float(iso[2])}, acc, shape
+
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-f32 MFMA = the f32 vector rate
+F32_PER_CU_GFLOPS = 157300.0 / 256
+
+
+def posemb_probe(sampler, posemb, first_id, nsteps, torch):
+    """Isolated eigensolver call over the views of ``nsteps`` steps with the library's per-class tick and FLOP counters
+    on (gcc_posemb_debug_ticks): wall time of the call, CU-time and executed f32 FLOPs per solver class."""
+    from gcc_amd import _cabi
+
+    lib = _cabi.load()
+    views = [g for s in range(nsteps) for g in sampler.sample(first_id(s))]
+    posemb.multi(views)
+    torch.cuda.synchronize()
+    ticks = torch.zeros(6 * 16, dtype=torch.int64, device=views[0].node_off.device)
+    lib.gcc_posemb_debug_ticks(ticks.data_ptr())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    posemb.multi(views)
+    e1.record()
+    torch.cuda.synchronize()
+    lib.gcc_posemb_debug_ticks(None)
+    t = ticks.cpu().numpy().reshape(6, 16)
+    out = dict(views=len(views), call_ms=float(e0.elapsed_time(e1)), classes={})
+    for c, name in enumerate(["small", "mid", "slot", "krylov", "big", "sparse-block"]):
+        items = int(t[c, 15])
+        if items == 0:
+            continue
+        cu_s = float(t[c, :14].sum()) / 1e8                      # 100 MHz ticks of one workgroup = one CU's LDS-resident solver
+        flops = float(t[c, 14])
+        out["classes"][name] = dict(items=items, cu_ms_per_item=cu_s * 1e3 / items, gflop=flops / 1e9,
+                                    frac_of_cu_f32_peak=(flops / cu_s / 1e9 / F32_PER_CU_GFLOPS) if cu_s > 0 and flops > 0 else None)
+    out["cu_seconds_per_step"] = sum(v["cu_ms_per_item"] * v["items"] for v in out["classes"].values()) / 1e3 / nsteps
+    return out
+
+
+def stage_rooflines(args, acc, kern_iso, stage_ms, shape, pe_probe):
+    """What bounds the step, stage by stage (SURVEY.md 8d byte / FLOP models; the 8(d) `roofline` object prices one
+    kernel only).  Sampler: isolated intervals.  Encoder / head: in-step HIP-event intervals on the training stream
+    (they include contention with the producer lanes)."""
+    H, B = 64, args.batch_size
+    out = {}
+    t_s = sum(kern_iso.values())
+    out["sampler_end_to_end"] = dict(bound="hbm", algorithmic_bytes_per_step=acc["total"], ms_isolated=t_s,
+                                     achieved=acc["total"] / (t_s * 1e-3) / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
+                                     frac=acc["total"] / (t_s * 1e-3) / 1e9 / HBM_PEAK_GBPS)
+    L = 4                                                      # GIN layers with an MLP (num_layer 5 -> 4 GINConv)
+    both = args.mode == "e2e"                                  # E2E: both views are differentiated
+    nf, ef = shape["nodes_q"] + shape["nodes_k"], shape["edges_q"] + shape["edges_k"]
+    nb, eb = (nf, ef) if both else (shape["nodes_q"], shape["edges_q"])
+
+    def enc(n, e, bwd):
+        # per layer (SURVEY 8d): SpMM bytes = 2 N d s + 4 nnz + 4 (N + 1), flops 2 nnz d; MLP bytes = in + out rows of both
+        # Linears, flops 2 N (d d + d d); the three BatchNorms add a read of z1 / z2 each in training mode.  Backward ~ 2x.
+        by = L * ((2 * n * H * 4 + 4 * e + 4 * (n + 1)) + 4 * n * H * 4 + 3 * n * H * 4)
+        fl = L * (2 * e * H + 2 * n * 2 * H * H)
+        return (2 * by, 2 * fl) if bwd else (by, fl)
+    for name, (by, fl), ms in (("gin_encoder_fwd", enc(nf, ef, False), stage_ms.get("gin_fwd")),
+                               ("gin_encoder_bwd", enc(nb, eb, True), stage_ms.get("gin_bwd"))):
+        if ms:
+            out[name] = dict(bound="hbm", algorithmic_bytes=by, algorithmic_flops=fl, ms_in_step=ms,
+                             achieved=by / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
+                             frac=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             f32_mfma_frac=fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                             note="latency-bound chain of small kernels: neither roof is near")
+    K = B if args.mode == "e2e" else args.nce_k
+    for name, mult in (("nce_fwd", 1), ("nce_bwd", 2)):
+        ms = stage_ms.get(name)
+        if ms:
+            fl, by = mult * 2 * B * (K + 1) * H, mult * (K * H * 4 + 2 * B * H * 4)
+            out["infonce_" + name[4:]] = dict(bound="hbm", algorithmic_bytes=by, algorithmic_flops=fl, ms_in_step=ms,
+                                              achieved=by / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
+                                              frac=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                              f32_mfma_frac=fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS)
+    if pe_probe:
+        out["positional_embedding"] = dict(bound="f32 vector/MFMA rate of the CUs a solver workgroup occupies",
+                                           peak_per_cu=F32_PER_CU_GFLOPS, unit="GFLOP/s per CU", **pe_probe)
+    return out
 
 
 def main():
@@ -305,6 +427,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.mode == "e2e" and world > 1:
+        raise SystemExit("--mode e2e is single-GPU (train.py has no data-parallel E2E step)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (run through gpurun)"
     ndev = torch.cuda.device_count()
     oversubscribed = ndev < world              # fewer devices than ranks (a 1-GPU box): ranks share devices, correctness only
@@ -359,7 +483,7 @@ def main():
         from gcc_amd.encoder import GraphEncoder
         from gcc_amd.misc import warmup_linear
         from gcc_amd.posemb import DevicePosEmb, PlaceholderPosEmb
-        from gcc_amd.train_step import MoCoTrainStep
+        from gcc_amd.train_step import E2ETrainStep, MoCoTrainStep
 
         # the timed region must produce exactly what it consumes: whole chunks only
         chunk = max(d for d in range(1, min(args.chunk, args.steps) + 1) if args.steps % d == 0)
@@ -382,12 +506,18 @@ def main():
         posemb = posembs[0]
         # every producer lane: one sampler + one eigensolver workspace, `chunk` steps (2 * chunk views) per turn
         lanes = [(samplers[i], posembs[i]) for i in range(args.lanes)]
-        trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank,
-                                lanes=lanes, depth=args.depth, chunk=chunk, reserved_cus=args.reserved_cus,
-                                cu_layout=args.cu_layout, ahead=args.ahead)
-        stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder q+k fwd",
-                  "moco-infonce fwd", "key all-gather" if world > 1 else "enqueue", "infonce bwd", "gin-encoder bwd",
-                  "grad all-reduce" if world > 1 else "clip", "adam", "ema"]
+        if args.mode == "e2e":
+            trainer = E2ETrainStep(model, sampler, posemb, nce_t=0.07, lanes=lanes, depth=args.depth, chunk=chunk,
+                                   ahead=args.ahead)
+            stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder fwd(q), fwd(k)",
+                      "in-batch infonce (NS) fwd", "infonce bwd (dq, dk)", "gin-encoder bwd(q) + bwd(k)", "clip", "adam", "meters"]
+        else:
+            trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank,
+                                    lanes=lanes, depth=args.depth, chunk=chunk, reserved_cus=args.reserved_cus,
+                                    cu_layout=args.cu_layout, ahead=args.ahead)
+            stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder q+k fwd",
+                      "moco-infonce fwd", "infonce bwd", "gin-encoder bwd", "grad all-reduce" if world > 1 else "clip", "adam",
+                      "ema", "key all-gather (overlapped since the encoder fwd) + enqueue" if world > 1 else "enqueue", "meters"]
         n_batch = 2000 * 12 // 32                                          # train.py:356 with default flags
         total_steps = 100 * n_batch
 
@@ -445,7 +575,10 @@ def main():
         # kernels, same batches as the timed steps, GPU otherwise idle).  Inside the timed region of --mode train the
         # producer streams overlap several sampler / eigensolver launches, so in-step marks measure contention.
         nsample = min(args.steps, 12)
-        kern_iso, acc = sampler_probe(sampler, rp, lambda i: first_id(first_timed + i), args, nsample, lt, Prof, torch)
+        pe_probe = None
+        kern_iso, acc, probe_shape = sampler_probe(sampler, rp, lambda i: first_id(first_timed + i), args, nsample, lt, Prof, torch)
+        if args.mode != "sampler" and args.posemb == "device":
+            pe_probe = posemb_probe(sampler, posemb, lambda i: first_id(first_timed + i), min(chunk, 8), torch)
         sampler.check_status()
         dom = "induce_kernel"
         achieved = acc["induce"] / (kern_iso[dom] * 1e-3) / 1e9
@@ -460,7 +593,8 @@ def main():
             "produced_steps": produced, "consumed_steps": consumed,
             "config": {"workload": workload_name(args, world, V, E), "mode": args.mode,
                        "graph_nodes": V, "graph_edges": E,
-                       "batch_size_per_gpu": B, "global_batch": B * world, "nce_k": args.nce_k if args.mode == "train" else None,
+                       "batch_size_per_gpu": B, "global_batch": B * world,
+                       "nce_k": args.nce_k if args.mode == "train" else (B - 1 if args.mode == "e2e" else None),
                        "rw_hops": args.rw_hops, "restart_prob": args.restart_prob, "stages": stages,
                        "parallelism": f"dp{world} (seed batch sharded, graph replicated)" + ("; OVERSUBSCRIBED: %d ranks on %d device(s), gloo, correctness only" % (world, ndev) if oversubscribed else "")},
             "kernel_ms_isolated": kern_iso,
@@ -469,10 +603,11 @@ def main():
                                      "before and after induce_kernel inside gcc_sample_batch; rocprofv3 --kernel-trace --stats of the same "
                                      "kernels alone: profiles/r2_kernel_stats_sampler_alone.csv",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "algorithmic_bytes_per_launch": acc["induce"], "traffic": traffic, "traffic_source": traffic_src},
+                         "algorithmic_bytes_per_launch": acc["induce"], "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_note": "committed constant from separate rocprofv3 --pmc passes of this build (hash-guarded), not a same-run measurement"},
             "algorithmic_bytes_per_step": acc,
         }
-        if args.mode == "train":
+        if args.mode in ("train", "e2e"):
             out["config"].update(producer_lanes=args.lanes, producer_depth=args.depth, producer_chunk=chunk,
                                  producer_ahead=trainer.producer.ahead, reserved_cus=args.reserved_cus)
             used = [p for p in profs if p.get("used")]
@@ -484,6 +619,7 @@ def main():
                     stage_ms["posemb_chunk_of_%d_views" % min(2 * chunk, 32)] = float(
                         np.mean([p["posemb"].elapsed_ms(0, 1) for p in used]))
             out["stage_ms"] = stage_ms
+            out["stage_rooflines"] = stage_rooflines(args, acc, kern_iso, stage_ms, probe_shape, pe_probe)
         out.update(extra)
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline_sampler(rp, ci, args) if args.mode == "sampler" else cpu_baseline(rp, ci, args)

@@ -87,6 +87,26 @@ def run(rp, ci, samples, procs, clear, rw_hops=256, restart=0.8):
     return 2 * samples / dt, dt
 
 
+def run_timed(rp, ci, procs, seconds, clear=True, rw_hops=256, restart=0.8, start="spawn"):
+    """The same loop under a time budget (bench.py's cpu_baseline leg): worker processes keep drawing samples until
+    ``seconds`` have passed.  ``start``: "spawn" when the parent holds a HIP context (fork + HIP is unsafe).
+    -> (subgraphs/s, seconds, samples)"""
+    with mp.get_context(start).Pool(procs, initializer=_init, initargs=(rp, ci, rw_hops, restart, clear)) as pool:
+        # (every wait is bounded: a worker that dies must not hang the caller)
+        pool.map_async(_one_sample, list(range(9_000_000, 9_000_000 + procs))).get(timeout=120)   # warm the workers (imports, ARPACK)
+        first, done = 10_000_000, 0
+        t = time.time()
+        while True:
+            ids = list(range(first, first + 8 * procs))
+            pool.map_async(_one_sample, ids, chunksize=2).get(timeout=120)
+            first += len(ids)
+            done += len(ids)
+            dt = time.time() - t
+            if dt >= seconds:
+                break
+    return 2 * done / dt, dt, done
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nodes", type=int, default=1_000_000)
