@@ -33,6 +33,9 @@ class GccGraph(ctypes.Structure):
         ("num_edges", ctypes.c_int64),
         ("ltab_len", ctypes.c_int32),
         ("lmax", ctypes.c_int32),
+        ("shard_off", ctypes.c_void_p),
+        ("num_shards", ctypes.c_int32),
+        ("reserved_", ctypes.c_int32),
     ]
 
 

@@ -165,7 +165,8 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
     const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
     const double *__restrict__ seed_cdf, const int32_t *__restrict__ ltab, int64_t num_nodes,
     int32_t ltab_len, int32_t p2max, uint64_t run_seed, int64_t first_sample_id, int32_t B,
-    uint32_t restart_u32, const int32_t *__restrict__ seeds_in, Work w)
+    uint32_t restart_u32, const int32_t *__restrict__ seeds_in, const int64_t *__restrict__ shard_off,
+    int32_t num_shards, Work w)
 {
     DYN_SMEM(smem);
     __shared__ int32_t wsum[5];
@@ -186,8 +187,16 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
                       (uint32_t)(run_seed >> 32) ^ 0x00A11CE5u, x);
         const uint64_t u53 = ((uint64_t)x[0] << 21) | (uint64_t)(x[1] >> 11);
         const double u = (double)u53 * (1.0 / 9007199254740992.0);
-        // workgroup-cooperative 256-ary upper bound: first index with cdf[i] > u (1M entries: 3 rounds)
+        // the worker shard this DataLoader batch comes from (graph_dataset.py:23-30,63-76: batch i is produced by worker
+        // i % num_workers out of ITS graphs; jobs repeat with period num_shards): the cdf is that shard's own
         int64_t lo = 0, hi = num_nodes;
+        if (num_shards > 1) {
+            const int64_t sh = (int64_t)((sid / (uint64_t)B) % (uint64_t)num_shards);
+            lo = shard_off[sh];
+            hi = shard_off[sh + 1];
+        }
+        const int64_t last = hi - 1;
+        // workgroup-cooperative 256-ary upper bound: first index with cdf[i] > u (1M entries: 3 rounds)
         while (lo < hi) {
             const int64_t len = hi - lo;
             const int64_t step = (len + kWalkThreads - 1) / kWalkThreads;
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
             lo = lo + (int64_t)(k - 1) * step + 1;
             if (nhi < hi) hi = nhi;
         }
-        seed = (int32_t)(lo < num_nodes ? lo : num_nodes - 1);
+        seed = (int32_t)(lo <= last ? lo : last);
     }
     if (view == 0 && tid == 0) w.seeds[b] = seed;
 
@@ -842,6 +851,10 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
         snprintf(g_err, kErrLen, "gcc_sample_batch: null argument");
         return -1;
     }
+    if (g->num_shards > 1 && !g->shard_off) {
+        snprintf(g_err, kErrLen, "gcc_sample_batch: num_shards = %d without shard_off", g->num_shards);
+        return -1;
+    }
     if (p->batch_size <= 0 || g->lmax <= 0 || g->lmax > 65534 || g->num_nodes <= 0 ||
         g->num_nodes > 0x7FFFFFFF || g->num_edges > 0x7FFFFFFF) {
         snprintf(g_err, kErrLen, "gcc_sample_batch: size out of range (B=%d lmax=%d V=%lld E=%lld)",
@@ -903,7 +916,7 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
 #endif
     hipLaunchKernelGGL(rwr_walk_kernel, dim3(G), dim3(kWalkThreads), lds1, s, g->row_ptr, g->col_idx, g->seed_cdf,
                        g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, B,
-                       p->restart_u32, p->seeds, w);
+                       p->restart_u32, p->seeds, g->num_shards > 1 ? g->shard_off : nullptr, g->num_shards, w);
     hipLaunchKernelGGL(prefix_a_kernel, dim3(1), dim3(kPrefixThreads), (size_t)(G + 1) * 4, s, B, w);
     prof_mark(p->prof, 1, s);                        // marks 1 -> 2 bracket induce_kernel alone (bench.py's roofline interval)
     hipLaunchKernelGGL(induce_kernel, dim3(G * kGridMult), dim3(kInduceThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,

@@ -15,13 +15,18 @@ from . import _cabi
 from .graphgen import check_contract
 
 
-def seed_cdf_table(row_ptr: np.ndarray) -> np.ndarray:
+def seed_cdf_table(row_ptr: np.ndarray, shard_off=None) -> np.ndarray:
     """P(seed = v) ~ in_degree(v)^0.75 (graph_dataset.py:86-90) as the float64
-    cdf numpy's ``choice(p=...)`` searches (``cdf = p.cumsum(); cdf /= cdf[-1]``)."""
+    cdf numpy's ``choice(p=...)`` searches (``cdf = p.cumsum(); cdf /= cdf[-1]``).
+    ``shard_off``: node ranges of the DataLoader workers' shards (graph_dataset.py:23-30,63-76) --
+    a worker normalises the weights over ITS graphs, so every range gets its own cdf."""
     w = np.diff(row_ptr).astype(np.float64) ** 0.75
-    p = w / w.sum()
-    cdf = np.cumsum(p)
-    cdf /= cdf[-1]
+    bounds = [0, len(w)] if shard_off is None or len(shard_off) <= 2 else [int(x) for x in shard_off]
+    cdf = np.empty(len(w), dtype=np.float64)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        p = w[a:b] / w[a:b].sum()
+        c = np.cumsum(p)
+        cdf[a:b] = c / c[-1]
     return cdf
 
 
@@ -48,7 +53,8 @@ class DeviceGraph:
     """int32 CSR + seed cdf + max_nodes table on one GPU."""
 
     def __init__(self, row_ptr: np.ndarray, col_idx: np.ndarray, rw_hops: int = 256,
-                 restart_prob: float = 0.8, device="cuda", validate: bool = True, ltab: np.ndarray = None):
+                 restart_prob: float = 0.8, device="cuda", validate: bool = True, ltab: np.ndarray = None,
+                 shard_off=None):
         import torch
 
         row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
@@ -74,13 +80,23 @@ class DeviceGraph:
         self.lmax = int(ltab.max())
         self.row_ptr = torch.from_numpy(row_ptr).to(self.device)
         self.col_idx = torch.from_numpy(col_idx).to(self.device)
-        self.seed_cdf = torch.from_numpy(seed_cdf_table(row_ptr)).to(self.device)
+        # worker shards (LoadBalanceGraphDataset): node ranges whose seeds are drawn separately, batch by batch
+        self.num_shards = 0
+        self.shard_off = None
+        if shard_off is not None and len(shard_off) > 2:
+            so = np.ascontiguousarray(shard_off, dtype=np.int64)
+            if so[0] != 0 or so[-1] != self.num_nodes or np.any(np.diff(so) <= 0):
+                raise ValueError("shard_off must be increasing node offsets from 0 to num_nodes (no empty shard)")
+            self.num_shards = len(so) - 1
+            self.shard_off = torch.from_numpy(so).to(self.device)
+        self.seed_cdf = torch.from_numpy(seed_cdf_table(row_ptr, shard_off if self.num_shards else None)).to(self.device)
         self.ltab = torch.from_numpy(ltab).to(self.device)
         self.c = _cabi.GccGraph(
             row_ptr=self.row_ptr.data_ptr(), col_idx=self.col_idx.data_ptr(),
             seed_cdf=self.seed_cdf.data_ptr(), ltab=self.ltab.data_ptr(),
             num_nodes=self.num_nodes, num_edges=self.num_edges,
-            ltab_len=int(ltab.shape[0]), lmax=self.lmax)
+            ltab_len=int(ltab.shape[0]), lmax=self.lmax,
+            shard_off=self.shard_off.data_ptr() if self.shard_off is not None else None, num_shards=self.num_shards)
 
     def byref(self):
         return ctypes.byref(self.c)

@@ -225,8 +225,9 @@ class LoadBalanceGraphDataset:
 
     ``dgl_graphs_file`` is read without DGL (gcc_amd/ingest.py: read_dgl_graphs);
     ``graph`` overrides it: a :class:`DeviceGraph`, or ``(row_ptr, col_idx)``
-    arrays, or a list of such pairs (disjoint graphs are unioned, which is what
-    sampling a node over all workers' graphs amounts to).
+    arrays, or a list of such pairs -- a multi-graph corpus: laid out in HBM shard
+    by shard (``jobs``), batch i draws its seeds from worker shard i % num_workers
+    as the reference's IterableDataset workers do.
     """
 
     def __init__(self, rw_hops=64, restart_prob=0.8, positional_embedding_size=32,
@@ -255,16 +256,12 @@ class LoadBalanceGraphDataset:
         if graph is None:
             graph, sizes = _load_graph_file(dgl_graphs_file)
         graphs = graph if isinstance(graph, list) else [graph]
+        if not isinstance(graphs[0], DeviceGraph) and sizes is None:
+            sizes = [len(rp) - 1 for rp, _ in graphs]
         if isinstance(graphs[0], DeviceGraph):
             assert len(graphs) == 1
-            self.graph = graphs[0]
-            sizes = [self.graph.num_nodes]
-        else:
-            if sizes is None:
-                sizes = [len(rp) - 1 for rp, _ in graphs]
-            rp, ci = _disjoint_union(graphs)
-            self.graph = DeviceGraph(rp, ci, rw_hops=rw_hops, restart_prob=restart_prob, device=device)
-        # greedy LPT load balance of graph_dataset.py:63-77, kept for its attributes
+            sizes = [graphs[0].num_nodes]
+        # greedy LPT load balance of graph_dataset.py:63-77: graph indices per worker
         assert num_workers % num_copies == 0
         bins = max(num_workers // num_copies, 1)
         jobs = [list() for _ in range(bins)]
@@ -274,6 +271,21 @@ class LoadBalanceGraphDataset:
             workloads[argmin] += size
             jobs[argmin].append(idx)
         self.jobs = jobs * num_copies
+        if isinstance(graphs[0], DeviceGraph):
+            self.graph = graphs[0]                           # one graph: every worker holds it, one shard
+            self.graph_order = [0]
+        else:
+            # Worker w samples among the nodes of ITS graphs jobs[w], concatenated in that order (worker_init_fn,
+            # graph_dataset.py:23-30; __iter__ :85-92), and an IterableDataset worker yields whole batches: batch i is
+            # worker i % num_workers's.  The corpus is laid out shard by shard in HBM, each shard with its own seed cdf;
+            # gcc_sample_batch picks the shard from the batch index.  Workers without graphs (more workers than graphs)
+            # would crash the reference (np.random.choice over nothing); they are left out of the rotation here.
+            live = [j for j in jobs if j]
+            self.graph_order = [i for j in live for i in j]
+            rp, ci = _disjoint_union([graphs[i] for i in self.graph_order])
+            shard_off = np.cumsum([0] + [sum(len(graphs[i][0]) - 1 for i in j) for j in live])
+            self.graph = DeviceGraph(rp, ci, rw_hops=rw_hops, restart_prob=restart_prob, device=device,
+                                     shard_off=shard_off if len(live) > 1 else None)
         self.total = self.num_samples * num_workers
         self.batch_size = batch_size
         self.run_seed = run_seed

@@ -68,13 +68,20 @@ typedef struct gcc_graph {
     const int32_t *row_ptr;   /* device [num_nodes + 1]                               */
     const int32_t *col_idx;   /* device [num_edges]                                   */
     const double  *seed_cdf;  /* device [num_nodes]: cumsum(deg^0.75)/sum, float64    */
-                              /*   (graph_dataset.py:86-90)                           */
+                              /*   (graph_dataset.py:86-90); with worker shards: each */
+                              /*   shard's own cdf over its node range (ends at 1.0)  */
     const int32_t *ltab;      /* device [ltab_len]: max_nodes_per_seed by in-degree,  */
                               /*   index clamped to ltab_len-1 (graph_dataset.py:113-124) */
     int64_t num_nodes;
     int64_t num_edges;
     int32_t ltab_len;
     int32_t lmax;             /* max(ltab): sizes LDS and per-subgraph capacities     */
+    /* Worker shards of LoadBalanceGraphDataset (graph_dataset.py:23-30,63-76): the corpus' graphs are laid out shard
+     * by shard, shard s = nodes [shard_off[s], shard_off[s+1]); DataLoader batch i (= sample ids [i*bsz, (i+1)*bsz))
+     * draws its seeds from shard i % num_shards only.  num_shards <= 1 (shard_off may be NULL): one shard = all. */
+    const int64_t *shard_off; /* device [num_shards + 1] or NULL                      */
+    int32_t num_shards;
+    int32_t reserved_;
 } gcc_graph;
 
 /* --------------------------------------------------------------- sampler ---

@@ -29,13 +29,23 @@ MASK32 = 0xFFFFFFFF
 # --------------------------------------------------------------------------
 # host-side tables (restated from the reference; compared with gcc_amd.graph)
 # --------------------------------------------------------------------------
-def seed_cdf(row_ptr: np.ndarray) -> np.ndarray:
-    """graph_dataset.py:86-90: p ~ in_degree^0.75 (float64), numpy choice() cdf."""
+def seed_cdf(row_ptr: np.ndarray, shard_off=None) -> np.ndarray:
+    """graph_dataset.py:86-90: p ~ in_degree^0.75 (float64), numpy choice() cdf.  With worker shards
+    (graph_dataset.py:23-30,63-76: worker w samples among the nodes of ITS graphs only) every node range
+    [shard_off[s], shard_off[s+1]) carries that shard's own cdf."""
     deg = np.diff(row_ptr).astype(np.float64) ** 0.75
-    p = deg / deg.sum()
-    cdf = p.cumsum()
-    cdf /= cdf[-1]
-    return cdf
+    if shard_off is None or len(shard_off) <= 2:
+        p = deg / deg.sum()
+        cdf = p.cumsum()
+        cdf /= cdf[-1]
+        return cdf
+    out = np.empty(len(deg), dtype=np.float64)
+    for s in range(len(shard_off) - 1):
+        a, b = int(shard_off[s]), int(shard_off[s + 1])
+        p = deg[a:b] / deg[a:b].sum()
+        c = p.cumsum()
+        out[a:b] = c / c[-1]
+    return out
 
 
 def max_nodes_table(max_degree: int, rw_hops: int, restart_prob: float) -> np.ndarray:
@@ -66,12 +76,16 @@ def py_philox4x32_10(ctr, key):
     return [c0, c1, c2, c3]
 
 
-def py_draw_seed(cdf, run_seed: int, sample_id: int) -> int:
+def py_draw_seed(cdf, run_seed: int, sample_id: int, shard_off=None, batch_size: int = 1) -> int:
     key = [(run_seed & MASK32) ^ 0x5EED5EED, ((run_seed >> 32) & MASK32) ^ 0x00A11CE5]
     x = py_philox4x32_10([sample_id & MASK32, (sample_id >> 32) & MASK32, 0, 0], key)
     u = ((x[0] << 21) | (x[1] >> 11)) / 9007199254740992.0
-    idx = int(np.searchsorted(cdf, u, side="right"))
-    return min(idx, len(cdf) - 1)
+    lo, hi = 0, len(cdf)
+    if shard_off is not None and len(shard_off) > 2:       # the shard of this sample's DataLoader batch
+        sh = (sample_id // batch_size) % (len(shard_off) - 1)
+        lo, hi = int(shard_off[sh]), int(shard_off[sh + 1])
+    idx = lo + int(np.searchsorted(cdf[lo:hi], u, side="right"))
+    return min(idx, hi - 1)
 
 
 def py_rwr_trace(row_ptr, col_idx, seed: int, L: int, run_seed: int, g: int, restart_u32: int):
@@ -135,6 +149,9 @@ class COracle:
         lib.oracle_draw_seeds.argtypes = [_f64p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int64,
                                           ctypes.c_int32, _i32p]
         lib.oracle_draw_seeds.restype = None
+        lib.oracle_draw_seeds_sharded.argtypes = [_f64p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                                  ctypes.c_uint64, ctypes.c_int64, ctypes.c_int32, _i32p]
+        lib.oracle_draw_seeds_sharded.restype = None
         lib.oracle_rwr_trace.argtypes = [_i32p, _i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64,
                                          ctypes.c_uint64, ctypes.c_uint32, _i32p]
         lib.oracle_rwr_trace.restype = ctypes.c_int32
@@ -153,8 +170,13 @@ class COracle:
         self.lib.oracle_philox4x32_10(np.asarray(ctr, dtype=np.uint32), np.asarray(key, dtype=np.uint32), out)
         return out
 
-    def draw_seeds(self, cdf, run_seed, first_sample_id, count):
+    def draw_seeds(self, cdf, run_seed, first_sample_id, count, shard_off=None, batch_size=None):
         seeds = np.empty(count, dtype=np.int32)
+        if shard_off is not None and len(shard_off) > 2:
+            so = np.ascontiguousarray(shard_off, dtype=np.int64)
+            self.lib.oracle_draw_seeds_sharded(np.ascontiguousarray(cdf), len(cdf), so.ctypes.data, len(so) - 1,
+                                               int(batch_size or count), run_seed, first_sample_id, count, seeds)
+            return seeds
         self.lib.oracle_draw_seeds(np.ascontiguousarray(cdf), len(cdf), run_seed, first_sample_id, count, seeds)
         return seeds
 

@@ -72,8 +72,22 @@ void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
 }
 
 /* graph_dataset.py:85-92 -- seeds drawn with probability ~ in_degree^0.75 */
+void oracle_draw_seeds_sharded(const double *cdf, int64_t num_nodes, const int64_t *shard_off, int32_t num_shards,
+                               int32_t batch_size, uint64_t run_seed, int64_t first_sample_id, int32_t count,
+                               int32_t *seeds);
+
 void oracle_draw_seeds(const double *cdf, int64_t num_nodes, uint64_t run_seed,
                        int64_t first_sample_id, int32_t count, int32_t *seeds)
+{
+    oracle_draw_seeds_sharded(cdf, num_nodes, 0, 0, count > 0 ? count : 1, run_seed, first_sample_id, count, seeds);
+}
+
+/* ... out of the worker shard its DataLoader batch belongs to (graph_dataset.py:23-30: worker w holds the graphs
+ * jobs[w]; :63-76: jobs repeat with period num_shards; an IterableDataset worker yields whole batches, batch i comes
+ * from worker i % num_workers).  cdf = every shard's own cdf over its node range [shard_off[s], shard_off[s+1]). */
+void oracle_draw_seeds_sharded(const double *cdf, int64_t num_nodes, const int64_t *shard_off, int32_t num_shards,
+                               int32_t batch_size, uint64_t run_seed, int64_t first_sample_id, int32_t count,
+                               int32_t *seeds)
 {
     uint32_t key[2] = { (uint32_t)run_seed ^ 0x5EED5EEDu, (uint32_t)(run_seed >> 32) ^ 0x00A11CE5u };
     for (int32_t b = 0; b < count; ++b) {
@@ -83,11 +97,17 @@ void oracle_draw_seeds(const double *cdf, int64_t num_nodes, uint64_t run_seed,
         uint64_t u53 = ((uint64_t)x[0] << 21) | (x[1] >> 11);
         double u = (double)u53 * (1.0 / 9007199254740992.0);
         int64_t lo = 0, hi = num_nodes;            /* first index with cdf[i] > u */
+        if (num_shards > 1) {
+            int64_t sh = (int64_t)((sid / (uint64_t)batch_size) % (uint64_t)num_shards);
+            lo = shard_off[sh];
+            hi = shard_off[sh + 1];
+        }
+        int64_t last = hi - 1;
         while (lo < hi) {
             int64_t mid = (lo + hi) >> 1;
             if (cdf[mid] > u) hi = mid; else lo = mid + 1;
         }
-        seeds[b] = (int32_t)(lo < num_nodes ? lo : num_nodes - 1);
+        seeds[b] = (int32_t)(lo <= last ? lo : last);
     }
 }
 

@@ -83,6 +83,7 @@ def test_load_balance_dataset_attributes_and_iteration(tmp_path, monkeypatch):
     class FakeGraph:                                                # no device in the CPU tier
         def __init__(self, rp, ci, **kw):
             self.num_nodes, self.lmax = len(rp) - 1, 40
+            self.rp, self.ci, self.kw = rp, ci, kw
 
     monkeypatch.setattr(S, "DeviceGraph", FakeGraph)
     monkeypatch.setattr(S, "DeviceRWRSampler", _FakeSampler)
@@ -101,6 +102,12 @@ def test_load_balance_dataset_attributes_and_iteration(tmp_path, monkeypatch):
         load[b] += int(sizes[i])
     assert ds.jobs == bins * 2 and ds.total == 160 and len(ds) == 160 and ds.num_samples == 40
     assert ds.graph.num_nodes == int(sizes.sum())                  # disjoint union of all graphs
+    # ... laid out shard by shard in jobs order, each worker shard a node range with its own seed cdf
+    assert ds.graph_order == bins[0] + bins[1]
+    assert ds.graph.kw["shard_off"].tolist() == [0, int(sizes[bins[0]].sum()), int(sizes.sum())]
+    from tests.shard_check import reference_layout
+    _, rp_ref, ci_ref, so_ref = reference_layout(gs, num_workers=4, num_copies=2)
+    assert np.array_equal(ds.graph.rp, rp_ref) and np.array_equal(ds.graph.ci, ci_ref) and so_ref.tolist() == ds.graph.kw["shard_off"].tolist()
     assert ds.node_cap == 8 * 41
     first = list(ds)
     assert len(first) == 20 and ds.sampler.calls == [i * 8 for i in range(20)]

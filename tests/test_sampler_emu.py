@@ -136,3 +136,48 @@ def test_last_quad_of_col_idx_is_partial(coracle):
         assert len(ci) % 4 == 2
         g = EmuGraph(rp, ci, rw_hops=12)
         _compare(coracle, rp, ci, g, 3, 8, 0, seeds=[len(rp) - 2, len(rp) - 2, 0])
+
+
+def test_multi_graph_corpus_samples_per_worker_shard(coracle):
+    """LoadBalanceGraphDataset on a multi-graph corpus (graph_dataset.py:23-30,63-92): worker w draws seeds ~ deg^0.75
+    normalised over ITS graphs only, and a DataLoader batch comes from one worker -- batch i from shard i % workers.
+    Device kernel (emulator build) vs C oracle vs the Python restatement, bit-exact, over a rotation of batches."""
+    from tests.shard_check import corpus, oracle_batch, reference_layout
+
+    graphs = corpus()
+    jobs, rp, ci, shard_off = reference_layout(graphs, num_workers=2)
+    assert jobs == [[1], [3, 0, 2]]                                     # LPT: the 6000-node graph alone
+    g = EmuGraph(rp, ci, rw_hops=32, shard_off=shard_off)
+    B = 6
+    hit = set()
+    for batch in range(4):
+        first = (10 + batch) * B
+        seeds, views = oracle_batch(coracle, rp, ci, shard_off, g.ltab, g.restart_u32, B, 3, first)
+        res, status, used = emu_sample_batch(g, B, 3, first)
+        assert status == 0 and used.tolist() == seeds.tolist()
+        for v in range(2):
+            for k in KEYS:
+                assert np.array_equal(res[v][k], views[v][k]), (batch, v, k)
+        hit.add(int(np.searchsorted(shard_off, seeds[0], side="right") - 1))
+    assert hit == {0, 1}
+    # the unsharded draw over the union is a different distribution (what round 2 did): not the same seeds
+    plain = coracle.draw_seeds(O.seed_cdf(rp), 3, 10 * B, B)
+    assert plain.tolist() != oracle_batch(coracle, rp, ci, shard_off, g.ltab, g.restart_u32, B, 3, 10 * B)[0].tolist()
+
+
+def test_shard_seed_distribution_is_deg_075_within_the_shard(coracle):
+    from tests.shard_check import corpus, reference_layout
+
+    _, rp, ci, shard_off = reference_layout(corpus(), num_workers=2)
+    cdf = O.seed_cdf(rp, shard_off)
+    B = 4096
+    for sh in range(2):
+        seeds = coracle.draw_seeds(cdf, 9, sh * B, B, shard_off=shard_off, batch_size=B)
+        a, b = int(shard_off[sh]), int(shard_off[sh + 1])
+        w = np.diff(rp)[a:b].astype(np.float64) ** 0.75
+        p = w / w.sum()
+        # compare the mass of the 20 heaviest nodes of the shard with its expectation (binomial, 5 sigma)
+        top = np.argsort(w)[-20:]
+        got = np.isin(seeds - a, top).mean()
+        exp = p[top].sum()
+        assert abs(got - exp) < 5 * np.sqrt(exp * (1 - exp) / B), (sh, got, exp)

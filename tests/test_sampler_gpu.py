@@ -162,3 +162,29 @@ def test_overflow_flag(torch_cuda):
     s.sample(0)
     with pytest.raises(RuntimeError, match="edge capacity"):
         s.check_status()
+
+
+def test_multi_graph_corpus_samples_per_worker_shard(coracle):
+    """SURVEY.md 8 a-1 / a-2 on the device: LoadBalanceGraphDataset over a multi-graph corpus draws every DataLoader
+    batch's seeds from ONE worker shard (graph_dataset.py:23-30,63-92), bit-exact against the C oracle."""
+    from gcc_amd.sampler import LoadBalanceGraphDataset
+    from tests.shard_check import corpus, oracle_batch, reference_layout
+
+    graphs = corpus()
+    jobs, rp, ci, shard_off = reference_layout(graphs, num_workers=2)
+    B = 16
+    ds = LoadBalanceGraphDataset(rw_hops=32, num_workers=2, num_copies=1, num_samples=4 * B, graph=graphs, batch_size=B,
+                                 run_seed=3, device="cuda:0")
+    assert ds.jobs == jobs and ds.graph.num_shards == 2
+    assert np.array_equal(ds.graph.row_ptr.cpu().numpy(), rp)
+    shards = []
+    for i, (q, k) in enumerate(ds):                       # total // B = 8 batches of epoch 0
+        ds.sampler.check_status()
+        seeds, views = oracle_batch(coracle, rp, ci, shard_off, ds.graph.ltab.cpu().numpy(), ds.graph.restart_u32, B, 3, i * B)
+        assert ds.sampler.last_seeds().cpu().numpy().tolist() == seeds.tolist()
+        for gb, ref in zip((q, k), views):
+            got = gb.csr_numpy()
+            for key in ("node_off", "parent_nid", "row_ptr", "col_idx"):
+                assert np.array_equal(got[key], ref[key]), (i, key)
+        shards.append(int(np.searchsorted(shard_off, seeds[0], side="right") - 1))
+    assert shards == [0, 1] * 4
