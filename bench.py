@@ -345,10 +345,11 @@ def posemb_probe(sampler, posemb, first_id, nsteps, torch):
     from gcc_amd import _cabi
 
     lib = _cabi.load()
+    NCLS = 8                                                     # GCC_POSEMB_TICK_CLASSES (include/gcc_amd.h)
     views = [g for s in range(nsteps) for g in sampler.sample(first_id(s))]
     posemb.multi(views)
     torch.cuda.synchronize()
-    ticks = torch.zeros(6 * 16, dtype=torch.int64, device=views[0].node_off.device)
+    ticks = torch.zeros(NCLS * 16, dtype=torch.int64, device=views[0].node_off.device)
     lib.gcc_posemb_debug_ticks(ticks.data_ptr())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -356,13 +357,14 @@ def posemb_probe(sampler, posemb, first_id, nsteps, torch):
     e1.record()
     torch.cuda.synchronize()
     lib.gcc_posemb_debug_ticks(None)
-    t = ticks.cpu().numpy().reshape(6, 16)
+    t = ticks.cpu().numpy().reshape(NCLS, 16)
     out = dict(views=len(views), call_ms=float(e0.elapsed_time(e1)), classes={})
-    for c, name in enumerate(["small", "mid", "slot", "krylov", "big", "sparse-block"]):
+    for c, name in enumerate(["small", "mid", "slot", "krylov", "big", "sparse-block", "wave48", "wave64"]):
         items = int(t[c, 15])
         if items == 0:
             continue
-        cu_s = float(t[c, :14].sum()) / 1e8                      # 100 MHz ticks of one workgroup = one CU's LDS-resident solver
+        # 100 MHz ticks of one workgroup (one-wave classes: of one wave, four of which share a workgroup)
+        cu_s = float(t[c, :14].sum()) / 1e8 / (4 if name.startswith("wave") else 1)
         flops = float(t[c, 14])
         out["classes"][name] = dict(items=items, cu_ms_per_item=cu_s * 1e3 / items, gflop=flops / 1e9,
                                     frac_of_cu_f32_peak=(flops / cu_s / 1e9 / F32_PER_CU_GFLOPS) if cu_s > 0 and flops > 0 else None)

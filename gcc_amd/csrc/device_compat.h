@@ -51,6 +51,12 @@ template <class T> static inline T wave_shfl_down(T v, int delta)
     return src > 63 ? v : r;
 }
 template <class T> static inline T wave_bcast_first(T v) { return wave_shfl(v, 0); }
+// value of lane `src` (src must be wave-uniform): v_readlane_b32 on the device
+static inline void opaque_u64(uint64_t &) {}
+static inline void opaque_u32(uint32_t &) {}
+#define COMPILER_MEMORY_FENCE() ((void)0)
+static inline float wave_readlane(float v, int src) { return wave_shfl(v, src); }
+static inline int wave_readlane(int v, int src) { return wave_shfl(v, src); }
 // a value the caller knows to be wave-uniform (device: moved to a scalar register) / lane 63's value as a uniform
 static inline int wave_uniform(int v) { return v; }
 static inline void keep_alive(double) {}
@@ -198,6 +204,21 @@ template <class T> __device__ __forceinline__ T wave_shfl_xor(T v, int mask) { r
 template <class T> __device__ __forceinline__ T wave_shfl_up(T v, int delta) { return __shfl_up(v, delta, 64); }
 template <class T> __device__ __forceinline__ T wave_shfl_down(T v, int delta) { return __shfl_down(v, delta, 64); }
 template <class T> __device__ __forceinline__ T wave_bcast_first(T v) { return __shfl(v, 0, 64); }
+#define COMPILER_MEMORY_FENCE() asm volatile("" ::: "memory")
+__device__ __forceinline__ void opaque_u32(uint32_t &x) { asm volatile("" : "+v"(x)); }
+// hides how a 64-bit value was computed from the optimiser (it stays in two vector registers)
+__device__ __forceinline__ void opaque_u64(uint64_t &x)
+{
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    x = ((uint64_t)hi << 32) | lo;
+}
+// value of lane `src` (src must be wave-uniform): one v_readlane_b32 with the lane in a scalar register, no LDS crossbar
+__device__ __forceinline__ float wave_readlane(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(src)));
+}
+__device__ __forceinline__ int wave_readlane(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
 // a value the caller knows to be wave-uniform, moved to a scalar register (the compiler cannot tell for values that
 // come from threadIdx or a vector load: everything derived from them would stay in VGPRs and on the VALU)
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -110,7 +110,11 @@ __device__ __forceinline__ void item_args(const PosMulti &m, int item, PosArgs &
 // solver kernel is launched with a SMALL fixed grid whose workgroups pull items from their class list.  (A grid of
 // one fat workgroup per subgraph that exits early when the class does not match keeps the workgroup dispatcher
 // busy placing 160-KiB-LDS / 1024-thread workgroups that do nothing, which delays every other queue.)
-enum { kClsSmall = 0, kClsMid = 1, kClsSlot = 2, kClsKrylov = 3, kClsBig = 4, kClsCheb = 5, kNumCls = 6 };
+enum { kClsSmall = 0, kClsMid = 1, kClsSlot = 2, kClsKrylov = 3, kClsBig = 4, kClsCheb = 5, kClsW48 = 6, kClsW64 = 7, kNumCls = 8 };
+// one-wave teams (posemb_wave_kernel): deflated size <= 48 / <= 64 with at most kWaveNodes original nodes; the
+// 256-thread small class stays behind them for the (rare) leafier subgraphs
+constexpr int kWaveNodes = 256;
+constexpr int kWaveTeams = 4;        // teams (waves) per workgroup
 static_assert(kNumCls == GCC_POSEMB_TICK_CLASSES, "include/gcc_amd.h: tick buffer classes");
 struct PosHead {                     // head of the caller's workspace (zeroed per call)
     int32_t *count;                  // [4] items per class
@@ -124,6 +128,7 @@ struct PosHead {                     // head of the caller's workspace (zeroed p
     int32_t T;
     int32_t ldv;                     // longest subgraph the Krylov class has room for (node_cap / batch_size, rounded up)
     int32_t use_cheb;                // deflated sizes above GCC_POSEMB_LDS_MAX try the sparse Chebyshev class first
+    int32_t use_wave;                // deflated sizes <= 64 go to the one-wave teams
     int64_t slot_floats;
 };
 
@@ -763,6 +768,332 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
     return lost > 0 || es.bad != 0;
 }
 
+// =========================================================================
+// ONE-WAVE solver core (n' <= kNMax <= 64): the same algorithms as above -- Householder tridiagonalisation, Sturm
+// bisection, inverse iteration with partial pivoting, Gram-Schmidt inside clusters, back-transformation -- for a
+// team of ONE wave, with no workgroup barrier anywhere.  The 256-thread version above spends an item's 0.2 ms in
+// barriers and LDS round trips (62 Householder steps x 3-4 __syncthreads for ~1 MFLOP of work) while it owns a
+// quarter of a CU's LDS; here a matrix row lives in one lane (p = A v and the rank-2 update walk the row in LDS,
+// the reflector and w are broadcast with v_readlane), an eigenvalue pair of probes or an eigenvector lives in one
+// lane, the LU factors of an inverse iteration live in that lane's REGISTERS (fully unrolled elimination; no LDS
+// slots), and several independent teams share a workgroup.  Dot products over rows are DPP wave reductions.
+struct WaveTri {
+    float *dg, *of, *of2, *tau;      // [kNMax] diagonal, off-diagonal, its square, reflector scales
+    float *nrm;                      // [64] squared norms inside the Gram-Schmidt sweep
+    float *Y;                        // [n'][ldy] eigenvectors
+    int ldy;
+};
+
+// A (n x n, symmetric, both triangles, row stride lda, LDS) -> T = Q^T A Q as tridiagonalize().  Lane i owns row i.
+template <int kNMax>
+__device__ __forceinline__ void wave_tridiagonalize(float *A, int lda, int n, const WaveTri &w)
+{
+    static_assert(kNMax <= 64, "one row per lane");
+    const int lane = lane_id();
+    for (int k = 0; k + 2 < n; ++k) {
+        const float arow = (lane > k && lane < n) ? A[k * lda + lane] : 0.f;     // row k, columns k+1 .. n-1 (lane = column)
+        const float sig = wave_sum(lane > k + 1 ? arow * arow : 0.f);
+        const float x0 = wave_readlane(arow, k + 1);
+        if (sig <= 1e-30f) {                             // wave-uniform: the column is already tridiagonal, H_k = I
+            if (lane == 0) { w.dg[k] = A[k * lda + k]; w.of[k] = x0; w.tau[k] = 0.f; }
+            continue;
+        }
+        const float mu = sqrtf(x0 * x0 + sig);
+        const float beta = x0 > 0.f ? -mu : mu;
+        const float t = (beta - x0) / beta;
+        const float scale = 1.0f / (x0 - beta);
+        const float v = lane == k + 1 ? 1.0f : arow * scale;                      // v_c in lane c (0 outside k+1 .. n-1)
+        // p_i = t sum_c A[i][c] v_c  (lane = row i; the row is walked in LDS, stride lda odd: conflict free)
+        float p0 = 0.f, p1 = 0.f;
+        const float *Ai = A + (lane < n ? lane : 0) * lda;
+        int c = k + 1;
+        for (; c + 1 < n; c += 2) {
+            p0 = fmaf(Ai[c], wave_readlane(v, c), p0);
+            p1 = fmaf(Ai[c + 1], wave_readlane(v, c + 1), p1);
+        }
+        if (c < n) p0 = fmaf(Ai[c], wave_readlane(v, c), p0);
+        const bool mine = lane > k && lane < n;
+        const float p = mine ? t * (p0 + p1) : 0.f;
+        const float K = 0.5f * t * wave_sum(p * v);
+        const float wv = p - K * v;                                               // w = p - K v  (0 outside the block)
+        if (lane > k + 1 && lane < n) A[k * lda + lane] = v;                      // row k is dead: it stores the reflector
+        if (lane == 0) { w.dg[k] = A[k * lda + k]; w.of[k] = beta; w.tau[k] = t; }
+        // A[i][c] -= v_i w_c + w_i v_c on the trailing block (the broadcasts are executed by every lane, the rows by their owners)
+        {
+            float *Aw = A + (lane < n ? lane : 0) * lda;
+#pragma unroll 4
+            for (int cc = k + 1; cc < n; ++cc) {
+                const float upd = v * wave_readlane(wv, cc) + wv * wave_readlane(v, cc);
+                if (mine) Aw[cc] -= upd;
+            }
+        }
+        wave_sync();                                     // the next step reads row k + 1 across lanes
+    }
+    if (lane == 0) {
+        if (n >= 2) { w.dg[n - 2] = A[(n - 2) * lda + n - 2]; w.of[n - 2] = A[(n - 2) * lda + n - 1]; }
+        w.dg[n - 1] = A[(n - 1) * lda + n - 1];
+        w.of[n - 1] = 0.f;
+    }
+    wave_sync();
+}
+
+// the kq largest eigenvalues of T (as eig_top_values): kVec = 32 -> two probes per eigenvalue and round (trisection),
+// kVec = 64 -> one (bisection); brackets live in registers, the partner's count comes by a shuffle.
+template <int kVec>
+__device__ __forceinline__ void wave_eig_top_values(const WaveTri &w, int nr, int kq, EigShared &es)
+{
+    constexpr int kP = 64 / kVec;                         // probes per eigenvalue
+    constexpr int kRounds = kP == 2 ? 18 : 28;            // 2.002 / (kP + 1)^rounds < 1e-8
+    const int lane = lane_id();
+    if (lane < nr) w.of2[lane] = w.of[lane] * w.of[lane];
+    wave_sync();
+    const int j = lane / kP, ip = lane - j * kP;
+    const int tgt = nr - 1 - j;
+    float lo = -1.001f, hi = 1.001f;
+    for (int round = 0; round < kRounds; ++round) {
+        const float step = (hi - lo) * (1.0f / (float)(kP + 1));
+        const float x = lo + step * (float)(ip + 1);
+        const int c = j < kq ? sturm_count(w.dg, w.of2, nr, x) : 0;
+        if (kP == 2) {
+            const int co = wave_shfl_xor(c, 1);
+            const int c1 = ip == 0 ? c : co, c2 = ip == 0 ? co : c;
+            const float x1 = lo + step, x2 = lo + 2.0f * step;
+            if (c1 > tgt) hi = x1;
+            else if (c2 > tgt) { lo = x1; hi = x2; }
+            else lo = x2;
+        } else {
+            if (c > tgt) hi = x; else lo = x;
+        }
+    }
+    if (ip == 0 && j < kq) es.lamv[j] = 0.5f * (lo + hi);
+    wave_sync();
+    if (lane == 0) {
+        for (int q = 1; q < kq; ++q)
+            if (es.lamv[q] > es.lamv[q - 1]) es.lamv[q] = es.lamv[q - 1];
+        es.bad = 0;
+    }
+    wave_sync();
+}
+
+// inverse_iteration_step() with the LU factors in REGISTERS: the eliminations are fully unrolled over kNMax rows --
+// T is padded with decoupled rows (diagonal kPadDiag far outside the spectrum, zero off-diagonals, zero right-hand
+// side; see wave_pad_tridiagonal) so that the unrolled code needs no per-row guards -- and the pivots, super-diagonals
+// and swap flags of one vector never leave its lane.
+constexpr float kPadDiag = 4.0f;
+template <int kNMax>
+__device__ __forceinline__ void wave_pad_tridiagonal(const WaveTri &w, int n)
+{
+    const int lane = lane_id();
+    if (lane >= n && lane < kNMax) { w.dg[lane] = kPadDiag; w.of[lane] = 0.f; }
+    for (int i = n * w.ldy + lane; i < kNMax * w.ldy; i += 64) w.Y[i] = 0.f;      // rows n .. kNMax-1 of every vector
+    wave_sync();
+}
+
+template <int kNMax>
+__device__ __forceinline__ bool wave_inverse_iteration_step(const WaveTri &w, int n, int j, float shift, bool random_rhs, uint32_t hseed)
+{
+    float *Y = w.Y + j;
+    const int ldy = w.ldy;
+    float ud[kNMax], us[kNMax];
+    uint32_t swp[2] = {0u, 0u};                      // row i swapped <=> bit i & 31 of swp[i >> 5]
+    COMPILER_MEMORY_FENCE();                         // T is re-read per solve: hoisted out of the caller's loop it would sit in 2 kNMax registers
+    if (random_rhs)                                  // (outside the unrolled elimination: the hashes would be kept in registers)
+        for (int i = 0; i < n; ++i) Y[i * ldy] = hash_unit(hseed, (uint32_t)j, (uint32_t)i);
+    float cd = w.dg[0] - shift, cs = w.of[0];
+    float cy = Y[0];
+#pragma unroll
+    for (int i = 0; i < kNMax - 1; ++i) {
+        const float sub = w.of[i], nd = w.dg[i + 1] - shift, ns = i + 2 < kNMax ? w.of[i + 1] : 0.f;
+        const float by = Y[(i + 1) * ldy];
+        const bool swap = fabsf(cd) < fabsf(sub);
+        const float piv = swap ? sub : cd, oth = swap ? cd : sub;
+        const float mult = piv != 0.f ? oth * fast_rcp(piv) : 0.f;
+        ud[i] = piv;
+        us[i] = swap ? nd : cs;
+        swp[i >> 5] |= swap ? (1u << (i & 31)) : 0u;
+        opaque_u32(swp[i >> 5]);                     // accumulated here and now: not kNMax separate registers OR-ed at the end
+        Y[i * ldy] = swap ? by : cy;
+        const float ncd = swap ? cs - mult * nd : nd - mult * cs;
+        const float ncs = swap ? -mult * ns : ns;
+        const float ncy = swap ? cy - mult * by : by - mult * cy;
+        cd = ncd; cs = ncs; cy = ncy;
+        if ((i & 3) == 3) SCHED_FENCE();             // keeps the scheduler from issuing all rows' LDS reads up front (registers)
+    }
+    // (opaque: were the bits recognisable as the comparisons above, the compiler would keep all kNMax lane masks alive in
+    //  scalar register pairs for the back substitution instead of these two words, and spill them)
+    COMPILER_MEMORY_FENCE();                         // the off-diagonals are read again below: reloaded, not kept in kNMax registers
+    float x1, x2 = 0.f, ss;
+    {   // last row
+        float d = cd;
+        if (fabsf(d) < kPivTiny) d = d < 0.f ? -kPivTiny : kPivTiny;
+        const float x = cy * fast_rcp(d);
+        Y[(kNMax - 1) * ldy] = x;
+        x1 = x;
+        ss = x * x;
+    }
+#pragma unroll
+    for (int i = kNMax - 2; i >= 0; --i) {
+        float d = ud[i];
+        if (fabsf(d) < kPivTiny) d = d < 0.f ? -kPivTiny : kPivTiny;
+        const float s2 = (((swp[i >> 5] >> (i & 31)) & 1u) && i + 2 < kNMax) ? w.of[i + 1] : 0.f;
+        const float x = (Y[i * ldy] - us[i] * x1 - s2 * x2) * fast_rcp(d);
+        Y[i * ldy] = x;
+        x2 = x1; x1 = x;
+        ss = fmaf(x, x, ss);
+        if ((i & 3) == 0) SCHED_FENCE();
+    }
+    const bool ok = ss > 0.f && ss < 3.0e38f;
+    const float inv = ok ? 1.0f / sqrtf(ss) : 0.f;
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) Y[i * ldy] *= inv;
+    return ok;
+}
+
+// cluster_orthonormalize() for one wave: lane = row of Y.  Members are taken in index order (the members of a cluster are
+// consecutive and its predecessors finished), projections on all predecessors are computed from the same vector (classical
+// Gram-Schmidt, a second pass where the first removed more than half: "twice is enough").
+__device__ __forceinline__ int wave_cluster_orthonormalize(const WaveTri &w, int n, int na, const int *cs, const int *posi, int maxpos,
+                                                           float *min_left, uint32_t hseed)
+{
+    *min_left = 1.0f;
+    if (maxpos == 0) return 0;
+    const int lane = lane_id();
+    float *Y = w.Y;
+    const int ldy = w.ldy;
+    const bool row = lane < n;
+    if (lane < na) w.nrm[lane] = 1.0f;                    // unit vectors come out of the solves
+    wave_sync();
+    int lost = 0;
+    float left = 1.0f;
+    for (int j = 0; j < na; ++j) {
+        if (posi[j] == 0) continue;                       // wave-uniform (LDS broadcast)
+        const int c0 = cs[j];
+        float y = row ? Y[lane * ldy + j] : 0.f;
+        float now = 1.0f;
+        for (int pass = 0; pass < 2; ++pass) {
+            float acc = 0.f;
+            for (int l = c0; l < j; ++l) {
+                const float nl = w.nrm[l];
+                const float yl = row ? Y[lane * ldy + l] : 0.f;
+                const float s = wave_sum(y * yl);
+                const float cf = nl >= kVanish ? s / nl : 0.f;   // a vanished predecessor spans nothing
+                acc = fmaf(cf, yl, acc);
+            }
+            y -= acc;
+            now = wave_sum(y * y);
+            if (!(pass == 0 && now < 0.5f)) break;
+        }
+        if (row) Y[lane * ldy + j] = y;
+        if (lane == 0) w.nrm[j] = now;
+        left = now < left ? now : left;
+        if (now < kVanish) ++lost;
+        wave_sync();
+    }
+    for (int j = 0; j < na; ++j) {                        // normalise; vanished members restart from pseudo-random numbers
+        if (posi[j] == 0) continue;
+        const float c = w.nrm[j];
+        if (row) {
+            if (c < kVanish) Y[lane * ldy + j] = hash_unit(hseed, (uint32_t)j, (uint32_t)lane);
+            else Y[lane * ldy + j] *= 1.0f / sqrtf(c);
+        }
+    }
+    wave_sync();
+    *min_left = left;
+    return lost;
+}
+
+// eig_top_vectors() for one wave: eigenvectors 0 .. na-1 of the matrix wave_tridiagonalize() reduced, in w.Y[i * ldy + j].
+// kVec = 32: na <= 32 and the back-transformation splits the rows of a reflector between the two half-waves.
+template <int kNMax, int kVec>
+__device__ __forceinline__ bool wave_eig_top_vectors(const float *A, int lda, int nr, int na, const WaveTri &w, EigShared &es, uint32_t hseed,
+                                                     long long *tick_row, long long &tick)
+{
+    const int lane = lane_id();
+    const int ldy = w.ldy;
+    if (lane == 0) {
+        // clusters and shifts exactly as eig_top_vectors(): chains of eigenvalues closer than kOrtol are orthogonalised
+        // against each other; the copies of a numerically multiple eigenvalue are displaced away from the nearest other one
+        int maxpos = 0;
+        for (int j = 0; j < na; ++j) {
+            es.shiftv[j] = es.lamv[j];
+            es.cs[j] = (j > 0 && es.lamv[j - 1] - es.lamv[j] <= kOrtol) ? es.cs[j - 1] : j;
+            es.posi[j] = j - es.cs[j];
+            maxpos = es.posi[j] > maxpos ? es.posi[j] : maxpos;
+        }
+        for (int j = 0; j < na;) {
+            int b = j;
+            while (b + 1 < na && es.lamv[b] - es.lamv[b + 1] < kSep) ++b;
+            const int c = b - j + 1;
+            if (c > 1) {
+                float room_up = 2.0f;
+                if (j > 0) room_up = fminf(es.lamv[j - 1], es.shiftv[j - 1]) - es.lamv[j];
+                const float room_dn = b + 1 < na ? es.lamv[b] - es.lamv[b + 1] : (na >= nr ? 2.0f : 0.0f);
+                const bool up = room_up >= room_dn;
+                const float room = up ? room_up : room_dn;
+                float step = kSep;
+                if ((float)c * step > 0.5f * room) step = fmaxf(0.5f * room / (float)c, 2.5e-7f);
+                for (int mm = 1; mm < c; ++mm) es.shiftv[j + mm] = up ? es.lamv[j] + (float)mm * step : es.lamv[b] - (float)mm * step;
+            }
+            j = b + 1;
+        }
+        es.maxpos = maxpos;
+    }
+    wave_sync();
+    wave_pad_tridiagonal<kNMax>(w, nr);
+    const int maxpos = es.maxpos;
+    int lost = 0;
+    int need_until = 2;
+    for (int it = 0; it < kMaxInvIt; ++it) {
+        if (lane < na) {
+            const int j = lane;
+            const bool frozen = it >= 2 && es.shiftv[j] == es.lamv[j] && j + 1 < na && es.lamv[j] - es.lamv[j + 1] < kSep;
+            if (!frozen) {
+                const bool ok = wave_inverse_iteration_step<kNMax>(w, nr, j, es.shiftv[j], it == 0, hseed);
+                if (!ok) es.bad = 1;
+            }
+        }
+        wave_sync();
+        if (tick_row && lane == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&tick_row[3], (unsigned long long)(now_ - tick)); tick = now_; }
+        if (it > 0) {
+            float left;
+            lost = wave_cluster_orthonormalize(w, nr, na, es.cs, es.posi, maxpos, &left, hseed ^ (0x51ED27u * (uint32_t)(it + 1)));
+            if (lost > 0) need_until = it + 3 > need_until ? it + 3 : need_until;
+            else if (left < kHeavy) need_until = it + 1 > need_until ? it + 1 : need_until;
+        }
+        if (tick_row && lane == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&tick_row[4], (unsigned long long)(now_ - tick)); tick = now_; }
+        if (lane == 0) { es.diag_lost = lost; es.diag_its = it + 1; }
+        if (it >= need_until) break;
+    }
+    // x = H_0 ... H_{nr-3} y: lane = vector; with na <= 32 the half-wave h takes the rows c = kk + 1 + h, kk + 3 + h, ...
+    {
+        constexpr int kH = kVec == 32 ? 2 : 1;
+        const int j = kH == 2 ? (lane & 31) : lane, h = kH == 2 ? (lane >> 5) : 0;
+        const bool act = j < na;
+        float *Yj = w.Y + (act ? j : 0);
+        for (int kk = nr - 3; kk >= 0; --kk) {
+            const float t = w.tau[kk];
+            if (t == 0.f) continue;                      // wave-uniform
+            const float *vk = A + kk * lda;              // reflector kk: v[kk+1] = 1, v[c] = vk[c] for c > kk + 1
+            float s = 0.f;
+            for (int c = kk + 1 + h; c < nr; c += kH) {
+                const float vc = c == kk + 1 ? 1.0f : vk[c];
+                s = fmaf(vc, act ? Yj[c * ldy] : 0.f, s);
+            }
+            if (kH == 2) s += wave_shfl_xor(s, 32);
+            s *= t;
+            if (act)
+                for (int c = kk + 1 + h; c < nr; c += kH) {
+                    const float vc = c == kk + 1 ? 1.0f : vk[c];
+                    Yj[c * ldy] = fmaf(-s, vc, Yj[c * ldy]);
+                }
+            if (kH == 2) wave_sync();                    // the next reflector pairs the rows with the other half-wave
+        }
+    }
+    wave_sync();
+    if (tick_row && lane == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&tick_row[5], (unsigned long long)(now_ - tick)); tick = now_; }
+    return lost > 0 || es.bad != 0;
+}
+
 // one wave per subgraph: deflated size -> class list; k <= 0 subgraphs are finished here (zeros, data_util.py:243-244)
 constexpr int kClsThreads = 256;
 __global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m, PosHead hd)
@@ -795,7 +1126,8 @@ __global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m
         for (int i = lane; i < n; i += 64) zz += t[i] >= 2 ? t[i] - 1 : 0;
         for (int dd = 32; dd >= 1; dd >>= 1) zz += wave_shfl_xor(zz, dd);
         const int nr = n - zz;                         // t >= 2 leaves of one parent count once
-        cls = nr <= kJSmall ? kClsSmall : nr <= kJMax ? kClsMid : hd.use_cheb ? kClsCheb : nr <= kGMax ? kClsSlot : nr <= kBMax ? kClsBig : kClsKrylov;
+        cls = (hd.use_wave && nr <= 64 && n <= kWaveNodes) ? (nr <= 48 ? kClsW48 : kClsW64)
+            : nr <= kJSmall ? kClsSmall : nr <= kJMax ? kClsMid : hd.use_cheb ? kClsCheb : nr <= kGMax ? kClsSlot : nr <= kBMax ? kClsBig : kClsKrylov;
     }
     if (cls == kClsKrylov && n >= hd.ldv) {          // no room: the caller's node_cap / batch_size must bound every subgraph
         for (int i = lane; i < n * a.hidden; i += 64) a.pos[(int64_t)n0 * a.hidden + i] = 0.f;
@@ -1023,6 +1355,203 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     }
     PHASE_TICK(6);                                 // expansion
     }   // next item
+}
+
+
+// ---- one subgraph per WAVE (deflated size <= kNMax <= 64, at most kWaveNodes original nodes): kWaveTeams independent
+// teams per workgroup, each with its own LDS carve-up, pulling items from the class list; no workgroup barrier.
+template <int kNMax>
+__host__ __device__ constexpr int wave_team_bytes()
+{
+    // A | Y | dg, of, of2, tau | nrm | per-node expansion records (8 bytes)   [the deflation tables overlay Y]
+    return (int)sizeof(float) * (kNMax * (kNMax + 1) + kNMax * kYld + 4 * kNMax + 64) + kWaveNodes * 8;
+}
+
+// (register budget: the LU factors of an inverse iteration take 2 kNMax registers per lane; without an occupancy
+//  target the scheduler spreads the unrolled eliminations over all 512)
+template <int kCls, int kNMax>
+__global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? 2 : 1) void posemb_wave_kernel(PosMulti m, PosHead hd)
+{
+    static_assert(kNMax <= 64 && kNMax * kYld * 4 >= kWaveNodes * 16, "the deflation tables overlay Y");
+    DYN_SMEM(smem);
+    __shared__ EigShared es_all[kWaveTeams];
+    __shared__ int colsrc_all[kWaveTeams][64];
+    constexpr int lda = kNMax + 1;                   // odd: lane = row and lane = column are both conflict free
+    const int lane = lane_id(), team = (int)threadIdx.x >> 6;
+    float *A = (float *)(smem + (size_t)team * wave_team_bytes<kNMax>());
+    WaveTri w;
+    w.Y = A + kNMax * lda;
+    w.ldy = kYld;
+    w.dg = w.Y + kNMax * kYld;
+    w.of = w.dg + kNMax;
+    w.of2 = w.of + kNMax;
+    w.tau = w.of2 + kNMax;
+    w.nrm = w.tau + kNMax;
+    uint16_t *xinfo = (uint16_t *)(w.nrm + 64);      // [kWaveNodes][4]: Y row, leaf order, twins of the parent, its contrast base
+    EigShared &es = es_all[team];
+    int *colsrc = colsrc_all[team];
+    for (;;) {                                       // items of this class, one per wave
+    int item = 0;
+    if (lane == 0) item = atomicAdd(hd.next + kCls, 1);
+    item = wave_bcast_first(item);
+    if (item >= hd.count[kCls]) return;
+    const int gb = hd.list[(int64_t)kCls * hd.T + item];
+    PosArgs a;
+    int b;
+    item_args(m, gb, a, b);
+    const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+    const int k = min(min(n - 2, a.hidden), kMaxVec);   // data_util.py:278; k >= 1 (classify kernel)
+    long long tick_ = m.ticks ? device_ticks() : 0;
+    if (m.ticks && lane == 0) atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 15], 1ull);   // items
+#define WAVE_TICK(ph) do { if (m.ticks && lane == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
+    const int32_t *rp = a.row_ptr + n0;
+    // ---- leaf groups (tables in the Y region: dead again before the first eigenvector is written)
+    Defl d;
+    d.tcnt = (int32_t *)w.Y;
+    d.cbase = d.tcnt + kWaveNodes;
+    d.par = (uint16_t *)(d.cbase + kWaveNodes);
+    d.rep = d.par + kWaveNodes;
+    d.ridx = d.rep + kWaveNodes;
+    d.ord = d.ridx + kWaveNodes;
+    for (int i = lane; i < n; i += 64) {
+        const int dg = rp[i + 1] - rp[i];
+        d.par[i] = dg == 1 ? (uint16_t)(a.col_idx[rp[i]] - n0) : kNone;
+        d.tcnt[i] = 0;
+        d.rep[i] = kNone;
+        d.ord[i] = 0;
+    }
+    wave_sync();
+    for (int i = lane; i < n; i += 64)
+        if (d.par[i] != kNone) atomicAdd(&d.tcnt[d.par[i]], 1);
+    wave_sync();
+    for (int p = lane; p < n; p += 64) {             // rows are sorted: a parent's leaves in index order
+        if (d.tcnt[p] >= 2) {
+            int o = 0;
+            for (int e = rp[p]; e < rp[p + 1]; ++e) {
+                const int j = a.col_idx[e] - n0;
+                if (d.par[j] == (uint16_t)p) {
+                    if (o == 0) d.rep[p] = (uint16_t)j;
+                    d.ord[j] = (uint16_t)o++;
+                }
+            }
+        }
+    }
+    wave_sync();
+    int nr = 0, z = 0;                               // reduced size n', number of contrast null vectors
+    for (int i0 = 0; i0 < n; i0 += 64) {             // prefixes over the nodes, 64 at a time
+        const int i = i0 + lane;
+        const bool valid = i < n;
+        const int tc = valid ? d.tcnt[i] : 0;
+        const int extra = tc >= 2 ? tc - 1 : 0;
+        const int pi = valid ? (int)d.par[i] : (int)kNone;
+        const bool collapsed = valid && pi != (int)kNone && d.tcnt[pi] >= 2 && d.rep[pi] != (uint16_t)i;
+        const bool kept = valid && !collapsed;
+        const int incl = wave_scan_incl(extra);
+        const unsigned long long km = wave_ballot(kept);
+        if (valid) {
+            d.cbase[i] = z + incl - extra;
+            d.ridx[i] = kept ? (uint16_t)(nr + __popcll(km & lanemask_lt())) : kNone;
+        }
+        nr += __popcll(km);
+        z += wave_last(incl);
+    }
+    wave_sync();
+    if (nr > kNMax || nr < 1) continue;              // cannot happen: the classify kernel computed the same size
+    for (int i = lane; i < nr * lda; i += 64) A[i] = 0.f;
+    wave_sync();
+    // M' = norm * adj * norm on the kept nodes (data_util.py:273-277), super-leaf couplings scaled by sqrt(t); lane = row
+    for (int i = lane; i < n; i += 64) {
+        if (d.ridx[i] == kNone) continue;
+        const int ri = d.ridx[i];
+        const int di = rp[i + 1] - rp[i];
+        for (int e = rp[i]; e < rp[i + 1]; ++e) {
+            const int j = a.col_idx[e] - n0;
+            if (d.ridx[j] == kNone) continue;
+            const int dj = rp[j + 1] - rp[j];
+            float val = 1.0f / sqrtf((float)di * (float)dj);      // in_degrees().clip(1) ** -0.5 on both sides
+            if (d.par[j] == (uint16_t)i && d.tcnt[i] >= 2) val *= sqrtf((float)d.tcnt[i]);
+            if (d.par[i] == (uint16_t)j && d.tcnt[j] >= 2) val *= sqrtf((float)d.tcnt[j]);
+            A[ri * lda + d.ridx[j]] = val;
+        }
+    }
+    // what the expansion at the end needs of the tables, 8 bytes per node
+    for (int v = lane; v < n; v += 64) {
+        const int pv = d.par[v];
+        const bool grouped = pv != (int)kNone && d.tcnt[pv] >= 2;
+        xinfo[4 * v + 0] = grouped ? d.ridx[d.rep[pv]] : d.ridx[v];
+        xinfo[4 * v + 1] = d.ord[v];
+        xinfo[4 * v + 2] = (uint16_t)(grouped ? d.tcnt[pv] : 0);
+        xinfo[4 * v + 3] = (uint16_t)(grouped ? d.cbase[pv] : 0);
+    }
+    wave_sync();
+    WAVE_TICK(0);                                    // deflation + matrix
+    wave_tridiagonalize<kNMax>(A, lda, nr, w);
+    WAVE_TICK(1);
+    const int kq = min(k, nr);
+    wave_eig_top_values<kMaxVec>(w, nr, kq, es);
+    WAVE_TICK(2);                                    // bisection
+    // ---- ranks: positive, null space = zeros of M' then the z contrasts, negative; eigsh(which="LA") returns the k
+    //      largest in ascending order (data_util.py:251)
+    colsrc[lane] = 0;
+    wave_sync();
+    int na = 0;
+    if (lane == 0) {
+        int npz = 0;
+        for (int j = 0; j < kq; ++j) {
+            const float l = es.lamv[j];
+            const int r = l < -kZeroEig ? j + z : j;
+            if (l >= -kZeroEig) npz = j + 1;
+            if (r < k) {
+                na = j + 1;
+                colsrc[k - 1 - r] = j;
+                if (a.evals) a.evals[(int64_t)b * a.hidden + (k - 1 - r)] = fabsf(l) <= kZeroEig ? 0.f : l;
+            }
+        }
+        for (int c = 0; c < z && npz + c < k; ++c) {              // contrast c has rank npz + c
+            colsrc[k - 1 - (npz + c)] = -(c + 1);
+            if (a.evals) a.evals[(int64_t)b * a.hidden + (k - 1 - (npz + c))] = 0.f;
+        }
+    }
+    na = wave_bcast_first(na);
+    if (a.evals) for (int i = k + lane; i < a.hidden; i += 64) a.evals[(int64_t)b * a.hidden + i] = 0.f;
+    wave_sync();
+    const bool failed = wave_eig_top_vectors<kNMax, kMaxVec>(A, lda, nr, na, w, es, (uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u),
+                                                            m.ticks ? m.ticks + kCls * 16 : nullptr, tick_);
+    if (lane == 0 && failed) {
+        atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
+        if (atomicAdd(a.status + 4, 1) == 0) {               // diagnostics: the first item that failed
+            a.status[5] = gb; a.status[6] = kCls; a.status[7] = nr; a.status[8] = es.bad; a.status[9] = n;
+            a.status[10] = es.diag_lost; a.status[11] = es.diag_its; a.status[12] = es.maxpos; a.status[13] = na;
+        }
+    }
+    // ---- expand to the n original nodes; x = normalize(u, "l2") row-wise, zero padded (data_util.py:260-262); lane = column
+    const int src = lane < k ? colsrc[lane] : 0;
+    for (int v = 0; v < n; ++v) {
+        const int rsrc = xinfo[4 * v + 0], o = xinfo[4 * v + 1], tp = xinfo[4 * v + 2], cb = xinfo[4 * v + 3];
+        float val = 0.f;
+        if (lane < k) {
+            if (src >= 0) {
+                val = w.Y[rsrc * kYld + src] * (tp ? 1.0f / sqrtf((float)tp) : 1.0f);
+            } else if (tp) {
+                const int jm1 = -src - 1 - cb;                   // contrast j = jm1 + 1 of the parent
+                if (jm1 >= 0 && jm1 < tp - 1) {
+                    const int j = jm1 + 1;
+                    const float nrm = 1.0f / sqrtf((float)(j * (j + 1)));
+                    val = o < j ? nrm : (o == j ? -(float)j * nrm : 0.f);
+                }
+            }
+        }
+        const float s2 = wave_sum(val * val);
+        const float inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
+        if (lane < a.hidden) {
+            a.pos[(int64_t)(n0 + v) * a.hidden + lane] = val * inv;
+            if (a.raw) a.raw[(int64_t)(n0 + v) * a.hidden + lane] = val;
+        }
+    }
+    WAVE_TICK(6);                                    // expansion
+    wave_sync();                                     // the next item reuses the team's LDS
+    }   // next item
+#undef WAVE_TICK
 }
 
 
@@ -2117,19 +2646,19 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
 extern "C" {
 
 static long long *g_posemb_ticks = nullptr;
-struct PosGrids { int32_t small, mid, slot, kry, big, cheb; };
+struct PosGrids { int32_t small, mid, slot, kry, big, cheb, w48, w64; };
 static PosGrids posemb_grids(int64_t T)
 {
     // fixed grids: enough workgroups for the typical class sizes (~73 % / 19 % / 6 % / 2 % of a batch at rw_hops 256);
     // larger classes loop.  No class may cover more than half of the 256 CUs (small: 2 workgroups per CU): a solver
     // workgroup holds most of a CU's LDS for milliseconds, and when every CU has one the training step's kernels whose
     // workgroups do not fit beside it wait for the whole launch to drain (3-5 ms stalls in the kernel trace).
-    static int caps[6] = {0, 0, 0, 0, 0, 0};
-    if (caps[0] == 0) {                              // tuning knob: GCC_POSEMB_GRID_CAPS="small,mid,slot,krylov,big,cheb"
-        int c[6] = {256, 128, 128, 64, 64, 128};
+    static int caps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (caps[0] == 0) {                              // tuning knob: GCC_POSEMB_GRID_CAPS="small,mid,slot,krylov,big,cheb,w48,w64"
+        int c[8] = {256, 128, 128, 64, 64, 128, 128, 64};
         const char *e = getenv("GCC_POSEMB_GRID_CAPS");
-        if (e) (void)sscanf(e, "%d,%d,%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3], &c[4], &c[5]);
-        for (int i = 0; i < 6; ++i) caps[i] = c[i] < 1 ? 1 : c[i];
+        if (e) (void)sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3], &c[4], &c[5], &c[6], &c[7]);
+        for (int i = 0; i < 8; ++i) caps[i] = c[i] < 1 ? 1 : c[i];
     }
     PosGrids g;
     g.small = (int32_t)(T < caps[0] ? T : caps[0]);
@@ -2138,6 +2667,10 @@ static PosGrids posemb_grids(int64_t T)
     g.kry = (int32_t)((T + 15) / 16 < caps[3] ? (T + 15) / 16 : caps[3]);
     g.big = (int32_t)((T + 15) / 16 < caps[4] ? (T + 15) / 16 : caps[4]);
     g.cheb = (int32_t)((T + 7) / 8 < caps[5] ? (T + 7) / 8 : caps[5]);
+    // one-wave teams: kWaveTeams items in flight per workgroup
+    const int64_t wg = (T + kWaveTeams - 1) / kWaveTeams;
+    g.w48 = (int32_t)(wg < caps[6] ? wg : caps[6]);
+    g.w64 = (int32_t)((wg + 1) / 2 < caps[7] ? (wg + 1) / 2 : caps[7]);
     return g;
 }
 static int64_t posemb_head_bytes(int64_t T) { return ((16 + kNumCls * T) * 4 + 255) / 256 * 256; }
@@ -2204,6 +2737,8 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     {
         const char *e = getenv("GCC_POSEMB_CHEB");
         hd.use_cheb = e ? atoi(e) != 0 : 1;
+        const char *ew = getenv("GCC_POSEMB_WAVE");   // 0: the 256-thread small class takes every n' <= 64 (A/B runs)
+        hd.use_wave = ew ? atoi(ew) != 0 : 1;
     }
     constexpr int lds_small = direct_lds_bytes<kJSmall, kSmallT, false>();
     constexpr int lds_big = direct_lds_bytes<kJMax, 1024, false>();
@@ -2218,6 +2753,10 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kGLds);
         (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsBig, kGMax + 1, kBMax, 1024, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kBLds);
+        (void)hipFuncSetAttribute((const void *)posemb_wave_kernel<kClsW48, 48>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kWaveTeams * wave_team_bytes<48>());
+        (void)hipFuncSetAttribute((const void *)posemb_wave_kernel<kClsW64, 64>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kWaveTeams * wave_team_bytes<64>());
         attr_set = true;
     }
 #endif
@@ -2262,6 +2801,10 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     hipLaunchKernelGGL((posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>), dim3(g.slot), dim3(1024), kGLds, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, 1024, false>), dim3(g.mid), dim3(1024), lds_big, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsSmall, 0, kJSmall, kSmallT, false>), dim3(g.small), dim3(kSmallT), lds_small, s, m, hd);
+    if (hd.use_wave) {
+        hipLaunchKernelGGL((posemb_wave_kernel<kClsW64, 64>), dim3(g.w64), dim3(kWaveTeams * 64), kWaveTeams * wave_team_bytes<64>(), s, m, hd);
+        hipLaunchKernelGGL((posemb_wave_kernel<kClsW48, 48>), dim3(g.w48), dim3(kWaveTeams * 64), kWaveTeams * wave_team_bytes<48>(), s, m, hd);
+    }
     prof_mark(prof, 1, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_posemb: %s", hipGetErrorString(e)); return -10; }

@@ -176,10 +176,12 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
                          gcc_prof *prof, void *stream);
 
 /* diagnostics: subsequent gcc_posemb* calls add wall-clock ticks (100 MHz) per solver class and phase into
- * device int64[GCC_POSEMB_TICK_CLASSES][16] -- SIX classes: small, mid, slot, Krylov, big, sparse block (Chebyshev);
+ * device int64[GCC_POSEMB_TICK_CLASSES][16] -- EIGHT classes: small, mid, slot, Krylov, big, sparse block (Chebyshev),
+ * one-wave teams n' <= 48, one-wave teams n' <= 64 (their ticks are WAVE time: 4 teams share a workgroup);
  * phases of the dense classes 0..6 = matrix, tridiagonalise, bisect, inverse iteration, Gram-Schmidt, back-transform,
- * expand; [15] = items; NULL switches it off.  A buffer sized for fewer classes is written out of bounds. */
-#define GCC_POSEMB_TICK_CLASSES 6
+ * expand; [14] = executed f32 FLOPs; [15] = items; NULL switches it off.  A buffer sized for fewer classes is written
+ * out of bounds. */
+#define GCC_POSEMB_TICK_CLASSES 8
 void gcc_posemb_debug_ticks(long long *device_ticks64);
 /* the same for gin_in_kernel: device int64[2][16] ([0] = first layer, [1] = others; [15] = tiles) */
 void gcc_gin_debug_ticks(long long *device_ticks64);

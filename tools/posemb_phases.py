@@ -17,20 +17,25 @@ sampler = DeviceRWRSampler(graph, B, run_seed=0, num_buffers=S)
 pe = DevicePosEmb(B, sampler.node_cap, 32, device=dev, seed=0, num_buffers=S, max_views=2 * S)
 views = [g for s in range(S) for g in sampler.sample(10_000_000 + s * B)]
 lib = _cabi.load()
-ticks = torch.zeros(96, dtype=torch.int64, device=dev)
+NCLS = 8      # GCC_POSEMB_TICK_CLASSES
+ticks = torch.zeros(NCLS * 16, dtype=torch.int64, device=dev)
 pe.multi(views); torch.cuda.synchronize()
 lib.gcc_posemb_debug_ticks(ticks.data_ptr())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); pe.multi(views); e1.record(); torch.cuda.synchronize()
 lib.gcc_posemb_debug_ticks(None)
-t = ticks.cpu().numpy().reshape(6, 16)
+t = ticks.cpu().numpy().reshape(NCLS, 16)
 print("multi call of %d views: %.2f ms" % (len(views), e0.elapsed_time(e1)))
 names = {0: ["matrix", "tridiag", "bisect", "invit", "gram-schmidt", "backtransf", "expand"], 3: ["arnoldi", "ritz(H)", "restart", "final"],
          5: ["matrix", "sparse-products", "ritz", "rotate", "expand", "gram", "cholesky", "inverse+H"]}
-for c, cname in enumerate(["small", "mid", "slot", "krylov", "big", "cheb"]):
+grand = 0.0
+for c, cname in enumerate(["small", "mid", "slot", "krylov", "big", "cheb", "wave48", "wave64"]):
     items = max(int(t[c, 15]), 1)
     ph = names.get(c, names[0])
-    tot = t[c, :len(ph)].sum() / 100.0          # us
+    share = 4.0 if cname.startswith("wave") else 1.0    # one-wave teams: 4 items in flight per workgroup, ticks are wave time
+    tot = t[c, :len(ph)].sum() / 100.0 / share          # us of workgroup residency
+    grand += tot
     print(f"{cname:7s} items {items:5d}  total {tot/1e3:8.2f} CU-ms  per item {tot/items:8.1f} us  | " +
           "  ".join(f"{n} {t[c, i]/100.0/items:7.1f}" for i, n in enumerate(ph)))
+print("total %.2f CU-s per call" % (grand / 1e6))
 print("status", pe.status.cpu().tolist())
