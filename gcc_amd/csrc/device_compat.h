@@ -52,6 +52,12 @@ template <class T> static inline T wave_shfl_down(T v, int delta)
 }
 template <class T> static inline T wave_bcast_first(T v) { return wave_shfl(v, 0); }
 // value of lane `src` (src must be wave-uniform): v_readlane_b32 on the device
+// sum over each half of the wave (lanes 0-31 / 32-63), returned in every lane of the half
+static inline float half32_sum(float v)
+{
+    for (int d = 1; d <= 16; d <<= 1) v += wave_shfl_xor(v, d);
+    return v;
+}
 static inline void opaque_u64(uint64_t &) {}
 static inline void opaque_u32(uint32_t &) {}
 #define COMPILER_MEMORY_FENCE() ((void)0)
@@ -288,6 +294,14 @@ __device__ __forceinline__ double wave_sum(double v)
 {
     v = wave_scan_incl_dpp(v);
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+// sum over each half of the wave (lanes 0-31 / 32-63), returned in every lane of the half: one DPP scan, two v_readlane
+__device__ __forceinline__ float half32_sum(float v)
+{
+    const float sc = wave_scan_incl_dpp(v);
+    const float t31 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), 31));
+    const float t63 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), 63));
+    return lane_id() < 32 ? t31 : t63 - t31;
 }
 template <int kCtrl, int kRowMask> __device__ __forceinline__ float dpp_or_self(float v)
 {

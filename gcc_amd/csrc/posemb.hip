@@ -803,15 +803,22 @@ __device__ __forceinline__ void wave_tridiagonalize(float *A, int lda, int n, co
         const float t = (beta - x0) / beta;
         const float scale = 1.0f / (x0 - beta);
         const float v = lane == k + 1 ? 1.0f : arow * scale;                      // v_c in lane c (0 outside k+1 .. n-1)
-        // p_i = t sum_c A[i][c] v_c  (lane = row i; the row is walked in LDS, stride lda odd: conflict free)
+        // p_i = t sum_c A[i][c] v_c  (lane = row i; the row is walked in LDS, stride lda odd: conflict free), eight row
+        // entries requested at a time: one wave per SIMD has nothing else to cover an LDS round trip with
         float p0 = 0.f, p1 = 0.f;
         const float *Ai = A + (lane < n ? lane : 0) * lda;
         int c = k + 1;
-        for (; c + 1 < n; c += 2) {
-            p0 = fmaf(Ai[c], wave_readlane(v, c), p0);
-            p1 = fmaf(Ai[c + 1], wave_readlane(v, c + 1), p1);
+        for (; c + 8 <= n; c += 8) {
+            float ar[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ar[u] = Ai[c + u];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                p0 = fmaf(ar[u], wave_readlane(v, c + u), p0);
+                p1 = fmaf(ar[u + 1], wave_readlane(v, c + u + 1), p1);
+            }
         }
-        if (c < n) p0 = fmaf(Ai[c], wave_readlane(v, c), p0);
+        for (; c < n; ++c) p0 = fmaf(Ai[c], wave_readlane(v, c), p0);
         const bool mine = lane > k && lane < n;
         const float p = mine ? t * (p0 + p1) : 0.f;
         const float K = 0.5f * t * wave_sum(p * v);
@@ -821,8 +828,19 @@ __device__ __forceinline__ void wave_tridiagonalize(float *A, int lda, int n, co
         // A[i][c] -= v_i w_c + w_i v_c on the trailing block (the broadcasts are executed by every lane, the rows by their owners)
         {
             float *Aw = A + (lane < n ? lane : 0) * lda;
-#pragma unroll 4
-            for (int cc = k + 1; cc < n; ++cc) {
+            int cc = k + 1;
+            for (; cc + 8 <= n; cc += 8) {
+                float ar[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ar[u] = Aw[cc + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ar[u] -= v * wave_readlane(wv, cc + u) + wv * wave_readlane(v, cc + u);
+                if (mine) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) Aw[cc + u] = ar[u];
+                }
+            }
+            for (; cc < n; ++cc) {
                 const float upd = v * wave_readlane(wv, cc) + wv * wave_readlane(v, cc);
                 if (mine) Aw[cc] -= upd;
             }
@@ -837,33 +855,77 @@ __device__ __forceinline__ void wave_tridiagonalize(float *A, int lda, int n, co
     wave_sync();
 }
 
-// the kq largest eigenvalues of T (as eig_top_values): kVec = 32 -> two probes per eigenvalue and round (trisection),
-// kVec = 64 -> one (bisection); brackets live in registers, the partner's count comes by a shuffle.
+// Sturm counts of TWO probe points at once: the recurrence of one point is a chain of dependent operations (reciprocal,
+// fused multiply-add, compare: ~40 cycles per row) that a single wave on its SIMD cannot hide; a second, independent chain
+// rides in its shadow, and the rows of T are requested four at a time.
+__device__ __forceinline__ void sturm_count2(const float *dg, const float *of2, int n, float xa, float xb, int &ca, int &cb)
+{
+    float qa = dg[0] - xa, qb = dg[0] - xb;
+    if (fabsf(qa) < 1e-30f) qa = -1e-30f;
+    if (fabsf(qb) < 1e-30f) qb = -1e-30f;
+    int na = qa < 0.f ? 1 : 0, nb = qb < 0.f ? 1 : 0;
+    int i = 1;
+    for (; i + 4 <= n; i += 4) {
+        float d[4], o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { d[u] = dg[i + u]; o[u] = of2[i + u - 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            qa = d[u] - xa - o[u] * fast_rcp(qa);
+            qb = d[u] - xb - o[u] * fast_rcp(qb);
+            if (fabsf(qa) < 1e-30f) qa = -1e-30f;
+            if (fabsf(qb) < 1e-30f) qb = -1e-30f;
+            na += qa < 0.f ? 1 : 0;
+            nb += qb < 0.f ? 1 : 0;
+        }
+    }
+    for (; i < n; ++i) {
+        const float d = dg[i], o = of2[i - 1];
+        qa = d - xa - o * fast_rcp(qa);
+        qb = d - xb - o * fast_rcp(qb);
+        if (fabsf(qa) < 1e-30f) qa = -1e-30f;
+        if (fabsf(qb) < 1e-30f) qb = -1e-30f;
+        na += qa < 0.f ? 1 : 0;
+        nb += qb < 0.f ? 1 : 0;
+    }
+    ca = na; cb = nb;
+}
+
+// the kq largest eigenvalues of T (as eig_top_values): 64 / kVec lanes per eigenvalue, two probe points per lane and round
+// (kVec = 32: four probes = 5-section, 12 rounds; kVec = 64: two = trisection, 18 rounds); brackets live in registers, the
+// partner lane's counts come by a shuffle.
 template <int kVec>
 __device__ __forceinline__ void wave_eig_top_values(const WaveTri &w, int nr, int kq, EigShared &es)
 {
-    constexpr int kP = 64 / kVec;                         // probes per eigenvalue
-    constexpr int kRounds = kP == 2 ? 18 : 28;            // 2.002 / (kP + 1)^rounds < 1e-8
+    constexpr int kL = 64 / kVec;                         // lanes per eigenvalue
+    constexpr int kP = 2 * kL;                            // probes per eigenvalue and round
+    constexpr int kRounds = kP == 4 ? 12 : 18;            // 2.002 / (kP + 1)^rounds < 1e-8
     const int lane = lane_id();
     if (lane < nr) w.of2[lane] = w.of[lane] * w.of[lane];
     wave_sync();
-    const int j = lane / kP, ip = lane - j * kP;
+    const int j = lane / kL, ip = lane - j * kL;
     const int tgt = nr - 1 - j;
     float lo = -1.001f, hi = 1.001f;
     for (int round = 0; round < kRounds; ++round) {
         const float step = (hi - lo) * (1.0f / (float)(kP + 1));
-        const float x = lo + step * (float)(ip + 1);
-        const int c = j < kq ? sturm_count(w.dg, w.of2, nr, x) : 0;
-        if (kP == 2) {
-            const int co = wave_shfl_xor(c, 1);
-            const int c1 = ip == 0 ? c : co, c2 = ip == 0 ? co : c;
-            const float x1 = lo + step, x2 = lo + 2.0f * step;
-            if (c1 > tgt) hi = x1;
-            else if (c2 > tgt) { lo = x1; hi = x2; }
-            else lo = x2;
+        // this lane's probes are number 2 ip + 1 and 2 ip + 2 of the kP interior points
+        const float xa = lo + step * (float)(2 * ip + 1), xb = lo + step * (float)(2 * ip + 2);
+        int ca = 0, cb = 0;
+        if (j < kq) sturm_count2(w.dg, w.of2, nr, xa, xb, ca, cb);
+        int cnt[kP];
+        if (kL == 2) {
+            const int oa = wave_shfl_xor(ca, 1), ob = wave_shfl_xor(cb, 1);
+            cnt[0] = ip == 0 ? ca : oa; cnt[1] = ip == 0 ? cb : ob;
+            cnt[2] = ip == 0 ? oa : ca; cnt[3] = ip == 0 ? ob : cb;
         } else {
-            if (c > tgt) hi = x; else lo = x;
+            cnt[0] = ca; cnt[1] = cb;
         }
+        // the eigenvalue lies left of the first probe whose count exceeds the target
+        float nlo = lo + step * (float)kP, nhi = hi;
+#pragma unroll
+        for (int mm = kP - 1; mm >= 0; --mm)
+            if (cnt[mm] > tgt) { nhi = lo + step * (float)(mm + 1); nlo = lo + step * (float)mm; }
+        lo = nlo; hi = nhi;
     }
     if (ip == 0 && j < kq) es.lamv[j] = 0.5f * (lo + hi);
     wave_sync();
@@ -1064,29 +1126,56 @@ __device__ __forceinline__ bool wave_eig_top_vectors(const float *A, int lda, in
         if (lane == 0) { es.diag_lost = lost; es.diag_its = it + 1; }
         if (it >= need_until) break;
     }
-    // x = H_0 ... H_{nr-3} y: lane = vector; with na <= 32 the half-wave h takes the rows c = kk + 1 + h, kk + 3 + h, ...
+    // x = H_0 ... H_{nr-3} y: lane = vector, the vector in REGISTERS (the LU registers are dead); with na <= 32 the two
+    // half-waves share a vector, half h holding the rows c = 2 r + h.  The reflector entries come as LDS broadcasts, blocks
+    // of rows the reflector does not reach are skipped by wave-uniform branches.
     {
         constexpr int kH = kVec == 32 ? 2 : 1;
+        constexpr int kR = (kNMax + kH - 1) / kH;
         const int j = kH == 2 ? (lane & 31) : lane, h = kH == 2 ? (lane >> 5) : 0;
         const bool act = j < na;
         float *Yj = w.Y + (act ? j : 0);
+        float y[kR], vc[kR];
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const int c = kH * r + h;
+            y[r] = (act && c < nr) ? Yj[c * ldy] : 0.f;
+            vc[r] = 0.f;
+        }
         for (int kk = nr - 3; kk >= 0; --kk) {
             const float t = w.tau[kk];
             if (t == 0.f) continue;                      // wave-uniform
-            const float *vk = A + kk * lda;              // reflector kk: v[kk+1] = 1, v[c] = vk[c] for c > kk + 1
+            const float *vk = A + kk * lda;              // reflector kk: v[kk+1] = 1, v[c] = vk[c] for c > kk + 1 (0 beyond nr)
             float s = 0.f;
-            for (int c = kk + 1 + h; c < nr; c += kH) {
-                const float vc = c == kk + 1 ? 1.0f : vk[c];
-                s = fmaf(vc, act ? Yj[c * ldy] : 0.f, s);
+#pragma unroll
+            for (int r0 = 0; r0 < kR; r0 += 4) {
+                if (kH * (r0 + 3) + (kH - 1) > kk) {     // some row of this block is beyond kk
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (r0 + u < kR) {
+                            const int c = kH * (r0 + u) + h;
+                            const float ld = c < kNMax ? vk[c] : 0.f;
+                            vc[r0 + u] = c > kk + 1 ? ld : (c == kk + 1 ? 1.0f : 0.f);
+                            s = fmaf(vc[r0 + u], y[r0 + u], s);
+                        }
+                    }
+                }
             }
             if (kH == 2) s += wave_shfl_xor(s, 32);
             s *= t;
-            if (act)
-                for (int c = kk + 1 + h; c < nr; c += kH) {
-                    const float vc = c == kk + 1 ? 1.0f : vk[c];
-                    Yj[c * ldy] = fmaf(-s, vc, Yj[c * ldy]);
+#pragma unroll
+            for (int r0 = 0; r0 < kR; r0 += 4) {
+                if (kH * (r0 + 3) + (kH - 1) > kk) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (r0 + u < kR) y[r0 + u] = fmaf(-s, vc[r0 + u], y[r0 + u]);
                 }
-            if (kH == 2) wave_sync();                    // the next reflector pairs the rows with the other half-wave
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const int c = kH * r + h;
+            if (act && c < nr) Yj[c * ldy] = y[r];
         }
     }
     wave_sync();
@@ -1525,11 +1614,16 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? 2 : 1) void posemb_w
         }
     }
     // ---- expand to the n original nodes; x = normalize(u, "l2") row-wise, zero padded (data_util.py:260-262); lane = column
-    const int src = lane < k ? colsrc[lane] : 0;
-    for (int v = 0; v < n; ++v) {
-        const int rsrc = xinfo[4 * v + 0], o = xinfo[4 * v + 1], tp = xinfo[4 * v + 2], cb = xinfo[4 * v + 3];
+    // (two nodes per iteration: lanes 0-31 write node v, lanes 32-63 node v + 1)
+    const int col = lane & 31, hv = lane >> 5;
+    const int src = col < k ? colsrc[col] : 0;
+    for (int v0 = 0; v0 < n; v0 += 2) {
+        const int v = v0 + hv;
+        const bool valid = v < n;
+        const int vv = valid ? v : 0;
+        const int rsrc = xinfo[4 * vv + 0], o = xinfo[4 * vv + 1], tp = xinfo[4 * vv + 2], cb = xinfo[4 * vv + 3];
         float val = 0.f;
-        if (lane < k) {
+        if (valid && col < k) {
             if (src >= 0) {
                 val = w.Y[rsrc * kYld + src] * (tp ? 1.0f / sqrtf((float)tp) : 1.0f);
             } else if (tp) {
@@ -1541,11 +1635,11 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? 2 : 1) void posemb_w
                 }
             }
         }
-        const float s2 = wave_sum(val * val);
+        const float s2 = half32_sum(val * val);
         const float inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
-        if (lane < a.hidden) {
-            a.pos[(int64_t)(n0 + v) * a.hidden + lane] = val * inv;
-            if (a.raw) a.raw[(int64_t)(n0 + v) * a.hidden + lane] = val;
+        if (valid && col < a.hidden) {
+            a.pos[(int64_t)(n0 + v) * a.hidden + col] = val * inv;
+            if (a.raw) a.raw[(int64_t)(n0 + v) * a.hidden + col] = val;
         }
     }
     WAVE_TICK(6);                                    // expansion
@@ -2655,7 +2749,7 @@ static PosGrids posemb_grids(int64_t T)
     // workgroups do not fit beside it wait for the whole launch to drain (3-5 ms stalls in the kernel trace).
     static int caps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (caps[0] == 0) {                              // tuning knob: GCC_POSEMB_GRID_CAPS="small,mid,slot,krylov,big,cheb,w48,w64"
-        int c[8] = {256, 128, 128, 64, 64, 128, 128, 64};
+        int c[8] = {256, 64, 128, 64, 64, 96, 512, 128};    // scripts/gpu/r3_call4.sh: bench by caps
         const char *e = getenv("GCC_POSEMB_GRID_CAPS");
         if (e) (void)sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3], &c[4], &c[5], &c[6], &c[7]);
         for (int i = 0; i < 8; ++i) caps[i] = c[i] < 1 ? 1 : c[i];
