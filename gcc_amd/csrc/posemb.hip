@@ -37,6 +37,17 @@ struct PosMulti {                    // one launch covers the subgraphs of all v
 };
 #define PHASE_TICK(ph) do { if (m.ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 
+// executed f32 FLOPs of one dense solve (diagnostics, ticks[class][14]): tridiagonalisation 2 n^3 (p = A v and the rank-2
+// update on both triangles), bisection 5 flops per Sturm row, an inverse-iteration solve ~16 n per vector, the cluster
+// sweep is not counted (data dependent, small), back-transformation 2 n^2 per vector, expansion 3 per output element
+__device__ __forceinline__ unsigned long long dense_solve_flops(int nr, int kq, int na, int its, int probes_times_rounds, int n, int k)
+{
+    const unsigned long long N = (unsigned long long)nr;
+    return 2ull * N * N * N + 5ull * (unsigned long long)probes_times_rounds * (unsigned long long)kq * N
+           + 16ull * (unsigned long long)its * (unsigned long long)na * N + 2ull * N * N * (unsigned long long)na
+           + 3ull * (unsigned long long)n * (unsigned long long)k;
+}
+
 struct PosArgs {
     const int32_t *node_off, *row_ptr, *col_idx;
     float *pos, *evals, *raw;
@@ -784,18 +795,36 @@ struct WaveTri {
     int ldy;
 };
 
-// A (n x n, symmetric, both triangles, row stride lda, LDS) -> T = Q^T A Q as tridiagonalize().  Lane i owns row i.
+// A (n x n, symmetric, both triangles, row stride lda, LDS) -> T = Q^T A Q as tridiagonalize().  Lane i owns row i and
+// keeps it in REGISTERS: the loops over the columns are unrolled in blocks of eight (wave-uniform branches skip the
+// blocks left of k and right of n), the reflector v and w = p - K v are broadcast with v_readlane, and the column the
+// NEXT reflector is made of (A[.][k+1], by symmetry row k+1) is captured while the rows are updated -- so a step touches
+// the LDS only to store its reflector into the (dead) row k of A.
 template <int kNMax>
 __device__ __forceinline__ void wave_tridiagonalize(float *A, int lda, int n, const WaveTri &w)
 {
-    static_assert(kNMax <= 64, "one row per lane");
+    static_assert(kNMax <= 64 && kNMax % 8 == 0, "one row per lane, blocks of eight columns");
+    constexpr int kB = kNMax / 8;
     const int lane = lane_id();
+    float a[kNMax];
+    {
+        const float *Ai = A + (lane < n ? lane : 0) * lda;
+#pragma unroll
+        for (int c = 0; c < kNMax; ++c) a[c] = (lane < n && c < n) ? Ai[c] : 0.f;
+    }
+    wave_sync();                                         // the rows are in registers: A's rows may be overwritten by reflectors
+    float cap = a[0];                                    // column k of the current matrix, entry i in lane i
+#pragma unroll 1
     for (int k = 0; k + 2 < n; ++k) {
-        const float arow = (lane > k && lane < n) ? A[k * lda + lane] : 0.f;     // row k, columns k+1 .. n-1 (lane = column)
+        const float arow = (lane > k && lane < n) ? cap : 0.f;
+        const float akk = wave_readlane(cap, k);
         const float sig = wave_sum(lane > k + 1 ? arow * arow : 0.f);
         const float x0 = wave_readlane(arow, k + 1);
         if (sig <= 1e-30f) {                             // wave-uniform: the column is already tridiagonal, H_k = I
-            if (lane == 0) { w.dg[k] = A[k * lda + k]; w.of[k] = x0; w.tau[k] = 0.f; }
+            if (lane == 0) { w.dg[k] = akk; w.of[k] = x0; w.tau[k] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < kNMax; ++c)
+                if (c == k + 1) cap = a[c];
             continue;
         }
         const float mu = sqrtf(x0 * x0 + sig);
@@ -803,54 +832,48 @@ __device__ __forceinline__ void wave_tridiagonalize(float *A, int lda, int n, co
         const float t = (beta - x0) / beta;
         const float scale = 1.0f / (x0 - beta);
         const float v = lane == k + 1 ? 1.0f : arow * scale;                      // v_c in lane c (0 outside k+1 .. n-1)
-        // p_i = t sum_c A[i][c] v_c  (lane = row i; the row is walked in LDS, stride lda odd: conflict free), eight row
-        // entries requested at a time: one wave per SIMD has nothing else to cover an LDS round trip with
+        // p_i = t sum_c A[i][c] v_c  (v is zero outside the trailing block, so whole blocks need no masks)
         float p0 = 0.f, p1 = 0.f;
-        const float *Ai = A + (lane < n ? lane : 0) * lda;
-        int c = k + 1;
-        for (; c + 8 <= n; c += 8) {
-            float ar[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) ar[u] = Ai[c + u];
+        for (int cb = 0; cb < kB; ++cb) {
+            if (8 * cb + 7 > k && 8 * cb < n) {
 #pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-                p0 = fmaf(ar[u], wave_readlane(v, c + u), p0);
-                p1 = fmaf(ar[u + 1], wave_readlane(v, c + u + 1), p1);
+                for (int u = 0; u < 8; u += 2) {
+                    p0 = fmaf(a[8 * cb + u], wave_readlane(v, 8 * cb + u), p0);
+                    p1 = fmaf(a[8 * cb + u + 1], wave_readlane(v, 8 * cb + u + 1), p1);
+                }
             }
         }
-        for (; c < n; ++c) p0 = fmaf(Ai[c], wave_readlane(v, c), p0);
         const bool mine = lane > k && lane < n;
         const float p = mine ? t * (p0 + p1) : 0.f;
         const float K = 0.5f * t * wave_sum(p * v);
         const float wv = p - K * v;                                               // w = p - K v  (0 outside the block)
-        if (lane > k + 1 && lane < n) A[k * lda + lane] = v;                      // row k is dead: it stores the reflector
-        if (lane == 0) { w.dg[k] = A[k * lda + k]; w.of[k] = beta; w.tau[k] = t; }
-        // A[i][c] -= v_i w_c + w_i v_c on the trailing block (the broadcasts are executed by every lane, the rows by their owners)
-        {
-            float *Aw = A + (lane < n ? lane : 0) * lda;
-            int cc = k + 1;
-            for (; cc + 8 <= n; cc += 8) {
-                float ar[8];
+        if (lane > k + 1 && lane < n) A[k * lda + lane] = v;                      // row k of A stores the reflector
+        if (lane == 0) { w.dg[k] = akk; w.of[k] = beta; w.tau[k] = t; }
+        // A[i][c] -= v_i w_c + w_i v_c  (dead rows have v_i = w_i = 0); column k + 1 is captured for the next step
 #pragma unroll
-                for (int u = 0; u < 8; ++u) ar[u] = Aw[cc + u];
+        for (int cb = 0; cb < kB; ++cb) {
+            if (8 * cb + 7 > k && 8 * cb < n) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) ar[u] -= v * wave_readlane(wv, cc + u) + wv * wave_readlane(v, cc + u);
-                if (mine) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) Aw[cc + u] = ar[u];
+                for (int u = 0; u < 8; ++u) {
+                    const int c = 8 * cb + u;
+                    a[c] -= v * wave_readlane(wv, c) + wv * wave_readlane(v, c);
+                    if (c == k + 1) cap = a[c];
                 }
             }
-            for (; cc < n; ++cc) {
-                const float upd = v * wave_readlane(wv, cc) + wv * wave_readlane(v, cc);
-                if (mine) Aw[cc] -= upd;
-            }
         }
-        wave_sync();                                     // the next step reads row k + 1 across lanes
     }
-    if (lane == 0) {
-        if (n >= 2) { w.dg[n - 2] = A[(n - 2) * lda + n - 2]; w.of[n - 2] = A[(n - 2) * lda + n - 1]; }
-        w.dg[n - 1] = A[(n - 1) * lda + n - 1];
-        w.of[n - 1] = 0.f;
+    {   // the last 2 x 2 block: column n - 2 is in cap (column 0 when no step ran), A[n-1][n-1] in lane n - 1
+        float last = 0.f;
+#pragma unroll
+        for (int c = 0; c < kNMax; ++c)
+            if (c == n - 1) last = a[c];
+        const float d2 = wave_readlane(cap, n >= 2 ? n - 2 : 0), o2 = wave_readlane(cap, n - 1), d1 = wave_readlane(last, n - 1);
+        if (lane == 0) {
+            if (n >= 2) { w.dg[n - 2] = d2; w.of[n - 2] = o2; }
+            w.dg[n - 1] = d1;
+            w.of[n - 1] = 0.f;
+        }
     }
     wave_sync();
 }
@@ -906,6 +929,7 @@ __device__ __forceinline__ void wave_eig_top_values(const WaveTri &w, int nr, in
     const int j = lane / kL, ip = lane - j * kL;
     const int tgt = nr - 1 - j;
     float lo = -1.001f, hi = 1.001f;
+#pragma unroll 1
     for (int round = 0; round < kRounds; ++round) {
         const float step = (hi - lo) * (1.0f / (float)(kP + 1));
         // this lane's probes are number 2 ip + 1 and 2 ip + 2 of the kP interior points
@@ -1105,6 +1129,7 @@ __device__ __forceinline__ bool wave_eig_top_vectors(const float *A, int lda, in
     const int maxpos = es.maxpos;
     int lost = 0;
     int need_until = 2;
+#pragma unroll 1
     for (int it = 0; it < kMaxInvIt; ++it) {
         if (lane < na) {
             const int j = lane;
@@ -1443,6 +1468,9 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
         }
     }
     PHASE_TICK(6);                                 // expansion
+    if (m.ticks && tid == 0)
+        atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 14],
+                  dense_solve_flops(nr, kq, sh_na, es.diag_its, (kT / kMaxVec) * ((kT / kMaxVec) >= 32 ? 6 : ((kT / kMaxVec) >= 16 ? 7 : 9)), n, k));
     }   // next item
 }
 
@@ -1458,8 +1486,11 @@ __host__ __device__ constexpr int wave_team_bytes()
 
 // (register budget: the LU factors of an inverse iteration take 2 kNMax registers per lane; without an occupancy
 //  target the scheduler spreads the unrolled eliminations over all 512)
+#ifndef GCC_POSEMB_W48_OCC
+#define GCC_POSEMB_W48_OCC 1      // 2 spills ~40 registers; measured 40.6 vs 37.9 us per item (scripts/gpu/r3_call5.sh)
+#endif
 template <int kCls, int kNMax>
-__global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? 2 : 1) void posemb_wave_kernel(PosMulti m, PosHead hd)
+__global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? GCC_POSEMB_W48_OCC : 1) void posemb_wave_kernel(PosMulti m, PosHead hd)
 {
     static_assert(kNMax <= 64 && kNMax * kYld * 4 >= kWaveNodes * 16, "the deflation tables overlay Y");
     DYN_SMEM(smem);
@@ -1643,6 +1674,8 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? 2 : 1) void posemb_w
         }
     }
     WAVE_TICK(6);                                    // expansion
+    if (m.ticks && lane == 0)
+        atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 14], dense_solve_flops(nr, kq, na, es.diag_its, 4 * 12, n, k));
     wave_sync();                                     // the next item reuses the team's LDS
     }   // next item
 #undef WAVE_TICK
@@ -2310,6 +2343,8 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     double *G = (double *)region, *K = G + kChP * kChP;      // fp64 [64][64] each
     float cut = 0.2f;
     int deg = 6, remaining = 6, round = 0, nrr = 0;
+    unsigned long long flops = 0;                            // executed FLOPs of this item (diagnostics, ticks[class][14])
+    const unsigned long long nnz_ = (unsigned long long)crow[nr], nr_ = (unsigned long long)nr;
     bool converged = false;
     if (!failed) {
         for (int i = tid; i < nr * kChP; i += kChThreads)    // start block: U(-1, 1), np.random.rand's role
@@ -2342,6 +2377,11 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             }                                                            // deg even: the result is in XA
         }
         if (rr) spmm(XA, XB, 1.0f, 0.f, 0.f);                            // W = M' X
+        // products: 2 nnz 64 + 5 n 64 each; Gram matrices 2 n 64^2 (x2 with K); Cholesky + inverse + projected matrix ~ 64^3 x 2;
+        // a Ritz problem 2 64^3 + 2 64^3 (tridiagonalisation, back-transformation of 64 vectors); rotation 2 n 64^2 (x2 with W)
+        flops += (unsigned long long)(deg + (rr ? 1 : 0)) * (2ull * nnz_ * kChP + 5ull * nr_ * kChP)
+                 + (rr ? 2ull : 1ull) * 2ull * nr_ * kChP * kChP + 2ull * kChP * kChP * kChP
+                 + (rr ? 4ull * kChP * kChP * kChP : 0ull) + (fullrr ? 2ull : 1ull) * 2ull * nr_ * kChP * kChP;
         PHASE_TICK(1);                                                   // sparse products
         // ---- G = X^T X (and K = X^T W), fp64 accumulation.  Tiles of 32 rows of X and of W go through LDS (the slab):
         //      one coalesced 16-byte load per thread and tile, requested a tile ahead, instead of a chain of L2 round trips
@@ -2731,6 +2771,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         }
     }
     PHASE_TICK(4);                                               // expansion
+    if (m.ticks && tid == 0) atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 14], flops);
     if (tid == 0) atomicMax(a.status + 1, round);                // diagnostics: most filter rounds of an item
     }   // next item
 }
