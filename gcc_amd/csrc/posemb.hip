@@ -2070,6 +2070,9 @@ constexpr float kChAmpLog = 12.9f;  // ln of the largest filter amplification be
 constexpr int kChLdy = kChP + 1;
 constexpr int kChBw = 32;            // inverse iterations of the Ritz problem per batch
 
+struct LdsYes { static constexpr bool value = true; };
+struct LdsNo { static constexpr bool value = false; };
+
 struct ChebArgs {
     PosMulti m;
     PosHead hd;
@@ -2267,10 +2270,15 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     const int kq = min(k, nr);
 
     // dst = alpha * (M' src - center * src) - gamma * dst   (rows of 64 floats; 16 threads x float4 per row)
-    // 8 threads per row (8 block vectors = 2 x float4 each), 128 rows at a time, four gathers per vector pair in flight:
-    // the block lives in L2 and a product is bound by the latency of its gathers (4 threads per row with 16 vectors each
-    // was measured slower: 1.27 against 0.86 ms of products per item)
-    auto gather = [&](const float *src, int e0, int e1, float *acc) {
+    // 8 threads per row (8 block vectors = 2 x float4 each), 128 rows at a time, four gathers per vector pair in flight.
+    // With the block in L2 a product is bound by the latency of its gathers (~29 us at n' ~ 300; 4 threads per row with 16
+    // vectors each was measured slower: 1.27 against 0.86 ms of products per item).  Blocks of at most kChLdsRows rows are
+    // therefore copied into LDS first (coalesced, once per product: the region of the dense matrices is free while the
+    // filter runs) and gathered from there; the result still goes to the L2-resident buffer, coalesced.
+    constexpr int kChLdsRows = cheb_region_bytes() / (kChP * (int)sizeof(float));
+    const bool lds_x = nr <= kChLdsRows;                     // block-uniform
+    auto gather = [&](auto in_lds, const float *src, int e0, int e1, float *acc) {
+        const float *base = decltype(in_lds)::value ? (const float *)region : src;
         const int q8 = 8 * (tid & 7);
         for (int e = e0; e < e1; e += 4) {
             int cj[4];
@@ -2284,8 +2292,8 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                xa[u] = *(const float4 *)(src + (int64_t)cj[u] * kChP + q8);
-                xb[u] = *(const float4 *)(src + (int64_t)cj[u] * kChP + q8 + 4);
+                xa[u] = *(const float4 *)(base + (int64_t)cj[u] * kChP + q8);
+                xb[u] = *(const float4 *)(base + (int64_t)cj[u] * kChP + q8 + 4);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -2296,15 +2304,15 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             }
         }
     };
-    // dst = alpha * (M' src - center * src) - gamma * dst   (rows of 64 floats)
-    auto spmm = [&](const float *src, float *dst, float alpha, float center, float gamma) {
+    auto spmm_body = [&](auto in_lds, const float *src, float *dst, float alpha, float center, float gamma) {
+        const float *base = decltype(in_lds)::value ? (const float *)region : src;
         const int q8 = 8 * (tid & 7), g8 = tid >> 3;
         for (int c = g8; c < nchunk; c += kChThreads / 8) {              // chunks of the long rows -> slab
             int x = 0;
             while (longfirst[x + 1] <= c) ++x;
             const int r = longrow[x];
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            gather(src, chunk_beg[c], min(chunk_beg[c] + kChLongDeg, (int)crow[r + 1]), acc);
+            gather(in_lds, src, chunk_beg[c], min(chunk_beg[c] + kChLongDeg, (int)crow[r + 1]), acc);
             *(float4 *)(slab + c * kChP + q8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             *(float4 *)(slab + c * kChP + q8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
         }
@@ -2321,10 +2329,10 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
                     acc[4] += pb.x; acc[5] += pb.y; acc[6] += pb.z; acc[7] += pb.w;
                 }
             } else {
-                gather(src, e0, e1, acc);
+                gather(in_lds, src, e0, e1, acc);
             }
             const float sr = scale[r];
-            const float4 oa = *(const float4 *)(src + (int64_t)r * kChP + q8), ob = *(const float4 *)(src + (int64_t)r * kChP + q8 + 4);
+            const float4 oa = *(const float4 *)(base + (int64_t)r * kChP + q8), ob = *(const float4 *)(base + (int64_t)r * kChP + q8 + 4);
             float o[8] = {alpha * (sr * acc[0] - center * oa.x), alpha * (sr * acc[1] - center * oa.y),
                           alpha * (sr * acc[2] - center * oa.z), alpha * (sr * acc[3] - center * oa.w),
                           alpha * (sr * acc[4] - center * ob.x), alpha * (sr * acc[5] - center * ob.y),
@@ -2338,6 +2346,18 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             *(float4 *)(dst + (int64_t)r * kChP + q8 + 4) = make_float4(o[4], o[5], o[6], o[7]);
         }
         __syncthreads();
+    };
+    // dst = alpha * (M' src - center * src) - gamma * dst   (rows of 64 floats)
+    auto spmm = [&](const float *src, float *dst, float alpha, float center, float gamma) {
+        if (lds_x) {
+            float4 *xs = (float4 *)region;
+            const float4 *gs = (const float4 *)src;
+            for (int i = tid; i < nr * (kChP / 4); i += kChThreads) xs[i] = gs[i];
+            __syncthreads();
+            spmm_body(LdsYes(), src, dst, alpha, center, gamma);
+        } else {
+            spmm_body(LdsNo(), src, dst, alpha, center, gamma);
+        }
     };
 
     double *G = (double *)region, *K = G + kChP * kChP;      // fp64 [64][64] each
