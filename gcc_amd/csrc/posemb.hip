@@ -172,6 +172,8 @@ struct EigShared {                   // per-workgroup scratch of the solver core
     int cs[kVecCap], posi[kVecCap];
     int na, maxpos, bad;
     int diag_lost, diag_its;         // diagnostics of the last eig_top_vectors call
+    int gs_lost;                     // result of the cluster sweep done by wave 0 (block classes)
+    float gs_left;
 };
 
 // A (n x n, symmetric, both triangles kept, row stride lda) -> T = Q^T A Q; Q = H_0 H_1 ... H_{n-3},
@@ -497,6 +499,86 @@ constexpr float kHeavy = 1e-2f;      // ... below which what is left is too nois
 // Returns (block-uniform) the number of vectors that vanished, i.e. were in the span of their predecessors; those are
 // refilled with fresh pseudo-random numbers (LAPACK stein restarts them the same way) and *min_left is the smallest
 // squared norm any member kept (1 = nothing removed).  All threads call it; ends with a barrier.
+// (one-wave solver core, further below)
+struct WaveTri {
+    float *dg, *of, *of2, *tau;      // [kNMax] diagonal, off-diagonal, its square, reflector scales
+    float *nrm;                      // [64] squared norms inside the Gram-Schmidt sweep
+    float *Y;                        // [n'][ldy] eigenvectors
+    int ldy;
+};
+
+// cluster_orthonormalize() for one wave: lane = rows lane, lane + 64, ... of Y (n <= 64 kCPL).  Members are taken in index
+// order (the members of a cluster are consecutive and its predecessors finished), projections on all predecessors are
+// computed from the same vector (classical Gram-Schmidt, a second pass where the first removed more than half: "twice is
+// enough").  No barrier: a sweep over a cluster of m copies is m^2 / 2 wave reductions instead of 3 m workgroup barriers.
+template <int kCPL>
+__device__ __forceinline__ int wave_cluster_orthonormalize(const WaveTri &w, int n, int na, const int *cs, const int *posi, int maxpos,
+                                                           float *min_left, uint32_t hseed)
+{
+    *min_left = 1.0f;
+    if (maxpos == 0) return 0;
+    const int lane = lane_id();
+    float *Y = w.Y;
+    const int ldy = w.ldy;
+    if (lane < na) w.nrm[lane] = 1.0f;                    // unit vectors come out of the solves
+    wave_sync();
+    int lost = 0;
+    float left = 1.0f;
+    for (int j = 0; j < na; ++j) {
+        if (posi[j] == 0) continue;                       // wave-uniform (LDS broadcast)
+        const int c0 = cs[j];
+        float y[kCPL];
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) y[u] = lane + 64 * u < n ? Y[(lane + 64 * u) * ldy + j] : 0.f;
+        float now = 1.0f;
+        for (int pass = 0; pass < 2; ++pass) {
+            float acc[kCPL];
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) acc[u] = 0.f;
+            for (int l = c0; l < j; ++l) {
+                const float nl = w.nrm[l];
+                float yl[kCPL], d = 0.f;
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) {
+                    yl[u] = lane + 64 * u < n ? Y[(lane + 64 * u) * ldy + l] : 0.f;
+                    d = fmaf(y[u], yl[u], d);
+                }
+                const float s = wave_sum(d);
+                const float cf = nl >= kVanish ? s / nl : 0.f;   // a vanished predecessor spans nothing
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) acc[u] = fmaf(cf, yl[u], acc[u]);
+            }
+            float d = 0.f;
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) { y[u] -= acc[u]; d = fmaf(y[u], y[u], d); }
+            now = wave_sum(d);
+            if (!(pass == 0 && now < 0.5f)) break;
+        }
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u)
+            if (lane + 64 * u < n) Y[(lane + 64 * u) * ldy + j] = y[u];
+        if (lane == 0) w.nrm[j] = now;
+        left = now < left ? now : left;
+        if (now < kVanish) ++lost;
+        wave_sync();
+    }
+    for (int j = 0; j < na; ++j) {                        // normalise; vanished members restart from pseudo-random numbers
+        if (posi[j] == 0) continue;
+        const float c = w.nrm[j];
+#pragma unroll
+        for (int u = 0; u < kCPL; ++u) {
+            const int r = lane + 64 * u;
+            if (r < n) {
+                if (c < kVanish) Y[r * ldy + j] = hash_unit(hseed, (uint32_t)j, (uint32_t)r);
+                else Y[r * ldy + j] *= 1.0f / sqrtf(c);
+            }
+        }
+    }
+    wave_sync();
+    *min_left = left;
+    return lost;
+}
+
 template <int kT>
 __device__ int cluster_orthonormalize(const TriLds &w, int n, int na, const int *cs, const int *posi, int maxpos,
                                       float *min_left, uint32_t hseed)
@@ -718,7 +800,25 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
 #endif
         if (it > 0) {                              // the first solve only enters the cluster subspaces
             float left;
+#ifdef GCC_POSEMB_BLOCK_GS
             lost = cluster_orthonormalize<kT>(w, nr, na, es.cs, es.posi, maxpos, &left, hseed ^ (0x51ED27u * (uint32_t)(it + 1)));
+#else
+            // The sweep is done by ONE wave without barriers (m^2 / 2 wave reductions for a cluster of m copies) while the
+            // others wait: the block version above needs 3 workgroup barriers per cluster position and pass, which cost
+            // 119 of the 484 us of a mid-class item (hub ego-nets carry clusters of 30-60 copies).
+            if (wv == 0) {
+                WaveTri ww;
+                ww.Y = w.Y; ww.ldy = w.ldy; ww.nrm = w.coef; ww.dg = ww.of = ww.of2 = ww.tau = nullptr;
+                float lf;
+                const int ls = wave_cluster_orthonormalize<kCPL>(ww, nr, na, es.cs, es.posi, maxpos, &lf,
+                                                                 hseed ^ (0x51ED27u * (uint32_t)(it + 1)));
+                if (lane == 0) { es.gs_lost = ls; es.gs_left = lf; }
+            }
+            __syncthreads();
+            lost = es.gs_lost;
+            left = es.gs_left;
+            __syncthreads();
+#endif
             if (lost > 0) need_until = it + 3 > need_until ? it + 3 : need_until;
             else if (left < kHeavy) need_until = it + 1 > need_until ? it + 1 : need_until;
         }
@@ -788,12 +888,6 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
 // the reflector and w are broadcast with v_readlane), an eigenvalue pair of probes or an eigenvector lives in one
 // lane, the LU factors of an inverse iteration live in that lane's REGISTERS (fully unrolled elimination; no LDS
 // slots), and several independent teams share a workgroup.  Dot products over rows are DPP wave reductions.
-struct WaveTri {
-    float *dg, *of, *of2, *tau;      // [kNMax] diagonal, off-diagonal, its square, reflector scales
-    float *nrm;                      // [64] squared norms inside the Gram-Schmidt sweep
-    float *Y;                        // [n'][ldy] eigenvectors
-    int ldy;
-};
 
 // A (n x n, symmetric, both triangles, row stride lda, LDS) -> T = Q^T A Q as tridiagonalize().  Lane i owns row i and
 // keeps it in REGISTERS: the loops over the columns are unrolled in blocks of eight (wave-uniform branches skip the
@@ -1035,59 +1129,6 @@ __device__ __forceinline__ bool wave_inverse_iteration_step(const WaveTri &w, in
     return ok;
 }
 
-// cluster_orthonormalize() for one wave: lane = row of Y.  Members are taken in index order (the members of a cluster are
-// consecutive and its predecessors finished), projections on all predecessors are computed from the same vector (classical
-// Gram-Schmidt, a second pass where the first removed more than half: "twice is enough").
-__device__ __forceinline__ int wave_cluster_orthonormalize(const WaveTri &w, int n, int na, const int *cs, const int *posi, int maxpos,
-                                                           float *min_left, uint32_t hseed)
-{
-    *min_left = 1.0f;
-    if (maxpos == 0) return 0;
-    const int lane = lane_id();
-    float *Y = w.Y;
-    const int ldy = w.ldy;
-    const bool row = lane < n;
-    if (lane < na) w.nrm[lane] = 1.0f;                    // unit vectors come out of the solves
-    wave_sync();
-    int lost = 0;
-    float left = 1.0f;
-    for (int j = 0; j < na; ++j) {
-        if (posi[j] == 0) continue;                       // wave-uniform (LDS broadcast)
-        const int c0 = cs[j];
-        float y = row ? Y[lane * ldy + j] : 0.f;
-        float now = 1.0f;
-        for (int pass = 0; pass < 2; ++pass) {
-            float acc = 0.f;
-            for (int l = c0; l < j; ++l) {
-                const float nl = w.nrm[l];
-                const float yl = row ? Y[lane * ldy + l] : 0.f;
-                const float s = wave_sum(y * yl);
-                const float cf = nl >= kVanish ? s / nl : 0.f;   // a vanished predecessor spans nothing
-                acc = fmaf(cf, yl, acc);
-            }
-            y -= acc;
-            now = wave_sum(y * y);
-            if (!(pass == 0 && now < 0.5f)) break;
-        }
-        if (row) Y[lane * ldy + j] = y;
-        if (lane == 0) w.nrm[j] = now;
-        left = now < left ? now : left;
-        if (now < kVanish) ++lost;
-        wave_sync();
-    }
-    for (int j = 0; j < na; ++j) {                        // normalise; vanished members restart from pseudo-random numbers
-        if (posi[j] == 0) continue;
-        const float c = w.nrm[j];
-        if (row) {
-            if (c < kVanish) Y[lane * ldy + j] = hash_unit(hseed, (uint32_t)j, (uint32_t)lane);
-            else Y[lane * ldy + j] *= 1.0f / sqrtf(c);
-        }
-    }
-    wave_sync();
-    *min_left = left;
-    return lost;
-}
-
 // eig_top_vectors() for one wave: eigenvectors 0 .. na-1 of the matrix wave_tridiagonalize() reduced, in w.Y[i * ldy + j].
 // kVec = 32: na <= 32 and the back-transformation splits the rows of a reflector between the two half-waves.
 template <int kNMax, int kVec>
@@ -1143,7 +1184,7 @@ __device__ __forceinline__ bool wave_eig_top_vectors(const float *A, int lda, in
         if (tick_row && lane == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&tick_row[3], (unsigned long long)(now_ - tick)); tick = now_; }
         if (it > 0) {
             float left;
-            lost = wave_cluster_orthonormalize(w, nr, na, es.cs, es.posi, maxpos, &left, hseed ^ (0x51ED27u * (uint32_t)(it + 1)));
+            lost = wave_cluster_orthonormalize<1>(w, nr, na, es.cs, es.posi, maxpos, &left, hseed ^ (0x51ED27u * (uint32_t)(it + 1)));
             if (lost > 0) need_until = it + 3 > need_until ? it + 3 : need_until;
             else if (left < kHeavy) need_until = it + 1 > need_until ? it + 1 : need_until;
         }
