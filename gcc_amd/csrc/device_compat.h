@@ -62,6 +62,7 @@ static inline void opaque_u64(uint64_t &) {}
 static inline void opaque_u32(uint32_t &) {}
 #define COMPILER_MEMORY_FENCE() ((void)0)
 static inline float wave_readlane(float v, int src) { return wave_shfl(v, src); }
+static inline double wave_readlane(double v, int src) { return wave_shfl(v, src); }
 static inline int wave_readlane(int v, int src) { return wave_shfl(v, src); }
 // a value the caller knows to be wave-uniform (device: moved to a scalar register) / lane 63's value as a uniform
 static inline int wave_uniform(int v) { return v; }
@@ -225,6 +226,11 @@ __device__ __forceinline__ float wave_readlane(float v, int src)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(src)));
 }
 __device__ __forceinline__ int wave_readlane(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+__device__ __forceinline__ double wave_readlane(double v, int src)
+{
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), s), __builtin_amdgcn_readlane(__double2loint(v), s));
+}
 // a value the caller knows to be wave-uniform, moved to a scalar register (the compiler cannot tell for values that
 // come from threadIdx or a vector load: everything derived from them would stay in VGPRs and on the VALU)
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -2523,49 +2523,64 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             }
         }
         __syncthreads();
-        {   // blocked: panels of 16 columns factorised by wave 0 (wave syncs only), rank-16 trailing updates by all waves
-            const int i = tid >> 4, j4 = 4 * (tid & 15);
-            for (int c0 = 0; c0 < kChP; c0 += 16) {
-                if (wv == 0) {
-                    const int r = c0 + lane;                     // this lane's row (rows c0 .. 63)
-                    for (int kk = 0; kk < 16; ++kk) {
-                        const int col = c0 + kk;
-                        const double piv = G[col * kChP + col];
-                        if (!(piv > 0.1 * kChShift)) {           // wave-uniform: the block lost its numerical rank
-#ifdef GCC_AMD_HIPEMU
-                            if (getenv("GCC_POSEMB_DEBUG") && lane == 0) fprintf(stderr, "cheb chol fail round=%d col=%d piv=%g\n", round, col, piv);
-#endif
-                            sh_fail = 1;
-                            break;
-                        }
-                        const double rs = 1.0 / sqrt(piv);
-                        wave_sync();                             // every lane has read the pivot before its row overwrites it
-                        double lik = 0.0;
-                        if (r >= col && r < kChP) { lik = G[r * kChP + col] * rs; G[r * kChP + col] = lik; }
-                        wave_sync();
-                        if (r > col && r < kChP) {
-                            const int jend = min(c0 + 15, r);
-                            for (int j = col + 1; j <= jend; ++j) G[r * kChP + j] -= lik * G[j * kChP + col];
-                        }
-                        wave_sync();
+        // Cholesky of the 64 x 64 matrix by ONE wave with no barrier inside (the panel version it replaces -- panels of 16
+        // columns by one wave, rank-16 updates by all 16 -- spent 64 us per factorisation in its 12 barriers and fp64 LDS
+        // traffic): lane = row, half a row (32 columns) in fp64 REGISTERS at a time (1024-thread workgroups leave 128
+        // registers per lane), the column l of step k broadcast with v_readlane, the next column captured while the rows
+        // are updated (as wave_tridiagonalize).  Columns 0..31 first; then columns 32..63 are loaded, the 32 finished
+        // steps are replayed on them, and the factorisation continues.  L^T is written row-contiguous into Li (free
+        // here) and transposed into G's lower triangle by all waves afterwards.
+        if (wv == 0) {
+            double *Lt = Li;                                     // [k][i] = L[i][k]
+            double ar[kChP / 2];
+            bool bad = false;
+#pragma unroll 1
+            for (int half = 0; half < 2 && !bad; ++half) {
+                const int cb = 32 * half;
+#pragma unroll
+                for (int c = 0; c < 32; ++c) ar[c] = G[lane * kChP + cb + c];
+                if (half == 1) {                                 // replay steps 0..31 on the right half
+#pragma unroll 1
+                    for (int k = 0; k < 32; ++k) {
+                        const double l = Lt[k * kChP + lane];    // 0 above the diagonal (written below)
+#pragma unroll
+                        for (int u = 0; u < 32; ++u) ar[u] = fma(-l, wave_readlane(l, 32 + u), ar[u]);
                     }
                 }
-                __syncthreads();
-                if (sh_fail) break;                              // block-uniform
-                if (c0 + 16 < kChP) {
+                double cap = ar[0];
+#pragma unroll 1
+                for (int k = cb; k < cb + 32; ++k) {
+                    const double piv = wave_readlane(cap, k);
+                    if (!(piv > 0.1 * kChShift)) {               // wave-uniform: the block lost its numerical rank
+#ifdef GCC_AMD_HIPEMU
+                        if (getenv("GCC_POSEMB_DEBUG") && lane == 0) fprintf(stderr, "cheb chol fail round=%d col=%d piv=%g\n", round, k, piv);
+#endif
+                        bad = true;
+                        break;
+                    }
+                    const double l = lane >= k ? cap * (1.0 / sqrt(piv)) : 0.0;  // L[lane][k]
+                    Lt[k * kChP + lane] = l;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int j = j4 + u;
-                        if (i >= c0 + 16 && j >= c0 + 16 && j <= i) {
-                            double acc = 0.0;
+                    for (int jb = 0; jb < 4; ++jb) {
+                        if (cb + 8 * jb + 7 > k) {               // wave-uniform: some column of the block is right of k
 #pragma unroll
-                            for (int q = 0; q < 16; ++q) acc += G[i * kChP + c0 + q] * G[j * kChP + c0 + q];
-                            G[i * kChP + j] -= acc;
+                            for (int u = 0; u < 8; ++u) {
+                                const int j = 8 * jb + u;
+                                ar[j] = fma(-l, wave_readlane(l, cb + j), ar[j]);
+                                if (cb + j == k + 1) cap = ar[j];
+                            }
                         }
                     }
-                    __syncthreads();
                 }
             }
+            if (bad && lane == 0) sh_fail = 1;
+        }
+        __syncthreads();
+        if (!sh_fail) {                                          // L -> lower triangle of G (what the inverse below reads)
+            const int i = tid >> 4, j4 = 4 * (tid & 15);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j4 + u <= i) G[i * kChP + j4 + u] = Li[(j4 + u) * kChP + i];
         }
         __syncthreads();
         if (sh_fail) { failed = true; break; }
