@@ -164,6 +164,9 @@ SIGNATURES = {
     "gcc_posemb_multi": (ctypes.c_int32, [ctypes.POINTER(GccPosembView), ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                           ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_posemb_multi_gated": (ctypes.c_int32, [ctypes.POINTER(GccPosembView), ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                          ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_posemb": (ctypes.c_int32, [ctypes.POINTER(GccBatchOut), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p]),

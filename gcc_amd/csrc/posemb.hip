@@ -2858,7 +2858,7 @@ extern "C" {
 
 static long long *g_posemb_ticks = nullptr;
 struct PosGrids { int32_t small, mid, slot, kry, big, cheb, w48, w64; };
-static PosGrids posemb_grids(int64_t T)
+static PosGrids posemb_grids(int64_t T, bool gated = false)
 {
     // fixed grids: enough workgroups for the typical class sizes (~73 % / 19 % / 6 % / 2 % of a batch at rw_hops 256);
     // larger classes loop.  No class may cover more than half of the 256 CUs (small: 2 workgroups per CU): a solver
@@ -2873,16 +2873,35 @@ static PosGrids posemb_grids(int64_t T)
     }
     PosGrids g;
     g.small = (int32_t)(T < caps[0] ? T : caps[0]);
-    g.mid = (int32_t)((T + 3) / 4 < caps[1] ? (T + 3) / 4 : caps[1]);
+    // behind a gate the heavy phases of concurrent calls take turns: one call's heavy workgroups may then hold half of
+    // the CUs (GCC_POSEMB_GATED_CAPS="mid,cheb")
+    static int gcaps[2] = {0, 0};
+    if (gcaps[0] == 0) {
+        int c[2] = {128, 128};
+        const char *e = getenv("GCC_POSEMB_GATED_CAPS");
+        if (e) (void)sscanf(e, "%d,%d", &c[0], &c[1]);
+        gcaps[0] = c[0] < 1 ? 1 : c[0]; gcaps[1] = c[1] < 1 ? 1 : c[1];
+    }
+    const int cap_mid = gated ? gcaps[0] : caps[1], cap_cheb = gated ? gcaps[1] : caps[5];
+    g.mid = (int32_t)((T + 3) / 4 < cap_mid ? (T + 3) / 4 : cap_mid);
     g.slot = (int32_t)((T + 7) / 8 < caps[2] ? (T + 7) / 8 : caps[2]);
     g.kry = (int32_t)((T + 15) / 16 < caps[3] ? (T + 15) / 16 : caps[3]);
     g.big = (int32_t)((T + 15) / 16 < caps[4] ? (T + 15) / 16 : caps[4]);
-    g.cheb = (int32_t)((T + 7) / 8 < caps[5] ? (T + 7) / 8 : caps[5]);
+    g.cheb = (int32_t)((T + 7) / 8 < cap_cheb ? (T + 7) / 8 : cap_cheb);
     // one-wave teams: kWaveTeams items in flight per workgroup
     const int64_t wg = (T + kWaveTeams - 1) / kWaveTeams;
     g.w48 = (int32_t)(wg < caps[6] ? wg : caps[6]);
     g.w64 = (int32_t)((wg + 1) / 2 < caps[7] ? (wg + 1) / 2 : caps[7]);
     return g;
+}
+// workspace sizing: the larger of the two grid sets, so that one workspace serves gated and ungated calls
+static PosGrids posemb_grids_for_sizing(int64_t T)
+{
+    PosGrids a = posemb_grids(T, false);
+    const PosGrids b = posemb_grids(T, true);
+    a.mid = a.mid > b.mid ? a.mid : b.mid;
+    a.cheb = a.cheb > b.cheb ? a.cheb : b.cheb;
+    return a;
 }
 static int64_t posemb_head_bytes(int64_t T) { return ((16 + kNumCls * T) * 4 + 255) / 256 * 256; }
 static int64_t posemb_slot_floats(void) { return (int64_t)kGMax * kGMax + (int64_t)kNodeMax * 4; }
@@ -2896,7 +2915,7 @@ int64_t gcc_posemb_multi_workspace_bytes(int32_t num_views, int32_t batch_size, 
         return -1;
     }
     const int64_t T = (int64_t)num_views * batch_size;
-    const PosGrids g = posemb_grids(T);
+    const PosGrids g = posemb_grids_for_sizing(T);
     return posemb_head_bytes(T) + g.slot * posemb_slot_floats() * (int64_t)sizeof(float)
            + g.big * posemb_bslot_floats() * (int64_t)sizeof(float)
            + (int64_t)(g.mid + g.small) * kNodeMax * 16
@@ -2912,6 +2931,14 @@ int64_t gcc_posemb_workspace_bytes(int32_t batch_size, int64_t node_cap, int32_t
 int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_t batch_size, int64_t node_cap,
                          int32_t hidden, uint64_t seed, void *workspace, int64_t workspace_bytes, int32_t *status,
                          gcc_prof *prof, void *stream)
+{
+    return gcc_posemb_multi_gated(views, num_views, batch_size, node_cap, hidden, seed, workspace, workspace_bytes, status,
+                                  prof, nullptr, nullptr, stream);
+}
+
+int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, int32_t batch_size, int64_t node_cap,
+                               int32_t hidden, uint64_t seed, void *workspace, int64_t workspace_bytes, int32_t *status,
+                               gcc_prof *prof, void *heavy_wait, void *heavy_record, void *stream)
 {
     if (!views || !status || num_views < 1 || num_views > kMaxViews || batch_size < 1 || hidden < 2 || hidden > kMaxVec) {
         snprintf(g_err, kErrLen, "gcc_posemb_multi: bad argument");
@@ -2931,17 +2958,18 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     m.nviews = num_views; m.B = batch_size; m.hidden = hidden; m.seed = seed; m.status = status;
     m.ticks = g_posemb_ticks;
     const int64_t T = (int64_t)num_views * batch_size;
-    const PosGrids g = posemb_grids(T);
+    const PosGrids g = posemb_grids(T, heavy_wait != nullptr || heavy_record != nullptr);
+    const PosGrids gs = posemb_grids_for_sizing(T);     // the workspace is carved up by the sizing grids
     hipStream_t s = (hipStream_t)stream;
     PosHead hd;
     hd.count = (int32_t *)workspace;
     hd.next = hd.count + 8;
     hd.list = hd.count + 16;
     hd.slots = (float *)((char *)workspace + posemb_head_bytes(T));
-    hd.bslots = hd.slots + g.slot * posemb_slot_floats();
+    hd.bslots = hd.slots + gs.slot * posemb_slot_floats();
     hd.bslot_floats = posemb_bslot_floats();
-    hd.tabs = hd.bslots + g.big * posemb_bslot_floats();
-    hd.tabs_small_off = g.mid;
+    hd.tabs = hd.bslots + gs.big * posemb_bslot_floats();
+    hd.tabs_small_off = gs.mid;
     hd.T = (int32_t)T;
     hd.slot_floats = posemb_slot_floats();
     hd.ldv = (int32_t)posemb_ldv(batch_size, node_cap);
@@ -2977,7 +3005,7 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     KryArgs ka;
     ka.m = m;
     ka.hd = hd;
-    ka.vws = hd.tabs + (int64_t)(g.mid + g.small) * kNodeMax * 4;
+    ka.vws = hd.tabs + (int64_t)(gs.mid + gs.small) * kNodeMax * 4;
     ka.ldv = (int32_t)posemb_ldv(batch_size, node_cap);
     // longest items first
     const size_t lds_kry = (size_t)3 * ka.ldv * sizeof(float)
@@ -2990,14 +3018,22 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
         kry_lds_opt_in = lds_kry;
     }
 #endif
+    // light launches first (one-wave teams, the 256-thread small class): short workgroups with modest LDS that overlap
+    // freely with everything; then the heavy ones behind the caller's gate (see gcc_posemb_multi_gated in the header)
+    hipLaunchKernelGGL((posemb_direct_kernel<kClsSmall, 0, kJSmall, kSmallT, false>), dim3(g.small), dim3(kSmallT), lds_small, s, m, hd);
+    if (hd.use_wave) {
+        hipLaunchKernelGGL((posemb_wave_kernel<kClsW64, 64>), dim3(g.w64), dim3(kWaveTeams * 64), kWaveTeams * wave_team_bytes<64>(), s, m, hd);
+        hipLaunchKernelGGL((posemb_wave_kernel<kClsW48, 48>), dim3(g.w48), dim3(kWaveTeams * 64), kWaveTeams * wave_team_bytes<48>(), s, m, hd);
+    }
+    if (heavy_wait) (void)hipStreamWaitEvent(s, (hipEvent_t)heavy_wait, 0);
     if (hd.use_cheb) {
         ChebArgs ca;
         ca.m = m;
         ca.hd = hd;
-        char *after_kry = (char *)(ka.vws + (int64_t)g.kry * 2 * (kM + 1) * ka.ldv);
+        char *after_kry = (char *)(ka.vws + (int64_t)gs.kry * 2 * (kM + 1) * ka.ldv);
         after_kry = (char *)(((uintptr_t)after_kry + 255) & ~(uintptr_t)255);
         ca.xws = (float *)after_kry;
-        ca.tabs = (uint32_t *)(ca.xws + (int64_t)g.cheb * 3 * kNodeMax * kChP);
+        ca.tabs = (uint32_t *)(ca.xws + (int64_t)gs.cheb * 3 * kNodeMax * kChP);
 #ifndef GCC_AMD_HIPEMU
         static bool cheb_attr = false;
         if (!cheb_attr) {
@@ -3011,11 +3047,7 @@ int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_
     hipLaunchKernelGGL((posemb_direct_kernel<kClsBig, kGMax + 1, kBMax, 1024, true>), dim3(g.big), dim3(1024), kBLds, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>), dim3(g.slot), dim3(1024), kGLds, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, 1024, false>), dim3(g.mid), dim3(1024), lds_big, s, m, hd);
-    hipLaunchKernelGGL((posemb_direct_kernel<kClsSmall, 0, kJSmall, kSmallT, false>), dim3(g.small), dim3(kSmallT), lds_small, s, m, hd);
-    if (hd.use_wave) {
-        hipLaunchKernelGGL((posemb_wave_kernel<kClsW64, 64>), dim3(g.w64), dim3(kWaveTeams * 64), kWaveTeams * wave_team_bytes<64>(), s, m, hd);
-        hipLaunchKernelGGL((posemb_wave_kernel<kClsW48, 48>), dim3(g.w48), dim3(kWaveTeams * 64), kWaveTeams * wave_team_bytes<48>(), s, m, hd);
-    }
+    if (heavy_record) (void)hipEventRecord((hipEvent_t)heavy_record, s);
     prof_mark(prof, 1, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_posemb: %s", hipGetErrorString(e)); return -10; }

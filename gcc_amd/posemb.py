@@ -23,6 +23,23 @@ class PlaceholderPosEmb:
         return graph
 
 
+class HeavyGate:
+    """Shared by the producer lanes' positional-embedding calls: the LDS-heavy launches of concurrent calls (sparse block,
+    Krylov, 1024-thread dense classes) take turns -- each call waits for the previous call's heavy phase and records the
+    end of its own (gcc_posemb_multi_gated) -- while the light launches of all lanes overlap freely."""
+
+    def __init__(self):
+        self.last = None            # torch.cuda.Event recorded after the most recent heavy phase
+
+    def next_pair(self, stream):
+        """-> (raw hipEvent_t to wait for or None, raw hipEvent_t to record, keep-alive)."""
+        wait = self.last
+        rec = torch.cuda.Event()
+        rec.record(stream)          # materialises the handle; the library records it again after its heavy launches
+        self.last = rec
+        return (wait.cuda_event if wait is not None else None), rec.cuda_event, (wait, rec)
+
+
 class DevicePosEmb:
     """``_add_undirected_graph_positional_embedding`` (data_util.py:266-281) for a whole
     batched graph in one launch set (gcc_amd/csrc/posemb.hip).  ``lib``/``ptr`` are
@@ -69,13 +86,14 @@ class DevicePosEmb:
         graph.pos_undirected = out
         return graph
 
-    def multi(self, graphs, prof=None, evals=None, raws=None):
-        """Embed several batched graphs (the views of several future steps) in one set of kernel launches."""
+    def multi(self, graphs, prof=None, evals=None, raws=None, gate=None):
+        """Embed several batched graphs (the views of several future steps) in one set of kernel launches.
+        ``gate``: a :class:`HeavyGate` shared with the other producer lanes (device streams only)."""
         if len(graphs) > self.max_views:          # more views than the workspace was sized for: several calls
             for i in range(0, len(graphs), self.max_views):
                 self.multi(graphs[i:i + self.max_views], prof=prof if i == 0 else None,
                            evals=evals[i:i + self.max_views] if evals is not None else None,
-                           raws=raws[i:i + self.max_views] if raws is not None else None)
+                           raws=raws[i:i + self.max_views] if raws is not None else None, gate=gate)
             return graphs
         views = (self._cabi.GccPosembView * len(graphs))()
         keep = []
@@ -92,9 +110,15 @@ class DevicePosEmb:
             graph.pos_undirected = out
         dev = self._ring[0].device
         st = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
-        rc = self.lib.gcc_posemb_multi(views, len(graphs), self.B, self.node_cap, self.hidden, self.seed,
-                                       self.ptr(self.workspace), self.nbytes, self.ptr(self.status),
-                                       prof.handle if prof is not None else None, st)
+        if gate is not None and dev.type == "cuda":
+            wait, rec, self._gate_keep = gate.next_pair(torch.cuda.current_stream(dev))
+            rc = self.lib.gcc_posemb_multi_gated(views, len(graphs), self.B, self.node_cap, self.hidden, self.seed,
+                                                 self.ptr(self.workspace), self.nbytes, self.ptr(self.status),
+                                                 prof.handle if prof is not None else None, wait, rec, st)
+        else:
+            rc = self.lib.gcc_posemb_multi(views, len(graphs), self.B, self.node_cap, self.hidden, self.seed,
+                                           self.ptr(self.workspace), self.nbytes, self.ptr(self.status),
+                                           prof.handle if prof is not None else None, st)
         if rc != 0:
             raise RuntimeError(f"gcc_posemb_multi failed ({rc}): {self.lib.gcc_last_error().decode()}")
         return graphs

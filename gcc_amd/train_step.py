@@ -77,7 +77,8 @@ class BatchProducer:
     (gcc_posemb_multi: the eigensolver kernels pull items from work lists over all views).  Chunk c is produced by
     lane c % lanes into slot (c // lanes) % depth of that lane's buffer rings."""
 
-    def __init__(self, lanes, first_id_fn, device, depth=2, chunk=1, reserved_cus=0, cu_layout="interleaved", ahead=None):
+    def __init__(self, lanes, first_id_fn, device, depth=2, chunk=1, reserved_cus=0, cu_layout="interleaved", ahead=None,
+                 gate_heavy=None):
         self.lanes = lanes                      # list of (sampler, posemb): sampler ring >= depth * chunk, posemb ring
         self.first_id = first_id_fn             # >= 2 * depth * chunk buffers, posemb.max_views >= 2 * chunk
         self.dev = device
@@ -95,6 +96,17 @@ class BatchProducer:
             self.streams = [o.stream for o in self._owners]
         else:
             self.streams = [torch.cuda.Stream(device) for _ in lanes] if self.cuda else [None] * len(lanes)
+        # Optional: the lanes' LDS-heavy eigensolver launches take turns (gcc_amd.posemb.HeavyGate), so that at most one
+        # lane's heavy workgroups hold CUs at a time.  Measured (scripts/gpu/r3_call12.sh): no gain -- 1.29 vs 1.28 ms per
+        # step sustained, the training kernels are as slow next to 64 heavy workgroups as next to 300 -- so it is OFF
+        # unless GCC_POSEMB_GATE=1.
+        import os
+        if gate_heavy is None:
+            gate_heavy = os.environ.get("GCC_POSEMB_GATE", "0") == "1"
+        self.gate = None
+        if self.cuda and gate_heavy and len(lanes) > 1:
+            from .posemb import HeavyGate
+            self.gate = HeavyGate()
         self.ready = {}                         # chunk -> (list of (q, k) per step, event)
         self.released = {}                      # chunk -> event recorded on the consumer stream after its last step
         self.next_chunk = 0
@@ -111,7 +123,12 @@ class BatchProducer:
         views = [g for pair in pairs for g in pair]
         pp = pr.get("posemb")
         if hasattr(posemb, "multi"):
-            posemb.multi(views, prof=pp) if pp is not None else posemb.multi(views)
+            kw = {}
+            if pp is not None:
+                kw["prof"] = pp
+            if self.gate is not None:
+                kw["gate"] = self.gate
+            posemb.multi(views, **kw)
         else:                                   # placeholder / CPU stand-ins: one view at a time
             for g in views:
                 posemb(g)

@@ -174,6 +174,15 @@ int64_t gcc_posemb_multi_workspace_bytes(int32_t num_views, int32_t batch_size, 
 int32_t gcc_posemb_multi(const gcc_posemb_view *views, int32_t num_views, int32_t batch_size, int64_t node_cap,
                          int32_t hidden, uint64_t seed, void *workspace, int64_t workspace_bytes, int32_t *status,
                          gcc_prof *prof, void *stream);
+/* The same call with a GATE around its LDS-heavy launches (sparse block, Krylov and the 1024-thread dense classes:
+ * workgroups that own most of a CU's LDS for milliseconds).  Several producer streams run such calls concurrently; with a
+ * shared gate their heavy phases take turns, so that at most one call's heavy workgroups hold CUs at any time and the
+ * rest of the GPU stays open to the training step's short kernels, while the light launches (classification, one-wave
+ * teams) of all calls overlap freely.  heavy_wait: hipEvent_t the stream waits for before the first heavy launch (or
+ * NULL); heavy_record: hipEvent_t recorded after the last one (or NULL). */
+int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, int32_t batch_size, int64_t node_cap,
+                               int32_t hidden, uint64_t seed, void *workspace, int64_t workspace_bytes, int32_t *status,
+                               gcc_prof *prof, void *heavy_wait, void *heavy_record, void *stream);
 
 /* diagnostics: subsequent gcc_posemb* calls add wall-clock ticks (100 MHz) per solver class and phase into
  * device int64[GCC_POSEMB_TICK_CLASSES][16] -- EIGHT classes: small, mid, slot, Krylov, big, sparse block (Chebyshev),
