@@ -217,6 +217,12 @@ def load() -> ctypes.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  gcc_amd has no CPU fallback.")
+        # PyTorch first: its wheel bundles its own libamdhip64.  If this library were opened before torch, the loader would
+        # satisfy its libamdhip64 dependency from /opt/rocm and the process would hold TWO HIP runtimes -- kernels
+        # registered with one, torch's streams and allocations owned by the other ("no ROCm-capable device is detected"
+        # at the first launch; seen when build() and smoke() ran in one process).
+        import torch  # noqa: F401
+
         _lib = declare(ctypes.CDLL(LIB_PATH))
     return _lib
 
