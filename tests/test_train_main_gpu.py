@@ -93,3 +93,40 @@ def test_moco_loss_stays_sane_over_an_epoch_and_every_step_is_metered(tmp_path):
     vals = [float(l.split("loss ")[1].split(" ")[0]) for l in buf.getvalue().splitlines() if l.startswith("Train:")]
     assert len(vals) == 6 and all(np.isfinite(v) and 0.0 < v < 7.0 for v in vals), vals
     print("loss per 8 steps:", vals)
+
+
+@pytest.mark.parametrize("flags,tag", [
+    ([], "e2e-fused-adam"),                                        # train.py:396-417 through E2ETrainStep
+    (["--optimizer", "adagrad"], "e2e-adagrad"),                   # train.py:672-678 through the API path
+    (["--moco", "--optimizer", "sgd", "--nce-k", "256"], "moco-sgd"),   # train.py:659-664, momentum 0.9
+])
+def test_e2e_mode_and_the_other_optimizers_through_train_py(tmp_path, flags, tag):
+    """BASELINE configs[0] (E2E: K = bsz - 1, NCESoftmaxLossNS) and --optimizer sgd | adagrad (train.py:658-679) run
+    through train.py's main on the multi-graph corpus: finite falling-or-flat loss, checkpoint written with the
+    reference's keys, every step metered."""
+    import io
+    from contextlib import redirect_stdout
+
+    import train
+
+    corpus, _ = _corpus(tmp_path)
+    argv = ["--exp", tag, "--model-path", str(tmp_path / "s"), "--tb-path", str(tmp_path / "t"), "--gpu", "0",
+            "--batch-size", "32", "--num-workers", "2", "--num-copies", "1", "--num-samples", "256",
+            "--rw-hops", "64", "--dgl-file", corpus, "--epochs", "2", "--print-freq", "4", "--tb-freq", "1000",
+            "--producer-lanes", "2", "--producer-chunk", "2"]
+    if "--nce-k" not in flags:
+        argv += ["--nce-k", "31"]                                   # K = batch_size - 1 (README.md:69-75)
+    args = train.parse_option(argv + flags)
+    args.gpu = args.gpu[0]
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        loss = train.main(args)
+    lines = [l for l in buf.getvalue().splitlines() if l.startswith("Train:")]
+    vals = [float(l.split("loss ")[1].split(" ")[0]) for l in lines]
+    assert len(vals) == 8 and all(np.isfinite(v) and 0.0 < v < 7.0 for v in vals), (tag, vals)   # 2 epochs x 16 steps / 4
+    assert np.isfinite(loss)
+    ckpt = torch.load(os.path.join(args.model_folder, "current.pth"), map_location="cpu", weights_only=False)
+    want = {"opt", "model", "contrast", "optimizer", "epoch"} | ({"model_ema"} if "--moco" in flags else set())
+    assert set(ckpt) == want and ckpt["epoch"] == 2
+    if "--moco" not in flags:                                       # in-batch negatives: ln(32) = 3.47 at the start
+        assert vals[0] < 3.6 and vals[-1] < vals[0] + 0.2, (tag, vals)
