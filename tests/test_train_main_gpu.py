@@ -128,5 +128,5 @@ def test_e2e_mode_and_the_other_optimizers_through_train_py(tmp_path, flags, tag
     ckpt = torch.load(os.path.join(args.model_folder, "current.pth"), map_location="cpu", weights_only=False)
     want = {"opt", "model", "contrast", "optimizer", "epoch"} | ({"model_ema"} if "--moco" in flags else set())
     assert set(ckpt) == want and ckpt["epoch"] == 2
-    if "--moco" not in flags:                                       # in-batch negatives: ln(32) = 3.47 at the start
-        assert vals[0] < 3.6 and vals[-1] < vals[0] + 0.2, (tag, vals)
+    if "--moco" not in flags:       # in-batch negatives: around ln(32) = 3.47 at the start (T = 0.07 puts it a little above), falling
+        assert vals[0] < 4.5 and min(vals[1:]) < vals[0] and vals[-1] < vals[0] + 0.2, (tag, vals)
