@@ -68,6 +68,9 @@ def parse_args(argv=None):
                                                           "the largest divisor of --steps not above it is used, so that the timed region "
                                                           "launches exactly the chunks it consumes")
     ap.add_argument("--depth", type=int, default=2, help="chunks in flight per producer lane")
+    ap.add_argument("--sampler-steps", type=int, default=16,
+                    help="--mode sampler: steps (DataLoader batches) per sampler call (gcc_sample_multi); the training modes "
+                         "sample a producer chunk per call")
     ap.add_argument("--ahead", type=int, default=None, help="chunks launched beyond the one being consumed (default lanes * (depth - 1))")
     ap.add_argument("--scratch-entries", type=int, default=0, help="induction scratch of the sampler (int32 slots); 0 = default")
     ap.add_argument("--edge-cap", type=int, default=0, help="edge capacity of a batch view; 0 = default")
@@ -465,17 +468,26 @@ def main():
 
     extra = {}
     if args.mode == "sampler":
-        sampler = DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=2, scratch_entries=args.scratch_entries or None,
-                                   edge_cap=args.edge_cap or None)
+        S = max(1, min(args.sampler_steps, args.steps))
+        sampler = DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=max(2, S), scratch_entries=args.scratch_entries or None,
+                                   edge_cap=args.edge_cap or None, max_steps=S)
+        S = sampler.max_steps
         samplers = [sampler]
-        for i in range(args.warmup):
-            sampler.sample(first_id(i))
+
+        def run_steps(first_step, count):            # `count` steps, S (or fewer) per call
+            at = 0
+            while at < count:
+                n = min(S, count - at)
+                sampler.sample_multi(first_id(first_step + at), n, world * B)
+                at += n
+
+        run_steps(0, args.warmup)
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            sampler.sample(first_id(args.warmup + i))
+        run_steps(args.warmup, args.steps)
         barrier()
         dt = time.perf_counter() - t0
+        extra["sampler_steps_per_call"] = S
         stages = ["seed-draw", "rwr-walk", "induce", "batch-pack"]
         produced = consumed = args.steps
         first_timed = args.warmup
@@ -491,7 +503,7 @@ def main():
         chunk = max(d for d in range(1, min(args.chunk, args.steps) + 1) if args.steps % d == 0)
         nbuf = args.depth * chunk
         samplers = [DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=nbuf, scratch_entries=args.scratch_entries or None,
-                                     edge_cap=args.edge_cap or None) for _ in range(args.lanes)]
+                                     edge_cap=args.edge_cap or None, max_steps=chunk) for _ in range(args.lanes)]
         sampler = samplers[0]
         enc_kw = dict(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
                       freq_embedding_size=16, degree_embedding_size=16, output_dim=64, node_hidden_dim=64,
@@ -609,6 +621,13 @@ def main():
                          "traffic_note": "committed constant from separate rocprofv3 --pmc passes of this build (hash-guarded), not a same-run measurement"},
             "algorithmic_bytes_per_step": acc,
         }
+        if args.mode == "sampler":
+            # the whole sampler (five kernels per call, `sampler_steps_per_call` steps per call) against the HBM roof
+            e2e = acc["total"] / (ms_per_step * 1e-3) / 1e9
+            out["stage_rooflines"] = {"sampler_end_to_end": dict(
+                bound="hbm", algorithmic_bytes_per_step=acc["total"], ms_per_step=ms_per_step, achieved=e2e, peak=HBM_PEAK_GBPS,
+                unit="GB/s", frac=e2e / HBM_PEAK_GBPS, steps_per_call=extra.get("sampler_steps_per_call"),
+                single_step_call_ms_isolated=sum(kern_iso.values()))}
         if args.mode in ("train", "e2e"):
             out["config"].update(producer_lanes=args.lanes, producer_depth=args.depth, producer_chunk=chunk,
                                  producer_ahead=trainer.producer.ahead, reserved_cus=args.reserved_cus)

@@ -151,6 +151,10 @@ SIGNATURES = {
     "gcc_prof_destroy": (None, [ctypes.c_void_p]),
     "gcc_prof_elapsed_ms": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, c_f32p]),
     "gcc_sampler_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(GccGraph), ctypes.c_int32, ctypes.c_int64]),
+    "gcc_sampler_workspace_bytes_multi": (ctypes.c_int64, [ctypes.POINTER(GccGraph), ctypes.c_int32, ctypes.c_int32, ctypes.c_int64]),
+    "gcc_sample_multi": (ctypes.c_int32, [
+        ctypes.POINTER(GccGraph), ctypes.POINTER(GccSampleParams), ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(GccBatchOut),
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_sample_batch": (ctypes.c_int32, [
         ctypes.POINTER(GccGraph), ctypes.POINTER(GccSampleParams), ctypes.POINTER(GccBatchOut),
         ctypes.POINTER(GccBatchOut), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,

@@ -8,7 +8,7 @@
 // batch).  RNG / ordering spec: oracle/sampler_oracle.c header; results are
 // bit-exact against that oracle.
 //
-// Kernels (G = 2B subgraphs, g = view * B + b):
+// Kernels (G = 2 B S subgraphs of S consecutive steps, g = segment * B + b, segment = 2 * step + view):
 //   rwr_walk_kernel   1 workgroup of 4 waves per subgraph.  Walk lengths depend on
 //                     the RNG only (no dead ends by contract), so 256 threads run
 //                     256 walks at a time and a block prefix sum over the lengths
@@ -97,6 +97,7 @@ struct Work {
     int32_t *wrec;        // [G * kGridMult][kRecInts] where each induce workgroup starts        (prefix step A)
     int32_t *scratch;     // [scratch_entries] hits: (row << 16) | local column, one slot of 1024 per unit
     int32_t ncap;
+    int32_t nseg;         // batch segments of this call: 2 (views q, k) per step; subgraph g = segment * B + b
     int64_t unit_cap;
 };
 
@@ -106,15 +107,15 @@ struct WorkLayout {
     int32_t ncap;
 };
 
-inline WorkLayout work_layout(int32_t lmax, int32_t B, int64_t scratch_entries)
+inline WorkLayout work_layout(int32_t lmax, int32_t B, int32_t nseg, int64_t scratch_entries)
 {
     WorkLayout w;
     auto al = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
-    const int64_t G = 2 * (int64_t)B;
+    const int64_t G = (int64_t)nseg * B;
     w.ncap = ((lmax + 1 + 63) / 64) * 64;
     w.unit_cap = scratch_entries / kUnitElems + G + 1;    // a unit owns up to 1024 scratch slots; the last unit of a subgraph fewer
     int64_t o = 0;
-    w.off_seeds = o;  o = al(o + 4 * (int64_t)B);
+    w.off_seeds = o;  o = al(o + 4 * (int64_t)B * (nseg / 2));
     w.off_n = o;      o = al(o + 4 * G);
     w.off_quads = o;  o = al(o + 4 * G);
     w.off_nnz = o;    o = al(o + 4 * G);
@@ -164,7 +165,7 @@ __device__ __forceinline__ int row_quads(int rb, int d) { return ((rb + d + 3) >
 __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
     const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
     const double *__restrict__ seed_cdf, const int32_t *__restrict__ ltab, int64_t num_nodes,
-    int32_t ltab_len, int32_t p2max, uint64_t run_seed, int64_t first_sample_id, int32_t B,
+    int32_t ltab_len, int32_t p2max, uint64_t run_seed, int64_t first_sample_id, int64_t step_stride, int32_t B,
     uint32_t restart_u32, const int32_t *__restrict__ seeds_in, const int64_t *__restrict__ shard_off,
     int32_t num_shards, Work w)
 {
@@ -174,13 +175,15 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
     int32_t *lq = (int32_t *)smem + p2max;     // [p2max + 64] quads of the kept rows (n <= L + 1)
     const int tid = (int)threadIdx.x;
     const int g = (int)blockIdx.x;
-    const int view = g / B, b = g - view * B;
-    const uint64_t sid = (uint64_t)(first_sample_id + b);
+    // subgraph g = segment * B + b, segment = 2 * step + view: a call covers the batches of several consecutive steps
+    const int seg = g / B, b = g - seg * B;
+    const int step = seg >> 1, view = seg & 1;
+    const uint64_t sid = (uint64_t)(first_sample_id + (int64_t)step * step_stride + b);
 
     // ---- seed: graph_dataset.py:85-92 (p ~ deg^0.75; numpy choice == cdf upper bound)
     int32_t seed;
     if (seeds_in) {
-        seed = seeds_in[b];
+        seed = seeds_in[step * B + b];
     } else {
         uint32_t x[4];
         philox4x32_10((uint32_t)sid, (uint32_t)(sid >> 32), 0u, 0u, (uint32_t)run_seed ^ 0x5EED5EEDu,
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
         }
         seed = (int32_t)(lo <= last ? lo : last);
     }
-    if (view == 0 && tid == 0) w.seeds[b] = seed;
+    if (view == 0 && tid == 0) w.seeds[step * B + b] = seed;
 
     const int32_t rp0 = row_ptr[seed];
     const int32_t deg0 = row_ptr[seed + 1] - rp0;
@@ -378,10 +381,10 @@ __device__ __forceinline__ int units_of(int quads) { return (quads + kUnitQuads 
 // of the kernel before was measured: the agent-scope release every workgroup needs for the hand-off writes back L2 on
 // this multi-die part, 4096 times per launch -- the induction went from 45 to 305 us.  A kernel boundary is cheaper.)
 // dst[view * B + b] = exclusive prefix of src within each view (dgl.batch offsets restart per view).  All threads call.
-__device__ void view_prefix(int32_t B, const int32_t *src, int32_t *dst, int32_t *wsum /* LDS [4] */)
+__device__ void view_prefix(int32_t B, int32_t nseg, const int32_t *src, int32_t *dst, int32_t *wsum /* LDS [waves] */)
 {
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int view = 0; view < 2; ++view) {
+    for (int view = 0; view < nseg; ++view) {              // every segment (a view of a step) is a batch of its own
         int carry = 0;                                   // block-uniform
         for (int b0 = 0; b0 < B; b0 += (int)blockDim.x) {
             const int b = b0 + tid;
@@ -408,7 +411,7 @@ __device__ void view_prefix(int32_t B, const int32_t *src, int32_t *dst, int32_t
 __device__ void prefix_step_a(int32_t B, const Work &w, int32_t *wsum /* LDS [16][4] */, long long *wsum64 /* LDS [16] */,
                               int32_t *lvbp /* LDS [G + 1] */)
 {
-    const int G = 2 * B, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = (int)blockDim.x >> 6;
+    const int G = w.nseg * B, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = (int)blockDim.x >> 6;
     int cv = 0, cu = 0;
     long long cs = 0;
     for (int g0 = 0; g0 < G; g0 += (int)blockDim.x) {
@@ -464,7 +467,7 @@ __device__ void prefix_step_a(int32_t B, const Work &w, int32_t *wsum /* LDS [16
         rec[7] = (int32_t)(sb >> 32);
     }
     __syncthreads();
-    view_prefix(B, w.sub_n, w.nbp, wsum);
+    view_prefix(B, w.nseg, w.sub_n, w.nbp, wsum);
 }
 
 __global__ __launch_bounds__(kPrefixThreads) void prefix_a_kernel(int32_t B, Work w)
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(kPrefixThreads) void prefix_a_kernel(int32_t B, Wor
 __global__ __launch_bounds__(256) void prefix_b_kernel(int32_t B, Work w)
 {
     __shared__ int32_t wsum[4];
-    view_prefix(B, w.sub_nnz, w.ebp, wsum);
+    view_prefix(B, w.nseg, w.sub_nnz, w.ebp, wsum);
 }
 
 __device__ __forceinline__ bool scratch_overflows(const Work &w, int g, int64_t scratch_entries)
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
     Work w, int32_t *__restrict__ status, long long *ticks)
 {
     DYN_SMEM(smem);
-    const int ncap = w.ncap, G = 2 * B;
+    const int ncap = w.ncap, G = w.nseg * B;
     uint32_t *snodes = (uint32_t *)smem;                     // [ncap]     members (seed first, the rest ascending)
     int32_t *sq = (int32_t *)(snodes + ncap);                // [ncap + 1] exclusive prefix of quads per row
     int32_t *srb = sq + (ncap + 2);                          // [ncap]     row begin  (sq padded: what follows stays 8-byte aligned)
@@ -706,7 +709,8 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
 }
 
 // ------------------------------------------------------------------ K3 ----
-__global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDev oq, BatchOutDev ok,
+struct PackOuts { BatchOutDev o[2 * GCC_SAMPLE_MAX_STEPS]; };   // one batch per segment: q, k of step 0, q, k of step 1, ...
+__global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, PackOuts outs,
                                                     int64_t scratch_entries, int32_t *__restrict__ status)
 {
     __shared__ int32_t wsum[5];
@@ -714,8 +718,8 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, BatchOutDe
     __shared__ int32_t sh_base, sh_carry;
     const int tid = (int)threadIdx.x;
     const int g = (int)blockIdx.x / kPackParts, part = (int)blockIdx.x % kPackParts;
-    const int view = g / B, b = g - view * B;
-    const BatchOutDev o = view ? ok : oq;
+    const int seg = g / B, b = g - seg * B;
+    const BatchOutDev o = outs.o[seg];
     const int n = w.sub_n[g];
     const int nnz = w.sub_nnz[g];
     const long long node_base = w.nbp[g];            // (prefix steps A / B)
@@ -834,20 +838,37 @@ extern "C" {
 void gcc_sampler_debug_ticks(long long *device_ticks64) { g_induce_ticks = device_ticks64; }   /* diagnostics only */
 
 
-int64_t gcc_sampler_workspace_bytes(const gcc_graph *g, int32_t batch_size, int64_t scratch_entries)
+static int32_t check_steps(const char *who, int32_t batch_size, int32_t num_steps)
+{
+    // prefix step A keeps one LDS word per subgraph of the call; 2 * batch_size * num_steps + 1 of them must fit 64 KiB
+    if (num_steps < 1 || num_steps > GCC_SAMPLE_MAX_STEPS || (2ll * batch_size * num_steps + 1) * 4 > 64 * 1024) {
+        snprintf(g_err, kErrLen, "%s: num_steps = %d (1 .. %d, and 2 * batch_size * num_steps <= 16383)", who, num_steps,
+                 GCC_SAMPLE_MAX_STEPS);
+        return -1;
+    }
+    return 0;
+}
+
+int64_t gcc_sampler_workspace_bytes_multi(const gcc_graph *g, int32_t batch_size, int32_t num_steps, int64_t scratch_entries)
 {
     if (!g || batch_size <= 0 || scratch_entries <= 0 || g->lmax <= 0) {
         snprintf(g_err, kErrLen, "gcc_sampler_workspace_bytes: bad argument");
         return -1;
     }
-    return work_layout(g->lmax, batch_size, scratch_entries).total;
+    if (check_steps("gcc_sampler_workspace_bytes_multi", batch_size, num_steps)) return -1;
+    return work_layout(g->lmax, batch_size, 2 * num_steps, scratch_entries).total;
 }
 
-int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const gcc_batch_out *out_q,
-                         const gcc_batch_out *out_k, void *workspace, int64_t workspace_bytes,
+int64_t gcc_sampler_workspace_bytes(const gcc_graph *g, int32_t batch_size, int64_t scratch_entries)
+{
+    return gcc_sampler_workspace_bytes_multi(g, batch_size, 1, scratch_entries);
+}
+
+int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t num_steps, int64_t sample_id_stride,
+                         const gcc_batch_out *outs, void *workspace, int64_t workspace_bytes,
                          int64_t scratch_entries, int32_t *status, void *stream)
 {
-    if (!g || !p || !out_q || !out_k || !workspace || !status) {
+    if (!g || !p || !outs || !workspace || !status) {
         snprintf(g_err, kErrLen, "gcc_sample_batch: null argument");
         return -1;
     }
@@ -861,7 +882,9 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
                  p->batch_size, g->lmax, (long long)g->num_nodes, (long long)g->num_edges);
         return -2;
     }
-    const WorkLayout wl = work_layout(g->lmax, p->batch_size, scratch_entries);
+    if (check_steps("gcc_sample_multi", p->batch_size, num_steps)) return -1;
+    const int nseg = 2 * num_steps;
+    const WorkLayout wl = work_layout(g->lmax, p->batch_size, nseg, scratch_entries);
     if (workspace_bytes < wl.total) {
         snprintf(g_err, kErrLen, "gcc_sample_batch: workspace %lld < %lld bytes",
                  (long long)workspace_bytes, (long long)wl.total);
@@ -889,9 +912,10 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     w.wrec = (int32_t *)(base + wl.off_wrec);
     w.scratch = (int32_t *)(base + wl.off_scratch);
     w.ncap = wl.ncap;
+    w.nseg = nseg;
     w.unit_cap = wl.unit_cap;
 
-    const int B = p->batch_size, G = 2 * B;
+    const int B = p->batch_size, G = nseg * B;
     hipStream_t s = (hipStream_t)stream;
     int p2max = 64;
     while (p2max < g->lmax) p2max <<= 1;
@@ -903,10 +927,12 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
         snprintf(g_err, kErrLen, "gcc_sample_batch: lmax=%d / batch too large for 160 KiB of LDS", g->lmax);
         return -4;
     }
-    BatchOutDev oq = {out_q->node_off, out_q->edge_off, out_q->parent_nid, out_q->graph_id,
-                      out_q->row_ptr, out_q->col_idx, out_q->node_cap, out_q->edge_cap};
-    BatchOutDev ok = {out_k->node_off, out_k->edge_off, out_k->parent_nid, out_k->graph_id,
-                      out_k->row_ptr, out_k->col_idx, out_k->node_cap, out_k->edge_cap};
+    PackOuts po;
+    memset(&po, 0, sizeof(po));
+    for (int i = 0; i < nseg; ++i) {
+        const gcc_batch_out &o = outs[i];
+        po.o[i] = {o.node_off, o.edge_off, o.parent_nid, o.graph_id, o.row_ptr, o.col_idx, o.node_cap, o.edge_cap};
+    }
 
     prof_mark(p->prof, 0, s);
 #ifndef GCC_AMD_HIPEMU
@@ -915,7 +941,7 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
     if (lds2 > 64 * 1024) (void)hipFuncSetAttribute((const void *)induce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
 #endif
     hipLaunchKernelGGL(rwr_walk_kernel, dim3(G), dim3(kWalkThreads), lds1, s, g->row_ptr, g->col_idx, g->seed_cdf,
-                       g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, B,
+                       g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, sample_id_stride, B,
                        p->restart_u32, p->seeds, g->num_shards > 1 ? g->shard_off : nullptr, g->num_shards, w);
     hipLaunchKernelGGL(prefix_a_kernel, dim3(1), dim3(kPrefixThreads), (size_t)(G + 1) * 4, s, B, w);
     prof_mark(p->prof, 1, s);                        // marks 1 -> 2 bracket induce_kernel alone (bench.py's roofline interval)
@@ -923,7 +949,7 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
                        scratch_entries, w, status, g_induce_ticks);
     prof_mark(p->prof, 2, s);
     hipLaunchKernelGGL(prefix_b_kernel, dim3(1), dim3(256), 0, s, B, w);
-    hipLaunchKernelGGL(pack_kernel, dim3(G * kPackParts), dim3(256), 0, s, B, w, oq, ok, scratch_entries, status);
+    hipLaunchKernelGGL(pack_kernel, dim3(G * kPackParts), dim3(256), 0, s, B, w, po, scratch_entries, status);
     prof_mark(p->prof, 3, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -931,6 +957,18 @@ int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const g
         return -10;
     }
     return 0;
+}
+
+int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p, const gcc_batch_out *out_q,
+                         const gcc_batch_out *out_k, void *workspace, int64_t workspace_bytes,
+                         int64_t scratch_entries, int32_t *status, void *stream)
+{
+    if (!out_q || !out_k) {
+        snprintf(g_err, kErrLen, "gcc_sample_batch: null argument");
+        return -1;
+    }
+    const gcc_batch_out outs[2] = {*out_q, *out_k};
+    return gcc_sample_multi(g, p, 1, 0, outs, workspace, workspace_bytes, scratch_entries, status, stream);
 }
 
 }  // extern "C"

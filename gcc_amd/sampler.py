@@ -116,7 +116,10 @@ class DeviceRWRSampler:
     """Owns the output/workspace buffers and issues ``gcc_sample_batch``."""
 
     def __init__(self, graph: DeviceGraph, batch_size: int, run_seed: int = 0,
-                 edge_cap: int | None = None, scratch_entries: int | None = None, num_buffers: int = 2):
+                 edge_cap: int | None = None, scratch_entries: int | None = None, num_buffers: int = 2,
+                 max_steps: int = 1):
+        """``max_steps``: most consecutive steps one call may cover (:meth:`sample_multi`; the workspace and the
+        induction scratch are sized for that many batches, and the buffer ring must hold at least as many)."""
         import torch
 
         self.graph = graph
@@ -137,6 +140,9 @@ class DeviceRWRSampler:
         expected = int(3 * 2 * B * (graph.rw_hops / 2.5) * getattr(graph, "sb_degree", 0.0))
         self.scratch_entries = int(scratch_entries) if scratch_entries else max(
             32 << 20, 512 * B * (graph.rw_hops + 1), 8 * (graph.lmax + 1) ** 2, expected)
+        # steps per call: bounded by the library (GCC_SAMPLE_MAX_STEPS, one LDS word per subgraph in the prefix kernel)
+        self.max_steps = max(1, min(int(max_steps), 16, 16383 // (2 * B), int(num_buffers)))
+        self.scratch_entries *= self.max_steps
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self._alloc_workspace()
         i32 = dict(dtype=torch.int32, device=dev)
@@ -154,7 +160,8 @@ class DeviceRWRSampler:
     def _alloc_workspace(self):
         import torch
 
-        nbytes = self.lib.gcc_sampler_workspace_bytes(self.graph.byref(), self.batch_size, self.scratch_entries)
+        nbytes = self.lib.gcc_sampler_workspace_bytes_multi(self.graph.byref(), self.batch_size, self.max_steps,
+                                                            self.scratch_entries)
         if nbytes < 0:
             raise RuntimeError(self.lib.gcc_last_error().decode())
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.graph.device)
@@ -181,7 +188,40 @@ class DeviceRWRSampler:
             self.workspace.data_ptr(), self.workspace.numel(), self.scratch_entries,
             self.status.data_ptr(), torch.cuda.current_stream(self.graph.device).cuda_stream)
         _cabi.check(rc, "gcc_sample_batch")
+        self._last_steps = 1
         return q, k
+
+    def sample_multi(self, first_sample_id: int, num_steps: int, stride: int | None = None, prof=None):
+        """The batches of ``num_steps`` consecutive steps in one launch set (gcc_sample_multi): step t covers the sample
+        ids ``first_sample_id + t * stride + [0, B)`` (``stride`` defaults to the batch size).  -> [(q, k)] per step, each
+        pair in its own ring slot; every subgraph is bit for bit what :meth:`sample` gives for the same id."""
+        import torch
+
+        B = self.batch_size
+        stride = B if stride is None else int(stride)
+        pairs = []
+        at = 0
+        while at < num_steps:                      # more steps than one call may cover: several calls
+            n = min(self.max_steps, num_steps - at)
+            outs = (_cabi.GccBatchOut * (2 * n))()
+            for t in range(n):
+                views = self._ring[self._next]
+                self._next = (self._next + 1) % len(self._ring)
+                q, k = BatchedCSR(B, **views[0]), BatchedCSR(B, **views[1])
+                outs[2 * t], outs[2 * t + 1] = q.c_struct(), k.c_struct()
+                pairs.append((q, k))
+            params = _cabi.GccSampleParams(
+                run_seed=self.run_seed, first_sample_id=int(first_sample_id) + at * stride, batch_size=B,
+                restart_u32=self.graph.restart_u32, seeds=None,
+                prof=prof.handle if (prof is not None and at == 0) else None)
+            rc = self.lib.gcc_sample_multi(
+                self.graph.byref(), ctypes.byref(params), n, stride, outs, self.workspace.data_ptr(),
+                self.workspace.numel(), self.scratch_entries, self.status.data_ptr(),
+                torch.cuda.current_stream(self.graph.device).cuda_stream)
+            _cabi.check(rc, "gcc_sample_multi")
+            self._last_steps = n
+            at += n
+        return pairs
 
     def check_status(self) -> None:
         """Synchronising check of the device overflow flags (raises, never truncates)."""
@@ -192,10 +232,10 @@ class DeviceRWRSampler:
                                " -- construct DeviceRWRSampler with larger edge_cap/scratch_entries")
 
     def last_seeds(self):
-        """int32 [B] device view of the seeds drawn by the most recent call."""
+        """int32 device view of the seeds drawn by the most recent call ([B], or [steps * B] after sample_multi)."""
         import torch
 
-        return self.workspace[: 4 * self.batch_size].view(torch.int32)
+        return self.workspace[: 4 * self.batch_size * getattr(self, "_last_steps", 1)].view(torch.int32)
 
 
 # ------------------------------------------------------------------ reference API

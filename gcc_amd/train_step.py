@@ -117,9 +117,16 @@ class BatchProducer:
         pr = self.prof or {}
         if self.prof is not None:
             self.prof["used"] = True            # this step's marks were recorded (only chunk-launching steps have them)
-        pairs = []
-        for step in range(c * self.chunk, (c + 1) * self.chunk):
-            pairs.append(sampler.sample(self.first_id(step), prof=pr.get("sampler") if step == c * self.chunk else None))
+        s0 = c * self.chunk
+        stride = self.first_id(s0 + 1) - self.first_id(s0)
+        if self.chunk > 1 and getattr(sampler, "max_steps", 1) > 1:
+            # the whole chunk's batches in one launch set per max_steps steps (gcc_sample_multi): the sampler's five kernels
+            # are latency chains that one step's 2 * batch_size subgraphs cannot fill the GPU with
+            pairs = sampler.sample_multi(self.first_id(s0), self.chunk, stride, prof=pr.get("sampler"))
+        else:
+            pairs = []
+            for step in range(s0, s0 + self.chunk):
+                pairs.append(sampler.sample(self.first_id(step), prof=pr.get("sampler") if step == s0 else None))
         views = [g for pair in pairs for g in pair]
         pp = pr.get("posemb")
         if hasattr(posemb, "multi"):

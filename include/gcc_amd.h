@@ -115,9 +115,12 @@ typedef struct gcc_batch_out {
 } gcc_batch_out;
 
 /* bytes of caller-provided workspace needed for batch_size samples with
- * scratch_entries int32 slots of induction scratch (>= sum over subgraphs of
- * sum_i min(deg_i, n); 64 * batch_size * (lmax+1) is generous). */
+ * scratch_entries int32 slots of induction scratch (one 1024-entry slot per unit of 256 aligned quads of the members'
+ * parent rows: about the sum of the members' parent degrees over all subgraphs of the call). */
 int64_t gcc_sampler_workspace_bytes(const gcc_graph *g, int32_t batch_size, int64_t scratch_entries);
+/* ... for calls that cover num_steps consecutive DataLoader batches (gcc_sample_multi) */
+#define GCC_SAMPLE_MAX_STEPS 16
+int64_t gcc_sampler_workspace_bytes_multi(const gcc_graph *g, int32_t batch_size, int32_t num_steps, int64_t scratch_entries);
 
 /* diagnostics: subsequent gcc_sample_batch calls add wall-clock ticks (100 MHz) of induce_kernel's phases into device
  * int64[16] ([0] prefix sums over the subgraphs, [1] hash map + row prefix sums, [2] segment scans, [15] workgroups). */
@@ -127,6 +130,17 @@ void gcc_sampler_debug_ticks(long long *device_ticks64);
 int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p,
                          const gcc_batch_out *out_q, const gcc_batch_out *out_k,
                          void *workspace, int64_t workspace_bytes, int64_t scratch_entries,
+                         int32_t *status, void *stream);
+
+/* The batches of num_steps consecutive DataLoader steps in ONE launch set: step t samples the ids
+ * p->first_sample_id + t * sample_id_stride + [0, batch_size) (stride = world * batch_size for a rank of a data-parallel
+ * job) into outs[2 t] (view q) and outs[2 t + 1] (view k); p->seeds, if given, holds num_steps * batch_size seeds.
+ * Every subgraph is the one gcc_sample_batch would produce for the same sample id (bit for bit); what changes is the
+ * cost: the five kernels of a call are latency chains that a single step's 2 * batch_size subgraphs cannot fill the
+ * GPU with (the reference's DataLoader prefetches whole batches ahead the same way, train.py:577-586).
+ * num_steps <= GCC_SAMPLE_MAX_STEPS and 2 * batch_size * num_steps <= 16383; scratch_entries covers the whole call. */
+int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t num_steps, int64_t sample_id_stride,
+                         const gcc_batch_out *outs, void *workspace, int64_t workspace_bytes, int64_t scratch_entries,
                          int32_t *status, void *stream);
 
 /* --------------------------------------------------- positional embedding ---

@@ -89,6 +89,43 @@ def emu_sample_batch(g: EmuGraph, B, run_seed, first_sample_id, seeds=None, edge
     return res, int(status[0]), ws[: 4 * B].view(np.int32).copy()
 
 
+def emu_sample_multi(g: EmuGraph, B, run_seed, first_sample_id, num_steps, stride, edge_cap=None, scratch_entries=None,
+                     node_cap=None):
+    """gcc_sample_multi on the emulator -> ([(q, k) per step], status, seeds [num_steps * B])."""
+    lib = emu_lib()
+    node_cap = node_cap or B * (g.lmax + 1)
+    edge_cap = edge_cap or B * (g.lmax + 1) ** 2
+    scratch_entries = scratch_entries or 2 * num_steps * B * (g.lmax + 1) * (int(np.diff(g.row_ptr).max()) + 8)
+    nbytes = lib.gcc_sampler_workspace_bytes_multi(ctypes.byref(g.c), B, num_steps, scratch_entries)
+    assert nbytes > 0, lib.gcc_last_error().decode()
+    ws = np.zeros(nbytes, dtype=np.uint8)
+    status = np.zeros(1, dtype=np.int32)
+    outs = []
+    structs = (_cabi.GccBatchOut * (2 * num_steps))()
+    for i in range(2 * num_steps):
+        o = dict(node_off=np.zeros(B + 1, np.int32), edge_off=np.zeros(B + 1, np.int32),
+                 parent_nid=np.zeros(node_cap, np.int32), graph_id=np.zeros(node_cap, np.int32),
+                 row_ptr=np.zeros(node_cap + 1, np.int32), col_idx=np.zeros(edge_cap, np.int32))
+        outs.append(o)
+        structs[i] = _cabi.GccBatchOut(node_off=_p(o["node_off"]), edge_off=_p(o["edge_off"]),
+                                       parent_nid=_p(o["parent_nid"]), graph_id=_p(o["graph_id"]),
+                                       row_ptr=_p(o["row_ptr"]), col_idx=_p(o["col_idx"]),
+                                       node_cap=node_cap, edge_cap=edge_cap)
+    params = _cabi.GccSampleParams(run_seed=run_seed, first_sample_id=first_sample_id, batch_size=B,
+                                   restart_u32=g.restart_u32, seeds=None)
+    rc = lib.gcc_sample_multi(ctypes.byref(g.c), ctypes.byref(params), num_steps, stride, structs, _p(ws), nbytes,
+                              scratch_entries, _p(status), None)
+    if rc != 0:
+        raise RuntimeError(lib.gcc_last_error().decode())
+    res = []
+    for o in outs:
+        n, e = int(o["node_off"][B]), int(o["edge_off"][B])
+        res.append(dict(node_off=o["node_off"], edge_off=o["edge_off"], parent_nid=o["parent_nid"][:n],
+                        graph_id=o["graph_id"][:n], row_ptr=o["row_ptr"][: n + 1], col_idx=o["col_idx"][:e]))
+    pairs = [(res[2 * t], res[2 * t + 1]) for t in range(num_steps)]
+    return pairs, int(status[0]), ws[: 4 * B * num_steps].view(np.int32).copy()
+
+
 def emu_ginw_forward(node_off, row_ptr, col_idx, x_bits, layers):
     """gcc_ginw_forward on the emulator.  x_bits: uint16 [N, 256] bf16 patterns; layers: dicts of numpy arrays with
     w0/w1 as uint16 bf16 patterns [256, 256] and s0..t2 float32 [256].  Returns (rows uint16, pooled f32, status)."""

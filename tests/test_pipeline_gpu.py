@@ -51,7 +51,8 @@ def _run(pipelined, graph):
     nbuf = (DEPTH if pipelined else 1) * CHUNK
     lanes = []
     for _ in range(nl):
-        smp = DeviceRWRSampler(graph, B, run_seed=0, num_buffers=nbuf)
+        # pipelined: a chunk's batches in one gcc_sample_multi launch set; sequential: one gcc_sample_batch per step
+        smp = DeviceRWRSampler(graph, B, run_seed=0, num_buffers=nbuf, max_steps=CHUNK if pipelined else 1)
         lanes.append((smp, DevicePosEmb(B, smp.node_cap, 32, device=dev, seed=0, num_buffers=nbuf, max_views=2 * CHUNK)))
     tr = MoCoTrainStep(model, ema, contrast, lanes[0][0], lanes[0][1], lanes=lanes, depth=DEPTH, chunk=CHUNK,
                        prefetch=pipelined)

@@ -31,7 +31,7 @@ def _run(collectives):
     contrast = MemoryMoCo(64, None, 256, 0.07, use_softmax=True).to(dev)
     lanes = []
     for _ in range(2):
-        smp = DeviceRWRSampler(graph, B, run_seed=3, num_buffers=depth * chunk)
+        smp = DeviceRWRSampler(graph, B, run_seed=3, num_buffers=depth * chunk, max_steps=chunk)
         lanes.append((smp, DevicePosEmb(B, smp.node_cap, 32, device=dev, seed=3, num_buffers=depth * chunk, max_views=2 * chunk)))
     tr = MoCoTrainStep(model, ema, contrast, lanes[0][0], lanes[0][1], lanes=lanes, depth=depth, chunk=chunk,
                        collectives=collectives)

@@ -181,3 +181,31 @@ def test_shard_seed_distribution_is_deg_075_within_the_shard(coracle):
         got = np.isin(seeds - a, top).mean()
         exp = p[top].sum()
         assert abs(got - exp) < 5 * np.sqrt(exp * (1 - exp) / B), (sh, got, exp)
+
+
+def test_multi_step_call_equals_the_single_step_calls(coracle):
+    """gcc_sample_multi: the batches of S consecutive steps in one launch set (sample ids first + t * stride + [0, B)) are,
+    bit for bit, what S gcc_sample_batch calls produce -- and what the oracle says -- including the per-segment batch
+    offsets, on a sharded corpus (the shard follows the batch index of every step) and with a rank stride."""
+    from tests.hipemu.emu_driver import emu_sample_multi
+    from tests.shard_check import corpus, oracle_batch, reference_layout
+
+    _, rp, ci, shard_off = reference_layout(corpus(), num_workers=2)
+    g = EmuGraph(rp, ci, rw_hops=32, shard_off=shard_off)
+    B, S, first, stride = 5, 3, 7 * 5, 2 * 5                       # rank 1 of 2: ids 35.., 45.., 55..
+    pairs, status, seeds = emu_sample_multi(g, B, 11, first, S, stride)
+    assert status == 0 and len(pairs) == S
+    for t in range(S):
+        f = first + t * stride
+        single, st1, used = emu_sample_batch(g, B, 11, f)
+        assert st1 == 0 and seeds[t * B:(t + 1) * B].tolist() == used.tolist()
+        oseeds, views = oracle_batch(coracle, rp, ci, shard_off, g.ltab, g.restart_u32, B, 11, f)
+        assert used.tolist() == oseeds.tolist()
+        for v in range(2):
+            for k in KEYS + ("edge_off", "graph_id"):
+                assert np.array_equal(pairs[t][v][k], single[v][k]), (t, v, k)
+            for k in KEYS:
+                assert np.array_equal(pairs[t][v][k], views[v][k]), (t, v, k)
+    # limits are refused, not truncated
+    with pytest.raises((RuntimeError, AssertionError), match="num_steps"):
+        emu_sample_multi(g, B, 11, first, 17, stride)

@@ -344,7 +344,7 @@ def main(args):
         lanes, depth = [], 2
         for _ in range(args.producer_lanes):
             smp = DeviceRWRSampler(train_dataset.graph, args.batch_size, run_seed=args.seed,
-                                   num_buffers=depth * args.producer_chunk)
+                                   num_buffers=depth * args.producer_chunk, max_steps=args.producer_chunk)
             lanes.append((smp, DevicePosEmb(args.batch_size, smp.node_cap, args.positional_embedding_size, device=dev,
                                             seed=args.seed, num_buffers=depth * args.producer_chunk,
                                             max_views=min(2 * args.producer_chunk, 32))))
