@@ -290,7 +290,7 @@ def sampler_source_hash():
     return h.hexdigest()
 
 
-def committed_pmc_traffic(args, v, e):
+def committed_pmc_traffic(args, v, e, steps_per_call=1):
     """PMC counters cannot be collected from inside the benchmarked process; the figure comes from the separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes summarised by tools/pmc_sampler.py into
     profiles/pmc_sampler.json.  That file records the hash of the kernel source and the workload it was collected
@@ -302,40 +302,50 @@ def committed_pmc_traffic(args, v, e):
     rec = json.load(open(PMC_FILE))
     if rec.get("source_sha256") != sampler_source_hash():
         return None, "profiles/pmc_sampler.json is stale (collected from another build of sampler.hip): refused"
-    key = f"{v}/{e}/bsz{args.batch_size}/hops{args.rw_hops}"
+    key = f"{v}/{e}/bsz{args.batch_size}/hops{args.rw_hops}" + (f"/steps{steps_per_call}" if steps_per_call > 1 else "")
     ent = rec.get("workloads", {}).get(key)
     if ent is None:
         return None, f"profiles/pmc_sampler.json has no entry for workload {key}"
     return ent["induce_kernel_hbm_bytes_per_launch"], f"profiles/pmc_sampler.json[{key}] ({ent.get('correction', 'raw')})"
 
 
-def sampler_probe(sampler, rp, first_id, args, nsample, lt, Prof, torch):
-    """Isolated probe loop: HIP-event durations of the three sampler kernels and the exact algorithmic bytes of the
-    batches they produced (same kernels, same batch ids as the timed steps, GPU otherwise idle)."""
+def sampler_probe(sampler, rp, first_id, args, nsample, lt, Prof, torch, steps_per_call=1, world=1):
+    """Isolated probe loop: HIP-event durations of the three sampler intervals and the exact algorithmic bytes of the
+    batches they produced (same kernels, same batch ids as the timed steps, GPU otherwise idle).  A launch covers
+    ``steps_per_call`` consecutive steps (gcc_sample_multi: what the producer lanes / the sampler mode issue); bytes
+    are per LAUNCH, i.e. summed over its steps."""
     acc = dict(walk=0, induce=0, pack=0, total=0)
     iso = np.zeros(3)
     deg = np.diff(rp)
     shape = dict(nodes_q=0.0, nodes_k=0.0, edges_q=0.0, edges_k=0.0)
-    for i in range(-2, nsample):                  # two untimed probe warm-ups
+    S = max(1, min(steps_per_call, getattr(sampler, "max_steps", 1)))
+    B = sampler.batch_size
+    ncalls = max(2, nsample // S)
+    for i in range(-2, ncalls):                   # two untimed probe warm-ups
         pr = Prof(4)
-        q, k = sampler.sample(first_id(max(i, 0)), prof=pr)
+        step0 = max(i, 0) * S
+        if S > 1:
+            pairs = sampler.sample_multi(first_id(step0), S, world * B, prof=pr)
+        else:
+            pairs = [sampler.sample(first_id(step0), prof=pr)]
         torch.cuda.synchronize()
         if i < 0:
             continue
-        iso += np.array([pr.elapsed_ms(j, j + 1) for j in range(3)]) / nsample
+        iso += np.array([pr.elapsed_ms(j, j + 1) for j in range(3)]) / ncalls
         seeds = sampler.last_seeds().cpu().numpy()
-        L = lt[deg[seeds]]
-        cq, ck = q.csr_numpy(), k.csr_numpy()
-        bts = sampler_algorithmic_bytes(rp, [(cq, L), (ck, L)])
-        for key in acc:
-            acc[key] += bts[key] / nsample
-        shape["nodes_q"] += len(cq["parent_nid"]) / nsample
-        shape["nodes_k"] += len(ck["parent_nid"]) / nsample
-        shape["edges_q"] += len(cq["col_idx"]) / nsample
-        shape["edges_k"] += len(ck["col_idx"]) / nsample
+        for t, (q, k) in enumerate(pairs):
+            L = lt[deg[seeds[t * B:(t + 1) * B]]]
+            cq, ck = q.csr_numpy(), k.csr_numpy()
+            bts = sampler_algorithmic_bytes(rp, [(cq, L), (ck, L)])
+            for key in acc:
+                acc[key] += bts[key] / ncalls
+            shape["nodes_q"] += len(cq["parent_nid"]) / (ncalls * S)
+            shape["nodes_k"] += len(ck["parent_nid"]) / (ncalls * S)
+            shape["edges_q"] += len(cq["col_idx"]) / (ncalls * S)
+            shape["edges_k"] += len(ck["col_idx"]) / (ncalls * S)
     # the event marks sit around groups of launches: walk + prefix step A | induction alone | prefix step B + pack
     return {"rwr_walk_kernel+prefix_a_kernel": float(iso[0]), "induce_kernel": float(iso[1]),
-            "prefix_b_kernel+pack_kernel": float(iso[2])}, acc, shape
+            "prefix_b_kernel+pack_kernel": float(iso[2])}, acc, shape, S
 
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-f32 MFMA = the f32 vector rate
@@ -590,13 +600,18 @@ def main():
         # producer streams overlap several sampler / eigensolver launches, so in-step marks measure contention.
         nsample = min(args.steps, 12)
         pe_probe = None
-        kern_iso, acc, probe_shape = sampler_probe(sampler, rp, lambda i: first_id(first_timed + i), args, nsample, lt, Prof, torch)
+        # the launch shape the mode really issues: a producer chunk (training modes) / --sampler-steps (sampler mode)
+        spc = chunk if args.mode != "sampler" else extra.get("sampler_steps_per_call", 1)
+        nsample = max(nsample, 2 * spc)
+        kern_iso, acc_call, probe_shape, spc = sampler_probe(sampler, rp, lambda i: first_id(first_timed + i), args, nsample, lt,
+                                                             Prof, torch, steps_per_call=spc, world=world)
+        acc = {k: v / spc for k, v in acc_call.items()}       # per STEP (stage_rooflines, algorithmic_bytes_per_step)
         if args.mode != "sampler" and args.posemb == "device":
             pe_probe = posemb_probe(sampler, posemb, lambda i: first_id(first_timed + i), min(chunk, 8), torch)
         sampler.check_status()
         dom = "induce_kernel"
-        achieved = acc["induce"] / (kern_iso[dom] * 1e-3) / 1e9
-        traffic, traffic_src = committed_pmc_traffic(args, V, E)
+        achieved = acc_call["induce"] / (kern_iso[dom] * 1e-3) / 1e9
+        traffic, traffic_src = committed_pmc_traffic(args, V, E, spc)
         ms_per_step = dt / args.steps * 1e3
         out = {
             "metric": "sampled-subgraphs/sec", "value": 2 * B * world * args.steps / dt, "unit": "subgraphs/s",
@@ -611,13 +626,15 @@ def main():
                        "nce_k": args.nce_k if args.mode == "train" else (B - 1 if args.mode == "e2e" else None),
                        "rw_hops": args.rw_hops, "restart_prob": args.restart_prob, "stages": stages,
                        "parallelism": f"dp{world} (seed batch sharded, graph replicated)" + ("; OVERSUBSCRIBED: %d ranks on %d device(s), gloo, correctness only" % (world, ndev) if oversubscribed else "")},
-            "kernel_ms_isolated": kern_iso,
+            "kernel_ms_isolated": kern_iso, "kernel_ms_isolated_steps_per_launch": spc,
             "roofline": {"bound": "hbm", "kernel": dom,
                          "measured": "isolated probe loop after the timed region: HIP events (gcc_prof marks on the launch stream) right "
-                                     "before and after induce_kernel inside gcc_sample_batch; rocprofv3 --kernel-trace --stats of the same "
-                                     "kernels alone: profiles/r2_kernel_stats_sampler_alone.csv",
+                                     "before and after induce_kernel inside gcc_sample_multi (one launch covers steps_per_launch "
+                                     "consecutive batches, as the producer lanes issue it); rocprofv3 --kernel-trace --stats of the "
+                                     "same launches alone: profiles/r3_kernel_stats_sampler_alone*.csv",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "algorithmic_bytes_per_launch": acc["induce"], "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": acc_call["induce"], "steps_per_launch": spc,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_note": "committed constant from separate rocprofv3 --pmc passes of this build (hash-guarded), not a same-run measurement"},
             "algorithmic_bytes_per_step": acc,
         }
@@ -627,7 +644,7 @@ def main():
             out["stage_rooflines"] = {"sampler_end_to_end": dict(
                 bound="hbm", algorithmic_bytes_per_step=acc["total"], ms_per_step=ms_per_step, achieved=e2e, peak=HBM_PEAK_GBPS,
                 unit="GB/s", frac=e2e / HBM_PEAK_GBPS, steps_per_call=extra.get("sampler_steps_per_call"),
-                single_step_call_ms_isolated=sum(kern_iso.values()))}
+                isolated_call_ms=sum(kern_iso.values()))}
         if args.mode in ("train", "e2e"):
             out["config"].update(producer_lanes=args.lanes, producer_depth=args.depth, producer_chunk=chunk,
                                  producer_ahead=trainer.producer.ahead, reserved_cus=args.reserved_cus)
@@ -640,7 +657,7 @@ def main():
                     stage_ms["posemb_chunk_of_%d_views" % min(2 * chunk, 32)] = float(
                         np.mean([p["posemb"].elapsed_ms(0, 1) for p in used]))
             out["stage_ms"] = stage_ms
-            out["stage_rooflines"] = stage_rooflines(args, acc, kern_iso, stage_ms, probe_shape, pe_probe)
+            out["stage_rooflines"] = stage_rooflines(args, acc, {k: v / spc for k, v in kern_iso.items()}, stage_ms, probe_shape, pe_probe)
         out.update(extra)
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline_sampler(rp, ci, args) if args.mode == "sampler" else cpu_baseline(rp, ci, args)

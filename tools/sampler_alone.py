@@ -18,13 +18,19 @@ ap.add_argument("--edges", type=int, default=10_000_000)
 ap.add_argument("--batch-size", type=int, default=256)
 ap.add_argument("--rw-hops", type=int, default=256)
 ap.add_argument("--launches", type=int, default=110)
+ap.add_argument("--steps-per-call", type=int, default=1, help="consecutive batches per launch set (gcc_sample_multi)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 rp, ci = powerlaw_graph(a.nodes, a.edges, seed=0)
 graph = DeviceGraph(rp, ci, rw_hops=a.rw_hops, restart_prob=0.8, device=dev, validate=False)
-sampler = DeviceRWRSampler(graph, a.batch_size, run_seed=0, num_buffers=2)
+S = a.steps_per_call
+sampler = DeviceRWRSampler(graph, a.batch_size, run_seed=0, num_buffers=max(2, S), max_steps=S)
 for i in range(a.launches):
-    sampler.sample(10_000_000 + i * a.batch_size)
+    if S > 1:
+        sampler.sample_multi(10_000_000 + i * S * a.batch_size, S)
+    else:
+        sampler.sample(10_000_000 + i * a.batch_size)
     torch.cuda.synchronize()
 sampler.check_status()
-print("ok workload %d/%d/bsz%d/hops%d launches %d" % (len(rp) - 1, len(ci), a.batch_size, a.rw_hops, a.launches))
+print("ok workload %d/%d/bsz%d/hops%d%s launches %d" % (len(rp) - 1, len(ci), a.batch_size, a.rw_hops,
+                                                        "/steps%d" % S if S > 1 else "", a.launches))
