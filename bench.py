@@ -344,7 +344,7 @@ def sampler_probe(sampler, rp, first_id, args, nsample, lt, Prof, torch, steps_p
             shape["edges_q"] += len(cq["col_idx"]) / (ncalls * S)
             shape["edges_k"] += len(ck["col_idx"]) / (ncalls * S)
     # the event marks sit around groups of launches: walk + prefix step A | induction alone | prefix step B + pack
-    return {"rwr_walk_kernel+prefix_a_kernel": float(iso[0]), "induce_kernel": float(iso[1]),
+    return {"rwr_walk_kernel+prefix_a_kernel+records_kernel": float(iso[0]), "induce_kernel": float(iso[1]),
             "prefix_b_kernel+pack_kernel": float(iso[2])}, acc, shape, S
 
 

@@ -89,6 +89,7 @@ struct Work {
     int32_t *rowbeg;      // [G][ncap]   row_ptr[node]
     int32_t *rowdeg;      // [G][ncap]   parent degree
     int32_t *rowq;        // [G][ncap]   exclusive prefix of the rows' quads within the subgraph (walk kernel)
+    int32_t *vbp;         // [G + 1]     exclusive prefix of the subgraphs' virtual workgroups   (prefix kernel A)
     int32_t *ubp;         // [G + 1]     exclusive prefix of the subgraphs' units                (prefix kernel A)
     long long *sbp;       // [G + 1]     exclusive prefix of the subgraphs' scratch slots        (prefix kernel A)
     int32_t *nbp;         // [G + 1]     node offset of a subgraph inside its view's batch       (prefix kernel A)
@@ -103,7 +104,7 @@ struct Work {
 
 struct WorkLayout {
     int64_t off_seeds, off_n, off_quads, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowq,
-        off_ubp, off_sbp, off_nbp, off_ebp, off_ucnt, off_wrec, off_scratch, total, unit_cap;
+        off_vbp, off_ubp, off_sbp, off_nbp, off_ebp, off_ucnt, off_wrec, off_scratch, total, unit_cap;
     int32_t ncap;
 };
 
@@ -123,6 +124,7 @@ inline WorkLayout work_layout(int32_t lmax, int32_t B, int32_t nseg, int64_t scr
     w.off_rowbeg = o; o = al(o + 4 * G * w.ncap);
     w.off_rowdeg = o; o = al(o + 4 * G * w.ncap);
     w.off_rowq = o;   o = al(o + 4 * G * w.ncap);
+    w.off_vbp = o;    o = al(o + 4 * (G + 1));
     w.off_ubp = o;    o = al(o + 4 * (G + 1));
     w.off_sbp = o;    o = al(o + 8 * (G + 1));
     w.off_nbp = o;    o = al(o + 4 * (G + 1));
@@ -443,30 +445,8 @@ __device__ void prefix_step_a(int32_t B, const Work &w, int32_t *wsum /* LDS [16
         __syncthreads();
     }
     if (tid == 0) { lvbp[G] = cv; w.ubp[G] = cu; w.sbp[G] = cs; }
-    __syncthreads();                                      // ubp / sbp (written above by this workgroup) are read back below
-    const int nwg = G * kGridMult;
-    const int chunk = (cv + nwg - 1) / nwg;
-    for (int b = tid; b < nwg; b += (int)blockDim.x) {
-        const int vb0 = b * chunk;
-        int32_t *rec = w.wrec + (int64_t)b * kRecInts;
-        const int count = min(chunk, cv - vb0);
-        if (count <= 0) { rec[0] = 0; continue; }
-        int lo = 0, hi = G;                               // last g with vbp[g] <= vb0 (it has virtual workgroups: vbp[g + 1] > vb0)
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (lvbp[mid] <= vb0) lo = mid; else hi = mid;
-        }
-        const long long sb = w.sbp[lo];
-        rec[0] = count;
-        rec[1] = lo;
-        rec[2] = vb0 - lvbp[lo];
-        rec[3] = w.sub_n[lo];
-        rec[4] = w.sub_quads[lo];
-        rec[5] = w.ubp[lo];
-        rec[6] = (int32_t)(sb & 0xFFFFFFFFll);
-        rec[7] = (int32_t)(sb >> 32);
-    }
     __syncthreads();
+    for (int g = tid; g <= G; g += (int)blockDim.x) w.vbp[g] = lvbp[g];      // for records_kernel
     view_prefix(B, w.nseg, w.sub_n, w.nbp, wsum);
 }
 
@@ -476,6 +456,37 @@ __global__ __launch_bounds__(kPrefixThreads) void prefix_a_kernel(int32_t B, Wor
     __shared__ int32_t wsum[64];
     __shared__ long long wsum64[16];
     prefix_step_a(B, w, wsum, wsum64, (int32_t *)smem);
+}
+// The start record of every induce workgroup (see prefix_step_a): one thread per record, on as many workgroups as it
+// takes -- as the tail of the single-workgroup prefix kernel this was 9 us per step, and 104 us of a 16-step launch
+// (65 k records by 1024 threads).
+__global__ __launch_bounds__(256) void records_kernel(int32_t B, Work w)
+{
+    const int G = w.nseg * B;
+    const int nwg = G * kGridMult;
+    const int b = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (b >= nwg) return;
+    const int32_t *vbp = w.vbp;
+    const int cv = vbp[G];
+    const int chunk = (cv + nwg - 1) / nwg;
+    const int vb0 = b * chunk;
+    int32_t *rec = w.wrec + (int64_t)b * kRecInts;
+    const int count = min(chunk, cv - vb0);
+    if (count <= 0) { rec[0] = 0; return; }
+    int lo = 0, hi = G;                               // last g with vbp[g] <= vb0 (it has virtual workgroups: vbp[g + 1] > vb0)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (vbp[mid] <= vb0) lo = mid; else hi = mid;
+    }
+    const long long sb = w.sbp[lo];
+    rec[0] = count;
+    rec[1] = lo;
+    rec[2] = vb0 - vbp[lo];
+    rec[3] = w.sub_n[lo];
+    rec[4] = w.sub_quads[lo];
+    rec[5] = w.ubp[lo];
+    rec[6] = (int32_t)(sb & 0xFFFFFFFFll);
+    rec[7] = (int32_t)(sb >> 32);
 }
 __global__ __launch_bounds__(256) void prefix_b_kernel(int32_t B, Work w)
 {
@@ -904,6 +915,7 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     w.rowbeg = (int32_t *)(base + wl.off_rowbeg);
     w.rowdeg = (int32_t *)(base + wl.off_rowdeg);
     w.rowq = (int32_t *)(base + wl.off_rowq);
+    w.vbp = (int32_t *)(base + wl.off_vbp);
     w.ubp = (int32_t *)(base + wl.off_ubp);
     w.sbp = (long long *)(base + wl.off_sbp);
     w.nbp = (int32_t *)(base + wl.off_nbp);
@@ -944,6 +956,7 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
                        g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, sample_id_stride, B,
                        p->restart_u32, p->seeds, g->num_shards > 1 ? g->shard_off : nullptr, g->num_shards, w);
     hipLaunchKernelGGL(prefix_a_kernel, dim3(1), dim3(kPrefixThreads), (size_t)(G + 1) * 4, s, B, w);
+    hipLaunchKernelGGL(records_kernel, dim3((G * kGridMult + 255) / 256), dim3(256), 0, s, B, w);
     prof_mark(p->prof, 1, s);                        // marks 1 -> 2 bracket induce_kernel alone (bench.py's roofline interval)
     hipLaunchKernelGGL(induce_kernel, dim3(G * kGridMult), dim3(kInduceThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,
                        scratch_entries, w, status, g_induce_ticks);
