@@ -71,10 +71,182 @@ constexpr int kNodeMax = 1024;       // largest subgraph the deflating direct ke
 constexpr uint16_t kNone = 0xFFFFu;
 constexpr float kZeroEig = 1e-5f;    // |lambda| below this is "the null space" when ranking
 
+//
+// ---- exact stalk deflation.  A "stalk" of a hub h is a pendant two-path h - a - b (deg a = 2, deg b = 1); hub seeds
+// of the 1M-node graph carry hundreds of them.  With s >= 2 stalks on h, the vectors c_i (x_a, x_b) = c_i (1, +-1) / sqrt(2)
+// with sum c_i = 0 are exact eigenvectors for +-1/sqrt(2) (they do not couple to h), s - 1 of each sign, and the rest of
+// the spectrum is that of the quotient in which the s stalks are ONE stalk whose middle node couples to h with
+// sqrt(s / (2 d_h)) (the a - b coupling 1/sqrt(2) is unchanged); a quotient eigenvector expands to every stalk divided by
+// sqrt(s).  The +1/sqrt(2) copies usually ARE among the top 32, so their contrasts (the same Helmert basis as for twin
+// leaves, over the stalks of a hub in index order) are merged into the ranking by value.  Twin leaves and stalks never
+// overlap: a stalk's middle node has exactly one leaf, a hub of >= 2 stalks has >= 2 non-leaf neighbours.
 struct Defl {
-    uint16_t *par, *rep, *ridx, *ord;   // [kNodeMax] parent of a leaf | first leaf of a parent | reduced index | leaf order
-    int32_t *tcnt, *cbase;              // [kNodeMax] leaves per parent | contrast numbering (exclusive prefix of t - 1)
+    int32_t *tcnt, *cbase, *pcnt;       // [cap] leaves per parent | contrast bases: twin groups (low 16 bits), stalk groups (high 16) | stalks per hub
+    uint16_t *par, *rep, *ridx, *ord;   // [cap] parent of a leaf | first leaf of a parent | reduced index | order inside the group
+    uint16_t *phub, *prep;              // [cap] hub of a stalk's middle node | middle node of a hub's first stalk
 };
+constexpr int kDeflNodeBytes = 24;
+constexpr float kStalkEig = 0.70710678f;
+constexpr int kStalkSrc = 4097;         // column codes: j >= 0 eigenvector j | -(c + 1) twin contrast c | -(kStalkSrc + 2 c + sign) stalk contrast c
+
+__device__ __forceinline__ void defl_bind(Defl &d, void *base, int cap)
+{
+    d.tcnt = (int32_t *)base;
+    d.cbase = d.tcnt + cap;
+    d.pcnt = d.cbase + cap;
+    d.par = (uint16_t *)(d.pcnt + cap);
+    d.rep = d.par + cap;
+    d.ridx = d.rep + cap;
+    d.ord = d.ridx + cap;
+    d.phub = d.ord + cap;
+    d.prep = d.phub + cap;
+}
+
+// the three per-node passes of the table build (a barrier between them; rp = the subgraph's row pointers, col = the batch's column ids)
+__device__ __forceinline__ void defl_init_node(const Defl &d, int i, const int32_t *rp, const int32_t *col, int n0)
+{
+    d.par[i] = rp[i + 1] - rp[i] == 1 ? (uint16_t)(col[rp[i]] - n0) : kNone;
+    d.tcnt[i] = 0;
+    d.pcnt[i] = 0;
+    d.rep[i] = kNone;
+    d.prep[i] = kNone;
+    d.phub[i] = kNone;
+    d.ord[i] = 0;
+}
+__device__ __forceinline__ void defl_count_node(const Defl &d, int i, const int32_t *rp, const int32_t *col, int n0, bool stalks)
+{
+    if (d.par[i] != kNone) {
+        atomicAdd(&d.tcnt[d.par[i]], 1);
+    } else if (stalks && rp[i + 1] - rp[i] == 2) {
+        const int x = col[rp[i]] - n0, y = col[rp[i] + 1] - n0;
+        const bool lx = rp[x + 1] - rp[x] == 1, ly = rp[y + 1] - rp[y] == 1;
+        if (lx != ly) {
+            const int h = lx ? y : x;
+            d.phub[i] = (uint16_t)h;
+            atomicAdd(&d.pcnt[h], 1);
+        }
+    }
+}
+__device__ __forceinline__ void defl_order_node(const Defl &d, int p, const int32_t *rp, const int32_t *col, int n0)
+{
+    const bool lt = d.tcnt[p] >= 2, st = d.pcnt[p] >= 2;
+    if (!lt && !st) return;
+    int o = 0, q = 0;
+    for (int e = rp[p]; e < rp[p + 1]; ++e) {      // rows are sorted: the members of a group in index order
+        const int j = col[e] - n0;
+        if (lt && d.par[j] == (uint16_t)p) {
+            if (o == 0) d.rep[p] = (uint16_t)j;
+            d.ord[j] = (uint16_t)o++;
+        } else if (st && d.phub[j] == (uint16_t)p) {
+            if (q == 0) d.prep[p] = (uint16_t)j;
+            d.ord[j] = (uint16_t)q++;
+        }
+    }
+}
+// node i is represented by another node of its group in the quotient
+__device__ __forceinline__ bool defl_collapsed(const Defl &d, int i)
+{
+    const int pi = d.par[i];
+    if (pi != (int)kNone) {
+        if (d.tcnt[pi] >= 2) return d.rep[pi] != (uint16_t)i;                    // twin leaf
+        const int h = d.phub[pi];                                                 // the leaf of a stalk?
+        return h != (int)kNone && d.pcnt[h] >= 2 && d.prep[h] != (uint16_t)pi;
+    }
+    const int h = d.phub[i];
+    return h != (int)kNone && d.pcnt[h] >= 2 && d.prep[h] != (uint16_t)i;
+}
+// factor on 1 / sqrt(d_i d_j) for the coupling of two KEPT neighbours
+__device__ __forceinline__ float defl_coupling(const Defl &d, int i, int j)
+{
+    float f = 1.0f;
+    if (d.par[j] == (uint16_t)i && d.tcnt[i] >= 2) f = sqrtf((float)d.tcnt[i]);
+    else if (d.par[i] == (uint16_t)j && d.tcnt[j] >= 2) f = sqrtf((float)d.tcnt[j]);
+    else if (d.phub[j] == (uint16_t)i && d.pcnt[i] >= 2) f = sqrtf((float)d.pcnt[i]);
+    else if (d.phub[i] == (uint16_t)j && d.pcnt[j] >= 2) f = sqrtf((float)d.pcnt[j]);
+    return f;
+}
+// what the expansion needs of the tables, 8 bytes per node: quotient row | order inside the group | group size (0 = not
+// grouped; bit 15 = stalk member, bit 14 = the stalk's leaf) | contrast base of the group
+constexpr int kRecStalk = 0x8000, kRecStalkLeaf = 0x4000, kRecSize = 0x3FFF;
+__device__ __forceinline__ void defl_record(const Defl &d, int v, const int32_t *rp, const int32_t *col, int n0, uint16_t *rec)
+{
+    const int pv = d.par[v];
+    int rsrc = d.ridx[v], o = 0, g = 0, cb = 0;
+    if (pv != (int)kNone && d.tcnt[pv] >= 2) {
+        rsrc = d.ridx[d.rep[pv]]; o = d.ord[v]; g = d.tcnt[pv]; cb = d.cbase[pv] & 0xFFFF;
+    } else {
+        const int mid = pv != (int)kNone ? pv : v;                               // the middle node if v belongs to a stalk
+        const int h = d.phub[mid];
+        if (h != (int)kNone && d.pcnt[h] >= 2) {
+            int r = d.prep[h];
+            if (pv != (int)kNone) {                                              // the first stalk's leaf
+                const int x = col[rp[r]] - n0, y = col[rp[r] + 1] - n0;
+                r = rp[x + 1] - rp[x] == 1 ? x : y;
+            }
+            rsrc = d.ridx[r]; o = d.ord[mid]; cb = (int)((uint32_t)d.cbase[h] >> 16);
+            g = d.pcnt[h] | kRecStalk | (pv != (int)kNone ? kRecStalkLeaf : 0);
+        }
+    }
+    rec[0] = (uint16_t)rsrc; rec[1] = (uint16_t)o; rec[2] = (uint16_t)g; rec[3] = (uint16_t)cb;
+}
+// entry (node, output column) of the raw eigenvector matrix; Y = the quotient's eigenvectors [row][ldy]
+__device__ __forceinline__ float defl_expand(int rsrc, int o, int g, int cb, int src, const float *Y, int ldy)
+{
+    const int tp = g & kRecSize;
+    if (src >= 0) return Y[rsrc * ldy + src] * (tp ? 1.0f / sqrtf((float)tp) : 1.0f);
+    if (!tp) return 0.f;
+    int c;
+    float f = 1.0f;
+    if (src > -kStalkSrc) {
+        if (g & kRecStalk) return 0.f;
+        c = -src - 1;
+    } else {
+        if (!(g & kRecStalk)) return 0.f;
+        const int q = -src - kStalkSrc;
+        c = q >> 1;
+        f = ((q & 1) && (g & kRecStalkLeaf)) ? -kStalkEig : kStalkEig;
+    }
+    const int jm1 = c - cb;                                                      // contrast j = jm1 + 1 of the group
+    if (jm1 < 0 || jm1 >= tp - 1) return 0.f;
+    const int j = jm1 + 1;
+    const float nrm = f / sqrtf((float)(j * (j + 1)));
+    return o < j ? nrm : (o == j ? -(float)j * nrm : 0.f);
+}
+// Ranks of the merged spectrum: lam[0 .. kq) (descending: the top of the quotient's spectrum), zp stalk contrasts at
+// +1/sqrt(2), the null space = zeros of M' then the z twin contrasts, zp stalk contrasts at -1/sqrt(2).  eigsh(which="LA")
+// returns the k largest in ascending order (data_util.py:251).  One thread.  -> number of quotient eigenvectors needed.
+__device__ int rank_columns(const float *lam, int kq, int k, int z, int zp, int *colsrc, float *ev)
+{
+    int nge_s = 0, npz = 0, nge_ms = 0, na = 0;
+    for (int j = 0; j < kq; ++j) {
+        const float l = lam[j];
+        if (l >= kStalkEig - kZeroEig) nge_s = j + 1;
+        if (l >= -kZeroEig) npz = j + 1;
+        if (l >= -kStalkEig - kZeroEig) nge_ms = j + 1;
+    }
+    for (int j = 0; j < kq; ++j) {
+        const float l = lam[j];
+        const int r = j + (j >= nge_s ? zp : 0) + (j >= npz ? z : 0) + (j >= nge_ms ? zp : 0);
+        if (r < k) {
+            na = j + 1;
+            colsrc[k - 1 - r] = j;
+            if (ev) ev[k - 1 - r] = fabsf(l) <= kZeroEig ? 0.f : l;
+        }
+    }
+    for (int c = 0; c < zp && nge_s + c < k; ++c) {
+        colsrc[k - 1 - (nge_s + c)] = -(kStalkSrc + 2 * c);
+        if (ev) ev[k - 1 - (nge_s + c)] = kStalkEig;
+    }
+    for (int c = 0; c < z && npz + zp + c < k; ++c) {
+        colsrc[k - 1 - (npz + zp + c)] = -(c + 1);
+        if (ev) ev[k - 1 - (npz + zp + c)] = 0.f;
+    }
+    for (int c = 0; c < zp && nge_ms + zp + z + c < k; ++c) {
+        colsrc[k - 1 - (nge_ms + zp + z + c)] = -(kStalkSrc + 2 * c + 1);
+        if (ev) ev[k - 1 - (nge_ms + zp + z + c)] = -kStalkEig;
+    }
+    return na;
+}
 
 // =========================================================================
 // Direct solver: Householder tridiagonalisation of the dense deflated matrix (one wave per row, the
@@ -140,19 +312,19 @@ struct PosHead {                     // head of the caller's workspace (zeroed p
     int32_t ldv;                     // longest subgraph the Krylov class has room for (node_cap / batch_size, rounded up)
     int32_t use_cheb;                // deflated sizes above GCC_POSEMB_LDS_MAX try the sparse Chebyshev class first
     int32_t use_wave;                // deflated sizes <= 64 go to the one-wave teams
+    int32_t use_stalks;              // pendant two-paths of a hub are deflated too (GCC_POSEMB_STALKS, default 1)
     int64_t slot_floats;
 };
 
-// The deflation tables (16 KiB) are built in LDS and moved to the workspace once the matrix is filled (the eigenvector
-// arrays overlay them; the expansion at the end reads them back): it keeps the mid class at 132 KiB, so that a
-// workgroup of the training step (26 KiB) still fits on the same CU, and the small class at 44 KiB (3 per CU).
-template <int kNMax> __host__ __device__ constexpr bool tables_in_workspace() { return true; }
+// The deflation tables (24 KiB) are built in LDS where the eigenvector arrays go later; the 8 bytes per node that the
+// expansion at the end needs of them (defl_record) go to the workspace: it keeps the mid class at 132 KiB, so that a
+// workgroup of the training step (26 KiB) still fits on the same CU, and the small class at 50 KiB (3 per CU).
 template <int kNMax, int kT, bool kGlobalA>
 __host__ __device__ constexpr int direct_lds_bytes()
 {
     return kGlobalA ? (kNMax > kGMax ? kBLds : kGLds)
                     : (int)(sizeof(float) * (6 * kNMax + 32 * kYld + kT + kNMax * (kNMax + 1) + kNMax * kYld)
-                            + (tables_in_workspace<kNMax>() ? 0 : kNodeMax * 16) + kNMax * (33 * 8 + 32));
+                            + kNMax * (33 * 8 + 32));
 }
 
 struct TriLds {
@@ -1274,13 +1446,24 @@ __global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m
         int32_t *t = tc[wv];
         for (int i = lane; i < n; i += 64) t[i] = 0;
         wave_sync();
-        for (int i = lane; i < n; i += 64)
-            if (rp[i + 1] - rp[i] == 1) atomicAdd(&t[a.col_idx[rp[i]] - n0], 1);
+        for (int i = lane; i < n; i += 64) {           // twin leaves per parent (low half), stalks per hub (high half)
+            const int dg = rp[i + 1] - rp[i];
+            if (dg == 1) {
+                atomicAdd(&t[a.col_idx[rp[i]] - n0], 1);
+            } else if (dg == 2 && hd.use_stalks) {
+                const int x = a.col_idx[rp[i]] - n0, y = a.col_idx[rp[i] + 1] - n0;
+                const bool lx = rp[x + 1] - rp[x] == 1, ly = rp[y + 1] - rp[y] == 1;
+                if (lx != ly) atomicAdd(&t[lx ? y : x], 1 << 16);
+            }
+        }
         wave_sync();
         int zz = 0;
-        for (int i = lane; i < n; i += 64) zz += t[i] >= 2 ? t[i] - 1 : 0;
+        for (int i = lane; i < n; i += 64) {
+            const int tl = t[i] & 0xFFFF, ts = t[i] >> 16;
+            zz += (tl >= 2 ? tl - 1 : 0) + (ts >= 2 ? 2 * (ts - 1) : 0);
+        }
         for (int dd = 32; dd >= 1; dd >>= 1) zz += wave_shfl_xor(zz, dd);
-        const int nr = n - zz;                         // t >= 2 leaves of one parent count once
+        const int nr = n - zz;                         // t >= 2 leaves of one parent count once, s >= 2 stalks of one hub as one stalk
         cls = (hd.use_wave && nr <= 64 && n <= kWaveNodes) ? (nr <= 48 ? kClsW48 : kClsW64)
             : nr <= kJSmall ? kClsSmall : nr <= kJMax ? kClsMid : hd.use_cheb ? kClsCheb : nr <= kGMax ? kClsSlot : nr <= kBMax ? kClsBig : kClsKrylov;
     }
@@ -1300,7 +1483,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     DYN_SMEM(smem);
     __shared__ EigShared es;
     __shared__ int colsrc[64];                  // per output column: eigenvector j >= 0, or -(c + 1) for contrast c
-    __shared__ int sh_np, sh_z, sh_na, sh_item;
+    __shared__ int sh_np, sh_z, sh_zp, sh_na, sh_item;
     constexpr int kNW = kT / 64, kCPL = kNMax / 64;
     constexpr int lda = kGlobalA ? kNMax : kNMax + 1;   // LDS: odd stride; workspace: rows start on 256-byte boundaries
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1334,56 +1517,34 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
         A = lds_rest;
         lds_rest += kNMax * lda;
     }
-    // the deflation tables are built in LDS; the workspace class moves them to its slot once the matrix is filled
-    // (the eigenvector arrays overlay them)
-    d.tcnt = (int32_t *)lds_rest;
-    constexpr bool kTabW = tables_in_workspace<kNMax>();
-    if (!kTabW) lds_rest += kNodeMax * 4;          // 2 int32 + 4 uint16 tables = 16 KiB
+    // the deflation tables (24 KiB) are built in LDS (the eigenvector arrays overlay them); what the expansion at the end
+    // needs of them goes to the workgroup's table in the workspace once the matrix is filled
+    static_assert(direct_lds_bytes<kNMax, kT, kGlobalA>() - (int)sizeof(float) * (6 * kNMax + 32 * kYld + kT + (kGlobalA ? 0 : kNMax * (kNMax + 1)))
+                  >= kNodeMax * kDeflNodeBytes, "the deflation tables overlay the eigenvector / LU region");
+    defl_bind(d, lds_rest, kNodeMax);
     const int32_t *rp = a.row_ptr + n0;
-    d.cbase = d.tcnt + kNodeMax;
-    d.par = (uint16_t *)(d.cbase + kNodeMax);
-    d.rep = d.par + kNodeMax;
-    d.ridx = d.rep + kNodeMax;
-    d.ord = d.ridx + kNodeMax;
 
-    // ---- leaf groups
-    for (int i = tid; i < n; i += kT) {
-        const int dg = rp[i + 1] - rp[i];
-        d.par[i] = dg == 1 ? (uint16_t)(a.col_idx[rp[i]] - n0) : kNone;
-        d.tcnt[i] = 0;
-        d.rep[i] = kNone;
-        d.ord[i] = 0;
-    }
+    // ---- twin-leaf and stalk groups
+    for (int i = tid; i < n; i += kT) defl_init_node(d, i, rp, a.col_idx, n0);
     __syncthreads();
-    for (int i = tid; i < n; i += kT)
-        if (d.par[i] != kNone) atomicAdd(&d.tcnt[d.par[i]], 1);
+    for (int i = tid; i < n; i += kT) defl_count_node(d, i, rp, a.col_idx, n0, hd.use_stalks != 0);
     __syncthreads();
-    for (int p = tid; p < n; p += kT) {            // rows are sorted: a parent's leaves in index order
-        if (d.tcnt[p] >= 2) {
-            int o = 0;
-            for (int e = rp[p]; e < rp[p + 1]; ++e) {
-                const int j = a.col_idx[e] - n0;
-                if (d.par[j] == (uint16_t)p) {
-                    if (o == 0) d.rep[p] = (uint16_t)j;
-                    d.ord[j] = (uint16_t)o++;
-                }
-            }
-        }
-    }
+    for (int p = tid; p < n; p += kT) defl_order_node(d, p, rp, a.col_idx, n0);
     __syncthreads();
     if (tid == 0) {                                // n <= 1024: a serial prefix is a few microseconds
-        int r = 0, c = 0;
+        int r = 0, c = 0, cp = 0;
         for (int i = 0; i < n; ++i) {
-            d.cbase[i] = c;
+            d.cbase[i] = c | (cp << 16);
             if (d.tcnt[i] >= 2) c += d.tcnt[i] - 1;
-            const bool collapsed = d.par[i] != kNone && d.tcnt[d.par[i]] >= 2 && d.rep[d.par[i]] != (uint16_t)i;
-            d.ridx[i] = collapsed ? kNone : (uint16_t)r++;
+            if (d.pcnt[i] >= 2) cp += d.pcnt[i] - 1;
+            d.ridx[i] = defl_collapsed(d, i) ? kNone : (uint16_t)r++;
         }
         sh_np = r;
         sh_z = c;
+        sh_zp = cp;
     }
     __syncthreads();
-    const int nr = sh_np, z = sh_z;                // reduced size n', number of contrast null vectors
+    const int nr = sh_np, z = sh_z, zp = sh_zp;    // reduced size n', number of twin / stalk contrasts
     if (nr > kNMax || nr < kNMin) continue;        // cannot happen: the classify kernel computed the same size
     if (kGlobalA) A = kCls == kClsBig ? hd.bslots + (int64_t)blockIdx.x * hd.bslot_floats
                                       : hd.slots + (int64_t)blockIdx.x * hd.slot_floats;   // the workgroup's own slot
@@ -1406,7 +1567,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     }
     for (int i = tid; i < nr * lda; i += kT) A[i] = 0.f;
     __syncthreads();
-    // M' = norm * adj * norm on the kept nodes (data_util.py:273-277), super-leaf couplings scaled by sqrt(t)
+    // M' = norm * adj * norm on the kept nodes (data_util.py:273-277), group couplings scaled by sqrt(group size)
     for (int i = wv; i < n; i += kNW) {
         if (d.ridx[i] == kNone) continue;          // wave-uniform
         const int ri = d.ridx[i];
@@ -1415,26 +1576,14 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
             const int j = a.col_idx[e] - n0;
             if (d.ridx[j] == kNone) continue;
             const int dj = rp[j + 1] - rp[j];
-            float val = 1.0f / sqrtf((float)di * (float)dj);      // in_degrees().clip(1) ** -0.5 on both sides
-            if (d.par[j] == (uint16_t)i && d.tcnt[i] >= 2) val *= sqrtf((float)d.tcnt[i]);
-            if (d.par[i] == (uint16_t)j && d.tcnt[j] >= 2) val *= sqrtf((float)d.tcnt[j]);
-            A[ri * lda + d.ridx[j]] = val;
+            A[ri * lda + d.ridx[j]] = defl_coupling(d, i, j) / sqrtf((float)di * (float)dj);   // in_degrees().clip(1) ** -0.5 on both sides
         }
     }
+    // what the expansion at the end needs of the tables: 8 bytes per node, in the workgroup's table in the workspace
+    uint16_t *xrec = kGlobalA ? (uint16_t *)(A + (int64_t)kNMax * lda)
+                              : (uint16_t *)(hd.tabs + ((int64_t)(kCls == kClsMid ? 0 : hd.tabs_small_off) + blockIdx.x) * kNodeMax * 4);
+    for (int v = tid; v < n; v += kT) defl_record(d, v, rp, a.col_idx, n0, xrec + 4 * v);
     __syncthreads();
-    if (kTabW) {
-        uint32_t *dst = kGlobalA ? (uint32_t *)(A + (int64_t)kNMax * lda)
-                                 : (uint32_t *)(hd.tabs + ((int64_t)(kCls == kClsMid ? 0 : hd.tabs_small_off) + blockIdx.x) * kNodeMax * 4);
-        const uint32_t *src = (const uint32_t *)d.tcnt;
-        for (int i = tid; i < kNodeMax * 4; i += kT) dst[i] = src[i];
-        d.tcnt = (int32_t *)dst;
-        d.cbase = d.tcnt + kNodeMax;
-        d.par = (uint16_t *)(d.cbase + kNodeMax);
-        d.rep = d.par + kNodeMax;
-        d.ridx = d.rep + kNodeMax;
-        d.ord = d.ridx + kNodeMax;
-        __syncthreads();
-    }
 
     PHASE_TICK(0);                                 // deflation + matrix
     if (kGlobalA) {
@@ -1448,28 +1597,10 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     const int kq = min(k, nr);
     eig_top_values<kT, kMaxVec>(w, nr, kq, es);
     PHASE_TICK(2);                                 // bisection
-    // ---- ranks: positive, null space = zeros of M' then the z contrasts, negative; eigsh(which="LA") returns the k
-    //      largest in ascending order (data_util.py:251)
+    // ---- ranks of the merged spectrum (rank_columns)
     if (tid < 64) colsrc[tid] = 0;
     __syncthreads();
-    if (tid == 0) {
-        int na = 0, npz = 0;
-        for (int j = 0; j < kq; ++j) {
-            const float l = es.lamv[j];
-            const int r = l < -kZeroEig ? j + z : j;
-            if (l >= -kZeroEig) npz = j + 1;
-            if (r < k) {
-                na = j + 1;
-                colsrc[k - 1 - r] = j;
-                if (a.evals) a.evals[(int64_t)b * a.hidden + (k - 1 - r)] = fabsf(l) <= kZeroEig ? 0.f : l;
-            }
-        }
-        for (int c = 0; c < z && npz + c < k; ++c) {              // contrast c has rank npz + c
-            colsrc[k - 1 - (npz + c)] = -(c + 1);
-            if (a.evals) a.evals[(int64_t)b * a.hidden + (k - 1 - (npz + c))] = 0.f;
-        }
-        sh_na = na;
-    }
+    if (tid == 0) sh_na = rank_columns(es.lamv, kq, k, z, zp, colsrc, a.evals ? a.evals + (int64_t)b * a.hidden : nullptr);
     if (a.evals) for (int i = k + tid; i < a.hidden; i += kT) a.evals[(int64_t)b * a.hidden + i] = 0.f;
     __syncthreads();
     const bool failed = eig_top_vectors<kCPL, kT>(A, lda, nr, sh_na, w, es, (uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u),
@@ -1483,24 +1614,8 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     }
     // ---- expand to the n original nodes; x = normalize(u, "l2") row-wise, zero padded (data_util.py:260-262)
     for (int v = wv; v < n; v += kNW) {
-        const int pv = d.par[v];
-        const bool grouped = pv != kNone && d.tcnt[pv] >= 2;
-        const int rsrc = grouped ? d.ridx[d.rep[pv]] : d.ridx[v];
-        const float scale = grouped ? 1.0f / sqrtf((float)d.tcnt[pv]) : 1.0f;
-        float val = 0.f;
-        if (lane < k) {
-            const int src = colsrc[lane];
-            if (src >= 0) {
-                val = w.Y[rsrc * kYld + src] * scale;
-            } else if (grouped) {
-                const int jm1 = -src - 1 - d.cbase[pv];          // contrast j = jm1 + 1 of parent pv
-                if (jm1 >= 0 && jm1 < d.tcnt[pv] - 1) {
-                    const int j = jm1 + 1, o = d.ord[v];
-                    const float nrm = 1.0f / sqrtf((float)(j * (j + 1)));
-                    val = o < j ? nrm : (o == j ? -(float)j * nrm : 0.f);
-                }
-            }
-        }
+        const int rsrc = xrec[4 * v], o = xrec[4 * v + 1], g = xrec[4 * v + 2], cb = xrec[4 * v + 3];
+        const float val = lane < k ? defl_expand(rsrc, o, g, cb, colsrc[lane], w.Y, kYld) : 0.f;
         const float s2 = wave_sum(val * val);
         const float inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
         if (lane < a.hidden) {
@@ -1533,7 +1648,7 @@ __host__ __device__ constexpr int wave_team_bytes()
 template <int kCls, int kNMax>
 __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? GCC_POSEMB_W48_OCC : 1) void posemb_wave_kernel(PosMulti m, PosHead hd)
 {
-    static_assert(kNMax <= 64 && kNMax * kYld * 4 >= kWaveNodes * 16, "the deflation tables overlay Y");
+    static_assert(kNMax <= 64 && kNMax * kYld * 4 >= kWaveNodes * kDeflNodeBytes, "the deflation tables overlay Y");
     DYN_SMEM(smem);
     __shared__ EigShared es_all[kWaveTeams];
     __shared__ int colsrc_all[kWaveTeams][64];
@@ -1548,7 +1663,7 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? GCC_POSEMB_W48_OCC :
     w.of2 = w.of + kNMax;
     w.tau = w.of2 + kNMax;
     w.nrm = w.tau + kNMax;
-    uint16_t *xinfo = (uint16_t *)(w.nrm + 64);      // [kWaveNodes][4]: Y row, leaf order, twins of the parent, its contrast base
+    uint16_t *xinfo = (uint16_t *)(w.nrm + 64);      // [kWaveNodes][4]: defl_record
     EigShared &es = es_all[team];
     int *colsrc = colsrc_all[team];
     for (;;) {                                       // items of this class, one per wave
@@ -1566,61 +1681,37 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? GCC_POSEMB_W48_OCC :
     if (m.ticks && lane == 0) atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 15], 1ull);   // items
 #define WAVE_TICK(ph) do { if (m.ticks && lane == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
     const int32_t *rp = a.row_ptr + n0;
-    // ---- leaf groups (tables in the Y region: dead again before the first eigenvector is written)
+    // ---- twin-leaf and stalk groups (tables in the Y region: dead again before the first eigenvector is written)
     Defl d;
-    d.tcnt = (int32_t *)w.Y;
-    d.cbase = d.tcnt + kWaveNodes;
-    d.par = (uint16_t *)(d.cbase + kWaveNodes);
-    d.rep = d.par + kWaveNodes;
-    d.ridx = d.rep + kWaveNodes;
-    d.ord = d.ridx + kWaveNodes;
-    for (int i = lane; i < n; i += 64) {
-        const int dg = rp[i + 1] - rp[i];
-        d.par[i] = dg == 1 ? (uint16_t)(a.col_idx[rp[i]] - n0) : kNone;
-        d.tcnt[i] = 0;
-        d.rep[i] = kNone;
-        d.ord[i] = 0;
-    }
+    defl_bind(d, w.Y, kWaveNodes);
+    for (int i = lane; i < n; i += 64) defl_init_node(d, i, rp, a.col_idx, n0);
     wave_sync();
-    for (int i = lane; i < n; i += 64)
-        if (d.par[i] != kNone) atomicAdd(&d.tcnt[d.par[i]], 1);
+    for (int i = lane; i < n; i += 64) defl_count_node(d, i, rp, a.col_idx, n0, hd.use_stalks != 0);
     wave_sync();
-    for (int p = lane; p < n; p += 64) {             // rows are sorted: a parent's leaves in index order
-        if (d.tcnt[p] >= 2) {
-            int o = 0;
-            for (int e = rp[p]; e < rp[p + 1]; ++e) {
-                const int j = a.col_idx[e] - n0;
-                if (d.par[j] == (uint16_t)p) {
-                    if (o == 0) d.rep[p] = (uint16_t)j;
-                    d.ord[j] = (uint16_t)o++;
-                }
-            }
-        }
-    }
+    for (int p = lane; p < n; p += 64) defl_order_node(d, p, rp, a.col_idx, n0);
     wave_sync();
-    int nr = 0, z = 0;                               // reduced size n', number of contrast null vectors
+    int nr = 0, z = 0, zp = 0;                       // reduced size n', number of twin / stalk contrasts
     for (int i0 = 0; i0 < n; i0 += 64) {             // prefixes over the nodes, 64 at a time
         const int i = i0 + lane;
         const bool valid = i < n;
-        const int tc = valid ? d.tcnt[i] : 0;
-        const int extra = tc >= 2 ? tc - 1 : 0;
-        const int pi = valid ? (int)d.par[i] : (int)kNone;
-        const bool collapsed = valid && pi != (int)kNone && d.tcnt[pi] >= 2 && d.rep[pi] != (uint16_t)i;
-        const bool kept = valid && !collapsed;
-        const int incl = wave_scan_incl(extra);
+        const int tc = valid ? d.tcnt[i] : 0, pc = valid ? d.pcnt[i] : 0;
+        const int extra = tc >= 2 ? tc - 1 : 0, pextra = pc >= 2 ? pc - 1 : 0;
+        const bool kept = valid && !defl_collapsed(d, i);
+        const int incl = wave_scan_incl(extra), pincl = wave_scan_incl(pextra);
         const unsigned long long km = wave_ballot(kept);
         if (valid) {
-            d.cbase[i] = z + incl - extra;
+            d.cbase[i] = (z + incl - extra) | ((zp + pincl - pextra) << 16);
             d.ridx[i] = kept ? (uint16_t)(nr + __popcll(km & lanemask_lt())) : kNone;
         }
         nr += __popcll(km);
         z += wave_last(incl);
+        zp += wave_last(pincl);
     }
     wave_sync();
     if (nr > kNMax || nr < 1) continue;              // cannot happen: the classify kernel computed the same size
     for (int i = lane; i < nr * lda; i += 64) A[i] = 0.f;
     wave_sync();
-    // M' = norm * adj * norm on the kept nodes (data_util.py:273-277), super-leaf couplings scaled by sqrt(t); lane = row
+    // M' = norm * adj * norm on the kept nodes (data_util.py:273-277), group couplings scaled by sqrt(group size); lane = row
     for (int i = lane; i < n; i += 64) {
         if (d.ridx[i] == kNone) continue;
         const int ri = d.ridx[i];
@@ -1629,21 +1720,11 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? GCC_POSEMB_W48_OCC :
             const int j = a.col_idx[e] - n0;
             if (d.ridx[j] == kNone) continue;
             const int dj = rp[j + 1] - rp[j];
-            float val = 1.0f / sqrtf((float)di * (float)dj);      // in_degrees().clip(1) ** -0.5 on both sides
-            if (d.par[j] == (uint16_t)i && d.tcnt[i] >= 2) val *= sqrtf((float)d.tcnt[i]);
-            if (d.par[i] == (uint16_t)j && d.tcnt[j] >= 2) val *= sqrtf((float)d.tcnt[j]);
-            A[ri * lda + d.ridx[j]] = val;
+            A[ri * lda + d.ridx[j]] = defl_coupling(d, i, j) / sqrtf((float)di * (float)dj);   // in_degrees().clip(1) ** -0.5 on both sides
         }
     }
     // what the expansion at the end needs of the tables, 8 bytes per node
-    for (int v = lane; v < n; v += 64) {
-        const int pv = d.par[v];
-        const bool grouped = pv != (int)kNone && d.tcnt[pv] >= 2;
-        xinfo[4 * v + 0] = grouped ? d.ridx[d.rep[pv]] : d.ridx[v];
-        xinfo[4 * v + 1] = d.ord[v];
-        xinfo[4 * v + 2] = (uint16_t)(grouped ? d.tcnt[pv] : 0);
-        xinfo[4 * v + 3] = (uint16_t)(grouped ? d.cbase[pv] : 0);
-    }
+    for (int v = lane; v < n; v += 64) defl_record(d, v, rp, a.col_idx, n0, xinfo + 4 * v);
     wave_sync();
     WAVE_TICK(0);                                    // deflation + matrix
     wave_tridiagonalize<kNMax>(A, lda, nr, w);
@@ -1651,28 +1732,11 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? GCC_POSEMB_W48_OCC :
     const int kq = min(k, nr);
     wave_eig_top_values<kMaxVec>(w, nr, kq, es);
     WAVE_TICK(2);                                    // bisection
-    // ---- ranks: positive, null space = zeros of M' then the z contrasts, negative; eigsh(which="LA") returns the k
-    //      largest in ascending order (data_util.py:251)
+    // ---- ranks of the merged spectrum (rank_columns)
     colsrc[lane] = 0;
     wave_sync();
     int na = 0;
-    if (lane == 0) {
-        int npz = 0;
-        for (int j = 0; j < kq; ++j) {
-            const float l = es.lamv[j];
-            const int r = l < -kZeroEig ? j + z : j;
-            if (l >= -kZeroEig) npz = j + 1;
-            if (r < k) {
-                na = j + 1;
-                colsrc[k - 1 - r] = j;
-                if (a.evals) a.evals[(int64_t)b * a.hidden + (k - 1 - r)] = fabsf(l) <= kZeroEig ? 0.f : l;
-            }
-        }
-        for (int c = 0; c < z && npz + c < k; ++c) {              // contrast c has rank npz + c
-            colsrc[k - 1 - (npz + c)] = -(c + 1);
-            if (a.evals) a.evals[(int64_t)b * a.hidden + (k - 1 - (npz + c))] = 0.f;
-        }
-    }
+    if (lane == 0) na = rank_columns(es.lamv, kq, k, z, zp, colsrc, a.evals ? a.evals + (int64_t)b * a.hidden : nullptr);
     na = wave_bcast_first(na);
     if (a.evals) for (int i = k + lane; i < a.hidden; i += 64) a.evals[(int64_t)b * a.hidden + i] = 0.f;
     wave_sync();
@@ -1693,20 +1757,8 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? GCC_POSEMB_W48_OCC :
         const int v = v0 + hv;
         const bool valid = v < n;
         const int vv = valid ? v : 0;
-        const int rsrc = xinfo[4 * vv + 0], o = xinfo[4 * vv + 1], tp = xinfo[4 * vv + 2], cb = xinfo[4 * vv + 3];
-        float val = 0.f;
-        if (valid && col < k) {
-            if (src >= 0) {
-                val = w.Y[rsrc * kYld + src] * (tp ? 1.0f / sqrtf((float)tp) : 1.0f);
-            } else if (tp) {
-                const int jm1 = -src - 1 - cb;                   // contrast j = jm1 + 1 of the parent
-                if (jm1 >= 0 && jm1 < tp - 1) {
-                    const int j = jm1 + 1;
-                    const float nrm = 1.0f / sqrtf((float)(j * (j + 1)));
-                    val = o < j ? nrm : (o == j ? -(float)j * nrm : 0.f);
-                }
-            }
-        }
+        const int rsrc = xinfo[4 * vv + 0], o = xinfo[4 * vv + 1], g = xinfo[4 * vv + 2], cb = xinfo[4 * vv + 3];
+        const float val = valid && col < k ? defl_expand(rsrc, o, g, cb, src, w.Y, kYld) : 0.f;
         const float s2 = half32_sum(val * val);
         const float inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
         if (valid && col < a.hidden) {
@@ -2142,7 +2194,8 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     __shared__ int longrow[kChMaxLong], longfirst[kChMaxLong + 1];
     __shared__ int chunk_beg[kChMaxChunks + 1];
     __shared__ int wsum[kChThreads / 64 + 1];
-    __shared__ int sh_item, sh_np, sh_nlong, sh_nchunk, sh_fail;
+    __shared__ int sh_item, sh_np, sh_z, sh_zp, sh_nlong, sh_nchunk, sh_fail;
+    __shared__ int colsrc[64];
     constexpr int kCls = kClsCheb;
     const PosMulti &m = ca.m;
     const PosHead &hd = ca.hd;
@@ -2170,58 +2223,46 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     // three block buffers in the workspace (L2-resident): X, W = M' X or filter scratch, rotation target
     float *XA = ca.xws + (int64_t)blockIdx.x * 3 * kNodeMax * kChP, *XB = XA + (int64_t)kNodeMax * kChP, *XC = XB + (int64_t)kNodeMax * kChP;
 
-    // ---- leaf groups (as posemb_direct_kernel)
+    // ---- twin-leaf and stalk groups (as posemb_direct_kernel)
     Defl d;
-    d.tcnt = (int32_t *)region;
-    d.cbase = d.tcnt + kNodeMax;
-    d.par = (uint16_t *)(d.cbase + kNodeMax);
-    d.rep = d.par + kNodeMax;
-    d.ridx = d.rep + kNodeMax;
-    d.ord = d.ridx + kNodeMax;
-    for (int i = tid; i < n; i += kChThreads) {
-        const int dg = rp[i + 1] - rp[i];
-        d.par[i] = dg == 1 ? (uint16_t)(a.col_idx[rp[i]] - n0) : kNone;
-        d.tcnt[i] = 0;
-        d.rep[i] = kNone;
-        d.ord[i] = 0;
-    }
+    defl_bind(d, region, kNodeMax);
+    for (int i = tid; i < n; i += kChThreads) defl_init_node(d, i, rp, a.col_idx, n0);
     if (tid == 0) { sh_fail = 0; sh_nlong = 0; sh_nchunk = 0; }
     __syncthreads();
-    for (int i = tid; i < n; i += kChThreads)
-        if (d.par[i] != kNone) atomicAdd(&d.tcnt[d.par[i]], 1);
+    for (int i = tid; i < n; i += kChThreads) defl_count_node(d, i, rp, a.col_idx, n0, hd.use_stalks != 0);
     __syncthreads();
-    for (int p = tid; p < n; p += kChThreads) {
-        if (d.tcnt[p] >= 2) {
-            int o = 0;
-            for (int e = rp[p]; e < rp[p + 1]; ++e) {
-                const int j = a.col_idx[e] - n0;
-                if (d.par[j] == (uint16_t)p) {
-                    if (o == 0) d.rep[p] = (uint16_t)j;
-                    d.ord[j] = (uint16_t)o++;
-                }
-            }
-        }
-    }
+    for (int p = tid; p < n; p += kChThreads) defl_order_node(d, p, rp, a.col_idx, n0);
     __syncthreads();
     if (tid == 0) {
-        int r = 0, c = 0;
+        int r = 0, c = 0, cp = 0;
         for (int i = 0; i < n; ++i) {
-            d.cbase[i] = c;
+            d.cbase[i] = c | (cp << 16);
             if (d.tcnt[i] >= 2) c += d.tcnt[i] - 1;
-            const bool collapsed = d.par[i] != kNone && d.tcnt[d.par[i]] >= 2 && d.rep[d.par[i]] != (uint16_t)i;
-            d.ridx[i] = collapsed ? kNone : (uint16_t)r++;
+            if (d.pcnt[i] >= 2) cp += d.pcnt[i] - 1;
+            d.ridx[i] = defl_collapsed(d, i) ? kNone : (uint16_t)r++;
         }
         sh_np = r;
+        sh_z = c;
+        sh_zp = cp;
     }
     __syncthreads();
-    const int nr = sh_np;
+    const int nr = sh_np, z = sh_z, zp = sh_zp;
     // ---- sparse M' = diag(scale) A' diag(scale): rows of the kept nodes, columns ascending; a super-leaf standing for t
-    //      twins carries sqrt(t) (its coupling to the parent is sqrt(t / d_p), data_util.py:273-277 on the quotient)
+    //      twins carries sqrt(t) (its coupling to the parent is sqrt(t / d_p), data_util.py:273-277 on the quotient); the
+    //      stalk standing for s stalks carries sqrt(s / 2) on its middle node and 1 / sqrt(s) on its leaf (couplings
+    //      sqrt(s / (2 d_h)) to the hub and 1 / sqrt(2) inside)
     for (int i = tid; i < n; i += kChThreads) {
         if (d.ridx[i] == kNone) continue;
         const int di = rp[i + 1] - rp[i];
-        const bool superleaf = d.par[i] != kNone && d.tcnt[d.par[i]] >= 2;
-        scale[d.ridx[i]] = superleaf ? sqrtf((float)d.tcnt[d.par[i]]) : 1.0f / sqrtf((float)(di < 1 ? 1 : di));
+        const int pi = d.par[i];
+        float sc = 1.0f / sqrtf((float)(di < 1 ? 1 : di));
+        if (pi != (int)kNone && d.tcnt[pi] >= 2) {
+            sc = sqrtf((float)d.tcnt[pi]);
+        } else {
+            const int h = d.phub[pi != (int)kNone ? pi : i];
+            if (h != (int)kNone && d.pcnt[h] >= 2) sc = pi != (int)kNone ? 1.0f / sqrtf((float)d.pcnt[h]) : sqrtf(0.5f * (float)d.pcnt[h]);
+        }
+        scale[d.ridx[i]] = sc;
     }
     if (tid <= nr) crow[tid] = 0;                            // nr <= kNodeMax = kChThreads
     __syncthreads();
@@ -2289,19 +2330,10 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         }
     }
     __syncthreads();
-    // deflation tables -> workspace (the dense matrices overlay them); the expansion at the end reads them there
-    {
-        uint32_t *dst = ca.tabs + (int64_t)blockIdx.x * kNodeMax * 4;
-        const uint32_t *src = (const uint32_t *)d.tcnt;
-        for (int i = tid; i < kNodeMax * 4; i += kChThreads) dst[i] = src[i];
-        d.tcnt = (int32_t *)dst;
-        d.cbase = d.tcnt + kNodeMax;
-        d.par = (uint16_t *)(d.cbase + kNodeMax);
-        d.rep = d.par + kNodeMax;
-        d.ridx = d.rep + kNodeMax;
-        d.ord = d.ridx + kNodeMax;
-        __syncthreads();
-    }
+    // what the expansion at the end needs of the tables -> workspace, 8 bytes per node (the dense matrices overlay the tables)
+    uint16_t *xrec = (uint16_t *)(ca.tabs + (int64_t)blockIdx.x * kNodeMax * 4);
+    for (int v = tid; v < n; v += kChThreads) defl_record(d, v, rp, a.col_idx, n0, xrec + 4 * v);
+    __syncthreads();
     PHASE_TICK(0);                                           // deflation + sparse matrix
     const int nchunk = sh_nchunk;
     bool failed = sh_fail != 0;
@@ -2776,21 +2808,29 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         // so beyond ~1e3 the block loses its numerical rank.  T_2m = 2 T_m^2 - 1: consecutive rounds with a
         // re-orthonormalisation in between multiply up like one long filter.
         if (rr) {
+            // quotient pairs that can reach the merged top k: everything above the stalk eigenvalue (generous window: the
+            // Ritz values still move) and, below it, what the zp stalk contrasts leave room for
+            int kw = kq;
+            if (zp > 0) {
+                int nge = 0;
+                for (int j = 0; j < kq; ++j) if (theta[j] >= kStalkEig - 1e-3f) nge = j + 1;
+                kw = max(max(nge, min(kq, k - zp)), 1);
+            }
             float worst = 0.1f;                                  // (values only: nothing measured yet)
             if (fullrr) {
                 worst = 0.f;
-                for (int i = 0; i < kq; ++i) worst = fmaxf(worst, resid[i]);
+                for (int i = 0; i < kw; ++i) worst = fmaxf(worst, resid[i]);
             }
 #ifdef GCC_AMD_HIPEMU
             if (getenv("GCC_POSEMB_DEBUG") && tid == 0)
-                fprintf(stderr, "cheb b=%d n=%d nr=%d round=%d deg=%d cut=%.4f worst=%.2e theta[kq-1]=%.5f theta[63]=%.5f\n", b, n, nr, round,
-                        deg, cut, worst, theta[kq - 1], theta[kChP - 1]);
+                fprintf(stderr, "cheb b=%d n=%d nr=%d zp=%d round=%d deg=%d cut=%.4f worst=%.2e kw=%d theta[kw-1]=%.5f theta[63]=%.5f\n", b, n, nr, zp, round,
+                        deg, cut, worst, kw, theta[kw - 1], theta[kChP - 1]);
 #endif
             if (fullrr && worst <= kChTol) { converged = true; ++round; break; }
             if (nrr >= kChMaxRitz) break;
             cut = fminf(fmaxf(theta[kChP - 1] - 0.02f, -0.9f), 0.9f);
             const float e = 0.5f * (cut + 1.0f), cen = 0.5f * (cut - 1.0f);
-            const float xk = fmaxf((theta[kq - 1] - cen) / e, 1.0001f);
+            const float xk = fmaxf((theta[kw - 1] - cen) / e, 1.0001f);
             const float rate = logf(xk + sqrtf(xk * xk - 1.0f));        // the wanted end grows by exp(rate) per degree
             int need = (int)(2.3f * logf(fmaxf(worst, 1e-3f) / (0.5f * kChTol)) / rate) + 4;   // a Ritz step costs ~30 degrees: overshoot
             remaining = need < 4 ? 4 : (need > 60 ? 60 : need);
@@ -2804,8 +2844,22 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             if (deg < 2) deg = 2;
         }
     }
-    // the top k must be strictly positive eigenvalues: the null space needs the direct solver's contrast bookkeeping
-    if (converged && !(theta[kq - 1] > 10.f * kZeroEig)) converged = false;
+    // ranks of the merged spectrum.  The top k must be strictly positive: the null space needs the direct solver (zeros of
+    // M' are not resolved by the filter)
+    if (converged) {
+        __syncthreads();
+        if (tid == 0) {
+            const int na = rank_columns(theta, kq, k, z, zp, colsrc, nullptr);
+            bool ok = na == 0 || theta[na - 1] > 10.f * kZeroEig;
+            for (int t = 0; t < k; ++t) {
+                const int src = colsrc[t];
+                if (src < 0 && (src > -kStalkSrc || ((-src - kStalkSrc) & 1))) ok = false;    // a twin contrast or -1/sqrt(2)
+            }
+            sh_fail = ok ? 0 : 1;
+        }
+        __syncthreads();
+        if (sh_fail) converged = false;
+    }
     if (!converged) {
         // ---- hand the item to the dense classes (they run after this kernel in the stream)
         if (tid == 0) {
@@ -2830,15 +2884,11 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     //      x = normalize(u, "l2") row-wise, zero padded (data_util.py:260-262)
     if (a.evals) {
         for (int i = tid; i < a.hidden; i += kChThreads)
-            a.evals[(int64_t)b * a.hidden + i] = i < k ? theta[k - 1 - i] : 0.f;
+            a.evals[(int64_t)b * a.hidden + i] = i < k ? (colsrc[i] >= 0 ? theta[colsrc[i]] : kStalkEig) : 0.f;
     }
     for (int v = wv; v < n; v += kNW) {
-        const int pv = d.par[v];
-        const bool grouped = pv != kNone && d.tcnt[pv] >= 2;
-        const int rsrc = grouped ? d.ridx[d.rep[pv]] : d.ridx[v];
-        const float sc = grouped ? 1.0f / sqrtf((float)d.tcnt[pv]) : 1.0f;
-        float val = 0.f;
-        if (lane < k) val = XA[(int64_t)rsrc * kChP + (k - 1 - lane)] * sc;
+        const int rsrc = xrec[4 * v], o = xrec[4 * v + 1], g = xrec[4 * v + 2], cb = xrec[4 * v + 3];
+        const float val = lane < k ? defl_expand(rsrc, o, g, cb, colsrc[lane], XA, kChP) : 0.f;
         const float s2 = wave_sum(val * val);
         const float inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
         if (lane < a.hidden) {
@@ -2978,6 +3028,8 @@ int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, 
         hd.use_cheb = e ? atoi(e) != 0 : 1;
         const char *ew = getenv("GCC_POSEMB_WAVE");   // 0: the 256-thread small class takes every n' <= 64 (A/B runs)
         hd.use_wave = ew ? atoi(ew) != 0 : 1;
+        const char *es = getenv("GCC_POSEMB_STALKS");  // 0: twin leaves only (A/B runs)
+        hd.use_stalks = es ? atoi(es) != 0 : 1;
     }
     constexpr int lds_small = direct_lds_bytes<kJSmall, kSmallT, false>();
     constexpr int lds_big = direct_lds_bytes<kJMax, 1024, false>();

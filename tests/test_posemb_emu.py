@@ -67,8 +67,9 @@ DIRECT_MAX = 704          # GCC_POSEMB_BIG_MAX: the direct solver's last size cl
 SLOT_MAX = 384            # GCC_POSEMB_DIRECT_MAX: 128 KiB-of-LDS workspace class
 
 
-def reduced_sizes(view):
-    """Deflated size n' of every subgraph: t >= 2 leaves of one parent count once."""
+def reduced_sizes(view, stalks=True):
+    """Deflated size n' of every subgraph: t >= 2 leaves of one parent count once, and (``stalks``) s >= 2 pendant
+    two-paths hub - a - leaf of one hub count as one."""
     no = view["node_off"].numpy()
     rp, ci = view["row_ptr"].numpy(), view["col_idx"].numpy()
     out = []
@@ -77,7 +78,16 @@ def reduced_sizes(view):
         deg = np.diff(rp[lo:hi + 1])
         leaves = np.where(deg == 1)[0]
         cnt = np.bincount(ci[rp[lo + leaves]] - lo, minlength=hi - lo) if len(leaves) else np.zeros(hi - lo, int)
-        out.append(int(hi - lo) - int(np.maximum(cnt - 1, 0).sum()))
+        size = int(hi - lo) - int(np.maximum(cnt - 1, 0).sum())
+        if stalks:
+            hubs = []
+            for a in np.where(deg == 2)[0]:
+                x, y = ci[rp[lo + a]] - lo, ci[rp[lo + a] + 1] - lo
+                if (deg[x] == 1) != (deg[y] == 1):
+                    hubs.append(y if deg[x] == 1 else x)
+            if hubs:
+                size -= 2 * int(np.maximum(np.bincount(hubs) - 1, 0).sum())
+        out.append(size)
     return np.array(out)
 
 
@@ -218,16 +228,29 @@ def test_krylov_fallback_above_the_direct_limit(cheb, monkeypatch):
     _check_krylov(view, x, evals, raw)
 
 
-@pytest.mark.parametrize("cheb", ["0", "1"])
-def test_hub_ego_net_with_repeated_eigenvalues_goes_through_the_big_direct_class(cheb, monkeypatch):
-    """The shape of a hub seed's ego-net at rw_hops 256 on the 1M-node graph (n ~ 850, deflated ~ 400..610): a hub
-    with hundreds of pendant two-paths (hub - a_i - leaf_i), which puts 1/sqrt(2) into the spectrum hundreds of times.
-    Exact multiplicities are out of reach of a single-vector Krylov iteration (ARPACK returns other, smaller
-    eigenvalues for the copies it cannot see).  cheb=1: the block Chebyshev class (whatever a block holds of a repeated
-    eigenvalue's eigenspace are eigenvectors); cheb=0: 384 < n' <= 704 by the dense direct solver.  STRICT invariants."""
+def _view_of(n, edges):
     import scipy.sparse as sp
 
+    e = np.array(edges)
+    a = sp.csr_matrix((np.ones(2 * len(e)), (np.r_[e[:, 0], e[:, 1]], np.r_[e[:, 1], e[:, 0]])), shape=(n, n))
+    a.sum_duplicates()
+    a.data[:] = 1
+    a.sort_indices()
+    return dict(node_off=torch.tensor([0, n]), row_ptr=torch.from_numpy(a.indptr.astype(np.int64)),
+                col_idx=torch.from_numpy(a.indices.astype(np.int64)))
+
+
+@pytest.mark.parametrize("cheb,stalks", [("0", "0"), ("1", "0"), ("1", "1")])
+def test_hub_ego_net_with_repeated_eigenvalues(cheb, stalks, monkeypatch):
+    """The shape of a hub seed's ego-net at rw_hops 256 on the 1M-node graph (n ~ 850): a hub with hundreds of pendant
+    two-paths (hub - a_i - leaf_i), which puts 1/sqrt(2) into the spectrum hundreds of times.  Exact multiplicities are
+    out of reach of a single-vector Krylov iteration (ARPACK returns other, smaller eigenvalues for the copies it cannot
+    see).  stalks=1 (the default): the stalks are deflated exactly, 63 quotient nodes remain and the copies are contrast
+    vectors.  stalks=0 (twin leaves only, deflated ~ 480): cheb=1 the block Chebyshev class (whatever a block holds of a
+    repeated eigenvalue's eigenspace are eigenvectors); cheb=0: 384 < n' <= 704 by the dense direct solver.  STRICT
+    invariants in every case."""
     monkeypatch.setenv("GCC_POSEMB_CHEB", cheb)
+    monkeypatch.setenv("GCC_POSEMB_STALKS", stalks)
     rng = np.random.RandomState(3)
     t = 210
     edges = [(0, 1 + i) for i in range(t)] + [(1 + i, 1 + t + i) for i in range(t)]
@@ -236,17 +259,67 @@ def test_hub_ego_net_with_repeated_eigenvalues_goes_through_the_big_direct_class
     edges += [(0, core0 + i) for i in range(core)]
     edges += [(core0 + i, core0 + j) for i in range(core) for j in range(i + 1, core) if rng.rand() < 0.1]
     n = core0 + core
-    e = np.array(edges)
-    a = sp.csr_matrix((np.ones(2 * len(e)), (np.r_[e[:, 0], e[:, 1]], np.r_[e[:, 1], e[:, 0]])), shape=(n, n))
-    a.sort_indices()
-    view = dict(node_off=torch.tensor([0, n]), row_ptr=torch.from_numpy(a.indptr.astype(np.int64)),
-                col_idx=torch.from_numpy(a.indices.astype(np.int64)))
-    red = reduced_sizes(view)
-    assert SLOT_MAX < red[0] <= DIRECT_MAX, red
+    view = _view_of(n, edges)
+    red = reduced_sizes(view, stalks=stalks == "1")
+    if stalks == "1":
+        assert red[0] == 63
+    else:
+        assert SLOT_MAX < red[0] <= DIRECT_MAX, red
     x, evals, raw = _run(view)
     assert _run.arnoldi_steps == 0 and _run.status[3] == 0
-    assert (_run.status[1] >= 2) == (cheb == "1")                       # filter rounds of the block class
+    assert (_run.status[1] >= 2) == (cheb == "1" and stalks == "0")    # filter rounds of the block class
     assert np.sum(np.abs(evals[0] - 2 ** -0.5) < 1e-4) >= 25          # the repeated eigenvalue fills the top 32
+    _check(view, x, evals, raw)
+
+
+def _stalky(rng, core, p, hubs, n_twins=()):
+    """A random connected core plus, per (hub, s) in ``hubs``, s pendant two-paths and, per (parent, t) in ``n_twins``,
+    t leaves."""
+    edges = [(i, j) for i in range(core) for j in range(i + 1, core) if rng.rand() < p]
+    edges += [(i, i + 1) for i in range(core - 1)]
+    nxt = core
+    for hub, s_ in hubs:
+        for _ in range(s_):
+            edges += [(hub, nxt), (nxt, nxt + 1)]
+            nxt += 2
+    for par, t in n_twins:
+        edges += [(par, nxt + i) for i in range(t)]
+        nxt += t
+    return nxt, edges
+
+
+@pytest.mark.parametrize("wave", ["0", "1"])
+def test_stalk_deflation_in_every_solver_class(wave, monkeypatch):
+    """Pendant two-paths are deflated exactly in the one-wave teams, the block classes and the sparse block class: stalk
+    groups on several hubs (sizes 2..40), twin leaves on the same hubs, a hub that is a path end, top-k cuts inside the
+    1/sqrt(2) cluster, and tiny graphs whose k = n - 2 reaches the null space and the -1/sqrt(2) copies."""
+    monkeypatch.setenv("GCC_POSEMB_WAVE", wave)
+    rng = np.random.RandomState(11)
+    blocks = []
+    blocks.append((7, [(0, 1), (1, 2), (0, 3), (3, 4), (0, 5), (5, 6)]))                   # spider: 3 stalks, k = 5
+    blocks.append(_stalky(rng, 1, 0.0, [(0, 3)], [(0, 2)]))                                # 3 stalks + 2 twin leaves on one node
+    blocks.append(_stalky(rng, 2, 1.0, [(0, 2), (1, 4)], [(1, 3)]))
+    blocks.append(_stalky(rng, 30, 0.15, [(0, 12), (3, 2), (7, 5)], [(0, 6), (9, 2)]))     # wave / small class
+    blocks.append(_stalky(rng, 60, 0.08, [(0, 40), (1, 17), (2, 9)], [(0, 30), (5, 4)]))   # n' ~ 70 after, ~190 before: mid class
+    blocks.append(_stalky(rng, 150, 0.03, [(0, 25), (10, 3), (20, 14)], [(4, 9)]))         # n' ~ 160: sparse block class
+    import scipy.sparse as sp
+    node_off, rows, cols = [0], [], []
+    for n, edges in blocks:
+        o = node_off[-1]
+        for i, j in set((min(i, j), max(i, j)) for i, j in edges):
+            rows += [o + i, o + j]
+            cols += [o + j, o + i]
+        node_off.append(o + n)
+    N = node_off[-1]
+    a = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(N, N))
+    a.sort_indices()
+    view = dict(node_off=torch.tensor(node_off), row_ptr=torch.from_numpy(a.indptr.astype(np.int64)),
+                col_idx=torch.from_numpy(a.indices.astype(np.int64)))
+    red, red0 = reduced_sizes(view), reduced_sizes(view, stalks=False)
+    assert (red0 - red >= 2).all() and 64 < red[4] <= 128 < red0[4] and red[5] > 128, (red, red0)
+    x, evals, raw = _run(view)
+    assert _run.arnoldi_steps == 0 and _run.status[3] == 0 and _run.status[1] >= 2, _run.status
+    assert np.sum(np.abs(evals[4] - 2 ** -0.5) < 1e-5) >= 20
     _check(view, x, evals, raw)
 
 
