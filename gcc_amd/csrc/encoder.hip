@@ -31,12 +31,14 @@
 namespace {
 
 // =========================================================================
-// F0: assemble input features (graph_encoder.py:158-165) + SumPooling of hidden_rep[0]
+// F0: assemble input features (graph_encoder.py:158-165); also zeroes the pass's accumulators (BatchNorm statistics
+// replicas, pooled sums), which the kernels after it add to -- four memset launches per step otherwise
 struct FeatArgs {
     const int32_t *node_off, *row_ptr, *graph_id, *seed_local;
     const float *pos, *emb;
     float *x0;
-    double *pooled0;
+    float4 *zero_a, *zero_b;     // two regions to clear, in 16-byte units
+    int64_t zero_a16, zero_b16;
     int32_t B, pos_dim, emb_dim, max_degree, mult;
 };
 struct FeatLaunch { FeatArgs p[kMaxPass]; };
@@ -44,15 +46,20 @@ struct FeatLaunch { FeatArgs p[kMaxPass]; };
 __global__ __launch_bounds__(kThreads) void gin_feat_kernel(FeatLaunch L)
 {
     TRAIN_STEP_WAVE_PRIORITY();
-    __shared__ float T[kTile * kLdt];
     const FeatArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
     const int N = a.node_off[a.B];
+    {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int64_t stride = (int64_t)gridDim.x * kThreads;
+        for (int64_t i = (int64_t)blockIdx.x * kThreads + tid; i < a.zero_a16; i += stride) a.zero_a[i] = z4;
+        for (int64_t i = (int64_t)blockIdx.x * kThreads + tid; i < a.zero_b16; i += stride) a.zero_b[i] = z4;
+    }
     for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
         const int nrows = min(kTile, N - tile0);
-        for (int r = gi; r < kTile; r += 16) {
-            F4 x = {0.f, 0.f, 0.f, 0.f};
-            if (r < nrows) {
+        for (int r = gi; r < nrows; r += 16) {
+            {
+                F4 x;
                 const int v = tile0 + r;
                 const int deg = (a.row_ptr[v + 1] - a.row_ptr[v]) * a.mult;          // g.in_degrees(), :154
                 const int dcl = deg < a.max_degree ? deg : a.max_degree;  // clamp(0, max_degree), :161
@@ -69,11 +76,7 @@ __global__ __launch_bounds__(kThreads) void gin_feat_kernel(FeatLaunch L)
                 }
                 st4(a.x0 + (int64_t)v * H + 4 * t, x);
             }
-            st4(&T[r * kLdt + 4 * t], x);
         }
-        __syncthreads();
-        pool_tile(T, tile0, nrows, a.graph_id, a.pooled0);
-        lds_barrier();
     }
 }
 
@@ -87,9 +90,7 @@ struct InArgs {
     float *agg;               // or NULL
     float *z1;
     double *stats_a;
-    double *tot_a;            // totals of stats_a, written by the last workgroup (finalize_stats), or NULL
-    int32_t *tick_a;
-    double *pooled;           // SumPooling of this layer's input h (hidden_rep[layer]); NULL for layer 0 (done by F0)
+    double *pooled;           // SumPooling of this layer's input h (hidden_rep[layer], gin.py:216,228)
     int32_t B, first, kdim, training;
     float eps, nbr_weight;    // nbr_weight: edge multiplicity
 };
@@ -173,7 +174,6 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
         lds_barrier();
         GIN_TICK(6);
     }
-    finalize_stats(a.stats_a, a.tot_a, a.tick_a, (int)gridDim.x);
 }
 
 // =========================================================================
@@ -185,8 +185,6 @@ struct MidArgs {
     const float *w1, *b1;
     float *z2;
     double *stats_b;
-    double *tot_b;
-    int32_t *tick_b;
     int32_t B, training;
     float eps;
 };
@@ -221,7 +219,6 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
         flush_stats(red, a.stats_b);
         lds_barrier();
     }
-    finalize_stats(a.stats_b, a.tot_b, a.tick_b, (int)gridDim.x);
 }
 
 // =========================================================================
@@ -231,8 +228,6 @@ struct StatArgs {
     const float *z2;
     BnDev bnb;
     double *stats_c;
-    double *tot_c;
-    int32_t *tick_c;
     int32_t B, training;
     float eps;
 };
@@ -270,11 +265,12 @@ __global__ __launch_bounds__(kThreads) void gin_stat_kernel(StatLaunch L)
             atomicAdd(&a.stats_c[((int)blockIdx.x % kRep) * 2 * H + tid], v);
         }
     }
-    finalize_stats(a.stats_c, a.tot_c, a.tick_c, (int)gridDim.x);
 }
 
 // =========================================================================
-// F4: SumPooling of the last hidden representation (gin.py:228, i = num_layers - 1)
+// F4: SumPooling of the last hidden representation (gin.py:228, i = num_layers - 1); the earlier ones are pooled by
+// gin_in_kernel, where the atomics' latency hides behind the gather (as launches of their own they take 22-33 us each,
+// and on a second stream the event hand-offs cost more than they hide: profiles/r3_side_stream_probe.txt)
 struct PoolArgs {
     const int32_t *node_off, *graph_id;
     const float *z2;
@@ -321,6 +317,7 @@ struct ReadArgs {
     BnDev bn[3 * GCC_GIN_MAX_LAYERS];
     int32_t B, nlayers, kdim0, normalize, update_running;
     float norm_eps, momentum;
+    double *totals;             // [3 * nlayers][2][64] or NULL: the statistics replicas added up, for the backward pass
 };
 struct ReadLaunch { ReadArgs p[kMaxPass]; };
 
@@ -389,14 +386,18 @@ __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
             }
         }
     }
-    // BatchNorm running statistics (torch: momentum 0.1, unbiased variance): BatchNorm k by workgroup k % gridDim.x
-    if (a.update_running && tid >= 64 && tid < 64 + H) {
+    // BatchNorm k by workgroup k % gridDim.x: the replicas of its batch statistics added up in replica order (the value
+    // every forward consumer computed for itself) for the ~16 kernels of the backward pass that need them, and the running
+    // statistics (torch: momentum 0.1, unbiased variance)
+    if ((a.update_running || a.totals) && tid >= 64 && tid < 64 + H) {
         const int c = tid - 64;
         const double n = (double)a.node_off[a.B];
         for (int k = (int)blockIdx.x; k < 3 * a.nlayers; k += (int)gridDim.x) {
             const BnDev &bn = a.bn[k];
             double s1 = 0.0, s2 = 0.0;
             for (int r = 0; r < kRep; ++r) { s1 += bn.stats[r * 2 * H + c]; s2 += bn.stats[r * 2 * H + H + c]; }
+            if (a.totals) { a.totals[(int64_t)k * 2 * H + c] = s1; a.totals[(int64_t)k * 2 * H + H + c] = s2; }
+            if (!a.update_running) continue;
             const double mean = s1 / n;
             double var = s2 / n - mean * mean;
             if (var < 0.0) var = 0.0;
@@ -432,17 +433,14 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
     }
     hipStream_t s = (hipStream_t)stream;
     prof_mark(prof, 0, s);
-    for (int i = 0; i < npass; ++i) {
-        const gcc_gin_pass &p = passes[i];
-        (void)hipMemsetAsync(p.stats, 0, sizeof(double) * (size_t)Lg * 3 * kRep * 2 * H, s);
-        (void)hipMemsetAsync(p.pooled, 0, sizeof(double) * (size_t)(Lg + 1) * p.batch_size * H, s);
-    }
     const dim3 grid(kGridX, npass), block(kThreads);
     {
         FeatLaunch L;
         for (int i = 0; i < npass; ++i) {
             const gcc_gin_pass &p = passes[i];
-            L.p[i] = {p.node_off, p.row_ptr, p.graph_id, p.seed_local, p.pos, p.w.degree_embedding, p.x0, p.pooled,
+            L.p[i] = {p.node_off, p.row_ptr, p.graph_id, p.seed_local, p.pos, p.w.degree_embedding, p.x0,
+                      (float4 *)p.stats, (float4 *)p.pooled, (int64_t)Lg * 3 * kRep * 2 * H * (int64_t)sizeof(double) / 16,
+                      (int64_t)(Lg + 1) * p.batch_size * H * (int64_t)sizeof(double) / 16,
                       p.batch_size, p.w.pos_dim, p.w.deg_emb_dim, p.w.max_degree, p.edge_multiplicity > 1 ? p.edge_multiplicity : 1};
         }
         hipLaunchKernelGGL(gin_feat_kernel, grid, block, 0, s, L);
@@ -455,13 +453,12 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
                 InArgs a;
                 a.node_off = p.node_off; a.row_ptr = p.row_ptr; a.col_idx = p.col_idx; a.graph_id = p.graph_id;
                 a.src = l == 0 ? p.x0 : p.z2[l - 1];
-                a.bnb = l == 0 ? BnDev() : bn_of(p, p.w.bn_b[l - 1], l - 1, 1);
-                a.bnc = l == 0 ? BnDev() : bn_of(p, p.w.bn_c[l - 1], l - 1, 2);
+                a.bnb = l == 0 ? BnDev() : bn_of(p, p.w.bn_b[l - 1], l - 1, 1, false);
+                a.bnc = l == 0 ? BnDev() : bn_of(p, p.w.bn_c[l - 1], l - 1, 2, false);
                 a.w0 = p.w.lin0_w[l]; a.b0 = p.w.lin0_b[l];
                 a.agg = p.agg[l]; a.z1 = p.z1[l];
                 a.stats_a = stats_of(p, l, 0);
-                a.tot_a = totals_of(p, l, 0); a.tick_a = ticket_of(p, l, 0);
-                a.pooled = l == 0 ? nullptr : p.pooled + (int64_t)l * p.batch_size * H;
+                a.pooled = p.pooled + (int64_t)l * p.batch_size * H;
                 a.B = p.batch_size; a.first = l == 0;
                 a.kdim = l == 0 ? p.w.pos_dim + p.w.deg_emb_dim + 1 : H;
                 a.training = p.training; a.eps = p.w.bn_eps;
@@ -475,8 +472,8 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
             MidLaunch L;
             for (int i = 0; i < npass; ++i) {
                 const gcc_gin_pass &p = passes[i];
-                L.p[i] = {p.node_off, p.z1[l], bn_of(p, p.w.bn_a[l], l, 0), p.w.lin1_w[l], p.w.lin1_b[l],
-                          p.z2[l], stats_of(p, l, 1), totals_of(p, l, 1), ticket_of(p, l, 1), p.batch_size, p.training,
+                L.p[i] = {p.node_off, p.z1[l], bn_of(p, p.w.bn_a[l], l, 0, false), p.w.lin1_w[l], p.w.lin1_b[l],
+                          p.z2[l], stats_of(p, l, 1), p.batch_size, p.training,
                           p.w.bn_eps};
             }
             hipLaunchKernelGGL(gin_mid_kernel, grid, block, 0, s, L);
@@ -486,8 +483,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
             bool need = false;
             for (int i = 0; i < npass; ++i) {
                 const gcc_gin_pass &p = passes[i];
-                L.p[i] = {p.node_off, p.z2[l], bn_of(p, p.w.bn_b[l], l, 1), stats_of(p, l, 2), totals_of(p, l, 2),
-                          ticket_of(p, l, 2), p.batch_size, p.training, p.w.bn_eps};
+                L.p[i] = {p.node_off, p.z2[l], bn_of(p, p.w.bn_b[l], l, 1, false), stats_of(p, l, 2), p.batch_size, p.training, p.w.bn_eps};
                 need = need || p.training;
             }
             if (need) hipLaunchKernelGGL(gin_stat_kernel, grid, block, 0, s, L);
@@ -497,8 +493,8 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
         PoolLaunch L;
         for (int i = 0; i < npass; ++i) {
             const gcc_gin_pass &p = passes[i];
-            L.p[i] = {p.node_off, p.graph_id, p.z2[Lg - 1], bn_of(p, p.w.bn_b[Lg - 1], Lg - 1, 1),
-                      bn_of(p, p.w.bn_c[Lg - 1], Lg - 1, 2), p.pooled + (int64_t)Lg * p.batch_size * H,
+            L.p[i] = {p.node_off, p.graph_id, p.z2[Lg - 1], bn_of(p, p.w.bn_b[Lg - 1], Lg - 1, 1, false),
+                      bn_of(p, p.w.bn_c[Lg - 1], Lg - 1, 2, false), p.pooled + (int64_t)Lg * p.batch_size * H,
                       p.batch_size, p.training, p.w.bn_eps};
         }
         hipLaunchKernelGGL(gin_pool_kernel, grid, block, 0, s, L);
@@ -512,10 +508,11 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
             for (int k = 0; k <= Lg; ++k) { a.pred_w[k] = p.w.pred_w[k]; a.pred_b[k] = p.w.pred_b[k]; }
             a.drop = drop_cfg(p); a.score = p.score; a.feat = p.feat;
             for (int l = 0; l < Lg; ++l) {
-                a.bn[3 * l + 0] = bn_of(p, p.w.bn_a[l], l, 0);
-                a.bn[3 * l + 1] = bn_of(p, p.w.bn_b[l], l, 1);
-                a.bn[3 * l + 2] = bn_of(p, p.w.bn_c[l], l, 2);
+                a.bn[3 * l + 0] = bn_of(p, p.w.bn_a[l], l, 0, false);
+                a.bn[3 * l + 1] = bn_of(p, p.w.bn_b[l], l, 1, false);
+                a.bn[3 * l + 2] = bn_of(p, p.w.bn_c[l], l, 2, false);
             }
+            a.totals = p.training ? p.bn_totals : nullptr;
             a.B = p.batch_size; a.nlayers = Lg; a.kdim0 = p.w.pos_dim + p.w.deg_emb_dim + 1;
             a.normalize = p.normalize; a.update_running = p.training && p.update_running_stats;
             a.norm_eps = p.w.norm_eps; a.momentum = p.w.bn_momentum;

@@ -115,11 +115,20 @@ struct ReadBwdArgs {
     float *G, *dpooled;       // [L+1][B][64]
     int32_t B, nlayers, kdim0, normalize;
     float norm_eps;
+    float4 *zero;             // workgroups past the first `nread` clear this region (the accumulators of the kernels that follow)
+    int64_t zero16;
+    int32_t nread;
 };
 
 __global__ __launch_bounds__(kThreads) void gin_bwd_readout_kernel(ReadBwdArgs a)
 {
     TRAIN_STEP_WAVE_PRIORITY();
+    if ((int)blockIdx.x >= a.nread) {              // block-uniform
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int64_t stride = (int64_t)((int)gridDim.x - a.nread) * kThreads;
+        for (int64_t i = (int64_t)((int)blockIdx.x - a.nread) * kThreads + threadIdx.x; i < a.zero16; i += stride) a.zero[i] = z4;
+        return;
+    }
     const int lane = lane_id(), wv = (int)threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
     const int b = ((int)blockIdx.x * 4 + wv) * 16 + j;
     const bool valid = b < a.B;
@@ -459,7 +468,8 @@ __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float S[H * H];
     __shared__ float Cx[2 * H];
-    const WgradJob &jb = a.job[blockIdx.y];
+    const int jid = (int)blockIdx.y;
+    const WgradJob &jb = a.job[jid];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
     __shared__ float Sb[4 * H];
     const int Nn = a.node_off[a.B];
@@ -516,7 +526,7 @@ __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
         }
         __syncthreads();
     }
-    float *slab = a.slabs + ((int64_t)blockIdx.y * kWgChunks + blockIdx.x) * H * H;
+    float *slab = a.slabs + ((int64_t)jid * kWgChunks + blockIdx.x) * H * H;
     for (int i = tid; i < H * H; i += kThreads) slab[i] = S[i];
     // bias gradient = column sums of dZ: over the 4 rows of a step (lanes q), then over the waves
 #pragma unroll
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
     }
     __syncthreads();
     if (tid < H)
-        a.bias_slabs[((int64_t)blockIdx.y * kWgChunks + blockIdx.x) * H + tid] =
+        a.bias_slabs[((int64_t)jid * kWgChunks + blockIdx.x) * H + tid] =
             (Sb[tid] + Sb[H + tid]) + (Sb[2 * H + tid] + Sb[3 * H + tid]);
 }
 
@@ -686,7 +696,6 @@ extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat
     }
     hipStream_t s = (hipStream_t)stream;
     prof_mark(prof, 0, s);
-    (void)hipMemsetAsync((char *)workspace + w.off_zero, 0, (size_t)w.zero_bytes, s);
     const dim3 grid(kGridX), block(kThreads);
     auto bst = [&](int l, int which) { return w.bst + ((int64_t)l * 3 + which) * kRep * 3 * H; };   // which: 0=a 1=b 2=c
     {
@@ -695,7 +704,9 @@ extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat
         for (int i = 0; i <= L; ++i) a.pred_w[i] = p.w.pred_w[i];
         a.G = w.G; a.dpooled = w.dpooled; a.B = B; a.nlayers = L; a.kdim0 = kdim0; a.normalize = p.normalize;
         a.norm_eps = p.w.norm_eps;
-        hipLaunchKernelGGL(gin_bwd_readout_kernel, dim3((B + 63) / 64), block, 0, s, a);
+        // the per-call accumulators (BatchNorm-backward column sums) are cleared by extra workgroups of this launch
+        a.zero = (float4 *)((char *)workspace + w.off_zero); a.zero16 = w.zero_bytes / 16; a.nread = (B + 63) / 64;
+        hipLaunchKernelGGL(gin_bwd_readout_kernel, dim3(a.nread + 64), block, 0, s, a);
     }
     for (int l = L - 1; l >= 0; --l) {
         const BnDev bna = bn_of(p, p.w.bn_a[l], l, 0);
@@ -727,6 +738,8 @@ extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat
         hipLaunchKernelGGL(gin_bwd_emb_kernel, dim3(kEmbBlocks), block, 0, s, a);
     }
     {
+        // (one launch for all 3 L + 1 products: a launch per layer takes as long as this one -- every workgroup's chain of
+        //  row tiles is the same -- so spreading them over a second stream bought nothing, profiles/r3_side_stream_probe.txt)
         WgradArgs a;
         a.node_off = p.node_off; a.slabs = w.slabs; a.bias_slabs = w.bias_slabs; a.B = B; a.eps = p.w.bn_eps;
         for (int l = 0; l < L; ++l) {

@@ -267,32 +267,6 @@ __device__ __forceinline__ void flush_stats(const float *red, double *stats)
 }
 
 
-// Every workgroup of a pass calls this once after its last flush_stats(): the one that arrives last adds the replicas
-// up in replica order into totals[2][64] (and re-arms the counter).  Ends with nothing pending; block-uniform.
-__device__ __forceinline__ void finalize_stats(double *stats, double *totals, int32_t *ticket, int nblocks)
-{
-    __shared__ int last_arrival;
-    if (!totals) return;
-    // No cache maintenance here (a __threadfence() per workgroup writes back / invalidates L2 some 1500 times per kernel
-    // and made the forward pass 4x slower): the statistics are device-scope atomics performed at the coherence point and
-    // the last arrival reads the replicas with device-scope loads.  What the ticket needs is that this workgroup's
-    // atomics have been PERFORMED, not merely accepted: they return nothing, so s_waitcnt alone does not say that
-    // (seen on freshly started devices: a total missing one workgroup, 1 run in ~4).  A returning atomic on each
-    // address this workgroup added to comes back only after the earlier ones to that address -- one round trip per
-    // workgroup, once per kernel.
-    if (threadIdx.x < 2 * H) keep_alive(atomicAdd(&stats[((int)blockIdx.x % kRep) * 2 * H + threadIdx.x], 0.0));
-    __syncthreads();
-    if (threadIdx.x == 0) last_arrival = atomicAdd(ticket, 1) == nblocks - 1;
-    __syncthreads();
-    if (!last_arrival) return;
-    if (threadIdx.x < 2 * H) {
-        double s = 0.0;
-        for (int r = 0; r < kRep; ++r) s += load_fresh_f64(stats + r * 2 * H + threadIdx.x);
-        totals[threadIdx.x] = s;
-    }
-    if (threadIdx.x == 0) *ticket = 0;
-}
-
 // ---- neighbourhood sum over an LDS tile.  Precondition: T rows [0, nrows) hold the self term, rp_lds[0 .. nrows] the
 // tile's row pointers, and a __syncthreads() separates those writes from this call.  Postcondition:
 // T[r] = self + nbr_weight * sum_{u in row(tile0 + r)} feat(u); ends with a __syncthreads().
@@ -420,14 +394,11 @@ inline double *totals_of(const gcc_gin_pass &p, int layer, int which)   // [laye
 {
     return p.bn_totals ? p.bn_totals + ((int64_t)layer * 3 + which) * 2 * H : nullptr;
 }
-inline int32_t *ticket_of(const gcc_gin_pass &p, int layer, int which)
+// BnDev of BatchNorm `which` (0 = mlp bn, 1 = apply_func bn, 2 = outer bn) of GIN layer `layer`.  The totals exist once
+// the forward pass's readout kernel has run: the forward kernels add the replicas up themselves (with_totals = false)
+inline BnDev bn_of(const gcc_gin_pass &p, const gcc_bn &b, int layer, int which, bool with_totals = true)
 {
-    return p.bn_totals ? (int32_t *)(p.bn_totals + (int64_t)p.w.num_gin_layers * 3 * 2 * H) + layer * 3 + which : nullptr;
-}
-// BnDev of BatchNorm `which` (0 = mlp bn, 1 = apply_func bn, 2 = outer bn) of GIN layer `layer`
-inline BnDev bn_of(const gcc_gin_pass &p, const gcc_bn &b, int layer, int which)
-{
-    return bn_dev(b, p.stats + ((int64_t)layer * 3 + which) * kRep * 2 * H, totals_of(p, layer, which));
+    return bn_dev(b, p.stats + ((int64_t)layer * 3 + which) * kRep * 2 * H, with_totals ? totals_of(p, layer, which) : nullptr);
 }
 
 inline double *stats_of(const gcc_gin_pass &p, int layer, int which)   // [layer][bn a|b|c][kRep][2][64]

@@ -133,8 +133,8 @@ class GinEngine:
                 z1=[torch.zeros(node_cap, H, **f32) for _ in range(L)],
                 z2=[torch.zeros(node_cap, H, **f32) for _ in range(L)],
                 stats=torch.zeros(L, 3, STATS_REPLICAS, 2, H, dtype=torch.float64, device=device),
-                # [L][3][2][64] totals of the replicas + int32 arrival counters (gcc_gin_pass.bn_totals)
-                bn_totals=torch.zeros(L * 3 * 2 * H + (L * 3 + 1) // 2 + 1, dtype=torch.float64, device=device),
+                # [L][3][2][64] totals of the replicas, written by the forward pass for the backward pass (gcc_gin_pass.bn_totals)
+                bn_totals=torch.zeros(L * 3 * 2 * H, dtype=torch.float64, device=device),
                 pooled=torch.zeros(L + 1, B, H, dtype=torch.float64, device=device),
                 score=torch.zeros(B, H, **f32), feat=torch.zeros(B, H, **f32))
         return self._bufs[k]

@@ -268,11 +268,10 @@ typedef struct gcc_gin_pass {    /* one encoder invocation on one batched graph 
                                   * neighbour sum.  The reference's NodeClassificationDataset builds its DGL graph
                                   * with every undirected edge twice per direction (data_util.py:84-85 +
                                   * graph_dataset.py:301-302); forward only (backward requires 1). */
-    double *bn_totals;           /* device [num_gin_layers][3][2][64] doubles, then int32[num_gin_layers * 3] arrival
-                                  * counters (zeroed once by the caller), or NULL.  The workgroup of a forward kernel
-                                  * that arrives last adds the 32 replicas of the statistics it produced up (in replica
-                                  * order: the same value every consumer would compute), so the ~20 later kernels of the
-                                  * step read 2 numbers per channel instead of 64 before they can start. */
+    double *bn_totals;           /* device [num_gin_layers][3][2][64] doubles, or NULL.  Training passes: gcc_gin_forward's
+                                  * last kernel adds the 32 replicas of every BatchNorm's statistics up (in replica order:
+                                  * the value each forward consumer computed for itself) and gcc_gin_backward's ~16 kernels
+                                  * read these 2 numbers per channel instead of 64 before they can start. */
     const int32_t *seed_local;   /* device [B] or NULL: local index of the seed node of every graph (NULL: node 0, as the
                                   * sampler emits; graph classification marks g.out_degrees().argmax(),
                                   * data_util.py:236-237 with entire_graph=True) */
