@@ -491,24 +491,48 @@ __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
     for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[ob][kb] = z; }
-    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+    // a workgroup walks 6-7 row tiles; with the loads of a tile issued right before its products every tile cost a full
+    // memory round trip (58 us for ~6 us of matrix work): the next tile's rows are requested before this tile's products
+    float av[4][4], xv[4][4];
+    auto fetch = [&](int tile0, float (&A)[4][4], float (&X)[4][4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int row = tile0 + 16 * wv + 4 * s + q;     // MFMA reduction index = row
-            float av[4], bv[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                av[k] = row < N ? jb.dZ[(int64_t)row * H + 16 * k + j] : 0.f;
-                bsum[k] += av[k];
+                A[s][k] = row < N ? jb.dZ[(int64_t)row * H + 16 * k + j] : 0.f;
                 float x = 0.f;
                 if (row < N) x = jb.Xd ? (float)jb.Xd[(int64_t)row * H + 16 * k + j] : jb.X[(int64_t)row * H + 16 * k + j];
-                if (act) x = row < N ? fmaxf(fmaf(x, xs[k], xh[k]), 0.f) : 0.f;
-                bv[k] = x;
+                X[s][k] = x;
+            }
+        }
+    };
+    const int tstride = (int)gridDim.x * kTile;
+    int tile0 = (int)blockIdx.x * kTile;
+    if (tile0 < N) fetch(tile0, av, xv);
+    for (; tile0 < N; tile0 += tstride) {
+        float an[4][4], xn[4][4];
+        const bool more = tile0 + tstride < N;               // block-uniform
+        if (more) fetch(tile0 + tstride, an, xn);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = tile0 + 16 * wv + 4 * s + q;
+            float bv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bsum[k] += av[s][k];
+                bv[k] = act ? (row < N ? fmaxf(fmaf(xv[s][k], xs[k], xh[k]), 0.f) : 0.f) : xv[s][k];
             }
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) acc[ob][kb] = mfma_16x16x4_f32(av[ob], bv[kb], acc[ob][kb]);
+                for (int kb = 0; kb < 4; ++kb) acc[ob][kb] = mfma_16x16x4_f32(av[s][ob], bv[kb], acc[ob][kb]);
+        }
+        if (more) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { av[s][k] = an[s][k]; xv[s][k] = xn[s][k]; }
         }
     }
     // combine the 4 waves in a fixed order, then write this chunk's slab
