@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
-    __shared__ float part[32 * H];
+    __shared__ __attribute__((aligned(16))) float part[32 * H];      // (also the fp64 scratch of bn_table)
     __shared__ float red[4 * 2 * H];
     __shared__ int prow[32];
     __shared__ int rpl[kTile + 1], gidl[kTile];
@@ -114,12 +114,19 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
     const int N = a.node_off[a.B];
     const double dn = (double)N;
     __shared__ float tabb[2 * H], tabc[2 * H];
+    __shared__ float Wl[H * kLdt];                 // linears.0 weight, staged once per workgroup
     Aff4 ab, ac;
     long long tick_ = L.ticks ? device_ticks() : 0;
+    {
+        const WStage wst = stage_weights_request(a.w0, a.kdim);     // in flight with N and the statistics
+        if (!a.first) {                            // block-uniform
+            bn_table(tabb, a.bnb, dn, a.eps, a.training, (double *)part);
+            bn_table(tabc, a.bnc, dn, a.eps, a.training, (double *)part);
+        }
+        stage_weights_store(Wl, wst);
+    }
+    __syncthreads();
     if (!a.first) {
-        bn_table(tabb, a.bnb, 0, dn, a.eps, a.training);
-        bn_table(tabc, a.bnc, H, dn, a.eps, a.training);
-        __syncthreads();
         ab = aff4_from_table(tabb, 4 * t);
         ac = aff4_from_table(tabc, 4 * t);
     }
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
             F4 xb[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) xb[c] = ld4(&T[rl * kLdt + 16 * c + 4 * q]);
-            linear_rows16_store_stats(xb, a.w0, a.kdim, a.b0, a.z1, tile0 + rl, rl < nrows, &red[wv * 2 * H]);
+            linear_rows16_lds_store_stats(xb, Wl, a.b0, a.z1, tile0 + rl, rl < nrows, &red[wv * 2 * H]);
         }
         __syncthreads();
         GIN_TICK(5);
@@ -193,13 +200,16 @@ struct MidLaunch { MidArgs p[kMaxPass]; };
 __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
 {
     TRAIN_STEP_WAVE_PRIORITY();
-    __shared__ float red[4 * 2 * H];
+    __shared__ __attribute__((aligned(16))) float red[4 * 2 * H];    // (also the fp64 scratch of bn_table)
     const MidArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
+    __shared__ float Wl[H * kLdt];
+    const WStage wst = stage_weights_request(a.w1, H);       // in flight with N and the statistics
     const int N = a.node_off[a.B];
     const double dn = (double)N;
     __shared__ float taba[2 * H];
-    bn_table(taba, a.bna, 0, dn, a.eps, a.training);
+    bn_table(taba, a.bna, dn, a.eps, a.training, (double *)red);
+    stage_weights_store(Wl, wst);
     __syncthreads();
     Aff4 aa[4];
 #pragma unroll
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
             if (valid) x = affine_relu(ld4(a.z1 + (int64_t)row * H + 16 * c + 4 * q), aa[c]);   // gin.py:115
             xb[c] = x;
         }
-        linear_rows16_store_stats(xb, a.w1, H, a.b1, a.z2, row, valid, &red[wv * 2 * H]);     // gin.py:116
+        linear_rows16_lds_store_stats(xb, Wl, a.b1, a.z2, row, valid, &red[wv * 2 * H]);      // gin.py:116
         __syncthreads();
         flush_stats(red, a.stats_b);
         lds_barrier();
@@ -236,13 +246,12 @@ struct StatLaunch { StatArgs p[kMaxPass]; };
 __global__ __launch_bounds__(kThreads) void gin_stat_kernel(StatLaunch L)
 {
     TRAIN_STEP_WAVE_PRIORITY();
-    __shared__ float part[16 * 2 * H];
+    __shared__ __attribute__((aligned(16))) float part[16 * 2 * H];  // (also the fp64 scratch of bn_table)
     const StatArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
     const int N = a.node_off[a.B];
     __shared__ float tabb[2 * H];
-    bn_table(tabb, a.bnb, 0, (double)N, a.eps, a.training);
-    __syncthreads();
+    bn_table(tabb, a.bnb, (double)N, a.eps, a.training, (double *)part);
     const Aff4 ab = aff4_from_table(tabb, 4 * t);
     F4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
     bool any = false;
@@ -284,14 +293,13 @@ struct PoolLaunch { PoolArgs p[kMaxPass]; };
 __global__ __launch_bounds__(kThreads) void gin_pool_kernel(PoolLaunch L)
 {
     TRAIN_STEP_WAVE_PRIORITY();
-    __shared__ float T[kTile * kLdt];
+    __shared__ __attribute__((aligned(16))) float T[kTile * kLdt];   // (also the fp64 scratch of bn_table)
     const PoolArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
     const int N = a.node_off[a.B];
     __shared__ float tabb[2 * H], tabc[2 * H];
-    bn_table(tabb, a.bnb, 0, (double)N, a.eps, a.training);
-    bn_table(tabc, a.bnc, H, (double)N, a.eps, a.training);
-    __syncthreads();
+    bn_table(tabb, a.bnb, (double)N, a.eps, a.training, (double *)T);
+    bn_table(tabc, a.bnc, (double)N, a.eps, a.training, (double *)T);
     const Aff4 ab = aff4_from_table(tabb, 4 * t);
     const Aff4 ac = aff4_from_table(tabc, 4 * t);
     for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
     TRAIN_STEP_WAVE_PRIORITY();
     // 16 graphs per workgroup; the prediction layers are split over the four waves (wave w: layers w, w + 4, ...) and
     // the partial scores meet in LDS, so the chain of dependent loads is 2 layers long instead of 5
-    __shared__ float part[4][16][H + 4];
+    __shared__ __attribute__((aligned(16))) float part[4][16][H + 4];
     const ReadArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
     const int b = (int)blockIdx.x * 16 + j;
@@ -386,25 +394,29 @@ __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
             }
         }
     }
-    // BatchNorm k by workgroup k % gridDim.x: the replicas of its batch statistics added up in replica order (the value
-    // every forward consumer computed for itself) for the ~16 kernels of the backward pass that need them, and the running
-    // statistics (torch: momentum 0.1, unbiased variance)
-    if ((a.update_running || a.totals) && tid >= 64 && tid < 64 + H) {
-        const int c = tid - 64;
+    // BatchNorm k by workgroup k % gridDim.x: the replicas of its batch statistics added up once for the ~16 kernels of
+    // the backward pass that need them, and the running statistics (torch: momentum 0.1, unbiased variance)
+    if (a.update_running || a.totals) {                       // block-uniform
         const double n = (double)a.node_off[a.B];
+        double *scratch = (double *)&part[0][0][0];
         for (int k = (int)blockIdx.x; k < 3 * a.nlayers; k += (int)gridDim.x) {
+            __syncthreads();                                   // the partial scores / the previous BatchNorm's sums are done with
             const BnDev &bn = a.bn[k];
-            double s1 = 0.0, s2 = 0.0;
-            for (int r = 0; r < kRep; ++r) { s1 += bn.stats[r * 2 * H + c]; s2 += bn.stats[r * 2 * H + H + c]; }
-            if (a.totals) { a.totals[(int64_t)k * 2 * H + c] = s1; a.totals[(int64_t)k * 2 * H + H + c] = s2; }
-            if (!a.update_running) continue;
-            const double mean = s1 / n;
-            double var = s2 / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-            bn.running_mean[c] = (float)((1.0 - a.momentum) * (double)bn.running_mean[c] + a.momentum * mean);
-            bn.running_var[c] = (float)((1.0 - a.momentum) * (double)bn.running_var[c] + a.momentum * unb);
-            if (c == 0 && bn.nbt) bn.nbt[0] += 1;
+            replica_sums128(bn.stats, 2 * H, scratch);
+            if (tid < H) {
+                const int c = tid;
+                const double s1 = scratch[c] + scratch[128 + c], s2 = scratch[H + c] + scratch[128 + H + c];
+                if (a.totals) { a.totals[(int64_t)k * 2 * H + c] = s1; a.totals[(int64_t)k * 2 * H + H + c] = s2; }
+                if (a.update_running) {
+                    const double mean = s1 / n;
+                    double var = s2 / n - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+                    bn.running_mean[c] = (float)((1.0 - a.momentum) * (double)bn.running_mean[c] + a.momentum * mean);
+                    bn.running_var[c] = (float)((1.0 - a.momentum) * (double)bn.running_var[c] + a.momentum * unb);
+                    if (c == 0 && bn.nbt) bn.nbt[0] += 1;
+                }
+            }
         }
     }
 }

@@ -20,17 +20,10 @@ namespace {
 
 constexpr int kWgChunks = 64;     // row chunks (slabs) per weight gradient
 
-// per-column training-mode BatchNorm constants
+// per-column training-mode BatchNorm constants from the column sum s1 and sum of squares s2 of its input
 struct BnCol { float mean, rstd, gamma, beta; };
-__device__ __forceinline__ BnCol bn_col(const BnDev &bn, int c, double n, float eps)
+__device__ __forceinline__ BnCol bn_col(const BnDev &bn, int c, double s1, double s2, double n, float eps)
 {
-    double s1 = 0.0, s2 = 0.0;
-    if (bn.totals) {
-        s1 = bn.totals[c];
-        s2 = bn.totals[H + c];
-    } else {
-        for (int r = 0; r < kRep; ++r) { s1 += bn.stats[r * 2 * H + c]; s2 += bn.stats[r * 2 * H + H + c]; }
-    }
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -48,19 +41,29 @@ __device__ __forceinline__ BnCol bn_col(const BnDev &bn, int c, double n, float 
 //   dx   = g * K1 + x * K2 + K3   (BatchNorm backward as an affine map of (g, x))
 enum { RS = 0, RM = 1, PS = 2, PH = 3, K1 = 4, K2 = 5, K3 = 6, kCoefRows = 7 };
 
+// ALL threads call it (block-uniform); scratch = LDS [256] doubles that nothing else uses during the call (replica_sums128);
+// ends with a barrier
 __device__ __forceinline__ void fill_coefs(float *C /* [7][64] */, const BnDev &bn, const double *bst, double n,
-                                           float eps)
+                                           float eps, double *scratch)
 {
     const int c = (int)threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    if (bn.totals) {                                   // (the forward pass's readout kernel added the replicas up)
+        if (c < H) { s1 = bn.totals[c]; s2 = bn.totals[H + c]; }
+    } else {
+        replica_sums128(bn.stats, 2 * H, scratch);
+        if (c < H) { s1 = scratch[c] + scratch[128 + c]; s2 = scratch[H + c] + scratch[128 + H + c]; }
+        __syncthreads();
+    }
+    if (bst) replica_sums128(bst, 3 * H, scratch);     // slots 0 and 1 of the backward sums
     if (c < H) {
-        const BnCol b = bn_col(bn, c, n, eps);
+        const BnCol b = bn_col(bn, c, s1, s2, n, eps);
         C[RS * H + c] = b.rstd;
         C[RM * H + c] = -b.mean * b.rstd;
         C[PS * H + c] = b.gamma * b.rstd;
         C[PH * H + c] = b.beta - b.gamma * b.rstd * b.mean;
         if (bst) {
-            double b1 = 0.0, b2 = 0.0;
-            for (int r = 0; r < kRep; ++r) { b1 += bst[r * 3 * H + c]; b2 += bst[r * 3 * H + H + c]; }
+            const double b1 = scratch[c] + scratch[128 + c], b2 = scratch[H + c] + scratch[128 + H + c];
             const float m1 = (float)(b1 / n), m2 = (float)(b2 / n);
             const float k1 = b.gamma * b.rstd;
             C[K1 * H + c] = k1;
@@ -68,6 +71,7 @@ __device__ __forceinline__ void fill_coefs(float *C /* [7][64] */, const BnDev &
             C[K3 * H + c] = k1 * (m2 * b.mean * b.rstd - m1);
         }
     }
+    __syncthreads();
 }
 
 __device__ __forceinline__ F4 fma4(F4 a, F4 b, F4 c)
@@ -206,15 +210,14 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_c_kernel(BwdCArgs a)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
-    __shared__ float part[16 * 2 * H];
+    __shared__ __attribute__((aligned(16))) float part[16 * 2 * H];      // (also the fp64 scratch of fill_coefs)
     __shared__ float Cb[kCoefRows * H], Cc[kCoefRows * H];
     __shared__ int prow[32];
     __shared__ int rpl[kTile + 1];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
     const int N = a.node_off[a.B];
-    fill_coefs(Cb, a.bnb, nullptr, (double)N, a.eps);
-    fill_coefs(Cc, a.bnc, nullptr, (double)N, a.eps);
-    __syncthreads();
+    fill_coefs(Cb, a.bnb, nullptr, (double)N, a.eps, (double *)part);
+    fill_coefs(Cc, a.bnc, nullptr, (double)N, a.eps, (double *)part);
     const F4 pbs = ld4(&Cb[PS * H + 4 * t]), pbh = ld4(&Cb[PH * H + 4 * t]);
     const F4 rcs = ld4(&Cc[RS * H + 4 * t]), rcm = ld4(&Cc[RM * H + 4 * t]);
     const F4 pcs = ld4(&Cc[PS * H + 4 * t]), pch = ld4(&Cc[PH * H + 4 * t]);
@@ -263,13 +266,12 @@ struct BwdBArgs {
 __global__ __launch_bounds__(kThreads) void gin_bwd_b_kernel(BwdBArgs a)
 {
     TRAIN_STEP_WAVE_PRIORITY();
-    __shared__ float part[16 * 2 * H];
+    __shared__ __attribute__((aligned(16))) float part[16 * 2 * H];      // (also the fp64 scratch of fill_coefs)
     __shared__ float Cb[kCoefRows * H], Cc[kCoefRows * H];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
     const int N = a.node_off[a.B];
-    fill_coefs(Cb, a.bnb, nullptr, (double)N, a.eps);
-    fill_coefs(Cc, a.bnc, a.bst_c, (double)N, a.eps);
-    __syncthreads();
+    fill_coefs(Cb, a.bnb, nullptr, (double)N, a.eps, (double *)part);
+    fill_coefs(Cc, a.bnc, a.bst_c, (double)N, a.eps, (double *)part);
     const F4 pbs = ld4(&Cb[PS * H + 4 * t]), pbh = ld4(&Cb[PH * H + 4 * t]);
     const F4 rbs = ld4(&Cb[RS * H + 4 * t]), rbm = ld4(&Cb[RM * H + 4 * t]);
     const F4 k1 = ld4(&Cc[K1 * H + 4 * t]), k2 = ld4(&Cc[K2 * H + 4 * t]), k3 = ld4(&Cc[K3 * H + 4 * t]);
@@ -318,45 +320,49 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_lin_kernel(BwdLinArgs a)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float Ci[kCoefRows * H], Co[kCoefRows * H];
-    __shared__ float red[4 * 3 * H];
+    __shared__ __attribute__((aligned(16))) float red[4 * 3 * H];        // (also the fp64 scratch of fill_coefs)
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
+    __shared__ float Wt[H * kLdt];                 // W transposed, staged once per workgroup (every wave fetched all 16
+                                                   // fragments as 64 strided 4-byte loads per lane before)
+    const WStage wst = stage_weights_request(a.W, a.kdim);      // in flight with N and the statistics
     const int N = a.node_off[a.B];
-    fill_coefs(Ci, a.bn_in, a.bst_in, (double)N, a.eps);
-    if (kMask) fill_coefs(Co, a.bn_out, nullptr, (double)N, a.eps);
+    fill_coefs(Ci, a.bn_in, a.bst_in, (double)N, a.eps, (double *)red);
+    if (kMask) fill_coefs(Co, a.bn_out, nullptr, (double)N, a.eps, (double *)red);
+    stage_weights_store_t(Wt, wst);
     __syncthreads();
     float *myred = &red[wv * 3 * H];
     for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
         const int row = tile0 + 16 * wv + j;
         const bool valid = row < N;
+        // every load of the tile is issued before the first use: unconditional (a lane past the end reads row 0, which exists
+        // when the loop runs at all), because loads under per-block `if (valid)` branches came out as one round trip each
+        const int64_t rbase = (int64_t)(valid ? row : 0) * H;
+        F4 gq[4], zq[4], zo[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            gq[c] = ld4(a.gin + rbase + 16 * c + 4 * q);
+            zq[c] = ld4(a.zin + rbase + 16 * c + 4 * q);
+            zo[c] = kMask ? ld4(a.zout + rbase + 16 * c + 4 * q) : zero4();
+        }
         F4 xb[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int col = 16 * c + 4 * q;
             F4 d = zero4();
             if (valid) {
-                const F4 g = ld4(a.gin + (int64_t)row * H + col), z = ld4(a.zin + (int64_t)row * H + col);
-                d = fma4(g, ld4(&Ci[K1 * H + col]), fma4(z, ld4(&Ci[K2 * H + col]), ld4(&Ci[K3 * H + col])));
+                d = fma4(gq[c], ld4(&Ci[K1 * H + col]), fma4(zq[c], ld4(&Ci[K2 * H + col]), ld4(&Ci[K3 * H + col])));
                 st4(a.dz + (int64_t)row * H + col, d);
             }
             xb[c] = d;
             const float bx = sum_rows16(d.x), by = sum_rows16(d.y), bz = sum_rows16(d.z), bw = sum_rows16(d.w);
             if (j == 15) { myred[2 * H + col] = bx; myred[2 * H + col + 1] = by; myred[2 * H + col + 2] = bz; myred[2 * H + col + 3] = bw; }
         }
-#pragma unroll 1
-        for (int cb = 0; cb < 4; ++cb) {               // one 16-channel block at a time: 4 weight fragments live
-            const int col = 16 * cb + 4 * q;
-            F4 wf[4];
-            {
-                const int orow = 16 * cb + j;          // output index = input column of W
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int k0 = 16 * c + 4 * q;     // reduction index = output row of W
-                    wf[c].x = orow < a.kdim ? a.W[(int64_t)(k0 + 0) * a.kdim + orow] : 0.f;
-                    wf[c].y = orow < a.kdim ? a.W[(int64_t)(k0 + 1) * a.kdim + orow] : 0.f;
-                    wf[c].z = orow < a.kdim ? a.W[(int64_t)(k0 + 2) * a.kdim + orow] : 0.f;
-                    wf[c].w = orow < a.kdim ? a.W[(int64_t)(k0 + 3) * a.kdim + orow] : 0.f;
-                }
-            }
+        for (int cb = 0; cb < 4; ++cb) {               // one 16-channel block at a time
+            const int col = 16 * cb + 4 * q;
+            F4 wf[4];                                  // output index = input column of W, reduction index = output row of W
+#pragma unroll
+            for (int c = 0; c < 4; ++c) wf[c] = ld4(&Wt[(16 * cb + j) * kLdt + 16 * c + 4 * q]);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -367,8 +373,7 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_lin_kernel(BwdLinArgs a)
             }
             F4 o = {acc[0], acc[1], acc[2], acc[3]};
             if (kMask) {
-                F4 z = zero4();
-                if (valid) z = ld4(a.zout + (int64_t)row * H + col);
+                const F4 z = zo[cb];
                 o = valid ? mask4(o, fma4(z, ld4(&Co[PS * H + col]), ld4(&Co[PH * H + col]))) : zero4();
                 const F4 xh = fma4(z, ld4(&Co[RS * H + col]), ld4(&Co[RM * H + col]));
                 const float s0 = sum_rows16(o.x), s1 = sum_rows16(o.y), s2 = sum_rows16(o.z), s3 = sum_rows16(o.w);
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_lin_kernel(BwdLinArgs a)
 // Many nodes share a (small) degree, so global atomics would serialise on a few cache lines:
 // each block accumulates into an LDS table (column c is owned by thread c: no atomics, fixed order)
 // and writes its table as one partial; the final kernel sums the kEmbBlocks partials.
-constexpr int kEmbBlocks = 256;
+constexpr int kEmbBlocks = 448;      // one 64-row tile per workgroup at bsz 256 (~390 tiles of the query view); 2 workgroups of 67 KiB fit a CU
 constexpr int kEmbMaxElems = 10240;      // (max_degree + 1) * deg_emb_dim floats of LDS (40 KiB)
 
 struct EmbArgs {
@@ -626,7 +631,14 @@ __global__ __launch_bounds__(kThreads) void gin_grad_final_kernel(FinalArgs a)
         const int64_t r = gid - base;
         const int c = (int)(r % H), slot = (int)((r / H) % 3), which = (int)((r / (3 * H)) % 3), l = (int)(r / (9 * H));
         double acc = 0.0;
-        for (int rep = 0; rep < kRep; ++rep) acc += a.bst[(((int64_t)l * 3 + which) * kRep + rep) * 3 * H + slot * H + c];
+        const double *src = a.bst + ((int64_t)l * 3 + which) * kRep * 3 * H + slot * H + c;
+#pragma unroll
+        for (int rep = 0; rep < kRep; rep += 8) {          // batches of 8 independent loads (see replica_sums128)
+            double v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v8[u] = src[(int64_t)(rep + u) * 3 * H];
+            acc += ((v8[0] + v8[1]) + (v8[2] + v8[3])) + ((v8[4] + v8[5]) + (v8[6] + v8[7]));
+        }
         const float v = (float)acc;
         float *dst = nullptr;
         if (which == 0) dst = slot == 0 ? a.g.bn_a_b[l] : slot == 1 ? a.g.bn_a_w[l] : a.g.lin0_b[l];
@@ -640,8 +652,12 @@ __global__ __launch_bounds__(kThreads) void gin_grad_final_kernel(FinalArgs a)
     const int64_t n5 = (int64_t)a.emb_rows * a.emb_dim;
     if (gid < base + n5) {
         const int64_t r = gid - base;
-        float sum = 0.f;
-        for (int k = 0; k < kEmbBlocks; ++k) sum += a.demb_parts[(int64_t)k * n5 + r];
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // 8 chains of loads in flight; a fixed order all the same
+        static_assert(kEmbBlocks % 8 == 0, "partials are summed in 8 interleaved chains");
+        for (int k = 0; k < kEmbBlocks; k += 8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part[u] += a.demb_parts[(int64_t)(k + u) * n5 + r];
+        const float sum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
         if (a.g.degree_embedding) put(a.g.degree_embedding + r, sum, a.accumulate);
     }
 }

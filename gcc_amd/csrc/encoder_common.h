@@ -50,20 +50,36 @@ struct BnDev {
     const double *totals;   // [2][64] the replicas added up by the producing kernel's last workgroup, or NULL
 };
 
-// BatchNorm1d as y = x * scale + shift for channel c.  training: biased batch variance
-// (gin.py:56,115,219 -> torch.nn.functional.batch_norm); eval: running statistics.
-__device__ __forceinline__ void bn_scale_shift(const BnDev &bn, int c, double n, float eps, int training,
-                                               float &scale, float &shift)
+// ---- column sums over the kRep replicas of an accumulator.  Pair p < 128 = (slot p >> 6, channel p & 63) of replica r
+// lives at rep[r * stride + p] (forward statistics: stride 2 * 64; backward sums: stride 3 * 64, slots 0 and 1).
+// ALL kThreads threads call it (block-uniform): thread t adds the replicas of half t >> 7 for pair t & 127 as batches of 8
+// independent loads.  (The obvious per-channel loop came out of the compiler as load - wait - add, 64 DEPENDENT L2 round
+// trips in the prologue of every kernel of the chain: 10-25 us each, profiles/r3_replica_sum_isa.txt.)  After the trailing
+// barrier: total(p) = sums[p] + sums[128 + p].
+__device__ __forceinline__ void replica_sums128(const double *rep, int stride, double *sums /* LDS [256] */)
+{
+    static_assert(kThreads == 256 && kRep % 16 == 0, "two halves of the replicas, batches of 8");
+    const int t = (int)threadIdx.x, p = t & 127, g = t >> 7;
+    const double *src = rep + (int64_t)(g * (kRep / 2)) * stride + p;
+    double acc = 0.0;
+#pragma unroll
+    for (int b = 0; b < kRep / 2; b += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + u) * stride];
+        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    sums[t] = acc;
+    __syncthreads();
+}
+
+// BatchNorm1d as y = x * scale + shift for channel c from the column sum s1 and sum of squares s2.  training: biased batch
+// variance (gin.py:56,115,219 -> torch.nn.functional.batch_norm); eval: running statistics.
+__device__ __forceinline__ void bn_scale_shift_from(const BnDev &bn, int c, double s1, double s2, double n, float eps, int training,
+                                                    float &scale, float &shift)
 {
     double mean, var;
     if (training) {
-        double s1 = 0.0, s2 = 0.0;
-        if (bn.totals) {
-            s1 = bn.totals[c];
-            s2 = bn.totals[H + c];
-        } else {
-            for (int r = 0; r < kRep; ++r) { s1 += bn.stats[r * 2 * H + c]; s2 += bn.stats[r * 2 * H + H + c]; }
-        }
         mean = s1 / n;
         var = s2 / n - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -75,12 +91,41 @@ __device__ __forceinline__ void bn_scale_shift(const BnDev &bn, int c, double n,
     scale = (float)((double)bn.weight[c] * rstd);
     shift = (float)((double)bn.bias[c] - mean * (double)bn.weight[c] * rstd);
 }
-
-// scale/shift of all 64 channels into an LDS table tab[2][64]; called by threads [t0, t0 + 64)
-__device__ __forceinline__ void bn_table(float *tab, const BnDev &bn, int t0, double n, float eps, int training)
+// one thread, one channel (callers outside the chain of big kernels; with totals this is 2 loads)
+__device__ __forceinline__ void bn_scale_shift(const BnDev &bn, int c, double n, float eps, int training,
+                                               float &scale, float &shift)
 {
-    const int c = (int)threadIdx.x - t0;
-    if (c >= 0 && c < H) bn_scale_shift(bn, c, n, eps, training, tab[c], tab[H + c]);
+    double s1 = 0.0, s2 = 0.0;
+    if (training) {
+        if (bn.totals) {
+            s1 = bn.totals[c];
+            s2 = bn.totals[H + c];
+        } else {
+            for (int r = 0; r < kRep; ++r) { s1 += bn.stats[r * 2 * H + c]; s2 += bn.stats[r * 2 * H + H + c]; }
+        }
+    }
+    bn_scale_shift_from(bn, c, s1, s2, n, eps, training, scale, shift);
+}
+
+// scale/shift of all 64 channels into an LDS table tab[2][64].  ALL threads call it (block-uniform); scratch = LDS
+// [256] doubles that nothing else uses during the call; ends with a barrier (tab is valid, scratch is free again).
+__device__ __forceinline__ void bn_table(float *tab, const BnDev &bn, double n, float eps, int training, double *scratch)
+{
+    const bool reps = training && !bn.totals;        // block-uniform
+    if (reps) replica_sums128(bn.stats, 2 * H, scratch);
+    const int c = (int)threadIdx.x;
+    if (c < H) {
+        double s1 = 0.0, s2 = 0.0;
+        if (reps) {
+            s1 = scratch[c] + scratch[128 + c];
+            s2 = scratch[H + c] + scratch[128 + H + c];
+        } else if (training) {
+            s1 = bn.totals[c];
+            s2 = bn.totals[H + c];
+        }
+        bn_scale_shift_from(bn, c, s1, s2, n, eps, training, tab[c], tab[H + c]);
+    }
+    __syncthreads();
 }
 __device__ __forceinline__ Aff4 aff4_from_table(const float *tab, int c0)
 {
@@ -251,6 +296,72 @@ __device__ __forceinline__ void linear_rows16_store_stats(const F4 xb[4], const 
             a = mfma_16x16x4_f32(wf[c].y, xb[c].y, a);
             a = mfma_16x16x4_f32(wf[c].z, xb[c].z, a);
             a = mfma_16x16x4_f32(wf[c].w, xb[c].w, a);
+        }
+        epilogue_block(cb, a, bias, Z, row, valid, red);
+    }
+}
+
+// ---- the same product with the weight matrix staged in LDS by the whole workgroup (one coalesced request, issued as
+// early as the kernel can, instead of every wave fetching all 16 fragments from L2 block by block): Wl[64][kLdt],
+// columns >= kdim zero.  stage_weights_request() returns the thread's 4 x 16 bytes, stage_weights_store() parks them.
+struct WStage { F4 v[4]; };
+__device__ __forceinline__ WStage stage_weights_request(const float *W, int kdim)
+{
+    WStage st;
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * kThreads, r = idx >> 4, c4 = 4 * (idx & 15);       // row r, columns c4 .. c4 + 3
+        const float *p = W + (int64_t)r * kdim + c4;
+        F4 x;
+        if ((kdim & 3) == 0 && c4 + 3 < kdim) {
+            x = ld4(p);
+        } else {
+            x.x = c4 + 0 < kdim ? p[0] : 0.f;
+            x.y = c4 + 1 < kdim ? p[1] : 0.f;
+            x.z = c4 + 2 < kdim ? p[2] : 0.f;
+            x.w = c4 + 3 < kdim ? p[3] : 0.f;
+        }
+        st.v[i] = x;
+    }
+    return st;
+}
+__device__ __forceinline__ void stage_weights_store(float *Wl, const WStage &st)
+{
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * kThreads, r = idx >> 4, c4 = 4 * (idx & 15);
+        st4(&Wl[r * kLdt + c4], st.v[i]);
+    }
+}
+// transposed: Wt[c][r] = W[r][c] (the backward product dx = dz W reduces over W's rows)
+__device__ __forceinline__ void stage_weights_store_t(float *Wt, const WStage &st)
+{
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * kThreads, r = idx >> 4, c4 = 4 * (idx & 15);
+        Wt[(c4 + 0) * kLdt + r] = st.v[i].x;
+        Wt[(c4 + 1) * kLdt + r] = st.v[i].y;
+        Wt[(c4 + 2) * kLdt + r] = st.v[i].z;
+        Wt[(c4 + 3) * kLdt + r] = st.v[i].w;
+    }
+}
+__device__ __forceinline__ void linear_rows16_lds_store_stats(const F4 xb[4], const float *Wl, const float *bias,
+                                                              float *Z, int row, bool valid, float *red)
+{
+    const int lane = lane_id(), j = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const F4 wf = ld4(&Wl[(16 * cb + j) * kLdt + 16 * c + 4 * q]);
+            a = mfma_16x16x4_f32(wf.x, xb[c].x, a);
+            a = mfma_16x16x4_f32(wf.y, xb[c].y, a);
+            a = mfma_16x16x4_f32(wf.z, xb[c].z, a);
+            a = mfma_16x16x4_f32(wf.w, xb[c].w, a);
         }
         epilogue_block(cb, a, bias, Z, row, valid, red);
     }
