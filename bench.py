@@ -61,7 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--posemb", choices=["device", "placeholder"], default="device")
-    ap.add_argument("--lanes", type=int, default=3, help="producer streams (sampler + positional embedding)")
+    ap.add_argument("--lanes", type=int, default=2, help="producer streams (sampler + positional embedding)")
     ap.add_argument("--reserved-cus", type=int, default=0, help="compute units the producer streams are masked off (kept for the training step)")
     ap.add_argument("--cu-layout", default="interleaved", choices=["interleaved", "block"])
     ap.add_argument("--chunk", type=int, default=16, help="most steps a producer lane prepares per turn (one multi-view eigensolver call); "

@@ -95,6 +95,9 @@ struct InArgs {
     float eps, nbr_weight;    // nbr_weight: edge multiplicity
 };
 struct InLaunch { InArgs p[kMaxPass]; long long *ticks; };
+#ifndef GIN_IN_LDS_W
+#define GIN_IN_LDS_W 1       // linears.0's weight through LDS (+18 KiB per workgroup)
+#endif
 #ifndef GIN_DBG_SKIP
 #define GIN_DBG_SKIP 0       // timing experiments only (wrong results): 1 no pooling, 2 no statistics flush, 4 no gather
 #endif
@@ -114,16 +117,22 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
     const int N = a.node_off[a.B];
     const double dn = (double)N;
     __shared__ float tabb[2 * H], tabc[2 * H];
+#if GIN_IN_LDS_W
     __shared__ float Wl[H * kLdt];                 // linears.0 weight, staged once per workgroup
+#endif
     Aff4 ab, ac;
     long long tick_ = L.ticks ? device_ticks() : 0;
     {
+#if GIN_IN_LDS_W
         const WStage wst = stage_weights_request(a.w0, a.kdim);     // in flight with N and the statistics
+#endif
         if (!a.first) {                            // block-uniform
             bn_table(tabb, a.bnb, dn, a.eps, a.training, (double *)part);
             bn_table(tabc, a.bnc, dn, a.eps, a.training, (double *)part);
         }
+#if GIN_IN_LDS_W
         stage_weights_store(Wl, wst);
+#endif
     }
     __syncthreads();
     if (!a.first) {
@@ -171,7 +180,11 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
             F4 xb[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) xb[c] = ld4(&T[rl * kLdt + 16 * c + 4 * q]);
+#if GIN_IN_LDS_W
             linear_rows16_lds_store_stats(xb, Wl, a.b0, a.z1, tile0 + rl, rl < nrows, &red[wv * 2 * H]);
+#else
+            linear_rows16_store_stats(xb, a.w0, a.kdim, a.b0, a.z1, tile0 + rl, rl < nrows, &red[wv * 2 * H]);
+#endif
         }
         __syncthreads();
         GIN_TICK(5);

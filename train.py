@@ -120,7 +120,7 @@ def parse_option(argv=None):
     parser.add_argument("--synthetic", type=str, default=None, help="V,E of a synthetic power-law graph, e.g. 1000000,10000000")
     parser.add_argument("--nce-dtype", type=str, default="f32", choices=["f32", "bf16"], help="operands of the MoCo head: f32 = exact (1e-3 parity with the reference), bf16 = matrix-core throughput mode")
     parser.add_argument("--max-steps", type=int, default=0, help="stop after this many steps (0 = full schedule)")
-    parser.add_argument("--producer-lanes", type=int, default=3, help="data-pipeline streams (the GPU's command processor serves few queues well)")
+    parser.add_argument("--producer-lanes", type=int, default=2, help="data-pipeline streams (the GPU's command processor serves few queues well)")
     parser.add_argument("--producer-chunk", type=int, default=4, help="steps a lane prepares per turn (2x as many views per eigensolver call, <= 32)")
     # fmt: on
 
