@@ -130,7 +130,8 @@ class GccNceArgs(ctypes.Structure):
 
 
 class GccGinwLayer(ctypes.Structure):
-    _fields_ = [("w0", _VP), ("w1", _VP), ("s0", _VP), ("t0", _VP), ("s1", _VP), ("t1", _VP), ("s2", _VP), ("t2", _VP)]
+    _fields_ = [("w0", _VP), ("w1", _VP), ("s0", _VP), ("t0", _VP), ("s1", _VP), ("t1", _VP), ("s2", _VP), ("t2", _VP),
+                ("w0_frag", _VP), ("w1_frag", _VP)]
 
 
 class GccGinwArgs(ctypes.Structure):
@@ -181,6 +182,7 @@ SIGNATURES = {
                                           ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_ginw_forward": (ctypes.c_int32, [ctypes.POINTER(GccGinwArgs), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_ginw_pack_weights": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
     "gcc_nce_workspace_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32]),
     "gcc_nce_forward": (ctypes.c_int32, [ctypes.POINTER(GccNceArgs), ctypes.c_void_p, ctypes.c_int64,
                                          ctypes.c_void_p, ctypes.c_void_p]),

@@ -369,3 +369,27 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float x)
     return u >> 16;
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+// acc + both bf16 halves of a word (v_dot2c_f32_bf16 with a pair of ones on gfx950: 1 instruction instead of 4)
+__device__ __forceinline__ float add2_bf16(uint32_t pk, float acc)
+{
+#ifdef GCC_AMD_HIPEMU
+    return acc + (bf16_bits_to_f32(pk & 0xFFFFu) + bf16_bits_to_f32(pk >> 16));
+#else
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk), __builtin_bit_cast(bf16x2_t, 0x3F803F80u), acc, false);
+#endif
+}
+// two floats -> two bf16 in one word (a in the low half), round to nearest even: one v_cvt_pk_bf16_f32 on gfx950 (the
+// integer formula above is ~5 VALU instructions per value, which made the epilogues of the bf16 GIN products as long as
+// their matrix instructions)
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b)
+{
+#ifdef GCC_AMD_HIPEMU
+    return f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16);
+#else
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+#endif
+}

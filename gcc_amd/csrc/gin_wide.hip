@@ -14,6 +14,8 @@
 // The two LDS regions swap roles: H^T -> AGG in the other -> Z1 over H^T -> H'^T over AGG.
 #include "host_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int kD = GCC_GINW_HIDDEN;
@@ -54,8 +56,8 @@ __device__ __forceinline__ u32x4 lds16(const unsigned char *p) { return *(const 
 __device__ __forceinline__ u32x2 pack4_bf16(float a, float b, float c, float d)
 {
     u32x2 r;
-    r[0] = f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16);
-    r[1] = f32_to_bf16_bits(c) | (f32_to_bf16_bits(d) << 16);
+    r[0] = pack2_bf16(a, b);
+    r[1] = pack2_bf16(c, d);
     return r;
 }
 __device__ __forceinline__ float sum4_bf16(u32x2 v)
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void gin_wide_kernel(WideArgs a)
                 u32x4 f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    f[q] = f32_to_bf16_bits((float)(c[q] & 0xFFFFu)) | (f32_to_bf16_bits((float)(c[q] >> 16)) << 16);
+                    f[q] = pack2_bf16((float)(c[q] & 0xFFFFu), (float)(c[q] >> 16));
                 adj[nb][ks] = f;
             }
         __syncthreads();
@@ -398,9 +400,368 @@ __global__ __launch_bounds__(kThreads) void gin_wide_kernel(WideArgs a)
     }
 }
 
+// =====================================================================================================================
+// Second kernel shape (default): 256 threads = ONE wave per SIMD with up to 512 registers each, so that a wave's register
+// tile is 64 channels x 128 nodes (Linear products) or 128 channels x 64 nodes (aggregation): every operand fragment read
+// from LDS feeds FOUR matrix instructions (two in the first kernel, whose products were bound by fragment reads), the
+// weight fragments stream through a 4-deep register ring straight from L2 (each read once per workgroup, requested four
+// k-steps = ~2000 cycles ahead across product boundaries), the adjacency is 16 fragments in registers for all layers, and
+// results are stored 16 bytes per lane: the rows of two adjacent A fragments are interleaved in blocks of 4
+// (row r of fragment e <-> index 8 (r >> 2) + 4 e + (r & 3) of a 32-block), so a lane's 4 + 4 accumulator rows are 8
+// consecutive channels (or nodes).  Rows are padded by 32 bytes (conflict-free 16-byte fragment reads, r1_lds_probe).
+constexpr int kT2 = 256;
+constexpr int kStrT2 = kNodes * 2 + 32;      // channel-major [256 ch][128 nodes]
+constexpr int kStrN2 = kD * 2 + 32;          // node-major    [128 nodes][256 ch]
+constexpr int kReg2 = kD * kStrT2;           // 73,728 B >= kNodes * kStrN2
+constexpr int kLds2 = 2 * kReg2 + (kNodes + 1 + 3) / 4 * 16;
+static_assert(kNodes * kStrN2 <= kReg2, "node-major layout must fit a region");
+
+__device__ __forceinline__ int perm8(int lr, int e) { return 8 * (lr >> 2) + 4 * e + (lr & 3); }
+__device__ __forceinline__ u32x4 pack8_bf16(const f32x4 &a, const f32x4 &b)
+{
+    u32x4 r;
+    r[0] = pack2_bf16(a[0], a[1]);
+    r[1] = pack2_bf16(a[2], a[3]);
+    r[2] = pack2_bf16(b[0], b[1]);
+    r[3] = pack2_bf16(b[2], b[3]);
+    return r;
+}
+__device__ __forceinline__ float sum8_bf16(u32x4 v, float s = 0.f)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s = add2_bf16(v[q], s);
+    return s;
+}
+// the 4 weight fragments of one k-step of a wave's 64 output channels.  kRowPerm: the fragments are A operands whose rows
+// are interleaved in pairs (first Linear); else B operands, column lr = channel 16 m + lr (second Linear)
+// kFrag: wmat is the fragment-major copy made by gcc_ginw_pack_weights (1 KiB contiguous per request)
+template <bool kRowPerm, bool kFrag>
+__device__ __forceinline__ void request_w(u32x4 (&dst)[4], const uint16_t *wmat, int w, int ks, int lr, int lg)
+{
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        if (kFrag) {
+            dst[m] = *(const u32x4 *)(wmat + (int64_t)((w * 4 + m) * 8 + ks) * 512 + (lg * 16 + lr) * 8);
+        } else {
+            const int ch = w * 64 + (kRowPerm ? (m >> 1) * 32 + perm8(lr, m & 1) : m * 16 + lr);
+            dst[m] = *(const u32x4 *)(wmat + (int64_t)ch * kD + ks * 32 + lg * 8);
+        }
+    }
+}
+
+__global__ void ginw_pack_kernel(const uint16_t *w, uint16_t *wf, int which)
+{
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);      // one 16-byte piece: ((w * 4 + m) * 8 + ks) * 64 + lane
+    if (idx >= kD * kD / 8) return;
+    const int lane = idx & 63, ks = (idx >> 6) & 7, m = (idx >> 9) & 3, wb = idx >> 11, lr = lane & 15, lg = lane >> 4;
+    const int row = wb * 64 + (which == 0 ? (m >> 1) * 32 + perm8(lr, m & 1) : m * 16 + lr);
+    *(u32x4 *)(wf + (int64_t)idx * 8) = *(const u32x4 *)(w + (int64_t)row * kD + ks * 32 + lg * 8);
+}
+
+// kDbg (timing experiments only, wrong results; GCC_GINW_DBG): 1 no epilogue arithmetic (one store per product keeps the
+// accumulators alive), 2 no weight requests inside the products, 4 no operand-fragment reads inside the k loops
+// (measured: epilogues 25 % of the launch, requests 15 % row-major / 2 % fragment-major, fragment reads 2 %).
+template <int kDbg, bool kFrag>
+__global__ __launch_bounds__(kT2) void gin_wide2_kernel(WideArgs a)
+{
+    DYN_SMEM(smem);
+    unsigned char *P = smem, *Q = smem + kReg2;
+    int32_t *rp = (int32_t *)(smem + 2 * kReg2);             // [129] row pointers of the subgraph
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int L = a.num_layers;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int nh = w & 1, chh = w >> 1;                      // aggregation: node half x channel half
+
+    for (int b = blockIdx.x; b < a.batch_size; b += gridDim.x) {
+        __syncthreads();                                     // the previous subgraph's output pass is done with P
+        long long tick = a.ticks ? device_ticks() : 0;
+        const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+        if (n <= 0 || n > kNodes) {                          // (uniform over the workgroup)
+            if (n > kNodes) {
+                if (tid == 0) atomicOr(a.status, (int32_t)GCC_STATUS_GINW_TOO_LARGE);
+                if (a.x_out)
+                    for (int64_t i = tid; i < (int64_t)n * (kD / 2); i += kT2) ((uint32_t *)(a.x_out + (int64_t)n0 * kD))[i] = 0u;
+            }
+            if (a.pooled)
+                for (int i = tid; i < (L + 1) * kD; i += kT2) a.pooled[(int64_t)b * (L + 1) * kD + i] = 0.f;
+            continue;
+        }
+        // ---- the subgraph's input rows -> P, channel-major; neighbour counts -> Q (16-bit counters, [node][u])
+        for (int i = tid; i < kNodes * kStrT2 / 4; i += kT2) ((uint32_t *)Q)[i] = 0u;
+        if (tid <= n) rp[tid] = a.row_ptr[n0 + tid];
+        for (int idx = tid; idx < kNodes * (kD / 8); idx += kT2) {
+            const int node = idx & (kNodes - 1), chunk = idx >> 7;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (node < n) v = *(const u32x4 *)(a.x_in + (int64_t)(n0 + node) * kD + chunk * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                *(uint16_t *)(P + (chunk * 8 + e) * kStrT2 + node * 2) = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
+        }
+        __syncthreads();
+        phase_tick(a.ticks, 0, tick);                        // rows in
+        {
+            const int e0 = rp[0], e1 = rp[n];
+            for (int e = e0 + tid; e < e1; e += kT2) {
+                const int u = a.col_idx[e] - n0;
+                int lo = 0, hi = n;                          // largest i with rp[i] <= e
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (rp[mid] <= e) lo = mid; else hi = mid;
+                }
+                if ((unsigned)u < (unsigned)n) atomicAdd((uint32_t *)(Q + lo * kStrT2 + (u >> 1) * 4), (u & 1) ? 0x10000u : 1u);
+                else atomicOr(a.status, (int32_t)GCC_STATUS_GINW_BAD_EDGE);
+            }
+            if (tid < n) atomicAdd((uint32_t *)(Q + tid * kStrT2 + (tid >> 1) * 4), (tid & 1) ? 0x10000u : 1u);   // + h_v itself
+        }
+        __syncthreads();
+        phase_tick(a.ticks, 1, tick);                        // neighbour counts
+        if (a.pooled) {                                      // hidden_rep[0] = the input (gin.py:216)
+            float s = 0.f;
+            for (int j = 0; j < kNodes / 8; ++j) s += sum8_bf16(lds16(P + tid * kStrT2 + j * 16));
+            a.pooled[((int64_t)b * (L + 1)) * kD + tid] = s;
+        }
+        // this wave's share of ADJ (64 nodes x all neighbours) as B fragments, kept in registers for every layer
+        u32x4 adj[4][4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 c = lds16(Q + (nh * 64 + nf * 16 + lr) * kStrT2 + (ks * 32 + lg * 8) * 2);
+                u32x4 f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    f[q] = pack2_bf16((float)(c[q] & 0xFFFFu), (float)(c[q] >> 16));
+                adj[nf][ks] = f;
+            }
+        u32x4 wr[4][4];                                      // weight ring: slot = k-step & 3
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) request_w<true, kFrag>(wr[ks], kFrag ? a.layers[0].w0_frag : a.layers[0].w0, w, ks, lr, lg);
+        __syncthreads();
+        phase_tick(a.ticks, 2, tick);                        // input pooling, adjacency fragments
+
+        for (int layer = 0; layer < L; ++layer) {
+            const gcc_ginw_layer ly = a.layers[layer];
+            // ---- AGG[node][ch] = sum_u H^T[ch][u] ADJ[node][u] -> Q (node-major): 128 channels x 64 nodes per wave
+            {
+                f32x4 acc[8][4];
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf) acc[m][nf] = zero4;
+                const unsigned char *src = P + (chh * 128) * kStrT2 + lg * 16;
+                u32x4 buf[2][8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) buf[0][m] = lds16(src + ((m >> 1) * 32 + perm8(lr, m & 1)) * kStrT2);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks + 1 < 4 && !(kDbg & 4)) {
+#pragma unroll
+                        for (int m = 0; m < 8; ++m)
+                            buf[(ks + 1) & 1][m] = lds16(src + ((m >> 1) * 32 + perm8(lr, m & 1)) * kStrT2 + (ks + 1) * 64);
+                    }
+                    SCHED_FENCE();
+#pragma unroll
+                    for (int m = 0; m < 8; ++m)
+#pragma unroll
+                        for (int nf = 0; nf < 4; ++nf) acc[m][nf] = mfma_16x16x32_bf16(buf[(kDbg & 4) ? 0 : (ks & 1)][m], adj[nf][ks], acc[m][nf]);
+                    SCHED_FENCE();
+                }
+                if (kDbg & 1) {
+                    f32x4 t4 = zero4;
+#pragma unroll
+                    for (int m = 0; m < 8; ++m)
+#pragma unroll
+                        for (int nf = 0; nf < 4; ++nf) t4 += acc[m][nf];
+                    *(u32x4 *)(Q + (nh * 64 + lr) * kStrN2 + (chh * 128 + lg * 8) * 2) = pack8_bf16(t4, t4);
+                } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf)
+                        *(u32x4 *)(Q + (nh * 64 + nf * 16 + lr) * kStrN2 + (chh * 128 + p * 32 + lg * 8) * 2) =
+                            pack8_bf16(acc[2 * p][nf], acc[2 * p + 1][nf]);
+                }
+            }
+            lds_barrier();
+            phase_tick(a.ticks, 3, tick);                    // aggregation
+            // ---- Z1[node][ch] = relu(s0 * (AGG W0^T) + t0) -> P (node-major): channels 64 w .. 64 w + 63, all nodes
+            {
+                f32x4 acc[4][8];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int nf = 0; nf < 8; ++nf) acc[m][nf] = zero4;
+                float4 sc[2][2], sh[2][2];                   // scale / shift of the lane's 8 channels per fragment pair
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        sc[p][e] = *(const float4 *)(ly.s0 + w * 64 + p * 32 + lg * 8 + e * 4);
+                        sh[p][e] = *(const float4 *)(ly.t0 + w * 64 + p * 32 + lg * 8 + e * 4);
+                    }
+                const unsigned char *src = Q + lr * kStrN2 + lg * 16;
+                u32x4 buf[2][8];
+#pragma unroll
+                for (int nf = 0; nf < 8; ++nf) buf[0][nf] = lds16(src + nf * 16 * kStrN2);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    if (ks + 1 < 8 && !(kDbg & 4)) {
+#pragma unroll
+                        for (int nf = 0; nf < 8; ++nf) buf[(ks + 1) & 1][nf] = lds16(src + nf * 16 * kStrN2 + (ks + 1) * 64);
+                    }
+                    SCHED_FENCE();
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int nf = 0; nf < 8; ++nf) acc[m][nf] = mfma_16x16x32_bf16(wr[ks & 3][m], buf[(kDbg & 4) ? 0 : (ks & 1)][nf], acc[m][nf]);
+                    SCHED_FENCE();
+                    if (!(kDbg & 2)) {
+                        if (ks < 4) request_w<true, kFrag>(wr[ks & 3], kFrag ? ly.w0_frag : ly.w0, w, ks + 4, lr, lg);
+                        else request_w<false, kFrag>(wr[ks & 3], kFrag ? ly.w1_frag : ly.w1, w, ks - 4, lr, lg);
+                    }
+                    SCHED_FENCE();
+                }
+                if (kDbg & 1) {
+                    f32x4 t4 = zero4;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int nf = 0; nf < 8; ++nf) t4 += acc[m][nf];
+                    t4[0] += sc[0][0].x + sh[1][1].w;
+                    *(u32x4 *)(P + lr * kStrN2 + (w * 64 + lg * 8) * 2) = pack8_bf16(t4, t4);
+                } else {
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int nf = 0; nf < 8; ++nf) {
+                        f32x4 lo = acc[2 * p][nf], hi = acc[2 * p + 1][nf];
+                        lo[0] = fmaxf(fmaf(lo[0], sc[p][0].x, sh[p][0].x), 0.f); lo[1] = fmaxf(fmaf(lo[1], sc[p][0].y, sh[p][0].y), 0.f);
+                        lo[2] = fmaxf(fmaf(lo[2], sc[p][0].z, sh[p][0].z), 0.f); lo[3] = fmaxf(fmaf(lo[3], sc[p][0].w, sh[p][0].w), 0.f);
+                        hi[0] = fmaxf(fmaf(hi[0], sc[p][1].x, sh[p][1].x), 0.f); hi[1] = fmaxf(fmaf(hi[1], sc[p][1].y, sh[p][1].y), 0.f);
+                        hi[2] = fmaxf(fmaf(hi[2], sc[p][1].z, sh[p][1].z), 0.f); hi[3] = fmaxf(fmaf(hi[3], sc[p][1].w, sh[p][1].w), 0.f);
+                        *(u32x4 *)(P + (nf * 16 + lr) * kStrN2 + (w * 64 + p * 32 + lg * 8) * 2) = pack8_bf16(lo, hi);
+                    }
+                }
+            }
+            lds_barrier();
+            phase_tick(a.ticks, 4, tick);                    // first Linear
+            // ---- H'^T[ch][node] = relu(s2 * relu(s1 * (Z1 W1^T) + t1) + t2) -> Q (channel-major), nodes >= n as 0; SumPooling
+            {
+                // (after the last layer the requests are dummies: no branch around them)
+                const gcc_ginw_layer &lnext = a.layers[layer + 1 < L ? layer + 1 : layer];
+                const uint16_t *wnext = kFrag ? lnext.w0_frag : lnext.w0;
+                f32x4 acc[8][4];
+#pragma unroll
+                for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[nf][m] = zero4;
+                float s1[4], t1[4], s2[4], t2[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int c = w * 64 + m * 16 + lr;
+                    s1[m] = ly.s1[c]; t1[m] = ly.t1[c]; s2[m] = ly.s2[c]; t2[m] = ly.t2[c];
+                }
+                const unsigned char *src = P + lg * 16;
+                u32x4 buf[2][8];
+#pragma unroll
+                for (int nf = 0; nf < 8; ++nf) buf[0][nf] = lds16(src + ((nf >> 1) * 32 + perm8(lr, nf & 1)) * kStrN2);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    if (ks + 1 < 8 && !(kDbg & 4)) {
+#pragma unroll
+                        for (int nf = 0; nf < 8; ++nf)
+                            buf[(ks + 1) & 1][nf] = lds16(src + ((nf >> 1) * 32 + perm8(lr, nf & 1)) * kStrN2 + (ks + 1) * 64);
+                    }
+                    SCHED_FENCE();
+#pragma unroll
+                    for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) acc[nf][m] = mfma_16x16x32_bf16(buf[(kDbg & 4) ? 0 : (ks & 1)][nf], wr[ks & 3][m], acc[nf][m]);
+                    SCHED_FENCE();
+                    if (!(kDbg & 2)) {
+                        if (ks < 4) request_w<false, kFrag>(wr[ks & 3], kFrag ? ly.w1_frag : ly.w1, w, ks + 4, lr, lg);
+                        else request_w<true, kFrag>(wr[ks & 3], wnext, w, ks - 4, lr, lg);
+                    }
+                    SCHED_FENCE();
+                }
+                if (kDbg & 1) {
+                    f32x4 t4 = zero4;
+#pragma unroll
+                    for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) t4 += acc[nf][m];
+                    t4[0] += s1[0] + t1[1] + s2[2] + t2[3];
+                    *(u32x4 *)(Q + (w * 64 + lr) * kStrT2 + lg * 16) = pack8_bf16(t4, t4);
+                } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int c = w * 64 + m * 16 + lr;
+                    float psum = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int node = q * 32 + lg * 8;
+                        f32x4 lo = acc[2 * q][m], hi = acc[2 * q + 1][m];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float ylo = fmaxf(fmaf(lo[r], s1[m], t1[m]), 0.f), yhi = fmaxf(fmaf(hi[r], s1[m], t1[m]), 0.f);   // apply_func: relu(bn(mlp))
+                            lo[r] = fmaxf(fmaf(ylo, s2[m], t2[m]), 0.f);                               // relu(batch_norms[i](.))
+                            hi[r] = fmaxf(fmaf(yhi, s2[m], t2[m]), 0.f);
+                        }
+                        if (q * 32 + 32 > n) {               // (block-uniform) this 32-block holds padding nodes: they stay 0
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                lo[r] = node + r < n ? lo[r] : 0.f;
+                                hi[r] = node + 4 + r < n ? hi[r] : 0.f;
+                            }
+                        }
+                        const u32x4 hv = pack8_bf16(lo, hi);
+                        psum = sum8_bf16(hv, psum);
+                        *(u32x4 *)(Q + c * kStrT2 + node * 2) = hv;
+                    }
+                    psum += wave_shfl_xor(psum, 16);
+                    psum += wave_shfl_xor(psum, 32);
+                    if (lg == 0 && a.pooled) a.pooled[((int64_t)b * (L + 1) + layer + 1) * kD + c] = psum;
+                }
+                }
+            }
+            lds_barrier();
+            phase_tick(a.ticks, 5, tick);                    // second Linear
+            unsigned char *t = P; P = Q; Q = t;
+        }
+        // ---- the last layer's rows back to node-major global memory
+        if (a.x_out)
+            for (int idx = tid; idx < kNodes * (kD / 8); idx += kT2) {
+                const int node = idx & (kNodes - 1), chunk = idx >> 7;
+                if (node < n) {
+                    u32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        v[q] = (uint32_t)*(const uint16_t *)(P + (chunk * 8 + 2 * q) * kStrT2 + node * 2)
+                             | ((uint32_t)*(const uint16_t *)(P + (chunk * 8 + 2 * q + 1) * kStrT2 + node * 2) << 16);
+                    *(u32x4 *)(a.x_out + (int64_t)(n0 + node) * kD + chunk * 8) = v;
+                }
+            }
+        phase_tick(a.ticks, 6, tick);                        // rows out
+        if (a.ticks && tid == 0) atomicAdd((unsigned long long *)&a.ticks[15], 1ull);
+    }
+}
+
 }  // namespace
 
 extern "C" void gcc_ginw_debug_ticks(long long *device_ticks64) { g_ticks = device_ticks64; }
+
+extern "C" int32_t gcc_ginw_pack_weights(const uint16_t *w, uint16_t *w_frag, int32_t which, void *stream)
+{
+    if (!w || !w_frag || which < 0 || which > 1) {
+        snprintf(g_err, kErrLen, "gcc_ginw_pack_weights: bad argument");
+        return -1;
+    }
+    hipLaunchKernelGGL(ginw_pack_kernel, dim3(kD * kD / 8 / 256), dim3(256), 0, (hipStream_t)stream, w, w_frag, (int)which);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_ginw_pack_weights: %s", hipGetErrorString(e)); return -10; }
+    return 0;
+}
 
 extern "C" int32_t gcc_ginw_forward(const gcc_ginw_args *g, int32_t *status, gcc_prof *prof, void *stream)
 {
@@ -423,16 +784,37 @@ extern "C" int32_t gcc_ginw_forward(const gcc_ginw_args *g, int32_t *status, gcc
         }
     }
     hipStream_t s = (hipStream_t)stream;
+    static int shape = 0;                                    // GCC_GINW_KERNEL=1: the first kernel shape (A/B runs)
+    if (shape == 0) {
+        const char *e = getenv("GCC_GINW_KERNEL");
+        shape = e && atoi(e) == 1 ? 1 : 2;
 #ifndef GCC_AMD_HIPEMU
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {                                       // more than 64 KiB of dynamic LDS has to be opted into
+        // more than 64 KiB of dynamic LDS has to be opted into
         (void)hipFuncSetAttribute((const void *)gin_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        lds_opt_in = true;
-    }
+        (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
+        (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
+        (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
+        (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
+        (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
+        (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
 #endif
+    }
     prof_mark(prof, 0, s);
-    // one workgroup per CU (141 KB of LDS each), walking the subgraphs with a stride of the grid
-    hipLaunchKernelGGL(gin_wide_kernel, dim3(min(g->batch_size, 256)), dim3(kThreads), kLdsBytes, s, a);
+    // one workgroup per CU (137 / 148 KB of LDS each), walking the subgraphs with a stride of the grid
+    if (shape == 1) hipLaunchKernelGGL(gin_wide_kernel, dim3(min(g->batch_size, 256)), dim3(kThreads), kLdsBytes, s, a);
+    else {
+        static int dbg = -1;
+        if (dbg < 0) { const char *e = getenv("GCC_GINW_DBG"); dbg = e ? atoi(e) : 0; }
+        bool frag = true;                                    // every layer carries the fragment-major copies?
+        for (int i = 0; i < g->num_layers; ++i) frag = frag && g->layers[i].w0_frag && g->layers[i].w1_frag;
+        const dim3 grid(min(g->batch_size, 256)), block(kT2);
+        if (!frag) hipLaunchKernelGGL((gin_wide2_kernel<0, false>), grid, block, kLds2, s, a);
+        else if (dbg == 1) hipLaunchKernelGGL((gin_wide2_kernel<1, true>), grid, block, kLds2, s, a);
+        else if (dbg == 2) hipLaunchKernelGGL((gin_wide2_kernel<2, true>), grid, block, kLds2, s, a);
+        else if (dbg == 4) hipLaunchKernelGGL((gin_wide2_kernel<4, true>), grid, block, kLds2, s, a);
+        else if (dbg == 7) hipLaunchKernelGGL((gin_wide2_kernel<7, true>), grid, block, kLds2, s, a);
+        else hipLaunchKernelGGL((gin_wide2_kernel<0, true>), grid, block, kLds2, s, a);
+    }
     prof_mark(prof, 1, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_ginw_forward: %s", hipGetErrorString(e)); return -10; }

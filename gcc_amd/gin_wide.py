@@ -46,6 +46,12 @@ class FoldedWideGIN:
                 if tuple(v.shape) != (HIDDEN,):
                     raise ValueError(f"{k} must be [{HIDDEN}]")
                 d[k] = v.to(self.device).contiguous()
+            # the same weights in the order the kernel's waves request them (include/gcc_amd.h: gcc_ginw_pack_weights)
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            for which, k in enumerate(("w0", "w1")):
+                d[k + "_frag"] = torch.empty_like(d[k])
+                _cabi.check(self.lib.gcc_ginw_pack_weights(_cabi.dev_ptr(d[k]), _cabi.dev_ptr(d[k + "_frag"]), which, st),
+                            "gcc_ginw_pack_weights")
             self.layers.append(d)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
 

@@ -320,6 +320,10 @@ int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat, const gcc
 typedef struct gcc_ginw_layer {
     const uint16_t *w0, *w1;             /* device [256, 256] bf16, torch Linear layout [out, in]               */
     const float *s0, *t0, *s1, *t1, *s2, *t2;   /* device [256] folded scale / shift                             */
+    const uint16_t *w0_frag, *w1_frag;   /* device [256 * 256] bf16: the same weights re-laid by gcc_ginw_pack_weights
+                                          * (which = 0 / 1), or NULL.  When every layer of a call has both, the kernel
+                                          * requests 1 KiB-contiguous fragments instead of 16 rows x 64 B each (a wave
+                                          * request over 16 rows costs ~3x the issue time; 13 % of the fused launch)  */
 } gcc_ginw_layer;
 typedef struct gcc_ginw_args {
     const int32_t *node_off;             /* device [B + 1]                                                       */
@@ -332,6 +336,12 @@ typedef struct gcc_ginw_args {
 } gcc_ginw_args;
 /* status: device int32[1], OR of GCC_STATUS_GINW_* (zeroed by the caller).  prof marks: 0 before, 1 after. */
 int32_t gcc_ginw_forward(const gcc_ginw_args *a, int32_t *status, gcc_prof *prof, void *stream);
+/* Re-lays a [256, 256] bf16 Linear weight (torch layout) in the order gcc_ginw_forward's waves request it: fragment
+ * (output block w < 4, fragment m < 4, k-step ks < 8) is 1 KiB contiguous at ((w * 4 + m) * 8 + ks) * 512 elements, lane
+ * (16 lg + lr) holding W[row][32 ks + 8 lg .. + 7]; which = 0 (first Linear of a layer): row = 64 w + 32 (m / 2) +
+ * 8 (lr / 4) + 4 (m % 2) + lr % 4 (the rows of two adjacent fragments interleaved in blocks of four), which = 1 (second
+ * Linear): row = 64 w + 16 m + lr.  Done once per model. */
+int32_t gcc_ginw_pack_weights(const uint16_t *w, uint16_t *w_frag, int32_t which, void *stream);
 /* diagnostics, as gcc_posemb_debug_ticks: device int64[16] (rows in, neighbour counts, fragments, aggregation, first
  * Linear, second Linear, rows out; [15] = subgraphs); NULL switches it off. */
 void gcc_ginw_debug_ticks(long long *device_ticks64);

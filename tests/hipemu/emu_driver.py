@@ -126,9 +126,10 @@ def emu_sample_multi(g: EmuGraph, B, run_seed, first_sample_id, num_steps, strid
     return pairs, int(status[0]), ws[: 4 * B * num_steps].view(np.int32).copy()
 
 
-def emu_ginw_forward(node_off, row_ptr, col_idx, x_bits, layers):
+def emu_ginw_forward(node_off, row_ptr, col_idx, x_bits, layers, pack=False):
     """gcc_ginw_forward on the emulator.  x_bits: uint16 [N, 256] bf16 patterns; layers: dicts of numpy arrays with
-    w0/w1 as uint16 bf16 patterns [256, 256] and s0..t2 float32 [256].  Returns (rows uint16, pooled f32, status)."""
+    w0/w1 as uint16 bf16 patterns [256, 256] and s0..t2 float32 [256].  ``pack``: also pass the fragment-major copies
+    made by gcc_ginw_pack_weights.  Returns (rows uint16, pooled f32, status)."""
     lib = emu_lib()
     node_off = np.ascontiguousarray(node_off, dtype=np.int32)
     row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
@@ -142,10 +143,15 @@ def emu_ginw_forward(node_off, row_ptr, col_idx, x_bits, layers):
                           x_out=_p(rows), pooled=_p(pooled), batch_size=B, num_layers=L)
     keep = []
     for i, ly in enumerate(layers):
-        for k in ("w0", "w1"):
+        for which, k in enumerate(("w0", "w1")):
             v = np.ascontiguousarray(ly[k], dtype=np.uint16)
             keep.append(v)
             setattr(a.layers[i], k, _p(v))
+            if pack:
+                f = np.zeros_like(v)
+                assert lib.gcc_ginw_pack_weights(_p(v), _p(f), which, None) == 0
+                keep.append(f)
+                setattr(a.layers[i], k + "_frag", _p(f))
         for k in ("s0", "t0", "s1", "t1", "s2", "t2"):
             v = np.ascontiguousarray(ly[k], dtype=np.float32)
             keep.append(v)

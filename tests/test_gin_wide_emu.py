@@ -102,6 +102,9 @@ def test_emulated_kernel_matches_the_oracle(sizes, deg, L):
     x = ow.bf16_round(rng.standard_normal((N, D)).astype(np.float32))
     rows, pooled, status = emu_ginw_forward(node_off, row_ptr, col_idx, ow.to_bf16_bits(x), bits_layers(layers))
     assert status == 0
+    # the fragment-major weight copies (gcc_ginw_pack_weights) hold the same numbers in request order: same results, bit for bit
+    rows_p, pooled_p, status_p = emu_ginw_forward(node_off, row_ptr, col_idx, ow.to_bf16_bits(x), bits_layers(layers), pack=True)
+    assert status_p == 0 and np.array_equal(rows, rows_p) and np.array_equal(pooled, pooled_p)
     want_rows, want_pooled = ow.gin_wide_forward(node_off, row_ptr, col_idx, x, layers, bf16=True)
     got = ow.from_bf16_bits(rows)
     # same rounding points, f32 (matrix core) vs f64 accumulation: a few results land on the other side of a bf16
