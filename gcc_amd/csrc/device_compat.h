@@ -369,6 +369,15 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float x)
     return u >> 16;
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+// min(max(x, lo), hi) for lo <= hi (one v_med3_f32 on gfx950)
+__device__ __forceinline__ float clamp_f32(float x, float lo, float hi)
+{
+#ifdef GCC_AMD_HIPEMU
+    return fminf(fmaxf(x, lo), hi);
+#else
+    return __builtin_amdgcn_fmed3f(x, lo, hi);
+#endif
+}
 // acc + both bf16 halves of a word (v_dot2c_f32_bf16 with a pair of ones on gfx950: 1 instruction instead of 4)
 __device__ __forceinline__ float add2_bf16(uint32_t pk, float acc)
 {

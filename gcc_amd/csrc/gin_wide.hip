@@ -490,27 +490,48 @@ __global__ __launch_bounds__(kT2) void gin_wide2_kernel(WideArgs a)
         // ---- the subgraph's input rows -> P, channel-major; neighbour counts -> Q (16-bit counters, [node][u])
         for (int i = tid; i < kNodes * kStrT2 / 4; i += kT2) ((uint32_t *)Q)[i] = 0u;
         if (tid <= n) rp[tid] = a.row_ptr[n0 + tid];
-        for (int idx = tid; idx < kNodes * (kD / 8); idx += kT2) {
-            const int node = idx & (kNodes - 1), chunk = idx >> 7;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (node < n) v = *(const u32x4 *)(a.x_in + (int64_t)(n0 + node) * kD + chunk * 8);
+        // (4 nodes x 8 channels per work item: four 16-byte loads, eight 8-byte LDS writes; requesting all 16 loads of a
+        //  thread's four work items first was measured too: no gain)
+        for (int idx = tid; idx < (kNodes / 4) * (kD / 8); idx += kT2) {
+            const int chunk = idx & (kD / 8 - 1), node = 4 * (idx >> 5);
+            u32x4 v[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                *(uint16_t *)(P + (chunk * 8 + e) * kStrT2 + node * 2) = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                v[j] = node + j < n ? *(const u32x4 *)(a.x_in + (int64_t)(n0 + node + j) * kD + chunk * 8) : z;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int sh = (e & 1) * 16;
+                u32x2 o;
+                o[0] = ((v[0][e >> 1] >> sh) & 0xFFFFu) | (((v[1][e >> 1] >> sh) & 0xFFFFu) << 16);
+                o[1] = ((v[2][e >> 1] >> sh) & 0xFFFFu) | (((v[3][e >> 1] >> sh) & 0xFFFFu) << 16);
+                *(u32x2 *)(P + (chunk * 8 + e) * kStrT2 + node * 2) = o;
+            }
         }
         __syncthreads();
         phase_tick(a.ticks, 0, tick);                        // rows in
         {
+            // runs of 16 consecutive edges per thread: one bisection of the row pointers per run, then the row advances with
+            // the edges (a bisection per edge was 9.8 us per subgraph)
             const int e0 = rp[0], e1 = rp[n];
-            for (int e = e0 + tid; e < e1; e += kT2) {
-                const int u = a.col_idx[e] - n0;
-                int lo = 0, hi = n;                          // largest i with rp[i] <= e
+            for (int eb = e0 + 16 * tid; eb < e1; eb += 16 * kT2) {
+                int cols[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) cols[j] = eb + j < e1 ? a.col_idx[eb + j] : -1;
+                int lo = 0, hi = n;                          // largest i with rp[i] <= eb
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
-                    if (rp[mid] <= e) lo = mid; else hi = mid;
+                    if (rp[mid] <= eb) lo = mid; else hi = mid;
                 }
-                if ((unsigned)u < (unsigned)n) atomicAdd((uint32_t *)(Q + lo * kStrT2 + (u >> 1) * 4), (u & 1) ? 0x10000u : 1u);
-                else atomicOr(a.status, (int32_t)GCC_STATUS_GINW_BAD_EDGE);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (eb + j >= e1) break;
+                    while (rp[lo + 1] <= eb + j) ++lo;       // (empty rows are skipped)
+                    const int u = cols[j] - n0;
+                    if ((unsigned)u < (unsigned)n) atomicAdd((uint32_t *)(Q + lo * kStrT2 + (u >> 1) * 4), (u & 1) ? 0x10000u : 1u);
+                    else atomicOr(a.status, (int32_t)GCC_STATUS_GINW_BAD_EDGE);
+                }
             }
             if (tid < n) atomicAdd((uint32_t *)(Q + tid * kStrT2 + (tid >> 1) * 4), (tid & 1) ? 0x10000u : 1u);   // + h_v itself
         }
@@ -537,7 +558,7 @@ __global__ __launch_bounds__(kT2) void gin_wide2_kernel(WideArgs a)
         u32x4 wr[4][4];                                      // weight ring: slot = k-step & 3
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) request_w<true, kFrag>(wr[ks], kFrag ? a.layers[0].w0_frag : a.layers[0].w0, w, ks, lr, lg);
-        __syncthreads();
+        lds_barrier();                                       // (not __syncthreads(): the requests stay in flight)
         phase_tick(a.ticks, 2, tick);                        // input pooling, adjacency fragments
 
         for (int layer = 0; layer < L; ++layer) {
@@ -656,11 +677,17 @@ __global__ __launch_bounds__(kT2) void gin_wide2_kernel(WideArgs a)
                 for (int nf = 0; nf < 8; ++nf)
 #pragma unroll
                     for (int m = 0; m < 4; ++m) acc[nf][m] = zero4;
-                float s1[4], t1[4], s2[4], t2[4];
+                // relu(s2 * relu(s1 * x + t1) + t2) as ONE multiply-add and ONE clamp per value: with A = s1 s2 and
+                // B = s2 t1 + t2 it is max(A x + B, max(t2, 0)) for s2 >= 0 and min(max(A x + B, 0), max(t2, 0)) for s2 < 0
+                float ea[4], eb[4], elo[4], ehi[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const int c = w * 64 + m * 16 + lr;
-                    s1[m] = ly.s1[c]; t1[m] = ly.t1[c]; s2[m] = ly.s2[c]; t2[m] = ly.t2[c];
+                    const float s1 = ly.s1[c], t1 = ly.t1[c], s2 = ly.s2[c], t2 = ly.t2[c];
+                    ea[m] = s1 * s2;
+                    eb[m] = fmaf(s2, t1, t2);
+                    elo[m] = s2 >= 0.f ? fmaxf(t2, 0.f) : 0.f;
+                    ehi[m] = s2 >= 0.f ? __uint_as_float(0x7F800000u) : fmaxf(t2, 0.f);
                 }
                 const unsigned char *src = P + lg * 16;
                 u32x4 buf[2][8];
@@ -691,7 +718,7 @@ __global__ __launch_bounds__(kT2) void gin_wide2_kernel(WideArgs a)
                     for (int nf = 0; nf < 8; ++nf)
 #pragma unroll
                         for (int m = 0; m < 4; ++m) t4 += acc[nf][m];
-                    t4[0] += s1[0] + t1[1] + s2[2] + t2[3];
+                    t4[0] += ea[0] + eb[1] + elo[2] + ehi[3];
                     *(u32x4 *)(Q + (w * 64 + lr) * kStrT2 + lg * 16) = pack8_bf16(t4, t4);
                 } else {
 #pragma unroll
@@ -703,10 +730,9 @@ __global__ __launch_bounds__(kT2) void gin_wide2_kernel(WideArgs a)
                         const int node = q * 32 + lg * 8;
                         f32x4 lo = acc[2 * q][m], hi = acc[2 * q + 1][m];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float ylo = fmaxf(fmaf(lo[r], s1[m], t1[m]), 0.f), yhi = fmaxf(fmaf(hi[r], s1[m], t1[m]), 0.f);   // apply_func: relu(bn(mlp))
-                            lo[r] = fmaxf(fmaf(ylo, s2[m], t2[m]), 0.f);                               // relu(batch_norms[i](.))
-                            hi[r] = fmaxf(fmaf(yhi, s2[m], t2[m]), 0.f);
+                        for (int r = 0; r < 4; ++r) {        // apply_func: relu(bn(mlp)), then relu(batch_norms[i](.))
+                            lo[r] = clamp_f32(fmaf(lo[r], ea[m], eb[m]), elo[m], ehi[m]);
+                            hi[r] = clamp_f32(fmaf(hi[r], ea[m], eb[m]), elo[m], ehi[m]);
                         }
                         if (q * 32 + 32 > n) {               // (block-uniform) this 32-block holds padding nodes: they stay 0
 #pragma unroll
@@ -729,17 +755,25 @@ __global__ __launch_bounds__(kT2) void gin_wide2_kernel(WideArgs a)
             phase_tick(a.ticks, 5, tick);                    // second Linear
             unsigned char *t = P; P = Q; Q = t;
         }
-        // ---- the last layer's rows back to node-major global memory
+        // ---- the last layer's rows back to node-major global memory (4 nodes x 8 channels per work item)
         if (a.x_out)
-            for (int idx = tid; idx < kNodes * (kD / 8); idx += kT2) {
-                const int node = idx & (kNodes - 1), chunk = idx >> 7;
+            for (int idx = tid; idx < (kNodes / 4) * (kD / 8); idx += kT2) {
+                const int chunk = idx & (kD / 8 - 1), node = 4 * (idx >> 5);
                 if (node < n) {
-                    u32x4 v;
+                    u32x2 c[8];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        v[q] = (uint32_t)*(const uint16_t *)(P + (chunk * 8 + 2 * q) * kStrT2 + node * 2)
-                             | ((uint32_t)*(const uint16_t *)(P + (chunk * 8 + 2 * q + 1) * kStrT2 + node * 2) << 16);
-                    *(u32x4 *)(a.x_out + (int64_t)(n0 + node) * kD + chunk * 8) = v;
+                    for (int e = 0; e < 8; ++e) c[e] = *(const u32x2 *)(P + (chunk * 8 + e) * kStrT2 + node * 2);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (node + j < n) {
+                            const int sh = (j & 1) * 16, h = j >> 1;
+                            u32x4 v;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                v[q] = ((c[2 * q][h] >> sh) & 0xFFFFu) | (((c[2 * q + 1][h] >> sh) & 0xFFFFu) << 16);
+                            *(u32x4 *)(a.x_out + (int64_t)(n0 + node + j) * kD + chunk * 8) = v;
+                        }
+                    }
                 }
             }
         phase_tick(a.ticks, 6, tick);                        // rows out
