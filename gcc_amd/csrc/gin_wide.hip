@@ -406,24 +406,27 @@ __global__ __launch_bounds__(kThreads) void gin_wide_kernel(WideArgs a)
 // from LDS feeds FOUR matrix instructions (two in the first kernel, whose products were bound by fragment reads), the
 // weight fragments stream through a 4-deep register ring straight from L2 (each read once per workgroup, requested four
 // k-steps = ~2000 cycles ahead across product boundaries), the adjacency is 16 fragments in registers for all layers, and
-// results are stored 16 bytes per lane: the rows of two adjacent A fragments are interleaved in blocks of 4
-// (row r of fragment e <-> index 8 (r >> 2) + 4 e + (r & 3) of a 32-block), so a lane's 4 + 4 accumulator rows are 8
-// consecutive channels (or nodes).  Rows are padded by 32 bytes (conflict-free 16-byte fragment reads, r1_lds_probe).
+// results are stored 16 bytes per lane: the rows of two adjacent A fragments are interleaved (row r of fragment e <->
+// index 2 r + e of a 32-block), so a lane's 4 + 4 accumulator rows are 8 consecutive channels (or nodes).  Row strides per
+// layout, from the LDS lane-group model of MI355X_MICROARCH.md (a 16-byte fragment read is serviced in 4 groups of 16
+// lanes): consecutive rows are conflict-free at 544 bytes, interleaved rows at 272 / 528 (blocks of four rows, the
+// first try, are 2-way conflicted at every stride: 53 % of the LDS cycles in profiles/r3_pmc_gin_wide.json's first run).
 constexpr int kT2 = 256;
-constexpr int kStrT2 = kNodes * 2 + 32;      // channel-major [256 ch][128 nodes]
-constexpr int kStrN2 = kD * 2 + 32;          // node-major    [128 nodes][256 ch]
-constexpr int kReg2 = kD * kStrT2;           // 73,728 B >= kNodes * kStrN2
+constexpr int kStrT2 = kNodes * 2 + 16;      // H^T, channel-major [256 ch][128 nodes]: read with interleaved rows (aggregation)
+constexpr int kStrN2 = kD * 2 + 32;          // AGG, node-major [128 nodes][256 ch]: read with consecutive rows (first Linear)
+constexpr int kStrZ2 = kD * 2 + 16;          // Z1,  node-major: read with interleaved rows (second Linear)
+constexpr int kReg2 = kD * kStrT2;           // 69,632 B = kNodes * kStrN2
 constexpr int kLds2 = 2 * kReg2 + (kNodes + 1 + 3) / 4 * 16;
-static_assert(kNodes * kStrN2 <= kReg2, "node-major layout must fit a region");
+static_assert(kNodes * kStrN2 <= kReg2 && kNodes * kStrZ2 <= kReg2, "the node-major layouts must fit a region");
 
-__device__ __forceinline__ int perm8(int lr, int e) { return 8 * (lr >> 2) + 4 * e + (lr & 3); }
+__device__ __forceinline__ int perm8(int lr, int e) { return 2 * lr + e; }
 __device__ __forceinline__ u32x4 pack8_bf16(const f32x4 &a, const f32x4 &b)
 {
     u32x4 r;
-    r[0] = pack2_bf16(a[0], a[1]);
-    r[1] = pack2_bf16(a[2], a[3]);
-    r[2] = pack2_bf16(b[0], b[1]);
-    r[3] = pack2_bf16(b[2], b[3]);
+    r[0] = pack2_bf16(a[0], b[0]);               // fragment 0 holds the even, fragment 1 the odd indices
+    r[1] = pack2_bf16(a[1], b[1]);
+    r[2] = pack2_bf16(a[2], b[2]);
+    r[3] = pack2_bf16(a[3], b[3]);
     return r;
 }
 __device__ __forceinline__ float sum8_bf16(u32x4 v, float s = 0.f)
@@ -650,18 +653,18 @@ __global__ __launch_bounds__(kT2) void gin_wide2_kernel(WideArgs a)
 #pragma unroll
                         for (int nf = 0; nf < 8; ++nf) t4 += acc[m][nf];
                     t4[0] += sc[0][0].x + sh[1][1].w;
-                    *(u32x4 *)(P + lr * kStrN2 + (w * 64 + lg * 8) * 2) = pack8_bf16(t4, t4);
+                    *(u32x4 *)(P + lr * kStrZ2 + (w * 64 + lg * 8) * 2) = pack8_bf16(t4, t4);
                 } else {
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
                     for (int nf = 0; nf < 8; ++nf) {
-                        f32x4 lo = acc[2 * p][nf], hi = acc[2 * p + 1][nf];
-                        lo[0] = fmaxf(fmaf(lo[0], sc[p][0].x, sh[p][0].x), 0.f); lo[1] = fmaxf(fmaf(lo[1], sc[p][0].y, sh[p][0].y), 0.f);
-                        lo[2] = fmaxf(fmaf(lo[2], sc[p][0].z, sh[p][0].z), 0.f); lo[3] = fmaxf(fmaf(lo[3], sc[p][0].w, sh[p][0].w), 0.f);
-                        hi[0] = fmaxf(fmaf(hi[0], sc[p][1].x, sh[p][1].x), 0.f); hi[1] = fmaxf(fmaf(hi[1], sc[p][1].y, sh[p][1].y), 0.f);
-                        hi[2] = fmaxf(fmaf(hi[2], sc[p][1].z, sh[p][1].z), 0.f); hi[3] = fmaxf(fmaf(hi[3], sc[p][1].w, sh[p][1].w), 0.f);
-                        *(u32x4 *)(P + (nf * 16 + lr) * kStrN2 + (w * 64 + p * 32 + lg * 8) * 2) = pack8_bf16(lo, hi);
+                        f32x4 lo = acc[2 * p][nf], hi = acc[2 * p + 1][nf];     // channels 8 lg + {0, 2, 4, 6} and + {1, 3, 5, 7}
+                        lo[0] = fmaxf(fmaf(lo[0], sc[p][0].x, sh[p][0].x), 0.f); hi[0] = fmaxf(fmaf(hi[0], sc[p][0].y, sh[p][0].y), 0.f);
+                        lo[1] = fmaxf(fmaf(lo[1], sc[p][0].z, sh[p][0].z), 0.f); hi[1] = fmaxf(fmaf(hi[1], sc[p][0].w, sh[p][0].w), 0.f);
+                        lo[2] = fmaxf(fmaf(lo[2], sc[p][1].x, sh[p][1].x), 0.f); hi[2] = fmaxf(fmaf(hi[2], sc[p][1].y, sh[p][1].y), 0.f);
+                        lo[3] = fmaxf(fmaf(lo[3], sc[p][1].z, sh[p][1].z), 0.f); hi[3] = fmaxf(fmaf(hi[3], sc[p][1].w, sh[p][1].w), 0.f);
+                        *(u32x4 *)(P + (nf * 16 + lr) * kStrZ2 + (w * 64 + p * 32 + lg * 8) * 2) = pack8_bf16(lo, hi);
                     }
                 }
             }
@@ -692,13 +695,13 @@ __global__ __launch_bounds__(kT2) void gin_wide2_kernel(WideArgs a)
                 const unsigned char *src = P + lg * 16;
                 u32x4 buf[2][8];
 #pragma unroll
-                for (int nf = 0; nf < 8; ++nf) buf[0][nf] = lds16(src + ((nf >> 1) * 32 + perm8(lr, nf & 1)) * kStrN2);
+                for (int nf = 0; nf < 8; ++nf) buf[0][nf] = lds16(src + ((nf >> 1) * 32 + perm8(lr, nf & 1)) * kStrZ2);
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     if (ks + 1 < 8 && !(kDbg & 4)) {
 #pragma unroll
                         for (int nf = 0; nf < 8; ++nf)
-                            buf[(ks + 1) & 1][nf] = lds16(src + ((nf >> 1) * 32 + perm8(lr, nf & 1)) * kStrN2 + (ks + 1) * 64);
+                            buf[(ks + 1) & 1][nf] = lds16(src + ((nf >> 1) * 32 + perm8(lr, nf & 1)) * kStrZ2 + (ks + 1) * 64);
                     }
                     SCHED_FENCE();
 #pragma unroll
@@ -736,9 +739,9 @@ __global__ __launch_bounds__(kT2) void gin_wide2_kernel(WideArgs a)
                         }
                         if (q * 32 + 32 > n) {               // (block-uniform) this 32-block holds padding nodes: they stay 0
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                lo[r] = node + r < n ? lo[r] : 0.f;
-                                hi[r] = node + 4 + r < n ? hi[r] : 0.f;
+                            for (int r = 0; r < 4; ++r) {        // (lo: nodes node + 0, 2, 4, 6; hi: + 1, 3, 5, 7)
+                                lo[r] = node + 2 * r < n ? lo[r] : 0.f;
+                                hi[r] = node + 2 * r + 1 < n ? hi[r] : 0.f;
                             }
                         }
                         const u32x4 hv = pack8_bf16(lo, hi);

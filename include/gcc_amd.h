@@ -339,8 +339,8 @@ int32_t gcc_ginw_forward(const gcc_ginw_args *a, int32_t *status, gcc_prof *prof
 /* Re-lays a [256, 256] bf16 Linear weight (torch layout) in the order gcc_ginw_forward's waves request it: fragment
  * (output block w < 4, fragment m < 4, k-step ks < 8) is 1 KiB contiguous at ((w * 4 + m) * 8 + ks) * 512 elements, lane
  * (16 lg + lr) holding W[row][32 ks + 8 lg .. + 7]; which = 0 (first Linear of a layer): row = 64 w + 32 (m / 2) +
- * 8 (lr / 4) + 4 (m % 2) + lr % 4 (the rows of two adjacent fragments interleaved in blocks of four), which = 1 (second
- * Linear): row = 64 w + 16 m + lr.  Done once per model. */
+ * 2 lr + m % 2 (the rows of two adjacent fragments interleaved), which = 1 (second Linear): row = 64 w + 16 m + lr.
+ * Done once per model. */
 int32_t gcc_ginw_pack_weights(const uint16_t *w, uint16_t *w_frag, int32_t which, void *stream);
 /* diagnostics, as gcc_posemb_debug_ticks: device int64[16] (rows in, neighbour counts, fragments, aggregation, first
  * Linear, second Linear, rows out; [15] = subgraphs); NULL switches it off. */

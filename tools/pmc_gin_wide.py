@@ -21,19 +21,19 @@ def main():
     for path in glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as f:
             for r in csv.DictReader(f):
-                if "gin_wide_kernel" not in r["Kernel_Name"]:
+                if "gin_wide" not in r["Kernel_Name"] or "pack" in r["Kernel_Name"]:
                     continue
                 d = rows.setdefault(r["Dispatch_Id"], dict(dur=int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), c={}))
                 d["c"][r["Counter_Name"]] = d["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     if not rows:
-        raise SystemExit("no gin_wide_kernel dispatches found")
+        raise SystemExit("no gin_wide dispatches found")
     longest = max(v["dur"] for v in rows.values())
     fused = [v for v in rows.values() if v["dur"] > 0.6 * longest]
     c = {k: sum(v["c"].get(k, 0.0) for v in fused) / len(fused) for k in fused[0]["c"]}
     dur = sum(v["dur"] for v in fused) / len(fused) / 1e3
     wc = c.get("SQ_WAVE_CYCLES", 0.0) or 1.0
     src = open(os.path.join(ROOT, "gcc_amd", "csrc", "gin_wide.hip"), "rb").read()
-    rec = dict(kernel="gin_wide_kernel, fused 8-layer launch (the longest dispatches of tools/gin_roofline.py)",
+    rec = dict(kernel="gin_wide2_kernel (default shape), fused 8-layer launch (the longest dispatches of tools/gin_roofline.py)",
                source_sha256=hashlib.sha256(src).hexdigest(), dispatches=len(fused), duration_us_under_profiler=dur, counters=c,
                derived=dict(parked_on_waitcnt_or_barrier=c.get("SQ_WAIT_ANY", 0) / wc, issue_stalled=c.get("SQ_WAIT_INST_ANY", 0) / wc,
                             issuing=c.get("SQ_ACTIVE_INST_ANY", 0) / wc,
