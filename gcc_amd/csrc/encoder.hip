@@ -55,7 +55,8 @@ __global__ __launch_bounds__(kThreads) void gin_feat_kernel(FeatLaunch L)
         for (int64_t i = (int64_t)blockIdx.x * kThreads + tid; i < a.zero_a16; i += stride) a.zero_a[i] = z4;
         for (int64_t i = (int64_t)blockIdx.x * kThreads + tid; i < a.zero_b16; i += stride) a.zero_b[i] = z4;
     }
-    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+    for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
+        const int tile0 = tw.ti * kTile;
         const int nrows = min(kTile, N - tile0);
         for (int r = gi; r < nrows; r += 16) {
             {
@@ -139,23 +140,29 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
         ab = aff4_from_table(tabb, 4 * t);
         ac = aff4_from_table(tabc, 4 * t);
     }
-    auto feat = [&](int u) -> F4 {
-        F4 x = ld4(a.src + (int64_t)u * H + 4 * t);
-        if (!a.first) x = affine_relu(affine_relu(x, ab), ac);   // h = relu(bn_c(relu(bn_b(z2))))  gin.py:56-57,219-220
-        return x;
-    };
+    const float *src = a.src;
+    const bool first = a.first != 0;              // (block-uniform; the launch has one layer)
+    auto load = [&](int u) -> F4 { return ld4(src + (int64_t)u * H + 4 * t); };
+    auto xform = [&](F4 x) -> F4 { return first ? x : affine_relu(affine_relu(x, ab), ac); };   // h = relu(bn_c(relu(bn_b(z2))))  gin.py:56-57,219-220
     GIN_TICK(0);                                  // BatchNorm tables
-    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+    for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
+        const int tile0 = tw.ti * kTile;
         const int nrows = min(kTile, N - tile0);
         if (L.ticks && tid == 0) atomicAdd((unsigned long long *)&L.ticks[(a.first ? 0 : 16) + 15], 1ull);
         // 1. own rows; the tile's row pointers and graph ids ride in the same round trip (the pooling and the gather
         //    would otherwise each start with one of their own)
         if (tid <= nrows) rpl[tid] = a.row_ptr[tile0 + tid];
         if (tid >= 128 && tid - 128 < nrows) gidl[tid - 128] = a.graph_id[tile0 + tid - 128];
-        for (int r = gi; r < kTile; r += 16) {
-            F4 x = {0.f, 0.f, 0.f, 0.f};
-            if (r < nrows) x = feat(tile0 + r);
-            st4(&T[r * kLdt + 4 * t], x);
+        {
+            F4 own[kTile / 16];                   // the 4 rows of this lane group: requested together, transformed afterwards
+#pragma unroll
+            for (int i = 0; i < kTile / 16; ++i) own[i] = load(min(tile0 + gi + 16 * i, N - 1));
+#pragma unroll
+            for (int i = 0; i < kTile / 16; ++i) {
+                const int r = gi + 16 * i;
+                const F4 z = {0.f, 0.f, 0.f, 0.f};
+                st4(&T[r * kLdt + 4 * t], r < nrows ? xform(own[i]) : z);
+            }
         }
         __syncthreads();
         GIN_TICK(1);
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
         GIN_TICK(2);
         // 3. GINConv aggregate: (1 + eps) * h_v + sum_{u -> v} h_u, eps = 0 (gin.py:179-185,218)
 #if !(GIN_DBG_SKIP & 4)
-        gather_tile<4>(T, part, prow, nrows, a.col_idx, feat, a.nbr_weight, rpl);
+        gather_tile<4>(T, part, prow, nrows, a.col_idx, load, xform, a.nbr_weight, rpl);
 #endif
         GIN_TICK(3);
         // 4. keep agg for the weight gradient of linears.0
@@ -227,15 +234,18 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
     Aff4 aa[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) aa[c] = aff4_from_table(taba, 16 * c + 4 * q);
-    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+    for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
+        const int tile0 = tw.ti * kTile;
         const int row = tile0 + 16 * wv + j;
         const bool valid = row < N;
         F4 xb[4];
+        const float *zrow = a.z1 + (int64_t)(valid ? row : 0) * H;      // (unconditional loads, all four requested at once)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xb[c] = ld4(zrow + 16 * c + 4 * q);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            F4 x = {0.f, 0.f, 0.f, 0.f};
-            if (valid) x = affine_relu(ld4(a.z1 + (int64_t)row * H + 16 * c + 4 * q), aa[c]);   // gin.py:115
-            xb[c] = x;
+            const F4 z = {0.f, 0.f, 0.f, 0.f};
+            xb[c] = valid ? affine_relu(xb[c], aa[c]) : z;                                      // gin.py:115
         }
         linear_rows16_lds_store_stats(xb, Wl, a.b1, a.z2, row, valid, &red[wv * 2 * H]);      // gin.py:116
         __syncthreads();
@@ -268,7 +278,8 @@ __global__ __launch_bounds__(kThreads) void gin_stat_kernel(StatLaunch L)
     const Aff4 ab = aff4_from_table(tabb, 4 * t);
     F4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
     bool any = false;
-    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+    for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
+        const int tile0 = tw.ti * kTile;
         any = true;
         for (int r = tile0 + gi; r < min(tile0 + kTile, N); r += 16) {
             const F4 y = affine_relu(ld4(a.z2 + (int64_t)r * H + 4 * t), ab);
@@ -315,7 +326,8 @@ __global__ __launch_bounds__(kThreads) void gin_pool_kernel(PoolLaunch L)
     bn_table(tabc, a.bnc, (double)N, a.eps, a.training, (double *)T);
     const Aff4 ab = aff4_from_table(tabb, 4 * t);
     const Aff4 ac = aff4_from_table(tabc, 4 * t);
-    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+    for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
+        const int tile0 = tw.ti * kTile;
         const int nrows = min(kTile, N - tile0);
         for (int r = gi; r < nrows; r += 16)
             st4(&T[r * kLdt + 4 * t], affine_relu(affine_relu(ld4(a.z2 + (int64_t)(tile0 + r) * H + 4 * t), ab), ac));

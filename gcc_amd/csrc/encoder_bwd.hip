@@ -224,14 +224,15 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_c_kernel(BwdCArgs a)
     auto ident = [&](int u) -> F4 { return ld4(a.D + (int64_t)u * H + 4 * t); };
     F4 s1 = zero4(), s2 = zero4();
     bool any = false;
-    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+    for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
+        const int tile0 = tw.ti * kTile;
         any = true;
         const int nrows = min(kTile, N - tile0);
         if (a.D) {
             if (tid <= nrows) rpl[tid] = a.row_ptr[tile0 + tid];      // (same round trip as the rows)
             for (int r = gi; r < kTile; r += 16) st4(&T[r * kLdt + 4 * t], r < nrows ? ident(tile0 + r) : zero4());
             __syncthreads();
-            gather_tile<8>(T, part, prow, nrows, a.col_idx, ident, 1.0f, rpl);
+            gather_tile<8>(T, part, prow, nrows, a.col_idx, ident, [](F4 x) { return x; }, 1.0f, rpl);
         }
         for (int r = gi; r < nrows; r += 16) {
             const int v = tile0 + r;
@@ -277,7 +278,8 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_b_kernel(BwdBArgs a)
     const F4 k1 = ld4(&Cc[K1 * H + 4 * t]), k2 = ld4(&Cc[K2 * H + 4 * t]), k3 = ld4(&Cc[K3 * H + 4 * t]);
     F4 s1 = zero4(), s2 = zero4();
     bool any = false;
-    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+    for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
+        const int tile0 = tw.ti * kTile;
         any = true;
         for (int v = tile0 + gi; v < min(tile0 + kTile, N); v += 16) {
             const F4 z = ld4(a.z2 + (int64_t)v * H + 4 * t);
@@ -331,7 +333,8 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_lin_kernel(BwdLinArgs a)
     stage_weights_store_t(Wt, wst);
     __syncthreads();
     float *myred = &red[wv * 3 * H];
-    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+    for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
+        const int tile0 = tw.ti * kTile;
         const int row = tile0 + 16 * wv + j;
         const bool valid = row < N;
         // every load of the tile is issued before the first use: unconditional (a lane past the end reads row 0, which exists
@@ -426,12 +429,13 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
     const int elems = (a.max_degree + 1) * a.emb_dim;
     for (int i = tid; i < elems; i += kThreads) E[i] = 0.f;
     auto ident = [&](int u) -> F4 { return ld4(a.D + (int64_t)u * H + 4 * t); };
-    for (int tile0 = (int)blockIdx.x * kTile; tile0 < N; tile0 += (int)gridDim.x * kTile) {
+    for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
+        const int tile0 = tw.ti * kTile;
         const int nrows = min(kTile, N - tile0);
         if (tid <= nrows) rpl[tid] = a.row_ptr[tile0 + tid];          // (same round trip as the rows)
         for (int r = gi; r < kTile; r += 16) st4(&T[r * kLdt + 4 * t], r < nrows ? ident(tile0 + r) : zero4());
         __syncthreads();
-        gather_tile<8>(T, part, prow, nrows, a.col_idx, ident, 1.0f, rpl);
+        gather_tile<8>(T, part, prow, nrows, a.col_idx, ident, [](F4 x) { return x; }, 1.0f, rpl);
         // all threads: add the pooled-path gradient and look the clamped degree up (global loads in parallel) ...
         if (tid < nrows) {
             const int deg = rpl[tid + 1] - rpl[tid];
@@ -499,26 +503,37 @@ __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
     // a workgroup walks 6-7 row tiles; with the loads of a tile issued right before its products every tile cost a full
     // memory round trip (58 us for ~6 us of matrix work): the next tile's rows are requested before this tile's products
     float av[4][4], xv[4][4];
+    // (unconditional loads from a clamped row, masked afterwards: under `row < N` branches every load waited for the one before)
+    const bool xdouble = jb.Xd != nullptr;               // block-uniform: prediction layers read the fp64 pooled sums
     auto fetch = [&](int tile0, float (&A)[4][4], float (&X)[4][4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int row = tile0 + 16 * wv + 4 * s + q;     // MFMA reduction index = row
+            const int64_t off = (int64_t)(row < N ? row : 0) * H + j;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                A[s][k] = row < N ? jb.dZ[(int64_t)row * H + 16 * k + j] : 0.f;
-                float x = 0.f;
-                if (row < N) x = jb.Xd ? (float)jb.Xd[(int64_t)row * H + 16 * k + j] : jb.X[(int64_t)row * H + 16 * k + j];
-                X[s][k] = x;
+            for (int k = 0; k < 4; ++k) A[s][k] = jb.dZ[off + 16 * k];
+            if (xdouble) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) X[s][k] = (float)jb.Xd[off + 16 * k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) X[s][k] = jb.X[off + 16 * k];
             }
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bool in = tile0 + 16 * wv + 4 * s + q < N;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { A[s][k] = in ? A[s][k] : 0.f; X[s][k] = in ? X[s][k] : 0.f; }
+        }
     };
-    const int tstride = (int)gridDim.x * kTile;
-    int tile0 = (int)blockIdx.x * kTile;
-    if (tile0 < N) fetch(tile0, av, xv);
-    for (; tile0 < N; tile0 += tstride) {
+    TileWalk tw(N);
+    if (tw.ti < tw.tend) fetch(tw.ti * kTile, av, xv);
+    for (; tw.ti < tw.tend; tw.ti += tw.step) {
+        const int tile0 = tw.ti * kTile;
         float an[4][4], xn[4][4];
-        const bool more = tile0 + tstride < N;               // block-uniform
-        if (more) fetch(tile0 + tstride, an, xn);
+        const bool more = tw.ti + tw.step < tw.tend;         // block-uniform
+        if (more) fetch((tw.ti + tw.step) * kTile, an, xn);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int row = tile0 + 16 * wv + 4 * s + q;

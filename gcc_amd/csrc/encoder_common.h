@@ -15,6 +15,28 @@ constexpr int kRep = 32;            // replicas of every atomically accumulated 
                                     // copy (blockIdx.x % kRep), consumers sum the copies -- ~730 workgroups hitting the
                                     // same 8 cache lines with fp64 atomics cost 20-40 us per kernel (rocprof, round 1)
 
+// ---- XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 (8 XCDs, each with its own 4 MiB L2), so with
+// tile = blockIdx.x every XCD touched every subgraph and the neighbour rows a tile gathers (rows of its own subgraphs,
+// written by other tiles) came through the fabric: ~60 MB per gin_in launch, 26 of its 50 us.  Here XCD x walks the
+// contiguous tiles [x * per, (x + 1) * per), per = ceil(tiles / 8): a tile's neighbours were written (and are re-read) by
+// workgroups of the same XCD.  Every tile kernel of the forward and backward pass uses the same walk, so a tile's own rows
+// also stay in one L2 from producer to consumer.
+struct TileWalk {
+    int ti, tend, step;
+    __device__ __forceinline__ explicit TileWalk(int N)
+    {
+        const int nt = (N + kTile - 1) / kTile;
+        if (((int)gridDim.x & 7) == 0) {
+            const int per = (nt + 7) >> 3, x = (int)blockIdx.x & 7;
+            ti = x * per + ((int)blockIdx.x >> 3);
+            tend = min((x + 1) * per, nt);
+            step = (int)gridDim.x >> 3;
+        } else {
+            ti = (int)blockIdx.x; tend = nt; step = (int)gridDim.x;
+        }
+    }
+};
+
 struct F4 { float x, y, z, w; };
 
 __device__ __forceinline__ F4 ld4(const float *p)
@@ -389,9 +411,16 @@ __device__ __forceinline__ void flush_stats(const float *red, double *stats)
 // kGatherJ = feature rows a lane group has in flight (4 VGPRs each): 8 where the registers are there (backward kernels:
 // 19 / 34 us against 20.5 / 36.5 with 4), 4 in gin_in_kernel, whose feat() carries two BatchNorm affines (8 spills 23
 // VGPRs there: 59.5 against 53.6 us).
-template <int kGatherJ, class Feat>
+#ifndef GATHER_DBG
+#define GATHER_DBG 0         // timing experiments only (wrong results): 1 no side-slot pass, 2 no row search, 4 no feature loads
+#endif
+// load(u) -> the raw 16 bytes of row u, xform(x) -> the feature (the BatchNorm affines of gin_in_kernel): kept apart so that
+// the kGatherJ loads of a round are all requested before the first transform -- with one callable doing both, the
+// transform's branch made the compiler wait for every load before requesting the next (4 round trips per round: 14 of
+// gin_in_kernel's 50 us, profiles/r3_gather_ablations.txt)
+template <int kGatherJ, class Load, class Xform>
 __device__ __forceinline__ void gather_tile(float *T, float *part /* [32 * H] */, int *prow /* [32] */, int nrows,
-                                            const int32_t *col_idx, Feat feat, float nbr_weight,
+                                            const int32_t *col_idx, Load load, Xform xform, float nbr_weight,
                                             const int *rp_lds /* [nrows + 1] */)
 {
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, gbase = lane_id() & ~15;
@@ -421,7 +450,7 @@ __device__ __forceinline__ void gather_tile(float *T, float *part /* [32 * H] */
         const bool valid = e < e1;
         const int idx = valid ? col_idx[e] : -1;
         int rid = 0;                                     // last r with rp_lds[r] <= e
-        if (valid) {
+        if (valid && !(GATHER_DBG & 2)) {
             int hi = nrows;
             while (hi - rid > 1) {
                 const int mid = (rid + hi) >> 1;
@@ -438,7 +467,9 @@ __device__ __forceinline__ void gather_tile(float *T, float *part /* [32 * H] */
                 rj[j] = wave_shfl(rid, gbase + eb + j);
             }
 #pragma unroll
-            for (int j = 0; j < kGatherJ; ++j) f[j] = feat(u[j] < 0 ? 0 : u[j]);   // branch free: all loads in flight
+            for (int j = 0; j < kGatherJ; ++j) f[j] = (GATHER_DBG & 4) ? F4{1.f, 1.f, 1.f, 1.f} : load(u[j] < 0 ? 0 : u[j]);   // branch free: all loads in flight
+#pragma unroll
+            for (int j = 0; j < kGatherJ; ++j) f[j] = xform(f[j]);
 #pragma unroll
             for (int j = 0; j < kGatherJ; ++j) {
                 if (u[j] >= 0) {                         // group-uniform
@@ -454,7 +485,7 @@ __device__ __forceinline__ void gather_tile(float *T, float *part /* [32 * H] */
     }
     flush(true);
     __syncthreads();
-    if (tid < H) {                                       // one wave, channel per lane: the side slots in group order
+    if (tid < H && !(GATHER_DBG & 1)) {                  // one wave, channel per lane: the side slots in group order
         for (int slot = 0; slot < 32; ++slot) {
             const int r = prow[slot];
             if (r >= 0) T[r * kLdt + tid] = fmaf(nbr_weight, part[slot * H + tid], T[r * kLdt + tid]);

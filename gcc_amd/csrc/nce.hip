@@ -84,17 +84,23 @@ __device__ __forceinline__ F4 rnd4(F4 v, bool on)
 // two fp32 values that are exactly representable in bf16 -> one packed pair (low half = first)
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u); }
 
-__device__ __forceinline__ F4 load_mem4_raw(const NceDev &a, int r, int c4);
-__device__ __forceinline__ F4 load_mem4(const NceDev &a, int r, int c4) { return rnd4(load_mem4_raw(a, r, c4), a.bf16 != 0); }
-__device__ __forceinline__ F4 load_mem4_raw(const NceDev &a, int r, int c4)
+// One unconditional 16-byte load per call (the ADDRESS is selected, not the load: with the load under branches the compiler
+// waited for each of a thread's four rows before requesting the next); rows >= K read row 0 and are zeroed by the caller.
+__device__ __forceinline__ const float *mem_row_ptr(const NceDev &a, int r)
 {
-    if (r >= a.K) { F4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
-    if (a.patch) {
+    const float *p = a.mem + (int64_t)(r < a.K ? r : 0) * D;
+    if (a.patch) {                                   // (uniform) queue rows already overwritten by the enqueue
         int rel = r - a.patch_index;
         if (rel < 0) rel += a.K;
-        if (rel < a.patch_rows) return ld4(a.patch + (int64_t)rel * D + c4);
+        if (r < a.K && rel < a.patch_rows) p = a.patch + (int64_t)rel * D;
     }
-    return ld4(a.mem + (int64_t)r * D + c4);
+    return p;
+}
+__device__ __forceinline__ F4 load_mem4(const NceDev &a, int r, int c4)
+{
+    F4 v = ld4(mem_row_ptr(a, r) + c4);
+    if (r >= a.K) { F4 z = {0.f, 0.f, 0.f, 0.f}; v = z; }
+    return rnd4(v, a.bf16 != 0);
 }
 
 template <bool kBwd, bool kBf16>
@@ -108,10 +114,13 @@ __global__ __launch_bounds__(kThreads) void nce_slice_kernel(NceDev a)
     const int qj = (int)blockIdx.y * kQPerBlock + 16 * wv + j;
     const bool qvalid = qj < a.B;
     F4 qf[4];
+    const float *qrow = a.q + (int64_t)(qvalid ? qj : 0) * D;      // (unconditional loads, masked afterwards)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[c] = ld4(qrow + 16 * c + 4 * q);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         F4 z = {0.f, 0.f, 0.f, 0.f};
-        qf[c] = qvalid ? rnd4(ld4(a.q + (int64_t)qj * D + 16 * c + 4 * q), kBf16) : z;
+        qf[c] = qvalid ? rnd4(qf[c], kBf16) : z;
     }
     // bf16 mode, forward logits on v_mfma_f32_16x16x32_bf16: lane (j, q) supplies 8 consecutive k of query j for the k-group q of
     // each 32-wide slab (the queue rows come from LDS the same way); the products of bf16 values are exact in fp32, so the
@@ -137,13 +146,24 @@ __global__ __launch_bounds__(kThreads) void nce_slice_kernel(NceDev a)
 #pragma unroll
         for (int db = 0; db < 4; ++db) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc2[db] = z; }
     }
+    // the next chunk of queue rows is requested while this one is being multiplied (a slice is 4 chunks: a round trip each)
+    F4 nxt[4];
+    auto request = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + kThreads * i, row = idx >> 4, c4 = (idx & 15) * 4;
+            nxt[i] = load_mem4(a, c0 + row, c4);
+        }
+    };
+    if (row_beg < row_end) request(row_beg);
     for (int c0 = row_beg; c0 < row_end; c0 += kChunk) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + kThreads * i, row = idx >> 4, c4 = (idx & 15) * 4;
-            st4(&Ms[row * kLd + c4], load_mem4(a, c0 + row, c4));
+            st4(&Ms[row * kLd + c4], nxt[i]);
         }
         __syncthreads();
+        if (c0 + kChunk < row_end) request(c0 + kChunk);
         for (int t = 0; t < 4; ++t) {
             if (c0 + 16 * t >= row_end) break;      // block-uniform
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};

@@ -4,7 +4,7 @@ set -u
 O=gpurun_out/r3c23
 mkdir -p $O
 export TMPDIR=/tmp GCC_AMD_GRAPH_CACHE=/tmp/graphs
-(timeout 900 python -m pytest tests/test_encoder_gpu.py tests/test_train_step_gpu.py -m gpu -q --tb=short 2>&1 | tail -30) > $O/pytest.log
+(timeout 900 python -m pytest tests/test_encoder_gpu.py tests/test_train_step_gpu.py tests/test_pipeline_gpu.py -m gpu -q --tb=short 2>&1 | tail -30) > $O/pytest.log
 grep -E "passed|failed" $O/pytest.log
 (timeout 300 python tools/graph_probe.py --steps 200 2>&1 | tail -1) > $O/probe.txt
 cat $O/probe.txt

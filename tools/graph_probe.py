@@ -23,7 +23,13 @@ from gcc_amd.train_step import MoCoTrainStep
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--lib", default=None, help="an ablation build of the library (timing experiments, e.g. -DGIN_DBG_SKIP=1)")
 a = ap.parse_args()
+if a.lib:
+    import ctypes
+
+    from gcc_amd import _cabi
+    _cabi._lib = _cabi.declare(ctypes.CDLL(os.path.abspath(a.lib)))
 dev = torch.device("cuda:0")
 rp, ci = powerlaw_graph(1_000_000, 10_000_000, seed=0)
 graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False)
