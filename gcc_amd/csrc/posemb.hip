@@ -155,6 +155,42 @@ __device__ __forceinline__ bool defl_collapsed(const Defl &d, int i)
     const int h = d.phub[i];
     return h != (int)kNone && d.pcnt[h] >= 2 && d.prep[h] != (uint16_t)i;
 }
+// Reduced indices and contrast bases of all n nodes (after the three table passes): block-wide prefix sums over kept
+// flags / twin contrasts / stalk contrasts, kT nodes at a time, in node order.  (Thread 0 walking the n nodes alone was
+// 17 us of the 65..128 class's items and 150 us of the sparse block class's, n up to 1024.)  ALL threads call it;
+// tot[0..2] (LDS) = n', z, zp after the trailing barrier; wsum = LDS scratch [3 * kT / 64].
+template <int kT>
+__device__ __forceinline__ void defl_prefix_block(const Defl &d, int n, int *tot /* [3] */, int *wsum)
+{
+    constexpr int kNW = kT / 64;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 3) tot[tid] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += kT) {
+        const int i = i0 + tid;
+        const bool valid = i < n;
+        const int tc = valid ? d.tcnt[i] : 0, pc = valid ? d.pcnt[i] : 0;
+        const int extra = tc >= 2 ? tc - 1 : 0, pextra = pc >= 2 ? pc - 1 : 0;
+        const int kept = valid && !defl_collapsed(d, i) ? 1 : 0;
+        const int sa = wave_scan_incl(kept), sb = wave_scan_incl(extra), sc = wave_scan_incl(pextra);
+        if (lane == 63) { wsum[wv] = sa; wsum[kNW + wv] = sb; wsum[2 * kNW + wv] = sc; }
+        __syncthreads();
+        int pa = tot[0], pb = tot[1], pcs = tot[2];
+        for (int q = 0; q < wv; ++q) { pa += wsum[q]; pb += wsum[kNW + q]; pcs += wsum[2 * kNW + q]; }
+        if (valid) {
+            d.cbase[i] = (pb + sb - extra) | ((pcs + sc - pextra) << 16);
+            d.ridx[i] = kept ? (uint16_t)(pa + sa - 1) : kNone;
+        }
+        __syncthreads();
+        if (tid < 3) {
+            int t = tot[tid];
+            for (int q = 0; q < kNW; ++q) t += wsum[tid * kNW + q];
+            tot[tid] = t;
+        }
+        __syncthreads();
+    }
+}
+
 // factor on 1 / sqrt(d_i d_j) for the coupling of two KEPT neighbours
 __device__ __forceinline__ float defl_coupling(const Defl &d, int i, int j)
 {
@@ -1483,7 +1519,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     DYN_SMEM(smem);
     __shared__ EigShared es;
     __shared__ int colsrc[64];                  // per output column: eigenvector j >= 0, or -(c + 1) for contrast c
-    __shared__ int sh_np, sh_z, sh_zp, sh_na, sh_item;
+    __shared__ int sh_tot[3], sh_na, sh_item;
     constexpr int kNW = kT / 64, kCPL = kNMax / 64;
     constexpr int lda = kGlobalA ? kNMax : kNMax + 1;   // LDS: odd stride; workspace: rows start on 256-byte boundaries
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1531,20 +1567,8 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     __syncthreads();
     for (int p = tid; p < n; p += kT) defl_order_node(d, p, rp, a.col_idx, n0);
     __syncthreads();
-    if (tid == 0) {                                // n <= 1024: a serial prefix is a few microseconds
-        int r = 0, c = 0, cp = 0;
-        for (int i = 0; i < n; ++i) {
-            d.cbase[i] = c | (cp << 16);
-            if (d.tcnt[i] >= 2) c += d.tcnt[i] - 1;
-            if (d.pcnt[i] >= 2) cp += d.pcnt[i] - 1;
-            d.ridx[i] = defl_collapsed(d, i) ? kNone : (uint16_t)r++;
-        }
-        sh_np = r;
-        sh_z = c;
-        sh_zp = cp;
-    }
-    __syncthreads();
-    const int nr = sh_np, z = sh_z, zp = sh_zp;    // reduced size n', number of twin / stalk contrasts
+    defl_prefix_block<kT>(d, n, sh_tot, w.cnt);    // (w.cnt: kT ints of LDS that are free until the bisection)
+    const int nr = sh_tot[0], z = sh_tot[1], zp = sh_tot[2];    // reduced size n', number of twin / stalk contrasts
     if (nr > kNMax || nr < kNMin) continue;        // cannot happen: the classify kernel computed the same size
     if (kGlobalA) A = kCls == kClsBig ? hd.bslots + (int64_t)blockIdx.x * hd.bslot_floats
                                       : hd.slots + (int64_t)blockIdx.x * hd.slot_floats;   // the workgroup's own slot
@@ -2194,7 +2218,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     __shared__ int longrow[kChMaxLong], longfirst[kChMaxLong + 1];
     __shared__ int chunk_beg[kChMaxChunks + 1];
     __shared__ int wsum[kChThreads / 64 + 1];
-    __shared__ int sh_item, sh_np, sh_z, sh_zp, sh_nlong, sh_nchunk, sh_fail;
+    __shared__ int sh_item, sh_tot[3], sh_nlong, sh_nchunk, sh_fail;
     __shared__ int colsrc[64];
     constexpr int kCls = kClsCheb;
     const PosMulti &m = ca.m;
@@ -2233,20 +2257,8 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     __syncthreads();
     for (int p = tid; p < n; p += kChThreads) defl_order_node(d, p, rp, a.col_idx, n0);
     __syncthreads();
-    if (tid == 0) {
-        int r = 0, c = 0, cp = 0;
-        for (int i = 0; i < n; ++i) {
-            d.cbase[i] = c | (cp << 16);
-            if (d.tcnt[i] >= 2) c += d.tcnt[i] - 1;
-            if (d.pcnt[i] >= 2) cp += d.pcnt[i] - 1;
-            d.ridx[i] = defl_collapsed(d, i) ? kNone : (uint16_t)r++;
-        }
-        sh_np = r;
-        sh_z = c;
-        sh_zp = cp;
-    }
-    __syncthreads();
-    const int nr = sh_np, z = sh_z, zp = sh_zp;
+    defl_prefix_block<kChThreads>(d, n, sh_tot, (int *)slab);
+    const int nr = sh_tot[0], z = sh_tot[1], zp = sh_tot[2];
     // ---- sparse M' = diag(scale) A' diag(scale): rows of the kept nodes, columns ascending; a super-leaf standing for t
     //      twins carries sqrt(t) (its coupling to the parent is sqrt(t / d_p), data_util.py:273-277 on the quotient); the
     //      stalk standing for s stalks carries sqrt(s / 2) on its middle node and 1 / sqrt(s) on its leaf (couplings
