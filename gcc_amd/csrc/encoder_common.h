@@ -15,12 +15,14 @@ constexpr int kRep = 32;            // replicas of every atomically accumulated 
                                     // copy (blockIdx.x % kRep), consumers sum the copies -- ~730 workgroups hitting the
                                     // same 8 cache lines with fp64 atomics cost 20-40 us per kernel (rocprof, round 1)
 
-// ---- XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 (8 XCDs, each with its own 4 MiB L2), so with
-// tile = blockIdx.x every XCD touched every subgraph and the neighbour rows a tile gathers (rows of its own subgraphs,
-// written by other tiles) came through the fabric: ~60 MB per gin_in launch, 26 of its 50 us.  Here XCD x walks the
-// contiguous tiles [x * per, (x + 1) * per), per = ceil(tiles / 8): a tile's neighbours were written (and are re-read) by
-// workgroups of the same XCD.  Every tile kernel of the forward and backward pass uses the same walk, so a tile's own rows
-// also stay in one L2 from producer to consumer.
+// ---- XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 (8 XCDs, each with its own 4 MiB L2); with
+// tile = blockIdx.x every XCD touches every subgraph, so the neighbour rows a tile gathers (rows of its own subgraphs,
+// written by other tiles) come from other XCDs' tiles.  Here XCD x walks the contiguous tiles [x * per, (x + 1) * per),
+// per = ceil(tiles / 8), and every tile kernel of the forward and backward pass uses the same walk, so a tile's own rows
+// and its neighbours' stay in one L2 from producer to consumer.  Measured at bsz 256 (13 MB of activations, all of it in
+// the 256 MiB Infinity Cache either way): no difference, 0.720 vs 0.716 ms per step (scripts/gpu/r3_call23.sh) -- what the
+// gather waited for was its own serialised loads (gather_tile below), not the fabric.  Kept: it is the mapping the guide
+// recommends and it cannot hurt larger batches.
 struct TileWalk {
     int ti, tend, step;
     __device__ __forceinline__ explicit TileWalk(int N)
