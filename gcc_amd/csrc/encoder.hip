@@ -105,7 +105,8 @@ struct InLaunch { InArgs p[kMaxPass]; long long *ticks; };
 static long long *g_gin_ticks = nullptr;   // diagnostics (gcc_gin_debug_ticks)
 #define GIN_TICK(ph) do { if (L.ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&L.ticks[(a.first ? 0 : 16) + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 
-__global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
+// (3 workgroups per CU by LDS -- 48.8 KiB with the staged weight -- so up to 168 registers are free: 8 gathered rows in flight)
+__global__ __launch_bounds__(kThreads, 3) void gin_in_kernel(InLaunch L)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kThreads, 4) void gin_in_kernel(InLaunch L)
         GIN_TICK(2);
         // 3. GINConv aggregate: (1 + eps) * h_v + sum_{u -> v} h_u, eps = 0 (gin.py:179-185,218)
 #if !(GIN_DBG_SKIP & 4)
-        gather_tile<4>(T, part, prow, nrows, a.col_idx, load, xform, a.nbr_weight, rpl);
+        gather_tile<8>(T, part, prow, nrows, a.col_idx, load, xform, a.nbr_weight, rpl);
 #endif
         GIN_TICK(3);
         // 4. keep agg for the weight gradient of linears.0
