@@ -461,7 +461,7 @@ __global__ void ginw_pack_kernel(const uint16_t *w, uint16_t *wf, int which)
     *(u32x4 *)(wf + (int64_t)idx * 8) = *(const u32x4 *)(w + (int64_t)row * kD + ks * 32 + lg * 8);
 }
 
-// kDbg (timing experiments only, wrong results; GCC_GINW_DBG): 1 no epilogue arithmetic (one store per product keeps the
+// kDbg (timing experiments only, wrong results; builds with -DGCC_GINW_ABLATE select them by GCC_GINW_DBG): 1 no epilogue arithmetic (one store per product keeps the
 // accumulators alive), 2 no weight requests inside the products, 4 no operand-fragment reads inside the k loops
 // (measured: epilogues 25 % of the launch, requests 15 % row-major / 2 % fragment-major, fragment reads 2 %).
 template <int kDbg, bool kFrag>
@@ -830,26 +830,28 @@ extern "C" int32_t gcc_ginw_forward(const gcc_ginw_args *g, int32_t *status, gcc
         (void)hipFuncSetAttribute((const void *)gin_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
         (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
+#ifdef GCC_GINW_ABLATE                                       // timing-only builds (make EXTRA=-DGCC_GINW_ABLATE): never in the shipped library
         (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
         (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
         (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
         (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
+#endif
 #endif
     }
     prof_mark(prof, 0, s);
     // one workgroup per CU (137 / 148 KB of LDS each), walking the subgraphs with a stride of the grid
     if (shape == 1) hipLaunchKernelGGL(gin_wide_kernel, dim3(min(g->batch_size, 256)), dim3(kThreads), kLdsBytes, s, a);
     else {
-        static int dbg = -1;
-        if (dbg < 0) { const char *e = getenv("GCC_GINW_DBG"); dbg = e ? atoi(e) : 0; }
         bool frag = true;                                    // every layer carries the fragment-major copies?
         for (int i = 0; i < g->num_layers; ++i) frag = frag && g->layers[i].w0_frag && g->layers[i].w1_frag;
         const dim3 grid(min(g->batch_size, 256)), block(kT2);
         if (!frag) hipLaunchKernelGGL((gin_wide2_kernel<0, false>), grid, block, kLds2, s, a);
-        else if (dbg == 1) hipLaunchKernelGGL((gin_wide2_kernel<1, true>), grid, block, kLds2, s, a);
-        else if (dbg == 2) hipLaunchKernelGGL((gin_wide2_kernel<2, true>), grid, block, kLds2, s, a);
-        else if (dbg == 4) hipLaunchKernelGGL((gin_wide2_kernel<4, true>), grid, block, kLds2, s, a);
-        else if (dbg == 7) hipLaunchKernelGGL((gin_wide2_kernel<7, true>), grid, block, kLds2, s, a);
+#ifdef GCC_GINW_ABLATE
+        else if (getenv("GCC_GINW_DBG") && atoi(getenv("GCC_GINW_DBG")) == 1) hipLaunchKernelGGL((gin_wide2_kernel<1, true>), grid, block, kLds2, s, a);
+        else if (getenv("GCC_GINW_DBG") && atoi(getenv("GCC_GINW_DBG")) == 2) hipLaunchKernelGGL((gin_wide2_kernel<2, true>), grid, block, kLds2, s, a);
+        else if (getenv("GCC_GINW_DBG") && atoi(getenv("GCC_GINW_DBG")) == 4) hipLaunchKernelGGL((gin_wide2_kernel<4, true>), grid, block, kLds2, s, a);
+        else if (getenv("GCC_GINW_DBG") && atoi(getenv("GCC_GINW_DBG")) == 7) hipLaunchKernelGGL((gin_wide2_kernel<7, true>), grid, block, kLds2, s, a);
+#endif
         else hipLaunchKernelGGL((gin_wide2_kernel<0, true>), grid, block, kLds2, s, a);
     }
     prof_mark(prof, 1, s);
