@@ -169,3 +169,30 @@ def test_host_side_folding_equals_the_oracle_folding():
         np.testing.assert_allclose(t.numpy(), want[kt], rtol=1e-6, atol=1e-7)
     with pytest.raises(RuntimeError, match="GPU only"):
         FoldedWideGIN.from_gin(gin, "cpu")
+
+
+def test_pack_weights_layout_is_the_one_the_header_documents():
+    """include/gcc_amd.h, gcc_ginw_pack_weights: fragment (w, m, ks) is 1 KiB contiguous at ((w * 4 + m) * 8 + ks) * 512
+    elements, lane (16 lg + lr) holding W[row][32 ks + 8 lg .. + 7]; which = 0: row = 64 w + 32 (m / 2) + 2 lr + m % 2,
+    which = 1: row = 64 w + 16 m + lr."""
+    from tests.hipemu.emu_driver import emu_lib
+
+    lib = emu_lib()
+    rng = np.random.default_rng(3)
+    w = rng.integers(0, 1 << 16, size=(D, D), dtype=np.uint16)
+    for which in (0, 1):
+        got = np.zeros(D * D, dtype=np.uint16)
+        assert lib.gcc_ginw_pack_weights(w.ctypes.data, got.ctypes.data, which, None) == 0
+        want = np.zeros(D * D, dtype=np.uint16)
+        for wb in range(4):
+            for m in range(4):
+                for ks in range(8):
+                    base = ((wb * 4 + m) * 8 + ks) * 512
+                    for lg in range(4):
+                        for lr in range(16):
+                            row = 64 * wb + (32 * (m // 2) + 2 * lr + m % 2 if which == 0 else 16 * m + lr)
+                            lane = 16 * lg + lr
+                            want[base + 8 * lane: base + 8 * lane + 8] = w[row, 32 * ks + 8 * lg: 32 * ks + 8 * lg + 8]
+        np.testing.assert_array_equal(got, want)
+    assert lib.gcc_ginw_pack_weights(None, got.ctypes.data, 0, None) != 0          # bad arguments are refused
+    assert lib.gcc_ginw_pack_weights(w.ctypes.data, got.ctypes.data, 2, None) != 0
