@@ -288,12 +288,12 @@ def _stalky(rng, core, p, hubs, n_twins=()):
     return nxt, edges
 
 
-@pytest.mark.parametrize("wave", ["0", "1"])
-def test_stalk_deflation_in_every_solver_class(wave, monkeypatch):
-    """Pendant two-paths are deflated exactly in the one-wave teams, the block classes and the sparse block class: stalk
-    groups on several hubs (sizes 2..40), twin leaves on the same hubs, a hub that is a path end, top-k cuts inside the
-    1/sqrt(2) cluster, and tiny graphs whose k = n - 2 reaches the null space and the -1/sqrt(2) copies."""
-    monkeypatch.setenv("GCC_POSEMB_WAVE", wave)
+def stalky_view():
+    """Graphs with pendant two-paths for every solver class: stalk groups on several hubs (sizes 2..40), twin leaves on the
+    same hubs, top-k cuts inside the 1/sqrt(2) cluster, and tiny graphs whose k = n - 2 reaches the null space and the
+    -1/sqrt(2) copies.  -> (view, deflated sizes with stalks, with twin leaves only)"""
+    import scipy.sparse as sp
+
     rng = np.random.RandomState(11)
     blocks = []
     blocks.append((7, [(0, 1), (1, 2), (0, 3), (3, 4), (0, 5), (5, 6)]))                   # spider: 3 stalks, k = 5
@@ -302,7 +302,6 @@ def test_stalk_deflation_in_every_solver_class(wave, monkeypatch):
     blocks.append(_stalky(rng, 30, 0.15, [(0, 12), (3, 2), (7, 5)], [(0, 6), (9, 2)]))     # wave / small class
     blocks.append(_stalky(rng, 60, 0.08, [(0, 40), (1, 17), (2, 9)], [(0, 30), (5, 4)]))   # n' ~ 70 after, ~190 before: mid class
     blocks.append(_stalky(rng, 150, 0.03, [(0, 25), (10, 3), (20, 14)], [(4, 9)]))         # n' ~ 160: sparse block class
-    import scipy.sparse as sp
     node_off, rows, cols = [0], [], []
     for n, edges in blocks:
         o = node_off[-1]
@@ -317,6 +316,15 @@ def test_stalk_deflation_in_every_solver_class(wave, monkeypatch):
                 col_idx=torch.from_numpy(a.indices.astype(np.int64)))
     red, red0 = reduced_sizes(view), reduced_sizes(view, stalks=False)
     assert (red0 - red >= 2).all() and 64 < red[4] <= 128 < red0[4] and red[5] > 128, (red, red0)
+    return view, red, red0
+
+
+@pytest.mark.parametrize("wave", ["0", "1"])
+def test_stalk_deflation_in_every_solver_class(wave, monkeypatch):
+    """Pendant two-paths are deflated exactly in the one-wave teams, the block classes and the sparse block class
+    (stalky_view); STRICT invariants."""
+    monkeypatch.setenv("GCC_POSEMB_WAVE", wave)
+    view, red, red0 = stalky_view()
     x, evals, raw = _run(view)
     assert _run.arnoldi_steps == 0 and _run.status[3] == 0 and _run.status[1] >= 2, _run.status
     assert np.sum(np.abs(evals[4] - 2 ** -0.5) < 1e-5) >= 20

@@ -63,6 +63,26 @@ def test_hub_seeds():
     check_by_path(view, x, evals, raw)
 
 
+def test_stalk_deflation_on_device():
+    """The synthetic stalk graphs of the emulator tier (pendant two-paths on several hubs, twin leaves beside them, tiny graphs
+    that reach the -1/sqrt(2) copies) through the device kernels: one-wave teams, 65..128 class and the sparse block class."""
+    from gcc_amd.sampler import BatchedCSR
+    from tests.test_posemb_emu import _check, stalky_view
+
+    view, red, _ = stalky_view()
+    no, rp, ci = (view[k].numpy() for k in ("node_off", "row_ptr", "col_idx"))
+    B, n = len(no) - 1, int(no[-1])
+    i32 = dict(dtype=torch.int32, device="cuda")
+    q = BatchedCSR(B, torch.from_numpy(no.astype(np.int32)).cuda(), torch.from_numpy(rp[no].astype(np.int32)).cuda(),
+                   torch.zeros(n, **i32), torch.from_numpy(np.repeat(np.arange(B), np.diff(no)).astype(np.int32)).cuda(),
+                   torch.from_numpy(rp.astype(np.int32)).cuda(), torch.from_numpy(ci.astype(np.int32)).cuda())
+    q.pos_undirected = torch.zeros(n, HID, device="cuda")
+    _, x, evals, raw = _device_posemb(q, B)
+    assert _device_posemb.arnoldi_steps == 0
+    assert np.sum(np.abs(evals[4] - 2 ** -0.5) < 1e-5) >= 20          # the contrast copies carry the exact value
+    _check(view, x, evals, raw)
+
+
 def test_krylov_fallback_on_device():
     """No twin leaves, n = 760 > GCC_POSEMB_BIG_MAX: the Krylov-Schur kernel runs (same case as the emulator test)."""
     import scipy.sparse as sp
