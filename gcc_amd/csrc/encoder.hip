@@ -371,14 +371,16 @@ __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
     for (int i = wv; i <= a.nlayers; i += 4) {
         const int kd = i == 0 ? a.kdim0 : H;
         F4 xb[4];
+        const double *prow = a.pooled + ((int64_t)i * a.B + (valid ? b : 0)) * H + 4 * q;   // (unconditional loads, masked afterwards)
+        double pd[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pd[c][e] = prow[16 * c + e];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            F4 x = {0.f, 0.f, 0.f, 0.f};
-            if (valid) {
-                const double *pl = a.pooled + ((int64_t)i * a.B + b) * H + 16 * c + 4 * q;
-                x.x = (float)pl[0]; x.y = (float)pl[1]; x.z = (float)pl[2]; x.w = (float)pl[3];
-            }
-            xb[c] = x;
+            const F4 x = {(float)pd[c][0], (float)pd[c][1], (float)pd[c][2], (float)pd[c][3]}, z = {0.f, 0.f, 0.f, 0.f};
+            xb[c] = valid ? x : z;
         }
         F4 wf[4][4];
         load_w_frags(a.pred_w[i], kd, wf);

@@ -96,9 +96,9 @@ __device__ __forceinline__ const float *mem_row_ptr(const NceDev &a, int r)
     }
     return p;
 }
-__device__ __forceinline__ F4 load_mem4(const NceDev &a, int r, int c4)
+// what follows a queue-row load once ALL loads of the batch have been requested: rows past the end are zeros, bf16 mode rounds
+__device__ __forceinline__ F4 finish_mem4(const NceDev &a, F4 v, int r)
 {
-    F4 v = ld4(mem_row_ptr(a, r) + c4);
     if (r >= a.K) { F4 z = {0.f, 0.f, 0.f, 0.f}; v = z; }
     return rnd4(v, a.bf16 != 0);
 }
@@ -148,11 +148,11 @@ __global__ __launch_bounds__(kThreads) void nce_slice_kernel(NceDev a)
     }
     // the next chunk of queue rows is requested while this one is being multiplied (a slice is 4 chunks: a round trip each)
     F4 nxt[4];
-    auto request = [&](int c0) {
+    auto request = [&](int c0) {                     // raw loads only: zeroing / rounding wait until the chunk is stored
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + kThreads * i, row = idx >> 4, c4 = (idx & 15) * 4;
-            nxt[i] = load_mem4(a, c0 + row, c4);
+            nxt[i] = ld4(mem_row_ptr(a, c0 + row) + c4);
         }
     };
     if (row_beg < row_end) request(row_beg);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kThreads) void nce_slice_kernel(NceDev a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + kThreads * i, row = idx >> 4, c4 = (idx & 15) * 4;
-            st4(&Ms[row * kLd + c4], nxt[i]);
+            st4(&Ms[row * kLd + c4], finish_mem4(a, nxt[i], c0 + row));
         }
         __syncthreads();
         if (c0 + kChunk < row_end) request(c0 + kChunk);
@@ -204,10 +204,15 @@ __global__ __launch_bounds__(kThreads) void nce_slice_kernel(NceDev a)
                     m = mn;
                 }
             } else {
+                float lse_r[4] = {my_lse, my_lse, my_lse, my_lse};
+                if (a.by_mem_row) {                          // (uniform) E2E: the softmax runs over the other view's rows
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lse_r[r] = a.lse[min(row0 + r, a.K - 1)];      // four loads requested together
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float p = 0.f;
-                    if (qvalid && lv[r] > -INFINITY) p = expf(lv[r] - (a.by_mem_row ? a.lse[row0 + r] : my_lse));
+                    if (qvalid && lv[r] > -INFINITY) p = expf(lv[r] - lse_r[r]);
                     // second GEMM: dq[query][d] += p[row][query] * mem[row][d]; this lane's p is the
                     // B operand (k = q <-> row 4q + r, column j = query)
 #pragma unroll
