@@ -282,11 +282,17 @@ __global__ __launch_bounds__(kThreads) void gin_stat_kernel(StatLaunch L)
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
         const int tile0 = tw.ti * kTile;
         any = true;
-        for (int r = tile0 + gi; r < min(tile0 + kTile, N); r += 16) {
-            const F4 y = affine_relu(ld4(a.z2 + (int64_t)r * H + 4 * t), ab);
-            s = add4(s, y);
-            ss.x = fmaf(y.x, y.x, ss.x); ss.y = fmaf(y.y, y.y, ss.y);
-            ss.z = fmaf(y.z, y.z, ss.z); ss.w = fmaf(y.w, y.w, ss.w);
+        F4 z4[kTile / 16];                           // the lane group's 4 rows, requested together
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i) z4[i] = ld4(a.z2 + (int64_t)min(tile0 + gi + 16 * i, N - 1) * H + 4 * t);
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i) {
+            if (tile0 + gi + 16 * i < N) {
+                const F4 y = affine_relu(z4[i], ab);
+                s = add4(s, y);
+                ss.x = fmaf(y.x, y.x, ss.x); ss.y = fmaf(y.y, y.y, ss.y);
+                ss.z = fmaf(y.z, y.z, ss.z); ss.w = fmaf(y.w, y.w, ss.w);
+            }
         }
     }
     if (any) {            // block-uniform
@@ -384,12 +390,15 @@ __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
         }
         F4 wf[4][4];
         load_w_frags(a.pred_w[i], kd, wf);
+        F4 bias4[4];                                               // (requested with the weights, not one by one in the epilogue)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) bias4[cb] = ld4(a.pred_b[i] + 16 * cb + 4 * q);
         f32x4 acc[4];
         mfma_rows16(xb, wf, acc);                                  // linears_prediction[i](pooled_h)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
             const int ch = 16 * cb + 4 * q;
-            const F4 bias = ld4(a.pred_b[i] + ch);
+            const F4 bias = bias4[cb];
             const F4 m = valid ? drop_mul4(a.drop, i, b, ch) : bias;   // self.drop, gin.py:230
             score[cb].x += (acc[cb][0] + bias.x) * m.x;
             score[cb].y += (acc[cb][1] + bias.y) * m.y;

@@ -234,16 +234,32 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_c_kernel(BwdCArgs a)
             __syncthreads();
             gather_tile<8>(T, part, prow, nrows, a.col_idx, ident, [](F4 x) { return x; }, 1.0f, rpl);
         }
-        for (int r = gi; r < nrows; r += 16) {
-            const int v = tile0 + r;
-            F4 g = ld4(a.dpooled + (int64_t)a.graph_id[v] * H + 4 * t);
-            if (a.D) g = add4(g, ld4(&T[r * kLdt + 4 * t]));
-            const F4 y2 = relu4(fma4(ld4(a.z2 + (int64_t)v * H + 4 * t), pbs, pbh));
-            const F4 yh = fma4(y2, rcs, rcm);
-            const F4 u = mask4(g, fma4(y2, pcs, pch));
-            st4(a.U + (int64_t)v * H + 4 * t, u);
-            s1 = add4(s1, u);
-            s2 = fma4(u, yh, s2);
+        {   // the lane group's 4 rows: graph ids, then pooled-path gradients and z2 rows, each batch requested together
+            // (a loop over r with its loads inside ran 8 dependent round trips)
+            int gid4[kTile / 16];
+            F4 g4[kTile / 16], z4[kTile / 16];
+#pragma unroll
+            for (int i = 0; i < kTile / 16; ++i) gid4[i] = a.graph_id[min(tile0 + gi + 16 * i, N - 1)];
+#pragma unroll
+            for (int i = 0; i < kTile / 16; ++i) {
+                const int v = min(tile0 + gi + 16 * i, N - 1);
+                g4[i] = ld4(a.dpooled + (int64_t)gid4[i] * H + 4 * t);
+                z4[i] = ld4(a.z2 + (int64_t)v * H + 4 * t);
+            }
+#pragma unroll
+            for (int i = 0; i < kTile / 16; ++i) {
+                const int r = gi + 16 * i, v = tile0 + r;
+                if (r < nrows) {
+                    F4 g = g4[i];
+                    if (a.D) g = add4(g, ld4(&T[r * kLdt + 4 * t]));
+                    const F4 y2 = relu4(fma4(z4[i], pbs, pbh));
+                    const F4 yh = fma4(y2, rcs, rcm);
+                    const F4 u = mask4(g, fma4(y2, pcs, pch));
+                    st4(a.U + (int64_t)v * H + 4 * t, u);
+                    s1 = add4(s1, u);
+                    s2 = fma4(u, yh, s2);
+                }
+            }
         }
         __syncthreads();
     }
@@ -281,15 +297,26 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_b_kernel(BwdBArgs a)
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
         const int tile0 = tw.ti * kTile;
         any = true;
-        for (int v = tile0 + gi; v < min(tile0 + kTile, N); v += 16) {
-            const F4 z = ld4(a.z2 + (int64_t)v * H + 4 * t);
-            const F4 pre = fma4(z, pbs, pbh);
-            const F4 y2 = relu4(pre);
-            const F4 dy2 = fma4(ld4(a.U + (int64_t)v * H + 4 * t), k1, fma4(y2, k2, k3));   // BN_c backward
-            const F4 vv = mask4(dy2, pre);
-            st4(a.V + (int64_t)v * H + 4 * t, vv);
-            s1 = add4(s1, vv);
-            s2 = fma4(vv, fma4(z, rbs, rbm), s2);
+        F4 z4[kTile / 16], u4[kTile / 16];          // the lane group's 4 rows of z2 and U, requested together
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i) {
+            const int64_t off = (int64_t)min(tile0 + gi + 16 * i, N - 1) * H + 4 * t;
+            z4[i] = ld4(a.z2 + off);
+            u4[i] = ld4(a.U + off);
+        }
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i) {
+            const int v = tile0 + gi + 16 * i;
+            if (v < N) {
+                const F4 z = z4[i];
+                const F4 pre = fma4(z, pbs, pbh);
+                const F4 y2 = relu4(pre);
+                const F4 dy2 = fma4(u4[i], k1, fma4(y2, k2, k3));   // BN_c backward
+                const F4 vv = mask4(dy2, pre);
+                st4(a.V + (int64_t)v * H + 4 * t, vv);
+                s1 = add4(s1, vv);
+                s2 = fma4(vv, fma4(z, rbs, rbm), s2);
+            }
         }
     }
     if (!any) return;
