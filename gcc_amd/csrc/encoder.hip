@@ -58,25 +58,45 @@ __global__ __launch_bounds__(kThreads) void gin_feat_kernel(FeatLaunch L)
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
         const int tile0 = tw.ti * kTile;
         const int nrows = min(kTile, N - tile0);
-        for (int r = gi; r < nrows; r += 16) {
-            {
-                F4 x;
-                const int v = tile0 + r;
-                const int deg = (a.row_ptr[v + 1] - a.row_ptr[v]) * a.mult;          // g.in_degrees(), :154
-                const int dcl = deg < a.max_degree ? deg : a.max_degree;  // clamp(0, max_degree), :161
-                const int gv = a.graph_id[v];
-                const bool is_seed = v == a.node_off[gv] + (a.seed_local ? a.seed_local[gv] : 0);   // ndata["seed"], data_util.py:234-238
+        // the lane group's 4 rows in two round trips (row extents and graph ids; then everything that depends on them),
+        // every load unconditional with a clamped address: one row at a time this was 3 dependent round trips per row
+        constexpr int kR = kTile / 16;
+        int vv[kR], r0[kR], r1[kR], gv[kR];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = 4 * t + e;
-                    float val = 0.f;
-                    if (c < a.pos_dim) val = a.pos[(int64_t)v * a.pos_dim + c];
-                    else if (c < a.pos_dim + a.emb_dim) val = a.emb[(int64_t)dcl * a.emb_dim + (c - a.pos_dim)];
-                    else if (c == a.pos_dim + a.emb_dim) val = is_seed ? 1.f : 0.f;
-                    at(x, e) = val;
-                }
-                st4(a.x0 + (int64_t)v * H + 4 * t, x);
+        for (int i = 0; i < kR; ++i) {
+            vv[i] = min(tile0 + gi + 16 * i, N - 1);
+            r0[i] = a.row_ptr[vv[i]];
+            r1[i] = a.row_ptr[vv[i] + 1];
+            gv[i] = a.graph_id[vv[i]];
+        }
+        int first[kR], sl[kR];
+        float val[kR][4];
+        const int dtot = a.pos_dim + a.emb_dim;
+#pragma unroll
+        for (int i = 0; i < kR; ++i) {
+            const int deg = (r1[i] - r0[i]) * a.mult;                         // g.in_degrees(), :154
+            const int dcl = deg < a.max_degree ? deg : a.max_degree;          // clamp(0, max_degree), :161
+            first[i] = a.node_off[gv[i]];
+            sl[i] = a.seed_local ? a.seed_local[gv[i]] : 0;                   // (block-uniform branch)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * t + e;
+                const float *src = c < a.pos_dim ? a.pos + (int64_t)vv[i] * a.pos_dim + c
+                                                 : a.emb + (int64_t)dcl * a.emb_dim + (c < dtot ? c - a.pos_dim : 0);
+                val[i][e] = *src;
             }
+        }
+#pragma unroll
+        for (int i = 0; i < kR; ++i) {
+            if (gi + 16 * i >= nrows) continue;
+            const bool is_seed = vv[i] == first[i] + sl[i];                   // ndata["seed"], data_util.py:234-238
+            F4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * t + e;
+                at(x, e) = c < dtot ? val[i][e] : (c == dtot && is_seed ? 1.f : 0.f);
+            }
+            st4(a.x0 + (int64_t)vv[i] * H + 4 * t, x);
         }
     }
 }
@@ -116,8 +136,7 @@ __global__ __launch_bounds__(kThreads, 3) void gin_in_kernel(InLaunch L)
     __shared__ int rpl[kTile + 1], gidl[kTile];
     const InArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
-    const int N = a.node_off[a.B];
-    const double dn = (double)N;
+    int N;
     __shared__ float tabb[2 * H], tabc[2 * H];
 #if GIN_IN_LDS_W
     __shared__ float Wl[H * kLdt];                 // linears.0 weight, staged once per workgroup
@@ -129,8 +148,13 @@ __global__ __launch_bounds__(kThreads, 3) void gin_in_kernel(InLaunch L)
         const WStage wst = stage_weights_request(a.w0, a.kdim);     // in flight with N and the statistics
 #endif
         if (!a.first) {                            // block-uniform
-            bn_table(tabb, a.bnb, dn, a.eps, a.training, (double *)part);
-            bn_table(tabc, a.bnc, dn, a.eps, a.training, (double *)part);
+            const BnReq rb = bn_request(a.bnb), rc = bn_request(a.bnc);
+            N = a.node_off[a.B];                   // (requested after the statistics: the wait for it is the wait for all)
+            SCHED_FENCE();
+            bn_table_finish(tabb, rb, (double)N, a.eps, a.training, (double *)part);
+            bn_table_finish(tabc, rc, (double)N, a.eps, a.training, (double *)part);
+        } else {
+            N = ((const volatile int32_t *)a.node_off)[a.B];       // (volatile: an ordinary load is hoisted above the branch, ahead of the other arm's requests)
         }
 #if GIN_IN_LDS_W
         stage_weights_store(Wl, wst);
@@ -152,12 +176,16 @@ __global__ __launch_bounds__(kThreads, 3) void gin_in_kernel(InLaunch L)
         if (L.ticks && tid == 0) atomicAdd((unsigned long long *)&L.ticks[(a.first ? 0 : 16) + 15], 1ull);
         // 1. own rows; the tile's row pointers and graph ids ride in the same round trip (the pooling and the gather
         //    would otherwise each start with one of their own)
-        if (tid <= nrows) rpl[tid] = a.row_ptr[tile0 + tid];
-        if (tid >= 128 && tid - 128 < nrows) gidl[tid - 128] = a.graph_id[tile0 + tid - 128];
         {
+            // (all requested together and stored afterwards: a load under `if (tid < ...)` next to its LDS store is a
+            // round trip of its own)
+            const int rp_own = a.row_ptr[tile0 + min(tid, nrows)];
+            const int gid_own = a.graph_id[min(tile0 + (tid & (kTile - 1)), N - 1)];
             F4 own[kTile / 16];                   // the 4 rows of this lane group: requested together, transformed afterwards
 #pragma unroll
             for (int i = 0; i < kTile / 16; ++i) own[i] = load(min(tile0 + gi + 16 * i, N - 1));
+            if (tid <= nrows) rpl[tid] = rp_own;
+            if (tid >= 128 && tid - 128 < nrows) gidl[tid - 128] = gid_own;
 #pragma unroll
             for (int i = 0; i < kTile / 16; ++i) {
                 const int r = gi + 16 * i;
@@ -169,7 +197,7 @@ __global__ __launch_bounds__(kThreads, 3) void gin_in_kernel(InLaunch L)
         GIN_TICK(1);
         // 2. SumPooling of hidden_rep[layer] (gin.py:228)
 #if !(GIN_DBG_SKIP & 1)
-        if (a.pooled) pool_tile(T, tile0, nrows, a.graph_id, a.pooled, gidl);
+        if (a.pooled) pool_tile(T, nrows, a.pooled, gidl);
 #endif
         lds_barrier();                             // (the pooling atomics stay in flight)
         GIN_TICK(2);
@@ -226,10 +254,11 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
     __shared__ float Wl[H * kLdt];
     const WStage wst = stage_weights_request(a.w1, H);       // in flight with N and the statistics
-    const int N = a.node_off[a.B];
-    const double dn = (double)N;
     __shared__ float taba[2 * H];
-    bn_table(taba, a.bna, dn, a.eps, a.training, (double *)red);
+    const BnReq ra = bn_request(a.bna);
+    const int N = a.node_off[a.B];                           // (requested last: the wait for it is the wait for all)
+    SCHED_FENCE();
+    bn_table_finish(taba, ra, (double)N, a.eps, a.training, (double *)red);
     stage_weights_store(Wl, wst);
     __syncthreads();
     Aff4 aa[4];
@@ -273,9 +302,11 @@ __global__ __launch_bounds__(kThreads) void gin_stat_kernel(StatLaunch L)
     __shared__ __attribute__((aligned(16))) float part[16 * 2 * H];  // (also the fp64 scratch of bn_table)
     const StatArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
-    const int N = a.node_off[a.B];
     __shared__ float tabb[2 * H];
-    bn_table(tabb, a.bnb, (double)N, a.eps, a.training, (double *)part);
+    const BnReq rb = bn_request(a.bnb);
+    const int N = a.node_off[a.B];                           // (requested last: the wait for it is the wait for all)
+    SCHED_FENCE();
+    bn_table_finish(tabb, rb, (double)N, a.eps, a.training, (double *)part);
     const Aff4 ab = aff4_from_table(tabb, 4 * t);
     F4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
     bool any = false;
@@ -325,21 +356,30 @@ __global__ __launch_bounds__(kThreads) void gin_pool_kernel(PoolLaunch L)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ __attribute__((aligned(16))) float T[kTile * kLdt];   // (also the fp64 scratch of bn_table)
+    __shared__ int gidl[kTile];
     const PoolArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
-    const int N = a.node_off[a.B];
     __shared__ float tabb[2 * H], tabc[2 * H];
-    bn_table(tabb, a.bnb, (double)N, a.eps, a.training, (double *)T);
-    bn_table(tabc, a.bnc, (double)N, a.eps, a.training, (double *)T);
+    const BnReq rb = bn_request(a.bnb), rc = bn_request(a.bnc);
+    const int N = a.node_off[a.B];                           // (requested last: the wait for it is the wait for all)
+    SCHED_FENCE();
+    bn_table_finish(tabb, rb, (double)N, a.eps, a.training, (double *)T);
+    bn_table_finish(tabc, rc, (double)N, a.eps, a.training, (double *)T);
     const Aff4 ab = aff4_from_table(tabb, 4 * t);
     const Aff4 ac = aff4_from_table(tabc, 4 * t);
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
         const int tile0 = tw.ti * kTile;
         const int nrows = min(kTile, N - tile0);
-        for (int r = gi; r < nrows; r += 16)
-            st4(&T[r * kLdt + 4 * t], affine_relu(affine_relu(ld4(a.z2 + (int64_t)(tile0 + r) * H + 4 * t), ab), ac));
+        F4 z4[kTile / 16];                           // the lane group's 4 rows and the tile's graph ids, requested together
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i) z4[i] = ld4(a.z2 + (int64_t)min(tile0 + gi + 16 * i, N - 1) * H + 4 * t);
+        const int gid_own = a.graph_id[min(tile0 + (tid & (kTile - 1)), N - 1)];
+        if (tid < nrows) gidl[tid] = gid_own;
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i)
+            if (gi + 16 * i < nrows) st4(&T[(gi + 16 * i) * kLdt + 4 * t], affine_relu(affine_relu(z4[i], ab), ac));
         __syncthreads();
-        pool_tile(T, tile0, nrows, a.graph_id, a.pooled);
+        pool_tile(T, nrows, a.pooled, gidl);
         __syncthreads();
     }
 }

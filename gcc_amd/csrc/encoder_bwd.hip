@@ -74,6 +74,48 @@ __device__ __forceinline__ void fill_coefs(float *C /* [7][64] */, const BnDev &
     __syncthreads();
 }
 
+// The same tables when the forward pass left the statistics' totals (every training pass of gcc_gin_forward does): coef_request
+// / rep_request put every load in flight, fill_coefs_from consumes them -- a kernel requests all its tables, then the node
+// count, and waits once (the chain was node count -> totals -> backward sums -> weights, per table).  ALL threads call
+// them (block-uniform); fill_coefs_from does NOT end with a barrier: the caller synchronises once after its last table.
+struct CoefReq { double s1, s2; float gamma, beta; };
+__device__ __forceinline__ CoefReq coef_request(const BnDev &bn)
+{
+    const int c = (int)threadIdx.x & (H - 1);
+    CoefReq r = {bn.totals[c], bn.totals[H + c], bn.weight[c], bn.bias[c]};
+    return r;
+}
+template <bool kBst>
+__device__ __forceinline__ void fill_coefs_from(float *C /* [7][64] */, const CoefReq &r, const RepReq &bst, double n,
+                                                float eps, double *scratch)
+{
+    if (kBst) {
+        scratch[threadIdx.x] = rep_sum(bst);         // slots 0 and 1 of the backward sums
+        __syncthreads();
+    }
+    // every thread computes channel t & 63 and stores it (four threads store the same value): under `if (t < 64)` the
+    // compiler sinks the requests into the branch, behind the wait for the node count -- a second round trip
+    const int c = (int)threadIdx.x & (H - 1);
+    {
+        const double mean = r.s1 / n;
+        double var = r.s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+        C[RS * H + c] = rstd;
+        C[RM * H + c] = -meanf * rstd;
+        C[PS * H + c] = r.gamma * rstd;
+        C[PH * H + c] = r.beta - r.gamma * rstd * meanf;
+        if (kBst) {
+            const double b1 = scratch[c] + scratch[128 + c], b2 = scratch[H + c] + scratch[128 + H + c];
+            const float m1 = (float)(b1 / n), m2 = (float)(b2 / n);
+            const float k1 = r.gamma * rstd;
+            C[K1 * H + c] = k1;
+            C[K2 * H + c] = -k1 * m2 * rstd;
+            C[K3 * H + c] = k1 * (m2 * meanf * rstd - m1);
+        }
+    }
+}
+
 __device__ __forceinline__ F4 fma4(F4 a, F4 b, F4 c)
 {
     F4 r = {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
@@ -206,7 +248,8 @@ struct BwdCArgs {
     float eps;
 };
 
-__global__ __launch_bounds__(kThreads, 4) void gin_bwd_c_kernel(BwdCArgs a)
+// (the grid is 3 workgroups per CU: 168 registers each)
+__global__ __launch_bounds__(kThreads, 3) void gin_bwd_c_kernel(BwdCArgs a)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
@@ -215,12 +258,20 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_c_kernel(BwdCArgs a)
     __shared__ int prow[32];
     __shared__ int rpl[kTile + 1];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
-    const int N = a.node_off[a.B];
-    fill_coefs(Cb, a.bnb, nullptr, (double)N, a.eps, (double *)part);
-    fill_coefs(Cc, a.bnc, nullptr, (double)N, a.eps, (double *)part);
-    const F4 pbs = ld4(&Cb[PS * H + 4 * t]), pbh = ld4(&Cb[PH * H + 4 * t]);
-    const F4 rcs = ld4(&Cc[RS * H + 4 * t]), rcm = ld4(&Cc[RM * H + 4 * t]);
-    const F4 pcs = ld4(&Cc[PS * H + 4 * t]), pch = ld4(&Cc[PH * H + 4 * t]);
+    int N;
+    if (a.bnb.totals && a.bnc.totals) {            // block-uniform; the usual case
+        const CoefReq rb = coef_request(a.bnb), rc = coef_request(a.bnc);
+        const RepReq none = {};
+        N = a.node_off[a.B];                       // (requested last: the wait for it is the wait for all)
+        SCHED_FENCE();
+        fill_coefs_from<false>(Cb, rb, none, (double)N, a.eps, (double *)part);
+        fill_coefs_from<false>(Cc, rc, none, (double)N, a.eps, (double *)part);
+        __syncthreads();
+    } else {
+        N = ((const volatile int32_t *)a.node_off)[a.B];      // (volatile: an ordinary load is hoisted above the branch, ahead of the other arm's requests)
+        fill_coefs(Cb, a.bnb, nullptr, (double)N, a.eps, (double *)part);
+        fill_coefs(Cc, a.bnc, nullptr, (double)N, a.eps, (double *)part);
+    }
     auto ident = [&](int u) -> F4 { return ld4(a.D + (int64_t)u * H + 4 * t); };
     F4 s1 = zero4(), s2 = zero4();
     bool any = false;
@@ -228,24 +279,38 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_c_kernel(BwdCArgs a)
         const int tile0 = tw.ti * kTile;
         any = true;
         const int nrows = min(kTile, N - tile0);
-        if (a.D) {
-            if (tid <= nrows) rpl[tid] = a.row_ptr[tile0 + tid];      // (same round trip as the rows)
-            for (int r = gi; r < kTile; r += 16) st4(&T[r * kLdt + 4 * t], r < nrows ? ident(tile0 + r) : zero4());
+        // the lane group's 4 rows: graph ids and z2 rows ride in the round trip of the tile's own rows of D, the
+        // pooled-path gradients (which need the graph ids) in the gather's first one; every load unconditional with a
+        // clamped address (a loop over r with its loads inside ran 8 dependent round trips, after the gather)
+        int gid4[kTile / 16];
+        F4 g4[kTile / 16], z4[kTile / 16];
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i) gid4[i] = a.graph_id[min(tile0 + gi + 16 * i, N - 1)];
+        if (a.D) {                                   // block-uniform
+            const int rp_own = a.row_ptr[tile0 + min(tid, nrows)];
+            F4 own[kTile / 16];
+#pragma unroll
+            for (int i = 0; i < kTile / 16; ++i) own[i] = ident(min(tile0 + gi + 16 * i, N - 1));
+#pragma unroll
+            for (int i = 0; i < kTile / 16; ++i) z4[i] = ld4(a.z2 + (int64_t)min(tile0 + gi + 16 * i, N - 1) * H + 4 * t);
+            if (tid <= nrows) rpl[tid] = rp_own;
+#pragma unroll
+            for (int i = 0; i < kTile / 16; ++i) st4(&T[(gi + 16 * i) * kLdt + 4 * t], gi + 16 * i < nrows ? own[i] : zero4());
+#pragma unroll
+            for (int i = 0; i < kTile / 16; ++i) g4[i] = ld4(a.dpooled + (int64_t)gid4[i] * H + 4 * t);
             __syncthreads();
             gather_tile<8>(T, part, prow, nrows, a.col_idx, ident, [](F4 x) { return x; }, 1.0f, rpl);
+        } else {
+#pragma unroll
+            for (int i = 0; i < kTile / 16; ++i) z4[i] = ld4(a.z2 + (int64_t)min(tile0 + gi + 16 * i, N - 1) * H + 4 * t);
+#pragma unroll
+            for (int i = 0; i < kTile / 16; ++i) g4[i] = ld4(a.dpooled + (int64_t)gid4[i] * H + 4 * t);
         }
-        {   // the lane group's 4 rows: graph ids, then pooled-path gradients and z2 rows, each batch requested together
-            // (a loop over r with its loads inside ran 8 dependent round trips)
-            int gid4[kTile / 16];
-            F4 g4[kTile / 16], z4[kTile / 16];
-#pragma unroll
-            for (int i = 0; i < kTile / 16; ++i) gid4[i] = a.graph_id[min(tile0 + gi + 16 * i, N - 1)];
-#pragma unroll
-            for (int i = 0; i < kTile / 16; ++i) {
-                const int v = min(tile0 + gi + 16 * i, N - 1);
-                g4[i] = ld4(a.dpooled + (int64_t)gid4[i] * H + 4 * t);
-                z4[i] = ld4(a.z2 + (int64_t)v * H + 4 * t);
-            }
+        {
+            // (the coefficient rows are read from LDS here, not held in 24 registers across the gather)
+            const F4 pbs = ld4(&Cb[PS * H + 4 * t]), pbh = ld4(&Cb[PH * H + 4 * t]);
+            const F4 rcs = ld4(&Cc[RS * H + 4 * t]), rcm = ld4(&Cc[RM * H + 4 * t]);
+            const F4 pcs = ld4(&Cc[PS * H + 4 * t]), pch = ld4(&Cc[PH * H + 4 * t]);
 #pragma unroll
             for (int i = 0; i < kTile / 16; ++i) {
                 const int r = gi + 16 * i, v = tile0 + r;
@@ -286,9 +351,20 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_b_kernel(BwdBArgs a)
     __shared__ __attribute__((aligned(16))) float part[16 * 2 * H];      // (also the fp64 scratch of fill_coefs)
     __shared__ float Cb[kCoefRows * H], Cc[kCoefRows * H];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
-    const int N = a.node_off[a.B];
-    fill_coefs(Cb, a.bnb, nullptr, (double)N, a.eps, (double *)part);
-    fill_coefs(Cc, a.bnc, a.bst_c, (double)N, a.eps, (double *)part);
+    int N;
+    if (a.bnb.totals && a.bnc.totals) {            // block-uniform; the usual case
+        const CoefReq rb = coef_request(a.bnb), rc = coef_request(a.bnc);
+        const RepReq sc = rep_request(a.bst_c, 3 * H);
+        N = a.node_off[a.B];                       // (requested last: the wait for it is the wait for all)
+        SCHED_FENCE();
+        fill_coefs_from<false>(Cb, rb, sc, (double)N, a.eps, (double *)part);
+        fill_coefs_from<true>(Cc, rc, sc, (double)N, a.eps, (double *)part);
+        __syncthreads();
+    } else {
+        N = ((const volatile int32_t *)a.node_off)[a.B];      // (volatile: an ordinary load is hoisted above the branch, ahead of the other arm's requests)
+        fill_coefs(Cb, a.bnb, nullptr, (double)N, a.eps, (double *)part);
+        fill_coefs(Cc, a.bnc, a.bst_c, (double)N, a.eps, (double *)part);
+    }
     const F4 pbs = ld4(&Cb[PS * H + 4 * t]), pbh = ld4(&Cb[PH * H + 4 * t]);
     const F4 rbs = ld4(&Cb[RS * H + 4 * t]), rbm = ld4(&Cb[RM * H + 4 * t]);
     const F4 k1 = ld4(&Cc[K1 * H + 4 * t]), k2 = ld4(&Cc[K2 * H + 4 * t]), k3 = ld4(&Cc[K3 * H + 4 * t]);
@@ -354,9 +430,19 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_lin_kernel(BwdLinArgs a)
     __shared__ float Wt[H * kLdt];                 // W transposed, staged once per workgroup (every wave fetched all 16
                                                    // fragments as 64 strided 4-byte loads per lane before)
     const WStage wst = stage_weights_request(a.W, a.kdim);      // in flight with N and the statistics
-    const int N = a.node_off[a.B];
-    fill_coefs(Ci, a.bn_in, a.bst_in, (double)N, a.eps, (double *)red);
-    if (kMask) fill_coefs(Co, a.bn_out, nullptr, (double)N, a.eps, (double *)red);
+    int N;
+    if (a.bn_in.totals && (!kMask || a.bn_out.totals)) {      // block-uniform; the usual case
+        const CoefReq ri = coef_request(a.bn_in), ro = kMask ? coef_request(a.bn_out) : CoefReq();
+        const RepReq si = rep_request(a.bst_in, 3 * H);
+        N = a.node_off[a.B];                       // (requested last: the wait for it is the wait for all)
+        SCHED_FENCE();
+        fill_coefs_from<true>(Ci, ri, si, (double)N, a.eps, (double *)red);
+        if (kMask) fill_coefs_from<false>(Co, ro, si, (double)N, a.eps, (double *)red);
+    } else {
+        N = ((const volatile int32_t *)a.node_off)[a.B];      // (volatile: an ordinary load is hoisted above the branch, ahead of the other arm's requests)
+        fill_coefs(Ci, a.bn_in, a.bst_in, (double)N, a.eps, (double *)red);
+        if (kMask) fill_coefs(Co, a.bn_out, nullptr, (double)N, a.eps, (double *)red);
+    }
     stage_weights_store_t(Wt, wst);
     __syncthreads();
     float *myred = &red[wv * 3 * H];
@@ -448,7 +534,7 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
     __shared__ float T[kTile * kLdt];
     __shared__ float part[32 * H];
     __shared__ float E[kEmbMaxElems];
-    __shared__ int dclrow[kTile];
+    __shared__ int dclrow[kTile], gidl[kTile];
     __shared__ int prow[32];
     __shared__ int rpl[kTile + 1];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
@@ -459,8 +545,18 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
         const int tile0 = tw.ti * kTile;
         const int nrows = min(kTile, N - tile0);
-        if (tid <= nrows) rpl[tid] = a.row_ptr[tile0 + tid];          // (same round trip as the rows)
-        for (int r = gi; r < kTile; r += 16) st4(&T[r * kLdt + 4 * t], r < nrows ? ident(tile0 + r) : zero4());
+        {   // row pointers, graph ids and the lane group's 4 rows: requested together, stored afterwards (a load under
+            // `if (tid < ...)` next to its LDS store is a round trip of its own)
+            const int rp_own = a.row_ptr[tile0 + min(tid, nrows)];
+            const int gid_own = a.graph_id[min(tile0 + (tid & (kTile - 1)), N - 1)];
+            F4 own[kTile / 16];
+#pragma unroll
+            for (int i = 0; i < kTile / 16; ++i) own[i] = ident(min(tile0 + gi + 16 * i, N - 1));
+            if (tid <= nrows) rpl[tid] = rp_own;
+            if (tid >= 128 && tid - 128 < nrows) gidl[tid - 128] = gid_own;
+#pragma unroll
+            for (int i = 0; i < kTile / 16; ++i) st4(&T[(gi + 16 * i) * kLdt + 4 * t], gi + 16 * i < nrows ? own[i] : zero4());
+        }
         __syncthreads();
         gather_tile<8>(T, part, prow, nrows, a.col_idx, ident, [](F4 x) { return x; }, 1.0f, rpl);
         // all threads: add the pooled-path gradient and look the clamped degree up (global loads in parallel) ...
@@ -468,9 +564,23 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
             const int deg = rpl[tid + 1] - rpl[tid];
             dclrow[tid] = deg < a.max_degree ? deg : a.max_degree;
         }
-        for (int idx = tid; idx < nrows * a.emb_dim; idx += kThreads) {
-            const int r = idx / a.emb_dim, c = idx - r * a.emb_dim;
-            T[r * kLdt + a.pos_dim + c] += a.dpooled0[(int64_t)a.graph_id[tile0 + r] * H + a.pos_dim + c];
+        {   // (the pooled-path gradients of a batch requested together, graph ids from LDS: 8 dependent round trips before)
+            constexpr int kIt = 4;                   // covers kTile rows x 16 columns with 256 threads; more columns loop below
+            const int total = nrows * a.emb_dim;
+            for (int base = 0; base < total; base += kIt * kThreads) {
+                int rr[kIt], cc[kIt];
+                float dv[kIt];
+#pragma unroll
+                for (int i = 0; i < kIt; ++i) {
+                    const int idx = min(base + tid + i * kThreads, total - 1);
+                    rr[i] = idx / a.emb_dim; cc[i] = idx - rr[i] * a.emb_dim;
+                }
+#pragma unroll
+                for (int i = 0; i < kIt; ++i) dv[i] = a.dpooled0[(int64_t)gidl[rr[i]] * H + a.pos_dim + cc[i]];
+#pragma unroll
+                for (int i = 0; i < kIt; ++i)
+                    if (base + tid + i * kThreads < total) T[rr[i] * kLdt + a.pos_dim + cc[i]] += dv[i];
+            }
         }
         __syncthreads();
         // ... then column c is owned by thread c: LDS only, fixed order, no atomics

@@ -76,24 +76,35 @@ struct BnDev {
 
 // ---- column sums over the kRep replicas of an accumulator.  Pair p < 128 = (slot p >> 6, channel p & 63) of replica r
 // lives at rep[r * stride + p] (forward statistics: stride 2 * 64; backward sums: stride 3 * 64, slots 0 and 1).
-// ALL kThreads threads call it (block-uniform): thread t adds the replicas of half t >> 7 for pair t & 127 as batches of 8
+// ALL kThreads threads take part (block-uniform): thread t adds the replicas of half t >> 7 for pair t & 127, requested as
 // independent loads.  (The obvious per-channel loop came out of the compiler as load - wait - add, 64 DEPENDENT L2 round
-// trips in the prologue of every kernel of the chain: 10-25 us each, profiles/r3_replica_sum_isa.txt.)  After the trailing
-// barrier: total(p) = sums[p] + sums[128 + p].
-__device__ __forceinline__ void replica_sums128(const double *rep, int stride, double *sums /* LDS [256] */)
+// trips in the prologue of every kernel of the chain: 10-25 us each, profiles/r3_replica_sum_isa.txt.)
+// rep_request only REQUESTS (so that a prologue can put every load it needs in flight before the first wait: node count,
+// replicas of one or two accumulators, BatchNorm weights); rep_sum adds them in a fixed order.
+struct RepReq { double v[kRep / 2]; };
+__device__ __forceinline__ RepReq rep_request(const double *rep, int stride)
 {
     static_assert(kThreads == 256 && kRep % 16 == 0, "two halves of the replicas, batches of 8");
     const int t = (int)threadIdx.x, p = t & 127, g = t >> 7;
     const double *src = rep + (int64_t)(g * (kRep / 2)) * stride + p;
+    RepReq r;
+#pragma unroll
+    for (int u = 0; u < kRep / 2; ++u) r.v[u] = src[(int64_t)u * stride];
+    return r;
+}
+__device__ __forceinline__ double rep_sum(const RepReq &r)
+{
     double acc = 0.0;
 #pragma unroll
-    for (int b = 0; b < kRep / 2; b += 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + u) * stride];
-        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    }
-    sums[t] = acc;
+    for (int b = 0; b < kRep / 2; b += 8)
+        acc += ((r.v[b] + r.v[b + 1]) + (r.v[b + 2] + r.v[b + 3])) + ((r.v[b + 4] + r.v[b + 5]) + (r.v[b + 6] + r.v[b + 7]));
+    return acc;
+}
+// After the trailing barrier: total(p) = sums[p] + sums[128 + p].
+__device__ __forceinline__ void replica_sums128(const double *rep, int stride, double *sums /* LDS [256] */)
+{
+    const RepReq r = rep_request(rep, stride);
+    sums[threadIdx.x] = rep_sum(r);
     __syncthreads();
 }
 
@@ -131,23 +142,41 @@ __device__ __forceinline__ void bn_scale_shift(const BnDev &bn, int c, double n,
     bn_scale_shift_from(bn, c, s1, s2, n, eps, training, scale, shift);
 }
 
-// scale/shift of all 64 channels into an LDS table tab[2][64].  ALL threads call it (block-uniform); scratch = LDS
-// [256] doubles that nothing else uses during the call; ends with a barrier (tab is valid, scratch is free again).
-__device__ __forceinline__ void bn_table(float *tab, const BnDev &bn, double n, float eps, int training, double *scratch)
+// scale/shift of all 64 channels into an LDS table tab[2][64] (the forward kernels: statistics replicas, no totals yet).
+// bn_request puts every load the table needs in flight -- the replicas, weight, bias and running statistics of channel
+// t & 63: all of them exist in both modes -- and bn_table_finish consumes them, so that a kernel's prologue is ONE round
+// trip (requests of all its tables, then the node count, then the waits) instead of node count -> replicas -> weights per
+// table.  ALL threads call both (block-uniform); scratch = LDS [256] doubles that nothing else uses during the call;
+// bn_table_finish ends with a barrier (tab is valid, scratch is free again).
+struct BnReq { RepReq rep; float w, b, rm, rv; };
+__device__ __forceinline__ BnReq bn_request(const BnDev &bn)
 {
-    const bool reps = training && !bn.totals;        // block-uniform
-    if (reps) replica_sums128(bn.stats, 2 * H, scratch);
+    const int c = (int)threadIdx.x & (H - 1);
+    BnReq r;
+    r.rep = rep_request(bn.stats, 2 * H);
+    r.w = bn.weight[c]; r.b = bn.bias[c];
+    r.rm = bn.running_mean[c]; r.rv = bn.running_var[c];
+    return r;
+}
+__device__ __forceinline__ void bn_table_finish(float *tab, const BnReq &r, double n, float eps, int training, double *scratch)
+{
     const int c = (int)threadIdx.x;
+    scratch[c] = rep_sum(r.rep);
+    __syncthreads();
     if (c < H) {
-        double s1 = 0.0, s2 = 0.0;
-        if (reps) {
-            s1 = scratch[c] + scratch[128 + c];
-            s2 = scratch[H + c] + scratch[128 + H + c];
-        } else if (training) {
-            s1 = bn.totals[c];
-            s2 = bn.totals[H + c];
+        double mean, var;
+        if (training) {                              // biased batch variance (gin.py:56,115,219 -> F.batch_norm)
+            const double s1 = scratch[c] + scratch[128 + c], s2 = scratch[H + c] + scratch[128 + H + c];
+            mean = s1 / n;
+            var = s2 / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+        } else {
+            mean = (double)r.rm;
+            var = (double)r.rv;
         }
-        bn_scale_shift_from(bn, c, s1, s2, n, eps, training, tab[c], tab[H + c]);
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        tab[c] = (float)((double)r.w * rstd);
+        tab[H + c] = (float)((double)r.b - mean * (double)r.w * rstd);
     }
     __syncthreads();
 }
@@ -172,15 +201,14 @@ __device__ __forceinline__ Aff4 bn_aff4(const BnDev &bn, int c0, double n, float
 // ---- SumPooling of an LDS tile (rows tile0 .. tile0+nrows of the batched graph) into
 // pooled[graph][64] (fp64 atomics; one flush per run of equal graph ids per thread)
 // gid_lds (optional): the tile's graph ids already staged in LDS by the caller (fetched together with the rows)
-__device__ __forceinline__ void pool_tile(const float *T, int tile0, int nrows, const int32_t *graph_id,
-                                          double *pooled, const int *gid_lds = nullptr)
+__device__ __forceinline__ void pool_tile(const float *T, int nrows, double *pooled, const int *gid_lds /* LDS [kTile] */)
 {
     const int c = (int)threadIdx.x & 63, part = (int)threadIdx.x >> 6;
-    int gids[16];                                    // the 16 graph ids first: one round trip instead of 16 in a row
+    int gids[16];                                    // (the tile's graph ids came with the tile's rows: no round trip here)
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int r = part * 16 + k;
-        gids[k] = r < nrows ? (gid_lds ? gid_lds[r] : graph_id[tile0 + r]) : -1;
+        gids[k] = r < nrows ? gid_lds[r] : -1;
     }
     double acc = 0.0;
     int cur = -1;
