@@ -140,12 +140,14 @@ __global__ __launch_bounds__(kThreads, 3) void gin_in_kernel(InLaunch L)
     __shared__ float tabb[2 * H], tabc[2 * H];
 #if GIN_IN_LDS_W
     __shared__ float Wl[H * kLdt];                 // linears.0 weight, staged once per workgroup
+    __shared__ __attribute__((aligned(16))) float bl[H];     // and its bias
 #endif
     Aff4 ab, ac;
     long long tick_ = L.ticks ? device_ticks() : 0;
     {
 #if GIN_IN_LDS_W
         const WStage wst = stage_weights_request(a.w0, a.kdim);     // in flight with N and the statistics
+        const float b_own = a.b0 ? a.b0[tid & (H - 1)] : 0.f;
 #endif
         if (!a.first) {                            // block-uniform
             const BnReq rb = bn_request(a.bnb), rc = bn_request(a.bnc);
@@ -157,7 +159,8 @@ __global__ __launch_bounds__(kThreads, 3) void gin_in_kernel(InLaunch L)
             N = ((const volatile int32_t *)a.node_off)[a.B];       // (volatile: an ordinary load is hoisted above the branch, ahead of the other arm's requests)
         }
 #if GIN_IN_LDS_W
-        stage_weights_store(Wl, wst);
+        stage_weights_store(Wl, wst, a.kdim);
+        if (tid < H) bl[tid] = b_own;
 #endif
     }
     __syncthreads();
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(kThreads, 3) void gin_in_kernel(InLaunch L)
 #pragma unroll
             for (int c = 0; c < 4; ++c) xb[c] = ld4(&T[rl * kLdt + 16 * c + 4 * q]);
 #if GIN_IN_LDS_W
-            linear_rows16_lds_store_stats(xb, Wl, a.b0, a.z1, tile0 + rl, rl < nrows, &red[wv * 2 * H]);
+            linear_rows16_lds_store_stats(xb, Wl, bl, a.z1, tile0 + rl, rl < nrows, &red[wv * 2 * H]);
 #else
             linear_rows16_store_stats(xb, a.w0, a.kdim, a.b0, a.z1, tile0 + rl, rl < nrows, &red[wv * 2 * H]);
 #endif
@@ -255,11 +258,14 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
     __shared__ float Wl[H * kLdt];
     const WStage wst = stage_weights_request(a.w1, H);       // in flight with N and the statistics
     __shared__ float taba[2 * H];
+    __shared__ __attribute__((aligned(16))) float bl[H];     // linears.1's bias
+    const float b_own = a.b1 ? a.b1[tid & (H - 1)] : 0.f;
     const BnReq ra = bn_request(a.bna);
     const int N = a.node_off[a.B];                           // (requested last: the wait for it is the wait for all)
     SCHED_FENCE();
     bn_table_finish(taba, ra, (double)N, a.eps, a.training, (double *)red);
-    stage_weights_store(Wl, wst);
+    stage_weights_store(Wl, wst, H);
+    if (tid < H) bl[tid] = b_own;
     __syncthreads();
     Aff4 aa[4];
 #pragma unroll
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
             const F4 z = {0.f, 0.f, 0.f, 0.f};
             xb[c] = valid ? affine_relu(xb[c], aa[c]) : z;                                      // gin.py:115
         }
-        linear_rows16_lds_store_stats(xb, Wl, a.b1, a.z2, row, valid, &red[wv * 2 * H]);      // gin.py:116
+        linear_rows16_lds_store_stats(xb, Wl, bl, a.z2, row, valid, &red[wv * 2 * H]);      // gin.py:116
         __syncthreads();
         flush_stats(red, a.stats_b);
         lds_barrier();

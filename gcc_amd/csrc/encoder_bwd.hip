@@ -443,7 +443,7 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_lin_kernel(BwdLinArgs a)
         fill_coefs(Ci, a.bn_in, a.bst_in, (double)N, a.eps, (double *)red);
         if (kMask) fill_coefs(Co, a.bn_out, nullptr, (double)N, a.eps, (double *)red);
     }
-    stage_weights_store_t(Wt, wst);
+    stage_weights_store_t(Wt, wst, a.kdim);
     __syncthreads();
     float *myred = &red[wv * 3 * H];
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {

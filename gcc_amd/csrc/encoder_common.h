@@ -287,16 +287,16 @@ __device__ __forceinline__ void load_wt_frags(const float *W, int kdim, F4 wf[4]
 // bias add, masked store of the 16x64 block and per-channel sum / sum of squares of the
 // valid rows into red[wave][2][64]
 // one 16-channel block cb of the epilogue: + bias, store, per-wave column sums / sums of squares into red
-__device__ __forceinline__ void epilogue_block(int cb, const f32x4 &acc, const float *bias, float *Z, int row,
-                                               bool valid, float *red /* [128] of this wave */)
+__device__ __forceinline__ void epilogue_block4(int cb, const f32x4 &acc, F4 bias4, float *Z, int row,
+                                                bool valid, float *red /* [128] of this wave */)
 {
     const int lane = lane_id(), q = lane >> 4;
     const int ch = 16 * cb + 4 * q;
     F4 z;
-    z.x = acc[0] + (bias ? bias[ch + 0] : 0.f);
-    z.y = acc[1] + (bias ? bias[ch + 1] : 0.f);
-    z.z = acc[2] + (bias ? bias[ch + 2] : 0.f);
-    z.w = acc[3] + (bias ? bias[ch + 3] : 0.f);
+    z.x = acc[0] + bias4.x;
+    z.y = acc[1] + bias4.y;
+    z.z = acc[2] + bias4.z;
+    z.w = acc[3] + bias4.w;
     if (valid) st4(Z + (int64_t)row * H + ch, z);
     if (red) {
         float s[4] = {valid ? z.x : 0.f, valid ? z.y : 0.f, valid ? z.z : 0.f, valid ? z.w : 0.f};
@@ -311,6 +311,14 @@ __device__ __forceinline__ void epilogue_block(int cb, const f32x4 &acc, const f
             for (int e = 0; e < 4; ++e) { red[ch + e] = s[e]; red[H + ch + e] = ss[e]; }
         }
     }
+}
+__device__ __forceinline__ void epilogue_block(int cb, const f32x4 &acc, const float *bias, float *Z, int row,
+                                               bool valid, float *red /* [128] of this wave */)
+{
+    const int ch = 16 * cb + 4 * (lane_id() >> 4);
+    F4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias) { b4.x = bias[ch + 0]; b4.y = bias[ch + 1]; b4.z = bias[ch + 2]; b4.w = bias[ch + 3]; }
+    epilogue_block4(cb, acc, b4, Z, row, valid, red);
 }
 __device__ __forceinline__ void epilogue_store_stats(f32x4 acc[4], const float *bias, float *Z, int row,
                                                      bool valid, float *red /* [128] of this wave */)
@@ -361,46 +369,57 @@ __device__ __forceinline__ WStage stage_weights_request(const float *W, int kdim
 {
     WStage st;
     const int tid = (int)threadIdx.x;
+    // every load unconditional with a clamped column; columns >= kdim are zeroed when the fragment is STORED, so that the
+    // request carries no wait (per-element `c < kdim ? p[c] : 0` came out as one round trip per element: the first layer's
+    // 49-column weight took ~8 dependent round trips to arrive)
+    if ((kdim & 3) == 0) {                           // block-uniform: a quad is inside the row or outside it
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + i * kThreads, r = idx >> 4, c4 = 4 * (idx & 15);       // row r, columns c4 .. c4 + 3
-        const float *p = W + (int64_t)r * kdim + c4;
-        F4 x;
-        if ((kdim & 3) == 0 && c4 + 3 < kdim) {
-            x = ld4(p);
-        } else {
-            x.x = c4 + 0 < kdim ? p[0] : 0.f;
-            x.y = c4 + 1 < kdim ? p[1] : 0.f;
-            x.z = c4 + 2 < kdim ? p[2] : 0.f;
-            x.w = c4 + 3 < kdim ? p[3] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * kThreads, r = idx >> 4, c4 = 4 * (idx & 15);
+            st.v[i] = ld4(W + (int64_t)r * kdim + min(c4, kdim - 4));
         }
-        st.v[i] = x;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * kThreads, r = idx >> 4, c4 = 4 * (idx & 15);
+            const float *p = W + (int64_t)r * kdim;
+            st.v[i] = F4{p[min(c4 + 0, kdim - 1)], p[min(c4 + 1, kdim - 1)], p[min(c4 + 2, kdim - 1)], p[min(c4 + 3, kdim - 1)]};
+        }
     }
     return st;
 }
-__device__ __forceinline__ void stage_weights_store(float *Wl, const WStage &st)
+__device__ __forceinline__ F4 stage_masked(const WStage &st, int i, int kdim)
+{
+    const int c4 = 4 * (((int)threadIdx.x + i * kThreads) & 15);
+    const F4 v = st.v[i];
+    return F4{c4 + 0 < kdim ? v.x : 0.f, c4 + 1 < kdim ? v.y : 0.f, c4 + 2 < kdim ? v.z : 0.f, c4 + 3 < kdim ? v.w : 0.f};
+}
+__device__ __forceinline__ void stage_weights_store(float *Wl, const WStage &st, int kdim)
 {
     const int tid = (int)threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + i * kThreads, r = idx >> 4, c4 = 4 * (idx & 15);
-        st4(&Wl[r * kLdt + c4], st.v[i]);
+        st4(&Wl[r * kLdt + c4], stage_masked(st, i, kdim));
     }
 }
 // transposed: Wt[c][r] = W[r][c] (the backward product dx = dz W reduces over W's rows)
-__device__ __forceinline__ void stage_weights_store_t(float *Wt, const WStage &st)
+__device__ __forceinline__ void stage_weights_store_t(float *Wt, const WStage &st, int kdim)
 {
     const int tid = (int)threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + i * kThreads, r = idx >> 4, c4 = 4 * (idx & 15);
-        Wt[(c4 + 0) * kLdt + r] = st.v[i].x;
-        Wt[(c4 + 1) * kLdt + r] = st.v[i].y;
-        Wt[(c4 + 2) * kLdt + r] = st.v[i].z;
-        Wt[(c4 + 3) * kLdt + r] = st.v[i].w;
+        const F4 v = stage_masked(st, i, kdim);
+        Wt[(c4 + 0) * kLdt + r] = v.x;
+        Wt[(c4 + 1) * kLdt + r] = v.y;
+        Wt[(c4 + 2) * kLdt + r] = v.z;
+        Wt[(c4 + 3) * kLdt + r] = v.w;
     }
 }
-__device__ __forceinline__ void linear_rows16_lds_store_stats(const F4 xb[4], const float *Wl, const float *bias,
+// bias_lds: the 64 biases in LDS (zeros without a bias), staged with the weights: from global memory the four blocks'
+// biases were four dependent round trips per tile
+__device__ __forceinline__ void linear_rows16_lds_store_stats(const F4 xb[4], const float *Wl, const float *bias_lds,
                                                               float *Z, int row, bool valid, float *red)
 {
     const int lane = lane_id(), j = lane & 15, q = lane >> 4;
@@ -415,7 +434,7 @@ __device__ __forceinline__ void linear_rows16_lds_store_stats(const F4 xb[4], co
             a = mfma_16x16x4_f32(wf.z, xb[c].z, a);
             a = mfma_16x16x4_f32(wf.w, xb[c].w, a);
         }
-        epilogue_block(cb, a, bias, Z, row, valid, red);
+        epilogue_block4(cb, a, ld4(&bias_lds[16 * cb + 4 * q]), Z, row, valid, red);
     }
 }
 
@@ -475,10 +494,12 @@ __device__ __forceinline__ void gather_tile(float *T, float *part /* [32 * H] */
             st4(dst, o);
         }
     };
+    int idx_next = e0 + t < e1 ? col_idx[e0 + t] : -1;
     for (int c = 0; c < chunk; c += 16) {                // block-uniform trip counts (the shuffles need every lane)
         const int e = e0 + c + t;
         const bool valid = e < e1;
-        const int idx = valid ? col_idx[e] : -1;
+        const int idx = idx_next;
+        idx_next = e + 16 < e1 ? col_idx[e + 16] : -1;   // the next 16 targets travel with this round's rows (a round trip per round before)
         int rid = 0;                                     // last r with rp_lds[r] <= e
         if (valid && !(GATHER_DBG & 2)) {
             int hi = nrows;
