@@ -256,17 +256,21 @@ __global__ __launch_bounds__(kThreads) void nce_combine_kernel(NceDev a)
     const int b = (int)blockIdx.x * (kThreads >> 6) + wv;
     if (b < a.B) {
         const float *other = a.pos_mode == 0 ? a.k : a.mem;        // l_pos = bmm(q, k) | diagonal of k q^T
+        // (the query, the key and the first 64 slices' maxima and sums in one round trip; more slices loop below)
         float qv = a.q[(int64_t)b * D + lane], ov = other[(int64_t)b * D + lane];
+        const int s0 = min(lane, a.S - 1);
+        const float pm0r = a.pm[(int64_t)s0 * a.B + b], ps0r = a.ps[(int64_t)s0 * a.B + b];
+        const float pm0 = lane < a.S ? pm0r : -INFINITY;
         if (a.bf16) { qv = rnd_bf16(qv); ov = rnd_bf16(ov); }
         const float pos = wave_sum(qv * ov) * a.inv_T;
-        float m = -INFINITY;
-        for (int s = lane; s < a.S; s += 64) m = fmaxf(m, a.pm[(int64_t)s * a.B + b]);
+        float m = pm0;
+        for (int s = lane + 64; s < a.S; s += 64) m = fmaxf(m, a.pm[(int64_t)s * a.B + b]);
         m = wave_max(m);
         if (a.pos_mode == 0) m = fmaxf(m, pos);
-        float sum = 0.f;
-        for (int s = lane; s < a.S; s += 64) {
-            const float pmv = a.pm[(int64_t)s * a.B + b];
-            if (pmv > -INFINITY) sum += a.ps[(int64_t)s * a.B + b] * expf(pmv - m);
+        float sum = pm0 > -INFINITY ? ps0r * expf(pm0 - m) : 0.f;
+        for (int s = lane + 64; s < a.S; s += 64) {
+            const float pmv = a.pm[(int64_t)s * a.B + b], psv = a.ps[(int64_t)s * a.B + b];
+            if (pmv > -INFINITY) sum += psv * expf(pmv - m);
         }
         sum = wave_sum(sum);
         if (a.pos_mode == 0) sum += expf(pos - m);
@@ -306,30 +310,31 @@ __global__ __launch_bounds__(kThreads) void nce_dq_kernel(NceDev a)
     const int gid = (int)blockIdx.x * kThreads + (int)threadIdx.x;
     const int b = gid >> 4, c4 = (gid & 15) * 4;
     if (b >= a.B) return;
+    // everything the epilogue needs is requested first and the slabs 16 at a time: with 4 per round and the scalars
+    // loaded at the end this was S / 4 + 3 = 19 dependent round trips for ~1 us of data
+    const float dl = a.dloss[0];
+    const float posb = a.pos_mode == 0 ? a.pos[b] : 0.f, lseb = a.pos_mode == 0 ? a.lse[b] : 0.f;     // (block-uniform branch)
+    const F4 other = rnd4(ld4((a.pos_mode == 0 ? a.k : a.mem) + (int64_t)b * D + c4), a.bf16 != 0);
     F4 s = {0.f, 0.f, 0.f, 0.f};
     const float *sp = a.slabs + (int64_t)b * D + c4;
     const int64_t st = (int64_t)a.B * D;
-    int sl = 0;
-    for (; sl + 4 <= a.S; sl += 4) {                 // 4 independent 16-B loads in flight; fixed summation order
-        const F4 v0 = ld4(sp + sl * st), v1 = ld4(sp + (sl + 1) * st), v2 = ld4(sp + (sl + 2) * st), v3 = ld4(sp + (sl + 3) * st);
-        s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
-        s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
-    }
-    for (; sl < a.S; ++sl) {
-        const F4 v = ld4(sp + sl * st);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    for (int sl = 0; sl < a.S; sl += 16) {           // fixed summation order: slab 0, 1, 2, ...
+        F4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = ld4(sp + (int64_t)min(sl + u, a.S - 1) * st);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (sl + u < a.S) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     }
     const int nrows = a.by_mem_row ? a.K : a.B;              // rows of the softmax that is averaged
-    const float coef = a.dloss[0] * a.inv_T / (float)nrows;
+    const float coef = dl * a.inv_T / (float)nrows;
     F4 o;
     if (a.pos_mode == 0) {
-        const float pp = expf(a.pos[b] - a.lse[b]) - 1.f;
-        const F4 kv = rnd4(ld4(a.k + (int64_t)b * D + c4), a.bf16 != 0);
-        o.x = coef * (s.x + pp * kv.x); o.y = coef * (s.y + pp * kv.y);
-        o.z = coef * (s.z + pp * kv.z); o.w = coef * (s.w + pp * kv.w);
+        const float pp = expf(posb - lseb) - 1.f;
+        o.x = coef * (s.x + pp * other.x); o.y = coef * (s.y + pp * other.y);
+        o.z = coef * (s.z + pp * other.z); o.w = coef * (s.w + pp * other.w);
     } else {
-        const F4 mv = rnd4(ld4(a.mem + (int64_t)b * D + c4), a.bf16 != 0);
-        o.x = coef * (s.x - mv.x); o.y = coef * (s.y - mv.y); o.z = coef * (s.z - mv.z); o.w = coef * (s.w - mv.w);
+        o.x = coef * (s.x - other.x); o.y = coef * (s.y - other.y); o.z = coef * (s.z - other.z); o.w = coef * (s.w - other.w);
     }
     st4(a.dq + (int64_t)b * D + c4, o);
 }
