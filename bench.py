@@ -534,14 +534,15 @@ def main():
             trainer = E2ETrainStep(model, sampler, posemb, nce_t=0.07, lanes=lanes, depth=args.depth, chunk=chunk,
                                    ahead=args.ahead)
             stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder fwd(q), fwd(k)",
-                      "in-batch infonce (NS) fwd", "infonce bwd (dq, dk)", "gin-encoder bwd(q) + bwd(k)", "clip", "adam", "meters"]
+                      "in-batch infonce (NS) fwd", "infonce bwd (dq, dk)", "gin-encoder bwd(q) + bwd(k)", "clip", "adam + meters (one launch)"]
         else:
             trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank,
                                     lanes=lanes, depth=args.depth, chunk=chunk, reserved_cus=args.reserved_cus,
                                     cu_layout=args.cu_layout, ahead=args.ahead)
             stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder q+k fwd",
-                      "moco-infonce fwd", "infonce bwd", "gin-encoder bwd", "grad all-reduce" if world > 1 else "clip", "adam",
-                      "ema", "key all-gather (overlapped since the encoder fwd) + enqueue" if world > 1 else "enqueue", "meters"]
+                      "moco-infonce fwd", "infonce bwd", "gin-encoder bwd", "grad all-reduce" if world > 1 else "clip",
+                      "adam + ema + meters (one launch)",
+                      "key all-gather (overlapped since the encoder fwd) + enqueue" if world > 1 else "enqueue"]
         n_batch = 2000 * 12 // 32                                          # train.py:356 with default flags
         total_steps = 100 * n_batch
 

@@ -129,6 +129,11 @@ class GccNceArgs(ctypes.Structure):
     ]
 
 
+class GccStepMetersArgs(ctypes.Structure):
+    _fields_ = [("acc", _VP), ("mx", _VP), ("loss", _VP), ("prob", _VP), ("node_off_q", _VP), ("edge_off_q", _VP),
+                ("node_off_k", _VP), ("batch_size", ctypes.c_int32)]
+
+
 class GccGinwLayer(ctypes.Structure):
     _fields_ = [("w0", _VP), ("w1", _VP), ("s0", _VP), ("t0", _VP), ("s1", _VP), ("t1", _VP), ("s2", _VP), ("t2", _VP),
                 ("w0_frag", _VP), ("w1_frag", _VP)]
@@ -195,6 +200,11 @@ SIGNATURES = {
                                        ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_float, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_adam_ema_step": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                           ctypes.c_float, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,
+                                           ctypes.POINTER(GccStepMetersArgs), ctypes.c_void_p]),
     "gcc_step_meters": (ctypes.c_int32, [ctypes.c_void_p] * 8 + [ctypes.c_int32, ctypes.c_void_p]),
     "gcc_ema_update": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,
                                         ctypes.c_void_p]),

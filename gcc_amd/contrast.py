@@ -95,6 +95,26 @@ class NceEngine:
         if rc != 0:
             raise RuntimeError(f"gcc_adam_step failed ({rc}): {self.lib.gcc_last_error().decode()}")
 
+    def adam_ema(self, param, grad, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, step, max_norm, grad_norm,
+                 scratch, stream=None, grad_scale=1.0, ema=None, ema_src=None, ema_m=0.0, meters=None):
+        """gcc_adam_ema_step: clip + Adam over ``param`` (the live prefix of the flat buffer ``ema_src``), the EMA copy
+        ``ema`` of all of ``ema_src`` and one step of the meters ``(acc, mx, loss, prob, q, k)`` in the Adam launch."""
+        ma = None
+        if meters is not None:
+            acc, mx, loss, prob, q, k = meters
+            ma = _cabi.GccStepMetersArgs(self.ptr(acc), self.ptr(mx), self.ptr(loss), self.ptr(prob), self.ptr(q.node_off),
+                                         self.ptr(q.edge_off), self.ptr(k.node_off), int(q.batch_size))
+        if ema is not None and (ema_src is None or ema_src.data_ptr() != param.data_ptr() or ema.numel() != ema_src.numel()):
+            raise ValueError("adam_ema: param must be a prefix of ema_src, and ema the same size as ema_src")
+        rc = self.lib.gcc_adam_ema_step(self.ptr(param), self.ptr(grad), self.ptr(exp_avg), self.ptr(exp_avg_sq),
+                                        param.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                        float(weight_decay), int(step), float(max_norm), float(grad_scale),
+                                        self.ptr(grad_norm), self.ptr(scratch),
+                                        self.ptr(ema) if ema is not None else None, ema.numel() if ema is not None else 0,
+                                        float(ema_m), ctypes.byref(ma) if ma is not None else None, stream)
+        if rc != 0:
+            raise RuntimeError(f"gcc_adam_ema_step failed ({rc}): {self.lib.gcc_last_error().decode()}")
+
     def meters(self, acc, mx, loss, prob, grad_norm, q, k, stream=None):
         rc = self.lib.gcc_step_meters(self.ptr(acc), self.ptr(mx), self.ptr(loss), self.ptr(prob), self.ptr(grad_norm),
                                       self.ptr(q.node_off), self.ptr(q.edge_off), self.ptr(k.node_off),

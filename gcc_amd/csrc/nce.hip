@@ -366,12 +366,21 @@ constexpr int kNormBlocks = 32;
 __global__ __launch_bounds__(kThreads) void gradnorm_kernel(const float *g, int64_t n, double *scratch)
 {
     TRAIN_STEP_WAVE_PRIORITY();
+    static_assert(kNormBlocks <= 64, "the last workgroup adds the partials up with one wave");
     __shared__ double red[kThreads / 64];
     __shared__ int last;
     const int tid = (int)threadIdx.x;
     double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + tid; i < n; i += (int64_t)gridDim.x * kThreads)
-        s += (double)g[i] * (double)g[i];
+    // 8 independent loads per round (clamped address, masked afterwards): one element per round was a dependent round
+    // trip per element, ~12 in a row for the 100 k parameters of the GIN encoder
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t base = (int64_t)blockIdx.x * kThreads + tid; base < n; base += 8 * stride) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int64_t i = base + u * stride; x[u] = g[i < n ? i : n - 1]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (base + u * stride < n) s += (double)x[u] * (double)x[u];
+    }
     s = wave_sum(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
@@ -381,42 +390,83 @@ __global__ __launch_bounds__(kThreads) void gradnorm_kernel(const float *g, int6
         scratch[2 + blockIdx.x] = t;
         device_fence();
         last = atomicAdd((int *)(scratch + 1), 1) == (int)gridDim.x - 1;
-        if (last) {
-            device_fence();
-            double tot = 0.0;
-            for (int i = 0; i < (int)gridDim.x; ++i) tot += load_fresh_f64(scratch + 2 + i);
+    }
+    __syncthreads();
+    if (last && tid < 64) {                                  // block-uniform; one wave: the partials in one round trip, fixed tree
+        device_fence();
+        const double v = tid < (int)gridDim.x ? load_fresh_f64(scratch + 2 + tid) : 0.0;
+        const double tot = wave_sum(v);
+        if (tid == 0) {
             scratch[0] = tot;
             *(int *)(scratch + 1) = 0;
         }
     }
 }
 
+// optional extras of the Adam launch (gcc_adam_ema_step): the EMA copy of the parameters and the per-step meters
+struct AdamExtras {
+    float *ema; int64_t n_ema; float ema_m;
+    double *acc; int32_t *mx; const float *loss, *prob; const int32_t *node_off_q, *edge_off_q, *node_off_k; int32_t B;
+};
+
 __global__ __launch_bounds__(kThreads) void adam_kernel(float *p, float *g, float *m, float *v, int64_t n, float lr,
                                                         float b1, float b2, float eps, float wd, float bc1,
                                                         float bc2_sqrt, float max_norm, float grad_scale,
-                                                        const double *sumsq, float *grad_norm)
+                                                        const double *sumsq, float *grad_norm, AdamExtras x)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     // grad_scale: the 1 / world of a summed (all-reduced) gradient, folded in here instead of a launch of its own
-    const float norm = grad_scale * (float)sqrt(sumsq[0]);
+    const double ss = sumsq[0];
+    // this thread's first element rides in the same round trip as the norm
+    const int64_t stride = (int64_t)gridDim.x * kThreads, i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t ic = i0 < n ? i0 : n - 1;
+    float g0 = g[ic], p0 = p[ic], m0 = m[ic], v0 = v[ic];
+    const float e0 = x.ema ? x.ema[i0 < x.n_ema ? i0 : x.n_ema - 1] : 0.f;      // (block-uniform branch)
+    const float norm = grad_scale * (float)sqrt(ss);
     float coef = 1.f;
     if (max_norm > 0.f) {                                      // torch.nn.utils.clip_grad_norm_
         coef = max_norm / (norm + 1e-6f);
         coef = coef > 1.f ? 1.f : coef;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) grad_norm[0] = norm;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        grad_norm[0] = norm;
+        if (x.acc) {                                           // train.py:418-428's meters (gcc_step_meters)
+            const int32_t nq = x.node_off_q[x.B], nk = x.node_off_k[x.B], eq = x.edge_off_q[x.B];
+            x.acc[0] += (double)x.loss[0];
+            x.acc[1] += (double)x.prob[0];
+            x.acc[2] += (double)norm;
+            x.acc[3] += (double)nq + (double)nk;
+            x.acc[4] += 1.0;
+            x.mx[0] = nq > x.mx[0] ? nq : x.mx[0];
+            x.mx[1] = eq > x.mx[1] ? eq : x.mx[1];
+        }
+    }
     coef *= grad_scale;
-    const int64_t stride = (int64_t)gridDim.x * kThreads;
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
-        const float gc = g[i] * coef;
-        g[i] = gc;                                             // the clipped gradient stays visible, as in torch
-        const float gi = fmaf(wd, p[i], gc);                   // weight_decay: grad = grad + wd * param
-        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
-        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] -= (lr / bc1) * (mi / denom);
+    const int64_t nmax = x.ema && x.n_ema > n ? x.n_ema : n;
+    for (int64_t i = i0; i < nmax; i += stride) {
+        float pi, ei = 0.f;
+        if (i != i0) {
+            const int64_t j = i < n ? i : n - 1;
+            g0 = g[j]; p0 = p[j]; m0 = m[j]; v0 = v[j];
+            if (x.ema) ei = x.ema[i < x.n_ema ? i : x.n_ema - 1];
+        } else {
+            ei = e0;
+        }
+        if (i < n) {
+            const float gc = g0 * coef;
+            g[i] = gc;                                         // the clipped gradient stays visible, as in torch
+            const float gi = fmaf(wd, p0, gc);                 // weight_decay: grad = grad + wd * param
+            const float mi = fmaf(b1, m0, (1.f - b1) * gi);
+            const float vi = fmaf(b2, v0, (1.f - b2) * gi * gi);
+            m[i] = mi;
+            v[i] = vi;
+            const float denom = sqrtf(vi) / bc2_sqrt + eps;
+            pi = p0 - (lr / bc1) * (mi / denom);
+            p[i] = pi;
+        } else {
+            pi = p[i];                                         // parameters past the live prefix: only averaged
+        }
+        if (x.ema && i < x.n_ema) x.ema[i] = ei * x.ema_m + (1.f - x.ema_m) * pi;   // p2.mul_(m).add_(1 - m, p1), train.py:169-172
     }
 }
 
@@ -539,8 +589,40 @@ int32_t gcc_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_
     hipLaunchKernelGGL(gradnorm_kernel, dim3(kNormBlocks), dim3(kThreads), 0, s, (const float *)grad, n, scratch);
     int blocks = (int)((n + kThreads - 1) / kThreads);
     if (blocks > 512) blocks = 512;
+    const AdamExtras none = {};
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(kThreads), 0, s, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                       beta2, eps, weight_decay, bc1, bc2_sqrt, max_norm, grad_scale, (const double *)scratch, grad_norm);
+                       beta2, eps, weight_decay, bc1, bc2_sqrt, max_norm, grad_scale, (const double *)scratch, grad_norm, none);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
+int32_t gcc_adam_ema_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                          float grad_scale, float *grad_norm, double *scratch, float *ema, int64_t n_ema, float ema_m,
+                          const gcc_step_meters_args *meters, void *stream)
+{
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !grad_norm || !scratch || n < 1 || step < 1 || !(grad_scale > 0.f) ||
+        (ema && n_ema < n) ||
+        (meters && (!meters->acc || !meters->mx || !meters->loss || !meters->prob || !meters->node_off_q ||
+                    !meters->edge_off_q || !meters->node_off_k || meters->batch_size < 1))) {
+        snprintf(g_err, kErrLen, "gcc_adam_ema_step: bad argument");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(gradnorm_kernel, dim3(kNormBlocks), dim3(kThreads), 0, s, (const float *)grad, n, scratch);
+    AdamExtras x = {};
+    if (ema) { x.ema = ema; x.n_ema = n_ema; x.ema_m = ema_m; }
+    if (meters) {
+        x.acc = meters->acc; x.mx = meters->mx; x.loss = meters->loss; x.prob = meters->prob;
+        x.node_off_q = meters->node_off_q; x.edge_off_q = meters->edge_off_q; x.node_off_k = meters->node_off_k;
+        x.B = meters->batch_size;
+    }
+    const int64_t nmax = ema ? n_ema : n;
+    int blocks = (int)((nmax + kThreads - 1) / kThreads);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(kThreads), 0, s, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                       beta2, eps, weight_decay, bc1, bc2_sqrt, max_norm, grad_scale, (const double *)scratch, grad_norm, x);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 

@@ -214,14 +214,22 @@ class FlatAdam:
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=param.device)
         self._scratch = torch.zeros(64, dtype=torch.float64, device=param.device)
 
-    def step(self, grad_scale=1.0):
-        """``grad_scale``: 1 / world when ``grad`` holds the SUM over ranks (folded into the two launches)."""
+    def step(self, grad_scale=1.0, ema=None, ema_src=None, ema_m=0.0, meters=None):
+        """``grad_scale``: 1 / world when ``grad`` holds the SUM over ranks (folded into the two launches).
+        ``ema`` / ``ema_src`` / ``ema_m``: moment_update of the flat EMA buffer from the flat parameter buffer
+        (``param`` is its live prefix); ``meters`` = (acc, mx, loss, prob, graph_q, graph_k): one step of the
+        device-side meters -- both inside the Adam launch (gcc_adam_ema_step) instead of launches of their own."""
         g = self.param_groups[0]
         self.steps += 1
         st = torch.cuda.current_stream(self.param.device).cuda_stream if self.param.is_cuda else None
-        self.engine.adam(self.param, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"], g["eps"],
-                         g["weight_decay"], self.steps, self.clip_norm, self.grad_norm, self._scratch, stream=st,
-                         grad_scale=grad_scale)
+        if ema is None and meters is None:
+            self.engine.adam(self.param, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"], g["eps"],
+                             g["weight_decay"], self.steps, self.clip_norm, self.grad_norm, self._scratch, stream=st,
+                             grad_scale=grad_scale)
+        else:
+            self.engine.adam_ema(self.param, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"], g["eps"],
+                                 g["weight_decay"], self.steps, self.clip_norm, self.grad_norm, self._scratch, stream=st,
+                                 grad_scale=grad_scale, ema=ema, ema_src=ema_src, ema_m=ema_m, meters=meters)
         return self.grad_norm
 
     def zero_grad(self):
@@ -386,16 +394,17 @@ class MoCoTrainStep:
         for grp in self.optimizer.param_groups:                          # train.py:411-416
             grp["lr"] = lr
         # clip (train.py:409) + Adam (train.py:417); the mean over ranks is folded into the two launches
-        gnorm = self.optimizer.step(grad_scale=1.0 / self.world if self.collectives else 1.0)
-        moment_update(self.model, self.ema, self.alpha, engine=self.nce)  # train.py:430-431
+        # ... moment_update (train.py:430-431) and train.py:418-428's meters ride in the Adam launch: the meters read
+        # this batch's offsets BEFORE its ring slot is handed back below
+        gnorm = self.optimizer.step(grad_scale=1.0 / self.world if self.collectives else 1.0,
+                                    ema=self.flat_ema, ema_src=self.flat, ema_m=self.alpha,
+                                    meters=(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], q, k))
         keys = feat_k
         if self.collectives:
             self._all_gather_end(gathering)
             keys = self.keys_all
         self.nce.enqueue(c.memory, keys, c.index, save=False, stream=st)
         c.index = (c.index + keys.shape[0]) % c.queueSize
-        # train.py:418-428's meters, on the device and BEFORE the ring slot of this batch is handed back
-        self.nce.meters(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], gnorm, q, k, stream=st)
         self.producer.release(step)
         return dict(loss=outs["loss"], prob=outs["prob"], grad_norm=gnorm, graph_q=q, graph_k=k)
 
@@ -468,7 +477,7 @@ class E2ETrainStep:
         self.gin.backward(self.model, pk, bufk, dk, targets=self.grad_views, accumulate=True, stream=st)
         for grp in self.optimizer.param_groups:                          # train.py:411-416
             grp["lr"] = lr
-        gnorm = self.optimizer.step()                                    # clip (train.py:409) + Adam (train.py:417)
-        self.nce.meters(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], gnorm, q, k, stream=st)
+        # clip (train.py:409) + Adam (train.py:417), train.py:418-428's meters inside the Adam launch
+        gnorm = self.optimizer.step(meters=(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], q, k))
         self.producer.release(step)
         return dict(loss=outs["loss"], prob=outs["prob"], grad_norm=gnorm, graph_q=q, graph_k=k)

@@ -410,6 +410,23 @@ int32_t gcc_step_meters(double *acc, int32_t *mx, const float *loss, const float
 /* moment_update of train.py:169-172 over one flat parameter buffer: ema = m * ema + (1 - m) * p */
 int32_t gcc_ema_update(float *ema, const float *p, int64_t n, float m, void *stream);
 
+/* The tail of a MoCo step (train.py:409,417-431) in the two launches of gcc_adam_step: clip + Adam over param[0, n),
+ * then -- inside the Adam launch -- moment_update of ema[0, n_ema) from param[0, n_ema) (n_ema >= n: the live
+ * parameters are a prefix of the flat buffer; the rest is only averaged, as the reference averages its unused
+ * set2set / lin_readout weights) and one step of gcc_step_meters with this step's gradient norm.  ema == NULL and/or
+ * meters == NULL leave that part out; with both NULL this is gcc_adam_step.  Same results as the three calls. */
+typedef struct {
+    double *acc;                 /* device double[5], as gcc_step_meters */
+    int32_t *mx;                 /* device int32[2] */
+    const float *loss, *prob;    /* device [1] each */
+    const int32_t *node_off_q, *edge_off_q, *node_off_k;
+    int32_t batch_size;
+} gcc_step_meters_args;
+int32_t gcc_adam_ema_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                          float grad_scale, float *grad_norm, double *scratch, float *ema, int64_t n_ema, float ema_m,
+                          const gcc_step_meters_args *meters, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
