@@ -417,11 +417,26 @@ __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
     const int b = (int)blockIdx.x * 16 + j;
     const bool valid = b < a.B;
+    // the statistics of BatchNorm blockIdx.x (added up at the end of this kernel) are requested now: in flight with the scores
+    const bool bn_work = (a.update_running || a.totals) && (int)blockIdx.x < 3 * a.nlayers;     // block-uniform
+    RepReq rq = {};
+    float rm0 = 0.f, rv0 = 0.f;
+    if (bn_work) {       // (not the node count: the compiler moves it to a scalar register at once, a wait for everything here)
+        const BnDev &bn0 = a.bn[blockIdx.x];
+        rq = rep_request(bn0.stats, 2 * H);
+        rm0 = bn0.running_mean[tid & (H - 1)];
+        rv0 = bn0.running_var[tid & (H - 1)];
+    }
     F4 score[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) { F4 z = {0.f, 0.f, 0.f, 0.f}; score[cb] = z; }
-    for (int i = wv; i <= a.nlayers; i += 4) {
+    for (int i = wave_uniform(wv); i <= a.nlayers; i += 4) {       // (scalar: pred_w[i] / pred_b[i] are scalar loads, not a round trip)
         const int kd = i == 0 ? a.kdim0 : H;
+        F4 wf[4][4];
+        load_w_frags(a.pred_w[i], kd, wf);                         // weights and biases first: the fp64 -> f32 conversions
+        F4 bias4[4];                                               // below wait for whatever was requested before them
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) bias4[cb] = ld4(a.pred_b[i] + 16 * cb + 4 * q);
         F4 xb[4];
         const double *prow = a.pooled + ((int64_t)i * a.B + (valid ? b : 0)) * H + 4 * q;   // (unconditional loads, masked afterwards)
         double pd[4][4];
@@ -429,16 +444,12 @@ __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int e = 0; e < 4; ++e) pd[c][e] = prow[16 * c + e];
+        SCHED_FENCE();                                             // (all requested before the first conversion waits)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const F4 x = {(float)pd[c][0], (float)pd[c][1], (float)pd[c][2], (float)pd[c][3]}, z = {0.f, 0.f, 0.f, 0.f};
             xb[c] = valid ? x : z;
         }
-        F4 wf[4][4];
-        load_w_frags(a.pred_w[i], kd, wf);
-        F4 bias4[4];                                               // (requested with the weights, not one by one in the epilogue)
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) bias4[cb] = ld4(a.pred_b[i] + 16 * cb + 4 * q);
         f32x4 acc[4];
         mfma_rows16(xb, wf, acc);                                  // linears_prediction[i](pooled_h)
 #pragma unroll
@@ -479,15 +490,24 @@ __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
     }
     // BatchNorm k by workgroup k % gridDim.x: the replicas of its batch statistics added up once for the ~16 kernels of
     // the backward pass that need them, and the running statistics (torch: momentum 0.1, unbiased variance)
-    if (a.update_running || a.totals) {                       // block-uniform
-        const double n = (double)a.node_off[a.B];
+    if (bn_work) {                                            // block-uniform
+        const int n_nodes = a.node_off[a.B];
         double *scratch = (double *)&part[0][0][0];
         for (int k = (int)blockIdx.x; k < 3 * a.nlayers; k += (int)gridDim.x) {
             __syncthreads();                                   // the partial scores / the previous BatchNorm's sums are done with
             const BnDev &bn = a.bn[k];
-            replica_sums128(bn.stats, 2 * H, scratch);
+            float rm = rm0, rv = rv0;
+            if (k == (int)blockIdx.x) {                        // requested at the top of the kernel
+                scratch[tid] = rep_sum(rq);
+                __syncthreads();
+            } else {                                           // (batches of fewer than 16 * 3 * nlayers graphs)
+                replica_sums128(bn.stats, 2 * H, scratch);
+                rm = bn.running_mean[tid & (H - 1)];
+                rv = bn.running_var[tid & (H - 1)];
+            }
             if (tid < H) {
                 const int c = tid;
+                const double n = (double)n_nodes;
                 const double s1 = scratch[c] + scratch[128 + c], s2 = scratch[H + c] + scratch[128 + H + c];
                 if (a.totals) { a.totals[(int64_t)k * 2 * H + c] = s1; a.totals[(int64_t)k * 2 * H + H + c] = s2; }
                 if (a.update_running) {
@@ -495,8 +515,8 @@ __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
                     double var = s2 / n - mean * mean;
                     if (var < 0.0) var = 0.0;
                     const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-                    bn.running_mean[c] = (float)((1.0 - a.momentum) * (double)bn.running_mean[c] + a.momentum * mean);
-                    bn.running_var[c] = (float)((1.0 - a.momentum) * (double)bn.running_var[c] + a.momentum * unb);
+                    bn.running_mean[c] = (float)((1.0 - a.momentum) * (double)rm + a.momentum * mean);
+                    bn.running_var[c] = (float)((1.0 - a.momentum) * (double)rv + a.momentum * unb);
                     if (c == 0 && bn.nbt) bn.nbt[0] += 1;
                 }
             }

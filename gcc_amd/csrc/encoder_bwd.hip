@@ -175,23 +175,38 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_readout_kernel(ReadBwdArgs a
         for (int64_t i = (int64_t)((int)blockIdx.x - a.nread) * kThreads + threadIdx.x; i < a.zero16; i += stride) a.zero[i] = z4;
         return;
     }
+    // one wave = (16 graphs, one prediction layer): the layers of a block of graphs run side by side instead of as a
+    // chain of 5 dependent (weights round trip -> product -> store) steps in one wave; d score is recomputed per layer
     const int lane = lane_id(), wv = (int)threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
-    const int b = ((int)blockIdx.x * 4 + wv) * 16 + j;
+    const int nl1 = a.nlayers + 1, job = wave_uniform((int)blockIdx.x * 4 + wv);   // (scalar: pred_w[i] is a scalar load)
+    const int i = job % nl1, blk = job / nl1;
+    if (blk * 16 >= a.B) return;                   // wave-uniform (the kernel has no barriers)
+    const int b = blk * 16 + j;
     const bool valid = b < a.B;
+    F4 wf[4][4];
+    load_wt_frags(a.pred_w[i], i == 0 ? a.kdim0 : H, wf);          // requested first: in flight with d feat / score / feat
     F4 ds[4];
     float ss = 0.f, dot = 0.f;
-    F4 fv[4];
+    F4 fv[4], sv[4];
+    {   // d feat, score and feat of the graph: all 12 loads requested together (unconditional, masked afterwards)
+        const int64_t rb = (int64_t)(valid ? b : 0) * H + 4 * q;
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        const int ch = 16 * cb + 4 * q;
-        F4 z = {0.f, 0.f, 0.f, 0.f};
-        ds[cb] = valid ? ld4(a.dfeat + (int64_t)b * H + ch) : z;
-        fv[cb] = z;
-        if (a.normalize && valid) {
-            const F4 s = ld4(a.score + (int64_t)b * H + ch);
-            fv[cb] = ld4(a.feat + (int64_t)b * H + ch);
-            ss += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
-            dot += fv[cb].x * ds[cb].x + fv[cb].y * ds[cb].y + fv[cb].z * ds[cb].z + fv[cb].w * ds[cb].w;
+        for (int cb = 0; cb < 4; ++cb) {
+            ds[cb] = ld4(a.dfeat + rb + 16 * cb);
+            sv[cb] = ld4(a.score + rb + 16 * cb);
+            fv[cb] = ld4(a.feat + rb + 16 * cb);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const F4 z = {0.f, 0.f, 0.f, 0.f};
+            if (!valid) ds[cb] = z;
+            if (a.normalize && valid) {
+                const F4 s = sv[cb];
+                ss += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+                dot += fv[cb].x * ds[cb].x + fv[cb].y * ds[cb].y + fv[cb].z * ds[cb].z + fv[cb].w * ds[cb].w;
+            } else {
+                fv[cb] = z;
+            }
         }
     }
     if (a.normalize) {
@@ -208,8 +223,7 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_readout_kernel(ReadBwdArgs a
             }
         }
     }
-    for (int i = 0; i <= a.nlayers; ++i) {
-        const int kd = i == 0 ? a.kdim0 : H;
+    {
         F4 g[4];
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
@@ -220,8 +234,6 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_readout_kernel(ReadBwdArgs a
             g[cb] = gg;
             if (valid) st4(a.G + ((int64_t)i * a.B + b) * H + ch, gg);
         }
-        F4 wf[4][4];
-        load_wt_frags(a.pred_w[i], kd, wf);
         f32x4 acc[4];
         mfma_rows16(g, wf, acc);                                   // dpooled_i = G_i W_i
         if (valid) {
@@ -618,19 +630,19 @@ __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
     const WgradJob &jb = a.job[jid];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
     __shared__ float Sb[4 * H];
-    const int Nn = a.node_off[a.B];
-    const int N = jb.rows_fixed > 0 ? jb.rows_fixed : Nn;
     const bool act = jb.bn.weight != nullptr;
-    if (tid < H) {
-        float sc = 1.f, sh = 0.f;
-        if (act) bn_scale_shift(jb.bn, tid, (double)Nn, a.eps, 1, sc, sh);
-        Cx[tid] = sc;
-        Cx[H + tid] = sh;
-    }
-    __syncthreads();
-    float xs[4], xh[4];
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) { xs[kb] = Cx[16 * kb + j]; xh[kb] = Cx[H + 16 * kb + j]; }
+    const bool fast = act && jb.bn.totals != nullptr;    // block-uniform: the statistics' totals exist (the usual case)
+    // the BatchNorm numbers of channel tid & 63, the node count and (below) the first tile's rows: one round trip
+    // (the chain was node count -> totals -> weights -> first tile)
+    // (unconditional: a job without a BatchNorm reads 4 numbers of the slab workspace and ignores them -- under `if (fast)`
+    //  the requests wait inside the branch, ahead of the node count)
+    const int cc = tid & (H - 1);
+    const double *tp = fast ? jb.bn.totals : (const double *)a.slabs;
+    const float *wp = fast ? jb.bn.weight : a.slabs, *bp = fast ? jb.bn.bias : a.slabs;
+    const CoefReq cr = {tp[cc], tp[H + cc], wp[cc], bp[cc]};
+    const int Nn = a.node_off[a.B];
+    SCHED_FENCE();
+    const int N = jb.rows_fixed > 0 ? jb.rows_fixed : Nn;
     f32x4 acc[4][4];
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -643,19 +655,32 @@ __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
     // (unconditional loads from a clamped row, masked afterwards: under `row < N` branches every load waited for the one before)
     const bool xdouble = jb.Xd != nullptr;               // block-uniform: prediction layers read the fp64 pooled sums
     auto fetch = [&](int tile0, float (&A)[4][4], float (&X)[4][4]) {
+        int64_t off[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int row = tile0 + 16 * wv + 4 * s + q;     // MFMA reduction index = row
-            const int64_t off = (int64_t)(row < N ? row : 0) * H + j;
+            off[s] = (int64_t)(row < N ? row : 0) * H + j;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) A[s][k] = jb.dZ[off + 16 * k];
-            if (xdouble) {
+            for (int k = 0; k < 4; ++k) A[s][k] = jb.dZ[off[s] + 16 * k];
+        }
+        if (xdouble) {                                       // (8 requested before the first conversion waits: 16 would spill)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) X[s][k] = (float)jb.Xd[off + 16 * k];
-            } else {
+            for (int h = 0; h < 4; h += 2) {
+                double xd[2][4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) X[s][k] = jb.X[off + 16 * k];
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xd[s][k] = jb.Xd[off[h + s] + 16 * k];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) X[h + s][k] = (float)xd[s][k];
             }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) X[s][k] = jb.X[off[s] + 16 * k];
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -666,6 +691,25 @@ __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
     };
     TileWalk tw(N);
     if (tw.ti < tw.tend) fetch(tw.ti * kTile, av, xv);
+    if (tid < H) {
+        float sc = 1.f, sh = 0.f;
+        if (fast) {
+            const double mean = cr.s1 / (double)Nn;
+            double var = cr.s2 / (double)Nn - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double rstd = 1.0 / sqrt(var + (double)a.eps);
+            sc = (float)((double)cr.gamma * rstd);
+            sh = (float)((double)cr.beta - mean * (double)cr.gamma * rstd);
+        } else if (act) {
+            bn_scale_shift(jb.bn, tid, (double)Nn, a.eps, 1, sc, sh);
+        }
+        Cx[tid] = sc;
+        Cx[H + tid] = sh;
+    }
+    __syncthreads();
+    float xs[4], xh[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) { xs[kb] = Cx[16 * kb + j]; xh[kb] = Cx[H + 16 * kb + j]; }
     for (; tw.ti < tw.tend; tw.ti += tw.step) {
         const int tile0 = tw.ti * kTile;
         float an[4][4], xn[4][4];
@@ -909,7 +953,7 @@ extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat
         a.G = w.G; a.dpooled = w.dpooled; a.B = B; a.nlayers = L; a.kdim0 = kdim0; a.normalize = p.normalize;
         a.norm_eps = p.w.norm_eps;
         // the per-call accumulators (BatchNorm-backward column sums) are cleared by extra workgroups of this launch
-        a.zero = (float4 *)((char *)workspace + w.off_zero); a.zero16 = w.zero_bytes / 16; a.nread = (B + 63) / 64;
+        a.zero = (float4 *)((char *)workspace + w.off_zero); a.zero16 = w.zero_bytes / 16; a.nread = ((B + 15) / 16 * (L + 1) + 3) / 4;
         hipLaunchKernelGGL(gin_bwd_readout_kernel, dim3(a.nread + 64), block, 0, s, a);
     }
     for (int l = L - 1; l >= 0; --l) {
