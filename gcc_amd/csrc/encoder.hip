@@ -126,7 +126,13 @@ static long long *g_gin_ticks = nullptr;   // diagnostics (gcc_gin_debug_ticks)
 #define GIN_TICK(ph) do { if (L.ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&L.ticks[(a.first ? 0 : 16) + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 
 // (3 workgroups per CU by LDS -- 48.8 KiB with the staged weight -- so up to 168 registers are free: 8 gathered rows in flight)
-__global__ __launch_bounds__(kThreads, 3) void gin_in_kernel(InLaunch L)
+#ifndef GIN_IN_PER_CU
+#define GIN_IN_PER_CU 3
+#endif
+#ifndef GIN_GATHER_J
+#define GIN_GATHER_J 8
+#endif
+__global__ __launch_bounds__(kThreads, GIN_IN_PER_CU) void gin_in_kernel(InLaunch L)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
@@ -153,10 +159,12 @@ __global__ __launch_bounds__(kThreads, 3) void gin_in_kernel(InLaunch L)
             const BnReq rb = bn_request(a.bnb), rc = bn_request(a.bnc);
             N = a.node_off[a.B];                   // (requested after the statistics: the wait for it is the wait for all)
             SCHED_FENCE();
+            if (no_tiles(N)) return;
             bn_table_finish(tabb, rb, (double)N, a.eps, a.training, (double *)part);
             bn_table_finish(tabc, rc, (double)N, a.eps, a.training, (double *)part);
         } else {
             N = ((const volatile int32_t *)a.node_off)[a.B];       // (volatile: an ordinary load is hoisted above the branch, ahead of the other arm's requests)
+            if (no_tiles(N)) return;
         }
 #if GIN_IN_LDS_W
         stage_weights_store(Wl, wst, a.kdim);
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(kThreads, 3) void gin_in_kernel(InLaunch L)
         GIN_TICK(2);
         // 3. GINConv aggregate: (1 + eps) * h_v + sum_{u -> v} h_u, eps = 0 (gin.py:179-185,218)
 #if !(GIN_DBG_SKIP & 4)
-        gather_tile<8>(T, part, prow, nrows, a.col_idx, load, xform, a.nbr_weight, rpl);
+        gather_tile<GIN_GATHER_J>(T, part, prow, nrows, a.col_idx, load, xform, a.nbr_weight, rpl);
 #endif
         GIN_TICK(3);
         // 4. keep agg for the weight gradient of linears.0
@@ -263,6 +271,7 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
     const BnReq ra = bn_request(a.bna);
     const int N = a.node_off[a.B];                           // (requested last: the wait for it is the wait for all)
     SCHED_FENCE();
+    if (no_tiles(N)) return;
     bn_table_finish(taba, ra, (double)N, a.eps, a.training, (double *)red);
     stage_weights_store(Wl, wst, H);
     if (tid < H) bl[tid] = b_own;
@@ -312,6 +321,7 @@ __global__ __launch_bounds__(kThreads) void gin_stat_kernel(StatLaunch L)
     const BnReq rb = bn_request(a.bnb);
     const int N = a.node_off[a.B];                           // (requested last: the wait for it is the wait for all)
     SCHED_FENCE();
+    if (no_tiles(N)) return;
     bn_table_finish(tabb, rb, (double)N, a.eps, a.training, (double *)part);
     const Aff4 ab = aff4_from_table(tabb, 4 * t);
     F4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
@@ -369,6 +379,7 @@ __global__ __launch_bounds__(kThreads) void gin_pool_kernel(PoolLaunch L)
     const BnReq rb = bn_request(a.bnb), rc = bn_request(a.bnc);
     const int N = a.node_off[a.B];                           // (requested last: the wait for it is the wait for all)
     SCHED_FENCE();
+    if (no_tiles(N)) return;
     bn_table_finish(tabb, rb, (double)N, a.eps, a.training, (double *)T);
     bn_table_finish(tabc, rc, (double)N, a.eps, a.training, (double *)T);
     const Aff4 ab = aff4_from_table(tabb, 4 * t);

@@ -261,7 +261,13 @@ struct BwdCArgs {
 };
 
 // (the grid is 3 workgroups per CU: 168 registers each)
-__global__ __launch_bounds__(kThreads, 3) void gin_bwd_c_kernel(BwdCArgs a)
+#ifndef BWD_C_PER_CU
+#define BWD_C_PER_CU 3
+#endif
+#ifndef BWD_GATHER_J
+#define BWD_GATHER_J 8
+#endif
+__global__ __launch_bounds__(kThreads, BWD_C_PER_CU) void gin_bwd_c_kernel(BwdCArgs a)
 {
     TRAIN_STEP_WAVE_PRIORITY();
     __shared__ float T[kTile * kLdt];
@@ -276,6 +282,7 @@ __global__ __launch_bounds__(kThreads, 3) void gin_bwd_c_kernel(BwdCArgs a)
         const RepReq none = {};
         N = a.node_off[a.B];                       // (requested last: the wait for it is the wait for all)
         SCHED_FENCE();
+        if (no_tiles(N)) return;
         fill_coefs_from<false>(Cb, rb, none, (double)N, a.eps, (double *)part);
         fill_coefs_from<false>(Cc, rc, none, (double)N, a.eps, (double *)part);
         __syncthreads();
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(kThreads, 3) void gin_bwd_c_kernel(BwdCArgs a)
 #pragma unroll
             for (int i = 0; i < kTile / 16; ++i) g4[i] = ld4(a.dpooled + (int64_t)gid4[i] * H + 4 * t);
             __syncthreads();
-            gather_tile<8>(T, part, prow, nrows, a.col_idx, ident, [](F4 x) { return x; }, 1.0f, rpl);
+            gather_tile<BWD_GATHER_J>(T, part, prow, nrows, a.col_idx, ident, [](F4 x) { return x; }, 1.0f, rpl);
         } else {
 #pragma unroll
             for (int i = 0; i < kTile / 16; ++i) z4[i] = ld4(a.z2 + (int64_t)min(tile0 + gi + 16 * i, N - 1) * H + 4 * t);
@@ -369,6 +376,7 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_b_kernel(BwdBArgs a)
         const RepReq sc = rep_request(a.bst_c, 3 * H);
         N = a.node_off[a.B];                       // (requested last: the wait for it is the wait for all)
         SCHED_FENCE();
+        if (no_tiles(N)) return;
         fill_coefs_from<false>(Cb, rb, sc, (double)N, a.eps, (double *)part);
         fill_coefs_from<true>(Cc, rc, sc, (double)N, a.eps, (double *)part);
         __syncthreads();
@@ -448,6 +456,7 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_lin_kernel(BwdLinArgs a)
         const RepReq si = rep_request(a.bst_in, 3 * H);
         N = a.node_off[a.B];                       // (requested last: the wait for it is the wait for all)
         SCHED_FENCE();
+        if (no_tiles(N)) return;
         fill_coefs_from<true>(Ci, ri, si, (double)N, a.eps, (double *)red);
         if (kMask) fill_coefs_from<false>(Co, ro, si, (double)N, a.eps, (double *)red);
     } else {
@@ -570,7 +579,7 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
             for (int i = 0; i < kTile / 16; ++i) st4(&T[(gi + 16 * i) * kLdt + 4 * t], gi + 16 * i < nrows ? own[i] : zero4());
         }
         __syncthreads();
-        gather_tile<8>(T, part, prow, nrows, a.col_idx, ident, [](F4 x) { return x; }, 1.0f, rpl);
+        gather_tile<BWD_GATHER_J>(T, part, prow, nrows, a.col_idx, ident, [](F4 x) { return x; }, 1.0f, rpl);
         // all threads: add the pooled-path gradient and look the clamped degree up (global loads in parallel) ...
         if (tid < nrows) {
             const int deg = rpl[tid + 1] - rpl[tid];

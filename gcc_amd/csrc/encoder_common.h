@@ -23,6 +23,9 @@ constexpr int kRep = 32;            // replicas of every atomically accumulated 
 // the 256 MiB Infinity Cache either way): no difference, 0.720 vs 0.716 ms per step (scripts/gpu/r3_call23.sh) -- what the
 // gather waited for was its own serialised loads (gather_tile below), not the fabric.  Kept: it is the mapping the guide
 // recommends and it cannot hurt larger batches.
+// no_tiles(N): this workgroup has nothing to walk -- the tile kernels return on it as soon as the node count is known,
+// before their tables and staged weights (the grid is sized for the node CAPACITY: at bsz 256 about half of the 768
+// workgroups of a launch have no tile, and their prologues competed with the others' for LDS and issue slots).
 struct TileWalk {
     int ti, tend, step;
     __device__ __forceinline__ explicit TileWalk(int N)
@@ -38,6 +41,7 @@ struct TileWalk {
         }
     }
 };
+__device__ __forceinline__ bool no_tiles(int N) { const TileWalk tw(N); return tw.ti >= tw.tend; }
 
 struct F4 { float x, y, z, w; };
 

@@ -304,6 +304,9 @@ __global__ __launch_bounds__(kThreads) void nce_combine_kernel(NceDev a)
     }
 }
 
+#ifndef NCE_DQ_BATCH
+#define NCE_DQ_BATCH 16      // slabs requested per round
+#endif
 __global__ __launch_bounds__(kThreads) void nce_dq_kernel(NceDev a)
 {
     TRAIN_STEP_WAVE_PRIORITY();
@@ -318,12 +321,12 @@ __global__ __launch_bounds__(kThreads) void nce_dq_kernel(NceDev a)
     F4 s = {0.f, 0.f, 0.f, 0.f};
     const float *sp = a.slabs + (int64_t)b * D + c4;
     const int64_t st = (int64_t)a.B * D;
-    for (int sl = 0; sl < a.S; sl += 16) {           // fixed summation order: slab 0, 1, 2, ...
-        F4 v[16];
+    for (int sl = 0; sl < a.S; sl += NCE_DQ_BATCH) {  // fixed summation order: slab 0, 1, 2, ...
+        F4 v[NCE_DQ_BATCH];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = ld4(sp + (int64_t)min(sl + u, a.S - 1) * st);
+        for (int u = 0; u < NCE_DQ_BATCH; ++u) v[u] = ld4(sp + (int64_t)min(sl + u, a.S - 1) * st);
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < NCE_DQ_BATCH; ++u)
             if (sl + u < a.S) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     }
     const int nrows = a.by_mem_row ? a.K : a.B;              // rows of the softmax that is averaged

@@ -67,6 +67,10 @@ __device__ __forceinline__ void item_args(const PosMulti &m, int item, struct Po
 // vectors), so M' is ~40 % smaller and the O(n^3) dense solve ~5x cheaper; an eigenvector y of M' expands
 // to the leaves as y[super-leaf] / sqrt(t).  Any orthonormal basis of a degenerate eigenspace is
 // as good as ARPACK's, so when the top-k reaches into the null space the contrasts are used.
+#ifndef GCC_POSEMB_MID_THREADS
+#define GCC_POSEMB_MID_THREADS 1024
+#endif
+constexpr int kMidT = GCC_POSEMB_MID_THREADS;    // workgroup size of the 65..kJMax class
 constexpr int kNodeMax = 1024;       // largest subgraph the deflating direct kernels look at (per-node LDS tables)
 constexpr uint16_t kNone = 0xFFFFu;
 constexpr float kZeroEig = 1e-5f;    // |lambda| below this is "the null space" when ranking
@@ -3044,13 +3048,13 @@ int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, 
         hd.use_stalks = es ? atoi(es) != 0 : 1;
     }
     constexpr int lds_small = direct_lds_bytes<kJSmall, kSmallT, false>();
-    constexpr int lds_big = direct_lds_bytes<kJMax, 1024, false>();
+    constexpr int lds_big = direct_lds_bytes<kJMax, kMidT, false>();
 #ifndef GCC_AMD_HIPEMU
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsSmall, 0, kJSmall, kSmallT, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_small);
-        (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, 1024, false>,
+        (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, kMidT, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
         (void)hipFuncSetAttribute((const void *)posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kGLds);
@@ -3110,7 +3114,7 @@ int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, 
     hipLaunchKernelGGL(posemb_krylov_kernel, dim3(g.kry), dim3(kKThreads), lds_kry, s, ka);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsBig, kGMax + 1, kBMax, 1024, true>), dim3(g.big), dim3(1024), kBLds, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>), dim3(g.slot), dim3(1024), kGLds, s, m, hd);
-    hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, 1024, false>), dim3(g.mid), dim3(1024), lds_big, s, m, hd);
+    hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, kMidT, false>), dim3(g.mid), dim3(kMidT), lds_big, s, m, hd);
     if (heavy_record) (void)hipEventRecord((hipEvent_t)heavy_record, s);
     prof_mark(prof, 1, s);
     hipError_t e = hipGetLastError();
