@@ -64,13 +64,24 @@ for i in range(a.steps):
 torch.cuda.synchronize()
 eager = (time.perf_counter() - t0) / a.steps * 1e3
 
+# host cost of issuing a step: a burst short enough for the hardware queue to take without back-pressure, timed WITHOUT a
+# synchronisation (if this is close to the step time, the host thread -- which also issues the producer lanes' launches in
+# the real pipeline -- is what the step waits for)
+burst = 24
+t0 = time.perf_counter()
+for i in range(burst):
+    tr.step(20 + a.steps + i, 0.005)
+host = (time.perf_counter() - t0) / burst * 1e3
+torch.cuda.synchronize()
+print(f"host time to issue one step (Python + {burst}-step burst, no synchronisation): {host:.3f} ms")
+
 side = torch.cuda.Stream(dev)
 g = torch.cuda.CUDAGraph()
 with torch.cuda.stream(side):
-    tr.step(1000, 0.005)
+    tr.step(100000, 0.005)
     torch.cuda.synchronize()
     with torch.cuda.graph(g, stream=side):
-        tr.step(1001, 0.005)
+        tr.step(100001, 0.005)
 torch.cuda.synchronize()
 for i in range(10):
     g.replay()
