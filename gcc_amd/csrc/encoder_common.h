@@ -159,7 +159,9 @@ __device__ __forceinline__ BnReq bn_request(const BnDev &bn)
     BnReq r;
     r.rep = rep_request(bn.stats, 2 * H);
     r.w = bn.weight[c]; r.b = bn.bias[c];
-    r.rm = bn.running_mean[c]; r.rv = bn.running_var[c];
+    // (a training-mode caller without running statistics: the values are not used then -- read the weights again instead)
+    const float *rmp = bn.running_mean ? bn.running_mean : bn.weight, *rvp = bn.running_var ? bn.running_var : bn.weight;
+    r.rm = rmp[c]; r.rv = rvp[c];
     return r;
 }
 __device__ __forceinline__ void bn_table_finish(float *tab, const BnReq &r, double n, float eps, int training, double *scratch)

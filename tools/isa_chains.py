@@ -110,7 +110,8 @@ def main():
             continue
         c = chain(body)
         waits = c.count("W")
-        print(f"{pretty.split('(')[0]}: {len(body)} lines, {waits} vector-load waits")
+        m = re.search(r"\d+([a-z0-9_]+_kernel(?:IL[a-z0-9_]+E)?)", name)
+        print(f"{m.group(1) if m else pretty}: {len(body)} lines, {waits} vector-load waits")
         print("   " + c)
 
 
