@@ -436,3 +436,22 @@ def test_subgraph_larger_than_its_share_of_node_cap_is_refused_loudly():
     assert not b.pos_undirected[:n].any()                    # zeros, not garbage
     with pytest.raises(RuntimeError):
         pe.check_status()
+
+
+def dense_views():
+    """Ego-nets whose CSR does NOT fit the LDS staging area of their solver class (csr_stage's fall-back to global memory),
+    next to ones that do: a 60-node random graph of density 0.7 (one-wave team: n + 1 + E = 61 + ~2480 > 2048 ints), a
+    110-node one of density 0.8 (65..128 class: ~9600 > its 7552 ints) and two sparse ones of the same sizes."""
+    rng = np.random.default_rng(3)
+    views = []
+    for n, p in ((60, 0.7), (60, 0.06), (110, 0.8), (110, 0.04)):
+        edges = [(i, j) for i in range(n) for j in range(i + 1, n) if rng.random() < p]
+        edges += [(i, i + 1) for i in range(n - 1)]                       # connected
+        views.append(_view_of(n, edges))
+    return views
+
+
+def test_dense_ego_nets_that_do_not_fit_the_csr_staging_area():
+    for view in dense_views():
+        x, evals, raw = _run(view)
+        _check(view, x, evals, raw)

@@ -83,6 +83,24 @@ def test_stalk_deflation_on_device():
     _check(view, x, evals, raw)
 
 
+def test_dense_ego_nets_that_do_not_fit_the_csr_staging_area_on_device():
+    """csr_stage's fall-back to global memory (ego-nets denser than the LDS staging area of their class) next to staged ones:
+    the synthetic dense graphs of the emulator tier through the device kernels."""
+    from gcc_amd.sampler import BatchedCSR
+    from tests.test_posemb_emu import _check, dense_views
+
+    for view in dense_views():
+        no, rp, ci = (view[k].numpy() for k in ("node_off", "row_ptr", "col_idx"))
+        B, n = len(no) - 1, int(no[-1])
+        i32 = dict(dtype=torch.int32, device="cuda")
+        q = BatchedCSR(B, torch.from_numpy(no.astype(np.int32)).cuda(), torch.from_numpy(rp[no].astype(np.int32)).cuda(),
+                       torch.zeros(n, **i32), torch.from_numpy(np.repeat(np.arange(B), np.diff(no)).astype(np.int32)).cuda(),
+                       torch.from_numpy(rp.astype(np.int32)).cuda(), torch.from_numpy(ci.astype(np.int32)).cuda())
+        q.pos_undirected = torch.zeros(n, HID, device="cuda")
+        _, x, evals, raw = _device_posemb(q, B)
+        _check(view, x, evals, raw)
+
+
 def test_krylov_fallback_on_device():
     """No twin leaves, n = 760 > GCC_POSEMB_BIG_MAX: the Krylov-Schur kernel runs (same case as the emulator test)."""
     import scipy.sparse as sp
