@@ -356,43 +356,6 @@ struct PosHead {                     // head of the caller's workspace (zeroed p
     int64_t slot_floats;
 };
 
-// The ego-net's CSR staged in LDS: row pointers rebased to 0 and neighbour ids as LOCAL ids (ints [n + 1 + E]).  The
-// deflation passes, the matrix fill and the expansion records chase rp[i] -> col[e] -> rp[j + 1] - rp[j]: from global
-// memory that is 2-3 DEPENDENT round trips per step of every pass (the fill of a one-wave team walks a row edge by edge:
-// 16 / 33 of the 38 / 69 us of an item).  One coalesced copy (a few round trips for the whole ego-net), then LDS only.
-// An ego-net that does not fit keeps reading global memory through the same three variables (rp, col, base).
-constexpr int kWaveStage = 2048;     // ints per one-wave team (n + 1 + E <= 2048: 8 KiB; the 48 class stays below 110 KiB per workgroup)
-#ifndef GCC_POSEMB_STAGE_CSR
-#define GCC_POSEMB_STAGE_CSR 1
-#endif
-struct CsrView { const int32_t *rp, *col; int base; };
-// kThreads threads (tid of them) copy; the caller synchronises afterwards.  Loads in batches of 4 independent requests.
-template <int kThreads>
-__device__ __forceinline__ CsrView csr_stage(const int32_t *rp_g, const int32_t *col_g, int n0, int n, int32_t *stage, int cap, int tid)
-{
-    CsrView v = {rp_g, col_g, n0};
-    if (!GCC_POSEMB_STAGE_CSR) return v;
-    const int e0 = rp_g[0], E = rp_g[n] - e0;       // (uniform)
-    if (n + 1 + E > cap) return v;
-    for (int i0 = 0; i0 <= n; i0 += 4 * kThreads) {
-        int x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) x[u] = rp_g[min(i0 + tid + u * kThreads, n)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (i0 + tid + u * kThreads <= n) stage[i0 + tid + u * kThreads] = x[u] - e0;
-    }
-    int32_t *cs = stage + n + 1;
-    for (int j0 = 0; j0 < E; j0 += 4 * kThreads) {
-        int x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) x[u] = col_g[e0 + min(j0 + tid + u * kThreads, E - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (j0 + tid + u * kThreads < E) cs[j0 + tid + u * kThreads] = x[u] - n0;
-    }
-    v.rp = stage; v.col = cs; v.base = 0;
-    return v;
-}
-
 // The deflation tables (24 KiB) are built in LDS where the eigenvector arrays go later; the 8 bytes per node that the
 // expansion at the end needs of them (defl_record) go to the workspace: it keeps the mid class at 132 KiB, so that a
 // workgroup of the training step (26 KiB) still fits on the same CU, and the small class at 50 KiB (3 per CU).
@@ -1599,24 +1562,14 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     static_assert(direct_lds_bytes<kNMax, kT, kGlobalA>() - (int)sizeof(float) * (6 * kNMax + 32 * kYld + kT + (kGlobalA ? 0 : kNMax * (kNMax + 1)))
                   >= kNodeMax * kDeflNodeBytes, "the deflation tables overlay the eigenvector / LU region");
     defl_bind(d, lds_rest, kNodeMax);
-    // the LDS-resident classes stage the ego-net's CSR (csr_stage) behind the deflation tables, in the same eigenvector /
-    // LU region: everything that reads it (table build, matrix fill, expansion records) is over before that region is written
-    CsrView cv = {a.row_ptr + n0, a.col_idx, n0};
-    if (!kGlobalA) {
-        constexpr int kStageCap = (direct_lds_bytes<kNMax, kT, kGlobalA>()
-                                   - (int)sizeof(float) * (6 * kNMax + 32 * kYld + kT + kNMax * (kNMax + 1)) - kNodeMax * kDeflNodeBytes) / 4;
-        cv = csr_stage<kT>(a.row_ptr + n0, a.col_idx, n0, n, (int32_t *)((char *)lds_rest + kNodeMax * kDeflNodeBytes), kStageCap, tid);
-        __syncthreads();
-    }
-    const int32_t *rp = cv.rp, *col = cv.col;
-    const int nb = cv.base;                        // col[e] - nb = local id of the neighbour
+    const int32_t *rp = a.row_ptr + n0;
 
     // ---- twin-leaf and stalk groups
-    for (int i = tid; i < n; i += kT) defl_init_node(d, i, rp, col, nb);
+    for (int i = tid; i < n; i += kT) defl_init_node(d, i, rp, a.col_idx, n0);
     __syncthreads();
-    for (int i = tid; i < n; i += kT) defl_count_node(d, i, rp, col, nb, hd.use_stalks != 0);
+    for (int i = tid; i < n; i += kT) defl_count_node(d, i, rp, a.col_idx, n0, hd.use_stalks != 0);
     __syncthreads();
-    for (int p = tid; p < n; p += kT) defl_order_node(d, p, rp, col, nb);
+    for (int p = tid; p < n; p += kT) defl_order_node(d, p, rp, a.col_idx, n0);
     __syncthreads();
     defl_prefix_block<kT>(d, n, sh_tot, w.cnt);    // (w.cnt: kT ints of LDS that are free until the bisection)
     const int nr = sh_tot[0], z = sh_tot[1], zp = sh_tot[2];    // reduced size n', number of twin / stalk contrasts
@@ -1648,7 +1601,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
         const int ri = d.ridx[i];
         const int di = rp[i + 1] - rp[i];
         for (int e = rp[i] + lane; e < rp[i + 1]; e += 64) {
-            const int j = col[e] - nb;
+            const int j = a.col_idx[e] - n0;
             if (d.ridx[j] == kNone) continue;
             const int dj = rp[j + 1] - rp[j];
             A[ri * lda + d.ridx[j]] = defl_coupling(d, i, j) / sqrtf((float)di * (float)dj);   // in_degrees().clip(1) ** -0.5 on both sides
@@ -1657,7 +1610,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     // what the expansion at the end needs of the tables: 8 bytes per node, in the workgroup's table in the workspace
     uint16_t *xrec = kGlobalA ? (uint16_t *)(A + (int64_t)kNMax * lda)
                               : (uint16_t *)(hd.tabs + ((int64_t)(kCls == kClsMid ? 0 : hd.tabs_small_off) + blockIdx.x) * kNodeMax * 4);
-    for (int v = tid; v < n; v += kT) defl_record(d, v, rp, col, nb, xrec + 4 * v);
+    for (int v = tid; v < n; v += kT) defl_record(d, v, rp, a.col_idx, n0, xrec + 4 * v);
     __syncthreads();
 
     PHASE_TICK(0);                                 // deflation + matrix
@@ -1711,8 +1664,8 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
 template <int kNMax>
 __host__ __device__ constexpr int wave_team_bytes()
 {
-    // A | Y | dg, of, of2, tau | nrm | per-node expansion records (8 bytes) | staged CSR   [the deflation tables overlay Y]
-    return (int)sizeof(float) * (kNMax * (kNMax + 1) + kNMax * kYld + 4 * kNMax + 64) + kWaveNodes * 8 + kWaveStage * 4;
+    // A | Y | dg, of, of2, tau | nrm | per-node expansion records (8 bytes)   [the deflation tables overlay Y]
+    return (int)sizeof(float) * (kNMax * (kNMax + 1) + kNMax * kYld + 4 * kNMax + 64) + kWaveNodes * 8;
 }
 
 // (register budget: the LU factors of an inverse iteration take 2 kNMax registers per lane; without an occupancy
@@ -1755,18 +1708,15 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? GCC_POSEMB_W48_OCC :
     long long tick_ = m.ticks ? device_ticks() : 0;
     if (m.ticks && lane == 0) atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 15], 1ull);   // items
 #define WAVE_TICK(ph) do { if (m.ticks && lane == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
-    const CsrView cv = csr_stage<64>(a.row_ptr + n0, a.col_idx, n0, n, (int32_t *)(xinfo + 4 * kWaveNodes), kWaveStage, lane);
-    const int32_t *rp = cv.rp, *cix = cv.col;
-    const int nb = cv.base;                          // cix[e] - nb = local id of the neighbour
-    wave_sync();
+    const int32_t *rp = a.row_ptr + n0;
     // ---- twin-leaf and stalk groups (tables in the Y region: dead again before the first eigenvector is written)
     Defl d;
     defl_bind(d, w.Y, kWaveNodes);
-    for (int i = lane; i < n; i += 64) defl_init_node(d, i, rp, cix, nb);
+    for (int i = lane; i < n; i += 64) defl_init_node(d, i, rp, a.col_idx, n0);
     wave_sync();
-    for (int i = lane; i < n; i += 64) defl_count_node(d, i, rp, cix, nb, hd.use_stalks != 0);
+    for (int i = lane; i < n; i += 64) defl_count_node(d, i, rp, a.col_idx, n0, hd.use_stalks != 0);
     wave_sync();
-    for (int p = lane; p < n; p += 64) defl_order_node(d, p, rp, cix, nb);
+    for (int p = lane; p < n; p += 64) defl_order_node(d, p, rp, a.col_idx, n0);
     wave_sync();
     int nr = 0, z = 0, zp = 0;                       // reduced size n', number of twin / stalk contrasts
     for (int i0 = 0; i0 < n; i0 += 64) {             // prefixes over the nodes, 64 at a time
@@ -1795,14 +1745,14 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? GCC_POSEMB_W48_OCC :
         const int ri = d.ridx[i];
         const int di = rp[i + 1] - rp[i];
         for (int e = rp[i]; e < rp[i + 1]; ++e) {
-            const int j = cix[e] - nb;
+            const int j = a.col_idx[e] - n0;
             if (d.ridx[j] == kNone) continue;
             const int dj = rp[j + 1] - rp[j];
             A[ri * lda + d.ridx[j]] = defl_coupling(d, i, j) / sqrtf((float)di * (float)dj);   // in_degrees().clip(1) ** -0.5 on both sides
         }
     }
     // what the expansion at the end needs of the tables, 8 bytes per node
-    for (int v = lane; v < n; v += 64) defl_record(d, v, rp, cix, nb, xinfo + 4 * v);
+    for (int v = lane; v < n; v += 64) defl_record(d, v, rp, a.col_idx, n0, xinfo + 4 * v);
     wave_sync();
     WAVE_TICK(0);                                    // deflation + matrix
     wave_tridiagonalize<kNMax>(A, lda, nr, w);
@@ -2297,24 +2247,19 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     const int k = min(min(n - 2, a.hidden), kMaxVec);
     long long tick_ = m.ticks ? device_ticks() : 0;
     if (m.ticks && tid == 0) atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 15], 1ull);
+    const int32_t *rp = a.row_ptr + n0;
     // three block buffers in the workspace (L2-resident): X, W = M' X or filter scratch, rotation target
     float *XA = ca.xws + (int64_t)blockIdx.x * 3 * kNodeMax * kChP, *XB = XA + (int64_t)kNodeMax * kChP, *XC = XB + (int64_t)kNodeMax * kChP;
 
-    // ---- twin-leaf and stalk groups (as posemb_direct_kernel); the ego-net's CSR staged behind the tables (csr_stage): the
-    //      region is not written before the deflated matrix and the expansion records are done
+    // ---- twin-leaf and stalk groups (as posemb_direct_kernel)
     Defl d;
     defl_bind(d, region, kNodeMax);
-    const CsrView cv = csr_stage<kChThreads>(a.row_ptr + n0, a.col_idx, n0, n, (int32_t *)(region + kNodeMax * kDeflNodeBytes),
-                                             (cheb_region_bytes() - kNodeMax * kDeflNodeBytes) / 4, tid);
-    const int32_t *rp = cv.rp, *col = cv.col;
-    const int nb = cv.base;                                  // col[e] - nb = local id of the neighbour
-    __syncthreads();
-    for (int i = tid; i < n; i += kChThreads) defl_init_node(d, i, rp, col, nb);
+    for (int i = tid; i < n; i += kChThreads) defl_init_node(d, i, rp, a.col_idx, n0);
     if (tid == 0) { sh_fail = 0; sh_nlong = 0; sh_nchunk = 0; }
     __syncthreads();
-    for (int i = tid; i < n; i += kChThreads) defl_count_node(d, i, rp, col, nb, hd.use_stalks != 0);
+    for (int i = tid; i < n; i += kChThreads) defl_count_node(d, i, rp, a.col_idx, n0, hd.use_stalks != 0);
     __syncthreads();
-    for (int p = tid; p < n; p += kChThreads) defl_order_node(d, p, rp, col, nb);
+    for (int p = tid; p < n; p += kChThreads) defl_order_node(d, p, rp, a.col_idx, n0);
     __syncthreads();
     defl_prefix_block<kChThreads>(d, n, sh_tot, (int *)slab);
     const int nr = sh_tot[0], z = sh_tot[1], zp = sh_tot[2];
@@ -2342,7 +2287,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         int c = 0;
         for (int e0 = rp[i]; e0 < rp[i + 1]; e0 += 64) {
             const int e = e0 + lane;
-            const bool keep = e < rp[i + 1] && d.ridx[col[e] - nb] != kNone;
+            const bool keep = e < rp[i + 1] && d.ridx[a.col_idx[e] - n0] != kNone;
             c += __popcll(wave_ballot(keep));
         }
         if (lane == 0) crow[d.ridx[i] + 1] = (uint16_t)(c > 65535 ? 65535 : c);
@@ -2373,7 +2318,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             int at = (int)crow[d.ridx[i]];
             for (int e0 = rp[i]; e0 < rp[i + 1]; e0 += 64) {
                 const int e = e0 + lane;
-                const int rj = e < rp[i + 1] ? (int)d.ridx[col[e] - nb] : (int)kNone;
+                const int rj = e < rp[i + 1] ? (int)d.ridx[a.col_idx[e] - n0] : (int)kNone;
                 const unsigned long long mk = wave_ballot(rj != (int)kNone);
                 if (rj != (int)kNone) ccol[at + __popcll(mk & lanemask_lt())] = (uint16_t)rj;
                 at += __popcll(mk);
@@ -2403,7 +2348,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     __syncthreads();
     // what the expansion at the end needs of the tables -> workspace, 8 bytes per node (the dense matrices overlay the tables)
     uint16_t *xrec = (uint16_t *)(ca.tabs + (int64_t)blockIdx.x * kNodeMax * 4);
-    for (int v = tid; v < n; v += kChThreads) defl_record(d, v, rp, col, nb, xrec + 4 * v);
+    for (int v = tid; v < n; v += kChThreads) defl_record(d, v, rp, a.col_idx, n0, xrec + 4 * v);
     __syncthreads();
     PHASE_TICK(0);                                           // deflation + sparse matrix
     const int nchunk = sh_nchunk;

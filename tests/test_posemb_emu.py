@@ -439,9 +439,10 @@ def test_subgraph_larger_than_its_share_of_node_cap_is_refused_loudly():
 
 
 def dense_views():
-    """Ego-nets whose CSR does NOT fit the LDS staging area of their solver class (csr_stage's fall-back to global memory),
-    next to ones that do: a 60-node random graph of density 0.7 (one-wave team: n + 1 + E = 61 + ~2480 > 2048 ints), a
-    110-node one of density 0.8 (65..128 class: ~9600 > its 7552 ints) and two sparse ones of the same sizes."""
+    """Dense ego-nets next to sparse ones of the same size: a 60-node random graph of density 0.7 (one-wave team, ~2500 CSR
+    entries), a 110-node one of density 0.8 (65..128 class, ~9600 entries) and two sparse ones.  (Written for an experiment
+    that staged the ego-net's CSR in LDS -- these do not fit such a staging area -- and kept as coverage of rows much longer
+    than a wave: no deflation applies, every row is a hub's.)"""
     rng = np.random.default_rng(3)
     views = []
     for n, p in ((60, 0.7), (60, 0.06), (110, 0.8), (110, 0.04)):
@@ -451,7 +452,7 @@ def dense_views():
     return views
 
 
-def test_dense_ego_nets_that_do_not_fit_the_csr_staging_area():
+def test_dense_ego_nets_without_anything_to_deflate():
     for view in dense_views():
         x, evals, raw = _run(view)
         _check(view, x, evals, raw)

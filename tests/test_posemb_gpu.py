@@ -83,9 +83,9 @@ def test_stalk_deflation_on_device():
     _check(view, x, evals, raw)
 
 
-def test_dense_ego_nets_that_do_not_fit_the_csr_staging_area_on_device():
-    """csr_stage's fall-back to global memory (ego-nets denser than the LDS staging area of their class) next to staged ones:
-    the synthetic dense graphs of the emulator tier through the device kernels."""
+def test_dense_ego_nets_without_anything_to_deflate_on_device():
+    """The synthetic dense graphs of the emulator tier (every row much longer than a wave, nothing to deflate) through the
+    device kernels: one-wave teams and the 65..128 class."""
     from gcc_amd.sampler import BatchedCSR
     from tests.test_posemb_emu import _check, dense_views
 
