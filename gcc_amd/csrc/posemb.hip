@@ -337,6 +337,9 @@ enum { kClsSmall = 0, kClsMid = 1, kClsSlot = 2, kClsKrylov = 3, kClsBig = 4, kC
 // one-wave teams (posemb_wave_kernel): deflated size <= 48 / <= 64 with at most kWaveNodes original nodes; the
 // 256-thread small class stays behind them for the (rare) leafier subgraphs
 constexpr int kWaveNodes = 256;
+#ifndef GCC_POSEMB_EDGE_FILL
+#define GCC_POSEMB_EDGE_FILL 0       // matrix fill of the one-wave teams by entry instead of by row: written at the end of round 3
+#endif                               // (emulator parity both ways), NOT yet measured or run on the device -- off until it is
 constexpr int kWaveTeams = 4;        // teams (waves) per workgroup
 static_assert(kNumCls == GCC_POSEMB_TICK_CLASSES, "include/gcc_amd.h: tick buffer classes");
 struct PosHead {                     // head of the caller's workspace (zeroed per call)
@@ -1739,8 +1742,39 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? GCC_POSEMB_W48_OCC :
     if (nr > kNMax || nr < 1) continue;              // cannot happen: the classify kernel computed the same size
     for (int i = lane; i < nr * lda; i += 64) A[i] = 0.f;
     wave_sync();
-    // M' = norm * adj * norm on the kept nodes (data_util.py:273-277), group couplings scaled by sqrt(group size); lane = row
-    for (int i = lane; i < n; i += 64) {
+    // M' = norm * adj * norm on the kept nodes (data_util.py:273-277), group couplings scaled by sqrt(group size)
+#if GCC_POSEMB_EDGE_FILL
+    {   // lane = ENTRY of the ego-net's CSR: the entries are split evenly over the lanes (row by bisection over the row
+        // pointers, rebased and parked in the record area, which is written only afterwards); with lane = row the lane that
+        // holds the hub walks its 100+ entries one by one while the others idle (15 / 32 us of an item's 38 / 69)
+        int32_t *rpl = (int32_t *)xinfo;             // [n + 1] <= kWaveNodes + 1 ints of the 8 * kWaveNodes bytes
+        const int e0 = rp[0];
+        for (int i = lane; i <= n; i += 64) rpl[i] = rp[i] - e0;
+        wave_sync();
+        const int E = rpl[n];
+        for (int eb = 0; eb < E; eb += 4 * 64) {
+            int jj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) jj[u] = a.col_idx[e0 + min(eb + u * 64 + lane, E - 1)] - n0;   // 4 coalesced requests in flight
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = eb + u * 64 + lane;
+                if (e >= E) continue;
+                int lo = 0, hi = n;                  // largest i with rpl[i] <= e
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (rpl[mid] <= e) lo = mid; else hi = mid;
+                }
+                const int i = lo, j = jj[u];
+                if (d.ridx[i] == kNone || d.ridx[j] == kNone) continue;
+                const int di = rpl[i + 1] - rpl[i], dj = rpl[j + 1] - rpl[j];
+                A[d.ridx[i] * lda + d.ridx[j]] = defl_coupling(d, i, j) / sqrtf((float)di * (float)dj);
+            }
+        }
+        wave_sync();                                 // rpl is done with before the records overwrite it
+    }
+#else
+    for (int i = lane; i < n; i += 64) {             // lane = row
         if (d.ridx[i] == kNone) continue;
         const int ri = d.ridx[i];
         const int di = rp[i + 1] - rp[i];
@@ -1751,6 +1785,7 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? GCC_POSEMB_W48_OCC :
             A[ri * lda + d.ridx[j]] = defl_coupling(d, i, j) / sqrtf((float)di * (float)dj);   // in_degrees().clip(1) ** -0.5 on both sides
         }
     }
+#endif
     // what the expansion at the end needs of the tables, 8 bytes per node
     for (int v = lane; v < n; v += 64) defl_record(d, v, rp, a.col_idx, n0, xinfo + 4 * v);
     wave_sync();
