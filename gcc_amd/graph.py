@@ -32,8 +32,9 @@ def seed_cdf_table(row_ptr: np.ndarray, shard_off=None) -> np.ndarray:
 
 def max_nodes_per_seed_table(max_degree: int, rw_hops: int, restart_prob: float) -> np.ndarray:
     """max_nodes_per_seed of graph_dataset.py:113-124 for every in-degree 0..max_degree."""
-    c = math.e / (math.e - 1) / restart_prob
-    return np.array([max(rw_hops, int((d ** 0.75) * c + 0.5)) for d in range(max_degree + 1)],
+    # (the reference's order of operations, so that the rounding at x.5 cannot differ: pinned by the reference-executed
+    #  tests/golden/getitem_calls_reference.json)
+    return np.array([max(rw_hops, int((d ** 0.75) * math.e / (math.e - 1) / restart_prob + 0.5)) for d in range(max_degree + 1)],
                     dtype=np.int32)
 
 

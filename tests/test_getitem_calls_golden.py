@@ -1,0 +1,30 @@
+"""What the reference asks of DGL's random walk for a seed (graph_dataset.py:94-130), recorded by EXECUTING the reference's own
+``LoadBalanceGraphDataset.__getitem__`` with ``random_walk_with_restart`` replaced by a recorder
+(tests/golden/make_getitem_golden.py -> tests/golden/getitem_calls_reference.json): both views start at the sampled node
+(step_dist [1, 0, 0]), the restart probability is passed through, and the node budget is
+max(rw_hops, int(in_degree ** 0.75 * e / (e - 1) / restart_prob + 0.5)) -- the table ``gcc_amd.graph`` uploads as ``ltab``."""
+import json
+import os
+
+from oracle import sampler as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "getitem_calls_reference.json")
+
+
+def test_node_budget_table_and_call_arguments_are_the_reference_ones():
+    items = json.load(open(GOLD))
+    assert len(items) >= 40
+    for it in items:
+        tab = O.max_nodes_table(600, it["rw_hops"], it["restart_prob"])
+        assert int(tab[it["in_degree"]]) == it["max_nodes_per_seed"], it
+        assert it["seeds"] == [it["in_degree"], it["in_degree"]]          # node id = its in-degree in the generator's parent graph
+    assert {(it["rw_hops"], it["restart_prob"]) for it in items} == {(256, 0.8), (64, 0.8), (16, 0.5), (4, 0.05)}
+
+
+def test_device_table_is_the_oracle_table():
+    import numpy as np
+
+    from gcc_amd.graph import max_nodes_per_seed_table as dev_table
+
+    for hops, rp in ((256, 0.8), (16, 0.5)):
+        assert np.array_equal(np.asarray(dev_table(600, hops, rp)), O.max_nodes_table(600, hops, rp))
