@@ -41,8 +41,9 @@ def max_nodes_per_seed_table(max_degree: int, rw_hops: int, restart_prob: float)
 def max_nodes_out_degree_table(max_degree: int, rw_hops: int, restart_prob: float, multiplicity: int = 1) -> np.ndarray:
     """max_nodes_per_seed of the GraphDataset family (graph_dataset.py:244-255): the out-degree enters WITHOUT the
     0.75 power; ``multiplicity`` = copies of every edge in the DGL graph the reference walks on."""
-    c = math.e / (math.e - 1) / restart_prob
-    return np.array([max(rw_hops, int(d * multiplicity * c + 0.5)) for d in range(max_degree + 1)], dtype=np.int32)
+    # (the reference's order of operations; pinned by tests/golden/getitem_calls_reference.json)
+    return np.array([max(rw_hops, int(d * multiplicity * math.e / (math.e - 1) / restart_prob + 0.5)) for d in range(max_degree + 1)],
+                    dtype=np.int32)
 
 
 def restart_threshold(restart_prob: float) -> int:

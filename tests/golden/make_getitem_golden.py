@@ -62,6 +62,9 @@ class StarForest:
     def in_degree(self, v):
         return v if 1 <= v <= self.D else 1
 
+    def out_degree(self, v):                                 # (symmetric parent)
+        return self.in_degree(v)
+
     def nbr(self, v):
         return self.first_leaf[v]
 
@@ -87,6 +90,20 @@ def main():
             ds[deg]                                           # node id = its in-degree
             assert len(calls) == 1
             items.append(dict(rw_hops=rw_hops, in_degree=deg, **calls[0]))
+    # the GraphDataset family (graph_dataset.py:230-275; NodeClassificationDataset / GraphClassificationDataset of generate.py
+    # inherit it): the OUT-degree enters without the 0.75 power
+    for rw_hops, restart_prob in ((64, 0.8), (16, 0.5)):
+        ds = object.__new__(graph_dataset.GraphDataset)
+        ds.graphs = [StarForest(600)]
+        ds.step_dist = [1.0, 0.0, 0.0]
+        ds.rw_hops, ds.restart_prob = rw_hops, restart_prob
+        ds.positional_embedding_size = 32
+        for deg in (1, 2, 3, 10, 47, 100, 255, 256, 257, 511, 600):
+            calls.clear()
+            np.random.seed(deg)
+            ds[deg]
+            assert len(calls) == 1
+            items.append(dict(family="GraphDataset", rw_hops=rw_hops, out_degree=deg, **calls[0]))
     with open(os.path.join(HERE, "getitem_calls_reference.json"), "w") as f:
         json.dump(items, f)
     print(len(items), "calls recorded; e.g.", items[0], items[-1])

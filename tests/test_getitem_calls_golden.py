@@ -14,11 +14,20 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "getit
 def test_node_budget_table_and_call_arguments_are_the_reference_ones():
     items = json.load(open(GOLD))
     assert len(items) >= 40
-    for it in items:
+    from gcc_amd.graph import max_nodes_out_degree_table
+
+    lb = [it for it in items if "family" not in it]
+    gd = [it for it in items if it.get("family") == "GraphDataset"]
+    assert len(lb) >= 40 and len(gd) >= 20
+    for it in lb:                                                          # LoadBalanceGraphDataset: in-degree ** 0.75
         tab = O.max_nodes_table(600, it["rw_hops"], it["restart_prob"])
         assert int(tab[it["in_degree"]]) == it["max_nodes_per_seed"], it
         assert it["seeds"] == [it["in_degree"], it["in_degree"]]          # node id = its in-degree in the generator's parent graph
-    assert {(it["rw_hops"], it["restart_prob"]) for it in items} == {(256, 0.8), (64, 0.8), (16, 0.5), (4, 0.05)}
+    assert {(it["rw_hops"], it["restart_prob"]) for it in lb} == {(256, 0.8), (64, 0.8), (16, 0.5), (4, 0.05)}
+    for it in gd:                                                          # GraphDataset family (generate.py): out-degree, no power
+        tab = max_nodes_out_degree_table(600, it["rw_hops"], it["restart_prob"])
+        assert int(tab[it["out_degree"]]) == it["max_nodes_per_seed"], it
+        assert it["seeds"] == [it["out_degree"], it["out_degree"]]
 
 
 def test_device_table_is_the_oracle_table():
