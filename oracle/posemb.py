@@ -11,8 +11,10 @@ Parity status: pinned.  tests/golden/posemb_reference.npz holds outputs of the
 reference's own function (tests/golden/make_posemb_golden.py executes it with
 DGL stubbed, NumPy's global generator seeded right before each call, since the
 reference seeds ARPACK with np.random.rand); tests/test_posemb_oracle_golden.py
-requires this restatement to reproduce them element by element under the same
-seed.  Eigenvectors are defined up to sign (and up to rotation inside degenerate
+requires this restatement to reproduce them under the same seed: element by
+element where the wanted eigenvalues are simple, row norms and Gram matrix of the
+rows where they repeat (ARPACK's basis inside a repeated eigenvalue depends on
+rounding, e.g. on the BLAS thread count).  Eigenvectors are defined up to sign (and up to rotation inside degenerate
 eigenspaces) and depend on the start vector, so the DEVICE solver is compared
 with this oracle / dense float64 eigh on invariants (residual, eigenvalues,
 subspace, row norms), not element-wise.

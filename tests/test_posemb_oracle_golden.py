@@ -21,12 +21,36 @@ def _items():
         yield str(name), z[f"{name}_rp"], z[f"{name}_ci"], z[f"{name}_x"], int(z[f"{name}_seed"])
 
 
+def _simple_spectrum(rp, ci, k):
+    """The k wanted eigenvalues are simple and separated from the rest: only then is an eigenvector a function of the matrix
+    (up to sign, which the start vector fixes).  Inside a repeated eigenvalue ARPACK returns whatever basis its rounding
+    leads to -- the star's 7-fold eigenvalue 0 comes out differently with a different BLAS thread count."""
+    s = np.linalg.eigvalsh(P.normalized_adjacency(rp, ci).toarray())
+    top = s[-(k + 1):] if len(s) > k else s
+    return np.diff(top).min() > 1e-6
+
+
 def test_restatement_reproduces_the_reference_outputs_given_the_same_start_vector():
+    exact = 0
     for name, rp, ci, x_ref, seed in _items():
+        n = len(rp) - 1
+        k = min(n - 2, HID)
         np.random.seed(seed)
         x, _ = P.positional_embedding(rp, ci, HID, rng=np.random)
         assert x.dtype == np.float32 and x.shape == x_ref.shape, name
-        np.testing.assert_allclose(x, x_ref, rtol=0, atol=1e-6, err_msg=name)
+        assert not x[:, k:].any() and not x_ref[:, k:].any(), name
+        if _simple_spectrum(rp, ci, k):
+            np.testing.assert_allclose(x, x_ref, rtol=0, atol=1e-5, err_msg=name)     # element by element
+            exact += 1
+        else:
+            # repeated eigenvalues among the wanted ones (twin leaves give ego-nets a multiple eigenvalue 0): the row norms
+            # are determined, and -- when the wanted SUBSPACE is still unique -- so is the Gram matrix of the normalised rows
+            assert np.allclose(np.linalg.norm(x[:, :k], axis=1), np.linalg.norm(x_ref[:, :k], axis=1), atol=1e-5), name
+            s = np.linalg.eigvalsh(P.normalized_adjacency(rp, ci).toarray())
+            if n - k - 1 < 0 or s[-k] - s[-k - 1] > 1e-3:
+                a, b = x.astype(np.float64), x_ref.astype(np.float64)
+                assert np.abs(a @ a.T - b @ b.T).max() < 1e-4, name
+    assert exact >= 4
 
 
 def test_normalised_adjacency_is_the_reference_one():
