@@ -337,6 +337,9 @@ enum { kClsSmall = 0, kClsMid = 1, kClsSlot = 2, kClsKrylov = 3, kClsBig = 4, kC
 // one-wave teams (posemb_wave_kernel): deflated size <= 48 / <= 64 with at most kWaveNodes original nodes; the
 // 256-thread small class stays behind them for the (rare) leafier subgraphs
 constexpr int kWaveNodes = 256;
+#ifndef GCC_POSEMB_EXPAND4
+#define GCC_POSEMB_EXPAND4 0         // expansion of the one-wave teams four nodes per iteration: same status as GCC_POSEMB_EDGE_FILL
+#endif
 #ifndef GCC_POSEMB_EDGE_FILL
 #define GCC_POSEMB_EDGE_FILL 0       // matrix fill of the one-wave teams by entry instead of by row: written at the end of round 3
 #endif                               // (emulator parity both ways), NOT yet measured or run on the device -- off until it is
@@ -1813,6 +1816,32 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? GCC_POSEMB_W48_OCC :
         }
     }
     // ---- expand to the n original nodes; x = normalize(u, "l2") row-wise, zero padded (data_util.py:260-262); lane = column
+#if GCC_POSEMB_EXPAND4
+    {   // four nodes per iteration: 16 lanes per node, columns c and c + 16 per lane (half the iterations of the loop below)
+        const int c16 = lane & 15, nv = lane >> 4;
+        const int src0 = c16 < k ? colsrc[c16] : 0, src1 = c16 + 16 < k ? colsrc[c16 + 16] : 0;
+        for (int v0 = 0; v0 < n; v0 += 4) {
+            const int v = v0 + nv;
+            const bool valid = v < n;
+            const int vv = valid ? v : 0;
+            const int rsrc = xinfo[4 * vv + 0], o = xinfo[4 * vv + 1], g = xinfo[4 * vv + 2], cb = xinfo[4 * vv + 3];
+            const float val0 = valid && c16 < k ? defl_expand(rsrc, o, g, cb, src0, w.Y, kYld) : 0.f;
+            const float val1 = valid && c16 + 16 < k ? defl_expand(rsrc, o, g, cb, src1, w.Y, kYld) : 0.f;
+            const float s2 = wave_shfl(row16_sum_last(fmaf(val0, val0, val1 * val1)), lane | 15);
+            const float inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
+            if (valid) {
+                if (c16 < a.hidden) {
+                    a.pos[(int64_t)(n0 + v) * a.hidden + c16] = val0 * inv;
+                    if (a.raw) a.raw[(int64_t)(n0 + v) * a.hidden + c16] = val0;
+                }
+                if (c16 + 16 < a.hidden) {
+                    a.pos[(int64_t)(n0 + v) * a.hidden + c16 + 16] = val1 * inv;
+                    if (a.raw) a.raw[(int64_t)(n0 + v) * a.hidden + c16 + 16] = val1;
+                }
+            }
+        }
+    }
+#else
     // (two nodes per iteration: lanes 0-31 write node v, lanes 32-63 node v + 1)
     const int col = lane & 31, hv = lane >> 5;
     const int src = col < k ? colsrc[col] : 0;
@@ -1829,6 +1858,7 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? GCC_POSEMB_W48_OCC :
             if (a.raw) a.raw[(int64_t)(n0 + v) * a.hidden + col] = val;
         }
     }
+#endif
     WAVE_TICK(6);                                    // expansion
     if (m.ticks && lane == 0)
         atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 14], dense_solve_flops(nr, kq, na, es.diag_its, 4 * 12, n, k));
