@@ -104,6 +104,44 @@ def main():
             ds[deg]
             assert len(calls) == 1
             items.append(dict(family="GraphDataset", rw_hops=rw_hops, out_degree=deg, **calls[0]))
+    # GraphClassificationDataset (graph_dataset.py:311-345): the "seed" of a whole graph is out_degrees().argmax(), both views
+    # are the ENTIRE graph in its own node order (g.subgraph(g.nodes())) and the seed flag sits on that node
+    class Whole:
+        def __init__(self, deg):
+            self.deg = list(deg)
+            self.asked = None
+
+        def number_of_nodes(self):
+            return len(self.deg)
+
+        def out_degrees(self):
+            return torch.tensor(self.deg)
+
+        def out_degree(self, v):
+            return self.deg[v]
+
+        def nodes(self):
+            return torch.arange(len(self.deg))
+
+        def nbr(self, v):
+            return (v + 1) % len(self.deg)
+
+        def subgraph(self, nodes):
+            self.asked = [int(v) for v in nodes]
+            n = len(self.deg)                                # a ring: enough for the positional embedding that follows
+            return StubGraph(np.arange(0, 2 * n + 1, 2), np.array([[(i - 1) % n, (i + 1) % n] for i in range(n)]).ravel())
+
+    for deg in ([2, 5, 3, 5, 1, 4], [7, 1, 1, 1, 1, 1, 1, 1], [1, 2, 3, 4, 5, 6, 7, 8, 9]):
+        ds = object.__new__(graph_dataset.GraphClassificationDataset)
+        ds.graphs = [Whole(deg)]
+        ds.step_dist = [1.0, 0.0, 0.0]
+        ds.rw_hops, ds.restart_prob, ds.positional_embedding_size, ds.entire_graph = 8, 0.8, 4, True
+        calls.clear()
+        np.random.seed(0)
+        gq, gk = ds[0]
+        flag = gq.ndata["seed"].tolist()
+        items.append(dict(family="GraphClassificationDataset", out_degrees=deg, subgraph_nodes=ds.graphs[0].asked,
+                          seed_flag_at=[j for j, f in enumerate(flag) if f], **calls[0]))
     with open(os.path.join(HERE, "getitem_calls_reference.json"), "w") as f:
         json.dump(items, f)
     print(len(items), "calls recorded; e.g.", items[0], items[-1])

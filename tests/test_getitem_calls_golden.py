@@ -37,3 +37,20 @@ def test_device_table_is_the_oracle_table():
 
     for hops, rp in ((256, 0.8), (16, 0.5)):
         assert np.array_equal(np.asarray(dev_table(600, hops, rp)), O.max_nodes_table(600, hops, rp))
+
+
+def test_graph_classification_seed_rule_and_whole_graph_views_are_the_reference_ones():
+    """GraphClassificationDataset (graph_dataset.py:311-345): seed = out_degrees().argmax() (first maximum), both views are the
+    whole graph in its own node order, the seed flag sits on the seed (data_util.py:225-237 with entire_graph=True)."""
+    import numpy as np
+
+    from gcc_amd.graph import max_nodes_out_degree_table
+
+    items = [it for it in json.load(open(GOLD)) if it.get("family") == "GraphClassificationDataset"]
+    assert len(items) == 3
+    for it in items:
+        deg = np.asarray(it["out_degrees"])
+        seed = int(np.argmax(deg))                                       # what gcc_amd.datasets.GraphClassificationDataset._convert_idx does
+        assert it["seeds"] == [seed, seed] and it["seed_flag_at"] == [seed]
+        assert it["subgraph_nodes"] == list(range(len(deg)))
+        assert int(max_nodes_out_degree_table(int(deg.max()), 8, it["restart_prob"])[deg[seed]]) == it["max_nodes_per_seed"]
