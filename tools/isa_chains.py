@@ -52,10 +52,14 @@ def kernels(text):
 
 
 def demangle(name):
-    try:
-        return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()
-    except OSError:
-        return name
+    for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+        try:
+            out = subprocess.run([tool, name], capture_output=True, text=True).stdout.strip()
+            if out:
+                return out
+        except OSError:
+            pass
+    return name
 
 
 def chain(body):
