@@ -40,7 +40,11 @@ def test_restatement_reproduces_the_reference_outputs_given_the_same_start_vecto
         assert x.dtype == np.float32 and x.shape == x_ref.shape, name
         assert not x[:, k:].any() and not x_ref[:, k:].any(), name
         if _simple_spectrum(rp, ci, k):
-            np.testing.assert_allclose(x, x_ref, rtol=0, atol=1e-5, err_msg=name)     # element by element
+            # element by element; a column may come back negated on another machine (the sign of a Lanczos vector is the one
+            # thing rounding can flip), never anything else
+            for j in range(k):
+                d = min(np.abs(x[:, j] - x_ref[:, j]).max(), np.abs(x[:, j] + x_ref[:, j]).max())
+                assert d < 1e-5, (name, j, d)
             exact += 1
         else:
             # repeated eigenvalues among the wanted ones (twin leaves give ego-nets a multiple eigenvalue 0): the row norms
