@@ -851,9 +851,10 @@ void gcc_sampler_debug_ticks(long long *device_ticks64) { g_induce_ticks = devic
 
 static int32_t check_steps(const char *who, int32_t batch_size, int32_t num_steps)
 {
-    // prefix step A keeps one LDS word per subgraph of the call; 2 * batch_size * num_steps + 1 of them must fit 64 KiB
-    if (num_steps < 1 || num_steps > GCC_SAMPLE_MAX_STEPS || (2ll * batch_size * num_steps + 1) * 4 > 64 * 1024) {
-        snprintf(g_err, kErrLen, "%s: num_steps = %d (1 .. %d, and 2 * batch_size * num_steps <= 16383)", who, num_steps,
+    // prefix step A keeps one LDS word per subgraph of the call: 2 * batch_size * num_steps + 1 of them PLUS the kernel's
+    // static LDS (wsum[64] + wsum64[16] = 384 B, budgeted as 512) must fit the 64 KiB a launch gets without an opt-in
+    if (num_steps < 1 || num_steps > GCC_SAMPLE_MAX_STEPS || (2ll * batch_size * num_steps + 1) * 4 + 512 > 64 * 1024) {
+        snprintf(g_err, kErrLen, "%s: num_steps = %d (1 .. %d, and 2 * batch_size * num_steps <= 16255)", who, num_steps,
                  GCC_SAMPLE_MAX_STEPS);
         return -1;
     }
@@ -880,16 +881,16 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
                          int64_t scratch_entries, int32_t *status, void *stream)
 {
     if (!g || !p || !outs || !workspace || !status) {
-        snprintf(g_err, kErrLen, "gcc_sample_batch: null argument");
+        snprintf(g_err, kErrLen, "gcc_sample_multi: null argument");
         return -1;
     }
     if (g->num_shards > 1 && !g->shard_off) {
-        snprintf(g_err, kErrLen, "gcc_sample_batch: num_shards = %d without shard_off", g->num_shards);
+        snprintf(g_err, kErrLen, "gcc_sample_multi: num_shards = %d without shard_off", g->num_shards);
         return -1;
     }
     if (p->batch_size <= 0 || g->lmax <= 0 || g->lmax > 65534 || g->num_nodes <= 0 ||
         g->num_nodes > 0x7FFFFFFF || g->num_edges > 0x7FFFFFFF) {
-        snprintf(g_err, kErrLen, "gcc_sample_batch: size out of range (B=%d lmax=%d V=%lld E=%lld)",
+        snprintf(g_err, kErrLen, "gcc_sample_multi: size out of range (B=%d lmax=%d V=%lld E=%lld)",
                  p->batch_size, g->lmax, (long long)g->num_nodes, (long long)g->num_edges);
         return -2;
     }
@@ -897,12 +898,12 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     const int nseg = 2 * num_steps;
     const WorkLayout wl = work_layout(g->lmax, p->batch_size, nseg, scratch_entries);
     if (workspace_bytes < wl.total) {
-        snprintf(g_err, kErrLen, "gcc_sample_batch: workspace %lld < %lld bytes",
+        snprintf(g_err, kErrLen, "gcc_sample_multi: workspace %lld < %lld bytes",
                  (long long)workspace_bytes, (long long)wl.total);
         return -3;
     }
     if (((uintptr_t)g->col_idx & 15u) != 0) {
-        snprintf(g_err, kErrLen, "gcc_sample_batch: col_idx must be 16-byte aligned (the induction streams it in dwordx4 quads)");
+        snprintf(g_err, kErrLen, "gcc_sample_multi: col_idx must be 16-byte aligned (the induction streams it in dwordx4 quads)");
         return -5;
     }
     char *base = (char *)workspace;
@@ -936,7 +937,7 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     const size_t lds1 = ((size_t)p2max * 2 + 64) * 4;
     const size_t lds2 = (size_t)wl.ncap * 16 + 8 + ((size_t)1 << (bmlog - 3)) + (size_t)kInduceWaves * (kCandCap * 6 + kUnitQuads * 2) + 16;
     if (lds1 > 160 * 1024 || lds2 > 160 * 1024 - 256) {
-        snprintf(g_err, kErrLen, "gcc_sample_batch: lmax=%d / batch too large for 160 KiB of LDS", g->lmax);
+        snprintf(g_err, kErrLen, "gcc_sample_multi: lmax=%d / batch too large for 160 KiB of LDS", g->lmax);
         return -4;
     }
     PackOuts po;
@@ -966,7 +967,7 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     prof_mark(p->prof, 3, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        snprintf(g_err, kErrLen, "gcc_sample_batch: launch failed: %s", hipGetErrorString(e));
+        snprintf(g_err, kErrLen, "gcc_sample_multi: launch failed: %s", hipGetErrorString(e));
         return -10;
     }
     return 0;

@@ -24,7 +24,10 @@ def seed_cdf_table(row_ptr: np.ndarray, shard_off=None) -> np.ndarray:
     bounds = [0, len(w)] if shard_off is None or len(shard_off) <= 2 else [int(x) for x in shard_off]
     cdf = np.empty(len(w), dtype=np.float64)
     for a, b in zip(bounds[:-1], bounds[1:]):
-        p = w[a:b] / w[a:b].sum()
+        tot = w[a:b].sum()
+        if not (np.isfinite(tot) and tot > 0):          # 0/0 would give a NaN cdf and every seed the shard's last node
+            raise ValueError(f"seed cdf: the nodes [{a}, {b}) of a worker shard have no edges (total deg^0.75 weight {tot})")
+        p = w[a:b] / tot
         c = np.cumsum(p)
         cdf[a:b] = c / c[-1]
     return cdf

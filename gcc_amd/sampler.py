@@ -138,12 +138,20 @@ class DeviceRWRSampler:
         # sets bit 0 of the device status word and leaves a truncated subgraph, which check_status() turns into an error
         # (train.py polls it at every log line, bench.py after the timed region).
         expected = int(3 * 2 * B * (graph.rw_hops / 2.5) * getattr(graph, "sb_degree", 0.0))
-        self.scratch_entries = int(scratch_entries) if scratch_entries else max(
+        # ``scratch_entries`` (argument) is PER STEP; a call covers up to ``max_steps`` steps, so the buffer handed to the
+        # library holds ``self.scratch_entries`` = per-step entries x max_steps (``scratch_entries_per_step`` keeps the
+        # argument's meaning; gcc_sample_multi's ``scratch_entries`` is the whole call's).
+        self.scratch_entries_per_step = int(scratch_entries) if scratch_entries else max(
             32 << 20, 512 * B * (graph.rw_hops + 1), 8 * (graph.lmax + 1) ** 2, expected)
-        # steps per call: bounded by the library (GCC_SAMPLE_MAX_STEPS, one LDS word per subgraph in the prefix kernel)
-        self.max_steps = max(1, min(int(max_steps), 16, 16383 // (2 * B), int(num_buffers)))
-        self.scratch_entries *= self.max_steps
+        # steps per call: bounded by the library (GCC_SAMPLE_MAX_STEPS; one LDS word per subgraph in the prefix kernel,
+        # (2 * B * steps + 1) * 4 + 512 <= 64 KiB)
+        self.max_steps = max(1, min(int(max_steps), 16, 16255 // (2 * B), int(num_buffers)))
+        self.scratch_entries = self.scratch_entries_per_step * self.max_steps
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.regrown = 0                   # times grow() enlarged the scratch / edge capacity after an overflow
+        self._retired = []                 # replaced buffers stay alive: launches in flight on other streams may still use them
+        self._snap = None                  # pinned host mirror of the status word, one slot per snapshot in flight
+        self._snap_next = 0
         self._alloc_workspace()
         i32 = dict(dtype=torch.int32, device=dev)
         self._ring = []
@@ -223,13 +231,69 @@ class DeviceRWRSampler:
             at += n
         return pairs
 
+    _BITS = ((1, "induction scratch"), (2, "node capacity"), (4, "edge capacity"))
+
     def check_status(self) -> None:
-        """Synchronising check of the device overflow flags (raises, never truncates)."""
+        """Synchronising check of the device overflow flags (raises, never truncates).  The producer pipeline does not
+        wait for this: it takes a :meth:`status_snapshot` per chunk and re-samples an overflowed chunk after
+        :meth:`grow` (gcc_amd/train_step.py: BatchProducer)."""
         s = int(self.status.item())
         if s:
-            what = [n for b, n in ((1, "induction scratch"), (2, "node capacity"), (4, "edge capacity")) if s & b]
+            what = [n for b, n in self._BITS if s & b]
             raise RuntimeError("gcc_sample_batch overflow: " + ", ".join(what) +
                                " -- construct DeviceRWRSampler with larger edge_cap/scratch_entries")
+
+    # ---- overflow -> regrow -> re-sample (instead of killing a multi-hour run at the next log line)
+    def status_snapshot(self):
+        """Enqueue, on the current stream, a copy of the status word into pinned host memory followed by its reset:
+        the word the token reads back covers exactly the calls issued since the previous snapshot.  -> token."""
+        import torch
+
+        if self._snap is None:
+            self._snap = torch.zeros(16, dtype=torch.int32).pin_memory()
+        i = self._snap_next
+        self._snap_next = (i + 1) % self._snap.numel()
+        self._snap[i:i + 1].copy_(self.status, non_blocking=True)
+        self.status.zero_()
+        return i
+
+    def snapshot_sync(self) -> None:
+        """Wait for snapshots enqueued on the current stream (callers without an event of their own)."""
+        import torch
+
+        torch.cuda.current_stream(self.graph.device).synchronize()
+
+    def read_snapshot(self, token) -> int:
+        """The status bits of a snapshot whose stream work has completed (the caller synchronised on an event recorded
+        after :meth:`status_snapshot`)."""
+        return int(self._snap[token])
+
+    def grow(self, bits: int, factor: int = 4, limit_bytes: int = 64 << 30) -> None:
+        """Enlarge what overflowed: the induction scratch (bit 1; the workspace is re-allocated) and / or the edge
+        capacity of every ring slot (bit 4).  Node capacity (bit 2) is an exact bound, B * (lmax + 1): its overflow is a
+        sizing error and raises.  Replaced buffers are kept alive (launches in flight elsewhere may still use them)."""
+        import torch
+
+        if bits & 2:
+            raise RuntimeError("gcc_sample_batch overflow: node capacity (node_cap must be batch_size * (lmax + 1))")
+        if bits & 1:
+            new = self.scratch_entries_per_step * factor
+            if new * self.max_steps * 4 > limit_bytes:
+                raise RuntimeError(f"gcc_sample_batch overflow: induction scratch of {new * self.max_steps * 4 >> 20} MiB refused")
+            self.scratch_entries_per_step = new
+            self.scratch_entries = new * self.max_steps
+            self._retired.append(self.workspace)
+            self._alloc_workspace()
+        if bits & 4:
+            new = self.edge_cap * factor
+            if new * 4 * 2 * len(self._ring) > limit_bytes:
+                raise RuntimeError(f"gcc_sample_batch overflow: edge capacity of {new} per view refused")
+            self.edge_cap = new
+            for views in self._ring:
+                for v in views:
+                    self._retired.append(v["col_idx"])
+                    v["col_idx"] = torch.zeros(new, dtype=torch.int32, device=self.graph.device)
+        self.regrown += 1
 
     def last_seeds(self):
         """int32 device view of the seeds drawn by the most recent call ([B], or [steps * B] after sample_multi)."""
@@ -348,7 +412,10 @@ class LoadBalanceGraphDataset:
 
     def __iter__(self):
         n_batch = self.total // self.batch_size
-        base = self._epoch * self.total
+        # sample ids of an epoch start at a multiple of the batch size -- the kernel takes the worker shard of a batch from
+        # sample_id // batch_size, and these are the ids the fused trainers use ((epoch - 1) * n_batch * batch_size): with
+        # epoch * total a batch of epoch 2 on would straddle two shards whenever total % batch_size != 0
+        base = self._epoch * n_batch * self.batch_size
         self._epoch += 1
         for i in range(n_batch):
             yield self.sampler.sample(base + i * self.batch_size)

@@ -111,6 +111,8 @@ class BatchProducer:
         self.released = {}                      # chunk -> event recorded on the consumer stream after its last step
         self.next_chunk = 0
         self.prof = None
+        self.snap = {}                          # chunk -> (status-snapshot token of its sampler, ring positions before it)
+        self.regrown = 0                        # chunks re-sampled after an overflow (sampler scratch / edge capacity grown)
 
     def _produce(self, c):
         sampler, posemb = self.lanes[c % len(self.lanes)][:2]
@@ -119,6 +121,8 @@ class BatchProducer:
             self.prof["used"] = True            # this step's marks were recorded (only chunk-launching steps have them)
         s0 = c * self.chunk
         stride = self.first_id(s0 + 1) - self.first_id(s0)
+        # ring positions before this chunk: an overflowed chunk is re-sampled into the SAME slots (_reproduce)
+        pos = (getattr(sampler, "_next", None), getattr(posemb, "_next", None))
         if self.chunk > 1 and getattr(sampler, "max_steps", 1) > 1:
             # the whole chunk's batches in one launch set per max_steps steps (gcc_sample_multi): the sampler's five kernels
             # are latency chains that one step's 2 * batch_size subgraphs cannot fill the GPU with
@@ -127,6 +131,10 @@ class BatchProducer:
             pairs = []
             for step in range(s0, s0 + self.chunk):
                 pairs.append(sampler.sample(self.first_id(step), prof=pr.get("sampler") if step == s0 else None))
+        if hasattr(sampler, "status_snapshot"):
+            # overflow flags of exactly this chunk's sampler calls -> pinned host word (read in get(), before the chunk is
+            # consumed); the device word is reset so that the next chunk's snapshot is its own
+            self.snap[c] = (sampler.status_snapshot(), pos)
         views = [g for pair in pairs for g in pair]
         pp = pr.get("posemb")
         if hasattr(posemb, "multi"):
@@ -158,6 +166,27 @@ class BatchProducer:
             done.record(st)
         self.ready[c] = (pairs, done)
 
+    def _reproduce(self, c, bits):
+        """Chunk ``c``'s sampler calls overflowed (``bits``): enlarge what overflowed and sample the chunk again into the
+        same ring slots -- every subgraph is a pure function of its sample id, so the re-issued chunk is the batch an
+        amply sized sampler would have produced.  (Round 3 raised at the next log line and the run was lost.)"""
+        sampler, posemb = self.lanes[c % len(self.lanes)][:2]
+        _, pos = self.snap.pop(c)
+        sampler.grow(bits)                       # raises on a sizing error (node capacity) or beyond its growth limit
+        self.regrown += 1
+        keep = (getattr(sampler, "_next", None), getattr(posemb, "_next", None))
+        if pos[0] is not None:
+            sampler._next = pos[0]
+        if pos[1] is not None:
+            posemb._next = pos[1]
+        self.launched -= 1                       # a re-issue, not a new chunk (bench.py: produced == consumed)
+        self.ready.pop(c, None)
+        self._launch(c)
+        if keep[0] is not None:
+            sampler._next = keep[0]
+        if keep[1] is not None:
+            posemb._next = keep[1]
+
     def get(self, step, prof=None):
         """Batch of ``step`` (made ready on the current stream); keeps lanes * (depth - 1) chunks in flight."""
         self.prof = prof
@@ -169,6 +198,22 @@ class BatchProducer:
             if self.next_chunk not in self.ready:
                 self._launch(self.next_chunk)
             self.next_chunk += 1
+        for _ in range(4):                       # overflow -> grow -> re-sample, at most a few times
+            pairs, ev = self.ready[c]
+            if c not in self.snap:
+                break
+            sampler = self.lanes[c % len(self.lanes)][0]
+            if ev is not None:
+                ev.synchronize()                 # the chunk was launched `ahead` chunks ago: normally long complete
+            elif hasattr(sampler, "snapshot_sync"):
+                sampler.snapshot_sync()          # produced on the current stream (prefetch off): wait for it
+            bits = sampler.read_snapshot(self.snap[c][0])
+            if not bits:
+                self.snap.pop(c)
+                break
+            self._reproduce(c, bits)
+        else:
+            raise RuntimeError(f"sampler overflow persists after growing {self.regrown} times (chunk {c})")
         pairs, ev = self.ready[c]
         if ev is not None:
             torch.cuda.current_stream(self.dev).wait_event(ev)
@@ -316,11 +361,18 @@ class MoCoTrainStep:
             except RuntimeError as e:           # keep going: every rank must reach the agreement below
                 err = err or e
         if self.collectives and torch.distributed.is_initialized():
-            # a rank that raised alone would leave the others waiting in their next collective
+            # a rank that raised alone would leave the others waiting in their next collective; the flag words are bit
+            # masks, so they are OR-ed (a MAX of masks is not their union) and every rank returns the same word
             t = torch.tensor([1 if err is not None else 0, flags], dtype=torch.int64,
                              device="cpu" if self._staged() or self.dev.type != "cuda" else self.dev)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            if err is None and int(t[0]):
+            every = [torch.zeros_like(t) for _ in range(torch.distributed.get_world_size())]
+            torch.distributed.all_gather(every, t)
+            any_err, flags = 0, 0
+            for e in every:
+                e = e.tolist()
+                any_err |= int(e[0])
+                flags |= int(e[1])
+            if err is None and any_err:
                 err = RuntimeError("another rank reported a sampler / positional-embedding overflow (see its log)")
         if err is not None:
             raise err

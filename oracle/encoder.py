@@ -90,7 +90,7 @@ class OracleGraphEncoder(nn.Module):
         src = torch.repeat_interleave(torch.arange(n), row_ptr[1:] - row_ptr[:-1])
         dst = col_idx
         gid = torch.repeat_interleave(torch.arange(B), node_off[1:] - node_off[:-1])
-        seed = torch.zeros(n)                                                   # data_util.py:234-238
+        seed = torch.zeros(n, dtype=pos_undirected.dtype)                       # data_util.py:234-238
         first = node_off[:-1] + (0 if seed_local is None else torch.as_tensor(seed_local, dtype=torch.long))
         seed[first[node_off[1:] > node_off[:-1]]] = 1.0                        # (empty padding graphs have no seed)
         degrees = torch.bincount(dst, minlength=n)                              # g.in_degrees(), :154
@@ -108,7 +108,7 @@ class OracleGraphEncoder(nn.Module):
             hidden.append(h)
         score, all_outputs = 0, []
         for i, hh in enumerate(hidden):                                         # gin.py:227-230
-            pooled = torch.zeros(B, hh.shape[1]).index_add_(0, gid, hh)
+            pooled = torch.zeros(B, hh.shape[1], dtype=hh.dtype).index_add_(0, gid, hh)
             all_outputs.append(pooled)
             y = g.linears_prediction[i](pooled)
             if dropout_masks is not None:

@@ -34,15 +34,21 @@ def seed_cdf(row_ptr: np.ndarray, shard_off=None) -> np.ndarray:
     (graph_dataset.py:23-30,63-76: worker w samples among the nodes of ITS graphs only) every node range
     [shard_off[s], shard_off[s+1]) carries that shard's own cdf."""
     deg = np.diff(row_ptr).astype(np.float64) ** 0.75
+    def _total(w, a, b):
+        tot = w.sum()
+        if not (np.isfinite(tot) and tot > 0):      # np.random.choice(p=NaN) raises in the reference; never a silent NaN cdf
+            raise ValueError(f"seed cdf: the nodes [{a}, {b}) of a worker shard have no edges (total deg^0.75 weight {tot})")
+        return tot
+
     if shard_off is None or len(shard_off) <= 2:
-        p = deg / deg.sum()
+        p = deg / _total(deg, 0, len(deg))
         cdf = p.cumsum()
         cdf /= cdf[-1]
         return cdf
     out = np.empty(len(deg), dtype=np.float64)
     for s in range(len(shard_off) - 1):
         a, b = int(shard_off[s]), int(shard_off[s + 1])
-        p = deg[a:b] / deg[a:b].sum()
+        p = deg[a:b] / _total(deg[a:b], a, b)
         c = p.cumsum()
         out[a:b] = c / c[-1]
     return out

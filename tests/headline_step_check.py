@@ -1,0 +1,225 @@
+"""Shared body of the headline-config parity tests: ONE fused training step (MoCoTrainStep / E2ETrainStep -- the code
+bench.py times) on a freshly sampled batch against oracle/encoder.py fed the SAME batched CSR, positional embedding,
+dropout masks, initial weights and queue.  Emulator tier on CPU at a small size, device tier at BASELINE configs[1]
+(G1, bsz 256, K 16384, rw_hops 256) and configs[0]'s E2E mode at bsz 256.  TEST INFRASTRUCTURE ONLY.
+
+Reference: train.py:378-434 (the step), gcc/models/graph_encoder.py:132-200, gcc/contrastive/memory_moco.py:26-63,
+gcc/contrastive/criterions.py:12-33, train.py:169-172 (moment_update), train.py:340-347,409,417 (clip + Adam).
+Tolerance: north_star's 1e-3 relative (fp32); tighter where it holds."""
+import numpy as np
+import torch
+
+from gcc_amd.encoder import grad_params
+from oracle import encoder as E
+
+
+def view_arrays(g):
+    """(node_off, row_ptr, col_idx) int64 + pos_undirected [n, P] of the LIVE extent of a batch view (BatchedCSR on the
+    device or the emulator tests' CpuBatch)."""
+    B = g.batch_size
+    node_off = g.node_off[: B + 1].cpu().numpy().astype(np.int64)
+    n = int(node_off[B])
+    row_ptr = g.row_ptr[: n + 1].cpu().numpy().astype(np.int64)
+    col_idx = g.col_idx[: int(row_ptr[n])].cpu().numpy().astype(np.int64)
+    return (node_off, row_ptr, col_idx), g.pos_undirected[:n].detach().cpu().clone()
+
+
+def _state(mod):
+    return {k: v.detach().cpu().clone() for k, v in mod.state_dict().items()}
+
+
+def _feat(tr, slot, g):
+    node_cap = g.parent_nid.numel() if hasattr(g, "parent_nid") else g.graph_id.numel()
+    return tr.gin._buffers(slot, node_cap, g.batch_size, tr.L if hasattr(tr, "L") else len(tr.model.gnn.ginlayers),
+                           g.node_off.device)["feat"]
+
+
+def _cmp_grads_and_update(model, flat_grad, oracle, init, after, report, truth=None, coef=1.0):
+    """flat gradient (clipped in place by gcc_adam_step, as clip_grad_norm_ does to .grad) and the Adam UPDATE of every
+    live parameter against the oracle's; the update is compared where the gradient is not rounding noise (a Linear bias
+    in front of a BatchNorm has an exactly-zero true gradient, Adam turns noise into +-lr).
+
+    Gradient tolerance: north_star's 1e-3, taken relative to the tensor's largest entry (a sum over ~25 k nodes in fp32
+    leaves every entry with an error proportional to the LARGE terms of its sum, not to its own size).  ``truth``: the
+    same oracle run in float64 -- the report says how far the device AND the fp32 oracle are from it
+    (``grad_err_vs_f64_device`` / ``_oracle32``, worst entry over all tensors, in units of the tensor's largest entry)."""
+    names = {id(p): n for n, p in model.named_parameters()}
+    ref = dict(oracle.named_parameters())
+    ref64 = dict(truth.named_parameters()) if truth is not None else None
+    ref_after = {k: v.detach() for k, v in oracle.state_dict().items()}
+    off, checked, worst, w_dev, w_o32 = 0, 0, 0.0, 0.0, 0.0
+    for _, _, p in grad_params(model):
+        n = names[id(p)]
+        got = flat_grad[off:off + p.numel()].view_as(p)
+        off += p.numel()
+        gref = ref[n].grad
+        scale = max(float(gref.abs().max()), 1e-3)
+        atol = max(1e-3 * scale, 1e-6)
+        if ".mlp.linears." in n and n.endswith(".bias"):
+            atol = max(atol, 1e-4)
+        torch.testing.assert_close(got, gref, rtol=2e-3, atol=atol, msg=lambda m, n=n: f"grad {n}: {m}")
+        worst = max(worst, float((got - gref).abs().max()) / scale)
+        if ref64 is not None:
+            g64 = ref64[n].grad * coef
+            w_dev = max(w_dev, float((got.double() - g64).abs().max()) / scale)
+            w_o32 = max(w_o32, float((gref.double() - g64).abs().max()) / scale)
+        if float(gref.abs().max()) > 1e-6:
+            solid = gref.abs() > 1e-2 * float(gref.abs().max())
+            upd, upd_ref = (after[n] - init[n])[solid], (ref_after[n] - init[n])[solid]
+            torch.testing.assert_close(upd, upd_ref, rtol=5e-3, atol=2e-5, msg=lambda m, n=n: f"update {n}: {m}")
+            checked += int(solid.sum())
+    report["grad_worst_abs_over_scale"] = worst
+    if ref64 is not None:
+        report["grad_err_vs_f64_device"] = w_dev
+        report["grad_err_vs_f64_oracle32"] = w_o32
+    report["update_elements_checked"] = checked
+    return checked
+
+
+def _seed_adam(opt, oracle, model, tr, exp_avg, exp_avg_sq, steps):
+    """give the oracle's torch.optim.Adam the trainer's moments (flat, grad_params order) when the step under test is
+    not the trainer's first"""
+    if steps == 0:
+        return
+    names = {id(p): n for n, p in model.named_parameters()}
+    ref = dict(oracle.named_parameters())
+    off = 0
+    for _, _, p in grad_params(model):
+        t = ref[names[id(p)]]
+        opt.state[t] = dict(step=torch.tensor(float(steps)), exp_avg=exp_avg[off:off + p.numel()].view_as(p).clone(),
+                            exp_avg_sq=exp_avg_sq[off:off + p.numel()].view_as(p).clone())
+        off += p.numel()
+
+
+def _truth64(init, args, pos, masks, tail):
+    """the oracle in float64 on the same inputs -> module with .grad populated by ``tail(feat) -> loss``"""
+    om = E.OracleGraphEncoder().double()
+    om.load_state_dict({k: (v.double() if v.dtype.is_floating_point else v) for k, v in init.items()})
+    om.train()
+    f = om(*args, pos.double(), dropout_masks=masks.double() if masks is not None else None)
+    return om, f
+
+
+def check_moco_step(tr, model, ema, contrast, lr, masks, sync=lambda: None, step_id=0, rtol=1e-3):
+    """One ``MoCoTrainStep.step`` (sampling + positional embedding through the trainer's own producer) vs the oracle.
+    ``masks``: float keep masks [5, B, 64] on the trainer's device.  Returns a report dict (for bench.py's line)."""
+    init_m, init_e = _state(model), _state(ema)
+    adam0 = (tr.optimizer.exp_avg.detach().cpu().clone(), tr.optimizer.exp_avg_sq.detach().cpu().clone(), int(tr.optimizer.steps))
+    mem0 = contrast.memory.detach().cpu().clone()
+    index0, K, B, T, alpha = int(contrast.index), contrast.queueSize, tr.B, contrast.T, tr.alpha
+    tr.mask_fn = lambda: masks
+    out = tr.step(step_id, lr)
+    sync()
+    gq, gk = out["graph_q"], out["graph_k"]
+    (aq, pos_q), (ak, pos_k) = view_arrays(gq), view_arrays(gk)
+    report = dict(batch_size=B, K=K, nodes_q=int(aq[0][-1]), nodes_k=int(ak[0][-1]), edges_q=len(aq[2]), edges_k=len(ak[2]))
+    report["_graphs"] = (gq, gk)                 # for the caller's sampler check; not serialisable
+    # ---- oracle on the same inputs
+    om, oe = E.OracleGraphEncoder(), E.OracleGraphEncoder()
+    om.load_state_dict(init_m)
+    oe.load_state_dict(init_e)
+    om.train()
+    oe.train()                                   # train.py:357-365: eval() + BatchNorm back to train(); dropout stays off
+    rq = om(*aq, pos_q, dropout_masks=masks.cpu())
+    with torch.no_grad():
+        rk = oe(*ak, pos_k)
+    ref_mem = mem0.clone()
+    rout, ref_index = E.moco_forward(ref_mem, index0, rq, rk, T)
+    rloss = E.nce_softmax_loss(rout)
+    rprob = rout[:, 0].mean().detach()           # train.py:394
+    opt = torch.optim.Adam(om.parameters(), lr=lr, betas=(0.9, 0.999), weight_decay=1e-5)   # train.py:667-672
+    _seed_adam(opt, om, model, tr, *adam0)
+    opt.zero_grad()
+    rloss.backward()
+    rgn = torch.nn.utils.clip_grad_norm_(om.parameters(), tr.clip_norm)                    # train.py:409
+    opt.step()
+    E.moment_update(om, oe, alpha)                                                          # train.py:430-431
+    # float64 run of the same oracle: who is closer to exact arithmetic, the device or the fp32 oracle?
+    o64, f64 = _truth64(init_m, aq, pos_q, masks.cpu(), None)
+    out64, _ = E.moco_forward(mem0.double(), index0, f64, rk.detach().double(), T)
+    E.nce_softmax_loss(out64).backward()
+    coef = min(1.0, tr.clip_norm / (float(rgn.detach()) + 1e-6)) if tr.clip_norm > 0 else 1.0
+    # ---- compare
+    feat_q, feat_k = _feat(tr, ("step", 0), gq).cpu(), _feat(tr, ("step", 1), gk).cpu()
+    torch.testing.assert_close(feat_q, rq.detach(), rtol=rtol, atol=1e-4, msg=lambda m: f"feat_q: {m}")
+    torch.testing.assert_close(feat_k, rk.detach(), rtol=rtol, atol=1e-4, msg=lambda m: f"feat_k: {m}")
+    loss, prob = out["loss"].reshape(()).cpu(), out["prob"].reshape(()).cpu()
+    gn = torch.as_tensor(out["grad_norm"]).reshape(()).cpu()
+    torch.testing.assert_close(loss, rloss.detach(), rtol=rtol, atol=1e-5, msg=lambda m: f"loss: {m}")
+    torch.testing.assert_close(prob, rprob, rtol=rtol, atol=1e-5, msg=lambda m: f"prob: {m}")
+    torch.testing.assert_close(gn, rgn.detach().reshape(()), rtol=rtol, atol=1e-6, msg=lambda m: f"grad_norm: {m}")
+    report.update(loss=float(loss), loss_oracle=float(rloss.detach()), loss_rel_err=abs(float(loss) - float(rloss.detach())) / abs(float(rloss.detach())),
+                  prob=float(prob), prob_oracle=float(rprob.detach()), grad_norm=float(gn), grad_norm_oracle=float(rgn.detach()),
+                  feat_q_max_abs_err=float((feat_q - rq.detach()).abs().max()),
+                  feat_k_max_abs_err=float((feat_k - rk.detach()).abs().max()))
+    after_m, after_e = _state(model), _state(ema)
+    checked = _cmp_grads_and_update(model, tr.flat_grad.detach().cpu(), om, init_m, after_m, report, truth=o64, coef=coef)
+    assert checked > 10000, checked
+    ref_m, ref_e = om.state_dict(), oe.state_dict()
+    for k, v in after_m.items():                 # running statistics, num_batches_tracked, every weight after Adam
+        if v.dtype.is_floating_point:
+            torch.testing.assert_close(v, ref_m[k], rtol=5e-3 if "running_" not in k else rtol, atol=2.1 * lr if "running_" not in k else 1e-5,
+                                       msg=lambda m, k=k: f"model {k}: {m}")
+        else:
+            assert torch.equal(v, ref_m[k]), k
+    for k, v in after_e.items():                 # EMA weights (moment_update) + the key encoder's running statistics
+        if v.dtype.is_floating_point:
+            torch.testing.assert_close(v, ref_e[k], rtol=rtol, atol=2e-5, msg=lambda m, k=k: f"model_ema {k}: {m}")
+        else:
+            assert torch.equal(v, ref_e[k]), k
+    # queue: rows [index0, index0 + B) are the keys, everything else untouched (memory_moco.py:55-61)
+    mem = contrast.memory.detach().cpu()
+    torch.testing.assert_close(mem, ref_mem, rtol=rtol, atol=1e-4, msg=lambda m: f"queue: {m}")
+    ids = (torch.arange(B) + index0) % K
+    rest = torch.ones(K, dtype=torch.bool)
+    rest[ids] = False
+    assert torch.equal(mem[rest], mem0[rest])
+    assert int(contrast.index) == ref_index
+    return report
+
+
+def check_e2e_step(tr, model, lr, masks_q, masks_k, sync=lambda: None, step_id=0, rtol=1e-3):
+    """One ``E2ETrainStep.step`` (train.py:396-417: both views through ``model``, out = fk fq^T / T, NCESoftmaxLossNS,
+    clip, Adam) vs the oracle on the same batch."""
+    init_m = _state(model)
+    adam0 = (tr.optimizer.exp_avg.detach().cpu().clone(), tr.optimizer.exp_avg_sq.detach().cpu().clone(), int(tr.optimizer.steps))
+    B, T = tr.B, tr.T
+    tr.mask_fn = lambda: (masks_q, masks_k)
+    out = tr.step(step_id, lr)
+    sync()
+    gq, gk = out["graph_q"], out["graph_k"]
+    (aq, pos_q), (ak, pos_k) = view_arrays(gq), view_arrays(gk)
+    report = dict(batch_size=B, nodes_q=int(aq[0][-1]), nodes_k=int(ak[0][-1]))
+    om = E.OracleGraphEncoder()
+    om.load_state_dict(init_m)
+    om.train()
+    rq = om(*aq, pos_q, dropout_masks=masks_q.cpu())                                      # train.py:397
+    rk = om(*ak, pos_k, dropout_masks=masks_k.cpu())                                      # train.py:398
+    rout = rk @ rq.t() / T                                                                 # train.py:400
+    rloss = E.nce_softmax_loss_ns(rout)
+    rprob = rout.diagonal().mean().detach()                                                # train.py:401
+    opt = torch.optim.Adam(om.parameters(), lr=lr, betas=(0.9, 0.999), weight_decay=1e-5)
+    _seed_adam(opt, om, model, tr, *adam0)
+    opt.zero_grad()
+    rloss.backward()
+    rgn = torch.nn.utils.clip_grad_norm_(om.parameters(), tr.clip_norm)
+    opt.step()
+    feat_q, feat_k = _feat(tr, ("e2e", 0), gq).cpu(), _feat(tr, ("e2e", 1), gk).cpu()
+    torch.testing.assert_close(feat_q, rq.detach(), rtol=rtol, atol=1e-4, msg=lambda m: f"feat_q: {m}")
+    torch.testing.assert_close(feat_k, rk.detach(), rtol=rtol, atol=1e-4, msg=lambda m: f"feat_k: {m}")
+    loss, prob = out["loss"].reshape(()).cpu(), out["prob"].reshape(()).cpu()
+    gn = torch.as_tensor(out["grad_norm"]).reshape(()).cpu()
+    torch.testing.assert_close(loss, rloss.detach(), rtol=rtol, atol=1e-5, msg=lambda m: f"loss: {m}")
+    torch.testing.assert_close(prob, rprob, rtol=rtol, atol=1e-5, msg=lambda m: f"prob: {m}")
+    torch.testing.assert_close(gn, rgn.detach().reshape(()), rtol=rtol, atol=1e-6, msg=lambda m: f"grad_norm: {m}")
+    report.update(loss=float(loss), loss_oracle=float(rloss.detach()), grad_norm=float(gn), grad_norm_oracle=float(rgn.detach()))
+    after_m = _state(model)
+    checked = _cmp_grads_and_update(model, tr.flat_grad.detach().cpu(), om, init_m, after_m, report)
+    assert checked > 10000, checked
+    ref_m = om.state_dict()
+    for k, v in after_m.items():
+        if "running_" in k:
+            torch.testing.assert_close(v, ref_m[k], rtol=rtol, atol=1e-5, msg=lambda m, k=k: f"model {k}: {m}")
+        elif not v.dtype.is_floating_point:
+            assert torch.equal(v, ref_m[k]), k
+    return report

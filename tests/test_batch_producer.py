@@ -62,3 +62,59 @@ def test_posemb_without_multi_is_called_per_view():
     bp.get(0)
     singles = [e[1] for e in log if e[0] == "single"]
     assert singles == [("q", 0), ("k", 0), ("q", 1), ("k", 1)]
+
+
+class OverflowingSampler(FakeSampler):
+    """fake of DeviceRWRSampler's overflow protocol: the first pass over ``bad`` sample ids sets a status bit until grown."""
+
+    def __init__(self, name, log, bad, bits=1):
+        super().__init__(name, log)
+        self.bad, self.bits, self.size, self.pending, self.snaps, self._next = set(bad), bits, 1, 0, [], 0
+
+    def sample(self, first_id, prof=None):
+        self._next += 1
+        if first_id in self.bad and self.size < 4:
+            self.pending |= self.bits
+        return super().sample(first_id, prof)
+
+    def status_snapshot(self):
+        self.snaps.append(self.pending)
+        self.pending = 0
+        return len(self.snaps) - 1
+
+    def read_snapshot(self, token):
+        return self.snaps[token]
+
+    def grow(self, bits):
+        self.log.append(("grow", self.name, bits))
+        self.size *= 4
+
+
+def test_overflowed_chunk_is_regrown_and_resampled_into_the_same_slots():
+    """sampler overflow -> grow -> the chunk is sampled again (gcc_amd/train_step.py: BatchProducer._reproduce); the ring
+    position is put back so that the re-issue lands in the chunk's own slots and later chunks keep theirs."""
+    log = []
+    smp = OverflowingSampler("A", log, bad={1020})
+    bp = BatchProducer([(smp, FakeMulti("A", log))], lambda step: 1000 + 10 * step, "cpu", depth=2, chunk=4)
+    got = [bp.get(s) for s in range(8)]
+    assert [q for q, _ in got] == [("q", 1000 + 10 * s) for s in range(8)]
+    assert bp.regrown == 1 and ("grow", "A", 1) in log
+    samples = [e[2] for e in log if e[0] == "sample"]
+    assert samples == [1000, 1010, 1020, 1030] * 2 + [1040, 1050, 1060, 1070]          # chunk 0 twice, chunk 1 once
+    assert smp._next == 12 - 4          # the re-issue did not advance the ring: 8 slots used by 2 chunks
+    assert bp.launched == 2             # a re-issue is not a new chunk
+    assert not bp.snap
+
+
+def test_overflow_that_growing_does_not_cure_raises():
+    import pytest
+
+    log = []
+
+    class Hopeless(OverflowingSampler):
+        def grow(self, bits):
+            self.log.append(("grow", self.name, bits))        # never helps
+
+    bp = BatchProducer([(Hopeless("A", log, bad={0}), FakeMulti("A", log))], lambda s: s, "cpu", depth=1, chunk=2)
+    with pytest.raises(RuntimeError, match="overflow persists"):
+        bp.get(0)
