@@ -282,6 +282,45 @@ def cpu_baseline_reference_shaped(rp, ci, args):
                        f"(DGL-recalled) + torch.unique + SciPy subgraph slicing + SciPy ARPACK pos-emb; data pipeline only")
 
 
+def parity_step(args, graph, dev):
+    """After the clock, in the checker leg: ONE fused step of the benchmarked trainer class at the benchmarked config
+    (fresh weights, device sampler + device eigensolvers, host-drawn dropout masks) against oracle/encoder.py on the same
+    batch -- the assertion tests/test_headline_parity_gpu.py makes, repeated on the box the number comes from.  Raises
+    when loss / embeddings / gradients / post-step state leave north_star's 1e-3; returns the report for the line."""
+    import torch
+
+    from gcc_amd.contrast import MemoryMoCo
+    from gcc_amd.encoder import GraphEncoder
+    from gcc_amd.posemb import DevicePosEmb
+    from gcc_amd.sampler import DeviceRWRSampler
+    from gcc_amd.train_step import E2ETrainStep, MoCoTrainStep
+    from tests.headline_step_check import check_e2e_step, check_moco_step
+
+    B = args.batch_size
+    torch.manual_seed(12345)
+    enc_kw = dict(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
+                  freq_embedding_size=16, degree_embedding_size=16, output_dim=64, node_hidden_dim=64,
+                  edge_hidden_dim=64, num_layers=5, num_step_set2set=6, num_layer_set2set=3, norm=True,
+                  gnn_model="gin", degree_input=True)
+    smp = DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=2)
+    pe = DevicePosEmb(B, smp.node_cap, 32, device=dev, seed=args.run_seed, num_buffers=2, max_views=2)
+    model = GraphEncoder(**enc_kw).to(dev)
+    masks = [(torch.rand(5, B, 64) >= 0.5).float().to(dev).contiguous() for _ in range(2)]
+    if args.mode == "e2e":
+        tr = E2ETrainStep(model, smp, pe, prefetch=False)
+        rep = check_e2e_step(tr, model, 0.005, masks[0], masks[1], sync=torch.cuda.synchronize, step_id=7)
+    else:
+        ema = GraphEncoder(**enc_kw).to(dev)
+        ema.load_state_dict(model.state_dict())
+        contrast = MemoryMoCo(64, None, args.nce_k, 0.07, use_softmax=True).to(dev)
+        tr = MoCoTrainStep(model, ema, contrast, smp, pe, prefetch=False)
+        rep = check_moco_step(tr, model, ema, contrast, 0.005, masks[0], sync=torch.cuda.synchronize, step_id=7)
+    rep.pop("_graphs", None)
+    tr.check_status(strict_posemb=True)
+    rep["checked"] = "one fused step vs oracle/encoder.py (fp32 and float64) on the same sampled batch: embeddings, loss, prob, grad norm, every gradient, Adam update, EMA, running statistics, queue -- all inside 1e-3 (tests/headline_step_check.py)"
+    return rep
+
+
 def sampler_source_hash():
     h = hashlib.sha256()
     for name in ("sampler.hip", "device_compat.h", "host_common.h"):
@@ -423,6 +462,10 @@ def stage_rooflines(args, acc, kern_iso, stage_ms, shape, pe_probe):
                                               achieved=by / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
                                               frac=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                               f32_mfma_frac=fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS)
+    # the whole step against the HBM roof: every stage's algorithmic bytes over the measured step time (the 8(d) `roofline`
+    # object prices induce_kernel, ~2 % of the step; this is the figure that says where the step as a whole stands)
+    out["_step_bytes"] = acc["total"] + sum(v["algorithmic_bytes"] for k, v in out.items()
+                                            if k.startswith(("gin_encoder", "infonce")))
     if pe_probe:
         out["positional_embedding"] = dict(bound="f32 vector/MFMA rate of the CUs a solver workgroup occupies",
                                            peak_per_cu=F32_PER_CU_GFLOPS, unit="GFLOP/s per CU", **pe_probe)
@@ -659,9 +702,19 @@ def main():
                         np.mean([p["posemb"].elapsed_ms(0, 1) for p in used]))
             out["stage_ms"] = stage_ms
             out["stage_rooflines"] = stage_rooflines(args, acc, {k: v / spc for k, v in kern_iso.items()}, stage_ms, probe_shape, pe_probe)
+            step_bytes = out["stage_rooflines"].pop("_step_bytes")
+            step_gbps = step_bytes / (ms_per_step * 1e-3) / 1e9
+            out["step_roofline"] = dict(
+                bound="hbm", algorithmic_bytes_per_step=step_bytes, ms_per_step=ms_per_step, achieved=step_gbps,
+                peak=HBM_PEAK_GBPS, unit="GB/s", frac=step_gbps / HBM_PEAK_GBPS,
+                note="sum of the stages' SURVEY 8(d) algorithmic bytes (sampler + encoder fwd/bwd + head fwd/bwd; the "
+                     "eigensolvers are FLOP/latency work and add none) over the timed step: the step is a latency-bound chain, "
+                     "not an HBM stream -- stage_rooflines says which stage is how far from which roof")
         out.update(extra)
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline_sampler(rp, ci, args) if args.mode == "sampler" else cpu_baseline(rp, ci, args)
+            if args.mode in ("train", "e2e") and args.posemb == "device":
+                out["cpu_baseline"]["parity_step"] = parity_step(args, graph, dev)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -337,12 +337,14 @@ enum { kClsSmall = 0, kClsMid = 1, kClsSlot = 2, kClsKrylov = 3, kClsBig = 4, kC
 // one-wave teams (posemb_wave_kernel): deflated size <= 48 / <= 64 with at most kWaveNodes original nodes; the
 // 256-thread small class stays behind them for the (rare) leafier subgraphs
 constexpr int kWaveNodes = 256;
+// Both measured on the device in round 4 (scripts/gpu/r4_call1.sh, profiles/r4_posemb_phases_protos.txt): 'matrix' 17.2 -> 12.6 us
+// (n' <= 48) / 32.3 -> 20.9 us (<= 64) of wave time per item, 'expand' 12.7 -> 10.7 / 19.5 -> 15.9; strict device tests green.
 #ifndef GCC_POSEMB_EXPAND4
-#define GCC_POSEMB_EXPAND4 0         // expansion of the one-wave teams four nodes per iteration: same status as GCC_POSEMB_EDGE_FILL
+#define GCC_POSEMB_EXPAND4 1         // expansion of the one-wave teams four nodes per iteration (0: two)
 #endif
 #ifndef GCC_POSEMB_EDGE_FILL
-#define GCC_POSEMB_EDGE_FILL 0       // matrix fill of the one-wave teams by entry instead of by row: written at the end of round 3
-#endif                               // (emulator parity both ways), NOT yet measured or run on the device -- off until it is
+#define GCC_POSEMB_EDGE_FILL 1       // matrix fill of the one-wave teams by entry instead of by row (0: lane = row)
+#endif
 constexpr int kWaveTeams = 4;        // teams (waves) per workgroup
 static_assert(kNumCls == GCC_POSEMB_TICK_CLASSES, "include/gcc_amd.h: tick buffer classes");
 struct PosHead {                     // head of the caller's workspace (zeroed per call)

@@ -141,8 +141,8 @@ class DeviceRWRSampler:
         # ``scratch_entries`` (argument) is PER STEP; a call covers up to ``max_steps`` steps, so the buffer handed to the
         # library holds ``self.scratch_entries`` = per-step entries x max_steps (``scratch_entries_per_step`` keeps the
         # argument's meaning; gcc_sample_multi's ``scratch_entries`` is the whole call's).
-        self.scratch_entries_per_step = int(scratch_entries) if scratch_entries else max(
-            32 << 20, 512 * B * (graph.rw_hops + 1), 8 * (graph.lmax + 1) ** 2, expected)
+        self._default_scratch = max(32 << 20, 512 * B * (graph.rw_hops + 1), 8 * (graph.lmax + 1) ** 2, expected)
+        self.scratch_entries_per_step = int(scratch_entries) if scratch_entries else self._default_scratch
         # steps per call: bounded by the library (GCC_SAMPLE_MAX_STEPS; one LDS word per subgraph in the prefix kernel,
         # (2 * B * steps + 1) * 4 + 512 <= 64 KiB)
         self.max_steps = max(1, min(int(max_steps), 16, 16255 // (2 * B), int(num_buffers)))
@@ -277,7 +277,7 @@ class DeviceRWRSampler:
         if bits & 2:
             raise RuntimeError("gcc_sample_batch overflow: node capacity (node_cap must be batch_size * (lmax + 1))")
         if bits & 1:
-            new = self.scratch_entries_per_step * factor
+            new = max(self.scratch_entries_per_step * factor, self._default_scratch)   # an undersized argument jumps to the heuristic first
             if new * self.max_steps * 4 > limit_bytes:
                 raise RuntimeError(f"gcc_sample_batch overflow: induction scratch of {new * self.max_steps * 4 >> 20} MiB refused")
             self.scratch_entries_per_step = new

@@ -54,15 +54,22 @@ def _cmp_grads_and_update(model, flat_grad, oracle, init, after, report, truth=N
         off += p.numel()
         gref = ref[n].grad
         scale = max(float(gref.abs().max()), 1e-3)
-        atol = max(1e-3 * scale, 1e-6)
-        if ".mlp.linears." in n and n.endswith(".bias"):
-            atol = max(atol, 1e-4)
-        torch.testing.assert_close(got, gref, rtol=2e-3, atol=atol, msg=lambda m, n=n: f"grad {n}: {m}")
-        worst = max(worst, float((got - gref).abs().max()) / scale)
+        noise = 1e-4 if (".mlp.linears." in n and n.endswith(".bias")) else 0.0    # exactly-zero true gradient: rounding noise on both sides
+        err32 = 0.0
         if ref64 is not None:
-            g64 = ref64[n].grad * coef
-            w_dev = max(w_dev, float((got.double() - g64).abs().max()) / scale)
-            w_o32 = max(w_o32, float((gref.double() - g64).abs().max()) / scale)
+            # (i) the bar proper: against the oracle in float64 (exact arithmetic for this purpose) at 2e-4 of the tensor's
+            # largest entry -- five times inside north_star's 1e-3
+            g64 = (ref64[n].grad * coef).float()
+            torch.testing.assert_close(got, g64, rtol=1e-3, atol=max(2e-4 * scale, 1e-6, noise),
+                                       msg=lambda m, n=n: f"grad {n} vs float64 oracle: {m}")
+            err32 = float((gref - g64).abs().max())
+            w_dev = max(w_dev, float((got - g64).abs().max()) / scale)
+            w_o32 = max(w_o32, err32 / scale)
+        # (ii) against the fp32 oracle at 1e-3 of the largest entry plus the fp32 oracle's OWN distance from float64 (its
+        # index_add_ sums over ~25 k nodes carry up to 1.3e-3 at C2 size; the device accumulates these sums in fp64)
+        torch.testing.assert_close(got, gref, rtol=2e-3, atol=max(1e-3 * scale, 1e-6, noise) + 2 * err32,
+                                   msg=lambda m, n=n: f"grad {n}: {m}")
+        worst = max(worst, float((got - gref).abs().max()) / scale)
         if float(gref.abs().max()) > 1e-6:
             solid = gref.abs() > 1e-2 * float(gref.abs().max())
             upd, upd_ref = (after[n] - init[n])[solid], (ref_after[n] - init[n])[solid]
@@ -204,6 +211,13 @@ def check_e2e_step(tr, model, lr, masks_q, masks_k, sync=lambda: None, step_id=0
     rloss.backward()
     rgn = torch.nn.utils.clip_grad_norm_(om.parameters(), tr.clip_norm)
     opt.step()
+    o64 = E.OracleGraphEncoder().double()
+    o64.load_state_dict({k: (v.double() if v.dtype.is_floating_point else v) for k, v in init_m.items()})
+    o64.train()
+    q64 = o64(*aq, pos_q.double(), dropout_masks=masks_q.cpu().double())
+    k64 = o64(*ak, pos_k.double(), dropout_masks=masks_k.cpu().double())
+    E.nce_softmax_loss_ns(k64 @ q64.t() / T).backward()
+    coef = min(1.0, tr.clip_norm / (float(rgn.detach()) + 1e-6)) if tr.clip_norm > 0 else 1.0
     feat_q, feat_k = _feat(tr, ("e2e", 0), gq).cpu(), _feat(tr, ("e2e", 1), gk).cpu()
     torch.testing.assert_close(feat_q, rq.detach(), rtol=rtol, atol=1e-4, msg=lambda m: f"feat_q: {m}")
     torch.testing.assert_close(feat_k, rk.detach(), rtol=rtol, atol=1e-4, msg=lambda m: f"feat_k: {m}")
@@ -214,7 +228,7 @@ def check_e2e_step(tr, model, lr, masks_q, masks_k, sync=lambda: None, step_id=0
     torch.testing.assert_close(gn, rgn.detach().reshape(()), rtol=rtol, atol=1e-6, msg=lambda m: f"grad_norm: {m}")
     report.update(loss=float(loss), loss_oracle=float(rloss.detach()), grad_norm=float(gn), grad_norm_oracle=float(rgn.detach()))
     after_m = _state(model)
-    checked = _cmp_grads_and_update(model, tr.flat_grad.detach().cpu(), om, init_m, after_m, report)
+    checked = _cmp_grads_and_update(model, tr.flat_grad.detach().cpu(), om, init_m, after_m, report, truth=o64, coef=coef)
     assert checked > 10000, checked
     ref_m = om.state_dict()
     for k, v in after_m.items():
