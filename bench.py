@@ -72,6 +72,7 @@ def parse_args(argv=None):
                     help="--mode sampler: steps (DataLoader batches) per sampler call (gcc_sample_multi); the training modes "
                          "sample a producer chunk per call")
     ap.add_argument("--ahead", type=int, default=None, help="chunks launched beyond the one being consumed (default lanes * (depth - 1))")
+    ap.add_argument("--no-graph", action="store_true", help="issue every step launch by launch instead of replaying the captured hipGraph of its ring slot")
     ap.add_argument("--scratch-entries", type=int, default=0, help="induction scratch of the sampler (int32 slots); 0 = default")
     ap.add_argument("--edge-cap", type=int, default=0, help="edge capacity of a batch view; 0 = default")
     ap.add_argument("--pmc-traffic", type=float, default=None,
@@ -581,7 +582,7 @@ def main():
         else:
             trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank,
                                     lanes=lanes, depth=args.depth, chunk=chunk, reserved_cus=args.reserved_cus,
-                                    cu_layout=args.cu_layout, ahead=args.ahead)
+                                    cu_layout=args.cu_layout, ahead=args.ahead, graph=False if args.no_graph else None)
             stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder q+k fwd",
                       "moco-infonce fwd", "infonce bwd", "gin-encoder bwd", "grad all-reduce" if world > 1 else "clip",
                       "adam + ema + meters (one launch)",
@@ -602,12 +603,16 @@ def main():
         for i in range(warm):
             trainer.step(i, lr_at(i))
         first_timed = warm
-        profs = [dict(sampler=Prof(4), **{n: Prof(2) for n in names}) for _ in range(args.steps)]
+        # with graph replay the step's launches carry no event marks (they are one graph launch): the timed steps mark the
+        # producers only and the in-step stage intervals come from a few eager steps after the clock
+        graph_on = bool(getattr(trainer, "use_graph", False))
+        profs = [dict(sampler=Prof(4), **({} if graph_on else {n: Prof(2) for n in names})) for _ in range(args.steps)]
         if args.posemb == "device":
             for p in profs:
                 p["posemb"] = Prof(2)
         barrier()
         launched0 = trainer.producer.launched
+        trainer.graph_replays_at_clock = getattr(trainer, "graph_replays", 0)
         t0 = time.perf_counter()
         for i in range(args.steps):
             last = trainer.step(first_timed + i, lr_at(first_timed + i), prof=profs[i])
@@ -616,6 +621,17 @@ def main():
         produced = (trainer.producer.launched - launched0) * chunk
         consumed = args.steps
         extra["final_loss"] = float(last["loss"].item())
+        extra["step_launch"] = "hipGraph replay (one captured graph per ring slot)" if graph_on else "eager (launch by launch)"
+        stage_profs = profs
+        if graph_on:
+            extra["graph_replays_in_timed_region"] = int(trainer.graph_replays - (trainer.graph_replays_at_clock if hasattr(trainer, "graph_replays_at_clock") else 0))
+            trainer.use_graph = False                                     # stage intervals: eager steps right after the clock
+            stage_profs = [{n: Prof(2) for n in names} for _ in range(chunk)]
+            for i in range(chunk):
+                trainer.step(first_timed + args.steps + i, lr_at(first_timed + args.steps + i), prof=stage_profs[i])
+            torch.cuda.synchronize()
+            trainer.use_graph = True
+        extra["sampler_regrown"] = int(sum(getattr(sm, "regrown", 0) for sm in samplers))
         if hasattr(posemb, "status"):
             sts = [p.status.cpu().tolist() for p in posembs]
             flags = 0
@@ -693,7 +709,7 @@ def main():
             out["config"].update(producer_lanes=args.lanes, producer_depth=args.depth, producer_chunk=chunk,
                                  producer_ahead=trainer.producer.ahead, reserved_cus=args.reserved_cus)
             used = [p for p in profs if p.get("used")]
-            stage_ms = {n: float(np.mean([p[n].elapsed_ms(0, 1) for p in profs])) for n in names}
+            stage_ms = {n: float(np.mean([p[n].elapsed_ms(0, 1) for p in stage_profs])) for n in names}
             if used:
                 k_ms = np.array([[p["sampler"].elapsed_ms(j, j + 1) for j in range(3)] for p in used])
                 stage_ms["sampler"] = float(k_ms.sum(axis=1).mean())

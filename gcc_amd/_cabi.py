@@ -88,6 +88,7 @@ class GccGinWeights(ctypes.Structure):
         ("pred_w", _VP * (GIN_MAX_LAYERS + 1)), ("pred_b", _VP * (GIN_MAX_LAYERS + 1)),
         ("bn_eps", ctypes.c_float), ("bn_momentum", ctypes.c_float), ("dropout_p", ctypes.c_float),
         ("norm_eps", ctypes.c_float),
+        ("hidden", ctypes.c_int32),
     ]
 
 
@@ -104,6 +105,7 @@ class GccGinPass(ctypes.Structure):
         ("edge_multiplicity", ctypes.c_int32),
         ("bn_totals", _VP),
         ("seed_local", _VP),
+        ("scalars", _VP),
     ]
 
 
@@ -205,6 +207,15 @@ SIGNATURES = {
                                            ctypes.c_float, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,
                                            ctypes.POINTER(GccStepMetersArgs), ctypes.c_void_p]),
+    "gcc_adam_ema_step_scalars": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
+                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,
+                                                   ctypes.POINTER(GccStepMetersArgs), ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_queue_enqueue_scalars": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                                   ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_step_scalars_set": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int32,
+                                              ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p]),
     "gcc_step_meters": (ctypes.c_int32, [ctypes.c_void_p] * 8 + [ctypes.c_int32, ctypes.c_void_p]),
     "gcc_ema_update": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,
                                         ctypes.c_void_p]),

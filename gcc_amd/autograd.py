@@ -34,7 +34,7 @@ class _GinFn(torch.autograd.Function):
         enc = ctx.enc
         if not ctx.p.training:
             raise RuntimeError("backward through an eval-mode (running statistics) pass is not supported")
-        targets = [torch.zeros_like(param) for _, _, param in grad_params(enc)]
+        targets = [enc.padded_zeros_like(param) for _, _, param in grad_params(enc)]
         enc.engine().backward(enc, ctx.p, ctx.buf, dfeat, targets=targets, stream=_stream(dfeat))
         return (None, None, None, None, *targets)
 

@@ -78,7 +78,20 @@ class NceEngine:
             raise RuntimeError(f"gcc_nce_backward failed ({rc}): {self.lib.gcc_last_error().decode()}")
         return dq
 
-    def enqueue(self, mem, keys, index, save=True, stream=None):
+    def set_scalars(self, scalars, lr, betas, adam_step, enqueue_index, dropout_seed, stream=None):
+        """gcc_step_scalars_set: the per-step scalars of a replayed step into their device struct (uint8[24] tensor)."""
+        rc = self.lib.gcc_step_scalars_set(self.ptr(scalars), float(lr), float(betas[0]), float(betas[1]), int(adam_step),
+                                           int(enqueue_index), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, stream)
+        if rc != 0:
+            raise RuntimeError(f"gcc_step_scalars_set failed ({rc}): {self.lib.gcc_last_error().decode()}")
+
+    def enqueue(self, mem, keys, index, save=True, stream=None, scalars=None):
+        if scalars is not None:                      # ring pointer from the device struct (replayed step); no saved rows
+            rc = self.lib.gcc_queue_enqueue_scalars(self.ptr(mem), mem.shape[0], self.ptr(keys), keys.shape[0],
+                                                    self.ptr(scalars), stream)
+            if rc != 0:
+                raise RuntimeError(f"gcc_queue_enqueue_scalars failed ({rc}): {self.lib.gcc_last_error().decode()}")
+            return None
         saved = torch.empty_like(keys) if save else None
         rc = self.lib.gcc_queue_enqueue(self.ptr(mem), mem.shape[0], self.ptr(keys), keys.shape[0], int(index),
                                         self.ptr(saved) if saved is not None else None, stream)
@@ -96,7 +109,7 @@ class NceEngine:
             raise RuntimeError(f"gcc_adam_step failed ({rc}): {self.lib.gcc_last_error().decode()}")
 
     def adam_ema(self, param, grad, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, step, max_norm, grad_norm,
-                 scratch, stream=None, grad_scale=1.0, ema=None, ema_src=None, ema_m=0.0, meters=None):
+                 scratch, stream=None, grad_scale=1.0, ema=None, ema_src=None, ema_m=0.0, meters=None, scalars=None):
         """gcc_adam_ema_step: clip + Adam over ``param`` (the live prefix of the flat buffer ``ema_src``), the EMA copy
         ``ema`` of all of ``ema_src`` and one step of the meters ``(acc, mx, loss, prob, q, k)`` in the Adam launch."""
         ma = None
@@ -106,6 +119,15 @@ class NceEngine:
                                          self.ptr(q.edge_off), self.ptr(k.node_off), int(q.batch_size))
         if ema is not None and (ema_src is None or ema_src.data_ptr() != param.data_ptr() or ema.numel() != ema_src.numel()):
             raise ValueError("adam_ema: param must be a prefix of ema_src, and ema the same size as ema_src")
+        if scalars is not None:                      # lr / bias corrections from the device struct (replayed step)
+            rc = self.lib.gcc_adam_ema_step_scalars(
+                self.ptr(param), self.ptr(grad), self.ptr(exp_avg), self.ptr(exp_avg_sq), param.numel(), float(betas[0]),
+                float(betas[1]), float(eps), float(weight_decay), float(max_norm), float(grad_scale), self.ptr(grad_norm),
+                self.ptr(scratch), self.ptr(ema) if ema is not None else None, ema.numel() if ema is not None else 0,
+                float(ema_m), ctypes.byref(ma) if ma is not None else None, self.ptr(scalars), stream)
+            if rc != 0:
+                raise RuntimeError(f"gcc_adam_ema_step_scalars failed ({rc}): {self.lib.gcc_last_error().decode()}")
+            return
         rc = self.lib.gcc_adam_ema_step(self.ptr(param), self.ptr(grad), self.ptr(exp_avg), self.ptr(exp_avg_sq),
                                         param.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
                                         float(weight_decay), int(step), float(max_norm), float(grad_scale),
@@ -145,7 +167,7 @@ class _MoCoLoss(torch.autograd.Function):
     def backward(ctx, dloss):
         q, k = ctx.saved_tensors
         m = ctx.module
-        dq = m.engine().backward(q, k, m.memory, m.T, 0, ctx.outs, dloss, patch=ctx.patch,
+        dq = m.engine().backward(q, k, m.kernel_memory(), m.T, 0, ctx.outs, dloss, patch=ctx.patch,
                                  patch_index=ctx.patch_index, stream=_stream(q))
         return dq, None, None, None, None, None
 
@@ -197,8 +219,8 @@ class MemoryMoCo(nn.Module):
     def __init__(self, inputSize, outputSize, K, T=0.07, use_softmax=False, nce_dtype="f32"):
         super().__init__()
         self.nce_dtype = nce_dtype         # not in the reference: "bf16" selects the throughput mode of the head
-        if inputSize != D:
-            raise NotImplementedError("feature size is fixed at 64 (train.py:93 default)")
+        if not 1 <= inputSize <= D:
+            raise NotImplementedError(f"feature size must be between 1 and {D} (narrower than {D}: run zero-padded, exactly)")
         if not use_softmax:
             raise NotImplementedError("train.py:628 always passes use_softmax=True (the exp/Z branch is dead)")
         self.outputSize = outputSize
@@ -219,28 +241,47 @@ class MemoryMoCo(nn.Module):
             self._engine = NceEngine(dtype=self.nce_dtype)
         return self._engine
 
+    # ---- feature sizes below 64 (--hidden-size): the kernels' rows are 64 floats.  The ``memory`` buffer keeps the
+    # reference's shape [K, inputSize] (checkpoint["contrast"]) as the column slice of a zero-padded [K, 64] block that the
+    # kernels read and write; zero columns change no dot product, norm or gradient.
+    def kernel_memory(self):
+        if self.inputSize == D:
+            return self.memory
+        m = self.memory
+        big = getattr(self, "_mem64", None)
+        if big is None or m.data_ptr() != big.data_ptr() or m.stride(0) != D or big.device != m.device:
+            big = torch.zeros(self.queueSize, D, dtype=m.dtype, device=m.device)   # (.to() / load re-materialised the buffer)
+            big[:, : self.inputSize].copy_(m)
+            self._mem64 = big
+            self._buffers["memory"] = big[:, : self.inputSize]
+        return big
+
+    def _pad(self, t):
+        return t if t.shape[1] == D else torch.nn.functional.pad(t, (0, D - t.shape[1]))
+
     def forward(self, q, k):
         eng = self.engine()
-        qc = q.contiguous()
-        kc = k.detach().contiguous()                                   # memory_moco.py:28
+        mem = self.kernel_memory()
+        qc = self._pad(q).contiguous()                                 # (differentiable: the gradient comes back sliced)
+        kc = self._pad(k.detach()).contiguous()                        # memory_moco.py:28
         st = _stream(qc)
-        outs = eng.forward(qc.detach(), kc, self.memory, self.T, 0, stream=st)   # logits vs the queue BEFORE the update
+        outs = eng.forward(qc.detach(), kc, mem, self.T, 0, stream=st)   # logits vs the queue BEFORE the update
         keys = self.gather_keys(kc) if self.gather_keys is not None else kc
         index = self.index
         with torch.no_grad():                                          # memory_moco.py:55-61
-            saved = eng.enqueue(self.memory, keys, index, save=True, stream=st)
+            saved = eng.enqueue(mem, keys, index, save=True, stream=st)
         self.index = (index + keys.shape[0]) % self.queueSize
         loss = _MoCoLoss.apply(qc, kc, self, outs, saved, index)
 
         def dense():
-            return eng.forward(qc.detach(), kc, self.memory, self.T, 0, dense=True, patch=saved, patch_index=index,
+            return eng.forward(qc.detach(), kc, mem, self.T, 0, dense=True, patch=saved, patch_index=index,
                                stream=st)["out"]
 
         return NCELogits(loss, outs["prob"].reshape(()), outs["pos"], (q.shape[0], self.queueSize + 1), dense)
 
     def logits(self, q, k):
         """Dense ``out`` of memory_moco.py:40-44 without the enqueue side effect (tests, debugging)."""
-        outs = self.engine().forward(q.detach().contiguous(), k.detach().contiguous(), self.memory, self.T, 0,
+        outs = self.engine().forward(self._pad(q.detach()).contiguous(), self._pad(k.detach()).contiguous(), self.kernel_memory(), self.T, 0,
                                      dense=True, stream=_stream(q))
         return outs["out"]
 
@@ -266,6 +307,9 @@ class NCESoftmaxLossNS(nn.Module):
 def e2e_logits(feat_q, feat_k, T, engine=None):
     """``torch.matmul(feat_k, feat_q.t()) / T`` of train.py:400, fused with its loss."""
     eng = engine if engine is not None else NceEngine()
+    if feat_q.shape[1] != D:                       # --hidden-size below 64: zero columns change no dot product
+        feat_q = torch.nn.functional.pad(feat_q, (0, D - feat_q.shape[1]))
+        feat_k = torch.nn.functional.pad(feat_k, (0, D - feat_k.shape[1]))
     loss, prob = _NSLoss.apply(feat_q, feat_k, T, eng)
 
     def dense():

@@ -254,6 +254,7 @@ struct MidArgs {
     double *stats_b;
     int32_t B, training;
     float eps;
+    int32_t hid;              // columns of w1 (gcc_gin_weights.hidden: the true hidden width, <= 64)
 };
 struct MidLaunch { MidArgs p[kMaxPass]; };
 
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
     const MidArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
     __shared__ float Wl[H * kLdt];
-    const WStage wst = stage_weights_request(a.w1, H);       // in flight with N and the statistics
+    const WStage wst = stage_weights_request(a.w1, a.hid);   // in flight with N and the statistics
     __shared__ float taba[2 * H];
     __shared__ __attribute__((aligned(16))) float bl[H];     // linears.1's bias
     const float b_own = a.b1 ? a.b1[tid & (H - 1)] : 0.f;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
     SCHED_FENCE();
     if (no_tiles(N)) return;
     bn_table_finish(taba, ra, (double)N, a.eps, a.training, (double *)red);
-    stage_weights_store(Wl, wst, H);
+    stage_weights_store(Wl, wst, a.hid);
     if (tid < H) bl[tid] = b_own;
     __syncthreads();
     Aff4 aa[4];
@@ -413,6 +414,7 @@ struct ReadArgs {
     float *score, *feat;
     BnDev bn[3 * GCC_GIN_MAX_LAYERS];
     int32_t B, nlayers, kdim0, normalize, update_running;
+    int32_t hid;                // columns of pred_w[i > 0] (the true hidden width)
     float norm_eps, momentum;
     double *totals;             // [3 * nlayers][2][64] or NULL: the statistics replicas added up, for the backward pass
 };
@@ -428,6 +430,7 @@ __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
     const int b = (int)blockIdx.x * 16 + j;
     const bool valid = b < a.B;
+    const DropCfg drop = drop_resolve(a.drop);
     // the statistics of BatchNorm blockIdx.x (added up at the end of this kernel) are requested now: in flight with the scores
     const bool bn_work = (a.update_running || a.totals) && (int)blockIdx.x < 3 * a.nlayers;     // block-uniform
     RepReq rq = {};
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) { F4 z = {0.f, 0.f, 0.f, 0.f}; score[cb] = z; }
     for (int i = wave_uniform(wv); i <= a.nlayers; i += 4) {       // (scalar: pred_w[i] / pred_b[i] are scalar loads, not a round trip)
-        const int kd = i == 0 ? a.kdim0 : H;
+        const int kd = i == 0 ? a.kdim0 : a.hid;
         F4 wf[4][4];
         load_w_frags(a.pred_w[i], kd, wf);                         // weights and biases first: the fp64 -> f32 conversions
         F4 bias4[4];                                               // below wait for whatever was requested before them
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(kThreads) void gin_readout_kernel(ReadLaunch L)
         for (int cb = 0; cb < 4; ++cb) {
             const int ch = 16 * cb + 4 * q;
             const F4 bias = bias4[cb];
-            const F4 m = valid ? drop_mul4(a.drop, i, b, ch) : bias;   // self.drop, gin.py:230
+            const F4 m = valid ? drop_mul4(drop, i, b, ch) : bias;   // self.drop, gin.py:230
             score[cb].x += (acc[cb][0] + bias.x) * m.x;
             score[cb].y += (acc[cb][1] + bias.y) * m.y;
             score[cb].z += (acc[cb][2] + bias.z) * m.z;
@@ -586,7 +589,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
                 a.stats_a = stats_of(p, l, 0);
                 a.pooled = p.pooled + (int64_t)l * p.batch_size * H;
                 a.B = p.batch_size; a.first = l == 0;
-                a.kdim = l == 0 ? p.w.pos_dim + p.w.deg_emb_dim + 1 : H;
+                a.kdim = l == 0 ? p.w.pos_dim + p.w.deg_emb_dim + 1 : hidden_of(p.w);
                 a.training = p.training; a.eps = p.w.bn_eps;
                 a.nbr_weight = p.edge_multiplicity > 1 ? (float)p.edge_multiplicity : 1.0f;
                 L.p[i] = a;
@@ -600,7 +603,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
                 const gcc_gin_pass &p = passes[i];
                 L.p[i] = {p.node_off, p.z1[l], bn_of(p, p.w.bn_a[l], l, 0, false), p.w.lin1_w[l], p.w.lin1_b[l],
                           p.z2[l], stats_of(p, l, 1), p.batch_size, p.training,
-                          p.w.bn_eps};
+                          p.w.bn_eps, hidden_of(p.w)};
             }
             hipLaunchKernelGGL(gin_mid_kernel, grid, block, 0, s, L);
         }
@@ -639,7 +642,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
                 a.bn[3 * l + 2] = bn_of(p, p.w.bn_c[l], l, 2, false);
             }
             a.totals = p.training ? p.bn_totals : nullptr;
-            a.B = p.batch_size; a.nlayers = Lg; a.kdim0 = p.w.pos_dim + p.w.deg_emb_dim + 1;
+            a.B = p.batch_size; a.nlayers = Lg; a.kdim0 = p.w.pos_dim + p.w.deg_emb_dim + 1; a.hid = hidden_of(p.w);
             a.normalize = p.normalize; a.update_running = p.training && p.update_running_stats;
             a.norm_eps = p.w.norm_eps; a.momentum = p.w.bn_momentum;
             L.p[i] = a;

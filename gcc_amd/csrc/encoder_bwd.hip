@@ -161,6 +161,7 @@ struct ReadBwdArgs {
     float *G, *dpooled;       // [L+1][B][64]
     int32_t B, nlayers, kdim0, normalize;
     float norm_eps;
+    int32_t hid;              // columns of pred_w[i > 0]
     float4 *zero;             // workgroups past the first `nread` clear this region (the accumulators of the kernels that follow)
     int64_t zero16;
     int32_t nread;
@@ -183,8 +184,9 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_readout_kernel(ReadBwdArgs a
     if (blk * 16 >= a.B) return;                   // wave-uniform (the kernel has no barriers)
     const int b = blk * 16 + j;
     const bool valid = b < a.B;
+    const DropCfg drop = drop_resolve(a.drop);
     F4 wf[4][4];
-    load_wt_frags(a.pred_w[i], i == 0 ? a.kdim0 : H, wf);          // requested first: in flight with d feat / score / feat
+    load_wt_frags(a.pred_w[i], i == 0 ? a.kdim0 : a.hid, wf);          // requested first: in flight with d feat / score / feat
     F4 ds[4];
     float ss = 0.f, dot = 0.f;
     F4 fv[4], sv[4];
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_readout_kernel(ReadBwdArgs a
         for (int cb = 0; cb < 4; ++cb) {
             const int ch = 16 * cb + 4 * q;
             F4 m = {0.f, 0.f, 0.f, 0.f};
-            if (valid) m = drop_mul4(a.drop, i, b, ch);
+            if (valid) m = drop_mul4(drop, i, b, ch);
             F4 gg = {ds[cb].x * m.x, ds[cb].y * m.y, ds[cb].z * m.z, ds[cb].w * m.w};
             g[cb] = gg;
             if (valid) st4(a.G + ((int64_t)i * a.B + b) * H + ch, gg);
@@ -782,7 +784,7 @@ struct FinalArgs {
     const double *bst;        // [L][3 (a,b,c)][kRep][3][64]
     const float *demb_parts;  // [kEmbBlocks][emb_rows * emb_dim]
     gcc_gin_grads g;
-    int32_t B, L, kdim0, emb_rows, emb_dim, accumulate;
+    int32_t B, L, kdim0, emb_rows, emb_dim, accumulate, hid;
 };
 
 __device__ __forceinline__ void put(float *dst, float v, int acc)
@@ -808,11 +810,11 @@ __global__ __launch_bounds__(kThreads) void gin_grad_final_kernel(FinalArgs a)
         float *dst;
         if (y < 2 * L) {
             const int l = y >> 1, which = y & 1;
-            kd = (which == 0 && l == 0) ? a.kdim0 : H;
+            kd = (which == 0 && l == 0) ? a.kdim0 : a.hid;
             dst = which ? a.g.lin1_w[l] : a.g.lin0_w[l];
         } else {
             const int i = y - 2 * L;
-            kd = i == 0 ? a.kdim0 : H;
+            kd = i == 0 ? a.kdim0 : a.hid;
             dst = a.g.pred_w[i];
         }
         if (k < kd && dst) put(dst + (int64_t)o * kd + k, s, a.accumulate);
@@ -959,7 +961,7 @@ extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat
         ReadBwdArgs a;
         a.dfeat = dfeat; a.score = p.score; a.feat = p.feat; a.drop = drop_cfg(p);
         for (int i = 0; i <= L; ++i) a.pred_w[i] = p.w.pred_w[i];
-        a.G = w.G; a.dpooled = w.dpooled; a.B = B; a.nlayers = L; a.kdim0 = kdim0; a.normalize = p.normalize;
+        a.G = w.G; a.dpooled = w.dpooled; a.B = B; a.nlayers = L; a.kdim0 = kdim0; a.normalize = p.normalize; a.hid = hidden_of(p.w);
         a.norm_eps = p.w.norm_eps;
         // the per-call accumulators (BatchNorm-backward column sums) are cleared by extra workgroups of this launch
         a.zero = (float4 *)((char *)workspace + w.off_zero); a.zero16 = w.zero_bytes / 16; a.nread = ((B + 15) / 16 * (L + 1) + 3) / 4;
@@ -979,13 +981,13 @@ extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat
             hipLaunchKernelGGL(gin_bwd_b_kernel, grid, block, 0, s, a);
         }
         {
-            BwdLinArgs a = {p.node_off, w.V, p.z2[l], bnb, bst(l, 1), bst(l, 1) + 2 * H, p.w.lin1_w[l], H,
+            BwdLinArgs a = {p.node_off, w.V, p.z2[l], bnb, bst(l, 1), bst(l, 1) + 2 * H, p.w.lin1_w[l], hidden_of(p.w),
                             w.dz2[l], w.Wt, p.z1[l], bna, bst(l, 0), B, p.w.bn_eps};
             hipLaunchKernelGGL((gin_bwd_lin_kernel<true>), grid, block, 0, s, a);
         }
         {
             BwdLinArgs a = {p.node_off, w.Wt, p.z1[l], bna, bst(l, 0), bst(l, 0) + 2 * H, p.w.lin0_w[l],
-                            l == 0 ? kdim0 : H, w.dz1[l], w.D, nullptr, BnDev(), nullptr, B, p.w.bn_eps};
+                            l == 0 ? kdim0 : hidden_of(p.w), w.dz1[l], w.D, nullptr, BnDev(), nullptr, B, p.w.bn_eps};
             hipLaunchKernelGGL((gin_bwd_lin_kernel<false>), grid, block, 0, s, a);
         }
     }
@@ -1010,7 +1012,7 @@ extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat
     {
         FinalArgs a;
         a.slabs = w.slabs; a.bias_slabs = w.bias_slabs; a.bst = w.bst; a.demb_parts = w.demb_parts; a.g = *grads;
-        a.B = B; a.L = L; a.kdim0 = kdim0; a.emb_rows = p.w.max_degree + 1; a.emb_dim = p.w.deg_emb_dim;
+        a.B = B; a.L = L; a.kdim0 = kdim0; a.emb_rows = p.w.max_degree + 1; a.emb_dim = p.w.deg_emb_dim; a.hid = hidden_of(p.w);
         a.accumulate = accumulate;
         const int64_t upto4 = (int64_t)(3 * L + 1) * H * H + (int64_t)(L + 1) * H + (int64_t)L * 9 * H;
         const int64_t total = ((upto4 + 63) & ~(int64_t)63) + (((int64_t)a.emb_rows * a.emb_dim * 8 + 63) & ~(int64_t)63);

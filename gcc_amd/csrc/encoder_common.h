@@ -576,7 +576,14 @@ struct DropCfg {
     uint64_t seed;
     int32_t philox, B;
     float p, inv_keep;
+    const gcc_step_scalars *sc;      // replayed step (hipGraph): the Philox key is sc->dropout_seed
 };
+// the readout kernels call this once at their top: one uniform load, in flight with their first requests
+__device__ __forceinline__ DropCfg drop_resolve(DropCfg d)
+{
+    if (d.sc && d.philox) d.seed = d.sc->dropout_seed;
+    return d;
+}
 __device__ __forceinline__ F4 drop_mul4(const DropCfg &d, int layer, int b, int ch)
 {
     F4 m = {1.f, 1.f, 1.f, 1.f};
@@ -598,9 +605,13 @@ __device__ __forceinline__ F4 drop_mul4(const DropCfg &d, int layer, int b, int 
 inline DropCfg drop_cfg(const gcc_gin_pass &p)
 {
     DropCfg d = {p.dropout_keep, p.dropout_seed, p.dropout_keep ? 0 : p.dropout_philox, p.batch_size,
-                 p.w.dropout_p, 1.0f / (1.0f - p.w.dropout_p)};
+                 p.w.dropout_p, 1.0f / (1.0f - p.w.dropout_p), p.scalars};
     return d;
 }
+
+// true hidden width of the model (<= 64; 0 = 64): the column count of every Linear that reads a hidden representation.
+// Every per-channel array and every weight's ROW count stays 64: rows / channels >= hidden are zero padding kept by the caller.
+inline int hidden_of(const gcc_gin_weights &w) { return w.hidden > 0 ? w.hidden : H; }
 
 inline BnDev bn_dev(const gcc_bn &b, const double *stats, const double *totals = nullptr)
 {

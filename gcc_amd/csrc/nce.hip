@@ -343,9 +343,10 @@ __global__ __launch_bounds__(kThreads) void nce_dq_kernel(NceDev a)
 }
 
 __global__ __launch_bounds__(kThreads) void queue_enqueue_kernel(float *mem, int K, const float *keys, int nkeys,
-                                                                 int index, float *saved)
+                                                                 int index, float *saved, const gcc_step_scalars *sc)
 {
     TRAIN_STEP_WAVE_PRIORITY();
+    if (sc) index = sc->enqueue_index % K;                    // replayed step: the ring pointer lives on the device
     const int gid = (int)blockIdx.x * kThreads + (int)threadIdx.x;
     const int i = gid >> 4, c4 = (gid & 15) * 4;
     if (i >= nkeys) return;
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(kThreads) void gradnorm_kernel(const float *g, int6
 // optional extras of the Adam launch (gcc_adam_ema_step): the EMA copy of the parameters and the per-step meters
 struct AdamExtras {
     float *ema; int64_t n_ema; float ema_m;
+    const gcc_step_scalars *sc;      // replayed step: lr and the bias corrections come from here
     double *acc; int32_t *mx; const float *loss, *prob; const int32_t *node_off_q, *edge_off_q, *node_off_k; int32_t B;
 };
 
@@ -420,6 +422,7 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(float *p, float *g, floa
     TRAIN_STEP_WAVE_PRIORITY();
     // grad_scale: the 1 / world of a summed (all-reduced) gradient, folded in here instead of a launch of its own
     const double ss = sumsq[0];
+    if (x.sc) { lr = x.sc->lr; bc1 = x.sc->bias_corr1; bc2_sqrt = x.sc->bias_corr2_sqrt; }   // (uniform: one scalar load, in flight with the rest)
     // this thread's first element rides in the same round trip as the norm
     const int64_t stride = (int64_t)gridDim.x * kThreads, i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const int64_t ic = i0 < n ? i0 : n - 1;
@@ -574,7 +577,38 @@ int32_t gcc_queue_enqueue(float *mem, int32_t K, const float *keys, int32_t nkey
         return -1;
     }
     hipLaunchKernelGGL(queue_enqueue_kernel, dim3((nkeys * 16 + kThreads - 1) / kThreads), dim3(kThreads), 0,
-                       (hipStream_t)stream, mem, K, keys, nkeys, index, saved);
+                       (hipStream_t)stream, mem, K, keys, nkeys, index, saved, (const gcc_step_scalars *)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
+int32_t gcc_queue_enqueue_scalars(float *mem, int32_t K, const float *keys, int32_t nkeys, const gcc_step_scalars *scalars,
+                                  void *stream)
+{
+    if (!mem || !keys || !scalars || K < 1 || nkeys < 1 || nkeys > K) {
+        snprintf(g_err, kErrLen, "gcc_queue_enqueue_scalars: bad argument (K=%d n=%d)", K, nkeys);
+        return -1;
+    }
+    hipLaunchKernelGGL(queue_enqueue_kernel, dim3((nkeys * 16 + kThreads - 1) / kThreads), dim3(kThreads), 0,
+                       (hipStream_t)stream, mem, K, keys, nkeys, 0, (float *)nullptr, scalars);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
+__global__ void step_scalars_kernel(gcc_step_scalars *dev, gcc_step_scalars v) { *dev = v; }
+
+int32_t gcc_step_scalars_set(gcc_step_scalars *dev, float lr, float beta1, float beta2, int32_t adam_step,
+                             int32_t enqueue_index, uint64_t dropout_seed, void *stream)
+{
+    if (!dev || adam_step < 1 || enqueue_index < 0) {
+        snprintf(g_err, kErrLen, "gcc_step_scalars_set: bad argument");
+        return -1;
+    }
+    gcc_step_scalars v;
+    v.lr = lr;
+    v.bias_corr1 = 1.0f - powf(beta1, (float)adam_step);          // exactly gcc_adam_step's host arithmetic
+    v.bias_corr2_sqrt = sqrtf(1.0f - powf(beta2, (float)adam_step));
+    v.enqueue_index = enqueue_index;
+    v.dropout_seed = dropout_seed;
+    hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dev, v);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
@@ -598,23 +632,24 @@ int32_t gcc_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
-int32_t gcc_adam_ema_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
-                          float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
-                          float grad_scale, float *grad_norm, double *scratch, float *ema, int64_t n_ema, float ema_m,
-                          const gcc_step_meters_args *meters, void *stream)
+static int32_t adam_ema_launch(const char *who, float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                               float grad_scale, float *grad_norm, double *scratch, float *ema, int64_t n_ema, float ema_m,
+                               const gcc_step_meters_args *meters, const gcc_step_scalars *scalars, void *stream)
 {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || !grad_norm || !scratch || n < 1 || step < 1 || !(grad_scale > 0.f) ||
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !grad_norm || !scratch || n < 1 || (!scalars && step < 1) || !(grad_scale > 0.f) ||
         (ema && n_ema < n) ||
         (meters && (!meters->acc || !meters->mx || !meters->loss || !meters->prob || !meters->node_off_q ||
                     !meters->edge_off_q || !meters->node_off_k || meters->batch_size < 1))) {
-        snprintf(g_err, kErrLen, "gcc_adam_ema_step: bad argument");
+        snprintf(g_err, kErrLen, "%s: bad argument", who);
         return -1;
     }
     hipStream_t s = (hipStream_t)stream;
-    const float bc1 = 1.0f - powf(beta1, (float)step);
-    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    const float bc1 = scalars ? 1.f : 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = scalars ? 1.f : sqrtf(1.0f - powf(beta2, (float)step));
     hipLaunchKernelGGL(gradnorm_kernel, dim3(kNormBlocks), dim3(kThreads), 0, s, (const float *)grad, n, scratch);
     AdamExtras x = {};
+    x.sc = scalars;
     if (ema) { x.ema = ema; x.n_ema = n_ema; x.ema_m = ema_m; }
     if (meters) {
         x.acc = meters->acc; x.mx = meters->mx; x.loss = meters->loss; x.prob = meters->prob;
@@ -627,6 +662,25 @@ int32_t gcc_adam_ema_step(float *param, float *grad, float *exp_avg, float *exp_
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(kThreads), 0, s, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
                        beta2, eps, weight_decay, bc1, bc2_sqrt, max_norm, grad_scale, (const double *)scratch, grad_norm, x);
     return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
+int32_t gcc_adam_ema_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                          float grad_scale, float *grad_norm, double *scratch, float *ema, int64_t n_ema, float ema_m,
+                          const gcc_step_meters_args *meters, void *stream)
+{
+    return adam_ema_launch("gcc_adam_ema_step", param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step,
+                           max_norm, grad_scale, grad_norm, scratch, ema, n_ema, ema_m, meters, nullptr, stream);
+}
+
+int32_t gcc_adam_ema_step_scalars(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                  float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                                  float grad_scale, float *grad_norm, double *scratch, float *ema, int64_t n_ema, float ema_m,
+                                  const gcc_step_meters_args *meters, const gcc_step_scalars *scalars, void *stream)
+{
+    if (!scalars) { snprintf(g_err, kErrLen, "gcc_adam_ema_step_scalars: scalars is NULL"); return -1; }
+    return adam_ema_launch("gcc_adam_ema_step_scalars", param, grad, exp_avg, exp_avg_sq, n, 0.f, beta1, beta2, eps, weight_decay,
+                           0, max_norm, grad_scale, grad_norm, scratch, ema, n_ema, ema_m, meters, scalars, stream);
 }
 
 int32_t gcc_step_meters(double *acc, int32_t *mx, const float *loss, const float *prob, const float *grad_norm,

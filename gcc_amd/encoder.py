@@ -94,6 +94,7 @@ def fill_weights(enc: "GraphEncoder", ptr) -> _cabi.GccGinWeights:
     w.bn_eps, w.bn_momentum = bn0.eps, bn0.momentum
     w.dropout_p = g.drop.p
     w.norm_eps = 1e-5                                   # graph_encoder.py:196
+    w.hidden = 0 if enc.hidden == H else enc.hidden     # narrower models run zero-padded (see GraphEncoder.ensure_padded)
     return w
 
 
@@ -139,10 +140,11 @@ class GinEngine:
                 score=torch.zeros(B, H, **f32), feat=torch.zeros(B, H, **f32))
         return self._bufs[k]
 
-    def make_pass(self, enc, g, training, keep=None, slot=0, dropout_seed=None):
+    def make_pass(self, enc, g, training, keep=None, slot=0, dropout_seed=None, scalars=None):
         """-> (GccGinPass, buffers).  ``g`` needs node_off,row_ptr,col_idx,graph_id,pos_undirected,batch_size."""
         ptr = self.ptr
         L = len(enc.gnn.ginlayers)
+        enc.ensure_padded()
         node_cap = g.parent_nid.numel() if hasattr(g, "parent_nid") else g.graph_id.numel()
         buf = self._buffers(slot, node_cap, g.batch_size, L, g.node_off.device)
         p = _cabi.GccGinPass()
@@ -166,6 +168,8 @@ class GinEngine:
         p.bn_totals = ptr(buf["bn_totals"]) if training else None
         seed_local = getattr(g, "seed_local", None)
         p.seed_local = ptr(seed_local) if seed_local is not None else None
+        # replayed step (hipGraph): the Philox key of the dropout masks is read from the device struct (gcc_step_scalars)
+        p.scalars = ptr(scalars) if scalars is not None else None
         buf = dict(buf)
         buf["_keepalive"] = (g, keep, enc)      # the struct holds raw pointers into these
         return p, buf
@@ -194,8 +198,8 @@ class GinEngine:
         if targets is None:
             targets = []
             for _, _, param in plist:
-                if param.grad is None:
-                    param.grad = torch.zeros_like(param)
+                if param.grad is None or (enc.is_padded() and not getattr(param.grad, "_gcc_padded", False)):
+                    param.grad = enc.padded_zeros_like(param)
                 targets.append(param.grad)
         for (name, idx, _), tgt in zip(plist, targets):
             if idx is None:
@@ -223,8 +227,10 @@ class GraphEncoder(nn.Module):
             raise NotImplementedError("gcc_amd accelerates the GIN path only (train.py:77 default)")
         if not degree_input:
             raise NotImplementedError("train.py:617 always passes degree_input=True")
-        if node_hidden_dim != H or output_dim != H:
-            raise NotImplementedError(f"hidden/output size is fixed at {H} (train.py:93 default)")
+        if not (1 <= node_hidden_dim <= H and 1 <= output_dim <= H):
+            # --hidden-size up to 64 runs on the 64-channel kernels, zero-padded and exact (ensure_padded); wider models have
+            # no training kernels here (the 256-wide bf16 stack of gcc_amd/gin_wide.py is inference only)
+            raise NotImplementedError(f"hidden / output size must be between 1 and {H} (got {node_hidden_dim} / {output_dim})")
         node_input_dim = positional_embedding_size + degree_embedding_size + 1      # graph_encoder.py:66-67
         if node_input_dim > H:
             raise NotImplementedError("positional + degree embedding + 1 must be <= 64")
@@ -242,9 +248,85 @@ class GraphEncoder(nn.Module):
         self.lin_readout = nn.Sequential(nn.Linear(2 * node_hidden_dim, node_hidden_dim), nn.ReLU(),
                                          nn.Linear(node_hidden_dim, output_dim))     # :125-129 (unused by GIN)
         self.norm = norm
+        self.hidden, self.output_dim = int(node_hidden_dim), int(output_dim)
+        self._pad_ptrs = {}          # name -> data_ptr of the tensor's padded home (ensure_padded)
         self._engine = None
         self._slot = id(self)
         self._calls = 0
+
+    # ---- hidden / output sizes below 64: the kernels always compute 64 channels.  Every tensor they index by channel
+    # (Linear rows and biases, BatchNorm weight / bias / running statistics, prediction layers) lives as the PREFIX of a
+    # zero-padded block: a [h, k] weight is the first h rows of a [64, k] block, a [h] vector the first h entries of a [64]
+    # block.  A zero channel stays exactly zero through Linear (zero rows, zero bias), BatchNorm (0 * scale + 0), ReLU and
+    # their backward, and Adam never moves a weight whose gradient and value are zero -- so the padded model IS the narrow
+    # model, and state_dict() / load_state_dict() see tensors of the reference's shapes (graph_encoder.py:44-63).
+    def is_padded(self) -> bool:
+        return self.hidden != H or self.output_dim != H
+
+    def _channel_tensors(self):
+        """(name, tensor holder, attribute, is_parameter) of every tensor whose leading dimension is a channel count."""
+        out = []
+        g = self.gnn
+
+        def bn(prefix, m):
+            for a in ("weight", "bias"):
+                out.append((f"{prefix}.{a}", m, a, True))
+            for a in ("running_mean", "running_var"):
+                out.append((f"{prefix}.{a}", m, a, False))
+
+        for i, layer in enumerate(g.ginlayers):
+            mlp = layer.apply_func.mlp
+            for j in (0, 1):
+                out.append((f"gin{i}.lin{j}.weight", mlp.linears[j], "weight", True))
+                out.append((f"gin{i}.lin{j}.bias", mlp.linears[j], "bias", True))
+            bn(f"gin{i}.bn_a", mlp.batch_norms[0])
+            bn(f"gin{i}.bn_b", layer.apply_func.bn)
+            bn(f"gin{i}.bn_c", g.batch_norms[i])
+        for i, lin in enumerate(g.linears_prediction):
+            out.append((f"pred{i}.weight", lin, "weight", True))
+            out.append((f"pred{i}.bias", lin, "bias", True))
+        return out
+
+    def padded_numel(self, t) -> int:
+        """elements of the zero-padded block ``t`` is the prefix of (``t.numel()`` for tensors that are not padded)."""
+        if not self.is_padded() or t.dim() == 0 or t.shape[0] not in (self.hidden, self.output_dim) or t.shape[0] == H:
+            return t.numel()
+        ids = getattr(self, "_chan_ids", None)
+        if ids is None or id(t) not in ids:
+            self._chan_ids = ids = {id(getattr(m, a)) for _, m, a, _ in self._channel_tensors()}
+        return (t.numel() // t.shape[0]) * H if id(t) in ids else t.numel()
+
+    def padded_zeros_like(self, t):
+        """a tensor shaped like ``t`` that is the prefix of a zeroed padded block (gradient targets of the kernels)."""
+        n = self.padded_numel(t)
+        block = torch.zeros(n, dtype=t.dtype, device=t.device)
+        v = block[: t.numel()].view(t.shape)
+        v._gcc_padded = True
+        return v
+
+    def mark_padded(self):
+        """The channel tensors' CURRENT storage is padded (the trainer's flat buffers lay them out that way)."""
+        self._pad_ptrs = {name: getattr(m, a).data_ptr() for name, m, a, _ in self._channel_tensors()}
+
+    def ensure_padded(self):
+        """(Re-)home every channel tensor as the prefix of a zero-padded block.  nn.Module.to() / .cuda() and
+        load-time re-materialisation replace ``.data`` by exactly sized tensors, so this runs before every pass and
+        compares data pointers (a few microseconds; nothing at all for hidden = output = 64)."""
+        if not self.is_padded():
+            return
+        for name, m, a, is_param in self._channel_tensors():
+            t = getattr(m, a)
+            if self._pad_ptrs.get(name) == t.data_ptr():
+                continue
+            n = (t.numel() // t.shape[0]) * H
+            block = torch.zeros(n, dtype=t.dtype, device=t.device)
+            block[: t.numel()].copy_(t.detach().reshape(-1))
+            home = block[: t.numel()].view(t.shape)
+            if is_param:
+                t.data = home
+            else:
+                m._buffers[a] = home
+            self._pad_ptrs[name] = home.data_ptr()
 
     def engine(self) -> GinEngine:
         if self._engine is None:
@@ -258,4 +340,9 @@ class GraphEncoder(nn.Module):
     def forward(self, g, return_all_outputs=False):
         from .autograd import gin_apply
 
-        return gin_apply(self, g, return_all_outputs)
+        out = gin_apply(self, g, return_all_outputs)
+        if not self.is_padded():
+            return out
+        if return_all_outputs:                       # the kernels' 64 channels -> the model's own widths
+            return out[0][:, : self.output_dim], [t[:, : self.hidden] for t in out[1]]
+        return out[:, : self.output_dim]

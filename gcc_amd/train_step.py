@@ -28,17 +28,32 @@ def flatten_parameters(enc: GraphEncoder):
     live = [p for _, _, p in grad_params(enc)]
     live_ids = {id(p) for p in live}
     dead = [p for p in enc.parameters() if id(p) not in live_ids]     # set2set.*, lin_readout.* (unused by GIN)
-    n_live = sum(p.numel() for p in live)
+    # --hidden-size below 64: a channel-indexed parameter is the prefix of a zero-padded block (GraphEncoder.ensure_padded);
+    # the flat buffers hold the BLOCKS, so clip + Adam, the EMA and the gradient all-reduce run over padded storage (the
+    # padding has zero value and zero gradient and stays zero)
+    pn = getattr(enc, "padded_numel", lambda t: t.numel())
+    n_live = sum(pn(p) for p in live)
     total = n_live + sum(p.numel() for p in dead)
     dev = live[0].device
-    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    flat = torch.zeros(total, dtype=torch.float32, device=dev)
     off = 0
     with torch.no_grad():
         for p in live + dead:
             n = p.numel()
             flat[off:off + n].copy_(p.reshape(-1))
             p.data = flat[off:off + n].view_as(p)
-            off += n
+            off += pn(p) if id(p) in live_ids else n
+    if getattr(enc, "is_padded", lambda: False)():
+        # the running statistics (buffers, not parameters) get their padded homes first, then every channel tensor's current
+        # storage -- the parameters' blocks inside ``flat`` included -- is recorded as its padded home
+        enc._pad_ptrs = {}
+        for name, m, a, is_param in enc._channel_tensors():
+            if not is_param:
+                t = getattr(m, a)
+                block = torch.zeros((t.numel() // t.shape[0]) * H, dtype=t.dtype, device=t.device)
+                block[: t.numel()].copy_(t.reshape(-1))
+                m._buffers[a] = block[: t.numel()].view(t.shape)
+        enc.mark_padded()
     enc._flat, enc._n_live = flat, n_live
     return flat, n_live
 
@@ -259,7 +274,7 @@ class FlatAdam:
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=param.device)
         self._scratch = torch.zeros(64, dtype=torch.float64, device=param.device)
 
-    def step(self, grad_scale=1.0, ema=None, ema_src=None, ema_m=0.0, meters=None):
+    def step(self, grad_scale=1.0, ema=None, ema_src=None, ema_m=0.0, meters=None, scalars=None):
         """``grad_scale``: 1 / world when ``grad`` holds the SUM over ranks (folded into the two launches).
         ``ema`` / ``ema_src`` / ``ema_m``: moment_update of the flat EMA buffer from the flat parameter buffer
         (``param`` is its live prefix); ``meters`` = (acc, mx, loss, prob, graph_q, graph_k): one step of the
@@ -267,14 +282,14 @@ class FlatAdam:
         g = self.param_groups[0]
         self.steps += 1
         st = torch.cuda.current_stream(self.param.device).cuda_stream if self.param.is_cuda else None
-        if ema is None and meters is None:
+        if ema is None and meters is None and scalars is None:
             self.engine.adam(self.param, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"], g["eps"],
                              g["weight_decay"], self.steps, self.clip_norm, self.grad_norm, self._scratch, stream=st,
                              grad_scale=grad_scale)
         else:
             self.engine.adam_ema(self.param, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"], g["eps"],
                                  g["weight_decay"], self.steps, self.clip_norm, self.grad_norm, self._scratch, stream=st,
-                                 grad_scale=grad_scale, ema=ema, ema_src=ema_src, ema_m=ema_m, meters=meters)
+                                 grad_scale=grad_scale, ema=ema, ema_src=ema_src, ema_m=ema_m, meters=meters, scalars=scalars)
         return self.grad_norm
 
     def zero_grad(self):
@@ -289,9 +304,11 @@ class MoCoTrainStep:
     def __init__(self, model: GraphEncoder, model_ema: GraphEncoder, contrast: MemoryMoCo, sampler, posemb,
                  learning_rate=0.005, betas=(0.9, 0.999), weight_decay=1e-5, clip_norm=1.0, alpha=0.999,
                  world_size=1, rank=0, prefetch=True, extra_lanes=(), depth=2, lanes=None, chunk=1, reserved_cus=0, cu_layout="interleaved",
-                 collectives=None, ahead=None):
+                 collectives=None, ahead=None, graph=None):
         """``sampler``/``posemb``: producer lane 0; ``extra_lanes``: more (sampler, posemb) pairs with their own
-        workspaces for multi-stream prefetch (see :class:`BatchProducer`)."""
+        workspaces for multi-stream prefetch (see :class:`BatchProducer`).
+        ``graph``: replay the step's ~45 launches as ONE captured hipGraph per ring slot (default: on with prefetch on a
+        device, off with collectives -- see :meth:`_step`)."""
         self.model, self.ema, self.contrast = model, model_ema, contrast
         self.sampler, self.posemb = sampler, posemb
         self.clip_norm, self.alpha = clip_norm, alpha
@@ -305,9 +322,9 @@ class MoCoTrainStep:
         # gradient buffer: views in grad_params order
         self.flat_grad = torch.zeros(self.n_live, dtype=torch.float32, device=self.dev)
         self.grad_views, off = [], 0
-        for _, _, p in grad_params(model):
+        for _, _, p in grad_params(model):                              # (blocks are zero-padded when hidden < 64)
             self.grad_views.append(self.flat_grad[off:off + p.numel()].view_as(p))
-            off += p.numel()
+            off += model.padded_numel(p)
         self.live = self.flat[: self.n_live]
         self.gin = model.engine()
         self.nce = contrast.engine()
@@ -336,6 +353,22 @@ class MoCoTrainStep:
                                       ahead=ahead)
         if not self.prefetch:
             self.producer.cuda = False
+        # ---- hipGraph replay of the step (the step's launches, not the producers')
+        # A step is a FIXED sequence of launches whose arguments depend only on (a) which ring slot holds the batch and
+        # (b) a few scalars: lr, Adam's step count, the queue's ring pointer, the dropout key.  (b) lives in a device
+        # struct (gcc_step_scalars) written by a one-thread launch in front of the replay; for (a) there is one captured
+        # graph per ring slot (lanes x depth x chunk of them), captured right after the slot's first eager step.  What it
+        # buys is HOST time (0.44 ms of Python + ~45 launches per step -> one set_scalars + one graph launch): the stream
+        # itself is as fast either way (tools/graph_probe.py), but the host thread also issues the producer lanes.
+        self.use_scalars = False            # kernels read lr / ring pointer / dropout key from self.scalars (tests: eager)
+        self.use_graph = bool(self.prefetch and not self.collectives) if graph is None else bool(graph)
+        if self.use_graph and (self.dev.type != "cuda" or self.collectives):
+            raise ValueError("graph replay needs a device and no collectives inside the step")
+        if self.use_graph and self.main is None:
+            self.main = torch.cuda.Stream(self.dev, priority=-1)        # stream capture cannot run on the default stream
+        self.scalars = torch.zeros(24, dtype=torch.uint8, device=self.dev)      # sizeof(gcc_step_scalars)
+        self.graphs = {}                    # ring-slot key -> (CUDAGraph, outs of the captured step)
+        self.graph_replays = 0
         model.train()                                                    # train.py:357-365
         model_ema.eval()
         for mod in model_ema.modules():
@@ -421,6 +454,10 @@ class MoCoTrainStep:
         caller.wait_stream(self.main)
         return out
 
+    def _slot_key(self, q, k):
+        return tuple(t.data_ptr() for g in (q, k) for t in (g.node_off, g.edge_off, g.row_ptr, g.col_idx, g.graph_id,
+                                                            g.pos_undirected))
+
     def _step(self, step, lr, prof=None):
         pr = prof or {}
         q, k = self.producer.get(step, prof=prof)
@@ -428,36 +465,74 @@ class MoCoTrainStep:
         p_drop = self.model.gnn.drop.p
         keep = self.mask_fn() if self.mask_fn is not None else None
         seed = (self.dropout_seed + step * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF if p_drop > 0 else None
-        pq, bufq = self.gin.make_pass(self.model, q, training=True, keep=keep, slot=("step", 0), dropout_seed=seed)
+        c = self.contrast
+        for grp in self.optimizer.param_groups:                          # train.py:411-416
+            grp["lr"] = lr
+        step_marks = any(n in pr for n in ("gin_fwd", "nce_fwd", "nce_bwd", "gin_bwd"))
+        graphed = self.use_graph and keep is None and not step_marks
+        scalars = self.scalars if (graphed or self.use_scalars) and keep is None else None
+        if scalars is not None:
+            g0 = self.optimizer.param_groups[0]
+            self.nce.set_scalars(scalars, lr, g0["betas"], self.optimizer.steps + 1, c.index, seed or 0, stream=st)
+        out = None
+        if graphed:
+            key = self._slot_key(q, k)
+            hit = self.graphs.get(key)
+            if hit is not None:                                          # replay: one launch for the whole step
+                hit[0].replay()
+                self.optimizer.steps += 1
+                self.graph_replays += 1
+                out = dict(hit[1], graph_q=q, graph_k=k)
+            else:
+                # first time this ring slot is consumed: run it eagerly (same kernels, scalars from the device struct) and
+                # capture the slot's graph afterwards -- capture records the launches without executing them
+                out = self._body(q, k, keep, seed, scalars, pr, st)
+                gobj = torch.cuda.CUDAGraph()
+                steps0 = self.optimizer.steps
+                gobj.capture_begin(capture_error_mode="thread_local")
+                try:
+                    cap = self._body(q, k, None, seed, scalars, {}, st)
+                finally:
+                    gobj.capture_end()
+                self.optimizer.steps = steps0                            # the captured body counted a step that did not run
+                self.graphs[key] = (gobj, dict(loss=cap["loss"], prob=cap["prob"], grad_norm=cap["grad_norm"]))
+        else:
+            out = self._body(q, k, keep, seed, scalars, pr, st)
+        c.index = (c.index + self.B * (self.world if self.collectives else 1)) % c.queueSize
+        self.producer.release(step)
+        return out
+
+    def _body(self, q, k, keep, seed, scalars, pr, st):
+        """The launches of one step on the current stream (eager, or under stream capture).  ``scalars``: device
+        gcc_step_scalars the Adam / enqueue / dropout kernels read instead of by-value arguments."""
+        pq, bufq = self.gin.make_pass(self.model, q, training=True, keep=keep, slot=("step", 0), dropout_seed=seed,
+                                      scalars=scalars)
         pk, bufk = self.gin.make_pass(self.ema, k, training=True, keep=None, slot=("step", 1))
         self.gin.forward([pq, pk], stream=st, prof=pr.get("gin_fwd"))      # train.py:389-391
         feat_q, feat_k = bufq["feat"], bufk["feat"]
         c = self.contrast
         gathering = self._all_gather_begin(self.keys_all, feat_k) if self.collectives else None   # RCCL, overlapped
-        outs = self.nce.forward(feat_q, feat_k, c.memory, c.T, 0, stream=st, prof=pr.get("nce_fwd"))   # train.py:393,407
+        outs = self.nce.forward(feat_q, feat_k, c.kernel_memory(), c.T, 0, stream=st, prof=pr.get("nce_fwd"))   # train.py:393,407
         # The enqueue (memory_moco.py:55-61) is the LAST thing the step does with the queue: logits and their backward
         # are taken against the queue before the update (the reference clones it, memory_moco.py:31), so deferring the
         # update is the same computation -- and it takes the key all-gather off the critical chain.
-        dq = self.nce.backward(feat_q, feat_k, c.memory, c.T, 0, outs, self.one, stream=st,
+        dq = self.nce.backward(feat_q, feat_k, c.kernel_memory(), c.T, 0, outs, self.one, stream=st,
                                prof=pr.get("nce_bwd"))                    # loss.backward(), train.py:408
         self.gin.backward(self.model, pq, bufq, dq, targets=self.grad_views, stream=st, prof=pr.get("gin_bwd"))
         if self.collectives:
             self._all_reduce(self.flat_grad)                             # SUM of one flat bucket (248 KiB) over xGMI
-        for grp in self.optimizer.param_groups:                          # train.py:411-416
-            grp["lr"] = lr
         # clip (train.py:409) + Adam (train.py:417); the mean over ranks is folded into the two launches
         # ... moment_update (train.py:430-431) and train.py:418-428's meters ride in the Adam launch: the meters read
-        # this batch's offsets BEFORE its ring slot is handed back below
+        # this batch's offsets BEFORE its ring slot is handed back
         gnorm = self.optimizer.step(grad_scale=1.0 / self.world if self.collectives else 1.0,
                                     ema=self.flat_ema, ema_src=self.flat, ema_m=self.alpha,
-                                    meters=(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], q, k))
+                                    meters=(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], q, k),
+                                    scalars=scalars)
         keys = feat_k
         if self.collectives:
             self._all_gather_end(gathering)
             keys = self.keys_all
-        self.nce.enqueue(c.memory, keys, c.index, save=False, stream=st)
-        c.index = (c.index + keys.shape[0]) % c.queueSize
-        self.producer.release(step)
+        self.nce.enqueue(c.kernel_memory(), keys, c.index, save=False, stream=st, scalars=scalars)
         return dict(loss=outs["loss"], prob=outs["prob"], grad_norm=gnorm, graph_q=q, graph_k=k)
 
 
@@ -481,7 +556,7 @@ class E2ETrainStep:
         self.grad_views, off = [], 0
         for _, _, p in grad_params(model):
             self.grad_views.append(self.flat_grad[off:off + p.numel()].view_as(p))
-            off += p.numel()
+            off += model.padded_numel(p)
         self.live = self.flat[: self.n_live]
         self.gin = model.engine()
         self.nce = engine if engine is not None else NceEngine()

@@ -213,8 +213,9 @@ void gcc_gin_debug_ticks(long long *device_ticks64);
  * GraphEncoder(gnn_model="gin", degree_input=True).forward of
  * gcc/models/graph_encoder.py:132-200 -> UnsupervisedGIN.forward gcc/models/gin.py:213-232
  * (DGL GINConv(sum, eps=0) + ApplyNodeFunc/MLP + BatchNorm1d + SumPooling +
- * linears_prediction + Dropout + F.normalize), and its backward.  hidden is
- * fixed at 64 (train.py:93 default); d_in = pos_dim + deg_emb_dim + 1 <= 64.
+ * linears_prediction + Dropout + F.normalize), and its backward.  The kernels
+ * compute 64 channels (train.py:93 default); narrower models (gcc_gin_weights.hidden)
+ * run zero-padded, exactly; d_in = pos_dim + deg_emb_dim + 1 <= 64.
  * All arithmetic is fp32 (f32 MFMA), BatchNorm / pooling sums accumulate in fp64. */
 #define GCC_GIN_MAX_LAYERS 8     /* GIN message-passing layers = num_layers - 1 (train.py:79 -> 4) */
 #define GCC_GIN_HIDDEN 64
@@ -242,7 +243,26 @@ typedef struct gcc_gin_weights { /* state_dict of the reference GraphEncoder (SU
     float bn_eps, bn_momentum;   /* 1e-5, 0.1 (torch defaults, gin.py:51,104,189)          */
     float dropout_p;             /* 0.5 (graph_encoder.py:99)                              */
     float norm_eps;              /* 1e-5 (graph_encoder.py:196)                            */
+    int32_t hidden;              /* --hidden-size (train.py:93) when it is below 64, 0 = 64: the COLUMN count of every weight
+                                  * that reads a hidden representation (lin0_w of layers > 0, lin1_w, pred_w[i > 0]); the
+                                  * kernels always compute 64 channels, so every weight keeps 64 ROWS and every per-channel
+                                  * array 64 entries -- rows / entries >= hidden are zero padding owned by the caller (a zero
+                                  * channel stays exactly zero through Linear, BatchNorm, ReLU and their backward, so the
+                                  * padded model IS the narrow model).  Gradients come back in the same padded shapes. */
 } gcc_gin_weights;
+
+/* DEVICE-resident per-step scalars of a REPLAYED step.  A training step captured in a hipGraph replays the same
+ * kernel arguments every time; what changes from step to step besides the data -- the learning rate (train.py:411-416),
+ * Adam's bias corrections, the queue's ring pointer (memory_moco.py:55-61), the dropout key -- is read from this struct
+ * by the kernels that need it (pass it where the `scalars` arguments below say; NULL = the by-value arguments), and
+ * written by gcc_step_scalars_set, a one-thread launch issued in front of the replay. */
+typedef struct gcc_step_scalars {
+    float lr, bias_corr1, bias_corr2_sqrt;   /* Adam: lr, 1 - beta1^step, sqrt(1 - beta2^step) */
+    int32_t enqueue_index;                   /* queue rows [index, index + nkeys) mod K are overwritten */
+    uint64_t dropout_seed;                   /* Philox key of the pass's dropout masks (gcc_gin_pass.dropout_seed) */
+} gcc_step_scalars;
+int32_t gcc_step_scalars_set(gcc_step_scalars *dev, float lr, float beta1, float beta2, int32_t adam_step,
+                             int32_t enqueue_index, uint64_t dropout_seed, void *stream);
 
 typedef struct gcc_gin_pass {    /* one encoder invocation on one batched graph            */
     const int32_t *node_off, *row_ptr, *col_idx, *graph_id;   /* gcc_batch_out of the view */
@@ -275,6 +295,8 @@ typedef struct gcc_gin_pass {    /* one encoder invocation on one batched graph 
     const int32_t *seed_local;   /* device [B] or NULL: local index of the seed node of every graph (NULL: node 0, as the
                                   * sampler emits; graph classification marks g.out_degrees().argmax(),
                                   * data_util.py:236-237 with entire_graph=True) */
+    const gcc_step_scalars *scalars;   /* device or NULL: with dropout_philox, the key is scalars->dropout_seed (read by the
+                                        * readout kernels of the forward AND the backward pass) instead of dropout_seed */
 } gcc_gin_pass;
 
 /* Runs `npass` independent passes (e.g. query with model, key with model_ema)
@@ -426,6 +448,14 @@ int32_t gcc_adam_ema_step(float *param, float *grad, float *exp_avg, float *exp_
                           float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
                           float grad_scale, float *grad_norm, double *scratch, float *ema, int64_t n_ema, float ema_m,
                           const gcc_step_meters_args *meters, void *stream);
+/* The same two launches and gcc_queue_enqueue with lr / bias corrections / ring pointer taken from a device-resident
+ * gcc_step_scalars (a step captured in a hipGraph: see above).  Same results as the by-value calls. */
+int32_t gcc_adam_ema_step_scalars(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                  float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                                  float grad_scale, float *grad_norm, double *scratch, float *ema, int64_t n_ema, float ema_m,
+                                  const gcc_step_meters_args *meters, const gcc_step_scalars *scalars, void *stream);
+int32_t gcc_queue_enqueue_scalars(float *mem, int32_t K, const float *keys, int32_t nkeys,
+                                  const gcc_step_scalars *scalars, void *stream);
 
 #ifdef __cplusplus
 }

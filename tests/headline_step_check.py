@@ -29,9 +29,16 @@ def _state(mod):
 
 
 def _feat(tr, slot, g):
+    """the pass's output embeddings (the kernels' 64 channels cut to the model's output width)"""
     node_cap = g.parent_nid.numel() if hasattr(g, "parent_nid") else g.graph_id.numel()
-    return tr.gin._buffers(slot, node_cap, g.batch_size, tr.L if hasattr(tr, "L") else len(tr.model.gnn.ginlayers),
-                           g.node_off.device)["feat"]
+    f = tr.gin._buffers(slot, node_cap, g.batch_size, tr.L if hasattr(tr, "L") else len(tr.model.gnn.ginlayers),
+                        g.node_off.device)["feat"]
+    assert float(f[:, tr.model.output_dim:].abs().sum()) == 0.0          # padding channels stay exactly zero
+    return f[:, : tr.model.output_dim]
+
+
+def _oracle_for(model):
+    return E.OracleGraphEncoder(node_hidden_dim=model.hidden, output_dim=model.output_dim)
 
 
 def _cmp_grads_and_update(model, flat_grad, oracle, init, after, report, truth=None, coef=1.0):
@@ -51,16 +58,19 @@ def _cmp_grads_and_update(model, flat_grad, oracle, init, after, report, truth=N
     for _, _, p in grad_params(model):
         n = names[id(p)]
         got = flat_grad[off:off + p.numel()].view_as(p)
-        off += p.numel()
+        pad = flat_grad[off + p.numel():off + model.padded_numel(p)]
+        assert float(pad.abs().sum()) == 0.0, n                           # (hidden < 64: the padding's gradient is exactly zero)
+        off += model.padded_numel(p)
         gref = ref[n].grad
         scale = max(float(gref.abs().max()), 1e-3)
         noise = 1e-4 if (".mlp.linears." in n and n.endswith(".bias")) else 0.0    # exactly-zero true gradient: rounding noise on both sides
         err32 = 0.0
         if ref64 is not None:
-            # (i) the bar proper: against the oracle in float64 (exact arithmetic for this purpose) at 2e-4 of the tensor's
-            # largest entry -- five times inside north_star's 1e-3
+            # (i) the bar proper: against the oracle in float64 (exact arithmetic for this purpose) at north_star's 1e-3 of the
+            # tensor's largest entry (measured at C2 size: 5e-5 in the MoCo step, 6e-4 in the E2E step, whose two passes'
+            # gradients largely cancel and are added up in fp32)
             g64 = (ref64[n].grad * coef).float()
-            torch.testing.assert_close(got, g64, rtol=1e-3, atol=max(2e-4 * scale, 1e-6, noise),
+            torch.testing.assert_close(got, g64, rtol=1e-3, atol=max(1e-3 * scale, 1e-6, noise),
                                        msg=lambda m, n=n: f"grad {n} vs float64 oracle: {m}")
             err32 = float((gref - g64).abs().max())
             w_dev = max(w_dev, float((got - g64).abs().max()) / scale)
@@ -95,12 +105,12 @@ def _seed_adam(opt, oracle, model, tr, exp_avg, exp_avg_sq, steps):
         t = ref[names[id(p)]]
         opt.state[t] = dict(step=torch.tensor(float(steps)), exp_avg=exp_avg[off:off + p.numel()].view_as(p).clone(),
                             exp_avg_sq=exp_avg_sq[off:off + p.numel()].view_as(p).clone())
-        off += p.numel()
+        off += model.padded_numel(p)
 
 
-def _truth64(init, args, pos, masks, tail):
+def _truth64(init, args, pos, masks, tail, model=None):
     """the oracle in float64 on the same inputs -> module with .grad populated by ``tail(feat) -> loss``"""
-    om = E.OracleGraphEncoder().double()
+    om = (_oracle_for(model) if model is not None else E.OracleGraphEncoder()).double()
     om.load_state_dict({k: (v.double() if v.dtype.is_floating_point else v) for k, v in init.items()})
     om.train()
     f = om(*args, pos.double(), dropout_masks=masks.double() if masks is not None else None)
@@ -122,12 +132,13 @@ def check_moco_step(tr, model, ema, contrast, lr, masks, sync=lambda: None, step
     report = dict(batch_size=B, K=K, nodes_q=int(aq[0][-1]), nodes_k=int(ak[0][-1]), edges_q=len(aq[2]), edges_k=len(ak[2]))
     report["_graphs"] = (gq, gk)                 # for the caller's sampler check; not serialisable
     # ---- oracle on the same inputs
-    om, oe = E.OracleGraphEncoder(), E.OracleGraphEncoder()
+    om, oe = _oracle_for(model), _oracle_for(model)
     om.load_state_dict(init_m)
     oe.load_state_dict(init_e)
     om.train()
     oe.train()                                   # train.py:357-365: eval() + BatchNorm back to train(); dropout stays off
-    rq = om(*aq, pos_q, dropout_masks=masks.cpu())
+    omask = masks.cpu()[:, :, : model.output_dim]   # (the kernels take 64-channel masks; the model's own channels matter)
+    rq = om(*aq, pos_q, dropout_masks=omask)
     with torch.no_grad():
         rk = oe(*ak, pos_k)
     ref_mem = mem0.clone()
@@ -142,7 +153,7 @@ def check_moco_step(tr, model, ema, contrast, lr, masks, sync=lambda: None, step
     opt.step()
     E.moment_update(om, oe, alpha)                                                          # train.py:430-431
     # float64 run of the same oracle: who is closer to exact arithmetic, the device or the fp32 oracle?
-    o64, f64 = _truth64(init_m, aq, pos_q, masks.cpu(), None)
+    o64, f64 = _truth64(init_m, aq, pos_q, omask, None, model=model)
     out64, _ = E.moco_forward(mem0.double(), index0, f64, rk.detach().double(), T)
     E.nce_softmax_loss(out64).backward()
     coef = min(1.0, tr.clip_norm / (float(rgn.detach()) + 1e-6)) if tr.clip_norm > 0 else 1.0
@@ -197,11 +208,12 @@ def check_e2e_step(tr, model, lr, masks_q, masks_k, sync=lambda: None, step_id=0
     gq, gk = out["graph_q"], out["graph_k"]
     (aq, pos_q), (ak, pos_k) = view_arrays(gq), view_arrays(gk)
     report = dict(batch_size=B, nodes_q=int(aq[0][-1]), nodes_k=int(ak[0][-1]))
-    om = E.OracleGraphEncoder()
+    om = _oracle_for(model)
     om.load_state_dict(init_m)
     om.train()
-    rq = om(*aq, pos_q, dropout_masks=masks_q.cpu())                                      # train.py:397
-    rk = om(*ak, pos_k, dropout_masks=masks_k.cpu())                                      # train.py:398
+    oq, ok = masks_q.cpu()[:, :, : model.output_dim], masks_k.cpu()[:, :, : model.output_dim]
+    rq = om(*aq, pos_q, dropout_masks=oq)                                                  # train.py:397
+    rk = om(*ak, pos_k, dropout_masks=ok)                                                  # train.py:398
     rout = rk @ rq.t() / T                                                                 # train.py:400
     rloss = E.nce_softmax_loss_ns(rout)
     rprob = rout.diagonal().mean().detach()                                                # train.py:401
@@ -211,11 +223,11 @@ def check_e2e_step(tr, model, lr, masks_q, masks_k, sync=lambda: None, step_id=0
     rloss.backward()
     rgn = torch.nn.utils.clip_grad_norm_(om.parameters(), tr.clip_norm)
     opt.step()
-    o64 = E.OracleGraphEncoder().double()
+    o64 = _oracle_for(model).double()
     o64.load_state_dict({k: (v.double() if v.dtype.is_floating_point else v) for k, v in init_m.items()})
     o64.train()
-    q64 = o64(*aq, pos_q.double(), dropout_masks=masks_q.cpu().double())
-    k64 = o64(*ak, pos_k.double(), dropout_masks=masks_k.cpu().double())
+    q64 = o64(*aq, pos_q.double(), dropout_masks=oq.double())
+    k64 = o64(*ak, pos_k.double(), dropout_masks=ok.double())
     E.nce_softmax_loss_ns(k64 @ q64.t() / T).backward()
     coef = min(1.0, tr.clip_norm / (float(rgn.detach()) + 1e-6)) if tr.clip_norm > 0 else 1.0
     feat_q, feat_k = _feat(tr, ("e2e", 0), gq).cpu(), _feat(tr, ("e2e", 1), gk).cpu()

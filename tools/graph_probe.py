@@ -75,6 +75,25 @@ host = (time.perf_counter() - t0) / burst * 1e3
 torch.cuda.synchronize()
 print(f"host time to issue one step (Python + {burst}-step burst, no synchronisation): {host:.3f} ms")
 
+# the SHIPPED graph path (MoCoTrainStep(graph=True): per-slot capture, device-resident scalars written by a one-thread launch
+# in front of every replay): host time to issue a step, and the stream's time per step
+tg = MoCoTrainStep(model, ema, contrast, Fixed(), posemb=lambda g, prof=None: g, prefetch=False, graph=True)
+for i in range(4):
+    tg.step(30000 + i, 0.005)
+torch.cuda.synchronize()
+assert tg.graph_replays >= 2, tg.graph_replays
+t0 = time.perf_counter()
+for i in range(burst):
+    tg.step(31000 + i, 0.005)
+host_g = (time.perf_counter() - t0) / burst * 1e3
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(a.steps):
+    tg.step(32000 + i, 0.005)
+torch.cuda.synchronize()
+shipped = (time.perf_counter() - t0) / a.steps * 1e3
+print(f"shipped graph path (MoCoTrainStep graph=True): host time to issue one step {host_g:.3f} ms; {shipped:.3f} ms/step on the stream")
+
 side = torch.cuda.Stream(dev)
 g = torch.cuda.CUDAGraph()
 with torch.cuda.stream(side):
