@@ -214,6 +214,10 @@ SIGNATURES = {
                                                    ctypes.POINTER(GccStepMetersArgs), ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_queue_enqueue_scalars": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                                    ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_gin_eval_fused": (ctypes.c_int32, [ctypes.POINTER(GccGinPass), ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_step_scalars_fill": (None, [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int32,
+                                      ctypes.c_int32, ctypes.c_uint64]),
+    "gcc_step_scalars_fetch": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_step_scalars_set": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int32,
                                               ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p]),
     "gcc_step_meters": (ctypes.c_int32, [ctypes.c_void_p] * 8 + [ctypes.c_int32, ctypes.c_void_p]),

@@ -22,7 +22,10 @@ class _GinFn(torch.autograd.Function):
         enc._calls += 1
         slot = (enc._slot, enc._calls % 2)          # two passes may be in flight (E2E: model(q), model(k))
         p, buf = eng.make_pass(enc, g, training=bn_training, keep=keep, slot=slot)
-        eng.forward([p], stream=_stream(g.node_off))
+        if not bn_training and getattr(enc, "fused_eval", True):
+            eng.eval_fused([p], stream=_stream(g.node_off))     # eval mode: one launch, one workgroup per subgraph
+        else:
+            eng.forward([p], stream=_stream(g.node_off))
         ctx.enc, ctx.p, ctx.buf = enc, p, buf
         L = len(enc.gnn.ginlayers)
         outs = [buf["feat"].clone()] + [buf["pooled"][i + 1].float() for i in range(L)]

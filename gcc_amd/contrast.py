@@ -85,6 +85,17 @@ class NceEngine:
         if rc != 0:
             raise RuntimeError(f"gcc_step_scalars_set failed ({rc}): {self.lib.gcc_last_error().decode()}")
 
+    def fill_scalars(self, ring, slot, lr, betas, adam_step, enqueue_index, dropout_seed):
+        """gcc_step_scalars_fill: entry ``slot`` of the host-pinned ring (a CPU uint8 tensor), no device work."""
+        self.lib.gcc_step_scalars_fill(ring.data_ptr() + 24 * int(slot), float(lr), float(betas[0]), float(betas[1]),
+                                       int(adam_step), int(enqueue_index), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF)
+
+    def fetch_scalars(self, scalars, ring, ring_len, counter, stream=None):
+        """gcc_step_scalars_fetch: the step's first launch (captured with it): ring[counter % ring_len] -> device struct."""
+        rc = self.lib.gcc_step_scalars_fetch(self.ptr(scalars), ring.data_ptr(), int(ring_len), self.ptr(counter), stream)
+        if rc != 0:
+            raise RuntimeError(f"gcc_step_scalars_fetch failed ({rc}): {self.lib.gcc_last_error().decode()}")
+
     def enqueue(self, mem, keys, index, save=True, stream=None, scalars=None):
         if scalars is not None:                      # ring pointer from the device struct (replayed step); no saved rows
             rc = self.lib.gcc_queue_enqueue_scalars(self.ptr(mem), mem.shape[0], self.ptr(keys), keys.shape[0],

@@ -17,6 +17,7 @@ static inline void device_fence() {}
 static inline float load_fresh(const float *p) { return *p; }
 static inline double load_fresh_f64(const double *p) { return *p; }
 static inline int load_fresh_i32(const int *p) { return *p; }
+static inline uint32_t load_system_u32(const uint32_t *p) { return *p; }
 #include "hipemu.h"
 
 #define DYN_SMEM(name) unsigned char *name = hipemu::g_dyn_smem
@@ -192,6 +193,8 @@ __device__ __forceinline__ void lds_barrier()
 __device__ __forceinline__ float load_fresh(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double load_fresh_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int load_fresh_i32(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// host-written (pinned, device-visible) memory: never from a cache line of an earlier launch
+__device__ __forceinline__ uint32_t load_system_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 #define DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -1,0 +1,312 @@
+// gcc_amd/csrc/encoder_eval.hip -- the eval-mode GIN encoder of generate.py as ONE launch: SURVEY.md 8(f)#2's
+// "per-subgraph LDS-resident megakernel".  Reference: generate.py:33-53 (test_moco: model.eval(), feat_q = model(graph_q),
+// feat_k = model(graph_k), emb = (feat_q + feat_k) / 2) -> GraphEncoder.forward gcc/models/graph_encoder.py:132-200 ->
+// UnsupervisedGIN.forward gcc/models/gin.py:213-232 with every BatchNorm on its running statistics (gin.py:54-58,113-116).
+//
+// In eval mode nothing couples two subgraphs of a batch (training-mode BatchNorm did: 12 batch-wide statistics per pass
+// are why gcc_gin_forward is a chain of 15 launches), so one workgroup takes ONE subgraph through feature assembly, all
+// GIN layers, the pooled readout and F.normalize:
+//   * the subgraph's hidden representation [n, 64] f32 lives in LDS (n <= kEvalCap rows; larger ego-nets -- ~2 % at
+//     rw_hops 256 -- gather from the L2-resident global copy instead, same code);
+//   * a layer walks the subgraph's 64-row tiles: own rows + neighbour sum (gather_tile of encoder_common.h: the tile's
+//     EDGES split over the 16 lane groups, fixed summation order) -> linears.0 on the exact-f32 MFMA -> BatchNorm affine +
+//     ReLU in registers (the MFMA's output layout IS the next product's input layout) -> linears.1 -> two more affines ->
+//     the new rows go to a global ping-pong buffer and are mirrored into LDS after the layer's last tile;
+//   * SumPooling of every hidden_rep in fp64, the five prediction layers, normalisation, and -- with two passes in the
+//     launch -- mean_out[b] += feat / 2, i.e. generate.py:52's (feat_q + feat_k) / 2.
+// Same arithmetic as gcc_gin_forward with training = 0 (same affine tables, same MFMA sequences; the gather's summation
+// order differs because tiles start at the subgraph, not at multiples of 64 of the batch): agreement ~1e-6.
+#include "encoder_common.h"
+
+namespace {
+
+constexpr int kEvalCap = 256;            // rows of a subgraph kept in LDS
+constexpr int kEvalLd = 68;              // floats per LDS row (272 B: 16-byte aligned, rows 8 apart share a bank group)
+
+struct EvalLayer {
+    const float *w0, *b0, *w1, *b1;
+    const float *bn_w[3], *bn_b[3], *bn_rm[3], *bn_rv[3];     // mlp.batch_norms.0, apply_func.bn, gnn.batch_norms.i
+};
+struct EvalArgs {
+    const int32_t *node_off, *row_ptr, *col_idx, *seed_local;
+    const float *pos, *emb;
+    float *g0, *g1;                      // global ping-pong [node_cap][64] (the pass's z1[0] / z2[0] buffers)
+    double *pooled;                      // [L + 1][B][64] or NULL
+    float *score, *feat;                 // [B][64]
+    float *mean_out;                     // [B][64] or NULL: += mean_w * feat (zeroed by the host side of the call)
+    float mean_w;
+    EvalLayer layer[GCC_GIN_MAX_LAYERS];
+    const float *pred_w[GCC_GIN_MAX_LAYERS + 1], *pred_b[GCC_GIN_MAX_LAYERS + 1];
+    int32_t B, L, pos_dim, emb_dim, max_degree, mult, normalize, hid, kdim0;
+    float eps, norm_eps;
+};
+struct EvalLaunch { EvalArgs p[kMaxPass]; };
+
+constexpr int kEvalLds = (kEvalCap * kEvalLd + kTile * kLdt + 2 * H * kLdt + 32 * H + 6 * H + 2 * H) * 4   // A, T, Wl0, Wl1, part, tables, biases
+                         + (GCC_GIN_MAX_LAYERS + 1) * H * 8 + 4 * H * 8                                      // pooled sums (fp64) + their partials
+                         + (kTile + 1 + 32 + 3) / 4 * 16;                                                    // rpl, prow
+
+__global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
+{
+    DYN_SMEM(smem);
+    const EvalArgs &a = Ln.p[blockIdx.y];
+    float *A = (float *)smem;                                   // [kEvalCap][kEvalLd]
+    float *T = A + kEvalCap * kEvalLd;                          // [kTile][kLdt]
+    float *Wl0 = T + kTile * kLdt, *Wl1 = Wl0 + H * kLdt;       // staged Linear weights of the current layer
+    float *part = Wl1 + H * kLdt;                               // [32 * H] side slots of gather_tile
+    float *tab = part + 32 * H;                                 // [3][2][64] scale / shift of the layer's three BatchNorms
+    float *bias = tab + 6 * H;                                  // [2][64]
+    double *pool = (double *)(bias + 2 * H);                    // [L + 1][64]
+    double *ppart = pool + (GCC_GIN_MAX_LAYERS + 1) * H;        // [4][64]
+    int *rpl = (int *)(ppart + 4 * H);                          // [kTile + 1]
+    int *prow = rpl + kTile + 1;                                // [32]
+
+    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
+    const int b = (int)blockIdx.x;
+    const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+    const bool in_lds = n <= kEvalCap;                           // (workgroup-uniform)
+    const int L = a.L;
+    // (an empty padding graph has no rows: its pooled sums are zero and its score is the sum of the prediction biases, as in
+    //  the reference and in gcc_gin_forward)
+    float *cur = a.g0, *nxt = a.g1;
+
+    // ---- hidden_rep[0]: input features (graph_encoder.py:158-165) -> cur (global) and A (LDS mirror)
+    {
+        const int dtot = a.pos_dim + a.emb_dim;
+        const int sl = a.seed_local ? a.seed_local[b] : 0;
+        for (int r = gi; r < n; r += 16) {
+            const int v = n0 + r;
+            const int deg = (a.row_ptr[v + 1] - a.row_ptr[v]) * a.mult;          // g.in_degrees(), :154
+            const int dcl = deg < a.max_degree ? deg : a.max_degree;             // clamp(0, max_degree), :161
+            F4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * t + e;
+                const float *src = c < a.pos_dim ? a.pos + (int64_t)v * a.pos_dim + c
+                                                 : a.emb + (int64_t)dcl * a.emb_dim + (c < dtot ? c - a.pos_dim : 0);
+                const float val = *src;
+                at(x, e) = c < dtot ? val : (c == dtot && r == sl ? 1.f : 0.f);   // ndata["seed"], data_util.py:234-238
+            }
+            st4(cur + (int64_t)v * H + 4 * t, x);
+            if (in_lds) st4(&A[r * kEvalLd + 4 * t], x);
+        }
+    }
+    device_fence();
+    __syncthreads();
+
+    // SumPooling of the current representation (gin.py:228) into pool[i] (fp64, fixed order)
+    auto pool_rows = [&](int i) {
+        const int c = tid & 63, pt = tid >> 6;
+        double acc = 0.0;
+        if (in_lds) for (int r = pt; r < n; r += 4) acc += (double)A[r * kEvalLd + c];
+        else for (int r = pt; r < n; r += 4) acc += (double)load_fresh(cur + (int64_t)(n0 + r) * H + c);
+        ppart[pt * H + c] = acc;
+        __syncthreads();
+        if (tid < H) pool[i * H + tid] = (ppart[tid] + ppart[H + tid]) + (ppart[2 * H + tid] + ppart[3 * H + tid]);
+        __syncthreads();
+    };
+    pool_rows(0);
+    if (n <= 0)                                                   // (workgroup-uniform)
+        for (int i = tid; i < L * H; i += kThreads) pool[H + i] = 0.0;
+    __syncthreads();
+
+    for (int l = 0; l < (n > 0 ? L : 0); ++l) {
+        const EvalLayer &ly = a.layer[l];
+        const int kd = l == 0 ? a.kdim0 : a.hid;
+        // ---- this layer's weights, biases and BatchNorm affines (running statistics: gin.py's modules in eval())
+        {
+            const WStage s0 = stage_weights_request(ly.w0, kd), s1 = stage_weights_request(ly.w1, a.hid);
+            const int c = tid & 63, which = tid >> 6;            // which < 3: a BatchNorm; 3: the two biases
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            if (which < 3) { v0 = ly.bn_w[which][c]; v1 = ly.bn_b[which][c]; v2 = ly.bn_rm[which][c]; v3 = ly.bn_rv[which][c]; }
+            else { v0 = ly.b0 ? ly.b0[c] : 0.f; v1 = ly.b1 ? ly.b1[c] : 0.f; }
+            stage_weights_store(Wl0, s0, kd);
+            stage_weights_store(Wl1, s1, a.hid);
+            if (which < 3) {                                     // bn_scale_shift_from(training = 0), encoder_common.h
+                const double rstd = 1.0 / sqrt((double)v3 + (double)a.eps);
+                tab[which * 2 * H + c] = (float)((double)v0 * rstd);
+                tab[which * 2 * H + H + c] = (float)((double)v1 - (double)v2 * (double)v0 * rstd);
+            } else {
+                bias[c] = v0;
+                bias[H + c] = v1;
+            }
+        }
+        __syncthreads();
+        const float *src = cur;
+        auto load = [&](int u) -> F4 {                           // row u (batched id) of the current representation
+            return in_lds ? ld4(&A[(u - n0) * kEvalLd + 4 * t]) : ld4(src + (int64_t)u * H + 4 * t);
+        };
+        auto ident = [&](F4 x) -> F4 { return x; };
+        for (int tile0 = 0; tile0 < n; tile0 += kTile) {
+            const int nrows = min(kTile, n - tile0);
+            // 1. own rows + the tile's row pointers
+            {
+                const int rp_own = a.row_ptr[n0 + tile0 + min(tid, nrows)];
+                F4 own[kTile / 16];
+#pragma unroll
+                for (int i = 0; i < kTile / 16; ++i) own[i] = load(n0 + min(tile0 + gi + 16 * i, n - 1));
+                if (tid <= nrows) rpl[tid] = rp_own;
+#pragma unroll
+                for (int i = 0; i < kTile / 16; ++i) {
+                    const int r = gi + 16 * i;
+                    const F4 z = {0.f, 0.f, 0.f, 0.f};
+                    st4(&T[r * kLdt + 4 * t], r < nrows ? own[i] : z);
+                }
+            }
+            __syncthreads();
+            // 2. GINConv aggregate: h_v + sum_{u -> v} h_u (eps = 0; gin.py:179-185,218); every CSR edge counts `mult` times
+            gather_tile<8>(T, part, prow, nrows, a.col_idx, load, ident, (float)a.mult, rpl);
+            // 3. the MLP and the three BatchNorm / ReLU stages on the wave's 16 rows, in registers
+            {
+                const int j = lane & 15, q = lane >> 4, rl = 16 * wv + j;
+                F4 xb[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xb[c] = ld4(&T[rl * kLdt + 16 * c + 4 * q]);
+                F4 y[4];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {                 // z1 = agg W0^T + b0; relu(bn_a(z1))  (gin.py:113-116)
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const F4 wf = ld4(&Wl0[(16 * cb + j) * kLdt + 16 * c + 4 * q]);
+                        acc = mfma_16x16x4_f32(wf.x, xb[c].x, acc);
+                        acc = mfma_16x16x4_f32(wf.y, xb[c].y, acc);
+                        acc = mfma_16x16x4_f32(wf.z, xb[c].z, acc);
+                        acc = mfma_16x16x4_f32(wf.w, xb[c].w, acc);
+                    }
+                    const int ch = 16 * cb + 4 * q;
+                    const F4 b4 = ld4(&bias[ch]);
+                    const F4 z = {acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w};
+                    y[cb] = affine_relu(z, aff4_from_table(tab, ch));
+                }
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {                 // z2 = y W1^T + b1; relu(bn_b(z2)); relu(bn_c(.))  (gin.py:55-57,219-220)
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const F4 wf = ld4(&Wl1[(16 * cb + j) * kLdt + 16 * c + 4 * q]);
+                        acc = mfma_16x16x4_f32(wf.x, y[c].x, acc);
+                        acc = mfma_16x16x4_f32(wf.y, y[c].y, acc);
+                        acc = mfma_16x16x4_f32(wf.z, y[c].z, acc);
+                        acc = mfma_16x16x4_f32(wf.w, y[c].w, acc);
+                    }
+                    const int ch = 16 * cb + 4 * q;
+                    const F4 b4 = ld4(&bias[H + ch]);
+                    const F4 z = {acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w};
+                    const F4 h = affine_relu(affine_relu(z, aff4_from_table(tab + 2 * H, ch)), aff4_from_table(tab + 4 * H, ch));
+                    if (rl < nrows) st4(nxt + (int64_t)(n0 + tile0 + rl) * H + ch, h);
+                }
+            }
+            __syncthreads();                                     // T, rpl and the side slots are reused by the next tile
+        }
+        // ---- the layer's output becomes the current representation: mirror it into LDS
+        device_fence();
+        __syncthreads();
+        { float *sw = cur; cur = nxt; nxt = sw; }
+        if (in_lds) {
+            for (int idx = tid; idx < n * 16; idx += kThreads) {
+                const int r = idx >> 4, c4 = (idx & 15) * 4;
+                const float *p = cur + (int64_t)(n0 + r) * H + c4;
+                const F4 v = {load_fresh(p), load_fresh(p + 1), load_fresh(p + 2), load_fresh(p + 3)};
+                st4(&A[r * kEvalLd + c4], v);
+            }
+            __syncthreads();
+        }
+        pool_rows(l + 1);
+    }
+
+    // ---- readout: score = sum_i linears_prediction[i](pooled_i) (gin.py:227-230; eval: dropout is the identity),
+    // F.normalize (graph_encoder.py:195-196)
+    {
+        const int o = tid & 63, pt = tid >> 6;
+        float s = 0.f;
+        for (int i = pt; i <= L; i += 4) {
+            const int kd = i == 0 ? a.kdim0 : a.hid;
+            const float *w = a.pred_w[i] + (int64_t)o * kd;
+            float acc = a.pred_b[i] ? a.pred_b[i][o] : 0.f;
+            for (int k = 0; k < kd; ++k) acc = fmaf(w[k], (float)pool[i * H + k], acc);
+            s += acc;
+        }
+        float *sp = (float *)ppart;                              // [4][64] partial scores, then [64] squares
+        sp[pt * H + o] = s;
+        __syncthreads();
+        if (tid < H) {
+            const float sc = (sp[tid] + sp[H + tid]) + (sp[2 * H + tid] + sp[3 * H + tid]);
+            float ss = sc * sc;
+            ss = wave_sum(ss);                                   // (the first wave holds all 64 channels)
+            float f = sc;
+            if (a.normalize) {
+                const float nrm = sqrtf(ss);
+                f = sc / (nrm > a.norm_eps ? nrm : a.norm_eps);
+            }
+            a.score[(int64_t)b * H + tid] = sc;
+            a.feat[(int64_t)b * H + tid] = f;
+            if (a.mean_out) atomicAdd(&a.mean_out[(int64_t)b * H + tid], a.mean_w * f);
+            if (a.pooled) for (int i = 0; i <= L; ++i) a.pooled[((int64_t)i * a.B + b) * H + tid] = pool[i * H + tid];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t gcc_gin_eval_fused(const gcc_gin_pass *passes, int32_t npass, float *mean_out, void *stream)
+{
+    if (!passes || npass < 1 || npass > kMaxPass) {
+        snprintf(g_err, kErrLen, "gcc_gin_eval_fused: npass must be 1..%d", kMaxPass);
+        return -1;
+    }
+    EvalLaunch Ln;
+    memset(&Ln, 0, sizeof(Ln));
+    const int B = passes[0].batch_size;
+    for (int i = 0; i < npass; ++i) {
+        const gcc_gin_pass &p = passes[i];
+        const int L = p.w.num_gin_layers, kdim0 = p.w.pos_dim + p.w.deg_emb_dim + 1;
+        if (p.training || L < 1 || L > GCC_GIN_MAX_LAYERS || kdim0 > H || p.batch_size != B || B < 1 || !p.z1[0] || !p.z2[0] ||
+            !p.score || !p.feat || !p.node_off || !p.row_ptr || !p.col_idx || !p.pos) {
+            snprintf(g_err, kErrLen, "gcc_gin_eval_fused: an eval-mode pass with z1[0] / z2[0] scratch, score and feat is needed "
+                                     "(training=%d layers=%d d_in=%d B=%d)", p.training, L, kdim0, p.batch_size);
+            return -2;
+        }
+        EvalArgs &a = Ln.p[i];
+        a.node_off = p.node_off; a.row_ptr = p.row_ptr; a.col_idx = p.col_idx; a.seed_local = p.seed_local;
+        a.pos = p.pos; a.emb = p.w.degree_embedding;
+        a.g0 = p.z1[0]; a.g1 = p.z2[0];
+        a.pooled = p.pooled; a.score = p.score; a.feat = p.feat;
+        a.mean_out = mean_out; a.mean_w = 1.0f / (float)npass;
+        for (int l = 0; l < L; ++l) {
+            EvalLayer &ly = a.layer[l];
+            ly.w0 = p.w.lin0_w[l]; ly.b0 = p.w.lin0_b[l]; ly.w1 = p.w.lin1_w[l]; ly.b1 = p.w.lin1_b[l];
+            const gcc_bn *bn[3] = {&p.w.bn_a[l], &p.w.bn_b[l], &p.w.bn_c[l]};
+            for (int k = 0; k < 3; ++k) {
+                ly.bn_w[k] = bn[k]->weight; ly.bn_b[k] = bn[k]->bias; ly.bn_rm[k] = bn[k]->running_mean; ly.bn_rv[k] = bn[k]->running_var;
+                if (!ly.bn_w[k] || !ly.bn_b[k] || !ly.bn_rm[k] || !ly.bn_rv[k]) {
+                    snprintf(g_err, kErrLen, "gcc_gin_eval_fused: BatchNorm %d of layer %d has no running statistics", k, l);
+                    return -2;
+                }
+            }
+        }
+        for (int l = 0; l <= L; ++l) { a.pred_w[l] = p.w.pred_w[l]; a.pred_b[l] = p.w.pred_b[l]; }
+        a.B = B; a.L = L; a.pos_dim = p.w.pos_dim; a.emb_dim = p.w.deg_emb_dim; a.max_degree = p.w.max_degree;
+        a.mult = p.edge_multiplicity > 1 ? p.edge_multiplicity : 1;
+        a.normalize = p.normalize; a.hid = hidden_of(p.w); a.kdim0 = kdim0;
+        a.eps = p.w.bn_eps; a.norm_eps = p.w.norm_eps;
+    }
+    hipStream_t s = (hipStream_t)stream;
+#ifndef GCC_AMD_HIPEMU
+    (void)hipFuncSetAttribute((const void *)gin_eval_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kEvalLds);
+    if (mean_out) (void)hipMemsetAsync(mean_out, 0, (size_t)B * H * sizeof(float), s);
+#else
+    if (mean_out) memset(mean_out, 0, (size_t)B * H * sizeof(float));
+#endif
+    hipLaunchKernelGGL(gin_eval_fused_kernel, dim3(B, npass), dim3(kThreads), kEvalLds, s, Ln);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, kErrLen, "gcc_gin_eval_fused: launch failed: %s", hipGetErrorString(e));
+        return -10;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -595,6 +595,50 @@ int32_t gcc_queue_enqueue_scalars(float *mem, int32_t K, const float *keys, int3
 
 __global__ void step_scalars_kernel(gcc_step_scalars *dev, gcc_step_scalars v) { *dev = v; }
 
+// one thread: ring entry (*counter mod ring_len) of the host-pinned ring -> the device struct; the entry was written by plain
+// host stores before this launch was submitted, and is read word by word with system-scope loads (the ring's lines are
+// reused every ring_len steps: nothing may be served from a stale cache line)
+__global__ void step_scalars_fetch_kernel(gcc_step_scalars *dev, const gcc_step_scalars *ring, int ring_len,
+                                          unsigned long long *counter)
+{
+    const unsigned long long n = *counter;
+    const uint32_t *src = (const uint32_t *)(ring + (n % (unsigned long long)ring_len));
+    uint32_t *dst = (uint32_t *)dev;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(gcc_step_scalars) / 4); ++i) dst[i] = load_system_u32(src + i);
+    *counter = n + 1;
+}
+
+static void fill_scalars(gcc_step_scalars &v, float lr, float beta1, float beta2, int32_t adam_step, int32_t enqueue_index,
+                         uint64_t dropout_seed)
+{
+    v.lr = lr;
+    v.bias_corr1 = 1.0f - powf(beta1, (float)adam_step);          // exactly gcc_adam_step's host arithmetic
+    v.bias_corr2_sqrt = sqrtf(1.0f - powf(beta2, (float)adam_step));
+    v.enqueue_index = enqueue_index;
+    v.dropout_seed = dropout_seed;
+}
+
+void gcc_step_scalars_fill(gcc_step_scalars *host_entry, float lr, float beta1, float beta2, int32_t adam_step,
+                           int32_t enqueue_index, uint64_t dropout_seed)
+{
+    gcc_step_scalars v;
+    fill_scalars(v, lr, beta1, beta2, adam_step, enqueue_index, dropout_seed);
+    memcpy(host_entry, &v, sizeof(v));
+    __atomic_thread_fence(__ATOMIC_RELEASE);                      // visible before the launch that follows is submitted
+}
+
+int32_t gcc_step_scalars_fetch(gcc_step_scalars *dev, const gcc_step_scalars *ring, int32_t ring_len,
+                               unsigned long long *counter, void *stream)
+{
+    if (!dev || !ring || !counter || ring_len < 1) {
+        snprintf(g_err, kErrLen, "gcc_step_scalars_fetch: bad argument");
+        return -1;
+    }
+    hipLaunchKernelGGL(step_scalars_fetch_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dev, ring, (int)ring_len, counter);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
 int32_t gcc_step_scalars_set(gcc_step_scalars *dev, float lr, float beta1, float beta2, int32_t adam_step,
                              int32_t enqueue_index, uint64_t dropout_seed, void *stream)
 {
@@ -603,11 +647,7 @@ int32_t gcc_step_scalars_set(gcc_step_scalars *dev, float lr, float beta1, float
         return -1;
     }
     gcc_step_scalars v;
-    v.lr = lr;
-    v.bias_corr1 = 1.0f - powf(beta1, (float)adam_step);          // exactly gcc_adam_step's host arithmetic
-    v.bias_corr2_sqrt = sqrtf(1.0f - powf(beta2, (float)adam_step));
-    v.enqueue_index = enqueue_index;
-    v.dropout_seed = dropout_seed;
+    fill_scalars(v, lr, beta1, beta2, adam_step, enqueue_index, dropout_seed);
     hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dev, v);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }

@@ -181,6 +181,14 @@ class GinEngine:
             raise RuntimeError(f"gcc_gin_forward failed ({rc}): {self.lib.gcc_last_error().decode()}")
 
 
+    def eval_fused(self, passes, mean_out=None, stream=None):
+        """gcc_gin_eval_fused: eval-mode passes (running statistics) as one launch, one workgroup per subgraph; with
+        ``mean_out`` [B, 64] the mean of the passes' embeddings (generate.py:52)."""
+        arr = (_cabi.GccGinPass * len(passes))(*passes)
+        rc = self.lib.gcc_gin_eval_fused(arr, len(passes), self.ptr(mean_out) if mean_out is not None else None, stream)
+        if rc != 0:
+            raise RuntimeError(f"gcc_gin_eval_fused failed ({rc}): {self.lib.gcc_last_error().decode()}")
+
     def backward(self, enc, p, buf, dfeat, targets=None, accumulate=False, stream=None, prof=None):
         """Backward of a training-mode pass.  Gradients are written (or added, ``accumulate``) into
         ``targets`` (tensors in :func:`grad_params` order); by default into each ``param.grad``."""
@@ -250,6 +258,7 @@ class GraphEncoder(nn.Module):
         self.norm = norm
         self.hidden, self.output_dim = int(node_hidden_dim), int(output_dim)
         self._pad_ptrs = {}          # name -> data_ptr of the tensor's padded home (ensure_padded)
+        self.fused_eval = True       # eval-mode forward as one launch (gcc_gin_eval_fused); False: the 15-launch chain
         self._engine = None
         self._slot = id(self)
         self._calls = 0
@@ -336,6 +345,23 @@ class GraphEncoder(nn.Module):
     def bn_training(self) -> bool:
         """train.py:357-365: model_ema is in eval() but its BatchNorm layers are switched back to train()."""
         return self.gnn.batch_norms[0].training
+
+    def embed_views(self, graph_q, graph_k):
+        """generate.py:45-52 in one launch: ``(model(graph_q) + model(graph_k)) / 2`` in eval mode (both views' subgraphs
+        as workgroups of the same gcc_gin_eval_fused call, the mean taken on the device).  -> [B, output_dim]"""
+        if self.bn_training():
+            raise RuntimeError("embed_views is the eval-mode path (generate.py:38 calls model.eval())")
+        eng = self.engine()
+        st = torch.cuda.current_stream(graph_q.node_off.device).cuda_stream if graph_q.node_off.is_cuda else None
+        views = [graph_q] if graph_k is graph_q else [graph_q, graph_k]        # entire_graph: both views are one graph
+        passes, keep = [], []
+        for i, g in enumerate(views):
+            p, buf = eng.make_pass(self, g, training=False, keep=None, slot=(self._slot, "embed", i))
+            passes.append(p)
+            keep.append(buf)
+        mean = eng._buffers((self._slot, "embed", "mean"), 1, graph_q.batch_size, 1, graph_q.node_off.device)["feat"]
+        eng.eval_fused(passes, mean_out=mean, stream=st)
+        return mean[:, : self.output_dim].clone()
 
     def forward(self, g, return_all_outputs=False):
         from .autograd import gin_apply

@@ -15,9 +15,14 @@ def test_moco(dataset, model, posemb, opt=None):
         views = [graph_q] if graph_k is graph_q else [graph_q, graph_k]       # entire_graph: both views are one graph
         posemb.multi(views) if hasattr(posemb, "multi") else [posemb(v) for v in views]
         with torch.no_grad():
-            feat_q = model(graph_q)
-            feat_k = feat_q if graph_k is graph_q else model(graph_k)
+            if getattr(model, "fused_eval", False):
+                # both views through the encoder AND (feat_q + feat_k) / 2 in one launch (gcc_gin_eval_fused)
+                emb = model.embed_views(graph_q, graph_k)
+            else:
+                feat_q = model(graph_q)
+                feat_k = feat_q if graph_k is graph_q else model(graph_k)
+                emb = (feat_q + feat_k) / 2
         if opt is not None:
-            assert feat_q.shape == (bsz, opt.hidden_size)          # generate.py:51
-        emb_list.append(((feat_q + feat_k) / 2)[: graph_q.valid].detach().cpu())
+            assert emb.shape == (bsz, opt.hidden_size)             # generate.py:51
+        emb_list.append(emb[: graph_q.valid].detach().cpu())
     return torch.cat(emb_list)

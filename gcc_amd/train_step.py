@@ -367,6 +367,17 @@ class MoCoTrainStep:
         if self.use_graph and self.main is None:
             self.main = torch.cuda.Stream(self.dev, priority=-1)        # stream capture cannot run on the default stream
         self.scalars = torch.zeros(24, dtype=torch.uint8, device=self.dev)      # sizeof(gcc_step_scalars)
+        # the scalars travel through a ring in pinned host memory: the host fills entry n before it submits step n, the
+        # step's first (captured) launch copies entry (device counter mod ring) into ``scalars`` -- no launch of its own
+        # between two replays (a kernel between two graph launches cost the stream 0.07 ms per step: 0.658 vs 0.589 ms in
+        # tools/graph_probe.py with gcc_step_scalars_set in front of every replay)
+        self.ring_len = 2048
+        self.ring = torch.zeros(24 * self.ring_len, dtype=torch.uint8)
+        if self.dev.type == "cuda":
+            self.ring = self.ring.pin_memory()
+        self.ring_count = 0                                                    # host's count of ring steps
+        self.ring_counter = torch.zeros(1, dtype=torch.int64, device=self.dev)  # the device's
+        self._ring_events = []                                                  # (count, event): run-ahead guard
         self.graphs = {}                    # ring-slot key -> (CUDAGraph, outs of the captured step)
         self.graph_replays = 0
         model.train()                                                    # train.py:357-365
@@ -473,7 +484,10 @@ class MoCoTrainStep:
         scalars = self.scalars if (graphed or self.use_scalars) and keep is None else None
         if scalars is not None:
             g0 = self.optimizer.param_groups[0]
-            self.nce.set_scalars(scalars, lr, g0["betas"], self.optimizer.steps + 1, c.index, seed or 0, stream=st)
+            self._ring_guard()
+            self.nce.fill_scalars(self.ring, self.ring_count % self.ring_len, lr, g0["betas"], self.optimizer.steps + 1,
+                                  c.index, seed or 0)
+            self.ring_count += 1
         out = None
         if graphed:
             key = self._slot_key(q, k)
@@ -502,9 +516,24 @@ class MoCoTrainStep:
         self.producer.release(step)
         return out
 
+    def _ring_guard(self):
+        """the host must stay less than a ring ahead of the device: every 256 ring steps an event is recorded, and a slot is
+        only rewritten once the event recorded 3/4 of a ring earlier has completed (in practice it always has)."""
+        if self.dev.type != "cuda":
+            return
+        n = self.ring_count
+        if n % 256 == 0:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            self._ring_events.append((n, ev))
+        while self._ring_events and self._ring_events[0][0] <= n - (self.ring_len * 3) // 4:
+            self._ring_events.pop(0)[1].synchronize()
+
     def _body(self, q, k, keep, seed, scalars, pr, st):
         """The launches of one step on the current stream (eager, or under stream capture).  ``scalars``: device
         gcc_step_scalars the Adam / enqueue / dropout kernels read instead of by-value arguments."""
+        if scalars is not None:                   # first launch of the step: this step's ring entry -> the device struct
+            self.nce.fetch_scalars(scalars, self.ring, self.ring_len, self.ring_counter, stream=st)
         pq, bufq = self.gin.make_pass(self.model, q, training=True, keep=keep, slot=("step", 0), dropout_seed=seed,
                                       scalars=scalars)
         pk, bufk = self.gin.make_pass(self.ema, k, training=True, keep=None, slot=("step", 1))

@@ -263,6 +263,15 @@ typedef struct gcc_step_scalars {
 } gcc_step_scalars;
 int32_t gcc_step_scalars_set(gcc_step_scalars *dev, float lr, float beta1, float beta2, int32_t adam_step,
                              int32_t enqueue_index, uint64_t dropout_seed, void *stream);
+/* The same without a launch between two replays: the HOST fills entry (n mod ring_len) of a ring in pinned, device-visible
+ * host memory (gcc_step_scalars_fill: plain stores, no device work) before it launches the n-th step that uses the ring,
+ * and the step's FIRST launch (gcc_step_scalars_fetch: one thread, part of the captured graph) copies entry
+ * (*counter mod ring_len) into the device struct and increments the device-resident counter.  Host and device count the
+ * same steps, so entry n is read by step n; the host must not run ring_len steps ahead of the device. */
+void gcc_step_scalars_fill(gcc_step_scalars *host_entry, float lr, float beta1, float beta2, int32_t adam_step,
+                           int32_t enqueue_index, uint64_t dropout_seed);
+int32_t gcc_step_scalars_fetch(gcc_step_scalars *dev, const gcc_step_scalars *ring, int32_t ring_len,
+                               unsigned long long *counter, void *stream);
 
 typedef struct gcc_gin_pass {    /* one encoder invocation on one batched graph            */
     const int32_t *node_off, *row_ptr, *col_idx, *graph_id;   /* gcc_batch_out of the view */
@@ -302,6 +311,15 @@ typedef struct gcc_gin_pass {    /* one encoder invocation on one batched graph 
 /* Runs `npass` independent passes (e.g. query with model, key with model_ema)
  * in the same launches.  prof marks: 0 before, 1 after. */
 int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gcc_prof *prof, void *stream);
+
+/* The eval-mode forward as ONE launch (generate.py:33-53: model.eval(); feat_q = model(graph_q); feat_k = model(graph_k);
+ * emb = (feat_q + feat_k) / 2): one workgroup carries one subgraph through feature assembly, every GIN layer, the pooled
+ * readout and F.normalize with its hidden representation resident in LDS (subgraphs up to 256 nodes; larger ones gather
+ * from the L2-resident global copy).  Every pass must have training = 0 (running statistics) and z1[0], z2[0] ([node_cap,
+ * 64] scratch), score and feat; pooled is written when not NULL.  mean_out: device [B, 64] or NULL -- receives the mean
+ * of the passes' feat (npass = 2: generate.py:52).  Same results as gcc_gin_forward in eval mode to ~1e-6 (the gather's
+ * summation order differs). */
+int32_t gcc_gin_eval_fused(const gcc_gin_pass *passes, int32_t npass, float *mean_out, void *stream);
 
 typedef struct gcc_gin_grads {   /* same shapes as the weights; written (not accumulated)  */
     float *degree_embedding;

@@ -1,0 +1,116 @@
+"""gcc_gin_eval_fused (gcc_amd/csrc/encoder_eval.hip): the eval-mode encoder of generate.py:33-53 as one launch, one
+workgroup per subgraph -- against the 15-launch chain in eval mode (same kernels' arithmetic) and oracle/encoder.py in
+eval(), on a batch with an LDS-resident subgraph, one larger than the LDS capacity (global gather path), a two-node one
+and an empty padding graph; edge multiplicity 2 and a non-zero seed position (the graph-classification datasets);
+``embed_views`` = (f(q) + f(k)) / 2.  Emulator tier; the device tier is tests/test_generate_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder as E
+from tests.hipemu.emu_encoder import CpuBatch, emu_engine, reference_encoder
+
+
+def _random_subgraph(rng, n, extra):
+    pairs = {(i, i + 1) for i in range(n - 1)}
+    while len(pairs) < n - 1 + extra:
+        a, b = sorted(rng.randint(0, n, 2))
+        if a != b:
+            pairs.add((a, b))
+    rows = [[] for _ in range(n)]
+    for a, b in pairs:
+        rows[a].append(b)
+        rows[b].append(a)
+    return [sorted(r) for r in rows]
+
+
+def _batch(sizes, seed, hub=False):
+    rng = np.random.RandomState(seed)
+    node_off, row_ptr, col = [0], [0], []
+    for n in sizes:
+        if n > 0:
+            rows = _random_subgraph(rng, n, 2 * n) if n > 2 else [[1], [0]]
+            if hub and n > 40:                         # a hub row (long rows cross lane-group chunks of the gather)
+                for u in range(2, n, 2):
+                    if u not in rows[0]:
+                        rows[0].append(u)
+                        rows[u].append(0)
+                rows = [sorted(r) for r in rows]
+            for r in rows:
+                col += [node_off[-1] + u for u in r]
+                row_ptr.append(len(col))
+        node_off.append(node_off[-1] + max(n, 0))
+    N = node_off[-1]
+    pos = torch.nn.functional.normalize(torch.randn(N, 32, generator=torch.Generator().manual_seed(seed)), dim=1)
+    return CpuBatch(dict(node_off=torch.tensor(node_off), row_ptr=torch.tensor(row_ptr), col_idx=torch.tensor(col),
+                         pos_undirected=pos))
+
+
+def _models(seed):
+    torch.manual_seed(seed)
+    oracle = E.OracleGraphEncoder()
+    for mod in oracle.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.normal_(0, 0.3)
+            mod.running_var.uniform_(0.5, 2.0)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.2)
+    model = reference_encoder()
+    model.load_state_dict(oracle.state_dict())
+    model._engine = emu_engine()
+    model.eval()
+    oracle.eval()
+    return model, oracle
+
+
+def _oracle_args(g, mult=1):
+    n = g.n
+    rp, ci = g.row_ptr[: n + 1].long(), g.col_idx.long()
+    if mult > 1:                                        # the reference's doubled DGL graph: every edge `mult` times
+        ci = ci.repeat_interleave(mult)
+        rp = rp * mult
+    return g.node_off.long(), rp, ci, g.pos_undirected[:n]
+
+
+@pytest.mark.parametrize("mult", [1, 2])
+def test_fused_eval_equals_the_chain_and_the_oracle(mult):
+    model, oracle = _models(3)
+    g = _batch([70, 300, 2, 0, 129, 33], seed=1, hub=True)
+    g.edge_multiplicity = mult
+    with torch.no_grad():
+        model.fused_eval = True
+        f_fused, p_fused = model(g, return_all_outputs=True)
+        model.fused_eval = False
+        f_chain, p_chain = model(g, return_all_outputs=True)
+        ref, p_ref = oracle(*_oracle_args(g, mult), return_all_outputs=True)
+    torch.testing.assert_close(f_fused, f_chain, rtol=1e-5, atol=2e-6)
+    for a, b in zip(p_fused, p_chain):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(f_fused, ref, rtol=1e-4, atol=2e-5)        # (graph 3 is empty: score = the prediction biases)
+    for a, b in zip(p_fused, p_ref):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-3)
+
+
+def test_seed_position_and_view_mean():
+    model, oracle = _models(4)
+    q, k = _batch([40, 90, 17], seed=2), _batch([35, 61, 260], seed=3)
+    q.seed_local = torch.tensor([5, 0, 16], dtype=torch.int32)        # entire_graph=True: data_util.py:236-237
+    with torch.no_grad():
+        emb = model.embed_views(q, k)
+        fq = oracle(*_oracle_args(q), seed_local=q.seed_local.long())
+        fk = oracle(*_oracle_args(k))
+    assert tuple(emb.shape) == (3, 64)
+    torch.testing.assert_close(emb, (fq + fk) / 2, rtol=1e-4, atol=2e-5)
+    with torch.no_grad():                                              # entire_graph: both views are ONE graph object
+        same = model.embed_views(q, q)
+    torch.testing.assert_close(same, fq, rtol=1e-4, atol=2e-5)
+
+
+def test_training_mode_passes_are_refused():
+    model, _ = _models(5)
+    model.train()
+    g = _batch([20], seed=4)
+    eng = model.engine()
+    p, buf = eng.make_pass(model, g, training=True)
+    with pytest.raises(RuntimeError, match="eval-mode"):
+        eng.eval_fused([p])

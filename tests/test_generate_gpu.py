@@ -115,3 +115,57 @@ def test_graph_classification_dataset_on_device():
     oracle.eval()
     ref = [oracle(no, rp, ci, pos, seed_local=sl).detach()[:valid] for no, rp, ci, pos, sl, valid in kept]
     torch.testing.assert_close(emb, torch.cat(ref), rtol=1e-3, atol=1e-4)
+
+
+def test_fused_eval_kernel_equals_the_eval_chain_on_the_device():
+    """gcc_gin_eval_fused (one launch, one workgroup per subgraph, generate.py:33-53) against gcc_gin_forward in eval mode
+    on sampled batches with rw_hops 256 ego-nets (LDS-resident subgraphs and ones above the 256-row capacity) and against
+    the torch oracle; edge multiplicity 2 as generate.py's datasets have it."""
+    from gcc_amd.encoder import GraphEncoder
+    from gcc_amd.graph import DeviceGraph
+    from gcc_amd.graphgen import powerlaw_graph
+    from gcc_amd.posemb import DevicePosEmb
+    from gcc_amd.sampler import DeviceRWRSampler
+    from oracle import encoder as E
+    from tests.headline_step_check import view_arrays
+
+    rp, ci = powerlaw_graph(200_000, 2_000_000, 4)
+    graph = DeviceGraph(rp, ci, rw_hops=256, device="cuda:0")
+    B = 64
+    smp = DeviceRWRSampler(graph, B, run_seed=2)
+    pe = DevicePosEmb(B, smp.node_cap, 32, device="cuda:0", seed=2, max_views=2)
+    q, k = smp.sample(0)
+    pe.multi([q, k])
+    smp.check_status()
+    sizes = torch.diff(q.node_off[: B + 1]).cpu()
+    assert int(sizes.max()) > 256 and int(sizes.min()) < 256            # both residency paths are exercised
+    torch.manual_seed(3)
+    oracle = E.OracleGraphEncoder()
+    for mod in oracle.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.normal_(0, 0.3)
+            mod.running_var.uniform_(0.5, 2.0)
+    model = GraphEncoder(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
+                         freq_embedding_size=16, degree_embedding_size=16, output_dim=64, node_hidden_dim=64,
+                         edge_hidden_dim=64, num_layers=5, num_step_set2set=6, num_layer_set2set=3, norm=True,
+                         gnn_model="gin", degree_input=True).cuda()
+    model.load_state_dict(oracle.state_dict())
+    model.eval()
+    oracle.eval()
+    for mult in (1, 2):
+        q.edge_multiplicity = k.edge_multiplicity = mult
+        with torch.no_grad():
+            model.fused_eval = True
+            ff, pf = model(q, return_all_outputs=True)
+            emb = model.embed_views(q, k)
+            model.fused_eval = False
+            fc, pc = model(q, return_all_outputs=True)
+            fk = model(k)
+        torch.testing.assert_close(ff, fc, rtol=1e-5, atol=5e-6)
+        for a, b in zip(pf, pc):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(emb, (fc + fk) / 2, rtol=1e-5, atol=5e-6)
+        (no, rpq, ciq), pos = view_arrays(q)
+        with torch.no_grad():
+            ref = oracle(no, mult * torch.from_numpy(rpq), torch.repeat_interleave(torch.from_numpy(ciq), mult), pos)
+        torch.testing.assert_close(ff.cpu(), ref, rtol=1e-3, atol=1e-4)

@@ -105,3 +105,109 @@ def test_rank_shards_tile_the_global_batch_bit_exactly():
         assert np.array_equal(sizes, np.diff(whole[view]["node_off"]))
         nnz = np.concatenate([np.diff(p["edge_off"]) for p in parts])
         assert np.array_equal(nnz, np.diff(whole[view]["edge_off"]))
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# 8 ranks (the size the driver's scaling run uses): the real host code of MoCoTrainStep over gloo on the emulator kernels
+def _worker8(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gcc_amd.contrast import MemoryMoCo
+        from gcc_amd.train_step import MoCoTrainStep
+        from oracle import encoder as E
+        from tests.hipemu.emu_encoder import CpuBatch, emu_engine, reference_encoder
+        from tests.test_nce_emu import emu_nce
+
+        gold = torch.load(GOLD_PATH, weights_only=False)
+        g = gold["moco"]
+        B, K = 6, 2 * world * 6                                   # two steps fill the queue exactly once
+
+        class Stub:
+            batch_size = B
+            ids = []
+
+            def sample(self, first_id, prof=None):
+                Stub.ids.append(first_id)
+                v = (first_id // B) % 2                           # the shard decides which golden views this rank sees
+                return CpuBatch(gold["views"][v]), CpuBatch(gold["views"][1 - v])
+
+            def check_status(self):
+                if rank == 5 and getattr(Stub, "fail", False):
+                    raise RuntimeError("gcc_sample_batch overflow: induction scratch (injected on rank 5)")
+
+        class Pos:
+            def __call__(self, gr, prof=None):
+                return gr
+
+            def check_status(self, strict=False):
+                return 8 if rank == 3 else (256 if rank == 6 else 0)     # flag words differ by rank: a bit mask, not a maximum
+
+        def build(K_):
+            model, ema = reference_encoder(), reference_encoder()
+            model.load_state_dict(g["init"]["model"])
+            ema.load_state_dict(g["init"]["model_ema"])
+            model._engine = ema._engine = emu_engine()
+            contrast = MemoryMoCo(64, None, K_, g["T"], use_softmax=True)
+            contrast._engine = emu_nce()
+            contrast.memory.copy_(E.memory_init(K_, 64, generator=torch.Generator().manual_seed(0)))
+            return model, ema, contrast
+
+        # (a) the queue must hold one step's keys of ALL ranks (memory_moco.py:55-61 enqueues every key of a step)
+        try:
+            MoCoTrainStep(*build(world * B - 1), Stub(), Pos(), prefetch=False, world_size=world, rank=rank)
+            refused = False
+        except ValueError as e:
+            refused = "nce_k" in str(e) or "--nce-k" in str(e)
+        model, ema, contrast = build(K)
+        tr = MoCoTrainStep(model, ema, contrast, Stub(), Pos(), prefetch=False, world_size=world, rank=rank, clip_norm=1.0)
+        masks = g["masks"].contiguous()
+        tr.mask_fn = lambda: masks
+        losses = [tr.step(s, g["lr"])["loss"].clone() for s in range(2)]
+        # (b) status words: OR over ranks on every rank; an error on one rank raises on all
+        flags = tr.check_status()
+        Stub.fail = True
+        try:
+            tr.check_status()
+            raised = None
+        except RuntimeError as e:
+            raised = str(e)
+        torch.save(dict(model=model.state_dict(), ema=ema.state_dict(), memory=contrast.memory.clone(), index=contrast.index,
+                        grad=tr.flat_grad.clone(), ids=list(Stub.ids), flags=flags, raised=raised, refused=refused,
+                        loss=torch.stack(losses)), os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_step_over_gloo(tmp_path):
+    """world_size 8 (the driver's SCALE run): queue divisibility, rank-rotated sample ids, rank-ordered key all-gather over
+    two steps, one averaged gradient, agreement on status flags (bitwise OR) and on errors.  CPU / gloo / emulator kernels:
+    correctness of the host code only -- no N > 1 throughput has been measured anywhere in this repository."""
+    world, B = 8, 6
+    port = 29700 + os.getpid() % 200
+    mp.spawn(_worker8, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"rank{r}.pt", weights_only=False) for r in range(world)]
+    for r, d in enumerate(rs):
+        assert d["refused"], r                                        # (a)
+        assert d["ids"] == [(s * world + r) * B for s in range(2)]    # rank-rotated shards: MoCoTrainStep._first_id
+        assert d["flags"] == (8 | 256), (r, d["flags"])               # (b) OR of the ranks' words, the same everywhere
+        assert d["raised"] is not None and ("rank 5" in d["raised"] or "another rank" in d["raised"]), (r, d["raised"])
+        assert d["index"] == 0                                        # 2 steps x 8 ranks x 6 keys = K: wrapped exactly once
+    for d in rs[1:]:                                                  # identical replicas
+        torch.testing.assert_close(d["memory"], rs[0]["memory"], rtol=0, atol=0)
+        torch.testing.assert_close(d["grad"], rs[0]["grad"], rtol=0, atol=0)
+        for k in d["model"]:
+            if "running_" in k or "num_batches" in k:
+                continue
+            torch.testing.assert_close(d["model"][k], rs[0]["model"][k], rtol=0, atol=0, msg=k)
+            torch.testing.assert_close(d["ema"][k], rs[0]["ema"][k], rtol=0, atol=0, msg=k)
+    # keys in rank order: ranks with the same shard parity enqueue the same keys, step 0 rows [0, 48), step 1 rows [48, 96)
+    mem = rs[0]["memory"]
+    for s in range(2):
+        blocks = [mem[(s * world + r) * B:(s * world + r + 1) * B] for r in range(world)]
+        for r in range(2, world):
+            same = blocks[r - 2]                                      # shard parity repeats every 2 ranks
+            torch.testing.assert_close(blocks[r], same, rtol=0, atol=0)
+        assert not torch.equal(blocks[0], blocks[1])
+    assert torch.isfinite(torch.stack([d["loss"] for d in rs])).all()

@@ -13,5 +13,5 @@ name=$1; shift
 cd "$(dirname "$0")/../gcc_amd/csrc"
 mkdir -p variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function "$@" -o variants/lib_$name.so \
-    common.hip sampler.hip encoder.hip encoder_bwd.hip nce.hip posemb.hip gin_wide.hip
+    common.hip sampler.hip encoder.hip encoder_bwd.hip encoder_eval.hip nce.hip posemb.hip gin_wide.hip
 ls -la variants/lib_$name.so
