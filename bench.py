@@ -72,6 +72,7 @@ def parse_args(argv=None):
                     help="--mode sampler: steps (DataLoader batches) per sampler call (gcc_sample_multi); the training modes "
                          "sample a producer chunk per call")
     ap.add_argument("--ahead", type=int, default=None, help="chunks launched beyond the one being consumed (default lanes * (depth - 1))")
+    ap.add_argument("--strict-streams", action="store_true", help="bracket every step with caller <-> step stream hand-offs (the API default; two event hops on the step's chain)")
     ap.add_argument("--no-graph", action="store_true", help="issue every step launch by launch instead of replaying the captured hipGraph of its ring slot")
     ap.add_argument("--scratch-entries", type=int, default=0, help="induction scratch of the sampler (int32 slots); 0 = default")
     ap.add_argument("--edge-cap", type=int, default=0, help="edge capacity of a batch view; 0 = default")
@@ -587,6 +588,7 @@ def main():
                       "moco-infonce fwd", "infonce bwd", "gin-encoder bwd", "grad all-reduce" if world > 1 else "clip",
                       "adam + ema + meters (one launch)",
                       "key all-gather (overlapped since the encoder fwd) + enqueue" if world > 1 else "enqueue"]
+        trainer.relaxed_streams = not args.strict_streams                  # results are read behind device synchronisations only
         n_batch = 2000 * 12 // 32                                          # train.py:356 with default flags
         total_steps = 100 * n_batch
 
@@ -621,7 +623,8 @@ def main():
         produced = (trainer.producer.launched - launched0) * chunk
         consumed = args.steps
         extra["final_loss"] = float(last["loss"].item())
-        extra["step_launch"] = "hipGraph replay (one captured graph per ring slot)" if graph_on else "eager (launch by launch)"
+        extra["step_launch"] = ("hipGraph replay (one captured graph per ring slot)" if graph_on else "eager (launch by launch)") + \
+            ("" if trainer.relaxed_streams else "; caller <-> step stream hand-offs around every step")
         stage_profs = profs
         if graph_on:
             extra["graph_replays_in_timed_region"] = int(trainer.graph_replays - (trainer.graph_replays_at_clock if hasattr(trainer, "graph_replays_at_clock") else 0))

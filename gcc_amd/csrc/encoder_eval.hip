@@ -134,7 +134,8 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
         __syncthreads();
         const float *src = cur;
         auto load = [&](int u) -> F4 {                           // row u (batched id) of the current representation
-            return in_lds ? ld4(&A[(u - n0) * kEvalLd + 4 * t]) : ld4(src + (int64_t)u * H + 4 * t);
+            // (gather_tile asks for row 0 in lanes without an edge: clamped into the subgraph, the value is not used)
+            return in_lds ? ld4(&A[max(u - n0, 0) * kEvalLd + 4 * t]) : ld4(src + (int64_t)u * H + 4 * t);
         };
         auto ident = [&](F4 x) -> F4 { return x; };
         for (int tile0 = 0; tile0 < n; tile0 += kTile) {

@@ -253,6 +253,8 @@ def _meter_buffers(dev):
 
 def read_meters(trainer):
     """-> (acc list[5], mx list[2]); synchronises (call once per log line, train.py:418-460)."""
+    if hasattr(trainer, "join"):
+        trainer.join()                      # the meters are written on the step's stream
     a, m = trainer.meter_acc.tolist(), trainer.meter_max.tolist()
     trainer.meter_acc.zero_()
     trainer.meter_max.zero_()
@@ -360,6 +362,8 @@ class MoCoTrainStep:
         # graph per ring slot (lanes x depth x chunk of them), captured right after the slot's first eager step.  What it
         # buys is HOST time (0.44 ms of Python + ~45 launches per step -> one set_scalars + one graph launch): the stream
         # itself is as fast either way (tools/graph_probe.py), but the host thread also issues the producer lanes.
+        self.relaxed_streams = False        # see step(): drop the per-step stream hand-offs (bench.py / train.py loops)
+        self._joined_caller = False
         self.use_scalars = False            # kernels read lr / ring pointer / dropout key from self.scalars (tests: eager)
         self.use_graph = bool(self.prefetch and not self.collectives) if graph is None else bool(graph)
         if self.use_graph and (self.dev.type != "cuda" or self.collectives):
@@ -459,11 +463,27 @@ class MoCoTrainStep:
         if self.main is None:
             return self._step(step, lr, prof)
         caller = torch.cuda.current_stream(self.dev)
-        self.main.wait_stream(caller)
+        # The step runs on its own (high-priority) stream.  By default every call is bracketed by two stream hand-offs --
+        # the step waits for what the caller enqueued, the caller waits for the step -- so that code written against
+        # train.py's single-stream semantics stays correct.  Each hand-off is an event record + wait ON THE STEP'S CHAIN
+        # (step n + 1 waits for the caller's stream, which waited for step n: ~35 us per hop, 0.07 ms per step in
+        # tools/graph_probe.py).  Loops that only read results behind :meth:`join` / a device synchronisation set
+        # ``relaxed_streams``: the first call still waits for the caller (weights, queue initialisation), later ones do not.
+        if not self.relaxed_streams or not self._joined_caller:
+            self.main.wait_stream(caller)
+            self._joined_caller = True
         with torch.cuda.stream(self.main):
             out = self._step(step, lr, prof)
-        caller.wait_stream(self.main)
+        if not self.relaxed_streams:
+            caller.wait_stream(self.main)
         return out
+
+    def join(self):
+        """Make the caller's current stream wait for the steps issued so far (needed before reading a step's outputs,
+        the meters or the weights from the caller's stream when ``relaxed_streams`` is set; harmless otherwise)."""
+        if self.main is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.main)
+            self._joined_caller = False          # whatever the caller enqueues next is waited for by the next step
 
     def _slot_key(self, q, k):
         return tuple(t.data_ptr() for g in (q, k) for t in (g.node_off, g.edge_off, g.row_ptr, g.col_idx, g.graph_id,
@@ -611,6 +631,9 @@ class E2ETrainStep:
     _staged = MoCoTrainStep._staged
     check_status = MoCoTrainStep.check_status
     step = MoCoTrainStep.step
+    join = MoCoTrainStep.join
+    relaxed_streams = False
+    _joined_caller = False
 
     def _step(self, step, lr, prof=None):
         pr = prof or {}

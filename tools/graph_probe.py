@@ -23,6 +23,7 @@ from gcc_amd.train_step import MoCoTrainStep
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--strict-streams", action="store_true", help="keep the per-step caller <-> step stream hand-offs")
 ap.add_argument("--lib", default=None, help="an ablation build of the library (timing experiments, e.g. -DGIN_DBG_SKIP=1)")
 a = ap.parse_args()
 if a.lib:
@@ -78,6 +79,7 @@ print(f"host time to issue one step (Python + {burst}-step burst, no synchronisa
 # the SHIPPED graph path (MoCoTrainStep(graph=True): per-slot capture, device-resident scalars written by a one-thread launch
 # in front of every replay): host time to issue a step, and the stream's time per step
 tg = MoCoTrainStep(model, ema, contrast, Fixed(), posemb=lambda g, prof=None: g, prefetch=False, graph=True)
+tg.relaxed_streams = "--strict-streams" not in sys.argv
 for i in range(4):
     tg.step(30000 + i, 0.005)
 torch.cuda.synchronize()

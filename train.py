@@ -358,6 +358,9 @@ def main(args):
                                    betas=(args.beta1, args.beta2), weight_decay=args.weight_decay,
                                    clip_norm=args.clip_norm, lanes=lanes, depth=depth, chunk=args.producer_chunk)
         optimizer = trainer.optimizer
+        # the loop reads results only behind read_meters() (which joins the step's stream) and the epoch's device
+        # synchronisation: no per-step stream hand-offs (gcc_amd/train_step.py: MoCoTrainStep.step)
+        trainer.relaxed_streams = True
     else:
         # train.py:658-679: SGD(momentum) / Adagrad through autograd and torch.optim -- the API path of the same kernels
         if world > 1:
