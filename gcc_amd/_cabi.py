@@ -146,6 +146,7 @@ class GccGinwArgs(ctypes.Structure):
         ("node_off", _VP), ("row_ptr", _VP), ("col_idx", _VP), ("x_in", _VP), ("x_out", _VP), ("pooled", _VP),
         ("batch_size", ctypes.c_int32), ("num_layers", ctypes.c_int32),
         ("layers", GccGinwLayer * 8),
+        ("scratch", _VP), ("scratch_bytes", ctypes.c_int64), ("num_nodes", ctypes.c_int64),
     ]
 
 
@@ -214,6 +215,7 @@ SIGNATURES = {
                                                    ctypes.POINTER(GccStepMetersArgs), ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_queue_enqueue_scalars": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                                    ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_ginw_scratch_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32]),
     "gcc_gin_eval_fused": (ctypes.c_int32, [ctypes.POINTER(GccGinPass), ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_step_scalars_fill": (None, [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int32,
                                       ctypes.c_int32, ctypes.c_uint64]),

@@ -69,8 +69,40 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
     // (an empty padding graph has no rows: its pooled sums are zero and its score is the sum of the prediction biases, as in
     //  the reference and in gcc_gin_forward)
     float *cur = a.g0, *nxt = a.g1;
+    // Visibility of the workgroup's own global writes (big subgraphs; rows in transit between two layers): a workgroup runs on
+    // one CU and __syncthreads() orders its stores before its later loads at workgroup scope -- no agent-scope fence (on this
+    // multi-die part an agent-scope release writes L2 back: 40 us per layer with 256 workgroups doing it, measured)
+    const bool single = in_lds && n <= kTile;                    // one tile: the layer updates A in place, nothing leaves LDS
 
-    // ---- hidden_rep[0]: input features (graph_encoder.py:158-165) -> cur (global) and A (LDS mirror)
+    // this layer's weights / BatchNorm numbers are requested one layer ahead (registers), stored when the buffers are free
+    struct LayerRegs { WStage s0, s1; float v0, v1, v2, v3; };
+    auto request_layer = [&](int l) -> LayerRegs {
+        const EvalLayer &ly = a.layer[l];
+        LayerRegs r;
+        r.s0 = stage_weights_request(ly.w0, l == 0 ? a.kdim0 : a.hid);
+        r.s1 = stage_weights_request(ly.w1, a.hid);
+        const int c = tid & 63, which = tid >> 6;                // which < 3: a BatchNorm; 3: the two biases
+        r.v2 = r.v3 = 0.f;
+        if (which < 3) { r.v0 = ly.bn_w[which][c]; r.v1 = ly.bn_b[which][c]; r.v2 = ly.bn_rm[which][c]; r.v3 = ly.bn_rv[which][c]; }
+        else { r.v0 = ly.b0 ? ly.b0[c] : 0.f; r.v1 = ly.b1 ? ly.b1[c] : 0.f; }
+        return r;
+    };
+    auto store_layer = [&](int l, const LayerRegs &r) {
+        stage_weights_store(Wl0, r.s0, l == 0 ? a.kdim0 : a.hid);
+        stage_weights_store(Wl1, r.s1, a.hid);
+        const int c = tid & 63, which = tid >> 6;
+        if (which < 3) {                                         // bn_scale_shift_from(training = 0), encoder_common.h
+            const double rstd = 1.0 / sqrt((double)r.v3 + (double)a.eps);
+            tab[which * 2 * H + c] = (float)((double)r.v0 * rstd);
+            tab[which * 2 * H + H + c] = (float)((double)r.v1 - (double)r.v2 * (double)r.v0 * rstd);
+        } else {
+            bias[c] = r.v0;
+            bias[H + c] = r.v1;
+        }
+    };
+    LayerRegs regs = request_layer(0);                           // (n == 0: harmless)
+
+    // ---- hidden_rep[0]: input features (graph_encoder.py:158-165) -> A (LDS) or, for a big subgraph, cur (global)
     {
         const int dtot = a.pos_dim + a.emb_dim;
         const int sl = a.seed_local ? a.seed_local[b] : 0;
@@ -87,11 +119,10 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
                 const float val = *src;
                 at(x, e) = c < dtot ? val : (c == dtot && r == sl ? 1.f : 0.f);   // ndata["seed"], data_util.py:234-238
             }
-            st4(cur + (int64_t)v * H + 4 * t, x);
             if (in_lds) st4(&A[r * kEvalLd + 4 * t], x);
+            else st4(cur + (int64_t)v * H + 4 * t, x);
         }
     }
-    device_fence();
     __syncthreads();
 
     // SumPooling of the current representation (gin.py:228) into pool[i] (fp64, fixed order)
@@ -99,7 +130,7 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
         const int c = tid & 63, pt = tid >> 6;
         double acc = 0.0;
         if (in_lds) for (int r = pt; r < n; r += 4) acc += (double)A[r * kEvalLd + c];
-        else for (int r = pt; r < n; r += 4) acc += (double)load_fresh(cur + (int64_t)(n0 + r) * H + c);
+        else for (int r = pt; r < n; r += 4) acc += (double)cur[(int64_t)(n0 + r) * H + c];
         ppart[pt * H + c] = acc;
         __syncthreads();
         if (tid < H) pool[i * H + tid] = (ppart[tid] + ppart[H + tid]) + (ppart[2 * H + tid] + ppart[3 * H + tid]);
@@ -111,26 +142,8 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
     __syncthreads();
 
     for (int l = 0; l < (n > 0 ? L : 0); ++l) {
-        const EvalLayer &ly = a.layer[l];
-        const int kd = l == 0 ? a.kdim0 : a.hid;
-        // ---- this layer's weights, biases and BatchNorm affines (running statistics: gin.py's modules in eval())
-        {
-            const WStage s0 = stage_weights_request(ly.w0, kd), s1 = stage_weights_request(ly.w1, a.hid);
-            const int c = tid & 63, which = tid >> 6;            // which < 3: a BatchNorm; 3: the two biases
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-            if (which < 3) { v0 = ly.bn_w[which][c]; v1 = ly.bn_b[which][c]; v2 = ly.bn_rm[which][c]; v3 = ly.bn_rv[which][c]; }
-            else { v0 = ly.b0 ? ly.b0[c] : 0.f; v1 = ly.b1 ? ly.b1[c] : 0.f; }
-            stage_weights_store(Wl0, s0, kd);
-            stage_weights_store(Wl1, s1, a.hid);
-            if (which < 3) {                                     // bn_scale_shift_from(training = 0), encoder_common.h
-                const double rstd = 1.0 / sqrt((double)v3 + (double)a.eps);
-                tab[which * 2 * H + c] = (float)((double)v0 * rstd);
-                tab[which * 2 * H + H + c] = (float)((double)v1 - (double)v2 * (double)v0 * rstd);
-            } else {
-                bias[c] = v0;
-                bias[H + c] = v1;
-            }
-        }
+        store_layer(l, regs);
+        if (l + 1 < L) regs = request_layer(l + 1);              // in flight during this layer
         __syncthreads();
         const float *src = cur;
         auto load = [&](int u) -> F4 {                           // row u (batched id) of the current representation
@@ -195,23 +208,25 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
                     const F4 b4 = ld4(&bias[H + ch]);
                     const F4 z = {acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w};
                     const F4 h = affine_relu(affine_relu(z, aff4_from_table(tab + 2 * H, ch)), aff4_from_table(tab + 4 * H, ch));
-                    if (rl < nrows) st4(nxt + (int64_t)(n0 + tile0 + rl) * H + ch, h);
+                    if (rl < nrows) {
+                        // (single tile: every read of A by this layer's gather is behind gather_tile's closing barrier)
+                        if (single) st4(&A[rl * kEvalLd + ch], h);
+                        else st4(nxt + (int64_t)(n0 + tile0 + rl) * H + ch, h);
+                    }
                 }
             }
             __syncthreads();                                     // T, rpl and the side slots are reused by the next tile
         }
-        // ---- the layer's output becomes the current representation: mirror it into LDS
-        device_fence();
-        __syncthreads();
-        { float *sw = cur; cur = nxt; nxt = sw; }
-        if (in_lds) {
-            for (int idx = tid; idx < n * 16; idx += kThreads) {
-                const int r = idx >> 4, c4 = (idx & 15) * 4;
-                const float *p = cur + (int64_t)(n0 + r) * H + c4;
-                const F4 v = {load_fresh(p), load_fresh(p + 1), load_fresh(p + 2), load_fresh(p + 3)};
-                st4(&A[r * kEvalLd + c4], v);
+        // ---- the layer's output becomes the current representation
+        if (!single) {
+            { float *sw = cur; cur = nxt; nxt = sw; }
+            if (in_lds) {                                        // several tiles: the new rows come back from their transit buffer
+                for (int idx = tid; idx < n * 16; idx += kThreads) {
+                    const int r = idx >> 4, c4 = (idx & 15) * 4;
+                    st4(&A[r * kEvalLd + c4], ld4(cur + (int64_t)(n0 + r) * H + c4));
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
         pool_rows(l + 1);
     }

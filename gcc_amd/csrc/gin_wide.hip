@@ -38,6 +38,11 @@ struct WideArgs {
     int32_t batch_size, num_layers;
     long long *ticks;                // diagnostics (gcc_ginw_debug_ticks): wall-clock ticks per phase, or NULL
     gcc_ginw_layer layers[GCC_GIN_MAX_LAYERS];
+    // subgraphs over kNodes nodes (gin_wide_big_kernel): two [N, 256] bf16 ping-pong buffers and a work list
+    // {count, -, (subgraph, row block) pairs}, or NULL: such subgraphs are refused (GCC_STATUS_GINW_TOO_LARGE)
+    uint16_t *big0, *big1;
+    int32_t *big_work;
+    int32_t big_cap;                 // pairs the work list holds
 };
 
 long long *g_ticks = nullptr;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(kThreads) void gin_wide_kernel(WideArgs a)
         long long tick = a.ticks ? device_ticks() : 0;
         const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
         if (n <= 0 || n > kNodes) {                          // (uniform over the workgroup)
-            if (n > kNodes) {
+            if (n > kNodes && !a.big_work) {                 // (with scratch: gin_wide_big_kernel takes it, block by block)
                 if (tid == 0) atomicOr(a.status, (int32_t)GCC_STATUS_GINW_TOO_LARGE);
                 if (a.x_out)
                     for (int64_t i = tid; i < (int64_t)n * (kD / 2); i += kThreads) ((uint32_t *)(a.x_out + (int64_t)n0 * kD))[i] = 0u;
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(kT2) void gin_wide2_kernel(WideArgs a)
         long long tick = a.ticks ? device_ticks() : 0;
         const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
         if (n <= 0 || n > kNodes) {                          // (uniform over the workgroup)
-            if (n > kNodes) {
+            if (n > kNodes && !a.big_work) {                 // (with scratch: gin_wide_big_kernel takes it, block by block)
                 if (tid == 0) atomicOr(a.status, (int32_t)GCC_STATUS_GINW_TOO_LARGE);
                 if (a.x_out)
                     for (int64_t i = tid; i < (int64_t)n * (kD / 2); i += kT2) ((uint32_t *)(a.x_out + (int64_t)n0 * kD))[i] = 0u;
@@ -784,6 +789,287 @@ __global__ __launch_bounds__(kT2) void gin_wide2_kernel(WideArgs a)
     }
 }
 
+// =====================================================================================================================
+// Subgraphs over kNodes nodes (ego-nets of the pre-training workload reach ~900 nodes: DESIGN.md section 6), one layer per
+// launch, one (subgraph, block of 128 rows) per workgroup at a time.  The layer's structure, LDS layouts and rounding points are
+// the fused kernel's (second shape); what changes is the aggregation: the row block's adjacency is a [128 x n] strip, taken
+// 128 columns at a time -- the column block's rows H_c^T come from global memory (the previous layer's output), the
+// 16-bit neighbour counts of (row block, column block) are rebuilt, and the products ACCUMULATE into the same registers,
+// so AGG is rounded to bf16 once, after the whole sum, exactly as for a small subgraph.  Rows travel through two global
+// ping-pong buffers between the launches of consecutive layers (a layer needs every row block of the one before).
+__global__ void ginw_classify_kernel(WideArgs a)
+{
+    __shared__ int32_t cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (int b = threadIdx.x; b < a.batch_size; b += blockDim.x) {
+        const int n = a.node_off[b + 1] - a.node_off[b];
+        if (n <= kNodes) continue;
+        const int nblk = (n + kNodes - 1) / kNodes;
+        const int at = atomicAdd(&cnt, nblk);
+        if (at + nblk > a.big_cap) { atomicOr(a.status, (int32_t)GCC_STATUS_GINW_TOO_LARGE); continue; }
+        for (int r = 0; r < nblk; ++r) { a.big_work[2 + 2 * (at + r)] = b; a.big_work[3 + 2 * (at + r)] = r; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.big_work[0] = cnt < a.big_cap ? cnt : a.big_cap;
+}
+
+template <bool kFrag>
+__global__ __launch_bounds__(kT2) void gin_wide_big_kernel(WideArgs a, int layer, const uint16_t *hin, uint16_t *hout)
+{
+    DYN_SMEM(smem);
+    unsigned char *P = smem, *Q = smem + kReg2;
+    int32_t *rp = (int32_t *)(smem + 2 * kReg2);             // [129] row pointers of the row block
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int L = a.num_layers;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int nh = w & 1, chh = w >> 1;
+    const gcc_ginw_layer ly = a.layers[layer];
+    const int nitems = a.big_work[0];
+
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int b = a.big_work[2 + 2 * it], r = a.big_work[3 + 2 * it];
+        const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+        const int nblk = (n + kNodes - 1) / kNodes;
+        const int row0 = n0 + r * kNodes, nr = min(kNodes, n - r * kNodes);
+        u32x4 wr[4][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) request_w<true, kFrag>(wr[ks], kFrag ? ly.w0_frag : ly.w0, w, ks, lr, lg);
+        f32x4 agg[8][4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) agg[m][nf] = zero4;
+        float pool0 = 0.f;                                   // hidden_rep[0] of the subgraph (layer 0, row block 0: it sees every column block)
+        for (int c = 0; c < nblk; ++c) {
+            __syncthreads();                                 // the previous block's fragments / this item's predecessor are done with P, Q, rp
+            const int col0 = n0 + c * kNodes, nc = min(kNodes, n - c * kNodes);
+            for (int i = tid; i < kNodes * kStrT2 / 4; i += kT2) ((uint32_t *)Q)[i] = 0u;
+            if (tid <= nr) rp[tid] = a.row_ptr[row0 + tid];
+            for (int idx = tid; idx < (kNodes / 4) * (kD / 8); idx += kT2) {       // H_c^T -> P (channel-major), as the fused kernel
+                const int chunk = idx & (kD / 8 - 1), node = 4 * (idx >> 5);
+                u32x4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    v[j] = node + j < nc ? *(const u32x4 *)(hin + (int64_t)(col0 + node + j) * kD + chunk * 8) : z;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int sh = (e & 1) * 16;
+                    u32x2 o;
+                    o[0] = ((v[0][e >> 1] >> sh) & 0xFFFFu) | (((v[1][e >> 1] >> sh) & 0xFFFFu) << 16);
+                    o[1] = ((v[2][e >> 1] >> sh) & 0xFFFFu) | (((v[3][e >> 1] >> sh) & 0xFFFFu) << 16);
+                    *(u32x2 *)(P + (chunk * 8 + e) * kStrT2 + node * 2) = o;
+                }
+            }
+            __syncthreads();
+            {   // neighbour counts of (row block r, column block c): targets outside the column block belong to another pass
+                const int e0 = rp[0], e1 = rp[nr];
+                for (int eb = e0 + 16 * tid; eb < e1; eb += 16 * kT2) {
+                    int cols[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) cols[j] = eb + j < e1 ? a.col_idx[eb + j] : -1;
+                    int lo = 0, hi = nr;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (rp[mid] <= eb) lo = mid; else hi = mid;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        if (eb + j >= e1) break;
+                        while (rp[lo + 1] <= eb + j) ++lo;
+                        const int ug = cols[j] - n0, u = ug - c * kNodes;
+                        if ((unsigned)ug >= (unsigned)n) { if (c == 0) atomicOr(a.status, (int32_t)GCC_STATUS_GINW_BAD_EDGE); }
+                        else if ((unsigned)u < (unsigned)kNodes) atomicAdd((uint32_t *)(Q + lo * kStrT2 + (u >> 1) * 4), (u & 1) ? 0x10000u : 1u);
+                    }
+                }
+                if (c == r && tid < nr) atomicAdd((uint32_t *)(Q + tid * kStrT2 + (tid >> 1) * 4), (tid & 1) ? 0x10000u : 1u);   // + h_v itself
+            }
+            __syncthreads();
+            if (layer == 0 && r == 0 && a.pooled)            // (uniform) hidden_rep[0] = the input (gin.py:216)
+                for (int j = 0; j < kNodes / 8; ++j) pool0 += sum8_bf16(lds16(P + tid * kStrT2 + j * 16));
+            u32x4 adj[4][4];
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const u32x4 cq = lds16(Q + (nh * 64 + nf * 16 + lr) * kStrT2 + (ks * 32 + lg * 8) * 2);
+                    u32x4 f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) f[q] = pack2_bf16((float)(cq[q] & 0xFFFFu), (float)(cq[q] >> 16));
+                    adj[nf][ks] = f;
+                }
+            {   // AGG += H_c^T ADJ(r, c): 128 channels x 64 nodes per wave, as the fused kernel
+                const unsigned char *src = P + (chh * 128) * kStrT2 + lg * 16;
+                u32x4 buf[2][8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) buf[0][m] = lds16(src + ((m >> 1) * 32 + perm8(lr, m & 1)) * kStrT2);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks + 1 < 4) {
+#pragma unroll
+                        for (int m = 0; m < 8; ++m)
+                            buf[(ks + 1) & 1][m] = lds16(src + ((m >> 1) * 32 + perm8(lr, m & 1)) * kStrT2 + (ks + 1) * 64);
+                    }
+                    SCHED_FENCE();
+#pragma unroll
+                    for (int m = 0; m < 8; ++m)
+#pragma unroll
+                        for (int nf = 0; nf < 4; ++nf) agg[m][nf] = mfma_16x16x32_bf16(buf[ks & 1][m], adj[nf][ks], agg[m][nf]);
+                    SCHED_FENCE();
+                }
+            }
+        }
+        if (layer == 0 && r == 0 && a.pooled) a.pooled[((int64_t)b * (L + 1)) * kD + tid] = pool0;
+        __syncthreads();                                     // every wave is done with the last column block's P and Q
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+                *(u32x4 *)(Q + (nh * 64 + nf * 16 + lr) * kStrN2 + (chh * 128 + p * 32 + lg * 8) * 2) =
+                    pack8_bf16(agg[2 * p][nf], agg[2 * p + 1][nf]);
+        lds_barrier();
+        // ---- Z1[node][ch] = relu(s0 * (AGG W0^T) + t0) -> P (node-major)
+        {
+            f32x4 acc[4][8];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nf = 0; nf < 8; ++nf) acc[m][nf] = zero4;
+            float4 sc[2][2], sh[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    sc[p][e] = *(const float4 *)(ly.s0 + w * 64 + p * 32 + lg * 8 + e * 4);
+                    sh[p][e] = *(const float4 *)(ly.t0 + w * 64 + p * 32 + lg * 8 + e * 4);
+                }
+            const unsigned char *src = Q + lr * kStrN2 + lg * 16;
+            u32x4 buf[2][8];
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf) buf[0][nf] = lds16(src + nf * 16 * kStrN2);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + 1 < 8) {
+#pragma unroll
+                    for (int nf = 0; nf < 8; ++nf) buf[(ks + 1) & 1][nf] = lds16(src + nf * 16 * kStrN2 + (ks + 1) * 64);
+                }
+                SCHED_FENCE();
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int nf = 0; nf < 8; ++nf) acc[m][nf] = mfma_16x16x32_bf16(wr[ks & 3][m], buf[ks & 1][nf], acc[m][nf]);
+                SCHED_FENCE();
+                if (ks < 4) request_w<true, kFrag>(wr[ks & 3], kFrag ? ly.w0_frag : ly.w0, w, ks + 4, lr, lg);
+                else request_w<false, kFrag>(wr[ks & 3], kFrag ? ly.w1_frag : ly.w1, w, ks - 4, lr, lg);
+                SCHED_FENCE();
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int nf = 0; nf < 8; ++nf) {
+                    f32x4 lo = acc[2 * p][nf], hi = acc[2 * p + 1][nf];
+                    lo[0] = fmaxf(fmaf(lo[0], sc[p][0].x, sh[p][0].x), 0.f); hi[0] = fmaxf(fmaf(hi[0], sc[p][0].y, sh[p][0].y), 0.f);
+                    lo[1] = fmaxf(fmaf(lo[1], sc[p][0].z, sh[p][0].z), 0.f); hi[1] = fmaxf(fmaf(hi[1], sc[p][0].w, sh[p][0].w), 0.f);
+                    lo[2] = fmaxf(fmaf(lo[2], sc[p][1].x, sh[p][1].x), 0.f); hi[2] = fmaxf(fmaf(hi[2], sc[p][1].y, sh[p][1].y), 0.f);
+                    lo[3] = fmaxf(fmaf(lo[3], sc[p][1].z, sh[p][1].z), 0.f); hi[3] = fmaxf(fmaf(hi[3], sc[p][1].w, sh[p][1].w), 0.f);
+                    *(u32x4 *)(P + (nf * 16 + lr) * kStrZ2 + (w * 64 + p * 32 + lg * 8) * 2) = pack8_bf16(lo, hi);
+                }
+        }
+        lds_barrier();
+        // ---- H'^T[ch][node] = relu(s2 * relu(s1 * (Z1 W1^T) + t1) + t2) -> Q (channel-major), rows >= nr as 0; SumPooling
+        {
+            f32x4 acc[8][4];
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[nf][m] = zero4;
+            float ea[4], eb[4], elo[4], ehi[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int ch = w * 64 + m * 16 + lr;
+                const float s1 = ly.s1[ch], t1 = ly.t1[ch], s2 = ly.s2[ch], t2 = ly.t2[ch];
+                ea[m] = s1 * s2;
+                eb[m] = fmaf(s2, t1, t2);
+                elo[m] = s2 >= 0.f ? fmaxf(t2, 0.f) : 0.f;
+                ehi[m] = s2 >= 0.f ? __uint_as_float(0x7F800000u) : fmaxf(t2, 0.f);
+            }
+            const unsigned char *src = P + lg * 16;
+            u32x4 buf[2][8];
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf) buf[0][nf] = lds16(src + ((nf >> 1) * 32 + perm8(lr, nf & 1)) * kStrZ2);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + 1 < 8) {
+#pragma unroll
+                    for (int nf = 0; nf < 8; ++nf)
+                        buf[(ks + 1) & 1][nf] = lds16(src + ((nf >> 1) * 32 + perm8(lr, nf & 1)) * kStrZ2 + (ks + 1) * 64);
+                }
+                SCHED_FENCE();
+#pragma unroll
+                for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[nf][m] = mfma_16x16x32_bf16(buf[ks & 1][nf], wr[ks & 3][m], acc[nf][m]);
+                SCHED_FENCE();
+                if (ks < 4) request_w<false, kFrag>(wr[ks & 3], kFrag ? ly.w1_frag : ly.w1, w, ks + 4, lr, lg);
+                SCHED_FENCE();
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int ch = w * 64 + m * 16 + lr;
+                float psum = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int node = q * 32 + lg * 8;
+                    f32x4 lo = acc[2 * q][m], hi = acc[2 * q + 1][m];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        lo[rr] = clamp_f32(fmaf(lo[rr], ea[m], eb[m]), elo[m], ehi[m]);
+                        hi[rr] = clamp_f32(fmaf(hi[rr], ea[m], eb[m]), elo[m], ehi[m]);
+                    }
+                    if (q * 32 + 32 > nr) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            lo[rr] = node + 2 * rr < nr ? lo[rr] : 0.f;
+                            hi[rr] = node + 2 * rr + 1 < nr ? hi[rr] : 0.f;
+                        }
+                    }
+                    const u32x4 hv = pack8_bf16(lo, hi);
+                    psum = sum8_bf16(hv, psum);
+                    *(u32x4 *)(Q + ch * kStrT2 + node * 2) = hv;
+                }
+                psum += wave_shfl_xor(psum, 16);
+                psum += wave_shfl_xor(psum, 32);
+                // (the row blocks of a subgraph add up in arrival order: fp32 atomics; the fused kernel zeroed the row)
+                if (lg == 0 && a.pooled) atomicAdd(&a.pooled[((int64_t)b * (L + 1) + layer + 1) * kD + ch], psum);
+            }
+        }
+        __syncthreads();
+        // ---- the row block's rows back to node-major global memory
+        for (int idx = tid; idx < (kNodes / 4) * (kD / 8); idx += kT2) {
+            const int chunk = idx & (kD / 8 - 1), node = 4 * (idx >> 5);
+            if (node < nr) {
+                u32x2 c8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) c8[e] = *(const u32x2 *)(Q + (chunk * 8 + e) * kStrT2 + node * 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (node + j < nr) {
+                        const int sh = (j & 1) * 16, h = j >> 1;
+                        u32x4 v;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            v[q] = ((c8[2 * q][h] >> sh) & 0xFFFFu) | (((c8[2 * q + 1][h] >> sh) & 0xFFFFu) << 16);
+                        *(u32x4 *)(hout + (int64_t)(row0 + node + j) * kD + chunk * 8) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" void gcc_ginw_debug_ticks(long long *device_ticks64) { g_ticks = device_ticks64; }
@@ -812,6 +1098,21 @@ extern "C" int32_t gcc_ginw_forward(const gcc_ginw_args *g, int32_t *status, gcc
     a.x_in = g->x_in; a.x_out = g->x_out; a.pooled = g->pooled; a.status = status;
     a.batch_size = g->batch_size; a.num_layers = g->num_layers;
     a.ticks = g_ticks;
+    a.big0 = a.big1 = nullptr; a.big_work = nullptr; a.big_cap = 0;
+    if (g->scratch) {
+        // [2][num_nodes][256] bf16 ping-pong rows | work list {count, -, pairs}: gcc_ginw_scratch_bytes
+        const int64_t rows = (int64_t)g->num_nodes * kD * 2;
+        const int64_t cap = g->num_nodes / kNodes + g->batch_size;
+        if (g->num_nodes < 1 || g->scratch_bytes < 2 * rows + (2 + 2 * cap) * 4 || ((uintptr_t)g->scratch & 15u)) {
+            snprintf(g_err, kErrLen, "gcc_ginw_forward: scratch of %lld bytes (16-byte aligned) needed for %lld nodes",
+                     (long long)(2 * rows + (2 + 2 * cap) * 4), (long long)g->num_nodes);
+            return -3;
+        }
+        a.big0 = (uint16_t *)g->scratch;
+        a.big1 = a.big0 + (int64_t)g->num_nodes * kD;
+        a.big_work = (int32_t *)((char *)g->scratch + 2 * rows);
+        a.big_cap = (int32_t)cap;
+    }
     for (int i = 0; i < GCC_GIN_MAX_LAYERS; ++i) {
         a.layers[i] = g->layers[i];
         const gcc_ginw_layer &l = g->layers[i];
@@ -830,6 +1131,8 @@ extern "C" int32_t gcc_ginw_forward(const gcc_ginw_args *g, int32_t *status, gcc
         (void)hipFuncSetAttribute((const void *)gin_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
         (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
+        (void)hipFuncSetAttribute((const void *)gin_wide_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
+        (void)hipFuncSetAttribute((const void *)gin_wide_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
 #ifdef GCC_GINW_ABLATE                                       // timing-only builds (make EXTRA=-DGCC_GINW_ABLATE): never in the shipped library
         (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
         (void)hipFuncSetAttribute((const void *)gin_wide2_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2);
@@ -854,8 +1157,28 @@ extern "C" int32_t gcc_ginw_forward(const gcc_ginw_args *g, int32_t *status, gcc
 #endif
         else hipLaunchKernelGGL((gin_wide2_kernel<0, true>), grid, block, kLds2, s, a);
     }
+    if (a.big_work) {
+        // subgraphs over 128 nodes: (subgraph, row block) work list, then one launch per layer (the fused launch above left
+        // them alone; nothing to do -- a few microseconds per launch -- when the batch has none)
+        bool frag = true;
+        for (int i = 0; i < g->num_layers; ++i) frag = frag && g->layers[i].w0_frag && g->layers[i].w1_frag;
+        hipLaunchKernelGGL(ginw_classify_kernel, dim3(1), dim3(256), 0, s, a);
+        const uint16_t *hin = g->x_in;
+        for (int l = 0; l < g->num_layers; ++l) {
+            uint16_t *hout = (l == g->num_layers - 1 && g->x_out) ? g->x_out : ((l & 1) ? a.big1 : a.big0);
+            if (frag) hipLaunchKernelGGL((gin_wide_big_kernel<true>), dim3(256), dim3(kT2), kLds2, s, a, l, hin, hout);
+            else hipLaunchKernelGGL((gin_wide_big_kernel<false>), dim3(256), dim3(kT2), kLds2, s, a, l, hin, hout);
+            hin = hout;
+        }
+    }
     prof_mark(prof, 1, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_ginw_forward: %s", hipGetErrorString(e)); return -10; }
     return 0;
+}
+
+extern "C" int64_t gcc_ginw_scratch_bytes(int64_t num_nodes, int32_t batch_size)
+{
+    if (num_nodes < 1 || batch_size < 1) return -1;
+    return 2 * num_nodes * kD * 2 + (2 + 2 * (num_nodes / kNodes + batch_size)) * 4;
 }

@@ -54,6 +54,7 @@ class FoldedWideGIN:
                             "gcc_ginw_pack_weights")
             self.layers.append(d)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._scratch = None             # rows in transit + work list of subgraphs over 128 nodes (gcc_ginw_scratch_bytes)
 
     @classmethod
     def from_gin(cls, gin, device):
@@ -70,7 +71,7 @@ class FoldedWideGIN:
         return cls(layers, device)
 
     def forward(self, node_off, row_ptr, col_idx, x, num_layers=None, first_layer=0, want_rows=True, want_pooled=True,
-                prof=None):
+                prof=None, big=True):
         """x: bf16 [N, 256] on the device; the CSR is the batched graph of the sampler (int32, row v = in-neighbours
         of v, global ids).  Runs layers first_layer .. first_layer + num_layers - 1 in one launch.  Returns (rows bf16 [N, 256] or None, pooled f32 [B, L + 1, 256] or None); call
         ``check_status()`` after synchronising."""
@@ -88,6 +89,13 @@ class FoldedWideGIN:
         for i in range(L):
             for k, v in self.layers[first_layer + i].items():
                 setattr(a.layers[i], k, _cabi.dev_ptr(v))
+        if big:
+            # subgraphs over 128 nodes run block by block (one launch per layer for them); without the scratch they are
+            # refused through the status word
+            need = int(self.lib.gcc_ginw_scratch_bytes(x.shape[0], B))
+            if self._scratch is None or self._scratch.numel() < need:
+                self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+            a.scratch, a.scratch_bytes, a.num_nodes = _cabi.dev_ptr(self._scratch), need, x.shape[0]
         st = torch.cuda.current_stream(self.device).cuda_stream
         _cabi.check(self.lib.gcc_ginw_forward(ctypes.byref(a), _cabi.dev_ptr(self.status),
                                               prof.handle if prof is not None else None, st), "gcc_ginw_forward")
@@ -96,7 +104,8 @@ class FoldedWideGIN:
     def check_status(self):
         s = int(self.status[0].item())
         if s & 32:
-            raise RuntimeError(f"gcc_ginw_forward: a subgraph has more than {MAX_NODES} nodes (its outputs are zero)")
+            raise RuntimeError(f"gcc_ginw_forward: a subgraph has more than {MAX_NODES} nodes and the call had no scratch "
+                               "(big=False), or more row blocks than the work list holds: its outputs are zero")
         if s & 64:
             raise RuntimeError("gcc_ginw_forward: a neighbour id lies outside its subgraph")
         return s

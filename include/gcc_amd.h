@@ -355,7 +355,7 @@ int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat, const gcc
  * SumPooling of hidden_rep[i] (gin.py:205,228), i = 0 being the input. */
 #define GCC_GINW_HIDDEN 256
 #define GCC_GINW_MAX_NODES 128
-#define GCC_STATUS_GINW_TOO_LARGE 32     /* a subgraph has more than GCC_GINW_MAX_NODES nodes: its outputs are 0 */
+#define GCC_STATUS_GINW_TOO_LARGE 32     /* a subgraph has more than GCC_GINW_MAX_NODES nodes and no scratch was given: its outputs are 0 */
 #define GCC_STATUS_GINW_BAD_EDGE 64      /* a neighbour id outside its own subgraph was skipped                 */
 typedef struct gcc_ginw_layer {
     const uint16_t *w0, *w1;             /* device [256, 256] bf16, torch Linear layout [out, in]               */
@@ -373,7 +373,16 @@ typedef struct gcc_ginw_args {
     float *pooled;                       /* device [B, num_layers + 1, 256] or NULL                              */
     int32_t batch_size, num_layers;      /* 1 <= num_layers <= GCC_GIN_MAX_LAYERS                                */
     gcc_ginw_layer layers[GCC_GIN_MAX_LAYERS];
+    /* Subgraphs over GCC_GINW_MAX_NODES nodes (ego-nets of the pre-training workload reach ~900): with scratch of
+     * gcc_ginw_scratch_bytes(num_nodes, batch_size) bytes (device, 16-byte aligned) they run block by block -- one launch
+     * per layer, one (subgraph, 128-row block) per workgroup, the block's adjacency strip taken 128 columns at a time with
+     * the products accumulating in registers, rows through two global ping-pong buffers between layers -- with the same
+     * rounding points as small subgraphs.  scratch == NULL: they are refused (GCC_STATUS_GINW_TOO_LARGE), as before. */
+    void *scratch;
+    int64_t scratch_bytes;
+    int64_t num_nodes;                   /* rows of x_in (node_off[B] <= num_nodes); used with scratch only              */
 } gcc_ginw_args;
+int64_t gcc_ginw_scratch_bytes(int64_t num_nodes, int32_t batch_size);
 /* status: device int32[1], OR of GCC_STATUS_GINW_* (zeroed by the caller).  prof marks: 0 before, 1 after. */
 int32_t gcc_ginw_forward(const gcc_ginw_args *a, int32_t *status, gcc_prof *prof, void *stream);
 /* Re-lays a [256, 256] bf16 Linear weight (torch layout) in the order gcc_ginw_forward's waves request it: fragment

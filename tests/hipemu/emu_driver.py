@@ -126,10 +126,11 @@ def emu_sample_multi(g: EmuGraph, B, run_seed, first_sample_id, num_steps, strid
     return pairs, int(status[0]), ws[: 4 * B * num_steps].view(np.int32).copy()
 
 
-def emu_ginw_forward(node_off, row_ptr, col_idx, x_bits, layers, pack=False):
+def emu_ginw_forward(node_off, row_ptr, col_idx, x_bits, layers, pack=False, scratch=False):
     """gcc_ginw_forward on the emulator.  x_bits: uint16 [N, 256] bf16 patterns; layers: dicts of numpy arrays with
     w0/w1 as uint16 bf16 patterns [256, 256] and s0..t2 float32 [256].  ``pack``: also pass the fragment-major copies
-    made by gcc_ginw_pack_weights.  Returns (rows uint16, pooled f32, status)."""
+    made by gcc_ginw_pack_weights.  ``scratch``: pass the scratch that lets subgraphs over 128 nodes run block by block.
+    Returns (rows uint16, pooled f32, status)."""
     lib = emu_lib()
     node_off = np.ascontiguousarray(node_off, dtype=np.int32)
     row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
@@ -156,6 +157,12 @@ def emu_ginw_forward(node_off, row_ptr, col_idx, x_bits, layers, pack=False):
             v = np.ascontiguousarray(ly[k], dtype=np.float32)
             keep.append(v)
             setattr(a.layers[i], k, _p(v))
+    if scratch:
+        nbytes = lib.gcc_ginw_scratch_bytes(len(x_bits), B)
+        assert nbytes > 0
+        sbuf = np.zeros(nbytes // 16 + 1, dtype=np.dtype([("a", np.uint64), ("b", np.uint64)]))      # 16-byte aligned
+        keep.append(sbuf)
+        a.scratch, a.scratch_bytes, a.num_nodes = _p(sbuf), nbytes, len(x_bits)
     rc = lib.gcc_ginw_forward(ctypes.byref(a), _p(status), None, None)
     if rc != 0:
         raise RuntimeError(lib.gcc_last_error().decode())

@@ -121,6 +121,36 @@ def test_emulated_kernel_matches_the_oracle(sizes, deg, L):
     assert rel_err(got, truth) < 2e-2
 
 
+@pytest.mark.parametrize("sizes,deg,L,pack", [([129, 40], 6, 2, True), ([300, 7, 128, 257], 5, 2, False)])
+def test_subgraphs_over_128_nodes_run_block_by_block(sizes, deg, L, pack):
+    """with scratch, subgraphs over GCC_GINW_MAX_NODES go through gin_wide_big_kernel: one launch per layer, one
+    (subgraph, 128-row block) per workgroup, the adjacency strip taken 128 columns at a time with the products
+    accumulating in registers -- the same rounding points as small subgraphs, so the same oracle at the same tolerance;
+    small subgraphs of the same batch keep the fused launch and are bit for bit what they are without scratch."""
+    rng = np.random.default_rng(sum(sizes) + L)
+    layers = random_layers(rng, L)
+    node_off, row_ptr, col_idx = random_batch(rng, sizes, deg)
+    N = int(node_off[-1])
+    x = ow.bf16_round(rng.standard_normal((N, D)).astype(np.float32))
+    rows, pooled, status = emu_ginw_forward(node_off, row_ptr, col_idx, ow.to_bf16_bits(x), bits_layers(layers), pack=pack,
+                                            scratch=True)
+    assert status == 0
+    want_rows, want_pooled = ow.gin_wide_forward(node_off, row_ptr, col_idx, x, layers, bf16=True)
+    got = ow.from_bf16_bits(rows)
+    for b, n in enumerate(sizes):
+        lo, hi = node_off[b], node_off[b + 1]
+        assert rel_err(got[lo:hi], want_rows[lo:hi]) < 2e-3, (b, n)
+        assert np.max(np.abs(got[lo:hi] - want_rows[lo:hi])) <= 2.0 ** -6 * np.max(np.abs(want_rows)), (b, n)
+        assert rel_err(pooled[b], want_pooled[b]) < 1e-3, (b, n)
+    plain_rows, plain_pooled, plain_status = emu_ginw_forward(node_off, row_ptr, col_idx, ow.to_bf16_bits(x), bits_layers(layers),
+                                                              pack=pack)
+    assert plain_status == 32                                # without scratch the big ones are refused, as before
+    for b, n in enumerate(sizes):
+        if n <= 128:
+            lo, hi = node_off[b], node_off[b + 1]
+            assert np.array_equal(rows[lo:hi], plain_rows[lo:hi]) and np.array_equal(pooled[b], plain_pooled[b])
+
+
 def test_input_pooling_and_refusals():
     rng = np.random.default_rng(7)
     layers = random_layers(rng, 1)

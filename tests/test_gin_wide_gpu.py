@@ -96,3 +96,39 @@ def test_config5_full_size_properties():
     torch.cuda.synchronize()
     assert torch.equal(rows_p.view(B, n, D)[perm].reshape(N, D), rows)
     assert torch.equal(pooled_p[perm], pooled)
+
+
+def test_subgraphs_of_129_to_1024_nodes_run_block_by_block():
+    """ego-nets of the pre-training workload reach several hundred nodes: with the scratch that
+    FoldedWideGIN passes by default, subgraphs over 128 nodes go through gin_wide_big_kernel -- (subgraph, 128-row block)
+    work items, one launch per layer, the adjacency strip 128 columns at a time -- at the oracle's tolerance for small ones;
+    the small subgraphs of the same batch are bit for bit what the fused launch gives without scratch."""
+    from gcc_amd.gin_wide import FoldedWideGIN
+
+    sizes = [129, 64, 1024, 300, 5, 128, 513, 256, 700, 0, 90]
+    got, pooled, (e_rows, e_pool, e_truth) = _run(sizes, 12, 4, seed=11)
+    assert e_rows < 5e-3 and e_pool < 2e-3 and e_truth < 3e-2 and np.isfinite(got).all()
+    # per subgraph: no block left behind
+    rng = np.random.default_rng(11)
+    layers = random_layers(rng, 4)
+    node_off, row_ptr, col_idx = random_batch(rng, sizes, 12)
+    x = ow.bf16_round(rng.standard_normal((int(node_off[-1]), D)).astype(np.float32))
+    want_rows, want_pooled = ow.gin_wide_forward(node_off, row_ptr, col_idx, x, layers, bf16=True)
+    for b, n in enumerate(sizes):
+        lo, hi = node_off[b], node_off[b + 1]
+        if n:
+            assert rel_err(got[lo:hi], want_rows[lo:hi]) < 5e-3, (b, n)
+            assert rel_err(pooled[b], want_pooled[b]) < 2e-3, (b, n)
+    # without scratch the big ones are refused (status bit 32) and the small ones are unchanged
+    dev = torch.device("cuda:0")
+    net = FoldedWideGIN([{k: torch.from_numpy(v) for k, v in ly.items()} for ly in layers], dev)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    rows0, pooled0 = net.forward(t(node_off), t(row_ptr), t(col_idx), t(x).to(torch.bfloat16), big=False)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="more than 128 nodes"):
+        net.check_status()
+    r0 = rows0.float().cpu().numpy()
+    for b, n in enumerate(sizes):
+        if 0 < n <= 128:
+            lo, hi = node_off[b], node_off[b + 1]
+            assert np.array_equal(r0[lo:hi], got[lo:hi]) and np.array_equal(pooled0[b].cpu().numpy(), pooled[b])
