@@ -577,7 +577,7 @@ def main():
         lanes = [(samplers[i], posembs[i]) for i in range(args.lanes)]
         if args.mode == "e2e":
             trainer = E2ETrainStep(model, sampler, posemb, nce_t=0.07, lanes=lanes, depth=args.depth, chunk=chunk,
-                                   ahead=args.ahead)
+                                   ahead=args.ahead, graph=False if args.no_graph else None)
             stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder fwd(q), fwd(k)",
                       "in-batch infonce (NS) fwd", "infonce bwd (dq, dk)", "gin-encoder bwd(q) + bwd(k)", "clip", "adam + meters (one launch)"]
         else:

@@ -581,7 +581,7 @@ struct DropCfg {
 // the readout kernels call this once at their top: one uniform load, in flight with their first requests
 __device__ __forceinline__ DropCfg drop_resolve(DropCfg d)
 {
-    if (d.sc && d.philox) d.seed = d.sc->dropout_seed;
+    if (d.sc && d.philox) d.seed += d.sc->dropout_seed;     // by-value seed = the pass's addend (E2E: the k pass's offset)
     return d;
 }
 __device__ __forceinline__ F4 drop_mul4(const DropCfg &d, int layer, int b, int ch)

@@ -311,7 +311,11 @@ int32_t gcc_gin_eval_fused(const gcc_gin_pass *passes, int32_t npass, float *mea
     }
     hipStream_t s = (hipStream_t)stream;
 #ifndef GCC_AMD_HIPEMU
-    (void)hipFuncSetAttribute((const void *)gin_eval_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kEvalLds);
+    static bool opted = false;                               // more than 64 KiB of dynamic LDS is opted into once
+    if (!opted) {
+        (void)hipFuncSetAttribute((const void *)gin_eval_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kEvalLds);
+        opted = true;
+    }
     if (mean_out) (void)hipMemsetAsync(mean_out, 0, (size_t)B * H * sizeof(float), s);
 #else
     if (mean_out) memset(mean_out, 0, (size_t)B * H * sizeof(float));

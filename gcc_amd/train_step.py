@@ -302,7 +302,96 @@ class FlatAdam:
                     param_groups=self.param_groups)
 
 
-class MoCoTrainStep:
+class _GraphedStep:
+    """hipGraph replay of a fused training step (shared by MoCoTrainStep and E2ETrainStep).
+
+    A step is a FIXED sequence of launches whose arguments depend only on (a) which ring slot holds the batch and (b) a few
+    scalars: lr, Adam's step count, the queue's ring pointer, the dropout key.  (b) lives in a device struct
+    (gcc_step_scalars) fed through a ring in pinned host memory: the host fills entry n before it submits step n, the
+    step's first (captured) launch copies entry (device counter mod ring) into the struct -- no launch of its own between
+    two replays.  For (a) there is one captured graph per ring slot (lanes x depth x chunk of them), captured right after the
+    slot's first eager step.  What it buys is HOST time (0.43 ms of Python + ~45 launches per step -> 0.05 ms: one host store
+    + one graph launch); the stream itself is as fast either way (tools/graph_probe.py), but the host thread also issues the
+    producer lanes' launches."""
+
+    def _graph_init(self, graph):
+        self.relaxed_streams = False        # see step(): drop the per-step stream hand-offs (bench.py / train.py loops)
+        self._joined_caller = False
+        self.use_scalars = False            # kernels read lr / ring pointer / dropout key from self.scalars (tests: eager)
+        self.use_graph = bool(self.prefetch and not self.collectives) if graph is None else bool(graph)
+        if self.use_graph and (self.dev.type != "cuda" or self.collectives):
+            raise ValueError("graph replay needs a device and no collectives inside the step")
+        if self.use_graph and self.main is None:
+            self.main = torch.cuda.Stream(self.dev, priority=-1)        # stream capture cannot run on the default stream
+        self.scalars = torch.zeros(24, dtype=torch.uint8, device=self.dev)      # sizeof(gcc_step_scalars)
+        self.ring_len = 2048
+        self.ring = torch.zeros(24 * self.ring_len, dtype=torch.uint8)
+        if self.dev.type == "cuda":
+            self.ring = self.ring.pin_memory()
+        self.ring_count = 0                                                    # host's count of ring steps
+        self.ring_counter = torch.zeros(1, dtype=torch.int64, device=self.dev)  # the device's
+        self._ring_events = []                                                  # (count, event): run-ahead guard
+        self.graphs = {}                    # ring-slot key -> (CUDAGraph, outs of the captured step)
+        self.graph_replays = 0
+
+    def _slot_key(self, q, k):
+        return tuple(t.data_ptr() for g in (q, k) for t in (g.node_off, g.edge_off, g.row_ptr, g.col_idx, g.graph_id,
+                                                            g.pos_undirected))
+
+    def _ring_guard(self):
+        """the host must stay less than a ring ahead of the device: every 256 ring steps an event is recorded, and a slot is
+        only rewritten once the event recorded 3/4 of a ring earlier has completed (in practice it always has)."""
+        if self.dev.type != "cuda":
+            return
+        n = self.ring_count
+        if n % 256 == 0:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            self._ring_events.append((n, ev))
+        while self._ring_events and self._ring_events[0][0] <= n - (self.ring_len * 3) // 4:
+            self._ring_events.pop(0)[1].synchronize()
+
+    def _run_step(self, q, k, lr, seed, enqueue_index, explicit_masks, pr, st, body):
+        """``body(scalars, pr) -> dict(loss, prob, grad_norm)`` issues the step's launches on the current stream.  Eager when
+        dropout masks are injected or the caller wants in-step event marks; otherwise the slot's graph is replayed (captured
+        after the slot's first eager step: capture records the launches without executing them)."""
+        step_marks = any(n in pr for n in ("gin_fwd", "nce_fwd", "nce_bwd", "gin_bwd"))
+        graphed = self.use_graph and not explicit_masks and not step_marks
+        scalars = self.scalars if (graphed or self.use_scalars) and not explicit_masks else None
+        if scalars is not None:
+            g0 = self.optimizer.param_groups[0]
+            self._ring_guard()
+            self.nce.fill_scalars(self.ring, self.ring_count % self.ring_len, lr, g0["betas"], self.optimizer.steps + 1,
+                                  enqueue_index, seed or 0)
+            self.ring_count += 1
+        if not graphed:
+            return body(scalars, pr)
+        key = self._slot_key(q, k)
+        hit = self.graphs.get(key)
+        if hit is not None:                                          # replay: one launch for the whole step
+            hit[0].replay()
+            self.optimizer.steps += 1
+            self.graph_replays += 1
+            return dict(hit[1])
+        out = body(scalars, pr)                                      # first time this ring slot is consumed: eager ...
+        gobj = torch.cuda.CUDAGraph()
+        steps0 = self.optimizer.steps
+        gobj.capture_begin(capture_error_mode="thread_local")        # ... then captured for the next time
+        try:
+            cap = body(scalars, {})
+        finally:
+            gobj.capture_end()
+        self.optimizer.steps = steps0                                # the captured body counted a step that did not run
+        self.graphs[key] = (gobj, dict(loss=cap["loss"], prob=cap["prob"], grad_norm=cap["grad_norm"]))
+        return out
+
+    def _fetch_scalars(self, scalars, st):
+        """first launch of a step that uses the device-resident scalars: this step's ring entry -> the device struct"""
+        if scalars is not None:
+            self.nce.fetch_scalars(scalars, self.ring, self.ring_len, self.ring_counter, stream=st)
+
+
+class MoCoTrainStep(_GraphedStep):
     def __init__(self, model: GraphEncoder, model_ema: GraphEncoder, contrast: MemoryMoCo, sampler, posemb,
                  learning_rate=0.005, betas=(0.9, 0.999), weight_decay=1e-5, clip_norm=1.0, alpha=0.999,
                  world_size=1, rank=0, prefetch=True, extra_lanes=(), depth=2, lanes=None, chunk=1, reserved_cus=0, cu_layout="interleaved",
@@ -355,35 +444,7 @@ class MoCoTrainStep:
                                       ahead=ahead)
         if not self.prefetch:
             self.producer.cuda = False
-        # ---- hipGraph replay of the step (the step's launches, not the producers')
-        # A step is a FIXED sequence of launches whose arguments depend only on (a) which ring slot holds the batch and
-        # (b) a few scalars: lr, Adam's step count, the queue's ring pointer, the dropout key.  (b) lives in a device
-        # struct (gcc_step_scalars) written by a one-thread launch in front of the replay; for (a) there is one captured
-        # graph per ring slot (lanes x depth x chunk of them), captured right after the slot's first eager step.  What it
-        # buys is HOST time (0.44 ms of Python + ~45 launches per step -> one set_scalars + one graph launch): the stream
-        # itself is as fast either way (tools/graph_probe.py), but the host thread also issues the producer lanes.
-        self.relaxed_streams = False        # see step(): drop the per-step stream hand-offs (bench.py / train.py loops)
-        self._joined_caller = False
-        self.use_scalars = False            # kernels read lr / ring pointer / dropout key from self.scalars (tests: eager)
-        self.use_graph = bool(self.prefetch and not self.collectives) if graph is None else bool(graph)
-        if self.use_graph and (self.dev.type != "cuda" or self.collectives):
-            raise ValueError("graph replay needs a device and no collectives inside the step")
-        if self.use_graph and self.main is None:
-            self.main = torch.cuda.Stream(self.dev, priority=-1)        # stream capture cannot run on the default stream
-        self.scalars = torch.zeros(24, dtype=torch.uint8, device=self.dev)      # sizeof(gcc_step_scalars)
-        # the scalars travel through a ring in pinned host memory: the host fills entry n before it submits step n, the
-        # step's first (captured) launch copies entry (device counter mod ring) into ``scalars`` -- no launch of its own
-        # between two replays (a kernel between two graph launches cost the stream 0.07 ms per step: 0.658 vs 0.589 ms in
-        # tools/graph_probe.py with gcc_step_scalars_set in front of every replay)
-        self.ring_len = 2048
-        self.ring = torch.zeros(24 * self.ring_len, dtype=torch.uint8)
-        if self.dev.type == "cuda":
-            self.ring = self.ring.pin_memory()
-        self.ring_count = 0                                                    # host's count of ring steps
-        self.ring_counter = torch.zeros(1, dtype=torch.int64, device=self.dev)  # the device's
-        self._ring_events = []                                                  # (count, event): run-ahead guard
-        self.graphs = {}                    # ring-slot key -> (CUDAGraph, outs of the captured step)
-        self.graph_replays = 0
+        self._graph_init(graph)
         model.train()                                                    # train.py:357-365
         model_ema.eval()
         for mod in model_ema.modules():
@@ -485,10 +546,6 @@ class MoCoTrainStep:
             torch.cuda.current_stream(self.dev).wait_stream(self.main)
             self._joined_caller = False          # whatever the caller enqueues next is waited for by the next step
 
-    def _slot_key(self, q, k):
-        return tuple(t.data_ptr() for g in (q, k) for t in (g.node_off, g.edge_off, g.row_ptr, g.col_idx, g.graph_id,
-                                                            g.pos_undirected))
-
     def _step(self, step, lr, prof=None):
         pr = prof or {}
         q, k = self.producer.get(step, prof=prof)
@@ -499,62 +556,19 @@ class MoCoTrainStep:
         c = self.contrast
         for grp in self.optimizer.param_groups:                          # train.py:411-416
             grp["lr"] = lr
-        step_marks = any(n in pr for n in ("gin_fwd", "nce_fwd", "nce_bwd", "gin_bwd"))
-        graphed = self.use_graph and keep is None and not step_marks
-        scalars = self.scalars if (graphed or self.use_scalars) and keep is None else None
-        if scalars is not None:
-            g0 = self.optimizer.param_groups[0]
-            self._ring_guard()
-            self.nce.fill_scalars(self.ring, self.ring_count % self.ring_len, lr, g0["betas"], self.optimizer.steps + 1,
-                                  c.index, seed or 0)
-            self.ring_count += 1
-        out = None
-        if graphed:
-            key = self._slot_key(q, k)
-            hit = self.graphs.get(key)
-            if hit is not None:                                          # replay: one launch for the whole step
-                hit[0].replay()
-                self.optimizer.steps += 1
-                self.graph_replays += 1
-                out = dict(hit[1], graph_q=q, graph_k=k)
-            else:
-                # first time this ring slot is consumed: run it eagerly (same kernels, scalars from the device struct) and
-                # capture the slot's graph afterwards -- capture records the launches without executing them
-                out = self._body(q, k, keep, seed, scalars, pr, st)
-                gobj = torch.cuda.CUDAGraph()
-                steps0 = self.optimizer.steps
-                gobj.capture_begin(capture_error_mode="thread_local")
-                try:
-                    cap = self._body(q, k, None, seed, scalars, {}, st)
-                finally:
-                    gobj.capture_end()
-                self.optimizer.steps = steps0                            # the captured body counted a step that did not run
-                self.graphs[key] = (gobj, dict(loss=cap["loss"], prob=cap["prob"], grad_norm=cap["grad_norm"]))
-        else:
-            out = self._body(q, k, keep, seed, scalars, pr, st)
+        out = self._run_step(q, k, lr, seed, c.index, keep is not None, pr, st,
+                             lambda scalars, marks: self._body(q, k, keep, seed, scalars, marks, st))
         c.index = (c.index + self.B * (self.world if self.collectives else 1)) % c.queueSize
         self.producer.release(step)
-        return out
-
-    def _ring_guard(self):
-        """the host must stay less than a ring ahead of the device: every 256 ring steps an event is recorded, and a slot is
-        only rewritten once the event recorded 3/4 of a ring earlier has completed (in practice it always has)."""
-        if self.dev.type != "cuda":
-            return
-        n = self.ring_count
-        if n % 256 == 0:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.dev))
-            self._ring_events.append((n, ev))
-        while self._ring_events and self._ring_events[0][0] <= n - (self.ring_len * 3) // 4:
-            self._ring_events.pop(0)[1].synchronize()
+        return dict(out, graph_q=q, graph_k=k)
 
     def _body(self, q, k, keep, seed, scalars, pr, st):
         """The launches of one step on the current stream (eager, or under stream capture).  ``scalars``: device
         gcc_step_scalars the Adam / enqueue / dropout kernels read instead of by-value arguments."""
-        if scalars is not None:                   # first launch of the step: this step's ring entry -> the device struct
-            self.nce.fetch_scalars(scalars, self.ring, self.ring_len, self.ring_counter, stream=st)
-        pq, bufq = self.gin.make_pass(self.model, q, training=True, keep=keep, slot=("step", 0), dropout_seed=seed,
+        self._fetch_scalars(scalars, st)
+        # (with scalars the by-value seed is an addend to the device-resident one: 0 here)
+        pq, bufq = self.gin.make_pass(self.model, q, training=True, keep=keep, slot=("step", 0),
+                                      dropout_seed=(0 if seed is not None else None) if scalars is not None else seed,
                                       scalars=scalars)
         pk, bufk = self.gin.make_pass(self.ema, k, training=True, keep=None, slot=("step", 1))
         self.gin.forward([pq, pk], stream=st, prof=pr.get("gin_fwd"))      # train.py:389-391
@@ -582,10 +596,10 @@ class MoCoTrainStep:
             self._all_gather_end(gathering)
             keys = self.keys_all
         self.nce.enqueue(c.kernel_memory(), keys, c.index, save=False, stream=st, scalars=scalars)
-        return dict(loss=outs["loss"], prob=outs["prob"], grad_norm=gnorm, graph_q=q, graph_k=k)
+        return dict(loss=outs["loss"], prob=outs["prob"], grad_norm=gnorm)
 
 
-class E2ETrainStep:
+class E2ETrainStep(_GraphedStep):
     """The E2E / in-batch-negatives step of train.py:396-417 (``--nce-k = batch_size - 1`` without ``--moco``,
     BASELINE configs[0]) as a fixed sequence of launches: both views go through ``model`` (two forward launch sets,
     one after the other, so that the BatchNorm running statistics are updated in the reference's order),
@@ -594,7 +608,8 @@ class E2ETrainStep:
     :class:`MoCoTrainStep`; single GPU (the reference has no data-parallel E2E mode)."""
 
     def __init__(self, model: GraphEncoder, sampler, posemb, nce_t=0.07, learning_rate=0.005, betas=(0.9, 0.999),
-                 weight_decay=1e-5, clip_norm=1.0, prefetch=True, depth=2, lanes=None, chunk=1, ahead=None, engine=None):
+                 weight_decay=1e-5, clip_norm=1.0, prefetch=True, depth=2, lanes=None, chunk=1, ahead=None, engine=None,
+                 graph=None):
         self.model = model
         self.sampler, self.posemb = sampler, posemb
         self.T, self.clip_norm = nce_t, clip_norm
@@ -623,6 +638,7 @@ class E2ETrainStep:
                                       chunk=chunk if self.prefetch else 1, ahead=ahead)
         if not self.prefetch:
             self.producer.cuda = False
+        self._graph_init(graph)
         model.train()
 
     def _first_id(self, step):
@@ -632,8 +648,6 @@ class E2ETrainStep:
     check_status = MoCoTrainStep.check_status
     step = MoCoTrainStep.step
     join = MoCoTrainStep.join
-    relaxed_streams = False
-    _joined_caller = False
 
     def _step(self, step, lr, prof=None):
         pr = prof or {}
@@ -642,9 +656,26 @@ class E2ETrainStep:
         p_drop = self.model.gnn.drop.p
         keep_q, keep_k = self.mask_fn() if self.mask_fn is not None else (None, None)
         s0 = (self.dropout_seed + 2 * step * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF if p_drop > 0 else None
-        s1 = (s0 + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF if s0 is not None else None
-        pq, bufq = self.gin.make_pass(self.model, q, training=True, keep=keep_q, slot=("e2e", 0), dropout_seed=s0)
-        pk, bufk = self.gin.make_pass(self.model, k, training=True, keep=keep_k, slot=("e2e", 1), dropout_seed=s1)
+        for grp in self.optimizer.param_groups:                          # train.py:411-416
+            grp["lr"] = lr
+        out = self._run_step(q, k, lr, s0, 0, keep_q is not None, pr, st,
+                             lambda scalars, marks: self._body(q, k, keep_q, keep_k, s0, scalars, marks, st))
+        self.producer.release(step)
+        return dict(out, graph_q=q, graph_k=k)
+
+    def _body(self, q, k, keep_q, keep_k, s0, scalars, pr, st):
+        self._fetch_scalars(scalars, st)
+        # the k pass's dropout key is the q pass's + the golden-ratio increment; with device-resident scalars the by-value
+        # seed of a pass is its addend to the device's (gcc_gin_pass.scalars)
+        G = 0x9E3779B97F4A7C15
+        if s0 is None:
+            sq = sk = None
+        elif scalars is not None:
+            sq, sk = 0, G
+        else:
+            sq, sk = s0, (s0 + G) & 0xFFFFFFFFFFFFFFFF
+        pq, bufq = self.gin.make_pass(self.model, q, training=True, keep=keep_q, slot=("e2e", 0), dropout_seed=sq, scalars=scalars)
+        pk, bufk = self.gin.make_pass(self.model, k, training=True, keep=keep_k, slot=("e2e", 1), dropout_seed=sk, scalars=scalars)
         self.gin.forward([pq], stream=st, prof=pr.get("gin_fwd"))          # feat_q = model(graph_q), train.py:397
         self.gin.forward([pk], stream=st)                                  # feat_k = model(graph_k), train.py:398
         feat_q, feat_k = bufq["feat"], bufk["feat"]
@@ -654,9 +685,6 @@ class E2ETrainStep:
         dq = self.nce.backward(feat_q, None, feat_k, self.T, 1, outs, self.one, by_mem_row=True, stream=st)
         self.gin.backward(self.model, pq, bufq, dq, targets=self.grad_views, stream=st, prof=pr.get("gin_bwd"))
         self.gin.backward(self.model, pk, bufk, dk, targets=self.grad_views, accumulate=True, stream=st)
-        for grp in self.optimizer.param_groups:                          # train.py:411-416
-            grp["lr"] = lr
         # clip (train.py:409) + Adam (train.py:417), train.py:418-428's meters inside the Adam launch
-        gnorm = self.optimizer.step(meters=(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], q, k))
-        self.producer.release(step)
-        return dict(loss=outs["loss"], prob=outs["prob"], grad_norm=gnorm, graph_q=q, graph_k=k)
+        gnorm = self.optimizer.step(meters=(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], q, k), scalars=scalars)
+        return dict(loss=outs["loss"], prob=outs["prob"], grad_norm=gnorm)

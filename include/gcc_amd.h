@@ -304,8 +304,9 @@ typedef struct gcc_gin_pass {    /* one encoder invocation on one batched graph 
     const int32_t *seed_local;   /* device [B] or NULL: local index of the seed node of every graph (NULL: node 0, as the
                                   * sampler emits; graph classification marks g.out_degrees().argmax(),
                                   * data_util.py:236-237 with entire_graph=True) */
-    const gcc_step_scalars *scalars;   /* device or NULL: with dropout_philox, the key is scalars->dropout_seed (read by the
-                                        * readout kernels of the forward AND the backward pass) instead of dropout_seed */
+    const gcc_step_scalars *scalars;   /* device or NULL: with dropout_philox, the key is scalars->dropout_seed + dropout_seed
+                                        * (read by the readout kernels of the forward AND the backward pass): dropout_seed is
+                                        * then the pass's fixed offset -- 0, or the second pass's of an E2E step */
 } gcc_gin_pass;
 
 /* Runs `npass` independent passes (e.g. query with model, key with model_ema)

@@ -49,12 +49,12 @@ def main():
     net = FoldedWideGIN(layers, dev)
 
     def fused():
-        return net.forward(node_off, row_ptr, col_idx, x)
+        return net.forward(node_off, row_ptr, col_idx, x, big=False)      # (every subgraph has 128 nodes: no block-tiled launches)
 
     def layerwise():
         rows = x
         for i in range(L):
-            rows, _ = net.forward(node_off, row_ptr, col_idx, rows, num_layers=1, first_layer=i)
+            rows, _ = net.forward(node_off, row_ptr, col_idx, rows, num_layers=1, first_layer=i, big=False)
         return rows
 
     def timed(fn):
