@@ -73,6 +73,7 @@ def parse_args(argv=None):
                          "sample a producer chunk per call")
     ap.add_argument("--ahead", type=int, default=None, help="chunks launched beyond the one being consumed (default lanes * (depth - 1))")
     ap.add_argument("--strict-streams", action="store_true", help="bracket every step with caller <-> step stream hand-offs (the API default; two event hops on the step's chain)")
+    ap.add_argument("--e2e-graph", action="store_true", help="--mode e2e: replay the step as a captured hipGraph (off by default: no gain measured)")
     ap.add_argument("--no-graph", action="store_true", help="issue every step launch by launch instead of replaying the captured hipGraph of its ring slot")
     ap.add_argument("--scratch-entries", type=int, default=0, help="induction scratch of the sampler (int32 slots); 0 = default")
     ap.add_argument("--edge-cap", type=int, default=0, help="edge capacity of a batch view; 0 = default")
@@ -577,7 +578,7 @@ def main():
         lanes = [(samplers[i], posembs[i]) for i in range(args.lanes)]
         if args.mode == "e2e":
             trainer = E2ETrainStep(model, sampler, posemb, nce_t=0.07, lanes=lanes, depth=args.depth, chunk=chunk,
-                                   ahead=args.ahead, graph=False if args.no_graph else None)
+                                   ahead=args.ahead, graph=args.e2e_graph and not args.no_graph)
             stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder fwd(q), fwd(k)",
                       "in-batch infonce (NS) fwd", "infonce bwd (dq, dk)", "gin-encoder bwd(q) + bwd(k)", "clip", "adam + meters (one launch)"]
         else:

@@ -216,6 +216,7 @@ SIGNATURES = {
     "gcc_queue_enqueue_scalars": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                                    ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_ginw_scratch_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32]),
+    "gcc_gin_eval_debug_ticks": (None, [ctypes.c_void_p]),
     "gcc_gin_eval_fused": (ctypes.c_int32, [ctypes.POINTER(GccGinPass), ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_step_scalars_fill": (None, [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int32,
                                       ctypes.c_int32, ctypes.c_uint64]),

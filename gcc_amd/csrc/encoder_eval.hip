@@ -40,7 +40,9 @@ struct EvalArgs {
     int32_t B, L, pos_dim, emb_dim, max_degree, mult, normalize, hid, kdim0;
     float eps, norm_eps;
 };
-struct EvalLaunch { EvalArgs p[kMaxPass]; };
+struct EvalLaunch { EvalArgs p[kMaxPass]; long long *ticks; };
+static long long *g_eval_ticks = nullptr;    // diagnostics (gcc_gin_eval_debug_ticks): device int64[16]
+#define EV_TICK(ph) do { if (Ln.ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&Ln.ticks[(ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 
 constexpr int kEvalLds = (kEvalCap * kEvalLd + kTile * kLdt + 2 * H * kLdt + 32 * H + 6 * H + 2 * H) * 4   // A, T, Wl0, Wl1, part, tables, biases
                          + (GCC_GIN_MAX_LAYERS + 1) * H * 8 + 4 * H * 8                                      // pooled sums (fp64) + their partials
@@ -62,6 +64,7 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
     int *prow = rpl + kTile + 1;                                // [32]
 
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
+    long long tick_ = Ln.ticks ? device_ticks() : 0;
     const int b = (int)blockIdx.x;
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
     const bool in_lds = n <= kEvalCap;                           // (workgroup-uniform)
@@ -136,7 +139,9 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
         if (tid < H) pool[i * H + tid] = (ppart[tid] + ppart[H + tid]) + (ppart[2 * H + tid] + ppart[3 * H + tid]);
         __syncthreads();
     };
+    EV_TICK(0);                                                  // features
     pool_rows(0);
+    EV_TICK(1);                                                  // pooling
     if (n <= 0)                                                   // (workgroup-uniform)
         for (int i = tid; i < L * H; i += kThreads) pool[H + i] = 0.0;
     __syncthreads();
@@ -145,6 +150,7 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
         store_layer(l, regs);
         if (l + 1 < L) regs = request_layer(l + 1);              // in flight during this layer
         __syncthreads();
+        EV_TICK(2);                                              // weights -> LDS
         const float *src = cur;
         auto load = [&](int u) -> F4 {                           // row u (batched id) of the current representation
             // (gather_tile asks for row 0 in lanes without an edge: clamped into the subgraph, the value is not used)
@@ -168,8 +174,10 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
                 }
             }
             __syncthreads();
+            EV_TICK(3);                                          // own rows
             // 2. GINConv aggregate: h_v + sum_{u -> v} h_u (eps = 0; gin.py:179-185,218); every CSR edge counts `mult` times
             gather_tile<8>(T, part, prow, nrows, a.col_idx, load, ident, (float)a.mult, rpl);
+            EV_TICK(4);                                          // gather
             // 3. the MLP and the three BatchNorm / ReLU stages on the wave's 16 rows, in registers
             {
                 const int j = lane & 15, q = lane >> 4, rl = 16 * wv + j;
@@ -216,6 +224,7 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
                 }
             }
             __syncthreads();                                     // T, rpl and the side slots are reused by the next tile
+            EV_TICK(5);                                          // the two Linears + affines
         }
         // ---- the layer's output becomes the current representation
         if (!single) {
@@ -228,7 +237,9 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
                 __syncthreads();
             }
         }
+        EV_TICK(6);                                              // mirror
         pool_rows(l + 1);
+        EV_TICK(1);
     }
 
     // ---- readout: score = sum_i linears_prediction[i](pooled_i) (gin.py:227-230; eval: dropout is the identity),
@@ -261,11 +272,17 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
             if (a.pooled) for (int i = 0; i <= L; ++i) a.pooled[((int64_t)i * a.B + b) * H + tid] = pool[i * H + tid];
         }
     }
+    EV_TICK(7);                                                  // readout
+    if (Ln.ticks && tid == 0) atomicAdd((unsigned long long *)&Ln.ticks[15], 1ull);
 }
 
 }  // namespace
 
 extern "C" {
+
+/* diagnostics, as gcc_gin_debug_ticks: device int64[16] of wall-clock ticks per phase of gcc_gin_eval_fused (features,
+ * pooling, weights, own rows, gather, Linears, mirror, readout; [15] = workgroups); NULL switches it off */
+void gcc_gin_eval_debug_ticks(long long *device_ticks64) { g_eval_ticks = device_ticks64; }
 
 int32_t gcc_gin_eval_fused(const gcc_gin_pass *passes, int32_t npass, float *mean_out, void *stream)
 {
@@ -275,6 +292,7 @@ int32_t gcc_gin_eval_fused(const gcc_gin_pass *passes, int32_t npass, float *mea
     }
     EvalLaunch Ln;
     memset(&Ln, 0, sizeof(Ln));
+    Ln.ticks = g_eval_ticks;
     const int B = passes[0].batch_size;
     for (int i = 0; i < npass; ++i) {
         const gcc_gin_pass &p = passes[i];

@@ -638,7 +638,9 @@ class E2ETrainStep(_GraphedStep):
                                       chunk=chunk if self.prefetch else 1, ahead=ahead)
         if not self.prefetch:
             self.producer.cuda = False
-        self._graph_init(graph)
+        # graph replay is available but OFF by default here: measured 1.241 vs 1.240 ms per step at bsz 256 and 0.872 vs
+        # 0.806 ms at bsz 32 (scripts/gpu/r4_call8.sh) -- the E2E step waits for its own latency chain, not for the host
+        self._graph_init(False if graph is None else graph)
         model.train()
 
     def _first_id(self, step):
