@@ -40,9 +40,230 @@ struct EvalArgs {
     int32_t B, L, pos_dim, emb_dim, max_degree, mult, normalize, hid, kdim0;
     float eps, norm_eps;
 };
-struct EvalLaunch { EvalArgs p[kMaxPass]; long long *ticks; };
+struct EvalLaunch { EvalArgs p[kMaxPass]; long long *ticks; int32_t split; };   // split: small subgraphs are gin_eval_small_kernel's
 static long long *g_eval_ticks = nullptr;    // diagnostics (gcc_gin_eval_debug_ticks): device int64[16]
 #define EV_TICK(ph) do { if (Ln.ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&Ln.ticks[(ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
+
+// ---- pieces shared by the two kernel shapes ------------------------------------------------------------------------------
+// a layer's weights / BatchNorm numbers are requested one layer ahead (registers) and stored when the LDS buffers are free
+struct LayerRegs { WStage s0, s1; float v0, v1, v2, v3; };
+__device__ __forceinline__ LayerRegs eval_request_layer(const EvalArgs &a, int l)
+{
+    const EvalLayer &ly = a.layer[l];
+    const int tid = (int)threadIdx.x;
+    LayerRegs r;
+    r.s0 = stage_weights_request(ly.w0, l == 0 ? a.kdim0 : a.hid);
+    r.s1 = stage_weights_request(ly.w1, a.hid);
+    const int c = tid & 63, which = tid >> 6;                    // which < 3: a BatchNorm; 3: the two biases
+    r.v2 = r.v3 = 0.f;
+    if (which < 3) { r.v0 = ly.bn_w[which][c]; r.v1 = ly.bn_b[which][c]; r.v2 = ly.bn_rm[which][c]; r.v3 = ly.bn_rv[which][c]; }
+    else { r.v0 = ly.b0 ? ly.b0[c] : 0.f; r.v1 = ly.b1 ? ly.b1[c] : 0.f; }
+    return r;
+}
+__device__ __forceinline__ void eval_store_layer(const EvalArgs &a, int l, const LayerRegs &r, float *Wl0, float *Wl1, float *tab,
+                                                 float *bias)
+{
+    const int tid = (int)threadIdx.x;
+    stage_weights_store(Wl0, r.s0, l == 0 ? a.kdim0 : a.hid);
+    stage_weights_store(Wl1, r.s1, a.hid);
+    const int c = tid & 63, which = tid >> 6;
+    if (which < 3) {                                             // bn_scale_shift_from(training = 0), encoder_common.h
+        const double rstd = 1.0 / sqrt((double)r.v3 + (double)a.eps);
+        tab[which * 2 * H + c] = (float)((double)r.v0 * rstd);
+        tab[which * 2 * H + H + c] = (float)((double)r.v1 - (double)r.v2 * (double)r.v0 * rstd);
+    } else {
+        bias[c] = r.v0;
+        bias[H + c] = r.v1;
+    }
+}
+// input features of local row r (graph_encoder.py:158-165), channels 4 t .. 4 t + 3
+__device__ __forceinline__ F4 eval_feature4(const EvalArgs &a, int n0, int r, int sl, int t)
+{
+    const int dtot = a.pos_dim + a.emb_dim;
+    const int v = n0 + r;
+    const int deg = (a.row_ptr[v + 1] - a.row_ptr[v]) * a.mult;                  // g.in_degrees(), :154
+    const int dcl = deg < a.max_degree ? deg : a.max_degree;                     // clamp(0, max_degree), :161
+    F4 x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * t + e;
+        const float *src = c < a.pos_dim ? a.pos + (int64_t)v * a.pos_dim + c
+                                         : a.emb + (int64_t)dcl * a.emb_dim + (c < dtot ? c - a.pos_dim : 0);
+        const float val = *src;
+        at(x, e) = c < dtot ? val : (c == dtot && r == sl ? 1.f : 0.f);           // ndata["seed"], data_util.py:234-238
+    }
+    return x;
+}
+// the MLP and the three BatchNorm / ReLU stages on a wave's 16 rows, in registers: xb[c] = agg[row j][16 c + 4 q ..] in,
+// h[cb] = the new representation's channels 16 cb + 4 q .. out (the MFMA's output layout is the next product's input layout)
+__device__ __forceinline__ void eval_mlp_rows16(const F4 xb[4], const float *Wl0, const float *Wl1, const float *tab,
+                                                const float *bias, int j, int q, F4 h[4])
+{
+    F4 y[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {                             // z1 = agg W0^T + b0; relu(bn_a(z1))  (gin.py:113-116)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const F4 wf = ld4(&Wl0[(16 * cb + j) * kLdt + 16 * c + 4 * q]);
+            acc = mfma_16x16x4_f32(wf.x, xb[c].x, acc);
+            acc = mfma_16x16x4_f32(wf.y, xb[c].y, acc);
+            acc = mfma_16x16x4_f32(wf.z, xb[c].z, acc);
+            acc = mfma_16x16x4_f32(wf.w, xb[c].w, acc);
+        }
+        const int ch = 16 * cb + 4 * q;
+        const F4 b4 = ld4(&bias[ch]);
+        const F4 z = {acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w};
+        y[cb] = affine_relu(z, aff4_from_table(tab, ch));
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {                             // z2 = y W1^T + b1; relu(bn_b(z2)); relu(bn_c(.))  (gin.py:55-57,219-220)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const F4 wf = ld4(&Wl1[(16 * cb + j) * kLdt + 16 * c + 4 * q]);
+            acc = mfma_16x16x4_f32(wf.x, y[c].x, acc);
+            acc = mfma_16x16x4_f32(wf.y, y[c].y, acc);
+            acc = mfma_16x16x4_f32(wf.z, y[c].z, acc);
+            acc = mfma_16x16x4_f32(wf.w, y[c].w, acc);
+        }
+        const int ch = 16 * cb + 4 * q;
+        const F4 b4 = ld4(&bias[H + ch]);
+        const F4 z = {acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w};
+        h[cb] = affine_relu(affine_relu(z, aff4_from_table(tab + 2 * H, ch)), aff4_from_table(tab + 4 * H, ch));
+    }
+}
+// readout: score = sum_i linears_prediction[i](pooled_i) (gin.py:227-230; eval: dropout is the identity), F.normalize
+// (graph_encoder.py:195-196), the mean over the passes, the pooled sums.  pool: LDS [L + 1][64] fp64; ppart: LDS scratch
+__device__ __forceinline__ void eval_readout(const EvalArgs &a, int b, const double *pool, double *ppart)
+{
+    const int tid = (int)threadIdx.x, L = a.L;
+    const int o = tid & 63, pt = tid >> 6;
+    float s = 0.f;
+    for (int i = pt; i <= L; i += 4) {
+        const int kd = i == 0 ? a.kdim0 : a.hid;
+        const float *w = a.pred_w[i] + (int64_t)o * kd;
+        float acc = a.pred_b[i] ? a.pred_b[i][o] : 0.f;
+        for (int k = 0; k < kd; ++k) acc = fmaf(w[k], (float)pool[i * H + k], acc);
+        s += acc;
+    }
+    float *sp = (float *)ppart;                                  // [4][64] partial scores
+    sp[pt * H + o] = s;
+    __syncthreads();
+    if (tid < H) {
+        const float sc = (sp[tid] + sp[H + tid]) + (sp[2 * H + tid] + sp[3 * H + tid]);
+        float ss = sc * sc;
+        ss = wave_sum(ss);                                       // (the first wave holds all 64 channels)
+        float f = sc;
+        if (a.normalize) {
+            const float nrm = sqrtf(ss);
+            f = sc / (nrm > a.norm_eps ? nrm : a.norm_eps);
+        }
+        a.score[(int64_t)b * H + tid] = sc;
+        a.feat[(int64_t)b * H + tid] = f;
+        if (a.mean_out) atomicAdd(&a.mean_out[(int64_t)b * H + tid], a.mean_w * f);
+        if (a.pooled) for (int i = 0; i <= L; ++i) a.pooled[((int64_t)i * a.B + b) * H + tid] = pool[i * H + tid];
+    }
+}
+
+// ---- small subgraphs (n <= 64 rows, at most kSmallEdges CSR entries): the common case (median ego-net 23 .. 55 nodes) ----------
+// One tile, nothing but the weights comes from global memory after the set-up: the subgraph's local column ids sit in LDS as
+// bytes, every lane sums ITS row's neighbours straight into the registers the first matrix product reads (lane (j, q) of wave w
+// owns row 16 w + j, channels 16 c + 4 q ..: the four lanes of a row read different quads of a neighbour's row, so nothing is
+// read twice and there is no staging tile, no side slots, no barrier inside the aggregation), the layer's result goes back into
+// the same rows after one barrier.  69 KB of LDS: two workgroups per CU (the general kernel below: 142 KB, one).
+constexpr int kSmallCap = kTile;
+constexpr int kSmallEdges = 6144;
+constexpr int kSmallLds = (kSmallCap * kEvalLd + 2 * H * kLdt + 6 * H + 2 * H) * 4 + (GCC_GIN_MAX_LAYERS + 1) * H * 8 + 4 * H * 8
+                          + 68 * 4 + kSmallEdges;
+__device__ __forceinline__ bool eval_is_small(int n, int nnz) { return n <= kSmallCap && nnz <= kSmallEdges; }
+
+__global__ __launch_bounds__(kThreads, 2) void gin_eval_small_kernel(EvalLaunch Ln)
+{
+    DYN_SMEM(smem);
+    const EvalArgs &a = Ln.p[blockIdx.y];
+    float *A = (float *)smem;                                   // [64][kEvalLd]
+    float *Wl0 = A + kSmallCap * kEvalLd, *Wl1 = Wl0 + H * kLdt;
+    float *tab = Wl1 + H * kLdt;
+    float *bias = tab + 6 * H;
+    double *pool = (double *)(bias + 2 * H);
+    double *ppart = pool + (GCC_GIN_MAX_LAYERS + 1) * H;
+    int *rp = (int *)(ppart + 4 * H);                           // [65] local row pointers
+    uint8_t *cols = (uint8_t *)(rp + 68);                       // [nnz] local column ids
+    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
+    long long tick_ = Ln.ticks ? device_ticks() : 0;
+    const int b = (int)blockIdx.x;
+    const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+    const int e0 = a.row_ptr[n0], nnz = a.row_ptr[n0 + n] - e0;
+    if (!eval_is_small(n, nnz)) return;                          // (workgroup-uniform) the general kernel's
+    const int L = a.L;
+    LayerRegs regs = eval_request_layer(a, 0);
+    {
+        const int sl = a.seed_local ? a.seed_local[b] : 0;
+        for (int r = gi; r < n; r += 16) st4(&A[r * kEvalLd + 4 * t], eval_feature4(a, n0, r, sl, t));
+        if (tid <= n) rp[tid] = a.row_ptr[n0 + tid] - e0;
+        for (int e = tid; e < nnz; e += kThreads) cols[e] = (uint8_t)(a.col_idx[e0 + e] - n0);
+    }
+    __syncthreads();
+    auto pool_rows = [&](int i) {
+        const int c = tid & 63, pt = tid >> 6;
+        double acc = 0.0;
+        for (int r = pt; r < n; r += 4) acc += (double)A[r * kEvalLd + c];
+        ppart[pt * H + c] = acc;
+        __syncthreads();
+        if (tid < H) pool[i * H + tid] = (ppart[tid] + ppart[H + tid]) + (ppart[2 * H + tid] + ppart[3 * H + tid]);
+        __syncthreads();
+    };
+    EV_TICK(0);
+    pool_rows(0);
+    EV_TICK(1);
+    if (n <= 0)
+        for (int i = tid; i < L * H; i += kThreads) pool[H + i] = 0.0;
+    __syncthreads();
+    const int j = lane & 15, q = lane >> 4, row = 16 * wv + j;
+    const float mult = (float)a.mult;
+    for (int l = 0; l < (n > 0 ? L : 0); ++l) {
+        eval_store_layer(a, l, regs, Wl0, Wl1, tab, bias);
+        if (l + 1 < L) regs = eval_request_layer(a, l + 1);       // in flight during this layer
+        __syncthreads();
+        EV_TICK(2);
+        // GINConv aggregate (eps = 0; gin.py:179-185,218) of this lane's row and channel quads, neighbours in CSR order
+        F4 xb[4];
+        {
+            const bool live = row < n;
+            const int rb = live ? rp[row] : 0, re = live ? rp[row + 1] : 0;
+            F4 acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = F4{0.f, 0.f, 0.f, 0.f};
+            for (int e = rb; e < re; ++e) {                      // (lanes of shorter rows wait: a wave runs its longest row)
+                const float *src = &A[(int)cols[e] * kEvalLd + 4 * q];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = add4(acc[c], ld4(src + 16 * c));
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const F4 self = live ? ld4(&A[row * kEvalLd + 16 * c + 4 * q]) : F4{0.f, 0.f, 0.f, 0.f};
+                xb[c].x = fmaf(mult, acc[c].x, self.x); xb[c].y = fmaf(mult, acc[c].y, self.y);
+                xb[c].z = fmaf(mult, acc[c].z, self.z); xb[c].w = fmaf(mult, acc[c].w, self.w);
+            }
+        }
+        EV_TICK(4);
+        F4 h[4];
+        eval_mlp_rows16(xb, Wl0, Wl1, tab, bias, j, q, h);
+        __syncthreads();                                         // every lane has read what it needs of the old rows
+        if (row < n) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) st4(&A[row * kEvalLd + 16 * cb + 4 * q], h[cb]);
+        }
+        __syncthreads();
+        EV_TICK(5);
+        pool_rows(l + 1);
+        EV_TICK(1);
+    }
+    eval_readout(a, b, pool, ppart);
+    EV_TICK(7);
+    if (Ln.ticks && tid == 0) atomicAdd((unsigned long long *)&Ln.ticks[15], 1ull);
+}
 
 constexpr int kEvalLds = (kEvalCap * kEvalLd + kTile * kLdt + 2 * H * kLdt + 32 * H + 6 * H + 2 * H) * 4   // A, T, Wl0, Wl1, part, tables, biases
                          + (GCC_GIN_MAX_LAYERS + 1) * H * 8 + 4 * H * 8                                      // pooled sums (fp64) + their partials
@@ -77,53 +298,16 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
     // multi-die part an agent-scope release writes L2 back: 40 us per layer with 256 workgroups doing it, measured)
     const bool single = in_lds && n <= kTile;                    // one tile: the layer updates A in place, nothing leaves LDS
 
-    // this layer's weights / BatchNorm numbers are requested one layer ahead (registers), stored when the buffers are free
-    struct LayerRegs { WStage s0, s1; float v0, v1, v2, v3; };
-    auto request_layer = [&](int l) -> LayerRegs {
-        const EvalLayer &ly = a.layer[l];
-        LayerRegs r;
-        r.s0 = stage_weights_request(ly.w0, l == 0 ? a.kdim0 : a.hid);
-        r.s1 = stage_weights_request(ly.w1, a.hid);
-        const int c = tid & 63, which = tid >> 6;                // which < 3: a BatchNorm; 3: the two biases
-        r.v2 = r.v3 = 0.f;
-        if (which < 3) { r.v0 = ly.bn_w[which][c]; r.v1 = ly.bn_b[which][c]; r.v2 = ly.bn_rm[which][c]; r.v3 = ly.bn_rv[which][c]; }
-        else { r.v0 = ly.b0 ? ly.b0[c] : 0.f; r.v1 = ly.b1 ? ly.b1[c] : 0.f; }
-        return r;
-    };
-    auto store_layer = [&](int l, const LayerRegs &r) {
-        stage_weights_store(Wl0, r.s0, l == 0 ? a.kdim0 : a.hid);
-        stage_weights_store(Wl1, r.s1, a.hid);
-        const int c = tid & 63, which = tid >> 6;
-        if (which < 3) {                                         // bn_scale_shift_from(training = 0), encoder_common.h
-            const double rstd = 1.0 / sqrt((double)r.v3 + (double)a.eps);
-            tab[which * 2 * H + c] = (float)((double)r.v0 * rstd);
-            tab[which * 2 * H + H + c] = (float)((double)r.v1 - (double)r.v2 * (double)r.v0 * rstd);
-        } else {
-            bias[c] = r.v0;
-            bias[H + c] = r.v1;
-        }
-    };
-    LayerRegs regs = request_layer(0);                           // (n == 0: harmless)
+    if (Ln.split && eval_is_small(n, a.row_ptr[n0 + n] - a.row_ptr[n0])) return;     // (workgroup-uniform) gin_eval_small_kernel's
+    LayerRegs regs = eval_request_layer(a, 0);                   // (n == 0: harmless)
 
     // ---- hidden_rep[0]: input features (graph_encoder.py:158-165) -> A (LDS) or, for a big subgraph, cur (global)
     {
-        const int dtot = a.pos_dim + a.emb_dim;
         const int sl = a.seed_local ? a.seed_local[b] : 0;
         for (int r = gi; r < n; r += 16) {
-            const int v = n0 + r;
-            const int deg = (a.row_ptr[v + 1] - a.row_ptr[v]) * a.mult;          // g.in_degrees(), :154
-            const int dcl = deg < a.max_degree ? deg : a.max_degree;             // clamp(0, max_degree), :161
-            F4 x;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = 4 * t + e;
-                const float *src = c < a.pos_dim ? a.pos + (int64_t)v * a.pos_dim + c
-                                                 : a.emb + (int64_t)dcl * a.emb_dim + (c < dtot ? c - a.pos_dim : 0);
-                const float val = *src;
-                at(x, e) = c < dtot ? val : (c == dtot && r == sl ? 1.f : 0.f);   // ndata["seed"], data_util.py:234-238
-            }
+            const F4 x = eval_feature4(a, n0, r, sl, t);
             if (in_lds) st4(&A[r * kEvalLd + 4 * t], x);
-            else st4(cur + (int64_t)v * H + 4 * t, x);
+            else st4(cur + (int64_t)(n0 + r) * H + 4 * t, x);
         }
     }
     __syncthreads();
@@ -147,8 +331,8 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
     __syncthreads();
 
     for (int l = 0; l < (n > 0 ? L : 0); ++l) {
-        store_layer(l, regs);
-        if (l + 1 < L) regs = request_layer(l + 1);              // in flight during this layer
+        eval_store_layer(a, l, regs, Wl0, Wl1, tab, bias);
+        if (l + 1 < L) regs = eval_request_layer(a, l + 1);       // in flight during this layer
         __syncthreads();
         EV_TICK(2);                                              // weights -> LDS
         const float *src = cur;
@@ -184,42 +368,14 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
                 F4 xb[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) xb[c] = ld4(&T[rl * kLdt + 16 * c + 4 * q]);
-                F4 y[4];
+                F4 h[4];
+                eval_mlp_rows16(xb, Wl0, Wl1, tab, bias, j, q, h);
+                if (rl < nrows) {
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {                 // z1 = agg W0^T + b0; relu(bn_a(z1))  (gin.py:113-116)
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const F4 wf = ld4(&Wl0[(16 * cb + j) * kLdt + 16 * c + 4 * q]);
-                        acc = mfma_16x16x4_f32(wf.x, xb[c].x, acc);
-                        acc = mfma_16x16x4_f32(wf.y, xb[c].y, acc);
-                        acc = mfma_16x16x4_f32(wf.z, xb[c].z, acc);
-                        acc = mfma_16x16x4_f32(wf.w, xb[c].w, acc);
-                    }
-                    const int ch = 16 * cb + 4 * q;
-                    const F4 b4 = ld4(&bias[ch]);
-                    const F4 z = {acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w};
-                    y[cb] = affine_relu(z, aff4_from_table(tab, ch));
-                }
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {                 // z2 = y W1^T + b1; relu(bn_b(z2)); relu(bn_c(.))  (gin.py:55-57,219-220)
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const F4 wf = ld4(&Wl1[(16 * cb + j) * kLdt + 16 * c + 4 * q]);
-                        acc = mfma_16x16x4_f32(wf.x, y[c].x, acc);
-                        acc = mfma_16x16x4_f32(wf.y, y[c].y, acc);
-                        acc = mfma_16x16x4_f32(wf.z, y[c].z, acc);
-                        acc = mfma_16x16x4_f32(wf.w, y[c].w, acc);
-                    }
-                    const int ch = 16 * cb + 4 * q;
-                    const F4 b4 = ld4(&bias[H + ch]);
-                    const F4 z = {acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w};
-                    const F4 h = affine_relu(affine_relu(z, aff4_from_table(tab + 2 * H, ch)), aff4_from_table(tab + 4 * H, ch));
-                    if (rl < nrows) {
+                    for (int cb = 0; cb < 4; ++cb) {
                         // (single tile: every read of A by this layer's gather is behind gather_tile's closing barrier)
-                        if (single) st4(&A[rl * kEvalLd + ch], h);
-                        else st4(nxt + (int64_t)(n0 + tile0 + rl) * H + ch, h);
+                        if (single) st4(&A[rl * kEvalLd + 16 * cb + 4 * q], h[cb]);
+                        else st4(nxt + (int64_t)(n0 + tile0 + rl) * H + 16 * cb + 4 * q, h[cb]);
                     }
                 }
             }
@@ -242,36 +398,7 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
         EV_TICK(1);
     }
 
-    // ---- readout: score = sum_i linears_prediction[i](pooled_i) (gin.py:227-230; eval: dropout is the identity),
-    // F.normalize (graph_encoder.py:195-196)
-    {
-        const int o = tid & 63, pt = tid >> 6;
-        float s = 0.f;
-        for (int i = pt; i <= L; i += 4) {
-            const int kd = i == 0 ? a.kdim0 : a.hid;
-            const float *w = a.pred_w[i] + (int64_t)o * kd;
-            float acc = a.pred_b[i] ? a.pred_b[i][o] : 0.f;
-            for (int k = 0; k < kd; ++k) acc = fmaf(w[k], (float)pool[i * H + k], acc);
-            s += acc;
-        }
-        float *sp = (float *)ppart;                              // [4][64] partial scores, then [64] squares
-        sp[pt * H + o] = s;
-        __syncthreads();
-        if (tid < H) {
-            const float sc = (sp[tid] + sp[H + tid]) + (sp[2 * H + tid] + sp[3 * H + tid]);
-            float ss = sc * sc;
-            ss = wave_sum(ss);                                   // (the first wave holds all 64 channels)
-            float f = sc;
-            if (a.normalize) {
-                const float nrm = sqrtf(ss);
-                f = sc / (nrm > a.norm_eps ? nrm : a.norm_eps);
-            }
-            a.score[(int64_t)b * H + tid] = sc;
-            a.feat[(int64_t)b * H + tid] = f;
-            if (a.mean_out) atomicAdd(&a.mean_out[(int64_t)b * H + tid], a.mean_w * f);
-            if (a.pooled) for (int i = 0; i <= L; ++i) a.pooled[((int64_t)i * a.B + b) * H + tid] = pool[i * H + tid];
-        }
-    }
+    eval_readout(a, b, pool, ppart);
     EV_TICK(7);                                                  // readout
     if (Ln.ticks && tid == 0) atomicAdd((unsigned long long *)&Ln.ticks[15], 1ull);
 }
@@ -332,12 +459,16 @@ int32_t gcc_gin_eval_fused(const gcc_gin_pass *passes, int32_t npass, float *mea
     static bool opted = false;                               // more than 64 KiB of dynamic LDS is opted into once
     if (!opted) {
         (void)hipFuncSetAttribute((const void *)gin_eval_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kEvalLds);
+        (void)hipFuncSetAttribute((const void *)gin_eval_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLds);
         opted = true;
     }
     if (mean_out) (void)hipMemsetAsync(mean_out, 0, (size_t)B * H * sizeof(float), s);
 #else
     if (mean_out) memset(mean_out, 0, (size_t)B * H * sizeof(float));
 #endif
+    // two launches over the same grid: subgraphs of at most 64 nodes in the two-per-CU kernel, the rest in the general one
+    Ln.split = 1;
+    hipLaunchKernelGGL(gin_eval_small_kernel, dim3(B, npass), dim3(kThreads), kSmallLds, s, Ln);
     hipLaunchKernelGGL(gin_eval_fused_kernel, dim3(B, npass), dim3(kThreads), kEvalLds, s, Ln);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
