@@ -314,6 +314,8 @@ class _GraphedStep:
     + one graph launch); the stream itself is as fast either way (tools/graph_probe.py), but the host thread also issues the
     producer lanes' launches."""
 
+    RING_LEN = 2048                         # entries of the pinned scalars ring (tests shrink it to exercise the wrap)
+
     def _graph_init(self, graph):
         self.relaxed_streams = False        # see step(): drop the per-step stream hand-offs (bench.py / train.py loops)
         self._joined_caller = False
@@ -324,7 +326,7 @@ class _GraphedStep:
         if self.use_graph and self.main is None:
             self.main = torch.cuda.Stream(self.dev, priority=-1)        # stream capture cannot run on the default stream
         self.scalars = torch.zeros(24, dtype=torch.uint8, device=self.dev)      # sizeof(gcc_step_scalars)
-        self.ring_len = 2048
+        self.ring_len = int(self.RING_LEN)
         self.ring = torch.zeros(24 * self.ring_len, dtype=torch.uint8)
         if self.dev.type == "cuda":
             self.ring = self.ring.pin_memory()
@@ -339,12 +341,13 @@ class _GraphedStep:
                                                             g.pos_undirected))
 
     def _ring_guard(self):
-        """the host must stay less than a ring ahead of the device: every 256 ring steps an event is recorded, and a slot is
-        only rewritten once the event recorded 3/4 of a ring earlier has completed (in practice it always has)."""
+        """the host must stay less than a ring ahead of the device: every ring_len / 8 ring steps an event is recorded, and a
+        slot is only rewritten once the event recorded 3/4 of a ring earlier has completed (in practice it always has)."""
         if self.dev.type != "cuda":
             return
         n = self.ring_count
-        if n % 256 == 0:
+        every = max(1, self.ring_len // 8)
+        if n % every == 0:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.dev))
             self._ring_events.append((n, ev))
