@@ -301,8 +301,8 @@ class GraphEncoder(nn.Module):
         if not self.is_padded() or t.dim() == 0 or t.shape[0] not in (self.hidden, self.output_dim) or t.shape[0] == H:
             return t.numel()
         ids = getattr(self, "_chan_ids", None)
-        if ids is None or id(t) not in ids:
-            self._chan_ids = ids = {id(getattr(m, a)) for _, m, a, _ in self._channel_tensors()}
+        if ids is None:          # the channel-indexed PARAMETERS (nn.Parameter objects keep their identity; only .data is re-homed)
+            self._chan_ids = ids = {id(getattr(m, a)) for _, m, a, is_param in self._channel_tensors() if is_param}
         return (t.numel() // t.shape[0]) * H if id(t) in ids else t.numel()
 
     def padded_zeros_like(self, t):
