@@ -47,6 +47,7 @@ class GccSampleParams(ctypes.Structure):
         ("restart_u32", ctypes.c_uint32),
         ("seeds", ctypes.c_void_p),
         ("prof", ctypes.c_void_p),
+        ("hub_degree", ctypes.c_int32),
     ]
 
 

@@ -69,6 +69,14 @@ constexpr int kRecInts = 12;       // per induce workgroup: {count, g, part, n, 
 constexpr int kPrefixThreads = 1024;
 constexpr int kCandCap = 256;      // per-wave queue of Bloom survivors (drained before every round of 256 that might not fit)
 constexpr int kPackParts = 4;      // pack workgroups per subgraph (hub-seed subgraphs have 100x the units)
+// Hub rows are NOT scanned (round 4).  The parent graph is symmetric (the input contract, x2dgl.py:43-47): member v's row
+// holds hub H exactly when H's row holds v, so every edge (H -> v) of the induced subgraph is the mirror image of a hit
+// (v -> H) found while scanning v's own -- short -- row, and edges between two hubs are found by one binary search per
+// pair.  On the power-law bench graphs the at most kMaxHub rows of degree >= 256 of an ego-net hold 67-82 % of the bytes
+// the induction would scan (measured on the CPU oracle's batches), so skipping them is worth more than any further
+// trimming of the scan itself.  The result is bit for bit the scanned one (same tests, same oracle).
+constexpr int kMaxHub = 32;        // hub rows per subgraph (more rows over the threshold: the rest are scanned)
+constexpr int kHubDegreeDefault = 256;
 constexpr uint32_t kHashMul = 0x9E3779u;    // 24-bit multiply (full rate; the 32-bit one is quarter rate): ids differing
                                             // only above bit 23 share a Bloom bit, which costs a look-up, not a result
 
@@ -97,6 +105,15 @@ struct Work {
     int32_t *ucnt;        // [unit_cap]  hits of every unit
     int32_t *wrec;        // [G * kGridMult][kRecInts] where each induce workgroup starts        (prefix step A)
     int32_t *scratch;     // [scratch_entries] hits: (row << 16) | local column, one slot of 1024 per unit
+    int32_t *srow;        // [G][ncap]   local id of the s-th SCANNED row (rowbeg / rowdeg / rowq are indexed by s, not by local id)
+    int32_t *sub_ns;      // [G]         scanned rows
+    int32_t *sub_nh;      // [G]         hub rows (not scanned)
+    int32_t *hubloc;      // [G][kMaxHub] local id of hub k (ascending)
+    int32_t *hubrb;       // [G][kMaxHub] its parent row's begin
+    int32_t *hubdeg;      // [G][kMaxHub] and degree
+    int32_t *hubcnt;      // [G][kMaxHub] entries of its induced row (hub_kernel)
+    uint32_t *hubmark;    // [G][kMaxHub][mwords] bit i: member with local id i is a neighbour of the hub
+    int32_t mwords;       // ncap / 32
     int32_t ncap;
     int32_t nseg;         // batch segments of this call: 2 (views q, k) per step; subgraph g = segment * B + b
     int64_t unit_cap;
@@ -105,6 +122,7 @@ struct Work {
 struct WorkLayout {
     int64_t off_seeds, off_n, off_quads, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowq,
         off_vbp, off_ubp, off_sbp, off_nbp, off_ebp, off_ucnt, off_wrec, off_scratch, total, unit_cap;
+    int64_t off_srow, off_ns, off_nh, off_hubloc, off_hubrb, off_hubdeg, off_hubcnt, off_hubmark;
     int32_t ncap;
 };
 
@@ -131,6 +149,14 @@ inline WorkLayout work_layout(int32_t lmax, int32_t B, int32_t nseg, int64_t scr
     w.off_ebp = o;    o = al(o + 4 * (G + 1));
     w.off_ucnt = o;   o = al(o + 4 * w.unit_cap);
     w.off_wrec = o;   o = al(o + 4 * G * kGridMult * kRecInts);
+    w.off_srow = o;   o = al(o + 4 * G * w.ncap);
+    w.off_ns = o;     o = al(o + 4 * G);
+    w.off_nh = o;     o = al(o + 4 * G);
+    w.off_hubloc = o; o = al(o + 4 * G * kMaxHub);
+    w.off_hubrb = o;  o = al(o + 4 * G * kMaxHub);
+    w.off_hubdeg = o; o = al(o + 4 * G * kMaxHub);
+    w.off_hubcnt = o; o = al(o + 4 * G * kMaxHub);
+    w.off_hubmark = o; o = al(o + 4 * G * kMaxHub * (int64_t)(w.ncap / 32));
     w.off_scratch = o; o = al(o + 4 * scratch_entries);
     w.total = o;
     return w;
@@ -169,12 +195,14 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
     const double *__restrict__ seed_cdf, const int32_t *__restrict__ ltab, int64_t num_nodes,
     int32_t ltab_len, int32_t p2max, uint64_t run_seed, int64_t first_sample_id, int64_t step_stride, int32_t B,
     uint32_t restart_u32, const int32_t *__restrict__ seeds_in, const int64_t *__restrict__ shard_off,
-    int32_t num_shards, Work w)
+    int32_t num_shards, int32_t hub_degree, Work w)
 {
     DYN_SMEM(smem);
     __shared__ int32_t wsum[5];
     uint32_t *buf = (uint32_t *)smem;          // [p2max] trace -> sorted trace
     int32_t *lq = (int32_t *)smem + p2max;     // [p2max + 64] quads of the kept rows (n <= L + 1)
+    int32_t *lrb = lq + p2max + 64;            // [p2max + 64] their row begins
+    int32_t *ld = lrb + p2max + 64;            // [p2max + 64] and degrees
     const int tid = (int)threadIdx.x;
     const int g = (int)blockIdx.x;
     // subgraph g = segment * B + b, segment = 2 * step + view: a call covers the batches of several consecutive steps
@@ -294,7 +322,7 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
     int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
     int32_t *rowbeg = w.rowbeg + (int64_t)g * w.ncap;
     int32_t *rowdeg = w.rowdeg + (int64_t)g * w.ncap;
-    if (tid == 0) { nodes[0] = seed; rowbeg[0] = rp0; rowdeg[0] = deg0; lq[0] = row_quads(rp0, deg0); }
+    if (tid == 0) { nodes[0] = seed; lrb[0] = rp0; ld[0] = deg0; lq[0] = row_quads(rp0, deg0); }
     int n = 1;   // block-uniform
     for (int i0 = 0; i0 < L; i0 += kWalkThreads) {
         const int i = i0 + tid;
@@ -308,26 +336,57 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
             const int32_t rb = row_ptr[v];
             const int32_t d = row_ptr[v + 1] - rb;
             nodes[pos] = (int32_t)v;
-            rowbeg[pos] = rb;
-            rowdeg[pos] = d;
+            lrb[pos] = rb;
+            ld[pos] = d;
             lq[pos] = row_quads(rb, d);
         }
         n += kept;
     }
     __syncthreads();
-    // induction work: row i covers row_quads() aligned quads of col_idx; exclusive prefix per row
-    int run = 0;
+    // induction work.  Rows of degree >= hub_degree (the first kMaxHub of them in local order) are hubs: not scanned, their
+    // induced rows come from the mirror images of the other rows' hits (hub_kernel / hub_write_kernel).  The scanned rows
+    // are compacted: scanned row s has local id srow[s], covers row_quads() aligned quads of col_idx, rowq = their
+    // exclusive prefix.
+    int run = 0, ns = 0, nhw = 0;                        // block-uniform: quads, scanned rows, rows over the threshold so far
     int32_t *rowq = w.rowq + (int64_t)g * w.ncap;
+    int32_t *srow = w.srow + (int64_t)g * w.ncap;
+    int32_t *hubloc = w.hubloc + (int64_t)g * kMaxHub, *hubrb = w.hubrb + (int64_t)g * kMaxHub, *hubdeg = w.hubdeg + (int64_t)g * kMaxHub;
     for (int i0 = 0; i0 < n; i0 += kWalkThreads) {
         const int i = i0 + tid;
-        const int c = i < n ? lq[i] : 0;
-        int sum;
-        const int incl = block_scan_incl(c, &sum, wsum);
-        if (i < n) rowq[i] = run + incl - c;
-        run += sum;
+        const bool in = i < n;
+        const int d = in ? ld[i] : 0;
+        const bool wants = in && d >= hub_degree;
+        int wsumh;
+        const int hincl = block_scan_incl(wants ? 1 : 0, &wsumh, wsum);
+        const int hidx = nhw + hincl - 1;
+        const bool is_hub = wants && hidx < kMaxHub;
+        const bool isn = in && !is_hub;
+        const int c = isn ? lq[i] : 0;
+        int qsum, nsum;
+        const int qincl = block_scan_incl(c, &qsum, wsum);
+        const int nincl = block_scan_incl(isn ? 1 : 0, &nsum, wsum);
+        if (isn) {
+            const int p = ns + nincl - 1;
+            srow[p] = i;
+            rowbeg[p] = lrb[i];
+            rowdeg[p] = d;
+            rowq[p] = run + qincl - c;
+        }
+        if (is_hub) { hubloc[hidx] = i; hubrb[hidx] = lrb[i]; hubdeg[hidx] = d; }
+        run += qsum;
+        ns += nsum;
+        nhw += wsumh;
+    }
+    const int nh = nhw < kMaxHub ? nhw : kMaxHub;
+    {   // the hubs' neighbour bitmaps start empty (only the words this subgraph can touch)
+        uint32_t *hm = w.hubmark + (int64_t)g * kMaxHub * w.mwords;
+        const int words = (n + 31) >> 5;
+        for (int i = tid; i < nh * words; i += kWalkThreads) hm[(i / words) * w.mwords + (i % words)] = 0u;
     }
     if (tid == 0) {
         w.sub_n[g] = n;
+        w.sub_ns[g] = ns;
+        w.sub_nh[g] = nh;
         w.sub_quads[g] = run;
         w.sub_nnz[g] = 0;
     }
@@ -487,6 +546,8 @@ __global__ __launch_bounds__(256) void records_kernel(int32_t B, Work w)
     rec[5] = w.ubp[lo];
     rec[6] = (int32_t)(sb & 0xFFFFFFFFll);
     rec[7] = (int32_t)(sb >> 32);
+    rec[8] = w.sub_ns[lo];
+    rec[9] = w.sub_nh[lo];
 }
 __global__ __launch_bounds__(256) void prefix_b_kernel(int32_t B, Work w)
 {
@@ -512,8 +573,10 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
     uint32_t *snodes = (uint32_t *)smem;                     // [ncap]     members (seed first, the rest ascending)
     int32_t *sq = (int32_t *)(snodes + ncap);                // [ncap + 1] exclusive prefix of quads per row
     int32_t *srb = sq + (ncap + 2);                          // [ncap]     row begin  (sq padded: what follows stays 8-byte aligned)
-    int32_t *srd = srb + ncap;                               // [ncap]     row degree
-    uint32_t *bm = (uint32_t *)(srd + ncap);                 // [1 << (bm_log2_cap - 5)] Bloom bitmap of the members
+    int32_t *srd = srb + ncap;                               // [ncap]     row degree   (sq / srb / srd: SCANNED rows, by scan position)
+    uint16_t *srow16 = (uint16_t *)(srd + ncap);             // [ncap]     local id of a scanned row
+    uint8_t *hubslot = (uint8_t *)(srow16 + ncap);           // [ncap]     hub index of a member, 255 = not a hub
+    uint32_t *bm = (uint32_t *)(hubslot + ncap);             // [1 << (bm_log2_cap - 5)] Bloom bitmap of the members   (ncap % 64 == 0)
     uint32_t *candv_all = bm + (1u << (bm_log2_cap - 5));    // [4][kCandCap] Bloom survivors (parent ids) ...
     uint16_t *candr_all = (uint16_t *)(candv_all + kInduceWaves * kCandCap);   // [waves][kCandCap] ... and their row
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = wave_uniform(tid >> 6);
@@ -524,8 +587,10 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
     if (ticks && tid == 0) atomicAdd((unsigned long long *)&ticks[15], 1ull);
     const uint4 *recp = (const uint4 *)(w.wrec + (int64_t)blockIdx.x * kRecInts);   // (prefix step A)
     const uint4 ra = recp[0], rb4 = recp[1];
+    const uint2 rc2 = *(const uint2 *)(w.wrec + (int64_t)blockIdx.x * kRecInts + 8);
     const int count = wave_uniform((int)ra.x);               // (uniform by construction: into scalar registers)
     int g = wave_uniform((int)ra.y), part = wave_uniform((int)ra.z), n = wave_uniform((int)ra.w);
+    int ns = wave_uniform((int)rc2.x), nh = wave_uniform((int)rc2.y);   // scanned rows, hubs
     int totq = wave_uniform((int)rb4.x), ubase = wave_uniform((int)rb4.y);
     long long sbase = (long long)(((unsigned long long)(uint32_t)wave_uniform((int)rb4.w) << 32) |
                                   (unsigned long long)(uint32_t)wave_uniform((int)rb4.z));
@@ -540,6 +605,8 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
                 do { ++g; totq = g < G ? wave_uniform(w.sub_quads[g]) : 1; } while (totq == 0);
                 if (g >= G) break;                           // (the records and the prefixes come from the same pass)
                 n = wave_uniform(w.sub_n[g]);
+                ns = wave_uniform(w.sub_ns[g]);
+                nh = wave_uniform(w.sub_nh[g]);
                 ubase = wave_uniform(w.ubp[g]);
                 const long long sb = w.sbp[g];
                 sbase = (long long)(((unsigned long long)(uint32_t)wave_uniform((int)(sb >> 32)) << 32) |
@@ -564,7 +631,7 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
             // unit mark their first quad in a 256-entry LDS strip, and a prefix maximum spreads the marks.
             const int qb = unit * kUnitQuads;
             {
-                int r0 = 0, span = n;                                // last slot with sq[slot] <= qb is in [r0, r0 + span)
+                int r0 = 0, span = ns;                               // last slot with sq[slot] <= qb is in [r0, r0 + span)
                 while (span > 1) {
                     const int stride = (span + 63) >> 6;
                     const int idx = r0 + lane * stride;
@@ -578,7 +645,7 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
                 wave_sync();
                 for (int i0 = r0 + 1;; i0 += 64) {                   // rows r0 + 1 ... start after qb (sq ascends strictly)
                     const int i = i0 + lane;
-                    const int q = i < n ? sq[i] : 0x7FFFFFFF;
+                    const int q = i < ns ? sq[i] : 0x7FFFFFFF;
                     const bool in = q < qb + kUnitQuads;
                     if (in) rowl[q - qb] = (uint16_t)(i - r0);       // <= 256: every row has at least one quad
                     if (wave_ballot(in) != ~0ull) break;             // wave-uniform
@@ -628,13 +695,20 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
             const int32_t *rq = w.rowq + (int64_t)g * ncap;
             const int32_t *rb = w.rowbeg + (int64_t)g * ncap;
             const int32_t *rd = w.rowdeg + (int64_t)g * ncap;
+            const int32_t *sr = w.srow + (int64_t)g * ncap;
             for (int i = tid; i < n; i += kInduceThreads) {
                 snodes[i] = (uint32_t)nodes[i];
+                hubslot[i] = 255;
+            }
+            for (int i = tid; i < ns; i += kInduceThreads) {
                 sq[i] = rq[i];
                 srb[i] = rb[i];
                 srd[i] = rd[i];
+                srow16[i] = (uint16_t)sr[i];
             }
-            if (tid == 0) sq[n] = totq;
+            if (tid == 0) sq[ns] = totq;
+            __syncthreads();
+            if (tid < nh) hubslot[w.hubloc[(int64_t)g * kMaxHub + tid]] = (uint8_t)tid;      // (nh <= kMaxHub <= threads)
             __syncthreads();
         }
         int my_nnz = 0;
@@ -653,6 +727,7 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
             }
             if (unit >= unit_end) break;
             int32_t *out = w.scratch + sbase + (long long)unit * kUnitElems;
+            uint32_t *hmark = w.hubmark + (int64_t)g * kMaxHub * w.mwords;
             int ncand = 0, nout = 0;                                 // wave-uniform
             auto drain = [&]() {
                 wave_sync();
@@ -673,7 +748,13 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
                         }
                     }
                     const unsigned long long m = wave_ballot(loc >= 0);
-                    if (loc >= 0) out[nout + __popcll(m & lanemask_lt())] = (int32_t)(((uint32_t)candr[c] << 16) | (uint32_t)loc);
+                    if (loc >= 0) {
+                        const uint32_t lrow = srow16[candr[c]];      // the scanned row's local id
+                        out[nout + __popcll(m & lanemask_lt())] = (int32_t)((lrow << 16) | (uint32_t)loc);
+                        const uint32_t hs = hubslot[loc];
+                        // the hit's mirror image: row `loc` is a hub and is not scanned -- (hub -> this row) is an edge too
+                        if (hs != 255u) atomicOr(&hmark[hs * (uint32_t)w.mwords + (lrow >> 5)], 1u << (lrow & 31));
+                    }
                     nout += __popcll(m);
                 }
                 wave_sync();
@@ -727,12 +808,27 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, PackOuts o
     __shared__ int32_t wsum[5];
     __shared__ int32_t uoff[257];                 // exclusive prefix of the hit counts of a chunk of 256 units
     __shared__ int32_t sh_base, sh_carry;
+    __shared__ int32_t hl[kMaxHub], hc[kMaxHub + 1];   // hub rows (ascending local ids) and the exclusive prefix of their entry counts
     const int tid = (int)threadIdx.x;
     const int g = (int)blockIdx.x / kPackParts, part = (int)blockIdx.x % kPackParts;
     const int seg = g / B, b = g - seg * B;
     const BatchOutDev o = outs.o[seg];
     const int n = w.sub_n[g];
-    const int nnz = w.sub_nnz[g];
+    const int nnz = w.sub_nnz[g];                    // scanned hits + the hub rows' entries (hub_kernel)
+    const int nh = w.sub_nh[g];
+    if (tid == 0) {
+        int run = 0;
+        for (int k = 0; k < nh; ++k) { hl[k] = w.hubloc[(int64_t)g * kMaxHub + k]; hc[k] = run; run += w.hubcnt[(int64_t)g * kMaxHub + k]; }
+        hc[nh] = run;
+    }
+    __syncthreads();
+    // Hub rows are not in the flat sequence of scanned hits: everything at or after row i sits hshift(i) entries further on
+    // (the entries of the hub rows before row i), and a hub row H itself starts at (scanned hits of rows < H) + hshift(H)
+    auto hshift = [&](int i) -> int {
+        int k = 0;
+        while (k < nh && hl[k] < i) ++k;
+        return hc[k];
+    };
     const long long node_base = w.nbp[g];            // (prefix steps A / B)
     const long long edge_base = w.ebp[g];
     const long long sbase = w.sbp[g];
@@ -816,7 +912,7 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, PackOuts o
             const uint32_t hv = (uint32_t)slot[kk];
             const int row = (int)(hv >> 16);
             const long long e = (long long)e_base + x;
-            o.col_idx[edge_base + e] = (int32_t)node_base + (int32_t)(hv & 0xFFFFu);
+            o.col_idx[edge_base + e + hshift(row)] = (int32_t)node_base + (int32_t)(hv & 0xFFFFu);
             int prow;
             if (kk > 0) {
                 prow = (int)((uint32_t)slot[kk - 1] >> 16);
@@ -826,7 +922,7 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, PackOuts o
             } else {
                 prow = carry;
             }
-            for (int i = prow + 1; i <= row; ++i) o.row_ptr[node_base + i] = (int32_t)(edge_base + e);
+            for (int i = prow + 1; i <= row; ++i) o.row_ptr[node_base + i] = (int32_t)(edge_base + e + hshift(i));
         }
         __syncthreads();
         if (tid == 0 && chunk_total > 0) {
@@ -838,7 +934,113 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, PackOuts o
     }
     if (part == kPackParts - 1) {                      // rows after the last hit have no induced edges
         const int carry = sh_carry;
-        for (int i = carry + 1 + tid; i < n; i += 256) o.row_ptr[node_base + i] = (int32_t)(edge_base + nnz);
+        const int scanned = nnz - hc[nh];              // (all scanned hits lie before these rows)
+        for (int i = carry + 1 + tid; i < n; i += 256) o.row_ptr[node_base + i] = (int32_t)(edge_base + scanned + hshift(i));
+    }
+}
+
+// ------------------------------------------------------------------ hub rows ----
+// hub_kernel (after the induction): edges between two hubs (neither row was scanned: one binary search per pair, in the
+// shorter row), then the number of entries of every hub's induced row = the bits of its neighbour bitmap.
+__global__ __launch_bounds__(256) void hub_kernel(const int32_t *__restrict__ col_idx, Work w)
+{
+    const int g = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nh = w.sub_nh[g];
+    if (nh == 0) return;                                 // (block-uniform)
+    __shared__ int32_t cnt[kMaxHub];
+    const int n = w.sub_n[g];
+    const int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
+    const int32_t *hloc = w.hubloc + (int64_t)g * kMaxHub, *hrb = w.hubrb + (int64_t)g * kMaxHub, *hdeg = w.hubdeg + (int64_t)g * kMaxHub;
+    uint32_t *hm = w.hubmark + (int64_t)g * kMaxHub * w.mwords;
+    for (int pr = tid; pr < nh * nh; pr += 256) {
+        const int a = pr / nh, c = pr % nh;
+        if (a >= c) continue;
+        const bool a_short = hdeg[a] <= hdeg[c];
+        const int s = a_short ? a : c, t = a_short ? c : a;   // look hub t's id up in hub s's (shorter) row
+        const int32_t key = nodes[hloc[t]];
+        int lo = hrb[s], hi = hrb[s] + hdeg[s];               // rows are sorted (input contract)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (col_idx[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        if (lo < hrb[s] + hdeg[s] && col_idx[lo] == key) {
+            atomicOr(&hm[a * w.mwords + (hloc[c] >> 5)], 1u << (hloc[c] & 31));
+            atomicOr(&hm[c * w.mwords + (hloc[a] >> 5)], 1u << (hloc[a] & 31));
+        }
+    }
+    __syncthreads();
+    const int words = (n + 31) >> 5;
+    int total = 0;
+    for (int k = wv; k < nh; k += 4) {                   // one wave per hub
+        int c = 0;
+        for (int i = lane; i < words; i += 64) c += __popc((uint32_t)load_fresh_i32((const int *)&hm[k * w.mwords + i]));
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += wave_shfl_xor(c, d);
+        if (lane == 0) { cnt[k] = c; w.hubcnt[(int64_t)g * kMaxHub + k] = c; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 0; k < nh; ++k) total += cnt[k];
+        w.sub_nnz[g] += total;                           // (the induction's atomics are complete: kernel boundary)
+    }
+}
+
+// hub_write_kernel (after the pack): the entries of every hub row, in the order of the parent row -- ascending parent id,
+// i.e. ascending local id except that the seed (local id 0) stands where ITS parent id belongs.
+__global__ __launch_bounds__(256) void hub_write_kernel(int32_t B, Work w, PackOuts outs, int64_t scratch_entries)
+{
+    __shared__ int32_t wsum[5];
+    __shared__ int32_t sh_p0;
+    const int g = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const int nh = w.sub_nh[g];
+    if (nh == 0) return;                                 // (block-uniform)
+    const int seg = g / B;
+    const BatchOutDev o = outs.o[seg];
+    const int n = w.sub_n[g], nnz = w.sub_nnz[g];
+    const long long node_base = w.nbp[g], edge_base = w.ebp[g];
+    if (scratch_overflows(w, g, scratch_entries) || node_base + n > o.node_cap || edge_base + nnz > o.edge_cap) return;   // (pack left clamped rows)
+    const int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
+    if (tid == 0) {                                      // locals 1 .. p0 have smaller parent ids than the seed
+        const int32_t seed = nodes[0];
+        int lo = 1, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (nodes[mid] < seed) lo = mid + 1; else hi = mid;
+        }
+        sh_p0 = lo - 1;
+    }
+    __syncthreads();
+    const int p0 = sh_p0;
+    const int words = (n + 31) >> 5;
+    const uint32_t *hm = w.hubmark + (int64_t)g * kMaxHub * w.mwords;
+    for (int k = 0; k < nh; ++k) {
+        const int H = w.hubloc[(int64_t)g * kMaxHub + k];
+        const long long base = (long long)o.row_ptr[node_base + H];      // written by the pack
+        const uint32_t *bits = hm + k * w.mwords;
+        const uint32_t seed_bit = bits[0] & 1u;
+        int before = 0;                                  // block-uniform: entries of locals >= 1 in the words already done
+        for (int w0 = 0; w0 < words; w0 += 256) {
+            const int wi = w0 + tid;
+            uint32_t v = wi < words ? bits[wi] : 0u;
+            if (wi == 0) v &= ~1u;                       // the seed is placed separately
+            int tot;
+            const int incl = block_scan_incl(__popc(v), &tot, wsum);
+            int at = before + incl - __popc(v);          // entries of locals >= 1 before this word
+            while (v) {
+                const int bit = __ffsll((unsigned long long)v) - 1;
+                v &= v - 1;
+                const int loc = wi * 32 + bit;
+                o.col_idx[base + at + (loc > p0 ? (int)seed_bit : 0)] = (int32_t)node_base + loc;
+                ++at;
+            }
+            before += tot;
+        }
+        if (seed_bit && tid == 0) {                      // after the p0 locals with smaller parent ids that are neighbours
+            int c = 0;
+            for (int i = 1; i <= p0; ++i) c += (int)((bits[i >> 5] >> (i & 31)) & 1u);
+            o.col_idx[base + c] = (int32_t)node_base;
+        }
+        __syncthreads();
     }
 }
 
@@ -916,6 +1118,15 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     w.rowbeg = (int32_t *)(base + wl.off_rowbeg);
     w.rowdeg = (int32_t *)(base + wl.off_rowdeg);
     w.rowq = (int32_t *)(base + wl.off_rowq);
+    w.srow = (int32_t *)(base + wl.off_srow);
+    w.sub_ns = (int32_t *)(base + wl.off_ns);
+    w.sub_nh = (int32_t *)(base + wl.off_nh);
+    w.hubloc = (int32_t *)(base + wl.off_hubloc);
+    w.hubrb = (int32_t *)(base + wl.off_hubrb);
+    w.hubdeg = (int32_t *)(base + wl.off_hubdeg);
+    w.hubcnt = (int32_t *)(base + wl.off_hubcnt);
+    w.hubmark = (uint32_t *)(base + wl.off_hubmark);
+    w.mwords = wl.ncap / 32;
     w.vbp = (int32_t *)(base + wl.off_vbp);
     w.ubp = (int32_t *)(base + wl.off_ubp);
     w.sbp = (long long *)(base + wl.off_sbp);
@@ -934,8 +1145,10 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     while (p2max < g->lmax) p2max <<= 1;
     int bmlog = 11;                                  // Bloom bitmap: 64 bits per member up to 1024 members, 8 KiB at most (LDS per
     while ((1 << bmlog) < 64 * (g->lmax + 1) && bmlog < 16) ++bmlog;   // workgroup decides how many are resident: 82 KiB at lmax 2360 left one per CU)
-    const size_t lds1 = ((size_t)p2max * 2 + 64) * 4;
-    const size_t lds2 = (size_t)wl.ncap * 16 + 8 + ((size_t)1 << (bmlog - 3)) + (size_t)kInduceWaves * (kCandCap * 6 + kUnitQuads * 2) + 16;
+    const size_t lds1 = ((size_t)p2max * 4 + 192) * 4;
+    const size_t lds2 = (size_t)wl.ncap * 19 + 8 + ((size_t)1 << (bmlog - 3)) + (size_t)kInduceWaves * (kCandCap * 6 + kUnitQuads * 2) + 16;
+    // rows of at least this degree are not scanned (kMaxHub per subgraph): hub_degree 0 = default, < 0 = scan everything
+    const int32_t hub_degree = p->hub_degree == 0 ? kHubDegreeDefault : (p->hub_degree < 0 ? 0x7FFFFFFF : p->hub_degree);
     if (lds1 > 160 * 1024 || lds2 > 160 * 1024 - 256) {
         snprintf(g_err, kErrLen, "gcc_sample_multi: lmax=%d / batch too large for 160 KiB of LDS", g->lmax);
         return -4;
@@ -955,15 +1168,17 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
 #endif
     hipLaunchKernelGGL(rwr_walk_kernel, dim3(G), dim3(kWalkThreads), lds1, s, g->row_ptr, g->col_idx, g->seed_cdf,
                        g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, sample_id_stride, B,
-                       p->restart_u32, p->seeds, g->num_shards > 1 ? g->shard_off : nullptr, g->num_shards, w);
+                       p->restart_u32, p->seeds, g->num_shards > 1 ? g->shard_off : nullptr, g->num_shards, hub_degree, w);
     hipLaunchKernelGGL(prefix_a_kernel, dim3(1), dim3(kPrefixThreads), (size_t)(G + 1) * 4, s, B, w);
     hipLaunchKernelGGL(records_kernel, dim3((G * kGridMult + 255) / 256), dim3(256), 0, s, B, w);
     prof_mark(p->prof, 1, s);                        // marks 1 -> 2 bracket induce_kernel alone (bench.py's roofline interval)
     hipLaunchKernelGGL(induce_kernel, dim3(G * kGridMult), dim3(kInduceThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,
                        scratch_entries, w, status, g_induce_ticks);
     prof_mark(p->prof, 2, s);
+    hipLaunchKernelGGL(hub_kernel, dim3(G), dim3(256), 0, s, g->col_idx, w);
     hipLaunchKernelGGL(prefix_b_kernel, dim3(1), dim3(256), 0, s, B, w);
     hipLaunchKernelGGL(pack_kernel, dim3(G * kPackParts), dim3(256), 0, s, B, w, po, scratch_entries, status);
+    hipLaunchKernelGGL(hub_write_kernel, dim3(G), dim3(256), 0, s, B, w, po, scratch_entries);
     prof_mark(p->prof, 3, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -209,3 +209,45 @@ def test_multi_step_call_equals_the_single_step_calls(coracle):
     # limits are refused, not truncated
     with pytest.raises((RuntimeError, AssertionError), match="num_steps"):
         emu_sample_multi(g, B, 11, first, 17, stride)
+
+
+# ---- hub rows are not scanned (sampler.hip: hub_kernel / hub_write_kernel): same result, bit for bit
+@pytest.mark.parametrize("hub_degree", [1, 2, 3, 8, 40, -1])
+def test_unscanned_hub_rows_give_the_same_subgraphs(coracle, hub_degree):
+    """Rows of at least ``hub_degree`` (at most 32 per subgraph) are skipped by the induction; their induced rows are the
+    mirror images of the other rows' hits (the parent graph is symmetric) + one binary search per pair of hubs.  With the
+    threshold at 1 EVERY row of a small ego-net is a hub (nothing is scanned at all: hub pairs only), at 2 .. 40 the mix
+    shifts, -1 scans everything (the rounds 1-3 path); the default 256 leaves these small graphs unaffected.  Always the
+    C oracle's batches: node lists, row order, the seed's position inside a row."""
+    rp, ci = powerlaw_graph(3000, 30000, 3)
+    g = EmuGraph(rp, ci, rw_hops=64)
+    _compare(coracle, rp, ci, g, 7, 21, 500, hub_degree=hub_degree)
+    # hub seeds with several hundred members (more rows over the threshold than the 32 hub slots: the rest are scanned)
+    rp2, ci2 = powerlaw_graph(20000, 400000, 1)
+    hubs = np.argsort(np.diff(rp2))[-2:].astype(np.int32)
+    _compare(coracle, rp2, ci2, EmuGraph(rp2, ci2, rw_hops=64), 2, 7, 0, seeds=hubs, hub_degree=hub_degree)
+
+
+@pytest.mark.parametrize("name", ["path5", "star6", "tri_tail", "k4"])
+@pytest.mark.parametrize("hub_degree", [1, 2, 3])
+def test_unscanned_hub_rows_on_tiny_graphs(coracle, name, hub_degree):
+    rp, ci = tiny_graphs()[name]
+    g = EmuGraph(rp, ci, rw_hops=12)
+    _compare(coracle, rp, ci, g, 4, 5, 0, hub_degree=hub_degree)
+    _compare(coracle, rp, ci, g, 2, 5, 0, seeds=[0, len(rp) - 2], hub_degree=hub_degree)
+
+
+def test_unscanned_hub_rows_in_multi_step_launches(coracle):
+    from tests.hipemu.emu_driver import emu_sample_multi
+
+    rp, ci = powerlaw_graph(3000, 30000, 5)
+    g = EmuGraph(rp, ci, rw_hops=32)
+    B, S = 4, 3
+    pairs, status, _ = emu_sample_multi(g, B, 9, 100, S, B, hub_degree=4)
+    assert status == 0
+    for t, (q, k) in enumerate(pairs):
+        single, st, _ = emu_sample_batch(g, B, 9, 100 + t * B, hub_degree=-1)
+        assert st == 0
+        for got, ref in ((q, single[0]), (k, single[1])):
+            for key in KEYS + ("edge_off", "graph_id"):
+                assert np.array_equal(got[key], ref[key]), (t, key)
