@@ -75,6 +75,8 @@ def parse_args(argv=None):
     ap.add_argument("--strict-streams", action="store_true", help="bracket every step with caller <-> step stream hand-offs (the API default; two event hops on the step's chain)")
     ap.add_argument("--e2e-graph", action="store_true", help="--mode e2e: replay the step as a captured hipGraph (off by default: no gain measured)")
     ap.add_argument("--no-graph", action="store_true", help="issue every step launch by launch instead of replaying the captured hipGraph of its ring slot")
+    ap.add_argument("--hub-degree", type=int, default=0, help="member rows of at least this degree are not scanned by the induction "
+                                                              "(0 = the library's default 512, -1 = scan every row: rounds 1-3)")
     ap.add_argument("--scratch-entries", type=int, default=0, help="induction scratch of the sampler (int32 slots); 0 = default")
     ap.add_argument("--edge-cap", type=int, default=0, help="edge capacity of a batch view; 0 = default")
     ap.add_argument("--pmc-traffic", type=float, default=None,
@@ -387,7 +389,7 @@ def sampler_probe(sampler, rp, first_id, args, nsample, lt, Prof, torch, steps_p
             shape["edges_k"] += len(ck["col_idx"]) / (ncalls * S)
     # the event marks sit around groups of launches: walk + prefix step A | induction alone | prefix step B + pack
     return {"rwr_walk_kernel+prefix_a_kernel+records_kernel": float(iso[0]), "induce_kernel": float(iso[1]),
-            "prefix_b_kernel+pack_kernel": float(iso[2])}, acc, shape, S
+            "prefix_b_kernel+pack_kernel+hub_write_kernel": float(iso[2])}, acc, shape, S
 
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-f32 MFMA = the f32 vector rate
@@ -526,7 +528,7 @@ def main():
     if args.mode == "sampler":
         S = max(1, min(args.sampler_steps, args.steps))
         sampler = DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=max(2, S), scratch_entries=args.scratch_entries or None,
-                                   edge_cap=args.edge_cap or None, max_steps=S)
+                                   edge_cap=args.edge_cap or None, max_steps=S, hub_degree=args.hub_degree)
         S = sampler.max_steps
         samplers = [sampler]
 
@@ -559,7 +561,7 @@ def main():
         chunk = max(d for d in range(1, min(args.chunk, args.steps) + 1) if args.steps % d == 0)
         nbuf = args.depth * chunk
         samplers = [DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=nbuf, scratch_entries=args.scratch_entries or None,
-                                     edge_cap=args.edge_cap or None, max_steps=chunk) for _ in range(args.lanes)]
+                                     edge_cap=args.edge_cap or None, max_steps=chunk, hub_degree=args.hub_degree) for _ in range(args.lanes)]
         sampler = samplers[0]
         enc_kw = dict(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
                       freq_embedding_size=16, degree_embedding_size=16, output_dim=64, node_hidden_dim=64,

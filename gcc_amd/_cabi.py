@@ -48,6 +48,7 @@ class GccSampleParams(ctypes.Structure):
         ("seeds", ctypes.c_void_p),
         ("prof", ctypes.c_void_p),
         ("hub_degree", ctypes.c_int32),
+        ("max_hubs", ctypes.c_int32),
     ]
 
 

@@ -37,6 +37,7 @@
 //                     and the start record of every induce workgroup.
 //   pack_kernel       prefix sums over subgraphs and units (dgl.batch offsets),
 //                     row_ptr/col_idx with batched ids, parent_nid, graph_id.
+//   hub_write_kernel  the rows of the members the induction did not scan (below).
 // HBM-bound integer work; no MFMA anywhere in this file.
 #include "device_compat.h"
 #include "../../include/gcc_amd.h"
@@ -71,12 +72,18 @@ constexpr int kCandCap = 256;      // per-wave queue of Bloom survivors (drained
 constexpr int kPackParts = 4;      // pack workgroups per subgraph (hub-seed subgraphs have 100x the units)
 // Hub rows are NOT scanned (round 4).  The parent graph is symmetric (the input contract, x2dgl.py:43-47): member v's row
 // holds hub H exactly when H's row holds v, so every edge (H -> v) of the induced subgraph is the mirror image of a hit
-// (v -> H) found while scanning v's own -- short -- row, and edges between two hubs are found by one binary search per
-// pair.  On the power-law bench graphs the at most kMaxHub rows of degree >= 256 of an ego-net hold 67-82 % of the bytes
-// the induction would scan (measured on the CPU oracle's batches), so skipping them is worth more than any further
-// trimming of the scan itself.  The result is bit for bit the scanned one (same tests, same oracle).
-constexpr int kMaxHub = 32;        // hub rows per subgraph (more rows over the threshold: the rest are scanned)
-constexpr int kHubDegreeDefault = 256;
+// (v -> H) found while scanning v's own -- short -- row (the induction marks it in H's neighbour bitmap), and edges
+// between two hubs are found by one binary search per pair (tail of the walk kernel).  hub_write_kernel turns the bitmaps
+// into rows after the pack.  The result is bit for bit the scanned one (same tests, same oracle); which rows are hubs
+// only changes the cost.  On the bench graphs the rows of degree >= 1024 (G1: 10 per ego-net) / >= 4096 (G2: 14) hold
+// 72 % of the entries a full scan reads.  Measured (profiles/r4_hub_rows.md): induction 437 -> 232 us (G1) and 1826 ->
+// 1105 us (G2) per 16-step launch, the pair searches and the row writer give 100 / 280 us back; the optimum over
+// (threshold, slots) is flat around 512 .. 1024 x 32.
+constexpr int kMaxHub = 32;        // most hub rows per subgraph (the workspace is laid out for this many)
+constexpr int kHubDegreeDefault = 512;
+constexpr int kMaxHubsDefault = 32; // with more rows over the threshold, the threshold of THAT subgraph rises to the power of two that
+                                   // leaves at most this many: the pair searches grow with the square of the count, the bytes saved come
+                                   // from the longest rows
 constexpr uint32_t kHashMul = 0x9E3779u;    // 24-bit multiply (full rate; the 32-bit one is quarter rate): ids differing
                                             // only above bit 23 share a Bloom bit, which costs a look-up, not a result
 
@@ -108,10 +115,11 @@ struct Work {
     int32_t *srow;        // [G][ncap]   local id of the s-th SCANNED row (rowbeg / rowdeg / rowq are indexed by s, not by local id)
     int32_t *sub_ns;      // [G]         scanned rows
     int32_t *sub_nh;      // [G]         hub rows (not scanned)
+    int32_t *sub_p0;      // [G]         members (other than the seed) whose parent id is below the seed's
     int32_t *hubloc;      // [G][kMaxHub] local id of hub k (ascending)
     int32_t *hubrb;       // [G][kMaxHub] its parent row's begin
     int32_t *hubdeg;      // [G][kMaxHub] and degree
-    int32_t *hubcnt;      // [G][kMaxHub] entries of its induced row (hub_kernel)
+    int32_t *hubcnt;      // [G][kMaxHub] entries of its induced row (counted by the walk kernel: hub pairs, and the induction: everything else)
     uint32_t *hubmark;    // [G][kMaxHub][mwords] bit i: member with local id i is a neighbour of the hub
     int32_t mwords;       // ncap / 32
     int32_t ncap;
@@ -122,7 +130,7 @@ struct Work {
 struct WorkLayout {
     int64_t off_seeds, off_n, off_quads, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowq,
         off_vbp, off_ubp, off_sbp, off_nbp, off_ebp, off_ucnt, off_wrec, off_scratch, total, unit_cap;
-    int64_t off_srow, off_ns, off_nh, off_hubloc, off_hubrb, off_hubdeg, off_hubcnt, off_hubmark;
+    int64_t off_srow, off_ns, off_nh, off_p0, off_hubloc, off_hubrb, off_hubdeg, off_hubcnt, off_hubmark;
     int32_t ncap;
 };
 
@@ -152,6 +160,7 @@ inline WorkLayout work_layout(int32_t lmax, int32_t B, int32_t nseg, int64_t scr
     w.off_srow = o;   o = al(o + 4 * G * w.ncap);
     w.off_ns = o;     o = al(o + 4 * G);
     w.off_nh = o;     o = al(o + 4 * G);
+    w.off_p0 = o;     o = al(o + 4 * G);
     w.off_hubloc = o; o = al(o + 4 * G * kMaxHub);
     w.off_hubrb = o;  o = al(o + 4 * G * kMaxHub);
     w.off_hubdeg = o; o = al(o + 4 * G * kMaxHub);
@@ -186,6 +195,25 @@ __device__ __forceinline__ int block_scan_incl(int v, int *total, int32_t *wsum)
     return base + incl;
 }
 
+// two scans for one pair of barriers; wsum: LDS [8]
+__device__ __forceinline__ void block_scan_incl2(int a, int b, int *ia, int *ib, int *ta, int *tb, int32_t *wsum)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sa = wave_scan_incl(a), sb = wave_scan_incl(b);
+    if (lane == 63) { wsum[wv] = sa; wsum[4 + wv] = sb; }
+    __syncthreads();
+    int ba = 0, bb = 0, aa = 0, ab = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int x = wsum[k], y = wsum[4 + k];
+        ba += k < wv ? x : 0;
+        bb += k < wv ? y : 0;
+        aa += x;
+        ab += y;
+    }
+    __syncthreads();
+    *ia = ba + sa; *ib = bb + sb; *ta = aa; *tb = ab;
+}
+
 __device__ __forceinline__ int row_quads(int rb, int d) { return ((rb + d + 3) >> 2) - (rb >> 2); }
 
 
@@ -195,10 +223,12 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
     const double *__restrict__ seed_cdf, const int32_t *__restrict__ ltab, int64_t num_nodes,
     int32_t ltab_len, int32_t p2max, uint64_t run_seed, int64_t first_sample_id, int64_t step_stride, int32_t B,
     uint32_t restart_u32, const int32_t *__restrict__ seeds_in, const int64_t *__restrict__ shard_off,
-    int32_t num_shards, int32_t hub_degree, Work w)
+    int32_t num_shards, int32_t hub_degree, int32_t max_hubs, Work w)
 {
     DYN_SMEM(smem);
-    __shared__ int32_t wsum[5];
+    __shared__ int32_t wsum[8];
+    __shared__ int32_t sh_want;                // members over the hub threshold
+    __shared__ int32_t dhist[32];              // members by floor(log2(degree))
     uint32_t *buf = (uint32_t *)smem;          // [p2max] trace -> sorted trace
     int32_t *lq = (int32_t *)smem + p2max;     // [p2max + 64] quads of the kept rows (n <= L + 1)
     int32_t *lrb = lq + p2max + 64;            // [p2max + 64] their row begins
@@ -252,6 +282,7 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
     const int p2 = pow2_ceil(L);
 
     for (int i = tid; i < p2; i += kWalkThreads) buf[i] = kEmpty;
+    if (tid < 32) dhist[tid] = 0;
     __syncthreads();
 
     // ---- walks: graph_dataset.py:125-130 (DGL random_walk_with_restart); walk id = base + thread
@@ -322,15 +353,19 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
     int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
     int32_t *rowbeg = w.rowbeg + (int64_t)g * w.ncap;
     int32_t *rowdeg = w.rowdeg + (int64_t)g * w.ncap;
-    if (tid == 0) { nodes[0] = seed; lrb[0] = rp0; ld[0] = deg0; lq[0] = row_quads(rp0, deg0); }
-    int n = 1;   // block-uniform
+    if (tid == 0) { nodes[0] = seed; lrb[0] = rp0; ld[0] = deg0; lq[0] = row_quads(rp0, deg0); sh_want = deg0 >= hub_degree ? 1 : 0; if (deg0 >= hub_degree) atomicAdd(&dhist[31 - __builtin_clz((uint32_t)deg0 | 1u)], 1); }
+    __syncthreads();
+    int n = 1, p0 = 0;   // block-uniform: members; members with a parent id below the seed's (they are sorted: locals 1 .. p0)
     for (int i0 = 0; i0 < L; i0 += kWalkThreads) {
         const int i = i0 + tid;
         uint32_t v = kEmpty, prev = kEmpty;
         if (i < L) { v = buf[i]; if (i > 0) prev = buf[i - 1]; }
         const bool keep = (i < L) && (v != (uint32_t)seed) && (i == 0 || v != prev);
         int kept;
-        const int incl = block_scan_incl(keep ? 1 : 0, &kept, wsum);
+        const int incl2 = block_scan_incl(keep ? 1 + ((int32_t)v < seed ? 1 << 16 : 0) : 0, &kept, wsum);
+        const int incl = incl2 & 0xFFFF;
+        p0 += kept >> 16;
+        kept &= 0xFFFF;
         if (keep) {
             const int pos = n + incl - 1;
             const int32_t rb = row_ptr[v];
@@ -339,56 +374,132 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
             lrb[pos] = rb;
             ld[pos] = d;
             lq[pos] = row_quads(rb, d);
+            if (d >= hub_degree) { atomicAdd(&sh_want, 1); atomicAdd(&dhist[31 - __builtin_clz((uint32_t)d | 1u)], 1); }
         }
         n += kept;
     }
     __syncthreads();
     // induction work.  Rows of degree >= hub_degree (the first kMaxHub of them in local order) are hubs: not scanned, their
-    // induced rows come from the mirror images of the other rows' hits (hub_kernel / hub_write_kernel).  The scanned rows
+    // induced rows come from the mirror images of the other rows' hits (hub_write_kernel).  The scanned rows
     // are compacted: scanned row s has local id srow[s], covers row_quads() aligned quads of col_idx, rowq = their
     // exclusive prefix.
     int run = 0, ns = 0, nhw = 0;                        // block-uniform: quads, scanned rows, rows over the threshold so far
     int32_t *rowq = w.rowq + (int64_t)g * w.ncap;
     int32_t *srow = w.srow + (int64_t)g * w.ncap;
     int32_t *hubloc = w.hubloc + (int64_t)g * kMaxHub, *hubrb = w.hubrb + (int64_t)g * kMaxHub, *hubdeg = w.hubdeg + (int64_t)g * kMaxHub;
+    // this subgraph's threshold: hub_degree, or -- with more than max_hubs rows over it -- the smallest power of two that
+    // leaves at most max_hubs (block-uniform; which rows are hubs changes the cost only, never the result)
+    int thr = hub_degree;
+    if (sh_want > max_hubs) {
+        int cnt = 0, bb = 31;
+        while (bb > 0 && cnt + dhist[bb - 1] <= max_hubs) { cnt += dhist[bb - 1]; --bb; }   // (members with d >= 2^bb: dhist[bb ..]; none has bit 31)
+        thr = bb >= 31 ? 0x7FFFFFFF : (1 << bb);
+        if (thr < hub_degree) thr = hub_degree;          // (the histogram holds the rows over hub_degree only: 2^bb may undercut it)
+    }
     for (int i0 = 0; i0 < n; i0 += kWalkThreads) {
         const int i = i0 + tid;
         const bool in = i < n;
         const int d = in ? ld[i] : 0;
-        const bool wants = in && d >= hub_degree;
-        int wsumh;
-        const int hincl = block_scan_incl(wants ? 1 : 0, &wsumh, wsum);
-        const int hidx = nhw + hincl - 1;
-        const bool is_hub = wants && hidx < kMaxHub;
-        const bool isn = in && !is_hub;
-        const int c = isn ? lq[i] : 0;
-        int qsum, nsum;
-        const int qincl = block_scan_incl(c, &qsum, wsum);
-        const int nincl = block_scan_incl(isn ? 1 : 0, &nsum, wsum);
-        if (isn) {
-            const int p = ns + nincl - 1;
+        const bool is_hub = in && d >= thr;
+        const int c = in && !is_hub ? lq[i] : 0;
+        int qincl, cnts, qsum, tots;                     // two scans, one pair of barriers
+        block_scan_incl2(c, in ? (is_hub ? 1 << 16 : 1) : 0, &qincl, &cnts, &qsum, &tots, wsum);
+        if (in && !is_hub) {
+            const int p = ns + (cnts & 0xFFFF) - 1;
             srow[p] = i;
             rowbeg[p] = lrb[i];
             rowdeg[p] = d;
             rowq[p] = run + qincl - c;
         }
-        if (is_hub) { hubloc[hidx] = i; hubrb[hidx] = lrb[i]; hubdeg[hidx] = d; }
+        if (is_hub) { const int hidx = nhw + (cnts >> 16) - 1; hubloc[hidx] = i; hubrb[hidx] = lrb[i]; hubdeg[hidx] = d; }
         run += qsum;
-        ns += nsum;
-        nhw += wsumh;
+        ns += tots & 0xFFFF;
+        nhw += tots >> 16;
     }
-    const int nh = nhw < kMaxHub ? nhw : kMaxHub;
-    {   // the hubs' neighbour bitmaps start empty (only the words this subgraph can touch)
-        uint32_t *hm = w.hubmark + (int64_t)g * kMaxHub * w.mwords;
+    const int nh = nhw;                                  // <= max_hubs <= kMaxHub
+    uint32_t *hm = w.hubmark + (int64_t)g * kMaxHub * w.mwords;
+    int32_t *hubcnt = w.hubcnt + (int64_t)g * kMaxHub;
+    {   // the hubs' neighbour bitmaps and entry counts start empty (only the words this subgraph can touch)
         const int words = (n + 31) >> 5;
         for (int i = tid; i < nh * words; i += kWalkThreads) hm[(i / words) * w.mwords + (i % words)] = 0u;
+        if (tid < nh) hubcnt[tid] = 0;
     }
     if (tid == 0) {
         w.sub_n[g] = n;
         w.sub_ns[g] = ns;
         w.sub_nh[g] = nh;
+        w.sub_p0[g] = p0;
         w.sub_quads[g] = run;
         w.sub_nnz[g] = 0;
+    }
+    __syncthreads();
+    // edges between two hubs (neither row will be scanned): one search per pair, in the shorter of the two rows (rows are
+    // sorted: the input contract); both mirror images are marked and counted here
+    const int npairs = nh * (nh - 1) / 2;
+    auto found = [&](int a, int c) {
+        const int la = hubloc[a], lc = hubloc[c];
+        atomicOr(&hm[a * w.mwords + (lc >> 5)], 1u << (lc & 31));
+        atomicOr(&hm[c * w.mwords + (la >> 5)], 1u << (la & 31));
+        atomicAdd(&hubcnt[a], 1);
+        atomicAdd(&hubcnt[c], 1);
+        atomicAdd(&w.sub_nnz[g], 2);
+    };
+    if (npairs == 0) return;                             // (block-uniform)
+    if (npairs <= 48) {
+        // few pairs (the usual case): a team of 16 lanes per pair narrows the range 16-fold per round of loads -- 2 to 5
+        // dependent loads for rows of 256 .. 1M entries where a one-lane binary search has 8 to 20
+        const int lane = tid & 63, team = tid >> 4, sl = tid & 15, tsh = (lane >> 4) * 16;
+        for (int pr0 = 0; pr0 < npairs; pr0 += kWalkThreads / 16) {
+            const int pr = pr0 + team;
+            const bool valid = pr < npairs;
+            int a = 0, c = 1, lo = 0, hi = 0;
+            int32_t key = 0;
+            if (valid) {
+                int rem = pr;
+                while (rem >= nh - 1 - a) { rem -= nh - 1 - a; ++a; }
+                c = a + 1 + rem;
+                const int da = hubdeg[a], dc = hubdeg[c];
+                const int sx = da <= dc ? a : c, tx = da <= dc ? c : a;
+                key = nodes[hubloc[tx]];
+                lo = hubrb[sx];
+                hi = lo + hubdeg[sx];
+            }
+            // invariant: the key, if present, lies in [lo, hi)
+            while (wave_ballot(hi - lo > 16) != 0ull) {
+                const bool act = hi - lo > 16;
+                const int stp = (hi - lo + 15) >> 4;
+                const int idx = lo + sl * stp;
+                const bool le = act && idx < hi && col_idx[idx] <= key;      // monotone over the team's lanes
+                const int k = __popcll((wave_ballot(le) >> tsh) & 0xFFFFull);
+                if (act) {
+                    if (k == 0) { hi = lo; }                 // below the first entry
+                    else {
+                        const int nlo = lo + (k - 1) * stp, nhi = lo + k * stp;
+                        lo = nlo;
+                        hi = nhi < hi ? nhi : hi;
+                    }
+                }
+            }
+            const bool hit = valid && lo + sl < hi && col_idx[lo + sl] == key;
+            const bool any = ((wave_ballot(hit) >> tsh) & 0xFFFFull) != 0ull;
+            if (any && sl == 0) found(a, c);
+        }
+        return;
+    }
+    for (int pr = tid; pr < nh * nh; pr += kWalkThreads) {
+        const int a = pr / nh, c = pr - a * nh;
+        if (a >= c) continue;
+        const int da = hubdeg[a], dc = hubdeg[c];
+        const int sx = da <= dc ? a : c, tx = da <= dc ? c : a;     // look hub tx's id up in hub sx's (shorter) row
+        const int32_t key = nodes[hubloc[tx]];
+        const int rb0 = hubrb[sx], re0 = rb0 + hubdeg[sx];
+        int lo = rb0, hi = re0;                          // lower bound of the key (three independent probes per round were
+                                                         // measured slower than this: the searches are bound by requests, not latency)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (col_idx[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        if (lo < re0 && col_idx[lo] == key) found(a, c);
     }
 }
 
@@ -711,7 +822,7 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
             if (tid < nh) hubslot[w.hubloc[(int64_t)g * kMaxHub + tid]] = (uint8_t)tid;      // (nh <= kMaxHub <= threads)
             __syncthreads();
         }
-        int my_nnz = 0;
+        int my_nnz = 0, nhub_hits = 0;                       // wave-uniform: this wave's hits, and how many of them have a hub as target
         const int unit_end = min(nunits, (part + 1) * kUnitsPerVwg);
 #pragma unroll 1
         for (int unit = unit0;; unit += kInduceWaves) {              // wave-uniform; every wave enters once
@@ -748,13 +859,19 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
                         }
                     }
                     const unsigned long long m = wave_ballot(loc >= 0);
+                    uint32_t hs = 255u;
                     if (loc >= 0) {
                         const uint32_t lrow = srow16[candr[c]];      // the scanned row's local id
                         out[nout + __popcll(m & lanemask_lt())] = (int32_t)((lrow << 16) | (uint32_t)loc);
-                        const uint32_t hs = hubslot[loc];
+                        hs = hubslot[loc];
                         // the hit's mirror image: row `loc` is a hub and is not scanned -- (hub -> this row) is an edge too
-                        if (hs != 255u) atomicOr(&hmark[hs * (uint32_t)w.mwords + (lrow >> 5)], 1u << (lrow & 31));
+                        // (every (row, hub) pair is hit once -- rows hold no duplicates --, so every mark is a new entry)
+                        if (hs != 255u) {
+                            atomicOr(&hmark[hs * (uint32_t)w.mwords + (lrow >> 5)], 1u << (lrow & 31));
+                            atomicAdd(&w.hubcnt[(int64_t)g * kMaxHub + hs], 1);
+                        }
                     }
+                    nhub_hits += __popcll(wave_ballot(hs != 255u));
                     nout += __popcll(m);
                 }
                 wave_sync();
@@ -795,7 +912,7 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
             if (lane == 0) w.ucnt[ubase + unit] = nout;
             my_nnz += nout;
         }
-        if (lane == 0 && my_nnz) atomicAdd(&w.sub_nnz[g], my_nnz);
+        if (lane == 0 && my_nnz + nhub_hits) atomicAdd(&w.sub_nnz[g], my_nnz + nhub_hits);   // (+ the mirror images: the hubs' own rows)
         IND_TICK(2);
     }
 }
@@ -808,25 +925,30 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, PackOuts o
     __shared__ int32_t wsum[5];
     __shared__ int32_t uoff[257];                 // exclusive prefix of the hit counts of a chunk of 256 units
     __shared__ int32_t sh_base, sh_carry;
-    __shared__ int32_t hl[kMaxHub], hc[kMaxHub + 1];   // hub rows (ascending local ids) and the exclusive prefix of their entry counts
+    __shared__ int32_t hl[kMaxHub + 1], hc[kMaxHub + 1];   // hub rows (ascending local ids) and the exclusive prefix of their entry counts
     const int tid = (int)threadIdx.x;
     const int g = (int)blockIdx.x / kPackParts, part = (int)blockIdx.x % kPackParts;
     const int seg = g / B, b = g - seg * B;
     const BatchOutDev o = outs.o[seg];
     const int n = w.sub_n[g];
-    const int nnz = w.sub_nnz[g];                    // scanned hits + the hub rows' entries (hub_kernel)
+    const int nnz = w.sub_nnz[g];                    // scanned hits + the hub rows' entries
     const int nh = w.sub_nh[g];
-    if (tid == 0) {
-        int run = 0;
-        for (int k = 0; k < nh; ++k) { hl[k] = w.hubloc[(int64_t)g * kMaxHub + k]; hc[k] = run; run += w.hubcnt[(int64_t)g * kMaxHub + k]; }
-        hc[nh] = run;
+    if (tid < 64) {                                  // (kMaxHub <= 64: one wave, one round of loads)
+        const int cnt = tid < nh ? w.hubcnt[(int64_t)g * kMaxHub + tid] : 0;
+        const int incl = wave_scan_incl(cnt);
+        if (tid <= kMaxHub) hl[tid] = tid < nh ? w.hubloc[(int64_t)g * kMaxHub + tid] : 0x7FFFFFFF;
+        if (tid < nh) hc[tid] = incl - cnt;
+        if (tid == 63) hc[nh] = incl;
     }
     __syncthreads();
+    const int hs0 = nh > 16 ? 16 : (nh > 8 ? 8 : (nh > 4 ? 4 : (nh > 2 ? 2 : 1)));   // (2 * hs0 >= nh)
     // Hub rows are not in the flat sequence of scanned hits: everything at or after row i sits hshift(i) entries further on
     // (the entries of the hub rows before row i), and a hub row H itself starts at (scanned hits of rows < H) + hshift(H)
     auto hshift = [&](int i) -> int {
-        int k = 0;
-        while (k < nh && hl[k] < i) ++k;
+        if (nh == 0) return 0;
+        int k = 0;                                   // hubs with a local id below i (hl is padded with INT_MAX)
+        for (int st = hs0; st >= 1; st >>= 1) k += hl[k + st - 1] < i ? st : 0;
+        k += hl[k] < i ? 1 : 0;
         return hc[k];
     };
     const long long node_base = w.nbp[g];            // (prefix steps A / B)
@@ -940,58 +1062,13 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, PackOuts o
 }
 
 // ------------------------------------------------------------------ hub rows ----
-// hub_kernel (after the induction): edges between two hubs (neither row was scanned: one binary search per pair, in the
-// shorter row), then the number of entries of every hub's induced row = the bits of its neighbour bitmap.
-__global__ __launch_bounds__(256) void hub_kernel(const int32_t *__restrict__ col_idx, Work w)
-{
-    const int g = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nh = w.sub_nh[g];
-    if (nh == 0) return;                                 // (block-uniform)
-    __shared__ int32_t cnt[kMaxHub];
-    const int n = w.sub_n[g];
-    const int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
-    const int32_t *hloc = w.hubloc + (int64_t)g * kMaxHub, *hrb = w.hubrb + (int64_t)g * kMaxHub, *hdeg = w.hubdeg + (int64_t)g * kMaxHub;
-    uint32_t *hm = w.hubmark + (int64_t)g * kMaxHub * w.mwords;
-    for (int pr = tid; pr < nh * nh; pr += 256) {
-        const int a = pr / nh, c = pr % nh;
-        if (a >= c) continue;
-        const bool a_short = hdeg[a] <= hdeg[c];
-        const int s = a_short ? a : c, t = a_short ? c : a;   // look hub t's id up in hub s's (shorter) row
-        const int32_t key = nodes[hloc[t]];
-        int lo = hrb[s], hi = hrb[s] + hdeg[s];               // rows are sorted (input contract)
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (col_idx[mid] < key) lo = mid + 1; else hi = mid;
-        }
-        if (lo < hrb[s] + hdeg[s] && col_idx[lo] == key) {
-            atomicOr(&hm[a * w.mwords + (hloc[c] >> 5)], 1u << (hloc[c] & 31));
-            atomicOr(&hm[c * w.mwords + (hloc[a] >> 5)], 1u << (hloc[a] & 31));
-        }
-    }
-    __syncthreads();
-    const int words = (n + 31) >> 5;
-    int total = 0;
-    for (int k = wv; k < nh; k += 4) {                   // one wave per hub
-        int c = 0;
-        for (int i = lane; i < words; i += 64) c += __popc((uint32_t)load_fresh_i32((const int *)&hm[k * w.mwords + i]));
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) c += wave_shfl_xor(c, d);
-        if (lane == 0) { cnt[k] = c; w.hubcnt[(int64_t)g * kMaxHub + k] = c; }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (int k = 0; k < nh; ++k) total += cnt[k];
-        w.sub_nnz[g] += total;                           // (the induction's atomics are complete: kernel boundary)
-    }
-}
-
-// hub_write_kernel (after the pack): the entries of every hub row, in the order of the parent row -- ascending parent id,
-// i.e. ascending local id except that the seed (local id 0) stands where ITS parent id belongs.
+// hub_write_kernel (after the pack): the entries of every hub row -- the set bits of its neighbour bitmap (marked by the
+// walk kernel for hub pairs and by the induction for everything else) -- in the order of the parent row: ascending parent
+// id, i.e. ascending local id except that the seed (local id 0) stands where ITS parent id belongs.  One WAVE per hub (no
+// workgroup barrier): a lane takes the bitmap words lane, lane + 64, ...; a wave scan of the popcounts places them.
 __global__ __launch_bounds__(256) void hub_write_kernel(int32_t B, Work w, PackOuts outs, int64_t scratch_entries)
 {
-    __shared__ int32_t wsum[5];
-    __shared__ int32_t sh_p0;
-    const int g = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const int g = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nh = w.sub_nh[g];
     if (nh == 0) return;                                 // (block-uniform)
     const int seg = g / B;
@@ -999,48 +1076,37 @@ __global__ __launch_bounds__(256) void hub_write_kernel(int32_t B, Work w, PackO
     const int n = w.sub_n[g], nnz = w.sub_nnz[g];
     const long long node_base = w.nbp[g], edge_base = w.ebp[g];
     if (scratch_overflows(w, g, scratch_entries) || node_base + n > o.node_cap || edge_base + nnz > o.edge_cap) return;   // (pack left clamped rows)
-    const int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
-    if (tid == 0) {                                      // locals 1 .. p0 have smaller parent ids than the seed
-        const int32_t seed = nodes[0];
-        int lo = 1, hi = n;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (nodes[mid] < seed) lo = mid + 1; else hi = mid;
-        }
-        sh_p0 = lo - 1;
-    }
-    __syncthreads();
-    const int p0 = sh_p0;
+    const int p0 = w.sub_p0[g];                          // locals 1 .. p0 have smaller parent ids than the seed (walk kernel)
     const int words = (n + 31) >> 5;
     const uint32_t *hm = w.hubmark + (int64_t)g * kMaxHub * w.mwords;
-    for (int k = 0; k < nh; ++k) {
+    for (int k = wv; k < nh; k += 4) {                   // (wave-uniform)
         const int H = w.hubloc[(int64_t)g * kMaxHub + k];
         const long long base = (long long)o.row_ptr[node_base + H];      // written by the pack
         const uint32_t *bits = hm + k * w.mwords;
-        const uint32_t seed_bit = bits[0] & 1u;
-        int before = 0;                                  // block-uniform: entries of locals >= 1 in the words already done
-        for (int w0 = 0; w0 < words; w0 += 256) {
-            const int wi = w0 + tid;
+        const int seed_bit = (int)(bits[0] & 1u);
+        int before = 0, seed_at = 0;                     // wave-uniform: entries of locals >= 1 in the words done; of locals 1 .. p0
+        for (int w0 = 0; w0 < words; w0 += 64) {
+            const int wi = w0 + lane;
             uint32_t v = wi < words ? bits[wi] : 0u;
             if (wi == 0) v &= ~1u;                       // the seed is placed separately
-            int tot;
-            const int incl = block_scan_incl(__popc(v), &tot, wsum);
-            int at = before + incl - __popc(v);          // entries of locals >= 1 before this word
+            // bits of this word that belong to locals <= p0
+            const int lo_bit = wi * 32;
+            const uint32_t m_le = p0 >= lo_bit + 31 ? 0xFFFFFFFFu : (p0 < lo_bit ? 0u : (0xFFFFFFFFu >> (31 - (p0 - lo_bit))));
+            const int pc = __popc(v), pl = __popc(v & m_le);
+            const int incl = wave_scan_incl(pc | (pl << 16));            // (n <= 65535: both sums fit 16 bits)
+            const int tot = wave_last(incl);
+            int at = before + (incl & 0xFFFF) - pc;      // entries of locals >= 1 before this word
             while (v) {
                 const int bit = __ffsll((unsigned long long)v) - 1;
                 v &= v - 1;
-                const int loc = wi * 32 + bit;
-                o.col_idx[base + at + (loc > p0 ? (int)seed_bit : 0)] = (int32_t)node_base + loc;
+                const int loc = lo_bit + bit;
+                o.col_idx[base + at + (loc > p0 ? seed_bit : 0)] = (int32_t)node_base + loc;
                 ++at;
             }
-            before += tot;
+            before += tot & 0xFFFF;
+            seed_at += tot >> 16;
         }
-        if (seed_bit && tid == 0) {                      // after the p0 locals with smaller parent ids that are neighbours
-            int c = 0;
-            for (int i = 1; i <= p0; ++i) c += (int)((bits[i >> 5] >> (i & 31)) & 1u);
-            o.col_idx[base + c] = (int32_t)node_base;
-        }
-        __syncthreads();
+        if (seed_bit && lane == 0) o.col_idx[base + seed_at] = (int32_t)node_base;
     }
 }
 
@@ -1121,6 +1187,7 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     w.srow = (int32_t *)(base + wl.off_srow);
     w.sub_ns = (int32_t *)(base + wl.off_ns);
     w.sub_nh = (int32_t *)(base + wl.off_nh);
+    w.sub_p0 = (int32_t *)(base + wl.off_p0);
     w.hubloc = (int32_t *)(base + wl.off_hubloc);
     w.hubrb = (int32_t *)(base + wl.off_hubrb);
     w.hubdeg = (int32_t *)(base + wl.off_hubdeg);
@@ -1149,6 +1216,7 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     const size_t lds2 = (size_t)wl.ncap * 19 + 8 + ((size_t)1 << (bmlog - 3)) + (size_t)kInduceWaves * (kCandCap * 6 + kUnitQuads * 2) + 16;
     // rows of at least this degree are not scanned (kMaxHub per subgraph): hub_degree 0 = default, < 0 = scan everything
     const int32_t hub_degree = p->hub_degree == 0 ? kHubDegreeDefault : (p->hub_degree < 0 ? 0x7FFFFFFF : p->hub_degree);
+    const int32_t max_hubs = p->max_hubs <= 0 ? kMaxHubsDefault : (p->max_hubs > kMaxHub ? kMaxHub : p->max_hubs);
     if (lds1 > 160 * 1024 || lds2 > 160 * 1024 - 256) {
         snprintf(g_err, kErrLen, "gcc_sample_multi: lmax=%d / batch too large for 160 KiB of LDS", g->lmax);
         return -4;
@@ -1168,14 +1236,13 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
 #endif
     hipLaunchKernelGGL(rwr_walk_kernel, dim3(G), dim3(kWalkThreads), lds1, s, g->row_ptr, g->col_idx, g->seed_cdf,
                        g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, sample_id_stride, B,
-                       p->restart_u32, p->seeds, g->num_shards > 1 ? g->shard_off : nullptr, g->num_shards, hub_degree, w);
+                       p->restart_u32, p->seeds, g->num_shards > 1 ? g->shard_off : nullptr, g->num_shards, hub_degree, max_hubs, w);
     hipLaunchKernelGGL(prefix_a_kernel, dim3(1), dim3(kPrefixThreads), (size_t)(G + 1) * 4, s, B, w);
     hipLaunchKernelGGL(records_kernel, dim3((G * kGridMult + 255) / 256), dim3(256), 0, s, B, w);
     prof_mark(p->prof, 1, s);                        // marks 1 -> 2 bracket induce_kernel alone (bench.py's roofline interval)
     hipLaunchKernelGGL(induce_kernel, dim3(G * kGridMult), dim3(kInduceThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,
                        scratch_entries, w, status, g_induce_ticks);
     prof_mark(p->prof, 2, s);
-    hipLaunchKernelGGL(hub_kernel, dim3(G), dim3(256), 0, s, g->col_idx, w);
     hipLaunchKernelGGL(prefix_b_kernel, dim3(1), dim3(256), 0, s, B, w);
     hipLaunchKernelGGL(pack_kernel, dim3(G * kPackParts), dim3(256), 0, s, B, w, po, scratch_entries, status);
     hipLaunchKernelGGL(hub_write_kernel, dim3(G), dim3(256), 0, s, B, w, po, scratch_entries);

@@ -117,7 +117,7 @@ class DeviceRWRSampler:
 
     def __init__(self, graph: DeviceGraph, batch_size: int, run_seed: int = 0,
                  edge_cap: int | None = None, scratch_entries: int | None = None, num_buffers: int = 2,
-                 max_steps: int = 1, hub_degree: int = 0):
+                 max_steps: int = 1, hub_degree: int = 0, max_hubs: int = 0):
         """``max_steps``: most consecutive steps one call may cover (:meth:`sample_multi`; the workspace and the
         induction scratch are sized for that many batches, and the buffer ring must hold at least as many)."""
         import torch
@@ -125,8 +125,9 @@ class DeviceRWRSampler:
         self.graph = graph
         self.lib = _cabi.load()
         # member rows of at least this parent degree are not scanned by the induction (gcc_sample_params.hub_degree:
-        # 0 = the library's default of 256, < 0 = scan every row); the subgraphs are the same bit for bit
+        # 0 = the library's default of 512, < 0 = scan every row); the subgraphs are the same bit for bit
         self.hub_degree = int(hub_degree)
+        self.max_hubs = int(max_hubs)         # most unscanned rows per subgraph (0 = the library's default and maximum, 32)
         self.batch_size = int(batch_size)
         self.run_seed = int(run_seed) & 0xFFFFFFFFFFFFFFFF
         dev = graph.device
@@ -192,7 +193,7 @@ class DeviceRWRSampler:
             run_seed=self.run_seed, first_sample_id=int(first_sample_id), batch_size=self.batch_size,
             restart_u32=self.graph.restart_u32,
             seeds=_cabi.dev_ptr(seeds, torch.int32) if seeds is not None else None,
-            prof=prof.handle if prof is not None else None, hub_degree=self.hub_degree)
+            prof=prof.handle if prof is not None else None, hub_degree=self.hub_degree, max_hubs=self.max_hubs)
         cq, ck = q.c_struct(), k.c_struct()
         rc = self.lib.gcc_sample_batch(
             self.graph.byref(), ctypes.byref(params), ctypes.byref(cq), ctypes.byref(ck),
@@ -224,7 +225,7 @@ class DeviceRWRSampler:
             params = _cabi.GccSampleParams(
                 run_seed=self.run_seed, first_sample_id=int(first_sample_id) + at * stride, batch_size=B,
                 restart_u32=self.graph.restart_u32, seeds=None,
-                prof=prof.handle if (prof is not None and at == 0) else None, hub_degree=self.hub_degree)
+                prof=prof.handle if (prof is not None and at == 0) else None, hub_degree=self.hub_degree, max_hubs=self.max_hubs)
             rc = self.lib.gcc_sample_multi(
                 self.graph.byref(), ctypes.byref(params), n, stride, outs, self.workspace.data_ptr(),
                 self.workspace.numel(), self.scratch_entries, self.status.data_ptr(),

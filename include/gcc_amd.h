@@ -98,10 +98,12 @@ typedef struct gcc_sample_params {
     uint32_t restart_u32;      /* floor(restart_prob * 2^32)                          */
     const int32_t *seeds;      /* device [B] or NULL; non-NULL overrides the seed draw */
     gcc_prof *prof;            /* NULL, or marks 0..3 recorded around walk/induce/pack */
-    int32_t hub_degree;        /* member rows of at least this parent degree (at most 32 per subgraph) are NOT scanned by the
-                                * induction: the graph is symmetric, so their induced rows are the mirror images of the other
-                                * rows' hits + one binary search per pair of hubs -- same result bit for bit, 67-82 % fewer
-                                * bytes scanned on power-law graphs.  0 = default (256), < 0 = scan every row */
+    int32_t hub_degree;        /* member rows of at least this parent degree are NOT scanned by the induction: the graph is
+                                * symmetric, so their induced rows are the mirror images of the other rows' hits + one search
+                                * per pair of hubs -- same result bit for bit, fewer bytes scanned on power-law graphs.
+                                * 0 = default (512), < 0 = scan every row */
+    int32_t max_hubs;          /* most such rows per subgraph (1..32; 0 = default, 32): with more rows over hub_degree the
+                                * subgraph's own threshold rises to the power of two that leaves at most this many */
 } gcc_sample_params;
 
 /* One view's batched graph = dgl.batch(list of subgraphs), data_util.py:26-32.

@@ -53,7 +53,7 @@ class EmuGraph:
 
 
 def emu_sample_batch(g: EmuGraph, B, run_seed, first_sample_id, seeds=None, edge_cap=None,
-                     scratch_entries=None, node_cap=None, hub_degree=0):
+                     scratch_entries=None, node_cap=None, hub_degree=0, max_hubs=0):
     lib = emu_lib()
     node_cap = node_cap or B * (g.lmax + 1)
     edge_cap = edge_cap or B * (g.lmax + 1) ** 2
@@ -76,7 +76,7 @@ def emu_sample_batch(g: EmuGraph, B, run_seed, first_sample_id, seeds=None, edge
     if seeds is not None:
         seeds = np.ascontiguousarray(seeds, dtype=np.int32)
     params = _cabi.GccSampleParams(run_seed=run_seed, first_sample_id=first_sample_id, batch_size=B,
-                                   restart_u32=g.restart_u32, seeds=_p(seeds), hub_degree=hub_degree)
+                                   restart_u32=g.restart_u32, seeds=_p(seeds), hub_degree=hub_degree, max_hubs=max_hubs)
     rc = lib.gcc_sample_batch(ctypes.byref(g.c), ctypes.byref(params), ctypes.byref(structs[0]),
                               ctypes.byref(structs[1]), _p(ws), nbytes, scratch_entries, _p(status), None)
     if rc != 0:
@@ -90,7 +90,7 @@ def emu_sample_batch(g: EmuGraph, B, run_seed, first_sample_id, seeds=None, edge
 
 
 def emu_sample_multi(g: EmuGraph, B, run_seed, first_sample_id, num_steps, stride, edge_cap=None, scratch_entries=None,
-                     node_cap=None, hub_degree=0):
+                     node_cap=None, hub_degree=0, max_hubs=0):
     """gcc_sample_multi on the emulator -> ([(q, k) per step], status, seeds [num_steps * B])."""
     lib = emu_lib()
     node_cap = node_cap or B * (g.lmax + 1)
@@ -112,7 +112,7 @@ def emu_sample_multi(g: EmuGraph, B, run_seed, first_sample_id, num_steps, strid
                                        row_ptr=_p(o["row_ptr"]), col_idx=_p(o["col_idx"]),
                                        node_cap=node_cap, edge_cap=edge_cap)
     params = _cabi.GccSampleParams(run_seed=run_seed, first_sample_id=first_sample_id, batch_size=B,
-                                   restart_u32=g.restart_u32, seeds=None, hub_degree=hub_degree)
+                                   restart_u32=g.restart_u32, seeds=None, hub_degree=hub_degree, max_hubs=max_hubs)
     rc = lib.gcc_sample_multi(ctypes.byref(g.c), ctypes.byref(params), num_steps, stride, structs, _p(ws), nbytes,
                               scratch_entries, _p(status), None)
     if rc != 0:

@@ -211,21 +211,24 @@ def test_multi_step_call_equals_the_single_step_calls(coracle):
         emu_sample_multi(g, B, 11, first, 17, stride)
 
 
-# ---- hub rows are not scanned (sampler.hip: hub_kernel / hub_write_kernel): same result, bit for bit
+# ---- hub rows are not scanned (sampler.hip: walk kernel tail / hub_write_kernel): same result, bit for bit
+@pytest.mark.parametrize("max_hubs", [0, 1, 3, 32])
 @pytest.mark.parametrize("hub_degree", [1, 2, 3, 8, 40, -1])
-def test_unscanned_hub_rows_give_the_same_subgraphs(coracle, hub_degree):
-    """Rows of at least ``hub_degree`` (at most 32 per subgraph) are skipped by the induction; their induced rows are the
-    mirror images of the other rows' hits (the parent graph is symmetric) + one binary search per pair of hubs.  With the
-    threshold at 1 EVERY row of a small ego-net is a hub (nothing is scanned at all: hub pairs only), at 2 .. 40 the mix
-    shifts, -1 scans everything (the rounds 1-3 path); the default 256 leaves these small graphs unaffected.  Always the
-    C oracle's batches: node lists, row order, the seed's position inside a row."""
+def test_unscanned_hub_rows_give_the_same_subgraphs(coracle, hub_degree, max_hubs):
+    """Rows of at least ``hub_degree`` are skipped by the induction; their induced rows are the mirror images of the other
+    rows' hits (the parent graph is symmetric) + one search per pair of hubs.  At most ``max_hubs`` per subgraph (0 = the
+    default, 8): a subgraph with more rows over the threshold raises ITS threshold to the next power of two that leaves few
+    enough.  With the threshold at 1 and 32 slots EVERY row of a small ego-net is a hub (nothing is scanned at all: hub
+    pairs only, the one-lane searches), with few slots the 16-lane searches run; -1 scans everything (the rounds 1-3
+    path); the default 256 leaves these small graphs unaffected.  Always the C oracle's batches: node lists, row order,
+    the seed's position inside a row."""
     rp, ci = powerlaw_graph(3000, 30000, 3)
     g = EmuGraph(rp, ci, rw_hops=64)
-    _compare(coracle, rp, ci, g, 7, 21, 500, hub_degree=hub_degree)
-    # hub seeds with several hundred members (more rows over the threshold than the 32 hub slots: the rest are scanned)
+    _compare(coracle, rp, ci, g, 7, 21, 500, hub_degree=hub_degree, max_hubs=max_hubs)
+    # hub seeds with several hundred members (far more rows over the threshold than hub slots: the threshold adapts)
     rp2, ci2 = powerlaw_graph(20000, 400000, 1)
     hubs = np.argsort(np.diff(rp2))[-2:].astype(np.int32)
-    _compare(coracle, rp2, ci2, EmuGraph(rp2, ci2, rw_hops=64), 2, 7, 0, seeds=hubs, hub_degree=hub_degree)
+    _compare(coracle, rp2, ci2, EmuGraph(rp2, ci2, rw_hops=64), 2, 7, 0, seeds=hubs, hub_degree=hub_degree, max_hubs=max_hubs)
 
 
 @pytest.mark.parametrize("name", ["path5", "star6", "tri_tail", "k4"])

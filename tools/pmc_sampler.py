@@ -32,7 +32,8 @@ def per_kernel(folder, counter):
                 if row.get("Counter_Name") != counter:
                     continue
                 full = row["Kernel_Name"]
-                name = next((k for k in ("rwr_walk_kernel", "induce_kernel", "pack_kernel", "prefix_a_kernel", "prefix_b_kernel", "records_kernel")
+                name = next((k for k in ("rwr_walk_kernel", "induce_kernel", "pack_kernel", "prefix_a_kernel", "prefix_b_kernel", "records_kernel",
+                                         "hub_write_kernel")
                              if k in full), None)
                 if name is None:
                     continue
