@@ -50,26 +50,43 @@ constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 constexpr int kWalkThreads = 256;  // 4 waves per subgraph
 constexpr int kUnitQuads = 256;    // 16-byte quads of col_idx per unit: 64 lanes x 4 dwordx4 loads
 constexpr int kUnitElems = 4 * kUnitQuads;
+// induce workgroups: the small class (subgraphs of at most kSmallMembers members) and the big class (induce_kernel).  A
+// virtual workgroup is 2 units per wave; the static grids are kGridMult workgroups per subgraph / kBigGrid workgroups.
+// Measured after hub rows stopped being scanned (profiles/r4_sampler_classes.md): 256 threads and 4 workgroups per
+// subgraph for the small class (most of its subgraphs have one to four units left), 512 threads for the big one.
 #ifndef GCC_INDUCE_THREADS
-#define GCC_INDUCE_THREADS 512
+#define GCC_INDUCE_THREADS 256
 #endif
-#ifndef GCC_INDUCE_VWG_UNITS
-#define GCC_INDUCE_VWG_UNITS (GCC_INDUCE_THREADS / 32)
+#ifndef GCC_INDUCE_BIG_THREADS
+#define GCC_INDUCE_BIG_THREADS 512
 #endif
-constexpr int kUnitsPerVwg = GCC_INDUCE_VWG_UNITS;    // units per virtual workgroup (2 per wave, one after the other)
 #ifndef GCC_INDUCE_GRID_MULT
-#define GCC_INDUCE_GRID_MULT 8
+#define GCC_INDUCE_GRID_MULT 4
 #endif
 #ifndef GCC_INDUCE_OCC
 #define GCC_INDUCE_OCC
 #endif
 constexpr int kInduceThreads = GCC_INDUCE_THREADS;
-constexpr int kInduceWaves = kInduceThreads / 64;
+constexpr int kInduceBigThreads = GCC_INDUCE_BIG_THREADS;
 constexpr int kGridMult = GCC_INDUCE_GRID_MULT;   // induce workgroups per subgraph (a static grid; see induce_kernel)
-constexpr int kRecInts = 12;       // per induce workgroup: {count, g, part, n, quads, unit base, scratch base (2), pad}
+__host__ __device__ constexpr int vwg_units(int threads) { return threads / 32; }    // units per virtual workgroup (2 per wave, one after the other)
+#ifndef GCC_SMALL_MEMBERS
+#define GCC_SMALL_MEMBERS 320
+#endif
+constexpr int kSmallMembers = GCC_SMALL_MEMBERS; // LDS tables of the small induce class (a multiple of 64)
+#ifndef GCC_INDUCE_BIG_GRID
+#define GCC_INDUCE_BIG_GRID 1024
+#endif
+constexpr int kBigGrid = GCC_INDUCE_BIG_GRID;     // induce workgroups of the big class (subgraphs with more members than the small class has LDS for)
+constexpr int kRecInts = 12;       // per induce workgroup: {count, g, part, n, quads, unit base, scratch base (2), scanned rows, hubs, pad}
 constexpr int kPrefixThreads = 1024;
 constexpr int kCandCap = 256;      // per-wave queue of Bloom survivors (drained before every round of 256 that might not fit)
-constexpr int kPackParts = 4;      // pack workgroups per subgraph (hub-seed subgraphs have 100x the units)
+#ifndef GCC_PACK_PARTS
+#define GCC_PACK_PARTS 2
+#endif
+constexpr int kPackParts = GCC_PACK_PARTS;      // pack workgroups per subgraph.  4 while every row was scanned (hub-seed subgraphs had 100x the units); with the
+                                                // hub rows out, measured per 16-step launch G1 / G2: 4 parts 0.606 / 1.486 ms, 2 parts 0.556 / 1.458, 1 part
+                                                // 0.546 / 1.520; one part for small subgraphs and four for big ones with the idle parts leaving at once: 0.599 / 1.476
 // Hub rows are NOT scanned (round 4).  The parent graph is symmetric (the input contract, x2dgl.py:43-47): member v's row
 // holds hub H exactly when H's row holds v, so every edge (H -> v) of the induced subgraph is the mirror image of a hit
 // (v -> H) found while scanning v's own -- short -- row (the induction marks it in H's neighbour bitmap), and edges
@@ -110,11 +127,14 @@ struct Work {
     int32_t *nbp;         // [G + 1]     node offset of a subgraph inside its view's batch       (prefix kernel A)
     int32_t *ebp;         // [G + 1]     edge offset of a subgraph inside its view's batch       (prefix kernel B)
     int32_t *ucnt;        // [unit_cap]  hits of every unit
-    int32_t *wrec;        // [G * kGridMult][kRecInts] where each induce workgroup starts        (prefix step A)
+    int32_t *wrec;        // [G * kGridMult + kBigGrid][kRecInts] where each induce workgroup starts (prefix step A); the big class's after the small one's
+    int32_t *vbpb;        // [G + 1]     the same prefix for the big class (subgraphs with more than lcap members; vbp counts the others)
+    int32_t lcap;         // members a small-class induce workgroup has LDS tables for (>= ncap: one class)
     int32_t *scratch;     // [scratch_entries] hits: (row << 16) | local column, one slot of 1024 per unit
     int32_t *srow;        // [G][ncap]   local id of the s-th SCANNED row (rowbeg / rowdeg / rowq are indexed by s, not by local id)
     int32_t *sub_ns;      // [G]         scanned rows
     int32_t *sub_nh;      // [G]         hub rows (not scanned)
+    int32_t *big;         // [1 + G]     count, then the subgraphs the small walk launch left to the big one
     int32_t *sub_p0;      // [G]         members (other than the seed) whose parent id is below the seed's
     int32_t *hubloc;      // [G][kMaxHub] local id of hub k (ascending)
     int32_t *hubrb;       // [G][kMaxHub] its parent row's begin
@@ -130,7 +150,7 @@ struct Work {
 struct WorkLayout {
     int64_t off_seeds, off_n, off_quads, off_nnz, off_nodes, off_rowbeg, off_rowdeg, off_rowq,
         off_vbp, off_ubp, off_sbp, off_nbp, off_ebp, off_ucnt, off_wrec, off_scratch, total, unit_cap;
-    int64_t off_srow, off_ns, off_nh, off_p0, off_hubloc, off_hubrb, off_hubdeg, off_hubcnt, off_hubmark;
+    int64_t off_srow, off_ns, off_nh, off_p0, off_big, off_vbpb, off_hubloc, off_hubrb, off_hubdeg, off_hubcnt, off_hubmark;
     int32_t ncap;
 };
 
@@ -156,11 +176,13 @@ inline WorkLayout work_layout(int32_t lmax, int32_t B, int32_t nseg, int64_t scr
     w.off_nbp = o;    o = al(o + 4 * (G + 1));
     w.off_ebp = o;    o = al(o + 4 * (G + 1));
     w.off_ucnt = o;   o = al(o + 4 * w.unit_cap);
-    w.off_wrec = o;   o = al(o + 4 * G * kGridMult * kRecInts);
+    w.off_wrec = o;   o = al(o + 4 * (G * kGridMult + kBigGrid) * kRecInts);
+    w.off_vbpb = o;   o = al(o + 4 * (G + 1));
     w.off_srow = o;   o = al(o + 4 * G * w.ncap);
     w.off_ns = o;     o = al(o + 4 * G);
     w.off_nh = o;     o = al(o + 4 * G);
     w.off_p0 = o;     o = al(o + 4 * G);
+    w.off_big = o;    o = al(o + 4 * (G + 1));
     w.off_hubloc = o; o = al(o + 4 * G * kMaxHub);
     w.off_hubrb = o;  o = al(o + 4 * G * kMaxHub);
     w.off_hubdeg = o; o = al(o + 4 * G * kMaxHub);
@@ -195,16 +217,17 @@ __device__ __forceinline__ int block_scan_incl(int v, int *total, int32_t *wsum)
     return base + incl;
 }
 
-// two scans for one pair of barriers; wsum: LDS [8]
+// two scans for one pair of barriers; wsum: LDS [2 * waves]
 __device__ __forceinline__ void block_scan_incl2(int a, int b, int *ia, int *ib, int *ta, int *tb, int32_t *wsum)
 {
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nw = (int)blockDim.x >> 6;
     const int sa = wave_scan_incl(a), sb = wave_scan_incl(b);
-    if (lane == 63) { wsum[wv] = sa; wsum[4 + wv] = sb; }
+    if (lane == 63) { wsum[wv] = sa; wsum[nw + wv] = sb; }
     __syncthreads();
     int ba = 0, bb = 0, aa = 0, ab = 0;
-    for (int k = 0; k < 4; ++k) {
-        const int x = wsum[k], y = wsum[4 + k];
+    for (int k = 0; k < nw; ++k) {
+        const int x = wsum[k], y = wsum[nw + k];
         ba += k < wv ? x : 0;
         bb += k < wv ? y : 0;
         aa += x;
@@ -218,23 +241,35 @@ __device__ __forceinline__ int row_quads(int rb, int d) { return ((rb + d + 3) >
 
 
 // ------------------------------------------------------------------ K1 ----
-__global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
+// Two launches: the small class (kBig = false: 256 threads, workgroup g = subgraph g, LDS for traces of at most p2cap
+// entries -- 1024, 17 KiB, 8 workgroups per CU) hands the subgraphs whose seed allows a longer trace (graph_dataset.py:113-124:
+// L grows with deg^0.75; 2.5 % of the seeds on the 10M / 200M graph) on through w.big; the big class (kBig = true: 1024
+// threads, a resident grid over that list, LDS for the graph's longest trace) takes them.  With ONE launch sized for the
+// longest trace every workgroup reserved 66 KiB there (two per CU) for the sake of those 2.5 %.
+template <int kT, bool kBig>
+__global__ __launch_bounds__(kT) void rwr_walk_kernel(
     const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx,
     const double *__restrict__ seed_cdf, const int32_t *__restrict__ ltab, int64_t num_nodes,
-    int32_t ltab_len, int32_t p2max, uint64_t run_seed, int64_t first_sample_id, int64_t step_stride, int32_t B,
+    int32_t ltab_len, int32_t p2cap, uint64_t run_seed, int64_t first_sample_id, int64_t step_stride, int32_t B,
     uint32_t restart_u32, const int32_t *__restrict__ seeds_in, const int64_t *__restrict__ shard_off,
     int32_t num_shards, int32_t hub_degree, int32_t max_hubs, Work w)
 {
     DYN_SMEM(smem);
-    __shared__ int32_t wsum[8];
+    __shared__ int32_t wsum[2 * (kT / 64) + 1];
     __shared__ int32_t sh_want;                // members over the hub threshold
     __shared__ int32_t dhist[32];              // members by floor(log2(degree))
-    uint32_t *buf = (uint32_t *)smem;          // [p2max] trace -> sorted trace
-    int32_t *lq = (int32_t *)smem + p2max;     // [p2max + 64] quads of the kept rows (n <= L + 1)
-    int32_t *lrb = lq + p2max + 64;            // [p2max + 64] their row begins
-    int32_t *ld = lrb + p2max + 64;            // [p2max + 64] and degrees
+    uint32_t *buf = (uint32_t *)smem;          // [p2cap] trace -> sorted trace
+    int32_t *ld = (int32_t *)smem + p2cap;     // [p2cap + 64] degrees of the kept rows (n <= L + 1)
+    int32_t *lrb = ld + p2cap + 64;            // [p2cap + 64] their row begins          } small class only: the big class reads
+    int32_t *lq = lrb + p2cap + 64;            // [p2cap + 64] and quads                 } row_ptr again (half the LDS)
     const int tid = (int)threadIdx.x;
-    const int g = (int)blockIdx.x;
+    for (int item = (int)blockIdx.x;; item += (int)gridDim.x) {
+    int g = item;
+    if constexpr (kBig) {
+        __syncthreads();                       // (the previous item's tables are no longer read)
+        if (item >= w.big[0]) return;
+        g = w.big[1 + item];
+    }
     // subgraph g = segment * B + b, segment = 2 * step + view: a call covers the batches of several consecutive steps
     const int seg = g / B, b = g - seg * B;
     const int step = seg >> 1, view = seg & 1;
@@ -262,7 +297,7 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
         // workgroup-cooperative 256-ary upper bound: first index with cdf[i] > u (1M entries: 3 rounds)
         while (lo < hi) {
             const int64_t len = hi - lo;
-            const int64_t step = (len + kWalkThreads - 1) / kWalkThreads;
+            const int64_t step = (len + kT - 1) / kT;
             const int64_t idx = lo + (int64_t)tid * step;
             const bool le = (idx < hi) && (seed_cdf[idx] <= u);
             int k;
@@ -280,8 +315,14 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
     const int32_t deg0 = row_ptr[seed + 1] - rp0;
     const int32_t L = ltab[deg0 < ltab_len ? deg0 : ltab_len - 1];   // graph_dataset.py:113-124
     const int p2 = pow2_ceil(L);
+    if constexpr (!kBig) {
+        if (p2 > p2cap) {                      // (block-uniform) a long trace: the big class's
+            if (tid == 0) w.big[1 + atomicAdd(&w.big[0], 1)] = g;
+            return;
+        }
+    }
 
-    for (int i = tid; i < p2; i += kWalkThreads) buf[i] = kEmpty;
+    for (int i = tid; i < p2; i += kT) buf[i] = kEmpty;
     if (tid < 32) dhist[tid] = 0;
     __syncthreads();
 
@@ -290,7 +331,7 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
     const uint32_t k0 = (uint32_t)run_seed, k1 = (uint32_t)(run_seed >> 32);
     const uint32_t g0 = (uint32_t)gid, g1 = (uint32_t)(gid >> 32);
     int total = 0;   // block-uniform: trace entries assigned so far
-    for (int base = 0; total < L; base += kWalkThreads) {
+    for (int base = 0; total < L; base += kT) {
         const uint32_t walk = (uint32_t)(base + tid);
         uint32_t x0[4];
         philox4x32_10(walk, 0u, g0, g1, k0, k1, x0);
@@ -338,7 +379,7 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
     // ---- torch.unique (data_util.py:221): bitonic sort of the padded trace, all four waves
     for (int k = 2; k <= p2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < (p2 >> 1); i += kWalkThreads) {
+            for (int i = tid; i < (p2 >> 1); i += kT) {
                 const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
                 const int hi = lo + j;
                 const bool up = (lo & k) == 0;
@@ -353,10 +394,10 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
     int32_t *nodes = w.nodes + (int64_t)g * w.ncap;
     int32_t *rowbeg = w.rowbeg + (int64_t)g * w.ncap;
     int32_t *rowdeg = w.rowdeg + (int64_t)g * w.ncap;
-    if (tid == 0) { nodes[0] = seed; lrb[0] = rp0; ld[0] = deg0; lq[0] = row_quads(rp0, deg0); sh_want = deg0 >= hub_degree ? 1 : 0; if (deg0 >= hub_degree) atomicAdd(&dhist[31 - __builtin_clz((uint32_t)deg0 | 1u)], 1); }
+    if (tid == 0) { nodes[0] = seed; ld[0] = deg0; if constexpr (!kBig) { lrb[0] = rp0; lq[0] = row_quads(rp0, deg0); } sh_want = deg0 >= hub_degree ? 1 : 0; if (deg0 >= hub_degree) atomicAdd(&dhist[31 - __builtin_clz((uint32_t)deg0 | 1u)], 1); }
     __syncthreads();
     int n = 1, p0 = 0;   // block-uniform: members; members with a parent id below the seed's (they are sorted: locals 1 .. p0)
-    for (int i0 = 0; i0 < L; i0 += kWalkThreads) {
+    for (int i0 = 0; i0 < L; i0 += kT) {
         const int i = i0 + tid;
         uint32_t v = kEmpty, prev = kEmpty;
         if (i < L) { v = buf[i]; if (i > 0) prev = buf[i - 1]; }
@@ -371,9 +412,8 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
             const int32_t rb = row_ptr[v];
             const int32_t d = row_ptr[v + 1] - rb;
             nodes[pos] = (int32_t)v;
-            lrb[pos] = rb;
             ld[pos] = d;
-            lq[pos] = row_quads(rb, d);
+            if constexpr (!kBig) { lrb[pos] = rb; lq[pos] = row_quads(rb, d); }
             if (d >= hub_degree) { atomicAdd(&sh_want, 1); atomicAdd(&dhist[31 - __builtin_clz((uint32_t)d | 1u)], 1); }
         }
         n += kept;
@@ -396,22 +436,25 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
         thr = bb >= 31 ? 0x7FFFFFFF : (1 << bb);
         if (thr < hub_degree) thr = hub_degree;          // (the histogram holds the rows over hub_degree only: 2^bb may undercut it)
     }
-    for (int i0 = 0; i0 < n; i0 += kWalkThreads) {
+    for (int i0 = 0; i0 < n; i0 += kT) {
         const int i = i0 + tid;
         const bool in = i < n;
         const int d = in ? ld[i] : 0;
         const bool is_hub = in && d >= thr;
-        const int c = in && !is_hub ? lq[i] : 0;
+        int rbi = 0;
+        if (in) { if constexpr (kBig) rbi = row_ptr[nodes[i]]; else rbi = lrb[i]; }   // (nodes: this workgroup's own stores, before a barrier)
+        int c = 0;
+        if (in && !is_hub) { if constexpr (kBig) c = row_quads(rbi, d); else c = lq[i]; }
         int qincl, cnts, qsum, tots;                     // two scans, one pair of barriers
         block_scan_incl2(c, in ? (is_hub ? 1 << 16 : 1) : 0, &qincl, &cnts, &qsum, &tots, wsum);
         if (in && !is_hub) {
             const int p = ns + (cnts & 0xFFFF) - 1;
             srow[p] = i;
-            rowbeg[p] = lrb[i];
+            rowbeg[p] = rbi;
             rowdeg[p] = d;
             rowq[p] = run + qincl - c;
         }
-        if (is_hub) { const int hidx = nhw + (cnts >> 16) - 1; hubloc[hidx] = i; hubrb[hidx] = lrb[i]; hubdeg[hidx] = d; }
+        if (is_hub) { const int hidx = nhw + (cnts >> 16) - 1; hubloc[hidx] = i; hubrb[hidx] = rbi; hubdeg[hidx] = d; }
         run += qsum;
         ns += tots & 0xFFFF;
         nhw += tots >> 16;
@@ -421,7 +464,7 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
     int32_t *hubcnt = w.hubcnt + (int64_t)g * kMaxHub;
     {   // the hubs' neighbour bitmaps and entry counts start empty (only the words this subgraph can touch)
         const int words = (n + 31) >> 5;
-        for (int i = tid; i < nh * words; i += kWalkThreads) hm[(i / words) * w.mwords + (i % words)] = 0u;
+        for (int i = tid; i < nh * words; i += kT) hm[(i / words) * w.mwords + (i % words)] = 0u;
         if (tid < nh) hubcnt[tid] = 0;
     }
     if (tid == 0) {
@@ -444,12 +487,11 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
         atomicAdd(&hubcnt[c], 1);
         atomicAdd(&w.sub_nnz[g], 2);
     };
-    if (npairs == 0) return;                             // (block-uniform)
-    if (npairs <= 48) {
+    if (npairs > 0 && npairs <= 48) {                    // (block-uniform)
         // few pairs (the usual case): a team of 16 lanes per pair narrows the range 16-fold per round of loads -- 2 to 5
         // dependent loads for rows of 256 .. 1M entries where a one-lane binary search has 8 to 20
         const int lane = tid & 63, team = tid >> 4, sl = tid & 15, tsh = (lane >> 4) * 16;
-        for (int pr0 = 0; pr0 < npairs; pr0 += kWalkThreads / 16) {
+        for (int pr0 = 0; pr0 < npairs; pr0 += kT / 16) {
             const int pr = pr0 + team;
             const bool valid = pr < npairs;
             int a = 0, c = 1, lo = 0, hi = 0;
@@ -484,9 +526,8 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
             const bool any = ((wave_ballot(hit) >> tsh) & 0xFFFFull) != 0ull;
             if (any && sl == 0) found(a, c);
         }
-        return;
-    }
-    for (int pr = tid; pr < nh * nh; pr += kWalkThreads) {
+    } else if (npairs > 0) {
+    for (int pr = tid; pr < nh * nh; pr += kT) {
         const int a = pr / nh, c = pr - a * nh;
         if (a >= c) continue;
         const int da = hubdeg[a], dc = hubdeg[c];
@@ -500,6 +541,9 @@ __global__ __launch_bounds__(kWalkThreads) void rwr_walk_kernel(
             if (col_idx[mid] < key) lo = mid + 1; else hi = mid;
         }
         if (lo < re0 && col_idx[lo] == key) found(a, c);
+    }
+    }
+    if constexpr (!kBig) return;
     }
 }
 
@@ -552,72 +596,91 @@ __device__ __forceinline__ int units_of(int quads) { return (quads + kUnitQuads 
 // every virtual workgroup), step B after the induction (edge offsets per view).  (Folding them into the last workgroup
 // of the kernel before was measured: the agent-scope release every workgroup needs for the hand-off writes back L2 on
 // this multi-die part, 4096 times per launch -- the induction went from 45 to 305 us.  A kernel boundary is cheaper.)
-// dst[view * B + b] = exclusive prefix of src within each view (dgl.batch offsets restart per view).  All threads call.
-__device__ void view_prefix(int32_t B, int32_t nseg, const int32_t *src, int32_t *dst, int32_t *wsum /* LDS [waves] */)
+// Prefixes over the G subgraphs of a launch on ONE workgroup: wave k owns the k-th contiguous chunk of subgraphs and walks it
+// 64 at a time (coalesced loads, a wave scan per step, no barrier), one block step joins the waves' totals, a second walk
+// writes.  (One block scan per 1024 subgraphs and per view -- 32 views in a 16-step launch -- were 54 + 21 us per launch, a
+// tenth of a G1 launch; `per` consecutive subgraphs per thread with one block scan: 38 + 10, the stride-`per` loads.)
+// dst[view * B + b] = exclusive prefix of src within each view (dgl.batch offsets restart per view) = the prefix over all
+// G subgraphs minus its value at the view's first subgraph.  All threads call.
+__device__ void view_prefix(int32_t B, int32_t nseg, const int32_t *src, int32_t *dst, int32_t *wsum /* LDS [waves] */,
+                            int32_t *pre /* LDS [G + 1] */)
 {
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int view = 0; view < nseg; ++view) {              // every segment (a view of a step) is a batch of its own
-        int carry = 0;                                   // block-uniform
-        for (int b0 = 0; b0 < B; b0 += (int)blockDim.x) {
-            const int b = b0 + tid;
-            const int v = b < B ? src[view * B + b] : 0;
-            const int incl = wave_scan_incl(v);
-            if (lane == 63) wsum[wv] = incl;
-            __syncthreads();
-            int base = carry, tot = 0;
-            for (int k = 0; k < ((int)blockDim.x >> 6); ++k) {
-                if (k < wv) base += wsum[k];
-                tot += wsum[k];
-            }
-            if (b < B) dst[view * B + b] = base + incl - v;
-            carry += tot;
-            __syncthreads();
-        }
+    const int G = nseg * B, tid = (int)threadIdx.x, T = (int)blockDim.x, lane = tid & 63, wv = tid >> 6, nw = T >> 6;
+    const int chunk = ((G + nw - 1) / nw + 63) & ~63, c0 = wv * chunk, c1 = min(G, c0 + chunk);
+    int sum = 0;
+    for (int g = c0 + lane; g < c1; g += 64) sum += src[g];
+    sum = wave_last(wave_scan_incl(sum));
+    if (lane == 0) wsum[wv] = sum;
+    __syncthreads();
+    int run = 0;
+    for (int k = 0; k < wv; ++k) run += wsum[k];
+    for (int g0 = c0; g0 < c1; g0 += 64) {
+        const int g = g0 + lane;
+        const int v = g < c1 ? src[g] : 0;
+        const int incl = wave_scan_incl(v);
+        if (g < c1) pre[g] = run + incl - v;
+        run += wave_last(incl);
     }
+    __syncthreads();
+    for (int g = tid; g < G; g += T) dst[g] = pre[g] - pre[(g / B) * B];
 }
 
-// step A, one pass: thread t owns subgraphs t, t + blockDim, ... ; carries in registers (block-uniform).  Then the start
-// record of every induce workgroup: workgroup b takes the `chunk` CONSECUTIVE virtual workgroups from b * chunk on
-// (chunk = 1 unless there are more virtual workgroups than workgroups), and its record holds everything it would
-// otherwise fetch through three dependent loads (measured 6.3 of its 20 us on G1).
-__device__ void prefix_step_a(int32_t B, const Work &w, int32_t *wsum /* LDS [16][4] */, long long *wsum64 /* LDS [16] */,
-                              int32_t *lvbp /* LDS [G + 1] */)
+__device__ __forceinline__ long long wave_scan_incl64(long long v)
 {
-    const int G = w.nseg * B, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = (int)blockDim.x >> 6;
-    int cv = 0, cu = 0;
-    long long cs = 0;
-    for (int g0 = 0; g0 < G; g0 += (int)blockDim.x) {
-        const int g = g0 + tid;
-        const bool in = g < G;
-        const int q = in ? w.sub_quads[g] : 0;
-        const int u = units_of(q), v = (u + kUnitsPerVwg - 1) / kUnitsPerVwg;
-        const int iv = wave_scan_incl(v), iu = wave_scan_incl(u);
-        long long is = 4ll * q;
+    const int lane = (int)threadIdx.x & 63;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const long long t = wave_shfl_up(is, d);
-            if (lane >= d) is += t;
-        }
-        if (lane == 63) { wsum[wv * 4 + 0] = iv; wsum[wv * 4 + 1] = iu; wsum64[wv] = is; }
-        __syncthreads();
-        int bv = cv, bu = cu, tv = 0, tu = 0;
-        long long bs = cs, ts = 0;
-        for (int k = 0; k < nw; ++k) {
-            if (k < wv) { bv += wsum[k * 4]; bu += wsum[k * 4 + 1]; bs += wsum64[k]; }
-            tv += wsum[k * 4]; tu += wsum[k * 4 + 1]; ts += wsum64[k];
-        }
-        if (in) {
-            lvbp[g] = bv + iv - v;
-            w.ubp[g] = bu + iu - u;
-            w.sbp[g] = bs + is - 4ll * q;
-        }
-        cv += tv; cu += tu; cs += ts;
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long t = wave_shfl_up(v, d);
+        if (lane >= d) v += t;
     }
-    if (tid == 0) { lvbp[G] = cv; w.ubp[G] = cu; w.sbp[G] = cs; }
+    return v;
+}
+
+// step A, after the walks: virtual workgroups of either induce class, units, scratch slots (all over the whole launch), node
+// offsets per view.  Same shape as view_prefix.
+__device__ void prefix_step_a(int32_t B, const Work &w, int32_t *wsum /* LDS [64] */, long long *wsum64 /* LDS [16] */,
+                              int32_t *pre /* LDS [G + 1] */)
+{
+    const int G = w.nseg * B, tid = (int)threadIdx.x, T = (int)blockDim.x, lane = tid & 63, wv = tid >> 6, nw = T >> 6;
+    const int chunk = ((G + nw - 1) / nw + 63) & ~63, c0 = wv * chunk, c1 = min(G, c0 + chunk);
+    auto parts = [&](int g, int &v, int &vb, int &u, int &q) {
+        q = w.sub_quads[g];
+        const bool isbig = w.sub_n[g] > w.lcap;
+        u = units_of(q);
+        v = isbig ? 0 : (u + vwg_units(kInduceThreads) - 1) / vwg_units(kInduceThreads);
+        vb = isbig ? (u + vwg_units(kInduceBigThreads) - 1) / vwg_units(kInduceBigThreads) : 0;
+    };
+    int sv = 0, sb = 0, su = 0;
+    long long ss = 0;
+    for (int g = c0 + lane; g < c1; g += 64) {
+        int v, vb, u, q;
+        parts(g, v, vb, u, q);
+        sv += v; sb += vb; su += u; ss += 4ll * q;
+    }
+    sv = wave_last(wave_scan_incl(sv));
+    sb = wave_last(wave_scan_incl(sb));
+    su = wave_last(wave_scan_incl(su));
+    ss = wave_shfl(wave_scan_incl64(ss), 63);
+    if (lane == 0) { wsum[wv * 4 + 0] = sv; wsum[wv * 4 + 1] = sb; wsum[wv * 4 + 2] = su; wsum64[wv] = ss; }
     __syncthreads();
-    for (int g = tid; g <= G; g += (int)blockDim.x) w.vbp[g] = lvbp[g];      // for records_kernel
-    view_prefix(B, w.nseg, w.sub_n, w.nbp, wsum);
+    int rv = 0, rb = 0, ru = 0, tv = 0, tb = 0, tu = 0;
+    long long rs = 0, ts = 0;
+    for (int k = 0; k < nw; ++k) {
+        if (k < wv) { rv += wsum[k * 4]; rb += wsum[k * 4 + 1]; ru += wsum[k * 4 + 2]; rs += wsum64[k]; }
+        tv += wsum[k * 4]; tb += wsum[k * 4 + 1]; tu += wsum[k * 4 + 2]; ts += wsum64[k];
+    }
+    for (int g0 = c0; g0 < c1; g0 += 64) {
+        const int g = g0 + lane;
+        int v = 0, vb = 0, u = 0, q = 0;
+        if (g < c1) parts(g, v, vb, u, q);
+        const int iv = wave_scan_incl(v), ib = wave_scan_incl(vb), iu = wave_scan_incl(u);
+        const long long is = wave_scan_incl64(4ll * q);
+        if (g < c1) { w.vbp[g] = rv + iv - v; w.vbpb[g] = rb + ib - vb; w.ubp[g] = ru + iu - u; w.sbp[g] = rs + is - 4ll * q; }
+        rv += wave_last(iv); rb += wave_last(ib); ru += wave_last(iu); rs += wave_shfl(is, 63);
+    }
+    if (tid == 0) { w.vbp[G] = tv; w.vbpb[G] = tb; w.ubp[G] = tu; w.sbp[G] = ts; }
+    __syncthreads();                                   // (wsum is reused)
+    view_prefix(B, w.nseg, w.sub_n, w.nbp, wsum, pre);
 }
 
 __global__ __launch_bounds__(kPrefixThreads) void prefix_a_kernel(int32_t B, Work w)
@@ -633,17 +696,19 @@ __global__ __launch_bounds__(kPrefixThreads) void prefix_a_kernel(int32_t B, Wor
 __global__ __launch_bounds__(256) void records_kernel(int32_t B, Work w)
 {
     const int G = w.nseg * B;
-    const int nwg = G * kGridMult;
-    const int b = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (b >= nwg) return;
-    const int32_t *vbp = w.vbp;
+    const int nsmall = G * kGridMult;
+    const int bb = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (bb >= nsmall + kBigGrid) return;
+    const bool big = bb >= nsmall;                    // the big class's records follow the small one's
+    const int b = big ? bb - nsmall : bb, nwg = big ? kBigGrid : nsmall;
+    const int32_t *vbp = big ? w.vbpb : w.vbp;
     const int cv = vbp[G];
     const int chunk = (cv + nwg - 1) / nwg;
     const int vb0 = b * chunk;
-    int32_t *rec = w.wrec + (int64_t)b * kRecInts;
+    int32_t *rec = w.wrec + (int64_t)bb * kRecInts;
     const int count = min(chunk, cv - vb0);
     if (count <= 0) { rec[0] = 0; return; }
-    int lo = 0, hi = G;                               // last g with vbp[g] <= vb0 (it has virtual workgroups: vbp[g + 1] > vb0)
+    int lo = 0, hi = G;                               // last g with vbp[g] <= vb0 (it has virtual workgroups OF THIS CLASS: vbp[g + 1] > vb0)
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (vbp[mid] <= vb0) lo = mid; else hi = mid;
@@ -660,10 +725,11 @@ __global__ __launch_bounds__(256) void records_kernel(int32_t B, Work w)
     rec[8] = w.sub_ns[lo];
     rec[9] = w.sub_nh[lo];
 }
-__global__ __launch_bounds__(256) void prefix_b_kernel(int32_t B, Work w)
+__global__ __launch_bounds__(kPrefixThreads) void prefix_b_kernel(int32_t B, Work w)
 {
-    __shared__ int32_t wsum[4];
-    view_prefix(B, w.nseg, w.sub_nnz, w.ebp, wsum);
+    DYN_SMEM(smem);
+    __shared__ int32_t wsum[16];
+    view_prefix(B, w.nseg, w.sub_nnz, w.ebp, wsum, (int32_t *)smem);
 }
 
 __device__ __forceinline__ bool scratch_overflows(const Work &w, int g, int64_t scratch_entries)
@@ -675,30 +741,36 @@ __device__ __forceinline__ bool scratch_overflows(const Work &w, int g, int64_t 
 // ------------------------------------------------------------------ K2 ----
 static long long *g_induce_ticks = nullptr;      // diagnostics (gcc_sampler_debug_ticks): [0..2] phase ticks, [15] workgroups
 #define IND_TICK(ph) do { if (ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&ticks[ph], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
-__global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
+template <int kT>
+__global__ __launch_bounds__(kT) GCC_INDUCE_OCC void induce_kernel(
     const int32_t *__restrict__ col_idx, int64_t num_edges, int32_t bm_log2_cap, int32_t B, int64_t scratch_entries,
-    Work w, int32_t *__restrict__ status, long long *ticks)
+    Work w, int32_t *__restrict__ status, long long *ticks, int32_t big, int32_t lcap)
 {
+    // Two launches (like the walks): the small class has LDS tables for lcap = w.lcap members (320: every subgraph whose
+    // seed has the rw_hops trace budget, 91 % on the bench graphs; 27 KiB, six workgroups per CU), the big class for the
+    // graph's longest trace (ncap; 70 KiB at lmax 2348: two per CU, which every workgroup paid before the split).
     DYN_SMEM(smem);
-    const int ncap = w.ncap, G = w.nseg * B;
-    uint32_t *snodes = (uint32_t *)smem;                     // [ncap]     members (seed first, the rest ascending)
-    int32_t *sq = (int32_t *)(snodes + ncap);                // [ncap + 1] exclusive prefix of quads per row
-    int32_t *srb = sq + (ncap + 2);                          // [ncap]     row begin  (sq padded: what follows stays 8-byte aligned)
-    int32_t *srd = srb + ncap;                               // [ncap]     row degree   (sq / srb / srd: SCANNED rows, by scan position)
-    uint16_t *srow16 = (uint16_t *)(srd + ncap);             // [ncap]     local id of a scanned row
-    uint8_t *hubslot = (uint8_t *)(srow16 + ncap);           // [ncap]     hub index of a member, 255 = not a hub
-    uint32_t *bm = (uint32_t *)(hubslot + ncap);             // [1 << (bm_log2_cap - 5)] Bloom bitmap of the members   (ncap % 64 == 0)
+    constexpr int kW = kT / 64, kUV = vwg_units(kT);
+    const int ncap = w.ncap, G = w.nseg * B;                 // (ncap: the stride of the per-subgraph arrays in the workspace)
+    uint32_t *snodes = (uint32_t *)smem;                     // [lcap]     members (seed first, the rest ascending)
+    int32_t *sq = (int32_t *)(snodes + lcap);                // [lcap + 1] exclusive prefix of quads per row
+    int32_t *srb = sq + (lcap + 2);                          // [lcap]     row begin  (sq padded: what follows stays 8-byte aligned)
+    int32_t *srd = srb + lcap;                               // [lcap]     row degree   (sq / srb / srd: SCANNED rows, by scan position)
+    uint16_t *srow16 = (uint16_t *)(srd + lcap);             // [lcap]     local id of a scanned row
+    uint8_t *hubslot = (uint8_t *)(srow16 + lcap);           // [lcap]     hub index of a member, 255 = not a hub
+    uint32_t *bm = (uint32_t *)(hubslot + lcap);             // [1 << (bm_log2_cap - 5)] Bloom bitmap of the members   (lcap % 64 == 0)
     uint32_t *candv_all = bm + (1u << (bm_log2_cap - 5));    // [4][kCandCap] Bloom survivors (parent ids) ...
-    uint16_t *candr_all = (uint16_t *)(candv_all + kInduceWaves * kCandCap);   // [waves][kCandCap] ... and their row
+    uint16_t *candr_all = (uint16_t *)(candv_all + kW * kCandCap);   // [waves][kCandCap] ... and their row
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = wave_uniform(tid >> 6);
     uint32_t *candv = candv_all + wave * kCandCap;
     uint16_t *candr = candr_all + wave * kCandCap;
-    uint16_t *rowl = candr_all + kInduceWaves * kCandCap + wave * kUnitQuads;   // [waves][256] row of every quad of a unit
+    uint16_t *rowl = candr_all + kW * kCandCap + wave * kUnitQuads;   // [waves][256] row of every quad of a unit
     long long tick_ = ticks ? device_ticks() : 0;
     if (ticks && tid == 0) atomicAdd((unsigned long long *)&ticks[15], 1ull);
-    const uint4 *recp = (const uint4 *)(w.wrec + (int64_t)blockIdx.x * kRecInts);   // (prefix step A)
+    const int32_t *myrec = w.wrec + ((int64_t)blockIdx.x + (big ? (int64_t)G * kGridMult : 0)) * kRecInts;   // (prefix step A)
+    const uint4 *recp = (const uint4 *)myrec;
     const uint4 ra = recp[0], rb4 = recp[1];
-    const uint2 rc2 = *(const uint2 *)(w.wrec + (int64_t)blockIdx.x * kRecInts + 8);
+    const uint2 rc2 = *(const uint2 *)(myrec + 8);
     const int count = wave_uniform((int)ra.x);               // (uniform by construction: into scalar registers)
     int g = wave_uniform((int)ra.y), part = wave_uniform((int)ra.z), n = wave_uniform((int)ra.w);
     int ns = wave_uniform((int)rc2.x), nh = wave_uniform((int)rc2.y);   // scanned rows, hubs
@@ -711,11 +783,14 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
     // workgroups handed out through a counter was measured slower: 52 against 45 us.)
     for (int it = 0; it < count; ++it) {
         if (it) {
-            if (++part * kUnitsPerVwg >= units_of(totq)) {   // on to the next subgraph that has edges (block-uniform)
+            if (++part * kUV >= units_of(totq)) {   // on to the next subgraph that has edges (block-uniform)
                 part = 0;
-                do { ++g; totq = g < G ? wave_uniform(w.sub_quads[g]) : 1; } while (totq == 0);
+                do {                                         // ... of this class
+                    ++g;
+                    totq = g < G ? wave_uniform(w.sub_quads[g]) : 1;
+                    n = g < G ? wave_uniform(w.sub_n[g]) : (big ? 0x7FFFFFFF : 0);
+                } while (totq == 0 || (n > w.lcap) != (big != 0));
                 if (g >= G) break;                           // (the records and the prefixes come from the same pass)
-                n = wave_uniform(w.sub_n[g]);
                 ns = wave_uniform(w.sub_ns[g]);
                 nh = wave_uniform(w.sub_nh[g]);
                 ubase = wave_uniform(w.ubp[g]);
@@ -730,7 +805,7 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
             continue;
         }
         IND_TICK(0);
-        // this wave's units are wave, wave + 4, ... of the virtual workgroup's kUnitsPerVwg.  issue(): the rows of a
+        // this wave's units are wave, wave + 4, ... of the virtual workgroup's kUV.  issue(): the rows of a
         // unit's quads (binary search in the LDS prefix), then its 4 dwordx4 loads per lane.  (Two units in flight per
         // wave were measured: 112 VGPRs, 4 workgroups per CU instead of 6, 42 against 37 us.)
         uint4 v[4];
@@ -795,23 +870,23 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
                 }
             }
         };
-        const int unit0 = part * kUnitsPerVwg + wave;
+        const int unit0 = part * kUV + wave;
         if (g != cur_g) {                                    // block-uniform
             __syncthreads();                                 // the previous subgraph's tables are no longer read
             int bl = 11;                                     // >= 64 bits per member, >= 2048 bits
             while ((1 << bl) < 64 * n && bl < bm_log2_cap) ++bl;
             bshift = 32 - bl;
-            for (int i = tid; i < (1 << (bl - 5)); i += kInduceThreads) bm[i] = 0u;
+            for (int i = tid; i < (1 << (bl - 5)); i += kT) bm[i] = 0u;
             const int32_t *nodes = w.nodes + (int64_t)g * ncap;
             const int32_t *rq = w.rowq + (int64_t)g * ncap;
             const int32_t *rb = w.rowbeg + (int64_t)g * ncap;
             const int32_t *rd = w.rowdeg + (int64_t)g * ncap;
             const int32_t *sr = w.srow + (int64_t)g * ncap;
-            for (int i = tid; i < n; i += kInduceThreads) {
+            for (int i = tid; i < n; i += kT) {
                 snodes[i] = (uint32_t)nodes[i];
                 hubslot[i] = 255;
             }
-            for (int i = tid; i < ns; i += kInduceThreads) {
+            for (int i = tid; i < ns; i += kT) {
                 sq[i] = rq[i];
                 srb[i] = rb[i];
                 srd[i] = rd[i];
@@ -823,12 +898,12 @@ __global__ __launch_bounds__(kInduceThreads) GCC_INDUCE_OCC void induce_kernel(
             __syncthreads();
         }
         int my_nnz = 0, nhub_hits = 0;                       // wave-uniform: this wave's hits, and how many of them have a hub as target
-        const int unit_end = min(nunits, (part + 1) * kUnitsPerVwg);
+        const int unit_end = min(nunits, (part + 1) * kUV);
 #pragma unroll 1
-        for (int unit = unit0;; unit += kInduceWaves) {              // wave-uniform; every wave enters once
+        for (int unit = unit0;; unit += kW) {              // wave-uniform; every wave enters once
             if (unit < unit_end) issue(unit);                        // (one call site: the body is large)
             if (g != cur_g) {                                        // block-uniform, first pass only: the first unit's
-                for (int i = tid; i < n; i += kInduceThreads) {      // loads fly while the bitmap is built
+                for (int i = tid; i < n; i += kT) {      // loads fly while the bitmap is built
                     const uint32_t h = umul24(snodes[i], kHashMul) >> bshift;
                     atomicOr(&bm[h >> 5], 1u << (h & 31));
                 }
@@ -928,6 +1003,8 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, PackOuts o
     __shared__ int32_t hl[kMaxHub + 1], hc[kMaxHub + 1];   // hub rows (ascending local ids) and the exclusive prefix of their entry counts
     const int tid = (int)threadIdx.x;
     const int g = (int)blockIdx.x / kPackParts, part = (int)blockIdx.x % kPackParts;
+    const int nunits = units_of(w.sub_quads[g]);
+    constexpr int nparts = kPackParts;
     const int seg = g / B, b = g - seg * B;
     const BatchOutDev o = outs.o[seg];
     const int n = w.sub_n[g];
@@ -955,7 +1032,6 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, PackOuts o
     const long long edge_base = w.ebp[g];
     const long long sbase = w.sbp[g];
     const int ubase = w.ubp[g];
-    const int nunits = units_of(w.sub_quads[g]);
     if (tid == 0 && part == 0) {
         o.node_off[b] = (int32_t)node_base;
         o.edge_off[b] = (int32_t)edge_base;
@@ -976,7 +1052,7 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, PackOuts o
         // leave a VALID structure behind (rows without edges, offsets clamped to the capacity) so that a
         // consumer that has not looked at `status` yet can never index out of bounds
         const long long ecl = edge_base < o.edge_cap ? edge_base : o.edge_cap;
-        for (int i = part * 256 + tid; i < n; i += 256 * kPackParts) {
+        for (int i = part * 256 + tid; i < n; i += 256 * nparts) {
             if (node_base + i < o.node_cap) {
                 o.parent_nid[node_base + i] = nodes[i];
                 o.graph_id[node_base + i] = b;
@@ -986,14 +1062,14 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, PackOuts o
         if (b == B - 1 && tid == 0 && part == 0 && node_base + n <= o.node_cap) o.row_ptr[node_base + n] = (int32_t)ecl;
         return;
     }
-    for (int i = part * 256 + tid; i < n; i += 256 * kPackParts) {
+    for (int i = part * 256 + tid; i < n; i += 256 * nparts) {
         o.parent_nid[node_base + i] = nodes[i];
         o.graph_id[node_base + i] = b;
     }
     if (b == B - 1 && tid == 0 && part == 0) o.row_ptr[node_base + n] = (int32_t)(edge_base + nnz);
 
     // this part's units; hits before them and the row of the last of those hits
-    const int u0 = (int)((long long)nunits * part / kPackParts), u1 = (int)((long long)nunits * (part + 1) / kPackParts);
+    const int u0 = (int)((long long)nunits * part / nparts), u1 = (int)((long long)nunits * (part + 1) / nparts);
     const int32_t *ucnt = w.ucnt + ubase;
     const int32_t *scratch = w.scratch + sbase;
     {
@@ -1054,7 +1130,7 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, PackOuts o
         e_base += chunk_total;
         __syncthreads();
     }
-    if (part == kPackParts - 1) {                      // rows after the last hit have no induced edges
+    if (part == nparts - 1) {                          // rows after the last hit have no induced edges
         const int carry = sh_carry;
         const int scanned = nnz - hc[nh];              // (all scanned hits lie before these rows)
         for (int i = carry + 1 + tid; i < n; i += 256) o.row_ptr[node_base + i] = (int32_t)(edge_base + scanned + hshift(i));
@@ -1079,15 +1155,26 @@ __global__ __launch_bounds__(256) void hub_write_kernel(int32_t B, Work w, PackO
     const int p0 = w.sub_p0[g];                          // locals 1 .. p0 have smaller parent ids than the seed (walk kernel)
     const int words = (n + 31) >> 5;
     const uint32_t *hm = w.hubmark + (int64_t)g * kMaxHub * w.mwords;
-    for (int k = wv; k < nh; k += 4) {                   // (wave-uniform)
-        const int H = w.hubloc[(int64_t)g * kMaxHub + k];
-        const long long base = (long long)o.row_ptr[node_base + H];      // written by the pack
-        const uint32_t *bits = hm + k * w.mwords;
-        const int seed_bit = (int)(bits[0] & 1u);
+    // every load this wave needs, up front: where its hubs' rows start (lanes 0 .. 7) and the first 64 words of their
+    // bitmaps (all there is up to 2048 members) -- one hub after the other was three dependent loads per hub, 24 in a row
+    // for a wave with 8 hubs
+    constexpr int kPerWave = kMaxHub / 4;
+    const int mine = nh > wv ? (nh - wv + 3) >> 2 : 0;   // hubs wv, wv + 4, ...
+    int basel = 0;
+    if (lane < mine) basel = o.row_ptr[node_base + w.hubloc[(int64_t)g * kMaxHub + wv + 4 * lane]];      // (written by the pack)
+    uint32_t first[kPerWave];
+#pragma unroll
+    for (int j = 0; j < kPerWave; ++j) first[j] = (j < mine && lane < words) ? hm[(wv + 4 * j) * w.mwords + lane] : 0u;
+#pragma unroll
+    for (int j = 0; j < kPerWave; ++j) {
+        if (j >= mine) break;                            // (wave-uniform)
+        const long long base = (long long)wave_shfl(basel, j);
+        const uint32_t *bits = hm + (wv + 4 * j) * w.mwords;
+        const int seed_bit = (int)(wave_shfl(first[j], 0) & 1u);
         int before = 0, seed_at = 0;                     // wave-uniform: entries of locals >= 1 in the words done; of locals 1 .. p0
         for (int w0 = 0; w0 < words; w0 += 64) {
             const int wi = w0 + lane;
-            uint32_t v = wi < words ? bits[wi] : 0u;
+            uint32_t v = w0 == 0 ? first[j] : (wi < words ? bits[wi] : 0u);
             if (wi == 0) v &= ~1u;                       // the seed is placed separately
             // bits of this word that belong to locals <= p0
             const int lo_bit = wi * 32;
@@ -1188,6 +1275,7 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     w.sub_ns = (int32_t *)(base + wl.off_ns);
     w.sub_nh = (int32_t *)(base + wl.off_nh);
     w.sub_p0 = (int32_t *)(base + wl.off_p0);
+    w.big = (int32_t *)(base + wl.off_big);
     w.hubloc = (int32_t *)(base + wl.off_hubloc);
     w.hubrb = (int32_t *)(base + wl.off_hubrb);
     w.hubdeg = (int32_t *)(base + wl.off_hubdeg);
@@ -1201,8 +1289,10 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     w.ebp = (int32_t *)(base + wl.off_ebp);
     w.ucnt = (int32_t *)(base + wl.off_ucnt);
     w.wrec = (int32_t *)(base + wl.off_wrec);
+    w.vbpb = (int32_t *)(base + wl.off_vbpb);
     w.scratch = (int32_t *)(base + wl.off_scratch);
     w.ncap = wl.ncap;
+    w.lcap = wl.ncap;
     w.nseg = nseg;
     w.unit_cap = wl.unit_cap;
 
@@ -1212,12 +1302,20 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     while (p2max < g->lmax) p2max <<= 1;
     int bmlog = 11;                                  // Bloom bitmap: 64 bits per member up to 1024 members, 8 KiB at most (LDS per
     while ((1 << bmlog) < 64 * (g->lmax + 1) && bmlog < 16) ++bmlog;   // workgroup decides how many are resident: 82 KiB at lmax 2360 left one per CU)
-    const size_t lds1 = ((size_t)p2max * 4 + 192) * 4;
-    const size_t lds2 = (size_t)wl.ncap * 19 + 8 + ((size_t)1 << (bmlog - 3)) + (size_t)kInduceWaves * (kCandCap * 6 + kUnitQuads * 2) + 16;
+    const int p2small = p2max < 1024 ? p2max : 1024;      // the small walk class: traces up to this many entries
+    const size_t lds1 = ((size_t)p2small * 4 + 192) * 4;   //   trace, degrees, row begins, quads
+    const size_t lds1b = ((size_t)p2max * 2 + 64) * 4;     // the big class: trace, degrees
+    const size_t lds2 = (size_t)wl.ncap * 19 + 8 + ((size_t)1 << (bmlog - 3)) + (size_t)(kInduceBigThreads / 64) * (kCandCap * 6 + kUnitQuads * 2) + 16;
+    // the small induce class: subgraphs of at most kSmallMembers members (a seed with the rw_hops budget: <= rw_hops + 1)
+    const int lcap_small = wl.ncap > kSmallMembers ? kSmallMembers : wl.ncap;
+    int bmlog_s = 11;
+    while ((1 << bmlog_s) < 64 * lcap_small && bmlog_s < bmlog) ++bmlog_s;
+    const size_t lds2s = (size_t)lcap_small * 19 + 8 + ((size_t)1 << (bmlog_s - 3)) + (size_t)(kInduceThreads / 64) * (kCandCap * 6 + kUnitQuads * 2) + 16;
+    w.lcap = lcap_small;
     // rows of at least this degree are not scanned (kMaxHub per subgraph): hub_degree 0 = default, < 0 = scan everything
     const int32_t hub_degree = p->hub_degree == 0 ? kHubDegreeDefault : (p->hub_degree < 0 ? 0x7FFFFFFF : p->hub_degree);
     const int32_t max_hubs = p->max_hubs <= 0 ? kMaxHubsDefault : (p->max_hubs > kMaxHub ? kMaxHub : p->max_hubs);
-    if (lds1 > 160 * 1024 || lds2 > 160 * 1024 - 256) {
+    if (lds1b > 160 * 1024 || lds2 > 160 * 1024 - 256) {
         snprintf(g_err, kErrLen, "gcc_sample_multi: lmax=%d / batch too large for 160 KiB of LDS", g->lmax);
         return -4;
     }
@@ -1231,19 +1329,28 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     prof_mark(p->prof, 0, s);
 #ifndef GCC_AMD_HIPEMU
     // more than 64 KiB of dynamic LDS has to be opted into per kernel
-    if (lds1 > 64 * 1024) (void)hipFuncSetAttribute((const void *)rwr_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    if (lds2 > 64 * 1024) (void)hipFuncSetAttribute((const void *)induce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    if (lds1b > 64 * 1024) (void)hipFuncSetAttribute((const void *)rwr_walk_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1b);
+    if (lds2 > 64 * 1024) (void)hipFuncSetAttribute((const void *)induce_kernel<kInduceBigThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
 #endif
-    hipLaunchKernelGGL(rwr_walk_kernel, dim3(G), dim3(kWalkThreads), lds1, s, g->row_ptr, g->col_idx, g->seed_cdf,
-                       g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, sample_id_stride, B,
-                       p->restart_u32, p->seeds, g->num_shards > 1 ? g->shard_off : nullptr, g->num_shards, hub_degree, max_hubs, w);
+    const int64_t *shards = g->num_shards > 1 ? g->shard_off : nullptr;
+    if (p2max > p2small) (void)hipMemsetAsync(w.big, 0, 4, s);
+    hipLaunchKernelGGL((rwr_walk_kernel<kWalkThreads, false>), dim3(G), dim3(kWalkThreads), lds1, s, g->row_ptr, g->col_idx, g->seed_cdf,
+                       g->ltab, g->num_nodes, g->ltab_len, p2small, p->run_seed, p->first_sample_id, sample_id_stride, B,
+                       p->restart_u32, p->seeds, shards, g->num_shards, hub_degree, max_hubs, w);
+    if (p2max > p2small)                             // seeds with longer traces: 1024 threads each, a resident grid over the list
+        hipLaunchKernelGGL((rwr_walk_kernel<1024, true>), dim3(G < 512 ? G : 512), dim3(1024), lds1b, s, g->row_ptr, g->col_idx, g->seed_cdf,
+                           g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, sample_id_stride, B,
+                           p->restart_u32, p->seeds, shards, g->num_shards, hub_degree, max_hubs, w);
     hipLaunchKernelGGL(prefix_a_kernel, dim3(1), dim3(kPrefixThreads), (size_t)(G + 1) * 4, s, B, w);
-    hipLaunchKernelGGL(records_kernel, dim3((G * kGridMult + 255) / 256), dim3(256), 0, s, B, w);
-    prof_mark(p->prof, 1, s);                        // marks 1 -> 2 bracket induce_kernel alone (bench.py's roofline interval)
-    hipLaunchKernelGGL(induce_kernel, dim3(G * kGridMult), dim3(kInduceThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,
-                       scratch_entries, w, status, g_induce_ticks);
+    hipLaunchKernelGGL(records_kernel, dim3((G * kGridMult + kBigGrid + 255) / 256), dim3(256), 0, s, B, w);
+    prof_mark(p->prof, 1, s);                        // marks 1 -> 2 bracket the induction alone (bench.py's roofline interval)
+    hipLaunchKernelGGL(induce_kernel<kInduceThreads>, dim3(G * kGridMult), dim3(kInduceThreads), lds2s, s, g->col_idx, g->num_edges, bmlog_s, B,
+                       scratch_entries, w, status, g_induce_ticks, 0, lcap_small);
+    if (wl.ncap > lcap_small)                        // subgraphs with more members: tables for the graph's longest trace
+        hipLaunchKernelGGL(induce_kernel<kInduceBigThreads>, dim3(kBigGrid), dim3(kInduceBigThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,
+                           scratch_entries, w, status, g_induce_ticks, 1, wl.ncap);
     prof_mark(p->prof, 2, s);
-    hipLaunchKernelGGL(prefix_b_kernel, dim3(1), dim3(256), 0, s, B, w);
+    hipLaunchKernelGGL(prefix_b_kernel, dim3(1), dim3(kPrefixThreads), (size_t)(G + 1) * 4, s, B, w);
     hipLaunchKernelGGL(pack_kernel, dim3(G * kPackParts), dim3(256), 0, s, B, w, po, scratch_entries, status);
     hipLaunchKernelGGL(hub_write_kernel, dim3(G), dim3(256), 0, s, B, w, po, scratch_entries);
     prof_mark(p->prof, 3, s);

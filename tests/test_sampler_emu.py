@@ -42,6 +42,58 @@ def test_hub_seeds_exceed_rw_hops(coracle):
     _compare(coracle, rp, ci, g, 3, 7, 0, seeds=hubs)
 
 
+def _graph_with_super_hub(n=20000, e=150000, spokes=9000, seed=4):
+    """A power-law graph + one node joined to ``spokes`` others: its trace budget (deg^0.75 * e / (e - 1) / restart) passes
+    1024, the small walk class's capacity, so the subgraphs seeded there go through the big-class launch."""
+    rp, ci = powerlaw_graph(n, e, seed)
+    src = np.repeat(np.arange(len(rp) - 1, dtype=np.int64), np.diff(rp))
+    dst = ci.astype(np.int64)
+    rng = np.random.default_rng(seed)
+    hub = 17
+    others = rng.choice(np.setdiff1d(np.arange(len(rp) - 1), [hub]), spokes, replace=False)
+    src = np.concatenate([src, np.full(spokes, hub), others])
+    dst = np.concatenate([dst, others, np.full(spokes, hub)])
+    key = np.unique(src * (len(rp) - 1) + dst)                      # symmetric, sorted rows, no duplicates
+    src, dst = key // (len(rp) - 1), key % (len(rp) - 1)
+    rp2 = np.zeros(len(rp), np.int32)
+    np.cumsum(np.bincount(src, minlength=len(rp) - 1), out=rp2[1:])
+    return rp2, dst.astype(np.int32), hub
+
+
+@pytest.mark.parametrize("hub_degree", [0, 4, -1])
+def test_long_traces_take_the_big_walk_class(coracle, hub_degree):
+    rp, ci, hub = _graph_with_super_hub()
+    g = EmuGraph(rp, ci, rw_hops=64)
+    deg = np.diff(rp)
+    assert g.ltab[deg[hub]] > 1024 and g.lmax > 1024
+    nb = ci[rp[hub]:rp[hub] + 2]
+    # the hub itself (big class), two of its neighbours and drawn seeds (small class) in ONE launch; both orders
+    _compare(coracle, rp, ci, g, 3, 5, 0, seeds=np.array([hub, nb[0], nb[1]], np.int32), hub_degree=hub_degree)
+    _compare(coracle, rp, ci, g, 3, 5, 0, seeds=np.array([nb[0], hub, hub], np.int32), hub_degree=hub_degree)
+    _compare(coracle, rp, ci, g, 6, 9, 40, hub_degree=hub_degree)
+
+
+def test_long_traces_in_multi_step_launches(coracle):
+    from tests.hipemu.emu_driver import emu_sample_multi
+
+    rp, ci, hub = _graph_with_super_hub()
+    g = EmuGraph(rp, ci, rw_hops=64)
+    B, S = 3, 3
+    cdf = O.seed_cdf(rp)
+    first = next(f for f in range(0, 100000, B * S) if hub in coracle.draw_seeds(cdf, 13, f, B * S).tolist())
+    pairs, status, seeds = emu_sample_multi(g, B, 13, first, S, B)
+    assert status == 0
+    big = 0
+    for t, (q, k) in enumerate(pairs):
+        single, st, used = emu_sample_batch(g, B, 13, first + t * B)
+        assert st == 0
+        big += int((g.ltab[np.minimum(np.diff(rp)[used], len(g.ltab) - 1)] > 1024).sum())
+        for got, ref in ((q, single[0]), (k, single[1])):
+            for key in KEYS + ("edge_off", "graph_id"):
+                assert np.array_equal(got[key], ref[key]), (t, key)
+    assert big >= 1, "pick a first id whose draws include the super hub"      # (seeds ~ deg^0.75: the hub is drawn often)
+
+
 @pytest.mark.parametrize("name", ["path5", "star6", "tri_tail", "k4"])
 def test_tiny_graphs(coracle, name):
     rp, ci = tiny_graphs()[name]
