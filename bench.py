@@ -695,9 +695,15 @@ def main():
             "kernel_ms_isolated": kern_iso, "kernel_ms_isolated_steps_per_launch": spc,
             "roofline": {"bound": "hbm", "kernel": dom,
                          "measured": "isolated probe loop after the timed region: HIP events (gcc_prof marks on the launch stream) right "
-                                     "before and after induce_kernel inside gcc_sample_multi (one launch covers steps_per_launch "
-                                     "consecutive batches, as the producer lanes issue it); rocprofv3 --kernel-trace --stats of the "
-                                     "same launches alone: profiles/r3_kernel_stats_sampler_alone*.csv",
+                                     "before and after the induction inside gcc_sample_multi (one call covers steps_per_launch "
+                                     "consecutive batches, as the producer lanes issue it; two launches of induce_kernel: the small "
+                                     "and the big size class, the sum is what is timed); rocprofv3 --kernel-trace --stats of the "
+                                     "same launches alone: profiles/r4_kernel_stats_sampler_alone*.csv",
+                         "note": "algorithmic bytes = SURVEY 8(d): every member's parent row read once + the output.  Since round 4 "
+                                 "the rows of the (at most 32) highest-degree members of a subgraph are NOT read -- their induced rows "
+                                 "are the mirror images of the other rows' hits (symmetric graph) -- so `achieved` is the rate "
+                                 "of the reference algorithm's bytes, not of bytes moved; `traffic` is what the kernels move"
+                                 + ("" if args.hub_degree >= 0 else " (this run: --hub-degree -1, every row is read)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": acc_call["induce"], "steps_per_launch": spc,
                          "traffic": traffic, "traffic_source": traffic_src,

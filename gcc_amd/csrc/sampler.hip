@@ -93,10 +93,13 @@ constexpr int kPackParts = GCC_PACK_PARTS;      // pack workgroups per subgraph.
 // between two hubs are found by one binary search per pair (tail of the walk kernel).  hub_write_kernel turns the bitmaps
 // into rows after the pack.  The result is bit for bit the scanned one (same tests, same oracle); which rows are hubs
 // only changes the cost.  On the bench graphs the rows of degree >= 1024 (G1: 10 per ego-net) / >= 4096 (G2: 14) hold
-// 72 % of the entries a full scan reads.  Measured (profiles/r4_hub_rows.md): induction 437 -> 232 us (G1) and 1826 ->
-// 1105 us (G2) per 16-step launch, the pair searches and the row writer give 100 / 280 us back; the optimum over
-// (threshold, slots) is flat around 512 .. 1024 x 32.
-constexpr int kMaxHub = 32;        // most hub rows per subgraph (the workspace is laid out for this many)
+// 72 % of the entries a full scan reads.  Measured (profiles/r4_hub_rows.md, r4_sampler_classes.md): induction 437 ->
+// 232 us (G1) and 1826 -> 1105 us (G2) per 16-step launch before the size classes, the pair searches and the row writer
+// give 90 / 170 us back; the optimum over (threshold, slots) is flat around 512 .. 1024 x 32 (64 slots: no gain).
+#ifndef GCC_MAX_HUB
+#define GCC_MAX_HUB 32
+#endif
+constexpr int kMaxHub = GCC_MAX_HUB;   // (<= 64) most hub rows per subgraph (the workspace is laid out for this many)
 constexpr int kHubDegreeDefault = 512;
 constexpr int kMaxHubsDefault = 32; // with more rows over the threshold, the threshold of THAT subgraph rises to the power of two that
                                    // leaves at most this many: the pair searches grow with the square of the count, the bytes saved come
@@ -1014,11 +1017,12 @@ __global__ __launch_bounds__(256) void pack_kernel(int32_t B, Work w, PackOuts o
         const int cnt = tid < nh ? w.hubcnt[(int64_t)g * kMaxHub + tid] : 0;
         const int incl = wave_scan_incl(cnt);
         if (tid <= kMaxHub) hl[tid] = tid < nh ? w.hubloc[(int64_t)g * kMaxHub + tid] : 0x7FFFFFFF;
+        if (kMaxHub == 64 && tid == 0) hl[64] = 0x7FFFFFFF;
         if (tid < nh) hc[tid] = incl - cnt;
         if (tid == 63) hc[nh] = incl;
     }
     __syncthreads();
-    const int hs0 = nh > 16 ? 16 : (nh > 8 ? 8 : (nh > 4 ? 4 : (nh > 2 ? 2 : 1)));   // (2 * hs0 >= nh)
+    const int hs0 = nh > 32 ? 32 : (nh > 16 ? 16 : (nh > 8 ? 8 : (nh > 4 ? 4 : (nh > 2 ? 2 : 1))));   // (2 * hs0 >= nh)
     // Hub rows are not in the flat sequence of scanned hits: everything at or after row i sits hshift(i) entries further on
     // (the entries of the hub rows before row i), and a hub row H itself starts at (scanned hits of rows < H) + hshift(H)
     auto hshift = [&](int i) -> int {

@@ -264,7 +264,7 @@ def test_multi_step_call_equals_the_single_step_calls(coracle):
 
 
 # ---- hub rows are not scanned (sampler.hip: walk kernel tail / hub_write_kernel): same result, bit for bit
-@pytest.mark.parametrize("max_hubs", [0, 1, 3, 32])
+@pytest.mark.parametrize("max_hubs", [0, 1, 3, 32, 64])
 @pytest.mark.parametrize("hub_degree", [1, 2, 3, 8, 40, -1])
 def test_unscanned_hub_rows_give_the_same_subgraphs(coracle, hub_degree, max_hubs):
     """Rows of at least ``hub_degree`` are skipped by the induction; their induced rows are the mirror images of the other
