@@ -341,6 +341,8 @@ def committed_pmc_traffic(args, v, e, steps_per_call=1):
     on; a file from another build or workload is refused (traffic = null) instead of quoted."""
     if args.pmc_traffic is not None:
         return args.pmc_traffic, "--pmc-traffic"
+    if getattr(args, "hub_degree", 0) != 0:
+        return None, "profiles/pmc_sampler.json was collected with the default hub-row settings, this run uses --hub-degree %d: refused" % args.hub_degree
     if not os.path.exists(PMC_FILE):
         return None, "no profiles/pmc_sampler.json"
     rec = json.load(open(PMC_FILE))
