@@ -133,6 +133,7 @@ struct Work {
     int32_t *wrec;        // [G * kGridMult + kBigGrid][kRecInts] where each induce workgroup starts (prefix step A); the big class's after the small one's
     int32_t *vbpb;        // [G + 1]     the same prefix for the big class (subgraphs with more than lcap members; vbp counts the others)
     int32_t lcap;         // members a small-class induce workgroup has LDS tables for (>= ncap: one class)
+    int32_t nsmall, nbig; // induce workgroups of the small / the big class (G * kGridMult, kBigGrid; fewer under gcc_sampler_debug_grids)
     int32_t *scratch;     // [scratch_entries] hits: (row << 16) | local column, one slot of 1024 per unit
     int32_t *srow;        // [G][ncap]   local id of the s-th SCANNED row (rowbeg / rowdeg / rowq are indexed by s, not by local id)
     int32_t *sub_ns;      // [G]         scanned rows
@@ -699,11 +700,11 @@ __global__ __launch_bounds__(kPrefixThreads) void prefix_a_kernel(int32_t B, Wor
 __global__ __launch_bounds__(256) void records_kernel(int32_t B, Work w)
 {
     const int G = w.nseg * B;
-    const int nsmall = G * kGridMult;
+    const int nsmall = w.nsmall;
     const int bb = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (bb >= nsmall + kBigGrid) return;
+    if (bb >= nsmall + w.nbig) return;
     const bool big = bb >= nsmall;                    // the big class's records follow the small one's
-    const int b = big ? bb - nsmall : bb, nwg = big ? kBigGrid : nsmall;
+    const int b = big ? bb - nsmall : bb, nwg = big ? w.nbig : nsmall;
     const int32_t *vbp = big ? w.vbpb : w.vbp;
     const int cv = vbp[G];
     const int chunk = (cv + nwg - 1) / nwg;
@@ -742,6 +743,7 @@ __device__ __forceinline__ bool scratch_overflows(const Work &w, int g, int64_t 
 }
 
 // ------------------------------------------------------------------ K2 ----
+static int g_dbg_grids[3] = {0, 0, 0};           // diagnostics (gcc_sampler_debug_grids): small / big induce grid, big walk grid
 static long long *g_induce_ticks = nullptr;      // diagnostics (gcc_sampler_debug_ticks): [0..2] phase ticks, [15] workgroups
 #define IND_TICK(ph) do { if (ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&ticks[ph], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 template <int kT>
@@ -770,7 +772,7 @@ __global__ __launch_bounds__(kT) GCC_INDUCE_OCC void induce_kernel(
     uint16_t *rowl = candr_all + kW * kCandCap + wave * kUnitQuads;   // [waves][256] row of every quad of a unit
     long long tick_ = ticks ? device_ticks() : 0;
     if (ticks && tid == 0) atomicAdd((unsigned long long *)&ticks[15], 1ull);
-    const int32_t *myrec = w.wrec + ((int64_t)blockIdx.x + (big ? (int64_t)G * kGridMult : 0)) * kRecInts;   // (prefix step A)
+    const int32_t *myrec = w.wrec + ((int64_t)blockIdx.x + (big ? (int64_t)w.nsmall : 0)) * kRecInts;   // (prefix step A)
     const uint4 *recp = (const uint4 *)myrec;
     const uint4 ra = recp[0], rb4 = recp[1];
     const uint2 rc2 = *(const uint2 *)(myrec + 8);
@@ -1206,6 +1208,10 @@ __global__ __launch_bounds__(256) void hub_write_kernel(int32_t B, Work w, PackO
 extern "C" {
 
 void gcc_sampler_debug_ticks(long long *device_ticks64) { g_induce_ticks = device_ticks64; }   /* diagnostics only */
+void gcc_sampler_debug_grids(int32_t small_grid, int32_t big_grid, int32_t walk_big_grid)          /* tests only */
+{
+    g_dbg_grids[0] = small_grid; g_dbg_grids[1] = big_grid; g_dbg_grids[2] = walk_big_grid;
+}
 
 
 static int32_t check_steps(const char *who, int32_t batch_size, int32_t num_steps)
@@ -1316,6 +1322,12 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     while ((1 << bmlog_s) < 64 * lcap_small && bmlog_s < bmlog) ++bmlog_s;
     const size_t lds2s = (size_t)lcap_small * 19 + 8 + ((size_t)1 << (bmlog_s - 3)) + (size_t)(kInduceThreads / 64) * (kCandCap * 6 + kUnitQuads * 2) + 16;
     w.lcap = lcap_small;
+    w.nsmall = G * kGridMult;
+    w.nbig = kBigGrid;
+    int walk_big_grid = G < 512 ? G : 512;
+    if (g_dbg_grids[0] > 0 && g_dbg_grids[0] < w.nsmall) w.nsmall = g_dbg_grids[0];     // (tests: tiny grids make every workgroup walk
+    if (g_dbg_grids[1] > 0 && g_dbg_grids[1] < w.nbig) w.nbig = g_dbg_grids[1];          //  through several virtual workgroups / subgraphs /
+    if (g_dbg_grids[2] > 0 && g_dbg_grids[2] < walk_big_grid) walk_big_grid = g_dbg_grids[2];   //  list entries)
     // rows of at least this degree are not scanned (kMaxHub per subgraph): hub_degree 0 = default, < 0 = scan everything
     const int32_t hub_degree = p->hub_degree == 0 ? kHubDegreeDefault : (p->hub_degree < 0 ? 0x7FFFFFFF : p->hub_degree);
     const int32_t max_hubs = p->max_hubs <= 0 ? kMaxHubsDefault : (p->max_hubs > kMaxHub ? kMaxHub : p->max_hubs);
@@ -1342,16 +1354,16 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
                        g->ltab, g->num_nodes, g->ltab_len, p2small, p->run_seed, p->first_sample_id, sample_id_stride, B,
                        p->restart_u32, p->seeds, shards, g->num_shards, hub_degree, max_hubs, w);
     if (p2max > p2small)                             // seeds with longer traces: 1024 threads each, a resident grid over the list
-        hipLaunchKernelGGL((rwr_walk_kernel<1024, true>), dim3(G < 512 ? G : 512), dim3(1024), lds1b, s, g->row_ptr, g->col_idx, g->seed_cdf,
+        hipLaunchKernelGGL((rwr_walk_kernel<1024, true>), dim3(walk_big_grid), dim3(1024), lds1b, s, g->row_ptr, g->col_idx, g->seed_cdf,
                            g->ltab, g->num_nodes, g->ltab_len, p2max, p->run_seed, p->first_sample_id, sample_id_stride, B,
                            p->restart_u32, p->seeds, shards, g->num_shards, hub_degree, max_hubs, w);
     hipLaunchKernelGGL(prefix_a_kernel, dim3(1), dim3(kPrefixThreads), (size_t)(G + 1) * 4, s, B, w);
-    hipLaunchKernelGGL(records_kernel, dim3((G * kGridMult + kBigGrid + 255) / 256), dim3(256), 0, s, B, w);
+    hipLaunchKernelGGL(records_kernel, dim3((w.nsmall + w.nbig + 255) / 256), dim3(256), 0, s, B, w);
     prof_mark(p->prof, 1, s);                        // marks 1 -> 2 bracket the induction alone (bench.py's roofline interval)
-    hipLaunchKernelGGL(induce_kernel<kInduceThreads>, dim3(G * kGridMult), dim3(kInduceThreads), lds2s, s, g->col_idx, g->num_edges, bmlog_s, B,
+    hipLaunchKernelGGL(induce_kernel<kInduceThreads>, dim3(w.nsmall), dim3(kInduceThreads), lds2s, s, g->col_idx, g->num_edges, bmlog_s, B,
                        scratch_entries, w, status, g_induce_ticks, 0, lcap_small);
     if (wl.ncap > lcap_small)                        // subgraphs with more members: tables for the graph's longest trace
-        hipLaunchKernelGGL(induce_kernel<kInduceBigThreads>, dim3(kBigGrid), dim3(kInduceBigThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,
+        hipLaunchKernelGGL(induce_kernel<kInduceBigThreads>, dim3(w.nbig), dim3(kInduceBigThreads), lds2, s, g->col_idx, g->num_edges, bmlog, B,
                            scratch_entries, w, status, g_induce_ticks, 1, wl.ncap);
     prof_mark(p->prof, 2, s);
     hipLaunchKernelGGL(prefix_b_kernel, dim3(1), dim3(kPrefixThreads), (size_t)(G + 1) * 4, s, B, w);

@@ -131,6 +131,9 @@ int64_t gcc_sampler_workspace_bytes_multi(const gcc_graph *g, int32_t batch_size
 /* diagnostics: subsequent gcc_sample_batch calls add wall-clock ticks (100 MHz) of induce_kernel's phases into device
  * int64[16] ([0] prefix sums over the subgraphs, [1] hash map + row prefix sums, [2] segment scans, [15] workgroups). */
 void gcc_sampler_debug_ticks(long long *device_ticks64);
+/* tests only: cap the static grids of the two induce classes and of the big walk class (0 = the defaults), so that small
+ * test batches exercise workgroups that walk through several virtual workgroups, subgraphs and list entries */
+void gcc_sampler_debug_grids(int32_t small_grid, int32_t big_grid, int32_t walk_big_grid);
 
 /* status: device int32[1], OR-ed with GCC_STATUS_* bits (caller zeroes it). */
 int32_t gcc_sample_batch(const gcc_graph *g, const gcc_sample_params *p,

@@ -73,6 +73,37 @@ def test_long_traces_take_the_big_walk_class(coracle, hub_degree):
     _compare(coracle, rp, ci, g, 6, 9, 40, hub_degree=hub_degree)
 
 
+@pytest.fixture
+def tiny_grids():
+    """Static grids of a few workgroups (gcc_sampler_debug_grids): every induce workgroup walks through several virtual
+    workgroups and subgraphs -- skipping those of the other size class --, every big-walk workgroup through several list
+    entries.  The bench graphs only reach that regime on the 10M / 200M graph."""
+    from tests.hipemu.emu_driver import emu_lib
+
+    lib = emu_lib()
+
+    def set_grids(small, big, walk_big):
+        lib.gcc_sampler_debug_grids(small, big, walk_big)
+
+    yield set_grids
+    lib.gcc_sampler_debug_grids(0, 0, 0)
+
+
+@pytest.mark.parametrize("grids", [(1, 1, 1), (3, 2, 2), (5, 1, 3)])
+@pytest.mark.parametrize("hub_degree", [0, 4, -1])
+def test_workgroups_walk_through_both_size_classes(coracle, tiny_grids, grids, hub_degree):
+    rp, ci, hub = _graph_with_super_hub()
+    g = EmuGraph(rp, ci, rw_hops=64)
+    nb = ci[rp[hub]:rp[hub] + 3]
+    big_deg = np.argsort(np.diff(rp))[-4:-1].astype(np.int32)             # the next largest rows: big induce class, small walk class
+    seeds = np.array([nb[0], hub, big_deg[0], nb[1], hub, big_deg[1], nb[2], big_deg[2], hub], np.int32)
+    tiny_grids(*grids)
+    res = _compare(coracle, rp, ci, g, len(seeds), 5, 0, seeds=seeds, hub_degree=hub_degree)
+    sizes = np.diff(res[0]["node_off"])
+    assert (sizes > 320).sum() >= 3 and (sizes <= 320).sum() >= 3           # both induce classes are populated
+    _compare(coracle, rp, ci, g, 7, 9, 40, hub_degree=hub_degree)            # drawn seeds
+
+
 def test_long_traces_in_multi_step_launches(coracle):
     from tests.hipemu.emu_driver import emu_sample_multi
 

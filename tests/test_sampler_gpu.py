@@ -111,6 +111,31 @@ def test_hub_seeds_large_L(coracle, torch_cuda):
     _check(coracle, torch_cuda, rp, ci, 8, 256, 7, 0, seeds=hubs.tolist())
 
 
+@pytest.mark.parametrize("grids", [(2, 1, 1), (64, 8, 3)])
+def test_size_classes_with_tiny_grids(coracle, torch_cuda, grids):
+    """Both size classes of the walk and of the induction in one launch (hub seeds: long traces, hundreds of members; their
+    neighbours: the rw_hops budget), with the static grids capped (gcc_sampler_debug_grids) so that every workgroup walks
+    through several virtual workgroups / subgraphs / list entries -- the regime the 10M / 200M graph runs in."""
+    from gcc_amd import _cabi
+    from tests.test_sampler_emu import _graph_with_super_hub
+
+    rp, ci, top = _graph_with_super_hub(200000, 4000000, 30000, 1)        # its trace budget is ~4500 entries: the big walk class
+    order = np.argsort(np.diff(rp))
+    assert order[-1] == top
+    hubs = order[-12:].astype(np.int32)
+    small = np.array([ci[rp[h]] for h in hubs], np.int32)                # a neighbour of every hub
+    seeds = np.stack([hubs, small], 1).reshape(-1)
+    lib = _cabi.load()
+    lib.gcc_sampler_debug_grids(*grids)
+    try:
+        for hd in (0, -1):
+            _check(coracle, torch_cuda, rp, ci, len(seeds), 256, 7, 0, seeds=seeds.tolist(), hub_degree=hd,
+                   scratch_entries=1 << 26, edge_cap=1 << 24)           # (a hub-only batch: beyond the sizing heuristics)
+        _check(coracle, torch_cuda, rp, ci, 64, 256, 3, 640)
+    finally:
+        lib.gcc_sampler_debug_grids(0, 0, 0)
+
+
 def test_full_size_g1_bit_exact_and_properties(coracle, torch_cuda):
     """BASELINE config 2's graph (1M nodes / 10M edges), bsz 256, rw_hops 256."""
     import scipy.sparse as sp
