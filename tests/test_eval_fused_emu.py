@@ -13,6 +13,7 @@ from tests.hipemu.emu_encoder import CpuBatch, emu_engine, reference_encoder
 
 def _random_subgraph(rng, n, extra):
     pairs = {(i, i + 1) for i in range(n - 1)}
+    extra = min(extra, n * (n - 1) // 2 - (n - 1))
     while len(pairs) < n - 1 + extra:
         a, b = sorted(rng.randint(0, n, 2))
         if a != b:
@@ -29,7 +30,7 @@ def _batch(sizes, seed, hub=False):
     node_off, row_ptr, col = [0], [0], []
     for n in sizes:
         if n > 0:
-            rows = _random_subgraph(rng, n, 2 * n) if n > 2 else [[1], [0]]
+            rows = _random_subgraph(rng, n, 2 * n) if n > 2 else ([[1], [0]] if n == 2 else [[]])
             if hub and n > 40:                         # a hub row (long rows cross lane-group chunks of the gather)
                 for u in range(2, n, 2):
                     if u not in rows[0]:
@@ -89,6 +90,43 @@ def test_fused_eval_equals_the_chain_and_the_oracle(mult):
     torch.testing.assert_close(f_fused, ref, rtol=1e-4, atol=2e-5)        # (graph 3 is empty: score = the prediction biases)
     for a, b in zip(p_fused, p_ref):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("case", ["mixed", "tiny", "dense"])
+def test_packed_small_subgraphs(case):
+    """The packed kernel for subgraphs of 1 .. 64 nodes (a workgroup takes all of them whose last node lies in one window of
+    64 node ids): windows with one subgraph and with dozens (more than one pooling round of 32: runs of 1- and 2-node graphs),
+    a big subgraph or empty padding graphs in between, the first subgraph of a pack starting before its window, complete
+    64-node graphs (the most CSR entries a pack can hold), more windows than one pass of the grid is not needed here."""
+    rng = np.random.RandomState(7)
+    if case == "mixed":
+        sizes = [int(x) for x in rng.randint(2, 65, 40)] + [0, 0, 200, 3, 64, 64, 1, 0, 70, 5] + [int(x) for x in rng.randint(2, 30, 30)]
+    elif case == "tiny":
+        sizes = [1] * 70 + [2] * 50 + [0] * 5 + [1, 2, 3] * 20 + [64, 1, 1, 63, 2]
+    else:
+        sizes = [64, 63, 64, 2, 64, 61]
+    model, oracle = _models(11)
+    g = _batch(sizes, seed=5)
+    if case == "dense":                                          # complete graphs: n (n - 1) CSR entries each
+        node_off, row_ptr, col = [0], [0], []
+        for n in sizes:
+            for i in range(n):
+                col += [node_off[-1] + u for u in range(n) if u != i]
+                row_ptr.append(len(col))
+            node_off.append(node_off[-1] + n)
+        g = CpuBatch(dict(node_off=torch.tensor(node_off), row_ptr=torch.tensor(row_ptr), col_idx=torch.tensor(col),
+                          pos_undirected=g.pos_undirected[: node_off[-1]]))
+    g.seed_local = torch.tensor([int(rng.randint(0, max(n, 1))) for n in sizes], dtype=torch.int32)
+    with torch.no_grad():
+        model.fused_eval = True
+        f_fused, p_fused = model(g, return_all_outputs=True)
+        model.fused_eval = False
+        f_chain, p_chain = model(g, return_all_outputs=True)
+        ref = oracle(*_oracle_args(g), seed_local=g.seed_local.long())
+    torch.testing.assert_close(f_fused, f_chain, rtol=1e-5, atol=2e-6)
+    for a, b in zip(p_fused, p_chain):                           # (the neighbour sums run in another order: absolute to the tensor's scale)
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=max(1e-4, 2e-6 * float(b.abs().max())))
+    torch.testing.assert_close(f_fused, ref, rtol=1e-4, atol=2e-5)
 
 
 def test_seed_position_and_view_mean():
