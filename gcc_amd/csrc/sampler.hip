@@ -9,20 +9,22 @@
 // bit-exact against that oracle.
 //
 // Kernels (G = 2 B S subgraphs of S consecutive steps, g = segment * B + b, segment = 2 * step + view):
-//   rwr_walk_kernel   1 workgroup of 4 waves per subgraph.  Walk lengths depend on
+//   rwr_walk_kernel   1 workgroup of 4 waves per subgraph (seeds whose trace budget exceeds
+//                     1024 entries: 16 waves, a second launch).  Walk lengths depend on
 //                     the RNG only (no dead ends by contract), so 256 threads run
 //                     256 walks at a time and a block prefix sum over the lengths
 //                     reproduces the sequential "stop after exactly L visited
 //                     nodes" rule exactly.  Trace in LDS -> bitonic sort -> unique
 //                     -> seed first; row extents of every member and the prefix of
 //                     the rows' 16-byte QUADS of col_idx are written here.
-//   induce_kernel     DGL VertexSubgraph = scan every member's parent row for
-//                     members (a sub-scan by binary search would touch the same
+//   induce_kernel     DGL VertexSubgraph = scan the members' parent rows for members
+//                     (all but the subgraph's <= 32 longest: "Hub rows" below; one
+//                     launch per size class; a sub-scan by binary search would touch the same
 //                     cache lines: a subgraph has more members than a hub row has
 //                     128-byte lines).  The rows of a subgraph form one flat space
 //                     of aligned quads; a UNIT = 256 consecutive quads (1024 edges)
 //                     = one wave x 4 coalesced dwordx4 loads per lane; a virtual
-//                     workgroup = 16 units (8 waves x 2).  The row of every quad of
+//                     workgroup = 2 units per wave (small class: 4 waves, big: 8).  The row of every quad of
 //                     a unit comes from a 256-entry LDS strip (rows mark their first
 //                     quad, a prefix maximum spreads the marks), not from a search
 //                     per quad.  Members sit in an LDS Bloom bitmap (>= 64 bits per
@@ -33,8 +35,8 @@
 //                     No atomics on shared counters inside the scan.  The kernel is
 //                     VALU-bound: everything wave-uniform is
 //                     kept in scalar registers on purpose.
-//   prefix_a_kernel   one workgroup between the two: prefixes over the subgraphs
-//                     and the start record of every induce workgroup.
+//   prefix_a_kernel   one workgroup between the two: prefixes over the subgraphs;
+//   records_kernel    the start record of every induce workgroup.
 //   pack_kernel       prefix sums over subgraphs and units (dgl.batch offsets),
 //                     row_ptr/col_idx with batched ids, parent_nid, graph_id.
 //   hub_write_kernel  the rows of the members the induction did not scan (below).
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(kT) void rwr_walk_kernel(
         n += kept;
     }
     __syncthreads();
-    // induction work.  Rows of degree >= hub_degree (the first kMaxHub of them in local order) are hubs: not scanned, their
+    // induction work.  Rows of degree >= the subgraph's threshold (below: at most max_hubs of them) are hubs: not scanned, their
     // induced rows come from the mirror images of the other rows' hits (hub_write_kernel).  The scanned rows
     // are compacted: scanned row s has local id srow[s], covers row_quads() aligned quads of col_idx, rowq = their
     // exclusive prefix.
