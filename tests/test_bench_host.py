@@ -54,3 +54,15 @@ def test_stale_pmc_file_is_refused(tmp_path, monkeypatch):
     f.write_text(json.dumps(dict(source_sha256=bench.sampler_source_hash(), workloads={key: dict(induce_kernel_hbm_bytes_per_launch=5.0)})))
     assert bench.committed_pmc_traffic(a, 1, 2)[0] == 5.0
     assert bench.committed_pmc_traffic(a, 3, 4)[0] is None          # another graph: no entry
+    # counters collected with the default hub-row settings say nothing about a run that scans every row
+    b = bench.parse_args(["--hub-degree", "-1"])
+    val, why = bench.committed_pmc_traffic(b, 1, 2)
+    assert val is None and "hub" in why
+
+
+def test_committed_pmc_file_matches_this_build():
+    """profiles/pmc_sampler.json is keyed by the hash of the sampler sources: a commit that touches them without re-collecting
+    the counters makes bench.py report ``traffic: null`` (by design) -- this test says so before the GPU box does."""
+    rec = json.load(open(bench.PMC_FILE))
+    assert rec["source_sha256"] == bench.sampler_source_hash(), "re-collect profiles/pmc_sampler.json (scripts/gpu/r4_call27.sh)"
+    assert any(k.endswith("/steps10") for k in rec["workloads"]) and any(k.endswith("/steps16") for k in rec["workloads"])

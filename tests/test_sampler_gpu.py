@@ -60,6 +60,16 @@ def test_small_powerlaw_bit_exact(coracle, torch_cuda, B, rw_hops, run_seed, fir
     _check(coracle, torch_cuda, rp, ci, B, rw_hops, run_seed, first)
 
 
+@pytest.mark.parametrize("hub_degree,max_hubs", [(8, 1), (8, 3), (40, 32), (2, 32), (-1, 0)])
+def test_unscanned_hub_rows_bit_exact(coracle, torch_cuda, hub_degree, max_hubs):
+    """Thresholds far below the default make most rows of these small ego-nets hubs (mirror images + pair searches only); few
+    slots raise the per-subgraph threshold; -1 scans everything.  Always the C oracle's batches."""
+    from gcc_amd.graphgen import powerlaw_graph
+
+    rp, ci = powerlaw_graph(3000, 30000, 3)
+    _check(coracle, torch_cuda, rp, ci, 32, 64, 21, 500, hub_degree=hub_degree, max_hubs=max_hubs)
+
+
 @pytest.mark.parametrize("name", ["path5", "star6", "tri_tail", "k4"])
 def test_tiny_graphs(coracle, torch_cuda, name):
     from gcc_amd.graphgen import tiny_graphs
