@@ -3,7 +3,7 @@
 # correctness of launcher / collectives / status agreement only, NOT a scaling number), and bench.py --gpus 1 under the
 # launcher against the plain run.
 set -u
-O=gpurun_out/r4c13
+O=gpurun_out/${R4_OUT:-r4c13}
 mkdir -p $O
 export TMPDIR=/tmp GCC_AMD_GRAPH_CACHE=/tmp/graphs
 (timeout 600 python bench.py --gpus 2 --steps 8 --warmup 2 --no-cpu-baseline --batch-size 64 --nce-k 1024 2>$O/g2.err | tail -1) > $O/bench_gpus2.json
