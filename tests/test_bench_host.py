@@ -66,3 +66,33 @@ def test_committed_pmc_file_matches_this_build():
     rec = json.load(open(bench.PMC_FILE))
     assert rec["source_sha256"] == bench.sampler_source_hash(), "re-collect profiles/pmc_sampler.json (scripts/gpu/r4_call27.sh)"
     assert any(k.endswith("/steps10") for k in rec["workloads"]) and any(k.endswith("/steps16") for k in rec["workloads"])
+
+
+def test_pmc_summary_adds_the_size_classes_up(tmp_path, monkeypatch):
+    """tools/pmc_sampler.py: a call of gcc_sample_multi launches the walk and the induction once per size class (different
+    template instances); bytes per call = the sum of the instances' per-dispatch averages, FETCH_SIZE x 2 for the induction."""
+    import csv
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("pmc_sampler", os.path.join(os.path.dirname(bench.__file__), "tools", "pmc_sampler.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows = [("void (anonymous namespace)::induce_kernel<256>(int const*)", 100.0), ("void (anonymous namespace)::induce_kernel<256>(int const*)", 300.0),
+            ("void (anonymous namespace)::induce_kernel<512>(int const*)", 1000.0), ("void (anonymous namespace)::induce_kernel<512>(int const*)", 3000.0),
+            ("(anonymous namespace)::pack_kernel(int)", 50.0), ("at::native::something", 999.0)]
+    for d, counter, scale in (("f", "FETCH_SIZE", 1.0), ("w", "WRITE_SIZE", 0.5)):
+        os.makedirs(tmp_path / d / "x")
+        with open(tmp_path / d / "x" / "p_counter_collection.csv", "w", newline="") as f:
+            wr = csv.writer(f)
+            wr.writerow(["Kernel_Name", "Counter_Name", "Counter_Value"])
+            for name, v in rows:
+                wr.writerow([name, counter, v * scale])
+    fetch = mod.per_kernel(str(tmp_path / "f"), "FETCH_SIZE")
+    assert fetch["induce_kernel"][0] == 200.0 + 2000.0 and fetch["pack_kernel"][0] == 50.0 and "something" not in str(fetch.keys())
+    out = tmp_path / "pmc.json"
+    monkeypatch.setattr(sys, "argv", ["pmc_sampler.py", str(tmp_path / "f"), str(tmp_path / "w"), "1/2/bsz256/hops256/steps16", str(out)])
+    mod.main()
+    rec = json.load(open(out))
+    ent = rec["workloads"]["1/2/bsz256/hops256/steps16"]
+    assert rec["source_sha256"] == bench.sampler_source_hash()
+    assert ent["induce_kernel_hbm_bytes_per_launch"] == (2200.0 * 2.0 + 1100.0) * 1024.0
