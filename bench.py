@@ -68,6 +68,9 @@ def parse_args(argv=None):
                                                           "the largest divisor of --steps not above it is used, so that the timed region "
                                                           "launches exactly the chunks it consumes")
     ap.add_argument("--depth", type=int, default=2, help="chunks in flight per producer lane")
+    ap.add_argument("--steady-steps", type=int, default=128, help="least number of untimed steps before the clock (training modes): the "
+                                                                  "pipeline fill and the first ~100 steps of a process are not the steady state; "
+                                                                  "0 = the requested warm-up / the pipeline fill only")
     ap.add_argument("--sampler-steps", type=int, default=16,
                     help="--mode sampler: steps (DataLoader batches) per sampler call (gcc_sample_multi); the training modes "
                          "sample a producer chunk per call")
@@ -605,8 +608,12 @@ def main():
         # untimed steps: the requested warm-up, extended to a whole number of producer rounds so that the look-ahead
         # pipeline (lanes x depth chunks) is in steady state when the clock starts; `steps` is a multiple of `chunk`, so the
         # timed region launches exactly as many chunks as it consumes (checked below: produced_steps == consumed_steps)
+        # ... and to --steady-steps (128): the first ~100 steps of a process run 2-3 % slower than the rest (measured,
+        # profiles/r4_bench_window_warmup.txt: a 20-step window reads 0.973-0.982 ms after 40 untimed steps, 0.951-0.955 after
+        # 200 / 400, and the second half of a 40-step window is already faster than the first); a pre-training run is hours
+        # long, so the steady state is the figure that describes it.  `untimed_steps` in the line says what was run.
         fill = args.lanes * args.depth * chunk
-        warm = ((max(args.warmup, fill) + chunk - 1) // chunk) * chunk
+        warm = ((max(args.warmup, fill, args.steady_steps) + chunk - 1) // chunk) * chunk
         for i in range(warm):
             trainer.step(i, lr_at(i))
         first_timed = warm
@@ -683,7 +690,10 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         out = {
             "metric": "sampled-subgraphs/sec", "value": 2 * B * world * args.steps / dt, "unit": "subgraphs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_steps": first_timed, "ms_per_step": ms_per_step,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_steps": first_timed,
+            "untimed_steps_note": "warm-up requested: %d; run before the clock: the larger of that, the producers' pipeline fill and --steady-steps "
+                                  "(%d), rounded up to whole producer chunks" % (args.warmup, getattr(args, "steady_steps", 0)),
+            "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32" if args.mode == "sampler" else "f32", "data": "synthetic",
             "steps_per_sec": args.steps / dt,
