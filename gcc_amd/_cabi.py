@@ -174,6 +174,8 @@ SIGNATURES = {
     "gcc_posemb_debug_ticks": (None, [ctypes.c_void_p]),
     "gcc_sampler_debug_ticks": (None, [ctypes.c_void_p]),
     "gcc_sampler_debug_grids": (None, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "gcc_debug_load": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
+                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_gin_debug_ticks": (None, [ctypes.c_void_p]),
     "gcc_ginw_debug_ticks": (None, [ctypes.c_void_p]),
     "gcc_posemb_multi_workspace_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32]),

@@ -368,14 +368,14 @@ struct PosHead {                     // head of the caller's workspace (zeroed p
 // expansion at the end needs of them (defl_record) go to the workspace: it keeps the mid class at 132 KiB, so that a
 // workgroup of the training step (26 KiB) still fits on the same CU, and the small class at 50 KiB (3 per CU).
 #ifndef GCC_POSEMB_LDS_PAD
-#define GCC_POSEMB_LDS_PAD 0          // timing experiments: LDS a 65..128-class workgroup requests beyond what it uses
+#define GCC_POSEMB_LDS_PAD 0          // timing experiments: LDS a 65..128-class workgroup requests beyond (or, negative: below -- the LU batch narrows) its default
 #endif
 template <int kNMax, int kT, bool kGlobalA>
 __host__ __device__ constexpr int direct_lds_bytes()
 {
     return kGlobalA ? (kNMax > kGMax ? kBLds : kGLds)
                     : (int)(sizeof(float) * (6 * kNMax + 32 * kYld + kT + kNMax * (kNMax + 1) + kNMax * kYld)
-                            + kNMax * (33 * 8 + 32)) + GCC_POSEMB_LDS_PAD;
+                            + kNMax * (33 * 8 + 32)) + (kNMax > 64 ? GCC_POSEMB_LDS_PAD : 0);
 }
 
 struct TriLds {
@@ -2251,7 +2251,10 @@ constexpr int kChP = 64;             // block size
 constexpr int kChThreads = 1024;
 constexpr int kChCsrCap = 12288;     // directed edges of the deflated subgraph (uint16 column ids in LDS)
 constexpr int kChLongDeg = 96;       // longer rows are cut into chunks of this many entries, summed in chunk order
-constexpr int kChMaxChunks = 64;
+#ifndef GCC_POSEMB_CH_CHUNKS
+#define GCC_POSEMB_CH_CHUNKS 64
+#endif
+constexpr int kChMaxChunks = GCC_POSEMB_CH_CHUNKS;   // (16 KB of LDS at 64; an item with more chunks goes to the dense classes)
 constexpr int kChMaxLong = 64;
 constexpr int kChRounds = 16;      // filter rounds of an item
 constexpr int kChMaxRitz = 5;      // Ritz steps of an item (the first one: values only)

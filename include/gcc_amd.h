@@ -57,6 +57,10 @@ int32_t gcc_prof_elapsed_ms(gcc_prof *p, int32_t from_mark, int32_t to_mark, flo
  * for free: its pipeline runs on CPU workers, train.py:577-586).
  * Returns 0 and the hipStream_t in *stream. */
 int32_t gcc_stream_create_cu_mask(const uint32_t *cu_mask, int32_t words, void **stream);
+/* diagnostics (tools/load_probe.py): a synthetic co-tenant -- `workgroups` workgroups of `threads` threads and `lds_bytes` of LDS that
+ * spend `ticks` of the 100 MHz clock (at most max_iters rounds) on kind 0: barriers + LDS, 1: float4 reads streamed over buf, 2: FMA chains */
+int32_t gcc_debug_load(int32_t kind, int32_t workgroups, int32_t threads, int32_t lds_bytes, int64_t ticks, int32_t max_iters,
+                       const float *buf, int64_t buf_floats, float *sink, void *stream);
 int32_t gcc_stream_destroy(void *stream);
 
 /* ---------------------------------------------------------------- graph ---
