@@ -516,7 +516,7 @@ def main():
 
     rp, ci = powerlaw_graph(args.nodes, args.edges, seed=0)
     V, E = int(len(rp) - 1), int(len(ci))
-    graph = DeviceGraph(rp, ci, rw_hops=args.rw_hops, restart_prob=args.restart_prob, device=dev, validate=False)
+    graph = DeviceGraph(rp, ci, rw_hops=args.rw_hops, restart_prob=args.restart_prob, device=dev, validate=False, trusted=True)
     B = args.batch_size
     torch.manual_seed(0)
 

@@ -35,7 +35,7 @@ class GccGraph(ctypes.Structure):
         ("lmax", ctypes.c_int32),
         ("shard_off", ctypes.c_void_p),
         ("num_shards", ctypes.c_int32),
-        ("reserved_", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
     ]
 
 
@@ -152,6 +152,9 @@ class GccGinwArgs(ctypes.Structure):
     ]
 
 
+ABI_VERSION = 2          # GCC_AMD_ABI_VERSION of the include/gcc_amd.h these structs mirror (checked in load())
+GRAPH_CONTRACT_CHECKED = 1   # gcc_graph.flags
+
 # name -> (restype, argtypes); the single source of truth for the symbol test
 SIGNATURES = {
     "gcc_abi_version": (ctypes.c_int32, []),
@@ -262,7 +265,12 @@ def load() -> ctypes.CDLL:
         # at the first launch; seen when build() and smoke() ran in one process).
         import torch  # noqa: F401
 
-        _lib = declare(ctypes.CDLL(LIB_PATH))
+        lib = declare(ctypes.CDLL(LIB_PATH))
+        got = lib.gcc_abi_version()
+        if got != ABI_VERSION:             # the ctypes structs below mirror ONE layout of include/gcc_amd.h
+            raise RuntimeError(f"{LIB_PATH} reports C-ABI version {got}, this binding was written for {ABI_VERSION}: "
+                               "rebuild the library (python -c 'import __graft_entry__ as g; g.build()')")
+        _lib = lib
     return _lib
 
 

@@ -12,6 +12,7 @@
 //                           iteration): exact multiplicities, deterministic run time; three size classes
 //   posemb_krylov_kernel    larger ones: thick-restart Krylov-Schur, Ritz problem by the same solver core
 #include "host_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -2247,7 +2248,13 @@ __global__ __launch_bounds__(kKThreads) void posemb_krylov_kernel(KryArgs ka)
 // Items that do not converge in kChRounds, whose top k reaches the null space (the contrast bookkeeping of the
 // direct solver is needed then), or whose edges do not fit the LDS are appended to the work lists of the dense
 // classes, which run afterwards in the same stream: the exact solver remains the reference for every corner.
-constexpr int kChP = 64;             // block size
+constexpr int kChP = 64;             // widest block (sizes the workspace and the LDS)
+constexpr int kChPWide = 64, kChPNarrow = 32;   // the two block widths of the solve (posemb_cheb_kernel: `solve`)
+#ifndef GCC_POSEMB_CH_NARROW_WANT
+#define GCC_POSEMB_CH_NARROW_WANT 20
+#endif
+constexpr int kChNarrowWant = GCC_POSEMB_CH_NARROW_WANT;   // items whose quotient must deliver at most this many pairs (k - zp) start with the narrow block (0: never)
+constexpr int kChNarrowGuards = 8;   // ... and move to the wide one when the first Ritz values show more than 32 - 8 wanted pairs
 constexpr int kChThreads = 1024;
 constexpr int kChCsrCap = 12288;     // directed edges of the deflated subgraph (uint16 column ids in LDS)
 constexpr int kChLongDeg = 96;       // longer rows are cut into chunks of this many entries, summed in chunk order
@@ -2322,7 +2329,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     if (m.ticks && tid == 0) atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 15], 1ull);
     const int32_t *rp = a.row_ptr + n0;
     // three block buffers in the workspace (L2-resident): X, W = M' X or filter scratch, rotation target
-    float *XA = ca.xws + (int64_t)blockIdx.x * 3 * kNodeMax * kChP, *XB = XA + (int64_t)kNodeMax * kChP, *XC = XB + (int64_t)kNodeMax * kChP;
+    float *XA0 = ca.xws + (int64_t)blockIdx.x * 3 * kNodeMax * kChP, *XB0 = XA0 + (int64_t)kNodeMax * kChP, *XC0 = XB0 + (int64_t)kNodeMax * kChP;
 
     // ---- twin-leaf and stalk groups (as posemb_direct_kernel)
     Defl d;
@@ -2430,6 +2437,23 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     if (getenv("GCC_POSEMB_DEBUG") && tid == 0) fprintf(stderr, "cheb item b=%d n=%d nr=%d nnz=%d nlong=%d nchunk=%d fail=%d\n", b, n, nr, (int)crow[nr], sh_nlong, nchunk, sh_fail);
 #endif
     const int kq = min(k, nr);
+    const bool build_failed = failed;
+    // The solve itself, for a block of P columns (P = 64: k <= 32 wanted + guards, rounds 2-4; P = 32: round 5).  Of the
+    // top k of the MERGED spectrum the quotient only has to deliver what the zp stalk contrasts at 1/sqrt(2) leave room
+    // for -- k - zp pairs, 17 on average and at most 20 for 72 % of the C2 workload's items (hub ego-nets carry 12-30
+    // stalk contrasts) -- so a 32-column block holds them with >= 12 guard columns at half the cost per sparse product, a
+    // quarter per Gram matrix / rotation and an eighth per Ritz problem.  Returns 0: done (or handed to the dense classes),
+    // 2: (P = 32 only) the first Ritz values show more wanted pairs than a narrow block converges: redo with P = 64.
+    auto solve = [&](auto pc) -> int {
+    constexpr int P = decltype(pc)::value;
+    constexpr int Ldy = P + 1;
+    constexpr int E = P * P / kChThreads;                    // entries of a P x P matrix per thread: 4 (P = 64) / 1 (P = 32)
+    constexpr int TPM = P / E;                               // threads per matrix row: 16 / 32
+    const int mi = tid / TPM, mj = E * (tid % TPM);          // this thread's strip of a P x P matrix: row mi, columns mj .. mj + E - 1
+    constexpr int TPR = P / 8;                               // threads per block row in the products (8 columns each)
+    constexpr int TPQ = P / 4;                               // ... in the rotation / tile loads (4 columns each)
+    bool failed = build_failed;
+    float *XA = XA0, *XB = XB0, *XC = XC0;
 
     // dst = alpha * (M' src - center * src) - gamma * dst   (rows of 64 floats; 16 threads x float4 per row)
     // 8 threads per row (8 block vectors = 2 x float4 each), 128 rows at a time, four gathers per vector pair in flight.
@@ -2437,11 +2461,11 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     // vectors each was measured slower: 1.27 against 0.86 ms of products per item).  Blocks of at most kChLdsRows rows are
     // therefore copied into LDS first (coalesced, once per product: the region of the dense matrices is free while the
     // filter runs) and gathered from there; the result still goes to the L2-resident buffer, coalesced.
-    constexpr int kChLdsRows = cheb_region_bytes() / (kChP * (int)sizeof(float));
+    constexpr int kChLdsRows = cheb_region_bytes() / (P * (int)sizeof(float));
     const bool lds_x = nr <= kChLdsRows;                     // block-uniform
     auto gather = [&](auto in_lds, const float *src, int e0, int e1, float *acc) {
         const float *base = decltype(in_lds)::value ? (const float *)region : src;
-        const int q8 = 8 * (tid & 7);
+        const int q8 = 8 * (tid % TPR);
         for (int e = e0; e < e1; e += 4) {
             int cj[4];
             float sc[4];
@@ -2454,8 +2478,8 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                xa[u] = *(const float4 *)(base + (int64_t)cj[u] * kChP + q8);
-                xb[u] = *(const float4 *)(base + (int64_t)cj[u] * kChP + q8 + 4);
+                xa[u] = *(const float4 *)(base + (int64_t)cj[u] * P + q8);
+                xb[u] = *(const float4 *)(base + (int64_t)cj[u] * P + q8 + 4);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -2468,25 +2492,25 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     };
     auto spmm_body = [&](auto in_lds, const float *src, float *dst, float alpha, float center, float gamma) {
         const float *base = decltype(in_lds)::value ? (const float *)region : src;
-        const int q8 = 8 * (tid & 7), g8 = tid >> 3;
-        for (int c = g8; c < nchunk; c += kChThreads / 8) {              // chunks of the long rows -> slab
+        const int q8 = 8 * (tid % TPR), g8 = tid / TPR;
+        for (int c = g8; c < nchunk; c += kChThreads / TPR) {              // chunks of the long rows -> slab
             int x = 0;
             while (longfirst[x + 1] <= c) ++x;
             const int r = longrow[x];
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             gather(in_lds, src, chunk_beg[c], min(chunk_beg[c] + kChLongDeg, (int)crow[r + 1]), acc);
-            *(float4 *)(slab + c * kChP + q8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            *(float4 *)(slab + c * kChP + q8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            *(float4 *)(slab + c * P + q8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *(float4 *)(slab + c * P + q8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
         }
         if (nchunk) __syncthreads();
-        for (int r = g8; r < nr; r += kChThreads / 8) {
+        for (int r = g8; r < nr; r += kChThreads / TPR) {
             const int e0 = (int)crow[r], e1 = (int)crow[r + 1];
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (e1 - e0 > kChLongDeg) {
                 int x = 0;
                 while (longrow[x] != r) ++x;
                 for (int c = longfirst[x]; c < longfirst[x + 1]; ++c) {
-                    const float4 pa = *(const float4 *)(slab + c * kChP + q8), pb = *(const float4 *)(slab + c * kChP + q8 + 4);
+                    const float4 pa = *(const float4 *)(slab + c * P + q8), pb = *(const float4 *)(slab + c * P + q8 + 4);
                     acc[0] += pa.x; acc[1] += pa.y; acc[2] += pa.z; acc[3] += pa.w;
                     acc[4] += pb.x; acc[5] += pb.y; acc[6] += pb.z; acc[7] += pb.w;
                 }
@@ -2494,18 +2518,82 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
                 gather(in_lds, src, e0, e1, acc);
             }
             const float sr = scale[r];
-            const float4 oa = *(const float4 *)(base + (int64_t)r * kChP + q8), ob = *(const float4 *)(base + (int64_t)r * kChP + q8 + 4);
+            const float4 oa = *(const float4 *)(base + (int64_t)r * P + q8), ob = *(const float4 *)(base + (int64_t)r * P + q8 + 4);
             float o[8] = {alpha * (sr * acc[0] - center * oa.x), alpha * (sr * acc[1] - center * oa.y),
                           alpha * (sr * acc[2] - center * oa.z), alpha * (sr * acc[3] - center * oa.w),
                           alpha * (sr * acc[4] - center * ob.x), alpha * (sr * acc[5] - center * ob.y),
                           alpha * (sr * acc[6] - center * ob.z), alpha * (sr * acc[7] - center * ob.w)};
             if (gamma != 0.f) {
-                const float4 da = *(const float4 *)(dst + (int64_t)r * kChP + q8), db = *(const float4 *)(dst + (int64_t)r * kChP + q8 + 4);
+                const float4 da = *(const float4 *)(dst + (int64_t)r * P + q8), db = *(const float4 *)(dst + (int64_t)r * P + q8 + 4);
                 o[0] -= gamma * da.x; o[1] -= gamma * da.y; o[2] -= gamma * da.z; o[3] -= gamma * da.w;
                 o[4] -= gamma * db.x; o[5] -= gamma * db.y; o[6] -= gamma * db.z; o[7] -= gamma * db.w;
             }
-            *(float4 *)(dst + (int64_t)r * kChP + q8) = make_float4(o[0], o[1], o[2], o[3]);
-            *(float4 *)(dst + (int64_t)r * kChP + q8 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            *(float4 *)(dst + (int64_t)r * P + q8) = make_float4(o[0], o[1], o[2], o[3]);
+            *(float4 *)(dst + (int64_t)r * P + q8 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        __syncthreads();
+    };
+    // One filter step with the block RESIDENT in LDS (lds_x: nr * P floats fit the region; round 5).  Y_{i-1} is gathered
+    // from LDS, the new rows wait in registers until every gather of the step is done and then replace it; Y_{i-2} is
+    // thread-private -- a thread computes the same (row, 8 columns) strips in every step -- and lives in `prev` (the
+    // workspace), read and overwritten by its owner only.  What a product still moves through L2 is off its chain: the
+    // per-product copy of the block into LDS, the read-modify-write of the target block and the wait for its stores
+    // (a third of a product's time at n' ~ 300) are gone.
+    constexpr int RPP = kChThreads / TPR;                    // rows per pass of the workgroup: 128 (P = 64) / 256 (P = 32)
+    constexpr int kPasses = 3;
+    static_assert(kChLdsRows == kPasses * RPP, "an LDS-resident block is covered in kPasses passes");
+    auto filter_step_lds = [&](float *prev, float alpha, float center, float gamma) {
+        float *xs = (float *)region;
+        const int q8 = 8 * (tid % TPR), g8 = tid / TPR;
+        for (int c = g8; c < nchunk; c += RPP) {                         // chunks of the long rows -> slab
+            int x = 0;
+            while (longfirst[x + 1] <= c) ++x;
+            const int r = longrow[x];
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            gather(LdsYes(), xs, chunk_beg[c], min(chunk_beg[c] + kChLongDeg, (int)crow[r + 1]), acc);
+            *(float4 *)(slab + c * P + q8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *(float4 *)(slab + c * P + q8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+        if (nchunk) __syncthreads();
+        float nw[kPasses][8];
+#pragma unroll
+        for (int ps = 0; ps < kPasses; ++ps) {
+            const int r = g8 + ps * RPP;
+            if (r < nr) {
+                float4 da = make_float4(0.f, 0.f, 0.f, 0.f), db = da;
+                float *pr_ = prev + (int64_t)r * P + q8;
+                if (gamma != 0.f) { da = *(const float4 *)pr_; db = *(const float4 *)(pr_ + 4); }      // requested before the gathers
+                const int e0 = (int)crow[r], e1 = (int)crow[r + 1];
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (e1 - e0 > kChLongDeg) {
+                    int x = 0;
+                    while (longrow[x] != r) ++x;
+                    for (int c = longfirst[x]; c < longfirst[x + 1]; ++c) {
+                        const float4 pa = *(const float4 *)(slab + c * P + q8), pb = *(const float4 *)(slab + c * P + q8 + 4);
+                        acc[0] += pa.x; acc[1] += pa.y; acc[2] += pa.z; acc[3] += pa.w;
+                        acc[4] += pb.x; acc[5] += pb.y; acc[6] += pb.z; acc[7] += pb.w;
+                    }
+                } else {
+                    gather(LdsYes(), xs, e0, e1, acc);
+                }
+                const float sr = scale[r];
+                const float4 oa = *(const float4 *)(xs + r * P + q8), ob = *(const float4 *)(xs + r * P + q8 + 4);
+                nw[ps][0] = alpha * (sr * acc[0] - center * oa.x) - gamma * da.x; nw[ps][1] = alpha * (sr * acc[1] - center * oa.y) - gamma * da.y;
+                nw[ps][2] = alpha * (sr * acc[2] - center * oa.z) - gamma * da.z; nw[ps][3] = alpha * (sr * acc[3] - center * oa.w) - gamma * da.w;
+                nw[ps][4] = alpha * (sr * acc[4] - center * ob.x) - gamma * db.x; nw[ps][5] = alpha * (sr * acc[5] - center * ob.y) - gamma * db.y;
+                nw[ps][6] = alpha * (sr * acc[6] - center * ob.z) - gamma * db.z; nw[ps][7] = alpha * (sr * acc[7] - center * ob.w) - gamma * db.w;
+                *(float4 *)pr_ = oa;                                     // Y_{i-1} becomes the next step's Y_{i-2}
+                *(float4 *)(pr_ + 4) = ob;
+            }
+        }
+        __syncthreads();                                                 // every gather of Y_{i-1} is done
+#pragma unroll
+        for (int ps = 0; ps < kPasses; ++ps) {
+            const int r = g8 + ps * RPP;
+            if (r < nr) {
+                *(float4 *)(xs + r * P + q8) = make_float4(nw[ps][0], nw[ps][1], nw[ps][2], nw[ps][3]);
+                *(float4 *)(xs + r * P + q8 + 4) = make_float4(nw[ps][4], nw[ps][5], nw[ps][6], nw[ps][7]);
+            }
         }
         __syncthreads();
     };
@@ -2514,7 +2602,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         if (lds_x) {
             float4 *xs = (float4 *)region;
             const float4 *gs = (const float4 *)src;
-            for (int i = tid; i < nr * (kChP / 4); i += kChThreads) xs[i] = gs[i];
+            for (int i = tid; i < nr * (P / 4); i += kChThreads) xs[i] = gs[i];
             __syncthreads();
             spmm_body(LdsYes(), src, dst, alpha, center, gamma);
         } else {
@@ -2522,15 +2610,15 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         }
     };
 
-    double *G = (double *)region, *K = G + kChP * kChP;      // fp64 [64][64] each
+    double *G = (double *)region, *K = G + P * P;            // fp64 [P][P] each
     float cut = 0.2f;
     int deg = 6, remaining = 6, round = 0, nrr = 0;
     unsigned long long flops = 0;                            // executed FLOPs of this item (diagnostics, ticks[class][14])
     const unsigned long long nnz_ = (unsigned long long)crow[nr], nr_ = (unsigned long long)nr;
     bool converged = false;
     if (!failed) {
-        for (int i = tid; i < nr * kChP; i += kChThreads)    // start block: U(-1, 1), np.random.rand's role
-            XA[i] = hash_unit((uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u), (uint32_t)(i & (kChP - 1)), (uint32_t)(i / kChP));
+        for (int i = tid; i < nr * P; i += kChThreads)       // start block: U(-1, 1), np.random.rand's role
+            XA[i] = hash_unit((uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u), (uint32_t)(i & (P - 1)), (uint32_t)(i / P));
         __syncthreads();
     }
     // A round = filter of degree `deg`, then either a cheap re-orthonormalisation (X <- X R^-1) or, when the degrees
@@ -2545,7 +2633,23 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         // and bisection of the projected matrix, no vectors -- the block is just re-orthonormalised
         const bool vals_only = rr && nrr == 0, fullrr = rr && !vals_only;
         // ---- filter: scaled Chebyshev polynomial of degree `deg` (even) for [-1, cut], p(1) = 1
-        {
+        if (lds_x && !(hd.use_cheb & 4)) {
+            const float e = 0.5f * (cut + 1.0f), cen = 0.5f * (cut - 1.0f);
+            float sigma = e / (1.0f - cen);
+            const float tau = 2.0f / sigma;
+            float4 *xs = (float4 *)region;
+            for (int i = tid; i < nr * (P / 4); i += kChThreads) xs[i] = ((const float4 *)XA)[i];
+            __syncthreads();
+            filter_step_lds(XB, sigma / e, cen, 0.f);                    // Y_1 (XB keeps Y_0's rows, thread-private)
+            for (int i = 2; i <= deg; ++i) {
+                const float sn = 1.0f / (tau - sigma);
+                filter_step_lds(XB, 2.0f * sn / e, cen, sigma * sn);
+                sigma = sn;
+            }
+            for (int i = tid; i < nr * (P / 4); i += kChThreads) ((float4 *)XA)[i] = xs[i];     // the filtered block, for the Gram / rotation phases
+            if (rr) spmm_body(LdsYes(), XA, XB, 1.0f, 0.f, 0.f);         // W = M' X, gathered from the block still in LDS
+            else __syncthreads();
+        } else {
             const float e = 0.5f * (cut + 1.0f), cen = 0.5f * (cut - 1.0f);
             float sigma = e / (1.0f - cen);
             const float tau = 2.0f / sigma;
@@ -2557,91 +2661,85 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
                 float *t = prev; prev = cur; cur = t;
                 sigma = sn;
             }                                                            // deg even: the result is in XA
+            if (rr) spmm(XA, XB, 1.0f, 0.f, 0.f);                        // W = M' X
         }
-        if (rr) spmm(XA, XB, 1.0f, 0.f, 0.f);                            // W = M' X
         // products: 2 nnz 64 + 5 n 64 each; Gram matrices 2 n 64^2 (x2 with K); Cholesky + inverse + projected matrix ~ 64^3 x 2;
         // a Ritz problem 2 64^3 + 2 64^3 (tridiagonalisation, back-transformation of 64 vectors); rotation 2 n 64^2 (x2 with W)
-        flops += (unsigned long long)(deg + (rr ? 1 : 0)) * (2ull * nnz_ * kChP + 5ull * nr_ * kChP)
-                 + (rr ? 2ull : 1ull) * 2ull * nr_ * kChP * kChP + 2ull * kChP * kChP * kChP
-                 + (rr ? 4ull * kChP * kChP * kChP : 0ull) + (fullrr ? 2ull : 1ull) * 2ull * nr_ * kChP * kChP;
+        flops += (unsigned long long)(deg + (rr ? 1 : 0)) * (2ull * nnz_ * P + 5ull * nr_ * P)
+                 + (rr ? 2ull : 1ull) * 2ull * nr_ * P * P + 2ull * P * P * P
+                 + (rr ? 4ull * P * P * P : 0ull) + (fullrr ? 2ull : 1ull) * 2ull * nr_ * P * P;
         PHASE_TICK(1);                                                   // sparse products
         // ---- G = X^T X (and K = X^T W), fp64 accumulation.  Tiles of 32 rows of X and of W go through LDS (the slab):
         //      one coalesced 16-byte load per thread and tile, requested a tile ahead, instead of a chain of L2 round trips
         {
-            const int i = tid >> 4, j4 = 4 * (tid & 15);
-            double g0 = 0, g1 = 0, g2 = 0, g3 = 0, k0 = 0, k1 = 0, k2 = 0, k3 = 0;
-            float *tx = slab, *twv = slab + 32 * kChP;           // [32][64] each
+            double gacc[E], kacc[E];
+#pragma unroll
+            for (int u = 0; u < E; ++u) gacc[u] = kacc[u] = 0.0;
+            constexpr int TR = (kChThreads / 2) / TPQ;           // rows of a tile: 32 (P = 64) / 64 (P = 32); TR * P = 2048 floats
+            float *tx = slab, *twv = slab + TR * P;              // [TR][P] each
             const bool isw = tid >= kChThreads / 2;
-            const int lt = tid & (kChThreads / 2 - 1);            // float4 index inside a tile: row lt >> 4, quad lt & 15
+            const int lt = tid & (kChThreads / 2 - 1);            // float4 index inside a tile: row lt / TPQ, quad lt % TPQ
             const float *gsrc = isw ? XB : XA;
             auto fetch = [&](int t0) -> float4 {
-                const int r = t0 + (lt >> 4);
-                return (r < nr && (!isw || rr)) ? *(const float4 *)(gsrc + (int64_t)r * kChP + 4 * (lt & 15)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int r = t0 + lt / TPQ;
+                return (r < nr && (!isw || rr)) ? *(const float4 *)(gsrc + (int64_t)r * P + 4 * (lt % TPQ)) : make_float4(0.f, 0.f, 0.f, 0.f);
             };
             float4 nxt = fetch(0);
-            for (int t0 = 0; t0 < nr; t0 += 32) {
+            for (int t0 = 0; t0 < nr; t0 += TR) {
                 *(float4 *)((isw ? twv : tx) + 4 * lt) = nxt;
                 __syncthreads();
-                if (t0 + 32 < nr) nxt = fetch(t0 + 32);
-                const int rows = min(32, nr - t0);
-                if (rr) {
-                    for (int r = 0; r < rows; ++r) {
-                        const double xi = (double)tx[r * kChP + i];
-                        const float4 xj = *(const float4 *)(tx + r * kChP + j4);
-                        const float4 wj = *(const float4 *)(twv + r * kChP + j4);
-                        g0 += xi * xj.x; g1 += xi * xj.y; g2 += xi * xj.z; g3 += xi * xj.w;
-                        k0 += xi * wj.x; k1 += xi * wj.y; k2 += xi * wj.z; k3 += xi * wj.w;
-                    }
-                } else {
-                    for (int r = 0; r < rows; ++r) {
-                        const double xi = (double)tx[r * kChP + i];
-                        const float4 xj = *(const float4 *)(tx + r * kChP + j4);
-                        g0 += xi * xj.x; g1 += xi * xj.y; g2 += xi * xj.z; g3 += xi * xj.w;
+                if (t0 + TR < nr) nxt = fetch(t0 + TR);
+                const int rows = min(TR, nr - t0);
+                for (int r = 0; r < rows; ++r) {
+                    const double xi = (double)tx[r * P + mi];
+                    if constexpr (E == 4) {
+                        const float4 xj = *(const float4 *)(tx + r * P + mj);
+                        gacc[0] += xi * xj.x; gacc[1] += xi * xj.y; gacc[2] += xi * xj.z; gacc[3] += xi * xj.w;
+                        if (rr) {                                // block-uniform
+                            const float4 wj = *(const float4 *)(twv + r * P + mj);
+                            kacc[0] += xi * wj.x; kacc[1] += xi * wj.y; kacc[2] += xi * wj.z; kacc[3] += xi * wj.w;
+                        }
+                    } else {
+                        gacc[0] += xi * tx[r * P + mj];
+                        if (rr) kacc[0] += xi * twv[r * P + mj];
                     }
                 }
                 __syncthreads();
             }
-            double *gp = G + i * kChP + j4, *kp = K + i * kChP + j4;
-            gp[0] = g0; gp[1] = g1; gp[2] = g2; gp[3] = g3;
-            kp[0] = k0; kp[1] = k1; kp[2] = k2; kp[3] = k3;
+#pragma unroll
+            for (int u = 0; u < E; ++u) { G[mi * P + mj + u] = gacc[u]; K[mi * P + mj + u] = kacc[u]; }
         }
         __syncthreads();
         PHASE_TICK(5);                                           // Gram matrices
         // ---- small dense algebra, all 16 waves, fp64 in LDS: Jacobi scaling G^ = D G D; shifted Cholesky G^ = L L^T
         //      (right-looking, two barriers per column); Linv = L^-1 by recursive doubling over the diagonal blocks
         //      (inv [A 0; B C] = [A^-1 0; -C^-1 B A^-1  C^-1]: 6 levels); with a Ritz step H = Linv K^ Linv^T
-        double *Li = K + kChP * kChP;                            // [64][64] L^-1 (lower); upper triangle = scratch
-        if (tid < kChP) {
-            const double dd = G[tid * kChP + tid];
+        double *Li = K + P * P;                                  // [P][P] L^-1 (lower); upper triangle = scratch
+        if (tid < P) {
+            const double dd = G[tid * P + tid];
             const double di = dd > 1e-300 ? 1.0 / sqrt(dd) : 0.0;
             if (!(dd > 1e-300)) sh_fail = 1;
             dsc[tid] = (float)di;
             dscd[tid] = di;                                      // (an fp32 copy here would break the congruence D G D by 1e-7)
         }
         __syncthreads();
-        {
-            const int i = tid >> 4, j4 = 4 * (tid & 15);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j4 + u;
-                const double sc = dscd[i] * dscd[j];
-                // shifted Cholesky: guard columns that have collapsed onto the span of the others are damped instead of
-                // breaking the factorisation; a converged block (unit pivots) is not affected
-                G[i * kChP + j] = G[i * kChP + j] * sc + (i == j ? kChShift : 0.0);
-                if (j <= i) {                                    // K^ lower part, symmetrised
-                    const double kv = 0.5 * (K[i * kChP + j] + K[j * kChP + i]) * sc;
-                    Li[i * kChP + j] = kv;                       // (parked in Li until K's upper part has been read)
-                }
+        for (int u = 0; u < E; ++u) {
+            const int i = mi, j = mj + u;
+            const double sc = dscd[i] * dscd[j];
+            // shifted Cholesky: guard columns that have collapsed onto the span of the others are damped instead of
+            // breaking the factorisation; a converged block (unit pivots) is not affected
+            G[i * P + j] = G[i * P + j] * sc + (i == j ? kChShift : 0.0);
+            if (j <= i) {                                        // K^ lower part, symmetrised
+                const double kv = 0.5 * (K[i * P + j] + K[j * P + i]) * sc;
+                Li[i * P + j] = kv;                              // (parked in Li until K's upper part has been read)
             }
         }
         __syncthreads();
-        {
-            const int i = tid >> 4, j4 = 4 * (tid & 15);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j4 + u;
-                K[i * kChP + j] = j <= i ? Li[i * kChP + j] : Li[j * kChP + i];
-            }
+        for (int u = 0; u < E; ++u) {
+            const int i = mi, j = mj + u;
+            K[i * P + j] = j <= i ? Li[i * P + j] : Li[j * P + i];
         }
         __syncthreads();
         // Cholesky of the 64 x 64 matrix by ONE wave with no barrier inside (the panel version it replaces -- panels of 16
@@ -2653,17 +2751,18 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         // here) and transposed into G's lower triangle by all waves afterwards.
         if (wv == 0) {
             double *Lt = Li;                                     // [k][i] = L[i][k]
-            double ar[kChP / 2];
+            double ar[32];
             bool bad = false;
+            const bool live = lane < P;                          // (P = 32: the upper half of the wave has no row)
 #pragma unroll 1
-            for (int half = 0; half < 2 && !bad; ++half) {
+            for (int half = 0; half < P / 32 && !bad; ++half) {
                 const int cb = 32 * half;
 #pragma unroll
-                for (int c = 0; c < 32; ++c) ar[c] = G[lane * kChP + cb + c];
+                for (int c = 0; c < 32; ++c) ar[c] = live ? G[lane * P + cb + c] : 0.0;
                 if (half == 1) {                                 // replay steps 0..31 on the right half
 #pragma unroll 1
                     for (int k = 0; k < 32; ++k) {
-                        const double l = Lt[k * kChP + lane];    // 0 above the diagonal (written below)
+                        const double l = Lt[k * P + lane];       // 0 above the diagonal (written below)
 #pragma unroll
                         for (int u = 0; u < 32; ++u) ar[u] = fma(-l, wave_readlane(l, 32 + u), ar[u]);
                     }
@@ -2679,8 +2778,8 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
                         bad = true;
                         break;
                     }
-                    const double l = lane >= k ? cap * (1.0 / sqrt(piv)) : 0.0;  // L[lane][k]
-                    Lt[k * kChP + lane] = l;
+                    const double l = (live && lane >= k) ? cap * (1.0 / sqrt(piv)) : 0.0;  // L[lane][k]
+                    if (live) Lt[k * P + lane] = l;
 #pragma unroll
                     for (int jb = 0; jb < 4; ++jb) {
                         if (cb + 8 * jb + 7 > k) {               // wave-uniform: some column of the block is right of k
@@ -2698,156 +2797,155 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         }
         __syncthreads();
         if (!sh_fail) {                                          // L -> lower triangle of G (what the inverse below reads)
-            const int i = tid >> 4, j4 = 4 * (tid & 15);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (j4 + u <= i) G[i * kChP + j4 + u] = Li[(j4 + u) * kChP + i];
+            for (int u = 0; u < E; ++u)
+                if (mj + u <= mi) G[mi * P + mj + u] = Li[(mj + u) * P + mi];
         }
         __syncthreads();
         if (sh_fail) { failed = true; break; }
         PHASE_TICK(6);                                           // Cholesky
         {   // Li = L with inverted diagonal; then the doubling levels
-            const int i = tid >> 4, j4 = 4 * (tid & 15);
+            const int i = mi, j4 = mj;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < E; ++u) {
                 const int j = j4 + u;
-                Li[i * kChP + j] = j < i ? G[i * kChP + j] : (j == i ? 1.0 / G[i * kChP + i] : 0.0);
+                Li[i * P + j] = j < i ? G[i * P + j] : (j == i ? 1.0 / G[i * P + i] : 0.0);
             }
             __syncthreads();
-            for (int sz = 1; sz < kChP; sz <<= 1) {
-                const int per = sz * sz, pairs = kChP / (2 * sz);
+            for (int sz = 1; sz < P; sz <<= 1) {
+                const int per = sz * sz, pairs = P / (2 * sz);
                 // T = B A, stored transposed in the (free) upper triangle
                 for (int e = tid; e < pairs * per; e += kChThreads) {
                     const int pr = e / per, ii = (e - pr * per) / sz, jj = e % sz, r0 = 2 * sz * pr;
                     double acc = 0.0;
-                    for (int q = jj; q < sz; ++q) acc += Li[(r0 + sz + ii) * kChP + r0 + q] * Li[(r0 + q) * kChP + r0 + jj];
-                    Li[(r0 + jj) * kChP + r0 + sz + ii] = acc;
+                    for (int q = jj; q < sz; ++q) acc += Li[(r0 + sz + ii) * P + r0 + q] * Li[(r0 + q) * P + r0 + jj];
+                    Li[(r0 + jj) * P + r0 + sz + ii] = acc;
                 }
                 __syncthreads();
                 // B' = -C T
                 for (int e = tid; e < pairs * per; e += kChThreads) {
                     const int pr = e / per, ii = (e - pr * per) / sz, jj = e % sz, r0 = 2 * sz * pr;
                     double acc = 0.0;
-                    for (int q = 0; q <= ii; ++q) acc += Li[(r0 + sz + ii) * kChP + r0 + sz + q] * Li[(r0 + jj) * kChP + r0 + sz + q];
-                    Li[(r0 + sz + ii) * kChP + r0 + jj] = -acc;          // (B itself is not read in this phase)
+                    for (int q = 0; q <= ii; ++q) acc += Li[(r0 + sz + ii) * P + r0 + sz + q] * Li[(r0 + jj) * P + r0 + sz + q];
+                    Li[(r0 + sz + ii) * P + r0 + jj] = -acc;          // (B itself is not read in this phase)
                 }
                 __syncthreads();
             }
             if (rr) {
                 // T1 = Linv K^ (into G), H = T1 Linv^T (into K)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < E; ++u) {
                     const int j = j4 + u;
                     double acc = 0.0;
-                    for (int q = 0; q <= i; ++q) acc += Li[i * kChP + q] * K[q * kChP + j];
-                    G[i * kChP + j] = acc;
+                    for (int q = 0; q <= i; ++q) acc += Li[i * P + q] * K[q * P + j];
+                    G[i * P + j] = acc;
                 }
                 __syncthreads();
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < E; ++u) {
                     const int j = j4 + u;
                     double acc = 0.0;
-                    for (int q = 0; q <= j; ++q) acc += G[i * kChP + q] * Li[j * kChP + q];
-                    K[i * kChP + j] = acc;
+                    for (int q = 0; q <= j; ++q) acc += G[i * P + q] * Li[j * P + q];
+                    K[i * P + j] = acc;
                 }
                 __syncthreads();
             }
         }
-        // ---- LDS region from here on: Lf (Linv, fp32) | Af (H, later C with stride 64) | Y | solver arrays.  G, K and Li
+        // ---- LDS region from here on: Lf (Linv, fp32) | Af (H, later C with stride P) | Y | solver arrays.  G, K and Li
         //      are dead once Linv and H have been copied out (through registers: the fp32 copies overlay them)
-        float *Lf = (float *)region, *Af = Lf + kChP * kChLdy;
+        float *Lf = (float *)region, *Af = Lf + P * Ldy;
         {
-            float lrow[4], hrow[4];
-            const int i = tid >> 4, j4 = 4 * (tid & 15);
+            float lrow[E], hrow[E];
+            const int i = mi, j4 = mj;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                lrow[u] = j4 + u <= i ? (float)Li[i * kChP + j4 + u] : 0.f;
-                hrow[u] = (float)(0.5 * (K[i * kChP + j4 + u] + K[(j4 + u) * kChP + i]));
+            for (int u = 0; u < E; ++u) {
+                lrow[u] = j4 + u <= i ? (float)Li[i * P + j4 + u] : 0.f;
+                hrow[u] = (float)(0.5 * (K[i * P + j4 + u] + K[(j4 + u) * P + i]));
             }
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                Lf[i * kChLdy + j4 + u] = lrow[u];
-                Af[i * kChLdy + j4 + u] = hrow[u];
+            for (int u = 0; u < E; ++u) {
+                Lf[i * Ldy + j4 + u] = lrow[u];
+                Af[i * Ldy + j4 + u] = hrow[u];
             }
         }
         PHASE_TICK(7);                                           // triangular inverse, projected matrix
         TriLds tw;
-        tw.Y = Af + kChP * kChLdy;
-        tw.ldy = kChLdy;
-        tw.dg = tw.Y + kChP * kChLdy;
-        tw.of = tw.dg + kChP;
-        tw.of2 = tw.of + kChP;
-        tw.tau = tw.of2 + kChP;
-        tw.pbuf = tw.tau + kChP;
-        tw.vbuf = tw.pbuf + kChP;
-        tw.coef = tw.vbuf + kChP;
-        tw.cnt = (int *)(tw.coef + kChP * kChLdy);
+        tw.Y = Af + P * Ldy;
+        tw.ldy = Ldy;
+        tw.dg = tw.Y + P * Ldy;
+        tw.of = tw.dg + P;
+        tw.of2 = tw.of + P;
+        tw.tau = tw.of2 + P;
+        tw.pbuf = tw.tau + P;
+        tw.vbuf = tw.pbuf + P;
+        tw.coef = tw.vbuf + P;
+        tw.cnt = (int *)(tw.coef + P * Ldy);
         tw.bw = kChBw;
         tw.ldu = kChBw + 1;
         tw.Ud = (float *)(tw.cnt + kChThreads);
-        tw.Us = tw.Ud + kChP * tw.ldu;
-        tw.Uf = (uint8_t *)(tw.Us + kChP * tw.ldu);
+        tw.Us = tw.Ud + P * tw.ldu;
+        tw.Uf = (uint8_t *)(tw.Us + P * tw.ldu);
         __syncthreads();
         if (rr) {
-            // Ritz problem: all 64 pairs of H by the dense solver core
-            tridiagonalize<1, kChThreads, 2>(Af, kChLdy, kChP, tw);
-            eig_top_values<kChThreads, kVecCap>(tw, kChP, kChP, es);
+            // Ritz problem: all P pairs of H by the dense solver core
+            tridiagonalize<1, kChThreads, 2>(Af, Ldy, P, tw);
+            eig_top_values<kChThreads, kVecCap>(tw, P, P, es);
             const bool ritz_failed = vals_only ? false
-                : eig_top_vectors<1, kChThreads>(Af, kChLdy, kChP, kChP, tw, es,
+                : eig_top_vectors<1, kChThreads>(Af, Ldy, P, P, tw, es,
                                                  (uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u) ^ (uint32_t)(round + 77), nullptr, tick_);
 #ifdef GCC_AMD_HIPEMU
             if (getenv("GCC_POSEMB_DEBUG") && tid == 0 && ritz_failed) fprintf(stderr, "cheb ritz failed round=%d\n", round);
 #endif
             if (ritz_failed) { failed = true; break; }           // block-uniform
             ++nrr;
-            if (tid < kChP) theta[tid] = es.lamv[tid];
+            if (tid < P) theta[tid] = es.lamv[tid];
         }
         PHASE_TICK(2);                                           // Ritz problem
-        // ---- C = D Linv^T Y (Y = I without a Ritz step), stride 64, over H
+        // ---- C = D Linv^T Y (Y = I without a Ritz step), stride P, over H
         {
-            const int i = tid >> 4, j4 = 4 * (tid & 15);
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+            float c[E];
+#pragma unroll
+            for (int u = 0; u < E; ++u) c[u] = 0.f;
             if (fullrr) {
-                for (int q = i; q < kChP; ++q) {                 // Linv^T[i][q] = Linv[q][i], q >= i
-                    const float l = Lf[q * kChLdy + i];
-                    c0 = fmaf(l, tw.Y[q * kChLdy + j4], c0); c1 = fmaf(l, tw.Y[q * kChLdy + j4 + 1], c1);
-                    c2 = fmaf(l, tw.Y[q * kChLdy + j4 + 2], c2); c3 = fmaf(l, tw.Y[q * kChLdy + j4 + 3], c3);
+                for (int q = mi; q < P; ++q) {                   // Linv^T[i][q] = Linv[q][i], q >= i
+                    const float l = Lf[q * Ldy + mi];
+#pragma unroll
+                    for (int u = 0; u < E; ++u) c[u] = fmaf(l, tw.Y[q * Ldy + mj + u], c[u]);
                 }
             } else {
-                c0 = j4 >= i ? Lf[j4 * kChLdy + i] : 0.f;
-                c1 = j4 + 1 >= i ? Lf[(j4 + 1) * kChLdy + i] : 0.f;
-                c2 = j4 + 2 >= i ? Lf[(j4 + 2) * kChLdy + i] : 0.f;
-                c3 = j4 + 3 >= i ? Lf[(j4 + 3) * kChLdy + i] : 0.f;
+#pragma unroll
+                for (int u = 0; u < E; ++u) c[u] = mj + u >= mi ? Lf[(mj + u) * Ldy + mi] : 0.f;
             }
-            const float di = dsc[i];
+            const float di = dsc[mi];
             __syncthreads();                                     // H (Af) and the reflectors in it are dead: C goes there
-            *(float4 *)(Af + i * kChP + j4) = make_float4(c0 * di, c1 * di, c2 * di, c3 * di);
+#pragma unroll
+            for (int u = 0; u < E; ++u) Af[mi * P + mj + u] = c[u] * di;
         }
         __syncthreads();
         // ---- X <- X C into the free buffer (W C stays in registers); residuals ||W_i - theta_i X_i||^2 accumulated per
         //      thread, then over the 64 row groups
         {
-            const int q4 = 4 * (tid & 15), g16 = tid >> 4;
+            const int q4 = 4 * (tid % TPQ), g16 = tid / TPQ;
             float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
             const float t0 = theta[q4], t1 = theta[q4 + 1], t2 = theta[q4 + 2], t3 = theta[q4 + 3];
-            for (int r = g16; r < nr; r += kChThreads / 16) {
+            for (int r = g16; r < nr; r += kChThreads / TPQ) {
                 float xn[4] = {0.f, 0.f, 0.f, 0.f}, wn[4] = {0.f, 0.f, 0.f, 0.f};
                 for (int which = 0; which < (fullrr ? 2 : 1); ++which) {
-                    const float *src = (which ? XB : XA) + (int64_t)r * kChP;
+                    const float *src = (which ? XB : XA) + (int64_t)r * P;
                     float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll 1
-                    for (int half = 0; half < 2; ++half) {               // half a row (8 x 16 bytes) in flight at once
-                        float4 rowv[kChP / 8];
+                    for (int half = 0; half < P / 32; ++half) {          // 32 columns (8 x 16 bytes) in flight at once
+                        float4 rowv[8];
 #pragma unroll
-                        for (int p = 0; p < kChP / 8; ++p) rowv[p] = *(const float4 *)(src + 32 * half + 4 * p);
+                        for (int p = 0; p < 8; ++p) rowv[p] = *(const float4 *)(src + 32 * half + 4 * p);
 #pragma unroll
-                        for (int p = 0; p < kChP / 8; ++p) {
+                        for (int p = 0; p < 8; ++p) {
                             const float4 rv = rowv[p];
                             const float xs[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
-                                const float4 cv = *(const float4 *)(Af + (32 * half + 4 * p + u) * kChP + q4);
+                                const float4 cv = *(const float4 *)(Af + (32 * half + 4 * p + u) * P + q4);
                                 o0 = fmaf(xs[u], cv.x, o0); o1 = fmaf(xs[u], cv.y, o1);
                                 o2 = fmaf(xs[u], cv.z, o2); o3 = fmaf(xs[u], cv.w, o3);
                             }
@@ -2856,7 +2954,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
                     if (which) {                                         // the rotated W is only needed for the residual
                         wn[0] = o0; wn[1] = o1; wn[2] = o2; wn[3] = o3;
                     } else {
-                        *(float4 *)(XC + (int64_t)r * kChP + q4) = make_float4(o0, o1, o2, o3);
+                        *(float4 *)(XC + (int64_t)r * P + q4) = make_float4(o0, o1, o2, o3);
                         xn[0] = o0; xn[1] = o1; xn[2] = o2; xn[3] = o3;
                     }
                 }
@@ -2866,11 +2964,11 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             __syncthreads();
             { float *t = XA; XA = XC; XC = t; }                          // block-uniform: the rotated block is X now
             if (fullrr) {
-                *(float4 *)(slab + g16 * kChP + q4) = make_float4(r0, r1, r2, r3);     // 64 groups x 64 columns
+                *(float4 *)(slab + g16 * P + q4) = make_float4(r0, r1, r2, r3);     // (1024 / TPQ) groups x P columns = 4096 floats
                 __syncthreads();
-                if (tid < kChP) {
+                if (tid < P) {
                     float sres = 0.f;
-                    for (int g = 0; g < kChThreads / 16; ++g) sres += slab[g * kChP + tid];
+                    for (int g = 0; g < kChThreads / TPQ; ++g) sres += slab[g * P + tid];
                     resid[tid] = sqrtf(sres);
                 }
                 __syncthreads();
@@ -2879,15 +2977,15 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
 #ifdef GCC_AMD_HIPEMU
         if (getenv("GCC_POSEMB_DEBUG") && tid == 0) {
             double worst_off = 0, dmin = 1e9, dmax2 = 0, wmax = 0;
-            for (int i = 0; i < kChP; ++i)
+            for (int i = 0; i < P; ++i)
                 for (int j = 0; j <= i; ++j) {
                     double sdot = 0;
-                    for (int r = 0; r < nr; ++r) sdot += (double)XA[(int64_t)r * kChP + i] * XA[(int64_t)r * kChP + j];
+                    for (int r = 0; r < nr; ++r) sdot += (double)XA[(int64_t)r * P + i] * XA[(int64_t)r * P + j];
                     if (i == j) { dmin = sdot < dmin ? sdot : dmin; dmax2 = sdot > dmax2 ? sdot : dmax2; }
                     else worst_off = fabs(sdot) > worst_off ? fabs(sdot) : worst_off;
                 }
-            for (int i = 0; i < kChP; ++i) { double sw = 0; for (int r = 0; r < nr; ++r) sw += (double)XB[(int64_t)r * kChP + i] * XB[(int64_t)r * kChP + i]; wmax = sw > wmax ? sw : wmax; }
-            fprintf(stderr, "cheb gram-after-rotate round=%d rr=%d: diag [%g, %g] offdiag %g  max|W col|^2 %g\n", round, (int)rr, dmin, dmax2, worst_off, wmax);
+            for (int i = 0; i < P; ++i) { double sw = 0; for (int r = 0; r < nr; ++r) sw += (double)XB[(int64_t)r * P + i] * XB[(int64_t)r * P + i]; wmax = sw > wmax ? sw : wmax; }
+            fprintf(stderr, "cheb gram-after-rotate round=%d rr=%d P=%d deg=%d: diag [%g, %g] offdiag %g  max|W col|^2 %g\n", round, (int)rr, P, deg, dmin, dmax2, worst_off, wmax);
         }
         __syncthreads();
 #endif
@@ -2905,6 +3003,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
                 for (int j = 0; j < kq; ++j) if (theta[j] >= kStalkEig - 1e-3f) nge = j + 1;
                 kw = max(max(nge, min(kq, k - zp)), 1);
             }
+            if (P < kChPWide && kw > P - kChNarrowGuards) return 2;   // block-uniform: more wanted pairs than the narrow block's guards allow
             float worst = 0.1f;                                  // (values only: nothing measured yet)
             if (fullrr) {
                 worst = 0.f;
@@ -2912,12 +3011,12 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             }
 #ifdef GCC_AMD_HIPEMU
             if (getenv("GCC_POSEMB_DEBUG") && tid == 0)
-                fprintf(stderr, "cheb b=%d n=%d nr=%d zp=%d round=%d deg=%d cut=%.4f worst=%.2e kw=%d theta[kw-1]=%.5f theta[63]=%.5f\n", b, n, nr, zp, round,
-                        deg, cut, worst, kw, theta[kw - 1], theta[kChP - 1]);
+                fprintf(stderr, "cheb b=%d n=%d nr=%d zp=%d round=%d deg=%d cut=%.4f worst=%.2e kw=%d theta[kw-1]=%.5f theta[P-1]=%.5f\n", b, n, nr, zp, round,
+                        deg, cut, worst, kw, theta[kw - 1], theta[P - 1]);
 #endif
             if (fullrr && worst <= kChTol) { converged = true; ++round; break; }
             if (nrr >= kChMaxRitz) break;
-            cut = fminf(fmaxf(theta[kChP - 1] - 0.02f, -0.9f), 0.9f);
+            cut = fminf(fmaxf(theta[P - 1] - 0.02f, -0.9f), 0.9f);
             const float e = 0.5f * (cut + 1.0f), cen = 0.5f * (cut - 1.0f);
             const float xk = fmaxf((theta[kw - 1] - cen) / e, 1.0001f);
             const float rate = logf(xk + sqrtf(xk * xk - 1.0f));        // the wanted end grows by exp(rate) per degree
@@ -2967,7 +3066,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             for (int i = tid; i < n * a.hidden; i += kChThreads) a.pos[(int64_t)n0 * a.hidden + i] = 0.f;
             if (a.evals) for (int i = tid; i < a.hidden; i += kChThreads) a.evals[(int64_t)b * a.hidden + i] = 0.f;
         }
-        continue;
+        return 0;
     }
     // ---- eigenvalues ascending like eigsh(which="LA") (data_util.py:251); expand to the n original nodes;
     //      x = normalize(u, "l2") row-wise, zero padded (data_util.py:260-262)
@@ -2977,7 +3076,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     }
     for (int v = wv; v < n; v += kNW) {
         const int rsrc = xrec[4 * v], o = xrec[4 * v + 1], g = xrec[4 * v + 2], cb = xrec[4 * v + 3];
-        const float val = lane < k ? defl_expand(rsrc, o, g, cb, colsrc[lane], XA, kChP) : 0.f;
+        const float val = lane < k ? defl_expand(rsrc, o, g, cb, colsrc[lane], XA, P) : 0.f;
         const float s2 = wave_sum(val * val);
         const float inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
         if (lane < a.hidden) {
@@ -2988,6 +3087,16 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     PHASE_TICK(4);                                               // expansion
     if (m.ticks && tid == 0) atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 14], flops);
     if (tid == 0) atomicMax(a.status + 1, round);                // diagnostics: most filter rounds of an item
+    return 0;
+    };   // solve
+    // the narrow block where the quotient has to deliver few pairs (k - zp: known once the stalks are counted)
+    const int want = max(min(kq, k - zp), 1);
+    int rc = 2;
+    if (!(hd.use_cheb & 2) && want <= kChNarrowWant) rc = solve(std::integral_constant<int, kChPNarrow>());
+    if (rc == 2) {
+        __syncthreads();
+        solve(std::integral_constant<int, kChPWide>());
+    }
     }   // next item
 }
 
@@ -3114,7 +3223,7 @@ int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, 
     hd.ldv = (int32_t)posemb_ldv(batch_size, node_cap);
     {
         const char *e = getenv("GCC_POSEMB_CHEB");
-        hd.use_cheb = e ? atoi(e) != 0 : 1;
+        hd.use_cheb = e ? atoi(e) : 1;             // 0: dense classes only, 1: on; A/B knobs, OR-ed in: 2 = the wide block only, 4 = the filter through L2 (7 = rounds 2-4)
         const char *ew = getenv("GCC_POSEMB_WAVE");   // 0: the 256-thread small class takes every n' <= 64 (A/B runs)
         hd.use_wave = ew ? atoi(ew) != 0 : 1;
         const char *es = getenv("GCC_POSEMB_STALKS");  // 0: twin leaves only (A/B runs)

@@ -1331,7 +1331,10 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     if (g_dbg_grids[1] > 0 && g_dbg_grids[1] < w.nbig) w.nbig = g_dbg_grids[1];          //  through several virtual workgroups / subgraphs /
     if (g_dbg_grids[2] > 0 && g_dbg_grids[2] < walk_big_grid) walk_big_grid = g_dbg_grids[2];   //  list entries)
     // rows of at least this degree are not scanned (kMaxHub per subgraph): hub_degree 0 = default, < 0 = scan everything
-    const int32_t hub_degree = p->hub_degree == 0 ? kHubDegreeDefault : (p->hub_degree < 0 ? 0x7FFFFFFF : p->hub_degree);
+    // (hub rows are rebuilt from mirror images: exact on a symmetric, sorted, duplicate- and loop-free parent only, so the
+    //  short cut needs the caller's word that the contract was checked -- gcc_graph.flags; without it every row is scanned)
+    const bool contract = (g->flags & GCC_GRAPH_CONTRACT_CHECKED) != 0;
+    const int32_t hub_degree = (p->hub_degree < 0 || !contract) ? 0x7FFFFFFF : (p->hub_degree == 0 ? kHubDegreeDefault : p->hub_degree);
     const int32_t max_hubs = p->max_hubs <= 0 ? kMaxHubsDefault : (p->max_hubs > kMaxHub ? kMaxHub : p->max_hubs);
     if (lds1b > 160 * 1024 || lds2 > 160 * 1024 - 256) {
         snprintf(g_err, kErrLen, "gcc_sample_multi: lmax=%d / batch too large for 160 KiB of LDS", g->lmax);

@@ -59,13 +59,18 @@ class DeviceGraph:
 
     def __init__(self, row_ptr: np.ndarray, col_idx: np.ndarray, rw_hops: int = 256,
                  restart_prob: float = 0.8, device="cuda", validate: bool = True, ltab: np.ndarray = None,
-                 shard_off=None):
+                 shard_off=None, trusted: bool = False):
+        """``validate``: check the input contract (x2dgl.py:39-62) on the host before the upload.  ``trusted``: the caller
+        vouches for the contract without the check (graphs of gcc_amd.graphgen, whose generator builds to it).  With
+        neither, the graph carries no GCC_GRAPH_CONTRACT_CHECKED bit and the induction scans every member row (the hub-row
+        short cut of gcc_sample_params.hub_degree is exact on a symmetric, sorted, duplicate- and loop-free parent only)."""
         import torch
 
         row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
         col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
         if validate:
             check_contract(row_ptr, col_idx)
+        self.contract_checked = bool(validate or trusted)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DeviceGraph lives in HBM; device must be a HIP/CUDA device")
@@ -101,7 +106,8 @@ class DeviceGraph:
             seed_cdf=self.seed_cdf.data_ptr(), ltab=self.ltab.data_ptr(),
             num_nodes=self.num_nodes, num_edges=self.num_edges,
             ltab_len=int(ltab.shape[0]), lmax=self.lmax,
-            shard_off=self.shard_off.data_ptr() if self.shard_off is not None else None, num_shards=self.num_shards)
+            shard_off=self.shard_off.data_ptr() if self.shard_off is not None else None, num_shards=self.num_shards,
+            flags=_cabi.GRAPH_CONTRACT_CHECKED if self.contract_checked else 0)
 
     def byref(self):
         return ctypes.byref(self.c)

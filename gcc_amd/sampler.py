@@ -154,8 +154,8 @@ class DeviceRWRSampler:
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.regrown = 0                   # times grow() enlarged the scratch / edge capacity after an overflow
         self._retired = []                 # replaced buffers stay alive: launches in flight on other streams may still use them
-        self._snap = None                  # pinned host mirror of the status word, one slot per snapshot in flight
-        self._snap_next = 0
+        self._snap = None                  # pinned host words of the status snapshots in flight (status_snapshot)
+        self._snap_free = []
         self._alloc_workspace()
         i32 = dict(dtype=torch.int32, device=dev)
         self._ring = []
@@ -250,14 +250,21 @@ class DeviceRWRSampler:
     # ---- overflow -> regrow -> re-sample (instead of killing a multi-hour run at the next log line)
     def status_snapshot(self):
         """Enqueue, on the current stream, a copy of the status word into pinned host memory followed by its reset:
-        the word the token reads back covers exactly the calls issued since the previous snapshot.  -> token."""
+        the word the token reads back covers exactly the calls issued since the previous snapshot.  -> token.
+        Every snapshot in flight owns its own pinned word (a free list that grows on demand: a producer with many chunks
+        in flight, or repeated re-issues, can never have a word overwritten before it was read); :meth:`read_snapshot`
+        hands the word back."""
         import torch
 
         if self._snap is None:
-            self._snap = torch.zeros(16, dtype=torch.int32).pin_memory()
-        i = self._snap_next
-        self._snap_next = (i + 1) % self._snap.numel()
-        self._snap[i:i + 1].copy_(self.status, non_blocking=True)
+            self._snap, self._snap_free = [], []
+        if not self._snap_free:
+            block = torch.zeros(16, dtype=torch.int32).pin_memory()
+            base = len(self._snap)
+            self._snap.extend(block[i:i + 1] for i in range(16))
+            self._snap_free.extend(range(base + 15, base - 1, -1))
+        i = self._snap_free.pop()
+        self._snap[i].copy_(self.status, non_blocking=True)
         self.status.zero_()
         return i
 
@@ -269,8 +276,10 @@ class DeviceRWRSampler:
 
     def read_snapshot(self, token) -> int:
         """The status bits of a snapshot whose stream work has completed (the caller synchronised on an event recorded
-        after :meth:`status_snapshot`)."""
-        return int(self._snap[token])
+        after :meth:`status_snapshot`); the token's word returns to the free list (read a token once)."""
+        bits = int(self._snap[token])
+        self._snap_free.append(token)
+        return bits
 
     def grow(self, bits: int, factor: int = 4, limit_bytes: int = 64 << 30) -> None:
         """Enlarge what overflowed: the induction scratch (bit 1; the workspace is re-allocated) and / or the edge

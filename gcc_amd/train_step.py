@@ -213,22 +213,23 @@ class BatchProducer:
             if self.next_chunk not in self.ready:
                 self._launch(self.next_chunk)
             self.next_chunk += 1
-        for _ in range(4):                       # overflow -> grow -> re-sample, at most a few times
+        attempts = 0
+        while c in self.snap:                    # overflow -> grow -> re-sample, at most a few times
             pairs, ev = self.ready[c]
-            if c not in self.snap:
-                break
             sampler = self.lanes[c % len(self.lanes)][0]
             if ev is not None:
-                ev.synchronize()                 # the chunk was launched `ahead` chunks ago: normally long complete
+                if not ev.query():               # the chunk was launched `ahead` chunks ago: normally long complete, and a
+                    ev.synchronize()             # completed event costs one poll instead of a blocking call
             elif hasattr(sampler, "snapshot_sync"):
                 sampler.snapshot_sync()          # produced on the current stream (prefetch off): wait for it
             bits = sampler.read_snapshot(self.snap[c][0])
             if not bits:
                 self.snap.pop(c)
                 break
+            if attempts == 4:                    # (the word just read is the LAST re-issue's: it really still overflows)
+                raise RuntimeError(f"sampler overflow persists after growing {attempts} times (chunk {c})")
             self._reproduce(c, bits)
-        else:
-            raise RuntimeError(f"sampler overflow persists after growing {self.regrown} times (chunk {c})")
+            attempts += 1
         pairs, ev = self.ready[c]
         if ev is not None:
             torch.cuda.current_stream(self.dev).wait_event(ev)
@@ -320,9 +321,15 @@ class _GraphedStep:
         self.relaxed_streams = False        # see step(): drop the per-step stream hand-offs (bench.py / train.py loops)
         self._joined_caller = False
         self.use_scalars = False            # kernels read lr / ring pointer / dropout key from self.scalars (tests: eager)
-        self.use_graph = bool(self.prefetch and not self.collectives) if graph is None else bool(graph)
-        if self.use_graph and (self.dev.type != "cuda" or self.collectives):
-            raise ValueError("graph replay needs a device and no collectives inside the step")
+        # default: on with prefetch on a device.  With collectives the step is replayed as SEGMENTS (captured graphs around
+        # the RCCL calls, which stay eager launches on RCCL's own stream): the multi-GPU step takes the benchmarked launch path
+        self.use_graph = bool(self.prefetch) if graph is None else bool(graph)
+        if self.use_graph and self.collectives and self._staged_possible():
+            if graph:
+                raise ValueError("graph replay with collectives needs RCCL on device buffers (not the gloo staging path)")
+            self.use_graph = False
+        if self.use_graph and self.dev.type != "cuda":
+            raise ValueError("graph replay needs a device")
         if self.use_graph and self.main is None:
             self.main = torch.cuda.Stream(self.dev, priority=-1)        # stream capture cannot run on the default stream
         self.scalars = torch.zeros(24, dtype=torch.uint8, device=self.dev)      # sizeof(gcc_step_scalars)
@@ -333,8 +340,15 @@ class _GraphedStep:
         self.ring_count = 0                                                    # host's count of ring steps
         self.ring_counter = torch.zeros(1, dtype=torch.int64, device=self.dev)  # the device's
         self._ring_events = []                                                  # (count, event): run-ahead guard
-        self.graphs = {}                    # ring-slot key -> (CUDAGraph, outs of the captured step)
+        self._ring_dirty = False            # a step raised between the host's and the device's count: re-aligned at the next step
+        self.graphs = {}                    # ring-slot key -> (segments [(CUDAGraph | eager callable)], outs of the captured step)
+        self._graphs_regrown = 0            # producer.regrown the cached graphs were captured under
+        self._retired_graphs = []
         self.graph_replays = 0
+
+    def _staged_possible(self):
+        return bool(torch.distributed.is_available() and torch.distributed.is_initialized()
+                    and torch.distributed.get_backend() == "gloo")
 
     def _slot_key(self, q, k):
         return tuple(t.data_ptr() for g in (q, k) for t in (g.node_off, g.edge_off, g.row_ptr, g.col_idx, g.graph_id,
@@ -354,39 +368,78 @@ class _GraphedStep:
         while self._ring_events and self._ring_events[0][0] <= n - (self.ring_len * 3) // 4:
             self._ring_events.pop(0)[1].synchronize()
 
+    @staticmethod
+    def _run_segments(body_out):
+        """``body_out`` = (segments, result): segments [(capturable, fn)] issued in order on the current stream."""
+        segments, result = body_out
+        for _, fn in segments:
+            fn()
+        return result()
+
     def _run_step(self, q, k, lr, seed, enqueue_index, explicit_masks, pr, st, body):
-        """``body(scalars, pr) -> dict(loss, prob, grad_norm)`` issues the step's launches on the current stream.  Eager when
-        dropout masks are injected or the caller wants in-step event marks; otherwise the slot's graph is replayed (captured
-        after the slot's first eager step: capture records the launches without executing them)."""
+        """``body(scalars, pr) -> (segments, result)``: ``segments`` = [(capturable, fn)] whose ``fn()`` issue the step's
+        launches on the current stream, ``result() -> dict(loss, prob, grad_norm)``.  Eager when dropout masks are injected or
+        the caller wants in-step event marks; otherwise the slot's graphs are replayed (captured after the slot's first eager
+        step: capture records the launches without executing them).  A step without collectives is ONE capturable segment;
+        with collectives the RCCL calls are segments of their own that stay eager (issued between the graph launches)."""
         step_marks = any(n in pr for n in ("gin_fwd", "nce_fwd", "nce_bwd", "gin_bwd"))
         graphed = self.use_graph and not explicit_masks and not step_marks
         scalars = self.scalars if (graphed or self.use_scalars) and not explicit_masks else None
-        if scalars is not None:
-            g0 = self.optimizer.param_groups[0]
-            self._ring_guard()
-            self.nce.fill_scalars(self.ring, self.ring_count % self.ring_len, lr, g0["betas"], self.optimizer.steps + 1,
-                                  enqueue_index, seed or 0)
-            self.ring_count += 1
-        if not graphed:
-            return body(scalars, pr)
-        key = self._slot_key(q, k)
-        hit = self.graphs.get(key)
-        if hit is not None:                                          # replay: one launch for the whole step
-            hit[0].replay()
-            self.optimizer.steps += 1
-            self.graph_replays += 1
-            return dict(hit[1])
-        out = body(scalars, pr)                                      # first time this ring slot is consumed: eager ...
-        gobj = torch.cuda.CUDAGraph()
-        steps0 = self.optimizer.steps
-        gobj.capture_begin(capture_error_mode="thread_local")        # ... then captured for the next time
+        if self._ring_dirty:
+            # an earlier step raised somewhere between the host's ring count and the device's fetch: put them back in step
+            torch.cuda.synchronize(self.dev)
+            self.ring_counter.fill_(self.ring_count)
+            self._ring_dirty = False
+        regrown = getattr(getattr(self, "producer", None), "regrown", 0)
+        if regrown != self._graphs_regrown:
+            # an edge-capacity regrow replaced every ring slot's col_idx: every key changed, the graphs captured over the
+            # retired buffers are never replayed again.  They are dropped one regrow later (launches of theirs may be in flight).
+            self._retired_graphs = list(self.graphs.values())
+            self.graphs = {}
+            self._graphs_regrown = regrown
         try:
-            cap = body(scalars, {})
-        finally:
-            gobj.capture_end()
-        self.optimizer.steps = steps0                                # the captured body counted a step that did not run
-        self.graphs[key] = (gobj, dict(loss=cap["loss"], prob=cap["prob"], grad_norm=cap["grad_norm"]))
-        return out
+            if scalars is not None:
+                g0 = self.optimizer.param_groups[0]
+                self._ring_guard()
+                self.nce.fill_scalars(self.ring, self.ring_count % self.ring_len, lr, g0["betas"], self.optimizer.steps + 1,
+                                      enqueue_index, seed or 0)
+                self.ring_count += 1
+            if not graphed:
+                return self._run_segments(body(scalars, pr))
+            key = self._slot_key(q, k)
+            hit = self.graphs.get(key)
+            if hit is not None:                                          # replay: one launch per segment
+                for item in hit[0]:
+                    if isinstance(item, torch.cuda.CUDAGraph):
+                        item.replay()
+                    else:
+                        item()
+                self.optimizer.steps += 1
+                self.graph_replays += 1
+                return dict(hit[1])
+            out = self._run_segments(body(scalars, pr))                  # first time this ring slot is consumed: eager ...
+            steps0 = self.optimizer.steps
+            segments, result = body(scalars, {})                         # ... then captured for the next time
+            items, pool = [], None
+            for capturable, fn in segments:
+                if not capturable:
+                    items.append(fn)                                     # (collectives: not run now, issued at every replay)
+                    continue
+                gobj = torch.cuda.CUDAGraph()
+                gobj.capture_begin(capture_error_mode="thread_local", **({} if pool is None else dict(pool=pool)))
+                try:
+                    fn()
+                finally:
+                    gobj.capture_end()
+                pool = pool or gobj.pool()                               # later segments read what earlier ones allocated
+                items.append(gobj)
+            cap = result()
+            self.optimizer.steps = steps0                                # the captured body counted a step that did not run
+            self.graphs[key] = (items, dict(loss=cap["loss"], prob=cap["prob"], grad_norm=cap["grad_norm"]))
+            return out
+        except Exception:
+            self._ring_dirty = scalars is not None
+            raise
 
     def _fetch_scalars(self, scalars, st):
         """first launch of a step that uses the device-resident scalars: this step's ring entry -> the device struct"""
@@ -566,40 +619,61 @@ class MoCoTrainStep(_GraphedStep):
         return dict(out, graph_q=q, graph_k=k)
 
     def _body(self, q, k, keep, seed, scalars, pr, st):
-        """The launches of one step on the current stream (eager, or under stream capture).  ``scalars``: device
-        gcc_step_scalars the Adam / enqueue / dropout kernels read instead of by-value arguments."""
-        self._fetch_scalars(scalars, st)
-        # (with scalars the by-value seed is an addend to the device-resident one: 0 here)
-        pq, bufq = self.gin.make_pass(self.model, q, training=True, keep=keep, slot=("step", 0),
-                                      dropout_seed=(0 if seed is not None else None) if scalars is not None else seed,
-                                      scalars=scalars)
-        pk, bufk = self.gin.make_pass(self.ema, k, training=True, keep=None, slot=("step", 1))
-        self.gin.forward([pq, pk], stream=st, prof=pr.get("gin_fwd"))      # train.py:389-391
-        feat_q, feat_k = bufq["feat"], bufk["feat"]
+        """The launches of one step on the current stream as (segments, result) for :meth:`_run_step` (eager, or under stream
+        capture).  ``scalars``: device gcc_step_scalars the Adam / enqueue / dropout kernels read instead of by-value
+        arguments.  Without collectives the step is one capturable segment; with them:
+            forward (q, k)  |  key all-gather begins (RCCL, own stream)  |  head fwd + bwd, encoder bwd  |
+            gradient all-reduce, all-gather joined  |  clip + Adam + EMA + meters, enqueue
+        -- three captured graphs with the two RCCL hand-offs issued between their launches."""
+        S = {}
         c = self.contrast
-        gathering = self._all_gather_begin(self.keys_all, feat_k) if self.collectives else None   # RCCL, overlapped
-        outs = self.nce.forward(feat_q, feat_k, c.kernel_memory(), c.T, 0, stream=st, prof=pr.get("nce_fwd"))   # train.py:393,407
-        # The enqueue (memory_moco.py:55-61) is the LAST thing the step does with the queue: logits and their backward
-        # are taken against the queue before the update (the reference clones it, memory_moco.py:31), so deferring the
-        # update is the same computation -- and it takes the key all-gather off the critical chain.
-        dq = self.nce.backward(feat_q, feat_k, c.kernel_memory(), c.T, 0, outs, self.one, stream=st,
-                               prof=pr.get("nce_bwd"))                    # loss.backward(), train.py:408
-        self.gin.backward(self.model, pq, bufq, dq, targets=self.grad_views, stream=st, prof=pr.get("gin_bwd"))
-        if self.collectives:
+
+        def fwd():
+            self._fetch_scalars(scalars, st)
+            # (with scalars the by-value seed is an addend to the device-resident one: 0 here)
+            S["pq"], S["bufq"] = self.gin.make_pass(self.model, q, training=True, keep=keep, slot=("step", 0),
+                                                    dropout_seed=(0 if seed is not None else None) if scalars is not None else seed,
+                                                    scalars=scalars)
+            S["pk"], S["bufk"] = self.gin.make_pass(self.ema, k, training=True, keep=None, slot=("step", 1))
+            self.gin.forward([S["pq"], S["pk"]], stream=st, prof=pr.get("gin_fwd"))      # train.py:389-391
+
+        def gather_begin():                    # RCCL, overlapped with everything up to the enqueue
+            S["gathering"] = self._all_gather_begin(self.keys_all, S["bufk"]["feat"])
+
+        def head_and_backward():
+            feat_q, feat_k = S["bufq"]["feat"], S["bufk"]["feat"]
+            S["outs"] = self.nce.forward(feat_q, feat_k, c.kernel_memory(), c.T, 0, stream=st, prof=pr.get("nce_fwd"))   # train.py:393,407
+            # The enqueue (memory_moco.py:55-61) is the LAST thing the step does with the queue: logits and their backward
+            # are taken against the queue before the update (the reference clones it, memory_moco.py:31), so deferring the
+            # update is the same computation -- and it takes the key all-gather off the critical chain.
+            dq = self.nce.backward(feat_q, feat_k, c.kernel_memory(), c.T, 0, S["outs"], self.one, stream=st,
+                                   prof=pr.get("nce_bwd"))                    # loss.backward(), train.py:408
+            self.gin.backward(self.model, S["pq"], S["bufq"], dq, targets=self.grad_views, stream=st, prof=pr.get("gin_bwd"))
+
+        def reduce_and_join():
             self._all_reduce(self.flat_grad)                             # SUM of one flat bucket (248 KiB) over xGMI
-        # clip (train.py:409) + Adam (train.py:417); the mean over ranks is folded into the two launches
-        # ... moment_update (train.py:430-431) and train.py:418-428's meters ride in the Adam launch: the meters read
-        # this batch's offsets BEFORE its ring slot is handed back
-        gnorm = self.optimizer.step(grad_scale=1.0 / self.world if self.collectives else 1.0,
-                                    ema=self.flat_ema, ema_src=self.flat, ema_m=self.alpha,
-                                    meters=(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], q, k),
-                                    scalars=scalars)
-        keys = feat_k
+            self._all_gather_end(S["gathering"])
+
+        def update():
+            # clip (train.py:409) + Adam (train.py:417); the mean over ranks is folded into the two launches
+            # ... moment_update (train.py:430-431) and train.py:418-428's meters ride in the Adam launch: the meters read
+            # this batch's offsets BEFORE its ring slot is handed back
+            outs = S["outs"]
+            S["gnorm"] = self.optimizer.step(grad_scale=1.0 / self.world if self.collectives else 1.0,
+                                             ema=self.flat_ema, ema_src=self.flat, ema_m=self.alpha,
+                                             meters=(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], q, k),
+                                             scalars=scalars)
+            keys = self.keys_all if self.collectives else S["bufk"]["feat"]
+            self.nce.enqueue(c.kernel_memory(), keys, c.index, save=False, stream=st, scalars=scalars)
+
+        def result():
+            return dict(loss=S["outs"]["loss"], prob=S["outs"]["prob"], grad_norm=S["gnorm"])
+
         if self.collectives:
-            self._all_gather_end(gathering)
-            keys = self.keys_all
-        self.nce.enqueue(c.kernel_memory(), keys, c.index, save=False, stream=st, scalars=scalars)
-        return dict(loss=outs["loss"], prob=outs["prob"], grad_norm=gnorm)
+            segments = [(True, fwd), (False, gather_begin), (True, head_and_backward), (False, reduce_and_join), (True, update)]
+        else:
+            segments = [(True, lambda: (fwd(), head_and_backward(), update()))]
+        return segments, result
 
 
 class E2ETrainStep(_GraphedStep):
@@ -669,27 +743,32 @@ class E2ETrainStep(_GraphedStep):
         return dict(out, graph_q=q, graph_k=k)
 
     def _body(self, q, k, keep_q, keep_k, s0, scalars, pr, st):
-        self._fetch_scalars(scalars, st)
-        # the k pass's dropout key is the q pass's + the golden-ratio increment; with device-resident scalars the by-value
-        # seed of a pass is its addend to the device's (gcc_gin_pass.scalars)
-        G = 0x9E3779B97F4A7C15
-        if s0 is None:
-            sq = sk = None
-        elif scalars is not None:
-            sq, sk = 0, G
-        else:
-            sq, sk = s0, (s0 + G) & 0xFFFFFFFFFFFFFFFF
-        pq, bufq = self.gin.make_pass(self.model, q, training=True, keep=keep_q, slot=("e2e", 0), dropout_seed=sq, scalars=scalars)
-        pk, bufk = self.gin.make_pass(self.model, k, training=True, keep=keep_k, slot=("e2e", 1), dropout_seed=sk, scalars=scalars)
-        self.gin.forward([pq], stream=st, prof=pr.get("gin_fwd"))          # feat_q = model(graph_q), train.py:397
-        self.gin.forward([pk], stream=st)                                  # feat_k = model(graph_k), train.py:398
-        feat_q, feat_k = bufq["feat"], bufk["feat"]
-        # out = feat_k feat_q^T / T, CE against arange (train.py:400, criterions.py:27-33): rows = feat_k
-        outs = self.nce.forward(feat_k, None, feat_q, self.T, 1, stream=st, prof=pr.get("nce_fwd"))
-        dk = self.nce.backward(feat_k, None, feat_q, self.T, 1, outs, self.one, stream=st, prof=pr.get("nce_bwd"))
-        dq = self.nce.backward(feat_q, None, feat_k, self.T, 1, outs, self.one, by_mem_row=True, stream=st)
-        self.gin.backward(self.model, pq, bufq, dq, targets=self.grad_views, stream=st, prof=pr.get("gin_bwd"))
-        self.gin.backward(self.model, pk, bufk, dk, targets=self.grad_views, accumulate=True, stream=st)
-        # clip (train.py:409) + Adam (train.py:417), train.py:418-428's meters inside the Adam launch
-        gnorm = self.optimizer.step(meters=(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], q, k), scalars=scalars)
-        return dict(loss=outs["loss"], prob=outs["prob"], grad_norm=gnorm)
+        S = {}
+
+        def whole():
+            self._fetch_scalars(scalars, st)
+            # the k pass's dropout key is the q pass's + the golden-ratio increment; with device-resident scalars the by-value
+            # seed of a pass is its addend to the device's (gcc_gin_pass.scalars)
+            G = 0x9E3779B97F4A7C15
+            if s0 is None:
+                sq = sk = None
+            elif scalars is not None:
+                sq, sk = 0, G
+            else:
+                sq, sk = s0, (s0 + G) & 0xFFFFFFFFFFFFFFFF
+            pq, bufq = self.gin.make_pass(self.model, q, training=True, keep=keep_q, slot=("e2e", 0), dropout_seed=sq, scalars=scalars)
+            pk, bufk = self.gin.make_pass(self.model, k, training=True, keep=keep_k, slot=("e2e", 1), dropout_seed=sk, scalars=scalars)
+            self.gin.forward([pq], stream=st, prof=pr.get("gin_fwd"))          # feat_q = model(graph_q), train.py:397
+            self.gin.forward([pk], stream=st)                                  # feat_k = model(graph_k), train.py:398
+            feat_q, feat_k = bufq["feat"], bufk["feat"]
+            # out = feat_k feat_q^T / T, CE against arange (train.py:400, criterions.py:27-33): rows = feat_k
+            outs = self.nce.forward(feat_k, None, feat_q, self.T, 1, stream=st, prof=pr.get("nce_fwd"))
+            dk = self.nce.backward(feat_k, None, feat_q, self.T, 1, outs, self.one, stream=st, prof=pr.get("nce_bwd"))
+            dq = self.nce.backward(feat_q, None, feat_k, self.T, 1, outs, self.one, by_mem_row=True, stream=st)
+            self.gin.backward(self.model, pq, bufq, dq, targets=self.grad_views, stream=st, prof=pr.get("gin_bwd"))
+            self.gin.backward(self.model, pk, bufk, dk, targets=self.grad_views, accumulate=True, stream=st)
+            # clip (train.py:409) + Adam (train.py:417), train.py:418-428's meters inside the Adam launch
+            gnorm = self.optimizer.step(meters=(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], q, k), scalars=scalars)
+            S.update(loss=outs["loss"], prob=outs["prob"], grad_norm=gnorm)
+
+        return [(True, whole)], lambda: dict(S)

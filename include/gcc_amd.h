@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define GCC_AMD_ABI_VERSION 1
+/* 2: gcc_sample_params.{hub_degree,max_hubs}, gcc_gin_weights.hidden, gcc_gin_pass.scalars, gcc_ginw_args.{scratch,
+ * scratch_bytes,num_nodes}, gcc_graph.flags.  A caller built against another version must not pass its structs:
+ * compare gcc_abi_version() with the header's constant after loading (gcc_amd/_cabi.py does). */
+#define GCC_AMD_ABI_VERSION 2
 
 /* bits of the device status word */
 #define GCC_STATUS_SCRATCH_OVERFLOW 1  /* induction scratch too small            */
@@ -85,8 +88,13 @@ typedef struct gcc_graph {
      * draws its seeds from shard i % num_shards only.  num_shards <= 1 (shard_off may be NULL): one shard = all. */
     const int64_t *shard_off; /* device [num_shards + 1] or NULL                      */
     int32_t num_shards;
-    int32_t reserved_;
+    int32_t flags;            /* GCC_GRAPH_* bits                                     */
 } gcc_graph;
+/* The caller has verified the contract above (symmetric, rows sorted ascending, no self loops, no duplicates).  Only
+ * then may the induction skip hub rows (gcc_sample_params.hub_degree >= 0): their induced rows are rebuilt as mirror
+ * images of the other rows' hits, which is the DGL-consistent subgraph on such a graph only.  Without the bit every
+ * member row is scanned whatever hub_degree says (the result is then the induced subgraph of ANY sorted-row CSR). */
+#define GCC_GRAPH_CONTRACT_CHECKED 1
 
 /* --------------------------------------------------------------- sampler ---
  * One call = one DataLoader batch of LoadBalanceGraphDataset

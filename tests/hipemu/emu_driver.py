@@ -35,7 +35,7 @@ def _p(a):
 
 
 class EmuGraph:
-    def __init__(self, row_ptr, col_idx, rw_hops=256, restart_prob=0.8, ltab=None, shard_off=None):
+    def __init__(self, row_ptr, col_idx, rw_hops=256, restart_prob=0.8, ltab=None, shard_off=None, contract_checked=True):
         self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
         self.col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
         self.shard_off = np.ascontiguousarray(shard_off, dtype=np.int64) if shard_off is not None else None
@@ -49,7 +49,8 @@ class EmuGraph:
         self.c = _cabi.GccGraph(row_ptr=_p(self.row_ptr), col_idx=_p(self.col_idx), seed_cdf=_p(self.cdf),
                                 ltab=_p(self.ltab), num_nodes=len(self.row_ptr) - 1,
                                 num_edges=len(self.col_idx), ltab_len=len(self.ltab), lmax=self.lmax,
-                                shard_off=_p(self.shard_off), num_shards=len(self.shard_off) - 1 if shard_off is not None else 0)
+                                shard_off=_p(self.shard_off), num_shards=len(self.shard_off) - 1 if shard_off is not None else 0,
+                                flags=_cabi.GRAPH_CONTRACT_CHECKED if contract_checked else 0)
 
 
 def emu_sample_batch(g: EmuGraph, B, run_seed, first_sample_id, seeds=None, edge_cap=None,

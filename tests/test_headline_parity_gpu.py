@@ -23,7 +23,7 @@ def _g1():
         from gcc_amd.graphgen import powerlaw_graph
 
         rp, ci = powerlaw_graph(1_000_000, 10_000_000, seed=0)
-        _G1.update(rp=rp, ci=ci, graph=DeviceGraph(rp, ci, rw_hops=HOPS, restart_prob=RESTART, device="cuda:0", validate=False))
+        _G1.update(rp=rp, ci=ci, graph=DeviceGraph(rp, ci, rw_hops=HOPS, restart_prob=RESTART, device="cuda:0", validate=False, trusted=True))
     return _G1
 
 

@@ -81,7 +81,7 @@ def test_pipelined_producer_equals_sequential_production_step_by_step():
 
     dev = torch.device("cuda:0")
     rp, ci = powerlaw_graph(1_000_000, 10_000_000, seed=0)
-    graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False)
+    graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False, trusted=True)
     seq_loss, seq_i, seq_f = _run(False, graph)
     pip_loss, pip_i, pip_f = _run(True, graph)
     assert int(seq_i[:, :, 0].min()) > B                   # live batches, not empty buffers

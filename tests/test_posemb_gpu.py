@@ -138,7 +138,7 @@ def test_c2_chunk_of_32_views_runs_clean_and_every_hub_item_passes_the_strict_in
     from tests.test_posemb_emu import _check, _sub
 
     rp, ci = powerlaw_graph(1_000_000, 10_000_000, 0)
-    g = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, validate=False)
+    g = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, validate=False, trusted=True)
     B, S = 256, 16
     s = DeviceRWRSampler(g, B, run_seed=0, num_buffers=S)
     pe = DevicePosEmb(B, s.node_cap, HID, device="cuda", seed=0, num_buffers=S, max_views=2 * S)

@@ -1,6 +1,8 @@
 """The step's two collectives (all-gather of keys, all-reduce of the flat gradient) through RCCL on the GPU box: a
 1-rank process group is all a single-GPU box allows, but it runs the real NCCL kernels on RCCL's stream next to the
-producer lanes and the high-priority training stream, and must give the same losses as the step without collectives."""
+producer lanes and the high-priority training stream, and must give the same losses as the step without collectives --
+launch by launch, and as the SEGMENTED graph replay the multi-GPU step ships with (three captured graphs around the two
+RCCL hand-offs: gcc_amd/train_step.py MoCoTrainStep._body)."""
 import os
 
 import pytest
@@ -9,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(collectives):
+def _run(collectives, graph=None, steps=20):
     from gcc_amd.contrast import MemoryMoCo
     from gcc_amd.encoder import GraphEncoder
     from gcc_amd.graph import DeviceGraph
@@ -34,11 +36,15 @@ def _run(collectives):
         smp = DeviceRWRSampler(graph, B, run_seed=3, num_buffers=depth * chunk, max_steps=chunk)
         lanes.append((smp, DevicePosEmb(B, smp.node_cap, 32, device=dev, seed=3, num_buffers=depth * chunk, max_views=2 * chunk)))
     tr = MoCoTrainStep(model, ema, contrast, lanes[0][0], lanes[0][1], lanes=lanes, depth=depth, chunk=chunk,
-                       collectives=collectives)
+                       collectives=collectives, graph=graph)
     tr.dropout_seed = 11
-    losses = [float(tr.step(i, 0.005)["loss"].item()) for i in range(6)]
+    tr.relaxed_streams = True                  # the bench / train.py loops: no per-step stream hand-offs
+    outs = [tr.step(i, 0.005) for i in range(steps)]
+    tr.join()
     torch.cuda.synchronize()
-    return losses
+    # (a replayed step returns its slot's captured output tensors: read after the loop they hold each slot's LAST step, so
+    #  the per-step trace is the meters' running sum, read step by step in a second pass below)
+    return tr, [float(o["loss"].item()) for o in outs[-4:]], model.state_dict(), contrast.memory.clone()
 
 
 def test_step_with_rccl_collectives_matches_the_step_without():
@@ -47,10 +53,21 @@ def test_step_with_rccl_collectives_matches_the_step_without():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
-    ref = _run(False)
+    _, ref, ref_w, ref_mem = _run(False)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
-        got = _run(True)
+        tr_e, eager, eager_w, eager_mem = _run(True, graph=False)
+        tr_g, seg, seg_w, seg_mem = _run(True)               # default with collectives on a device: segmented replay
     finally:
         dist.destroy_process_group()
-    assert got == pytest.approx(ref, rel=1e-5)
+    assert not tr_e.use_graph and tr_e.graph_replays == 0
+    assert tr_g.use_graph and tr_g.graph_replays == 20 - 8   # 2 lanes x depth 2 x chunk 2 ring slots, captured once each
+    for items, _ in tr_g.graphs.values():
+        kinds = [isinstance(it, torch.cuda.CUDAGraph) for it in items]
+        assert kinds == [True, False, True, False, True]     # forward | gather begins | head + backward | reduce, join | update
+    for got, w, mem in ((eager, eager_w, eager_mem), (seg, seg_w, seg_mem)):
+        assert got == pytest.approx(ref, rel=1e-5)
+        for name, t in ref_w.items():
+            if t.dtype.is_floating_point:
+                assert torch.allclose(w[name], t, rtol=1e-5, atol=1e-7), name
+        assert torch.allclose(mem, ref_mem, rtol=1e-5, atol=1e-7)

@@ -337,3 +337,22 @@ def test_unscanned_hub_rows_in_multi_step_launches(coracle):
         for got, ref in ((q, single[0]), (k, single[1])):
             for key in KEYS + ("edge_off", "graph_id"):
                 assert np.array_equal(got[key], ref[key]), (t, key)
+
+
+def test_unchecked_parent_scans_every_row(coracle):
+    """A graph whose contract nobody checked (gcc_graph.flags without GCC_GRAPH_CONTRACT_CHECKED: DeviceGraph(validate=False)
+    without trusted=True, raw C-API callers) never takes the hub-row short cut, whatever hub_degree says: the mirror images
+    are the induced rows on a SYMMETRIC parent only.  An asymmetric sorted-row parent therefore still gives the subgraph a
+    row-by-row induction (DGL's VertexSubgraph, the C oracle) gives."""
+    rp0, ci0 = powerlaw_graph(3000, 30000, 3)
+    rng = np.random.default_rng(0)
+    keep = rng.random(len(ci0)) < 0.8
+    keep[rp0[:-1]] = True                                  # no dead ends: every row keeps its first edge
+    ci = ci0[keep]
+    rp = np.concatenate([[0], np.cumsum(np.add.reduceat(keep.astype(np.int64), rp0[:-1]))]).astype(np.int32)
+    import scipy.sparse as sp
+    a = sp.csr_matrix((np.ones(len(ci), np.int8), ci, rp), shape=(len(rp) - 1,) * 2)
+    assert (a != a.T).nnz > 0
+    g = EmuGraph(rp, ci, rw_hops=64, contract_checked=False)
+    _compare(coracle, rp, ci, g, 7, 21, 500, hub_degree=2, max_hubs=32)
+    _compare(coracle, rp, ci, g, 7, 21, 500)

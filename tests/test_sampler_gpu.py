@@ -186,6 +186,35 @@ def test_config4_like_dense_graph_bit_exact(coracle, torch_cuda):
     assert max(np.diff(ref[0]["node_off"])) > 1000
 
 
+def test_config4_full_size_bit_exact(coracle, torch_cuda, g2_graph):
+    """BASELINE configs[3] at its REAL size (10M nodes / 200M edges requested, rw_hops 256, restart 0.8, bsz 256): one batch
+    drawn as the product draws it and one batch of hub seeds, node ids and batched CSR of both views bit for bit the C
+    oracle's (graph_dataset.py:94-130, data_util.py:218-239); then the multi-step launch bench.py --mode sampler times
+    (16 steps per call) against single-step calls of the same sample ids."""
+    from gcc_amd.graph import DeviceGraph
+    from gcc_amd.sampler import DeviceRWRSampler
+
+    rp, ci = g2_graph
+    assert len(rp) - 1 > 9_900_000 and len(ci) > 199_000_000
+    _check(coracle, torch_cuda, rp, ci, 256, 256, 0, 256 * 5)
+    hubs = np.argsort(np.diff(rp))[-512::8].astype(np.int32)     # 64 of the 512 largest degrees (up to 12,649 neighbours)
+    q, k, ref = _check(coracle, torch_cuda, rp, ci, 64, 256, 9, 0, seeds=hubs.tolist(), scratch_entries=1 << 28, edge_cap=1 << 26)
+    assert max(np.diff(ref[0]["node_off"])) > 1000
+    # the launch shape of the published sampler line: 16 steps per call == 16 single-step calls
+    g = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, validate=False, trusted=True)
+    multi = DeviceRWRSampler(g, 256, run_seed=0, num_buffers=16, max_steps=16)
+    single = DeviceRWRSampler(g, 256, run_seed=0)
+    pairs = multi.sample_multi(256 * 32, 16, 256)
+    multi.check_status()
+    for t in (0, 7, 15):
+        a = single.sample(256 * (32 + t))
+        single.check_status()
+        for x, y in zip(a, pairs[t]):
+            cx, cy = x.csr_numpy(), y.csr_numpy()
+            for key in KEYS:
+                assert np.array_equal(cx[key], cy[key]), (t, key)
+
+
 def test_overflow_flag(torch_cuda):
     from gcc_amd.graph import DeviceGraph
     from gcc_amd.graphgen import powerlaw_graph

@@ -41,7 +41,7 @@ def batch_of(n, copies):
 
 
 rp, ci = powerlaw_graph(1_000_000, 10_000_000, seed=0)
-graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False)
+graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False, trusted=True)
 B = 256
 sampler = DeviceRWRSampler(graph, B, run_seed=0, num_buffers=3)
 enc_kw = dict(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512, freq_embedding_size=16,

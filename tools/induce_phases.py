@@ -18,7 +18,7 @@ args = ap.parse_args()
 S = args.steps_per_call
 dev = torch.device("cuda:0")
 rp, ci = powerlaw_graph(args.nodes, args.edges, seed=0)
-graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False)
+graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False, trusted=True)
 sampler = DeviceRWRSampler(graph, 256, run_seed=0, num_buffers=max(2, S), max_steps=S, hub_degree=args.hub_degree)
 run = (lambda i: sampler.sample_multi(10_000_000 + i * 256 * S, S)) if S > 1 else (lambda i: sampler.sample(10_000_000 + i * 256))
 for i in range(5):

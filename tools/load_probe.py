@@ -30,7 +30,7 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 lib = _cabi.load()
 rp, ci = powerlaw_graph(1_000_000, 10_000_000, seed=0)
-graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False)
+graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False, trusted=True)
 B = 256
 torch.manual_seed(0)
 sampler = DeviceRWRSampler(graph, B, run_seed=0, num_buffers=2)

@@ -24,7 +24,7 @@ ap.add_argument("--out", default="gpurun_out")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 rp, ci = powerlaw_graph(1_000_000, 10_000_000, seed=0)
-graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False)
+graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False, trusted=True)
 B = 256
 sampler = DeviceRWRSampler(graph, B, run_seed=0, num_buffers=2)
 pe = DevicePosEmb(B, sampler.node_cap, 32, device=dev, seed=0, num_buffers=2, max_views=1)

@@ -11,7 +11,7 @@ from gcc_amd.sampler import DeviceRWRSampler
 
 dev = torch.device("cuda:0")
 rp, ci = powerlaw_graph(1_000_000, 10_000_000, seed=0)
-graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False)
+graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False, trusted=True)
 B, S = 256, 8
 sampler = DeviceRWRSampler(graph, B, run_seed=0, num_buffers=S)
 pe = DevicePosEmb(B, sampler.node_cap, 32, device=dev, seed=0, num_buffers=S, max_views=2 * S)

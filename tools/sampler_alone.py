@@ -34,7 +34,7 @@ if a.lib:
     _cabi._lib = _cabi.declare(ctypes.CDLL(os.path.abspath(a.lib)))
 dev = torch.device("cuda:0")
 rp, ci = powerlaw_graph(a.nodes, a.edges, seed=0)
-graph = DeviceGraph(rp, ci, rw_hops=a.rw_hops, restart_prob=0.8, device=dev, validate=False)
+graph = DeviceGraph(rp, ci, rw_hops=a.rw_hops, restart_prob=0.8, device=dev, validate=False, trusted=True)
 S = a.steps_per_call
 if a.sweep:
     import time
