@@ -10,6 +10,9 @@ MoCo K=16384, bsz 256, rw_hops 256, restart 0.8 on the synthetic 1M-node/10M-edg
 §8d), everything resident in HBM before the timed region.
 --mode sampler (BASELINE configs[3]): the sampler alone (seed draw, walks, induction, batch packing) on the
 10M-node/200M-edge graph G2; no collective.
+--mode sample-ready (SURVEY.md 8d, C2 "sample-ready subgraphs/s"): sampler + device positional embedding on the producer
+lanes, no training step -- what the reference's DataLoader workers deliver (graph_dataset.py:94-179 incl. the ARPACK
+call of data_util.py:242-281), and the figure the >= 10x target is quoted on.
 --mode e2e (BASELINE configs[0], train.py:396-401): in-batch negatives (K = bsz - 1, NCESoftmaxLossNS), both views
 through `model`, fused clip + Adam, on G1 (small.bin is not obtainable offline); --batch-size 32 is the reference's
 README setting, 256 the default here.  Single GPU (the reference has no data-parallel E2E mode).
@@ -50,7 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--mode", choices=["train", "sampler", "e2e"], default="train")
+    ap.add_argument("--mode", choices=["train", "sampler", "sample-ready", "e2e"], default="train")
     ap.add_argument("--batch-size", type=int, default=256)
     ap.add_argument("--nce-k", type=int, default=16384)
     ap.add_argument("--rw-hops", type=int, default=256)
@@ -68,9 +71,11 @@ def parse_args(argv=None):
                                                           "the largest divisor of --steps not above it is used, so that the timed region "
                                                           "launches exactly the chunks it consumes")
     ap.add_argument("--depth", type=int, default=2, help="chunks in flight per producer lane")
-    ap.add_argument("--steady-steps", type=int, default=128, help="least number of untimed steps before the clock (training modes): the "
-                                                                  "pipeline fill and the first ~100 steps of a process are not the steady state; "
-                                                                  "0 = the requested warm-up / the pipeline fill only")
+    ap.add_argument("--steady-steps", type=int, default=0, help="extra: run at least this many untimed steps before the clock (the first ~100 steps "
+                                                                "of a process run 2-3 %% slower than the rest); 0 (default) = exactly --warmup "
+                                                                "untimed steps.  The line's `warmup` field reports what was run")
+    ap.add_argument("--collectives", action="store_true", help="--gpus 1: run the multi-GPU step (key all-gather + gradient all-reduce over "
+                                                               "RCCL, segmented graph replay) on a 1-rank process group")
     ap.add_argument("--sampler-steps", type=int, default=16,
                     help="--mode sampler: steps (DataLoader batches) per sampler call (gcc_sample_multi); the training modes "
                          "sample a producer chunk per call")
@@ -116,6 +121,11 @@ def workload_name(args, world, v, e):
         tag = "BASELINE configs[3]: " if (args.nodes, args.edges, args.rw_hops) == (10_000_000, 200_000_000, 256) \
             and abs(args.restart_prob - 0.8) < 1e-12 else ""
         return f"{tag}sampler-only rw_hops={args.rw_hops} restart={args.restart_prob} bsz={args.batch_size}/GPU, {graph}, {world}xMI355X"
+    if args.mode == "sample-ready":
+        tag = "BASELINE configs[1] data pipeline (SURVEY 8d C2 sample-ready): " \
+            if (args.nodes, args.edges, args.batch_size, args.rw_hops) == (1_000_000, 10_000_000, 256, 256) else ""
+        return (f"{tag}sampler + device positional embedding, no training step, bsz={args.batch_size}/GPU rw_hops={args.rw_hops} "
+                f"restart={args.restart_prob}, {graph}, {world}xMI355X")
     if args.mode == "e2e":
         return (f"BASELINE configs[0] on G1: E2E K={args.batch_size - 1} (in-batch negatives, NCESoftmaxLossNS) bsz={args.batch_size} "
                 f"hid=64 rw_hops={args.rw_hops} restart={args.restart_prob}, {graph}, {world}xMI355X")
@@ -183,10 +193,14 @@ def cpu_baseline_sampler(rp, ci, args):
 
 
 def cpu_baseline(rp, ci, args):
-    """The reference-shaped CPU path on this box's host cores ("port" kind): C oracle of the
-    sampler (OpenMP over subgraphs) + SciPy ARPACK positional embedding (data_util.py:242-281, one
-    process per core like the reference's DataLoader workers) + the torch-CPU oracle of
-    encoder/head/Adam/EMA (train.py:378-431)."""
+    """The CPU path on this box's host cores, two ways.
+
+    ``value`` (kind "port", the STRONGER one): C oracle of the sampler (OpenMP over subgraphs) + SciPy ARPACK positional
+    embedding (data_util.py:242-281, one process per core like the reference's DataLoader workers) + the torch-CPU
+    oracle of encoder/head/Adam/EMA (train.py:378-431), the three stages PIPELINED one step deep the way the reference
+    overlaps its workers with the trainer (the eigen-solves of step i + 1 run while step i trains): full steps.
+    ``reference_shaped``: BASELINE.md's B-ref-N -- the reference's per-sample Python data pipeline in ``nproc`` worker
+    processes and in train.py:49's default 12: sample-ready subgraphs/s, no training step."""
     import multiprocessing as mp
 
     import torch
@@ -203,21 +217,22 @@ def cpu_baseline(rp, ci, args):
     lt = O.max_nodes_table(int(np.diff(rp).max()), args.rw_hops, args.restart_prob)
     thr = O.restart_threshold(args.restart_prob)
     B = args.batch_size
-    model, ema = E.OracleGraphEncoder(), E.OracleGraphEncoder()
-    ema.load_state_dict(model.state_dict())
-    memory = E.memory_init(args.nce_k, 64)
-    opt = torch.optim.Adam(model.parameters(), lr=0.005, betas=(0.9, 0.999), weight_decay=1e-5)
-    model.train()
-    ema.train()
-    index, done, first = 0, 0, 10_000_000
-    pool = mp.get_context("spawn").Pool(workers, initializer=_posemb_init)
-    try:
-        pool.map(_posemb_chunk, [(np.array([0, 3]), np.array([0, 2, 4, 6]), np.array([1, 2, 0, 2, 0, 1]), 0)] * workers)   # import scipy in every worker before the clock
-        t0 = time.perf_counter()
-        while True:
+    deg = np.diff(rp)
+    res = None
+    if args.mode != "sample-ready":
+        model, ema = E.OracleGraphEncoder(), E.OracleGraphEncoder()
+        ema.load_state_dict(model.state_dict())
+        memory = E.memory_init(args.nce_k, 64)
+        opt = torch.optim.Adam(model.parameters(), lr=0.005, betas=(0.9, 0.999), weight_decay=1e-5)
+        model.train()
+        ema.train()
+        index, done = 0, 0
+        pool = mp.get_context("spawn").Pool(workers, initializer=_posemb_init)
+
+        def submit(first):                       # sampler (C, OpenMP) now, the eigen-solves as asynchronous pool jobs
             seeds = c.draw_seeds(cdf, args.run_seed, first, B)
-            L = lt[np.diff(rp)[seeds]]
-            views = []
+            L = lt[deg[seeds]]
+            out = []
             for view in range(2):
                 r = c.sample_batch(rp, ci, seeds, L, view, args.run_seed, first, thr, threads=threads)
                 nb = len(r["node_off"]) - 1
@@ -230,64 +245,139 @@ def cpu_baseline(rp, ci, args):
                         e0, e1 = r["row_ptr"][n0], r["row_ptr"][n1]
                         jobs.append((r["node_off"][lo:hi + 1] - n0, r["row_ptr"][n0:n1 + 1] - e0,
                                      r["col_idx"][e0:e1] - n0, first + w))
-                pos = np.concatenate(pool.map(_posemb_chunk, jobs))
-                views.append((r, torch.from_numpy(pos)))
-            keep = (torch.rand(5, B, 64) >= 0.5).float()
-            (rq, pq), (rk, pk) = views
-            fq = model(rq["node_off"].astype(np.int64), rq["row_ptr"].astype(np.int64),
-                       rq["col_idx"].astype(np.int64), pq, dropout_masks=keep)
-            if args.mode == "e2e":                           # train.py:396-401
-                keep_k = (torch.rand(5, B, 64) >= 0.5).float()
-                fk = model(rk["node_off"].astype(np.int64), rk["row_ptr"].astype(np.int64),
-                           rk["col_idx"].astype(np.int64), pk, dropout_masks=keep_k)
-                loss = E.nce_softmax_loss_ns(fk @ fq.t() / 0.07)
-            else:
-                with torch.no_grad():
-                    fk = ema(rk["node_off"].astype(np.int64), rk["row_ptr"].astype(np.int64),
-                             rk["col_idx"].astype(np.int64), pk)
-                out, index = E.moco_forward(memory, index, fq, fk, 0.07)
-                loss = E.nce_softmax_loss(out)
-            opt.zero_grad()
-            loss.backward()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-            opt.step()
-            if args.mode != "e2e":
-                E.moment_update(model, ema, 0.999)
-            done += 2 * B
-            first += B
-            dt = time.perf_counter() - t0
-            if dt >= args.cpu_seconds:
-                break
-    finally:
-        pool.terminate()
-    head = "encoder/E2E-NS/Adam" if args.mode == "e2e" else "encoder/MoCo/Adam/EMA"
-    res = dict(value=done / dt, unit="subgraphs/s", cores=cores, kind="port",
-               sample=f"{done // (2 * B)} full steps of bsz {B} ({done} subgraphs) in {dt:.1f}s: C sampler oracle "
-                      f"(OpenMP x{threads}) + SciPy eigsh pos-emb ({workers} processes) + torch-CPU "
-                      f"{head} oracle ({torch.get_num_threads()} threads)")
-    res["reference_shaped"] = cpu_baseline_reference_shaped(rp, ci, args)
+                out.append((r, pool.map_async(_posemb_chunk, jobs)))
+            return out
+        try:
+            pool.map(_posemb_chunk, [(np.array([0, 3]), np.array([0, 2, 4, 6]), np.array([1, 2, 0, 2, 0, 1]), 0)] * workers)   # import scipy in every worker before the clock
+            first = 10_000_000
+            t0 = time.perf_counter()
+            pending = submit(first)
+            while True:
+                nxt = submit(first + B)          # step i + 1's data pipeline runs under step i's training
+                (rq, pq), (rk, pk) = [(r, torch.from_numpy(np.concatenate(a.get(timeout=300)))) for r, a in pending]
+                keep = (torch.rand(5, B, 64) >= 0.5).float()
+                fq = model(rq["node_off"].astype(np.int64), rq["row_ptr"].astype(np.int64),
+                           rq["col_idx"].astype(np.int64), pq, dropout_masks=keep)
+                if args.mode == "e2e":                           # train.py:396-401
+                    keep_k = (torch.rand(5, B, 64) >= 0.5).float()
+                    fk = model(rk["node_off"].astype(np.int64), rk["row_ptr"].astype(np.int64),
+                               rk["col_idx"].astype(np.int64), pk, dropout_masks=keep_k)
+                    loss = E.nce_softmax_loss_ns(fk @ fq.t() / 0.07)
+                else:
+                    with torch.no_grad():
+                        fk = ema(rk["node_off"].astype(np.int64), rk["row_ptr"].astype(np.int64),
+                                 rk["col_idx"].astype(np.int64), pk)
+                    out, index = E.moco_forward(memory, index, fq, fk, 0.07)
+                    loss = E.nce_softmax_loss(out)
+                opt.zero_grad()
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+                opt.step()
+                if args.mode != "e2e":
+                    E.moment_update(model, ema, 0.999)
+                done += 2 * B
+                first += B
+                pending = nxt
+                dt = time.perf_counter() - t0
+                if dt >= args.cpu_seconds:
+                    break
+        finally:
+            pool.terminate()
+        head = "encoder/E2E-NS/Adam" if args.mode == "e2e" else "encoder/MoCo/Adam/EMA"
+        res = dict(value=done / dt, unit="subgraphs/s", cores=cores, kind="port",
+                   sample=f"{done // (2 * B)} full steps of bsz {B} ({done} subgraphs) in {dt:.1f}s: C sampler oracle "
+                          f"(OpenMP x{threads}) + SciPy eigsh pos-emb ({workers} processes) + torch-CPU "
+                          f"{head} oracle ({torch.get_num_threads()} threads), stages pipelined one step deep")
+    # BASELINE.md B-ref-N: the reference-shaped data pipeline on every host core, and on train.py:49's default 12 workers
+    shaped = {}
+    for procs in sorted({cores, min(12, cores)}, reverse=True):
+        shaped["nproc" if procs == cores else "workers_%d" % procs] = cpu_baseline_reference_shaped(rp, ci, args, procs)
+    if cores <= 12:
+        shaped["workers_12"] = dict(shaped["nproc"], note="this host has no more than 12 cores: the same run")
+    if res is None:                              # --mode sample-ready: the data pipeline IS the workload
+        top = shaped["nproc"]
+        res = dict(value=top.get("value"), unit="subgraphs/s", cores=top.get("cores"), kind="port", sample=top.get("sample"))
+    res["reference_shaped"] = shaped
     return res
 
 
-def cpu_baseline_reference_shaped(rp, ci, args):
-    """SURVEY.md 8(d) baseline (i), the WEAKER one: the reference's data pipeline the way the reference runs it -- a
+def cpu_baseline_reference_shaped(rp, ci, args, procs):
+    """SURVEY.md 8(d) baseline (i) / BASELINE.md B-ref-N: the reference's data pipeline the way the reference runs it -- a
     Python loop per sample mirroring graph_dataset.py:94-179 call for call (walker in C standing in for DGL's C++
-    one, torch.unique, SciPy slicing for g.subgraph, SciPy ARPACK exactly as data_util.py:242-281), in as many worker
-    processes as train.py:49's default (--num-workers 12) -- sample-ready subgraphs/s, no encoder step.  Spawned
-    processes (a forked child of a process holding a HIP context is unsafe)."""
+    one, torch.unique, SciPy slicing for g.subgraph, SciPy ARPACK exactly as data_util.py:242-281), in ``procs`` worker
+    processes -- sample-ready subgraphs/s, no encoder step.  Spawned processes (a forked child of a process holding a HIP
+    context is unsafe); the graph reaches them as mapped files."""
     from tests.tools.cpu_baseline_reference_shaped import run_timed
 
     cores = os.cpu_count() or 1
-    procs = min(12, cores)
     try:
-        v, dt, n = run_timed(rp, ci, procs, max(4.0, 0.6 * args.cpu_seconds), clear=True, rw_hops=args.rw_hops,
+        v, dt, n = run_timed(rp, ci, procs, max(4.0, 0.5 * args.cpu_seconds), clear=True, rw_hops=args.rw_hops,
                              restart=args.restart_prob, start="spawn")
-    except Exception as e:                                   # the stronger "port" figure above stands on its own
+    except Exception as e:                                   # the other figures stand on their own
         return dict(value=None, error=repr(e)[:200])
     return dict(value=v, unit="subgraphs/s", cores=procs, host_cores=cores, kind="port",
                 sample=f"{n} samples (2 views each) in {dt:.1f}s: per-sample Python loop of graph_dataset.py:94-179 in {procs} "
-                       f"worker processes (train.py:49 default num_workers=12), C walker + per-seed O(|V|) visit-count clear "
-                       f"(DGL-recalled) + torch.unique + SciPy subgraph slicing + SciPy ARPACK pos-emb; data pipeline only")
+                       f"worker processes (BASELINE.md B-ref-N; train.py:49 default num_workers=12), C walker + per-seed O(|V|) "
+                       f"visit-count clear (DGL-recalled) + torch.unique + SciPy subgraph slicing + SciPy ARPACK pos-emb; data pipeline only")
+
+
+def parity_batch(sampler, rp, ci, args, first_sample_id):
+    """After the clock, in the checker leg: the batch with sample ids ``first_sample_id`` + [0, bsz) -- the first one the timed
+    region produced -- sampled again by the device sampler and compared with oracle/sampler_oracle.c bit for bit: seeds,
+    node ids, batched CSR of both views (graph_dataset.py:94-130, data_util.py:218-239, 26-32).  Raises on a mismatch."""
+    from oracle import sampler as O
+
+    c = O.COracle()
+    B = args.batch_size
+    q, k = sampler.sample(first_sample_id)
+    sampler.check_status()
+    seeds = c.draw_seeds(O.seed_cdf(rp), args.run_seed, first_sample_id, B)
+    if sampler.last_seeds().cpu().numpy().tolist() != seeds.tolist():
+        raise AssertionError("parity_batch: the device's seed draw differs from the oracle's")
+    L = O.max_nodes_table(int(np.diff(rp).max()), args.rw_hops, args.restart_prob)[np.diff(rp)[seeds]]
+    nodes = edges = 0
+    for view, gb in enumerate((q, k)):
+        ref = c.sample_batch(rp, ci, seeds, L, view, args.run_seed, first_sample_id, O.restart_threshold(args.restart_prob))
+        got = gb.csr_numpy()
+        for key in ("node_off", "edge_off", "parent_nid", "row_ptr", "col_idx"):
+            if not np.array_equal(got[key], ref[key]):
+                raise AssertionError(f"parity_batch: view {view} {key} differs from oracle/sampler_oracle.c")
+        nodes += len(ref["parent_nid"])
+        edges += len(ref["col_idx"])
+    return dict(first_sample_id=int(first_sample_id), subgraphs=2 * B, nodes=int(nodes), edges=int(edges),
+                checked="seeds, node_off, edge_off, parent_nid, row_ptr, col_idx of both views of the first timed batch, "
+                        "re-sampled after the clock: bit-equal to oracle/sampler_oracle.c")
+
+
+def parity_posemb(view, pos, evals, picks=6, tol=2e-4):
+    """Checker leg of --mode sample-ready: the device positional embedding of a few subgraphs of one view against a dense
+    float64 eigendecomposition of D^-1/2 A D^-1/2 (data_util.py:242-281) on the invariants tests/test_posemb_gpu.py uses:
+    eigenvalues, residual, orthonormality of the raw vectors is not available here, so: eigenvalues and unit rows."""
+    from oracle import posemb as P
+
+    c = view.csr_numpy()
+    no, rpv, civ = c["node_off"], c["row_ptr"], c["col_idx"]
+    sizes = np.diff(no)
+    order = np.argsort(sizes)
+    chosen = sorted({int(order[int(f * (len(order) - 1))]) for f in np.linspace(0.05, 1.0, picks)})
+    worst = 0.0
+    for b in chosen:
+        lo, hi = int(no[b]), int(no[b + 1])
+        n = hi - lo
+        k = min(n - 2, 32)
+        if k <= 0:
+            continue
+        M = P.normalized_adjacency(rpv[lo:hi + 1] - rpv[lo], civ[rpv[lo]:rpv[hi]] - lo).toarray()
+        s = np.linalg.eigvalsh(M)
+        err = float(np.abs(evals[b, :k] - s[-k:]).max())
+        worst = max(worst, err)
+        if err > tol:
+            raise AssertionError(f"parity_posemb: subgraph {b} (n = {n}): eigenvalues off by {err:.2e}")
+        norms = np.linalg.norm(pos[lo:hi, :k], axis=1)
+        if not np.all((np.abs(norms - 1) < 1e-4) | (norms == 0)):
+            raise AssertionError(f"parity_posemb: subgraph {b}: rows are not unit vectors")
+    return dict(subgraphs_checked=len(chosen), sizes=[int(sizes[b]) for b in chosen], worst_eigenvalue_error=worst, tol=tol,
+                checked="top-k eigenvalues against numpy eigvalsh (float64) of D^-1/2 A D^-1/2, unit rows (data_util.py:242-281)")
 
 
 def parity_step(args, graph, dev):
@@ -356,6 +446,63 @@ def committed_pmc_traffic(args, v, e, steps_per_call=1):
     if ent is None:
         return None, f"profiles/pmc_sampler.json has no entry for workload {key}"
     return ent["induce_kernel_hbm_bytes_per_launch"], f"profiles/pmc_sampler.json[{key}] ({ent.get('correction', 'raw')})"
+
+
+def committed_pmc_entry(args, v, e, steps_per_call=1):
+    """Per-kernel HBM bytes per launch of the committed PMC passes for this build and workload, or {} (refused / absent)."""
+    if args.pmc_traffic is not None or getattr(args, "hub_degree", 0) != 0 or not os.path.exists(PMC_FILE):
+        return {}
+    rec = json.load(open(PMC_FILE))
+    if rec.get("source_sha256") != sampler_source_hash():
+        return {}
+    key = f"{v}/{e}/bsz{args.batch_size}/hops{args.rw_hops}" + (f"/steps{steps_per_call}" if steps_per_call > 1 else "")
+    ent = rec.get("workloads", {}).get(key) or {}
+    return {k: float(vv["hbm_bytes_per_launch"]) for k, vv in ent.get("kernels", {}).items()}
+
+
+SAMPLER_INTERVALS = (   # (name in kernel_ms_isolated, byte-model key, kernels of the interval)
+    ("rwr_walk_kernel+prefix_a_kernel+records_kernel", "walk", ("rwr_walk_kernel", "prefix_a_kernel", "records_kernel")),
+    ("induce_kernel", "induce", ("induce_kernel",)),
+    ("prefix_b_kernel+pack_kernel+hub_write_kernel", "pack", ("prefix_b_kernel", "pack_kernel", "hub_write_kernel")))
+
+
+def hbm_roofline(kernel, alg_bytes, ms, traffic, **more):
+    """SURVEY 8(d) roofline object of an HBM-bound launch: `frac` prices the ALGORITHMIC bytes (what the reference algorithm
+    would read and write), `frac_moved` the bytes the kernels really moved (PMC traffic) -- side by side, because a kernel
+    that skips work (the unscanned hub rows) scores high on the first and low on the second."""
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    out = dict(bound="hbm", kernel=kernel, achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s", frac=ach / HBM_PEAK_GBPS,
+               algorithmic_bytes_per_launch=alg_bytes, ms_per_launch=ms, traffic=traffic,
+               frac_moved=(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None)
+    out.update(more)
+    return out
+
+
+SOLVER_KERNELS = {"mid": "posemb_direct_kernel<1, 65, 128, 1024, false>", "sparse-block": "posemb_cheb_kernel", "wave48": "posemb_wave_kernel<6, 48>",
+                  "wave64": "posemb_wave_kernel<7, 64>", "small": "posemb_direct_kernel<0, 0, 64, 256, false>", "slot": "posemb_direct_kernel<2, ...>",
+                  "big": "posemb_direct_kernel<4, ...>", "krylov": "posemb_krylov_kernel"}
+
+
+def solver_roofline(pe_probe):
+    """The eigensolver class that holds the most CU-time per step, priced against ONE compute unit's exact-f32 rate (a solver
+    workgroup owns one CU; MI355X_MICROARCH.md: 157.3 TFLOP/s / 256 CUs): executed f32 FLOPs (the kernels' own counters) over
+    the workgroups' residency time."""
+    cls = pe_probe.get("classes") or {}
+    if not cls:
+        return None
+    name = max(cls, key=lambda k: cls[k]["cu_ms_per_item"] * cls[k]["items"])
+    c = cls[name]
+    cu_s = c["cu_ms_per_item"] * c["items"] / 1e3
+    total = sum(v["cu_ms_per_item"] * v["items"] for v in cls.values()) / 1e3
+    ach = c["gflop"] / cu_s / 1e3 if cu_s > 0 else 0.0
+    peak = F32_PER_CU_GFLOPS / 1e3
+    return dict(bound="mfma", kernel=SOLVER_KERNELS.get(name, name), solver_class=name, achieved=ach, peak=peak, unit="TFLOP/s",
+                frac=ach / peak, traffic=None, items=c["items"], cu_ms_per_item=c["cu_ms_per_item"],
+                share_of_solver_cu_time=cu_s / total if total > 0 else None,
+                note="f32 FLOP-bound latency chains, not an HBM stream (the solvers move < 30 GB/s: profiles/r4_posemb_traffic.txt): "
+                     "executed f32 FLOPs of the class / its workgroups' residency, against the exact-f32 MFMA/vector rate of the one CU a "
+                     "solver workgroup occupies; measured by an isolated multi-view call after the clock with the kernels' tick / FLOP "
+                     "counters on (gcc_posemb_debug_ticks)")
 
 
 def sampler_probe(sampler, rp, first_id, args, nsample, lt, Prof, torch, steps_per_call=1, world=1):
@@ -508,6 +655,12 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    elif args.collectives:                     # the multi-GPU step's launch path on a one-rank RCCL group
+        if args.mode != "train":
+            raise SystemExit("--collectives is the MoCo step's data-parallel path (--mode train)")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     from gcc_amd.graph import DeviceGraph
     from gcc_amd.graphgen import powerlaw_graph
@@ -555,6 +708,44 @@ def main():
         produced = consumed = args.steps
         first_timed = args.warmup
         chunk = 1
+    elif args.mode == "sample-ready":
+        from gcc_amd.posemb import DevicePosEmb
+
+        # the producer lanes of the training modes without a consumer: lane l samples chunk c (c % lanes == l) -- `chunk`
+        # steps per sampler call -- and runs ONE multi-view eigensolver call over its 2 * chunk views, on its own stream
+        chunk = max(d for d in range(1, min(args.chunk, args.steps) + 1) if args.steps % d == 0)
+        if args.warmup % chunk:
+            chunk = max(d for d in range(1, chunk + 1) if args.steps % d == 0 and args.warmup % d == 0)
+        samplers = [DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=args.depth * chunk, scratch_entries=args.scratch_entries or None,
+                                     edge_cap=args.edge_cap or None, max_steps=chunk, hub_degree=args.hub_degree) for _ in range(args.lanes)]
+        sampler = samplers[0]
+        posembs = [DevicePosEmb(B, sampler.node_cap, 32, device=dev, seed=args.run_seed, num_buffers=args.depth * chunk,
+                                max_views=min(2 * chunk, 32)) for _ in range(args.lanes)]
+        posemb = posembs[0]
+        lane_streams = [torch.cuda.Stream(dev) for _ in range(args.lanes)]
+
+        def run_steps(first_step, count):
+            for cidx in range(first_step // chunk, (first_step + count) // chunk):
+                lane = cidx % args.lanes
+                with torch.cuda.stream(lane_streams[lane]):
+                    pairs = samplers[lane].sample_multi(first_id(cidx * chunk), chunk, world * B)
+                    posembs[lane].multi([g for pair in pairs for g in pair])
+
+        run_steps(0, args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.warmup, args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        first_timed = args.warmup
+        produced = consumed = args.steps
+        stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind]
+        sts = [p.status.cpu().tolist() for p in posembs]
+        extra["posemb_status"] = dict(flags=int(np.bitwise_or.reduce([int(st[0]) for st in sts])),
+                                      items_handed_on=int(sum(st[3] for st in sts)), items_failed=int(sum(st[4] for st in sts)))
+        for pe_ in posembs:
+            pe_.check_status(strict=not args.allow_posemb_flags)
+        extra["producer_lanes"], extra["producer_chunk"] = args.lanes, chunk
     else:
         from gcc_amd.contrast import MemoryMoCo
         from gcc_amd.encoder import GraphEncoder
@@ -591,11 +782,12 @@ def main():
         else:
             trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank,
                                     lanes=lanes, depth=args.depth, chunk=chunk, reserved_cus=args.reserved_cus,
-                                    cu_layout=args.cu_layout, ahead=args.ahead, graph=False if args.no_graph else None)
+                                    cu_layout=args.cu_layout, ahead=args.ahead, graph=False if args.no_graph else None,
+                                    collectives=True if args.collectives else None)
             stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder q+k fwd",
-                      "moco-infonce fwd", "infonce bwd", "gin-encoder bwd", "grad all-reduce" if world > 1 else "clip",
+                      "moco-infonce fwd", "infonce bwd", "gin-encoder bwd", "grad all-reduce" if (world > 1 or args.collectives) else "clip",
                       "adam + ema + meters (one launch)",
-                      "key all-gather (overlapped since the encoder fwd) + enqueue" if world > 1 else "enqueue"]
+                      "key all-gather (overlapped since the encoder fwd) + enqueue" if (world > 1 or args.collectives) else "enqueue"]
         trainer.relaxed_streams = not args.strict_streams                  # results are read behind device synchronisations only
         n_batch = 2000 * 12 // 32                                          # train.py:356 with default flags
         total_steps = 100 * n_batch
@@ -605,15 +797,15 @@ def main():
 
         names = ("gin_fwd", "nce_fwd", "nce_bwd", "gin_bwd")
 
-        # untimed steps: the requested warm-up, extended to a whole number of producer rounds so that the look-ahead
-        # pipeline (lanes x depth chunks) is in steady state when the clock starts; `steps` is a multiple of `chunk`, so the
-        # timed region launches exactly as many chunks as it consumes (checked below: produced_steps == consumed_steps)
-        # ... and to --steady-steps (128): the first ~100 steps of a process run 2-3 % slower than the rest (measured,
-        # profiles/r4_bench_window_warmup.txt: a 20-step window reads 0.973-0.982 ms after 40 untimed steps, 0.951-0.955 after
-        # 200 / 400, and the second half of a 40-step window is already faster than the first); a pre-training run is hours
-        # long, so the steady state is the figure that describes it.  `untimed_steps` in the line says what was run.
-        fill = args.lanes * args.depth * chunk
-        warm = ((max(args.warmup, fill, args.steady_steps) + chunk - 1) // chunk) * chunk
+        # The data pipeline is primed first (chunk 0 and the producers' look-ahead launched and complete: what a DataLoader's
+        # workers do before the first iteration, no training step), then EXACTLY --warmup untimed steps run, then the clock
+        # covers EXACTLY --steps steps.  `steps` is a multiple of `chunk`, so the timed region launches as many chunks as it
+        # consumes (checked below: produced_steps == consumed_steps).  --steady-steps N (default 0) adds untimed steps up to
+        # N: the first ~100 steps of a process run 2-3 % slower than the rest (profiles/r4_bench_window_warmup.txt); the
+        # line's `warmup` field reports what was actually run.
+        trainer.producer.prefill()
+        torch.cuda.synchronize()
+        warm = max(args.warmup, args.steady_steps)
         for i in range(warm):
             trainer.step(i, lr_at(i))
         first_timed = warm
@@ -681,18 +873,46 @@ def main():
         kern_iso, acc_call, probe_shape, spc = sampler_probe(sampler, rp, lambda i: first_id(first_timed + i), args, nsample, lt,
                                                              Prof, torch, steps_per_call=spc, world=world)
         acc = {k: v / spc for k, v in acc_call.items()}       # per STEP (stage_rooflines, algorithmic_bytes_per_step)
-        if args.mode != "sampler" and args.posemb == "device":
+        if args.mode != "sampler" and (args.mode == "sample-ready" or args.posemb == "device"):
             pe_probe = posemb_probe(sampler, posemb, lambda i: first_id(first_timed + i), min(chunk, 8), torch)
         sampler.check_status()
-        dom = "induce_kernel"
-        achieved = acc_call["induce"] / (kern_iso[dom] * 1e-3) / 1e9
         traffic, traffic_src = committed_pmc_traffic(args, V, E, spc)
+        pmc = committed_pmc_entry(args, V, E, spc)
         ms_per_step = dt / args.steps * 1e3
+        # one roofline object per sampler interval (HIP-event marks inside gcc_sample_multi): algorithmic bytes AND moved bytes
+        samp_roofs = {}
+        for iname, key, kerns in SAMPLER_INTERVALS:
+            tr = sum(pmc.get(k, 0.0) for k in kerns) if all(k in pmc for k in kerns if k != "hub_write_kernel") else None
+            if key == "induce" and tr is None:
+                tr = traffic
+            samp_roofs[key] = hbm_roofline(iname, acc_call[key], kern_iso[iname], tr, steps_per_launch=spc)
+        samp_roofs["induce"].update(
+            measured="isolated probe loop after the timed region: HIP events (gcc_prof marks on the launch stream) right before and after "
+                     "the induction inside gcc_sample_multi (one call covers steps_per_launch consecutive batches, as the producer lanes "
+                     "issue it; two launches of induce_kernel: the small and the big size class, the sum is what is timed); rocprofv3 "
+                     "--kernel-trace --stats of the same launches alone: profiles/r5_kernel_stats_sampler_alone*.csv",
+            note="algorithmic bytes = SURVEY 8(d): every member's parent row read once + the output.  The rows of the (at most 32) "
+                 "highest-degree members of a subgraph are NOT read -- their induced rows are the mirror images of the other rows' hits "
+                 "(symmetric graph) -- so `frac` is the rate of the reference algorithm's bytes (a replacement rate), `frac_moved` "
+                 "the fraction of the HBM roof the kernel's own traffic reaches"
+                 + ("" if args.hub_degree >= 0 else " (this run: --hub-degree -1, every row is read)"),
+            traffic_source=traffic_src,
+            traffic_note="committed constant from separate rocprofv3 --pmc passes of this build (hash-guarded), not a same-run measurement")
+        sampler_dom = max(samp_roofs, key=lambda k: samp_roofs[k]["ms_per_launch"])
+        sol_roof = solver_roofline(pe_probe) if pe_probe else None
+        if sol_roof is not None:
+            # training / sample-ready modes: the eigensolvers hold most of the GPU's kernel time (rocprofv3 --stats of this command:
+            # profiles/r5_kernel_stats_default.csv); the line's `roofline` is THAT kernel, the sampler's objects follow
+            roof = dict(sol_roof, dominant_by="CU-time per step among the solver classes (isolated multi-view call); share of all kernel "
+                                              "time in the rocprofv3 --stats of this command: profiles/r5_kernel_stats_default.csv")
+        else:
+            roof = dict(samp_roofs[sampler_dom], dominant_by="largest isolated interval of a sampler call")
         out = {
             "metric": "sampled-subgraphs/sec", "value": 2 * B * world * args.steps / dt, "unit": "subgraphs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_steps": first_timed,
-            "untimed_steps_note": "warm-up requested: %d; run before the clock: the larger of that, the producers' pipeline fill and --steady-steps "
-                                  "(%d), rounded up to whole producer chunks" % (args.warmup, getattr(args, "steady_steps", 0)),
+            "n_gpus": world, "steps": args.steps, "warmup": first_timed, "warmup_requested": args.warmup,
+            "untimed_steps": first_timed,
+            "untimed_steps_note": "exactly the requested warm-up%s; the data pipeline is primed (first chunks sampled and embedded, no "
+                                  "training step) before the warm-up steps" % (" extended by --steady-steps %d" % args.steady_steps if getattr(args, "steady_steps", 0) > args.warmup else ""),
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32" if args.mode == "sampler" else "f32", "data": "synthetic",
@@ -703,32 +923,26 @@ def main():
                        "batch_size_per_gpu": B, "global_batch": B * world,
                        "nce_k": args.nce_k if args.mode == "train" else (B - 1 if args.mode == "e2e" else None),
                        "rw_hops": args.rw_hops, "restart_prob": args.restart_prob, "stages": stages,
-                       "parallelism": f"dp{world} (seed batch sharded, graph replicated)" + ("; OVERSUBSCRIBED: %d ranks on %d device(s), gloo, correctness only" % (world, ndev) if oversubscribed else "")},
+                       "parallelism": f"dp{world} (seed batch sharded, graph replicated)" + ("; OVERSUBSCRIBED: %d ranks on %d device(s), gloo, correctness only" % (world, ndev) if oversubscribed else "")
+                                      + ("; collectives forced on a 1-rank RCCL group (--collectives)" if args.collectives and world == 1 else "")},
             "kernel_ms_isolated": kern_iso, "kernel_ms_isolated_steps_per_launch": spc,
-            "roofline": {"bound": "hbm", "kernel": dom,
-                         "measured": "isolated probe loop after the timed region: HIP events (gcc_prof marks on the launch stream) right "
-                                     "before and after the induction inside gcc_sample_multi (one call covers steps_per_launch "
-                                     "consecutive batches, as the producer lanes issue it; two launches of induce_kernel: the small "
-                                     "and the big size class, the sum is what is timed); rocprofv3 --kernel-trace --stats of the "
-                                     "same launches alone: profiles/r4_kernel_stats_sampler_alone*.csv",
-                         "note": "algorithmic bytes = SURVEY 8(d): every member's parent row read once + the output.  Since round 4 "
-                                 "the rows of the (at most 32) highest-degree members of a subgraph are NOT read -- their induced rows "
-                                 "are the mirror images of the other rows' hits (symmetric graph) -- so `achieved` is the rate "
-                                 "of the reference algorithm's bytes, not of bytes moved; `traffic` is what the kernels move"
-                                 + ("" if args.hub_degree >= 0 else " (this run: --hub-degree -1, every row is read)"),
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "algorithmic_bytes_per_launch": acc_call["induce"], "steps_per_launch": spc,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_note": "committed constant from separate rocprofv3 --pmc passes of this build (hash-guarded), not a same-run measurement"},
+            "roofline": roof,
+            "dominant_kernel": {"kernel": roof["kernel"], "bound": roof["bound"], "frac": roof["frac"], "by": roof["dominant_by"]},
+            "sampler_rooflines": samp_roofs, "sampler_dominant_interval": sampler_dom,
             "algorithmic_bytes_per_step": acc,
         }
         if args.mode == "sampler":
             # the whole sampler (five kernels per call, `sampler_steps_per_call` steps per call) against the HBM roof
             e2e = acc["total"] / (ms_per_step * 1e-3) / 1e9
+            moved = sum(v["traffic"] for v in samp_roofs.values()) / spc if all(v["traffic"] for v in samp_roofs.values()) else None
             out["stage_rooflines"] = {"sampler_end_to_end": dict(
                 bound="hbm", algorithmic_bytes_per_step=acc["total"], ms_per_step=ms_per_step, achieved=e2e, peak=HBM_PEAK_GBPS,
-                unit="GB/s", frac=e2e / HBM_PEAK_GBPS, steps_per_call=extra.get("sampler_steps_per_call"),
-                isolated_call_ms=sum(kern_iso.values()))}
+                unit="GB/s", frac=e2e / HBM_PEAK_GBPS, moved_bytes_per_step=moved,
+                frac_moved=(moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS) if moved else None,
+                steps_per_call=extra.get("sampler_steps_per_call"), isolated_call_ms=sum(kern_iso.values()))}
+        if args.mode == "sample-ready" and pe_probe:
+            out["stage_rooflines"] = {"positional_embedding": dict(bound="f32 vector/MFMA rate of the CUs a solver workgroup occupies",
+                                                                   peak_per_cu=F32_PER_CU_GFLOPS, unit="GFLOP/s per CU", **pe_probe)}
         if args.mode in ("train", "e2e"):
             out["config"].update(producer_lanes=args.lanes, producer_depth=args.depth, producer_chunk=chunk,
                                  producer_ahead=trainer.producer.ahead, reserved_cus=args.reserved_cus)
@@ -755,6 +969,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline_sampler(rp, ci, args) if args.mode == "sampler" else cpu_baseline(rp, ci, args)
             if args.mode in ("train", "e2e") and args.posemb == "device":
                 out["cpu_baseline"]["parity_step"] = parity_step(args, graph, dev)
+            if args.mode in ("sampler", "sample-ready"):
+                # the first batch the timed region produced, re-sampled and compared with the C oracle bit for bit
+                out["cpu_baseline"]["parity_batch"] = parity_batch(sampler, rp, ci, args, first_id(first_timed))
+            if args.mode == "sample-ready":
+                q, _ = sampler.sample(first_id(first_timed))
+                ev = torch.zeros(B, 32, device=dev)
+                posemb(q, evals=ev)
+                torch.cuda.synchronize()
+                posemb.check_status(strict=True)
+                out["cpu_baseline"]["parity_posemb"] = parity_posemb(q, q.pos_undirected.cpu().numpy(), ev.cpu().numpy())
+            ref_n = (out["cpu_baseline"].get("reference_shaped") or {}).get("nproc") or {}
+            if ref_n.get("value"):
+                out["cpu_baseline"]["vs_reference_shaped_nproc"] = out["value"] / ref_n["value"]
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

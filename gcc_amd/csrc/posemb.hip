@@ -2257,12 +2257,20 @@ constexpr int kChNarrowWant = GCC_POSEMB_CH_NARROW_WANT;   // items whose quotie
 constexpr int kChNarrowGuards = 8;   // ... and move to the wide one when the first Ritz values show more than 32 - 8 wanted pairs
 constexpr int kChThreads = 1024;
 constexpr int kChCsrCap = 12288;     // directed edges of the deflated subgraph (uint16 column ids in LDS)
-constexpr int kChLongDeg = 96;       // longer rows are cut into chunks of this many entries, summed in chunk order
-#ifndef GCC_POSEMB_CH_CHUNKS
-#define GCC_POSEMB_CH_CHUNKS 64
+#ifndef GCC_POSEMB_CH_LONGDEG
+#define GCC_POSEMB_CH_LONGDEG 32
 #endif
-constexpr int kChMaxChunks = GCC_POSEMB_CH_CHUNKS;   // (16 KB of LDS at 64; an item with more chunks goes to the dense classes)
-constexpr int kChMaxLong = 64;
+// Rows with more kept entries than this are "long": cut into chunks whose partial sums go through the slab, so that a
+// product's critical path is a chunk (or a short row), not the subgraph's densest row.  (Rounds 2-4 used 96 for both the
+// threshold and the chunk length: a hub row of 450 entries was five chunks of 24 dependent gather rounds each on five
+// 8-thread groups, with the other 1000 threads waiting at the barrier behind them, and every row of 33..96 entries was a
+// serial chain of its own in the row pass -- ~28 us per product at n' ~ 300 whether the block sat in LDS or in L2.)
+// The threshold doubles per item until at most half of the chunk slots are long rows; the chunk length is what spreads
+// the long rows' entries over the remaining slots (a multiple of 4, at least 8).
+constexpr int kChLongDeg = GCC_POSEMB_CH_LONGDEG;
+constexpr int kChSlabFloats = 4096;  // 16 KB of partial sums: 64 chunk slots for a 64-column block, 128 for a 32-column one
+constexpr int kChMaxChunks = kChSlabFloats / 32;
+constexpr int kChMaxLong = kChMaxChunks / 2;
 constexpr int kChRounds = 16;      // filter rounds of an item
 constexpr int kChMaxRitz = 5;      // Ritz steps of an item (the first one: values only)
 constexpr float kChTol = 2e-5f;      // residual norm of the wanted Ritz pairs
@@ -2290,7 +2298,7 @@ __host__ __device__ constexpr int cheb_region_bytes()
 }
 __host__ __device__ constexpr int cheb_lds_bytes()
 {
-    return 2 * (kNodeMax + 8) + 2 * kChCsrCap + 4 * kNodeMax + 4 * kChMaxChunks * kChP + cheb_region_bytes();
+    return 2 * (kNodeMax + 8) + 2 * kChCsrCap + 4 * kNodeMax + 4 * kChSlabFloats + cheb_region_bytes();
 }
 
 __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
@@ -2301,6 +2309,8 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     __shared__ double dscd[kChP];
     __shared__ int longrow[kChMaxLong], longfirst[kChMaxLong + 1];
     __shared__ int chunk_beg[kChMaxChunks + 1];
+    __shared__ uint8_t chunk_row[kChMaxChunks], rowx[kNodeMax];      // long-row index of a chunk / of a row (0xFF: short)
+    __shared__ int sh_clen, sh_long_t;
     __shared__ int wsum[kChThreads / 64 + 1];
     __shared__ int sh_item, sh_tot[3], sh_nlong, sh_nchunk, sh_fail;
     __shared__ int colsrc[64];
@@ -2312,8 +2322,8 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     uint16_t *crow = (uint16_t *)smem;                       // [kNodeMax + 1] row offsets of the deflated CSR
     uint16_t *ccol = crow + (kNodeMax + 8);                  // [kChCsrCap]
     float *scale = (float *)(ccol + kChCsrCap);              // [kNodeMax] M' = diag(scale) A' diag(scale)
-    float *slab = scale + kNodeMax;                          // [kChMaxChunks][kChP] partial sums of the long rows
-    unsigned char *region = (unsigned char *)(slab + kChMaxChunks * kChP);
+    float *slab = scale + kNodeMax;                          // [chunk slots][P] partial sums of the long rows (kChSlabFloats)
+    unsigned char *region = (unsigned char *)(slab + kChSlabFloats);
     for (;;) {                                               // items of this class
     __syncthreads();
     if (tid == 0) sh_item = atomicAdd(hd.next + kCls, 1);
@@ -2385,10 +2395,6 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
         if (tid < nr) {
             if (incl > kChCsrCap) sh_fail = 1;               // does not fit: dense classes
             crow[tid + 1] = (uint16_t)(incl > 65535 ? 65535 : incl);
-            if (c > kChLongDeg) {
-                const int slot = atomicAdd(&sh_nlong, 1);
-                if (slot < kChMaxLong) longrow[slot] = tid; else sh_fail = 1;
-            }
         }
     }
     __syncthreads();
@@ -2404,26 +2410,6 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
                 at += __popcll(mk);
             }
         }
-        if (tid == 0) {                                      // chunks of the long rows, rows in index order
-            const int nl = sh_nlong;
-            for (int x = 1; x < nl; ++x) {                   // insertion sort: nl <= 32
-                const int v = longrow[x];
-                int y = x - 1;
-                while (y >= 0 && longrow[y] > v) { longrow[y + 1] = longrow[y]; --y; }
-                longrow[y + 1] = v;
-            }
-            int nc = 0;
-            for (int x = 0; x < nl && !sh_fail; ++x) {
-                longfirst[x] = nc;
-                const int r = longrow[x];
-                for (int e = (int)crow[r]; e < (int)crow[r + 1]; e += kChLongDeg) {
-                    if (nc >= kChMaxChunks) { sh_fail = 1; break; }
-                    chunk_beg[nc++] = e;
-                }
-            }
-            longfirst[nl] = nc;
-            sh_nchunk = nc;
-        }
     }
     __syncthreads();
     // what the expansion at the end needs of the tables -> workspace, 8 bytes per node (the dense matrices overlay the tables)
@@ -2431,11 +2417,43 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     for (int v = tid; v < n; v += kChThreads) defl_record(d, v, rp, a.col_idx, n0, xrec + 4 * v);
     __syncthreads();
     PHASE_TICK(0);                                           // deflation + sparse matrix
-    const int nchunk = sh_nchunk;
     bool failed = sh_fail != 0;
-#ifdef GCC_AMD_HIPEMU
-    if (getenv("GCC_POSEMB_DEBUG") && tid == 0) fprintf(stderr, "cheb item b=%d n=%d nr=%d nnz=%d nlong=%d nchunk=%d fail=%d\n", b, n, nr, (int)crow[nr], sh_nlong, nchunk, sh_fail);
-#endif
+    // Long rows -> chunk tables for `slots` chunk slots (all threads; ends with a barrier).  Row r = thread r.
+    auto build_chunks = [&](int slots) {
+        const int len = (tid < nr && !failed) ? (int)crow[tid + 1] - (int)crow[tid] : 0;
+        auto block_scan = [&](int v, int &total) -> int {                // exclusive prefix of v over the workgroup
+            int incl = wave_scan_incl(v);
+            if (lane == 63) wsum[wv] = incl;
+            __syncthreads();
+            int base = 0, tot = 0;
+            for (int q = 0; q < kNW; ++q) { if (q < wv) base += wsum[q]; tot += wsum[q]; }
+            __syncthreads();
+            total = tot;
+            return incl - v + base;
+        };
+        int T = kChLongDeg, nl = 0, x = 0;
+        for (;;) {                                                       // block-uniform: at most half of the slots are rows
+            x = block_scan(len > T ? 1 : 0, nl);
+            if (nl <= slots / 2) break;
+            T *= 2;
+        }
+        const bool lg = len > T;
+        int total = 0;
+        (void)block_scan(lg ? len : 0, total);
+        int clen = nl ? (total + (slots - nl) - 1) / (slots - nl) : 8;
+        clen = clen < 8 ? 8 : (clen + 3) & ~3;
+        const int nch = lg ? (len + clen - 1) / clen : 0;
+        int nc = 0;
+        const int fx = block_scan(nch, nc);                              // nc <= total / clen + nl <= slots
+        if (tid < nr) rowx[tid] = lg ? (uint8_t)x : (uint8_t)0xFF;
+        if (lg) {
+            longrow[x] = tid;
+            longfirst[x] = fx;
+            for (int j = 0; j < nch; ++j) { chunk_beg[fx + j] = (int)crow[tid] + j * clen; chunk_row[fx + j] = (uint8_t)x; }
+        }
+        if (tid == 0) { longfirst[nl] = nc; sh_nlong = nl; sh_nchunk = nc; sh_clen = clen; sh_long_t = T; }
+        __syncthreads();
+    };
     const int kq = min(k, nr);
     const bool build_failed = failed;
     // The solve itself, for a block of P columns (P = 64: k <= 32 wanted + guards, rounds 2-4; P = 32: round 5).  Of the
@@ -2454,6 +2472,11 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     constexpr int TPQ = P / 4;                               // ... in the rotation / tile loads (4 columns each)
     bool failed = build_failed;
     float *XA = XA0, *XB = XB0, *XC = XC0;
+    build_chunks(kChSlabFloats / P);
+    const int nchunk = sh_nchunk, nlong = sh_nlong, clen = sh_clen, longT = sh_long_t;
+#ifdef GCC_AMD_HIPEMU
+    if (getenv("GCC_POSEMB_DEBUG") && tid == 0) fprintf(stderr, "cheb item b=%d n=%d nr=%d nnz=%d nlong=%d nchunk=%d fail=%d P=%d clen=%d T=%d\n", b, n, nr, (int)crow[nr], nlong, nchunk, sh_fail, P, clen, longT);
+#endif
 
     // dst = alpha * (M' src - center * src) - gamma * dst   (rows of 64 floats; 16 threads x float4 per row)
     // 8 threads per row (8 block vectors = 2 x float4 each), 128 rows at a time, four gathers per vector pair in flight.
@@ -2493,30 +2516,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     auto spmm_body = [&](auto in_lds, const float *src, float *dst, float alpha, float center, float gamma) {
         const float *base = decltype(in_lds)::value ? (const float *)region : src;
         const int q8 = 8 * (tid % TPR), g8 = tid / TPR;
-        for (int c = g8; c < nchunk; c += kChThreads / TPR) {              // chunks of the long rows -> slab
-            int x = 0;
-            while (longfirst[x + 1] <= c) ++x;
-            const int r = longrow[x];
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            gather(in_lds, src, chunk_beg[c], min(chunk_beg[c] + kChLongDeg, (int)crow[r + 1]), acc);
-            *(float4 *)(slab + c * P + q8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            *(float4 *)(slab + c * P + q8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-        }
-        if (nchunk) __syncthreads();
-        for (int r = g8; r < nr; r += kChThreads / TPR) {
-            const int e0 = (int)crow[r], e1 = (int)crow[r + 1];
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (e1 - e0 > kChLongDeg) {
-                int x = 0;
-                while (longrow[x] != r) ++x;
-                for (int c = longfirst[x]; c < longfirst[x + 1]; ++c) {
-                    const float4 pa = *(const float4 *)(slab + c * P + q8), pb = *(const float4 *)(slab + c * P + q8 + 4);
-                    acc[0] += pa.x; acc[1] += pa.y; acc[2] += pa.z; acc[3] += pa.w;
-                    acc[4] += pb.x; acc[5] += pb.y; acc[6] += pb.z; acc[7] += pb.w;
-                }
-            } else {
-                gather(in_lds, src, e0, e1, acc);
-            }
+        auto finish = [&](int r, const float *acc) {
             const float sr = scale[r];
             const float4 oa = *(const float4 *)(base + (int64_t)r * P + q8), ob = *(const float4 *)(base + (int64_t)r * P + q8 + 4);
             float o[8] = {alpha * (sr * acc[0] - center * oa.x), alpha * (sr * acc[1] - center * oa.y),
@@ -2530,6 +2530,32 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             }
             *(float4 *)(dst + (int64_t)r * P + q8) = make_float4(o[0], o[1], o[2], o[3]);
             *(float4 *)(dst + (int64_t)r * P + q8 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        };
+        for (int c = g8; c < nchunk; c += kChThreads / TPR) {            // chunks of the long rows -> slab ...
+            const int r = longrow[chunk_row[c]];
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            gather(in_lds, src, chunk_beg[c], min(chunk_beg[c] + clen, (int)crow[r + 1]), acc);
+            *(float4 *)(slab + c * P + q8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *(float4 *)(slab + c * P + q8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+        for (int r = g8; r < nr; r += kChThreads / TPR) {                // ... and the short rows, in the same pass
+            const int e0 = (int)crow[r], e1 = (int)crow[r + 1];
+            if (e1 - e0 > longT) continue;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            gather(in_lds, src, e0, e1, acc);
+            finish(r, acc);
+        }
+        if (nchunk) {
+            __syncthreads();
+            for (int x = g8; x < nlong; x += kChThreads / TPR) {         // the long rows: sums of their chunks, in chunk order
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int c = longfirst[x]; c < longfirst[x + 1]; ++c) {
+                    const float4 pa = *(const float4 *)(slab + c * P + q8), pb = *(const float4 *)(slab + c * P + q8 + 4);
+                    acc[0] += pa.x; acc[1] += pa.y; acc[2] += pa.z; acc[3] += pa.w;
+                    acc[4] += pb.x; acc[5] += pb.y; acc[6] += pb.z; acc[7] += pb.w;
+                }
+                finish(longrow[x], acc);
+            }
         }
         __syncthreads();
     };
@@ -2545,45 +2571,54 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     auto filter_step_lds = [&](float *prev, float alpha, float center, float gamma) {
         float *xs = (float *)region;
         const int q8 = 8 * (tid % TPR), g8 = tid / TPR;
-        for (int c = g8; c < nchunk; c += RPP) {                         // chunks of the long rows -> slab
-            int x = 0;
-            while (longfirst[x + 1] <= c) ++x;
-            const int r = longrow[x];
+        float nw[kPasses][8];
+        auto finish = [&](int ps, int r, const float *acc) {             // -> nw[ps]; Y_{i-1}'s row becomes the next step's Y_{i-2}
+            float4 da = make_float4(0.f, 0.f, 0.f, 0.f), db = da;
+            float *pr_ = prev + (int64_t)r * P + q8;
+            if (gamma != 0.f) { da = *(const float4 *)pr_; db = *(const float4 *)(pr_ + 4); }
+            const float sr = scale[r];
+            const float4 oa = *(const float4 *)(xs + r * P + q8), ob = *(const float4 *)(xs + r * P + q8 + 4);
+            nw[ps][0] = alpha * (sr * acc[0] - center * oa.x) - gamma * da.x; nw[ps][1] = alpha * (sr * acc[1] - center * oa.y) - gamma * da.y;
+            nw[ps][2] = alpha * (sr * acc[2] - center * oa.z) - gamma * da.z; nw[ps][3] = alpha * (sr * acc[3] - center * oa.w) - gamma * da.w;
+            nw[ps][4] = alpha * (sr * acc[4] - center * ob.x) - gamma * db.x; nw[ps][5] = alpha * (sr * acc[5] - center * ob.y) - gamma * db.y;
+            nw[ps][6] = alpha * (sr * acc[6] - center * ob.z) - gamma * db.z; nw[ps][7] = alpha * (sr * acc[7] - center * ob.w) - gamma * db.w;
+            *(float4 *)pr_ = oa;
+            *(float4 *)(pr_ + 4) = ob;
+        };
+        for (int c = g8; c < nchunk; c += RPP) {                         // chunks of the long rows -> slab ...
+            const int r = longrow[chunk_row[c]];
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            gather(LdsYes(), xs, chunk_beg[c], min(chunk_beg[c] + kChLongDeg, (int)crow[r + 1]), acc);
+            gather(LdsYes(), xs, chunk_beg[c], min(chunk_beg[c] + clen, (int)crow[r + 1]), acc);
             *(float4 *)(slab + c * P + q8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             *(float4 *)(slab + c * P + q8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
         }
-        if (nchunk) __syncthreads();
-        float nw[kPasses][8];
 #pragma unroll
-        for (int ps = 0; ps < kPasses; ++ps) {
+        for (int ps = 0; ps < kPasses; ++ps) {                           // ... and this thread's short rows, in the same pass
             const int r = g8 + ps * RPP;
             if (r < nr) {
-                float4 da = make_float4(0.f, 0.f, 0.f, 0.f), db = da;
-                float *pr_ = prev + (int64_t)r * P + q8;
-                if (gamma != 0.f) { da = *(const float4 *)pr_; db = *(const float4 *)(pr_ + 4); }      // requested before the gathers
                 const int e0 = (int)crow[r], e1 = (int)crow[r + 1];
-                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (e1 - e0 > kChLongDeg) {
-                    int x = 0;
-                    while (longrow[x] != r) ++x;
+                if (e1 - e0 <= longT) {
+                    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    gather(LdsYes(), xs, e0, e1, acc);
+                    finish(ps, r, acc);
+                }
+            }
+        }
+        if (nchunk) {
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < kPasses; ++ps) {                       // this thread's long rows: sums of their chunks, in chunk order
+                const int r = g8 + ps * RPP;
+                if (r < nr && rowx[r] != 0xFF) {
+                    const int x = rowx[r];
+                    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     for (int c = longfirst[x]; c < longfirst[x + 1]; ++c) {
                         const float4 pa = *(const float4 *)(slab + c * P + q8), pb = *(const float4 *)(slab + c * P + q8 + 4);
                         acc[0] += pa.x; acc[1] += pa.y; acc[2] += pa.z; acc[3] += pa.w;
                         acc[4] += pb.x; acc[5] += pb.y; acc[6] += pb.z; acc[7] += pb.w;
                     }
-                } else {
-                    gather(LdsYes(), xs, e0, e1, acc);
+                    finish(ps, r, acc);
                 }
-                const float sr = scale[r];
-                const float4 oa = *(const float4 *)(xs + r * P + q8), ob = *(const float4 *)(xs + r * P + q8 + 4);
-                nw[ps][0] = alpha * (sr * acc[0] - center * oa.x) - gamma * da.x; nw[ps][1] = alpha * (sr * acc[1] - center * oa.y) - gamma * da.y;
-                nw[ps][2] = alpha * (sr * acc[2] - center * oa.z) - gamma * da.z; nw[ps][3] = alpha * (sr * acc[3] - center * oa.w) - gamma * da.w;
-                nw[ps][4] = alpha * (sr * acc[4] - center * ob.x) - gamma * db.x; nw[ps][5] = alpha * (sr * acc[5] - center * ob.y) - gamma * db.y;
-                nw[ps][6] = alpha * (sr * acc[6] - center * ob.z) - gamma * db.z; nw[ps][7] = alpha * (sr * acc[7] - center * ob.w) - gamma * db.w;
-                *(float4 *)pr_ = oa;                                     // Y_{i-1} becomes the next step's Y_{i-2}
-                *(float4 *)(pr_ + 4) = ob;
             }
         }
         __syncthreads();                                                 // every gather of Y_{i-1} is done
@@ -2923,6 +2958,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             for (int u = 0; u < E; ++u) Af[mi * P + mj + u] = c[u] * di;
         }
         __syncthreads();
+        PHASE_TICK(8);                                           // C matrix
         // ---- X <- X C into the free buffer (W C stays in registers); residuals ||W_i - theta_i X_i||^2 accumulated per
         //      thread, then over the 64 row groups
         {

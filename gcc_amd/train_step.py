@@ -202,6 +202,17 @@ class BatchProducer:
         if keep[1] is not None:
             posemb._next = keep[1]
 
+    def prefill(self):
+        """Launch the chunks the first :meth:`get` would launch (chunk 0 and the look-ahead) without consuming anything:
+        the data pipeline primed, as a DataLoader's workers fill their prefetch queues before the first iteration
+        (train.py:577-586).  bench.py calls it before the warm-up steps so that the step count it is asked for is the step
+        count it runs."""
+        horizon = self.ahead if self.cuda else 0
+        while self.next_chunk <= horizon:
+            if self.next_chunk not in self.ready:
+                self._launch(self.next_chunk)
+            self.next_chunk += 1
+
     def get(self, step, prof=None):
         """Batch of ``step`` (made ready on the current stream); keeps lanes * (depth - 1) chunks in flight."""
         self.prof = prof
@@ -418,28 +429,54 @@ class _GraphedStep:
                 self.graph_replays += 1
                 return dict(hit[1])
             out = self._run_segments(body(scalars, pr))                  # first time this ring slot is consumed: eager ...
-            steps0 = self.optimizer.steps
-            segments, result = body(scalars, {})                         # ... then captured for the next time
-            items, pool = [], None
-            for capturable, fn in segments:
-                if not capturable:
-                    items.append(fn)                                     # (collectives: not run now, issued at every replay)
-                    continue
-                gobj = torch.cuda.CUDAGraph()
-                gobj.capture_begin(capture_error_mode="thread_local", **({} if pool is None else dict(pool=pool)))
-                try:
-                    fn()
-                finally:
-                    gobj.capture_end()
-                pool = pool or gobj.pool()                               # later segments read what earlier ones allocated
-                items.append(gobj)
-            cap = result()
-            self.optimizer.steps = steps0                                # the captured body counted a step that did not run
-            self.graphs[key] = (items, dict(loss=cap["loss"], prob=cap["prob"], grad_norm=cap["grad_norm"]))
+            first_ever = not self.graphs and not self._retired_graphs
+            self._capture(key, body)                                     # ... then captured for the next time
+            if first_ever:
+                self._precapture_ready(st)
             return out
         except Exception:
             self._ring_dirty = scalars is not None
             raise
+
+    def _capture(self, key, body):
+        """Record ``body``'s launches for ring slot ``key`` (nothing executes): one CUDAGraph per capturable segment, all from
+        one memory pool (later segments read what earlier ones allocated)."""
+        steps0 = self.optimizer.steps
+        segments, result = body(self.scalars, {})
+        items, pool = [], None
+        for capturable, fn in segments:
+            if not capturable:
+                items.append(fn)                                         # (collectives: not run now, issued at every replay)
+                continue
+            gobj = torch.cuda.CUDAGraph()
+            gobj.capture_begin(capture_error_mode="thread_local", **({} if pool is None else dict(pool=pool)))
+            try:
+                fn()
+            finally:
+                gobj.capture_end()
+            pool = pool or gobj.pool()
+            items.append(gobj)
+        cap = result()
+        self.optimizer.steps = steps0                                    # the captured body counted a step that did not run
+        self.graphs[key] = (items, dict(loss=cap["loss"], prob=cap["prob"], grad_norm=cap["grad_norm"]))
+
+    def _precapture_ready(self, st):
+        """Right after the FIRST step of a run (launched eagerly: every lazily allocated engine buffer exists now), the graphs
+        of all the other ring slots the producers have already filled or are filling -- the look-ahead chunks -- are captured
+        as well, without an eager step of their own: a capture only records.  The steps that consume those slots are replays
+        from the start instead of each paying an eager issue + a capture (+ 0.6 ms per step over the first lanes x depth x
+        chunk steps of a run: what a 20-step window right after 5 warm-up steps measured)."""
+        prod = getattr(self, "producer", None)
+        if prod is None or not hasattr(self, "_capture_body"):
+            return
+        self.graphs_precaptured = 0
+        for c in sorted(prod.ready):
+            pairs, _ev = prod.ready[c]
+            for q, k in pairs:
+                key = self._slot_key(q, k)
+                if key not in self.graphs:
+                    self._capture(key, self._capture_body(q, k, st))
+                    self.graphs_precaptured += 1
 
     def _fetch_scalars(self, scalars, st):
         """first launch of a step that uses the device-resident scalars: this step's ring entry -> the device struct"""
@@ -618,6 +655,10 @@ class MoCoTrainStep(_GraphedStep):
         self.producer.release(step)
         return dict(out, graph_q=q, graph_k=k)
 
+    def _capture_body(self, q, k, st):
+        seed = 0 if self.model.gnn.drop.p > 0 else None              # (with scalars only dropout on / off matters here)
+        return lambda scalars, marks: self._body(q, k, None, seed, scalars, marks, st)
+
     def _body(self, q, k, keep, seed, scalars, pr, st):
         """The launches of one step on the current stream as (segments, result) for :meth:`_run_step` (eager, or under stream
         capture).  ``scalars``: device gcc_step_scalars the Adam / enqueue / dropout kernels read instead of by-value
@@ -741,6 +782,10 @@ class E2ETrainStep(_GraphedStep):
                              lambda scalars, marks: self._body(q, k, keep_q, keep_k, s0, scalars, marks, st))
         self.producer.release(step)
         return dict(out, graph_q=q, graph_k=k)
+
+    def _capture_body(self, q, k, st):
+        s0 = 0 if self.model.gnn.drop.p > 0 else None
+        return lambda scalars, marks: self._body(q, k, None, None, s0, scalars, marks, st)
 
     def _body(self, q, k, keep_q, keep_k, s0, scalars, pr, st):
         S = {}

@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(collectives, graph=None, steps=20):
+def _run(collectives, use_graph=None, steps=20):
     from gcc_amd.contrast import MemoryMoCo
     from gcc_amd.encoder import GraphEncoder
     from gcc_amd.graph import DeviceGraph
@@ -36,7 +36,7 @@ def _run(collectives, graph=None, steps=20):
         smp = DeviceRWRSampler(graph, B, run_seed=3, num_buffers=depth * chunk, max_steps=chunk)
         lanes.append((smp, DevicePosEmb(B, smp.node_cap, 32, device=dev, seed=3, num_buffers=depth * chunk, max_views=2 * chunk)))
     tr = MoCoTrainStep(model, ema, contrast, lanes[0][0], lanes[0][1], lanes=lanes, depth=depth, chunk=chunk,
-                       collectives=collectives, graph=graph)
+                       collectives=collectives, graph=use_graph)
     tr.dropout_seed = 11
     tr.relaxed_streams = True                  # the bench / train.py loops: no per-step stream hand-offs
     outs = [tr.step(i, 0.005) for i in range(steps)]
@@ -56,12 +56,14 @@ def test_step_with_rccl_collectives_matches_the_step_without():
     _, ref, ref_w, ref_mem = _run(False)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
-        tr_e, eager, eager_w, eager_mem = _run(True, graph=False)
+        tr_e, eager, eager_w, eager_mem = _run(True, use_graph=False)
         tr_g, seg, seg_w, seg_mem = _run(True)               # default with collectives on a device: segmented replay
     finally:
         dist.destroy_process_group()
     assert not tr_e.use_graph and tr_e.graph_replays == 0
-    assert tr_g.use_graph and tr_g.graph_replays == 20 - 8   # 2 lanes x depth 2 x chunk 2 ring slots, captured once each
+    # 2 lanes x depth 2 x chunk 2 = 8 ring slots: step 0 is eager, the 5 other slots of the look-ahead chunks 0..2 are captured
+    # right after it, chunk 3's two slots on their first use
+    assert tr_g.use_graph and tr_g.graph_replays == 20 - 3 and len(tr_g.graphs) == 8
     for items, _ in tr_g.graphs.values():
         kinds = [isinstance(it, torch.cuda.CUDAGraph) for it in items]
         assert kinds == [True, False, True, False, True]     # forward | gather begins | head + backward | reduce, join | update

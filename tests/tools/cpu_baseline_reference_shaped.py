@@ -28,7 +28,14 @@ _G = {}
 
 
 def _init(rp, ci, rw_hops, restart, clear):
+    # one thread per worker process, as a DataLoader worker has: without this every worker's OpenMP runtime (the C walker's
+    # library) starts one thread per core -- 256 x 256 spinning threads on the GPU box made 256 workers 4x SLOWER than 12
+    os.environ["OMP_NUM_THREADS"] = "1"
     import scipy.sparse as sp
+
+    if isinstance(rp, str):                                 # paths of .npy files (run_timed with many workers: the graph is
+        rp, ci = np.load(rp, mmap_mode="r"), np.load(ci, mmap_mode="r")   # mapped, not pickled into every worker)
+        rp, ci = np.asarray(rp), np.asarray(ci)
     import torch
 
     from oracle import posemb as P
@@ -91,19 +98,31 @@ def run_timed(rp, ci, procs, seconds, clear=True, rw_hops=256, restart=0.8, star
     """The same loop under a time budget (bench.py's cpu_baseline leg): worker processes keep drawing samples until
     ``seconds`` have passed.  ``start``: "spawn" when the parent holds a HIP context (fork + HIP is unsafe).
     -> (subgraphs/s, seconds, samples)"""
-    with mp.get_context(start).Pool(procs, initializer=_init, initargs=(rp, ci, rw_hops, restart, clear)) as pool:
-        # (every wait is bounded: a worker that dies must not hang the caller)
-        pool.map_async(_one_sample, list(range(9_000_000, 9_000_000 + procs))).get(timeout=120)   # warm the workers (imports, ARPACK)
-        first, done = 10_000_000, 0
-        t = time.time()
-        while True:
-            ids = list(range(first, first + 8 * procs))
-            pool.map_async(_one_sample, ids, chunksize=2).get(timeout=120)
-            first += len(ids)
-            done += len(ids)
-            dt = time.time() - t
-            if dt >= seconds:
-                break
+    import tempfile
+
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=shm) as tmp:
+        # the graph goes to the workers as two mapped .npy files, not pickled into every one of them (256 workers x 50 MB)
+        np.save(os.path.join(tmp, "rp.npy"), rp)
+        np.save(os.path.join(tmp, "ci.npy"), ci)
+        with mp.get_context(start).Pool(procs, initializer=_init,
+                                        initargs=(os.path.join(tmp, "rp.npy"), os.path.join(tmp, "ci.npy"), rw_hops, restart, clear)) as pool:
+            return _timed_loop(pool, procs, seconds)
+
+
+def _timed_loop(pool, procs, seconds):
+    # (every wait is bounded: a worker that dies must not hang the caller)
+    pool.map_async(_one_sample, list(range(9_000_000, 9_000_000 + procs))).get(timeout=300)   # warm the workers (imports, ARPACK)
+    first, done = 10_000_000, 0
+    t = time.time()
+    while True:
+        ids = list(range(first, first + 8 * procs))
+        pool.map_async(_one_sample, ids, chunksize=2).get(timeout=120)
+        first += len(ids)
+        done += len(ids)
+        dt = time.time() - t
+        if dt >= seconds:
+            break
     return 2 * done / dt, dt, done
 
 

@@ -27,7 +27,7 @@ lib.gcc_posemb_debug_ticks(None)
 t = ticks.cpu().numpy().reshape(NCLS, 16)
 print("multi call of %d views: %.2f ms" % (len(views), e0.elapsed_time(e1)))
 names = {0: ["matrix", "tridiag", "bisect", "invit", "gram-schmidt", "backtransf", "expand"], 3: ["arnoldi", "ritz(H)", "restart", "final"],
-         5: ["matrix", "sparse-products", "ritz", "rotate", "expand", "gram", "cholesky", "inverse+H"]}
+         5: ["matrix", "sparse-products", "ritz", "rotate", "expand", "gram", "cholesky", "inverse+H", "c-matrix"]}
 grand = 0.0
 for c, cname in enumerate(["small", "mid", "slot", "krylov", "big", "cheb", "wave48", "wave64"]):
     items = max(int(t[c, 15]), 1)
