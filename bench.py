@@ -982,7 +982,13 @@ def main():
             ref_n = (out["cpu_baseline"].get("reference_shaped") or {}).get("nproc") or {}
             if ref_n.get("value"):
                 out["cpu_baseline"]["vs_reference_shaped_nproc"] = out["value"] / ref_n["value"]
-        print(json.dumps(out))
+        try:                                     # (RCCL's version banner sits in the C library's stdout buffer until exit: out first,
+            import ctypes                        #  so that the JSON line is the LAST line of stdout)
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

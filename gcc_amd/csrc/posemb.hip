@@ -2714,29 +2714,42 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
             float *tx = slab, *twv = slab + TR * P;              // [TR][P] each
             const bool isw = tid >= kChThreads / 2;
             const int lt = tid & (kChThreads / 2 - 1);            // float4 index inside a tile: row lt / TPQ, quad lt % TPQ
-            const float *gsrc = isw ? XB : XA;
+            // with a Ritz step the second half of the workgroup stages W's tile (K = X^T W); without one it stages the NEXT
+            // tile of X, so a barrier pair covers 2 TR rows (the loop is bound by its barriers and the L2 latency of a tile)
+            const float *gsrc = (isw && rr) ? XB : XA;
+            const int step = rr ? TR : 2 * TR, toff = (isw && !rr) ? TR : 0;
             auto fetch = [&](int t0) -> float4 {
-                const int r = t0 + lt / TPQ;
-                return (r < nr && (!isw || rr)) ? *(const float4 *)(gsrc + (int64_t)r * P + 4 * (lt % TPQ)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int r = t0 + toff + lt / TPQ;
+                return r < nr ? *(const float4 *)(gsrc + (int64_t)r * P + 4 * (lt % TPQ)) : make_float4(0.f, 0.f, 0.f, 0.f);
             };
             float4 nxt = fetch(0);
-            for (int t0 = 0; t0 < nr; t0 += TR) {
+            for (int t0 = 0; t0 < nr; t0 += step) {
                 *(float4 *)((isw ? twv : tx) + 4 * lt) = nxt;
                 __syncthreads();
-                if (t0 + TR < nr) nxt = fetch(t0 + TR);
-                const int rows = min(TR, nr - t0);
-                for (int r = 0; r < rows; ++r) {
-                    const double xi = (double)tx[r * P + mi];
-                    if constexpr (E == 4) {
-                        const float4 xj = *(const float4 *)(tx + r * P + mj);
-                        gacc[0] += xi * xj.x; gacc[1] += xi * xj.y; gacc[2] += xi * xj.z; gacc[3] += xi * xj.w;
-                        if (rr) {                                // block-uniform
+                if (t0 + step < nr) nxt = fetch(t0 + step);
+                const int rows = min(step, nr - t0);             // (without a Ritz step tx and twv are one tile of 2 TR rows)
+                if (rr) {
+                    for (int r = 0; r < rows; ++r) {
+                        const double xi = (double)tx[r * P + mi];
+                        if constexpr (E == 4) {
+                            const float4 xj = *(const float4 *)(tx + r * P + mj);
                             const float4 wj = *(const float4 *)(twv + r * P + mj);
+                            gacc[0] += xi * xj.x; gacc[1] += xi * xj.y; gacc[2] += xi * xj.z; gacc[3] += xi * xj.w;
                             kacc[0] += xi * wj.x; kacc[1] += xi * wj.y; kacc[2] += xi * wj.z; kacc[3] += xi * wj.w;
+                        } else {
+                            gacc[0] += xi * tx[r * P + mj];
+                            kacc[0] += xi * twv[r * P + mj];
                         }
-                    } else {
-                        gacc[0] += xi * tx[r * P + mj];
-                        if (rr) kacc[0] += xi * twv[r * P + mj];
+                    }
+                } else {
+                    for (int r = 0; r < rows; ++r) {
+                        const double xi = (double)tx[r * P + mi];
+                        if constexpr (E == 4) {
+                            const float4 xj = *(const float4 *)(tx + r * P + mj);
+                            gacc[0] += xi * xj.x; gacc[1] += xi * xj.y; gacc[2] += xi * xj.z; gacc[3] += xi * xj.w;
+                        } else {
+                            gacc[0] += xi * tx[r * P + mj];
+                        }
                     }
                 }
                 __syncthreads();
@@ -2970,18 +2983,21 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
                 for (int which = 0; which < (fullrr ? 2 : 1); ++which) {
                     const float *src = (which ? XB : XA) + (int64_t)r * P;
                     float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+                    // 16 columns (4 x 16 bytes) of the row in flight at once.  (Rounds 2-4 kept 32: with the 128 registers a
+                    // 1024-thread workgroup leaves per lane that loop body spilled 38 values per iteration -- the rotation of a
+                    // 32-column block took twice as long as that of a 64-column one.)
 #pragma unroll 1
-                    for (int half = 0; half < P / 32; ++half) {          // 32 columns (8 x 16 bytes) in flight at once
-                        float4 rowv[8];
+                    for (int part = 0; part < P / 16; ++part) {
+                        float4 rowv[4];
 #pragma unroll
-                        for (int p = 0; p < 8; ++p) rowv[p] = *(const float4 *)(src + 32 * half + 4 * p);
+                        for (int p = 0; p < 4; ++p) rowv[p] = *(const float4 *)(src + 16 * part + 4 * p);
 #pragma unroll
-                        for (int p = 0; p < 8; ++p) {
+                        for (int p = 0; p < 4; ++p) {
                             const float4 rv = rowv[p];
                             const float xs[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
-                                const float4 cv = *(const float4 *)(Af + (32 * half + 4 * p + u) * P + q4);
+                                const float4 cv = *(const float4 *)(Af + (16 * part + 4 * p + u) * P + q4);
                                 o0 = fmaf(xs[u], cv.x, o0); o1 = fmaf(xs[u], cv.y, o1);
                                 o2 = fmaf(xs[u], cv.z, o2); o3 = fmaf(xs[u], cv.w, o3);
                             }

@@ -84,7 +84,11 @@ def _cmp_grads_and_update(model, flat_grad, oracle, init, after, report, truth=N
                                    msg=lambda m, n=n: f"grad {n}: {m}")
         worst = max(worst, float((got - gref).abs().max()) / scale)
         if float(gref.abs().max()) > 1e-6:
-            solid = gref.abs() > 1e-2 * float(gref.abs().max())
+            # elements whose gradient stands clear of rounding noise: 1 % of the tensor's largest entry AND four times the fp32
+            # oracle's own distance from the float64 run on this tensor (a first Adam step moves every element by lr * sign(g):
+            # where the fp32 oracle's sign is noise -- seen on 1 element of 4096 with err32 = 3e-3 of scale -- its update is no
+            # reference)
+            solid = gref.abs() > max(1e-2 * float(gref.abs().max()), 4 * err32)
             upd, upd_ref = (after[n] - init[n])[solid], (ref_after[n] - init[n])[solid]
             torch.testing.assert_close(upd, upd_ref, rtol=5e-3, atol=2e-5, msg=lambda m, n=n: f"update {n}: {m}")
             checked += int(solid.sum())
