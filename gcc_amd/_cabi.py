@@ -36,6 +36,9 @@ class GccGraph(ctypes.Structure):
         ("shard_off", ctypes.c_void_p),
         ("num_shards", ctypes.c_int32),
         ("flags", ctypes.c_int32),
+        ("hub_index", ctypes.c_void_p), ("hub_adj", ctypes.c_void_p),
+        ("num_hubs", ctypes.c_int32), ("hub_words", ctypes.c_int32),
+        ("hub_table_degree", ctypes.c_int32), ("reserved_", ctypes.c_int32),
     ]
 
 

@@ -151,6 +151,10 @@ struct Work {
     int32_t ncap;
     int32_t nseg;         // batch segments of this call: 2 (views q, k) per step; subgraph g = segment * B + b
     int64_t unit_cap;
+    // adjacency among the parent's high-degree rows (gcc_graph.hub_index / hub_adj), or NULL: hub pairs are searched
+    const int32_t *hub_index;
+    const uint32_t *hub_adj;
+    int32_t hub_words;
 };
 
 struct WorkLayout {
@@ -493,7 +497,14 @@ __global__ __launch_bounds__(kT) void rwr_walk_kernel(
         atomicAdd(&hubcnt[c], 1);
         atomicAdd(&w.sub_nnz[g], 2);
     };
-    if (npairs > 0 && npairs <= 48) {                    // (block-uniform)
+    if (npairs > 0 && w.hub_index) {                     // (block-uniform) one bit probe per pair in the parent's hub-hub table
+        for (int pr = tid; pr < nh * nh; pr += kT) {
+            const int a = pr / nh, c = pr - a * nh;
+            if (a >= c) continue;
+            const int ia = w.hub_index[nodes[hubloc[a]]], ic = w.hub_index[nodes[hubloc[c]]];   // (both >= 0: degree >= the table's threshold)
+            if ((w.hub_adj[(int64_t)ia * w.hub_words + (ic >> 5)] >> (ic & 31)) & 1u) found(a, c);
+        }
+    } else if (npairs > 0 && npairs <= 48) {             // (block-uniform)
         // few pairs (the usual case): a team of 16 lanes per pair narrows the range 16-fold per round of loads -- 2 to 5
         // dependent loads for rows of 256 .. 1M entries where a one-lane binary search has 8 to 20
         const int lane = tid & 63, team = tid >> 4, sl = tid & 15, tsh = (lane >> 4) * 16;
@@ -746,6 +757,7 @@ __device__ __forceinline__ bool scratch_overflows(const Work &w, int g, int64_t 
 
 // ------------------------------------------------------------------ K2 ----
 static int g_dbg_grids[3] = {0, 0, 0};           // diagnostics (gcc_sampler_debug_grids): small / big induce grid, big walk grid
+static const bool g_use_hub_table = [] { const char *e = getenv("GCC_SAMPLER_HUB_TABLE"); return !e || atoi(e) != 0; }();   // A/B knob: 0 = search every hub pair
 static long long *g_induce_ticks = nullptr;      // diagnostics (gcc_sampler_debug_ticks): [0..2] phase ticks, [15] workgroups
 #define IND_TICK(ph) do { if (ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&ticks[ph], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 template <int kT>
@@ -1354,6 +1366,11 @@ int32_t gcc_sample_multi(const gcc_graph *g, const gcc_sample_params *p, int32_t
     if (lds2 > 64 * 1024) (void)hipFuncSetAttribute((const void *)induce_kernel<kInduceBigThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
 #endif
     const int64_t *shards = g->num_shards > 1 ? g->shard_off : nullptr;
+    // the hub-hub table serves a call whose hubs all have at least the table's degree (GCC_SAMPLER_HUB_TABLE=0: searches, for A/B)
+    const bool table = g->hub_index && g->hub_adj && g->num_hubs > 0 && hub_degree != 0x7FFFFFFF && hub_degree >= g->hub_table_degree && g_use_hub_table;
+    w.hub_index = table ? g->hub_index : nullptr;
+    w.hub_adj = table ? g->hub_adj : nullptr;
+    w.hub_words = g->hub_words;
     if (p2max > p2small) (void)hipMemsetAsync(w.big, 0, 4, s);
     hipLaunchKernelGGL((rwr_walk_kernel<kWalkThreads, false>), dim3(G), dim3(kWalkThreads), lds1, s, g->row_ptr, g->col_idx, g->seed_cdf,
                        g->ltab, g->num_nodes, g->ltab_len, p2small, p->run_seed, p->first_sample_id, sample_id_stride, B,

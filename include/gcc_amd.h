@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 /* 2: gcc_sample_params.{hub_degree,max_hubs}, gcc_gin_weights.hidden, gcc_gin_pass.scalars, gcc_ginw_args.{scratch,
- * scratch_bytes,num_nodes}, gcc_graph.flags.  A caller built against another version must not pass its structs:
+ * scratch_bytes,num_nodes}, gcc_graph.{flags,hub_index,hub_adj,num_hubs,hub_words,hub_table_degree}.  A caller built against another version must not pass its structs:
  * compare gcc_abi_version() with the header's constant after loading (gcc_amd/_cabi.py does). */
 #define GCC_AMD_ABI_VERSION 2
 
@@ -89,6 +89,14 @@ typedef struct gcc_graph {
     const int64_t *shard_off; /* device [num_shards + 1] or NULL                      */
     int32_t num_shards;
     int32_t flags;            /* GCC_GRAPH_* bits                                     */
+    /* Optional (NULL / 0: off): adjacency among the parent's high-degree rows, built once at upload.  The induction does not
+     * scan a subgraph's hub rows; the edges BETWEEN two of them used to cost one search per pair in the shorter row (8-14
+     * dependent loads; 55 of the walk launch's 120 us on the 1M-node graph) and are one bit probe with this table.  Used when
+     * the call's effective hub_degree is >= hub_table_degree (every hub is in the table then). */
+    const int32_t  *hub_index;        /* device [num_nodes]: index among the rows of degree >= hub_table_degree, -1 otherwise */
+    const uint32_t *hub_adj;          /* device [num_hubs][hub_words]: bit (c & 31) of word c >> 5 of row a: hubs a, c adjacent */
+    int32_t num_hubs, hub_words;      /* hub_words = (num_hubs + 31) / 32                                                      */
+    int32_t hub_table_degree, reserved_;
 } gcc_graph;
 /* The caller has verified the contract above (symmetric, rows sorted ascending, no self loops, no duplicates).  Only
  * then may the induction skip hub rows (gcc_sample_params.hub_degree >= 0): their induced rows are rebuilt as mirror

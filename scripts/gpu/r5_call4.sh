@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round 5, call 4: the parent's hub-hub adjacency table (one bit probe per hub pair) against the pair searches
+# (GCC_SAMPLER_HUB_TABLE=0): sampler device tests, kernel stats of the sampler alone on G1 (10 / 16 steps per launch) and G2,
+# wall clock both ways; the whole GPU tier.
+set -u
+O=gpurun_out/r5c4
+mkdir -p $O
+export TMPDIR=/tmp GCC_AMD_GRAPH_CACHE=/tmp/graphs
+timeout 1500 python -m pytest tests -m gpu -q --tb=short > $O/pytest_gpu.log 2>&1
+echo "== gpu tier: $(grep -E 'passed|failed' $O/pytest_gpu.log | tail -1)"; grep -E "^(FAILED|ERROR)|core dumped|VIOLATION|Error|^E  " $O/pytest_gpu.log | head -20 | cut -c1-300
+stats() {  # tag, env, args
+  rm -rf /tmp/st_$1
+  (cd /tmp && env $2 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$1 -o s -- python $GRAFT_REPO_ROOT/tools/sampler_alone.py $3 --time 2>&1 | grep -E "ms per launch|ok workload") > $O/time_$1.txt
+  f=$(find /tmp/st_$1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$1.csv
+  echo "[$1] $(head -1 $O/time_$1.txt)"; python - <<PY
+import csv
+rows=list(csv.DictReader(open('$O/kernel_stats_$1.csv')))
+for r in rows[:8]: print('   %-60s calls %5s avg %9.1f us  %5s %%' % (r['Name'][:60], r['Calls'], float(r['AverageNs'])/1e3, r['Percentage']))
+PY
+}
+stats g1_s10_table GCC_SAMPLER_HUB_TABLE=1 "--launches 30 --steps-per-call 10"
+stats g1_s10_search GCC_SAMPLER_HUB_TABLE=0 "--launches 30 --steps-per-call 10"
+stats g1_s16_table GCC_SAMPLER_HUB_TABLE=1 "--launches 30 --steps-per-call 16"
+stats g2_s16_table GCC_SAMPLER_HUB_TABLE=1 "--nodes 10000000 --edges 200000000 --launches 12 --steps-per-call 16"
+stats g2_s16_search GCC_SAMPLER_HUB_TABLE=0 "--nodes 10000000 --edges 200000000 --launches 12 --steps-per-call 16"

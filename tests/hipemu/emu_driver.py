@@ -35,7 +35,8 @@ def _p(a):
 
 
 class EmuGraph:
-    def __init__(self, row_ptr, col_idx, rw_hops=256, restart_prob=0.8, ltab=None, shard_off=None, contract_checked=True):
+    def __init__(self, row_ptr, col_idx, rw_hops=256, restart_prob=0.8, ltab=None, shard_off=None, contract_checked=True,
+                 hub_table_degree=None):
         self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
         self.col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
         self.shard_off = np.ascontiguousarray(shard_off, dtype=np.int64) if shard_off is not None else None
@@ -51,6 +52,14 @@ class EmuGraph:
                                 num_edges=len(self.col_idx), ltab_len=len(self.ltab), lmax=self.lmax,
                                 shard_off=_p(self.shard_off), num_shards=len(self.shard_off) - 1 if shard_off is not None else 0,
                                 flags=_cabi.GRAPH_CONTRACT_CHECKED if contract_checked else 0)
+        if hub_table_degree is not None:       # the hub-hub adjacency table (gcc_amd.graph.hub_tables) for this threshold
+            from gcc_amd.graph import hub_tables
+
+            tabs = hub_tables(self.row_ptr, self.col_idx, hub_table_degree)
+            if tabs is not None:
+                self.hub_index, self.hub_adj = tabs
+                self.c.hub_index, self.c.hub_adj = _p(self.hub_index), _p(self.hub_adj)
+                self.c.num_hubs, self.c.hub_words, self.c.hub_table_degree = self.hub_adj.shape[0], self.hub_adj.shape[1], hub_table_degree
 
 
 def emu_sample_batch(g: EmuGraph, B, run_seed, first_sample_id, seeds=None, edge_cap=None,

@@ -356,3 +356,17 @@ def test_unchecked_parent_scans_every_row(coracle):
     g = EmuGraph(rp, ci, rw_hops=64, contract_checked=False)
     _compare(coracle, rp, ci, g, 7, 21, 500, hub_degree=2, max_hubs=32)
     _compare(coracle, rp, ci, g, 7, 21, 500)
+
+
+@pytest.mark.parametrize("hub_degree,max_hubs", [(8, 3), (8, 32), (40, 32), (16, 8)])
+def test_hub_pairs_through_the_parent_table(coracle, hub_degree, max_hubs):
+    """With gcc_graph.hub_index / hub_adj (the adjacency among the parent's rows of at least hub_table_degree entries, built at
+    upload: gcc_amd.graph.hub_tables) an edge between two unscanned hub rows is one bit probe instead of a search in the
+    shorter row.  Same subgraphs bit for bit; a call whose threshold is BELOW the table's falls back to the searches."""
+    rp, ci = powerlaw_graph(20000, 400000, 1)
+    hubs = np.argsort(np.diff(rp))[-4:].astype(np.int32)
+    g = EmuGraph(rp, ci, rw_hops=64, hub_table_degree=8)
+    assert g.c.num_hubs > 100 and g.c.hub_table_degree == 8
+    _compare(coracle, rp, ci, g, 4, 7, 0, seeds=hubs, hub_degree=hub_degree, max_hubs=max_hubs)
+    _compare(coracle, rp, ci, g, 5, 3, 77, hub_degree=hub_degree, max_hubs=max_hubs)
+    _compare(coracle, rp, ci, g, 3, 3, 99, hub_degree=4, max_hubs=max_hubs)      # below the table's threshold: searches

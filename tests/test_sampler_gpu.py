@@ -198,7 +198,15 @@ def test_config4_full_size_bit_exact(coracle, torch_cuda, g2_graph):
     assert len(rp) - 1 > 9_900_000 and len(ci) > 199_000_000
     _check(coracle, torch_cuda, rp, ci, 256, 256, 0, 256 * 5)
     hubs = np.argsort(np.diff(rp))[-512::8].astype(np.int32)     # 64 of the 512 largest degrees (up to 12,649 neighbours)
-    q, k, ref = _check(coracle, torch_cuda, rp, ci, 64, 256, 9, 0, seeds=hubs.tolist(), scratch_entries=1 << 28, edge_cap=1 << 26)
+    # (a batch of nothing but hubs is far beyond the sizing heuristics: the scratch is sized from the oracle's own batch --
+    #  one 1024-entry slot per unit of 256 aligned quads of the members' parent rows, every row counted)
+    from oracle import sampler as O
+    lt = O.max_nodes_table(int(np.diff(rp).max()), 256, 0.8)
+    views = _oracle_views(coracle, rp, ci, hubs, lt[np.diff(rp)[hubs]], 9, 0, O.restart_threshold(0.8))
+    units = sum(int(((rp[m + 1] + 3) // 4 - rp[m] // 4).sum() + 255) // 256 + 1
+                for r in views for m in (r["parent_nid"][a:b] for a, b in zip(r["node_off"][:-1], r["node_off"][1:])))
+    q, k, ref = _check(coracle, torch_cuda, rp, ci, 64, 256, 9, 0, seeds=hubs.tolist(), scratch_entries=int(1.05 * 1024 * units),
+                       edge_cap=max(int(1.05 * max(len(r["col_idx"]) for r in views)), 1 << 20))
     assert max(np.diff(ref[0]["node_off"])) > 1000
     # the launch shape of the published sampler line: 16 steps per call == 16 single-step calls
     g = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, validate=False, trusted=True)
