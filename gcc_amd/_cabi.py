@@ -114,6 +114,20 @@ class GccGinPass(ctypes.Structure):
     ]
 
 
+class GccGinxPass(ctypes.Structure):          # gcc_ginx_pass: the encoder at any width (csrc/ginx.hip)
+    _fields_ = [
+        ("node_off", _VP), ("row_ptr", _VP), ("col_idx", _VP), ("graph_id", _VP), ("pos", _VP), ("seed_local", _VP),
+        ("batch_size", ctypes.c_int32), ("training", ctypes.c_int32), ("update_running_stats", ctypes.c_int32),
+        ("normalize", ctypes.c_int32),
+        ("dropout_keep", _VP),
+        ("hidden", ctypes.c_int32), ("out_dim", ctypes.c_int32), ("edge_multiplicity", ctypes.c_int32), ("reserved_", ctypes.c_int32),
+        ("node_cap", ctypes.c_int64),
+        ("w", GccGinWeights),
+        ("workspace", _VP), ("workspace_bytes", ctypes.c_int64),
+        ("feat", _VP), ("pooled_out", _VP),
+    ]
+
+
 class GccGinGrads(ctypes.Structure):
     _fields_ = [
         ("degree_embedding", _VP),
@@ -200,6 +214,9 @@ SIGNATURES = {
     "gcc_gin_backward": (ctypes.c_int32, [ctypes.POINTER(GccGinPass), ctypes.c_void_p, ctypes.POINTER(GccGinGrads),
                                           ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_void_p, ctypes.c_void_p]),
+    "gcc_ginx_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "gcc_ginx_forward": (ctypes.c_int32, [ctypes.POINTER(GccGinxPass), ctypes.c_void_p]),
+    "gcc_ginx_backward": (ctypes.c_int32, [ctypes.POINTER(GccGinxPass), ctypes.c_void_p, ctypes.POINTER(GccGinGrads), ctypes.c_void_p]),
     "gcc_ginw_forward": (ctypes.c_int32, [ctypes.POINTER(GccGinwArgs), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_ginw_pack_weights": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
     "gcc_nce_workspace_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32]),

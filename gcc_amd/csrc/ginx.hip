@@ -1,0 +1,536 @@
+// gcc_amd/csrc/ginx.hip -- the GIN encoder at ANY hidden / output width, training mode included: forward with batch
+// statistics and the full backward, fp32 on the matrix cores (v_mfma_f32_16x16x4_f32).  `--hidden-size` is part of the
+// reference's flag surface (train.py:93; GraphEncoder node_hidden_dim / output_dim, graph_encoder.py:44-63); the fused
+// 64-channel kernels of encoder.hip / encoder_bwd.hip serve widths up to 64 (zero-padded, exact), this file serves the
+// rest.  Reference arithmetic, statement by statement:
+//     features       graph_encoder.py:152-165   [pos_undirected | degree_embedding(clamp(in_deg)) | seed flag]
+//     GINConv        gin.py:179-185,218         agg = h + sum over the in-neighbours (sum aggregation, eps = 0)
+//     MLP            gin.py:107-116             linears.1(relu(batch_norms.0(linears.0(agg))))
+//     ApplyNodeFunc  gin.py:54-58               relu(bn(mlp(.)))
+//     outer BN/ReLU  gin.py:219-220
+//     readout        gin.py:223-232             sum_i dropout(linears_prediction[i](SumPooling(hidden_rep[i])))
+//     normalise      graph_encoder.py:195-196   F.normalize(p = 2, eps = 1e-5)
+// and autograd's backward of exactly this graph (BatchNorm in training mode: biased batch variance for the
+// normalisation, unbiased for running_var, momentum 0.1).
+//
+// Shape of the implementation: NOT fused.  One launch per operator -- a CSR gather, a strided MFMA GEMM used for every
+// Linear (forward, data gradient, weight gradient with split-K atomics), column statistics in fp64, BatchNorm + ReLU
+// forward / backward passes, per-graph pooling -- ~70 launches forward, ~150 backward at 4 layers.  Every activation is
+// kept for the backward pass (6 [N, W] tensors per layer: HBM is 288 GB).  The batched subgraph of a symmetric parent is
+// symmetric, so the gather's own transpose is the same gather (the sampler's contract; the 64-channel backward relies on
+// it too).  Row counts live on the device (node_off[B]): every kernel is launched for node_cap rows and reads the live
+// extent itself, no host synchronisation.
+#include "host_common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int kGT = 256;                 // threads of the GEMM workgroup: 4 waves, a 64 x 64 tile of C
+constexpr int kBM = 64, kBN = 64, kBK = 16;
+constexpr int kLdT = kBM + 4;            // LDS row stride of the k-major operand tiles
+constexpr int kSplitRows = 2048;         // rows of the reduction dimension per workgroup when it is the node dimension
+
+// C[m][n] (+)= sum_k A(m, k) B(k, n) [+ bias[n]];  A(m, k) = A[m * sam + k * sak], B(k, n) = B[k * sbk + n * sbn].
+// rows_dim: 0 = all extents are the host's; 1 = M is *rows (device); 2 = K is *rows (device; split over gridDim.z with
+// atomic adds into a zeroed C).
+struct GemmArgs {
+    const float *A, *B, *bias;
+    float *C;
+    int64_t sam, sak, sbk, sbn, ldc;
+    int32_t M, N, K;
+    const int32_t *rows;
+    int32_t rows_dim, atomic;
+};
+
+__global__ __launch_bounds__(kGT) void ginx_gemm_kernel(GemmArgs g)
+{
+    __shared__ float As[kBK][kLdT], Bs[kBK][kLdT];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int M = g.M, K = g.K;
+    if (g.rows_dim == 1) M = *g.rows;
+    if (g.rows_dim == 2) K = *g.rows;
+    const int m0 = (int)blockIdx.x * kBM, n0 = (int)blockIdx.y * kBN;
+    int k_lo = 0, k_hi = K;
+    if (g.rows_dim == 2) { k_lo = (int)blockIdx.z * kSplitRows; k_hi = min(K, k_lo + kSplitRows); }
+    if (m0 >= M || k_lo >= k_hi) return;                     // (block-uniform)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][2] = {{zero4, zero4}, {zero4, zero4}};
+    const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;       // this wave's 32 x 32 quarter of the tile
+    const bool a_kc = g.sak == 1, b_nc = g.sbn == 1;         // which index of an operand is contiguous in memory
+    for (int k0 = k_lo; k0 < k_hi; k0 += kBK) {
+        // operand tiles -> LDS, k-major; four elements per thread, along the contiguous index
+        if (a_kc) {
+            const int m = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int mm = m0 + m, kk = k0 + kq + u;
+                As[kq + u][m] = (mm < M && kk < k_hi) ? g.A[(int64_t)mm * g.sam + (int64_t)kk * g.sak] : 0.f;
+            }
+        } else {
+            const int kk_ = tid >> 4, m4 = (tid & 15) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int mm = m0 + m4 + u, kk = k0 + kk_;
+                As[kk_][m4 + u] = (mm < M && kk < k_hi) ? g.A[(int64_t)mm * g.sam + (int64_t)kk * g.sak] : 0.f;
+            }
+        }
+        if (b_nc) {
+            const int kk_ = tid >> 4, n4 = (tid & 15) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int nn = n0 + n4 + u, kk = k0 + kk_;
+                Bs[kk_][n4 + u] = (nn < g.N && kk < k_hi) ? g.B[(int64_t)kk * g.sbk + (int64_t)nn * g.sbn] : 0.f;
+            }
+        } else {
+            const int n = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int nn = n0 + n, kk = k0 + kq + u;
+                Bs[kq + u][n] = (nn < g.N && kk < k_hi) ? g.B[(int64_t)kk * g.sbk + (int64_t)nn * g.sbn] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < kBK; ks += 4) {
+            const int kk = ks + (lane >> 4);
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[kk][wr + 16 * i + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[kk][wc + 16 * j + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_16x16x4_f32(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr + 16 * i + 4 * (lane >> 4) + r, n = n0 + wc + 16 * j + (lane & 15);
+                if (m < M && n < g.N) {
+                    float v = acc[i][j][r];
+                    if (g.bias && (g.rows_dim != 2 || blockIdx.z == 0)) v += g.bias[n];
+                    float *c = g.C + (int64_t)m * g.ldc + n;
+                    if (g.atomic) atomicAdd(c, v); else *c = v;
+                }
+            }
+}
+
+// x0[v] = [pos_undirected[v] | degree_embedding[clamp(in_deg(v), 0, max_degree)] | seed flag]   (graph_encoder.py:152-165)
+__global__ void ginx_feat_kernel(const int32_t *node_off, const int32_t *row_ptr, const int32_t *graph_id, const int32_t *seed_local,
+                                 const float *pos, const float *emb, int B, int pos_dim, int de, int max_degree, int mult, float *x0)
+{
+    const int d_in = pos_dim + de + 1;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = node_off[B];
+    const int v = (int)(i / d_in), c = (int)(i % d_in);
+    if (v >= N) return;
+    float val;
+    if (c < pos_dim) val = pos[(int64_t)v * pos_dim + c];
+    else if (c < pos_dim + de) {
+        int d = (row_ptr[v + 1] - row_ptr[v]) * mult;
+        d = d < 0 ? 0 : (d > max_degree ? max_degree : d);
+        val = emb[(int64_t)d * de + (c - pos_dim)];
+    } else {
+        const int b = graph_id[v];
+        val = (v == node_off[b] + (seed_local ? seed_local[b] : 0)) ? 1.f : 0.f;
+    }
+    x0[(int64_t)v * d_in + c] = val;
+}
+
+// d degree_embedding[clamp(deg(v))][c] += dx0[v][pos_dim + c]   (the gradient of nn.Embedding: a scatter-add)
+__global__ void ginx_feat_bwd_kernel(const int32_t *node_off, const int32_t *row_ptr, int B, int pos_dim, int de, int max_degree,
+                                     const float *dx0, float *demb)
+{
+    const int d_in = pos_dim + de + 1;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = node_off[B];
+    const int v = (int)(i / de), c = (int)(i % de);
+    if (v >= N) return;
+    int d = row_ptr[v + 1] - row_ptr[v];
+    d = d < 0 ? 0 : (d > max_degree ? max_degree : d);
+    atomicAdd(&demb[(int64_t)d * de + c], dx0[(int64_t)v * d_in + pos_dim + c]);
+}
+
+// out[v] = x[v] + sum over row v of x[col]  (+ add[v] when add != NULL): one wave per row, lanes over the channels
+__global__ __launch_bounds__(256) void ginx_spmm_kernel(const int32_t *node_off, const int32_t *row_ptr, const int32_t *col_idx, int B,
+                                                         const float *x, int D, const float *add, float *out)
+{
+    const int lane = (int)threadIdx.x & 63;
+    const int v = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (v >= node_off[B]) return;
+    const int e0 = row_ptr[v], e1 = row_ptr[v + 1];
+    for (int c = lane; c < D; c += 64) {
+        float acc = x[(int64_t)v * D + c];
+        for (int e = e0; e < e1; ++e) acc += x[(int64_t)col_idx[e] * D + c];
+        if (add) acc += add[(int64_t)v * D + c];
+        out[(int64_t)v * D + c] = acc;
+    }
+}
+
+// column sums over the live rows, fp64: sums[0][c] += sum_v f(v, c), sums[1][c] += sum_v g(v, c)
+//   mode 0 (BatchNorm forward statistics):  f = x, g = x^2
+//   mode 1 (BatchNorm + ReLU backward):     gr = dy * (y > 0);  f = gr,  g = gr * xhat,  xhat = (x - mean) * rstd
+//   mode 2 (bias gradient):                 f = x              (sums[1] untouched)
+__global__ __launch_bounds__(256) void ginx_colsum_kernel(const int32_t *node_off, int B, int fixed_rows, int mode, const float *x,
+                                                           const float *y, const float *dy, const float *mr /* [2][D] mean, rstd */,
+                                                           int D, double *sums)
+{
+    const int N = fixed_rows > 0 ? fixed_rows : node_off[B];
+    const int r0 = (int)blockIdx.x * 128, r1 = min(N, r0 + 128);
+    if (r0 >= N) return;
+    for (int c = (int)threadIdx.x; c < D; c += 256) {
+        double s0 = 0.0, s1 = 0.0;
+        if (mode == 0) {
+            for (int r = r0; r < r1; ++r) { const double v = (double)x[(int64_t)r * D + c]; s0 += v; s1 += v * v; }
+        } else if (mode == 1) {
+            const float mean = mr[c], rstd = mr[D + c];
+            for (int r = r0; r < r1; ++r) {
+                const int64_t i = (int64_t)r * D + c;
+                const float gr = y[i] > 0.f ? dy[i] : 0.f;
+                s0 += (double)gr;
+                s1 += (double)gr * (double)((x[i] - mean) * rstd);
+            }
+        } else {
+            for (int r = r0; r < r1; ++r) s0 += (double)x[(int64_t)r * D + c];
+        }
+        atomicAdd(&sums[c], s0);
+        if (mode != 2) atomicAdd(&sums[D + c], s1);
+    }
+}
+
+// per channel: batch mean / 1 / sqrt(biased variance + eps) from the sums (training) or from the running statistics
+// (eval); training also moves the running statistics (momentum; unbiased variance) and counts the batch
+__global__ void ginx_bn_prepare_kernel(const int32_t *node_off, int B, const double *sums, int D, float eps, float momentum, int training,
+                                       int update, float *running_mean, float *running_var, int64_t *tracked, float *mr)
+{
+    const int c = (int)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    const double n = (double)node_off[B];
+    if (training) {
+        const double mean = n > 0 ? sums[c] / n : 0.0;
+        double var = n > 0 ? sums[D + c] / n - mean * mean : 0.0;
+        var = var < 0.0 ? 0.0 : var;
+        mr[c] = (float)mean;
+        mr[D + c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (update) {
+            const double unb = n > 1 ? var * n / (n - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+            if (c == 0 && tracked) *tracked += 1;
+        }
+    } else {
+        mr[c] = running_mean[c];
+        mr[D + c] = 1.0f / sqrtf(running_var[c] + eps);
+    }
+}
+
+// y = relu((x - mean) * rstd * gamma + beta)
+__global__ void ginx_bn_relu_kernel(const int32_t *node_off, int B, const float *x, const float *mr, const float *gamma, const float *beta,
+                                    int D, float *y)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)node_off[B] * D) return;
+    const int c = (int)(i % D);
+    const float v = (x[i] - mr[c]) * mr[D + c] * gamma[c] + beta[c];
+    y[i] = v > 0.f ? v : 0.f;
+}
+
+// dx = gamma * rstd * (gr - mean(gr) - xhat * mean(gr * xhat)),  gr = dy * (y > 0)   (BatchNorm1d backward in training mode)
+__global__ void ginx_bn_relu_bwd_kernel(const int32_t *node_off, int B, const float *x, const float *y, const float *dy, const float *mr,
+                                        const float *gamma, const double *sums, int D, float *dx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = node_off[B];
+    if (i >= (int64_t)N * D) return;
+    const int c = (int)(i % D);
+    const float gr = y[i] > 0.f ? dy[i] : 0.f;
+    const float xhat = (x[i] - mr[c]) * mr[D + c];
+    const float m0 = (float)(sums[c] / (double)N), m1 = (float)(sums[D + c] / (double)N);
+    dx[i] = gamma[c] * mr[D + c] * (gr - m0 - xhat * m1);
+}
+
+// fp64 sums -> fp32 parameter gradients: dst[c] (+)= (float)src[c]
+__global__ void ginx_sums_to_grad_kernel(const double *src, int D, float *dst, int accumulate)
+{
+    const int c = (int)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < D) dst[c] = (accumulate ? dst[c] : 0.f) + (float)src[c];
+}
+
+// pooled[b][c] = sum of h over the nodes of graph b (SumPooling, gin.py:205,228): one workgroup per graph
+__global__ __launch_bounds__(256) void ginx_pool_kernel(const int32_t *node_off, const float *h, int D, float *pooled)
+{
+    const int b = (int)blockIdx.x;
+    const int r0 = node_off[b], r1 = node_off[b + 1];
+    for (int c = (int)threadIdx.x; c < D; c += 256) {
+        double s = 0.0;
+        for (int r = r0; r < r1; ++r) s += (double)h[(int64_t)r * D + c];
+        pooled[(int64_t)b * D + c] = (float)s;
+    }
+}
+
+// dh[v][c] (+)= dpooled[graph_id[v]][c]
+__global__ void ginx_pool_bwd_kernel(const int32_t *node_off, const int32_t *graph_id, int B, const float *dpooled, int D, float *dh, int accumulate)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)node_off[B] * D) return;
+    const int v = (int)(i / D), c = (int)(i % D);
+    const float g = dpooled[(int64_t)graph_id[v] * D + c];
+    dh[i] = accumulate ? dh[i] + g : g;
+}
+
+// score (+)= y * keep * scale   (dropout with an explicit 0/1 keep mask, scale = 1 / (1 - p); keep == NULL: no dropout);
+// backward: dy = dscore * keep * scale -- the same kernel with `first` = 1
+__global__ void ginx_mask_acc_kernel(const float *y, const float *keep, float scale, int n, float *score, int first)
+{
+    const int i = (int)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = keep ? y[i] * keep[i] * scale : y[i];
+    score[i] = first ? v : score[i] + v;
+}
+
+// feat = score / max(||score||_2, eps)   (one wave per row)
+__global__ __launch_bounds__(64) void ginx_normalize_kernel(const float *score, int D, float eps, int normalize, float *feat)
+{
+    const int b = (int)blockIdx.x, lane = (int)threadIdx.x;
+    float ss = 0.f;
+    for (int c = lane; c < D; c += 64) { const float v = score[(int64_t)b * D + c]; ss += v * v; }
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+    const float inv = normalize ? 1.0f / fmaxf(nrm, eps) : 1.0f;
+    for (int c = lane; c < D; c += 64) feat[(int64_t)b * D + c] = score[(int64_t)b * D + c] * inv;
+}
+
+// dscore = (dfeat - feat * <feat, dfeat>) / ||score||  when ||score|| >= eps, dfeat / eps below it; dfeat without normalisation
+__global__ __launch_bounds__(64) void ginx_normalize_bwd_kernel(const float *score, const float *feat, const float *dfeat, int D, float eps,
+                                                                 int normalize, float *dscore)
+{
+    const int b = (int)blockIdx.x, lane = (int)threadIdx.x;
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const int64_t i = (int64_t)b * D + c;
+        ss += score[i] * score[i];
+        dot += feat[i] * dfeat[i];
+    }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    const float nrm = sqrtf(ss);
+    for (int c = lane; c < D; c += 64) {
+        const int64_t i = (int64_t)b * D + c;
+        float v = dfeat[i];
+        if (normalize) v = nrm >= eps ? (dfeat[i] - feat[i] * dot) / nrm : dfeat[i] / eps;
+        dscore[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------- host side ----
+struct XLayout {                         // float offsets inside the pass's workspace
+    int64_t x0, agg[GCC_GIN_MAX_LAYERS], z1[GCC_GIN_MAX_LAYERS], a1[GCC_GIN_MAX_LAYERS], z2[GCC_GIN_MAX_LAYERS], a2[GCC_GIN_MAX_LAYERS],
+        h[GCC_GIN_MAX_LAYERS];
+    int64_t mr[GCC_GIN_MAX_LAYERS][3];   // [2][W] mean / rstd of the three BatchNorms of a layer
+    int64_t pooled[GCC_GIN_MAX_LAYERS + 1], y, score;
+    int64_t da, db, dc, dpool, dy, dscore;      // backward scratch: three [N, Wmax] buffers, [B, Wmax] x 3
+    int64_t sums;                        // doubles: [2][Wmax] scratch of the statistics kernels (offset in FLOATS, 8-byte aligned)
+    int64_t total;
+};
+
+XLayout ginx_layout(int64_t N, int B, int L, int d_in, int W, int O)
+{
+    XLayout x;
+    const int64_t Wm = W > d_in ? (W > O ? W : O) : (d_in > O ? d_in : O);
+    int64_t o = 0;
+    auto take = [&](int64_t n) { const int64_t at = o; o += (n + 63) / 64 * 64; return at; };
+    x.x0 = take(N * d_in);
+    for (int l = 0; l < L; ++l) {
+        x.agg[l] = take(N * (l == 0 ? d_in : W));
+        x.z1[l] = take(N * W); x.a1[l] = take(N * W); x.z2[l] = take(N * W); x.a2[l] = take(N * W); x.h[l] = take(N * W);
+        for (int j = 0; j < 3; ++j) x.mr[l][j] = take(2 * W);
+    }
+    for (int l = 0; l <= L; ++l) x.pooled[l] = take((int64_t)B * (l == 0 ? d_in : W));
+    x.y = take((int64_t)B * O);
+    x.score = take((int64_t)B * O);
+    x.da = take(N * Wm); x.db = take(N * Wm); x.dc = take(N * Wm);
+    x.dpool = take((int64_t)B * Wm); x.dy = take((int64_t)B * O); x.dscore = take((int64_t)B * O);
+    x.sums = take(4 * Wm + 16);
+    x.total = o;
+    return x;
+}
+
+void gemm(hipStream_t s, const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn, float *C, int64_t ldc,
+          int M, int N, int K, const float *bias, const int32_t *rows, int rows_dim, int64_t rows_cap)
+{
+    GemmArgs g = {A, B, bias, C, sam, sak, sbk, sbn, ldc, M, N, K, rows, rows_dim, rows_dim == 2 ? 1 : 0};
+    const int mcap = rows_dim == 1 ? (int)rows_cap : M;
+    dim3 grid((mcap + kBM - 1) / kBM, (N + kBN - 1) / kBN, rows_dim == 2 ? (unsigned)((rows_cap + kSplitRows - 1) / kSplitRows) : 1u);
+    if (rows_dim == 2) (void)hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * (size_t)ldc, s);     // (C is dense: ldc == N)
+    hipLaunchKernelGGL(ginx_gemm_kernel, grid, dim3(kGT), 0, s, g);
+}
+
+inline unsigned blocks(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
+
+}  // namespace
+
+extern "C" {
+
+int64_t gcc_ginx_workspace_bytes(int64_t node_cap, int32_t batch_size, int32_t num_gin_layers, int32_t d_in, int32_t hidden, int32_t out_dim)
+{
+    if (node_cap <= 0 || batch_size <= 0 || num_gin_layers < 1 || num_gin_layers > GCC_GIN_MAX_LAYERS || d_in < 1 || hidden < 1 || out_dim < 1) {
+        snprintf(g_err, kErrLen, "gcc_ginx_workspace_bytes: bad sizes");
+        return -1;
+    }
+    return ginx_layout(node_cap, batch_size, num_gin_layers, d_in, hidden, out_dim).total * 4;
+}
+
+static int ginx_check(const gcc_ginx_pass *p, const char *who)
+{
+    const gcc_gin_weights &w = p->w;
+    if (!p->node_off || !p->row_ptr || !p->col_idx || !p->graph_id || !p->pos || !p->workspace || !p->feat) {
+        snprintf(g_err, kErrLen, "%s: NULL argument", who);
+        return -1;
+    }
+    if (w.num_gin_layers < 1 || w.num_gin_layers > GCC_GIN_MAX_LAYERS || p->hidden < 1 || p->out_dim < 1 || p->batch_size < 1) {
+        snprintf(g_err, kErrLen, "%s: bad sizes", who);
+        return -2;
+    }
+    const int d_in = w.pos_dim + w.deg_emb_dim + 1;
+    if (p->workspace_bytes < gcc_ginx_workspace_bytes(p->node_cap, p->batch_size, w.num_gin_layers, d_in, p->hidden, p->out_dim)) {
+        snprintf(g_err, kErrLen, "%s: workspace too small", who);
+        return -3;
+    }
+    return 0;
+}
+
+int32_t gcc_ginx_forward(const gcc_ginx_pass *p, void *stream)
+{
+    if (int rc = ginx_check(p, "gcc_ginx_forward")) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const gcc_gin_weights &w = p->w;
+    const int L = w.num_gin_layers, B = p->batch_size, W = p->hidden, O = p->out_dim, d_in = w.pos_dim + w.deg_emb_dim + 1;
+    const int64_t N = p->node_cap;
+    const XLayout x = ginx_layout(N, B, L, d_in, W, O);
+    float *ws = (float *)p->workspace;
+    double *sums = (double *)(ws + x.sums);
+    const int32_t *rows = p->node_off + B;                   // the live row count, on the device
+    hipLaunchKernelGGL(ginx_feat_kernel, dim3(blocks(N * d_in)), dim3(256), 0, s, p->node_off, p->row_ptr, p->graph_id, p->seed_local, p->pos,
+                       w.degree_embedding, B, w.pos_dim, w.deg_emb_dim, w.max_degree, p->edge_multiplicity > 0 ? p->edge_multiplicity : 1, ws + x.x0);
+    const float *h = ws + x.x0;
+    int D = d_in;
+    auto bn = [&](const float *in, const gcc_bn &m, int64_t mr_off, float *out) {          // statistics -> (mean, rstd) -> y
+        if (p->training) {
+            (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * W, s);
+            hipLaunchKernelGGL(ginx_colsum_kernel, dim3(blocks(N, 128)), dim3(256), 0, s, p->node_off, B, 0, 0, in, (const float *)nullptr,
+                               (const float *)nullptr, (const float *)nullptr, W, sums);
+        }
+        hipLaunchKernelGGL(ginx_bn_prepare_kernel, dim3(blocks(W)), dim3(256), 0, s, p->node_off, B, sums, W, w.bn_eps, w.bn_momentum, p->training,
+                           p->update_running_stats, m.running_mean, m.running_var, m.num_batches_tracked, ws + mr_off);
+        hipLaunchKernelGGL(ginx_bn_relu_kernel, dim3(blocks(N * W)), dim3(256), 0, s, p->node_off, B, in, ws + mr_off, m.weight, m.bias, W, out);
+    };
+    hipLaunchKernelGGL(ginx_pool_kernel, dim3(B), dim3(256), 0, s, p->node_off, h, D, ws + x.pooled[0]);
+    for (int l = 0; l < L; ++l) {
+        if (p->edge_multiplicity > 1) { snprintf(g_err, kErrLen, "gcc_ginx_forward: edge_multiplicity > 1 is not supported at this width"); return -4; }
+        hipLaunchKernelGGL(ginx_spmm_kernel, dim3(blocks(N, 4)), dim3(256), 0, s, p->node_off, p->row_ptr, p->col_idx, B, h, D, (const float *)nullptr,
+                           ws + x.agg[l]);
+        gemm(s, ws + x.agg[l], D, 1, w.lin0_w[l], 1, D, ws + x.z1[l], W, 0, W, D, w.lin0_b[l], rows, 1, N);            // z1 = agg W0^T + b0
+        bn(ws + x.z1[l], w.bn_a[l], x.mr[l][0], ws + x.a1[l]);
+        gemm(s, ws + x.a1[l], W, 1, w.lin1_w[l], 1, W, ws + x.z2[l], W, 0, W, W, w.lin1_b[l], rows, 1, N);             // z2 = a1 W1^T + b1
+        bn(ws + x.z2[l], w.bn_b[l], x.mr[l][1], ws + x.a2[l]);
+        bn(ws + x.a2[l], w.bn_c[l], x.mr[l][2], ws + x.h[l]);
+        h = ws + x.h[l];
+        D = W;
+        hipLaunchKernelGGL(ginx_pool_kernel, dim3(B), dim3(256), 0, s, p->node_off, h, D, ws + x.pooled[l + 1]);
+    }
+    for (int l = 0; l <= L; ++l) {                           // score = sum_l dropout(pooled_l Wp_l^T + bp_l)
+        const int Dl = l == 0 ? d_in : W;
+        gemm(s, ws + x.pooled[l], Dl, 1, w.pred_w[l], 1, Dl, ws + x.y, O, B, O, Dl, w.pred_b[l], nullptr, 0, 0);
+        const float *keep = p->dropout_keep ? p->dropout_keep + (int64_t)l * B * O : nullptr;
+        hipLaunchKernelGGL(ginx_mask_acc_kernel, dim3(blocks((int64_t)B * O)), dim3(256), 0, s, ws + x.y, keep, 1.0f / (1.0f - w.dropout_p), B * O,
+                           ws + x.score, l == 0 ? 1 : 0);
+    }
+    hipLaunchKernelGGL(ginx_normalize_kernel, dim3(B), dim3(64), 0, s, ws + x.score, O, w.norm_eps, p->normalize, p->feat);
+    if (p->pooled_out)
+        for (int l = 1; l <= L; ++l)
+            (void)hipMemcpyAsync(p->pooled_out + (int64_t)(l - 1) * B * W, ws + x.pooled[l], sizeof(float) * (size_t)B * W, hipMemcpyDeviceToDevice, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_ginx_forward: launch failed: %s", hipGetErrorString(e)); return -10; }
+    return 0;
+}
+
+int32_t gcc_ginx_backward(const gcc_ginx_pass *p, const float *dfeat, const gcc_gin_grads *gr, void *stream)
+{
+    if (int rc = ginx_check(p, "gcc_ginx_backward")) return rc;
+    if (!dfeat || !gr || !p->training) { snprintf(g_err, kErrLen, "gcc_ginx_backward: needs dfeat, grads and a training-mode pass"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    const gcc_gin_weights &w = p->w;
+    const int L = w.num_gin_layers, B = p->batch_size, W = p->hidden, O = p->out_dim, d_in = w.pos_dim + w.deg_emb_dim + 1;
+    const int64_t N = p->node_cap;
+    const XLayout x = ginx_layout(N, B, L, d_in, W, O);
+    float *ws = (float *)p->workspace;
+    double *sums = (double *)(ws + x.sums);
+    const int32_t *rows = p->node_off + B;
+    float *dA = ws + x.da, *dB_ = ws + x.db, *dC = ws + x.dc;
+    // ---- readout: dscore -> per hidden_rep: dy = dscore * keep / (1 - p); dWp = dy^T pooled; dbp = colsum(dy); dpooled = dy Wp
+    hipLaunchKernelGGL(ginx_normalize_bwd_kernel, dim3(B), dim3(64), 0, s, ws + x.score, p->feat, dfeat, O, w.norm_eps, p->normalize, ws + x.dscore);
+    auto readout_bwd = [&](int l, float *dpool) {
+        const int Dl = l == 0 ? d_in : W;
+        const float *keep = p->dropout_keep ? p->dropout_keep + (int64_t)l * B * O : nullptr;
+        hipLaunchKernelGGL(ginx_mask_acc_kernel, dim3(blocks((int64_t)B * O)), dim3(256), 0, s, ws + x.dscore, keep, 1.0f / (1.0f - w.dropout_p), B * O,
+                           ws + x.dy, 1);
+        gemm(s, ws + x.dy, 1, O, ws + x.pooled[l], Dl, 1, gr->pred_w[l], Dl, O, Dl, B, nullptr, nullptr, 0, 0);         // dWp [O, Dl] = dy^T pooled
+        (void)hipMemsetAsync(sums, 0, sizeof(double) * O, s);
+        hipLaunchKernelGGL(ginx_colsum_kernel, dim3(blocks(B, 128)), dim3(256), 0, s, p->node_off, B, B, 2, ws + x.dy, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, O, sums);
+        hipLaunchKernelGGL(ginx_sums_to_grad_kernel, dim3(blocks(O)), dim3(256), 0, s, sums, O, gr->pred_b[l], 0);
+        gemm(s, ws + x.dy, O, 1, w.pred_w[l], Dl, 1, dpool, Dl, B, Dl, O, nullptr, nullptr, 0, 0);                        // dpooled [B, Dl] = dy Wp
+    };
+    // BatchNorm + ReLU backward: (x, y, dy) -> dx in place of dy's buffer `dx`; gamma / beta gradients from the two column sums
+    auto bn_bwd = [&](const float *xin, const float *y, const float *dy, const gcc_bn &m, int64_t mr_off, float *dx, float *dgamma, float *dbeta) {
+        (void)hipMemsetAsync(sums, 0, sizeof(double) * 2 * W, s);
+        hipLaunchKernelGGL(ginx_colsum_kernel, dim3(blocks(N, 128)), dim3(256), 0, s, p->node_off, B, 0, 1, xin, y, dy, (const float *)(ws + mr_off), W, sums);
+        hipLaunchKernelGGL(ginx_sums_to_grad_kernel, dim3(blocks(W)), dim3(256), 0, s, sums, W, dbeta, 0);
+        hipLaunchKernelGGL(ginx_sums_to_grad_kernel, dim3(blocks(W)), dim3(256), 0, s, sums + W, W, dgamma, 0);
+        hipLaunchKernelGGL(ginx_bn_relu_bwd_kernel, dim3(blocks(N * W)), dim3(256), 0, s, p->node_off, B, xin, y, dy, (const float *)(ws + mr_off), m.weight,
+                           sums, W, dx);
+    };
+    auto bias_grad = [&](const float *dz, float *db) {
+        (void)hipMemsetAsync(sums, 0, sizeof(double) * W, s);
+        hipLaunchKernelGGL(ginx_colsum_kernel, dim3(blocks(N, 128)), dim3(256), 0, s, p->node_off, B, 0, 2, dz, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, W, sums);
+        hipLaunchKernelGGL(ginx_sums_to_grad_kernel, dim3(blocks(W)), dim3(256), 0, s, sums, W, db, 0);
+    };
+    // dh of the last hidden representation: only its pooled readout feeds the loss
+    readout_bwd(L, ws + x.dpool);
+    hipLaunchKernelGGL(ginx_pool_bwd_kernel, dim3(blocks(N * W)), dim3(256), 0, s, p->node_off, p->graph_id, B, ws + x.dpool, W, dA, 0);
+    for (int l = L - 1; l >= 0; --l) {
+        const int Din = l == 0 ? d_in : W;
+        const float *hin = l == 0 ? ws + x.x0 : ws + x.h[l - 1];
+        (void)hin;
+        bn_bwd(ws + x.a2[l], ws + x.h[l], dA, w.bn_c[l], x.mr[l][2], dB_, gr->bn_c_w[l], gr->bn_c_b[l]);                  // -> d a2
+        bn_bwd(ws + x.z2[l], ws + x.a2[l], dB_, w.bn_b[l], x.mr[l][1], dA, gr->bn_b_w[l], gr->bn_b_b[l]);                 // -> d z2
+        gemm(s, dA, 1, W, ws + x.a1[l], W, 1, gr->lin1_w[l], W, W, W, 0, nullptr, rows, 2, N);                            // dW1 [W, W] = dz2^T a1
+        bias_grad(dA, gr->lin1_b[l]);
+        gemm(s, dA, W, 1, w.lin1_w[l], W, 1, dB_, W, 0, W, W, nullptr, rows, 1, N);                                        // d a1 = dz2 W1
+        bn_bwd(ws + x.z1[l], ws + x.a1[l], dB_, w.bn_a[l], x.mr[l][0], dA, gr->bn_a_w[l], gr->bn_a_b[l]);                 // -> d z1
+        gemm(s, dA, 1, W, ws + x.agg[l], Din, 1, gr->lin0_w[l], Din, W, Din, 0, nullptr, rows, 2, N);                     // dW0 [W, Din] = dz1^T agg
+        bias_grad(dA, gr->lin0_b[l]);
+        gemm(s, dA, W, 1, w.lin0_w[l], Din, 1, dB_, Din, 0, Din, W, nullptr, rows, 1, N);                                  // d agg = dz1 W0
+        // d h_{l-1} = d agg + A d agg (the batched subgraph is symmetric) + the pooled readout of hidden_rep[l]'s input
+        readout_bwd(l, ws + x.dpool);
+        hipLaunchKernelGGL(ginx_pool_bwd_kernel, dim3(blocks(N * Din)), dim3(256), 0, s, p->node_off, p->graph_id, B, ws + x.dpool, Din, dC, 0);
+        hipLaunchKernelGGL(ginx_spmm_kernel, dim3(blocks(N, 4)), dim3(256), 0, s, p->node_off, p->row_ptr, p->col_idx, B, dB_, Din, (const float *)dC, dA);
+    }
+    // d x0 (in dA, width d_in) -> the degree embedding's rows
+    (void)hipMemsetAsync(gr->degree_embedding, 0, sizeof(float) * (size_t)(w.max_degree + 1) * w.deg_emb_dim, s);
+    hipLaunchKernelGGL(ginx_feat_bwd_kernel, dim3(blocks(N * w.deg_emb_dim)), dim3(256), 0, s, p->node_off, p->row_ptr, B, w.pos_dim, w.deg_emb_dim,
+                       w.max_degree, dA, gr->degree_embedding);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_ginx_backward: launch failed: %s", hipGetErrorString(e)); return -10; }
+    return 0;
+}
+
+}  // extern "C"

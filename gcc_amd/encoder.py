@@ -235,13 +235,12 @@ class GraphEncoder(nn.Module):
             raise NotImplementedError("gcc_amd accelerates the GIN path only (train.py:77 default)")
         if not degree_input:
             raise NotImplementedError("train.py:617 always passes degree_input=True")
-        if not (1 <= node_hidden_dim <= H and 1 <= output_dim <= H):
-            # --hidden-size up to 64 runs on the 64-channel kernels, zero-padded and exact (ensure_padded); wider models have
-            # no training kernels here (the 256-wide bf16 stack of gcc_amd/gin_wide.py is inference only)
-            raise NotImplementedError(f"hidden / output size must be between 1 and {H} (got {node_hidden_dim} / {output_dim})")
+        if node_hidden_dim < 1 or output_dim < 1:
+            raise ValueError(f"hidden / output size must be positive (got {node_hidden_dim} / {output_dim})")
         node_input_dim = positional_embedding_size + degree_embedding_size + 1      # graph_encoder.py:66-67
-        if node_input_dim > H:
-            raise NotImplementedError("positional + degree embedding + 1 must be <= 64")
+        # --hidden-size up to 64 runs on the fused 64-channel kernels, zero-padded and exact (ensure_padded); anything wider
+        # (or a wider input) on the any-width kernels of csrc/ginx.hip (gcc_amd/encoder_wide.py): same arithmetic, unfused
+        self.wide = node_hidden_dim > H or output_dim > H or node_input_dim > H
         if num_layers - 1 > _cabi.GIN_MAX_LAYERS:
             raise NotImplementedError("too many GIN layers")
         self.gnn = _UnsupervisedGIN(num_layers, node_input_dim, node_hidden_dim, output_dim, final_dropout=0.5)
@@ -260,6 +259,7 @@ class GraphEncoder(nn.Module):
         self._pad_ptrs = {}          # name -> data_ptr of the tensor's padded home (ensure_padded)
         self.fused_eval = True       # eval-mode forward as one launch (gcc_gin_eval_fused); False: the 15-launch chain
         self._engine = None
+        self._wide_engine = None
         self._slot = id(self)
         self._calls = 0
 
@@ -270,7 +270,7 @@ class GraphEncoder(nn.Module):
     # their backward, and Adam never moves a weight whose gradient and value are zero -- so the padded model IS the narrow
     # model, and state_dict() / load_state_dict() see tensors of the reference's shapes (graph_encoder.py:44-63).
     def is_padded(self) -> bool:
-        return self.hidden != H or self.output_dim != H
+        return not self.wide and (self.hidden != H or self.output_dim != H)
 
     def _channel_tensors(self):
         """(name, tensor holder, attribute, is_parameter) of every tensor whose leading dimension is a channel count."""
@@ -338,9 +338,19 @@ class GraphEncoder(nn.Module):
             self._pad_ptrs[name] = home.data_ptr()
 
     def engine(self) -> GinEngine:
+        if self.wide:
+            raise NotImplementedError(f"the fused 64-channel kernels serve hidden / output sizes up to {H}; this model "
+                                      f"({self.hidden} / {self.output_dim}) runs through GraphEncoder.forward (csrc/ginx.hip)")
         if self._engine is None:
             self._engine = GinEngine()
         return self._engine
+
+    def wide_engine(self):
+        if self._wide_engine is None:
+            from .encoder_wide import WideGinEngine
+
+            self._wide_engine = WideGinEngine()
+        return self._wide_engine
 
     def bn_training(self) -> bool:
         """train.py:357-365: model_ema is in eval() but its BatchNorm layers are switched back to train()."""
@@ -351,6 +361,10 @@ class GraphEncoder(nn.Module):
         as workgroups of the same gcc_gin_eval_fused call, the mean taken on the device).  -> [B, output_dim]"""
         if self.bn_training():
             raise RuntimeError("embed_views is the eval-mode path (generate.py:38 calls model.eval())")
+        if self.wide:                                   # two eval passes and their mean (generate.py:48-52 as written)
+            with torch.no_grad():
+                fq = self(graph_q)
+                return fq.clone() if graph_k is graph_q else (fq + self(graph_k)) / 2
         eng = self.engine()
         st = torch.cuda.current_stream(graph_q.node_off.device).cuda_stream if graph_q.node_off.is_cuda else None
         views = [graph_q] if graph_k is graph_q else [graph_q, graph_k]        # entire_graph: both views are one graph
@@ -364,6 +378,10 @@ class GraphEncoder(nn.Module):
         return mean[:, : self.output_dim].clone()
 
     def forward(self, g, return_all_outputs=False):
+        if self.wide:
+            from .encoder_wide import ginx_apply
+
+            return ginx_apply(self, g, return_all_outputs)
         from .autograd import gin_apply
 
         out = gin_apply(self, g, return_all_outputs)

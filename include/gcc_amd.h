@@ -374,6 +374,41 @@ int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat, const gcc
                          int32_t accumulate, void *workspace, int64_t workspace_bytes, int64_t node_cap,
                          gcc_prof *prof, void *stream);
 
+/* ------------------------------------- GIN encoder at any width (training) ---
+ * The same encoder -- GraphEncoder(gnn_model="gin").forward, graph_encoder.py:132-200 -> gin.py:213-232 -- for hidden /
+ * output sizes the 64-channel kernels above do not serve (`--hidden-size` above 64, train.py:93), forward in training
+ * or eval mode and the full backward, fp32 on the matrix cores.  Not fused: one launch per operator (CSR gather, strided
+ * MFMA GEMM, fp64 column statistics, BatchNorm + ReLU passes, per-graph pooling); every activation is kept in the
+ * caller's workspace for the backward pass.  Weights / gradients use gcc_gin_weights / gcc_gin_grads with the tensors'
+ * own (unpadded) shapes: lin0_w[0] [hidden, d_in], lin0_w[i > 0] and lin1_w [hidden, hidden], pred_w[0] [out_dim, d_in],
+ * pred_w[i > 0] [out_dim, hidden], per-channel arrays [hidden]; gcc_gin_weights.hidden is ignored.  Dropout: explicit
+ * keep masks only (the host draws them, as torch.nn.Dropout does: gin.py:202,230).  The batched graph must be symmetric
+ * (the sampler's output is): the gather is its own transpose in the backward pass. */
+typedef struct gcc_ginx_pass {
+    const int32_t *node_off, *row_ptr, *col_idx, *graph_id;   /* gcc_batch_out of the view                              */
+    const float *pos;            /* device [node_cap, pos_dim]                                                          */
+    const int32_t *seed_local;   /* device [B] or NULL (gcc_gin_pass.seed_local)                                        */
+    int32_t batch_size;
+    int32_t training;            /* 1: batch statistics; 0: running statistics (no backward)                            */
+    int32_t update_running_stats;
+    int32_t normalize;           /* graph_encoder.py:195                                                                */
+    const float *dropout_keep;   /* device [num_gin_layers + 1, B, out_dim] 0 / 1 keep masks, or NULL: no dropout       */
+    int32_t hidden, out_dim;     /* node_hidden_dim, output_dim: any positive size                                      */
+    int32_t edge_multiplicity;   /* gcc_gin_pass.edge_multiplicity; 0 / 1 only                                          */
+    int32_t reserved_;
+    int64_t node_cap;            /* rows the launches are sized for (node_off[B] <= node_cap, read on the device)       */
+    gcc_gin_weights w;
+    void *workspace;             /* device, gcc_ginx_workspace_bytes(): activations of the forward pass (kept for the   */
+    int64_t workspace_bytes;     /*   backward pass of the SAME struct) + backward scratch                              */
+    float *feat;                 /* device [B, out_dim] out                                                             */
+    float *pooled_out;           /* device [num_gin_layers, B, hidden] out or NULL: SumPooling of hidden_rep[1..]       */
+} gcc_ginx_pass;
+int64_t gcc_ginx_workspace_bytes(int64_t node_cap, int32_t batch_size, int32_t num_gin_layers, int32_t d_in, int32_t hidden,
+                                 int32_t out_dim);
+int32_t gcc_ginx_forward(const gcc_ginx_pass *p, void *stream);
+/* dfeat: device [B, out_dim]; grads: written (not accumulated).  After gcc_ginx_forward of the same pass (training = 1). */
+int32_t gcc_ginx_backward(const gcc_ginx_pass *p, const float *dfeat, const gcc_gin_grads *grads, void *stream);
+
 /* ------------------------------------------ wide GIN layers, bf16 (config 5) ---
  * BASELINE.json configs[4]: "GIN hid=256 layers=8 deg=32 bf16, SpMM+MFMA-MLP roofline run on batched
  * subgraphs".  The layer stack of UnsupervisedGIN.forward (gcc/models/gin.py:213-221) with hidden 256 and

@@ -74,6 +74,8 @@ typedef int hipError_t;
 static inline hipError_t hipGetLastError() { return 0; }
 static inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+enum { hipMemcpyDeviceToDevice = 3 };
+static inline hipError_t hipMemcpyAsync(void *d, const void *src, size_t n, int, hipStream_t) { memcpy(d, src, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 typedef void *hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return 0; }
