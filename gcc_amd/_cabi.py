@@ -217,6 +217,10 @@ SIGNATURES = {
     "gcc_ginx_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "gcc_ginx_forward": (ctypes.c_int32, [ctypes.POINTER(GccGinxPass), ctypes.c_void_p]),
     "gcc_ginx_backward": (ctypes.c_int32, [ctypes.POINTER(GccGinxPass), ctypes.c_void_p, ctypes.POINTER(GccGinGrads), ctypes.c_void_p]),
+    "gcc_ncex_forward": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_float, ctypes.c_int32] + [ctypes.c_void_p] * 8),
+    "gcc_queue_enqueue_x": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_void_p]),
     "gcc_ginw_forward": (ctypes.c_int32, [ctypes.POINTER(GccGinwArgs), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gcc_ginw_pack_weights": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
     "gcc_nce_workspace_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32]),

@@ -204,6 +204,52 @@ class _NSLoss(torch.autograd.Function):
         return dq, dk, None, None
 
 
+class WideNceEngine:
+    """The head at feature sizes above 64 (csrc/ginx.hip: gcc_ncex_forward / gcc_queue_enqueue_x): dense logits, and the
+    gradient of the loss taken in the forward call -- against the queue before the step's keys overwrite rows of it."""
+
+    def __init__(self, lib=None, ptr=None):
+        self.lib = lib if lib is not None else _cabi.load()
+        self.ptr = ptr if ptr is not None else _cabi.dev_ptr
+
+    def forward(self, rows, k, mem, T, mode, stream=None):
+        """mode 0: MoCo (rows = q, k = keys, mem = queue [K, D]); mode 1: in-batch (rows = feat_k, mem = feat_q).
+        -> dict(out, dlog, grad_rows, grad_mem, loss, prob)"""
+        B, D = rows.shape
+        K = mem.shape[0]
+        f32 = dict(dtype=torch.float32, device=rows.device)
+        ncols = K + 1 if mode == 0 else K
+        o = dict(out=torch.empty(B, ncols, **f32), dlog=torch.empty(B, ncols, **f32), grad_rows=torch.empty(B, D, **f32),
+                 grad_mem=torch.empty(K, D, **f32) if mode == 1 else None, loss=torch.empty(1, **f32), prob=torch.empty(1, **f32),
+                 acc=torch.zeros(2, dtype=torch.float64, device=rows.device))
+        rc = self.lib.gcc_ncex_forward(self.ptr(rows), self.ptr(k) if k is not None else None, self.ptr(mem), B, K, D, 1.0 / T, mode,
+                                       self.ptr(o["out"]), self.ptr(o["dlog"]), self.ptr(o["grad_rows"]),
+                                       self.ptr(o["grad_mem"]) if o["grad_mem"] is not None else None, self.ptr(o["loss"]),
+                                       self.ptr(o["prob"]), self.ptr(o["acc"]), stream)
+        if rc != 0:
+            raise RuntimeError(f"gcc_ncex_forward failed ({rc}): {self.lib.gcc_last_error().decode()}")
+        return o
+
+    def enqueue(self, mem, keys, index, stream=None):
+        rc = self.lib.gcc_queue_enqueue_x(self.ptr(mem), mem.shape[0], mem.shape[1], self.ptr(keys), keys.shape[0], int(index), stream)
+        if rc != 0:
+            raise RuntimeError(f"gcc_queue_enqueue_x failed ({rc}): {self.lib.gcc_last_error().decode()}")
+
+
+class _WideLoss(torch.autograd.Function):
+    """loss of a WideNceEngine.forward result; backward scales the gradients that call already produced."""
+
+    @staticmethod
+    def forward(ctx, rows, other, outs):
+        ctx.outs, ctx.has_other = outs, other is not None
+        return outs["loss"].reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        o = ctx.outs
+        return o["grad_rows"] * dloss, (o["grad_mem"] * dloss if ctx.has_other else None), None
+
+
 class NCELogits:
     """What ``MemoryMoCo.forward`` returns in place of the dense [B, K+1] tensor."""
 
@@ -230,8 +276,11 @@ class MemoryMoCo(nn.Module):
     def __init__(self, inputSize, outputSize, K, T=0.07, use_softmax=False, nce_dtype="f32"):
         super().__init__()
         self.nce_dtype = nce_dtype         # not in the reference: "bf16" selects the throughput mode of the head
-        if not 1 <= inputSize <= D:
-            raise NotImplementedError(f"feature size must be between 1 and {D} (narrower than {D}: run zero-padded, exactly)")
+        if inputSize < 1:
+            raise ValueError("feature size must be positive")
+        # up to 64: the fused head of csrc/nce.hip (narrower than 64: zero-padded, exactly); above: the dense any-size head of
+        # csrc/ginx.hip (--hidden-size above 64, train.py:93,627-629)
+        self.wide = inputSize > D
         if not use_softmax:
             raise NotImplementedError("train.py:628 always passes use_softmax=True (the exp/Z branch is dead)")
         self.outputSize = outputSize
@@ -247,16 +296,16 @@ class MemoryMoCo(nn.Module):
         self._engine = None
         print("using queue shape: ({},{})".format(self.queueSize, inputSize))
 
-    def engine(self) -> NceEngine:
+    def engine(self):
         if self._engine is None:
-            self._engine = NceEngine(dtype=self.nce_dtype)
+            self._engine = WideNceEngine() if self.wide else NceEngine(dtype=self.nce_dtype)
         return self._engine
 
     # ---- feature sizes below 64 (--hidden-size): the kernels' rows are 64 floats.  The ``memory`` buffer keeps the
     # reference's shape [K, inputSize] (checkpoint["contrast"]) as the column slice of a zero-padded [K, 64] block that the
     # kernels read and write; zero columns change no dot product, norm or gradient.
     def kernel_memory(self):
-        if self.inputSize == D:
+        if self.inputSize >= D:
             return self.memory
         m = self.memory
         big = getattr(self, "_mem64", None)
@@ -270,7 +319,21 @@ class MemoryMoCo(nn.Module):
     def _pad(self, t):
         return t if t.shape[1] == D else torch.nn.functional.pad(t, (0, D - t.shape[1]))
 
+    def _forward_wide(self, q, k):
+        eng = self.engine()
+        qc, kc = q.contiguous(), k.detach().contiguous()               # memory_moco.py:28
+        st = _stream(qc)
+        o = eng.forward(qc.detach(), kc, self.memory, self.T, 0, stream=st)   # logits AND gradient vs the queue before the update
+        keys = self.gather_keys(kc) if self.gather_keys is not None else kc
+        with torch.no_grad():                                          # memory_moco.py:55-61
+            eng.enqueue(self.memory, keys, self.index, stream=st)
+        self.index = (self.index + keys.shape[0]) % self.queueSize
+        loss = _WideLoss.apply(qc, None, o)
+        return NCELogits(loss, o["prob"].reshape(()), o["out"][:, 0], (q.shape[0], self.queueSize + 1), lambda: o["out"])
+
     def forward(self, q, k):
+        if self.wide:
+            return self._forward_wide(q, k)
         eng = self.engine()
         mem = self.kernel_memory()
         qc = self._pad(q).contiguous()                                 # (differentiable: the gradient comes back sliced)
@@ -292,6 +355,8 @@ class MemoryMoCo(nn.Module):
 
     def logits(self, q, k):
         """Dense ``out`` of memory_moco.py:40-44 without the enqueue side effect (tests, debugging)."""
+        if self.wide:
+            return self.engine().forward(q.detach().contiguous(), k.detach().contiguous(), self.memory, self.T, 0, stream=_stream(q))["out"]
         outs = self.engine().forward(self._pad(q.detach()).contiguous(), self._pad(k.detach()).contiguous(), self.kernel_memory(), self.T, 0,
                                      dense=True, stream=_stream(q))
         return outs["out"]
@@ -317,6 +382,12 @@ class NCESoftmaxLossNS(nn.Module):
 
 def e2e_logits(feat_q, feat_k, T, engine=None):
     """``torch.matmul(feat_k, feat_q.t()) / T`` of train.py:400, fused with its loss."""
+    if feat_q.shape[1] > D:                        # --hidden-size above 64: the dense any-size head (csrc/ginx.hip)
+        eng = engine if engine is not None else WideNceEngine()
+        fq, fk = feat_q.contiguous(), feat_k.contiguous()
+        o = eng.forward(fk.detach(), None, fq.detach(), T, 1, stream=_stream(fq))      # rows = feat_k, columns = feat_q
+        loss = _WideLoss.apply(fk, fq, o)
+        return NCELogits(loss, o["prob"].reshape(()), None, (fq.shape[0], fq.shape[0]), lambda: o["out"])
     eng = engine if engine is not None else NceEngine()
     if feat_q.shape[1] != D:                       # --hidden-size below 64: zero columns change no dot product
         feat_q = torch.nn.functional.pad(feat_q, (0, D - feat_q.shape[1]))

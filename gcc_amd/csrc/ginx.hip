@@ -41,6 +41,7 @@ struct GemmArgs {
     int32_t M, N, K;
     const int32_t *rows;
     int32_t rows_dim, atomic;
+    float alpha;
 };
 
 __global__ __launch_bounds__(kGT) void ginx_gemm_kernel(GemmArgs g)
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(kGT) void ginx_gemm_kernel(GemmArgs g)
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wr + 16 * i + 4 * (lane >> 4) + r, n = n0 + wc + 16 * j + (lane & 15);
                 if (m < M && n < g.N) {
-                    float v = acc[i][j][r];
+                    float v = acc[i][j][r] * g.alpha;
                     if (g.bias && (g.rows_dim != 2 || blockIdx.z == 0)) v += g.bias[n];
                     float *c = g.C + (int64_t)m * g.ldc + n;
                     if (g.atomic) atomicAdd(c, v); else *c = v;
@@ -160,15 +161,16 @@ __global__ void ginx_feat_bwd_kernel(const int32_t *node_off, const int32_t *row
 
 // out[v] = x[v] + sum over row v of x[col]  (+ add[v] when add != NULL): one wave per row, lanes over the channels
 __global__ __launch_bounds__(256) void ginx_spmm_kernel(const int32_t *node_off, const int32_t *row_ptr, const int32_t *col_idx, int B,
-                                                         const float *x, int D, const float *add, float *out)
+                                                         const float *x, int D, const float *add, float *out, float mult)
 {
     const int lane = (int)threadIdx.x & 63;
     const int v = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
     if (v >= node_off[B]) return;
     const int e0 = row_ptr[v], e1 = row_ptr[v + 1];
     for (int c = lane; c < D; c += 64) {
-        float acc = x[(int64_t)v * D + c];
-        for (int e = e0; e < e1; ++e) acc += x[(int64_t)col_idx[e] * D + c];
+        float nb = 0.f;
+        for (int e = e0; e < e1; ++e) nb += x[(int64_t)col_idx[e] * D + c];
+        float acc = x[(int64_t)v * D + c] + mult * nb;                   // (every edge counts `mult` times: gcc_gin_pass.edge_multiplicity)
         if (add) acc += add[(int64_t)v * D + c];
         out[(int64_t)v * D + c] = acc;
     }
@@ -329,6 +331,69 @@ __global__ __launch_bounds__(64) void ginx_normalize_bwd_kernel(const float *sco
     }
 }
 
+// ---- MoCo / InfoNCE head at any feature size (memory_moco.py:26-63, criterions.py:5-33), dense: the logits are materialised
+// out[b][0] = <q_b, k_b> / T   (memory_moco.py:33-34; the negatives come from the GEMM)
+__global__ __launch_bounds__(64) void ginx_rowdot_kernel(const float *q, const float *k, int D, float inv_T, float *out, int64_t ldo)
+{
+    const int b = (int)blockIdx.x, lane = (int)threadIdx.x;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += q[(int64_t)b * D + c] * k[(int64_t)b * D + c];
+    s = wave_sum(s);
+    if (lane == 0) out[(int64_t)b * ldo] = s * inv_T;
+}
+
+// per row: lse, CE against column 0 (mode 0) or the row's own index (mode 1: criterions.py:27-33), d loss / d logits * B
+// = softmax - onehot into dlog; acc[0] += CE, acc[1] += the label's logit (train.py:394,401 "prob")
+__global__ __launch_bounds__(256) void ginx_ce_kernel(const float *out, int64_t ldo, int ncols, int mode, float *dlog, double *acc)
+{
+    __shared__ float red[4];
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float *x = out + (int64_t)b * ldo;
+    float m = -3.0e38f;
+    for (int j = tid; j < ncols; j += 256) m = fmaxf(m, x[j]);
+    m = wave_max(m);
+    if (lane == 0) red[wv] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int j = tid; j < ncols; j += 256) s += expf(x[j] - m);
+    s = wave_sum(s);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    const float lse = m + logf(s);
+    const int label = mode == 0 ? 0 : b;
+    for (int j = tid; j < ncols; j += 256) dlog[(int64_t)b * ldo + j] = expf(x[j] - lse) - (j == label ? 1.f : 0.f);
+    if (tid == 0) {
+        atomicAdd(&acc[0], (double)(lse - x[label]));
+        atomicAdd(&acc[1], (double)x[label]);
+    }
+}
+
+__global__ void ginx_ce_final_kernel(const double *acc, int B, float *loss, float *prob)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { *loss = (float)(acc[0] / B); *prob = (float)(acc[1] / B); }
+}
+
+// g[b][c] += coef * dlog[b * ldd] * k[b][c]   (the positive logit's share of d loss / d q)
+__global__ void ginx_rank1_rows_kernel(const float *dlog, int64_t ldd, const float *k, int B, int D, float coef, float *g)
+{
+    const int i = (int)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D;
+    g[i] += coef * dlog[(int64_t)b * ldd] * k[i];
+}
+
+// memory.index_copy_(0, (arange(n) + index) % K, keys)   (memory_moco.py:55-61)
+__global__ void ginx_enqueue_kernel(float *mem, int K, int D, const float *keys, int n, int index)
+{
+    const int i = (int)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    const int r = i / D, c = i % D;
+    mem[(int64_t)((index + r) % K) * D + c] = keys[i];
+}
+
 // ---------------------------------------------------------------- host side ----
 struct XLayout {                         // float offsets inside the pass's workspace
     int64_t x0, agg[GCC_GIN_MAX_LAYERS], z1[GCC_GIN_MAX_LAYERS], a1[GCC_GIN_MAX_LAYERS], z2[GCC_GIN_MAX_LAYERS], a2[GCC_GIN_MAX_LAYERS],
@@ -363,9 +428,9 @@ XLayout ginx_layout(int64_t N, int B, int L, int d_in, int W, int O)
 }
 
 void gemm(hipStream_t s, const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn, float *C, int64_t ldc,
-          int M, int N, int K, const float *bias, const int32_t *rows, int rows_dim, int64_t rows_cap)
+          int M, int N, int K, const float *bias, const int32_t *rows, int rows_dim, int64_t rows_cap, float alpha = 1.0f)
 {
-    GemmArgs g = {A, B, bias, C, sam, sak, sbk, sbn, ldc, M, N, K, rows, rows_dim, rows_dim == 2 ? 1 : 0};
+    GemmArgs g = {A, B, bias, C, sam, sak, sbk, sbn, ldc, M, N, K, rows, rows_dim, rows_dim == 2 ? 1 : 0, alpha};
     const int mcap = rows_dim == 1 ? (int)rows_cap : M;
     dim3 grid((mcap + kBM - 1) / kBM, (N + kBN - 1) / kBN, rows_dim == 2 ? (unsigned)((rows_cap + kSplitRows - 1) / kSplitRows) : 1u);
     if (rows_dim == 2) (void)hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * (size_t)ldc, s);     // (C is dense: ldc == N)
@@ -433,9 +498,8 @@ int32_t gcc_ginx_forward(const gcc_ginx_pass *p, void *stream)
     };
     hipLaunchKernelGGL(ginx_pool_kernel, dim3(B), dim3(256), 0, s, p->node_off, h, D, ws + x.pooled[0]);
     for (int l = 0; l < L; ++l) {
-        if (p->edge_multiplicity > 1) { snprintf(g_err, kErrLen, "gcc_ginx_forward: edge_multiplicity > 1 is not supported at this width"); return -4; }
         hipLaunchKernelGGL(ginx_spmm_kernel, dim3(blocks(N, 4)), dim3(256), 0, s, p->node_off, p->row_ptr, p->col_idx, B, h, D, (const float *)nullptr,
-                           ws + x.agg[l]);
+                           ws + x.agg[l], (float)(p->edge_multiplicity > 1 ? p->edge_multiplicity : 1));
         gemm(s, ws + x.agg[l], D, 1, w.lin0_w[l], 1, D, ws + x.z1[l], W, 0, W, D, w.lin0_b[l], rows, 1, N);            // z1 = agg W0^T + b0
         bn(ws + x.z1[l], w.bn_a[l], x.mr[l][0], ws + x.a1[l]);
         gemm(s, ws + x.a1[l], W, 1, w.lin1_w[l], 1, W, ws + x.z2[l], W, 0, W, W, w.lin1_b[l], rows, 1, N);             // z2 = a1 W1^T + b1
@@ -465,6 +529,7 @@ int32_t gcc_ginx_backward(const gcc_ginx_pass *p, const float *dfeat, const gcc_
 {
     if (int rc = ginx_check(p, "gcc_ginx_backward")) return rc;
     if (!dfeat || !gr || !p->training) { snprintf(g_err, kErrLen, "gcc_ginx_backward: needs dfeat, grads and a training-mode pass"); return -1; }
+    if (p->edge_multiplicity > 1) { snprintf(g_err, kErrLen, "gcc_ginx_backward: edge_multiplicity must be 1 (as gcc_gin_backward)"); return -4; }
     hipStream_t s = (hipStream_t)stream;
     const gcc_gin_weights &w = p->w;
     const int L = w.num_gin_layers, B = p->batch_size, W = p->hidden, O = p->out_dim, d_in = w.pos_dim + w.deg_emb_dim + 1;
@@ -522,7 +587,7 @@ int32_t gcc_ginx_backward(const gcc_ginx_pass *p, const float *dfeat, const gcc_
         // d h_{l-1} = d agg + A d agg (the batched subgraph is symmetric) + the pooled readout of hidden_rep[l]'s input
         readout_bwd(l, ws + x.dpool);
         hipLaunchKernelGGL(ginx_pool_bwd_kernel, dim3(blocks(N * Din)), dim3(256), 0, s, p->node_off, p->graph_id, B, ws + x.dpool, Din, dC, 0);
-        hipLaunchKernelGGL(ginx_spmm_kernel, dim3(blocks(N, 4)), dim3(256), 0, s, p->node_off, p->row_ptr, p->col_idx, B, dB_, Din, (const float *)dC, dA);
+        hipLaunchKernelGGL(ginx_spmm_kernel, dim3(blocks(N, 4)), dim3(256), 0, s, p->node_off, p->row_ptr, p->col_idx, B, dB_, Din, (const float *)dC, dA, 1.0f);
     }
     // d x0 (in dA, width d_in) -> the degree embedding's rows
     (void)hipMemsetAsync(gr->degree_embedding, 0, sizeof(float) * (size_t)(w.max_degree + 1) * w.deg_emb_dim, s);
@@ -530,6 +595,41 @@ int32_t gcc_ginx_backward(const gcc_ginx_pass *p, const float *dfeat, const gcc_
                        w.max_degree, dA, gr->degree_embedding);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_ginx_backward: launch failed: %s", hipGetErrorString(e)); return -10; }
+    return 0;
+}
+
+/* ---- the head at any feature size */
+int32_t gcc_ncex_forward(const float *q, const float *k, const float *mem, int32_t B, int32_t K, int32_t D, float inv_T, int32_t mode,
+                         float *out, float *dlog, float *grad_rows, float *grad_mem, float *loss, float *prob, double *acc, void *stream)
+{
+    if (!q || !mem || !out || !dlog || !grad_rows || !loss || !prob || !acc || B < 1 || K < 1 || D < 1 || (mode == 0 && !k) || (mode == 1 && (K != B || !grad_mem))) {
+        snprintf(g_err, kErrLen, "gcc_ncex_forward: bad arguments");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int ncols = mode == 0 ? K + 1 : K;
+    const int64_t ld = ncols;
+    float *neg = out + (mode == 0 ? 1 : 0);
+    (void)hipMemsetAsync(acc, 0, 2 * sizeof(double), s);
+    if (mode == 0) hipLaunchKernelGGL(ginx_rowdot_kernel, dim3(B), dim3(64), 0, s, q, k, D, inv_T, out, ld);
+    gemm(s, q, D, 1, mem, 1, D, neg, ld, B, K, D, nullptr, nullptr, 0, 0, inv_T);                                  // q mem^T / T
+    hipLaunchKernelGGL(ginx_ce_kernel, dim3(B), dim3(256), 0, s, (const float *)out, ld, ncols, mode, dlog, acc);
+    hipLaunchKernelGGL(ginx_ce_final_kernel, dim3(1), dim3(64), 0, s, (const double *)acc, B, loss, prob);
+    // the gradients for a unit upstream gradient, taken NOW -- before the caller enqueues the step's keys over queue rows
+    // (memory_moco.py:55-61): d loss / d rows = (softmax - onehot) [k; mem] / (T B)
+    const float coef = inv_T / (float)B;
+    gemm(s, dlog + (mode == 0 ? 1 : 0), ld, 1, mem, D, 1, grad_rows, D, B, D, K, nullptr, nullptr, 0, 0, coef);
+    if (mode == 0) hipLaunchKernelGGL(ginx_rank1_rows_kernel, dim3(blocks((int64_t)B * D)), dim3(256), 0, s, (const float *)dlog, ld, k, B, D, coef, grad_rows);
+    else gemm(s, dlog, 1, ld, q, D, 1, grad_mem, D, K, D, B, nullptr, nullptr, 0, 0, coef);                         // d loss / d mem rows = dlog^T rows / (T B)
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_ncex_forward: launch failed: %s", hipGetErrorString(e)); return -10; }
+    return 0;
+}
+
+int32_t gcc_queue_enqueue_x(float *mem, int32_t K, int32_t D, const float *keys, int32_t nkeys, int32_t index, void *stream)
+{
+    if (!mem || !keys || nkeys < 0 || nkeys > K || index < 0 || index >= K) { snprintf(g_err, kErrLen, "gcc_queue_enqueue_x: bad arguments"); return -1; }
+    hipLaunchKernelGGL(ginx_enqueue_kernel, dim3(blocks((int64_t)nkeys * D)), dim3(256), 0, (hipStream_t)stream, mem, K, D, keys, nkeys, index);
     return 0;
 }
 

@@ -394,7 +394,7 @@ typedef struct gcc_ginx_pass {
     int32_t normalize;           /* graph_encoder.py:195                                                                */
     const float *dropout_keep;   /* device [num_gin_layers + 1, B, out_dim] 0 / 1 keep masks, or NULL: no dropout       */
     int32_t hidden, out_dim;     /* node_hidden_dim, output_dim: any positive size                                      */
-    int32_t edge_multiplicity;   /* gcc_gin_pass.edge_multiplicity; 0 / 1 only                                          */
+    int32_t edge_multiplicity;   /* gcc_gin_pass.edge_multiplicity (forward; the backward pass requires 0 / 1)          */
     int32_t reserved_;
     int64_t node_cap;            /* rows the launches are sized for (node_off[B] <= node_cap, read on the device)       */
     gcc_gin_weights w;
@@ -408,6 +408,17 @@ int64_t gcc_ginx_workspace_bytes(int64_t node_cap, int32_t batch_size, int32_t n
 int32_t gcc_ginx_forward(const gcc_ginx_pass *p, void *stream);
 /* dfeat: device [B, out_dim]; grads: written (not accumulated).  After gcc_ginx_forward of the same pass (training = 1). */
 int32_t gcc_ginx_backward(const gcc_ginx_pass *p, const float *dfeat, const gcc_gin_grads *grads, void *stream);
+
+/* MemoryMoCo.forward + NCESoftmaxLoss (mode 0: memory_moco.py:26-63, criterions.py:5-17) / the in-batch E2E head (mode 1:
+ * out = rows mem^T / T with mem = the other view's features, K = B, labels on the diagonal: train.py:400, criterions.py:20-33)
+ * at any feature size D, dense: out [B, K + 1] (mode 0: column 0 = <q, k> / T) or [B, B]; dlog: same shape, softmax - onehot;
+ * grad_rows [B, D] = d loss / d rows and (mode 1) grad_mem [B, D] = d loss / d mem, both for a unit upstream gradient and
+ * taken against the queue as it is NOW -- the caller enqueues afterwards; loss, prob: device scalars (mean CE; mean label
+ * logit, train.py:394,401); acc: device double[2] scratch. */
+int32_t gcc_ncex_forward(const float *q, const float *k, const float *mem, int32_t B, int32_t K, int32_t D, float inv_T, int32_t mode,
+                         float *out, float *dlog, float *grad_rows, float *grad_mem, float *loss, float *prob, double *acc, void *stream);
+/* memory.index_copy_(0, (arange(nkeys) + index) % K, keys) (memory_moco.py:55-61) for rows of D floats */
+int32_t gcc_queue_enqueue_x(float *mem, int32_t K, int32_t D, const float *keys, int32_t nkeys, int32_t index, void *stream);
 
 /* ------------------------------------------ wide GIN layers, bf16 (config 5) ---
  * BASELINE.json configs[4]: "GIN hid=256 layers=8 deg=32 bf16, SpMM+MFMA-MLP roofline run on batched

@@ -1,0 +1,142 @@
+"""--hidden-size above 64 (train.py:93; GraphEncoder(node_hidden_dim, output_dim), graph_encoder.py:44-63): the any-width
+encoder of gcc_amd/csrc/ginx.hip through gcc_amd/encoder_wide.py -- forward in training mode (batch statistics, running
+statistics updated), backward, eval mode, state_dict round trip -- against oracle/encoder.py built with the same widths.
+Emulator tier; the device tier is tests/test_wide_encoder_gpu.py."""
+import pytest
+import torch
+
+from gcc_amd.encoder import GraphEncoder
+from gcc_amd.encoder_wide import WideGinEngine
+from oracle import encoder as E
+from tests.hipemu.emu_driver import emu_lib
+from tests.test_headline_step_emu import B, OracleSampler
+
+
+def wide_encoder(hidden, out, layers=5):
+    return GraphEncoder(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
+                        freq_embedding_size=16, degree_embedding_size=16, output_dim=out, node_hidden_dim=hidden,
+                        edge_hidden_dim=hidden, num_layers=layers, num_step_set2set=6, num_layer_set2set=3, norm=True,
+                        gnn_model="gin", degree_input=True)
+
+
+def emu_wide_engine():
+    return WideGinEngine(lib=emu_lib(), ptr=lambda t: 0 if t is None else t.data_ptr())
+
+
+def check_against_oracle(model, oracle, q, keep, out, hidden, monkeypatch, rtol=2e-4):
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: keep.clone())       # the API path draws its dropout masks here
+    feat, pooled = model(q, return_all_outputs=True)
+    assert tuple(feat.shape) == (B, out) and all(tuple(t.shape) == (B, hidden) for t in pooled)
+    n = q.n
+    args = (q.node_off.long(), q.row_ptr[: n + 1].long(), q.col_idx.long(), q.pos_undirected[:n])
+    ref, ref_pooled = oracle(*args, dropout_masks=keep, return_all_outputs=True)
+    torch.testing.assert_close(feat, ref, rtol=rtol, atol=2e-5)
+    for a, b in zip(pooled, ref_pooled):
+        torch.testing.assert_close(a, b, rtol=rtol, atol=2e-4)
+    d = torch.randn(B, out)
+    feat.backward(d)
+    ref.backward(d)
+    refg = dict(oracle.named_parameters())
+    for name, p in model.named_parameters():
+        if refg[name].grad is None:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, name
+            continue
+        assert p.grad.shape == p.shape
+        scale = max(float(refg[name].grad.abs().max()), 1e-3)
+        torch.testing.assert_close(p.grad, refg[name].grad, rtol=2e-3, atol=max(1e-3 * scale, 1e-4 if name.endswith("bias") else 5e-6),
+                                   msg=lambda m, name=name: f"{name}: {m}")
+    return args
+
+
+@pytest.mark.parametrize("hidden,out,layers", [(128, 128, 5), (96, 80, 3), (256, 256, 5), (72, 40, 2)])
+def test_wide_api_path_forward_backward_vs_oracle(hidden, out, layers, monkeypatch):
+    torch.manual_seed(hidden * 100 + out)
+    model = wide_encoder(hidden, out, layers)
+    assert model.wide and not model.is_padded()
+    oracle = E.OracleGraphEncoder(node_hidden_dim=hidden, output_dim=out, num_layers=layers)
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == {k: tuple(v.shape) for k, v in oracle.state_dict().items()}
+    oracle.load_state_dict(model.state_dict())
+    model._wide_engine = emu_wide_engine()
+    model.train()
+    oracle.train()
+    q, _ = OracleSampler().views
+    keep = (torch.rand(layers, B, out) >= 0.5).float()
+    args = check_against_oracle(model, oracle, q, keep, out, hidden, monkeypatch)
+    # running statistics moved exactly as torch's BatchNorm1d moves them (momentum 0.1, unbiased variance)
+    for (k1, v1), (k2, v2) in zip(model.state_dict().items(), oracle.state_dict().items()):
+        if "running_" in k1 or "num_batches" in k1:
+            torch.testing.assert_close(v1, v2, rtol=1e-4, atol=1e-5, msg=lambda m, k=k1: f"{k}: {m}")
+    # the state survives a save / load round trip, and eval mode (running statistics, no dropout) agrees too
+    m2 = wide_encoder(hidden, out, layers)
+    m2.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+    m2._wide_engine = emu_wide_engine()
+    m2.eval()
+    oracle.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(m2(q), oracle(*args), rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(m2.embed_views(q, q), oracle(*args), rtol=2e-4, atol=2e-5)
+
+
+def test_the_fused_engine_refuses_a_wide_model():
+    model = wide_encoder(128, 128)
+    with pytest.raises(NotImplementedError, match="runs through GraphEncoder.forward"):
+        model.engine()
+
+
+def emu_wide_nce():
+    from gcc_amd.contrast import WideNceEngine
+
+    return WideNceEngine(lib=emu_lib(), ptr=lambda t: 0 if t is None else t.data_ptr())
+
+
+@pytest.mark.parametrize("D,K", [(128, 96), (80, 200), (256, 64)])
+def test_wide_moco_head_vs_oracle(D, K):
+    """MemoryMoCo(inputSize > 64): dense logits, loss, prob, the gradient w.r.t. q against the queue BEFORE the enqueue, the
+    queue after it (memory_moco.py:26-63, criterions.py:5-17), over three steps with a wrapping ring pointer."""
+    from gcc_amd.contrast import MemoryMoCo, NCESoftmaxLoss
+
+    torch.manual_seed(D + K)
+    Bq = 40
+    contrast = MemoryMoCo(D, None, K, 0.07, use_softmax=True)
+    contrast._engine = emu_wide_nce()
+    mem = contrast.memory.clone()
+    index = 0
+    for step in range(3):
+        q = torch.nn.functional.normalize(torch.randn(Bq, D), dim=1).requires_grad_()
+        k = torch.nn.functional.normalize(torch.randn(Bq, D), dim=1)
+        qo = q.detach().clone().requires_grad_()
+        out = contrast(q, k)
+        loss = NCESoftmaxLoss()(out)
+        loss.backward()
+        ref_out, new_index = E.moco_forward(mem, index, qo, k, 0.07)
+        ref_loss = E.nce_softmax_loss(ref_out)
+        ref_loss.backward()
+        torch.testing.assert_close(out.dense(), ref_out.detach(), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(loss.detach(), ref_loss.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(out.prob, ref_out[:, 0].mean().detach(), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(out[:, 0], ref_out[:, 0].detach(), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(q.grad, qo.grad, rtol=1e-3, atol=1e-6)
+        torch.testing.assert_close(contrast.memory, mem, rtol=0, atol=0)      # E.moco_forward enqueued into `mem` in place
+        index = new_index
+        assert contrast.index == index
+
+
+def test_wide_e2e_head_vs_oracle():
+    from gcc_amd.contrast import NCESoftmaxLossNS, e2e_logits
+
+    torch.manual_seed(3)
+    Bq, D = 48, 128
+    fq = torch.nn.functional.normalize(torch.randn(Bq, D), dim=1).requires_grad_()
+    fk = torch.nn.functional.normalize(torch.randn(Bq, D), dim=1).requires_grad_()
+    rq, rk = fq.detach().clone().requires_grad_(), fk.detach().clone().requires_grad_()
+    out = e2e_logits(fq, fk, 0.07, engine=emu_wide_nce())
+    loss = NCESoftmaxLossNS()(out)
+    loss.backward()
+    ref_out = rk @ rq.t() / 0.07                                                  # train.py:400
+    ref_loss = E.nce_softmax_loss_ns(ref_out)
+    ref_loss.backward()
+    torch.testing.assert_close(out.dense(), ref_out.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(loss.detach(), ref_loss.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out.prob, ref_out.diagonal().mean().detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(fq.grad, rq.grad, rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(fk.grad, rk.grad, rtol=1e-3, atol=1e-6)

@@ -338,7 +338,10 @@ def main(args):
 
     posemb = None                                         # API path only; the fused steps embed in their producer lanes
     trainer, optimizer = None, None
-    if args.optimizer == "adam":
+    wide = args.hidden_size > 64          # above 64 channels: the any-width kernels (csrc/ginx.hip) through the API path below
+    if wide and world > 1:
+        raise NotImplementedError("--hidden-size above 64 runs the single-GPU API path; the data-parallel step is the fused 64-channel one")
+    if args.optimizer == "adam" and not wide:
         # data pipeline: `producer_lanes` streams, each preparing `producer_chunk` steps per turn (sampler calls + one
         # multi-view eigensolver call) -- the role of the reference's --num-workers DataLoader processes
         lanes, depth = [], 2
@@ -362,12 +365,16 @@ def main(args):
         # synchronisation: no per-step stream hand-offs (gcc_amd/train_step.py: MoCoTrainStep.step)
         trainer.relaxed_streams = True
     else:
-        # train.py:658-679: SGD(momentum) / Adagrad through autograd and torch.optim -- the API path of the same kernels
+        # train.py:658-679: SGD(momentum) / Adagrad through autograd and torch.optim -- the API path of the same kernels; also
+        # Adam for models wider than the fused step's 64 channels
         if world > 1:
             raise NotImplementedError("--optimizer sgd/adagrad runs the single-GPU API path; the data-parallel step is fused Adam")
         posemb = DevicePosEmb(args.batch_size, train_dataset.node_cap, args.positional_embedding_size,
                               device=dev, seed=args.seed)
-        if args.optimizer == "sgd":
+        if args.optimizer == "adam":                      # (--hidden-size above 64) train.py:667-672
+            optimizer = torch.optim.Adam(model.parameters(), lr=args.learning_rate, betas=(args.beta1, args.beta2),
+                                         weight_decay=args.weight_decay)
+        elif args.optimizer == "sgd":
             optimizer = torch.optim.SGD(model.parameters(), lr=args.learning_rate, momentum=args.momentum,
                                         weight_decay=args.weight_decay)
         else:
