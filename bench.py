@@ -289,13 +289,20 @@ def cpu_baseline(rp, ci, args):
                           f"(OpenMP x{threads}) + SciPy eigsh pos-emb ({workers} processes) + torch-CPU "
                           f"{head} oracle ({torch.get_num_threads()} threads), stages pipelined one step deep")
     # BASELINE.md B-ref-N: the reference-shaped data pipeline on every host core, and on train.py:49's default 12 workers
+    # (every core, a quarter of them capped at 64, and the reference's default 12: the per-sample Python pipeline does not scale
+    #  to 256 processes on the GPU box's host -- 12 workers deliver 2.8 k subgraphs/s, 256 deliver 0.5-0.9 k: page faults of the
+    #  per-seed O(|V|) clear and the interpreter's allocator across 256 address spaces -- so the line carries the curve and
+    #  `best`, the figure the >= 10x statement is made against)
     shaped = {}
-    for procs in sorted({cores, min(12, cores)}, reverse=True):
-        shaped["nproc" if procs == cores else "workers_%d" % procs] = cpu_baseline_reference_shaped(rp, ci, args, procs)
+    for procs in sorted({cores, min(64, max(12, cores // 4)), min(12, cores)}, reverse=True):
+        if procs <= cores:
+            shaped["nproc" if procs == cores else "workers_%d" % procs] = cpu_baseline_reference_shaped(rp, ci, args, procs)
     if cores <= 12:
         shaped["workers_12"] = dict(shaped["nproc"], note="this host has no more than 12 cores: the same run")
+    best = max(shaped, key=lambda k: shaped[k].get("value") or 0.0)
+    shaped["best"] = dict(config=best, value=shaped[best].get("value"), cores=shaped[best].get("cores"))
     if res is None:                              # --mode sample-ready: the data pipeline IS the workload
-        top = shaped["nproc"]
+        top = shaped[best]
         res = dict(value=top.get("value"), unit="subgraphs/s", cores=top.get("cores"), kind="port", sample=top.get("sample"))
     res["reference_shaped"] = shaped
     return res
@@ -979,9 +986,11 @@ def main():
                 torch.cuda.synchronize()
                 posemb.check_status(strict=True)
                 out["cpu_baseline"]["parity_posemb"] = parity_posemb(q, q.pos_undirected.cpu().numpy(), ev.cpu().numpy())
-            ref_n = (out["cpu_baseline"].get("reference_shaped") or {}).get("nproc") or {}
-            if ref_n.get("value"):
-                out["cpu_baseline"]["vs_reference_shaped_nproc"] = out["value"] / ref_n["value"]
+            shaped = out["cpu_baseline"].get("reference_shaped") or {}
+            if (shaped.get("nproc") or {}).get("value"):
+                out["cpu_baseline"]["vs_reference_shaped_nproc"] = out["value"] / shaped["nproc"]["value"]
+            if (shaped.get("best") or {}).get("value"):
+                out["cpu_baseline"]["vs_reference_shaped_best"] = out["value"] / shaped["best"]["value"]
         try:                                     # (RCCL's version banner sits in the C library's stdout buffer until exit: out first,
             import ctypes                        #  so that the JSON line is the LAST line of stdout)
             ctypes.CDLL(None).fflush(None)

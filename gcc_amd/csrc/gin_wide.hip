@@ -807,7 +807,11 @@ __global__ void ginw_classify_kernel(WideArgs a)
         if (n <= kNodes) continue;
         const int nblk = (n + kNodes - 1) / kNodes;
         const int at = atomicAdd(&cnt, nblk);
-        if (at + nblk > a.big_cap) { atomicOr(a.status, (int32_t)GCC_STATUS_GINW_TOO_LARGE); continue; }
+        if (at + nblk > a.big_cap) {                         // no room: refused (status); the slots it reserved below the cap are
+            atomicOr(a.status, (int32_t)GCC_STATUS_GINW_TOO_LARGE);      // marked so that the block kernel skips them instead of
+            for (int r = 0; r < nblk && at + r < a.big_cap; ++r) a.big_work[2 + 2 * (at + r)] = -1;   // reading uninitialised pairs
+            continue;
+        }
         for (int r = 0; r < nblk; ++r) { a.big_work[2 + 2 * (at + r)] = b; a.big_work[3 + 2 * (at + r)] = r; }
     }
     __syncthreads();
@@ -830,6 +834,7 @@ __global__ __launch_bounds__(kT2) void gin_wide_big_kernel(WideArgs a, int layer
 
     for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
         const int b = a.big_work[2 + 2 * it], r = a.big_work[3 + 2 * it];
+        if (b < 0) continue;                                 // (workgroup-uniform) a slot of a refused subgraph
         const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
         const int nblk = (n + kNodes - 1) / kNodes;
         const int row0 = n0 + r * kNodes, nr = min(kNodes, n - r * kNodes);

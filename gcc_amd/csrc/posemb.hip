@@ -368,15 +368,12 @@ struct PosHead {                     // head of the caller's workspace (zeroed p
 // The deflation tables (24 KiB) are built in LDS where the eigenvector arrays go later; the 8 bytes per node that the
 // expansion at the end needs of them (defl_record) go to the workspace: it keeps the mid class at 132 KiB, so that a
 // workgroup of the training step (26 KiB) still fits on the same CU, and the small class at 50 KiB (3 per CU).
-#ifndef GCC_POSEMB_LDS_PAD
-#define GCC_POSEMB_LDS_PAD 0          // timing experiments: LDS a 65..128-class workgroup requests beyond (or, negative: below -- the LU batch narrows) its default
-#endif
 template <int kNMax, int kT, bool kGlobalA>
 __host__ __device__ constexpr int direct_lds_bytes()
 {
     return kGlobalA ? (kNMax > kGMax ? kBLds : kGLds)
                     : (int)(sizeof(float) * (6 * kNMax + 32 * kYld + kT + kNMax * (kNMax + 1) + kNMax * kYld)
-                            + kNMax * (33 * 8 + 32)) + (kNMax > 64 ? GCC_POSEMB_LDS_PAD : 0);
+                            + kNMax * (33 * 8 + 32));
 }
 
 struct TriLds {

@@ -83,10 +83,7 @@ constexpr int kBigGrid = GCC_INDUCE_BIG_GRID;     // induce workgroups of the bi
 constexpr int kRecInts = 12;       // per induce workgroup: {count, g, part, n, quads, unit base, scratch base (2), scanned rows, hubs, pad}
 constexpr int kPrefixThreads = 1024;
 constexpr int kCandCap = 256;      // per-wave queue of Bloom survivors (drained before every round of 256 that might not fit)
-#ifndef GCC_PACK_PARTS
-#define GCC_PACK_PARTS 2
-#endif
-constexpr int kPackParts = GCC_PACK_PARTS;      // pack workgroups per subgraph.  4 while every row was scanned (hub-seed subgraphs had 100x the units); with the
+constexpr int kPackParts = 2;      // pack workgroups per subgraph.  4 while every row was scanned (hub-seed subgraphs had 100x the units); with the
                                                 // hub rows out, measured per 16-step launch G1 / G2: 4 parts 0.606 / 1.486 ms, 2 parts 0.556 / 1.458, 1 part
                                                 // 0.546 / 1.520; one part for small subgraphs and four for big ones with the idle parts leaving at once: 0.599 / 1.476
 // Hub rows are NOT scanned (round 4).  The parent graph is symmetric (the input contract, x2dgl.py:43-47): member v's row
@@ -98,10 +95,7 @@ constexpr int kPackParts = GCC_PACK_PARTS;      // pack workgroups per subgraph.
 // 72 % of the entries a full scan reads.  Measured (profiles/r4_hub_rows.md, r4_sampler_classes.md): induction 437 ->
 // 232 us (G1) and 1826 -> 1105 us (G2) per 16-step launch before the size classes, the pair searches and the row writer
 // give 90 / 170 us back; the optimum over (threshold, slots) is flat around 512 .. 1024 x 32 (64 slots: no gain).
-#ifndef GCC_MAX_HUB
-#define GCC_MAX_HUB 32
-#endif
-constexpr int kMaxHub = GCC_MAX_HUB;   // (<= 64) most hub rows per subgraph (the workspace is laid out for this many)
+constexpr int kMaxHub = 32;   // (<= 64) most hub rows per subgraph (the workspace is laid out for this many)
 constexpr int kHubDegreeDefault = 512;
 constexpr int kMaxHubsDefault = 32; // with more rows over the threshold, the threshold of THAT subgraph rises to the power of two that
                                    // leaves at most this many: the pair searches grow with the square of the count, the bytes saved come
