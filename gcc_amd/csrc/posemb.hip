@@ -672,11 +672,21 @@ __device__ bool inverse_iteration_step(const TriLds &w, int n, int j, int jl, fl
     float cd = w.dg[0] - shift, cs = n > 1 ? w.of[0] : 0.f;
     float cy = random_rhs ? hash_unit(hseed, (uint32_t)j, 0u) : Y[0];
     // forward elimination, branch free: row i is either the running row (cd, cs, 0 | cy) or, when the sub-diagonal
-    // entry is larger, the next row of T - shift (sub, nd, ns | by) and the running row is eliminated instead
+    // entry is larger, the next row of T - shift (sub, nd, ns | by) and the running row is eliminated instead.
+    // The operands of row i + 2 are requested BEFORE row i's dependent arithmetic (round 5; the compiler cannot move the loads
+    // over the loop's own stores: Y is read and written).  Measured: NO gain -- 'invit' of the 65..128 class 86 against 83 us
+    // per item (scripts/gpu/r5_call7.sh) --, i.e. a row's ~240 cycles are the lone half-wave's own instruction issue (7 LDS
+    // operations + ~15 dependent VALU operations per row), not the latency of its loads.  Kept: same arithmetic, same results.
+    float sub = cs, nd = n > 1 ? w.dg[1] - shift : 0.f, ns = n > 2 ? w.of[1] : 0.f;
+    float by = n > 1 ? (random_rhs ? hash_unit(hseed, (uint32_t)j, 1u) : Y[ldy]) : 0.f;
 #pragma unroll 4
     for (int i = 0; i + 1 < n; ++i) {
-        const float sub = w.of[i], nd = w.dg[i + 1] - shift, ns = i + 2 < n ? w.of[i + 1] : 0.f;
-        const float by = random_rhs ? hash_unit(hseed, (uint32_t)j, (uint32_t)(i + 1)) : Y[(i + 1) * ldy];
+        float nd2 = 0.f, ns2 = 0.f, by2 = 0.f;               // row i + 2 (the next iteration's "next row")
+        if (i + 2 < n) {
+            nd2 = w.dg[i + 2] - shift;
+            ns2 = i + 3 < n ? w.of[i + 2] : 0.f;
+            by2 = random_rhs ? hash_unit(hseed, (uint32_t)j, (uint32_t)(i + 2)) : Y[(i + 2) * ldy];
+        }
         const bool swap = fabsf(cd) < fabsf(sub);
         const float piv = swap ? sub : cd, oth = swap ? cd : sub;
         const float mult = piv != 0.f ? oth * fast_rcp(piv) : 0.f;
@@ -688,18 +698,28 @@ __device__ bool inverse_iteration_step(const TriLds &w, int n, int j, int jl, fl
         const float ncs = swap ? -mult * ns : ns;
         const float ncy = swap ? cy - mult * by : by - mult * cy;
         cd = ncd; cs = ncs; cy = ncy;
+        sub = ns;                                            // of[i + 1]: the sub-diagonal entry under the new running row (i + 2 < n here whenever it is used)
+        nd = nd2; ns = ns2; by = by2;
     }
     Ud[(n - 1) * ldu] = cd; Us[(n - 1) * ldu] = 0.f; Uf[(n - 1) * ldf] = 0; Y[(n - 1) * ldy] = cy;
     float x1 = 0.f, x2 = 0.f, ss = 0.f;
+    // back substitution, the next row's operands requested ahead in the same way
+    float d = cd, us = 0.f, s2 = 0.f, yi = cy;               // row n - 1
 #pragma unroll 4
     for (int i = n - 1; i >= 0; --i) {
-        float d = Ud[i * ldu];
+        float dn = 0.f, usn = 0.f, s2n = 0.f, yn = 0.f;      // row i - 1
+        if (i > 0) {
+            dn = Ud[(i - 1) * ldu];
+            usn = Us[(i - 1) * ldu];
+            s2n = (Uf[(i - 1) * ldf] && i + 1 < n) ? w.of[i] : 0.f;
+            yn = Y[(i - 1) * ldy];
+        }
         if (fabsf(d) < kPivTiny) d = d < 0.f ? -kPivTiny : kPivTiny;
-        const float s2 = (Uf[i * ldf] && i + 2 < n) ? w.of[i + 1] : 0.f;
-        const float x = (Y[i * ldy] - Us[i * ldu] * x1 - s2 * x2) * fast_rcp(d);
+        const float x = (yi - us * x1 - s2 * x2) * fast_rcp(d);
         Y[i * ldy] = x;
         x2 = x1; x1 = x;
         ss = fmaf(x, x, ss);
+        d = dn; us = usn; s2 = s2n; yi = yn;
     }
     const bool ok = ss > 0.f && ss < 3.0e38f;
     const float inv = ok ? 1.0f / sqrtf(ss) : 0.f;

@@ -34,6 +34,7 @@ def test_wide_encoder_and_head_on_the_device_vs_oracle(hidden, B, hops, monkeypa
     oe.load_state_dict(om.state_dict())
     contrast = MemoryMoCo(hidden, None, K, 0.07, use_softmax=True).cuda()
     mem = contrast.memory.detach().cpu().clone()
+    mem0 = mem.clone()
     smp = DeviceRWRSampler(graph, B, run_seed=4)
     pe = DevicePosEmb(B, smp.node_cap, 32, device="cuda:0", seed=4)
     q, k = smp.sample(0)
@@ -66,17 +67,28 @@ def test_wide_encoder_and_head_on_the_device_vs_oracle(hidden, B, hops, monkeypa
     torch.testing.assert_close(feat_k.cpu(), rk, rtol=1e-3, atol=1e-4)
     torch.testing.assert_close(loss.detach().cpu(), rloss.detach(), rtol=1e-3, atol=1e-5)
     torch.testing.assert_close(contrast.memory.cpu(), mem, rtol=0, atol=1e-6)
-    refg = dict(om.named_parameters())
-    worst = 0.0
+    # gradients: the bar proper is the oracle run in float64 (exact arithmetic for this purpose) at north_star's 1e-3 of the tensor's
+    # largest entry; the fp32 oracle's own sums over thousands of nodes are ~1e-3 away from it themselves
+    o64 = E.OracleGraphEncoder(node_hidden_dim=hidden, output_dim=hidden).double()
+    o64.load_state_dict({k: (v.cpu().double() if v.dtype.is_floating_point else v.cpu()) for k, v in ema.state_dict().items()})   # (= the initial weights)
+    o64.train()
+    f64 = o64(*aq, pos_q.double(), dropout_masks=keep.double())
+    out64, _ = E.moco_forward(mem0.double(), 0, f64, rk.double(), 0.07)
+    E.nce_softmax_loss(out64).backward()
+    ref64, ref32 = dict(o64.named_parameters()), dict(om.named_parameters())
+    worst, worst32 = 0.0, 0.0
     for name, p in model.named_parameters():
-        if refg[name].grad is None:
+        if ref64[name].grad is None:
             assert p.grad is None or float(p.grad.abs().sum()) == 0.0, name
             continue
-        scale = max(float(refg[name].grad.abs().max()), 1e-3)
-        torch.testing.assert_close(p.grad.cpu(), refg[name].grad, rtol=5e-3, atol=max(3e-3 * scale, 1e-4 if name.endswith("bias") else 5e-6),
-                                   msg=lambda m, name=name: f"{name}: {m}")
-        worst = max(worst, float((p.grad.cpu() - refg[name].grad).abs().max()) / scale)
-    print(f"hidden {hidden}: {int(aq[0][-1])} nodes, loss {float(loss):.5f} (oracle {float(rloss):.5f}), worst gradient error / scale {worst:.2e}")
+        g64 = ref64[name].grad.float()
+        scale = max(float(g64.abs().max()), 1e-3)
+        torch.testing.assert_close(p.grad.cpu(), g64, rtol=2e-3, atol=max(1e-3 * scale, 1e-4 if name.endswith("bias") else 5e-6),
+                                   msg=lambda m, name=name: f"{name} vs float64 oracle: {m}")
+        worst = max(worst, float((p.grad.cpu() - g64).abs().max()) / scale)
+        worst32 = max(worst32, float((ref32[name].grad - g64).abs().max()) / scale)
+    print(f"hidden {hidden}: {int(aq[0][-1])} nodes, loss {float(loss):.5f} (oracle {float(rloss):.5f}), worst gradient error / scale vs float64: "
+          f"device {worst:.2e}, fp32 oracle {worst32:.2e}")
 
 
 def test_train_py_with_hidden_size_128_then_generate(tmp_path):
