@@ -1013,8 +1013,12 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
     // LAPACK's stein iterates on the same criterion.
     int need_until = 2;
     for (int it = 0; it < kMaxInvIt; ++it) {
+        // (one half wave runs the batch's 32 solves.  Dealing them out over all 16 waves -- two lanes each -- was measured and is
+        //  SLOWER: 'invit' 86 -> 111 us per 65..128-class item (scripts/gpu/r5_call7.sh, second run): a row's cost is its ~7 LDS
+        //  instructions, and one instruction serving 32 solves beats sixteen serving two each)
+        const int slot = tid;
         for (int j0 = 0; j0 < na; j0 += w.bw) {
-            if (tid < w.bw && j0 + tid < na) {
+            if (slot < w.bw && j0 + slot < na) {
                 // The head of a cluster keeps its own eigenvalue as shift.  When the cluster is a numerically multiple
                 // eigenvalue (copies within a few ulp), T - shift is singular to working precision in several directions at
                 // once and every further solve returns a DIFFERENT vector of that eigenspace (pivot clamping / rounding
@@ -1023,10 +1027,10 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
                 // 3e-4 of its squared norm in every sweep).  The same holds for the first copy of a second multiple eigenvalue
                 // inside one chain of close eigenvalues.  Two solves make such a vector an eigenvector to 1e-14; it is frozen
                 // from the third round on and the others converge against a fixed reference.
-                const int j = j0 + tid;
+                const int j = j0 + slot;
                 const bool frozen = it >= 2 && es.shiftv[j] == es.lamv[j] && j + 1 < na && es.lamv[j] - es.lamv[j + 1] < kSep;
                 if (!frozen) {
-                    const bool ok = inverse_iteration_step(w, nr, j, tid, es.shiftv[j], it == 0, hseed);
+                    const bool ok = inverse_iteration_step(w, nr, j, slot, es.shiftv[j], it == 0, hseed);
                     if (!ok) es.bad = 1;
                 }
             }
