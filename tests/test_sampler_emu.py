@@ -370,3 +370,16 @@ def test_hub_pairs_through_the_parent_table(coracle, hub_degree, max_hubs):
     _compare(coracle, rp, ci, g, 4, 7, 0, seeds=hubs, hub_degree=hub_degree, max_hubs=max_hubs)
     _compare(coracle, rp, ci, g, 5, 3, 77, hub_degree=hub_degree, max_hubs=max_hubs)
     _compare(coracle, rp, ci, g, 3, 3, 99, hub_degree=4, max_hubs=max_hubs)      # below the table's threshold: searches
+
+
+def test_two_classes_when_the_big_tables_are_small(coracle):
+    """Hub seeds on a graph whose longest trace is a few hundred members (G1's regime): subgraphs over the small class's 320
+    members go to the big class with tables for that trace.  (Written while a third, middle induce class was tried in round 5 --
+    measured slower on the 10M / 200M graph, not kept: profiles/r5_induce_three_classes.txt -- whose first device run lost exactly
+    these subgraphs.)"""
+    rp, ci = powerlaw_graph(20000, 400000, 1)
+    hubs = np.argsort(np.diff(rp))[-3:].astype(np.int32)
+    g = EmuGraph(rp, ci, rw_hops=700)
+    assert 320 < g.lmax + 1 < 1536
+    res = _compare(coracle, rp, ci, g, 3, 7, 0, seeds=hubs)
+    assert (np.diff(res[0]["node_off"]) > 320).any()
