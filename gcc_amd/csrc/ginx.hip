@@ -29,7 +29,8 @@ namespace {
 constexpr int kGT = 256;                 // threads of the GEMM workgroup: 4 waves, a 64 x 64 tile of C
 constexpr int kBM = 64, kBN = 64, kBK = 16;
 constexpr int kLdT = kBM + 4;            // LDS row stride of the k-major operand tiles
-constexpr int kSplitRows = 2048;         // rows of the reduction dimension per workgroup when it is the node dimension
+constexpr int kSplitRows = 256;          // rows of the reduction dimension per workgroup when it is the node dimension: f32 on the matrix cores
+                                         // inside a slab, fp64 atomics across slabs (a weight gradient sums over ~10^4 nodes whose terms largely cancel)
 
 // C[m][n] (+)= sum_k A(m, k) B(k, n) [+ bias[n]];  A(m, k) = A[m * sam + k * sak], B(k, n) = B[k * sbk + n * sbn].
 // rows_dim: 0 = all extents are the host's; 1 = M is *rows (device); 2 = K is *rows (device; split over gridDim.z with
@@ -42,6 +43,7 @@ struct GemmArgs {
     const int32_t *rows;
     int32_t rows_dim, atomic;
     float alpha;
+    double *Cd;                          // rows_dim == 2: the fp64 accumulator the slabs add into (converted to C afterwards)
 };
 
 __global__ __launch_bounds__(kGT) void ginx_gemm_kernel(GemmArgs g)
@@ -117,8 +119,7 @@ __global__ __launch_bounds__(kGT) void ginx_gemm_kernel(GemmArgs g)
                 if (m < M && n < g.N) {
                     float v = acc[i][j][r] * g.alpha;
                     if (g.bias && (g.rows_dim != 2 || blockIdx.z == 0)) v += g.bias[n];
-                    float *c = g.C + (int64_t)m * g.ldc + n;
-                    if (g.atomic) atomicAdd(c, v); else *c = v;
+                    if (g.atomic) atomicAdd(g.Cd + (int64_t)m * g.ldc + n, (double)v); else g.C[(int64_t)m * g.ldc + n] = v;
                 }
             }
 }
@@ -258,7 +259,7 @@ __global__ void ginx_bn_relu_bwd_kernel(const int32_t *node_off, int B, const fl
     dx[i] = gamma[c] * mr[D + c] * (gr - m0 - xhat * m1);
 }
 
-// fp64 sums -> fp32 parameter gradients: dst[c] (+)= (float)src[c]
+// fp64 sums -> fp32 parameter gradients: dst[c] (+)= (float)src[c]   (also the weight gradients' fp64 accumulators, n = rows * cols)
 __global__ void ginx_sums_to_grad_kernel(const double *src, int D, float *dst, int accumulate)
 {
     const int c = (int)blockIdx.x * blockDim.x + threadIdx.x;
@@ -402,6 +403,7 @@ struct XLayout {                         // float offsets inside the pass's work
     int64_t pooled[GCC_GIN_MAX_LAYERS + 1], y, score;
     int64_t da, db, dc, dpool, dy, dscore;      // backward scratch: three [N, Wmax] buffers, [B, Wmax] x 3
     int64_t sums;                        // doubles: [2][Wmax] scratch of the statistics kernels (offset in FLOATS, 8-byte aligned)
+    int64_t wg64;                        // doubles: [Wmax][Wmax] accumulator of a weight gradient
     int64_t total;
 };
 
@@ -423,18 +425,20 @@ XLayout ginx_layout(int64_t N, int B, int L, int d_in, int W, int O)
     x.da = take(N * Wm); x.db = take(N * Wm); x.dc = take(N * Wm);
     x.dpool = take((int64_t)B * Wm); x.dy = take((int64_t)B * O); x.dscore = take((int64_t)B * O);
     x.sums = take(4 * Wm + 16);
+    x.wg64 = take(2 * Wm * Wm + 16);
     x.total = o;
     return x;
 }
 
 void gemm(hipStream_t s, const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn, float *C, int64_t ldc,
-          int M, int N, int K, const float *bias, const int32_t *rows, int rows_dim, int64_t rows_cap, float alpha = 1.0f)
+          int M, int N, int K, const float *bias, const int32_t *rows, int rows_dim, int64_t rows_cap, float alpha = 1.0f, double *acc64 = nullptr)
 {
-    GemmArgs g = {A, B, bias, C, sam, sak, sbk, sbn, ldc, M, N, K, rows, rows_dim, rows_dim == 2 ? 1 : 0, alpha};
+    GemmArgs g = {A, B, bias, C, sam, sak, sbk, sbn, ldc, M, N, K, rows, rows_dim, rows_dim == 2 ? 1 : 0, alpha, acc64};
     const int mcap = rows_dim == 1 ? (int)rows_cap : M;
     dim3 grid((mcap + kBM - 1) / kBM, (N + kBN - 1) / kBN, rows_dim == 2 ? (unsigned)((rows_cap + kSplitRows - 1) / kSplitRows) : 1u);
-    if (rows_dim == 2) (void)hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * (size_t)ldc, s);     // (C is dense: ldc == N)
+    if (rows_dim == 2) (void)hipMemsetAsync(acc64, 0, sizeof(double) * (size_t)M * (size_t)ldc, s);     // (C is dense: ldc == N)
     hipLaunchKernelGGL(ginx_gemm_kernel, grid, dim3(kGT), 0, s, g);
+    if (rows_dim == 2) hipLaunchKernelGGL(ginx_sums_to_grad_kernel, dim3((unsigned)(((int64_t)M * ldc + 255) / 256)), dim3(256), 0, s, (const double *)acc64, (int)(M * ldc), C, 0);
 }
 
 inline unsigned blocks(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
@@ -539,6 +543,7 @@ int32_t gcc_ginx_backward(const gcc_ginx_pass *p, const float *dfeat, const gcc_
     double *sums = (double *)(ws + x.sums);
     const int32_t *rows = p->node_off + B;
     float *dA = ws + x.da, *dB_ = ws + x.db, *dC = ws + x.dc;
+    double *wg64 = (double *)(ws + x.wg64);
     // ---- readout: dscore -> per hidden_rep: dy = dscore * keep / (1 - p); dWp = dy^T pooled; dbp = colsum(dy); dpooled = dy Wp
     hipLaunchKernelGGL(ginx_normalize_bwd_kernel, dim3(B), dim3(64), 0, s, ws + x.score, p->feat, dfeat, O, w.norm_eps, p->normalize, ws + x.dscore);
     auto readout_bwd = [&](int l, float *dpool) {
@@ -577,11 +582,11 @@ int32_t gcc_ginx_backward(const gcc_ginx_pass *p, const float *dfeat, const gcc_
         (void)hin;
         bn_bwd(ws + x.a2[l], ws + x.h[l], dA, w.bn_c[l], x.mr[l][2], dB_, gr->bn_c_w[l], gr->bn_c_b[l]);                  // -> d a2
         bn_bwd(ws + x.z2[l], ws + x.a2[l], dB_, w.bn_b[l], x.mr[l][1], dA, gr->bn_b_w[l], gr->bn_b_b[l]);                 // -> d z2
-        gemm(s, dA, 1, W, ws + x.a1[l], W, 1, gr->lin1_w[l], W, W, W, 0, nullptr, rows, 2, N);                            // dW1 [W, W] = dz2^T a1
+        gemm(s, dA, 1, W, ws + x.a1[l], W, 1, gr->lin1_w[l], W, W, W, 0, nullptr, rows, 2, N, 1.0f, wg64);                            // dW1 [W, W] = dz2^T a1
         bias_grad(dA, gr->lin1_b[l]);
         gemm(s, dA, W, 1, w.lin1_w[l], W, 1, dB_, W, 0, W, W, nullptr, rows, 1, N);                                        // d a1 = dz2 W1
         bn_bwd(ws + x.z1[l], ws + x.a1[l], dB_, w.bn_a[l], x.mr[l][0], dA, gr->bn_a_w[l], gr->bn_a_b[l]);                 // -> d z1
-        gemm(s, dA, 1, W, ws + x.agg[l], Din, 1, gr->lin0_w[l], Din, W, Din, 0, nullptr, rows, 2, N);                     // dW0 [W, Din] = dz1^T agg
+        gemm(s, dA, 1, W, ws + x.agg[l], Din, 1, gr->lin0_w[l], Din, W, Din, 0, nullptr, rows, 2, N, 1.0f, wg64);                     // dW0 [W, Din] = dz1^T agg
         bias_grad(dA, gr->lin0_b[l]);
         gemm(s, dA, W, 1, w.lin0_w[l], Din, 1, dB_, Din, 0, Din, W, nullptr, rows, 1, N);                                  // d agg = dz1 W0
         // d h_{l-1} = d agg + A d agg (the batched subgraph is symmetric) + the pooled readout of hidden_rep[l]'s input

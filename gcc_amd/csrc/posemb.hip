@@ -399,6 +399,10 @@ struct EigShared {                   // per-workgroup scratch of the solver core
 
 // A (n x n, symmetric, both triangles kept, row stride lda) -> T = Q^T A Q; Q = H_0 H_1 ... H_{n-3},
 // H_k = I - tau_k v_k v_k^T with v_k = (0, ..., 0, 1, A[k][k+2], ..., A[k][n-1]).  All threads call it; ends with a barrier.
+// (Round 5: a fused variant -- every wave forms reflector k + 1 for itself from the row as it will be after the update, the rows are
+//  multiplied with it while they are updated: one pass and one barrier per column instead of two -- was built, passed the strict tests
+//  and measured 151 against 161 us per 65..128-class item and 283 against 268 us in the block class's Ritz problems
+//  (scripts/gpu/r5_call7.sh, third run): with 16 waves on 4 SIMDs the redundant per-wave work costs what the barrier saved.  Not kept.)
 template <int kCPL, int kT, int kR>
 __device__ void tridiagonalize(float *A, int lda, int n, const TriLds &w)
 {

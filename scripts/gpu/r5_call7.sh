@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 5, call 7: inverse iteration with the next row's operands requested ahead (one thread per eigenvector runs the elimination
-# chain alone: every row paid a full LDS load latency): strict eigensolver tests, phases, sustained bench; the any-width GPU tests with
-# the float64 gradient bar.
+# Round 5, call 7 (the same programme for four builds): inverse iteration with the next rows' operands requested ahead; the same with the
+# solves spread over all 16 waves; the fused tridiagonalisation (one pass, one barrier per column); the any-width weight gradients
+# accumulated in fp64.  Strict eigensolver tests, the any-width GPU tests with the float64 gradient bar, phases, sustained bench.
 set -u
 O=gpurun_out/r5c7
 mkdir -p $O

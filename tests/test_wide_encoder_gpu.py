@@ -83,7 +83,10 @@ def test_wide_encoder_and_head_on_the_device_vs_oracle(hidden, B, hops, monkeypa
             continue
         g64 = ref64[name].grad.float()
         scale = max(float(g64.abs().max()), 1e-3)
-        torch.testing.assert_close(p.grad.cpu(), g64, rtol=2e-3, atol=max(1e-3 * scale, 1e-4 if name.endswith("bias") else 5e-6),
+        # the bar: 1e-3 of the tensor's largest entry, or -- where fp32 itself cannot do that (sums of ~10^4 cancelling terms at width 256)
+        # -- three times what torch's own fp32 pass of the same model is off by against float64
+        err32 = float((ref32[name].grad - g64).abs().max())
+        torch.testing.assert_close(p.grad.cpu(), g64, rtol=2e-3, atol=max(1e-3 * scale, 3.0 * err32, 1e-4 if name.endswith("bias") else 5e-6),
                                    msg=lambda m, name=name: f"{name} vs float64 oracle: {m}")
         worst = max(worst, float((p.grad.cpu() - g64).abs().max()) / scale)
         worst32 = max(worst32, float((ref32[name].grad - g64).abs().max()) / scale)
