@@ -363,6 +363,8 @@ struct PosHead {                     // head of the caller's workspace (zeroed p
     int32_t use_wave;                // deflated sizes <= 64 go to the one-wave teams
     int32_t use_stalks;              // pendant two-paths of a hub are deflated too (GCC_POSEMB_STALKS, default 1)
     int64_t slot_floats;
+    float *pslots;                   // [workgroups of the two-wave 65..128 class][kPairSlotFloats]: matrix / reflectors + expansion records
+    int32_t use_pair;
 };
 
 // The deflation tables (24 KiB) are built in LDS where the eigenvector arrays go later; the 8 bytes per node that the
@@ -668,6 +670,7 @@ __device__ __forceinline__ float hash_unit(uint32_t a, uint32_t b, uint32_t c)
 // one inverse-iteration step for eigenvector j (called by ONE thread, slot jl of the LU batch): solve
 // (T - shift) x = y in place in column j of Y, by Gaussian elimination with partial pivoting fused with the
 // right-hand side; x is normalised.  Returns false if the solution is not finite.
+template <bool kDeep = false>
 __device__ bool inverse_iteration_step(const TriLds &w, int n, int j, int jl, float shift, bool random_rhs, uint32_t hseed)
 {
     float *Y = w.Y + j, *Ud = w.Ud + jl, *Us = w.Us + jl;
@@ -709,6 +712,40 @@ __device__ bool inverse_iteration_step(const TriLds &w, int n, int j, int jl, fl
     float x1 = 0.f, x2 = 0.f, ss = 0.f;
     // back substitution, the next row's operands requested ahead in the same way
     float d = cd, us = 0.f, s2 = 0.f, yi = cy;               // row n - 1
+    if constexpr (kDeep) {
+        // the factors live in the workspace (two-wave teams): a row's operands come from L2, so they are requested FOUR rows (one
+        // chunk) ahead; same arithmetic in the same order
+        float dq[4], uq[4];
+        uint8_t fq[4];
+        auto fetch = [&](int top) {                          // rows top, top - 1, .. top - 3 (clamped; rows below 0 are not used)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ii = top - u > 0 ? top - u : 0;
+                dq[u] = Ud[ii * ldu]; uq[u] = Us[ii * ldu]; fq[u] = Uf[ii * ldf];
+            }
+        };
+        fetch(n - 1);
+        for (int top = n - 1; top >= 0; top -= 4) {
+            float dc[4], uc[4];
+            uint8_t fc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { dc[u] = dq[u]; uc[u] = uq[u]; fc[u] = fq[u]; }
+            if (top >= 4) fetch(top - 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = top - u;
+                if (i >= 0) {
+                    float dd = dc[u];
+                    const float s2c = (fc[u] && i + 2 < n) ? w.of[i + 1] : 0.f;
+                    if (fabsf(dd) < kPivTiny) dd = dd < 0.f ? -kPivTiny : kPivTiny;
+                    const float x = (Y[i * ldy] - uc[u] * x1 - s2c * x2) * fast_rcp(dd);
+                    Y[i * ldy] = x;
+                    x2 = x1; x1 = x;
+                    ss = fmaf(x, x, ss);
+                }
+            }
+        }
+    } else
 #pragma unroll 4
     for (int i = n - 1; i >= 0; --i) {
         float dn = 0.f, usn = 0.f, s2n = 0.f, yn = 0.f;      // row i - 1
@@ -961,10 +998,11 @@ __device__ __forceinline__ void phase_tick(long long *row, int ph, long long &ti
 // inverse iteration on T (shifts at least kSep apart; three solves, Gram-Schmidt inside clusters of eigenvalues closer
 // than kOrtol after the second and third), then x = H_0 ... H_{nr-3} y with one wave per pair of vectors, the vectors in
 // registers.  Result in w.Y[i * ldy + j].  Returns (block-uniform) true if a vector could not be produced.
-template <int kCPL, int kT>
+template <int kCPL, int kT, bool kPair = false>
 __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const TriLds &w, EigShared &es, uint32_t hseed,
                                 long long *tick_row, long long &tick)
 {
+    static_assert(!kPair || (kT == 128 && kCPL == 2), "two-wave teams");
     constexpr int kNW = kT / 64;
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ldy = w.ldy;
@@ -1034,7 +1072,7 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
                 const int j = j0 + slot;
                 const bool frozen = it >= 2 && es.shiftv[j] == es.lamv[j] && j + 1 < na && es.lamv[j] - es.lamv[j + 1] < kSep;
                 if (!frozen) {
-                    const bool ok = inverse_iteration_step(w, nr, j, slot, es.shiftv[j], it == 0, hseed);
+                    const bool ok = inverse_iteration_step<kPair>(w, nr, j, slot, es.shiftv[j], it == 0, hseed);
                     if (!ok) es.bad = 1;
                 }
             }
@@ -1087,6 +1125,62 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
 #endif
         if (it >= need_until) break;
     }
+    if constexpr (kPair) {
+        // x = H_0 ... H_{nr-3} y for a two-wave team: wave h takes the vectors 16 h .. 16 h + 15, FOUR lanes per vector -- quarter q of the
+        // wave holds the rows 4 r + q of its vector in registers --, so a reflector costs (nr - kk) / 4 multiply-adds per lane twice and
+        // two cross-lane additions; the reflectors come from the workspace one step ahead, through a double-buffered LDS copy (one
+        // 2-wave barrier per reflector).  (The version below gives a wave two vectors at a time: 8 passes over all reflectors with two
+        // full wave reductions each, 152 us per item.)
+        constexpr int kR = 32;
+        const int j = 16 * wv + (lane & 15), q = lane >> 4;
+        const bool act = j < na;
+        float *Yj = w.Y + (act ? j : 0);
+        float y[kR], vc[kR];
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const int c = 4 * r + q;
+            y[r] = (act && c < nr) ? Yj[c * ldy] : 0.f;
+            vc[r] = 0.f;
+        }
+        auto fetch = [&](int kk) -> float { return (tid > kk + 1 && tid < nr) ? A[(int64_t)kk * lda + tid] : (tid == kk + 1 ? 1.0f : 0.f); };
+        float nxt = nr >= 3 ? fetch(nr - 3) : 0.f;
+        int par = 0;
+        for (int kk = nr - 3; kk >= 0; --kk) {
+            float *vb = w.pbuf + par * 128;              // (pbuf and vbuf are adjacent: 2 x 128 floats)
+            vb[tid] = nxt;
+            __syncthreads();
+            if (kk > 0) nxt = fetch(kk - 1);
+            par ^= 1;
+            const float t = w.tau[kk];
+            if (t == 0.f) continue;                      // uniform
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < kR / 4; ++g) {
+                if (16 * g + 15 > kk) {                  // uniform: rows 16 g .. 16 g + 15 reach beyond kk
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        vc[4 * g + u] = vb[16 * g + 4 * u + q];
+                        s = fmaf(vc[4 * g + u], y[4 * g + u], s);
+                    }
+                }
+            }
+            s += wave_shfl_xor(s, 16);
+            s += wave_shfl_xor(s, 32);
+            s *= t;
+#pragma unroll
+            for (int g = 0; g < kR / 4; ++g) {
+                if (16 * g + 15 > kk) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) y[4 * g + u] = fmaf(-s, vc[4 * g + u], y[4 * g + u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const int c = 4 * r + q;
+            if (act && c < nr) Yj[c * ldy] = y[r];
+        }
+    } else
     for (int j = 2 * wv; j < na; j += 2 * kNW) {
         const bool two = j + 1 < na;
         float y0[kCPL], y1[kCPL], v[kCPL], vn[kCPL];
@@ -1126,6 +1220,132 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
     __syncthreads();
     phase_tick(tick_row, 5, tick);                 // back-transformation
     return lost > 0 || es.bad != 0;
+}
+
+// ---- two-wave teams (65 <= n' <= 128): tridiagonalize() for a workgroup of TWO waves with the matrix in REGISTERS -- thread r owns
+// row r (128 floats).  The 16-wave version above is bound by its two barriers and ~6 LDS round trips per column while it owns a whole
+// CU (1,024 threads at 128 registers, 132 KiB of LDS); here a column costs two 2-wave barriers, the FLOPs run out of registers with
+// the other operand broadcast from LDS (16 bytes per instruction), and a workgroup takes 128 threads and kPairLds of LDS, so that
+// four of them share a CU.  A lives in the workgroup's workspace slot (L2): read once (by columns -- A is symmetric -- so that the
+// read is coalesced), its rows then receive the reflectors as in the other versions.
+//   column k:  the owners of rows k and k + 1 put them into LDS                                  | barrier
+//              all: sigma, x0, a_kk from row k (a 2 x 64 wave reduction, the same in both waves); v_r; S_r = sum_{c>k+1} a_rc row_k[c];
+//              p_r = tau (a_{r,k+1} + scale S_r)  [a_{r,k+1} = row_{k+1}[r]];  p_r, v_r and the wave's part of p.v into LDS  | barrier
+//              K = tau/2 p.v;  a_rc -= v_r p_c + (p_r - 2 K v_r) v_c   [= v_r w_c + w_r v_c with w = p - K v]
+constexpr int kPairT = 128;
+constexpr int kPairLds = 32 * 1024;      // dynamic LDS of a two-wave workgroup (+ ~2 KiB static): the deflation tables (24 KiB), later the eigenvectors (17 KiB)
+constexpr int kPairSlotFloats = 128 * 128 + 2048 + 2 * 128 * 33 + 1024 + 64;   // matrix / reflectors | expansion records (8 bytes per node) | LU factors
+template <int kNMax>
+__device__ void tridiagonalize_pair(float *A, int lda, int n, const TriLds &w, float *xb /* LDS, 16-byte aligned, 6 kNMax + 8 floats */)
+{
+    static_assert(kNMax == 128, "two waves, one row per thread");
+    constexpr int kB = kNMax / 8, kG = kNMax / 32;
+    const int r = (int)threadIdx.x, lane = r & 63, h = r >> 6;
+    float a[kNMax];
+    {   // unconditional loads (the slot holds kNMax rows) and a bit mask: a select is turned back into a branch per element, and
+        // addresses that do not depend on the item are hoisted out of the item loop -- 128 of them -- and spilled
+        uint64_t ap = (uint64_t)(A + r);
+        opaque_u64(ap);
+        const float *Ar = (const float *)ap;
+        const uint32_t mr = r < n ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int c = 0; c < kNMax; ++c) a[c] = __uint_as_float(__float_as_uint(Ar[c * lda]) & (c < n ? mr : 0u));
+    }
+    __syncthreads();                                     // all rows are in registers: A's rows may now receive the reflectors
+    float *pv = xb + 4 * kNMax, *vv = xb + 5 * kNMax, *kpart = xb + 6 * kNMax;
+    const int ncols = (n + 31) & ~31;                    // the readers take groups of 32 columns: zeros up to the group's end
+    auto put_row = [&](float *dst, int from) {           // one lane: its row, blocks of eight columns from `from` on
+#pragma unroll
+        for (int cb = 0; cb < kB; ++cb) {
+            if (8 * cb + 7 >= from && 8 * cb < ncols) {
+                *(float4 *)(dst + 8 * cb) = make_float4(a[8 * cb], a[8 * cb + 1], a[8 * cb + 2], a[8 * cb + 3]);
+                *(float4 *)(dst + 8 * cb + 4) = make_float4(a[8 * cb + 4], a[8 * cb + 5], a[8 * cb + 6], a[8 * cb + 7]);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int k = 0; k + 2 < n; ++k) {
+        float *rk = xb + (k & 1) * 2 * kNMax, *rk1 = rk + kNMax;     // (two buffers: a column without a reflector has one barrier only)
+        if (h == (k >> 6) && lane == (k & 63)) put_row(rk, k);
+        if (h == ((k + 1) >> 6) && lane == ((k + 1) & 63)) put_row(rk1, k);
+        __syncthreads();
+        const float c0 = lane < n ? rk[lane] : 0.f, c1 = lane + 64 < n ? rk[64 + lane] : 0.f;   // (blocks of columns beyond n are not written)
+        const float sig = wave_sum((lane > k + 1 ? c0 * c0 : 0.f) + (lane + 64 > k + 1 ? c1 * c1 : 0.f));
+        const float x0 = rk[k + 1], akk = rk[k];
+        if (sig <= 1e-30f) {                             // uniform over the workgroup: the column is already tridiagonal, H_k = I
+            if (r == 0) { w.dg[k] = akk; w.of[k] = x0; w.tau[k] = 0.f; }
+            continue;
+        }
+        const float mu = sqrtf(x0 * x0 + sig);
+        const float beta = x0 > 0.f ? -mu : mu;
+        const float t = (beta - x0) / beta;
+        const float scale = 1.0f / (x0 - beta);
+        const float vr = r == k + 1 ? 1.0f : (r > k + 1 ? (h ? c1 : c0) * scale : 0.f);
+        // (groups of 32 columns under one uniform branch: the operands of a group are requested together -- a branch per block of
+        //  eight made every block wait for its own LDS reads -- at the price of up to 31 columns of multiply-adds with zeros)
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int g = 0; g < kG; ++g) {
+            if (32 * g + 31 > k + 1 && 32 * g < n) {     // uniform
+                float q[32];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float4 t4 = *(const float4 *)(rk + 32 * g + 4 * u);
+                    q[4 * u] = t4.x; q[4 * u + 1] = t4.y; q[4 * u + 2] = t4.z; q[4 * u + 3] = t4.w;
+                }
+                if (32 * g > k + 1) {
+#pragma unroll
+                    for (int u = 0; u < 32; u += 2) { s0 = fmaf(a[32 * g + u], q[u], s0); s1 = fmaf(a[32 * g + u + 1], q[u + 1], s1); }
+                } else {                                 // the group the reflector starts in
+#pragma unroll
+                    for (int u = 0; u < 32; u += 2) {
+                        s0 = fmaf(a[32 * g + u], 32 * g + u > k + 1 ? q[u] : 0.f, s0);
+                        s1 = fmaf(a[32 * g + u + 1], 32 * g + u + 1 > k + 1 ? q[u + 1] : 0.f, s1);
+                    }
+                }
+            }
+        }
+        const float p = (r > k && r < n) ? t * fmaf(scale, s0 + s1, rk1[r]) : 0.f;
+        const float kp = wave_sum(p * vr);
+        pv[r] = p;
+        vv[r] = vr;
+        if (lane == 0) kpart[h] = kp;
+        if (r > k + 1 && r < n) A[(int64_t)k * lda + r] = vr;        // row k of A stores the reflector
+        if (r == 0) { w.dg[k] = akk; w.of[k] = beta; w.tau[k] = t; }
+        __syncthreads();
+        const float K = 0.5f * t * (kpart[0] + kpart[1]);
+        const float wr = fmaf(-2.0f * K, vr, p);
+#pragma unroll
+        for (int g = 0; g < kG; ++g) {
+            if (32 * g + 31 > k && 32 * g < n) {         // (p and v are zero left of column k + 1 and beyond n)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {         // (two halves: 32 + 32 operand registers beside the 128 of the row spill a few)
+                    float pc[16], vc[16];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float4 p4 = *(const float4 *)(pv + 32 * g + 16 * hf + 4 * u), v4 = *(const float4 *)(vv + 32 * g + 16 * hf + 4 * u);
+                        pc[4 * u] = p4.x; pc[4 * u + 1] = p4.y; pc[4 * u + 2] = p4.z; pc[4 * u + 3] = p4.w;
+                        vc[4 * u] = v4.x; vc[4 * u + 1] = v4.y; vc[4 * u + 2] = v4.z; vc[4 * u + 3] = v4.w;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) a[32 * g + 16 * hf + u] = fmaf(-vr, pc[u], fmaf(-wr, vc[u], a[32 * g + 16 * hf + u]));
+                }
+            }
+        }
+    }
+    {   // the last 2 x 2 block
+        __syncthreads();
+        float *rk = xb, *rk1 = xb + kNMax;
+        if (n >= 2 && r == n - 2) put_row(rk, n - 2);
+        if (r == n - 1) put_row(rk1, n - 2);
+        __syncthreads();
+        if (r == 0) {
+            if (n >= 2) { w.dg[n - 2] = rk[n - 2]; w.of[n - 2] = rk[n - 1]; }
+            w.dg[n - 1] = rk1[n - 1];
+            w.of[n - 1] = 0.f;
+        }
+    }
+    __syncthreads();
 }
 
 // =========================================================================
@@ -1553,10 +1773,11 @@ __global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m
     if (lane == 0) hd.list[(int64_t)cls * hd.T + atomicAdd(hd.count + cls, 1)] = item;
 }
 
-template <int kCls, int kNMin, int kNMax, int kT, bool kGlobalA>
-__global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead hd)
+template <int kCls, int kNMin, int kNMax, int kT, bool kGlobalA, bool kPair = false>
+__global__ __launch_bounds__(kT, kPair ? 2 : 1) void posemb_direct_kernel(PosMulti m, PosHead hd)
 {
     static_assert(kNMax % 64 == 0 && kT % 64 == 0 && kT >= 64, "size class");
+    static_assert(!kPair || (kGlobalA && kT == kPairT && kNMax == 128), "two-wave teams: the matrix and the reflectors live in the workspace");
     DYN_SMEM(smem);
     __shared__ EigShared es;
     __shared__ int colsrc[64];                  // per output column: eigenvector j >= 0, or -(c + 1) for contrast c
@@ -1574,6 +1795,9 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     int b;
     item_args(m, gb, a, b);
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+#ifdef GCC_POSEMB_ABLATE_MID                          // timing experiments only (tools/build_variant.sh): the class costs nothing, its rows stay zero
+    if (kCls == kClsMid) continue;
+#endif
     const int k = min(min(n - 2, a.hidden), kMaxVec);   // data_util.py:278; k >= 1 (classify kernel)
     long long tick_ = m.ticks ? device_ticks() : 0;
     if (m.ticks && tid == 0) atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 15], 1ull);   // items
@@ -1596,7 +1820,8 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     }
     // the deflation tables (24 KiB) are built in LDS (the eigenvector arrays overlay them); what the expansion at the end
     // needs of them goes to the workgroup's table in the workspace once the matrix is filled
-    static_assert(direct_lds_bytes<kNMax, kT, kGlobalA>() - (int)sizeof(float) * (6 * kNMax + 32 * kYld + kT + (kGlobalA ? 0 : kNMax * (kNMax + 1)))
+    constexpr int lds_total = kPair ? kPairLds : direct_lds_bytes<kNMax, kT, kGlobalA>();
+    static_assert(lds_total - (int)sizeof(float) * (6 * kNMax + 32 * kYld + kT + (kGlobalA ? 0 : kNMax * (kNMax + 1)))
                   >= kNodeMax * kDeflNodeBytes, "the deflation tables overlay the eigenvector / LU region");
     defl_bind(d, lds_rest, kNodeMax);
     const int32_t *rp = a.row_ptr + n0;
@@ -1611,15 +1836,22 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     defl_prefix_block<kT>(d, n, sh_tot, w.cnt);    // (w.cnt: kT ints of LDS that are free until the bisection)
     const int nr = sh_tot[0], z = sh_tot[1], zp = sh_tot[2];    // reduced size n', number of twin / stalk contrasts
     if (nr > kNMax || nr < kNMin) continue;        // cannot happen: the classify kernel computed the same size
-    if (kGlobalA) A = kCls == kClsBig ? hd.bslots + (int64_t)blockIdx.x * hd.bslot_floats
-                                      : hd.slots + (int64_t)blockIdx.x * hd.slot_floats;   // the workgroup's own slot
+    if (kGlobalA) A = kPair ? hd.pslots + (int64_t)blockIdx.x * kPairSlotFloats
+                            : kCls == kClsBig ? hd.bslots + (int64_t)blockIdx.x * hd.bslot_floats
+                                              : hd.slots + (int64_t)blockIdx.x * hd.slot_floats;   // the workgroup's own slot
     // ---- rest of the carve-up: eigenvectors and as many LU slots as fit
     w.Y = lds_rest;
     w.ldy = kYld;
     {
-        constexpr int lds_total = direct_lds_bytes<kNMax, kT, kGlobalA>();
         static_assert(!kGlobalA || (int)sizeof(float) * (6 * kNMax + 32 * kYld + kT + kNMax * kYld) + kNMax * (5 * 8 + 4) <= lds_total,
                       "eigenvectors + the narrowest LU batch must fit");
+        if constexpr (kPair) {                           // the LU factors of all 32 inverse iterations: in the slot (L2), behind the records
+            w.bw = 32;
+            w.ldu = 33;
+            w.Ud = A + kNMax * lda + kNodeMax * 2;
+            w.Us = w.Ud + kNMax * 33;
+            w.Uf = (uint8_t *)(w.Us + kNMax * 33);
+        } else {
         const int used = (int)((unsigned char *)(w.Y + nr * kYld) - smem);
         const int left = lds_total - used;
         int bw = 32;
@@ -1629,6 +1861,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
         w.Ud = w.Y + nr * kYld;
         w.Us = w.Ud + nr * w.ldu;
         w.Uf = (uint8_t *)(w.Us + nr * w.ldu);
+        }
     }
     for (int i = tid; i < nr * lda; i += kT) A[i] = 0.f;
     __syncthreads();
@@ -1651,7 +1884,9 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     __syncthreads();
 
     PHASE_TICK(0);                                 // deflation + matrix
-    if (kGlobalA) {
+    if constexpr (kPair) {
+        tridiagonalize_pair<kNMax>(A, lda, nr, w, lds_rest);      // (the eigenvector / LU region of the LDS is free until the bisection)
+    } else if (kGlobalA) {
         // (the eigenvector / LU region of the LDS is free until the bisection: per-wave column sums and the pivot column)
         float *xcol = lds_rest, *slab = lds_rest + kNMax;
         tridiagonalize_lower<kCPL, kT, 4>(A, lda, nr, w, slab, kNMax, xcol);
@@ -1668,7 +1903,7 @@ __global__ __launch_bounds__(kT) void posemb_direct_kernel(PosMulti m, PosHead h
     if (tid == 0) sh_na = rank_columns(es.lamv, kq, k, z, zp, colsrc, a.evals ? a.evals + (int64_t)b * a.hidden : nullptr);
     if (a.evals) for (int i = k + tid; i < a.hidden; i += kT) a.evals[(int64_t)b * a.hidden + i] = 0.f;
     __syncthreads();
-    const bool failed = eig_top_vectors<kCPL, kT>(A, lda, nr, sh_na, w, es, (uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u),
+    const bool failed = eig_top_vectors<kCPL, kT, kPair>(A, lda, nr, sh_na, w, es, (uint32_t)a.seed ^ ((uint32_t)gb * 0x9E3779B1u),
                                                   m.ticks ? m.ticks + kCls * 16 : nullptr, tick_);
     if (tid == 0 && failed) {
         atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_NOT_CONVERGED);
@@ -3182,19 +3417,19 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
 extern "C" {
 
 static long long *g_posemb_ticks = nullptr;
-struct PosGrids { int32_t small, mid, slot, kry, big, cheb, w48, w64; };
+struct PosGrids { int32_t small, mid, slot, kry, big, cheb, w48, w64, pair; };
 static PosGrids posemb_grids(int64_t T, bool gated = false)
 {
     // fixed grids: enough workgroups for the typical class sizes (~73 % / 19 % / 6 % / 2 % of a batch at rw_hops 256);
     // larger classes loop.  No class may cover more than half of the 256 CUs (small: 2 workgroups per CU): a solver
     // workgroup holds most of a CU's LDS for milliseconds, and when every CU has one the training step's kernels whose
     // workgroups do not fit beside it wait for the whole launch to drain (3-5 ms stalls in the kernel trace).
-    static int caps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (caps[0] == 0) {                              // tuning knob: GCC_POSEMB_GRID_CAPS="small,mid,slot,krylov,big,cheb,w48,w64"
-        int c[8] = {256, 64, 128, 64, 64, 96, 512, 128};    // scripts/gpu/r3_call4.sh: bench by caps
+    static int caps[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (caps[0] == 0) {                              // tuning knob: GCC_POSEMB_GRID_CAPS="small,mid,slot,krylov,big,cheb,w48,w64,pair"
+        int c[9] = {256, 64, 128, 64, 64, 96, 512, 128, 128};    // scripts/gpu/r3_call4.sh: bench by caps; pair: r5_call10.sh (64: 0.837, 128: 0.836, 256: 0.856 ms per step)
         const char *e = getenv("GCC_POSEMB_GRID_CAPS");
-        if (e) (void)sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3], &c[4], &c[5], &c[6], &c[7]);
-        for (int i = 0; i < 8; ++i) caps[i] = c[i] < 1 ? 1 : c[i];
+        if (e) (void)sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3], &c[4], &c[5], &c[6], &c[7], &c[8]);
+        for (int i = 0; i < 9; ++i) caps[i] = c[i] < 1 ? 1 : c[i];
     }
     PosGrids g;
     g.small = (int32_t)(T < caps[0] ? T : caps[0]);
@@ -3217,6 +3452,8 @@ static PosGrids posemb_grids(int64_t T, bool gated = false)
     const int64_t wg = (T + kWaveTeams - 1) / kWaveTeams;
     g.w48 = (int32_t)(wg < caps[6] ? wg : caps[6]);
     g.w64 = (int32_t)((wg + 1) / 2 < caps[7] ? (wg + 1) / 2 : caps[7]);
+    const int cap_pair = gated ? 2 * caps[8] : caps[8];
+    g.pair = (int32_t)((T + 1) / 2 < cap_pair ? (T + 1) / 2 : cap_pair);
     return g;
 }
 // workspace sizing: the larger of the two grid sets, so that one workspace serves gated and ungated calls
@@ -3226,6 +3463,7 @@ static PosGrids posemb_grids_for_sizing(int64_t T)
     const PosGrids b = posemb_grids(T, true);
     a.mid = a.mid > b.mid ? a.mid : b.mid;
     a.cheb = a.cheb > b.cheb ? a.cheb : b.cheb;
+    a.pair = a.pair > b.pair ? a.pair : b.pair;
     return a;
 }
 static int64_t posemb_head_bytes(int64_t T) { return ((16 + kNumCls * T) * 4 + 255) / 256 * 256; }
@@ -3245,7 +3483,8 @@ int64_t gcc_posemb_multi_workspace_bytes(int32_t num_views, int32_t batch_size, 
            + g.big * posemb_bslot_floats() * (int64_t)sizeof(float)
            + (int64_t)(g.mid + g.small) * kNodeMax * 16
            + (int64_t)g.kry * 2 * (kM + 1) * posemb_ldv(batch_size, node_cap) * (int64_t)sizeof(float)
-           + (int64_t)g.cheb * (3 * (int64_t)kNodeMax * kChP * (int64_t)sizeof(float) + (int64_t)kNodeMax * 16) + 512;
+           + (int64_t)g.cheb * (3 * (int64_t)kNodeMax * kChP * (int64_t)sizeof(float) + (int64_t)kNodeMax * 16) + 512
+           + (int64_t)g.pair * kPairSlotFloats * (int64_t)sizeof(float) + 256;
 }
 
 int64_t gcc_posemb_workspace_bytes(int32_t batch_size, int64_t node_cap, int32_t hidden)
@@ -3305,6 +3544,12 @@ int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, 
         hd.use_wave = ew ? atoi(ew) != 0 : 1;
         const char *es = getenv("GCC_POSEMB_STALKS");  // 0: twin leaves only (A/B runs)
         hd.use_stalks = es ? atoi(es) != 0 : 1;
+        const char *ep = getenv("GCC_POSEMB_PAIR");    // 0: the 65..128 class on 1,024-thread workgroups with the matrix in LDS (A/B runs)
+        hd.use_pair = ep ? atoi(ep) != 0 : 1;
+    }
+    {   // the two-wave class's slots: the tail of the workspace
+        char *end = (char *)workspace + need;
+        hd.pslots = (float *)(((uintptr_t)(end - (int64_t)gs.pair * kPairSlotFloats * (int64_t)sizeof(float))) & ~(uintptr_t)255);
     }
     constexpr int lds_small = direct_lds_bytes<kJSmall, kSmallT, false>();
     constexpr int lds_big = direct_lds_bytes<kJMax, kMidT, false>();
@@ -3373,7 +3618,10 @@ int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, 
     hipLaunchKernelGGL(posemb_krylov_kernel, dim3(g.kry), dim3(kKThreads), lds_kry, s, ka);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsBig, kGMax + 1, kBMax, 1024, true>), dim3(g.big), dim3(1024), kBLds, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>), dim3(g.slot), dim3(1024), kGLds, s, m, hd);
-    hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, kMidT, false>), dim3(g.mid), dim3(kMidT), lds_big, s, m, hd);
+    if (hd.use_pair)
+        hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, kPairT, true, true>), dim3(g.pair), dim3(kPairT), kPairLds, s, m, hd);
+    else
+        hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, kMidT, false>), dim3(g.mid), dim3(kMidT), lds_big, s, m, hd);
     if (heavy_record) (void)hipEventRecord((hipEvent_t)heavy_record, s);
     prof_mark(prof, 1, s);
     hipError_t e = hipGetLastError();

@@ -380,13 +380,21 @@ def test_leafy_large_subgraph_is_solved_exactly_by_deflation():
     _check(view, *_run(view))
 
 
-def test_both_size_classes_of_the_direct_solver():
-    """Deflated sizes on both sides of 64 (256-thread and 1024-thread LDS instantiations of posemb_direct_kernel)."""
+@pytest.mark.parametrize("pair", ["1", "0"])
+def test_both_size_classes_of_the_direct_solver(pair, monkeypatch):
+    """Deflated sizes on both sides of 64: the one-wave teams and the 65..128 class -- two-wave teams with the matrix rows in registers
+    (the default) or, GCC_POSEMB_PAIR=0, the 1,024-thread LDS instantiation of posemb_direct_kernel.  Both meet the strict invariants;
+    their eigenvalues agree to fp32 accuracy."""
+    monkeypatch.setenv("GCC_POSEMB_PAIR", pair)
     view = _sampled_views(rw_hops=160, B=10, run_seed=11)
     red = reduced_sizes(view)
     assert (red <= 64).any() and ((red > 64) & (red <= 128)).any(), red
     x, evals, raw = _run(view)
     check_by_path(view, x, evals, raw)
+    keep = test_both_size_classes_of_the_direct_solver.__dict__.setdefault("evals", {})
+    keep[pair] = evals.copy()
+    if len(keep) == 2:
+        assert np.abs(keep["1"] - keep["0"]).max() < 5e-6
 
 
 def test_multi_view_call_matches_per_view_invariants():

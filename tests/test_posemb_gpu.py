@@ -27,7 +27,10 @@ def _device_posemb(q, B):
     return view, q.pos_undirected[:n].cpu().numpy(), evals.cpu().numpy(), raw[:n].cpu().numpy()
 
 
-def test_sampled_batch_on_g1_like_graph():
+@pytest.mark.parametrize("pair", ["1", "0"])
+def test_sampled_batch_on_g1_like_graph(pair, monkeypatch):
+    """(pair: the 65..128 class on two-wave teams -- the default -- or on the 1,024-thread LDS-resident instantiation)"""
+    monkeypatch.setenv("GCC_POSEMB_PAIR", pair)
     from gcc_amd.graph import DeviceGraph
     from gcc_amd.graphgen import powerlaw_graph
     from gcc_amd.sampler import DeviceRWRSampler
