@@ -1976,6 +1976,9 @@ __global__ __launch_bounds__(kWaveTeams * 64, kNMax <= 48 ? GCC_POSEMB_W48_OCC :
     int b;
     item_args(m, gb, a, b);
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+#ifdef GCC_POSEMB_ABLATE_WAVE                         // timing experiments only (tools/build_variant.sh)
+    continue;
+#endif
     const int k = min(min(n - 2, a.hidden), kMaxVec);   // data_util.py:278; k >= 1 (classify kernel)
     long long tick_ = m.ticks ? device_ticks() : 0;
     if (m.ticks && lane == 0) atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 15], 1ull);   // items
@@ -2515,7 +2518,10 @@ constexpr int kChPWide = 64, kChPNarrow = 32;   // the two block widths of the s
 #endif
 constexpr int kChNarrowWant = GCC_POSEMB_CH_NARROW_WANT;   // items whose quotient must deliver at most this many pairs (k - zp) start with the narrow block (0: never)
 constexpr int kChNarrowGuards = 8;   // ... and move to the wide one when the first Ritz values show more than 32 - 8 wanted pairs
-constexpr int kChThreads = 1024;
+#ifndef GCC_POSEMB_CH_THREADS
+#define GCC_POSEMB_CH_THREADS 1024
+#endif
+constexpr int kChThreads = GCC_POSEMB_CH_THREADS;
 constexpr int kChCsrCap = 12288;     // directed edges of the deflated subgraph (uint16 column ids in LDS)
 #ifndef GCC_POSEMB_CH_LONGDEG
 #define GCC_POSEMB_CH_LONGDEG 32
@@ -2594,6 +2600,9 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     int b;
     item_args(m, gb, a, b);
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+#ifdef GCC_POSEMB_ABLATE_CHEB                         // timing experiments only (tools/build_variant.sh)
+    continue;
+#endif
     const int k = min(min(n - 2, a.hidden), kMaxVec);
     long long tick_ = m.ticks ? device_ticks() : 0;
     if (m.ticks && tid == 0) atomicAdd((unsigned long long *)&m.ticks[kCls * 16 + 15], 1ull);
@@ -3426,7 +3435,7 @@ static PosGrids posemb_grids(int64_t T, bool gated = false)
     // workgroups do not fit beside it wait for the whole launch to drain (3-5 ms stalls in the kernel trace).
     static int caps[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (caps[0] == 0) {                              // tuning knob: GCC_POSEMB_GRID_CAPS="small,mid,slot,krylov,big,cheb,w48,w64,pair"
-        int c[9] = {256, 64, 128, 64, 64, 96, 512, 128, 128};    // scripts/gpu/r3_call4.sh: bench by caps; pair: r5_call10.sh (64: 0.837, 128: 0.836, 256: 0.856 ms per step)
+        int c[9] = {256, 64, 128, 64, 64, 64, 256, 64, 128};    // scripts/gpu/r3_call4.sh: bench by caps; pair: r5_call10.sh (64: 0.837, 128: 0.836, 256: 0.856 ms per step); cheb 96 -> 64, one-wave teams 512, 128 -> 256, 64: r5_call12.sh (0.839 -> 0.819)
         const char *e = getenv("GCC_POSEMB_GRID_CAPS");
         if (e) (void)sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3], &c[4], &c[5], &c[6], &c[7], &c[8]);
         for (int i = 0; i < 9; ++i) caps[i] = c[i] < 1 ? 1 : c[i];
