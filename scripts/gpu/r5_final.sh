@@ -3,7 +3,7 @@
 #   GPU tier + smoke; sampler counters (profiles/pmc_sampler.json is keyed by the source hash) + kernel stats of the sampler alone;
 #   bench lines (driver's flags with the CPU legs and the parity step, sustained, E2E, sample-ready, sampler mode on both graphs,
 #   the multi-GPU launch path on one rank); rocprofv3 --stats of the bench command; eigensolver phases (with the round-4 path as
-#   A/B); graph probe; eval probe; wide-GIN roofline.
+#   A/B, and the 65..128 class on its 1,024-thread workgroups: GCC_POSEMB_PAIR=0); graph probe; eval probe; wide-GIN roofline.
 set -u
 O=gpurun_out/${R5_OUT:-r5final}
 PARTS=${PARTS:-"tests pmc bench modes stats probes"}
@@ -56,6 +56,7 @@ if has bench; then
   (timeout 400 python bench.py --steps 192 --warmup 64 --no-cpu-baseline 2>$O/bench_192.err | tail -1) > $O/bench_192_steps.json; line $O/bench_192_steps.json
   (GCC_POSEMB_CHEB=7 timeout 400 python bench.py --steps 192 --warmup 64 --no-cpu-baseline 2>>$O/bench_192.err | tail -1) > $O/bench_192_steps_round4_block_solver.json; line $O/bench_192_steps_round4_block_solver.json
   (timeout 400 python bench.py --steps 192 --warmup 64 --no-cpu-baseline 2>>$O/bench_192.err | tail -1) > $O/bench_192_steps_run2.json; line $O/bench_192_steps_run2.json
+  (GCC_POSEMB_PAIR=0 GCC_POSEMB_GRID_CAPS=256,64,128,64,64,96,512,128,128 timeout 400 python bench.py --steps 192 --warmup 64 --no-cpu-baseline 2>>$O/bench_192.err | tail -1) > $O/bench_192_steps_1024_thread_mid_class.json; line $O/bench_192_steps_1024_thread_mid_class.json
 fi
 if has modes; then
   (timeout 400 python bench.py --steps 192 --warmup 64 --no-cpu-baseline --collectives 2>$O/bench_coll.err | tail -1) > $O/bench_192_steps_collectives.json; line $O/bench_192_steps_collectives.json
@@ -73,6 +74,7 @@ if has stats; then
 fi
 if has probes; then
   (timeout 300 python tools/posemb_phases.py 2>&1 | tail -12) > $O/posemb_phases.txt; grep -E "multi call|total|^mid|^cheb|^wave" $O/posemb_phases.txt | cut -c1-260
+  (GCC_POSEMB_PAIR=0 timeout 300 python tools/posemb_phases.py 2>&1 | tail -12) > $O/posemb_phases_1024_thread_mid_class.txt; grep -E "multi call|total|^mid" $O/posemb_phases_1024_thread_mid_class.txt | cut -c1-260
   (GCC_POSEMB_CHEB=7 timeout 300 python tools/posemb_phases.py 2>&1 | tail -12) > $O/posemb_phases_round4_block_solver.txt; grep -E "multi call|total|^cheb" $O/posemb_phases_round4_block_solver.txt | cut -c1-260
   (timeout 300 python tools/graph_probe.py --steps 200 2>&1 | tail -4) > $O/graph_probe.txt; cat $O/graph_probe.txt | cut -c1-200
   (timeout 300 python tools/eval_probe.py 2>&1 | tail -8) > $O/eval_probe.txt; cut -c1-220 $O/eval_probe.txt
