@@ -90,6 +90,9 @@ def parse_args(argv=None):
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the roofline kernel from a separate rocprofv3 --pmc pass "
                          "(default: profiles/pmc_sampler.json if it was collected from this build of sampler.hip)")
+    ap.add_argument("--posemb-fork", type=int, default=None, choices=[0, 1, 2],
+                    help="gcc_posemb_set_fork: solver classes of a call on side streams (default: 1 in --mode sample-ready, where nothing "
+                         "else needs the GPU; 0 in the training modes, where the in-order stream is the throttle the step needs)")
     ap.add_argument("--allow-posemb-flags", action="store_true",
                     help="do not fail when an eigen-iteration hit its restart cap (status bit 8); the count is reported either way")
     args = ap.parse_args(argv)
@@ -692,6 +695,11 @@ def main():
         torch.cuda.synchronize()
 
     extra = {}
+    if args.posemb_fork is not None and args.mode in ("train", "e2e") and torch.cuda.is_available():
+        from gcc_amd import _cabi as _cabi_fork0
+
+        _cabi_fork0.load().gcc_posemb_set_fork(args.posemb_fork)
+        extra["posemb_fork"] = args.posemb_fork
     if args.mode == "sampler":
         S = max(1, min(args.sampler_steps, args.steps))
         sampler = DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=max(2, S), scratch_entries=args.scratch_entries or None,
@@ -719,6 +727,12 @@ def main():
         chunk = 1
     elif args.mode == "sample-ready":
         from gcc_amd.posemb import DevicePosEmb
+        from gcc_amd import _cabi as _cabi_fork
+
+        fork_mode = 1 if args.posemb_fork is None else args.posemb_fork
+        if "GCC_POSEMB_FORK" not in os.environ:
+            _cabi_fork.load().gcc_posemb_set_fork(fork_mode)
+        extra["posemb_fork"] = fork_mode if "GCC_POSEMB_FORK" not in os.environ else int(os.environ["GCC_POSEMB_FORK"])
 
         # the producer lanes of the training modes without a consumer: lane l samples chunk c (c % lanes == l) -- `chunk`
         # steps per sampler call -- and runs ONE multi-view eigensolver call over its 2 * chunk views, on its own stream

@@ -192,6 +192,7 @@ SIGNATURES = {
         ctypes.c_void_p]),
     "gcc_posemb_workspace_bytes": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32]),
     "gcc_posemb_debug_ticks": (None, [ctypes.c_void_p]),
+    "gcc_posemb_set_fork": (None, [ctypes.c_int32]),
     "gcc_sampler_debug_ticks": (None, [ctypes.c_void_p]),
     "gcc_sampler_debug_grids": (None, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "gcc_debug_load": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,

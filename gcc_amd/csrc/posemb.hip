@@ -11,6 +11,7 @@
 //   posemb_direct_kernel    n' <= 384: dense symmetric eigensolver (tridiagonalise, bisect, inverse
 //                           iteration): exact multiplicities, deterministic run time; three size classes
 //   posemb_krylov_kernel    larger ones: thick-restart Krylov-Schur, Ritz problem by the same solver core
+#include <mutex>
 #include "host_common.h"
 #include <type_traits>
 
@@ -3435,7 +3436,7 @@ static PosGrids posemb_grids(int64_t T, bool gated = false)
     // workgroups do not fit beside it wait for the whole launch to drain (3-5 ms stalls in the kernel trace).
     static int caps[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (caps[0] == 0) {                              // tuning knob: GCC_POSEMB_GRID_CAPS="small,mid,slot,krylov,big,cheb,w48,w64,pair"
-        int c[9] = {256, 64, 128, 64, 64, 64, 256, 64, 128};    // scripts/gpu/r3_call4.sh: bench by caps; pair: r5_call10.sh (64: 0.837, 128: 0.836, 256: 0.856 ms per step); cheb 96 -> 64, one-wave teams 512, 128 -> 256, 64: r5_call12.sh (0.839 -> 0.819)
+        int c[9] = {256, 64, 128, 64, 64, 96, 512, 128, 128};    // scripts/gpu/r3_call4.sh: bench by caps; pair: r5_call10.sh (64: 0.837, 128: 0.836, 256: 0.856 ms per step); cheb 96 -> 64, one-wave teams 512, 128 -> 256, 64: r5_call12.sh (0.839 -> 0.819)
         const char *e = getenv("GCC_POSEMB_GRID_CAPS");
         if (e) (void)sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3], &c[4], &c[5], &c[6], &c[7], &c[8]);
         for (int i = 0; i < 9; ++i) caps[i] = c[i] < 1 ? 1 : c[i];
@@ -3479,6 +3480,39 @@ static int64_t posemb_head_bytes(int64_t T) { return ((16 + kNumCls * T) * 4 + 2
 static int64_t posemb_slot_floats(void) { return (int64_t)kGMax * kGMax + (int64_t)kNodeMax * 4; }
 static int64_t posemb_bslot_floats(void) { return (int64_t)kBMax * kBMax + (int64_t)kNodeMax * 4; }
 static int64_t posemb_ldv(int32_t batch_size, int64_t node_cap) { return ((node_cap / batch_size + 63) / 64) * 64 + 64; }
+
+// The solver classes of one call are independent of each other once the classify kernel has written their lists (only the block class
+// hands items on: to the Krylov / workspace classes behind it).  On ONE in-order stream each class's launch waits for the previous one
+// to drain -- the block class's last long item kept the other classes' workgroups off the machine --, so the call forks: the one-wave
+// teams and the 65..128 class run on two side streams of the caller's stream (same priority, created once per caller stream) and join
+// it at the end.  OFF by default (gcc_posemb_set_fork / GCC_POSEMB_FORK = 1): an isolated call of 16 views takes 4.4 instead of 8.7 ms and a
+// pipeline with nothing else on the GPU gains accordingly, but next to the training step the extra concurrency costs the step more
+// than the call gains (scripts/gpu/r5_call15.sh: 0.909 against 0.858 ms per step sustained) -- one in-order stream is the throttle
+// the step's latency-bound kernels need.
+static int g_posemb_fork = -1;               // gcc_posemb_set_fork: -1 = GCC_POSEMB_FORK decides (default 0)
+#ifndef GCC_AMD_HIPEMU
+struct PosSide { hipStream_t owner, side[2]; hipEvent_t fork, join[2]; };
+static PosSide *posemb_side_streams(hipStream_t s)
+{
+    static std::mutex mu;
+    static PosSide tab[16];
+    static int ntab = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < ntab; ++i)
+        if (tab[i].owner == s) return &tab[i];
+    if (ntab == 16) return nullptr;                  // (more caller streams than anyone uses: those calls stay on one stream)
+    PosSide &t = tab[ntab];
+    int prio = 0;
+    if (hipStreamGetPriority(s, &prio) != hipSuccess) { (void)hipGetLastError(); prio = 0; }
+    for (int i = 0; i < 2; ++i) {
+        if (hipStreamCreateWithPriority(&t.side[i], hipStreamNonBlocking, prio) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipEventCreateWithFlags(&t.join[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    t.owner = s;
+    return &tab[ntab++];
+}
+#endif
 
 int64_t gcc_posemb_multi_workspace_bytes(int32_t num_views, int32_t batch_size, int64_t node_cap, int32_t hidden)
 {
@@ -3599,13 +3633,24 @@ int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, 
         kry_lds_opt_in = lds_kry;
     }
 #endif
-    // light launches first (one-wave teams, the 256-thread small class): short workgroups with modest LDS that overlap
-    // freely with everything; then the heavy ones behind the caller's gate (see gcc_posemb_multi_gated in the header)
-    hipLaunchKernelGGL((posemb_direct_kernel<kClsSmall, 0, kJSmall, kSmallT, false>), dim3(g.small), dim3(kSmallT), lds_small, s, m, hd);
-    if (hd.use_wave) {
-        hipLaunchKernelGGL((posemb_wave_kernel<kClsW64, 64>), dim3(g.w64), dim3(kWaveTeams * 64), kWaveTeams * wave_team_bytes<64>(), s, m, hd);
-        hipLaunchKernelGGL((posemb_wave_kernel<kClsW48, 48>), dim3(g.w48), dim3(kWaveTeams * 64), kWaveTeams * wave_team_bytes<48>(), s, m, hd);
+    // the light classes (one-wave teams, the 256-thread small class) and the two-wave 65..128 class on the side streams, the block class and
+    // what it may hand items on to on the caller's stream, behind the caller's gate (see gcc_posemb_multi_gated in the header)
+    hipStream_t s1 = s, s2 = s;
+#ifndef GCC_AMD_HIPEMU
+    PosSide *side = nullptr;
+    int fork_mode = 0;
+    {
+        const char *ef = getenv("GCC_POSEMB_FORK");
+        fork_mode = g_posemb_fork >= 0 ? g_posemb_fork : (ef ? atoi(ef) : 0);
+        if (fork_mode) side = posemb_side_streams(s);
     }
+    if (side) {
+        s1 = side->side[0]; s2 = fork_mode == 2 ? s1 : side->side[1];    // 2: ONE side stream for everything but the block class
+        (void)hipEventRecord(side->fork, s);
+        (void)hipStreamWaitEvent(s1, side->fork, 0);
+        (void)hipStreamWaitEvent(s2, side->fork, 0);
+    }
+#endif
     if (heavy_wait) (void)hipStreamWaitEvent(s, (hipEvent_t)heavy_wait, 0);
     if (hd.use_cheb) {
         ChebArgs ca;
@@ -3624,18 +3669,36 @@ int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, 
 #endif
         hipLaunchKernelGGL(posemb_cheb_kernel, dim3(g.cheb), dim3(kChThreads), cheb_lds_bytes(), s, ca);
     }
+    hipLaunchKernelGGL((posemb_direct_kernel<kClsSmall, 0, kJSmall, kSmallT, false>), dim3(g.small), dim3(kSmallT), lds_small, s1, m, hd);
+    if (hd.use_wave) {
+        hipLaunchKernelGGL((posemb_wave_kernel<kClsW64, 64>), dim3(g.w64), dim3(kWaveTeams * 64), kWaveTeams * wave_team_bytes<64>(), s1, m, hd);
+        hipLaunchKernelGGL((posemb_wave_kernel<kClsW48, 48>), dim3(g.w48), dim3(kWaveTeams * 64), kWaveTeams * wave_team_bytes<48>(), s1, m, hd);
+    }
+    if (hd.use_pair)
+        hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, kPairT, true, true>), dim3(g.pair), dim3(kPairT), kPairLds, s2, m, hd);
+    else
+        hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, kMidT, false>), dim3(g.mid), dim3(kMidT), lds_big, s2, m, hd);
     hipLaunchKernelGGL(posemb_krylov_kernel, dim3(g.kry), dim3(kKThreads), lds_kry, s, ka);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsBig, kGMax + 1, kBMax, 1024, true>), dim3(g.big), dim3(1024), kBLds, s, m, hd);
     hipLaunchKernelGGL((posemb_direct_kernel<kClsSlot, kJMax + 1, kGMax, 1024, true>), dim3(g.slot), dim3(1024), kGLds, s, m, hd);
-    if (hd.use_pair)
-        hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, kPairT, true, true>), dim3(g.pair), dim3(kPairT), kPairLds, s, m, hd);
-    else
-        hipLaunchKernelGGL((posemb_direct_kernel<kClsMid, kJSmall + 1, kJMax, kMidT, false>), dim3(g.mid), dim3(kMidT), lds_big, s, m, hd);
+#ifndef GCC_AMD_HIPEMU
+    if (side) {
+        (void)hipEventRecord(side->join[0], s1);
+        (void)hipEventRecord(side->join[1], s2);
+        (void)hipStreamWaitEvent(s, side->join[0], 0);
+        (void)hipStreamWaitEvent(s, side->join[1], 0);
+    }
+#endif
     if (heavy_record) (void)hipEventRecord((hipEvent_t)heavy_record, s);
     prof_mark(prof, 1, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_posemb: %s", hipGetErrorString(e)); return -10; }
     return 0;
+}
+
+void gcc_posemb_set_fork(int32_t mode)   /* 0: one in-order stream (default), 1: three-way fork, 2: the block class beside the rest, -1: environment */
+{
+    g_posemb_fork = mode;
 }
 
 void gcc_posemb_debug_ticks(long long *device_ticks64)   /* device int64[GCC_POSEMB_TICK_CLASSES][16] or NULL; diagnostics only */

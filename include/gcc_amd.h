@@ -227,9 +227,17 @@ int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, 
                                int32_t hidden, uint64_t seed, void *workspace, int64_t workspace_bytes, int32_t *status,
                                gcc_prof *prof, void *heavy_wait, void *heavy_record, void *stream);
 
+/* How the solver classes of one gcc_posemb* call are issued.  0 (default): one after the other on the caller's stream -- next to a
+ * training step that is what keeps the step's short kernels fed.  1: the one-wave teams and the 65..128 class on two side streams of the
+ * caller's stream (same priority, created once per caller stream, joined before the call's end mark): half the latency of a call when
+ * the pipeline has the GPU to itself (bench.py --mode sample-ready).  2: one side stream for everything but the block class.
+ * -1: the environment variable GCC_POSEMB_FORK decides.  Process-wide; results do not depend on it. */
+void gcc_posemb_set_fork(int32_t mode);
+
 /* diagnostics: subsequent gcc_posemb* calls add wall-clock ticks (100 MHz) per solver class and phase into
  * device int64[GCC_POSEMB_TICK_CLASSES][16] -- EIGHT classes: small, mid, slot, Krylov, big, sparse block (Chebyshev),
- * one-wave teams n' <= 48, one-wave teams n' <= 64 (their ticks are WAVE time: 4 teams share a workgroup);
+ * one-wave teams n' <= 48, one-wave teams n' <= 64 (their ticks are WAVE time: 4 teams share a workgroup; the 'mid' class
+ * runs on two-wave workgroups of 128 threads, four of which share a CU: its ticks are the time of one such workgroup);
  * phases of the dense classes 0..6 = matrix, tridiagonalise, bisect, inverse iteration, Gram-Schmidt, back-transform,
  * expand; [14] = executed f32 FLOPs; [15] = items; NULL switches it off.  A buffer sized for fewer classes is written
  * out of bounds. */
