@@ -854,6 +854,7 @@ def main():
             ("" if trainer.relaxed_streams else "; caller <-> step stream hand-offs around every step")
         stage_profs = profs
         if graph_on:
+            extra["graph_capture_failures"] = int(getattr(trainer, "graph_capture_failures", 0))
             extra["graph_replays_in_timed_region"] = int(trainer.graph_replays - (trainer.graph_replays_at_clock if hasattr(trainer, "graph_replays_at_clock") else 0))
             trainer.use_graph = False                                     # stage intervals: eager steps right after the clock
             stage_profs = [{n: Prof(2) for n in names} for _ in range(chunk)]

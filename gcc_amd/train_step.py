@@ -442,23 +442,37 @@ class _GraphedStep:
         """Record ``body``'s launches for ring slot ``key`` (nothing executes): one CUDAGraph per capturable segment, all from
         one memory pool (later segments read what earlier ones allocated)."""
         steps0 = self.optimizer.steps
-        segments, result = body(self.scalars, {})
-        items, pool = [], None
-        for capturable, fn in segments:
-            if not capturable:
-                items.append(fn)                                         # (collectives: not run now, issued at every replay)
-                continue
-            gobj = torch.cuda.CUDAGraph()
-            gobj.capture_begin(capture_error_mode="thread_local", **({} if pool is None else dict(pool=pool)))
-            try:
-                fn()
-            finally:
-                gobj.capture_end()
-            pool = pool or gobj.pool()
-            items.append(gobj)
-        cap = result()
-        self.optimizer.steps = steps0                                    # the captured body counted a step that did not run
+        try:
+            segments, result = body(self.scalars, {})
+            items, pool = [], None
+            for capturable, fn in segments:
+                if not capturable:
+                    items.append(fn)                                     # (collectives: not run now, issued at every replay)
+                    continue
+                gobj = torch.cuda.CUDAGraph()
+                gobj.capture_begin(capture_error_mode="thread_local", **({} if pool is None else dict(pool=pool)))
+                try:
+                    fn()
+                finally:
+                    gobj.capture_end()
+                pool = pool or gobj.pool()
+                items.append(gobj)
+            cap = result()
+        except RuntimeError as e:
+            # A capture that the runtime invalidated (seen once in ~10 runs of the collectives path on ROCm 7.0: "operation failed
+            # due to a previous error during capture", with RCCL's threads busy beside the capturing one).  Nothing executed and
+            # nothing is lost: the slot stays uncaptured, its next step is issued launch by launch and captured again afterwards.
+            self.graph_capture_failures = getattr(self, "graph_capture_failures", 0) + 1
+            if self.graph_capture_failures > 8:
+                raise
+            import warnings
+            warnings.warn(f"step graph capture failed ({e}); the slot stays eager")
+            torch.cuda.synchronize(self.dev)
+            return False
+        finally:
+            self.optimizer.steps = steps0                                # the captured body counted a step that did not run
         self.graphs[key] = (items, dict(loss=cap["loss"], prob=cap["prob"], grad_norm=cap["grad_norm"]))
+        return True
 
     def _precapture_ready(self, st):
         """Right after the FIRST step of a run (launched eagerly: every lazily allocated engine buffer exists now), the graphs
@@ -474,8 +488,7 @@ class _GraphedStep:
             pairs, _ev = prod.ready[c]
             for q, k in pairs:
                 key = self._slot_key(q, k)
-                if key not in self.graphs:
-                    self._capture(key, self._capture_body(q, k, st))
+                if key not in self.graphs and self._capture(key, self._capture_body(q, k, st)):
                     self.graphs_precaptured += 1
 
     def _fetch_scalars(self, scalars, st):

@@ -37,13 +37,24 @@ def check_against_oracle(model, oracle, q, keep, out, hidden, monkeypatch, rtol=
     feat.backward(d)
     ref.backward(d)
     refg = dict(oracle.named_parameters())
+    # the binding reference for the gradients is the same model in float64: a weight gradient sums thousands of terms that largely cancel,
+    # so two fp32 implementations (the kernels, torch's) differ from each other by what each is off from float64.  The bar: 1e-3 of the
+    # tensor's largest entry, or three times torch's own fp32 error where that is larger (width 256; see tests/test_wide_encoder_gpu.py)
+    import copy
+    o64 = copy.deepcopy(oracle).double()
+    o64.zero_grad()
+    r64 = o64(args[0], args[1], args[2], args[3].double(), dropout_masks=keep.double(), return_all_outputs=True)[0]
+    r64.backward(d.double())
+    ref64 = dict(o64.named_parameters())
     for name, p in model.named_parameters():
         if refg[name].grad is None:
             assert p.grad is None or float(p.grad.abs().sum()) == 0.0, name
             continue
         assert p.grad.shape == p.shape
-        scale = max(float(refg[name].grad.abs().max()), 1e-3)
-        torch.testing.assert_close(p.grad, refg[name].grad, rtol=2e-3, atol=max(1e-3 * scale, 1e-4 if name.endswith("bias") else 5e-6),
+        g64 = ref64[name].grad.float()
+        scale = max(float(g64.abs().max()), 1e-3)
+        err32 = float((refg[name].grad - g64).abs().max())
+        torch.testing.assert_close(p.grad, g64, rtol=2e-3, atol=max(1e-3 * scale, 3.0 * err32, 1e-4 if name.endswith("bias") else 5e-6),
                                    msg=lambda m, name=name: f"{name}: {m}")
     return args
 
