@@ -23,6 +23,19 @@ def emu_wide_engine():
     return WideGinEngine(lib=emu_lib(), ptr=lambda t: 0 if t is None else t.data_ptr())
 
 
+def fixed_views():
+    """The sampled batch of the headline tests with a REPRODUCIBLE positional embedding: OracleSampler's comes from SciPy ARPACK, whose
+    output differs from call to call (the degenerate eigenspaces of small ego-nets), and with ~2 M pre-activations per pass an input
+    now and then puts one of them within fp32 rounding of a ReLU kink -- then ANY two fp32 implementations may disagree on that
+    element's mask and its whole upstream gradient (seen: 1e-2 of a gradient's scale, one element with |y| < 1e-6 in float64).  Unit rows
+    from a seeded generator keep the test's inputs, and so its verdict, the same on every run."""
+    q, k = OracleSampler().views
+    for v, seed in ((q, 11), (k, 12)):
+        x = torch.randn(v.pos_undirected.shape, generator=torch.Generator().manual_seed(seed))
+        v.pos_undirected = torch.nn.functional.normalize(x, dim=1)
+    return q, k
+
+
 def check_against_oracle(model, oracle, q, keep, out, hidden, monkeypatch, rtol=2e-4):
     monkeypatch.setattr(torch, "rand", lambda *a, **k: keep.clone())       # the API path draws its dropout masks here
     feat, pooled = model(q, return_all_outputs=True)
@@ -70,7 +83,7 @@ def test_wide_api_path_forward_backward_vs_oracle(hidden, out, layers, monkeypat
     model._wide_engine = emu_wide_engine()
     model.train()
     oracle.train()
-    q, _ = OracleSampler().views
+    q, _ = fixed_views()
     keep = (torch.rand(layers, B, out) >= 0.5).float()
     args = check_against_oracle(model, oracle, q, keep, out, hidden, monkeypatch)
     # running statistics moved exactly as torch's BatchNorm1d moves them (momentum 0.1, unbiased variance)
