@@ -463,10 +463,13 @@ class _GraphedStep:
             # due to a previous error during capture", with RCCL's threads busy beside the capturing one).  Nothing executed and
             # nothing is lost: the slot stays uncaptured, its next step is issued launch by launch and captured again afterwards.
             self.graph_capture_failures = getattr(self, "graph_capture_failures", 0) + 1
-            if self.graph_capture_failures > 8:
-                raise
             import warnings
-            warnings.warn(f"step graph capture failed ({e}); the slot stays eager")
+            if self.graph_capture_failures > 4:
+                # not a stray event but the rule on this system: stop trying, every step is issued launch by launch from here on
+                self.use_graph = False
+                warnings.warn(f"step graph capture failed {self.graph_capture_failures} times ({e}); graph replay is switched off")
+            else:
+                warnings.warn(f"step graph capture failed ({e}); the slot stays eager")
             torch.cuda.synchronize(self.dev)
             return False
         finally:
