@@ -1003,7 +1003,7 @@ template <int kCPL, int kT, bool kPair = false>
 __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const TriLds &w, EigShared &es, uint32_t hseed,
                                 long long *tick_row, long long &tick)
 {
-    static_assert(!kPair || (kT == 128 && kCPL == 2), "two-wave teams");
+    static_assert(!kPair || ((kT == 128 || kT == 256) && kCPL == 2), "two- / four-wave teams");
     constexpr int kNW = kT / 64;
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ldy = w.ldy;
@@ -1127,50 +1127,50 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
         if (it >= need_until) break;
     }
     if constexpr (kPair) {
-        // x = H_0 ... H_{nr-3} y for a two-wave team: wave h takes the vectors 16 h .. 16 h + 15, FOUR lanes per vector -- quarter q of the
-        // wave holds the rows 4 r + q of its vector in registers --, so a reflector costs (nr - kk) / 4 multiply-adds per lane twice and
-        // two cross-lane additions; the reflectors come from the workspace one step ahead, through a double-buffered LDS copy (one
-        // 2-wave barrier per reflector).  (The version below gives a wave two vectors at a time: 8 passes over all reflectors with two
-        // full wave reductions each, 152 us per item.)
-        constexpr int kR = 32;
-        const int j = 16 * wv + (lane & 15), q = lane >> 4;
+        // x = H_0 ... H_{nr-3} y for a two- / four-wave team: kLPV = kT / 32 lanes per vector (4 / 8) -- lane group q of a wave holds the rows
+        // kLPV r + q of its vector in registers --, so a reflector costs (nr - kk) / kLPV multiply-adds per lane twice and 2 / 3 cross-lane
+        // additions; the reflectors come from the workspace one step ahead, through a double-buffered LDS copy (one team barrier per
+        // reflector).  (The version below gives a wave two vectors at a time: 8 passes over all reflectors with two full wave
+        // reductions each, 152 us per item on two waves.)
+        constexpr int kLPV = kT / 32, kVPW = 64 / kLPV, kR = 128 / kLPV;
+        const int j = kVPW * wv + (lane & (kVPW - 1)), q = lane / kVPW;
         const bool act = j < na;
         float *Yj = w.Y + (act ? j : 0);
         float y[kR], vc[kR];
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
-            const int c = 4 * r + q;
+            const int c = kLPV * r + q;
             y[r] = (act && c < nr) ? Yj[c * ldy] : 0.f;
             vc[r] = 0.f;
         }
         auto fetch = [&](int kk) -> float { return (tid > kk + 1 && tid < nr) ? A[(int64_t)kk * lda + tid] : (tid == kk + 1 ? 1.0f : 0.f); };
-        float nxt = nr >= 3 ? fetch(nr - 3) : 0.f;
+        float nxt = (nr >= 3 && tid < 128) ? fetch(nr - 3) : 0.f;
         int par = 0;
         for (int kk = nr - 3; kk >= 0; --kk) {
             float *vb = w.pbuf + par * 128;              // (pbuf and vbuf are adjacent: 2 x 128 floats)
-            vb[tid] = nxt;
+            if (tid < 128) vb[tid] = nxt;
             __syncthreads();
-            if (kk > 0) nxt = fetch(kk - 1);
+            if (kk > 0 && tid < 128) nxt = fetch(kk - 1);
             par ^= 1;
             const float t = w.tau[kk];
             if (t == 0.f) continue;                      // uniform
             float s = 0.f;
 #pragma unroll
             for (int g = 0; g < kR / 4; ++g) {
-                if (16 * g + 15 > kk) {                  // uniform: rows 16 g .. 16 g + 15 reach beyond kk
+                if (4 * kLPV * g + 4 * kLPV - 1 > kk) {  // uniform: the rows of these four registers reach beyond kk
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        vc[4 * g + u] = vb[16 * g + 4 * u + q];
+                        vc[4 * g + u] = vb[kLPV * (4 * g + u) + q];
                         s = fmaf(vc[4 * g + u], y[4 * g + u], s);
                     }
                 }
             }
-            s += wave_shfl_xor(s, 16);
-            s += wave_shfl_xor(s, 32);
+#pragma unroll
+            for (int m = kVPW; m < 64; m <<= 1) s += wave_shfl_xor(s, m);
             s *= t;
 #pragma unroll
             for (int g = 0; g < kR / 4; ++g) {
-                if (16 * g + 15 > kk) {
+                if (4 * kLPV * g + 4 * kLPV - 1 > kk) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) y[4 * g + u] = fmaf(-s, vc[4 * g + u], y[4 * g + u]);
                 }
@@ -1178,7 +1178,7 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
         }
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
-            const int c = 4 * r + q;
+            const int c = kLPV * r + q;
             if (act && c < nr) Yj[c * ldy] = y[r];
         }
     } else
@@ -1233,8 +1233,15 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
 //              all: sigma, x0, a_kk from row k (a 2 x 64 wave reduction, the same in both waves); v_r; S_r = sum_{c>k+1} a_rc row_k[c];
 //              p_r = tau (a_{r,k+1} + scale S_r)  [a_{r,k+1} = row_{k+1}[r]];  p_r, v_r and the wave's part of p.v into LDS  | barrier
 //              K = tau/2 p.v;  a_rc -= v_r p_c + (p_r - 2 K v_r) v_c   [= v_r w_c + w_r v_c with w = p - K v]
-constexpr int kPairT = 128;
-constexpr int kPairLds = 32 * 1024;      // dynamic LDS of a two-wave workgroup (+ ~2 KiB static): the deflation tables (24 KiB), later the eigenvectors (17 KiB)
+#ifndef GCC_POSEMB_PAIR_THREADS
+#define GCC_POSEMB_PAIR_THREADS 256  // 128: two waves, thread = row (tridiagonalize_pair); 256: four waves, thread = half a row (tridiagonalize_quad)
+#endif
+#ifndef GCC_POSEMB_QUAD_OCC
+#define GCC_POSEMB_QUAD_OCC 4        // waves per SIMD the four-wave kernel is compiled for (4: <= 128 registers, four workgroups per CU)
+#endif
+constexpr int kPairT = GCC_POSEMB_PAIR_THREADS;
+static_assert(kPairT == 128 || kPairT == 256, "two- or four-wave teams");
+constexpr int kPairLds = (kPairT == 128 ? 32 : 33) * 1024;   // dynamic LDS of such a workgroup (+ ~2 KiB static): the deflation tables (24 KiB), later the eigenvectors (17 KiB)
 constexpr int kPairSlotFloats = 128 * 128 + 2048 + 2 * 128 * 33 + 1024 + 64;   // matrix / reflectors | expansion records (8 bytes per node) | LU factors
 template <int kNMax>
 __device__ void tridiagonalize_pair(float *A, int lda, int n, const TriLds &w, float *xb /* LDS, 16-byte aligned, 6 kNMax + 8 floats */)
@@ -1343,6 +1350,126 @@ __device__ void tridiagonalize_pair(float *A, int lda, int n, const TriLds &w, f
         if (r == 0) {
             if (n >= 2) { w.dg[n - 2] = rk[n - 2]; w.of[n - 2] = rk[n - 1]; }
             w.dg[n - 1] = rk1[n - 1];
+            w.of[n - 1] = 0.f;
+        }
+    }
+    __syncthreads();
+}
+
+// The same for FOUR waves: thread t owns HALF of row r = t >> 1 -- the columns of parity t & 1, 64 registers -- so that a column's
+// multiply-adds and LDS broadcasts per thread are half the two-wave version's, the two halves of a row's product meet with one lane
+// exchange, and a workgroup's four waves at <= 128 registers take the same share of a CU as the two at 227.  Rows and the p / v
+// vectors lie in LDS de-interleaved (even columns | 16 bytes | odd columns: the two parities of a 16-lane group read different banks).
+constexpr int kQuadHalf = 68;            // floats from the even half of a row in LDS to its odd half
+template <int kNMax>
+__device__ void tridiagonalize_quad(float *A, int lda, int n, const TriLds &w, float *xb /* LDS, 16-byte aligned, 6 * 136 + 8 floats */)
+{
+    static_assert(kNMax == 128, "four waves, half a row per thread");
+    constexpr int kRow = 2 * kQuadHalf, kG = kNMax / 32;
+    const int t = (int)threadIdx.x, r = t >> 1, hh = t & 1, lane = t & 63, h = t >> 6;
+    float a[64];                                         // a[j] = A[r][2 j + hh]
+    {
+        uint64_t ap = (uint64_t)(A + r);
+        opaque_u64(ap);
+        const float *Ar = (const float *)ap;
+        const uint32_t mr = r < n ? 0xFFFFFFFFu : 0u;
+        const int jmax = (n - hh + 1) >> 1;              // 2 j + hh < n  <=>  j < jmax  (a compare against a constant per element: no index vectors)
+        const float *Ah = Ar + hh * lda;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) a[j] = __uint_as_float(__float_as_uint(Ah[2 * j * lda]) & (j < jmax ? mr : 0u));
+    }
+    __syncthreads();                                     // all rows are in registers: A's rows may now receive the reflectors
+    float *pv = xb + 4 * kRow, *vv = xb + 5 * kRow, *kpart = xb + 6 * kRow;
+    auto flat = [&](const float *row, int c) -> float { return row[(c & 1) * kQuadHalf + (c >> 1)]; };
+    const int ncols = (n + 31) & ~31;
+    auto put_half = [&](float *dst, int from) {          // one thread: its half of the row, blocks of 8 registers = 16 columns
+        float *d = dst + hh * kQuadHalf;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (16 * b + 15 >= from && 16 * b < ncols) {
+                *(float4 *)(d + 8 * b) = make_float4(a[8 * b], a[8 * b + 1], a[8 * b + 2], a[8 * b + 3]);
+                *(float4 *)(d + 8 * b + 4) = make_float4(a[8 * b + 4], a[8 * b + 5], a[8 * b + 6], a[8 * b + 7]);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int k = 0; k + 2 < n; ++k) {
+        float *rk = xb + (k & 1) * 2 * kRow, *rk1 = rk + kRow;
+        if (r == k) put_half(rk, k);
+        if (r == k + 1) put_half(rk1, k);
+        __syncthreads();
+        const float c0 = lane < n ? flat(rk, lane) : 0.f, c1 = lane + 64 < n ? flat(rk, lane + 64) : 0.f;
+        const float sig = wave_sum((lane > k + 1 ? c0 * c0 : 0.f) + (lane + 64 > k + 1 ? c1 * c1 : 0.f));
+        const float x0 = flat(rk, k + 1), akk = flat(rk, k);
+        if (sig <= 1e-30f) {                             // uniform over the workgroup
+            if (t == 0) { w.dg[k] = akk; w.of[k] = x0; w.tau[k] = 0.f; }
+            continue;
+        }
+        const float mu = sqrtf(x0 * x0 + sig);
+        const float beta = x0 > 0.f ? -mu : mu;
+        const float tt = (beta - x0) / beta;
+        const float scale = 1.0f / (x0 - beta);
+        const float vr = r == k + 1 ? 1.0f : (r > k + 1 && r < n ? flat(rk, r) * scale : 0.f);
+        float s0 = 0.f, s1 = 0.f;
+        const float *rkh = rk + hh * kQuadHalf;
+        const int jlo = (k + 1 - hh) >> 1;               // 2 j + hh > k + 1  <=>  j > jlo
+#pragma unroll
+        for (int g = 0; g < kG; ++g) {
+            if (32 * g + 31 > k + 1 && 32 * g < n) {     // uniform
+                float q[16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 t4 = *(const float4 *)(rkh + 16 * g + 4 * u);
+                    q[4 * u] = t4.x; q[4 * u + 1] = t4.y; q[4 * u + 2] = t4.z; q[4 * u + 3] = t4.w;
+                }
+                if (32 * g > k + 1) {
+#pragma unroll
+                    for (int u = 0; u < 16; u += 2) { s0 = fmaf(a[16 * g + u], q[u], s0); s1 = fmaf(a[16 * g + u + 1], q[u + 1], s1); }
+                } else {                                 // the group the reflector starts in
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) s0 = fmaf(a[16 * g + u], 16 * g + u > jlo ? q[u] : 0.f, s0);
+                }
+            }
+        }
+        float S = s0 + s1;
+        S += wave_shfl_xor(S, 1);                        // the two halves of the row
+        const float p = (r > k && r < n) ? tt * fmaf(scale, S, flat(rk1, r)) : 0.f;
+        const float kp = wave_sum(hh == 0 ? p * vr : 0.f);
+        if (hh == 0) {
+            pv[(r & 1) * kQuadHalf + (r >> 1)] = p;
+            vv[(r & 1) * kQuadHalf + (r >> 1)] = vr;
+            if (r > k + 1 && r < n) A[(int64_t)k * lda + r] = vr;    // row k of A stores the reflector
+        }
+        if (lane == 0) kpart[h] = kp;
+        if (t == 0) { w.dg[k] = akk; w.of[k] = beta; w.tau[k] = tt; }
+        __syncthreads();
+        const float K = 0.5f * tt * ((kpart[0] + kpart[1]) + (kpart[2] + kpart[3]));
+        const float wr = fmaf(-2.0f * K, vr, p);
+        const float *pvh = pv + hh * kQuadHalf, *vvh = vv + hh * kQuadHalf;
+#pragma unroll
+        for (int g = 0; g < kG; ++g) {
+            if (32 * g + 31 > k && 32 * g < n) {         // (p and v are zero left of column k + 1 and beyond n)
+                float pc[16], vc[16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 p4 = *(const float4 *)(pvh + 16 * g + 4 * u), v4 = *(const float4 *)(vvh + 16 * g + 4 * u);
+                    pc[4 * u] = p4.x; pc[4 * u + 1] = p4.y; pc[4 * u + 2] = p4.z; pc[4 * u + 3] = p4.w;
+                    vc[4 * u] = v4.x; vc[4 * u + 1] = v4.y; vc[4 * u + 2] = v4.z; vc[4 * u + 3] = v4.w;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a[16 * g + u] = fmaf(-vr, pc[u], fmaf(-wr, vc[u], a[16 * g + u]));
+            }
+        }
+    }
+    {   // the last 2 x 2 block
+        __syncthreads();
+        float *rk = xb, *rk1 = xb + kRow;
+        if (n >= 2 && r == n - 2) put_half(rk, n - 2);
+        if (r == n - 1) put_half(rk1, n - 2);
+        __syncthreads();
+        if (t == 0) {
+            if (n >= 2) { w.dg[n - 2] = flat(rk, n - 2); w.of[n - 2] = flat(rk, n - 1); }
+            w.dg[n - 1] = flat(rk1, n - 1);
             w.of[n - 1] = 0.f;
         }
     }
@@ -1775,7 +1902,7 @@ __global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m
 }
 
 template <int kCls, int kNMin, int kNMax, int kT, bool kGlobalA, bool kPair = false>
-__global__ __launch_bounds__(kT, kPair ? 2 : 1) void posemb_direct_kernel(PosMulti m, PosHead hd)
+__global__ __launch_bounds__(kT, kPair ? (kT == 256 ? GCC_POSEMB_QUAD_OCC : 2) : 1) void posemb_direct_kernel(PosMulti m, PosHead hd)
 {
     static_assert(kNMax % 64 == 0 && kT % 64 == 0 && kT >= 64, "size class");
     static_assert(!kPair || (kGlobalA && kT == kPairT && kNMax == 128), "two-wave teams: the matrix and the reflectors live in the workspace");
@@ -1885,7 +2012,9 @@ __global__ __launch_bounds__(kT, kPair ? 2 : 1) void posemb_direct_kernel(PosMul
     __syncthreads();
 
     PHASE_TICK(0);                                 // deflation + matrix
-    if constexpr (kPair) {
+    if constexpr (kPair && kT == 256) {
+        tridiagonalize_quad<kNMax>(A, lda, nr, w, lds_rest);      // (the eigenvector / LU region of the LDS is free until the bisection)
+    } else if constexpr (kPair) {
         tridiagonalize_pair<kNMax>(A, lda, nr, w, lds_rest);      // (the eigenvector / LU region of the LDS is free until the bisection)
     } else if (kGlobalA) {
         // (the eigenvector / LU region of the LDS is free until the bisection: per-wave column sums and the pivot column)
