@@ -488,8 +488,9 @@ def hbm_roofline(kernel, alg_bytes, ms, traffic, **more):
     return out
 
 
-PAIR_CLASS = os.environ.get("GCC_POSEMB_PAIR", "1") != "0"      # the 65..128 class on two-wave teams (csrc/posemb.hip; 0: 1,024-thread workgroups)
-SOLVER_KERNELS = {"mid": "posemb_direct_kernel<1, 65, 128, 128, true, true>" if PAIR_CLASS else "posemb_direct_kernel<1, 65, 128, 1024, false>", "sparse-block": "posemb_cheb_kernel", "wave48": "posemb_wave_kernel<6, 48>",
+PAIR_CLASS = os.environ.get("GCC_POSEMB_PAIR", "1") != "0"      # the 65..128 class on four-wave teams (csrc/posemb.hip; 0: 1,024-thread workgroups)
+TEAM_SHARE = 3                                                  # such workgroups per CU: 256 threads at 168 registers (GCC_POSEMB_QUAD_OCC 3), 33 KiB of LDS
+SOLVER_KERNELS = {"mid": "posemb_direct_kernel<1, 65, 128, 256, true, true>" if PAIR_CLASS else "posemb_direct_kernel<1, 65, 128, 1024, false>", "sparse-block": "posemb_cheb_kernel", "wave48": "posemb_wave_kernel<6, 48>",
                   "wave64": "posemb_wave_kernel<7, 64>", "small": "posemb_direct_kernel<0, 0, 64, 256, false>", "slot": "posemb_direct_kernel<2, ...>",
                   "big": "posemb_direct_kernel<4, ...>", "krylov": "posemb_krylov_kernel"}
 
@@ -583,9 +584,9 @@ def posemb_probe(sampler, posemb, first_id, nsteps, torch):
         items = int(t[c, 15])
         if items == 0:
             continue
-        # 100 MHz ticks of one workgroup (one-wave classes: of one wave, four of which share a workgroup; the two-wave teams of the
-        # 65..128 class: of one 128-thread workgroup, four of which share a CU -- 32 KiB of LDS and 227 registers each)
-        cu_s = float(t[c, :14].sum()) / 1e8 / (4 if name.startswith("wave") or (name == "mid" and PAIR_CLASS) else 1)
+        # 100 MHz ticks of one workgroup (one-wave classes: of one wave, four of which share a workgroup; the four-wave teams of the
+        # 65..128 class: of one 256-thread workgroup, TEAM_SHARE of which share a CU)
+        cu_s = float(t[c, :14].sum()) / 1e8 / (4 if name.startswith("wave") else TEAM_SHARE if (name == "mid" and PAIR_CLASS) else 1)
         flops = float(t[c, 14])
         out["classes"][name] = dict(items=items, cu_ms_per_item=cu_s * 1e3 / items, gflop=flops / 1e9,
                                     frac_of_cu_f32_peak=(flops / cu_s / 1e9 / F32_PER_CU_GFLOPS) if cu_s > 0 and flops > 0 else None)

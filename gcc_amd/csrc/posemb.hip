@@ -1237,7 +1237,8 @@ __device__ bool eig_top_vectors(const float *A, int lda, int nr, int na, const T
 #define GCC_POSEMB_PAIR_THREADS 256  // 128: two waves, thread = row (tridiagonalize_pair); 256: four waves, thread = half a row (tridiagonalize_quad)
 #endif
 #ifndef GCC_POSEMB_QUAD_OCC
-#define GCC_POSEMB_QUAD_OCC 4        // waves per SIMD the four-wave kernel is compiled for (4: <= 128 registers, four workgroups per CU)
+#define GCC_POSEMB_QUAD_OCC 3        // waves per SIMD the four-wave kernel is compiled for: 3 = 168 registers, three workgroups per CU (423 us per item,
+                                     // 0.827 ms per step); 4 = 128 registers with ~50 spilled values (467 us, 0.830); 2 = 208 registers (424 us, 0.837): scripts/gpu/r5_call24.sh, r5_call25.sh
 #endif
 constexpr int kPairT = GCC_POSEMB_PAIR_THREADS;
 static_assert(kPairT == 128 || kPairT == 256, "two- or four-wave teams");
@@ -1358,7 +1359,7 @@ __device__ void tridiagonalize_pair(float *A, int lda, int n, const TriLds &w, f
 
 // The same for FOUR waves: thread t owns HALF of row r = t >> 1 -- the columns of parity t & 1, 64 registers -- so that a column's
 // multiply-adds and LDS broadcasts per thread are half the two-wave version's, the two halves of a row's product meet with one lane
-// exchange, and a workgroup's four waves at <= 128 registers take the same share of a CU as the two at 227.  Rows and the p / v
+// exchange, and a workgroup's four waves at 168 registers take a third of a CU where the two at 227 took a quarter -- for 423 instead of 556 us.  Rows and the p / v
 // vectors lie in LDS de-interleaved (even columns | 16 bytes | odd columns: the two parities of a 16-lane group read different banks).
 constexpr int kQuadHalf = 68;            // floats from the even half of a row in LDS to its odd half
 template <int kNMax>

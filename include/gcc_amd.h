@@ -237,7 +237,7 @@ void gcc_posemb_set_fork(int32_t mode);
 /* diagnostics: subsequent gcc_posemb* calls add wall-clock ticks (100 MHz) per solver class and phase into
  * device int64[GCC_POSEMB_TICK_CLASSES][16] -- EIGHT classes: small, mid, slot, Krylov, big, sparse block (Chebyshev),
  * one-wave teams n' <= 48, one-wave teams n' <= 64 (their ticks are WAVE time: 4 teams share a workgroup; the 'mid' class
- * runs on two-wave workgroups of 128 threads, four of which share a CU: its ticks are the time of one such workgroup);
+ * runs on four-wave workgroups of 256 threads, three of which share a CU: its ticks are the time of one such workgroup);
  * phases of the dense classes 0..6 = matrix, tridiagonalise, bisect, inverse iteration, Gram-Schmidt, back-transform,
  * expand; [14] = executed f32 FLOPs; [15] = items; NULL switches it off.  A buffer sized for fewer classes is written
  * out of bounds. */

@@ -34,7 +34,7 @@ for c, cname in enumerate(["small", "mid", "slot", "krylov", "big", "cheb", "wav
     ph = names.get(c, names[0])
     share = 4.0 if cname.startswith("wave") else 1.0    # one-wave teams: 4 items in flight per workgroup, ticks are wave time
     if cname == "mid" and __import__("os").environ.get("GCC_POSEMB_PAIR", "1") != "0":
-        share = 4.0                                     # two-wave teams: four 128-thread workgroups share a CU (36 KiB of LDS, 227 registers)
+        share = float(__import__("os").environ.get("GCC_POSEMB_TEAM_SHARE", "3"))   # four-wave teams: three 256-thread workgroups share a CU (168 registers; 33 KiB of LDS) -- 4 for the two-wave build
     tot = t[c, :len(ph)].sum() / 100.0 / share          # us of workgroup residency
     grand += tot
     print(f"{cname:7s} items {items:5d}  total {tot/1e3:8.2f} CU-ms  per item {tot/items:8.1f} us  | " +
