@@ -57,6 +57,11 @@ if has bench; then
   (GCC_POSEMB_CHEB=7 timeout 400 python bench.py --steps 192 --warmup 64 --no-cpu-baseline 2>>$O/bench_192.err | tail -1) > $O/bench_192_steps_round4_block_solver.json; line $O/bench_192_steps_round4_block_solver.json
   (timeout 400 python bench.py --steps 192 --warmup 64 --no-cpu-baseline 2>>$O/bench_192.err | tail -1) > $O/bench_192_steps_run2.json; line $O/bench_192_steps_run2.json
   (GCC_POSEMB_PAIR=0 GCC_POSEMB_GRID_CAPS=256,64,128,64,64,96,512,128,128 timeout 400 python bench.py --steps 192 --warmup 64 --no-cpu-baseline 2>>$O/bench_192.err | tail -1) > $O/bench_192_steps_1024_thread_mid_class.json; line $O/bench_192_steps_1024_thread_mid_class.json
+  if [ -f gcc_amd/csrc/variants/lib_pair128.so ]; then   # the two-wave build of the 65..128 class (tools/build_variant.sh pair128 -DGCC_POSEMB_PAIR_THREADS=128)
+    cp gcc_amd/csrc/libgcc_amd.so /tmp/lib_default.so; cp gcc_amd/csrc/variants/lib_pair128.so gcc_amd/csrc/libgcc_amd.so
+    (timeout 400 python bench.py --steps 192 --warmup 64 --no-cpu-baseline 2>>$O/bench_192.err | tail -1) > $O/bench_192_steps_two_wave_mid_class.json; line $O/bench_192_steps_two_wave_mid_class.json
+    cp /tmp/lib_default.so gcc_amd/csrc/libgcc_amd.so
+  fi
 fi
 if has modes; then
   (timeout 400 python bench.py --steps 192 --warmup 64 --no-cpu-baseline --collectives 2>$O/bench_coll.err | tail -1) > $O/bench_192_steps_collectives.json; line $O/bench_192_steps_collectives.json
@@ -74,6 +79,11 @@ if has stats; then
 fi
 if has probes; then
   (timeout 300 python tools/posemb_phases.py 2>&1 | tail -12) > $O/posemb_phases.txt; grep -E "multi call|total|^mid|^cheb|^wave" $O/posemb_phases.txt | cut -c1-260
+  if [ -f gcc_amd/csrc/variants/lib_pair128.so ]; then
+    cp gcc_amd/csrc/libgcc_amd.so /tmp/lib_default.so; cp gcc_amd/csrc/variants/lib_pair128.so gcc_amd/csrc/libgcc_amd.so
+    (GCC_POSEMB_TEAM_SHARE=4 timeout 300 python tools/posemb_phases.py 2>&1 | tail -12) > $O/posemb_phases_two_wave_mid_class.txt; grep -E "multi call|total|^mid" $O/posemb_phases_two_wave_mid_class.txt | cut -c1-260
+    cp /tmp/lib_default.so gcc_amd/csrc/libgcc_amd.so
+  fi
   (GCC_POSEMB_PAIR=0 timeout 300 python tools/posemb_phases.py 2>&1 | tail -12) > $O/posemb_phases_1024_thread_mid_class.txt; grep -E "multi call|total|^mid" $O/posemb_phases_1024_thread_mid_class.txt | cut -c1-260
   (GCC_POSEMB_CHEB=7 timeout 300 python tools/posemb_phases.py 2>&1 | tail -12) > $O/posemb_phases_round4_block_solver.txt; grep -E "multi call|total|^cheb" $O/posemb_phases_round4_block_solver.txt | cut -c1-260
   (timeout 300 python tools/graph_probe.py --steps 200 2>&1 | tail -4) > $O/graph_probe.txt; cat $O/graph_probe.txt | cut -c1-200

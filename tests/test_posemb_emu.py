@@ -382,7 +382,7 @@ def test_leafy_large_subgraph_is_solved_exactly_by_deflation():
 
 @pytest.mark.parametrize("pair", ["1", "0"])
 def test_both_size_classes_of_the_direct_solver(pair, monkeypatch):
-    """Deflated sizes on both sides of 64: the one-wave teams and the 65..128 class -- two-wave teams with the matrix rows in registers
+    """Deflated sizes on both sides of 64: the one-wave teams and the 65..128 class -- four-wave teams with the matrix rows in registers
     (the default) or, GCC_POSEMB_PAIR=0, the 1,024-thread LDS instantiation of posemb_direct_kernel.  Both meet the strict invariants;
     their eigenvalues agree to fp32 accuracy."""
     monkeypatch.setenv("GCC_POSEMB_PAIR", pair)

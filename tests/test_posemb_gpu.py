@@ -29,7 +29,7 @@ def _device_posemb(q, B):
 
 @pytest.mark.parametrize("pair", ["1", "0"])
 def test_sampled_batch_on_g1_like_graph(pair, monkeypatch):
-    """(pair: the 65..128 class on two-wave teams -- the default -- or on the 1,024-thread LDS-resident instantiation)"""
+    """(pair: the 65..128 class on four-wave teams -- the default -- or on the 1,024-thread LDS-resident instantiation)"""
     monkeypatch.setenv("GCC_POSEMB_PAIR", pair)
     from gcc_amd.graph import DeviceGraph
     from gcc_amd.graphgen import powerlaw_graph
