@@ -69,6 +69,10 @@ def _run(pipelined, graph):
         dq, dk = _digest(out["graph_q"]), _digest(out["graph_k"])
         ints.append(torch.stack([dq[0], dk[0]]))
         flts.append(torch.stack([dq[1], dk[1]]))
+        # the digests above run on THIS stream, the step ran on the trainer's: the next step() call hands the consumed ring slots back to
+        # the producer lanes, whose "slot free" event covers the step's kernels, not these -- a refill could overtake them (seen once the
+        # eigensolver got faster: step 9's batch read as the next chunk's).  A test-side read of a ring slot has to finish first.
+        torch.cuda.synchronize()
     torch.cuda.synchronize()
     flags = tr.check_status(strict_posemb=True)
     assert flags == 0
