@@ -352,7 +352,6 @@ static_assert(kNumCls == GCC_POSEMB_TICK_CLASSES, "include/gcc_amd.h: tick buffe
 struct PosHead {                     // head of the caller's workspace (zeroed per call)
     int32_t *count;                  // [4] items per class
     int32_t *next;                   // [4] work counters
-    int32_t *ends;                   // [0] / [1]: block-class items appended at the front (the long ones) / at the back of its list
     int32_t *list;                   // [4][T] item ids, T = views * B
     float *slots;                    // [workgroups of the slot class][slot_floats]: matrix (kGMax x kGMax) + deflation tables
     float *bslots;                   // [workgroups of the big class][bslot_floats]: matrix (kBMax x kBMax) + deflation tables
@@ -1848,7 +1847,6 @@ __device__ __forceinline__ bool wave_eig_top_vectors(const float *A, int lda, in
     return lost > 0 || es.bad != 0;
 }
 
-constexpr int kChLongFirst = 384;     // block-class items with more deflated nodes than this are taken first
 // one wave per subgraph: deflated size -> class list; k <= 0 subgraphs are finished here (zeros, data_util.py:243-244)
 constexpr int kClsThreads = 256;
 __global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m, PosHead hd)
@@ -1868,7 +1866,7 @@ __global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m
         if (a.evals) for (int i = lane; i < a.hidden; i += 64) a.evals[(int64_t)b * a.hidden + i] = 0.f;
         return;
     }
-    int cls = kClsKrylov, reduced_size = n;
+    int cls = kClsKrylov;
     if (n <= kNodeMax) {
         const int32_t *rp = a.row_ptr + n0;
         int32_t *t = tc[wv];
@@ -1892,7 +1890,6 @@ __global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m
         }
         for (int dd = 32; dd >= 1; dd >>= 1) zz += wave_shfl_xor(zz, dd);
         const int nr = n - zz;                         // t >= 2 leaves of one parent count once, s >= 2 stalks of one hub as one stalk
-        reduced_size = nr;
         cls = (hd.use_wave && nr <= 64 && n <= kWaveNodes) ? (nr <= 48 ? kClsW48 : kClsW64)
             : nr <= kJSmall ? kClsSmall : nr <= kJMax ? kClsMid : hd.use_cheb ? kClsCheb : nr <= kGMax ? kClsSlot : nr <= kBMax ? kClsBig : kClsKrylov;
     }
@@ -1902,19 +1899,7 @@ __global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m
         if (lane == 0) atomicOr(a.status, (int32_t)GCC_STATUS_POSEMB_TOO_LARGE);
         return;
     }
-    if (lane == 0) {
-        if (cls == kClsCheb) {
-            // longest first: the block class's items differ by a factor of ten in time (0.5 .. 5 ms) and a launch has about as many
-            // workgroups as items -- a long item taken last is a launch that lasts its whole time longer.  Items over kChLongFirst
-            // deflated nodes go to the front of the list, the others fill it from the back; workgroups take the front first.
-            const bool big = reduced_size > kChLongFirst;
-            const int at = atomicAdd(hd.ends + (big ? 0 : 1), 1);
-            hd.list[(int64_t)cls * hd.T + (big ? at : hd.T - 1 - at)] = item;
-            atomicAdd(hd.count + cls, 1);
-        } else {
-            hd.list[(int64_t)cls * hd.T + atomicAdd(hd.count + cls, 1)] = item;
-        }
-    }
+    if (lane == 0) hd.list[(int64_t)cls * hd.T + atomicAdd(hd.count + cls, 1)] = item;
 }
 
 template <int kCls, int kNMin, int kNMax, int kT, bool kGlobalA, bool kPair = false>
@@ -2741,8 +2726,7 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
     if (tid == 0) sh_item = atomicAdd(hd.next + kCls, 1);
     __syncthreads();
     if (sh_item >= hd.count[kCls]) return;
-    const int nfront = hd.ends[0];                           // (final: the classify kernel has finished)
-    const int gb = hd.list[(int64_t)kCls * hd.T + (sh_item < nfront ? sh_item : hd.T - 1 - (sh_item - nfront))];
+    const int gb = hd.list[(int64_t)kCls * hd.T + sh_item];
     PosArgs a;
     int b;
     item_args(m, gb, a, b);
@@ -3622,7 +3606,7 @@ static PosGrids posemb_grids_for_sizing(int64_t T)
     a.pair = a.pair > b.pair ? a.pair : b.pair;
     return a;
 }
-static int64_t posemb_head_bytes(int64_t T) { return ((32 + kNumCls * T) * 4 + 255) / 256 * 256; }
+static int64_t posemb_head_bytes(int64_t T) { return ((16 + kNumCls * T) * 4 + 255) / 256 * 256; }
 static int64_t posemb_slot_floats(void) { return (int64_t)kGMax * kGMax + (int64_t)kNodeMax * 4; }
 static int64_t posemb_bslot_floats(void) { return (int64_t)kBMax * kBMax + (int64_t)kNodeMax * 4; }
 static int64_t posemb_ldv(int32_t batch_size, int64_t node_cap) { return ((node_cap / batch_size + 63) / 64) * 64 + 64; }
@@ -3717,8 +3701,7 @@ int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, 
     PosHead hd;
     hd.count = (int32_t *)workspace;
     hd.next = hd.count + 8;
-    hd.ends = hd.count + 16;
-    hd.list = hd.count + 32;
+    hd.list = hd.count + 16;
     hd.slots = (float *)((char *)workspace + posemb_head_bytes(T));
     hd.bslots = hd.slots + gs.slot * posemb_slot_floats();
     hd.bslot_floats = posemb_bslot_floats();
@@ -3762,7 +3745,7 @@ int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, 
     }
 #endif
     prof_mark(prof, 0, s);
-    (void)hipMemsetAsync(workspace, 0, 128, s);      // class counts + work counters + the block class's two list ends
+    (void)hipMemsetAsync(workspace, 0, 64, s);       // class counts + work counters
     hipLaunchKernelGGL(posemb_classify_kernel, dim3((unsigned)((T + 3) / 4)), dim3(kClsThreads), 0, s, m, hd);
     KryArgs ka;
     ka.m = m;
