@@ -364,7 +364,7 @@ struct PosHead {                     // head of the caller's workspace (zeroed p
     int32_t use_wave;                // deflated sizes <= 64 go to the one-wave teams
     int32_t use_stalks;              // pendant two-paths of a hub are deflated too (GCC_POSEMB_STALKS, default 1)
     int64_t slot_floats;
-    float *pslots;                   // [workgroups of the two-wave 65..128 class][kPairSlotFloats]: matrix / reflectors + expansion records
+    float *pslots;                   // [workgroups of the register-resident 65..128 class (two / four waves)][kPairSlotFloats]: matrix / reflectors + expansion records
     int32_t use_pair;
 };
 
@@ -714,7 +714,7 @@ __device__ bool inverse_iteration_step(const TriLds &w, int n, int j, int jl, fl
     // back substitution, the next row's operands requested ahead in the same way
     float d = cd, us = 0.f, s2 = 0.f, yi = cy;               // row n - 1
     if constexpr (kDeep) {
-        // the factors live in the workspace (two-wave teams): a row's operands come from L2, so they are requested FOUR rows (one
+        // the factors live in the workspace (two- / four-wave teams): a row's operands come from L2, so they are requested FOUR rows (one
         // chunk) ahead; same arithmetic in the same order
         float dq[4], uq[4];
         uint8_t fq[4];
@@ -1906,7 +1906,7 @@ template <int kCls, int kNMin, int kNMax, int kT, bool kGlobalA, bool kPair = fa
 __global__ __launch_bounds__(kT, kPair ? (kT == 256 ? GCC_POSEMB_QUAD_OCC : 2) : 1) void posemb_direct_kernel(PosMulti m, PosHead hd)
 {
     static_assert(kNMax % 64 == 0 && kT % 64 == 0 && kT >= 64, "size class");
-    static_assert(!kPair || (kGlobalA && kT == kPairT && kNMax == 128), "two-wave teams: the matrix and the reflectors live in the workspace");
+    static_assert(!kPair || (kGlobalA && kT == kPairT && kNMax == 128), "two- / four-wave teams: the matrix and the reflectors live in the workspace");
     DYN_SMEM(smem);
     __shared__ EigShared es;
     __shared__ int colsrc[64];                  // per output column: eigenvector j >= 0, or -(c + 1) for contrast c
@@ -3720,7 +3720,7 @@ int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, 
         const char *ep = getenv("GCC_POSEMB_PAIR");    // 0: the 65..128 class on 1,024-thread workgroups with the matrix in LDS (A/B runs)
         hd.use_pair = ep ? atoi(ep) != 0 : 1;
     }
-    {   // the two-wave class's slots: the tail of the workspace
+    {   // the register-resident class's slots: the tail of the workspace
         char *end = (char *)workspace + need;
         hd.pslots = (float *)(((uintptr_t)(end - (int64_t)gs.pair * kPairSlotFloats * (int64_t)sizeof(float))) & ~(uintptr_t)255);
     }
@@ -3763,7 +3763,7 @@ int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, 
         kry_lds_opt_in = lds_kry;
     }
 #endif
-    // the light classes (one-wave teams, the 256-thread small class) and the two-wave 65..128 class on the side streams, the block class and
+    // the light classes (one-wave teams, the 256-thread small class) and the four-wave 65..128 class on the side streams, the block class and
     // what it may hand items on to on the caller's stream, behind the caller's gate (see gcc_posemb_multi_gated in the header)
     hipStream_t s1 = s, s2 = s;
 #ifndef GCC_AMD_HIPEMU
