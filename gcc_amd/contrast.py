@@ -281,6 +281,9 @@ class MemoryMoCo(nn.Module):
         # up to 64: the fused head of csrc/nce.hip (narrower than 64: zero-padded, exactly); above: the dense any-size head of
         # csrc/ginx.hip (--hidden-size above 64, train.py:93,627-629)
         self.wide = inputSize > D
+        if self.wide and nce_dtype != "f32":
+            raise NotImplementedError(f"nce_dtype={nce_dtype!r} is the 64-channel head's throughput mode (csrc/nce.hip); the any-size head "
+                                      f"(feature size {inputSize} > {D}) computes in f32 -- drop --nce-dtype or use --hidden-size <= {D}")
         if not use_softmax:
             raise NotImplementedError("train.py:628 always passes use_softmax=True (the exp/Z branch is dead)")
         self.outputSize = outputSize

@@ -578,8 +578,6 @@ int32_t gcc_ginx_backward(const gcc_ginx_pass *p, const float *dfeat, const gcc_
     hipLaunchKernelGGL(ginx_pool_bwd_kernel, dim3(blocks(N * W)), dim3(256), 0, s, p->node_off, p->graph_id, B, ws + x.dpool, W, dA, 0);
     for (int l = L - 1; l >= 0; --l) {
         const int Din = l == 0 ? d_in : W;
-        const float *hin = l == 0 ? ws + x.x0 : ws + x.h[l - 1];
-        (void)hin;
         bn_bwd(ws + x.a2[l], ws + x.h[l], dA, w.bn_c[l], x.mr[l][2], dB_, gr->bn_c_w[l], gr->bn_c_b[l]);                  // -> d a2
         bn_bwd(ws + x.z2[l], ws + x.a2[l], dB_, w.bn_b[l], x.mr[l][1], dA, gr->bn_b_w[l], gr->bn_b_b[l]);                 // -> d z2
         gemm(s, dA, 1, W, ws + x.a1[l], W, 1, gr->lin1_w[l], W, W, W, 0, nullptr, rows, 2, N, 1.0f, wg64);                            // dW1 [W, W] = dz2^T a1

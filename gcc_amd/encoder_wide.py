@@ -21,6 +21,7 @@ class WideGinEngine:
         self.lib = lib if lib is not None else _cabi.load()
         self.ptr = ptr if ptr is not None else _cabi.dev_ptr
         self._ws = {}
+        self._gen = {}                      # workspace key -> generation: a forward stamps its slot, a backward checks the stamp
 
     def make_pass(self, enc, g, training, keep=None, slot=0, want_pooled=False):
         from .encoder import fill_weights
@@ -39,6 +40,7 @@ class WideGinEngine:
                                  feat=torch.zeros(B, enc.output_dim, dtype=torch.float32, device=dev),
                                  pooled=torch.zeros(L, B, enc.hidden, dtype=torch.float32, device=dev))
         buf = self._ws[key]
+        self._gen[key] = self._gen.get(key, 0) + 1
         if g.pos_undirected is None:
             raise RuntimeError("the batch has no pos_undirected (run the positional embedding first)")
         p = _cabi.GccGinxPass()
@@ -57,12 +59,18 @@ class WideGinEngine:
         p.pooled_out = ptr(buf["pooled"]) if want_pooled else None
         out = dict(buf)
         out["_keepalive"] = (g, keep, enc)          # the struct holds raw pointers into these
+        out["_slot"] = (key, self._gen[key])        # which workspace this pass's activations live in, and its generation
         return p, out
 
     def forward(self, p, stream=None):
         rc = self.lib.gcc_ginx_forward(ctypes.byref(p), stream)
         if rc != 0:
             raise RuntimeError(f"gcc_ginx_forward failed ({rc}): {self.lib.gcc_last_error().decode()}")
+
+    def slot_is_current(self, buf):
+        """False once a later forward has reused the workspace slot this pass's activations were stored in."""
+        key, gen = buf["_slot"]
+        return self._gen.get(key) == gen
 
     def backward(self, enc, p, dfeat, targets, stream=None):
         from .encoder import grad_params
@@ -106,6 +114,12 @@ class _GinxFn(torch.autograd.Function):
         enc = ctx.enc
         if not ctx.p.training:
             raise RuntimeError("backward through an eval-mode (running statistics) pass is not supported")
+        if not enc.wide_engine().slot_is_current(ctx.buf):
+            # the activations of a pending backward live in one of two workspace slots per encoder (model(q), model(k) of an
+            # E2E step); a third forward before this backward has overwritten them -- gradients from the wrong activations
+            # would be silent
+            raise RuntimeError("backward of a GraphEncoder forward whose activations were overwritten: at most two forward passes "
+                               "of one wide encoder may be pending a backward (run backward, or wrap the extra passes in torch.no_grad())")
         targets = [torch.zeros_like(param) for _, _, param in grad_params(enc)]
         enc.wide_engine().backward(enc, ctx.p, dfeat, targets, stream=_stream(dfeat))
         return (None, None, None, None, *targets)

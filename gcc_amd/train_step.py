@@ -259,6 +259,16 @@ class BatchProducer:
                 self.released[c] = ev
 
 
+_CAPTURE_ERROR_MARKS = ("capture", "hipErrorStreamCapture", "cudaErrorStreamCapture", "operation not permitted when stream is capturing",
+                        "operation failed due to a previous error during capture")
+
+
+def _is_capture_error(e):
+    """an invalidated / unsupported stream capture (HIP: hipErrorStreamCapture*), as opposed to a failure of the captured body"""
+    msg = str(e)
+    return any(m in msg for m in _CAPTURE_ERROR_MARKS)
+
+
 def _meter_buffers(dev):
     """(acc double[5]: sums of loss, prob, gnorm, nodes(q + k), steps; mx int32[2]: max nodes / edges of a q view)
     -- gcc_step_meters adds one step; :func:`read_meters` reads and zeroes them when a log line is due."""
@@ -461,6 +471,10 @@ class _GraphedStep:
                 items.append(gobj)
             cap = result()
         except RuntimeError as e:
+            if not _is_capture_error(e):
+                # a real failure inside the body (a C-ABI call's rc != 0, a shape or allocation error): not something a later
+                # eager step would cure -- a silent fall-back would degrade a multi-hour run to the launch-by-launch path
+                raise
             # A capture that the runtime invalidated (seen once in ~10 runs of the collectives path on ROCm 7.0: "operation failed
             # due to a previous error during capture", with RCCL's threads busy beside the capturing one).  Nothing executed and
             # nothing is lost: the slot stays uncaptured, its next step is issued launch by launch and captured again afterwards.
@@ -472,7 +486,10 @@ class _GraphedStep:
                 warnings.warn(f"step graph capture failed {self.graph_capture_failures} times ({e}); graph replay is switched off")
             else:
                 warnings.warn(f"step graph capture failed ({e}); the slot stays eager")
-            torch.cuda.synchronize(self.dev)
+            try:
+                torch.cuda.synchronize(self.dev)
+            except RuntimeError:                                         # (a stream left in capture by a failed capture_end)
+                pass
             return False
         finally:
             self.optimizer.steps = steps0                                # the captured body counted a step that did not run
@@ -631,7 +648,13 @@ class MoCoTrainStep(_GraphedStep):
 
     # ---- one step
     def step(self, step, lr, prof=None):
-        """``prof``: optional dict of gcc_amd.prof.Prof (sampler: 4 marks; gin_fwd/nce_fwd/nce_bwd/gin_bwd: 2)."""
+        """``prof``: optional dict of gcc_amd.prof.Prof (sampler: 4 marks; gin_fwd/nce_fwd/nce_bwd/gin_bwd: 2).
+
+        Lifetime of the returned batches: ``graph_q`` / ``graph_k`` are RING SLOTS of the producer lanes.  The slot is handed
+        back to its lane by an event recorded on the step's stream at the end of this step, i.e. before anything the caller
+        enqueues afterwards: a lane may refill the slot ``ahead`` chunks later while caller-stream kernels still read it.  Read
+        them on the step's stream (``with torch.cuda.stream(trainer.main)``), copy what must outlive the next
+        ``producer.ahead`` steps, or synchronise before the next ``step()`` (tests/test_pipeline_gpu.py does the last)."""
         if self.main is None:
             return self._step(step, lr, prof)
         caller = torch.cuda.current_stream(self.dev)

@@ -76,20 +76,23 @@ def test_wide_encoder_and_head_on_the_device_vs_oracle(hidden, B, hops, monkeypa
     out64, _ = E.moco_forward(mem0.double(), 0, f64, rk.double(), 0.07)
     E.nce_softmax_loss(out64).backward()
     ref64, ref32 = dict(o64.named_parameters()), dict(om.named_parameters())
-    worst, worst32 = 0.0, 0.0
+    worst, worst32, table = 0.0, 0.0, []
     for name, p in model.named_parameters():
         if ref64[name].grad is None:
             assert p.grad is None or float(p.grad.abs().sum()) == 0.0, name
             continue
         g64 = ref64[name].grad.float()
         scale = max(float(g64.abs().max()), 1e-3)
-        # the bar: 1e-3 of the tensor's largest entry, or -- where fp32 itself cannot do that (sums of ~10^4 cancelling terms at width 256)
-        # -- three times what torch's own fp32 pass of the same model is off by against float64
+        # the bar: north_star's 1e-3 of the tensor's largest entry, against the float64 run, no allowance for fp32 (round 5 accepted three
+        # times torch's own fp32 error; with the weight gradients' slabs added up in fp64 the device sits where torch's fp32 pass sits:
+        # 5e-4 .. 7e-4 at both widths, the two within 1e-6 of EACH OTHER -- profiles/r6_wide_gradient_errors.txt)
         err32 = float((ref32[name].grad - g64).abs().max())
-        torch.testing.assert_close(p.grad.cpu(), g64, rtol=2e-3, atol=max(1e-3 * scale, 3.0 * err32, 1e-4 if name.endswith("bias") else 5e-6),
-                                   msg=lambda m, name=name: f"{name} vs float64 oracle: {m}")
+        torch.testing.assert_close(p.grad.cpu(), g64, rtol=0, atol=1e-3 * scale, msg=lambda m, name=name: f"{name} vs float64 oracle: {m}")
         worst = max(worst, float((p.grad.cpu() - g64).abs().max()) / scale)
         worst32 = max(worst32, float((ref32[name].grad - g64).abs().max()) / scale)
+        table.append((float((p.grad.cpu() - g64).abs().max()) / scale, err32 / scale, name))
+    for dev_err, o32, name in sorted(table, reverse=True)[:8]:
+        print(f"   {name:60s} device {dev_err:.2e}   fp32 oracle {o32:.2e}   (of the tensor's largest entry, vs float64)")
     print(f"hidden {hidden}: {int(aq[0][-1])} nodes, loss {float(loss):.5f} (oracle {float(rloss):.5f}), worst gradient error / scale vs float64: "
           f"device {worst:.2e}, fp32 oracle {worst32:.2e}")
 

@@ -338,7 +338,7 @@ def main(args):
 
     posemb = None                                         # API path only; the fused steps embed in their producer lanes
     trainer, optimizer = None, None
-    wide = args.hidden_size > 64          # above 64 channels: the any-width kernels (csrc/ginx.hip) through the API path below
+    wide = model.wide or contrast.wide    # above 64 channels (or a wider input): the any-width kernels (csrc/ginx.hip) through the API path below
     if wide and world > 1:
         raise NotImplementedError("--hidden-size above 64 runs the single-GPU API path; the data-parallel step is the fused 64-channel one")
     if args.optimizer == "adam" and not wide:
