@@ -111,6 +111,8 @@ class GccGinPass(ctypes.Structure):
         ("bn_totals", _VP),
         ("seed_local", _VP),
         ("scalars", _VP),
+        ("node_cap", ctypes.c_int64),
+        ("rows_hint", ctypes.c_int64),
     ]
 
 
@@ -169,7 +171,7 @@ class GccGinwArgs(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 2          # GCC_AMD_ABI_VERSION of the include/gcc_amd.h these structs mirror (checked in load())
+ABI_VERSION = 3          # GCC_AMD_ABI_VERSION of the include/gcc_amd.h these structs mirror (checked in load())
 GRAPH_CONTRACT_CHECKED = 1   # gcc_graph.flags
 
 # name -> (restype, argtypes); the single source of truth for the symbol test

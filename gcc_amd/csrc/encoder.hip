@@ -40,6 +40,7 @@ struct FeatArgs {
     float4 *zero_a, *zero_b;     // two regions to clear, in 16-byte units
     int64_t zero_a16, zero_b16;
     int32_t B, pos_dim, emb_dim, max_degree, mult;
+    int32_t cap;                 // gcc_gin_pass.node_cap
 };
 struct FeatLaunch { FeatArgs p[kMaxPass]; };
 
@@ -48,7 +49,28 @@ __global__ __launch_bounds__(kThreads) void gin_feat_kernel(FeatLaunch L)
     TRAIN_STEP_WAVE_PRIORITY();
     const FeatArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
+    constexpr int kR = kTile / 16;
+    // the lane group's 4 rows in two round trips: (1) row extents, graph ids and the positional columns -- requested for the
+    // workgroup's first tile TOGETHER with the node count (addresses clamped to the capacity, rows >= N dropped below) --, then
+    // (2) everything that depends on them; every load unconditional: one row at a time this was 3 dependent round trips per row
+    int vv[kR], r0[kR], r1[kR], gv[kR];
+    float pv[kR][4];
+    auto request = [&](int tile0) {
+#pragma unroll
+        for (int i = 0; i < kR; ++i) {
+            vv[i] = cap_row(tile0 + gi + 16 * i, a.cap);
+            r0[i] = a.row_ptr[vv[i]];
+            r1[i] = a.row_ptr[vv[i] + 1];
+            gv[i] = a.graph_id[vv[i]];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)                                       // (block-uniform condition)
+                pv[i][e] = a.pos_dim > 0 ? a.pos[(int64_t)vv[i] * a.pos_dim + min(4 * t + e, a.pos_dim - 1)] : 0.f;
+        }
+    };
+    const int tf = first_tile();
+    request(tf * kTile);
     const int N = a.node_off[a.B];
+    SCHED_FENCE();
     {
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         const int64_t stride = (int64_t)gridDim.x * kThreads;
@@ -58,32 +80,21 @@ __global__ __launch_bounds__(kThreads) void gin_feat_kernel(FeatLaunch L)
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
         const int tile0 = tw.ti * kTile;
         const int nrows = min(kTile, N - tile0);
-        // the lane group's 4 rows in two round trips (row extents and graph ids; then everything that depends on them),
-        // every load unconditional with a clamped address: one row at a time this was 3 dependent round trips per row
-        constexpr int kR = kTile / 16;
-        int vv[kR], r0[kR], r1[kR], gv[kR];
-#pragma unroll
-        for (int i = 0; i < kR; ++i) {
-            vv[i] = min(tile0 + gi + 16 * i, N - 1);
-            r0[i] = a.row_ptr[vv[i]];
-            r1[i] = a.row_ptr[vv[i] + 1];
-            gv[i] = a.graph_id[vv[i]];
-        }
+        if (tw.ti != tf) request(tile0);
         int first[kR], sl[kR];
-        float val[kR][4];
+        float ev[kR][4];
         const int dtot = a.pos_dim + a.emb_dim;
 #pragma unroll
         for (int i = 0; i < kR; ++i) {
             const int deg = (r1[i] - r0[i]) * a.mult;                         // g.in_degrees(), :154
-            const int dcl = deg < a.max_degree ? deg : a.max_degree;          // clamp(0, max_degree), :161
-            first[i] = a.node_off[gv[i]];
-            sl[i] = a.seed_local ? a.seed_local[gv[i]] : 0;                   // (block-uniform branch)
+            const int dcl = max(0, deg < a.max_degree ? deg : a.max_degree);  // clamp(0, max_degree), :161 (rows >= N hold anything)
+            const int g = min(max(gv[i], 0), a.B - 1);
+            first[i] = a.node_off[g];
+            sl[i] = a.seed_local ? a.seed_local[g] : 0;                       // (block-uniform branch)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = 4 * t + e;
-                const float *src = c < a.pos_dim ? a.pos + (int64_t)vv[i] * a.pos_dim + c
-                                                 : a.emb + (int64_t)dcl * a.emb_dim + (c < dtot ? c - a.pos_dim : 0);
-                val[i][e] = *src;
+                ev[i][e] = a.emb[(int64_t)dcl * a.emb_dim + (c >= a.pos_dim && c < dtot ? c - a.pos_dim : 0)];
             }
         }
 #pragma unroll
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(kThreads) void gin_feat_kernel(FeatLaunch L)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = 4 * t + e;
-                at(x, e) = c < dtot ? val[i][e] : (c == dtot && is_seed ? 1.f : 0.f);
+                at(x, e) = c < a.pos_dim ? pv[i][e] : c < dtot ? ev[i][e] : (c == dtot && is_seed ? 1.f : 0.f);
             }
             st4(a.x0 + (int64_t)vv[i] * H + 4 * t, x);
         }
@@ -114,6 +125,7 @@ struct InArgs {
     double *pooled;           // SumPooling of this layer's input h (hidden_rep[layer], gin.py:216,228)
     int32_t B, first, kdim, training;
     float eps, nbr_weight;    // nbr_weight: edge multiplicity
+    int32_t cap;              // gcc_gin_pass.node_cap
 };
 struct InLaunch { InArgs p[kMaxPass]; long long *ticks; };
 #ifndef GIN_IN_LDS_W
@@ -150,6 +162,21 @@ __global__ __launch_bounds__(kThreads, GIN_IN_PER_CU) void gin_in_kernel(InLaunc
 #endif
     Aff4 ab, ac;
     long long tick_ = L.ticks ? device_ticks() : 0;
+    const float *src = a.src;
+    auto load = [&](int u) -> F4 { return ld4(src + (int64_t)u * H + 4 * t); };
+    // The first tile's own rows, row pointers and graph ids are requested HERE, with the weights, the statistics and the node
+    // count: one round trip (they were a second one, after the node count; addresses clamped to the capacity, rows >= N are
+    // dropped when the tile is stored).  (all requested together and stored afterwards: a load under `if (tid < ...)` next to
+    // its LDS store is a round trip of its own)
+    const int tf = first_tile();
+    int rp_own, gid_own;
+    F4 own[kTile / 16];                           // the 4 rows of this lane group
+    auto request = [&](int tile0) {
+        rp_own = a.row_ptr[min(tile0 + min(tid, kTile), a.cap)];
+        gid_own = a.graph_id[cap_row(tile0 + (tid & (kTile - 1)), a.cap)];
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i) own[i] = load(cap_row(tile0 + gi + 16 * i, a.cap));
+    };
     {
 #if GIN_IN_LDS_W
         const WStage wst = stage_weights_request(a.w0, a.kdim);     // in flight with N and the statistics
@@ -157,12 +184,14 @@ __global__ __launch_bounds__(kThreads, GIN_IN_PER_CU) void gin_in_kernel(InLaunc
 #endif
         if (!a.first) {                            // block-uniform
             const BnReq rb = bn_request(a.bnb), rc = bn_request(a.bnc);
+            request(tf * kTile);
             N = a.node_off[a.B];                   // (requested after the statistics: the wait for it is the wait for all)
             SCHED_FENCE();
             if (no_tiles(N)) return;
             bn_table_finish(tabb, rb, (double)N, a.eps, a.training, (double *)part);
             bn_table_finish(tabc, rc, (double)N, a.eps, a.training, (double *)part);
         } else {
+            request(tf * kTile);
             N = ((const volatile int32_t *)a.node_off)[a.B];       // (volatile: an ordinary load is hoisted above the branch, ahead of the other arm's requests)
             if (no_tiles(N)) return;
         }
@@ -176,9 +205,7 @@ __global__ __launch_bounds__(kThreads, GIN_IN_PER_CU) void gin_in_kernel(InLaunc
         ab = aff4_from_table(tabb, 4 * t);
         ac = aff4_from_table(tabc, 4 * t);
     }
-    const float *src = a.src;
     const bool first = a.first != 0;              // (block-uniform; the launch has one layer)
-    auto load = [&](int u) -> F4 { return ld4(src + (int64_t)u * H + 4 * t); };
     auto xform = [&](F4 x) -> F4 { return first ? x : affine_relu(affine_relu(x, ab), ac); };   // h = relu(bn_c(relu(bn_b(z2))))  gin.py:56-57,219-220
     GIN_TICK(0);                                  // BatchNorm tables
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
@@ -188,13 +215,7 @@ __global__ __launch_bounds__(kThreads, GIN_IN_PER_CU) void gin_in_kernel(InLaunc
         // 1. own rows; the tile's row pointers and graph ids ride in the same round trip (the pooling and the gather
         //    would otherwise each start with one of their own)
         {
-            // (all requested together and stored afterwards: a load under `if (tid < ...)` next to its LDS store is a
-            // round trip of its own)
-            const int rp_own = a.row_ptr[tile0 + min(tid, nrows)];
-            const int gid_own = a.graph_id[min(tile0 + (tid & (kTile - 1)), N - 1)];
-            F4 own[kTile / 16];                   // the 4 rows of this lane group: requested together, transformed afterwards
-#pragma unroll
-            for (int i = 0; i < kTile / 16; ++i) own[i] = load(min(tile0 + gi + 16 * i, N - 1));
+            if (tw.ti != tf) request(tile0);      // (a launch with more tiles than workgroups)
             if (tid <= nrows) rpl[tid] = rp_own;
             if (tid >= 128 && tid - 128 < nrows) gidl[tid - 128] = gid_own;
 #pragma unroll
@@ -206,15 +227,19 @@ __global__ __launch_bounds__(kThreads, GIN_IN_PER_CU) void gin_in_kernel(InLaunc
         }
         __syncthreads();
         GIN_TICK(1);
-        // 2. SumPooling of hidden_rep[layer] (gin.py:228)
-#if !(GIN_DBG_SKIP & 1)
-        if (a.pooled) pool_tile(T, nrows, a.pooled, gidl);
-#endif
-        lds_barrier();                             // (the pooling atomics stay in flight)
-        GIN_TICK(2);
+        // 2. SumPooling of hidden_rep[layer] (gin.py:228): inside the gather, behind its first request of neighbour ids
         // 3. GINConv aggregate: (1 + eps) * h_v + sum_{u -> v} h_u, eps = 0 (gin.py:179-185,218)
+        auto pooling = [&] {
+#if !(GIN_DBG_SKIP & 1)
+            if (a.pooled) pool_tile(T, nrows, a.pooled, gidl);
+#endif
+            lds_barrier();                         // (the pooling atomics stay in flight)
+            GIN_TICK(2);
+        };
 #if !(GIN_DBG_SKIP & 4)
-        gather_tile<GIN_GATHER_J>(T, part, prow, nrows, a.col_idx, load, xform, a.nbr_weight, rpl);
+        gather_tile<GIN_GATHER_J>(T, part, prow, nrows, a.col_idx, load, xform, a.nbr_weight, rpl, pooling);
+#else
+        pooling();
 #endif
         GIN_TICK(3);
         // 4. keep agg for the weight gradient of linears.0
@@ -255,6 +280,7 @@ struct MidArgs {
     int32_t B, training;
     float eps;
     int32_t hid;              // columns of w1 (gcc_gin_weights.hidden: the true hidden width, <= 64)
+    int32_t cap;              // gcc_gin_pass.node_cap
 };
 struct MidLaunch { MidArgs p[kMaxPass]; };
 
@@ -270,6 +296,15 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
     __shared__ __attribute__((aligned(16))) float bl[H];     // linears.1's bias
     const float b_own = a.b1 ? a.b1[tid & (H - 1)] : 0.f;
     const BnReq ra = bn_request(a.bna);
+    // the first tile's row of z1 rides in the same round trip (clamped to the capacity; rows >= N are zeroed below)
+    const int tf = first_tile();
+    F4 xb[4];
+    auto request = [&](int tile0) {
+        const float *zrow = a.z1 + (int64_t)cap_row(tile0 + 16 * wv + j, a.cap) * H;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xb[c] = ld4(zrow + 16 * c + 4 * q);
+    };
+    request(tf * kTile);
     const int N = a.node_off[a.B];                           // (requested last: the wait for it is the wait for all)
     SCHED_FENCE();
     if (no_tiles(N)) return;
@@ -284,10 +319,7 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
         const int tile0 = tw.ti * kTile;
         const int row = tile0 + 16 * wv + j;
         const bool valid = row < N;
-        F4 xb[4];
-        const float *zrow = a.z1 + (int64_t)(valid ? row : 0) * H;      // (unconditional loads, all four requested at once)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) xb[c] = ld4(zrow + 16 * c + 4 * q);
+        if (tw.ti != tf) request(tile0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const F4 z = {0.f, 0.f, 0.f, 0.f};
@@ -309,6 +341,7 @@ struct StatArgs {
     double *stats_c;
     int32_t B, training;
     float eps;
+    int32_t cap;              // gcc_gin_pass.node_cap
 };
 struct StatLaunch { StatArgs p[kMaxPass]; };
 
@@ -320,6 +353,14 @@ __global__ __launch_bounds__(kThreads) void gin_stat_kernel(StatLaunch L)
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
     __shared__ float tabb[2 * H];
     const BnReq rb = bn_request(a.bnb);
+    // the first tile's rows of z2 ride in the same round trip (clamped to the capacity; rows >= N are skipped below)
+    const int tf = first_tile();
+    F4 z4[kTile / 16];                               // the lane group's 4 rows, requested together
+    auto request = [&](int tile0) {
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i) z4[i] = ld4(a.z2 + (int64_t)cap_row(tile0 + gi + 16 * i, a.cap) * H + 4 * t);
+    };
+    request(tf * kTile);
     const int N = a.node_off[a.B];                           // (requested last: the wait for it is the wait for all)
     SCHED_FENCE();
     if (no_tiles(N)) return;
@@ -330,9 +371,7 @@ __global__ __launch_bounds__(kThreads) void gin_stat_kernel(StatLaunch L)
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
         const int tile0 = tw.ti * kTile;
         any = true;
-        F4 z4[kTile / 16];                           // the lane group's 4 rows, requested together
-#pragma unroll
-        for (int i = 0; i < kTile / 16; ++i) z4[i] = ld4(a.z2 + (int64_t)min(tile0 + gi + 16 * i, N - 1) * H + 4 * t);
+        if (tw.ti != tf) request(tile0);
 #pragma unroll
         for (int i = 0; i < kTile / 16; ++i) {
             if (tile0 + gi + 16 * i < N) {
@@ -366,6 +405,7 @@ struct PoolArgs {
     double *pooled;
     int32_t B, training;
     float eps;
+    int32_t cap;              // gcc_gin_pass.node_cap
 };
 struct PoolLaunch { PoolArgs p[kMaxPass]; };
 
@@ -378,6 +418,16 @@ __global__ __launch_bounds__(kThreads) void gin_pool_kernel(PoolLaunch L)
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
     __shared__ float tabb[2 * H], tabc[2 * H];
     const BnReq rb = bn_request(a.bnb), rc = bn_request(a.bnc);
+    // the first tile's rows and graph ids ride in the same round trip (clamped to the capacity; rows >= N are dropped below)
+    const int tf = first_tile();
+    F4 z4[kTile / 16];
+    int gid_own;
+    auto request = [&](int tile0) {
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i) z4[i] = ld4(a.z2 + (int64_t)cap_row(tile0 + gi + 16 * i, a.cap) * H + 4 * t);
+        gid_own = a.graph_id[cap_row(tile0 + (tid & (kTile - 1)), a.cap)];
+    };
+    request(tf * kTile);
     const int N = a.node_off[a.B];                           // (requested last: the wait for it is the wait for all)
     SCHED_FENCE();
     if (no_tiles(N)) return;
@@ -388,14 +438,13 @@ __global__ __launch_bounds__(kThreads) void gin_pool_kernel(PoolLaunch L)
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
         const int tile0 = tw.ti * kTile;
         const int nrows = min(kTile, N - tile0);
-        F4 z4[kTile / 16];                           // the lane group's 4 rows and the tile's graph ids, requested together
-#pragma unroll
-        for (int i = 0; i < kTile / 16; ++i) z4[i] = ld4(a.z2 + (int64_t)min(tile0 + gi + 16 * i, N - 1) * H + 4 * t);
-        const int gid_own = a.graph_id[min(tile0 + (tid & (kTile - 1)), N - 1)];
+        if (tw.ti != tf) request(tile0);
         if (tid < nrows) gidl[tid] = gid_own;
 #pragma unroll
-        for (int i = 0; i < kTile / 16; ++i)
-            if (gi + 16 * i < nrows) st4(&T[(gi + 16 * i) * kLdt + 4 * t], affine_relu(affine_relu(z4[i], ab), ac));
+        for (int i = 0; i < kTile / 16; ++i) {
+            const F4 z = {0.f, 0.f, 0.f, 0.f};        // (rows past the tile's end are zero: pool_tile's one-graph path sums all 16 rows of a wave)
+            st4(&T[(gi + 16 * i) * kLdt + 4 * t], gi + 16 * i < nrows ? affine_relu(affine_relu(z4[i], ab), ac) : z);
+        }
         __syncthreads();
         pool_tile(T, nrows, a.pooled, gidl);
         __syncthreads();
@@ -558,11 +607,22 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
                      p.w.num_gin_layers, din, p.batch_size);
             return -2;
         }
+        if (p.node_cap < 1 || p.node_cap > 0x7fffffff) {        // (ABI 3: the kernels clamp their speculative first-tile requests to it)
+            snprintf(g_err, kErrLen, "gcc_gin_forward: gcc_gin_pass.node_cap = %lld (the row capacity of the pass's buffers is required)",
+                     (long long)p.node_cap);
+            return -2;
+        }
         maxB = p.batch_size > maxB ? p.batch_size : maxB;
     }
     hipStream_t s = (hipStream_t)stream;
     prof_mark(prof, 0, s);
-    const dim3 grid(kGridX, npass), block(kThreads);
+    int64_t rows_max = 0;                            // workgroups per pass: for the rows expected (rows_hint), else for the capacity
+    for (int i = 0; i < npass; ++i) {
+        const gcc_gin_pass &p = passes[i];
+        const int64_t r = p.rows_hint > 0 && p.rows_hint < p.node_cap ? p.rows_hint : p.node_cap;
+        rows_max = r > rows_max ? r : rows_max;
+    }
+    const dim3 grid(tile_grid(rows_max), npass), block(kThreads);
     {
         FeatLaunch L;
         for (int i = 0; i < npass; ++i) {
@@ -570,7 +630,8 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
             L.p[i] = {p.node_off, p.row_ptr, p.graph_id, p.seed_local, p.pos, p.w.degree_embedding, p.x0,
                       (float4 *)p.stats, (float4 *)p.pooled, (int64_t)Lg * 3 * kRep * 2 * H * (int64_t)sizeof(double) / 16,
                       (int64_t)(Lg + 1) * p.batch_size * H * (int64_t)sizeof(double) / 16,
-                      p.batch_size, p.w.pos_dim, p.w.deg_emb_dim, p.w.max_degree, p.edge_multiplicity > 1 ? p.edge_multiplicity : 1};
+                      p.batch_size, p.w.pos_dim, p.w.deg_emb_dim, p.w.max_degree, p.edge_multiplicity > 1 ? p.edge_multiplicity : 1,
+                      (int32_t)p.node_cap};
         }
         hipLaunchKernelGGL(gin_feat_kernel, grid, block, 0, s, L);
     }
@@ -592,6 +653,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
                 a.kdim = l == 0 ? p.w.pos_dim + p.w.deg_emb_dim + 1 : hidden_of(p.w);
                 a.training = p.training; a.eps = p.w.bn_eps;
                 a.nbr_weight = p.edge_multiplicity > 1 ? (float)p.edge_multiplicity : 1.0f;
+                a.cap = (int32_t)p.node_cap;
                 L.p[i] = a;
             }
             L.ticks = g_gin_ticks;
@@ -603,7 +665,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
                 const gcc_gin_pass &p = passes[i];
                 L.p[i] = {p.node_off, p.z1[l], bn_of(p, p.w.bn_a[l], l, 0, false), p.w.lin1_w[l], p.w.lin1_b[l],
                           p.z2[l], stats_of(p, l, 1), p.batch_size, p.training,
-                          p.w.bn_eps, hidden_of(p.w)};
+                          p.w.bn_eps, hidden_of(p.w), (int32_t)p.node_cap};
             }
             hipLaunchKernelGGL(gin_mid_kernel, grid, block, 0, s, L);
         }
@@ -612,7 +674,8 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
             bool need = false;
             for (int i = 0; i < npass; ++i) {
                 const gcc_gin_pass &p = passes[i];
-                L.p[i] = {p.node_off, p.z2[l], bn_of(p, p.w.bn_b[l], l, 1, false), stats_of(p, l, 2), p.batch_size, p.training, p.w.bn_eps};
+                L.p[i] = {p.node_off, p.z2[l], bn_of(p, p.w.bn_b[l], l, 1, false), stats_of(p, l, 2), p.batch_size, p.training, p.w.bn_eps,
+                          (int32_t)p.node_cap};
                 need = need || p.training;
             }
             if (need) hipLaunchKernelGGL(gin_stat_kernel, grid, block, 0, s, L);
@@ -624,7 +687,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
             const gcc_gin_pass &p = passes[i];
             L.p[i] = {p.node_off, p.graph_id, p.z2[Lg - 1], bn_of(p, p.w.bn_b[Lg - 1], Lg - 1, 1, false),
                       bn_of(p, p.w.bn_c[Lg - 1], Lg - 1, 2, false), p.pooled + (int64_t)Lg * p.batch_size * H,
-                      p.batch_size, p.training, p.w.bn_eps};
+                      p.batch_size, p.training, p.w.bn_eps, (int32_t)p.node_cap};
         }
         hipLaunchKernelGGL(gin_pool_kernel, grid, block, 0, s, L);
     }

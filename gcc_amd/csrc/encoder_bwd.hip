@@ -260,6 +260,7 @@ struct BwdCArgs {
     double *bst_c;            // [3][64]
     int32_t B;
     float eps;
+    int32_t cap;              // node capacity of the per-node buffers
 };
 
 // (the grid is 3 workgroups per CU: 168 registers each)
@@ -279,9 +280,28 @@ __global__ __launch_bounds__(kThreads, BWD_C_PER_CU) void gin_bwd_c_kernel(BwdCA
     __shared__ int rpl[kTile + 1];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
     int N;
+    const float *Dp = a.D ? a.D : a.z2;              // (last layer: no D -- the requests below stay unconditional and read z2 twice)
+    auto ident = [&](int u) -> F4 { return ld4(Dp + (int64_t)u * H + 4 * t); };
+    // the lane group's 4 rows of the FIRST tile: graph ids, z2 rows, the tile's own rows of D and its row pointers are requested
+    // together with the node count and the statistics (addresses clamped to the capacity, rows >= N dropped below); the
+    // pooled-path gradients (which need the graph ids) go out with the gather's first request.  Every load unconditional (a loop
+    // over r with its loads inside ran 8 dependent round trips, after the gather)
+    const int tf = first_tile();
+    int gid4[kTile / 16], rp_own = 0;
+    F4 own[kTile / 16], z4[kTile / 16];
+    auto request = [&](int tile0) {
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i) gid4[i] = a.graph_id[cap_row(tile0 + gi + 16 * i, a.cap)];
+        rp_own = a.row_ptr[min(tile0 + min(tid, kTile), a.cap)];       // (no branch on a.D here: loads behind a branch are a batch of their own)
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i) own[i] = ident(cap_row(tile0 + gi + 16 * i, a.cap));
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i) z4[i] = ld4(a.z2 + (int64_t)cap_row(tile0 + gi + 16 * i, a.cap) * H + 4 * t);
+    };
     if (a.bnb.totals && a.bnc.totals) {            // block-uniform; the usual case
         const CoefReq rb = coef_request(a.bnb), rc = coef_request(a.bnc);
         const RepReq none = {};
+        request(tf * kTile);
         N = a.node_off[a.B];                       // (requested last: the wait for it is the wait for all)
         SCHED_FENCE();
         if (no_tiles(N)) return;
@@ -289,43 +309,31 @@ __global__ __launch_bounds__(kThreads, BWD_C_PER_CU) void gin_bwd_c_kernel(BwdCA
         fill_coefs_from<false>(Cc, rc, none, (double)N, a.eps, (double *)part);
         __syncthreads();
     } else {
+        request(tf * kTile);
         N = ((const volatile int32_t *)a.node_off)[a.B];      // (volatile: an ordinary load is hoisted above the branch, ahead of the other arm's requests)
         fill_coefs(Cb, a.bnb, nullptr, (double)N, a.eps, (double *)part);
         fill_coefs(Cc, a.bnc, nullptr, (double)N, a.eps, (double *)part);
     }
-    auto ident = [&](int u) -> F4 { return ld4(a.D + (int64_t)u * H + 4 * t); };
     F4 s1 = zero4(), s2 = zero4();
     bool any = false;
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
         const int tile0 = tw.ti * kTile;
         any = true;
         const int nrows = min(kTile, N - tile0);
-        // the lane group's 4 rows: graph ids and z2 rows ride in the round trip of the tile's own rows of D, the
-        // pooled-path gradients (which need the graph ids) in the gather's first one; every load unconditional with a
-        // clamped address (a loop over r with its loads inside ran 8 dependent round trips, after the gather)
-        int gid4[kTile / 16];
-        F4 g4[kTile / 16], z4[kTile / 16];
+        if (tw.ti != tf) request(tile0);
+        F4 g4[kTile / 16];
+        auto pooled_path = [&] {                     // d pooled of the rows' graphs (ids of rows >= N clamped: not used)
 #pragma unroll
-        for (int i = 0; i < kTile / 16; ++i) gid4[i] = a.graph_id[min(tile0 + gi + 16 * i, N - 1)];
+            for (int i = 0; i < kTile / 16; ++i) g4[i] = ld4(a.dpooled + (int64_t)min(max(gid4[i], 0), a.B - 1) * H + 4 * t);
+        };
         if (a.D) {                                   // block-uniform
-            const int rp_own = a.row_ptr[tile0 + min(tid, nrows)];
-            F4 own[kTile / 16];
-#pragma unroll
-            for (int i = 0; i < kTile / 16; ++i) own[i] = ident(min(tile0 + gi + 16 * i, N - 1));
-#pragma unroll
-            for (int i = 0; i < kTile / 16; ++i) z4[i] = ld4(a.z2 + (int64_t)min(tile0 + gi + 16 * i, N - 1) * H + 4 * t);
             if (tid <= nrows) rpl[tid] = rp_own;
 #pragma unroll
             for (int i = 0; i < kTile / 16; ++i) st4(&T[(gi + 16 * i) * kLdt + 4 * t], gi + 16 * i < nrows ? own[i] : zero4());
-#pragma unroll
-            for (int i = 0; i < kTile / 16; ++i) g4[i] = ld4(a.dpooled + (int64_t)gid4[i] * H + 4 * t);
             __syncthreads();
-            gather_tile<BWD_GATHER_J>(T, part, prow, nrows, a.col_idx, ident, [](F4 x) { return x; }, 1.0f, rpl);
+            gather_tile<BWD_GATHER_J>(T, part, prow, nrows, a.col_idx, ident, [](F4 x) { return x; }, 1.0f, rpl, pooled_path);
         } else {
-#pragma unroll
-            for (int i = 0; i < kTile / 16; ++i) z4[i] = ld4(a.z2 + (int64_t)min(tile0 + gi + 16 * i, N - 1) * H + 4 * t);
-#pragma unroll
-            for (int i = 0; i < kTile / 16; ++i) g4[i] = ld4(a.dpooled + (int64_t)gid4[i] * H + 4 * t);
+            pooled_path();
         }
         {
             // (the coefficient rows are read from LDS here, not held in 24 registers across the gather)
@@ -364,6 +372,7 @@ struct BwdBArgs {
     double *bst_b;
     int32_t B;
     float eps;
+    int32_t cap;              // node capacity of the per-node buffers
 };
 
 __global__ __launch_bounds__(kThreads) void gin_bwd_b_kernel(BwdBArgs a)
@@ -373,9 +382,21 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_b_kernel(BwdBArgs a)
     __shared__ float Cb[kCoefRows * H], Cc[kCoefRows * H];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
     int N;
+    // the first tile's rows of z2 and U ride in the round trip of the node count and the statistics (clamped to the capacity)
+    const int tf = first_tile();
+    F4 z4[kTile / 16], u4[kTile / 16];              // the lane group's 4 rows of z2 and U, requested together
+    auto request = [&](int tile0) {
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i) {
+            const int64_t off = (int64_t)cap_row(tile0 + gi + 16 * i, a.cap) * H + 4 * t;
+            z4[i] = ld4(a.z2 + off);
+            u4[i] = ld4(a.U + off);
+        }
+    };
     if (a.bnb.totals && a.bnc.totals) {            // block-uniform; the usual case
         const CoefReq rb = coef_request(a.bnb), rc = coef_request(a.bnc);
         const RepReq sc = rep_request(a.bst_c, 3 * H);
+        request(tf * kTile);
         N = a.node_off[a.B];                       // (requested last: the wait for it is the wait for all)
         SCHED_FENCE();
         if (no_tiles(N)) return;
@@ -383,6 +404,7 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_b_kernel(BwdBArgs a)
         fill_coefs_from<true>(Cc, rc, sc, (double)N, a.eps, (double *)part);
         __syncthreads();
     } else {
+        request(tf * kTile);
         N = ((const volatile int32_t *)a.node_off)[a.B];      // (volatile: an ordinary load is hoisted above the branch, ahead of the other arm's requests)
         fill_coefs(Cb, a.bnb, nullptr, (double)N, a.eps, (double *)part);
         fill_coefs(Cc, a.bnc, a.bst_c, (double)N, a.eps, (double *)part);
@@ -395,13 +417,7 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_b_kernel(BwdBArgs a)
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
         const int tile0 = tw.ti * kTile;
         any = true;
-        F4 z4[kTile / 16], u4[kTile / 16];          // the lane group's 4 rows of z2 and U, requested together
-#pragma unroll
-        for (int i = 0; i < kTile / 16; ++i) {
-            const int64_t off = (int64_t)min(tile0 + gi + 16 * i, N - 1) * H + 4 * t;
-            z4[i] = ld4(a.z2 + off);
-            u4[i] = ld4(a.U + off);
-        }
+        if (tw.ti != tf) request(tile0);
 #pragma unroll
         for (int i = 0; i < kTile / 16; ++i) {
             const int v = tile0 + gi + 16 * i;
@@ -440,6 +456,7 @@ struct BwdLinArgs {
     double *bst_out;          // [3][64] slots 0,1 (kMask)
     int32_t B;
     float eps;
+    int32_t cap;              // node capacity of the per-node buffers
 };
 
 template <bool kMask>
@@ -453,15 +470,31 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_lin_kernel(BwdLinArgs a)
                                                    // fragments as 64 strided 4-byte loads per lane before)
     const WStage wst = stage_weights_request(a.W, a.kdim);      // in flight with N and the statistics
     int N;
+    // every load of the FIRST tile is issued with the node count, the statistics and the weights: one round trip.  Unconditional,
+    // clamped to the capacity (a lane past the live rows reads a row that exists and drops it), because loads under per-block
+    // `if (valid)` branches came out as one round trip each
+    const int tf = first_tile();
+    F4 gq[4], zq[4], zo[4];
+    auto request = [&](int tile0) {
+        const int64_t rbase = (int64_t)cap_row(tile0 + 16 * wv + j, a.cap) * H;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            gq[c] = ld4(a.gin + rbase + 16 * c + 4 * q);
+            zq[c] = ld4(a.zin + rbase + 16 * c + 4 * q);
+            zo[c] = kMask ? ld4(a.zout + rbase + 16 * c + 4 * q) : zero4();
+        }
+    };
     if (a.bn_in.totals && (!kMask || a.bn_out.totals)) {      // block-uniform; the usual case
         const CoefReq ri = coef_request(a.bn_in), ro = kMask ? coef_request(a.bn_out) : CoefReq();
         const RepReq si = rep_request(a.bst_in, 3 * H);
+        request(tf * kTile);
         N = a.node_off[a.B];                       // (requested last: the wait for it is the wait for all)
         SCHED_FENCE();
         if (no_tiles(N)) return;
         fill_coefs_from<true>(Ci, ri, si, (double)N, a.eps, (double *)red);
         if (kMask) fill_coefs_from<false>(Co, ro, si, (double)N, a.eps, (double *)red);
     } else {
+        request(tf * kTile);
         N = ((const volatile int32_t *)a.node_off)[a.B];      // (volatile: an ordinary load is hoisted above the branch, ahead of the other arm's requests)
         fill_coefs(Ci, a.bn_in, a.bst_in, (double)N, a.eps, (double *)red);
         if (kMask) fill_coefs(Co, a.bn_out, nullptr, (double)N, a.eps, (double *)red);
@@ -473,16 +506,7 @@ __global__ __launch_bounds__(kThreads, 4) void gin_bwd_lin_kernel(BwdLinArgs a)
         const int tile0 = tw.ti * kTile;
         const int row = tile0 + 16 * wv + j;
         const bool valid = row < N;
-        // every load of the tile is issued before the first use: unconditional (a lane past the end reads row 0, which exists
-        // when the loop runs at all), because loads under per-block `if (valid)` branches came out as one round trip each
-        const int64_t rbase = (int64_t)(valid ? row : 0) * H;
-        F4 gq[4], zq[4], zo[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            gq[c] = ld4(a.gin + rbase + 16 * c + 4 * q);
-            zq[c] = ld4(a.zin + rbase + 16 * c + 4 * q);
-            zo[c] = kMask ? ld4(a.zout + rbase + 16 * c + 4 * q) : zero4();
-        }
+        if (tw.ti != tf) request(tile0);
         F4 xb[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -549,6 +573,7 @@ struct EmbArgs {
     const float *D, *dpooled0;
     float *demb_parts;        // [kEmbBlocks][(max_degree + 1) * emb_dim]
     int32_t B, pos_dim, emb_dim, max_degree;
+    int32_t cap;              // node capacity of the per-node buffers
 };
 
 __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
@@ -561,49 +586,60 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
     __shared__ int prow[32];
     __shared__ int rpl[kTile + 1];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
+    auto ident = [&](int u) -> F4 { return ld4(a.D + (int64_t)u * H + 4 * t); };
+    // row pointers, graph ids and the lane group's 4 rows of the FIRST tile: requested together with the node count (clamped to
+    // the capacity), stored afterwards (a load under `if (tid < ...)` next to its LDS store is a round trip of its own)
+    const int tf = first_tile();
+    int rp_own, gid_own;
+    F4 own[kTile / 16];
+    auto request = [&](int tile0) {
+        rp_own = a.row_ptr[min(tile0 + min(tid, kTile), a.cap)];
+        gid_own = a.graph_id[cap_row(tile0 + (tid & (kTile - 1)), a.cap)];
+#pragma unroll
+        for (int i = 0; i < kTile / 16; ++i) own[i] = ident(cap_row(tile0 + gi + 16 * i, a.cap));
+    };
+    request(tf * kTile);
     const int N = a.node_off[a.B];
+    SCHED_FENCE();
     const int elems = (a.max_degree + 1) * a.emb_dim;
     for (int i = tid; i < elems; i += kThreads) E[i] = 0.f;
-    auto ident = [&](int u) -> F4 { return ld4(a.D + (int64_t)u * H + 4 * t); };
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
         const int tile0 = tw.ti * kTile;
         const int nrows = min(kTile, N - tile0);
-        {   // row pointers, graph ids and the lane group's 4 rows: requested together, stored afterwards (a load under
-            // `if (tid < ...)` next to its LDS store is a round trip of its own)
-            const int rp_own = a.row_ptr[tile0 + min(tid, nrows)];
-            const int gid_own = a.graph_id[min(tile0 + (tid & (kTile - 1)), N - 1)];
-            F4 own[kTile / 16];
-#pragma unroll
-            for (int i = 0; i < kTile / 16; ++i) own[i] = ident(min(tile0 + gi + 16 * i, N - 1));
+        {
+            if (tw.ti != tf) request(tile0);
             if (tid <= nrows) rpl[tid] = rp_own;
             if (tid >= 128 && tid - 128 < nrows) gidl[tid - 128] = gid_own;
 #pragma unroll
             for (int i = 0; i < kTile / 16; ++i) st4(&T[(gi + 16 * i) * kLdt + 4 * t], gi + 16 * i < nrows ? own[i] : zero4());
         }
         __syncthreads();
-        gather_tile<BWD_GATHER_J>(T, part, prow, nrows, a.col_idx, ident, [](F4 x) { return x; }, 1.0f, rpl);
-        // all threads: add the pooled-path gradient and look the clamped degree up (global loads in parallel) ...
+        // (the pooled-path gradients of a batch requested together, graph ids from LDS: 8 dependent round trips before; the first
+        //  kIt * kThreads of them -- all of them at emb_dim 16 -- go out behind the gather's first request of neighbour ids)
+        constexpr int kIt = 4;                       // covers kTile rows x 16 columns with 256 threads; more columns loop below
+        const int total = nrows * a.emb_dim;
+        int rr[kIt], cc[kIt];
+        float dv[kIt];
+        auto pooled_request = [&](int base) {
+#pragma unroll
+            for (int i = 0; i < kIt; ++i) {
+                const int idx = min(base + tid + i * kThreads, total - 1);
+                rr[i] = idx / a.emb_dim; cc[i] = idx - rr[i] * a.emb_dim;
+            }
+#pragma unroll
+            for (int i = 0; i < kIt; ++i) dv[i] = a.dpooled0[(int64_t)gidl[rr[i]] * H + a.pos_dim + cc[i]];
+        };
+        gather_tile<BWD_GATHER_J>(T, part, prow, nrows, a.col_idx, ident, [](F4 x) { return x; }, 1.0f, rpl, [&] { pooled_request(0); });
+        // all threads: add the pooled-path gradient and look the clamped degree up ...
         if (tid < nrows) {
             const int deg = rpl[tid + 1] - rpl[tid];
             dclrow[tid] = deg < a.max_degree ? deg : a.max_degree;
         }
-        {   // (the pooled-path gradients of a batch requested together, graph ids from LDS: 8 dependent round trips before)
-            constexpr int kIt = 4;                   // covers kTile rows x 16 columns with 256 threads; more columns loop below
-            const int total = nrows * a.emb_dim;
-            for (int base = 0; base < total; base += kIt * kThreads) {
-                int rr[kIt], cc[kIt];
-                float dv[kIt];
+        for (int base = 0; base < total; base += kIt * kThreads) {
+            if (base) pooled_request(base);
 #pragma unroll
-                for (int i = 0; i < kIt; ++i) {
-                    const int idx = min(base + tid + i * kThreads, total - 1);
-                    rr[i] = idx / a.emb_dim; cc[i] = idx - rr[i] * a.emb_dim;
-                }
-#pragma unroll
-                for (int i = 0; i < kIt; ++i) dv[i] = a.dpooled0[(int64_t)gidl[rr[i]] * H + a.pos_dim + cc[i]];
-#pragma unroll
-                for (int i = 0; i < kIt; ++i)
-                    if (base + tid + i * kThreads < total) T[rr[i] * kLdt + a.pos_dim + cc[i]] += dv[i];
-            }
+            for (int i = 0; i < kIt; ++i)
+                if (base + tid + i * kThreads < total) T[rr[i] * kLdt + a.pos_dim + cc[i]] += dv[i];
         }
         __syncthreads();
         // ... then column c is owned by thread c: LDS only, fixed order, no atomics
@@ -630,6 +666,7 @@ struct WgradArgs {
     float *bias_slabs;        // [njobs][kWgChunks][64]   column sums of dZ
     int32_t B;
     float eps;
+    int32_t cap;              // node capacity of the per-node buffers
 };
 
 __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
@@ -651,9 +688,7 @@ __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
     const double *tp = fast ? jb.bn.totals : (const double *)a.slabs;
     const float *wp = fast ? jb.bn.weight : a.slabs, *bp = fast ? jb.bn.bias : a.slabs;
     const CoefReq cr = {tp[cc], tp[H + cc], wp[cc], bp[cc]};
-    const int Nn = a.node_off[a.B];
-    SCHED_FENCE();
-    const int N = jb.rows_fixed > 0 ? jb.rows_fixed : Nn;
+    const int rcap = jb.rows_fixed > 0 ? jb.rows_fixed : a.cap;     // rows the job's operands hold
     f32x4 acc[4][4];
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -661,7 +696,8 @@ __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[ob][kb] = z; }
     // a workgroup walks 6-7 row tiles; with the loads of a tile issued right before its products every tile cost a full
-    // memory round trip (58 us for ~6 us of matrix work): the next tile's rows are requested before this tile's products
+    // memory round trip (58 us for ~6 us of matrix work): the next tile's rows are requested before this tile's products,
+    // and the FIRST tile's with the node count (clamped to the operands' capacity; rows >= N zeroed in mask_tile)
     float av[4][4], xv[4][4];
     // (unconditional loads from a clamped row, masked afterwards: under `row < N` branches every load waited for the one before)
     const bool xdouble = jb.Xd != nullptr;               // block-uniform: prediction layers read the fp64 pooled sums
@@ -670,7 +706,7 @@ __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int row = tile0 + 16 * wv + 4 * s + q;     // MFMA reduction index = row
-            off[s] = (int64_t)(row < N ? row : 0) * H + j;
+            off[s] = (int64_t)cap_row(row, rcap) * H + j;
 #pragma unroll
             for (int k = 0; k < 4; ++k) A[s][k] = jb.dZ[off[s] + 16 * k];
         }
@@ -693,6 +729,8 @@ __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) X[s][k] = jb.X[off[s] + 16 * k];
         }
+    };
+    auto mask_tile = [&](int tile0, int N, float (&A)[4][4], float (&X)[4][4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bool in = tile0 + 16 * wv + 4 * s + q < N;
@@ -700,8 +738,12 @@ __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
             for (int k = 0; k < 4; ++k) { A[s][k] = in ? A[s][k] : 0.f; X[s][k] = in ? X[s][k] : 0.f; }
         }
     };
+    const int tf = first_tile();
+    fetch(tf * kTile, av, xv);
+    const int Nn = a.node_off[a.B];
+    SCHED_FENCE();
+    const int N = jb.rows_fixed > 0 ? jb.rows_fixed : Nn;
     TileWalk tw(N);
-    if (tw.ti < tw.tend) fetch(tw.ti * kTile, av, xv);
     if (tid < H) {
         float sc = 1.f, sh = 0.f;
         if (fast) {
@@ -726,6 +768,7 @@ __global__ __launch_bounds__(kThreads, 3) void gin_wgrad_kernel(WgradArgs a)
         float an[4][4], xn[4][4];
         const bool more = tw.ti + tw.step < tw.tend;         // block-uniform
         if (more) fetch((tw.ti + tw.step) * kTile, an, xn);
+        mask_tile(tile0, N, av, xv);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int row = tile0 + 16 * wv + 4 * s + q;
@@ -953,9 +996,14 @@ extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat
                  (long long)w.total);
         return -3;
     }
+    if (node_cap < 1 || node_cap > 0x7fffffff || (p.node_cap > 0 && p.node_cap != node_cap)) {
+        snprintf(g_err, kErrLen, "gcc_gin_backward: node_cap %lld (the pass says %lld)", (long long)node_cap, (long long)p.node_cap);
+        return -2;
+    }
+    const int32_t cap = (int32_t)node_cap;           // the kernels clamp their speculative first-tile requests to it
     hipStream_t s = (hipStream_t)stream;
     prof_mark(prof, 0, s);
-    const dim3 grid(kGridX), block(kThreads);
+    const dim3 grid(tile_grid(p.rows_hint > 0 && p.rows_hint < node_cap ? p.rows_hint : node_cap)), block(kThreads);
     auto bst = [&](int l, int which) { return w.bst + ((int64_t)l * 3 + which) * kRep * 3 * H; };   // which: 0=a 1=b 2=c
     {
         ReadBwdArgs a;
@@ -973,34 +1021,34 @@ extern "C" int32_t gcc_gin_backward(const gcc_gin_pass *pass, const float *dfeat
         const BnDev bnc = bn_of(p, p.w.bn_c[l], l, 2);
         {
             BwdCArgs a = {p.node_off, p.row_ptr, p.col_idx, p.graph_id, l == L - 1 ? nullptr : w.D,
-                          w.dpooled + (int64_t)(l + 1) * B * H, p.z2[l], bnb, bnc, w.U, bst(l, 2), B, p.w.bn_eps};
+                          w.dpooled + (int64_t)(l + 1) * B * H, p.z2[l], bnb, bnc, w.U, bst(l, 2), B, p.w.bn_eps, cap};
             hipLaunchKernelGGL(gin_bwd_c_kernel, grid, block, 0, s, a);
         }
         {
-            BwdBArgs a = {p.node_off, w.U, p.z2[l], bnb, bnc, bst(l, 2), w.V, bst(l, 1), B, p.w.bn_eps};
+            BwdBArgs a = {p.node_off, w.U, p.z2[l], bnb, bnc, bst(l, 2), w.V, bst(l, 1), B, p.w.bn_eps, cap};
             hipLaunchKernelGGL(gin_bwd_b_kernel, grid, block, 0, s, a);
         }
         {
             BwdLinArgs a = {p.node_off, w.V, p.z2[l], bnb, bst(l, 1), bst(l, 1) + 2 * H, p.w.lin1_w[l], hidden_of(p.w),
-                            w.dz2[l], w.Wt, p.z1[l], bna, bst(l, 0), B, p.w.bn_eps};
+                            w.dz2[l], w.Wt, p.z1[l], bna, bst(l, 0), B, p.w.bn_eps, cap};
             hipLaunchKernelGGL((gin_bwd_lin_kernel<true>), grid, block, 0, s, a);
         }
         {
             BwdLinArgs a = {p.node_off, w.Wt, p.z1[l], bna, bst(l, 0), bst(l, 0) + 2 * H, p.w.lin0_w[l],
-                            l == 0 ? kdim0 : hidden_of(p.w), w.dz1[l], w.D, nullptr, BnDev(), nullptr, B, p.w.bn_eps};
+                            l == 0 ? kdim0 : hidden_of(p.w), w.dz1[l], w.D, nullptr, BnDev(), nullptr, B, p.w.bn_eps, cap};
             hipLaunchKernelGGL((gin_bwd_lin_kernel<false>), grid, block, 0, s, a);
         }
     }
     {
         EmbArgs a = {p.node_off, p.row_ptr, p.col_idx, p.graph_id, w.D, w.dpooled, w.demb_parts, B, p.w.pos_dim,
-                     p.w.deg_emb_dim, p.w.max_degree};
+                     p.w.deg_emb_dim, p.w.max_degree, cap};
         hipLaunchKernelGGL(gin_bwd_emb_kernel, dim3(kEmbBlocks), block, 0, s, a);
     }
     {
         // (one launch for all 3 L + 1 products: a launch per layer takes as long as this one -- every workgroup's chain of
         //  row tiles is the same -- so spreading them over a second stream bought nothing, profiles/r3_side_stream_probe.txt)
         WgradArgs a;
-        a.node_off = p.node_off; a.slabs = w.slabs; a.bias_slabs = w.bias_slabs; a.B = B; a.eps = p.w.bn_eps;
+        a.node_off = p.node_off; a.slabs = w.slabs; a.bias_slabs = w.bias_slabs; a.B = B; a.eps = p.w.bn_eps; a.cap = cap;
         for (int l = 0; l < L; ++l) {
             a.job[2 * l + 0] = {w.dz1[l], p.agg[l], nullptr, BnDev(), 0};
             a.job[2 * l + 1] = {w.dz2[l], p.z1[l], nullptr, bn_of(p, p.w.bn_a[l], l, 0), 0};

@@ -15,33 +15,33 @@ constexpr int kRep = 32;            // replicas of every atomically accumulated 
                                     // copy (blockIdx.x % kRep), consumers sum the copies -- ~730 workgroups hitting the
                                     // same 8 cache lines with fp64 atomics cost 20-40 us per kernel (rocprof, round 1)
 
-// ---- XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 (8 XCDs, each with its own 4 MiB L2); with
-// tile = blockIdx.x every XCD touches every subgraph, so the neighbour rows a tile gathers (rows of its own subgraphs,
-// written by other tiles) come from other XCDs' tiles.  Here XCD x walks the contiguous tiles [x * per, (x + 1) * per),
-// per = ceil(tiles / 8), and every tile kernel of the forward and backward pass uses the same walk, so a tile's own rows
-// and its neighbours' stay in one L2 from producer to consumer.  Measured at bsz 256 (13 MB of activations, all of it in
-// the 256 MiB Infinity Cache either way): no difference, 0.720 vs 0.716 ms per step (scripts/gpu/r3_call23.sh) -- what the
-// gather waited for was its own serialised loads (gather_tile below), not the fabric.  Kept: it is the mapping the guide
-// recommends and it cannot hurt larger batches.
-// no_tiles(N): this workgroup has nothing to walk -- the tile kernels return on it as soon as the node count is known,
-// before their tables and staged weights (the grid is sized for the node CAPACITY: at bsz 256 about half of the 768
-// workgroups of a launch have no tile, and their prologues competed with the others' for LDS and issue slots).
+// ---- tile order.  Two properties:
+// (1) a workgroup's FIRST tile is a function of blockIdx alone, NOT of the live node count N = node_off[B] (device memory): every
+//     tile kernel requests its first tile's rows TOGETHER with N, its statistics and its weights, clamped to the buffers' CAPACITY
+//     (gcc_gin_pass.node_cap), and masks rows >= N afterwards.  Rounds 1-5 computed the tile from N (per = ceil(tiles / 8)), so every
+//     kernel of the ~40-launch chain ran node count -> wait -> tile rows -> wait: two DEPENDENT memory round trips where one does
+//     (profiles/r6_stream_trace_start.txt: the kernels that do nothing else take 6.5 us).
+// (2) XCD-aware: the dispatcher places workgroup b on XCD b % 8 (8 XCDs, each with its own 4 MiB L2).  XCD x takes the tiles
+//     {32 g + 4 x .. 32 g + 4 x + 3 : g = 0, 1, ...}: runs of four consecutive tiles (256 rows, two or three ego-nets) share an L2, so
+//     most of the neighbour rows a tile gathers were fetched by a neighbouring tile of the same XCD, for ANY N.  (The N-dependent
+//     contiguous ranges of round 3 measured no different from tile = blockIdx.x at bsz 256: scripts/gpu/r3_call23.sh.)
+// A launch with more tiles than workgroups walks on in steps of gridDim.x (a multiple of 32 keeps the pattern).
+// no_tiles(N): this workgroup has nothing to walk -- the tile kernels return on it as soon as N is known, before their tables and
+// staged weights (the grid is sized for the node CAPACITY: at bsz 256 about half of the 768 workgroups of a launch have no tile).
+__device__ __forceinline__ int first_tile()
+{
+    const int b = (int)blockIdx.x;
+    if (((int)gridDim.x & 31) != 0) return b;
+    const int x = b & 7, j = b >> 3;
+    return ((((j >> 2) << 3) + x) << 2) + (j & 3);
+}
 struct TileWalk {
     int ti, tend, step;
-    __device__ __forceinline__ explicit TileWalk(int N)
-    {
-        const int nt = (N + kTile - 1) / kTile;
-        if (((int)gridDim.x & 7) == 0) {
-            const int per = (nt + 7) >> 3, x = (int)blockIdx.x & 7;
-            ti = x * per + ((int)blockIdx.x >> 3);
-            tend = min((x + 1) * per, nt);
-            step = (int)gridDim.x >> 3;
-        } else {
-            ti = (int)blockIdx.x; tend = nt; step = (int)gridDim.x;
-        }
-    }
+    __device__ __forceinline__ explicit TileWalk(int N) : ti(first_tile()), tend((N + kTile - 1) / kTile), step((int)gridDim.x) {}
 };
-__device__ __forceinline__ bool no_tiles(int N) { const TileWalk tw(N); return tw.ti >= tw.tend; }
+__device__ __forceinline__ bool no_tiles(int N) { return first_tile() * kTile >= N; }
+// row r of a tile, clamped into the buffers (speculative requests: cap = node capacity; afterwards masked by r < N)
+__device__ __forceinline__ int cap_row(int row, int cap) { return min(row, cap - 1); }
 
 struct F4 { float x, y, z, w; };
 
@@ -210,6 +210,27 @@ __device__ __forceinline__ Aff4 bn_aff4(const BnDev &bn, int c0, double n, float
 __device__ __forceinline__ void pool_tile(const float *T, int nrows, double *pooled, const int *gid_lds /* LDS [kTile] */)
 {
     const int c = (int)threadIdx.x & 63, part = (int)threadIdx.x >> 6;
+    // Precondition (every caller stores the tile that way): rows [nrows, kTile) of T are zero.
+    // A wave owns 16 consecutive rows; graph ids ascend, so "first == last" means ONE graph -- 85 % of the waves at rw_hops 256
+    // (ego-nets of ~100 nodes): 16 independent LDS reads, an add tree, one atomic.  The general loop below (a flush at every
+    // change of graph: a branch and a dependent LDS read per row) cost 5.4 us of gin_in_kernel's 38 (profiles/r6_gin_phases_start.txt).
+    const int nv = min(16, nrows - part * 16);                   // live rows of this wave (wave-uniform)
+    if (nv <= 0) return;
+    const int g_first = wave_uniform(gid_lds[part * 16]), g_last = wave_uniform(gid_lds[part * 16 + nv - 1]);
+    if (g_first == g_last) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = T[(part * 16 + k) * kLdt + c];
+        double d[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = (double)v[k];
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+            for (int k = 0; k < w; ++k) d[k] += d[k + w];
+        atomicAdd(&pooled[(int64_t)g_first * H + c], d[0]);
+        return;
+    }
     int gids[16];                                    // (the tile's graph ids came with the tile's rows: no round trip here)
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -473,10 +494,13 @@ __device__ __forceinline__ void flush_stats(const float *red, double *stats)
 // the kGatherJ loads of a round are all requested before the first transform -- with one callable doing both, the
 // transform's branch made the compiler wait for every load before requesting the next (4 round trips per round: 14 of
 // gin_in_kernel's 50 us, profiles/r3_gather_ablations.txt)
-template <int kGatherJ, class Load, class Xform>
+// overlap(): block-uniform work that only READS T (gin_in_kernel's SumPooling), run after the first 16 targets of every lane
+// group are requested and before anything here writes T: that round trip hides behind it.  Must end with a barrier that orders
+// its reads of T before the writes below.
+template <int kGatherJ, class Load, class Xform, class Overlap>
 __device__ __forceinline__ void gather_tile(float *T, float *part /* [32 * H] */, int *prow /* [32] */, int nrows,
                                             const int32_t *col_idx, Load load, Xform xform, float nbr_weight,
-                                            const int *rp_lds /* [nrows + 1] */)
+                                            const int *rp_lds /* [nrows + 1] */, Overlap overlap)
 {
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, gbase = lane_id() & ~15;
     const int ebeg = rp_lds[0], eend = rp_lds[nrows];
@@ -501,6 +525,7 @@ __device__ __forceinline__ void gather_tile(float *T, float *part /* [32 * H] */
         }
     };
     int idx_next = e0 + t < e1 ? col_idx[e0 + t] : -1;
+    overlap();
     for (int c = 0; c < chunk; c += 16) {                // block-uniform trip counts (the shuffles need every lane)
         const int e = e0 + c + t;
         const bool valid = e < e1;
@@ -567,6 +592,24 @@ __device__ __forceinline__ void gather_tile(float *T, float *part /* [32 * H] */
         if (cur >= 0) T[cur * kLdt + tid] = tv;
     }
     __syncthreads();
+}
+
+template <int kGatherJ, class Load, class Xform>
+__device__ __forceinline__ void gather_tile(float *T, float *part, int *prow, int nrows, const int32_t *col_idx, Load load, Xform xform,
+                                            float nbr_weight, const int *rp_lds)
+{
+    gather_tile<kGatherJ>(T, part, prow, nrows, col_idx, load, xform, nbr_weight, rp_lds, [] {});
+}
+
+// workgroups per pass of a tile kernel: enough for the pass's row capacity, at most kGridX, a multiple of 32 (first_tile's
+// pattern); GCC_GIN_GRID overrides (timing experiments)
+inline int tile_grid(int64_t node_cap)
+{
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("GCC_GIN_GRID"); forced = e ? atoi(e) : 0; }
+    int64_t g = forced > 0 ? forced : (node_cap + kTile - 1) / kTile;
+    g = (g + 31) / 32 * 32;
+    return (int)(g < 32 ? 32 : g > kGridX ? kGridX : g);
 }
 
 // ---- dropout multiplier of linears_prediction[layer](pooled)[b][ch .. ch+3] (gin.py:230):

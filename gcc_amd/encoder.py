@@ -123,6 +123,15 @@ class GinEngine:
         self.lib = lib if lib is not None else _cabi.load()
         self.ptr = ptr if ptr is not None else _cabi.dev_ptr
         self._bufs = {}
+        self.rows_hint = None       # gcc_gin_pass.rows_hint of every pass made from here on (None: launch for the capacity)
+
+    def hint_rows(self, n, margin=1.10):
+        """``n`` live rows were seen in a batch: size the tile kernels' grids for ``margin`` times the largest batch so far
+        (a batch beyond it is still correct -- some workgroups walk two tiles --, a grid for the CAPACITY launches about
+        twice the workgroups a batch needs, and the idle ones' requests cost 10 % of the step)."""
+        want = int(n * margin) + 64
+        if self.rows_hint is None or want > self.rows_hint:
+            self.rows_hint = want
 
     def _buffers(self, key, node_cap, B, L, device):
         k = (key, node_cap, B, L, str(device))
@@ -170,6 +179,8 @@ class GinEngine:
         p.seed_local = ptr(seed_local) if seed_local is not None else None
         # replayed step (hipGraph): the Philox key of the dropout masks is read from the device struct (gcc_step_scalars)
         p.scalars = ptr(scalars) if scalars is not None else None
+        p.node_cap = node_cap
+        p.rows_hint = int(self.rows_hint or 0)   # grid of the tile kernels: an upper estimate of the live rows (0: the capacity)
         buf = dict(buf)
         buf["_keepalive"] = (g, keep, enc)      # the struct holds raw pointers into these
         return p, buf

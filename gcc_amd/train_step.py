@@ -269,6 +269,15 @@ def _is_capture_error(e):
     return any(m in msg for m in _CAPTURE_ERROR_MARKS)
 
 
+def _hint_rows_once(engine, q, k):
+    """The FIRST batch of a run tells the encoder engine how many rows a batch has (one host read of two device integers, once
+    per run: every later step stays free of host synchronisation); :func:`read_meters` raises the estimate when a log line finds a
+    larger batch.  Graphs captured under an earlier estimate stay valid (any grid is correct)."""
+    if engine.rows_hint is None:
+        B = q.batch_size
+        engine.hint_rows(max(int(q.node_off[B].item()), int(k.node_off[B].item())))
+
+
 def _meter_buffers(dev):
     """(acc double[5]: sums of loss, prob, gnorm, nodes(q + k), steps; mx int32[2]: max nodes / edges of a q view)
     -- gcc_step_meters adds one step; :func:`read_meters` reads and zeroes them when a log line is due."""
@@ -282,6 +291,8 @@ def read_meters(trainer):
     a, m = trainer.meter_acc.tolist(), trainer.meter_max.tolist()
     trainer.meter_acc.zero_()
     trainer.meter_max.zero_()
+    if getattr(trainer, "gin", None) is not None and m[0] > 0:
+        trainer.gin.hint_rows(m[0], margin=1.04)       # (the largest q view since the last log line; the k views are as large)
     return a, m
 
 
@@ -683,6 +694,7 @@ class MoCoTrainStep(_GraphedStep):
     def _step(self, step, lr, prof=None):
         pr = prof or {}
         q, k = self.producer.get(step, prof=prof)
+        _hint_rows_once(self.gin, q, k)
         st = torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else None
         p_drop = self.model.gnn.drop.p
         keep = self.mask_fn() if self.mask_fn is not None else None
@@ -815,6 +827,7 @@ class E2ETrainStep(_GraphedStep):
     def _step(self, step, lr, prof=None):
         pr = prof or {}
         q, k = self.producer.get(step, prof=prof)
+        _hint_rows_once(self.gin, q, k)
         st = torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else None
         p_drop = self.model.gnn.drop.p
         keep_q, keep_k = self.mask_fn() if self.mask_fn is not None else (None, None)

@@ -28,10 +28,11 @@
 extern "C" {
 #endif
 
-/* 2: gcc_sample_params.{hub_degree,max_hubs}, gcc_gin_weights.hidden, gcc_gin_pass.scalars, gcc_ginw_args.{scratch,
+/* 3: gcc_gin_pass.{node_cap,rows_hint}.
+ * 2: gcc_sample_params.{hub_degree,max_hubs}, gcc_gin_weights.hidden, gcc_gin_pass.scalars, gcc_ginw_args.{scratch,
  * scratch_bytes,num_nodes}, gcc_graph.{flags,hub_index,hub_adj,num_hubs,hub_words,hub_table_degree}.  A caller built against another version must not pass its structs:
  * compare gcc_abi_version() with the header's constant after loading (gcc_amd/_cabi.py does). */
-#define GCC_AMD_ABI_VERSION 2
+#define GCC_AMD_ABI_VERSION 3
 
 /* bits of the device status word */
 #define GCC_STATUS_SCRATCH_OVERFLOW 1  /* induction scratch too small            */
@@ -344,6 +345,14 @@ typedef struct gcc_gin_pass {    /* one encoder invocation on one batched graph 
     const gcc_step_scalars *scalars;   /* device or NULL: with dropout_philox, the key is scalars->dropout_seed + dropout_seed
                                         * (read by the readout kernels of the forward AND the backward pass): dropout_seed is
                                         * then the pass's fixed offset -- 0, or the second pass's of an E2E step */
+    int64_t node_cap;            /* (ABI 3) rows every per-node buffer of this pass holds (row_ptr: node_cap + 1 entries; graph_id, pos,
+                                  * x0, agg, z1, z2: node_cap rows).  The tile kernels request a workgroup's first tile TOGETHER with the
+                                  * live node count node_off[B] (one memory round trip instead of two dependent ones per kernel), clamped
+                                  * to this capacity; rows past the live count are read and discarded.  Required (> 0). */
+    int64_t rows_hint;           /* (ABI 3) 0, or an upper estimate of the live row count node_off[B] (e.g. 1.1 x the largest batch seen):
+                                  * the tile kernels are launched with ceil(min(rows_hint, node_cap) / 64) workgroups per pass instead of
+                                  * one per 64 rows of CAPACITY.  Any value is correct (workgroups walk on when there are more tiles);
+                                  * workgroups without a tile cost what their speculative requests cost (0.63 vs 0.57 ms per step). */
 } gcc_gin_pass;
 
 /* Runs `npass` independent passes (e.g. query with model, key with model_ema)

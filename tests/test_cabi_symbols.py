@@ -27,7 +27,7 @@ def test_library_exports_every_symbol():
         if name not in _cabi.PENDING:
             assert hasattr(lib, name), name
     _cabi.declare(lib)
-    assert lib.gcc_abi_version() == 2 == _cabi.ABI_VERSION
+    assert lib.gcc_abi_version() == 3 == _cabi.ABI_VERSION
 
 
 def test_product_refuses_cpu_tensors():

@@ -193,6 +193,40 @@ def test_long_rows_full_size_batch_vs_oracle():
     _check_grads(model, {n: p_.grad for n, p_ in oracle.named_parameters() if p_.grad is not None})
 
 
+def test_tile_grid_smaller_than_the_batch_walks_on():
+    """gcc_gin_pass.rows_hint sizes the tile kernels' grids for the rows EXPECTED; a batch with more rows than that must come out the
+    same (workgroups walk on from their first tile in steps of the grid).  A hint of 1 gives the smallest grid (32 workgroups): every
+    workgroup walks several tiles of this ~3000-node batch, the speculative first-tile requests are used by the first one only."""
+    from gcc_amd.graph import DeviceGraph
+    from gcc_amd.graphgen import powerlaw_graph
+    from gcc_amd.sampler import DeviceRWRSampler
+
+    rp, ci = powerlaw_graph(100000, 1000000, 2)
+    g = DeviceGraph(rp, ci, rw_hops=256)
+    s = DeviceRWRSampler(g, 32, run_seed=6)
+    q, _ = s.sample(0)
+    assert q.number_of_nodes() > 32 * 64                     # more tiles than the small grid has workgroups
+    torch.manual_seed(1)
+    q.pos_undirected = torch.randn(q.parent_nid.numel(), 32, device="cuda") * 0.2
+    keep = (torch.rand(5, 32, 64) > 0.5).float().cuda()
+    dfeat = torch.randn(32, 64).cuda()
+    out = []
+    for hint in (None, 1, q.number_of_nodes() + 1):
+        torch.manual_seed(2)
+        model = reference_encoder().cuda()
+        model.train()
+        eng = model.engine()
+        eng.rows_hint = hint
+        p, buf = eng.make_pass(model, q, training=True, keep=keep)
+        eng.forward([p])
+        eng.backward(model, p, buf, dfeat)
+        out.append((buf["feat"].clone(), [p_.grad.clone() for p_ in model.parameters() if p_.grad is not None]))
+    for feat, grads in out[1:]:
+        torch.testing.assert_close(feat, out[0][0], rtol=1e-5, atol=1e-6)
+        for a, b in zip(grads, out[0][1]):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6 + 1e-5 * float(b.abs().max()))
+
+
 def test_bf16_head_on_the_device_at_full_size():
     """GCC_NCE_BF16 at (B 256, K 16384): equals the oracle evaluated on bf16-rounded operands (loss, lse, dq); the distance to
     the fp32 mode is printed -- it is what rules the mode out for the 1e-3 parity bar (f32 stays the default)."""
