@@ -11,7 +11,12 @@ constexpr int kLdt = 72;            // LDS row stride in floats (conflict-free d
 constexpr int kThreads = 256;
 constexpr int kGridX = 768;         // tiles are grid-strided
 constexpr int kMaxPass = 2;
-constexpr int kRep = 32;            // replicas of every atomically accumulated statistics row: a block adds to
+#ifndef GCC_KREP
+#define GCC_KREP GCC_GIN_STAT_REPLICAS   // 16.  Every consumer kernel's workgroups each read ALL replicas of the statistics they normalise
+#endif                                   // with (2 x 64 doubles per replica and BatchNorm): at 32 that was 32-64 KiB per workgroup next to a
+                                         // 16 KiB tile.  Training stream alone: 0.569 ms (32), 0.558 (16), 0.553 (8, but the producers'
+                                         // atomics start to queue: gin_stat 5.0 -> 5.4 us) -- scripts/gpu/r6_call.sh r6c8 / r6c9
+constexpr int kRep = GCC_KREP;      // replicas of every atomically accumulated statistics row: a block adds to
                                     // copy (blockIdx.x % kRep), consumers sum the copies -- ~730 workgroups hitting the
                                     // same 8 cache lines with fp64 atomics cost 20-40 us per kernel (rocprof, round 1)
 
@@ -88,7 +93,8 @@ struct BnDev {
 struct RepReq { double v[kRep / 2]; };
 __device__ __forceinline__ RepReq rep_request(const double *rep, int stride)
 {
-    static_assert(kThreads == 256 && kRep % 16 == 0, "two halves of the replicas, batches of 8");
+    static_assert(kThreads == 256 && (kRep == 8 || kRep % 16 == 0), "two halves of the replicas, batches of 8 (4 at kRep 8)");
+    static_assert(kRep <= GCC_GIN_STAT_REPLICAS, "callers size the statistics buffers by the header's constant");
     const int t = (int)threadIdx.x, p = t & 127, g = t >> 7;
     const double *src = rep + (int64_t)(g * (kRep / 2)) * stride + p;
     RepReq r;
@@ -99,8 +105,9 @@ __device__ __forceinline__ RepReq rep_request(const double *rep, int stride)
 __device__ __forceinline__ double rep_sum(const RepReq &r)
 {
     double acc = 0.0;
+    if (kRep / 2 == 4) return (r.v[0] + r.v[1]) + (r.v[2] + r.v[3]);
 #pragma unroll
-    for (int b = 0; b < kRep / 2; b += 8)
+    for (int b = 0; b + 7 < kRep / 2; b += 8)
         acc += ((r.v[b] + r.v[b + 1]) + (r.v[b + 2] + r.v[b + 3])) + ((r.v[b + 4] + r.v[b + 5]) + (r.v[b + 6] + r.v[b + 7]));
     return acc;
 }

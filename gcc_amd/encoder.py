@@ -16,7 +16,7 @@ import torch.nn as nn
 from . import _cabi
 
 H = _cabi.GIN_HIDDEN
-STATS_REPLICAS = 32        # kRep of gcc_amd/csrc/encoder_common.h
+STATS_REPLICAS = 16        # kRep of gcc_amd/csrc/encoder_common.h (GCC_GIN_STAT_REPLICAS)
 
 
 # ---------------------------------------------------------------------------

@@ -257,7 +257,7 @@ void gcc_gin_debug_ticks(long long *device_ticks64);
  * All arithmetic is fp32 (f32 MFMA), BatchNorm / pooling sums accumulate in fp64. */
 #define GCC_GIN_MAX_LAYERS 8     /* GIN message-passing layers = num_layers - 1 (train.py:79 -> 4) */
 #define GCC_GIN_HIDDEN 64
-#define GCC_GIN_STAT_REPLICAS 32  /* atomically accumulated rows are spread over this many copies */
+#define GCC_GIN_STAT_REPLICAS 16  /* atomically accumulated rows are spread over this many copies (32 until ABI 3) */
 
 typedef struct gcc_bn {          /* torch.nn.BatchNorm1d(64) */
     const float *weight, *bias;  /* device [64]                                           */

@@ -47,8 +47,8 @@ def test_forward_tile_kernels_request_their_prologue_as_one_batch():
         # no load is requested after the first wait (the waits of one batch may come in steps: vmcnt(n) counting down)
         head = ch[k].split("B", 1)[0]
         assert "W" in head and "L" not in head[head.index("W"):], (k, ch[k])
-        assert re.search(r"L([89]|[1-9][0-9])", head), (k, ch[k])              # the replica loads come in runs (16, or 8 + 8 around scalar loads)
-        assert sum(int(n or 1) for n in re.findall(r"L(\d*)", head)) >= 16 + 4 + 4, (k, ch[k])   # replicas + BatchNorm numbers + the tile's rows
+        assert re.search(r"L([89]|[1-9][0-9])", head), (k, ch[k])              # the replica loads (kRep / 2 = 8 per thread) are one run
+        assert sum(int(n or 1) for n in re.findall(r"L(\d*)", head)) >= 8 + 4 + 4, (k, ch[k])   # replicas + BatchNorm numbers + the tile's rows
     # no load-wait-load-wait ladders anywhere in the forward kernels' listings
     for k, v in ch.items():
         assert "LWLWLWLW" not in v, (k, v)
@@ -58,9 +58,9 @@ def test_backward_tile_kernels_have_a_one_batch_fast_path():
     ch = _chains("encoder_bwd.hip")
     # the fast arm (statistics' totals present) of the kernels with two coefficient tables: one run of requests -- two totals +
     # weight + bias per table, the backward sums' 16 replicas where the kernel has them, the node count, and (round 6) the
-    # first tile's rows: 8 + 4 graph ids + row pointer + 8 rows in gin_bwd_c, 8 + 16 + 8 rows in gin_bwd_b, ...
+    # first tile's rows: 8 + 4 graph ids + row pointer + 8 rows in gin_bwd_c, 8 + 8 replicas + 8 rows in gin_bwd_b, ...
     assert re.search(r"L2[0-9]WB", ch["gin_bwd_c_kernel"]), ch["gin_bwd_c_kernel"]
-    assert re.search(r"L3[0-9]WB", ch["gin_bwd_b_kernel"]), ch["gin_bwd_b_kernel"]
-    assert re.search(r"L3[0-9]WB", ch["gin_bwd_lin_kernelILb1E"]) and re.search(r"L2[0-9]WB", ch["gin_bwd_lin_kernelILb0E"])
+    assert re.search(r"L2[0-9]WB", ch["gin_bwd_b_kernel"]), ch["gin_bwd_b_kernel"]
+    assert re.search(r"L2[0-9]WB", ch["gin_bwd_lin_kernelILb1E"]) and re.search(r"L2[0-9]WB", ch["gin_bwd_lin_kernelILb0E"])
     for k, v in ch.items():
         assert "LWLWLWLW" not in v, (k, v)
