@@ -135,7 +135,13 @@ struct InLaunch { InArgs p[kMaxPass]; long long *ticks; };
 #define GIN_DBG_SKIP 0       // timing experiments only (wrong results): 1 no pooling, 2 no statistics flush, 4 no gather
 #endif
 static long long *g_gin_ticks = nullptr;   // diagnostics (gcc_gin_debug_ticks)
-#define GIN_TICK(ph) do { if (L.ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&L.ticks[(a.first ? 0 : 16) + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
+// phase ticks (diagnostics, tools/gin_phases.py): ticks[kind][phase 0..15][workgroup 0..2047] (workgroup = blockIdx.y * 1024 + blockIdx.x),
+// kind 0 = gin_in first layer, 1 = gin_in other layers, 2 = gin_mid.  Every workgroup ADDS its own durations to its own slots with
+// plain read-modify-writes of thread 0 (launches of one stream do not overlap): no contention.  (Rounds 1-5 used one atomic per
+// phase on a shared slot: 780 workgroups queuing on one address cost more than the phases they timed.)  Phase 15 counts tiles.
+constexpr int kTickWgs = 2048, kTickPhases = 16;
+#define TICK_SLOT(kind, ph) L.ticks[((kind) * kTickPhases + (ph)) * kTickWgs + (int)blockIdx.y * 1024 + (int)blockIdx.x]
+#define GIN_TICK(ph) do { if (L.ticks && tid == 0) { const long long now_ = device_ticks(); TICK_SLOT(a.first ? 0 : 1, ph) += now_ - tick_; tick_ = now_; } } while (0)
 
 // (3 workgroups per CU by LDS -- 48.8 KiB with the staged weight -- so up to 168 registers are free: 8 gathered rows in flight)
 #ifndef GIN_IN_PER_CU
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(kThreads, GIN_IN_PER_CU) void gin_in_kernel(InLaunc
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
         const int tile0 = tw.ti * kTile;
         const int nrows = min(kTile, N - tile0);
-        if (L.ticks && tid == 0) atomicAdd((unsigned long long *)&L.ticks[(a.first ? 0 : 16) + 15], 1ull);
+        if (L.ticks && tid == 0) TICK_SLOT(a.first ? 0 : 1, 15) += 1;
         // 1. own rows; the tile's row pointers and graph ids ride in the same round trip (the pooling and the gather
         //    would otherwise each start with one of their own)
         {
@@ -282,7 +288,8 @@ struct MidArgs {
     int32_t hid;              // columns of w1 (gcc_gin_weights.hidden: the true hidden width, <= 64)
     int32_t cap;              // gcc_gin_pass.node_cap
 };
-struct MidLaunch { MidArgs p[kMaxPass]; };
+struct MidLaunch { MidArgs p[kMaxPass]; long long *ticks; };   // ticks: diagnostics (kind 2)
+#define MID_TICK(ph) do { if (L.ticks && tid == 0) { const long long now_ = device_ticks(); TICK_SLOT(2, ph) += now_ - tick_; tick_ = now_; } } while (0)
 
 __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
 {
@@ -290,6 +297,7 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
     __shared__ __attribute__((aligned(16))) float red[4 * 2 * H];    // (also the fp64 scratch of bn_table)
     const MidArgs &a = L.p[blockIdx.y];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = tid >> 6, j = lane & 15, q = lane >> 4;
+    long long tick_ = L.ticks ? device_ticks() : 0;
     __shared__ float Wl[H * kLdt];
     const WStage wst = stage_weights_request(a.w1, a.hid);   // in flight with N and the statistics
     __shared__ float taba[2 * H];
@@ -308,10 +316,13 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
     const int N = a.node_off[a.B];                           // (requested last: the wait for it is the wait for all)
     SCHED_FENCE();
     if (no_tiles(N)) return;
+    MID_TICK(0);                                              // node count (scalar) arrived
     bn_table_finish(taba, ra, (double)N, a.eps, a.training, (double *)red);
+    MID_TICK(1);                                              // statistics arrived, table computed
     stage_weights_store(Wl, wst, a.hid);
     if (tid < H) bl[tid] = b_own;
     __syncthreads();
+    MID_TICK(2);                                              // weights in LDS
     Aff4 aa[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) aa[c] = aff4_from_table(taba, 16 * c + 4 * q);
@@ -325,10 +336,15 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
             const F4 z = {0.f, 0.f, 0.f, 0.f};
             xb[c] = valid ? affine_relu(xb[c], aa[c]) : z;                                      // gin.py:115
         }
+        if (L.ticks && tid == 0) TICK_SLOT(2, 15) += 1;
+        MID_TICK(3);                                          // the tile's rows arrived, normalised
         linear_rows16_lds_store_stats(xb, Wl, bl, a.z2, row, valid, &red[wv * 2 * H]);      // gin.py:116
+        MID_TICK(4);                                          // products, stores issued
         __syncthreads();
+        MID_TICK(5);                                          // barrier (waits for the stores' acknowledgement)
         flush_stats(red, a.stats_b);
         lds_barrier();
+        MID_TICK(6);
     }
 }
 
@@ -667,6 +683,7 @@ extern "C" int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gc
                           p.z2[l], stats_of(p, l, 1), p.batch_size, p.training,
                           p.w.bn_eps, hidden_of(p.w), (int32_t)p.node_cap};
             }
+            L.ticks = g_gin_ticks;
             hipLaunchKernelGGL(gin_mid_kernel, grid, block, 0, s, L);
         }
         {

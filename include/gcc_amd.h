@@ -244,7 +244,8 @@ void gcc_posemb_set_fork(int32_t mode);
  * out of bounds. */
 #define GCC_POSEMB_TICK_CLASSES 8
 void gcc_posemb_debug_ticks(long long *device_ticks64);
-/* the same for gin_in_kernel: device int64[2][16] ([0] = first layer, [1] = others; [15] = tiles) */
+/* the same for gin_in_kernel / gin_mid_kernel: device int64[3][16][2048] -- [kind 0 = gin_in first layer, 1 = gin_in other layers,
+ * 2 = gin_mid][phase; 15 = tiles][workgroup = pass * 1024 + blockIdx.x]: every workgroup adds to its own slots (no shared counter) */
 void gcc_gin_debug_ticks(long long *device_ticks64);
 
 /* ------------------------------------------------------------ GIN encoder ---

@@ -1,4 +1,5 @@
-"""Per-phase wall-clock ticks of gin_in_kernel (training stream alone, placeholder positional embedding)."""
+"""Per-phase wall-clock ticks of gin_in_kernel and gin_mid_kernel (training stream alone, placeholder positional embedding): mean over
+the workgroups that had a tile, us per tile; every workgroup times itself into its own slots."""
 import sys
 import torch
 
@@ -29,15 +30,20 @@ for i in range(20):
     trainer.step(i, 0.005)
 torch.cuda.synchronize()
 lib = _cabi.load()
-ticks = torch.zeros(32, dtype=torch.int64, device=dev)
+ticks = torch.zeros(3 * 16 * 2048, dtype=torch.int64, device=dev)
 lib.gcc_gin_debug_ticks(ticks.data_ptr())
 n = 20
 for i in range(n):
     trainer.step(20 + i, 0.005)
 torch.cuda.synchronize()
 lib.gcc_gin_debug_ticks(None)
-t = ticks.cpu().numpy().reshape(2, 16)
-names = ["bn-table", "own-rows", "pool", "gather", "agg-store", "mfma+epilogue", "flush-stats"]
-for r, nm in enumerate(["first layer", "other layers"]):
-    tiles = max(int(t[r, 15]), 1)
-    print(f"{nm:13s} tiles {tiles:7d} | " + "  ".join(f"{x} {t[r, i] / 100.0 / tiles:6.2f}us" for i, x in enumerate(names)))
+t = ticks.cpu().numpy().reshape(3, 16, 2048).astype(float)
+names = {0: ["bn-table", "own-rows", "pool", "gather", "agg-store", "mfma+epilogue", "flush-stats"],
+         2: ["node-count", "statistics+table", "weights->LDS", "rows+normalise", "products+stores", "barrier", "flush-stats"]}
+names[1] = names[0]
+for kind, nm in enumerate(["gin_in first layer", "gin_in other layers", "gin_mid"]):
+    tiles = t[kind, 15]
+    live = tiles > 0                                   # workgroups that had a tile
+    per = t[kind, :7][:, live] / tiles[live] / 100.0   # us per tile and workgroup (100 MHz clock)
+    print(f"{nm:20s} workgroups {int(live.sum()):5d} | " + "  ".join(f"{x} {per[i].mean():6.2f}" for i, x in enumerate(names[kind]))
+          + f" | sum {per.sum(axis=0).mean():6.2f} us (slowest workgroup {per.sum(axis=0).max():6.2f})")
