@@ -90,6 +90,28 @@ static inline f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c)
     return d;
 }
 
+// v_mfma_f64_16x16x4_f64: A / B as the f32 form (one f64 per lane); C / D: c/d[r] = C[(l>>4) + 4 * r][l&15] -- NOT the f32 row map
+// (cdna_hip_programming.md, "f64 MFMA does NOT use these maps")
+typedef double f64x4 __attribute__((vector_size(32)));
+static inline f64x4 mfma_16x16x4_f64(double a, double b, f64x4 c)
+{
+    struct AB { double a, b; } ab = {a, b};
+    const unsigned char *t = hipemu::wave_gather(&ab, sizeof(ab), 0xF64Au);
+    int l = lane_id();
+    f64x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) + 4 * r, col = l & 15;
+        double acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            AB x = hipemu::gather_at<AB>(t, k * 16 + row);
+            AB y = hipemu::gather_at<AB>(t, k * 16 + col);
+            acc = fma(x.a, y.b, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+
 // D(16x16) = A(16x32) * B(32x16) + C with bf16 operands: lane l passes 8 bf16 of row (l & 15) of A and of COLUMN
 // (l & 15) of B, both for the same 8 values of k (the (l >> 4)-th group); c/d as mfma_16x16x4_f32.
 typedef unsigned u32x4 __attribute__((vector_size(16)));
@@ -243,6 +265,14 @@ __device__ __forceinline__ int wave_last(int v) { return __builtin_amdgcn_readla
 __device__ __forceinline__ f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f64_16x16x4_f64 (lane l: a = A[l&15][l>>4], b = B[l>>4][l&15]; c/d[r] = C[(l>>4) + 4 r][l&15]): fp64 products and
+// accumulation on the matrix cores -- 128 FLOP per cycle and CU on gfx950, the vector fp64 rate, but without a register / LDS
+// operand fetch per FMA (the eigensolver's Gram matrices: gcc_amd/csrc/posemb.hip)
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f64x4 mfma_16x16x4_f64(double a, double b, f64x4 c)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 // v_mfma_f32_16x16x32_bf16: lane l passes 8 bf16 of row (l & 15) of A and of column (l & 15) of B for the k-group
 // (l >> 4); the products pair element e of group g of A with element e of group g of B, so any operand layout

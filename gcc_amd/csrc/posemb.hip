@@ -3104,58 +3104,44 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
                  + (rr ? 2ull : 1ull) * 2ull * nr_ * P * P + 2ull * P * P * P
                  + (rr ? 4ull * P * P * P : 0ull) + (fullrr ? 2ull : 1ull) * 2ull * nr_ * P * P;
         PHASE_TICK(1);                                                   // sparse products
-        // ---- G = X^T X (and K = X^T W), fp64 accumulation.  Tiles of 32 rows of X and of W go through LDS (the slab):
-        //      one coalesced 16-byte load per thread and tile, requested a tile ahead, instead of a chain of L2 round trips
+        // ---- G = X^T X (and K = X^T W), fp64 products and accumulation ON THE MATRIX CORES (round 6): a 16 x 16 block of G (and
+        //      the same block of K) per wave, v_mfma_f64_16x16x4_f64 over four rows of the block per instruction.  Both operands
+        //      of a step are 16-float segments of the same four rows of X (W): lane (j, q) loads X[r0 + q][16 bi + j] and
+        //      X[r0 + q][16 bj + j] straight from the L2-resident block -- no LDS tile, no barrier inside the loop.  The products
+        //      of two fp32 values are exact in fp64, so this is the sum the vector loop formed (sum order aside).  (Rounds 2-5:
+        //      tiles through LDS, per thread a strip of E entries, one LDS read per 4-8 fp64 FMAs: 113 us of a 1,236 us item.)
         {
-            double gacc[E], kacc[E];
+            constexpr int NB = P / 16;                            // blocks per side: 4 (P = 64) / 2 (P = 32)
+            constexpr int kUn = 4;                                // steps (of four rows) requested together
+            if (wv < NB * NB) {                                   // (P = 32: four of the sixteen waves)
+                const int bi = wv / NB, bj = wv % NB, j = lane & 15, q = lane >> 4;
+                const f64x4 z4 = {0.0, 0.0, 0.0, 0.0};
+                f64x4 ga[2] = {z4, z4}, ka[2] = {z4, z4};         // two accumulators per product: consecutive steps do not wait for each other
+                const float *xa_ = XA + 16 * bi + j, *xb_ = XA + 16 * bj + j, *wb_ = XB + 16 * bj + j;
+                for (int r0 = 0; r0 < nr; r0 += 4 * kUn) {
+                    float av[kUn], bv[kUn], wv_[kUn];
 #pragma unroll
-            for (int u = 0; u < E; ++u) gacc[u] = kacc[u] = 0.0;
-            constexpr int TR = (kChThreads / 2) / TPQ;           // rows of a tile: 32 (P = 64) / 64 (P = 32); TR * P = 2048 floats
-            float *tx = slab, *twv = slab + TR * P;              // [TR][P] each
-            const bool isw = tid >= kChThreads / 2;
-            const int lt = tid & (kChThreads / 2 - 1);            // float4 index inside a tile: row lt / TPQ, quad lt % TPQ
-            // with a Ritz step the second half of the workgroup stages W's tile (K = X^T W); without one it stages the NEXT
-            // tile of X, so a barrier pair covers 2 TR rows (the loop is bound by its barriers and the L2 latency of a tile)
-            const float *gsrc = (isw && rr) ? XB : XA;
-            const int step = rr ? TR : 2 * TR, toff = (isw && !rr) ? TR : 0;
-            auto fetch = [&](int t0) -> float4 {
-                const int r = t0 + toff + lt / TPQ;
-                return r < nr ? *(const float4 *)(gsrc + (int64_t)r * P + 4 * (lt % TPQ)) : make_float4(0.f, 0.f, 0.f, 0.f);
-            };
-            float4 nxt = fetch(0);
-            for (int t0 = 0; t0 < nr; t0 += step) {
-                *(float4 *)((isw ? twv : tx) + 4 * lt) = nxt;
-                __syncthreads();
-                if (t0 + step < nr) nxt = fetch(t0 + step);
-                const int rows = min(step, nr - t0);             // (without a Ritz step tx and twv are one tile of 2 TR rows)
-                if (rr) {
-                    for (int r = 0; r < rows; ++r) {
-                        const double xi = (double)tx[r * P + mi];
-                        if constexpr (E == 4) {
-                            const float4 xj = *(const float4 *)(tx + r * P + mj);
-                            const float4 wj = *(const float4 *)(twv + r * P + mj);
-                            gacc[0] += xi * xj.x; gacc[1] += xi * xj.y; gacc[2] += xi * xj.z; gacc[3] += xi * xj.w;
-                            kacc[0] += xi * wj.x; kacc[1] += xi * wj.y; kacc[2] += xi * wj.z; kacc[3] += xi * wj.w;
-                        } else {
-                            gacc[0] += xi * tx[r * P + mj];
-                            kacc[0] += xi * twv[r * P + mj];
-                        }
+                    for (int u = 0; u < kUn; ++u) {               // (rows past the end read row nr - 1 and are zeroed below)
+                        const int64_t ro = (int64_t)min(r0 + 4 * u + q, nr - 1) * P;
+                        av[u] = xa_[ro];
+                        bv[u] = xb_[ro];
+                        wv_[u] = rr ? wb_[ro] : 0.f;              // (block-uniform)
                     }
-                } else {
-                    for (int r = 0; r < rows; ++r) {
-                        const double xi = (double)tx[r * P + mi];
-                        if constexpr (E == 4) {
-                            const float4 xj = *(const float4 *)(tx + r * P + mj);
-                            gacc[0] += xi * xj.x; gacc[1] += xi * xj.y; gacc[2] += xi * xj.z; gacc[3] += xi * xj.w;
-                        } else {
-                            gacc[0] += xi * tx[r * P + mj];
-                        }
+#pragma unroll
+                    for (int u = 0; u < kUn; ++u) {
+                        const bool in = r0 + 4 * u + q < nr;
+                        const double a_ = in ? (double)av[u] : 0.0;
+                        ga[u & 1] = mfma_16x16x4_f64(a_, (double)bv[u], ga[u & 1]);
+                        if (rr) ka[u & 1] = mfma_16x16x4_f64(a_, (double)wv_[u], ka[u & 1]);
                     }
                 }
-                __syncthreads();
-            }
 #pragma unroll
-            for (int u = 0; u < E; ++u) { G[mi * P + mj + u] = gacc[u]; K[mi * P + mj + u] = kacc[u]; }
+                for (int r = 0; r < 4; ++r) {                     // c/d[r] = C[q + 4 r][j]
+                    const int row = 16 * bi + q + 4 * r, col = 16 * bj + j;
+                    G[row * P + col] = ga[0][r] + ga[1][r];
+                    K[row * P + col] = ka[0][r] + ka[1][r];
+                }
+            }
         }
         __syncthreads();
         PHASE_TICK(5);                                           // Gram matrices
@@ -3280,21 +3266,33 @@ __global__ __launch_bounds__(kChThreads) void posemb_cheb_kernel(ChebArgs ca)
                 __syncthreads();
             }
             if (rr) {
-                // T1 = Linv K^ (into G), H = T1 Linv^T (into K)
+                // T1 = Linv K^ (into G), H = T1 Linv^T (into K): two P x P x P fp64 products on the matrix cores (round 6), a
+                // 16 x 16 block per wave, operands from the fp64 matrices in LDS.  Linv is lower triangular and its upper triangle
+                // holds scratch of the doubling levels: entries above the diagonal are read as zero, blocks above it are skipped.
+                // (Per thread E entries with a dot product of up to P terms each before: ~10 us per product.)
+                constexpr int NB = P / 16;
+                const int bi = wv / NB, bj = wv % NB, jl = lane & 15, ql = lane >> 4;
+                const f64x4 z4 = {0.0, 0.0, 0.0, 0.0};
+                if (wv < NB * NB) {
+                    f64x4 acc = z4;
+                    for (int k0 = 0; k0 < 16 * (bi + 1); k0 += 4) {      // T1[i][j] = sum_{q <= i} Linv[i][q] K[q][j]
+                        const int ii = 16 * bi + jl, kk = k0 + ql;
+                        const double a_ = kk <= ii ? Li[ii * P + kk] : 0.0;
+                        acc = mfma_16x16x4_f64(a_, K[kk * P + 16 * bj + jl], acc);
+                    }
 #pragma unroll
-                for (int u = 0; u < E; ++u) {
-                    const int j = j4 + u;
-                    double acc = 0.0;
-                    for (int q = 0; q <= i; ++q) acc += Li[i * P + q] * K[q * P + j];
-                    G[i * P + j] = acc;
+                    for (int r = 0; r < 4; ++r) G[(16 * bi + ql + 4 * r) * P + 16 * bj + jl] = acc[r];
                 }
                 __syncthreads();
+                if (wv < NB * NB) {
+                    f64x4 acc = z4;
+                    for (int k0 = 0; k0 < 16 * (bj + 1); k0 += 4) {      // H[i][j] = sum_{q <= j} T1[i][q] Linv[j][q]
+                        const int jj = 16 * bj + jl, kk = k0 + ql;
+                        const double b_ = kk <= jj ? Li[jj * P + kk] : 0.0;
+                        acc = mfma_16x16x4_f64(G[(16 * bi + jl) * P + kk], b_, acc);
+                    }
 #pragma unroll
-                for (int u = 0; u < E; ++u) {
-                    const int j = j4 + u;
-                    double acc = 0.0;
-                    for (int q = 0; q <= j; ++q) acc += G[i * P + q] * Li[j * P + q];
-                    K[i * P + j] = acc;
+                    for (int r = 0; r < 4; ++r) K[(16 * bi + ql + 4 * r) * P + 16 * bj + jl] = acc[r];
                 }
                 __syncthreads();
             }
