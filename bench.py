@@ -56,6 +56,9 @@ def parse_args(argv=None):
     ap.add_argument("--mode", choices=["train", "sampler", "sample-ready", "e2e"], default="train")
     ap.add_argument("--batch-size", type=int, default=256)
     ap.add_argument("--nce-k", type=int, default=16384)
+    ap.add_argument("--hidden-size", type=int, default=64,
+                    help="train.py:93 (GraphEncoder output / hidden width, MemoryMoCo feature size).  Above 64 the step runs on the "
+                         "any-width kernels (csrc/ginx.hip) launch by launch; the headline config is 64")
     ap.add_argument("--rw-hops", type=int, default=256)
     ap.add_argument("--restart-prob", type=float, default=0.8)
     ap.add_argument("--nodes", type=int, default=None, help="default 1,000,000 (train) / 10,000,000 (sampler)")
@@ -136,8 +139,11 @@ def workload_name(args, world, v, e):
         return (f"BASELINE configs[0] on G1: E2E K={args.batch_size - 1} (in-batch negatives, NCESoftmaxLossNS) bsz={args.batch_size} "
                 f"hid=64 rw_hops={args.rw_hops} restart={args.restart_prob}, {graph}, {world}xMI355X")
     tag = ""
-    if (args.nodes, args.edges, args.batch_size, args.nce_k, args.rw_hops) == (1_000_000, 10_000_000, 256, 16384, 256):
+    hs = getattr(args, "hidden_size", 64)
+    if (args.nodes, args.edges, args.batch_size, args.nce_k, args.rw_hops, hs) == (1_000_000, 10_000_000, 256, 16384, 256, 64):
         tag = "BASELINE configs[1]: " if world == 1 else ("BASELINE configs[2]: " if world == 8 else "BASELINE configs[1] per GPU: ")
+    elif hs != 64:
+        tag = f"--hidden-size {hs} (train.py:93; not a BASELINE config): "
     return (f"{tag}MoCo K={args.nce_k} m=0.999 bsz={args.batch_size}/GPU (global {args.batch_size * world}) rw_hops={args.rw_hops} "
             f"restart={args.restart_prob}, {graph}, {world}xMI355X")
 
@@ -310,6 +316,15 @@ def cpu_baseline(rp, ci, args):
     if res is None:                              # --mode sample-ready: the data pipeline IS the workload
         top = shaped[best]
         res = dict(value=top.get("value"), unit="subgraphs/s", cores=top.get("cores"), kind="port", sample=top.get("sample"))
+    elif (shaped[best].get("value") or 0.0) > (res.get("value") or 0.0):
+        # `value` is the STRONGEST CPU leg measured here (round 5's line carried the pipelined full-step port, 1.5 k/s, next to a
+        # reference-shaped data pipeline that delivered 4.3 k/s with 64 workers): the reference-shaped pipeline alone -- no training
+        # step -- bounds what the reference's CPU path can deliver from above; the full-step port stays in `full_step_port`
+        top = shaped[best]
+        res = dict(value=top.get("value"), unit="subgraphs/s", cores=top.get("cores"), kind="port",
+                   sample=(top.get("sample") or "") + " -- the strongest CPU leg of this run (data pipeline only, an upper bound of the "
+                                                       "reference-shaped CPU path; the pipelined full-step port: `full_step_port`)",
+                   value_is="reference_shaped." + best, full_step_port=res)
     res["reference_shaped"] = shaped
     return res
 
@@ -408,28 +423,72 @@ def parity_step(args, graph, dev):
     from tests.headline_step_check import check_e2e_step, check_moco_step
 
     B = args.batch_size
+    HS = getattr(args, "hidden_size", 64)
     torch.manual_seed(12345)
     enc_kw = dict(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
-                  freq_embedding_size=16, degree_embedding_size=16, output_dim=64, node_hidden_dim=64,
-                  edge_hidden_dim=64, num_layers=5, num_step_set2set=6, num_layer_set2set=3, norm=True,
+                  freq_embedding_size=16, degree_embedding_size=16, output_dim=HS, node_hidden_dim=HS,
+                  edge_hidden_dim=HS, num_layers=5, num_step_set2set=6, num_layer_set2set=3, norm=True,
                   gnn_model="gin", degree_input=True)
     smp = DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=2)
     pe = DevicePosEmb(B, smp.node_cap, 32, device=dev, seed=args.run_seed, num_buffers=2, max_views=2)
     model = GraphEncoder(**enc_kw).to(dev)
-    masks = [(torch.rand(5, B, 64) >= 0.5).float().to(dev).contiguous() for _ in range(2)]
+    masks = [(torch.rand(5, B, max(HS, 64)) >= 0.5).float().to(dev).contiguous() for _ in range(2)]
     if args.mode == "e2e":
         tr = E2ETrainStep(model, smp, pe, prefetch=False)
         rep = check_e2e_step(tr, model, 0.005, masks[0], masks[1], sync=torch.cuda.synchronize, step_id=7)
     else:
         ema = GraphEncoder(**enc_kw).to(dev)
         ema.load_state_dict(model.state_dict())
-        contrast = MemoryMoCo(64, None, args.nce_k, 0.07, use_softmax=True).to(dev)
+        contrast = MemoryMoCo(HS, None, args.nce_k, 0.07, use_softmax=True).to(dev)
         tr = MoCoTrainStep(model, ema, contrast, smp, pe, prefetch=False)
         rep = check_moco_step(tr, model, ema, contrast, 0.005, masks[0], sync=torch.cuda.synchronize, step_id=7)
     rep.pop("_graphs", None)
     tr.check_status(strict_posemb=True)
     rep["checked"] = "one fused step vs oracle/encoder.py (fp32 and float64) on the same sampled batch: embeddings, loss, prob, grad norm, every gradient, Adam update, EMA, running statistics, queue -- all inside 1e-3 (tests/headline_step_check.py)"
     return rep
+
+
+def wide_step_roofline(trainer, last, args, torch, reps=5):
+    """--hidden-size above 64: the step's training-stream launches (encoder forward of both views, head, encoder backward, clip +
+    Adam + EMA, enqueue) replayed on the last timed batch with the producers idle, timed with events on the step's stream; against
+    the exact-f32 MFMA peak the FLOPs of every Linear (forward, data gradient, weight gradient: the strided 64 x 64 GEMM of
+    csrc/ginx.hip, v_mfma_f32_16x16x4_f32).  The fraction is a LOWER bound of the GEMM kernel's own rate: the interval also holds
+    the step's ~230 other launches (gathers, BatchNorm passes, column sums)."""
+    q, k = last["graph_q"], last["graph_k"]
+    B, W, K = args.batch_size, args.hidden_size, args.nce_k
+    nq, nk = int(q.node_off[B].item()), int(k.node_off[B].item())
+    L = trainer.L
+    d_in = 32 + 16 + 1
+    lin = lambda n: 2.0 * n * (d_in * W + W * W + (L - 1) * 2 * W * W)        # linears.0 / .1 of every layer, one pass over n rows
+    pred = lambda: 2.0 * B * (d_in * W + L * W * W)                            # linears_prediction on the pooled rows
+    fwd_q, fwd_k = lin(nq) + pred(), lin(nk) + pred()
+    head = 2.0 * B * K * W * 2                                                  # logits + d loss / d q
+    flops = fwd_q + fwd_k + 2.0 * fwd_q + head                                  # backward of q: data + weight gradient of every Linear
+    st = trainer.main if trainer.main is not None else torch.cuda.current_stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        raw = st.cuda_stream
+        for _ in range(2):
+            segs, _res = trainer._body_wide(q, k, None, {}, raw)
+            for _c, fn in segs:
+                fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            segs, _res = trainer._body_wide(q, k, None, {}, raw)
+            for _c, fn in segs:
+                fn()
+        e1.record(st)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    ach = flops / (ms * 1e-3) / 1e12
+    return dict(bound="mfma", kernel="ginx_gemm_kernel (every Linear of the any-width encoder and head: forward, data gradient, weight gradient)",
+                achieved=ach, peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / F32_MFMA_PEAK_TFLOPS, traffic=None,
+                gemm_gflop_per_step=flops / 1e9, training_stream_ms_isolated=ms, nodes_q=nq, nodes_k=nk, hidden=W,
+                dominant_by="FLOPs: at width 256 the Linears are 94 GFLOP per step against < 1 GFLOP of everything else",
+                note="achieved = GEMM FLOPs of a step / the step's whole training-stream interval (isolated, producers idle, HIP events on "
+                     "the step's stream): a lower bound of the GEMM kernel's own rate.  The kernel is a plain 64 x 64 tile with scalar LDS "
+                     "operand loads, one launch per operator (DESIGN 4f): the any-width path is a correctness path first")
 
 
 def sampler_source_hash():
@@ -511,8 +570,15 @@ def solver_roofline(pe_probe):
     total = sum(v["cu_ms_per_item"] * v["items"] for v in cls.values()) / 1e3
     ach = c["gflop"] / cu_s / 1e3 if cu_s > 0 else 0.0
     peak = F32_PER_CU_GFLOPS / 1e3
+    # the same FLOPs over the kernel's WALL time share of the call against the whole chip (what a reader of `unit: TFLOP/s` expects
+    # next to a per-CU fraction): the class's launch keeps `workgroups` CUs busy for cu_s / workgroups seconds
+    wall_s = pe_probe.get("call_ms", 0.0) / 1e3
     return dict(bound="mfma", kernel=SOLVER_KERNELS.get(name, name), solver_class=name, achieved=ach, peak=peak, unit="TFLOP/s",
-                frac=ach / peak, traffic=None, items=c["items"], cu_ms_per_item=c["cu_ms_per_item"],
+                frac=ach / peak, peak_note="ONE compute unit's exact-f32 rate (157.3 TFLOP/s / 256): a solver workgroup owns one CU",
+                frac_of_chip=(c["gflop"] / 1e3 / wall_s / F32_MFMA_PEAK_TFLOPS) if wall_s > 0 else None,
+                frac_of_chip_note="the class's executed FLOPs over the WALL time of the whole multi-view eigensolver call (all classes "
+                                  "run side by side in it) against the chip's 157.3 TFLOP/s",
+                traffic=None, items=c["items"], cu_ms_per_item=c["cu_ms_per_item"],
                 share_of_solver_cu_time=cu_s / total if total > 0 else None,
                 note="f32 FLOP-bound latency chains, not an HBM stream (the solvers move < 30 GB/s: profiles/r4_posemb_traffic.txt): "
                      "executed f32 FLOPs of the class / its workgroups' residency, against the exact-f32 MFMA/vector rate of the one CU a "
@@ -786,13 +852,17 @@ def main():
         samplers = [DeviceRWRSampler(graph, B, run_seed=args.run_seed, num_buffers=nbuf, scratch_entries=args.scratch_entries or None,
                                      edge_cap=args.edge_cap or None, max_steps=chunk, hub_degree=args.hub_degree) for _ in range(args.lanes)]
         sampler = samplers[0]
+        HS = args.hidden_size
+        wide = HS > 64
+        if wide and args.mode == "e2e":
+            raise SystemExit("--hidden-size above 64: --mode train (the wide MoCo step); the wide E2E step is the API path (train.py)")
         enc_kw = dict(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
-                      freq_embedding_size=16, degree_embedding_size=16, output_dim=64, node_hidden_dim=64,
-                      edge_hidden_dim=64, num_layers=5, num_step_set2set=6, num_layer_set2set=3, norm=True,
-                      gnn_model="gin", degree_input=True)                 # train.py:601-618 with default flags
+                      freq_embedding_size=16, degree_embedding_size=16, output_dim=HS, node_hidden_dim=HS,
+                      edge_hidden_dim=HS, num_layers=5, num_step_set2set=6, num_layer_set2set=3, norm=True,
+                      gnn_model="gin", degree_input=True)                 # train.py:601-618 with default flags (--hidden-size: :93)
         model, model_ema = GraphEncoder(**enc_kw).to(dev), GraphEncoder(**enc_kw).to(dev)
         model_ema.load_state_dict(model.state_dict())                     # moment_update(model, model_ema, 0), train.py:624
-        contrast = MemoryMoCo(64, None, args.nce_k, 0.07, use_softmax=True).to(dev)
+        contrast = MemoryMoCo(HS, None, args.nce_k, 0.07, use_softmax=True).to(dev)
         if args.posemb == "device":
             posembs = [DevicePosEmb(B, sampler.node_cap, 32, device=dev, seed=args.run_seed, num_buffers=nbuf,
                                     max_views=min(2 * chunk, 32)) for _ in range(args.lanes)]
@@ -809,7 +879,7 @@ def main():
         else:
             trainer = MoCoTrainStep(model, model_ema, contrast, sampler, posemb, world_size=world, rank=rank,
                                     lanes=lanes, depth=args.depth, chunk=chunk, reserved_cus=args.reserved_cus,
-                                    cu_layout=args.cu_layout, ahead=args.ahead, graph=False if args.no_graph else None,
+                                    cu_layout=args.cu_layout, ahead=args.ahead, graph=False if (args.no_graph or wide) else None,
                                     collectives=True if args.collectives else None)
             stages = ["seed-draw", "rwr-walk", "induce", "batch-pack", "pos-emb:" + posemb.kind, "gin-encoder q+k fwd",
                       "moco-infonce fwd", "infonce bwd", "gin-encoder bwd", "grad all-reduce" if (world > 1 or args.collectives) else "clip",
@@ -839,6 +909,8 @@ def main():
         # with graph replay the step's launches carry no event marks (they are one graph launch): the timed steps mark the
         # producers only and the in-step stage intervals come from a few eager steps after the clock
         graph_on = bool(getattr(trainer, "use_graph", False))
+        if wide:
+            names = ()                                                     # (the any-width engine records no in-step marks)
         profs = [dict(sampler=Prof(4), **({} if graph_on else {n: Prof(2) for n in names})) for _ in range(args.steps)]
         if args.posemb == "device":
             for p in profs:
@@ -853,6 +925,22 @@ def main():
         dt = time.perf_counter() - t0
         produced = (trainer.producer.launched - launched0) * chunk
         consumed = args.steps
+        # two more windows of the same length right after the clock (diagnostics: `value` comes from the first window alone): a
+        # 20-step window is 16 ms, and the line should say how much such a window moves from one to the next
+        windows = [dt / args.steps * 1e3]
+        nxt_step = first_timed + args.steps
+        if world == 1 and args.steps <= 64:
+            for _w in range(2):
+                torch.cuda.synchronize()
+                tw0 = time.perf_counter()
+                for i in range(args.steps):
+                    last = trainer.step(nxt_step + i, lr_at(nxt_step + i))
+                torch.cuda.synchronize()
+                windows.append((time.perf_counter() - tw0) / args.steps * 1e3)
+                nxt_step += args.steps
+        extra["ms_per_step_windows"] = windows
+        extra["ms_per_step_windows_note"] = "the timed window (= ms_per_step) and two more windows of --steps steps run right after it"
+        first_after = nxt_step
         extra["final_loss"] = float(last["loss"].item())
         extra["step_launch"] = ("hipGraph replay (one captured graph per ring slot)" if graph_on else "eager (launch by launch)") + \
             ("" if trainer.relaxed_streams else "; caller <-> step stream hand-offs around every step")
@@ -863,7 +951,7 @@ def main():
             trainer.use_graph = False                                     # stage intervals: eager steps right after the clock
             stage_profs = [{n: Prof(2) for n in names} for _ in range(chunk)]
             for i in range(chunk):
-                trainer.step(first_timed + args.steps + i, lr_at(first_timed + args.steps + i), prof=stage_profs[i])
+                trainer.step(first_after + i, lr_at(first_after + i), prof=stage_profs[i])
             torch.cuda.synchronize()
             trainer.use_graph = True
         extra["sampler_regrown"] = int(sum(getattr(sm, "regrown", 0) for sm in samplers))
@@ -983,6 +1071,23 @@ def main():
                     stage_ms["posemb_chunk_of_%d_views" % min(2 * chunk, 32)] = float(
                         np.mean([p["posemb"].elapsed_ms(0, 1) for p in used]))
             out["stage_ms"] = stage_ms
+            out["config"]["hidden_size"] = args.hidden_size
+            if args.hidden_size > 64:
+                # the any-width step: no per-stage marks; the line's roofline is the GEMM every Linear runs on (csrc/ginx.hip),
+                # priced from an isolated replay of the step's training-stream launches on the last timed batch
+                wr = wide_step_roofline(trainer, last, args, torch)
+                out["solver_roofline"] = out["roofline"]
+                out["roofline"] = wr
+                out["dominant_kernel"] = {"kernel": wr["kernel"], "bound": wr["bound"], "frac": wr["frac"], "by": wr["dominant_by"]}
+                out.update(extra)
+                if not args.no_parity and world == 1:
+                    out["parity"] = {"parity_step": parity_step(args, graph, dev)}
+                sys.stdout.flush()
+                print(json.dumps(out), flush=True)
+                if world > 1:
+                    dist.barrier()
+                    dist.destroy_process_group()
+                return
             out["stage_rooflines"] = stage_rooflines(args, acc, {k: v / spc for k, v in kern_iso.items()}, stage_ms, probe_shape, pe_probe)
             step_bytes = out["stage_rooflines"].pop("_step_bytes")
             step_gbps = step_bytes / (ms_per_step * 1e-3) / 1e9

@@ -221,7 +221,7 @@ class WideNceEngine:
         ncols = K + 1 if mode == 0 else K
         o = dict(out=torch.empty(B, ncols, **f32), dlog=torch.empty(B, ncols, **f32), grad_rows=torch.empty(B, D, **f32),
                  grad_mem=torch.empty(K, D, **f32) if mode == 1 else None, loss=torch.empty(1, **f32), prob=torch.empty(1, **f32),
-                 acc=torch.zeros(2, dtype=torch.float64, device=rows.device))
+                 acc=torch.zeros(2 + B * D, dtype=torch.float64, device=rows.device))     # [2] loss / prob sums + [B, D] accumulator of grad_rows
         rc = self.lib.gcc_ncex_forward(self.ptr(rows), self.ptr(k) if k is not None else None, self.ptr(mem), B, K, D, 1.0 / T, mode,
                                        self.ptr(o["out"]), self.ptr(o["dlog"]), self.ptr(o["grad_rows"]),
                                        self.ptr(o["grad_mem"]) if o["grad_mem"] is not None else None, self.ptr(o["loss"]),

@@ -29,12 +29,14 @@ namespace {
 constexpr int kGT = 256;                 // threads of the GEMM workgroup: 4 waves, a 64 x 64 tile of C
 constexpr int kBM = 64, kBN = 64, kBK = 16;
 constexpr int kLdT = kBM + 4;            // LDS row stride of the k-major operand tiles
-constexpr int kSplitRows = 256;          // rows of the reduction dimension per workgroup when it is the node dimension: f32 on the matrix cores
+constexpr int kSplitRows = 1024;         // rows of the reduction dimension per workgroup when it is the node dimension (256 until round 6: 100 slabs of a
+                                         // 25k-node batch queued on every fp64 accumulator, 2.3 ms per weight gradient at width 256): f32 on the matrix cores
                                          // inside a slab, fp64 atomics across slabs (a weight gradient sums over ~10^4 nodes whose terms largely cancel)
 
 // C[m][n] (+)= sum_k A(m, k) B(k, n) [+ bias[n]];  A(m, k) = A[m * sam + k * sak], B(k, n) = B[k * sbk + n * sbn].
 // rows_dim: 0 = all extents are the host's; 1 = M is *rows (device); 2 = K is *rows (device; split over gridDim.z with
-// atomic adds into a zeroed C).
+// atomic adds into a zeroed fp64 accumulator); 3 = as 2 with the host's K (a long reduction over few output tiles: the head's
+// d loss / d q = dlog [B, K] x queue [K, D] at K = 16384 was 16 workgroups x 1024 steps, 2.3 ms of an 11 ms step).
 struct GemmArgs {
     const float *A, *B, *bias;
     float *C;
@@ -43,7 +45,8 @@ struct GemmArgs {
     const int32_t *rows;
     int32_t rows_dim, atomic;
     float alpha;
-    double *Cd;                          // rows_dim == 2: the fp64 accumulator the slabs add into (converted to C afterwards)
+    double *Cd;                          // rows_dim >= 2: the fp64 accumulator the slabs add into (converted to C afterwards)
+    int32_t vec;                         // bit 0 / 1: A / B may be read 16 bytes at a time along its contiguous index (strides and base aligned)
 };
 
 __global__ __launch_bounds__(kGT) void ginx_gemm_kernel(GemmArgs g)
@@ -55,45 +58,85 @@ __global__ __launch_bounds__(kGT) void ginx_gemm_kernel(GemmArgs g)
     if (g.rows_dim == 2) K = *g.rows;
     const int m0 = (int)blockIdx.x * kBM, n0 = (int)blockIdx.y * kBN;
     int k_lo = 0, k_hi = K;
-    if (g.rows_dim == 2) { k_lo = (int)blockIdx.z * kSplitRows; k_hi = min(K, k_lo + kSplitRows); }
+    if (g.rows_dim >= 2) { k_lo = (int)blockIdx.z * kSplitRows; k_hi = min(K, k_lo + kSplitRows); }
     if (m0 >= M || k_lo >= k_hi) return;                     // (block-uniform)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[2][2] = {{zero4, zero4}, {zero4, zero4}};
     const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;       // this wave's 32 x 32 quarter of the tile
     const bool a_kc = g.sak == 1, b_nc = g.sbn == 1;         // which index of an operand is contiguous in memory
-    for (int k0 = k_lo; k0 < k_hi; k0 += kBK) {
-        // operand tiles -> LDS, k-major; four elements per thread, along the contiguous index
+    // four elements of each operand tile per thread, along the contiguous index; the NEXT k-tile is requested before this one's
+    // products (round 6: load -> barrier -> products -> barrier exposed a memory round trip per 16 columns of k), and where the
+    // four elements are 16 contiguous, aligned bytes inside the operand they travel as one load (g.vec bit 0: A, bit 1: B)
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
+        if (a_kc) {
+            const int mm = m0 + (tid >> 2), kk = k0 + (tid & 3) * 4;
+            const float *p = g.A + (int64_t)mm * g.sam + kk;
+            if ((g.vec & 1) && mm < M && kk + 3 < k_hi) {
+                const float4 v = *(const float4 *)p;
+                ra[0] = v.x; ra[1] = v.y; ra[2] = v.z; ra[3] = v.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ra[u] = (mm < M && kk + u < k_hi) ? p[u] : 0.f;
+            }
+        } else {
+            const int kk = k0 + (tid >> 4), mm = m0 + (tid & 15) * 4;
+            const float *p = g.A + (int64_t)mm * g.sam + (int64_t)kk * g.sak;
+            if ((g.vec & 1) && g.sam == 1 && mm + 3 < M && kk < k_hi) {
+                const float4 v = *(const float4 *)p;
+                ra[0] = v.x; ra[1] = v.y; ra[2] = v.z; ra[3] = v.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ra[u] = (mm + u < M && kk < k_hi) ? p[(int64_t)u * g.sam] : 0.f;
+            }
+        }
+        if (b_nc) {
+            const int kk = k0 + (tid >> 4), nn = n0 + (tid & 15) * 4;
+            const float *p = g.B + (int64_t)kk * g.sbk + nn;
+            if ((g.vec & 2) && nn + 3 < g.N && kk < k_hi) {
+                const float4 v = *(const float4 *)p;
+                rb[0] = v.x; rb[1] = v.y; rb[2] = v.z; rb[3] = v.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rb[u] = (nn + u < g.N && kk < k_hi) ? p[u] : 0.f;
+            }
+        } else {
+            const int nn = n0 + (tid >> 2), kk = k0 + (tid & 3) * 4;
+            const float *p = g.B + (int64_t)nn * g.sbn + (int64_t)kk * g.sbk;
+            if ((g.vec & 2) && g.sbk == 1 && nn < g.N && kk + 3 < k_hi) {
+                const float4 v = *(const float4 *)p;
+                rb[0] = v.x; rb[1] = v.y; rb[2] = v.z; rb[3] = v.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rb[u] = (nn < g.N && kk + u < k_hi) ? p[(int64_t)u * g.sbk] : 0.f;
+            }
+        }
+    };
+    auto store = [&]() {                                     // operand tiles -> LDS, k-major
         if (a_kc) {
             const int m = tid >> 2, kq = (tid & 3) * 4;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int mm = m0 + m, kk = k0 + kq + u;
-                As[kq + u][m] = (mm < M && kk < k_hi) ? g.A[(int64_t)mm * g.sam + (int64_t)kk * g.sak] : 0.f;
-            }
+            for (int u = 0; u < 4; ++u) As[kq + u][m] = ra[u];
         } else {
             const int kk_ = tid >> 4, m4 = (tid & 15) * 4;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int mm = m0 + m4 + u, kk = k0 + kk_;
-                As[kk_][m4 + u] = (mm < M && kk < k_hi) ? g.A[(int64_t)mm * g.sam + (int64_t)kk * g.sak] : 0.f;
-            }
+            for (int u = 0; u < 4; ++u) As[kk_][m4 + u] = ra[u];
         }
         if (b_nc) {
             const int kk_ = tid >> 4, n4 = (tid & 15) * 4;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int nn = n0 + n4 + u, kk = k0 + kk_;
-                Bs[kk_][n4 + u] = (nn < g.N && kk < k_hi) ? g.B[(int64_t)kk * g.sbk + (int64_t)nn * g.sbn] : 0.f;
-            }
+            for (int u = 0; u < 4; ++u) Bs[kk_][n4 + u] = rb[u];
         } else {
             const int n = tid >> 2, kq = (tid & 3) * 4;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int nn = n0 + n, kk = k0 + kq + u;
-                Bs[kq + u][n] = (nn < g.N && kk < k_hi) ? g.B[(int64_t)kk * g.sbk + (int64_t)nn * g.sbn] : 0.f;
-            }
+            for (int u = 0; u < 4; ++u) Bs[kq + u][n] = rb[u];
         }
+    };
+    fetch(k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += kBK) {
+        store();
         __syncthreads();
+        if (k0 + kBK < k_hi) fetch(k0 + kBK);
 #pragma unroll
         for (int ks = 0; ks < kBK; ks += 4) {
             const int kk = ks + (lane >> 4);
@@ -118,7 +161,7 @@ __global__ __launch_bounds__(kGT) void ginx_gemm_kernel(GemmArgs g)
                 const int m = m0 + wr + 16 * i + 4 * (lane >> 4) + r, n = n0 + wc + 16 * j + (lane & 15);
                 if (m < M && n < g.N) {
                     float v = acc[i][j][r] * g.alpha;
-                    if (g.bias && (g.rows_dim != 2 || blockIdx.z == 0)) v += g.bias[n];
+                    if (g.bias && (g.rows_dim < 2 || blockIdx.z == 0)) v += g.bias[n];
                     if (g.atomic) atomicAdd(g.Cd + (int64_t)m * g.ldc + n, (double)v); else g.C[(int64_t)m * g.ldc + n] = v;
                 }
             }
@@ -160,7 +203,10 @@ __global__ void ginx_feat_bwd_kernel(const int32_t *node_off, const int32_t *row
     atomicAdd(&demb[(int64_t)d * de + c], dx0[(int64_t)v * d_in + pos_dim + c]);
 }
 
-// out[v] = x[v] + sum over row v of x[col]  (+ add[v] when add != NULL): one wave per row, lanes over the channels
+// out[v] = x[v] + mult * sum over row v of x[col]  (+ add[v] when add != NULL): one wave per row.  Rows whose width is a multiple of
+// four are walked 16 bytes per lane with eight neighbour rows requested per round (round 6: one float per lane and one neighbour
+// at a time -- a dependent col_idx -> row round trip per edge -- was 660 us per call at width 256, a third of the step); the
+// neighbours are added in CSR order either way, so both paths give the same sums.
 __global__ __launch_bounds__(256) void ginx_spmm_kernel(const int32_t *node_off, const int32_t *row_ptr, const int32_t *col_idx, int B,
                                                          const float *x, int D, const float *add, float *out, float mult)
 {
@@ -168,6 +214,31 @@ __global__ __launch_bounds__(256) void ginx_spmm_kernel(const int32_t *node_off,
     const int v = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
     if (v >= node_off[B]) return;
     const int e0 = row_ptr[v], e1 = row_ptr[v + 1];
+    if ((D & 3) == 0) {
+        constexpr int kJ = 8;
+        for (int c = 4 * lane; c < D; c += 256) {
+            float4 nb = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = e0; e < e1; e += kJ) {
+                int u[kJ];
+                float4 f[kJ];
+#pragma unroll
+                for (int j = 0; j < kJ; ++j) u[j] = col_idx[min(e + j, e1 - 1)];
+#pragma unroll
+                for (int j = 0; j < kJ; ++j) f[j] = *(const float4 *)(x + (int64_t)u[j] * D + c);
+#pragma unroll
+                for (int j = 0; j < kJ; ++j)
+                    if (e + j < e1) { nb.x += f[j].x; nb.y += f[j].y; nb.z += f[j].z; nb.w += f[j].w; }
+            }
+            const float4 s = *(const float4 *)(x + (int64_t)v * D + c);
+            float4 acc = make_float4(s.x + mult * nb.x, s.y + mult * nb.y, s.z + mult * nb.z, s.w + mult * nb.w);
+            if (add) {
+                const float4 a = *(const float4 *)(add + (int64_t)v * D + c);
+                acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+            }
+            *(float4 *)(out + (int64_t)v * D + c) = acc;
+        }
+        return;
+    }
     for (int c = lane; c < D; c += 64) {
         float nb = 0.f;
         for (int e = e0; e < e1; ++e) nb += x[(int64_t)col_idx[e] * D + c];
@@ -190,18 +261,42 @@ __global__ __launch_bounds__(256) void ginx_colsum_kernel(const int32_t *node_of
     if (r0 >= N) return;
     for (int c = (int)threadIdx.x; c < D; c += 256) {
         double s0 = 0.0, s1 = 0.0;
+        // (eight rows requested per round: a row at a time was a chain of 128 dependent-latency loads, 60 us per call)
         if (mode == 0) {
-            for (int r = r0; r < r1; ++r) { const double v = (double)x[(int64_t)r * D + c]; s0 += v; s1 += v * v; }
+            for (int r = r0; r < r1; r += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = x[(int64_t)min(r + u, r1 - 1) * D + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (r + u < r1) { const double d = (double)v[u]; s0 += d; s1 += d * d; }
+            }
         } else if (mode == 1) {
             const float mean = mr[c], rstd = mr[D + c];
-            for (int r = r0; r < r1; ++r) {
-                const int64_t i = (int64_t)r * D + c;
-                const float gr = y[i] > 0.f ? dy[i] : 0.f;
-                s0 += (double)gr;
-                s1 += (double)gr * (double)((x[i] - mean) * rstd);
+            for (int r = r0; r < r1; r += 8) {
+                float xv[8], yv[8], dv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t i = (int64_t)min(r + u, r1 - 1) * D + c;
+                    xv[u] = x[i]; yv[u] = y[i]; dv[u] = dy[i];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (r + u < r1) {
+                        const float gr = yv[u] > 0.f ? dv[u] : 0.f;
+                        s0 += (double)gr;
+                        s1 += (double)gr * (double)((xv[u] - mean) * rstd);
+                    }
             }
         } else {
-            for (int r = r0; r < r1; ++r) s0 += (double)x[(int64_t)r * D + c];
+            for (int r = r0; r < r1; r += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = x[(int64_t)min(r + u, r1 - 1) * D + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (r + u < r1) s0 += (double)v[u];
+            }
         }
         atomicAdd(&sums[c], s0);
         if (mode != 2) atomicAdd(&sums[D + c], s1);
@@ -234,29 +329,62 @@ __global__ void ginx_bn_prepare_kernel(const int32_t *node_off, int B, const dou
     }
 }
 
-// y = relu((x - mean) * rstd * gamma + beta)
+// y = relu((x - mean) * rstd * gamma + beta).  Launched with one thread per FOUR elements when D is a multiple of four (16-byte
+// accesses; `vec` = 1), else one per element
 __global__ void ginx_bn_relu_kernel(const int32_t *node_off, int B, const float *x, const float *mr, const float *gamma, const float *beta,
-                                    int D, float *y)
+                                    int D, float *y, int vec)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)node_off[B] * D) return;
-    const int c = (int)(i % D);
-    const float v = (x[i] - mr[c]) * mr[D + c] * gamma[c] + beta[c];
-    y[i] = v > 0.f ? v : 0.f;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)node_off[B] * D;
+    if (vec) {
+        const int64_t i = 4 * t;
+        if (i >= total) return;
+        const int c = (int)(i % D);
+        const float4 xv = *(const float4 *)(x + i), m = *(const float4 *)(mr + c), r = *(const float4 *)(mr + D + c);
+        const float4 g = *(const float4 *)(gamma + c), b = *(const float4 *)(beta + c);
+        float4 o;
+        o.x = fmaxf((xv.x - m.x) * r.x * g.x + b.x, 0.f); o.y = fmaxf((xv.y - m.y) * r.y * g.y + b.y, 0.f);
+        o.z = fmaxf((xv.z - m.z) * r.z * g.z + b.z, 0.f); o.w = fmaxf((xv.w - m.w) * r.w * g.w + b.w, 0.f);
+        *(float4 *)(y + i) = o;
+        return;
+    }
+    if (t >= total) return;
+    const int c = (int)(t % D);
+    const float v = (x[t] - mr[c]) * mr[D + c] * gamma[c] + beta[c];
+    y[t] = v > 0.f ? v : 0.f;
 }
 
 // dx = gamma * rstd * (gr - mean(gr) - xhat * mean(gr * xhat)),  gr = dy * (y > 0)   (BatchNorm1d backward in training mode)
-__global__ void ginx_bn_relu_bwd_kernel(const int32_t *node_off, int B, const float *x, const float *y, const float *dy, const float *mr,
-                                        const float *gamma, const double *sums, int D, float *dx)
+__device__ __forceinline__ float ginx_bn_bwd_one(float x, float y, float dy, float mean, float rstd, float gamma, float m0, float m1)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float gr = y > 0.f ? dy : 0.f;
+    const float xhat = (x - mean) * rstd;
+    return gamma * rstd * (gr - m0 - xhat * m1);
+}
+__global__ void ginx_bn_relu_bwd_kernel(const int32_t *node_off, int B, const float *x, const float *y, const float *dy, const float *mr,
+                                        const float *gamma, const double *sums, int D, float *dx, int vec)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int N = node_off[B];
-    if (i >= (int64_t)N * D) return;
-    const int c = (int)(i % D);
-    const float gr = y[i] > 0.f ? dy[i] : 0.f;
-    const float xhat = (x[i] - mr[c]) * mr[D + c];
-    const float m0 = (float)(sums[c] / (double)N), m1 = (float)(sums[D + c] / (double)N);
-    dx[i] = gamma[c] * mr[D + c] * (gr - m0 - xhat * m1);
+    const int64_t total = (int64_t)N * D;
+    if (vec) {
+        const int64_t i = 4 * t;
+        if (i >= total) return;
+        const int c = (int)(i % D);
+        const float4 xv = *(const float4 *)(x + i), yv = *(const float4 *)(y + i), dv = *(const float4 *)(dy + i);
+        const float4 m = *(const float4 *)(mr + c), r = *(const float4 *)(mr + D + c), g = *(const float4 *)(gamma + c);
+        const double n = (double)N;
+        float4 o;
+        o.x = ginx_bn_bwd_one(xv.x, yv.x, dv.x, m.x, r.x, g.x, (float)(sums[c + 0] / n), (float)(sums[D + c + 0] / n));
+        o.y = ginx_bn_bwd_one(xv.y, yv.y, dv.y, m.y, r.y, g.y, (float)(sums[c + 1] / n), (float)(sums[D + c + 1] / n));
+        o.z = ginx_bn_bwd_one(xv.z, yv.z, dv.z, m.z, r.z, g.z, (float)(sums[c + 2] / n), (float)(sums[D + c + 2] / n));
+        o.w = ginx_bn_bwd_one(xv.w, yv.w, dv.w, m.w, r.w, g.w, (float)(sums[c + 3] / n), (float)(sums[D + c + 3] / n));
+        *(float4 *)(dx + i) = o;
+        return;
+    }
+    if (t >= total) return;
+    const int c = (int)(t % D);
+    dx[t] = ginx_bn_bwd_one(x[t], y[t], dy[t], mr[c], mr[D + c], gamma[c], (float)(sums[c] / (double)N), (float)(sums[D + c] / (double)N));
 }
 
 // fp64 sums -> fp32 parameter gradients: dst[c] (+)= (float)src[c]   (also the weight gradients' fp64 accumulators, n = rows * cols)
@@ -273,7 +401,14 @@ __global__ __launch_bounds__(256) void ginx_pool_kernel(const int32_t *node_off,
     const int r0 = node_off[b], r1 = node_off[b + 1];
     for (int c = (int)threadIdx.x; c < D; c += 256) {
         double s = 0.0;
-        for (int r = r0; r < r1; ++r) s += (double)h[(int64_t)r * D + c];
+        for (int r = r0; r < r1; r += 8) {                                // (eight rows requested per round, added in row order)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = h[(int64_t)min(r + u, r1 - 1) * D + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r + u < r1) s += (double)v[u];
+        }
         pooled[(int64_t)b * D + c] = (float)s;
     }
 }
@@ -433,12 +568,17 @@ XLayout ginx_layout(int64_t N, int B, int L, int d_in, int W, int O)
 void gemm(hipStream_t s, const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn, float *C, int64_t ldc,
           int M, int N, int K, const float *bias, const int32_t *rows, int rows_dim, int64_t rows_cap, float alpha = 1.0f, double *acc64 = nullptr)
 {
-    GemmArgs g = {A, B, bias, C, sam, sak, sbk, sbn, ldc, M, N, K, rows, rows_dim, rows_dim == 2 ? 1 : 0, alpha, acc64};
+    // 16-byte loads along the contiguous index need the base and the OTHER index's stride to keep that alignment
+    const auto al16 = [](const void *p_) { return (((uintptr_t)p_) & 15) == 0; };
+    const int vec_a = (sak == 1 ? (sam % 4 == 0) : (sam == 1 && sak % 4 == 0)) && al16(A);
+    const int vec_b = (sbn == 1 ? (sbk % 4 == 0) : (sbk == 1 && sbn % 4 == 0)) && al16(B);
+    GemmArgs g = {A, B, bias, C, sam, sak, sbk, sbn, ldc, M, N, K, rows, rows_dim, rows_dim >= 2 ? 1 : 0, alpha, acc64, vec_a | (vec_b << 1)};
     const int mcap = rows_dim == 1 ? (int)rows_cap : M;
-    dim3 grid((mcap + kBM - 1) / kBM, (N + kBN - 1) / kBN, rows_dim == 2 ? (unsigned)((rows_cap + kSplitRows - 1) / kSplitRows) : 1u);
-    if (rows_dim == 2) (void)hipMemsetAsync(acc64, 0, sizeof(double) * (size_t)M * (size_t)ldc, s);     // (C is dense: ldc == N)
+    const int64_t kcap = rows_dim == 2 ? rows_cap : K;
+    dim3 grid((mcap + kBM - 1) / kBM, (N + kBN - 1) / kBN, rows_dim >= 2 ? (unsigned)((kcap + kSplitRows - 1) / kSplitRows) : 1u);
+    if (rows_dim >= 2) (void)hipMemsetAsync(acc64, 0, sizeof(double) * (size_t)M * (size_t)ldc, s);     // (C is dense: ldc == N)
     hipLaunchKernelGGL(ginx_gemm_kernel, grid, dim3(kGT), 0, s, g);
-    if (rows_dim == 2) hipLaunchKernelGGL(ginx_sums_to_grad_kernel, dim3((unsigned)(((int64_t)M * ldc + 255) / 256)), dim3(256), 0, s, (const double *)acc64, (int)(M * ldc), C, 0);
+    if (rows_dim >= 2) hipLaunchKernelGGL(ginx_sums_to_grad_kernel, dim3((unsigned)(((int64_t)M * ldc + 255) / 256)), dim3(256), 0, s, (const double *)acc64, (int)(M * ldc), C, 0);
 }
 
 inline unsigned blocks(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
@@ -498,7 +638,9 @@ int32_t gcc_ginx_forward(const gcc_ginx_pass *p, void *stream)
         }
         hipLaunchKernelGGL(ginx_bn_prepare_kernel, dim3(blocks(W)), dim3(256), 0, s, p->node_off, B, sums, W, w.bn_eps, w.bn_momentum, p->training,
                            p->update_running_stats, m.running_mean, m.running_var, m.num_batches_tracked, ws + mr_off);
-        hipLaunchKernelGGL(ginx_bn_relu_kernel, dim3(blocks(N * W)), dim3(256), 0, s, p->node_off, B, in, ws + mr_off, m.weight, m.bias, W, out);
+        // (workspace blocks are 256-byte aligned: rows of 4 k floats stay 16-byte aligned; the parameters are the caller's)
+        const int vec = (W & 3) == 0 && ((((uintptr_t)m.weight) | ((uintptr_t)m.bias)) & 15) == 0;
+        hipLaunchKernelGGL(ginx_bn_relu_kernel, dim3(blocks(vec ? N * W / 4 : N * W)), dim3(256), 0, s, p->node_off, B, in, ws + mr_off, m.weight, m.bias, W, out, vec);
     };
     hipLaunchKernelGGL(ginx_pool_kernel, dim3(B), dim3(256), 0, s, p->node_off, h, D, ws + x.pooled[0]);
     for (int l = 0; l < L; ++l) {
@@ -564,8 +706,9 @@ int32_t gcc_ginx_backward(const gcc_ginx_pass *p, const float *dfeat, const gcc_
         hipLaunchKernelGGL(ginx_colsum_kernel, dim3(blocks(N, 128)), dim3(256), 0, s, p->node_off, B, 0, 1, xin, y, dy, (const float *)(ws + mr_off), W, sums);
         hipLaunchKernelGGL(ginx_sums_to_grad_kernel, dim3(blocks(W)), dim3(256), 0, s, sums, W, dbeta, 0);
         hipLaunchKernelGGL(ginx_sums_to_grad_kernel, dim3(blocks(W)), dim3(256), 0, s, sums + W, W, dgamma, 0);
-        hipLaunchKernelGGL(ginx_bn_relu_bwd_kernel, dim3(blocks(N * W)), dim3(256), 0, s, p->node_off, B, xin, y, dy, (const float *)(ws + mr_off), m.weight,
-                           sums, W, dx);
+        const int vec = (W & 3) == 0 && (((uintptr_t)m.weight) & 15) == 0;
+        hipLaunchKernelGGL(ginx_bn_relu_bwd_kernel, dim3(blocks(vec ? N * W / 4 : N * W)), dim3(256), 0, s, p->node_off, B, xin, y, dy, (const float *)(ws + mr_off), m.weight,
+                           sums, W, dx, vec);
     };
     auto bias_grad = [&](const float *dz, float *db) {
         (void)hipMemsetAsync(sums, 0, sizeof(double) * W, s);
@@ -621,7 +764,9 @@ int32_t gcc_ncex_forward(const float *q, const float *k, const float *mem, int32
     // the gradients for a unit upstream gradient, taken NOW -- before the caller enqueues the step's keys over queue rows
     // (memory_moco.py:55-61): d loss / d rows = (softmax - onehot) [k; mem] / (T B)
     const float coef = inv_T / (float)B;
-    gemm(s, dlog + (mode == 0 ? 1 : 0), ld, 1, mem, D, 1, grad_rows, D, B, D, K, nullptr, nullptr, 0, 0, coef);
+    // (reduction over the K queue rows: split over workgroups when it is long, fp64 atomics into acc + 2)
+    if (K >= 4 * kSplitRows) gemm(s, dlog + (mode == 0 ? 1 : 0), ld, 1, mem, D, 1, grad_rows, D, B, D, K, nullptr, nullptr, 3, 0, coef, acc + 2);
+    else gemm(s, dlog + (mode == 0 ? 1 : 0), ld, 1, mem, D, 1, grad_rows, D, B, D, K, nullptr, nullptr, 0, 0, coef);
     if (mode == 0) hipLaunchKernelGGL(ginx_rank1_rows_kernel, dim3(blocks((int64_t)B * D)), dim3(256), 0, s, (const float *)dlog, ld, k, B, D, coef, grad_rows);
     else gemm(s, dlog, 1, ld, q, D, 1, grad_mem, D, K, D, B, nullptr, nullptr, 0, 0, coef);                         // d loss / d mem rows = dlog^T rows / (T B)
     hipError_t e = hipGetLastError();

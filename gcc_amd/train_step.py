@@ -270,6 +270,12 @@ def _is_capture_error(e):
 
 
 def _hint_rows_once(engine, q, k):
+    if not hasattr(engine, "hint_rows"):         # (the any-width engine launches for the capacity)
+        return
+    _hint_rows_once_(engine, q, k)
+
+
+def _hint_rows_once_(engine, q, k):
     """The FIRST batch of a run tells the encoder engine how many rows a batch has (one host read of two device integers, once
     per run: every later step stays free of host synchronisation); :func:`read_meters` raises the estimate when a log line finds a
     larger batch.  Graphs captured under an earlier estimate stay valid (any grid is correct)."""
@@ -291,7 +297,7 @@ def read_meters(trainer):
     a, m = trainer.meter_acc.tolist(), trainer.meter_max.tolist()
     trainer.meter_acc.zero_()
     trainer.meter_max.zero_()
-    if getattr(trainer, "gin", None) is not None and m[0] > 0:
+    if hasattr(getattr(trainer, "gin", None), "hint_rows") and m[0] > 0:
         trainer.gin.hint_rows(m[0], margin=1.04)       # (the largest q view since the last log line; the k views are as large)
     return a, m
 
@@ -534,7 +540,7 @@ class MoCoTrainStep(_GraphedStep):
     def __init__(self, model: GraphEncoder, model_ema: GraphEncoder, contrast: MemoryMoCo, sampler, posemb,
                  learning_rate=0.005, betas=(0.9, 0.999), weight_decay=1e-5, clip_norm=1.0, alpha=0.999,
                  world_size=1, rank=0, prefetch=True, extra_lanes=(), depth=2, lanes=None, chunk=1, reserved_cus=0, cu_layout="interleaved",
-                 collectives=None, ahead=None, graph=None):
+                 collectives=None, ahead=None, graph=None, flat_engine=None):
         """``sampler``/``posemb``: producer lane 0; ``extra_lanes``: more (sampler, posemb) pairs with their own
         workspaces for multi-stream prefetch (see :class:`BatchProducer`).
         ``graph``: replay the step's ~45 launches as ONE captured hipGraph per ring slot (default: on with prefetch on a
@@ -556,11 +562,18 @@ class MoCoTrainStep(_GraphedStep):
             self.grad_views.append(self.flat_grad[off:off + p.numel()].view_as(p))
             off += model.padded_numel(p)
         self.live = self.flat[: self.n_live]
-        self.gin = model.engine()
+        # --hidden-size above 64 (train.py:93): the any-width kernels of csrc/ginx.hip (one launch per operator; dense head) under the
+        # SAME step -- producer lanes, flat buffers, clip + Adam + EMA + meters as two launches, key all-gather / gradient all-reduce
+        # across ranks -- issued launch by launch (their enqueue index / learning rate are by-value arguments: no graph replay)
+        self.wide = bool(model.wide or contrast.wide)
+        if self.wide and not (model.wide and contrast.wide and model_ema.wide):
+            raise ValueError("a wide step needs a wide encoder pair AND a wide head (hidden-size and MemoryMoCo's feature size above 64)")
+        self.gin = model.wide_engine() if self.wide else model.engine()
         self.nce = contrast.engine()
         # Adam(lr, betas, weight_decay as L2) over exactly the parameters that get gradients, train.py:667-672
-        self.optimizer = FlatAdam(self.live, self.flat_grad, learning_rate, betas, weight_decay, clip_norm, self.nce)
-        self.mask_fn = None          # tests inject explicit dropout keep-masks here; default = in-kernel Philox
+        self.optimizer = FlatAdam(self.live, self.flat_grad, learning_rate, betas, weight_decay, clip_norm,
+                                  (flat_engine or NceEngine()) if self.wide else self.nce)      # (the flat-buffer kernels live in csrc/nce.hip; ``flat_engine``: tests)
+        self.mask_fn = None          # tests inject explicit dropout keep-masks here; default = in-kernel Philox (wide: torch.rand)
         self.dropout_seed = 0x5EED0000
         self.B = sampler.batch_size
         if contrast.queueSize < self.B * world_size:
@@ -569,7 +582,7 @@ class MoCoTrainStep(_GraphedStep):
             raise ValueError(f"nce_k = {contrast.queueSize} is smaller than the {self.B * world_size} keys enqueued per step "
                              f"(batch_size {self.B} x world {world_size}): raise --nce-k")
         self.L = len(model.gnn.ginlayers)
-        self.keys_all = torch.empty(self.B * world_size, H, device=self.dev) if self.collectives else None
+        self.keys_all = torch.empty(self.B * world_size, contrast.inputSize if self.wide else H, device=self.dev) if self.collectives else None
         self.one = torch.ones(1, device=self.dev)
         self.meter_acc, self.meter_max = _meter_buffers(self.dev)
         self.prefetch = prefetch and self.dev.type == "cuda"
@@ -583,7 +596,9 @@ class MoCoTrainStep(_GraphedStep):
                                       ahead=ahead)
         if not self.prefetch:
             self.producer.cuda = False
-        self._graph_init(graph)
+        if self.wide and graph:
+            raise ValueError("graph replay is the 64-channel step's (device-resident scalars); the wide step is issued launch by launch")
+        self._graph_init(False if self.wide else graph)
         model.train()                                                    # train.py:357-365
         model_ema.eval()
         for mod in model_ema.modules():
@@ -661,11 +676,10 @@ class MoCoTrainStep(_GraphedStep):
     def step(self, step, lr, prof=None):
         """``prof``: optional dict of gcc_amd.prof.Prof (sampler: 4 marks; gin_fwd/nce_fwd/nce_bwd/gin_bwd: 2).
 
-        Lifetime of the returned batches: ``graph_q`` / ``graph_k`` are RING SLOTS of the producer lanes.  The slot is handed
-        back to its lane by an event recorded on the step's stream at the end of this step, i.e. before anything the caller
-        enqueues afterwards: a lane may refill the slot ``ahead`` chunks later while caller-stream kernels still read it.  Read
-        them on the step's stream (``with torch.cuda.stream(trainer.main)``), copy what must outlive the next
-        ``producer.ahead`` steps, or synchronise before the next ``step()`` (tests/test_pipeline_gpu.py does the last)."""
+        Lifetime of the returned batches: ``graph_q`` / ``graph_k`` are RING SLOTS of the producer lanes, valid until the NEXT
+        ``step()`` call: that call hands them back on the step's stream, after the caller's stream has been waited for (per-step
+        hand-offs, the default) -- kernels the caller enqueued on its own stream in between are covered.  With
+        ``relaxed_streams`` read them on the step's stream (``with torch.cuda.stream(trainer.main)``) or synchronise first."""
         if self.main is None:
             return self._step(step, lr, prof)
         caller = torch.cuda.current_stream(self.dev)
@@ -693,6 +707,7 @@ class MoCoTrainStep(_GraphedStep):
 
     def _step(self, step, lr, prof=None):
         pr = prof or {}
+        self._release_pending()
         q, k = self.producer.get(step, prof=prof)
         _hint_rows_once(self.gin, q, k)
         st = torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else None
@@ -705,8 +720,66 @@ class MoCoTrainStep(_GraphedStep):
         out = self._run_step(q, k, lr, seed, c.index, keep is not None, pr, st,
                              lambda scalars, marks: self._body(q, k, keep, seed, scalars, marks, st))
         c.index = (c.index + self.B * (self.world if self.collectives else 1)) % c.queueSize
-        self.producer.release(step)
+        self._pending_release = step
         return dict(out, graph_q=q, graph_k=k)
+
+    def _release_pending(self):
+        """Hand the PREVIOUS step's ring slots back to their lane -- at the start of the next step, on the step's stream: the
+        "slot free" event then also covers what the caller enqueued after that step returned (reads of ``graph_q`` / ``graph_k`` on
+        the step's stream, or on the caller's own stream when the per-step hand-offs are on: ``main.wait_stream(caller)`` has run
+        by now).  Rounds 1-5 recorded the event at the END of the step that consumed the slot, before any caller read: a refill
+        could overtake a caller's kernels (tests/test_pipeline_gpu.py needed a synchronisation per step)."""
+        step = getattr(self, "_pending_release", None)
+        if step is not None:
+            self._pending_release = None
+            self.producer.release(step)
+
+    def _body_wide(self, q, k, keep, S, st):
+        """:meth:`MoCoTrainStep._body` on the any-width kernels (csrc/ginx.hip; train.py:93 ``--hidden-size`` above 64): the same five
+        stages -- forward of both views | key all-gather begins | head + encoder backward | gradient all-reduce, gather joined | clip +
+        Adam + EMA + meters, enqueue -- with explicit dropout masks (torch.rand on the device, as nn.Dropout draws them: gin.py:202,230)
+        and by-value scalars."""
+        c, enc = self.contrast, self.model
+        p_drop = enc.gnn.drop.p
+
+        def fwd():
+            kq = keep
+            if kq is None and p_drop > 0:
+                kq = (torch.rand(len(enc.gnn.ginlayers) + 1, self.B, enc.output_dim, device=self.dev) >= p_drop).float()
+            S["pq"], S["bufq"] = self.gin.make_pass(enc, q, training=True, keep=kq, slot=("step", 0))
+            S["pk"], S["bufk"] = self.gin.make_pass(self.ema, k, training=True, keep=None, slot=("step", 1))
+            self.gin.forward(S["pq"], stream=st)                             # train.py:389
+            self.gin.forward(S["pk"], stream=st)                             # train.py:390-391
+            self.last_bufs = (S["bufq"], S["bufk"])                          # (tests / bench.py's parity step read the embeddings here)
+
+        def gather_begin():
+            S["gathering"] = self._all_gather_begin(self.keys_all, S["bufk"]["feat"])
+
+        def head_and_backward():
+            # logits, loss and d loss / d q against the queue BEFORE the enqueue (memory_moco.py:31 clones it): train.py:393,407-408
+            S["outs"] = self.nce.forward(S["bufq"]["feat"], S["bufk"]["feat"], c.memory, c.T, 0, stream=st)
+            self.gin.backward(enc, S["pq"], S["outs"]["grad_rows"], self.grad_views, stream=st)
+
+        def reduce_and_join():
+            self._all_reduce(self.flat_grad)
+            self._all_gather_end(S["gathering"])
+
+        def update():
+            outs = S["outs"]
+            S["gnorm"] = self.optimizer.step(grad_scale=1.0 / self.world if self.collectives else 1.0,
+                                             ema=self.flat_ema, ema_src=self.flat, ema_m=self.alpha,
+                                             meters=(self.meter_acc, self.meter_max, outs["loss"], outs["prob"], q, k), scalars=None)
+            keys = self.keys_all if self.collectives else S["bufk"]["feat"]
+            self.nce.enqueue(c.memory, keys, c.index, stream=st)             # memory_moco.py:55-61
+
+        def result():
+            return dict(loss=S["outs"]["loss"], prob=S["outs"]["prob"], grad_norm=S["gnorm"])
+
+        if self.collectives:
+            segments = [(False, fwd), (False, gather_begin), (False, head_and_backward), (False, reduce_and_join), (False, update)]
+        else:
+            segments = [(False, lambda: (fwd(), head_and_backward(), update()))]
+        return segments, result
 
     def _capture_body(self, q, k, st):
         seed = 0 if self.model.gnn.drop.p > 0 else None              # (with scalars only dropout on / off matters here)
@@ -721,6 +794,8 @@ class MoCoTrainStep(_GraphedStep):
         -- three captured graphs with the two RCCL hand-offs issued between their launches."""
         S = {}
         c = self.contrast
+        if self.wide:
+            return self._body_wide(q, k, keep, S, st)
 
         def fwd():
             self._fetch_scalars(scalars, st)
@@ -826,6 +901,7 @@ class E2ETrainStep(_GraphedStep):
 
     def _step(self, step, lr, prof=None):
         pr = prof or {}
+        self._release_pending()
         q, k = self.producer.get(step, prof=prof)
         _hint_rows_once(self.gin, q, k)
         st = torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else None
@@ -836,8 +912,10 @@ class E2ETrainStep(_GraphedStep):
             grp["lr"] = lr
         out = self._run_step(q, k, lr, s0, 0, keep_q is not None, pr, st,
                              lambda scalars, marks: self._body(q, k, keep_q, keep_k, s0, scalars, marks, st))
-        self.producer.release(step)
+        self._pending_release = step
         return dict(out, graph_q=q, graph_k=k)
+
+    _release_pending = MoCoTrainStep._release_pending
 
     def _capture_body(self, q, k, st):
         s0 = 0 if self.model.gnn.drop.p > 0 else None

@@ -432,7 +432,8 @@ int32_t gcc_ginx_backward(const gcc_ginx_pass *p, const float *dfeat, const gcc_
  * at any feature size D, dense: out [B, K + 1] (mode 0: column 0 = <q, k> / T) or [B, B]; dlog: same shape, softmax - onehot;
  * grad_rows [B, D] = d loss / d rows and (mode 1) grad_mem [B, D] = d loss / d mem, both for a unit upstream gradient and
  * taken against the queue as it is NOW -- the caller enqueues afterwards; loss, prob: device scalars (mean CE; mean label
- * logit, train.py:394,401); acc: device double[2] scratch. */
+ * logit, train.py:394,401); acc: device double[2 + B * D] scratch (ABI 3: the B x D tail accumulates grad_rows, whose reduction runs
+ * over the K queue rows and is split over workgroups). */
 int32_t gcc_ncex_forward(const float *q, const float *k, const float *mem, int32_t B, int32_t K, int32_t D, float inv_T, int32_t mode,
                          float *out, float *dlog, float *grad_rows, float *grad_mem, float *loss, float *prob, double *acc, void *stream);
 /* memory.index_copy_(0, (arange(nkeys) + index) % K, keys) (memory_moco.py:55-61) for rows of D floats */

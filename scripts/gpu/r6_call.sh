@@ -40,6 +40,23 @@ for part in "$@"; do
       (timeout 400 python bench.py $flags --no-cpu-baseline --no-parity 2>>$O/bench_$v.err | tail -1) > $O/${f}_$v.json
       python -c "
 import json; d=json.loads(open('$O/${f}_$v.json').read()); s=d['stage_rooflines']; print('[$v] $f', round(d['ms_per_step'],4), 'ms/step', round(d['value']), 'subgraphs/s flags', (d.get('posemb_status') or {}).get('flags'), 'encoder fwd/bwd in step', round(s['gin_encoder_fwd']['ms_in_step'],3), round(s['gin_encoder_bwd']['ms_in_step'],3))" ;;
+    pmc)  # sampler counters (separate --pmc passes, as MI355X_MICROARCH.md prescribes) + kernel stats of the sampler alone -> profiles/pmc_sampler.json
+      pmc_pass() { cd /tmp && (timeout 600 rocprofv3 --output-format csv --pmc $2 --kernel-trace -d /tmp/pmc_$1 -o p -- python $GRAFT_REPO_ROOT/tools/sampler_alone.py $3 2>&1 | tail -1) > $GRAFT_REPO_ROOT/$O/log_$1.txt; cd $GRAFT_REPO_ROOT; }
+      st_pass() { cd /tmp && (timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d /tmp/st_$1 -o s -- python $GRAFT_REPO_ROOT/tools/sampler_alone.py $2 2>&1 | tail -1) > $GRAFT_REPO_ROOT/$O/log_st_$1.txt; cd $GRAFT_REPO_ROOT
+                  find /tmp/st_$1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_sampler_alone_$1.csv; }
+      rm -f $O/pmc_sampler.json
+      for S in 10 16; do
+        pmc_pass f1_$S FETCH_SIZE "--launches 24 --steps-per-call $S"
+        pmc_pass w1_$S WRITE_SIZE "--launches 24 --steps-per-call $S"
+        (timeout 100 python tools/pmc_sampler.py /tmp/pmc_f1_$S /tmp/pmc_w1_$S 961441/9938200/bsz256/hops256/steps$S $O/pmc_sampler.json 2>&1 | tail -3) > $O/summary_g1_$S.log
+        st_pass g1_steps$S "--launches 30 --steps-per-call $S"
+      done
+      G2="--nodes 10000000 --edges 200000000 --launches 12 --steps-per-call 16"
+      pmc_pass f2 FETCH_SIZE "$G2"
+      pmc_pass w2 WRITE_SIZE "$G2"
+      (timeout 100 python tools/pmc_sampler.py /tmp/pmc_f2 /tmp/pmc_w2 9964365/199372800/bsz256/hops256/steps16 $O/pmc_sampler.json 2>&1 | tail -3) > $O/summary_g2.log
+      st_pass g2_steps16 "$G2"
+      cat $O/summary_g1_10.log $O/summary_g2.log | cut -c1-200 ;;
     sh:*) . scripts/gpu/snippets/${part#sh:}.sh ;;
     *) echo "unknown part $part" ;;
   esac

@@ -30,6 +30,8 @@ def _state(mod):
 
 def _feat(tr, slot, g):
     """the pass's output embeddings (the kernels' 64 channels cut to the model's output width)"""
+    if getattr(tr, "wide", False):                       # the any-width step keeps its last passes' buffers (MoCoTrainStep._body_wide)
+        return tr.last_bufs[slot[1]]["feat"]
     node_cap = g.parent_nid.numel() if hasattr(g, "parent_nid") else g.graph_id.numel()
     f = tr.gin._buffers(slot, node_cap, g.batch_size, tr.L if hasattr(tr, "L") else len(tr.model.gnn.ginlayers),
                         g.node_off.device)["feat"]

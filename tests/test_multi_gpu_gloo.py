@@ -211,3 +211,78 @@ def test_eight_rank_step_over_gloo(tmp_path):
             torch.testing.assert_close(blocks[r], same, rtol=0, atol=0)
         assert not torch.equal(blocks[0], blocks[1])
     assert torch.isfinite(torch.stack([d["loss"] for d in rs])).all()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# --hidden-size above 64 (train.py:93) data parallel: the wide branch of MoCoTrainStep over gloo, two ranks, width 128
+def _build_wide(rank_views, world, rank, hidden=128):
+    from gcc_amd.contrast import MemoryMoCo
+    from gcc_amd.train_step import MoCoTrainStep
+    from tests.golden import wide_init
+    from tests.hipemu.emu_encoder import CpuBatch
+    from tests.test_nce_emu import emu_nce
+    from tests.test_wide_encoder_emu import emu_wide_engine, emu_wide_nce, wide_encoder
+    from tests.wide_golden_check import gold as wide_gold
+
+    G = wide_gold()
+    c = G["cases"][hidden]
+    model, ema = wide_init.fill_(wide_encoder(hidden, hidden), 0), wide_init.fill_(wide_encoder(hidden, hidden), 1)
+    model._wide_engine = ema._wide_engine = emu_wide_engine()
+    contrast = MemoryMoCo(hidden, None, c["K"], c["T"], use_softmax=True)
+    with torch.no_grad():
+        contrast.memory.copy_(wide_init.tensor_for("contrast.memory", contrast.memory) * c["memory0_scale"])
+    contrast._engine = emu_wide_nce()
+    views = [CpuBatch(G["views"][v]) for v in rank_views]
+
+    class Stub:
+        batch_size = views[0].batch_size
+
+        def sample(self, first_id, prof=None):
+            return views[0], views[1]
+
+    step = MoCoTrainStep(model, ema, contrast, Stub(), posemb=lambda gr, prof=None: gr, prefetch=False, world_size=world, rank=rank,
+                         clip_norm=0.0, flat_engine=emu_nce())
+    return c, step, model, ema, contrast
+
+
+def _worker_wide(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c, step, model, ema, contrast = _build_wide((0, 1) if rank == 0 else (1, 0), world, rank)
+        assert step.wide and step.collectives
+        masks = c["masks"].contiguous()
+        step.mask_fn = lambda: masks
+        out = step.step(0, c["lr"])
+        torch.save(dict(model=model.state_dict(), ema=ema.state_dict(), memory=contrast.memory.clone(), index=contrast.index,
+                        grad=step.flat_grad.clone(), loss=out["loss"].clone()), os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_wide_step_over_gloo(tmp_path):
+    port = 29500 + (os.getpid() + 7) % 1000
+    mp.spawn(_worker_wide, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=False)
+    for k in r0["model"]:
+        if "running_" in k or "num_batches" in k:
+            continue                                     # BatchNorm statistics are per rank
+        torch.testing.assert_close(r0["model"][k], r1["model"][k], rtol=0, atol=0, msg=k)
+        torch.testing.assert_close(r0["ema"][k], r1["ema"][k], rtol=0, atol=0, msg=k)
+    torch.testing.assert_close(r0["memory"], r1["memory"], rtol=0, atol=0)
+    torch.testing.assert_close(r0["grad"], r1["grad"], rtol=0, atol=0)
+    grads, keys = [], []
+    for views in ((0, 1), (1, 0)):
+        c, step, model, ema, contrast = _build_wide(views, 1, 0)
+        masks = c["masks"].contiguous()
+        step.mask_fn = lambda: masks
+        step.step(0, c["lr"])
+        grads.append(step.flat_grad.clone())
+        B = step.B
+        keys.append(contrast.memory[:B].clone())
+    assert r0["index"] == r1["index"] == 2 * B
+    torch.testing.assert_close(r0["grad"], (grads[0] + grads[1]) / 2, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(r0["memory"][:B], keys[0], rtol=1e-6, atol=1e-7)          # rank 0's keys first
+    torch.testing.assert_close(r0["memory"][B:2 * B], keys[1], rtol=1e-6, atol=1e-7)     # then rank 1's

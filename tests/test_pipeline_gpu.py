@@ -32,7 +32,7 @@ def _digest(g):
     return torch.stack([n, e, nid, col]), torch.stack([psum, pabs, unit_err.double()])
 
 
-def _run(pipelined, graph):
+def _run(pipelined, graph, steps=STEPS, stress=False):
     from gcc_amd.contrast import MemoryMoCo
     from gcc_amd.encoder import GraphEncoder
     from gcc_amd.posemb import DevicePosEmb
@@ -63,16 +63,42 @@ def _run(pipelined, graph):
         tr.producer.cuda = False
     tr.dropout_seed = 7
     losses, ints, flts = [], [], []
-    for i in range(STEPS):
+    if stress:
+        # the hazard the round-5 fix (ad9f506) was about, provoked on purpose: no per-step synchronisation, no caller <-> step stream
+        # hand-offs (relaxed_streams), graph replay, and the producer lanes held up by random device-side sleeps so that refills,
+        # look-ahead launches and the consumer interleave differently at every step.  The batches are read ON THE STEP'S STREAM (the
+        # documented way, MoCoTrainStep.step): a slot handed back too early or consumed too early shows as a differing digest.
+        import random
+
+        rnd = random.Random(1234)
+        tr.relaxed_streams = True
+        for i in range(steps):
+            if rnd.random() < 0.35:
+                lane_stream = rnd.choice(tr.producer.streams)
+                with torch.cuda.stream(lane_stream):
+                    torch.cuda._sleep(int(rnd.uniform(2e5, 4e6)))          # 0.1 - 2 ms at ~2 GHz
+            if rnd.random() < 0.15:
+                with torch.cuda.stream(tr.main):
+                    torch.cuda._sleep(int(rnd.uniform(2e5, 2e6)))
+            out = tr.step(i, 0.005)
+            with torch.cuda.stream(tr.main):
+                losses.append(out["loss"].reshape(()).clone())
+                dq, dk = _digest(out["graph_q"]), _digest(out["graph_k"])
+                ints.append(torch.stack([dq[0], dk[0]]))
+                flts.append(torch.stack([dq[1], dk[1]]))
+        torch.cuda.synchronize()
+        assert tr.check_status(strict_posemb=True) == 0
+        assert getattr(tr, "graph_capture_failures", 0) == 0 and tr.graph_replays > steps // 2
+        return torch.stack(losses).cpu(), torch.stack(ints).cpu(), torch.stack(flts).cpu()
+    for i in range(steps):
         out = tr.step(i, 0.005)
         losses.append(out["loss"].reshape(()).clone())
         dq, dk = _digest(out["graph_q"]), _digest(out["graph_k"])
         ints.append(torch.stack([dq[0], dk[0]]))
         flts.append(torch.stack([dq[1], dk[1]]))
-        # the digests above run on THIS stream, the step ran on the trainer's: the next step() call hands the consumed ring slots back to
-        # the producer lanes, whose "slot free" event covers the step's kernels, not these -- a refill could overtake them (seen once the
-        # eigensolver got faster: step 9's batch read as the next chunk's).  A test-side read of a ring slot has to finish first.
-        torch.cuda.synchronize()
+        # (no synchronisation here: the digests run on THIS stream, the step on the trainer's; the next step() waits for this stream
+        #  and only then hands the consumed ring slots back -- round 5 recorded the "slot free" event before these reads and needed
+        #  a synchronisation per step here)
     torch.cuda.synchronize()
     flags = tr.check_status(strict_posemb=True)
     assert flags == 0
@@ -98,4 +124,24 @@ def test_pipelined_producer_equals_sequential_production_step_by_step():
     assert float(pip_f[:, :, 2].max()) < 1e-4 and float(seq_f[:, :, 2].max()) < 1e-4   # unit rows (data_util.py:260)
     # and the step
     assert torch.isfinite(seq_loss).all()
+    torch.testing.assert_close(pip_loss, seq_loss, rtol=2e-5, atol=1e-6)
+
+
+def test_ring_slots_under_random_producer_delays():
+    """120 steps of the pipelined producer with random device-side delays on the lanes' and the step's streams, relaxed stream
+    hand-offs and graph replay, read on the step's stream without a host synchronisation in the loop, against sequential
+    production: every step's sampler digests bit-equal, positional-embedding digests and losses equal."""
+    from gcc_amd.graph import DeviceGraph
+    from gcc_amd.graphgen import powerlaw_graph
+
+    dev = torch.device("cuda:0")
+    rp, ci = powerlaw_graph(1_000_000, 10_000_000, seed=0)
+    graph = DeviceGraph(rp, ci, rw_hops=256, restart_prob=0.8, device=dev, validate=False, trusted=True)
+    n = 120
+    seq_loss, seq_i, seq_f = _run(False, graph, steps=n)
+    pip_loss, pip_i, pip_f = _run(True, graph, steps=n, stress=True)
+    bad = (seq_i != pip_i).nonzero()
+    assert bad.numel() == 0, bad[:8].tolist()
+    torch.testing.assert_close(pip_f[:, :, 0], seq_f[:, :, 0], rtol=1e-6, atol=1e-3)
+    torch.testing.assert_close(pip_f[:, :, 1], seq_f[:, :, 1], rtol=1e-6, atol=1e-3)
     torch.testing.assert_close(pip_loss, seq_loss, rtol=2e-5, atol=1e-6)

@@ -111,7 +111,7 @@ def emu_wide_nce():
     return WideNceEngine(lib=emu_lib(), ptr=lambda t: 0 if t is None else t.data_ptr())
 
 
-@pytest.mark.parametrize("D,K", [(128, 96), (80, 200), (256, 64)])
+@pytest.mark.parametrize("D,K", [(128, 96), (80, 200), (256, 64), (96, 4400)])    # (K >= 4096: the split reduction of d loss / d q)
 def test_wide_moco_head_vs_oracle(D, K):
     """MemoryMoCo(inputSize > 64): dense logits, loss, prob, the gradient w.r.t. q against the queue BEFORE the enqueue, the
     queue after it (memory_moco.py:26-63, criterions.py:5-17), over three steps with a wrapping ring pointer."""

@@ -338,10 +338,13 @@ def main(args):
 
     posemb = None                                         # API path only; the fused steps embed in their producer lanes
     trainer, optimizer = None, None
-    wide = model.wide or contrast.wide    # above 64 channels (or a wider input): the any-width kernels (csrc/ginx.hip) through the API path below
-    if wide and world > 1:
-        raise NotImplementedError("--hidden-size above 64 runs the single-GPU API path; the data-parallel step is the fused 64-channel one")
-    if args.optimizer == "adam" and not wide:
+    wide = model.wide or contrast.wide    # above 64 channels (or a wider input): the any-width kernels (csrc/ginx.hip)
+    # --moco with Adam: the fused step at every width (MoCoTrainStep: producer lanes, flat buffers, clip + Adam + EMA as two launches,
+    # data parallel; above 64 channels on the any-width kernels, launch by launch).  E2E above 64 channels and SGD / Adagrad: the API
+    # path below (single GPU)
+    if wide and world > 1 and not (args.moco and args.optimizer == "adam"):
+        raise NotImplementedError("--hidden-size above 64 on several GPUs needs --moco with --optimizer adam (the data-parallel step)")
+    if args.optimizer == "adam" and (not wide or args.moco):
         # data pipeline: `producer_lanes` streams, each preparing `producer_chunk` steps per turn (sampler calls + one
         # multi-view eigensolver call) -- the role of the reference's --num-workers DataLoader processes
         lanes, depth = [], 2
