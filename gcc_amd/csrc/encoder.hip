@@ -137,11 +137,11 @@ struct InLaunch { InArgs p[kMaxPass]; long long *ticks; };
 static long long *g_gin_ticks = nullptr;   // diagnostics (gcc_gin_debug_ticks)
 // phase ticks (diagnostics, tools/gin_phases.py): ticks[kind][phase 0..15][workgroup 0..2047] (workgroup = blockIdx.y * 1024 + blockIdx.x),
 // kind 0 = gin_in first layer, 1 = gin_in other layers, 2 = gin_mid.  Every workgroup ADDS its own durations to its own slots with
-// plain read-modify-writes of thread 0 (launches of one stream do not overlap): no contention.  (Rounds 1-5 used one atomic per
+// non-returning atomics of thread 0 on slots nobody else touches: no contention, and no load in the listing (tests/test_isa_chains.py).  (Rounds 1-5 used one atomic per
 // phase on a shared slot: 780 workgroups queuing on one address cost more than the phases they timed.)  Phase 15 counts tiles.
 constexpr int kTickWgs = 2048, kTickPhases = 16;
-#define TICK_SLOT(kind, ph) L.ticks[((kind) * kTickPhases + (ph)) * kTickWgs + (int)blockIdx.y * 1024 + (int)blockIdx.x]
-#define GIN_TICK(ph) do { if (L.ticks && tid == 0) { const long long now_ = device_ticks(); TICK_SLOT(a.first ? 0 : 1, ph) += now_ - tick_; tick_ = now_; } } while (0)
+#define TICK_ADD(kind, ph, v) atomicAdd((unsigned long long *)&L.ticks[((kind) * kTickPhases + (ph)) * kTickWgs + (int)blockIdx.y * 1024 + (int)blockIdx.x], (unsigned long long)(v))
+#define GIN_TICK(ph) do { if (L.ticks && tid == 0) { const long long now_ = device_ticks(); TICK_ADD(a.first ? 0 : 1, ph, now_ - tick_); tick_ = now_; } } while (0)
 
 // (3 workgroups per CU by LDS -- 48.8 KiB with the staged weight -- so up to 168 registers are free: 8 gathered rows in flight)
 #ifndef GIN_IN_PER_CU
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kThreads, GIN_IN_PER_CU) void gin_in_kernel(InLaunc
     for (TileWalk tw(N); tw.ti < tw.tend; tw.ti += tw.step) {
         const int tile0 = tw.ti * kTile;
         const int nrows = min(kTile, N - tile0);
-        if (L.ticks && tid == 0) TICK_SLOT(a.first ? 0 : 1, 15) += 1;
+        if (L.ticks && tid == 0) TICK_ADD(a.first ? 0 : 1, 15, 1);
         // 1. own rows; the tile's row pointers and graph ids ride in the same round trip (the pooling and the gather
         //    would otherwise each start with one of their own)
         {
@@ -289,7 +289,7 @@ struct MidArgs {
     int32_t cap;              // gcc_gin_pass.node_cap
 };
 struct MidLaunch { MidArgs p[kMaxPass]; long long *ticks; };   // ticks: diagnostics (kind 2)
-#define MID_TICK(ph) do { if (L.ticks && tid == 0) { const long long now_ = device_ticks(); TICK_SLOT(2, ph) += now_ - tick_; tick_ = now_; } } while (0)
+#define MID_TICK(ph) do { if (L.ticks && tid == 0) { const long long now_ = device_ticks(); TICK_ADD(2, ph, now_ - tick_); tick_ = now_; } } while (0)
 
 __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
 {
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kThreads) void gin_mid_kernel(MidLaunch L)
             const F4 z = {0.f, 0.f, 0.f, 0.f};
             xb[c] = valid ? affine_relu(xb[c], aa[c]) : z;                                      // gin.py:115
         }
-        if (L.ticks && tid == 0) TICK_SLOT(2, 15) += 1;
+        if (L.ticks && tid == 0) TICK_ADD(2, 15, 1);
         MID_TICK(3);                                          // the tile's rows arrived, normalised
         linear_rows16_lds_store_stats(xb, Wl, bl, a.z2, row, valid, &red[wv * 2 * H]);      // gin.py:116
         MID_TICK(4);                                          // products, stores issued
