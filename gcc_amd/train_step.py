@@ -471,6 +471,7 @@ class _GraphedStep:
         """Record ``body``'s launches for ring slot ``key`` (nothing executes): one CUDAGraph per capturable segment, all from
         one memory pool (later segments read what earlier ones allocated)."""
         steps0 = self.optimizer.steps
+        self._drain_collectives()
         try:
             segments, result = body(self.scalars, {})
             items, pool = [], None
@@ -479,7 +480,10 @@ class _GraphedStep:
                     items.append(fn)                                     # (collectives: not run now, issued at every replay)
                     continue
                 gobj = torch.cuda.CUDAGraph()
-                gobj.capture_begin(capture_error_mode="thread_local", **({} if pool is None else dict(pool=pool)))
+                # (GCC_CAPTURE_MODE=relaxed was tried against the invalidated captures of the collectives path: no difference,
+                #  2 of 6 runs died either way -- see _drain_collectives)
+                mode = os.environ.get("GCC_CAPTURE_MODE") or "thread_local"
+                gobj.capture_begin(capture_error_mode=mode, **({} if pool is None else dict(pool=pool)))
                 try:
                     fn()
                 finally:
@@ -512,6 +516,28 @@ class _GraphedStep:
             self.optimizer.steps = steps0                                # the captured body counted a step that did not run
         self.graphs[key] = (items, dict(loss=cap["loss"], prob=cap["prob"], grad_norm=cap["grad_norm"]))
         return True
+
+    def _drain_collectives(self):
+        """Before a capture with a process group alive: wait until the group's watchdog thread has nothing left to poll.  The watchdog
+        queries the events of the collectives in flight every ~100 ms from ITS thread; on this runtime such a query while another
+        thread captures invalidates the capture (in "thread_local" and in "relaxed" mode alike: 2 of 6 runs of 1024 steps, always in
+        the start-up burst of captures right after the first eager step's collectives), the stream stays in the invalidated state,
+        the next eager collective records its hand-off event on it and the watchdog -- and the process -- die on "an event last
+        recorded in a capturing stream" (profiles/r6_collectives_soak_crash.txt; round 5 saw the first half of this once in ~10 runs
+        and tolerated it).  With the device idle and the pending-work list empty the watchdog has no event to query, and a capture
+        issues no collective (their segments stay eager)."""
+        if not self.collectives or self.dev.type != "cuda":
+            return
+        dist = torch.distributed
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
+            return
+        torch.cuda.synchronize(self.dev)
+        wait = getattr(dist.group.WORLD, "_wait_for_pending_works", None)
+        if wait is not None:
+            wait()
+        else:                                    # (older torch: one watchdog period)
+            import time
+            time.sleep(0.25)
 
     def _precapture_ready(self, st):
         """Right after the FIRST step of a run (launched eagerly: every lazily allocated engine buffer exists now), the graphs
