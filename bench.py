@@ -917,6 +917,7 @@ def main():
                 p["posemb"] = Prof(2)
         barrier()
         launched0 = trainer.producer.launched
+        late0 = (trainer.producer.late_chunks, trainer.producer.late_wait_s)
         trainer.graph_replays_at_clock = getattr(trainer, "graph_replays", 0)
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -925,6 +926,13 @@ def main():
         dt = time.perf_counter() - t0
         produced = (trainer.producer.launched - launched0) * chunk
         consumed = args.steps
+        extra["producer_late"] = dict(chunks=trainer.producer.late_chunks - late0[0], chunks_consumed=args.steps // chunk,
+                                      wait_ms_per_step=(trainer.producer.late_wait_s - late0[1]) * 1e3 / args.steps,
+                                      note="chunks whose data was not complete when the HOST reached their first step (it waits for the chunk's "
+                                           "event before it reads its status word), and that host wait spread over the timed steps.  The host "
+                                           "runs up to a chunk ahead of the device, so this is how the host paces itself, not a device stall: "
+                                           "more look-ahead (--depth 3) does not change the step time, a third lane makes it slower "
+                                           "(profiles/r6_producer_lateness.txt)")
         # two more windows of the same length right after the clock (diagnostics: `value` comes from the first window alone): a
         # 20-step window is 16 ms, and the line should say how much such a window moves from one to the next
         windows = [dt / args.steps * 1e3]

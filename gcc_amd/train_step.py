@@ -14,6 +14,7 @@ each; ``state_dict()`` is unaffected.
 from __future__ import annotations
 
 import os
+import time
 
 import torch
 
@@ -105,6 +106,7 @@ class BatchProducer:
         cap = len(lanes) * depth - 1
         self.ahead = max(1, min(cap, ahead if ahead is not None else len(lanes) * (depth - 1)))
         self.launched = 0                       # chunks launched so far (bench.py: produced == consumed in the window)
+        self.late_chunks, self.late_wait_s = 0, 0.0   # chunks the consumer had to wait for, and for how long (host clock)
         self.cuda = torch.device(device).type == "cuda"
         self._owners = []
         if self.cuda and reserved_cus:          # producers stay off `reserved_cus` compute units (gcc_amd/streams.py)
@@ -232,7 +234,10 @@ class BatchProducer:
             sampler = self.lanes[c % len(self.lanes)][0]
             if ev is not None:
                 if not ev.query():               # the chunk was launched `ahead` chunks ago: normally long complete, and a
-                    ev.synchronize()             # completed event costs one poll instead of a blocking call
+                    t_wait = time.perf_counter() # completed event costs one poll instead of a blocking call
+                    ev.synchronize()
+                    self.late_chunks += 1        # (bench.py reports both: a step that waits here is producer-bound)
+                    self.late_wait_s += time.perf_counter() - t_wait
             elif hasattr(sampler, "snapshot_sync"):
                 sampler.snapshot_sync()          # produced on the current stream (prefetch off): wait for it
             bits = sampler.read_snapshot(self.snap[c][0])
