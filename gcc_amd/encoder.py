@@ -180,6 +180,8 @@ class GinEngine:
         # replayed step (hipGraph): the Philox key of the dropout masks is read from the device struct (gcc_step_scalars)
         p.scalars = ptr(scalars) if scalars is not None else None
         p.node_cap = node_cap
+        if self.rows_hint is None:               # API path / tests: the first batch this engine sees sizes the grids (one host read, once;
+            self.hint_rows(int(g.node_off[g.batch_size].item()))      # the fused steps set it before their first pass, outside any capture)
         p.rows_hint = int(self.rows_hint or 0)   # grid of the tile kernels: an upper estimate of the live rows (0: the capacity)
         buf = dict(buf)
         buf["_keepalive"] = (g, keep, enc)      # the struct holds raw pointers into these
