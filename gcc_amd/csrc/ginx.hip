@@ -189,18 +189,36 @@ __global__ void ginx_feat_kernel(const int32_t *node_off, const int32_t *row_ptr
     x0[(int64_t)v * d_in + c] = val;
 }
 
-// d degree_embedding[clamp(deg(v))][c] += dx0[v][pos_dim + c]   (the gradient of nn.Embedding: a scatter-add)
-__global__ void ginx_feat_bwd_kernel(const int32_t *node_off, const int32_t *row_ptr, int B, int pos_dim, int de, int max_degree,
-                                     const float *dx0, float *demb)
+// d degree_embedding[clamp(deg(v))][c] += dx0[v][pos_dim + c]   (the gradient of nn.Embedding: a scatter-add).  Most nodes share a
+// handful of small degrees: one global atomic per (node, column) queued 25 k nodes on a few cache lines (382 us at bsz 256).  A
+// workgroup now adds its kFeatRows rows into an LDS copy of the table first and flushes the entries it touched.
+constexpr int kFeatRows = 1024, kFeatMaxElems = 10240;     // rows per workgroup; (max_degree + 1) * de floats of LDS (40 KiB)
+__global__ __launch_bounds__(256) void ginx_feat_bwd_kernel(const int32_t *node_off, const int32_t *row_ptr, int B, int pos_dim, int de, int max_degree,
+                                                             const float *dx0, float *demb)
 {
+    __shared__ float E[kFeatMaxElems];
     const int d_in = pos_dim + de + 1;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int N = node_off[B];
-    const int v = (int)(i / de), c = (int)(i % de);
-    if (v >= N) return;
-    int d = row_ptr[v + 1] - row_ptr[v];
-    d = d < 0 ? 0 : (d > max_degree ? max_degree : d);
-    atomicAdd(&demb[(int64_t)d * de + c], dx0[(int64_t)v * d_in + pos_dim + c]);
+    const int r0 = (int)blockIdx.x * kFeatRows, r1 = min(N, r0 + kFeatRows);
+    if (r0 >= N) return;
+    const int elems = (max_degree + 1) * de;
+    const bool lds = elems <= kFeatMaxElems;                 // (block-uniform; larger tables: straight to global memory)
+    if (lds) {
+        for (int i = (int)threadIdx.x; i < elems; i += 256) E[i] = 0.f;
+        __syncthreads();
+    }
+    for (int64_t i = (int64_t)r0 * de + threadIdx.x; i < (int64_t)r1 * de; i += 256) {
+        const int v = (int)(i / de), c = (int)(i % de);
+        int d = row_ptr[v + 1] - row_ptr[v];
+        d = d < 0 ? 0 : (d > max_degree ? max_degree : d);
+        const float g = dx0[(int64_t)v * d_in + pos_dim + c];
+        if (lds) atomicAdd(&E[d * de + c], g); else atomicAdd(&demb[(int64_t)d * de + c], g);
+    }
+    if (lds) {
+        __syncthreads();
+        for (int i = (int)threadIdx.x; i < elems; i += 256)
+            if (E[i] != 0.f) atomicAdd(&demb[i], E[i]);
+    }
 }
 
 // out[v] = x[v] + mult * sum over row v of x[col]  (+ add[v] when add != NULL): one wave per row.  Rows whose width is a multiple of
@@ -239,9 +257,20 @@ __global__ __launch_bounds__(256) void ginx_spmm_kernel(const int32_t *node_off,
         }
         return;
     }
-    for (int c = lane; c < D; c += 64) {
+    for (int c = lane; c < D; c += 64) {                                 // (widths that are not a multiple of four: the 49 input features)
+        constexpr int kJ = 8;
         float nb = 0.f;
-        for (int e = e0; e < e1; ++e) nb += x[(int64_t)col_idx[e] * D + c];
+        for (int e = e0; e < e1; e += kJ) {
+            int u[kJ];
+            float f[kJ];
+#pragma unroll
+            for (int j = 0; j < kJ; ++j) u[j] = col_idx[min(e + j, e1 - 1)];
+#pragma unroll
+            for (int j = 0; j < kJ; ++j) f[j] = x[(int64_t)u[j] * D + c];
+#pragma unroll
+            for (int j = 0; j < kJ; ++j)
+                if (e + j < e1) nb += f[j];
+        }
         float acc = x[(int64_t)v * D + c] + mult * nb;                   // (every edge counts `mult` times: gcc_gin_pass.edge_multiplicity)
         if (add) acc += add[(int64_t)v * D + c];
         out[(int64_t)v * D + c] = acc;
@@ -394,11 +423,44 @@ __global__ void ginx_sums_to_grad_kernel(const double *src, int D, float *dst, i
     if (c < D) dst[c] = (accumulate ? dst[c] : 0.f) + (float)src[c];
 }
 
-// pooled[b][c] = sum of h over the nodes of graph b (SumPooling, gin.py:205,228): one workgroup per graph
+// pooled[b][c] = sum of h over the nodes of graph b (SumPooling, gin.py:205,228): one workgroup per graph.  Widths that are a multiple
+// of four: 64 lanes x 16 bytes cover 256 channels, the four waves take every fourth row (eight rows each in flight) and their fp64
+// partial sums are added in wave order; otherwise a thread per channel walks the rows eight at a time.
 __global__ __launch_bounds__(256) void ginx_pool_kernel(const int32_t *node_off, const float *h, int D, float *pooled)
 {
+    __shared__ double part[4][4 * 64];
     const int b = (int)blockIdx.x;
     const int r0 = node_off[b], r1 = node_off[b + 1];
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
+    if ((D & 3) == 0) {
+        for (int c0 = 0; c0 < D; c0 += 256) {                             // (block-uniform trip count)
+            const int c = c0 + 4 * lane;
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+            if (c < D) {
+                for (int r = r0 + wv; r < r1; r += 32) {                      // this wave's rows r0 + wv, + 4, ...: eight per round
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = *(const float4 *)(h + (int64_t)min(r + 4 * u, r1 - 1) * D + c);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (r + 4 * u < r1) { s[0] += (double)v[u].x; s[1] += (double)v[u].y; s[2] += (double)v[u].z; s[3] += (double)v[u].w; }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[wv][4 * lane + e] = s[e];
+            __syncthreads();
+            if (wv == 0 && c < D) {
+                float4 o;
+                o.x = (float)((part[0][4 * lane + 0] + part[1][4 * lane + 0]) + (part[2][4 * lane + 0] + part[3][4 * lane + 0]));
+                o.y = (float)((part[0][4 * lane + 1] + part[1][4 * lane + 1]) + (part[2][4 * lane + 1] + part[3][4 * lane + 1]));
+                o.z = (float)((part[0][4 * lane + 2] + part[1][4 * lane + 2]) + (part[2][4 * lane + 2] + part[3][4 * lane + 2]));
+                o.w = (float)((part[0][4 * lane + 3] + part[1][4 * lane + 3]) + (part[2][4 * lane + 3] + part[3][4 * lane + 3]));
+                *(float4 *)(pooled + (int64_t)b * D + c) = o;
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int c = (int)threadIdx.x; c < D; c += 256) {
         double s = 0.0;
         for (int r = r0; r < r1; r += 8) {                                // (eight rows requested per round, added in row order)
@@ -413,14 +475,24 @@ __global__ __launch_bounds__(256) void ginx_pool_kernel(const int32_t *node_off,
     }
 }
 
-// dh[v][c] (+)= dpooled[graph_id[v]][c]
-__global__ void ginx_pool_bwd_kernel(const int32_t *node_off, const int32_t *graph_id, int B, const float *dpooled, int D, float *dh, int accumulate)
+// dh[v][c] (+)= dpooled[graph_id[v]][c]   (`vec`: one thread per four elements, D a multiple of four)
+__global__ void ginx_pool_bwd_kernel(const int32_t *node_off, const int32_t *graph_id, int B, const float *dpooled, int D, float *dh, int accumulate, int vec)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)node_off[B] * D) return;
-    const int v = (int)(i / D), c = (int)(i % D);
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)node_off[B] * D;
+    if (vec) {
+        const int64_t i = 4 * t;
+        if (i >= total) return;
+        const int v = (int)(i / D), c = (int)(i % D);
+        float4 g = *(const float4 *)(dpooled + (int64_t)graph_id[v] * D + c);
+        if (accumulate) { const float4 o = *(const float4 *)(dh + i); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
+        *(float4 *)(dh + i) = g;
+        return;
+    }
+    if (t >= total) return;
+    const int v = (int)(t / D), c = (int)(t % D);
     const float g = dpooled[(int64_t)graph_id[v] * D + c];
-    dh[i] = accumulate ? dh[i] + g : g;
+    dh[t] = accumulate ? dh[t] + g : g;
 }
 
 // score (+)= y * keep * scale   (dropout with an explicit 0/1 keep mask, scale = 1 / (1 - p); keep == NULL: no dropout);
@@ -718,7 +790,7 @@ int32_t gcc_ginx_backward(const gcc_ginx_pass *p, const float *dfeat, const gcc_
     };
     // dh of the last hidden representation: only its pooled readout feeds the loss
     readout_bwd(L, ws + x.dpool);
-    hipLaunchKernelGGL(ginx_pool_bwd_kernel, dim3(blocks(N * W)), dim3(256), 0, s, p->node_off, p->graph_id, B, ws + x.dpool, W, dA, 0);
+    hipLaunchKernelGGL(ginx_pool_bwd_kernel, dim3(blocks((W & 3) == 0 ? N * W / 4 : N * W)), dim3(256), 0, s, p->node_off, p->graph_id, B, ws + x.dpool, W, dA, 0, (W & 3) == 0);
     for (int l = L - 1; l >= 0; --l) {
         const int Din = l == 0 ? d_in : W;
         bn_bwd(ws + x.a2[l], ws + x.h[l], dA, w.bn_c[l], x.mr[l][2], dB_, gr->bn_c_w[l], gr->bn_c_b[l]);                  // -> d a2
@@ -732,12 +804,13 @@ int32_t gcc_ginx_backward(const gcc_ginx_pass *p, const float *dfeat, const gcc_
         gemm(s, dA, W, 1, w.lin0_w[l], Din, 1, dB_, Din, 0, Din, W, nullptr, rows, 1, N);                                  // d agg = dz1 W0
         // d h_{l-1} = d agg + A d agg (the batched subgraph is symmetric) + the pooled readout of hidden_rep[l]'s input
         readout_bwd(l, ws + x.dpool);
-        hipLaunchKernelGGL(ginx_pool_bwd_kernel, dim3(blocks(N * Din)), dim3(256), 0, s, p->node_off, p->graph_id, B, ws + x.dpool, Din, dC, 0);
+        hipLaunchKernelGGL(ginx_pool_bwd_kernel, dim3(blocks((Din & 3) == 0 ? N * Din / 4 : N * Din)), dim3(256), 0, s, p->node_off, p->graph_id, B, ws + x.dpool, Din, dC, 0,
+                           (Din & 3) == 0);
         hipLaunchKernelGGL(ginx_spmm_kernel, dim3(blocks(N, 4)), dim3(256), 0, s, p->node_off, p->row_ptr, p->col_idx, B, dB_, Din, (const float *)dC, dA, 1.0f);
     }
     // d x0 (in dA, width d_in) -> the degree embedding's rows
     (void)hipMemsetAsync(gr->degree_embedding, 0, sizeof(float) * (size_t)(w.max_degree + 1) * w.deg_emb_dim, s);
-    hipLaunchKernelGGL(ginx_feat_bwd_kernel, dim3(blocks(N * w.deg_emb_dim)), dim3(256), 0, s, p->node_off, p->row_ptr, B, w.pos_dim, w.deg_emb_dim,
+    hipLaunchKernelGGL(ginx_feat_bwd_kernel, dim3(blocks(N, kFeatRows)), dim3(256), 0, s, p->node_off, p->row_ptr, B, w.pos_dim, w.deg_emb_dim,
                        w.max_degree, dA, gr->degree_embedding);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, kErrLen, "gcc_ginx_backward: launch failed: %s", hipGetErrorString(e)); return -10; }
