@@ -53,13 +53,19 @@ struct NceDev {
     float *dq;
 };
 
+#ifndef GCC_NCE_WGS_DEFAULT
+#define GCC_NCE_WGS_DEFAULT 256
+#endif
+constexpr int kNceWgs = GCC_NCE_WGS_DEFAULT;     // ~one workgroup per CU: enough to spread the queue, few enough slabs to reduce
 struct Plan { int32_t S, R, QB; int64_t off_pm, off_ps, off_slabs, off_ticket, total; };
 
 inline Plan make_plan(int32_t B, int32_t K)
 {
     Plan p;
     p.QB = (B + kQPerBlock - 1) / kQPerBlock;
-    int s = (256 + p.QB - 1) / p.QB;       // ~256 workgroups (one per CU): enough to spread the queue, few enough slabs to reduce
+    static int wgs = 0;                      // workgroups of a slice launch (GCC_NCE_WGS: timing experiments)
+    if (wgs == 0) { const char *e = getenv("GCC_NCE_WGS"); wgs = e ? atoi(e) : 0; if (wgs <= 0) wgs = kNceWgs; }
+    int s = (wgs + p.QB - 1) / p.QB;
     const int maxs = (K + kChunk - 1) / kChunk;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
