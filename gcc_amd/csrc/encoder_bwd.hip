@@ -586,7 +586,10 @@ __global__ __launch_bounds__(kThreads) void gin_bwd_emb_kernel(EmbArgs a)
     __shared__ int prow[32];
     __shared__ int rpl[kTile + 1];
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4;
-    auto ident = [&](int u) -> F4 { return ld4(a.D + (int64_t)u * H + 4 * t); };
+    // only the degree-embedding columns [pos_dim, pos_dim + emb_dim) of dx0 are used: the lanes whose four columns lie outside them
+    // request nothing (a quarter of the gather's bytes at pos 32 / emb 16) and carry zeros
+    const bool my_cols = 4 * t + 3 >= a.pos_dim && 4 * t < a.pos_dim + a.emb_dim;
+    auto ident = [&](int u) -> F4 { return my_cols ? ld4(a.D + (int64_t)u * H + 4 * t) : zero4(); };
     // row pointers, graph ids and the lane group's 4 rows of the FIRST tile: requested together with the node count (clamped to
     // the capacity), stored afterwards (a load under `if (tid < ...)` next to its LDS store is a round trip of its own)
     const int tf = first_tile();

@@ -149,8 +149,10 @@ class GinEngine:
                 score=torch.zeros(B, H, **f32), feat=torch.zeros(B, H, **f32))
         return self._bufs[k]
 
-    def make_pass(self, enc, g, training, keep=None, slot=0, dropout_seed=None, scalars=None):
-        """-> (GccGinPass, buffers).  ``g`` needs node_off,row_ptr,col_idx,graph_id,pos_undirected,batch_size."""
+    def make_pass(self, enc, g, training, keep=None, slot=0, dropout_seed=None, scalars=None, backward=True):
+        """-> (GccGinPass, buffers).  ``g`` needs node_off,row_ptr,col_idx,graph_id,pos_undirected,batch_size.
+        ``backward=False``: a pass nobody differentiates (MoCo's key encoder): ``agg`` -- kept only for the weight gradient of
+        linears.0 -- is not stored (6.4 MB per layer at bsz 256)."""
         ptr = self.ptr
         L = len(enc.gnn.ginlayers)
         enc.ensure_padded()
@@ -171,7 +173,7 @@ class GinEngine:
         p.w = fill_weights(enc, ptr)
         p.x0 = ptr(buf["x0"])
         for i in range(L):
-            p.agg[i], p.z1[i], p.z2[i] = ptr(buf["agg"][i]), ptr(buf["z1"][i]), ptr(buf["z2"][i])
+            p.agg[i], p.z1[i], p.z2[i] = (ptr(buf["agg"][i]) if backward else None), ptr(buf["z1"][i]), ptr(buf["z2"][i])
         p.stats, p.pooled, p.score, p.feat = ptr(buf["stats"]), ptr(buf["pooled"]), ptr(buf["score"]), ptr(buf["feat"])
         p.edge_multiplicity = int(getattr(g, "edge_multiplicity", 1))
         p.bn_totals = ptr(buf["bn_totals"]) if training else None

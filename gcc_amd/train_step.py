@@ -834,7 +834,7 @@ class MoCoTrainStep(_GraphedStep):
             S["pq"], S["bufq"] = self.gin.make_pass(self.model, q, training=True, keep=keep, slot=("step", 0),
                                                     dropout_seed=(0 if seed is not None else None) if scalars is not None else seed,
                                                     scalars=scalars)
-            S["pk"], S["bufk"] = self.gin.make_pass(self.ema, k, training=True, keep=None, slot=("step", 1))
+            S["pk"], S["bufk"] = self.gin.make_pass(self.ema, k, training=True, keep=None, slot=("step", 1), backward=False)
             self.gin.forward([S["pq"], S["pk"]], stream=st, prof=pr.get("gin_fwd"))      # train.py:389-391
 
         def gather_begin():                    # RCCL, overlapped with everything up to the enqueue
