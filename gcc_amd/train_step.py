@@ -303,7 +303,14 @@ def read_meters(trainer):
     trainer.meter_acc.zero_()
     trainer.meter_max.zero_()
     if hasattr(getattr(trainer, "gin", None), "hint_rows") and m[0] > 0:
+        before = trainer.gin.rows_hint
         trainer.gin.hint_rows(m[0], margin=1.04)       # (the largest q view since the last log line; the k views are as large)
+        if before is not None and trainer.gin.rows_hint > before and getattr(trainer, "graphs", None):
+            # batches have outgrown the grids the step graphs were captured with (a corpus whose shards differ in size: the first
+            # batch came from a small one): a captured grid is baked in, and its workgroups would walk two or three tiles each
+            # for the rest of the run.  The slots are captured again, under the new estimate, after their next (eager) step.
+            trainer._retired_graphs = list(trainer.graphs.values())
+            trainer.graphs = {}
     return a, m
 
 
