@@ -436,7 +436,9 @@ int32_t gcc_ginx_backward(const gcc_ginx_pass *p, const float *dfeat, const gcc_
  * over the K queue rows and is split over workgroups). */
 int32_t gcc_ncex_forward(const float *q, const float *k, const float *mem, int32_t B, int32_t K, int32_t D, float inv_T, int32_t mode,
                          float *out, float *dlog, float *grad_rows, float *grad_mem, float *loss, float *prob, double *acc, void *stream);
-/* memory.index_copy_(0, (arange(nkeys) + index) % K, keys) (memory_moco.py:55-61) for rows of D floats */
+/* memory.index_copy_(0, (arange(nkeys) + index) % K, keys) (memory_moco.py:55-61) for rows of D floats.  nkeys <= K is required
+ * (rc -1 otherwise), as gcc_queue_enqueue requires it: with more keys than queue rows the indices collide and the reference's
+ * index_copy_ result depends on the order its kernel happens to write in -- nothing a replacement could be bit-equal to. */
 int32_t gcc_queue_enqueue_x(float *mem, int32_t K, int32_t D, const float *keys, int32_t nkeys, int32_t index, void *stream);
 
 /* ------------------------------------------ wide GIN layers, bf16 (config 5) ---
