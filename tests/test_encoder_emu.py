@@ -243,3 +243,48 @@ def test_api_path_autograd_matches_golden(monkeypatch):
         torch.testing.assert_close(got[n], ref, rtol=2e-3, atol=max(2e-4 * scale, 1e-6), msg=n)
     # parameters the reference leaves without gradient (set2set, lin_readout) stay that way
     assert all(p.grad is None for n, p in model.named_parameters() if n.startswith(("set2set", "lin_readout")))
+
+
+def test_grid_smaller_than_the_batch_walks_on():
+    """gcc_gin_pass.rows_hint sizes the tile kernels' grids (round 6); a batch with more tiles than the grid has workgroups must come out
+    the same: every workgroup walks on from its first tile in steps of the grid, and only the first tile uses the speculative requests
+    issued with the node count.  22 graphs, 2,400 nodes = 38 tiles against the smallest grid (32 workgroups, rows_hint = 1); emulator
+    tier of tests/test_encoder_gpu.py::test_tile_grid_smaller_than_the_batch_walks_on."""
+    import numpy as np
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(0)
+    offs, rows, cols = [0], [], []
+    for _ in range(22):
+        n = int(rng.integers(80, 130))
+        a = np.r_[rng.integers(0, n, 3 * n), np.arange(n)]
+        b = np.r_[rng.integers(0, n, 3 * n), (np.arange(n) + 1) % n]
+        k = a != b
+        rows += list(offs[-1] + a[k]) + list(offs[-1] + b[k])
+        cols += list(offs[-1] + b[k]) + list(offs[-1] + a[k])
+        offs.append(offs[-1] + n)
+    N = offs[-1]
+    A = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(N, N))
+    A.sum_duplicates()
+    A.sort_indices()
+    assert N > 32 * 64 and np.diff(A.indptr).min() > 0
+    view = dict(node_off=torch.tensor(offs), row_ptr=torch.from_numpy(A.indptr.astype(np.int64)),
+                col_idx=torch.from_numpy(A.indices.astype(np.int64)),
+                pos_undirected=torch.randn(N, 32, generator=torch.Generator().manual_seed(2)) * 0.2)
+    keep = (torch.rand(5, 22, 64, generator=torch.Generator().manual_seed(3)) > 0.5).float()
+    d = torch.randn(22, 64, generator=torch.Generator().manual_seed(4))
+    outs = []
+    for hint in (None, 1):
+        torch.manual_seed(1)
+        model = reference_encoder()
+        model.train()
+        eng = emu_engine()
+        model._engine = eng
+        eng.rows_hint = hint                      # None: taken from the batch (43 tiles -> 64 workgroups); 1: 32 workgroups
+        p, buf = eng.make_pass(model, CpuBatch(view), training=True, keep=keep)
+        eng.forward([p])
+        eng.backward(model, p, buf, d)
+        outs.append((buf["feat"].clone(), [q.grad.clone() for q in model.parameters() if q.grad is not None]))
+    torch.testing.assert_close(outs[1][0], outs[0][0], rtol=1e-5, atol=1e-6)
+    for a, b in zip(outs[1][1], outs[0][1]):      # (fp32 partial sums group differently when a workgroup walks two tiles)
+        torch.testing.assert_close(a, b, rtol=0, atol=max(2e-4 * float(b.abs().max()), 1e-5))       # (a Linear bias in front of a BatchNorm: noise around 0)
