@@ -17,6 +17,8 @@
 // Same arithmetic as gcc_gin_forward with training = 0 (same affine tables, same MFMA sequences; the gather's summation
 // order differs because tiles start at the subgraph, not at multiples of 64 of the batch): agreement ~1e-6.
 #include "encoder_common.h"
+#include <cstdlib>
+#include <mutex>
 
 namespace {
 
@@ -41,20 +43,41 @@ struct EvalArgs {
     float eps, norm_eps;
 };
 struct EvalLaunch { EvalArgs p[kMaxPass]; long long *ticks; int32_t split; };   // split: small subgraphs are gin_eval_small_kernel's
-static long long *g_eval_ticks = nullptr;    // diagnostics (gcc_gin_eval_debug_ticks): device int64[16]
-#define EV_TICK(ph) do { if (Ln.ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&Ln.ticks[(ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
+static long long *g_eval_ticks = nullptr;    // diagnostics (gcc_gin_eval_debug_ticks): device int64[3][16] (small, medium, general kernel)
+#define EV_TICK(ph) do { if (Ln.ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 
 // ---- pieces shared by the two kernel shapes ------------------------------------------------------------------------------
 // a layer's weights / BatchNorm numbers are requested one layer ahead (registers) and stored when the LDS buffers are free
 struct LayerRegs { WStage s0, s1; float v0, v1, v2, v3; };
-__device__ __forceinline__ LayerRegs eval_request_layer(const EvalArgs &a, int l)
+// kQ: the matrix's rows are whole 16-byte quads (width % 4 == 0, base aligned: the host checks) -> four global_load_dwordx4 per
+// thread.  A compile-time choice per kernel: with both forms behind a run-time branch (stage_weights_request) the compiler merged
+// them into sixteen global_load_dword -- four times the requests for the same bytes.
+template <bool kQ> __device__ __forceinline__ WStage eval_weights_request(const float *W, int kdim)
+{
+    WStage st;
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                // (unconditional, clamped; columns >= kdim are zeroed when stored)
+        const int idx = tid + i * kThreads, r = idx >> 4, c4 = 4 * (idx & 15);
+        const float *p = W + (int64_t)r * kdim;
+        if constexpr (kQ) st.v[i] = ld4(p + min(c4, kdim - 4));
+        else st.v[i] = F4{p[min(c4 + 0, kdim - 1)], p[min(c4 + 1, kdim - 1)], p[min(c4 + 2, kdim - 1)], p[min(c4 + 3, kdim - 1)]};
+    }
+    return st;
+}
+// kFirst: layer 0, whose first matrix is d_in = 49 wide (element loads, once per kernel)
+template <bool kQ, bool kFirst> __device__ __forceinline__ LayerRegs eval_request_layer(const EvalArgs &a, int l)
 {
     const EvalLayer &ly = a.layer[l];
     const int tid = (int)threadIdx.x;
     LayerRegs r;
-    r.s0 = stage_weights_request(ly.w0, l == 0 ? a.kdim0 : a.hid);
-    r.s1 = stage_weights_request(ly.w1, a.hid);
-    const int c = tid & 63, which = tid >> 6;                    // which < 3: a BatchNorm; 3: the two biases
+    if constexpr (kFirst) r.s0 = eval_weights_request<false>(ly.w0, a.kdim0);
+    else r.s0 = eval_weights_request<kQ>(ly.w0, a.hid);
+    r.s1 = eval_weights_request<kQ>(ly.w1, a.hid);
+    // which < 3: a BatchNorm; 3: the two biases.  wave_uniform: the index into the descriptor's pointer arrays is then a scalar
+    // (s_load); as a vector index the POINTERS came through global_load + s_waitcnt vmcnt(0) -- behind the weight requests just
+    // issued, i.e. every layer waited for its successor's weights (the "weights" phase: 46 of a workgroup's 95 us)
+    const int c = tid & 63, which = wave_uniform(tid >> 6);
     r.v2 = r.v3 = 0.f;
     if (which < 3) { r.v0 = ly.bn_w[which][c]; r.v1 = ly.bn_b[which][c]; r.v2 = ly.bn_rm[which][c]; r.v3 = ly.bn_rv[which][c]; }
     else { r.v0 = ly.b0 ? ly.b0[c] : 0.f; r.v1 = ly.b1 ? ly.b1[c] : 0.f; }
@@ -133,19 +156,89 @@ __device__ __forceinline__ void eval_mlp_rows16(const F4 xb[4], const float *Wl0
         h[cb] = affine_relu(affine_relu(z, aff4_from_table(tab + 2 * H, ch)), aff4_from_table(tab + 4 * H, ch));
     }
 }
+// The LDS-resident kernels' aggregation: lane (j, q) of a wave owns row j of the wave's 16 and the channel quads 16 c + 4 q; its
+// result is the sum of rows cols[rb .. re) of A.
+//   * rows of at most kEvalHub neighbours: every lane walks ITS row in CSR order, four neighbours per round trip -- their ids
+//     first, then the sixteen quad reads, then the adds (one id and four reads at a time was two dependent LDS latencies per
+//     neighbour: ~300 clocks each).  A lane past its row's end reads the zero row `zrow` of A (x + 0 = x: the sums are those of
+//     the one-at-a-time loop, bit for bit).
+//   * hub rows (the seed of an ego-net is adjacent to a large part of it: 100-300 neighbours): one at a time by the whole wave --
+//     lane (j, q) sums the neighbours hb + j, hb + j + 16, ... (again four per round trip), the 16 partial sums of a quad are
+//     added over the DPP row (fixed tree) and handed to the owning lane.  A wave used to run as long as its longest row: 75
+//     rounds for a 300-neighbour hub while the other 15 rows had finished after 2.
+constexpr int kEvalHub = 32;
+template <class ColT>
+__device__ __forceinline__ void eval_gather4(const float *A, const ColT *cols, int e, int stride, int end, int zrow, int q, F4 acc[4])
+{
+    int id[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) id[u] = (int)cols[min(e + u * stride, end - 1)];
+    F4 v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float *src = &A[(e + u * stride < end ? id[u] : zrow) * kEvalLd + 4 * q];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[u][c] = ld4(src + 16 * c);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = add4(acc[c], v[u][c]);
+}
+template <class ColT>
+__device__ __forceinline__ void eval_gather_row(const float *A, const ColT *cols, int rb, int re, int zrow, int j, int q, F4 acc[4])
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = F4{0.f, 0.f, 0.f, 0.f};
+    const bool hub = re - rb > kEvalHub;
+    unsigned long long hubs = wave_ballot(hub) & 0xFFFFull;      // (lanes 0 .. 15 are q = 0 of the 16 rows)
+    for (int e = rb; e < (hub ? rb : re); e += 4) eval_gather4(A, cols, e, 1, re, zrow, q, acc);
+    while (hubs) {                                               // (wave-uniform)
+        const int jh = __builtin_ctzll(hubs);
+        hubs &= hubs - 1;
+        const int hb = wave_readlane(rb, jh), he = wave_readlane(re, jh);
+        F4 s[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] = F4{0.f, 0.f, 0.f, 0.f};
+        for (int e = hb + j; e < he; e += 64) eval_gather4(A, cols, e, 16, he, zrow, q, s);
+        const int last = (lane_id() & 48) | 15;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const F4 tot = {wave_shfl(row16_sum_last(s[c].x), last), wave_shfl(row16_sum_last(s[c].y), last),
+                            wave_shfl(row16_sum_last(s[c].z), last), wave_shfl(row16_sum_last(s[c].w), last)};
+            if (j == jh) acc[c] = tot;
+        }
+    }
+}
+// one output of a prediction layer: b + sum_k w[k] pooled[k], k ascending (gin.py:229); the weight row in quads when it can be
+__device__ __forceinline__ float eval_pred_dot(const float *w, const float *bias_o, const double *pool, int kd, bool quads)
+{
+    float acc = bias_o ? *bias_o : 0.f;
+    if (quads) {
+        for (int k = 0; k < kd; k += 4) {
+            const F4 w4 = ld4(w + k);
+            acc = fmaf(w4.x, (float)pool[k], acc);
+            acc = fmaf(w4.y, (float)pool[k + 1], acc);
+            acc = fmaf(w4.z, (float)pool[k + 2], acc);
+            acc = fmaf(w4.w, (float)pool[k + 3], acc);
+        }
+    } else {
+        for (int k = 0; k < kd; ++k) acc = fmaf(w[k], (float)pool[k], acc);
+    }
+    return acc;
+}
+__device__ __forceinline__ bool eval_pred_quads(const float *W, int kd) { return (kd & 3) == 0 && ((uintptr_t)W & 15) == 0; }   // (block-uniform)
 // readout: score = sum_i linears_prediction[i](pooled_i) (gin.py:227-230; eval: dropout is the identity), F.normalize
 // (graph_encoder.py:195-196), the mean over the passes, the pooled sums.  pool: LDS [L + 1][64] fp64; ppart: LDS scratch
 __device__ __forceinline__ void eval_readout(const EvalArgs &a, int b, const double *pool, double *ppart)
 {
     const int tid = (int)threadIdx.x, L = a.L;
-    const int o = tid & 63, pt = tid >> 6;
+    const int o = tid & 63, pt = wave_uniform(tid >> 6);         // (scalar: the layer's pointers come by s_load)
     float s = 0.f;
     for (int i = pt; i <= L; i += 4) {
         const int kd = i == 0 ? a.kdim0 : a.hid;
-        const float *w = a.pred_w[i] + (int64_t)o * kd;
-        float acc = a.pred_b[i] ? a.pred_b[i][o] : 0.f;
-        for (int k = 0; k < kd; ++k) acc = fmaf(w[k], (float)pool[i * H + k], acc);
-        s += acc;
+        s += eval_pred_dot(a.pred_w[i] + (int64_t)o * kd, a.pred_b[i] ? a.pred_b[i] + o : nullptr, pool + i * H, kd,
+                           eval_pred_quads(a.pred_w[i], kd));
     }
     float *sp = (float *)ppart;                                  // [4][64] partial scores
     sp[pt * H + o] = s;
@@ -174,16 +267,16 @@ __device__ __forceinline__ void eval_readout(const EvalArgs &a, int b, const dou
 // the same rows after one barrier.  69 KB of LDS: two workgroups per CU (the general kernel below: 142 KB, one).
 constexpr int kSmallCap = kTile;
 constexpr int kSmallEdges = 6144;
-constexpr int kSmallLds = (kSmallCap * kEvalLd + 2 * H * kLdt + 6 * H + 2 * H) * 4 + (GCC_GIN_MAX_LAYERS + 1) * H * 8 + 4 * H * 8
+constexpr int kSmallLds = ((kSmallCap + 1) * kEvalLd + 2 * H * kLdt + 6 * H + 2 * H) * 4 + (GCC_GIN_MAX_LAYERS + 1) * H * 8 + 4 * H * 8
                           + 68 * 4 + kSmallEdges;
 __device__ __forceinline__ bool eval_is_small(int n, int nnz) { return n <= kSmallCap && nnz <= kSmallEdges; }
 
-__global__ __launch_bounds__(kThreads, 2) void gin_eval_small_kernel(EvalLaunch Ln)
+template <bool kQ> __global__ __launch_bounds__(kThreads, 2) void gin_eval_small_kernel(EvalLaunch Ln)
 {
     DYN_SMEM(smem);
     const EvalArgs &a = Ln.p[blockIdx.y];
-    float *A = (float *)smem;                                   // [64][kEvalLd]
-    float *Wl0 = A + kSmallCap * kEvalLd, *Wl1 = Wl0 + H * kLdt;
+    float *A = (float *)smem;                                   // [64 + the zero row][kEvalLd]
+    float *Wl0 = A + (kSmallCap + 1) * kEvalLd, *Wl1 = Wl0 + H * kLdt;
     float *tab = Wl1 + H * kLdt;
     float *bias = tab + 6 * H;
     double *pool = (double *)(bias + 2 * H);
@@ -191,16 +284,18 @@ __global__ __launch_bounds__(kThreads, 2) void gin_eval_small_kernel(EvalLaunch 
     int *rp = (int *)(ppart + 4 * H);                           // [65] local row pointers
     uint8_t *cols = (uint8_t *)(rp + 68);                       // [nnz] local column ids
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
+    constexpr int kTickBase = 0;
     long long tick_ = Ln.ticks ? device_ticks() : 0;
     const int b = (int)blockIdx.x;
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
     const int e0 = a.row_ptr[n0], nnz = a.row_ptr[n0 + n] - e0;
     if (!eval_is_small(n, nnz)) return;                          // (workgroup-uniform) the general kernel's
     const int L = a.L;
-    LayerRegs regs = eval_request_layer(a, 0);
+    LayerRegs regs = eval_request_layer<kQ, true>(a, 0);
     {
         const int sl = a.seed_local ? a.seed_local[b] : 0;
         for (int r = gi; r < n; r += 16) st4(&A[r * kEvalLd + 4 * t], eval_feature4(a, n0, r, sl, t));
+        if (tid < 16) st4(&A[kSmallCap * kEvalLd + 4 * tid], F4{0.f, 0.f, 0.f, 0.f});
         if (tid <= n) rp[tid] = a.row_ptr[n0 + tid] - e0;
         for (int e = tid; e < nnz; e += kThreads) cols[e] = (uint8_t)(a.col_idx[e0 + e] - n0);
     }
@@ -224,7 +319,7 @@ __global__ __launch_bounds__(kThreads, 2) void gin_eval_small_kernel(EvalLaunch 
     const float mult = (float)a.mult;
     for (int l = 0; l < (n > 0 ? L : 0); ++l) {
         eval_store_layer(a, l, regs, Wl0, Wl1, tab, bias);
-        if (l + 1 < L) regs = eval_request_layer(a, l + 1);       // in flight during this layer
+        if (l + 1 < L) regs = eval_request_layer<kQ, false>(a, l + 1);       // in flight during this layer
         __syncthreads();
         EV_TICK(2);
         // GINConv aggregate (eps = 0; gin.py:179-185,218) of this lane's row and channel quads, neighbours in CSR order
@@ -233,13 +328,7 @@ __global__ __launch_bounds__(kThreads, 2) void gin_eval_small_kernel(EvalLaunch 
             const bool live = row < n;
             const int rb = live ? rp[row] : 0, re = live ? rp[row + 1] : 0;
             F4 acc[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = F4{0.f, 0.f, 0.f, 0.f};
-            for (int e = rb; e < re; ++e) {                      // (lanes of shorter rows wait: a wave runs its longest row)
-                const float *src = &A[(int)cols[e] * kEvalLd + 4 * q];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = add4(acc[c], ld4(src + 16 * c));
-            }
+            eval_gather_row(A, cols, rb, re, kSmallCap, j, q, acc);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const F4 self = live ? ld4(&A[row * kEvalLd + 16 * c + 4 * q]) : F4{0.f, 0.f, 0.f, 0.f};
@@ -262,14 +351,202 @@ __global__ __launch_bounds__(kThreads, 2) void gin_eval_small_kernel(EvalLaunch 
     }
     eval_readout(a, b, pool, ppart);
     EV_TICK(7);
-    if (Ln.ticks && tid == 0) atomicAdd((unsigned long long *)&Ln.ticks[15], 1ull);
+    if (Ln.ticks && tid == 0) atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + 15], 1ull);
+}
+
+// ---- medium subgraphs (65 .. kMedCap rows, at most kMedEdges CSR entries): the small kernel's shape on 8 waves ------------
+// At rw_hops 256 four subgraphs in ten have more than 64 nodes and the general kernel below walked their tiles one after the
+// other (own rows -> gather_tile -> MLP -> transit through global memory, ~12-16 us per 64-row tile and layer: 147 us for a
+// 145-node subgraph, 321 us for a 298-node one, profiles/r6_eval_trace.txt).  Here the subgraph's rows stay in LDS, the local
+// column ids too (16 bits), a wave owns 16 rows per pass of 128 and sums ITS rows' neighbours in CSR order into the registers the
+// first product reads -- no staging tile, no side slots, no global traffic inside a layer -- and the passes' results wait in
+// registers for the one barrier after which the rows are overwritten in place.  Same arithmetic, statement by statement, as
+// gin_eval_small_kernel (the gather order is the CSR's, the products are eval_mlp_rows16, the prediction layers keep the
+// summation order of eval_readout), so a subgraph gives the same bits in either kernel.
+constexpr int kMedThreads = 512;
+constexpr int kMedCap = 320;
+constexpr int kMedPasses = (kMedCap + 127) / 128;
+constexpr int kMedEdges = 13664;
+constexpr int kMedRp = 328;              // ints: kMedCap + 1 row pointers, padded to 16 bytes
+constexpr int kMedLds = ((kMedCap + 1) * kEvalLd + 2 * H * kLdt + 6 * H + 2 * H) * 4 + (GCC_GIN_MAX_LAYERS + 1) * H * 8 + 8 * H * 8
+                        + kMedRp * 4 + kMedEdges * 2;
+static_assert(kMedLds <= 160 * 1024, "one workgroup per CU");
+static_assert((GCC_GIN_MAX_LAYERS + 1) * H * 4 <= 8 * H * 8, "the per-layer scores share the pooling partials' space");
+__device__ __forceinline__ bool eval_is_medium(int n, int nnz) { return !eval_is_small(n, nnz) && n <= kMedCap && nnz <= kMedEdges; }
+
+struct MedRegs { F4 w0[2], w1[2]; float v0, v1, v2, v3; };
+template <bool kQ> __device__ __forceinline__ void med_weights_request(const float *W, int kdim, F4 (&v)[2])
+{
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                                // (as eval_weights_request, 512 threads)
+        const int idx = tid + i * kMedThreads, r = idx >> 4, c4 = 4 * (idx & 15);
+        const float *p = W + (int64_t)r * kdim;
+        if constexpr (kQ) v[i] = ld4(p + min(c4, kdim - 4));
+        else v[i] = F4{p[min(c4 + 0, kdim - 1)], p[min(c4 + 1, kdim - 1)], p[min(c4 + 2, kdim - 1)], p[min(c4 + 3, kdim - 1)]};
+    }
+}
+__device__ __forceinline__ void med_weights_store(float *Wl, const F4 (&v)[2], int kdim)
+{
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * kMedThreads, r = idx >> 4, c4 = 4 * (idx & 15);
+        const F4 x = v[i];
+        st4(&Wl[r * kLdt + c4], F4{c4 + 0 < kdim ? x.x : 0.f, c4 + 1 < kdim ? x.y : 0.f, c4 + 2 < kdim ? x.z : 0.f, c4 + 3 < kdim ? x.w : 0.f});
+    }
+}
+template <bool kQ, bool kFirst> __device__ __forceinline__ MedRegs med_request_layer(const EvalArgs &a, int l)
+{
+    const EvalLayer &ly = a.layer[l];
+    const int tid = (int)threadIdx.x;
+    MedRegs r;
+    if constexpr (kFirst) med_weights_request<false>(ly.w0, a.kdim0, r.w0);
+    else med_weights_request<kQ>(ly.w0, a.hid, r.w0);
+    med_weights_request<kQ>(ly.w1, a.hid, r.w1);
+    const int c = tid & 63, which = wave_uniform(tid >> 6);      // which < 3: a BatchNorm; 3: the two biases; 4 .. 7: nothing (scalar: see eval_request_layer)
+    r.v0 = r.v1 = r.v2 = r.v3 = 0.f;
+    if (which < 3) { r.v0 = ly.bn_w[which][c]; r.v1 = ly.bn_b[which][c]; r.v2 = ly.bn_rm[which][c]; r.v3 = ly.bn_rv[which][c]; }
+    else if (which == 3) { r.v0 = ly.b0 ? ly.b0[c] : 0.f; r.v1 = ly.b1 ? ly.b1[c] : 0.f; }
+    return r;
+}
+__device__ __forceinline__ void med_store_layer(const EvalArgs &a, int l, const MedRegs &r, float *Wl0, float *Wl1, float *tab, float *bias)
+{
+    const int tid = (int)threadIdx.x;
+    med_weights_store(Wl0, r.w0, l == 0 ? a.kdim0 : a.hid);
+    med_weights_store(Wl1, r.w1, a.hid);
+    const int c = tid & 63, which = tid >> 6;
+    if (which < 3) {                                             // (eval_store_layer's table)
+        const double rstd = 1.0 / sqrt((double)r.v3 + (double)a.eps);
+        tab[which * 2 * H + c] = (float)((double)r.v0 * rstd);
+        tab[which * 2 * H + H + c] = (float)((double)r.v1 - (double)r.v2 * (double)r.v0 * rstd);
+    } else if (which == 3) {
+        bias[c] = r.v0;
+        bias[H + c] = r.v1;
+    }
+}
+
+template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_medium_kernel(EvalLaunch Ln)
+{
+    DYN_SMEM(smem);
+    const EvalArgs &a = Ln.p[blockIdx.y];
+    float *A = (float *)smem;                                   // [kMedCap + the zero row][kEvalLd]
+    float *Wl0 = A + (kMedCap + 1) * kEvalLd, *Wl1 = Wl0 + H * kLdt;
+    float *tab = Wl1 + H * kLdt;
+    float *bias = tab + 6 * H;
+    double *pool = (double *)(bias + 2 * H);                    // [L + 1][64]
+    double *ppart = pool + (GCC_GIN_MAX_LAYERS + 1) * H;        // [8][64]; the readout's per-layer scores afterwards
+    int *rp = (int *)(ppart + 8 * H);                           // [n + 1] local row pointers
+    uint16_t *cols = (uint16_t *)(rp + kMedRp);                 // [nnz] local column ids
+    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
+    constexpr int kTickBase = 16;
+    long long tick_ = Ln.ticks ? device_ticks() : 0;
+    const int b = (int)blockIdx.x;
+    const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+    const int e0 = a.row_ptr[n0], nnz = a.row_ptr[n0 + n] - e0;
+    if (!eval_is_medium(n, nnz)) return;                         // (workgroup-uniform) the small or the general kernel's
+    const int L = a.L;
+    MedRegs regs = med_request_layer<kQ, true>(a, 0);
+    {
+        const int sl = a.seed_local ? a.seed_local[b] : 0;
+        for (int r = gi; r < n; r += kMedThreads / 16) st4(&A[r * kEvalLd + 4 * t], eval_feature4(a, n0, r, sl, t));
+        if (tid < 16) st4(&A[kMedCap * kEvalLd + 4 * tid], F4{0.f, 0.f, 0.f, 0.f});
+        if (tid <= n) rp[tid] = a.row_ptr[n0 + tid] - e0;
+        for (int e = tid; e < nnz; e += kMedThreads) cols[e] = (uint16_t)(a.col_idx[e0 + e] - n0);
+    }
+    __syncthreads();
+    auto pool_rows = [&](int i) {                                // SumPooling (gin.py:228), fp64, fixed order: 8 strided partials
+        const int c = tid & 63, pt = tid >> 6;
+        double acc = 0.0;
+        for (int r = pt; r < n; r += 8) acc += (double)A[r * kEvalLd + c];
+        ppart[pt * H + c] = acc;
+        __syncthreads();
+        if (tid < H)
+            pool[i * H + tid] = ((ppart[tid] + ppart[H + tid]) + (ppart[2 * H + tid] + ppart[3 * H + tid]))
+                                + ((ppart[4 * H + tid] + ppart[5 * H + tid]) + (ppart[6 * H + tid] + ppart[7 * H + tid]));
+        __syncthreads();
+    };
+    EV_TICK(0);
+    pool_rows(0);
+    EV_TICK(1);
+    const int j = lane & 15, q = lane >> 4;
+    const float mult = (float)a.mult;
+    for (int l = 0; l < L; ++l) {
+        med_store_layer(a, l, regs, Wl0, Wl1, tab, bias);
+        if (l + 1 < L) regs = med_request_layer<kQ, false>(a, l + 1);        // in flight during this layer
+        __syncthreads();
+        EV_TICK(2);
+        F4 hh[kMedPasses][4];
+#pragma unroll
+        for (int p = 0; p < kMedPasses; ++p) {
+            const int row = 128 * p + 16 * wv + j;
+            if (128 * p + 16 * wv < n) {                         // (wave-uniform) the wave has rows in this pass
+                // GINConv aggregate (eps = 0; gin.py:179-185,218) of this lane's row and channel quads, neighbours in CSR order
+                F4 xb[4];
+                const bool live = row < n;
+                const int rb = live ? rp[row] : 0, re = live ? rp[row + 1] : 0;
+                F4 acc[4];
+                eval_gather_row(A, cols, rb, re, kMedCap, j, q, acc);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const F4 self = live ? ld4(&A[row * kEvalLd + 16 * c + 4 * q]) : F4{0.f, 0.f, 0.f, 0.f};
+                    xb[c].x = fmaf(mult, acc[c].x, self.x); xb[c].y = fmaf(mult, acc[c].y, self.y);
+                    xb[c].z = fmaf(mult, acc[c].z, self.z); xb[c].w = fmaf(mult, acc[c].w, self.w);
+                }
+                eval_mlp_rows16(xb, Wl0, Wl1, tab, bias, j, q, hh[p]);
+            }
+        }
+        EV_TICK(4);
+        __syncthreads();                                         // every lane has read what it needs of the old rows
+#pragma unroll
+        for (int p = 0; p < kMedPasses; ++p) {
+            const int row = 128 * p + 16 * wv + j;
+            if (row < n) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) st4(&A[row * kEvalLd + 16 * cb + 4 * q], hh[p][cb]);
+            }
+        }
+        __syncthreads();
+        EV_TICK(5);
+        pool_rows(l + 1);
+        EV_TICK(1);
+    }
+    // readout (eval_readout's sums in eval_readout's order, one prediction layer per 64 threads instead of one or two)
+    {
+        const int o = tid & 63, pt = wave_uniform(tid >> 6);
+        float *sl = (float *)ppart;                              // [L + 1][64] per-layer scores
+        for (int i = pt; i <= L; i += 8) {
+            const int kd = i == 0 ? a.kdim0 : a.hid;
+            sl[i * H + o] = eval_pred_dot(a.pred_w[i] + (int64_t)o * kd, a.pred_b[i] ? a.pred_b[i] + o : nullptr, pool + i * H, kd,
+                                          eval_pred_quads(a.pred_w[i], kd));
+        }
+        __syncthreads();
+        if (tid < H) {
+            float sp[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i <= L; ++i) sp[i & 3] += sl[i * H + tid];
+            const float sc = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+            float ss = sc * sc;
+            ss = wave_sum(ss);
+            float f = sc;
+            if (a.normalize) {
+                const float nrm = sqrtf(ss);
+                f = sc / (nrm > a.norm_eps ? nrm : a.norm_eps);
+            }
+            a.score[(int64_t)b * H + tid] = sc;
+            a.feat[(int64_t)b * H + tid] = f;
+            if (a.mean_out) atomicAdd(&a.mean_out[(int64_t)b * H + tid], a.mean_w * f);
+            if (a.pooled) for (int i = 0; i <= L; ++i) a.pooled[((int64_t)i * a.B + b) * H + tid] = pool[i * H + tid];
+        }
+    }
+    EV_TICK(7);
+    if (Ln.ticks && tid == 0) atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + 15], 1ull);
 }
 
 constexpr int kEvalLds = (kEvalCap * kEvalLd + kTile * kLdt + 2 * H * kLdt + 32 * H + 6 * H + 2 * H) * 4   // A, T, Wl0, Wl1, part, tables, biases
                          + (GCC_GIN_MAX_LAYERS + 1) * H * 8 + 4 * H * 8                                      // pooled sums (fp64) + their partials
                          + (kTile + 1 + 32 + 3) / 4 * 16;                                                    // rpl, prow
 
-__global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
+template <bool kQ> __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
 {
     DYN_SMEM(smem);
     const EvalArgs &a = Ln.p[blockIdx.y];
@@ -285,6 +562,7 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
     int *prow = rpl + kTile + 1;                                // [32]
 
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
+    constexpr int kTickBase = 32;
     long long tick_ = Ln.ticks ? device_ticks() : 0;
     const int b = (int)blockIdx.x;
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
@@ -298,8 +576,11 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
     // multi-die part an agent-scope release writes L2 back: 40 us per layer with 256 workgroups doing it, measured)
     const bool single = in_lds && n <= kTile;                    // one tile: the layer updates A in place, nothing leaves LDS
 
-    if (Ln.split && eval_is_small(n, a.row_ptr[n0 + n] - a.row_ptr[n0])) return;     // (workgroup-uniform) gin_eval_small_kernel's
-    LayerRegs regs = eval_request_layer(a, 0);                   // (n == 0: harmless)
+    if (Ln.split) {                                              // (workgroup-uniform) the LDS-resident kernels' subgraphs
+        const int nnz = a.row_ptr[n0 + n] - a.row_ptr[n0];
+        if (eval_is_small(n, nnz) || eval_is_medium(n, nnz)) return;
+    }
+    LayerRegs regs = eval_request_layer<kQ, true>(a, 0);                   // (n == 0: harmless)
 
     // ---- hidden_rep[0]: input features (graph_encoder.py:158-165) -> A (LDS) or, for a big subgraph, cur (global)
     {
@@ -332,7 +613,7 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
 
     for (int l = 0; l < (n > 0 ? L : 0); ++l) {
         eval_store_layer(a, l, regs, Wl0, Wl1, tab, bias);
-        if (l + 1 < L) regs = eval_request_layer(a, l + 1);       // in flight during this layer
+        if (l + 1 < L) regs = eval_request_layer<kQ, false>(a, l + 1);       // in flight during this layer
         __syncthreads();
         EV_TICK(2);                                              // weights -> LDS
         const float *src = cur;
@@ -400,14 +681,76 @@ __global__ __launch_bounds__(kThreads) void gin_eval_fused_kernel(EvalLaunch Ln)
 
     eval_readout(a, b, pool, ppart);
     EV_TICK(7);                                                  // readout
-    if (Ln.ticks && tid == 0) atomicAdd((unsigned long long *)&Ln.ticks[15], 1ull);
+    if (Ln.ticks && tid == 0) atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + 15], 1ull);
+}
+
+// The three kernels share nothing but mean_out (atomic adds): they run side by side -- the medium kernel (one workgroup per
+// CU, the call's longest workgroups) on the caller's stream, the other two on side streams forked from it and joined back
+// (capturable: a hipGraph gets three parallel branches).  In one stream the launches serialised: 54 + 75 + 5 us at rw_hops 64
+// with 470 small and 42 medium subgraphs.  GCC_EVAL_FORK=0 keeps them in one stream.
+#ifndef GCC_AMD_HIPEMU
+struct EvalSide { hipStream_t owner, side[2]; hipEvent_t fork, join[2]; };
+static EvalSide *eval_side_streams(hipStream_t s)
+{
+    static const bool on = [] { const char *e = getenv("GCC_EVAL_FORK"); return e && atoi(e) != 0; }();
+    if (!on) return nullptr;
+    static std::mutex mu;
+    static EvalSide tab[16];
+    static int ntab = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < ntab; ++i)
+        if (tab[i].owner == s) return &tab[i];
+    if (ntab == 16) return nullptr;                  // (more caller streams than anyone uses: those calls stay on one stream)
+    EvalSide &t = tab[ntab];
+    int prio = 0;
+    if (hipStreamGetPriority(s, &prio) != hipSuccess) { (void)hipGetLastError(); prio = 0; }
+    for (int i = 0; i < 2; ++i) {
+        if (hipStreamCreateWithPriority(&t.side[i], hipStreamNonBlocking, prio) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipEventCreateWithFlags(&t.join[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    t.owner = s;
+    return &tab[ntab++];
+}
+#endif
+
+template <bool kQ> void eval_launch(const EvalLaunch &Ln, dim3 grid, hipStream_t s)
+{
+    hipStream_t s_small = s, s_general = s;
+#ifndef GCC_AMD_HIPEMU
+    static bool opted = false;                               // more than 64 KiB of dynamic LDS is opted into once
+    if (!opted) {
+        (void)hipFuncSetAttribute((const void *)gin_eval_fused_kernel<kQ>, hipFuncAttributeMaxDynamicSharedMemorySize, kEvalLds);
+        (void)hipFuncSetAttribute((const void *)gin_eval_small_kernel<kQ>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLds);
+        (void)hipFuncSetAttribute((const void *)gin_eval_medium_kernel<kQ>, hipFuncAttributeMaxDynamicSharedMemorySize, kMedLds);
+        opted = true;
+    }
+    EvalSide *side = eval_side_streams(s);
+    if (side) {
+        s_small = side->side[0]; s_general = side->side[1];
+        (void)hipEventRecord(side->fork, s);                 // (behind the memset of mean_out)
+        (void)hipStreamWaitEvent(s_small, side->fork, 0);
+        (void)hipStreamWaitEvent(s_general, side->fork, 0);
+    }
+#endif
+    hipLaunchKernelGGL(gin_eval_fused_kernel<kQ>, grid, dim3(kThreads), kEvalLds, s_general, Ln);
+    hipLaunchKernelGGL(gin_eval_medium_kernel<kQ>, grid, dim3(kMedThreads), kMedLds, s, Ln);
+    hipLaunchKernelGGL(gin_eval_small_kernel<kQ>, grid, dim3(kThreads), kSmallLds, s_small, Ln);
+#ifndef GCC_AMD_HIPEMU
+    if (side) {
+        (void)hipEventRecord(side->join[0], s_small);
+        (void)hipEventRecord(side->join[1], s_general);
+        (void)hipStreamWaitEvent(s, side->join[0], 0);
+        (void)hipStreamWaitEvent(s, side->join[1], 0);
+    }
+#endif
 }
 
 }  // namespace
 
 extern "C" {
 
-/* diagnostics, as gcc_gin_debug_ticks: device int64[16] of wall-clock ticks per phase of gcc_gin_eval_fused (features,
+/* diagnostics, as gcc_gin_debug_ticks: device int64[3][16] (per kernel) of wall-clock ticks per phase of gcc_gin_eval_fused (features,
  * pooling, weights, own rows, gather, Linears, mirror, readout; [15] = workgroups); NULL switches it off */
 void gcc_gin_eval_debug_ticks(long long *device_ticks64) { g_eval_ticks = device_ticks64; }
 
@@ -454,22 +797,27 @@ int32_t gcc_gin_eval_fused(const gcc_gin_pass *passes, int32_t npass, float *mea
         a.normalize = p.normalize; a.hid = hidden_of(p.w); a.kdim0 = kdim0;
         a.eps = p.w.bn_eps; a.norm_eps = p.w.norm_eps;
     }
-    hipStream_t s = (hipStream_t)stream;
-#ifndef GCC_AMD_HIPEMU
-    static bool opted = false;                               // more than 64 KiB of dynamic LDS is opted into once
-    if (!opted) {
-        (void)hipFuncSetAttribute((const void *)gin_eval_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kEvalLds);
-        (void)hipFuncSetAttribute((const void *)gin_eval_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLds);
-        opted = true;
+    // the hidden-wide matrices come by 16-byte quads when their rows are whole quads (eval_weights_request)
+    bool quads = true;
+    for (int i = 0; i < npass; ++i) {
+        const EvalArgs &a = Ln.p[i];
+        quads = quads && (a.hid & 3) == 0;
+        for (int l = 0; l < a.L; ++l)
+            quads = quads && ((uintptr_t)a.layer[l].w1 & 15) == 0 && (l == 0 || ((uintptr_t)a.layer[l].w0 & 15) == 0);
     }
-    if (mean_out) (void)hipMemsetAsync(mean_out, 0, (size_t)B * H * sizeof(float), s);
+    hipStream_t s = (hipStream_t)stream;
+    if (mean_out) {
+#ifndef GCC_AMD_HIPEMU
+        (void)hipMemsetAsync(mean_out, 0, (size_t)B * H * sizeof(float), s);
 #else
-    if (mean_out) memset(mean_out, 0, (size_t)B * H * sizeof(float));
+        memset(mean_out, 0, (size_t)B * H * sizeof(float));
 #endif
-    // two launches over the same grid: subgraphs of at most 64 nodes in the two-per-CU kernel, the rest in the general one
+    }
+    // three launches over the same grid: subgraphs of at most 64 nodes in the two-per-CU kernel, up to kMedCap nodes in the
+    // 8-wave LDS-resident one, the rest (hub ego-nets) in the general one
     Ln.split = 1;
-    hipLaunchKernelGGL(gin_eval_small_kernel, dim3(B, npass), dim3(kThreads), kSmallLds, s, Ln);
-    hipLaunchKernelGGL(gin_eval_fused_kernel, dim3(B, npass), dim3(kThreads), kEvalLds, s, Ln);
+    if (quads) eval_launch<true>(Ln, dim3(B, npass), s);
+    else eval_launch<false>(Ln, dim3(B, npass), s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         snprintf(g_err, kErrLen, "gcc_gin_eval_fused: launch failed: %s", hipGetErrorString(e));

@@ -368,8 +368,9 @@ int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gcc_prof *pro
  * of the passes' feat (npass = 2: generate.py:52).  Same results as gcc_gin_forward in eval mode to ~1e-6 (the gather's
  * summation order differs). */
 int32_t gcc_gin_eval_fused(const gcc_gin_pass *passes, int32_t npass, float *mean_out, void *stream);
-/* diagnostics: device int64[16] of 100 MHz ticks per phase (features, pooling, weights, own rows, gather, Linears, mirror,
- * readout; [15] = workgroups), summed over the workgroups of the following calls; NULL switches it off */
+/* diagnostics: device int64[3][16] -- per kernel of the call (subgraphs of <= 64 nodes, <= 320 nodes, the rest) 100 MHz ticks per
+ * phase (features, pooling, weights, own rows, gather, Linears, mirror, readout; [15] = workgroups), summed over the workgroups
+ * of the following calls; NULL switches it off */
 void gcc_gin_eval_debug_ticks(long long *device_ticks64);
 
 typedef struct gcc_gin_grads {   /* same shapes as the weights; written (not accumulated)  */

@@ -122,17 +122,22 @@ try:
     hc, hf = graphed(chain_cap), graphed(fused_cap)
 finally:
     st = st_keep
-ticks = torch.zeros(16, dtype=torch.int64, device=dev)
+ticks = torch.zeros(48, dtype=torch.int64, device=dev)
 eng.lib.gcc_gin_eval_debug_ticks(ticks.data_ptr())
 fused_launch()
 torch.cuda.synchronize()
 eng.lib.gcc_gin_eval_debug_ticks(None)
 tk = ticks.cpu().tolist()
-wg = max(tk[15], 1)
-phases = "  ".join(f"{n} {tk[i] / 100.0 / wg:.1f}" for i, n in enumerate(["features", "pooling", "weights", "own-rows", "gather", "linears", "mirror", "readout"]))
+names = ["features", "pooling", "weights", "own-rows", "gather", "linears", "mirror", "readout"]
+phases = ""
+for k, kern in enumerate(["small (<= 64 nodes)", "medium (<= 320)", "general"]):
+    wg = tk[16 * k + 15]
+    if wg:
+        phases += f"\n   {kern}: {wg} workgroups, us per workgroup: " + "  ".join(
+            f"{n} {tk[16 * k + i] / 100.0 / wg:.1f}" for i, n in enumerate(names) if tk[16 * k + i])
 print(f"graph {len(rp) - 1} nodes / {len(ci)} edges, batch {B} x 2 views, rw_hops {a.rw_hops}: subgraph sizes "
       f"median {int(sizes.median())} max {int(sizes.max())}; eval chain (2 x 15 launches + mean) {tc * 1e3:.1f} us per batch, "
       f"gcc_gin_eval_fused (1 launch) {tf * 1e3:.1f} us per batch = {tc / tf:.1f}x; max |difference| {err:.2e}; "
       f"launches only (descriptors built once): chain {gc * 1e3:.1f} us, fused {gf * 1e3:.1f} us = {gc / gf:.1f}x; "
       f"GPU time (hipGraph replay of the same launches): chain {hc * 1e3:.1f} us, fused {hf * 1e3:.1f} us = {hc / hf:.1f}x\n"
-      f"   fused kernel, us per workgroup ({wg} workgroups): {phases}")
+      f"   fused call, phase ticks per kernel:{phases}")
