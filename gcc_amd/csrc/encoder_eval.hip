@@ -43,8 +43,9 @@ struct EvalArgs {
     float eps, norm_eps;
 };
 struct EvalLaunch { EvalArgs p[kMaxPass]; long long *ticks; int32_t split; };   // split: small subgraphs are gin_eval_small_kernel's
-static long long *g_eval_ticks = nullptr;    // diagnostics (gcc_gin_eval_debug_ticks): device int64[3][16] (small, medium, general kernel)
-#define EV_TICK(ph) do { if (Ln.ticks && tid == 0) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
+static long long *g_eval_ticks = nullptr;    // diagnostics (gcc_gin_eval_debug_ticks): device int64[3][16] (small, medium, general kernel);
+                                             // every 8th workgroup reports (all of them adding to the same counters waited on their own atomics)
+#define EV_TICK(ph) do { if (tick_on) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 
 // ---- pieces shared by the two kernel shapes ------------------------------------------------------------------------------
 // a layer's weights / BatchNorm numbers are requested one layer ahead (registers) and stored when the LDS buffers are free
@@ -285,9 +286,11 @@ template <bool kQ> __global__ __launch_bounds__(kThreads, 2) void gin_eval_small
     uint8_t *cols = (uint8_t *)(rp + 68);                       // [nnz] local column ids
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
     constexpr int kTickBase = 0;
+    const bool tick_on = Ln.ticks && threadIdx.x == 0 && ((int)blockIdx.x & 7) == 0;
     long long tick_ = Ln.ticks ? device_ticks() : 0;
     const int b = (int)blockIdx.x;
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+    if (n > kSmallCap) return;                                   // (workgroup-uniform; before the dependent row_ptr reads)
     const int e0 = a.row_ptr[n0], nnz = a.row_ptr[n0 + n] - e0;
     if (!eval_is_small(n, nnz)) return;                          // (workgroup-uniform) the general kernel's
     const int L = a.L;
@@ -307,14 +310,13 @@ template <bool kQ> __global__ __launch_bounds__(kThreads, 2) void gin_eval_small
         ppart[pt * H + c] = acc;
         __syncthreads();
         if (tid < H) pool[i * H + tid] = (ppart[tid] + ppart[H + tid]) + (ppart[2 * H + tid] + ppart[3 * H + tid]);
-        __syncthreads();
+        // (no barrier here: the partials are next written behind the following layer's barriers, the sums are read by the readout)
     };
     EV_TICK(0);
     pool_rows(0);
     EV_TICK(1);
     if (n <= 0)
         for (int i = tid; i < L * H; i += kThreads) pool[H + i] = 0.0;
-    __syncthreads();
     const int j = lane & 15, q = lane >> 4, row = 16 * wv + j;
     const float mult = (float)a.mult;
     for (int l = 0; l < (n > 0 ? L : 0); ++l) {
@@ -323,8 +325,9 @@ template <bool kQ> __global__ __launch_bounds__(kThreads, 2) void gin_eval_small
         __syncthreads();
         EV_TICK(2);
         // GINConv aggregate (eps = 0; gin.py:179-185,218) of this lane's row and channel quads, neighbours in CSR order
-        F4 xb[4];
-        {
+        F4 h[4];
+        if (16 * wv < n) {                                       // (wave-uniform) a wave without rows leaves the MFMA pipe -- 128 products of
+            F4 xb[4];                                            //  32 clocks per layer and wave -- to the waves that have some (median n: 23)
             const bool live = row < n;
             const int rb = live ? rp[row] : 0, re = live ? rp[row + 1] : 0;
             F4 acc[4];
@@ -335,10 +338,9 @@ template <bool kQ> __global__ __launch_bounds__(kThreads, 2) void gin_eval_small
                 xb[c].x = fmaf(mult, acc[c].x, self.x); xb[c].y = fmaf(mult, acc[c].y, self.y);
                 xb[c].z = fmaf(mult, acc[c].z, self.z); xb[c].w = fmaf(mult, acc[c].w, self.w);
             }
+            EV_TICK(4);
+            eval_mlp_rows16(xb, Wl0, Wl1, tab, bias, j, q, h);
         }
-        EV_TICK(4);
-        F4 h[4];
-        eval_mlp_rows16(xb, Wl0, Wl1, tab, bias, j, q, h);
         __syncthreads();                                         // every lane has read what it needs of the old rows
         if (row < n) {
 #pragma unroll
@@ -349,9 +351,10 @@ template <bool kQ> __global__ __launch_bounds__(kThreads, 2) void gin_eval_small
         pool_rows(l + 1);
         EV_TICK(1);
     }
+    __syncthreads();                                             // the pooled sums are complete, their partials are free
     eval_readout(a, b, pool, ppart);
     EV_TICK(7);
-    if (Ln.ticks && tid == 0) atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + 15], 1ull);
+    if (tick_on) atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + 15], 1ull);
 }
 
 // ---- medium subgraphs (65 .. kMedCap rows, at most kMedEdges CSR entries): the small kernel's shape on 8 waves ------------
@@ -372,7 +375,7 @@ constexpr int kMedLds = ((kMedCap + 1) * kEvalLd + 2 * H * kLdt + 6 * H + 2 * H)
                         + kMedRp * 4 + kMedEdges * 2;
 static_assert(kMedLds <= 160 * 1024, "one workgroup per CU");
 static_assert((GCC_GIN_MAX_LAYERS + 1) * H * 4 <= 8 * H * 8, "the per-layer scores share the pooling partials' space");
-__device__ __forceinline__ bool eval_is_medium(int n, int nnz) { return !eval_is_small(n, nnz) && n <= kMedCap && nnz <= kMedEdges; }
+__device__ __forceinline__ bool eval_is_medium(int n, int nnz) { return n > kSmallCap && n <= kMedCap && nnz <= kMedEdges; }
 
 struct MedRegs { F4 w0[2], w1[2]; float v0, v1, v2, v3; };
 template <bool kQ> __device__ __forceinline__ void med_weights_request(const float *W, int kdim, F4 (&v)[2])
@@ -443,8 +446,14 @@ template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_mediu
     long long tick_ = Ln.ticks ? device_ticks() : 0;
     const int b = (int)blockIdx.x;
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+#ifdef GCC_EVAL_TICK_BIG                                         // (diagnostic build: the phases of the largest subgraphs only)
+    const bool tick_on = Ln.ticks && threadIdx.x == 0 && n >= GCC_EVAL_TICK_BIG;
+#else
+    const bool tick_on = Ln.ticks && threadIdx.x == 0 && (b & 7) == 0;
+#endif
+    if (n <= kSmallCap || n > kMedCap) return;                   // (workgroup-uniform; <= 64 nodes: the small kernel's, or -- more than 6144 entries, no simple graph -- the general one's)
     const int e0 = a.row_ptr[n0], nnz = a.row_ptr[n0 + n] - e0;
-    if (!eval_is_medium(n, nnz)) return;                         // (workgroup-uniform) the small or the general kernel's
+    if (!eval_is_medium(n, nnz)) return;                         // (workgroup-uniform) the general kernel's
     const int L = a.L;
     MedRegs regs = med_request_layer<kQ, true>(a, 0);
     {
@@ -464,7 +473,7 @@ template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_mediu
         if (tid < H)
             pool[i * H + tid] = ((ppart[tid] + ppart[H + tid]) + (ppart[2 * H + tid] + ppart[3 * H + tid]))
                                 + ((ppart[4 * H + tid] + ppart[5 * H + tid]) + (ppart[6 * H + tid] + ppart[7 * H + tid]));
-        __syncthreads();
+        // (no barrier here: as in the small kernel)
     };
     EV_TICK(0);
     pool_rows(0);
@@ -493,11 +502,13 @@ template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_mediu
                     xb[c].x = fmaf(mult, acc[c].x, self.x); xb[c].y = fmaf(mult, acc[c].y, self.y);
                     xb[c].z = fmaf(mult, acc[c].z, self.z); xb[c].w = fmaf(mult, acc[c].w, self.w);
                 }
+                EV_TICK(3);                                      // (wave 0's aggregation)
                 eval_mlp_rows16(xb, Wl0, Wl1, tab, bias, j, q, hh[p]);
+                EV_TICK(4);                                      // (wave 0's products)
             }
         }
-        EV_TICK(4);
         __syncthreads();                                         // every lane has read what it needs of the old rows
+        EV_TICK(6);                                              // (wave 0 waiting for the other waves)
 #pragma unroll
         for (int p = 0; p < kMedPasses; ++p) {
             const int row = 128 * p + 16 * wv + j;
@@ -512,6 +523,7 @@ template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_mediu
         EV_TICK(1);
     }
     // readout (eval_readout's sums in eval_readout's order, one prediction layer per 64 threads instead of one or two)
+    __syncthreads();                                             // the pooled sums are complete, their partials are free
     {
         const int o = tid & 63, pt = wave_uniform(tid >> 6);
         float *sl = (float *)ppart;                              // [L + 1][64] per-layer scores
@@ -539,7 +551,7 @@ template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_mediu
         }
     }
     EV_TICK(7);
-    if (Ln.ticks && tid == 0) atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + 15], 1ull);
+    if (tick_on) atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + 15], 1ull);
 }
 
 constexpr int kEvalLds = (kEvalCap * kEvalLd + kTile * kLdt + 2 * H * kLdt + 32 * H + 6 * H + 2 * H) * 4   // A, T, Wl0, Wl1, part, tables, biases
@@ -563,6 +575,7 @@ template <bool kQ> __global__ __launch_bounds__(kThreads) void gin_eval_fused_ke
 
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
     constexpr int kTickBase = 32;
+    const bool tick_on = Ln.ticks && threadIdx.x == 0 && ((int)blockIdx.x & 7) == 0;
     long long tick_ = Ln.ticks ? device_ticks() : 0;
     const int b = (int)blockIdx.x;
     const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
@@ -681,7 +694,7 @@ template <bool kQ> __global__ __launch_bounds__(kThreads) void gin_eval_fused_ke
 
     eval_readout(a, b, pool, ppart);
     EV_TICK(7);                                                  // readout
-    if (Ln.ticks && tid == 0) atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + 15], 1ull);
+    if (tick_on) atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + 15], 1ull);
 }
 
 // The three kernels share nothing but mean_out (atomic adds): they run side by side -- the medium kernel (one workgroup per

@@ -369,7 +369,7 @@ int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gcc_prof *pro
  * summation order differs). */
 int32_t gcc_gin_eval_fused(const gcc_gin_pass *passes, int32_t npass, float *mean_out, void *stream);
 /* diagnostics: device int64[3][16] -- per kernel of the call (subgraphs of <= 64 nodes, <= 320 nodes, the rest) 100 MHz ticks per
- * phase (features, pooling, weights, own rows, gather, Linears, mirror, readout; [15] = workgroups), summed over the workgroups
+ * phase (features, pooling, weights, own rows, gather, Linears, mirror, readout; [15] = workgroups), summed over every 8th workgroup
  * of the following calls; NULL switches it off */
 void gcc_gin_eval_debug_ticks(long long *device_ticks64);
 

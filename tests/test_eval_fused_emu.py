@@ -159,6 +159,29 @@ def test_three_size_classes():
     torch.testing.assert_close(f_fused, ref, rtol=1e-4, atol=2e-5)
 
 
+def test_multi_edges_beyond_the_small_kernels_edge_space():
+    """A 64-node subgraph with every entry of the complete graph listed twice (8064 CSR entries: no simple graph, but the C ABI
+    takes any CSR): too many column ids for the small kernel's LDS space, so the general kernel takes it; next to a simple one."""
+    model, oracle = _models(17)
+    node_off, row_ptr, col = [0, 64, 64 + 20], [0], []
+    for i in range(64):
+        col += [u for u in range(64) if u != i for _ in range(2)]
+        row_ptr.append(len(col))
+    for r in _random_subgraph(np.random.RandomState(3), 20, 30):
+        col += [64 + u for u in r]
+        row_ptr.append(len(col))
+    pos = torch.nn.functional.normalize(torch.randn(84, 32, generator=torch.Generator().manual_seed(2)), dim=1)
+    g = CpuBatch(dict(node_off=torch.tensor(node_off), row_ptr=torch.tensor(row_ptr), col_idx=torch.tensor(col), pos_undirected=pos))
+    with torch.no_grad():
+        model.fused_eval = True
+        f_fused = model(g)
+        model.fused_eval = False
+        f_chain = model(g)
+        ref = oracle(*_oracle_args(g))
+    torch.testing.assert_close(f_fused, f_chain, rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(f_fused, ref, rtol=1e-4, atol=2e-5)
+
+
 def test_seed_position_and_view_mean():
     model, oracle = _models(4)
     q, k = _batch([40, 90, 17], seed=2), _batch([35, 61, 260], seed=3)

@@ -129,12 +129,13 @@ torch.cuda.synchronize()
 eng.lib.gcc_gin_eval_debug_ticks(None)
 tk = ticks.cpu().tolist()
 names = ["features", "pooling", "weights", "own-rows", "gather", "linears", "mirror", "readout"]
+med_names = ["features", "pooling", "weights", "aggregation(wave 0)", "products(wave 0)", "write-back", "wait for the other waves", "readout"]
 phases = ""
-for k, kern in enumerate(["small (<= 64 nodes)", "medium (<= 320)", "general"]):
+for k, kern in enumerate(["small (<= 64 nodes)", "medium (<= 320)", "general"]):  # (every 8th workgroup reports)
     wg = tk[16 * k + 15]
     if wg:
         phases += f"\n   {kern}: {wg} workgroups, us per workgroup: " + "  ".join(
-            f"{n} {tk[16 * k + i] / 100.0 / wg:.1f}" for i, n in enumerate(names) if tk[16 * k + i])
+            f"{n} {tk[16 * k + i] / 100.0 / wg:.1f}" for i, n in enumerate(names if k != 1 else med_names) if tk[16 * k + i])
 print(f"graph {len(rp) - 1} nodes / {len(ci)} edges, batch {B} x 2 views, rw_hops {a.rw_hops}: subgraph sizes "
       f"median {int(sizes.median())} max {int(sizes.max())}; eval chain (2 x 15 launches + mean) {tc * 1e3:.1f} us per batch, "
       f"gcc_gin_eval_fused (1 launch) {tf * 1e3:.1f} us per batch = {tc / tf:.1f}x; max |difference| {err:.2e}; "
