@@ -429,6 +429,57 @@ __device__ __forceinline__ void med_store_layer(const EvalArgs &a, int l, const 
     }
 }
 
+// Which subgraphs workgroup b of the LDS-resident kernel takes (split mode 2: no separate kernel for the small ones).
+//   * a subgraph of 65 .. kMedCap nodes: itself;
+//   * a subgraph of at most 64 nodes: the RUN of consecutive such subgraphs around it inside its aligned group of four -- rows
+//     [n0, n0 + n) of the batched CSR are then ONE block-diagonal graph of at most 256 rows, and the run's first workgroup takes
+//     it whole: the layer's weights are staged once for up to four subgraphs, 7 of the 8 waves have rows at the median size
+//     (23 nodes: a workgroup of its own used 2 of 4), and the small subgraphs no longer wait in a launch of their own;
+//   * a run with more entries than the column-id space holds (no simple graphs) falls apart into its members.
+// take: the run is the LDS-resident kernel's (the caller checks t == b for "mine"); otherwise the general kernel's.
+constexpr int kRunMax = 4;
+struct EvalRun { int t, e, n0, n, e0, nnz; int off[kRunMax + 1]; bool take; };
+__device__ __forceinline__ EvalRun eval_lds_run(const EvalArgs &a, int b)
+{
+    EvalRun r;
+    const int q0 = b & ~(kRunMax - 1), i0 = b - q0;
+    int off[kRunMax + 1];
+#pragma unroll
+    for (int i = 0; i <= kRunMax; ++i) off[i] = a.node_off[min(q0 + i, a.B)];
+    bool small[kRunMax];
+#pragma unroll
+    for (int i = 0; i < kRunMax; ++i) small[i] = q0 + i < a.B && off[i + 1] - off[i] <= kSmallCap;
+    int nb = 0;
+#pragma unroll
+    for (int i = 0; i < kRunMax; ++i) nb = i == i0 ? off[i + 1] - off[i] : nb;
+    int t = i0, e = i0 + 1;
+    if (nb <= kSmallCap) {
+#pragma unroll
+        for (int i = kRunMax - 1; i >= 1; --i) t = (i == t && small[i - 1]) ? i - 1 : t;     // (descending: each step may extend by one)
+#pragma unroll
+        for (int i = 1; i < kRunMax; ++i) e = (i == e && small[i]) ? i + 1 : e;
+    }
+    auto span = [&](int tt, int ee) {
+        int lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i <= kRunMax; ++i) { lo = i == tt ? off[i] : lo; hi = i == ee ? off[i] : hi; }
+        r.n0 = lo; r.n = hi - lo;
+        r.e0 = a.row_ptr[lo]; r.nnz = a.row_ptr[hi] - r.e0;
+    };
+    span(t, e);
+    if (r.nnz > kMedEdges && e - t > 1) { t = i0; e = i0 + 1; span(t, e); }
+    r.t = q0 + t; r.e = q0 + e;
+#pragma unroll
+    for (int g = 0; g <= kRunMax; ++g) {                         // local row offsets of the run's subgraphs (past the run: n)
+        int v = r.n;
+#pragma unroll
+        for (int i = 0; i <= kRunMax; ++i) v = (i == t + g && t + g <= e) ? off[i] - r.n0 : v;
+        r.off[g] = v;
+    }
+    r.take = nb <= kMedCap && r.nnz <= kMedEdges;
+    return r;
+}
+
 template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_medium_kernel(EvalLaunch Ln)
 {
     DYN_SMEM(smem);
@@ -444,35 +495,73 @@ template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_mediu
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
     constexpr int kTickBase = 16;
     long long tick_ = Ln.ticks ? device_ticks() : 0;
-    const int b = (int)blockIdx.x;
-    const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
+    // Workgroup x -> subgraph 4 (x mod Q) + x / Q, Q = ceil(B / 4): consecutive workgroups go to consecutive XCDs, and a run's first
+    // subgraph is (as a rule) a multiple of 4 -- with b = x the runs' workgroups all sat on XCDs 0 and 4 (64 of the 256 CUs, one
+    // workgroup per CU: 120 us for 45 us of work); this way they are the first quarter of the grid, spread over all eight
+    const int nq = (a.B + kRunMax - 1) / kRunMax;
+    const int b = Ln.split == 2 ? kRunMax * ((int)blockIdx.x % nq) + (int)blockIdx.x / nq : (int)blockIdx.x;
+    if (b >= a.B) return;
+    EvalRun run;
+    if (Ln.split == 2) {
+        run = eval_lds_run(a, b);
+        if (!run.take || run.t != b) return;                     // (workgroup-uniform) the general kernel's, or another workgroup's run
+    } else {
+        run.n0 = a.node_off[b]; run.n = a.node_off[b + 1] - run.n0;
+        if (run.n <= kSmallCap || run.n > kMedCap) return;       // (workgroup-uniform; <= 64 nodes: the small kernel's, or -- more than 6144 entries, no simple graph -- the general one's)
+        run.e0 = a.row_ptr[run.n0]; run.nnz = a.row_ptr[run.n0 + run.n] - run.e0;
+        if (!eval_is_medium(run.n, run.nnz)) return;             // (workgroup-uniform) the general kernel's
+        run.t = b; run.e = b + 1;
+        run.off[0] = 0;
+#pragma unroll
+        for (int g = 1; g <= kRunMax; ++g) run.off[g] = run.n;
+    }
+    const int n0 = run.n0, n = run.n, e0 = run.e0, nnz = run.nnz, G = run.e - run.t;
 #ifdef GCC_EVAL_TICK_BIG                                         // (diagnostic build: the phases of the largest subgraphs only)
     const bool tick_on = Ln.ticks && threadIdx.x == 0 && n >= GCC_EVAL_TICK_BIG;
 #else
     const bool tick_on = Ln.ticks && threadIdx.x == 0 && (b & 7) == 0;
 #endif
-    if (n <= kSmallCap || n > kMedCap) return;                   // (workgroup-uniform; <= 64 nodes: the small kernel's, or -- more than 6144 entries, no simple graph -- the general one's)
-    const int e0 = a.row_ptr[n0], nnz = a.row_ptr[n0 + n] - e0;
-    if (!eval_is_medium(n, nnz)) return;                         // (workgroup-uniform) the general kernel's
     const int L = a.L;
     MedRegs regs = med_request_layer<kQ, true>(a, 0);
     {
-        const int sl = a.seed_local ? a.seed_local[b] : 0;
-        for (int r = gi; r < n; r += kMedThreads / 16) st4(&A[r * kEvalLd + 4 * t], eval_feature4(a, n0, r, sl, t));
+        int seedrow[kRunMax];                                    // local row of each subgraph's seed (ndata["seed"], data_util.py:234-238)
+#pragma unroll
+        for (int g = 0; g < kRunMax; ++g) seedrow[g] = run.off[g] + ((a.seed_local && g < G) ? a.seed_local[run.t + g] : 0);
+        for (int r = gi; r < n; r += kMedThreads / 16) {
+            const int sl = r >= run.off[3] ? seedrow[3] : r >= run.off[2] ? seedrow[2] : r >= run.off[1] ? seedrow[1] : seedrow[0];
+            st4(&A[r * kEvalLd + 4 * t], eval_feature4(a, n0, r, sl, t));
+        }
         if (tid < 16) st4(&A[kMedCap * kEvalLd + 4 * tid], F4{0.f, 0.f, 0.f, 0.f});
         if (tid <= n) rp[tid] = a.row_ptr[n0 + tid] - e0;
         for (int e = tid; e < nnz; e += kMedThreads) cols[e] = (uint16_t)(a.col_idx[e0 + e] - n0);
     }
     __syncthreads();
-    auto pool_rows = [&](int i) {                                // SumPooling (gin.py:228), fp64, fixed order: 8 strided partials
+    // pooled sums of subgraph g of the run: the first one's behind the tables, the others' in rows 257 .. of A (a run has at most
+    // 256 rows; the zero row is row kMedCap)
+    static_assert(kRunMax * kSmallCap + 1 + ((kRunMax - 1) * (GCC_GIN_MAX_LAYERS + 1) * H * 8 + kEvalLd * 4 - 1) / (kEvalLd * 4) <= kMedCap,
+                  "the other subgraphs' pooled sums fit between a run's rows and the zero row");
+    auto pool_of = [&](int g) -> double * {
+        return g == 0 ? pool : (double *)(A + (kRunMax * kSmallCap + 1) * kEvalLd) + (g - 1) * (GCC_GIN_MAX_LAYERS + 1) * H;
+    };
+    auto pool_rows = [&](int i) {                                // SumPooling (gin.py:228), fp64, fixed order
         const int c = tid & 63, pt = tid >> 6;
-        double acc = 0.0;
-        for (int r = pt; r < n; r += 8) acc += (double)A[r * kEvalLd + c];
-        ppart[pt * H + c] = acc;
-        __syncthreads();
-        if (tid < H)
-            pool[i * H + tid] = ((ppart[tid] + ppart[H + tid]) + (ppart[2 * H + tid] + ppart[3 * H + tid]))
-                                + ((ppart[4 * H + tid] + ppart[5 * H + tid]) + (ppart[6 * H + tid] + ppart[7 * H + tid]));
+        if (G == 1) {                                            // (workgroup-uniform) one subgraph: 8 strided partials
+            double acc = 0.0;
+            for (int r = pt; r < n; r += 8) acc += (double)A[r * kEvalLd + c];
+            ppart[pt * H + c] = acc;
+            __syncthreads();
+            if (tid < H)
+                pool[i * H + tid] = ((ppart[tid] + ppart[H + tid]) + (ppart[2 * H + tid] + ppart[3 * H + tid]))
+                                    + ((ppart[4 * H + tid] + ppart[5 * H + tid]) + (ppart[6 * H + tid] + ppart[7 * H + tid]));
+        } else {                                                 // a run: waves g and g + 4 take the even / odd rows of subgraph g
+            const int g = pt & 3, r1 = g == 0 ? run.off[1] : g == 1 ? run.off[2] : g == 2 ? run.off[3] : run.off[4];
+            const int r0 = g == 0 ? run.off[0] : g == 1 ? run.off[1] : g == 2 ? run.off[2] : run.off[3];
+            double acc = 0.0;
+            for (int r = r0 + (pt >> 2); r < r1; r += 2) acc += (double)A[r * kEvalLd + c];
+            ppart[pt * H + c] = acc;
+            __syncthreads();
+            if (pt < G) pool_of(pt)[i * H + c] = ppart[pt * H + c] + ppart[(pt + 4) * H + c];
+        }
         // (no barrier here: as in the small kernel)
     };
     EV_TICK(0);
@@ -522,9 +611,23 @@ template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_mediu
         pool_rows(l + 1);
         EV_TICK(1);
     }
-    // readout (eval_readout's sums in eval_readout's order, one prediction layer per 64 threads instead of one or two)
+    // readout (eval_readout's sums in eval_readout's order)
     __syncthreads();                                             // the pooled sums are complete, their partials are free
-    {
+    auto emit = [&](int sub, const double *pl, float sc) {      // one wave, lane = channel: F.normalize, outputs of subgraph `sub`
+        float ss = sc * sc;
+        ss = wave_sum(ss);
+        float f = sc;
+        if (a.normalize) {
+            const float nrm = sqrtf(ss);
+            f = sc / (nrm > a.norm_eps ? nrm : a.norm_eps);
+        }
+        const int o = tid & 63;
+        a.score[(int64_t)sub * H + o] = sc;
+        a.feat[(int64_t)sub * H + o] = f;
+        if (a.mean_out) atomicAdd(&a.mean_out[(int64_t)sub * H + o], a.mean_w * f);
+        if (a.pooled) for (int i = 0; i <= L; ++i) a.pooled[((int64_t)i * a.B + sub) * H + o] = pl[i * H + o];
+    };
+    if (G == 1) {                                                // (workgroup-uniform) one prediction layer per wave
         const int o = tid & 63, pt = wave_uniform(tid >> 6);
         float *sl = (float *)ppart;                              // [L + 1][64] per-layer scores
         for (int i = pt; i <= L; i += 8) {
@@ -536,18 +639,28 @@ template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_mediu
         if (tid < H) {
             float sp[4] = {0.f, 0.f, 0.f, 0.f};
             for (int i = 0; i <= L; ++i) sp[i & 3] += sl[i * H + tid];
-            const float sc = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-            float ss = sc * sc;
-            ss = wave_sum(ss);
-            float f = sc;
-            if (a.normalize) {
-                const float nrm = sqrtf(ss);
-                f = sc / (nrm > a.norm_eps ? nrm : a.norm_eps);
+            emit(b, pool, (sp[0] + sp[1]) + (sp[2] + sp[3]));
+        }
+    } else {                                                     // a run: waves g and g + 4 take the even / odd layers of subgraph g
+        const int o = tid & 63, pt = wave_uniform(tid >> 6), g = pt & 3, h = pt >> 2;
+        float *spx = (float *)ppart;                             // [4 subgraphs][4 partial sums][64]
+        float sa = 0.f, sb = 0.f;                                // eval_readout's partial sums h and h + 2 (layers i = h, h + 2, ... ascending)
+        if (g < G) {
+            const double *pl = pool_of(g);
+            for (int i = h; i <= L; i += 2) {
+                const int kd = i == 0 ? a.kdim0 : a.hid;
+                const float v = eval_pred_dot(a.pred_w[i] + (int64_t)o * kd, a.pred_b[i] ? a.pred_b[i] + o : nullptr, pl + i * H, kd,
+                                              eval_pred_quads(a.pred_w[i], kd));
+                if ((i & 3) == h) sa += v;
+                else sb += v;
             }
-            a.score[(int64_t)b * H + tid] = sc;
-            a.feat[(int64_t)b * H + tid] = f;
-            if (a.mean_out) atomicAdd(&a.mean_out[(int64_t)b * H + tid], a.mean_w * f);
-            if (a.pooled) for (int i = 0; i <= L; ++i) a.pooled[((int64_t)i * a.B + b) * H + tid] = pool[i * H + tid];
+        }
+        spx[(g * 4 + h) * H + o] = sa;
+        spx[(g * 4 + h + 2) * H + o] = sb;
+        __syncthreads();
+        if (pt < G) {
+            const float *sp = spx + pt * 4 * H + o;
+            emit(run.t + pt, pool_of(pt), (sp[0] + sp[H]) + (sp[2 * H] + sp[3 * H]));
         }
     }
     EV_TICK(7);
@@ -589,7 +702,9 @@ template <bool kQ> __global__ __launch_bounds__(kThreads) void gin_eval_fused_ke
     // multi-die part an agent-scope release writes L2 back: 40 us per layer with 256 workgroups doing it, measured)
     const bool single = in_lds && n <= kTile;                    // one tile: the layer updates A in place, nothing leaves LDS
 
-    if (Ln.split) {                                              // (workgroup-uniform) the LDS-resident kernels' subgraphs
+    if (Ln.split == 2) {                                         // (workgroup-uniform) the LDS-resident kernel's subgraphs and runs
+        if (eval_lds_run(a, b).take) return;
+    } else if (Ln.split) {                                       // (workgroup-uniform) the LDS-resident kernels' subgraphs
         const int nnz = a.row_ptr[n0 + n] - a.row_ptr[n0];
         if (eval_is_small(n, nnz) || eval_is_medium(n, nnz)) return;
     }
@@ -747,8 +862,8 @@ template <bool kQ> void eval_launch(const EvalLaunch &Ln, dim3 grid, hipStream_t
     }
 #endif
     hipLaunchKernelGGL(gin_eval_fused_kernel<kQ>, grid, dim3(kThreads), kEvalLds, s_general, Ln);
-    hipLaunchKernelGGL(gin_eval_medium_kernel<kQ>, grid, dim3(kMedThreads), kMedLds, s, Ln);
-    hipLaunchKernelGGL(gin_eval_small_kernel<kQ>, grid, dim3(kThreads), kSmallLds, s_small, Ln);
+    hipLaunchKernelGGL(gin_eval_medium_kernel<kQ>, Ln.split == 2 ? dim3((grid.x + kRunMax - 1) / kRunMax * kRunMax, grid.y) : grid, dim3(kMedThreads), kMedLds, s, Ln);
+    if (Ln.split != 2) hipLaunchKernelGGL(gin_eval_small_kernel<kQ>, grid, dim3(kThreads), kSmallLds, s_small, Ln);
 #ifndef GCC_AMD_HIPEMU
     if (side) {
         (void)hipEventRecord(side->join[0], s_small);
@@ -828,7 +943,8 @@ int32_t gcc_gin_eval_fused(const gcc_gin_pass *passes, int32_t npass, float *mea
     }
     // three launches over the same grid: subgraphs of at most 64 nodes in the two-per-CU kernel, up to kMedCap nodes in the
     // 8-wave LDS-resident one, the rest (hub ego-nets) in the general one
-    Ln.split = 1;
+    static const bool groups = [] { const char *e = getenv("GCC_EVAL_GROUPS"); return !e || atoi(e) != 0; }();
+    Ln.split = groups ? 2 : 1;
     if (quads) eval_launch<true>(Ln, dim3(B, npass), s);
     else eval_launch<false>(Ln, dim3(B, npass), s);
     hipError_t e = hipGetLastError();

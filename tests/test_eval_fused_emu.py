@@ -92,7 +92,7 @@ def test_fused_eval_equals_the_chain_and_the_oracle(mult):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("case", ["mixed", "tiny", "dense"])
+@pytest.mark.parametrize("case", ["mixed", "tiny", "dense", "dense4"])
 def test_packed_small_subgraphs(case):
     """The packed kernel for subgraphs of 1 .. 64 nodes (a workgroup takes all of them whose last node lies in one window of
     64 node ids): windows with one subgraph and with dozens (more than one pooling round of 32: runs of 1- and 2-node graphs),
@@ -103,11 +103,13 @@ def test_packed_small_subgraphs(case):
         sizes = [int(x) for x in rng.randint(2, 65, 40)] + [0, 0, 200, 3, 64, 64, 1, 0, 70, 5] + [int(x) for x in rng.randint(2, 30, 30)]
     elif case == "tiny":
         sizes = [1] * 70 + [2] * 50 + [0] * 5 + [1, 2, 3] * 20 + [64, 1, 1, 63, 2]
-    else:
+    elif case == "dense":
         sizes = [64, 63, 64, 2, 64, 61]
+    else:                                                        # four complete 64-node graphs: 16128 entries, more than a run's column ids
+        sizes = [64, 64, 64, 64, 5]                              # hold -> the run falls apart into its members
     model, oracle = _models(11)
     g = _batch(sizes, seed=5)
-    if case == "dense":                                          # complete graphs: n (n - 1) CSR entries each
+    if case.startswith("dense"):                                 # complete graphs: n (n - 1) CSR entries each
         node_off, row_ptr, col = [0], [0], []
         for n in sizes:
             for i in range(n):
