@@ -66,7 +66,18 @@ static inline float wave_readlane(float v, int src) { return wave_shfl(v, src); 
 static inline double wave_readlane(double v, int src) { return wave_shfl(v, src); }
 static inline int wave_readlane(int v, int src) { return wave_shfl(v, src); }
 // a value the caller knows to be wave-uniform (device: moved to a scalar register) / lane 63's value as a uniform
-static inline int wave_uniform(int v) { return v; }
+// (the emulator CHECKS the claim among the lanes that are still running: on the device a non-uniform value silently becomes the
+// first active lane's -- round 6's work-list kernel passed every emulator test that way and was wrong on the GPU)
+static inline int wave_uniform(int v)
+{
+    struct { int live, v; } me = {1, v};
+    const unsigned char *t = hipemu::wave_gather(&me, sizeof(me), 0x0F1E1Du);
+    for (int l = 0; l < 64; ++l) {
+        const auto o = hipemu::gather_at<decltype(me)>(t, l);
+        if (o.live && o.v != v) hipemu::fail("wave_uniform() of a value that differs between the lanes of a wave");
+    }
+    return v;
+}
 static inline void keep_alive(double) {}
 static inline int wave_last(int v) { return wave_shfl(v, 63); }
 // D = A(16x4) * B(4x16) + C; lane l: a = A[l&15][l>>4], b = B[l>>4][l&15],

@@ -1,28 +1,26 @@
-// gcc_amd/csrc/encoder_eval.hip -- the eval-mode GIN encoder of generate.py as ONE launch: SURVEY.md 8(f)#2's
+// gcc_amd/csrc/encoder_eval.hip -- the eval-mode GIN encoder of generate.py as ONE call: SURVEY.md 8(f)#2's
 // "per-subgraph LDS-resident megakernel".  Reference: generate.py:33-53 (test_moco: model.eval(), feat_q = model(graph_q),
 // feat_k = model(graph_k), emb = (feat_q + feat_k) / 2) -> GraphEncoder.forward gcc/models/graph_encoder.py:132-200 ->
 // UnsupervisedGIN.forward gcc/models/gin.py:213-232 with every BatchNorm on its running statistics (gin.py:54-58,113-116).
 //
 // In eval mode nothing couples two subgraphs of a batch (training-mode BatchNorm did: 12 batch-wide statistics per pass
-// are why gcc_gin_forward is a chain of 15 launches), so one workgroup takes ONE subgraph through feature assembly, all
-// GIN layers, the pooled readout and F.normalize:
-//   * the subgraph's hidden representation [n, 64] f32 lives in LDS (n <= kEvalCap rows; larger ego-nets -- ~2 % at
-//     rw_hops 256 -- gather from the L2-resident global copy instead, same code);
-//   * a layer walks the subgraph's 64-row tiles: own rows + neighbour sum (gather_tile of encoder_common.h: the tile's
-//     EDGES split over the 16 lane groups, fixed summation order) -> linears.0 on the exact-f32 MFMA -> BatchNorm affine +
-//     ReLU in registers (the MFMA's output layout IS the next product's input layout) -> linears.1 -> two more affines ->
-//     the new rows go to a global ping-pong buffer and are mirrored into LDS after the layer's last tile;
-//   * SumPooling of every hidden_rep in fp64, the five prediction layers, normalisation, and -- with two passes in the
-//     launch -- mean_out[b] += feat / 2, i.e. generate.py:52's (feat_q + feat_k) / 2.
-// Same arithmetic as gcc_gin_forward with training = 0 (same affine tables, same MFMA sequences; the gather's summation
-// order differs because tiles start at the subgraph, not at multiples of 64 of the batch): agreement ~1e-6.
+// are why gcc_gin_forward is a chain of 15 launches), so a workgroup takes a subgraph -- or a run of small ones -- through
+// feature assembly, all GIN layers, the pooled readout and F.normalize.  Three launches per call (both views of generate.py in
+// each):
+//   1. gin_eval_plan_kernel: the work list of (2), largest first, and mean_out = 0;
+//   2. gin_eval_lds_kernel: subgraphs of up to 320 nodes and runs of up to four subgraphs of at most 64 -- rows, local column
+//      ids and the layer's weights in LDS, 8 waves, per-lane neighbour sums straight into the registers the exact-f32 MFMA
+//      products read (eval_gather_row, eval_mlp_rows16), results back in place;
+//   3. gin_eval_fused_kernel: the rest (hub ego-nets of more than 320 nodes, subgraphs whose entries do not fit the column-id
+//      space) -- 64-row tiles through gather_tile of encoder_common.h, rows in LDS up to 256 nodes, in L2 above.
+// SumPooling of every hidden_rep in fp64, the prediction layers, normalisation, and -- with two passes in the call --
+// mean_out[b] += feat / 2, i.e. generate.py:52's (feat_q + feat_k) / 2.  Same arithmetic as gcc_gin_forward with training = 0
+// (same affine tables, same MFMA sequences; the neighbour sums run in another order): agreement ~1e-6.
 #include "encoder_common.h"
-#include <cstdlib>
-#include <mutex>
 
 namespace {
 
-constexpr int kEvalCap = 256;            // rows of a subgraph kept in LDS
+constexpr int kEvalCap = 256;            // rows of a subgraph the general kernel keeps in LDS
 constexpr int kEvalLd = 68;              // floats per LDS row (272 B: 16-byte aligned, rows 8 apart share a bank group)
 
 struct EvalLayer {
@@ -33,6 +31,7 @@ struct EvalArgs {
     const int32_t *node_off, *row_ptr, *col_idx, *seed_local;
     const float *pos, *emb;
     float *g0, *g1;                      // global ping-pong [node_cap][64] (the pass's z1[0] / z2[0] buffers)
+    int32_t *plan;                       // [1 + B] work list of the LDS-resident kernel (the pass's x0 buffer, unused in eval mode)
     double *pooled;                      // [L + 1][B][64] or NULL
     float *score, *feat;                 // [B][64]
     float *mean_out;                     // [B][64] or NULL: += mean_w * feat (zeroed by the host side of the call)
@@ -42,8 +41,8 @@ struct EvalArgs {
     int32_t B, L, pos_dim, emb_dim, max_degree, mult, normalize, hid, kdim0;
     float eps, norm_eps;
 };
-struct EvalLaunch { EvalArgs p[kMaxPass]; long long *ticks; int32_t split; };   // split: small subgraphs are gin_eval_small_kernel's
-static long long *g_eval_ticks = nullptr;    // diagnostics (gcc_gin_eval_debug_ticks): device int64[3][16] (small, medium, general kernel);
+struct EvalLaunch { EvalArgs p[kMaxPass]; long long *ticks; int32_t split, npass; };   // split: the general kernel leaves the LDS-resident kernel's subgraphs alone
+static long long *g_eval_ticks = nullptr;    // diagnostics (gcc_gin_eval_debug_ticks): device int64[2][16] (LDS-resident kernel, general kernel);
                                              // every 8th workgroup reports (all of them adding to the same counters waited on their own atomics)
 #define EV_TICK(ph) do { if (tick_on) { const long long now_ = device_ticks(); atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + (ph)], (unsigned long long)(now_ - tick_)); tick_ = now_; } } while (0)
 
@@ -260,112 +259,17 @@ __device__ __forceinline__ void eval_readout(const EvalArgs &a, int b, const dou
     }
 }
 
-// ---- small subgraphs (n <= 64 rows, at most kSmallEdges CSR entries): the common case (median ego-net 23 .. 55 nodes) ----------
-// One tile, nothing but the weights comes from global memory after the set-up: the subgraph's local column ids sit in LDS as
-// bytes, every lane sums ITS row's neighbours straight into the registers the first matrix product reads (lane (j, q) of wave w
-// owns row 16 w + j, channels 16 c + 4 q ..: the four lanes of a row read different quads of a neighbour's row, so nothing is
-// read twice and there is no staging tile, no side slots, no barrier inside the aggregation), the layer's result goes back into
-// the same rows after one barrier.  69 KB of LDS: two workgroups per CU (the general kernel below: 142 KB, one).
-constexpr int kSmallCap = kTile;
-constexpr int kSmallEdges = 6144;
-constexpr int kSmallLds = ((kSmallCap + 1) * kEvalLd + 2 * H * kLdt + 6 * H + 2 * H) * 4 + (GCC_GIN_MAX_LAYERS + 1) * H * 8 + 4 * H * 8
-                          + 68 * 4 + kSmallEdges;
-__device__ __forceinline__ bool eval_is_small(int n, int nnz) { return n <= kSmallCap && nnz <= kSmallEdges; }
-
-template <bool kQ> __global__ __launch_bounds__(kThreads, 2) void gin_eval_small_kernel(EvalLaunch Ln)
-{
-    DYN_SMEM(smem);
-    const EvalArgs &a = Ln.p[blockIdx.y];
-    float *A = (float *)smem;                                   // [64 + the zero row][kEvalLd]
-    float *Wl0 = A + (kSmallCap + 1) * kEvalLd, *Wl1 = Wl0 + H * kLdt;
-    float *tab = Wl1 + H * kLdt;
-    float *bias = tab + 6 * H;
-    double *pool = (double *)(bias + 2 * H);
-    double *ppart = pool + (GCC_GIN_MAX_LAYERS + 1) * H;
-    int *rp = (int *)(ppart + 4 * H);                           // [65] local row pointers
-    uint8_t *cols = (uint8_t *)(rp + 68);                       // [nnz] local column ids
-    const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
-    constexpr int kTickBase = 0;
-    const bool tick_on = Ln.ticks && threadIdx.x == 0 && ((int)blockIdx.x & 7) == 0;
-    long long tick_ = Ln.ticks ? device_ticks() : 0;
-    const int b = (int)blockIdx.x;
-    const int n0 = a.node_off[b], n = a.node_off[b + 1] - n0;
-    if (n > kSmallCap) return;                                   // (workgroup-uniform; before the dependent row_ptr reads)
-    const int e0 = a.row_ptr[n0], nnz = a.row_ptr[n0 + n] - e0;
-    if (!eval_is_small(n, nnz)) return;                          // (workgroup-uniform) the general kernel's
-    const int L = a.L;
-    LayerRegs regs = eval_request_layer<kQ, true>(a, 0);
-    {
-        const int sl = a.seed_local ? a.seed_local[b] : 0;
-        for (int r = gi; r < n; r += 16) st4(&A[r * kEvalLd + 4 * t], eval_feature4(a, n0, r, sl, t));
-        if (tid < 16) st4(&A[kSmallCap * kEvalLd + 4 * tid], F4{0.f, 0.f, 0.f, 0.f});
-        if (tid <= n) rp[tid] = a.row_ptr[n0 + tid] - e0;
-        for (int e = tid; e < nnz; e += kThreads) cols[e] = (uint8_t)(a.col_idx[e0 + e] - n0);
-    }
-    __syncthreads();
-    auto pool_rows = [&](int i) {
-        const int c = tid & 63, pt = tid >> 6;
-        double acc = 0.0;
-        for (int r = pt; r < n; r += 4) acc += (double)A[r * kEvalLd + c];
-        ppart[pt * H + c] = acc;
-        __syncthreads();
-        if (tid < H) pool[i * H + tid] = (ppart[tid] + ppart[H + tid]) + (ppart[2 * H + tid] + ppart[3 * H + tid]);
-        // (no barrier here: the partials are next written behind the following layer's barriers, the sums are read by the readout)
-    };
-    EV_TICK(0);
-    pool_rows(0);
-    EV_TICK(1);
-    if (n <= 0)
-        for (int i = tid; i < L * H; i += kThreads) pool[H + i] = 0.0;
-    const int j = lane & 15, q = lane >> 4, row = 16 * wv + j;
-    const float mult = (float)a.mult;
-    for (int l = 0; l < (n > 0 ? L : 0); ++l) {
-        eval_store_layer(a, l, regs, Wl0, Wl1, tab, bias);
-        if (l + 1 < L) regs = eval_request_layer<kQ, false>(a, l + 1);       // in flight during this layer
-        __syncthreads();
-        EV_TICK(2);
-        // GINConv aggregate (eps = 0; gin.py:179-185,218) of this lane's row and channel quads, neighbours in CSR order
-        F4 h[4];
-        if (16 * wv < n) {                                       // (wave-uniform) a wave without rows leaves the MFMA pipe -- 128 products of
-            F4 xb[4];                                            //  32 clocks per layer and wave -- to the waves that have some (median n: 23)
-            const bool live = row < n;
-            const int rb = live ? rp[row] : 0, re = live ? rp[row + 1] : 0;
-            F4 acc[4];
-            eval_gather_row(A, cols, rb, re, kSmallCap, j, q, acc);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const F4 self = live ? ld4(&A[row * kEvalLd + 16 * c + 4 * q]) : F4{0.f, 0.f, 0.f, 0.f};
-                xb[c].x = fmaf(mult, acc[c].x, self.x); xb[c].y = fmaf(mult, acc[c].y, self.y);
-                xb[c].z = fmaf(mult, acc[c].z, self.z); xb[c].w = fmaf(mult, acc[c].w, self.w);
-            }
-            EV_TICK(4);
-            eval_mlp_rows16(xb, Wl0, Wl1, tab, bias, j, q, h);
-        }
-        __syncthreads();                                         // every lane has read what it needs of the old rows
-        if (row < n) {
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) st4(&A[row * kEvalLd + 16 * cb + 4 * q], h[cb]);
-        }
-        __syncthreads();
-        EV_TICK(5);
-        pool_rows(l + 1);
-        EV_TICK(1);
-    }
-    __syncthreads();                                             // the pooled sums are complete, their partials are free
-    eval_readout(a, b, pool, ppart);
-    EV_TICK(7);
-    if (tick_on) atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + 15], 1ull);
-}
-
-// ---- medium subgraphs (65 .. kMedCap rows, at most kMedEdges CSR entries): the small kernel's shape on 8 waves ------------
-// At rw_hops 256 four subgraphs in ten have more than 64 nodes and the general kernel below walked their tiles one after the
-// other (own rows -> gather_tile -> MLP -> transit through global memory, ~12-16 us per 64-row tile and layer: 147 us for a
-// 145-node subgraph, 321 us for a 298-node one, profiles/r6_eval_trace.txt).  Here the subgraph's rows stay in LDS, the local
-// column ids too (16 bits), a wave owns 16 rows per pass of 128 and sums ITS rows' neighbours in CSR order into the registers the
-// first product reads -- no staging tile, no side slots, no global traffic inside a layer -- and the passes' results wait in
-// registers for the one barrier after which the rows are overwritten in place.  Same arithmetic, statement by statement, as
-// gin_eval_small_kernel (the gather order is the CSR's, the products are eval_mlp_rows16, the prediction layers keep the
-// summation order of eval_readout), so a subgraph gives the same bits in either kernel.
+// ---- the LDS-resident kernel: subgraphs of up to kMedCap nodes, and runs of small ones ------------------------------------------
+// History: round 4 gave subgraphs of <= 64 nodes a 4-wave kernel of their own (two per CU) and sent the rest through the general
+// kernel below, which walked their 64-row tiles one after the other (own rows -> gather_tile -> MLP -> transit through global
+// memory, ~12-16 us per tile and layer: 147 us for a 145-node subgraph, 321 us for a 298-node one, profiles/r6_eval_trace_before.txt).
+// Now ONE kernel of 8 waves keeps a subgraph's -- or a run's, eval_lds_run -- rows and 16-bit local column ids in LDS; a wave owns
+// 16 rows per pass of 128 and sums ITS rows' neighbours into the registers the first product reads (eval_gather_row: no staging
+// tile, no side slots, no global traffic inside a layer); the passes' results wait in registers for the one barrier after which
+// the rows are overwritten in place.  The products are eval_mlp_rows16, the prediction layers keep eval_readout's summation
+// order: a subgraph gives the same result alone, in a run, or in the general kernel, up to the order of its hub row's sum and
+// of the fp64 pooled sums.
+constexpr int kSmallCap = kTile;         // a "small" subgraph: at most 64 nodes (the median ego-net has 23 .. 55)
 constexpr int kMedThreads = 512;
 constexpr int kMedCap = 320;
 constexpr int kMedPasses = (kMedCap + 127) / 128;
@@ -375,7 +279,8 @@ constexpr int kMedLds = ((kMedCap + 1) * kEvalLd + 2 * H * kLdt + 6 * H + 2 * H)
                         + kMedRp * 4 + kMedEdges * 2;
 static_assert(kMedLds <= 160 * 1024, "one workgroup per CU");
 static_assert((GCC_GIN_MAX_LAYERS + 1) * H * 4 <= 8 * H * 8, "the per-layer scores share the pooling partials' space");
-__device__ __forceinline__ bool eval_is_medium(int n, int nnz) { return n > kSmallCap && n <= kMedCap && nnz <= kMedEdges; }
+// the LDS-resident kernel's subgraphs (alone or in a run); the general kernel takes the others
+__device__ __forceinline__ bool eval_in_lds(int n, int nnz) { return n <= kMedCap && nnz <= kMedEdges; }
 
 struct MedRegs { F4 w0[2], w1[2]; float v0, v1, v2, v3; };
 template <bool kQ> __device__ __forceinline__ void med_weights_request(const float *W, int kdim, F4 (&v)[2])
@@ -429,19 +334,21 @@ __device__ __forceinline__ void med_store_layer(const EvalArgs &a, int l, const 
     }
 }
 
-// Which subgraphs workgroup b of the LDS-resident kernel takes (split mode 2: no separate kernel for the small ones).
+// Which subgraphs workgroup b takes, from the node offsets alone (one round trip: three workgroups in four leave after it):
 //   * a subgraph of 65 .. kMedCap nodes: itself;
 //   * a subgraph of at most 64 nodes: the RUN of consecutive such subgraphs around it inside its aligned group of four -- rows
 //     [n0, n0 + n) of the batched CSR are then ONE block-diagonal graph of at most 256 rows, and the run's first workgroup takes
 //     it whole: the layer's weights are staged once for up to four subgraphs, 7 of the 8 waves have rows at the median size
-//     (23 nodes: a workgroup of its own used 2 of 4), and the small subgraphs no longer wait in a launch of their own;
-//   * a run with more entries than the column-id space holds (no simple graphs) falls apart into its members.
-// take: the run is the LDS-resident kernel's (the caller checks t == b for "mine"); otherwise the general kernel's.
+//     (23 nodes: a workgroup of its own used 2 of 4 waves), and the small subgraphs do not wait in a launch of their own.
+// (A run with more entries than the column-id space holds -- four complete 64-node graphs, multi-edges -- is taken member by
+// member by the same workgroup.)
 constexpr int kRunMax = 4;
-struct EvalRun { int t, e, n0, n, e0, nnz; int off[kRunMax + 1]; bool take; };
-__device__ __forceinline__ EvalRun eval_lds_run(const EvalArgs &a, int b)
+struct EvalRun { int t, g, n0, n, o1, o2, o3; };     // subgraphs [t, t + g), rows [n0, n0 + n); o1..o3: local first rows of members 1..3 (n past the run)
+                                                      // (named scalars: an offset ARRAY picked by wave index became a table in scratch memory)
+// kUniform: b is the same in every lane of the wave (the results go to scalar registers); the work-list kernel asks per lane
+template <bool kUniform = true> __device__ __forceinline__ EvalRun eval_lds_run(const EvalArgs &a, int b, int &nb)
 {
-    EvalRun r;
+    auto uni = [](int v) { return kUniform ? wave_uniform(v) : v; };
     const int q0 = b & ~(kRunMax - 1), i0 = b - q0;
     int off[kRunMax + 1];
 #pragma unroll
@@ -449,9 +356,10 @@ __device__ __forceinline__ EvalRun eval_lds_run(const EvalArgs &a, int b)
     bool small[kRunMax];
 #pragma unroll
     for (int i = 0; i < kRunMax; ++i) small[i] = q0 + i < a.B && off[i + 1] - off[i] <= kSmallCap;
-    int nb = 0;
+    nb = 0;
 #pragma unroll
     for (int i = 0; i < kRunMax; ++i) nb = i == i0 ? off[i + 1] - off[i] : nb;
+    nb = uni(nb);
     int t = i0, e = i0 + 1;
     if (nb <= kSmallCap) {
 #pragma unroll
@@ -459,31 +367,82 @@ __device__ __forceinline__ EvalRun eval_lds_run(const EvalArgs &a, int b)
 #pragma unroll
         for (int i = 1; i < kRunMax; ++i) e = (i == e && small[i]) ? i + 1 : e;
     }
-    auto span = [&](int tt, int ee) {
-        int lo = 0, hi = 0;
+    auto at = [&](int k) {                                       // node offset k of the group of four (k <= 4), past the run: the run's end
+        int v = 0;
 #pragma unroll
-        for (int i = 0; i <= kRunMax; ++i) { lo = i == tt ? off[i] : lo; hi = i == ee ? off[i] : hi; }
-        r.n0 = lo; r.n = hi - lo;
-        r.e0 = a.row_ptr[lo]; r.nnz = a.row_ptr[hi] - r.e0;
+        for (int i = 0; i <= kRunMax; ++i) v = i == min(k, e) ? off[i] : v;
+        return v;
     };
-    span(t, e);
-    if (r.nnz > kMedEdges && e - t > 1) { t = i0; e = i0 + 1; span(t, e); }
-    r.t = q0 + t; r.e = q0 + e;
-#pragma unroll
-    for (int g = 0; g <= kRunMax; ++g) {                         // local row offsets of the run's subgraphs (past the run: n)
-        int v = r.n;
-#pragma unroll
-        for (int i = 0; i <= kRunMax; ++i) v = (i == t + g && t + g <= e) ? off[i] - r.n0 : v;
-        r.off[g] = v;
-    }
-    r.take = nb <= kMedCap && r.nnz <= kMedEdges;
+    EvalRun r;
+    r.t = uni(q0 + t); r.g = uni(e - t);      // (all of it is workgroup-uniform: scalar registers)
+    r.n0 = uni(at(t)); r.n = uni(at(e)) - r.n0;
+    r.o1 = uni(at(t + 1)) - r.n0; r.o2 = uni(at(t + 2)) - r.n0; r.o3 = uni(at(t + 3)) - r.n0;
+    return r;
+}
+// member g of a run as a run of its own
+__device__ __forceinline__ EvalRun eval_run_member(const EvalRun &run, int g)
+{
+    const int a1 = run.o1, a2 = run.o2, a3 = run.o3, an = run.n;   // (values first: selects over the fields become an indexed load)
+    const int lo = g == 0 ? 0 : g == 1 ? a1 : g == 2 ? a2 : a3;
+    const int hi = g == 0 ? a1 : g == 1 ? a2 : g == 2 ? a3 : an;
+    EvalRun r;
+    r.t = run.t + g; r.g = 1; r.n0 = run.n0 + lo; r.n = hi - lo; r.o1 = r.o2 = r.o3 = r.n;
     return r;
 }
 
-template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_medium_kernel(EvalLaunch Ln)
+// The work list of the LDS-resident kernel, one workgroup per pass: plan[0] = number of runs / subgraphs it takes, plan[1 ..] = their
+// first subgraphs, LARGEST FIRST (counting sort by rows).  Why a list: the kernel holds one workgroup per CU, and with a workgroup
+// per subgraph three in four only looked at the node offsets and left -- but each of them held a CU's LDS for the microseconds
+// that takes, in dispatch order, so the last workgroups WITH work started 46 us (rw_hops 64: 176 of 512 have work) to 76 us
+// (rw_hops 256) after the first.  With the list the first plan[0] workgroups all have work, the longest go first and round-robin
+// over the XCDs, and the rest leave after one scalar load.  Also zeroes mean_out (the memset this launch replaces).
+constexpr int kPlanThreads = 256;
+__global__ __launch_bounds__(kPlanThreads) void gin_eval_plan_kernel(EvalLaunch Ln)
+{
+    __shared__ int hist[kMedCap + 1 + 63], start[kMedCap + 1 + 63];
+    const EvalArgs &a = Ln.p[blockIdx.x];
+    const int tid = (int)threadIdx.x;
+    if (blockIdx.x == 0 && a.mean_out)
+        for (int i = tid; i < a.B * (H / 4); i += kPlanThreads) st4(a.mean_out + 4 * (int64_t)i, F4{0.f, 0.f, 0.f, 0.f});
+    for (int i = tid; i < kMedCap + 1 + 63; i += kPlanThreads) hist[i] = 0;
+    __syncthreads();
+    auto item = [&](int b, int &rows) {                          // does a workgroup of the LDS-resident kernel start at subgraph b?
+        int nb;
+        const EvalRun run = eval_lds_run<false>(a, b, nb);
+        rows = run.n;
+        return nb <= kMedCap && run.t == b;
+    };
+    for (int b = tid; b < a.B; b += kPlanThreads) {
+        int rows;
+        if (item(b, rows)) atomicAdd(&hist[rows], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {                                              // start[r] = number of items with more rows than r (6 bins per lane, descending)
+        int mine = 0;
+        for (int k = 0; k < 6; ++k) mine += hist[kMedCap + 63 - (6 * tid + k)];
+        int before = wave_scan_incl(mine) - mine;
+        for (int k = 0; k < 6; ++k) {
+            const int r = kMedCap + 63 - (6 * tid + k);
+            start[r] = before;
+            before += hist[r];
+        }
+        if (tid == 63) a.plan[0] = before;
+    }
+    __syncthreads();
+    for (int i = tid; i < kMedCap + 1 + 63; i += kPlanThreads) hist[i] = 0;
+    __syncthreads();
+    for (int b = tid; b < a.B; b += kPlanThreads) {
+        int rows;
+        if (item(b, rows)) a.plan[1 + start[rows] + atomicAdd(&hist[rows], 1)] = b;
+    }
+}
+
+template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_lds_kernel(EvalLaunch Ln)
 {
     DYN_SMEM(smem);
-    const EvalArgs &a = Ln.p[blockIdx.y];
+    // grid (B, passes): workgroup x takes item x of the pass's work list (gin_eval_plan_kernel), if there is one
+    const int pass = (int)blockIdx.y;
+    const EvalArgs &a = Ln.p[pass];
     float *A = (float *)smem;                                   // [kMedCap + the zero row][kEvalLd]
     float *Wl0 = A + (kMedCap + 1) * kEvalLd, *Wl1 = Wl0 + H * kLdt;
     float *tab = Wl1 + H * kLdt;
@@ -493,42 +452,44 @@ template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_mediu
     int *rp = (int *)(ppart + 8 * H);                           // [n + 1] local row pointers
     uint16_t *cols = (uint16_t *)(rp + kMedRp);                 // [nnz] local column ids
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
-    constexpr int kTickBase = 16;
+    constexpr int kTickBase = 0;
     long long tick_ = Ln.ticks ? device_ticks() : 0;
-    // Workgroup x -> subgraph 4 (x mod Q) + x / Q, Q = ceil(B / 4): consecutive workgroups go to consecutive XCDs, and a run's first
-    // subgraph is (as a rule) a multiple of 4 -- with b = x the runs' workgroups all sat on XCDs 0 and 4 (64 of the 256 CUs, one
-    // workgroup per CU: 120 us for 45 us of work); this way they are the first quarter of the grid, spread over all eight
-    const int nq = (a.B + kRunMax - 1) / kRunMax;
-    const int b = Ln.split == 2 ? kRunMax * ((int)blockIdx.x % nq) + (int)blockIdx.x / nq : (int)blockIdx.x;
-    if (b >= a.B) return;
-    EvalRun run;
-    if (Ln.split == 2) {
-        run = eval_lds_run(a, b);
-        if (!run.take || run.t != b) return;                     // (workgroup-uniform) the general kernel's, or another workgroup's run
-    } else {
-        run.n0 = a.node_off[b]; run.n = a.node_off[b + 1] - run.n0;
-        if (run.n <= kSmallCap || run.n > kMedCap) return;       // (workgroup-uniform; <= 64 nodes: the small kernel's, or -- more than 6144 entries, no simple graph -- the general one's)
-        run.e0 = a.row_ptr[run.n0]; run.nnz = a.row_ptr[run.n0 + run.n] - run.e0;
-        if (!eval_is_medium(run.n, run.nnz)) return;             // (workgroup-uniform) the general kernel's
-        run.t = b; run.e = b + 1;
-        run.off[0] = 0;
-#pragma unroll
-        for (int g = 1; g <= kRunMax; ++g) run.off[g] = run.n;
+    const long long wg_start_ = tick_;
+    if ((int)blockIdx.x >= wave_uniform(a.plan[0])) return;      // (workgroup-uniform) nothing left
+    const int b = wave_uniform(a.plan[1 + blockIdx.x]);
+    int nb;
+    const EvalRun whole = eval_lds_run(a, b, nb);
+    const int whole_e0 = wave_uniform(a.row_ptr[whole.n0]);
+    const int whole_nnz = wave_uniform(a.row_ptr[whole.n0 + whole.n]) - whole_e0;
+    const int L = a.L;
+    // a run as a whole or -- more entries than column ids fit (workgroup-uniform) -- member by member.  (A loop around the body, not
+    // a lambda called in a loop: through the lambda's captures the LDS pointers became generic ones, 180 flat_load / flat_store.)
+    if (whole_nnz > kMedEdges && whole.g == 1) return;           // (workgroup-uniform) one subgraph with too many entries: the general kernel's
+    const int parts = whole_nnz <= kMedEdges ? 1 : whole.g;
+    for (int part = 0; part < parts; ++part) {
+    EvalRun one = whole;
+    int e0 = whole_e0, nnz = whole_nnz;
+    if (parts > 1) {
+        __syncthreads();                                         // the next member overwrites everything
+        one = eval_run_member(whole, part);
+        e0 = wave_uniform(a.row_ptr[one.n0]);
+        nnz = wave_uniform(a.row_ptr[one.n0 + one.n]) - e0;
+        if (nnz > kMedEdges) continue;                           // (the general kernel's)
     }
-    const int n0 = run.n0, n = run.n, e0 = run.e0, nnz = run.nnz, G = run.e - run.t;
+    const int first = one.t, G = one.g, n0 = one.n0, n = one.n, o0 = 0, o1 = one.o1, o2 = one.o2, o3 = one.o3, o4 = one.n;
 #ifdef GCC_EVAL_TICK_BIG                                         // (diagnostic build: the phases of the largest subgraphs only)
     const bool tick_on = Ln.ticks && threadIdx.x == 0 && n >= GCC_EVAL_TICK_BIG;
 #else
-    const bool tick_on = Ln.ticks && threadIdx.x == 0 && (b & 7) == 0;
+    const bool tick_on = Ln.ticks && threadIdx.x == 0 && (blockIdx.x & 3) == 0;
 #endif
-    const int L = a.L;
     MedRegs regs = med_request_layer<kQ, true>(a, 0);
     {
         int seedrow[kRunMax];                                    // local row of each subgraph's seed (ndata["seed"], data_util.py:234-238)
 #pragma unroll
-        for (int g = 0; g < kRunMax; ++g) seedrow[g] = run.off[g] + ((a.seed_local && g < G) ? a.seed_local[run.t + g] : 0);
+        for (int g = 0; g < kRunMax; ++g)
+            seedrow[g] = (g == 0 ? o0 : g == 1 ? o1 : g == 2 ? o2 : o3) + ((a.seed_local && g < G) ? a.seed_local[first + g] : 0);
         for (int r = gi; r < n; r += kMedThreads / 16) {
-            const int sl = r >= run.off[3] ? seedrow[3] : r >= run.off[2] ? seedrow[2] : r >= run.off[1] ? seedrow[1] : seedrow[0];
+            const int sl = r >= o3 ? seedrow[3] : r >= o2 ? seedrow[2] : r >= o1 ? seedrow[1] : seedrow[0];
             st4(&A[r * kEvalLd + 4 * t], eval_feature4(a, n0, r, sl, t));
         }
         if (tid < 16) st4(&A[kMedCap * kEvalLd + 4 * tid], F4{0.f, 0.f, 0.f, 0.f});
@@ -540,11 +501,17 @@ template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_mediu
     // 256 rows; the zero row is row kMedCap)
     static_assert(kRunMax * kSmallCap + 1 + ((kRunMax - 1) * (GCC_GIN_MAX_LAYERS + 1) * H * 8 + kEvalLd * 4 - 1) / (kEvalLd * 4) <= kMedCap,
                   "the other subgraphs' pooled sums fit between a run's rows and the zero row");
-    auto pool_of = [&](int g) -> double * {
+    auto pool_of = [&](int g) __attribute__((always_inline)) -> double * {
         return g == 0 ? pool : (double *)(A + (kRunMax * kSmallCap + 1) * kEvalLd) + (g - 1) * (GCC_GIN_MAX_LAYERS + 1) * H;
     };
-    auto pool_rows = [&](int i) {                                // SumPooling (gin.py:228), fp64, fixed order
-        const int c = tid & 63, pt = tid >> 6;
+    // rows of the subgraph this wave pools in a run (waves g and g + 4: subgraph g).  Picked here, from values: inside the lambda the
+    // selects over captured variables became an indexed load from the closure object, which then had to live in scratch memory
+    // -- and every LDS pointer it held turned into a generic one (180 flat_load / flat_store instead of ds_read / ds_write)
+    const int seg_g = wave_uniform(tid >> 6) & 3;
+    const int seg_r0 = seg_g == 0 ? o0 : seg_g == 1 ? o1 : seg_g == 2 ? o2 : o3;
+    const int seg_r1 = seg_g == 0 ? o1 : seg_g == 1 ? o2 : seg_g == 2 ? o3 : o4;
+    auto pool_rows = [&](int i) __attribute__((always_inline)) {   // SumPooling (gin.py:228), fp64, fixed order
+        const int c = tid & 63, pt = wave_uniform(tid >> 6);    // (scalar: the run's offsets are picked by scalar selects, not from a copy in scratch)
         if (G == 1) {                                            // (workgroup-uniform) one subgraph: 8 strided partials
             double acc = 0.0;
             for (int r = pt; r < n; r += 8) acc += (double)A[r * kEvalLd + c];
@@ -554,15 +521,13 @@ template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_mediu
                 pool[i * H + tid] = ((ppart[tid] + ppart[H + tid]) + (ppart[2 * H + tid] + ppart[3 * H + tid]))
                                     + ((ppart[4 * H + tid] + ppart[5 * H + tid]) + (ppart[6 * H + tid] + ppart[7 * H + tid]));
         } else {                                                 // a run: waves g and g + 4 take the even / odd rows of subgraph g
-            const int g = pt & 3, r1 = g == 0 ? run.off[1] : g == 1 ? run.off[2] : g == 2 ? run.off[3] : run.off[4];
-            const int r0 = g == 0 ? run.off[0] : g == 1 ? run.off[1] : g == 2 ? run.off[2] : run.off[3];
             double acc = 0.0;
-            for (int r = r0 + (pt >> 2); r < r1; r += 2) acc += (double)A[r * kEvalLd + c];
+            for (int r = seg_r0 + (pt >> 2); r < seg_r1; r += 2) acc += (double)A[r * kEvalLd + c];
             ppart[pt * H + c] = acc;
             __syncthreads();
             if (pt < G) pool_of(pt)[i * H + c] = ppart[pt * H + c] + ppart[(pt + 4) * H + c];
         }
-        // (no barrier here: as in the small kernel)
+        // (no barrier here: the partials are next written behind the following layer's barriers, the sums are read by the readout)
     };
     EV_TICK(0);
     pool_rows(0);
@@ -613,7 +578,7 @@ template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_mediu
     }
     // readout (eval_readout's sums in eval_readout's order)
     __syncthreads();                                             // the pooled sums are complete, their partials are free
-    auto emit = [&](int sub, const double *pl, float sc) {      // one wave, lane = channel: F.normalize, outputs of subgraph `sub`
+    auto emit = [&](int sub, const double *pl, float sc) __attribute__((always_inline)) {      // one wave, lane = channel: F.normalize, outputs of subgraph `sub`
         float ss = sc * sc;
         ss = wave_sum(ss);
         float f = sc;
@@ -639,7 +604,7 @@ template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_mediu
         if (tid < H) {
             float sp[4] = {0.f, 0.f, 0.f, 0.f};
             for (int i = 0; i <= L; ++i) sp[i & 3] += sl[i * H + tid];
-            emit(b, pool, (sp[0] + sp[1]) + (sp[2] + sp[3]));
+            emit(first, pool, (sp[0] + sp[1]) + (sp[2] + sp[3]));
         }
     } else {                                                     // a run: waves g and g + 4 take the even / odd layers of subgraph g
         const int o = tid & 63, pt = wave_uniform(tid >> 6), g = pt & 3, h = pt >> 2;
@@ -660,11 +625,19 @@ template <bool kQ> __global__ __launch_bounds__(kMedThreads) void gin_eval_mediu
         __syncthreads();
         if (pt < G) {
             const float *sp = spx + pt * 4 * H + o;
-            emit(run.t + pt, pool_of(pt), (sp[0] + sp[H]) + (sp[2 * H] + sp[3 * H]));
+            emit(first + pt, pool_of(pt), (sp[0] + sp[H]) + (sp[2 * H] + sp[3 * H]));
         }
     }
     EV_TICK(7);
     if (tick_on) atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + 15], 1ull);
+    }  // parts
+    if (Ln.ticks && tid == 0) {                                  // every workgroup with work: first / last start, last end, longest stay (100 MHz clock)
+        const unsigned long long now = (unsigned long long)device_ticks();
+        atomicMin((unsigned long long *)&Ln.ticks[kTickBase + 8], (unsigned long long)wg_start_);
+        atomicMax((unsigned long long *)&Ln.ticks[kTickBase + 9], (unsigned long long)wg_start_);
+        atomicMax((unsigned long long *)&Ln.ticks[kTickBase + 10], now);
+        atomicMax((unsigned long long *)&Ln.ticks[kTickBase + 11], now - (unsigned long long)wg_start_);
+    }
 }
 
 constexpr int kEvalLds = (kEvalCap * kEvalLd + kTile * kLdt + 2 * H * kLdt + 32 * H + 6 * H + 2 * H) * 4   // A, T, Wl0, Wl1, part, tables, biases
@@ -687,7 +660,7 @@ template <bool kQ> __global__ __launch_bounds__(kThreads) void gin_eval_fused_ke
     int *prow = rpl + kTile + 1;                                // [32]
 
     const int tid = (int)threadIdx.x, t = tid & 15, gi = tid >> 4, lane = lane_id(), wv = tid >> 6;
-    constexpr int kTickBase = 32;
+    constexpr int kTickBase = 16;
     const bool tick_on = Ln.ticks && threadIdx.x == 0 && ((int)blockIdx.x & 7) == 0;
     long long tick_ = Ln.ticks ? device_ticks() : 0;
     const int b = (int)blockIdx.x;
@@ -702,12 +675,7 @@ template <bool kQ> __global__ __launch_bounds__(kThreads) void gin_eval_fused_ke
     // multi-die part an agent-scope release writes L2 back: 40 us per layer with 256 workgroups doing it, measured)
     const bool single = in_lds && n <= kTile;                    // one tile: the layer updates A in place, nothing leaves LDS
 
-    if (Ln.split == 2) {                                         // (workgroup-uniform) the LDS-resident kernel's subgraphs and runs
-        if (eval_lds_run(a, b).take) return;
-    } else if (Ln.split) {                                       // (workgroup-uniform) the LDS-resident kernels' subgraphs
-        const int nnz = a.row_ptr[n0 + n] - a.row_ptr[n0];
-        if (eval_is_small(n, nnz) || eval_is_medium(n, nnz)) return;
-    }
+    if (Ln.split && eval_in_lds(n, a.row_ptr[n0 + n] - a.row_ptr[n0])) return;      // (workgroup-uniform) the LDS-resident kernel's
     LayerRegs regs = eval_request_layer<kQ, true>(a, 0);                   // (n == 0: harmless)
 
     // ---- hidden_rep[0]: input features (graph_encoder.py:158-165) -> A (LDS) or, for a big subgraph, cur (global)
@@ -812,73 +780,29 @@ template <bool kQ> __global__ __launch_bounds__(kThreads) void gin_eval_fused_ke
     if (tick_on) atomicAdd((unsigned long long *)&Ln.ticks[kTickBase + 15], 1ull);
 }
 
-// The three kernels share nothing but mean_out (atomic adds): they run side by side -- the medium kernel (one workgroup per
-// CU, the call's longest workgroups) on the caller's stream, the other two on side streams forked from it and joined back
-// (capturable: a hipGraph gets three parallel branches).  In one stream the launches serialised: 54 + 75 + 5 us at rw_hops 64
-// with 470 small and 42 medium subgraphs.  GCC_EVAL_FORK=0 keeps them in one stream.
-#ifndef GCC_AMD_HIPEMU
-struct EvalSide { hipStream_t owner, side[2]; hipEvent_t fork, join[2]; };
-static EvalSide *eval_side_streams(hipStream_t s)
+// Three launches: the work list (and mean_out = 0), the LDS-resident kernel, then the general one (hub ego-nets of more than kMedCap nodes; 5 us when there are none).
+// (Side by side on forked streams they gained 8 us as launches and lost 30 replayed from a hipGraph, plus 120 us of host time
+// per call for the events: profiles/r6_eval_probe.txt's header.)
+template <bool kQ> void eval_launch(const EvalLaunch &Ln, int B, int npass, hipStream_t s)
 {
-    static const bool on = [] { const char *e = getenv("GCC_EVAL_FORK"); return e && atoi(e) != 0; }();
-    if (!on) return nullptr;
-    static std::mutex mu;
-    static EvalSide tab[16];
-    static int ntab = 0;
-    std::lock_guard<std::mutex> lk(mu);
-    for (int i = 0; i < ntab; ++i)
-        if (tab[i].owner == s) return &tab[i];
-    if (ntab == 16) return nullptr;                  // (more caller streams than anyone uses: those calls stay on one stream)
-    EvalSide &t = tab[ntab];
-    int prio = 0;
-    if (hipStreamGetPriority(s, &prio) != hipSuccess) { (void)hipGetLastError(); prio = 0; }
-    for (int i = 0; i < 2; ++i) {
-        if (hipStreamCreateWithPriority(&t.side[i], hipStreamNonBlocking, prio) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (hipEventCreateWithFlags(&t.join[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    }
-    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    t.owner = s;
-    return &tab[ntab++];
-}
-#endif
-
-template <bool kQ> void eval_launch(const EvalLaunch &Ln, dim3 grid, hipStream_t s)
-{
-    hipStream_t s_small = s, s_general = s;
 #ifndef GCC_AMD_HIPEMU
     static bool opted = false;                               // more than 64 KiB of dynamic LDS is opted into once
     if (!opted) {
         (void)hipFuncSetAttribute((const void *)gin_eval_fused_kernel<kQ>, hipFuncAttributeMaxDynamicSharedMemorySize, kEvalLds);
-        (void)hipFuncSetAttribute((const void *)gin_eval_small_kernel<kQ>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLds);
-        (void)hipFuncSetAttribute((const void *)gin_eval_medium_kernel<kQ>, hipFuncAttributeMaxDynamicSharedMemorySize, kMedLds);
+        (void)hipFuncSetAttribute((const void *)gin_eval_lds_kernel<kQ>, hipFuncAttributeMaxDynamicSharedMemorySize, kMedLds);
         opted = true;
     }
-    EvalSide *side = eval_side_streams(s);
-    if (side) {
-        s_small = side->side[0]; s_general = side->side[1];
-        (void)hipEventRecord(side->fork, s);                 // (behind the memset of mean_out)
-        (void)hipStreamWaitEvent(s_small, side->fork, 0);
-        (void)hipStreamWaitEvent(s_general, side->fork, 0);
-    }
 #endif
-    hipLaunchKernelGGL(gin_eval_fused_kernel<kQ>, grid, dim3(kThreads), kEvalLds, s_general, Ln);
-    hipLaunchKernelGGL(gin_eval_medium_kernel<kQ>, Ln.split == 2 ? dim3((grid.x + kRunMax - 1) / kRunMax * kRunMax, grid.y) : grid, dim3(kMedThreads), kMedLds, s, Ln);
-    if (Ln.split != 2) hipLaunchKernelGGL(gin_eval_small_kernel<kQ>, grid, dim3(kThreads), kSmallLds, s_small, Ln);
-#ifndef GCC_AMD_HIPEMU
-    if (side) {
-        (void)hipEventRecord(side->join[0], s_small);
-        (void)hipEventRecord(side->join[1], s_general);
-        (void)hipStreamWaitEvent(s, side->join[0], 0);
-        (void)hipStreamWaitEvent(s, side->join[1], 0);
-    }
-#endif
+    hipLaunchKernelGGL(gin_eval_plan_kernel, dim3(npass), dim3(kPlanThreads), 0, s, Ln);
+    hipLaunchKernelGGL(gin_eval_lds_kernel<kQ>, dim3(B, npass), dim3(kMedThreads), kMedLds, s, Ln);
+    hipLaunchKernelGGL(gin_eval_fused_kernel<kQ>, dim3(B, npass), dim3(kThreads), kEvalLds, s, Ln);
 }
 
 }  // namespace
 
 extern "C" {
 
-/* diagnostics, as gcc_gin_debug_ticks: device int64[3][16] (per kernel) of wall-clock ticks per phase of gcc_gin_eval_fused (features,
+/* diagnostics, as gcc_gin_debug_ticks: device int64[2][16] (per kernel) of wall-clock ticks per phase of gcc_gin_eval_fused (features,
  * pooling, weights, own rows, gather, Linears, mirror, readout; [15] = workgroups); NULL switches it off */
 void gcc_gin_eval_debug_ticks(long long *device_ticks64) { g_eval_ticks = device_ticks64; }
 
@@ -895,16 +819,16 @@ int32_t gcc_gin_eval_fused(const gcc_gin_pass *passes, int32_t npass, float *mea
     for (int i = 0; i < npass; ++i) {
         const gcc_gin_pass &p = passes[i];
         const int L = p.w.num_gin_layers, kdim0 = p.w.pos_dim + p.w.deg_emb_dim + 1;
-        if (p.training || L < 1 || L > GCC_GIN_MAX_LAYERS || kdim0 > H || p.batch_size != B || B < 1 || !p.z1[0] || !p.z2[0] ||
+        if (p.training || L < 1 || L > GCC_GIN_MAX_LAYERS || kdim0 > H || p.batch_size != B || B < 1 || !p.z1[0] || !p.z2[0] || !p.x0 ||
             !p.score || !p.feat || !p.node_off || !p.row_ptr || !p.col_idx || !p.pos) {
-            snprintf(g_err, kErrLen, "gcc_gin_eval_fused: an eval-mode pass with z1[0] / z2[0] scratch, score and feat is needed "
+            snprintf(g_err, kErrLen, "gcc_gin_eval_fused: an eval-mode pass with x0 / z1[0] / z2[0] scratch, score and feat is needed "
                                      "(training=%d layers=%d d_in=%d B=%d)", p.training, L, kdim0, p.batch_size);
             return -2;
         }
         EvalArgs &a = Ln.p[i];
         a.node_off = p.node_off; a.row_ptr = p.row_ptr; a.col_idx = p.col_idx; a.seed_local = p.seed_local;
         a.pos = p.pos; a.emb = p.w.degree_embedding;
-        a.g0 = p.z1[0]; a.g1 = p.z2[0];
+        a.g0 = p.z1[0]; a.g1 = p.z2[0]; a.plan = (int32_t *)p.x0;
         a.pooled = p.pooled; a.score = p.score; a.feat = p.feat;
         a.mean_out = mean_out; a.mean_w = 1.0f / (float)npass;
         for (int l = 0; l < L; ++l) {
@@ -934,19 +858,10 @@ int32_t gcc_gin_eval_fused(const gcc_gin_pass *passes, int32_t npass, float *mea
             quads = quads && ((uintptr_t)a.layer[l].w1 & 15) == 0 && (l == 0 || ((uintptr_t)a.layer[l].w0 & 15) == 0);
     }
     hipStream_t s = (hipStream_t)stream;
-    if (mean_out) {
-#ifndef GCC_AMD_HIPEMU
-        (void)hipMemsetAsync(mean_out, 0, (size_t)B * H * sizeof(float), s);
-#else
-        memset(mean_out, 0, (size_t)B * H * sizeof(float));
-#endif
-    }
-    // three launches over the same grid: subgraphs of at most 64 nodes in the two-per-CU kernel, up to kMedCap nodes in the
-    // 8-wave LDS-resident one, the rest (hub ego-nets) in the general one
-    static const bool groups = [] { const char *e = getenv("GCC_EVAL_GROUPS"); return !e || atoi(e) != 0; }();
-    Ln.split = groups ? 2 : 1;
-    if (quads) eval_launch<true>(Ln, dim3(B, npass), s);
-    else eval_launch<false>(Ln, dim3(B, npass), s);
+    Ln.split = 1;
+    Ln.npass = npass;
+    if (quads) eval_launch<true>(Ln, B, npass, s);
+    else eval_launch<false>(Ln, B, npass, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         snprintf(g_err, kErrLen, "gcc_gin_eval_fused: launch failed: %s", hipGetErrorString(e));

@@ -360,17 +360,19 @@ typedef struct gcc_gin_pass {    /* one encoder invocation on one batched graph 
  * in the same launches.  prof marks: 0 before, 1 after. */
 int32_t gcc_gin_forward(const gcc_gin_pass *passes, int32_t npass, gcc_prof *prof, void *stream);
 
-/* The eval-mode forward as ONE launch (generate.py:33-53: model.eval(); feat_q = model(graph_q); feat_k = model(graph_k);
- * emb = (feat_q + feat_k) / 2): one workgroup carries one subgraph through feature assembly, every GIN layer, the pooled
- * readout and F.normalize with its hidden representation resident in LDS (subgraphs up to 256 nodes; larger ones gather
- * from the L2-resident global copy).  Every pass must have training = 0 (running statistics) and z1[0], z2[0] ([node_cap,
- * 64] scratch), score and feat; pooled is written when not NULL.  mean_out: device [B, 64] or NULL -- receives the mean
- * of the passes' feat (npass = 2: generate.py:52).  Same results as gcc_gin_forward in eval mode to ~1e-6 (the gather's
- * summation order differs). */
+/* The eval-mode forward as ONE call (generate.py:33-53: model.eval(); feat_q = model(graph_q); feat_k = model(graph_k);
+ * emb = (feat_q + feat_k) / 2): a workgroup carries a subgraph -- or a run of up to four subgraphs of at most 64 nodes --
+ * through feature assembly, every GIN layer, the pooled readout and F.normalize with the hidden representation resident in
+ * LDS (up to 320 nodes; larger ego-nets go through a second kernel that keeps up to 256 rows in LDS and gathers from the
+ * L2-resident global copy above).  Every pass must have training = 0 (running statistics) and x0, z1[0], z2[0] ([node_cap,
+ * 64] scratch: x0 holds the call's work list), score and feat; pooled is written when not NULL.  mean_out: device [B, 64]
+ * or NULL -- receives the mean of the passes' feat (npass = 2: generate.py:52).  Same results as gcc_gin_forward in eval
+ * mode to ~1e-6 (the neighbour sums run in another order). */
 int32_t gcc_gin_eval_fused(const gcc_gin_pass *passes, int32_t npass, float *mean_out, void *stream);
-/* diagnostics: device int64[3][16] -- per kernel of the call (subgraphs of <= 64 nodes, <= 320 nodes, the rest) 100 MHz ticks per
- * phase (features, pooling, weights, own rows, gather, Linears, mirror, readout; [15] = workgroups), summed over every 8th workgroup
- * of the following calls; NULL switches it off */
+/* diagnostics: device int64[2][16] -- per kernel of the call (subgraphs and runs of up to 320 nodes; the rest) 100 MHz ticks per
+ * phase (features, pooling, weights, own rows / one wave's neighbour sums, gather / one wave's products, Linears / write-back,
+ * mirror / barrier wait, readout; [8..11] = first start, last start, last end, longest stay of a workgroup; [15] = workgroups),
+ * summed over every 4th (8th) workgroup of the following calls; NULL switches it off */
 void gcc_gin_eval_debug_ticks(long long *device_ticks64);
 
 typedef struct gcc_gin_grads {   /* same shapes as the weights; written (not accumulated)  */

@@ -84,6 +84,8 @@ void prepare(Fiber &f)
 
 }  // namespace
 
+[[noreturn]] void fail(const char *msg) { die(msg); }
+
 void sync_block()
 {
     unsigned gen = blk_gen;

@@ -40,6 +40,7 @@ extern Fiber *cur;
 extern Dim3 g_blockIdx, g_blockDim, g_gridDim;
 extern unsigned char *g_dyn_smem;
 
+[[noreturn]] void fail(const char *msg);      // message + block / thread, abort
 void sync_block();
 void wave_barrier_only();
 // every lane deposits `size` bytes; returns pointer to a [64][size] table valid

@@ -131,24 +131,35 @@ def test_packed_small_subgraphs(case):
     torch.testing.assert_close(f_fused, ref, rtol=1e-4, atol=2e-5)
 
 
-def test_three_size_classes():
-    """One subgraph on each side of every dispatch boundary of gcc_gin_eval_fused: 64 / 65 nodes (two-per-CU kernel | 8-wave
-    LDS-resident kernel), 320 / 321 nodes (| general kernel), a 400-node hub ego-net, and a complete graph on 130 nodes whose
-    16770 CSR entries exceed the LDS-resident kernel's column-id space (general kernel by edge count); three passes of 128 rows,
-    a last pass with one wave's worth of rows, edge multiplicity 1."""
-    sizes = [320, 64, 321, 65, 400, 257, 130]
-    model, oracle = _models(13)
+def size_class_batch():
+    """One subgraph on each side of every dispatch boundary of gcc_gin_eval_fused: 64 / 65 nodes (member of a run | a workgroup of
+    its own), 320 / 321 nodes (LDS-resident kernel | general kernel), a 400-node hub ego-net, a complete graph on 130 nodes whose
+    16770 CSR entries exceed the LDS-resident kernel's column-id space (general kernel by edge count), runs of one to four small
+    subgraphs broken by larger ones and by the groups of four, three passes of 128 rows, a last pass with one wave's worth of rows."""
+    sizes = [320, 64, 321, 65, 400, 257, 130, 3, 40, 17, 64, 9, 70, 1, 0, 33, 64, 64, 5]
     g = _batch(sizes, seed=9, hub=True)
     node_off = g.node_off.tolist()
-    rp, ci = g.row_ptr.tolist(), g.col_idx.tolist()
-    n0, n = node_off[-2], sizes[-1]                               # the last subgraph becomes complete
-    rp, ci = rp[: n0 + 1], ci[: rp[n0]]
+    rp, ci = g.row_ptr[: node_off[-1] + 1].tolist(), g.col_idx.tolist()
+    n0, n1, n = node_off[6], node_off[7], sizes[6]                # the 130-node subgraph becomes complete
+    head_ci, tail_ci = ci[: rp[n0]], ci[rp[n1]:]
+    mid_rp, mid_ci = [], []
     for i in range(n):
-        ci += [n0 + u for u in range(n) if u != i]
-        rp.append(len(ci))
+        mid_ci += [n0 + u for u in range(n) if u != i]
+        mid_rp.append(len(head_ci) + len(mid_ci))                 # end of row n0 + i
+    shift = mid_rp[-1] - rp[n1]
+    rp = rp[: n0 + 1] + mid_rp + [x + shift for x in rp[n1 + 1:]]
+    ci = head_ci + mid_ci + tail_ci
     g = CpuBatch(dict(node_off=torch.tensor(node_off), row_ptr=torch.tensor(rp), col_idx=torch.tensor(ci),
                       pos_undirected=g.pos_undirected[: node_off[-1]]))
-    g.seed_local = torch.tensor([7, 63, 320, 0, 399, 256, 129], dtype=torch.int32)
+    rng = np.random.RandomState(5)
+    g.seed_local = torch.tensor([int(rng.randint(0, max(s, 1))) for s in sizes], dtype=torch.int32)
+    return g
+
+
+def test_three_size_classes():
+    """size_class_batch through the fused call, the eval chain and the oracle."""
+    model, oracle = _models(13)
+    g = size_class_batch()
     with torch.no_grad():
         model.fused_eval = True
         f_fused, p_fused = model(g, return_all_outputs=True)

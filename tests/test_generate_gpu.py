@@ -169,3 +169,71 @@ def test_fused_eval_kernel_equals_the_eval_chain_on_the_device():
         with torch.no_grad():
             ref = oracle(no, mult * torch.from_numpy(rpq), torch.repeat_interleave(torch.from_numpy(ciq), mult), pos)
         torch.testing.assert_close(ff.cpu(), ref, rtol=1e-3, atol=1e-4)
+
+
+def _device_batch(g):
+    """tests/hipemu/emu_encoder.CpuBatch -> the same batch on the device"""
+    for name in ("node_off", "row_ptr", "col_idx", "edge_off", "graph_id", "parent_nid", "pos_undirected", "seed_local"):
+        if getattr(g, name, None) is not None:
+            setattr(g, name, getattr(g, name).cuda())
+    return g
+
+
+@pytest.mark.parametrize("case", ["boundaries", "mixed", "tiny", "dense4"])
+def test_fused_eval_size_classes_on_the_device(case):
+    """The emulator tier's dispatch-boundary batches (tests/test_eval_fused_emu.py: one subgraph on each side of 64 / 65 and 320 /
+    321 nodes, the edge-count limit, runs of one to four small subgraphs, empty graphs, a run whose entries do not fit) through
+    gcc_gin_eval_fused on the GPU -- where wave_uniform() IS v_readfirstlane and a workgroup's LDS is real -- against the eval
+    chain and the torch oracle."""
+    import numpy as np
+
+    from gcc_amd.encoder import GraphEncoder
+    from oracle import encoder as E
+    from tests import test_eval_fused_emu as T
+
+    if case == "boundaries":
+        g = T.size_class_batch()
+    else:
+        rng = np.random.RandomState(7)
+        sizes = {"mixed": [int(x) for x in rng.randint(2, 65, 40)] + [0, 0, 200, 3, 64, 64, 1, 0, 70, 5] + [int(x) for x in rng.randint(2, 30, 30)],
+                 "tiny": [1] * 70 + [2] * 50 + [0] * 5 + [1, 2, 3] * 20 + [64, 1, 1, 63, 2],
+                 "dense4": [64, 64, 64, 64, 5]}[case]
+        g = T._batch(sizes, seed=5)
+        if case == "dense4":                                      # four complete graphs: more entries than a run's column ids hold
+            node_off, row_ptr, col = [0], [0], []
+            for n in sizes:
+                for i in range(n):
+                    col += [node_off[-1] + u for u in range(n) if u != i]
+                    row_ptr.append(len(col))
+                node_off.append(node_off[-1] + n)
+            g = T.CpuBatch(dict(node_off=torch.tensor(node_off), row_ptr=torch.tensor(row_ptr), col_idx=torch.tensor(col),
+                                pos_undirected=g.pos_undirected[: node_off[-1]]))
+        g.seed_local = torch.tensor([int(rng.randint(0, max(n, 1))) for n in sizes], dtype=torch.int32)
+    torch.manual_seed(11)
+    oracle = E.OracleGraphEncoder()
+    for mod in oracle.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.normal_(0, 0.3)
+            mod.running_var.uniform_(0.5, 2.0)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.2)
+    oracle.eval()
+    with torch.no_grad():
+        ref = oracle(*T._oracle_args(g), seed_local=g.seed_local.long())
+    model = GraphEncoder(positional_embedding_size=32, max_node_freq=16, max_edge_freq=16, max_degree=512,
+                         freq_embedding_size=16, degree_embedding_size=16, output_dim=64, node_hidden_dim=64,
+                         edge_hidden_dim=64, num_layers=5, num_step_set2set=6, num_layer_set2set=3, norm=True,
+                         gnn_model="gin", degree_input=True).cuda()
+    model.load_state_dict(oracle.state_dict())
+    model.eval()
+    g = _device_batch(g)
+    with torch.no_grad():
+        model.fused_eval = True
+        ff, pf = model(g, return_all_outputs=True)
+        ff, pf = ff.clone(), [x.clone() for x in pf]
+        model.fused_eval = False
+        fc, pc = model(g, return_all_outputs=True)
+    torch.testing.assert_close(ff, fc, rtol=1e-5, atol=5e-6)
+    for a, b in zip(pf, pc):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=max(1e-3, 2e-6 * float(b.abs().max())))
+    torch.testing.assert_close(ff.cpu(), ref, rtol=1e-3, atol=1e-4)

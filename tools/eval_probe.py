@@ -122,7 +122,8 @@ try:
     hc, hf = graphed(chain_cap), graphed(fused_cap)
 finally:
     st = st_keep
-ticks = torch.zeros(48, dtype=torch.int64, device=dev)
+ticks = torch.zeros(32, dtype=torch.int64, device=dev)
+ticks[8] = 2 ** 62          # (first start: a minimum)
 eng.lib.gcc_gin_eval_debug_ticks(ticks.data_ptr())
 fused_launch()
 torch.cuda.synchronize()
@@ -131,11 +132,14 @@ tk = ticks.cpu().tolist()
 names = ["features", "pooling", "weights", "own-rows", "gather", "linears", "mirror", "readout"]
 med_names = ["features", "pooling", "weights", "aggregation(wave 0)", "products(wave 0)", "write-back", "wait for the other waves", "readout"]
 phases = ""
-for k, kern in enumerate(["small (<= 64 nodes)", "medium (<= 320)", "general"]):  # (every 8th workgroup reports)
+for k, kern in enumerate(["LDS-resident kernel (subgraphs / runs of <= 320 nodes)", "general kernel"]):  # (every 4th group of four reports)
     wg = tk[16 * k + 15]
     if wg:
         phases += f"\n   {kern}: {wg} workgroups, us per workgroup: " + "  ".join(
-            f"{n} {tk[16 * k + i] / 100.0 / wg:.1f}" for i, n in enumerate(names if k != 1 else med_names) if tk[16 * k + i])
+            f"{n} {tk[16 * k + i] / 100.0 / wg:.1f}" for i, n in enumerate(med_names if k == 0 else names) if i < 8 and tk[16 * k + i])
+        if k == 0 and tk[10]:
+            phases += (f"\n      workgroups with work: last start {(tk[9] - tk[8]) / 100.0:.1f} us after the first, last end "
+                       f"{(tk[10] - tk[8]) / 100.0:.1f} us after the first start, longest stay {tk[11] / 100.0:.1f} us")
 print(f"graph {len(rp) - 1} nodes / {len(ci)} edges, batch {B} x 2 views, rw_hops {a.rw_hops}: subgraph sizes "
       f"median {int(sizes.median())} max {int(sizes.max())}; eval chain (2 x 15 launches + mean) {tc * 1e3:.1f} us per batch, "
       f"gcc_gin_eval_fused (1 launch) {tf * 1e3:.1f} us per batch = {tc / tf:.1f}x; max |difference| {err:.2e}; "
