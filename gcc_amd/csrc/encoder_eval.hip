@@ -399,7 +399,9 @@ __device__ __forceinline__ EvalRun eval_run_member(const EvalRun &run, int g)
 constexpr int kPlanThreads = 256;
 __global__ __launch_bounds__(kPlanThreads) void gin_eval_plan_kernel(EvalLaunch Ln)
 {
+    constexpr int kPlanKeys = 2048;
     __shared__ int hist[kMedCap + 1 + 63], start[kMedCap + 1 + 63];
+    __shared__ short key[kPlanKeys];
     const EvalArgs &a = Ln.p[blockIdx.x];
     const int tid = (int)threadIdx.x;
     if (blockIdx.x == 0 && a.mean_out)
@@ -414,7 +416,9 @@ __global__ __launch_bounds__(kPlanThreads) void gin_eval_plan_kernel(EvalLaunch 
     };
     for (int b = tid; b < a.B; b += kPlanThreads) {
         int rows;
-        if (item(b, rows)) atomicAdd(&hist[rows], 1);
+        const bool it = item(b, rows);
+        if (it) atomicAdd(&hist[rows], 1);
+        if (b < kPlanKeys) key[b] = it ? (short)rows : (short)-1;                // (the second pass reads these instead of the offsets again)
     }
     __syncthreads();
     if (tid < 64) {                                              // start[r] = number of items with more rows than r (6 bins per lane, descending)
@@ -433,7 +437,10 @@ __global__ __launch_bounds__(kPlanThreads) void gin_eval_plan_kernel(EvalLaunch 
     __syncthreads();
     for (int b = tid; b < a.B; b += kPlanThreads) {
         int rows;
-        if (item(b, rows)) a.plan[1 + start[rows] + atomicAdd(&hist[rows], 1)] = b;
+        bool it;
+        if (b < kPlanKeys) { rows = key[b]; it = rows >= 0; }
+        else it = item(b, rows);
+        if (it) a.plan[1 + start[rows] + atomicAdd(&hist[rows], 1)] = b;
     }
 }
 

@@ -28,7 +28,7 @@ if has modes; then
   (timeout 400 python bench.py --mode e2e --batch-size 32 --no-cpu-baseline 2>>$O/bench_e2e.err | tail -1) > $O/bench_e2e32.json; line $O/bench_e2e32.json
   (timeout 900 python bench.py --mode sample-ready --steps 192 --warmup 64 2>$O/bench_sr.err | tail -1) > $O/bench_sample_ready.json; line $O/bench_sample_ready.json
   (timeout 900 python bench.py --mode sampler --steps 96 --warmup 16 --cpu-seconds 10 2>$O/bench_g2.err | tail -1) > $O/bench_g2_sampler.json; line $O/bench_g2_sampler.json
-  (timeout 300 python bench.py --mode sampler --nodes 1000000 --edges 10000000 --steps 96 --warmup 16 --no-cpu-baseline 2>$O/bench_g1s.err | tail -1) > $O/bench_g1_sampler.json; line $O/bench_g1_sampler.json
+  (timeout 300 python bench.py --mode sampler --nodes 1000000 --edges 10000000 --steps 96 --warmup 16 --cpu-seconds 10 2>$O/bench_g1s.err | tail -1) > $O/bench_g1_sampler.json; line $O/bench_g1_sampler.json
   (timeout 900 python bench.py --hidden-size 256 --steps 20 --warmup 5 --no-cpu-baseline 2>$O/bench_hidden256.err | tail -1) > $O/bench_hidden256.json; line $O/bench_hidden256.json
   # soak of the multi-GPU launch path on one rank: 1024 steps with the RCCL hand-offs between the step's three graph segments
   (timeout 600 python bench.py --steps 1024 --warmup 64 --no-cpu-baseline --no-parity --collectives 2>$O/bench_coll_soak.err | tail -1) > $O/bench_1024_steps_collectives.json; line $O/bench_1024_steps_collectives.json

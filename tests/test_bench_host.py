@@ -64,7 +64,7 @@ def test_committed_pmc_file_matches_this_build():
     """profiles/pmc_sampler.json is keyed by the hash of the sampler sources: a commit that touches them without re-collecting
     the counters makes bench.py report ``traffic: null`` (by design) -- this test says so before the GPU box does."""
     rec = json.load(open(bench.PMC_FILE))
-    assert rec["source_sha256"] == bench.sampler_source_hash(), "re-collect profiles/pmc_sampler.json (scripts/gpu/r4_call27.sh)"
+    assert rec["source_sha256"] == bench.sampler_source_hash(), "re-collect profiles/pmc_sampler.json (scripts/gpu/r6_call.sh <tag> pmc)"
     assert any(k.endswith("/steps10") for k in rec["workloads"]) and any(k.endswith("/steps16") for k in rec["workloads"])
 
 
