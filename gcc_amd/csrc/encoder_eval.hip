@@ -827,7 +827,7 @@ int32_t gcc_gin_eval_fused(const gcc_gin_pass *passes, int32_t npass, float *mea
         const gcc_gin_pass &p = passes[i];
         const int L = p.w.num_gin_layers, kdim0 = p.w.pos_dim + p.w.deg_emb_dim + 1;
         if (p.training || L < 1 || L > GCC_GIN_MAX_LAYERS || kdim0 > H || p.batch_size != B || B < 1 || !p.z1[0] || !p.z2[0] || !p.x0 ||
-            !p.score || !p.feat || !p.node_off || !p.row_ptr || !p.col_idx || !p.pos) {
+            !p.score || !p.feat || !p.node_off || !p.row_ptr || !p.pos) {               // (col_idx may be NULL: a batch without edges has none to read)
             snprintf(g_err, kErrLen, "gcc_gin_eval_fused: an eval-mode pass with x0 / z1[0] / z2[0] scratch, score and feat is needed "
                                      "(training=%d layers=%d d_in=%d B=%d)", p.training, L, kdim0, p.batch_size);
             return -2;

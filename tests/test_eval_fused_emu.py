@@ -195,6 +195,19 @@ def test_multi_edges_beyond_the_small_kernels_edge_space():
     torch.testing.assert_close(f_fused, ref, rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("sizes", [[20], [0], [65], [64, 65], [0, 0, 0], [321], [5, 0, 0, 0, 7], [1, 1, 0, 1]])
+def test_tiny_batches(sizes):
+    """Batches smaller than a group of four, made of empty graphs only (no edges: col_idx is NULL), of isolated nodes, one
+    subgraph on either side of a size limit: the work list, the run finder's clamps at the batch's end."""
+    model, oracle = _models(3)
+    g = _batch(sizes, seed=1)
+    with torch.no_grad():
+        model.fused_eval = True
+        f = model(g).clone()
+        ref = oracle(*_oracle_args(g))
+    torch.testing.assert_close(f, ref, rtol=1e-4, atol=2e-5)
+
+
 def test_seed_position_and_view_mean():
     model, oracle = _models(4)
     q, k = _batch([40, 90, 17], seed=2), _batch([35, 61, 260], seed=3)
