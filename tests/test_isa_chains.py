@@ -64,3 +64,34 @@ def test_backward_tile_kernels_have_a_one_batch_fast_path():
     assert re.search(r"L2[0-9]WB", ch["gin_bwd_lin_kernelILb1E"]) and re.search(r"L2[0-9]WB", ch["gin_bwd_lin_kernelILb0E"])
     for k, v in ch.items():
         assert "LWLWLWLW" not in v, (k, v)
+
+
+def test_eval_kernels_keep_their_lds_pointers_and_their_weight_prefetch():
+    """Round 6, csrc/encoder_eval.hip -- three properties of the LDS-resident eval kernel that the source does not show and the
+    emulator cannot see:
+    * no flat_load / flat_store: a lambda whose closure stays in memory (select chains over captured values become an indexed
+      load from the closure object) turns every LDS pointer it captured into a generic one -- 180 flat instructions once;
+    * the next layer's weights come by global_load_dwordx4 (the 16-byte and the element-wise request forms behind ONE run-time
+      branch were merged into sixteen global_load_dword);
+    * inside the layer loop no wait for ALL outstanding loads sits between the weight requests and the barrier behind them (a
+      descriptor pointer indexed by a per-wave vector index came through global_load + s_waitcnt vmcnt(0): every layer waited
+      for its successor's weights)."""
+    text = isa_chains.isa_of(isa_chains.ROOT / "gcc_amd" / "csrc" / "encoder_eval.hip")
+    bodies = {name: body for name, body in isa_chains.kernels(text)}
+    lds = [b for n, b in bodies.items() if "gin_eval_lds_kernelILb1E" in n]
+    assert len(lds) == 1
+    body = lds[0]
+    ops = [s.split()[0] for s in body if s and not s.startswith((";", "."))]
+    assert not [o for o in ops if o.startswith(("flat_load", "flat_store"))]
+    assert sum(o == "global_load_dwordx4" for o in ops) >= 4                     # 2 matrices x 2 quads per thread, in the loop
+    # the layer loop: the stretch of the listing that holds the matrix instructions; find the weight requests inside it
+    first_mfma = next(i for i, s in enumerate(body) if s.startswith("v_mfma"))
+    x4 = [i for i, s in enumerate(body) if s.startswith("global_load_dwordx4")]
+    in_loop = [i for i in x4 if i < first_mfma][-4:]                             # the last requests ahead of the products: the loop's
+    assert len(in_loop) == 4 and in_loop[-1] - in_loop[0] < 40, (x4, first_mfma)
+    barrier = next(i for i in range(in_loop[-1], len(body)) if body[i].startswith("s_barrier"))
+    between = body[in_loop[-1]:barrier]
+    assert not [s for s in between if re.match(r"s_waitcnt\s+vmcnt\(0\)", s)], between
+    # and the spills stay out of the matrix-instruction stretch
+    last_mfma = max(i for i, s in enumerate(body) if s.startswith("v_mfma"))
+    assert not [s for s in body[first_mfma:last_mfma] if s.startswith("scratch_")]
