@@ -1902,6 +1902,58 @@ __global__ __launch_bounds__(kClsThreads) void posemb_classify_kernel(PosMulti m
     if (lane == 0) hd.list[(int64_t)cls * hd.T + atomicAdd(hd.count + cls, 1)] = item;
 }
 
+// ---- work lists, largest first.  The class kernels' workgroups pull items off their list with an atomic counter; the classify
+// kernel appends in arrival order.  An item of the block class runs 0.6 .. 2.5 ms, 194 of them per call of 16 views go to 64
+// workgroups: in arrival order the last long item starts when most workgroups have already run dry, and the kernels behind it in
+// the stream wait for it.  One workgroup per class sorts its list by node count, descending (counting sort, ties in any order --
+// the order of the items never mattered to their results): longest-processing-time-first over the same atomic counter.
+// Items a later kernel appends (the block class hands on what it cannot solve) stay behind the sorted ones.
+constexpr int kSortMax = 4096, kSortBins = 1024, kSortThreads = 256;
+__global__ __launch_bounds__(kSortThreads) void posemb_sort_kernel(PosMulti m, PosHead hd)
+{
+    __shared__ int items[kSortMax];
+    __shared__ short keys[kSortMax];
+    __shared__ int hist[kSortBins], start[kSortBins], wsum[kSortThreads / 64];
+    const int cls = (int)blockIdx.x, tid = (int)threadIdx.x, cnt = hd.count[cls];
+    if (cnt < 2 || cnt > kSortMax) return;                                   // (block-uniform)
+    int32_t *list = hd.list + (int64_t)cls * hd.T;
+    for (int i = tid; i < kSortBins; i += kSortThreads) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < cnt; i += kSortThreads) {
+        const int gb = list[i];
+        PosArgs a;
+        int b;
+        item_args(m, gb, a, b);
+        const int n = a.node_off[b + 1] - a.node_off[b];
+        const int key = n < kSortBins ? n : kSortBins - 1;
+        items[i] = gb;
+        keys[i] = (short)key;
+        atomicAdd(&hist[key], 1);
+    }
+    __syncthreads();
+    {                                                                        // start[key] = items with a larger key: 4 bins per thread, descending
+        int mine = 0;
+        for (int k = 0; k < 4; ++k) mine += hist[kSortBins - 1 - (4 * tid + k)];
+        const int incl = wave_scan_incl(mine);
+        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        __syncthreads();
+        int before = incl - mine;
+        for (int w = 0; w < (tid >> 6); ++w) before += wsum[w];
+        for (int k = 0; k < 4; ++k) {
+            const int key = kSortBins - 1 - (4 * tid + k);
+            start[key] = before;
+            before += hist[key];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < kSortBins; i += kSortThreads) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < cnt; i += kSortThreads) {
+        const int key = keys[i];
+        list[start[key] + atomicAdd(&hist[key], 1)] = items[i];
+    }
+}
+
 template <int kCls, int kNMin, int kNMax, int kT, bool kGlobalA, bool kPair = false>
 __global__ __launch_bounds__(kT, kPair ? (kT == 256 ? GCC_POSEMB_QUAD_OCC : 2) : 1) void posemb_direct_kernel(PosMulti m, PosHead hd)
 {
@@ -3748,6 +3800,8 @@ int32_t gcc_posemb_multi_gated(const gcc_posemb_view *views, int32_t num_views, 
     prof_mark(prof, 0, s);
     (void)hipMemsetAsync(workspace, 0, 64, s);       // class counts + work counters
     hipLaunchKernelGGL(posemb_classify_kernel, dim3((unsigned)((T + 3) / 4)), dim3(kClsThreads), 0, s, m, hd);
+    static const bool sort_lists = [] { const char *e = getenv("GCC_POSEMB_SORT"); return !e || atoi(e) != 0; }();
+    if (sort_lists) hipLaunchKernelGGL(posemb_sort_kernel, dim3(kNumCls), dim3(kSortThreads), 0, s, m, hd);
     KryArgs ka;
     ka.m = m;
     ka.hd = hd;
