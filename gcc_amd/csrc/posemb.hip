@@ -3616,7 +3616,7 @@ static PosGrids posemb_grids(int64_t T, bool gated = false)
     // workgroups do not fit beside it wait for the whole launch to drain (3-5 ms stalls in the kernel trace).
     static int caps[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (caps[0] == 0) {                              // tuning knob: GCC_POSEMB_GRID_CAPS="small,mid,slot,krylov,big,cheb,w48,w64,pair"
-        int c[9] = {256, 64, 128, 64, 64, 96, 128, 64, 128};     // round 6: the one-wave teams 512 / 128 -> 128 / 64 (their workgroups hold 74 / 111 KiB of LDS each: at two per CU
+        int c[9] = {256, 64, 128, 64, 64, 96, 128, 64, 192};     // (pair 128 -> 192 once the work lists were sorted, profiles/r6_bench_sorted_lists.txt: the driver's window 0.752 -> 0.740, sustained 0.735 -> 0.742) round 6: the one-wave teams 512 / 128 -> 128 / 64 (their workgroups hold 74 / 111 KiB of LDS each: at two per CU
                                                                  // no CU had room for a 49 KiB gin_in_kernel workgroup while they ran): sustained 0.776 -> 0.743 ms per step, the
                                                                  // driver's 20-step window unchanged (0.785 vs 0.788); smaller caps still (64 / 32, or cheb 64) win another 1-2 %
                                                                  // sustained and LOSE 5-10 % in the 20-step window (profiles/r6_bench_grid_caps.txt)    // the defaults: cheb 96, one-wave teams 512 / 128, pair 128 (scripts/gpu/r3_call4.sh: bench by caps; pair: r5_call10.sh 64: 0.837, 128: 0.836, 256: 0.856 ms per step; the cheb 64 / teams 256, 64 setting of r5_call12.sh measured 0.819 once and inside the spread afterwards: not adopted)
