@@ -166,7 +166,10 @@ __device__ __forceinline__ void eval_mlp_rows16(const F4 xb[4], const float *Wl0
 //     lane (j, q) sums the neighbours hb + j, hb + j + 16, ... (again four per round trip), the 16 partial sums of a quad are
 //     added over the DPP row (fixed tree) and handed to the owning lane.  A wave used to run as long as its longest row: 75
 //     rounds for a 300-neighbour hub while the other 15 rows had finished after 2.
-constexpr int kEvalHub = 32;
+#ifndef GCC_EVAL_HUB
+#define GCC_EVAL_HUB 32
+#endif
+constexpr int kEvalHub = GCC_EVAL_HUB;      // (GPU time per call at rw_hops 64 / 256 by this threshold: 20: 83.7 / 127.2 us, 32: 83.9 / 127.8, 48: 88.0 / 128.5, 64: 91.0 / 129.5)
 template <class ColT>
 __device__ __forceinline__ void eval_gather4(const float *A, const ColT *cols, int e, int stride, int end, int zrow, int q, F4 acc[4])
 {
